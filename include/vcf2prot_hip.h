@@ -1,0 +1,173 @@
+/*
+ * vcf2prot_hip.h -- C ABI of the MI355X (gfx950) backend engine for vcf2prot's
+ * step 6, the SIR executor.  This is what the reference's `-g gpu` plugin arm
+ * binds (Rust `extern "C"` block shown in INTEGRATION.md).
+ *
+ * Reference interfaces replaced (paths under /root/reference/src):
+ *   data_structures/InternalRep/gir.rs:236-239   Engine::GPU arm of GIR::execute
+ *       -> v2p_execute_gir(); argument shapes = the SoA marshaller the reference
+ *          already carries for its device engine (gir.rs:283-299) with
+ *          usize -> uint64_t and char -> uint32_t.
+ *   data_structures/InternalRep/gir.rs:203-229   DEBUG_CPU_EXEC validation
+ *   README.md:156-157 (DEBUG_GPU)                -> v2p_validate_gir()
+ *   data_structures/InternalRep/engines.rs:17-29 Engine::from_str -> v2p_engine_from_str()
+ *   data_structures/InternalRep/personalized_genome.rs:61-69 + parts/exec.rs:34-40
+ *       (two GIRs per sample, many samples in flight) -> the v2p_batch_* calls,
+ *       which execute many haplotypes per launch from one concatenated image.
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Every call returns an
+ * int status: 0 = V2P_OK, negative = error; the message (and, for task errors,
+ * the offending row) is retrievable with v2p_last_error()/v2p_last_error_index().
+ * The reference's convention for every one of these errors is panic!().
+ * The caller owns every host buffer for the duration of a call; the library
+ * copies what it needs and retains nothing.  Device memory belongs to the ctx.
+ * A ctx (and its batches) may be used from one thread at a time; create one ctx
+ * per worker thread (Rayon worker) -- contexts are independent and each owns a
+ * HIP stream.
+ */
+#ifndef VCF2PROT_HIP_H
+#define VCF2PROT_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V2P_OK                   0
+#define V2P_ERR_INVALID_ARG     -1
+#define V2P_ERR_HIP             -2   /* HIP runtime error, no device, out of memory        */
+#define V2P_ERR_BAD_CODE        -3   /* exe_code not in {0,1} (haplotype_instruction.rs:154) */
+#define V2P_ERR_RES_OOB         -4   /* start_pos_res+length beyond the result tape (task.rs:43,47) */
+#define V2P_ERR_SRC_OOB         -5   /* start_pos+length beyond the ref/alt tape (task.rs:43,47)    */
+#define V2P_ERR_NOT_CONTIGUOUS  -6   /* gir.rs:208-226 predicate failed                   */
+#define V2P_ERR_NOT_CANONICAL   -7   /* batch image needs ascending, non-overlapping result ranges */
+#define V2P_ERR_NON_BYTE_CHAR   -8   /* a char > 0xFF cannot enter the 1-byte-per-residue batch image */
+#define V2P_ERR_UNSUPPORTED     -9
+#define V2P_ERR_STATE          -10   /* call sequence error (e.g. execute before finalize) */
+
+/* engines.rs:15 */
+#define V2P_ENGINE_ST  0
+#define V2P_ENGINE_MT  1
+#define V2P_ENGINE_GPU 2
+
+/* v2p_init flags */
+#define V2P_FLAG_DEBUG_GPU   1u   /* validate every GIR on the device before executing it (DEBUG_GPU) */
+#define V2P_FLAG_TEMPORAL    2u   /* plain result stores instead of non-temporal ones                  */
+
+typedef struct v2p_ctx v2p_ctx;
+typedef struct v2p_batch v2p_batch;
+
+/* 16-byte work item of the device image (see vcf2prot_amd/csrc/sir_pack.hpp) */
+typedef struct { uint64_t task_begin; uint64_t dst_n; } v2p_chunk;
+
+/* ---- library / context ------------------------------------------------------- */
+const char* v2p_version(void);
+/* number of visible HIP devices, or a negative status */
+int v2p_device_count(void);
+/* engines.rs:17-29: "st"/"ST"/"mt"/"MT"/"gpu"/"GPU"; anything else -> V2P_ERR_INVALID_ARG */
+int v2p_engine_from_str(const char* name, int* engine);
+
+int  v2p_init(int device_ordinal, unsigned flags, v2p_ctx** out);
+void v2p_destroy(v2p_ctx* ctx);
+/* message of the last failing call on this ctx (ctx may be NULL: last failing v2p_init of this thread) */
+const char* v2p_last_error(const v2p_ctx* ctx);
+/* row (task index) the last task error refers to, -1 if none */
+int64_t v2p_last_error_index(const v2p_ctx* ctx);
+/* run the engine on a caller-provided hipStream_t instead of the ctx's own (NULL restores it) */
+int v2p_set_stream(v2p_ctx* ctx, void* hip_stream);
+
+/* ---- GIR-faithful mode: one haplotype per call ------------------------------- */
+/* Engine::GPU arm of GIR::execute (gir.rs:197-241).  Executes
+ *     res[start_pos_res[i] .. +length[i]] = (code[i]==0 ? ref : alt)[start_pos[i] .. +length[i]]
+ * for i = 0..n_tasks in order (later tasks win where ranges overlap) on the GPU.
+ * Tapes hold Rust chars (uint32_t); `res` comes in as the caller filled it
+ * (haplotype_instruction.rs:78 fills '.') and cells no task covers are left as they are. */
+int v2p_execute_gir(v2p_ctx* ctx,
+                    const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
+                    const uint64_t* start_pos_res, uint64_t n_tasks,
+                    const uint32_t* ref, uint64_t n_ref,
+                    const uint32_t* alt, uint64_t n_alt,
+                    uint32_t* res, uint64_t n_res);
+
+/* DEBUG_GPU: inspect the device input arrays for indexing errors.  *first_bad = first
+ * offending row or -1; *reason = V2P_ERR_BAD_CODE / _RES_OOB / _SRC_OOB / _NOT_CONTIGUOUS or 0.
+ * Returns V2P_OK when the inspection ran (whatever it found). */
+int v2p_validate_gir(v2p_ctx* ctx,
+                     const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
+                     const uint64_t* start_pos_res, uint64_t n_tasks,
+                     uint64_t n_ref, uint64_t n_alt, uint64_t n_res,
+                     int64_t* first_bad, int* reason);
+
+/* ---- resident reference ------------------------------------------------------ */
+/* Upload the reference proteome once (1 byte per residue, transcripts back to back).
+ * Batches built with v2p_batch_add_haplotype() read reference residues from it. */
+int v2p_upload_proteome(v2p_ctx* ctx, const uint8_t* aa, uint64_t n);
+
+/* ---- batched native mode: many haplotypes per launch -------------------------- */
+int  v2p_batch_create(v2p_ctx* ctx, v2p_batch** out);
+void v2p_batch_destroy(v2p_batch* b);
+
+/* Append one haplotype given exactly as a GIR (private ref tape travels with the batch). */
+int v2p_batch_add_gir(v2p_batch* b,
+                      const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
+                      const uint64_t* start_pos_res, uint64_t n_tasks,
+                      const uint32_t* ref, uint64_t n_ref,
+                      const uint32_t* alt, uint64_t n_alt,
+                      uint64_t n_res);
+
+/* Append one haplotype whose ref tape is the concatenation of n_seg proteome transcripts
+ * (haplotype_instruction.rs:118,130): segment s covers ref-tape offsets
+ * [seg_ref_begin[s], seg_ref_begin[s+1]) and starts at proteome offset seg_proteome_off[s].
+ * Code-0 tasks are rebased onto the resident proteome; no reference bytes travel. */
+int v2p_batch_add_haplotype(v2p_batch* b,
+                            const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
+                            const uint64_t* start_pos_res, uint64_t n_tasks,
+                            const uint64_t* seg_ref_begin, const uint64_t* seg_proteome_off, uint64_t n_seg,
+                            const uint8_t* alt, uint64_t n_alt,
+                            uint64_t n_res);
+
+/* Adopt an already packed image (descriptors, chunks, payload, haplotype result ranges),
+ * e.g. from the synthetic cohort generator (include/v2p_cohort.h). */
+int v2p_batch_set_packed(v2p_batch* b,
+                         const uint64_t* desc, uint64_t n_desc,
+                         const v2p_chunk* chunks, uint64_t n_chunks,
+                         const uint8_t* payload, uint64_t n_payload,
+                         const uint64_t* hap_out_begin, uint64_t n_haps);
+
+/* Cut the image into chunks (if built by add_*) and move it to the device. */
+int v2p_batch_finalize(v2p_batch* b);
+/* Enqueue one pass of the SIR executor over the whole batch on the ctx stream (asynchronous). */
+int v2p_batch_execute(v2p_batch* b);
+/* Wait for the stream and collect the device status word; task errors surface here. */
+int v2p_batch_sync(v2p_batch* b);
+
+int v2p_batch_counts(const v2p_batch* b, uint64_t* n_haps, uint64_t* n_desc, uint64_t* n_chunks,
+                     uint64_t* out_bytes, uint64_t* payload_bytes);
+/* result range of haplotype h inside the arena */
+int v2p_batch_hap_range(const v2p_batch* b, uint64_t h, uint64_t* begin, uint64_t* len);
+/* copy arena bytes [begin, begin+len) to the host (1 byte per residue) */
+int v2p_batch_download(v2p_batch* b, uint64_t begin, uint64_t len, uint8_t* out);
+/* per-haplotype digests computed on the device (sum (byte+1)*splitmix64(pos), pos relative to the haplotype) */
+int v2p_batch_digests(v2p_batch* b, uint64_t* digests, uint64_t n_haps);
+/* device pointer of the result arena (for callers that keep consuming on the GPU) */
+void* v2p_batch_device_out(v2p_batch* b);
+
+/* ---- raw launchers on caller-owned device memory (torch tensors, other runtimes) ----- */
+/* src0/src1 must have 16 readable bytes before and after; out must be 16-byte aligned;
+ * status is one device uint64 initialised to ~0. */
+int v2p_stitch_launch(void* hip_stream,
+                      const uint64_t* d_desc, const v2p_chunk* d_chunks, uint32_t n_chunks,
+                      const uint8_t* d_src0, uint64_t src0_len,
+                      const uint8_t* d_src1, uint64_t src1_len,
+                      uint8_t* d_out, uint64_t out_len,
+                      uint64_t* d_status, int nontemporal, uint32_t max_blocks);
+int v2p_digest_launch(void* hip_stream, const uint8_t* d_out, const uint64_t* d_hap_begin, uint64_t n_haps,
+                      uint64_t out_bytes, uint64_t* d_digests);
+int v2p_fill_launch(void* hip_stream, uint8_t* d_out, uint64_t bytes, uint32_t word, int nontemporal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VCF2PROT_HIP_H */

@@ -1,0 +1,39 @@
+"""Seeded random Task vectors in the reference's shape (test helper, numpy only)."""
+from __future__ import annotations
+
+import numpy as np
+
+AA = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+
+
+def random_tape(rng, n, dtype=np.uint32):
+    return AA[rng.integers(0, len(AA), size=n)].astype(dtype)
+
+
+def random_gir(rng, n_tasks, n_ref, n_alt, mean_len=40, p_zero=0.1, p_gap=0.0, max_len=None, p_alt=0.4):
+    """Canonical Task vector: ascending, non-overlapping result ranges; optional gaps.
+
+    Returns dict(code, start_pos, length, start_pos_res, n_res)."""
+    length = rng.geometric(1.0 / mean_len, size=n_tasks).astype(np.uint64)
+    if max_len:
+        length = np.minimum(length, max_len)
+    length[rng.random(n_tasks) < p_zero] = 0
+    code = (rng.random(n_tasks) < p_alt).astype(np.uint8)
+    n_src = np.where(code == 0, n_ref, n_alt).astype(np.uint64)
+    length = np.minimum(length, n_src)
+    start_pos = (rng.random(n_tasks) * (n_src - length + 1)).astype(np.uint64)
+    start_pos = np.minimum(start_pos, n_src - length)
+    gaps = np.where(rng.random(n_tasks) < p_gap, rng.integers(1, 20, size=n_tasks), 0).astype(np.uint64)
+    ends = np.cumsum(length + gaps)
+    start_pos_res = (ends - length).astype(np.uint64)
+    tail = int(rng.integers(0, 9)) if p_gap > 0 else 0
+    n_res = int(ends[-1]) + tail if n_tasks else tail
+    return dict(code=code, start_pos=start_pos, length=length, start_pos_res=start_pos_res, n_res=n_res)
+
+
+def oracle_run(coracle, g, ref, alt, fill=ord(".")):
+    t = coracle.pack_tasks(g["code"], g["start_pos"], g["length"], g["start_pos_res"])
+    res = np.full(g["n_res"], fill, dtype=ref.dtype)
+    if ref.dtype == np.uint32:
+        return coracle.gir_execute(t, ref, alt, res)
+    return coracle.gir_execute_u8(t, ref, alt, res)

@@ -1,0 +1,109 @@
+"""ctypes bindings of the C ABI (include/vcf2prot_hip.h, include/v2p_cohort.h).
+
+The HIP library is the product: if it is missing this module raises -- there is
+no Python or CPU fallback for the engine.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_size_t, c_uint8, c_uint32, c_uint64, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_PKG, "lib", "libvcf2prot_hip.so")
+COHORT_LIB_PATH = os.path.join(_PKG, "lib", "libv2p_cohort.so")
+
+V2P_OK = 0
+ERR_NAMES = {
+    0: "V2P_OK", -1: "V2P_ERR_INVALID_ARG", -2: "V2P_ERR_HIP", -3: "V2P_ERR_BAD_CODE", -4: "V2P_ERR_RES_OOB",
+    -5: "V2P_ERR_SRC_OOB", -6: "V2P_ERR_NOT_CONTIGUOUS", -7: "V2P_ERR_NOT_CANONICAL", -8: "V2P_ERR_NON_BYTE_CHAR",
+    -9: "V2P_ERR_UNSUPPORTED", -10: "V2P_ERR_STATE",
+}
+V2P_ERR_INVALID_ARG, V2P_ERR_HIP, V2P_ERR_BAD_CODE, V2P_ERR_RES_OOB, V2P_ERR_SRC_OOB = -1, -2, -3, -4, -5
+V2P_ERR_NOT_CONTIGUOUS, V2P_ERR_NOT_CANONICAL, V2P_ERR_NON_BYTE_CHAR, V2P_ERR_UNSUPPORTED, V2P_ERR_STATE = -6, -7, -8, -9, -10
+V2P_FLAG_DEBUG_GPU, V2P_FLAG_TEMPORAL = 1, 2
+
+
+class v2p_chunk(ctypes.Structure):
+    _fields_ = [("task_begin", c_uint64), ("dst_n", c_uint64)]
+
+
+# name -> (restype, argtypes); every symbol include/vcf2prot_hip.h declares
+HIP_API = {
+    "v2p_version": (c_char_p, []),
+    "v2p_device_count": (c_int, []),
+    "v2p_engine_from_str": (c_int, [c_char_p, POINTER(c_int)]),
+    "v2p_init": (c_int, [c_int, ctypes.c_uint, POINTER(c_void_p)]),
+    "v2p_destroy": (None, [c_void_p]),
+    "v2p_last_error": (c_char_p, [c_void_p]),
+    "v2p_last_error_index": (c_int64, [c_void_p]),
+    "v2p_set_stream": (c_int, [c_void_p, c_void_p]),
+    "v2p_execute_gir": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
+                                c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_uint64]),
+    "v2p_validate_gir": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
+                                 c_uint64, c_uint64, c_uint64, POINTER(c_int64), POINTER(c_int)]),
+    "v2p_upload_proteome": (c_int, [c_void_p, c_void_p, c_uint64]),
+    "v2p_batch_create": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "v2p_batch_destroy": (None, [c_void_p]),
+    "v2p_batch_add_gir": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
+                                  c_void_p, c_uint64, c_void_p, c_uint64, c_uint64]),
+    "v2p_batch_add_haplotype": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
+                                        c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_uint64]),
+    "v2p_batch_set_packed": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_uint64,
+                                     c_void_p, c_uint64]),
+    "v2p_batch_finalize": (c_int, [c_void_p]),
+    "v2p_batch_execute": (c_int, [c_void_p]),
+    "v2p_batch_sync": (c_int, [c_void_p]),
+    "v2p_batch_counts": (c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64),
+                                 POINTER(c_uint64), POINTER(c_uint64)]),
+    "v2p_batch_hap_range": (c_int, [c_void_p, c_uint64, POINTER(c_uint64), POINTER(c_uint64)]),
+    "v2p_batch_download": (c_int, [c_void_p, c_uint64, c_uint64, c_void_p]),
+    "v2p_batch_digests": (c_int, [c_void_p, c_void_p, c_uint64]),
+    "v2p_batch_device_out": (c_void_p, [c_void_p]),
+    "v2p_stitch_launch": (c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, c_uint64,
+                                  c_void_p, c_uint64, c_void_p, c_int, c_uint32]),
+    "v2p_digest_launch": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
+    "v2p_fill_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_int]),
+}
+
+_hip = None
+_cohort = None
+
+
+def _bind(lib, api):
+    for name, (res, args) in api.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def hip_lib():
+    """The HIP engine library.  Raises if it has not been built (no fallback)."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise RuntimeError(
+                f"{HIP_LIB_PATH} is missing: build it with `python -m vcf2prot_amd.build` "
+                "(the gpu engine has no CPU fallback)")
+        _hip = _bind(ctypes.CDLL(HIP_LIB_PATH), HIP_API)
+    return _hip
+
+
+def cohort_lib():
+    global _cohort
+    if _cohort is None:
+        if not os.path.exists(COHORT_LIB_PATH):
+            raise RuntimeError(f"{COHORT_LIB_PATH} is missing: build it with `python -m vcf2prot_amd.build`")
+        from ._cohort_api import COHORT_API  # noqa: WPS433
+        _cohort = _bind(ctypes.CDLL(COHORT_LIB_PATH), COHORT_API)
+    return _cohort
+
+
+class V2PError(RuntimeError):
+    """A non-zero status from the C ABI; stands for the reference's panic!()."""
+
+    def __init__(self, code: int, message: str, index: int = -1):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {message}")
+        self.code = code
+        self.index = index

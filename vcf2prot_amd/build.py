@@ -1,0 +1,79 @@
+"""Build recipe for the native parts (hipcc cross-compiles gfx950 without a GPU).
+
+    python -m vcf2prot_amd.build          # build everything that is out of date
+    python -m vcf2prot_amd.build --force
+
+Outputs (git-ignored, shipped to the GPU box by gpurun):
+    vcf2prot_amd/lib/libvcf2prot_hip.so   HIP kernels + C ABI (include/vcf2prot_hip.h)
+    vcf2prot_amd/lib/libv2p_cohort.so     synthetic cohort generator (include/v2p_cohort.h), plain C++
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+ARCH = "gfx950"
+
+HIP_LIB = os.path.join(LIBDIR, "libvcf2prot_hip.so")
+COHORT_LIB = os.path.join(LIBDIR, "libv2p_cohort.so")
+
+HIP_SOURCES = ["stitch_kernels.hip", "v2p_api.hip"]
+HIP_DEPS = HIP_SOURCES + ["stitch_kernels.h", "sir_pack.hpp", os.path.join(ROOT, "include", "vcf2prot_hip.h")]
+COHORT_SOURCES = ["cohort_gen.cpp"]
+COHORT_DEPS = COHORT_SOURCES + ["sir_pack.hpp", os.path.join(ROOT, "include", "v2p_cohort.h")]
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    for d in deps:
+        p = d if os.path.isabs(d) else os.path.join(CSRC, d)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def _hipcc() -> str:
+    for c in ("/opt/rocm/bin/hipcc", "hipcc"):
+        if os.path.isabs(c) and os.path.exists(c):
+            return c
+    return "hipcc"
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    if force or _stale(HIP_LIB, HIP_DEPS):
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-Wall", "-Wno-unused-result",
+               *[os.path.join(CSRC, s) for s in HIP_SOURCES], "-o", HIP_LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HIP_LIB
+
+
+def build_cohort(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    if not all(os.path.exists(os.path.join(CSRC, s)) for s in COHORT_SOURCES):
+        return ""
+    if force or _stale(COHORT_LIB, COHORT_DEPS):
+        cmd = ["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall",
+               *[os.path.join(CSRC, s) for s in COHORT_SOURCES], "-o", COHORT_LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return COHORT_LIB
+
+
+def build_all(force: bool = False, verbose: bool = False):
+    return build_hip(force, verbose), build_cohort(force, verbose)
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,170 @@
+// sir_pack.hpp -- device image of a batch of haplotype Task vectors (host side).
+//
+// The reference hands the executor, per haplotype, a Vec<Task> plus three char
+// tapes (GIR, gir.rs:15-23; SoA form gir.rs:283-299).  The MI355X engine
+// executes many haplotypes per launch from ONE concatenated image:
+//
+//   desc[N]      8-byte packed task descriptors, in result order
+//                  bits  0..39  source offset (bytes) inside its source space
+//                  bits 40..61  length (bytes), < 4 Mi  (longer tasks are split)
+//                  bits 62..63  source space: 0 = resident proteome (ref tape),
+//                               1 = batch payload arena (alt bytes, private ref tapes),
+//                               2 = fill with '.' (cells no task covers keep the
+//                                   '.' of haplotype_instruction.rs:78)
+//   chunks[C]    work items of <= 256 consecutive descriptors and <= 64 KiB of
+//                result: {first descriptor, result offset, descriptor count}.
+//                Inside a chunk result offsets are the exclusive prefix sum of the
+//                lengths (computed on the device by a wave64 scan), so the 8-byte
+//                start_pos_res of every Task never crosses PCIe or HBM.
+//   payload[]    alt tapes (1 byte per residue) of all haplotypes, back to back
+//   hap_out_begin[H+1]  result range of each haplotype inside the arena
+//
+// A Task vector is *canonical* when its result ranges are ascending and
+// non-overlapping; gaps are legal (transcript_instructions.rs 'P' instruction
+// leaves the last cell '.', golden case test_correct_translation_20) and become
+// fill descriptors.  Overlapping or descending vectors keep the reference's
+// "later task wins" semantics only on the ordered path (v2p_execute_gir).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include <string>
+
+namespace v2p {
+
+constexpr unsigned SPACE_PROTEOME = 0;
+constexpr unsigned SPACE_PAYLOAD  = 1;
+constexpr unsigned SPACE_FILL     = 2;
+
+constexpr uint64_t SRC_MASK   = (1ull << 40) - 1;
+constexpr uint32_t LEN_BITS   = 22;
+constexpr uint32_t LEN_MASK   = (1u << LEN_BITS) - 1;
+constexpr uint32_t CHUNK_TASKS = 256;          // descriptors per work item (one per lane of a 256-thread workgroup)
+constexpr uint32_t CHUNK_BYTES = 64u * 1024u;  // result bytes per work item
+constexpr uint64_t DST_MASK   = (1ull << 48) - 1;
+constexpr uint32_t PAD_BYTES  = 16;            // readable slack each side of a source arena (16-byte gathers)
+
+struct Chunk {
+    uint64_t task_begin;   // index of the first descriptor
+    uint64_t dst_n;        // result offset (48 bits) | descriptor count (16 bits)
+};
+static_assert(sizeof(Chunk) == 16, "Chunk is 16 bytes");
+
+inline uint64_t pack_desc(uint64_t src, uint32_t len, unsigned space) {
+    return (src & SRC_MASK) | (uint64_t(len & LEN_MASK) << 40) | (uint64_t(space & 3u) << 62);
+}
+inline uint64_t desc_src(uint64_t d)   { return d & SRC_MASK; }
+inline uint32_t desc_len(uint64_t d)   { return uint32_t(d >> 40) & LEN_MASK; }
+inline unsigned desc_space(uint64_t d) { return unsigned(d >> 62); }
+
+enum PackStatus : int {
+    PACK_OK = 0,
+    PACK_BAD_CODE = 1,        // exe_code not in {0,1}: haplotype_instruction.rs:154 panics
+    PACK_RES_OOB = 2,         // start_pos_res + length > result length: task.rs:43/47 panics
+    PACK_SRC_OOB = 3,         // start_pos + length > tape length: task.rs:43/47 panics
+    PACK_NOT_CANONICAL = 4,   // result ranges overlap or go backwards (ordered path required)
+    PACK_TOO_LARGE = 5        // offset does not fit the descriptor
+};
+
+// Appends haplotypes to the concatenated image and cuts it into chunks.
+class ImageBuilder {
+public:
+    std::vector<uint64_t> desc;
+    std::vector<Chunk>    chunks;
+    std::vector<uint8_t>  payload;
+    std::vector<uint64_t> hap_out_begin{0};
+    uint64_t n_copy_bytes = 0;     // A: residues written by copy tasks (Sum task.length)
+    uint64_t n_ref_tasks = 0;      // N: Task descriptors consumed, zero-length ones included
+    uint32_t chunk_tasks = CHUNK_TASKS;
+    uint32_t chunk_bytes = CHUNK_BYTES;
+
+    uint64_t out_size() const { return hap_out_begin.back(); }
+    uint64_t n_haplotypes() const { return hap_out_begin.size() - 1; }
+
+    // Reserve `n` payload bytes for the haplotype being added; returns their arena offset.
+    uint64_t payload_alloc(uint64_t n) { uint64_t o = payload.size(); payload.resize(o + n); return o; }
+
+    // One task of the current haplotype, already translated to a source space/offset.
+    // `dst` is relative to the haplotype's result tape; tasks must arrive in canonical order.
+    int add_task(unsigned space, uint64_t src, uint64_t len, uint64_t dst, uint64_t n_res) {
+        if (dst < cursor_) return PACK_NOT_CANONICAL;
+        if (dst + len > n_res || dst + len < dst) return PACK_RES_OOB;
+        if (dst > cursor_) emit(SPACE_FILL, 0, dst - cursor_);
+        if (src + len > SRC_MASK) return PACK_TOO_LARGE;
+        ++n_ref_tasks;
+        n_copy_bytes += len;
+        emit(space, src, len);
+        cursor_ = dst + len;
+        return PACK_OK;
+    }
+    void end_haplotype(uint64_t n_res) {
+        if (cursor_ < n_res) emit(SPACE_FILL, 0, n_res - cursor_);
+        hap_out_begin.push_back(hap_out_begin.back() + n_res);
+        cursor_ = 0;
+    }
+    // Close the open chunk; call once after the last haplotype.
+    void finish() { close_chunk(); }
+
+    // Raw append used by generators that already produce canonical descriptors.
+    void emit(unsigned space, uint64_t src, uint64_t len) {
+        if (len == 0) { push(space, src, 0); return; }
+        while (len) {
+            uint32_t piece = uint32_t(len < chunk_bytes ? len : chunk_bytes);
+            push(space, src, piece);
+            if (space != SPACE_FILL) src += piece;
+            len -= piece;
+        }
+    }
+
+private:
+    uint64_t cursor_ = 0;            // next uncovered cell of the current haplotype
+    uint64_t arena_cursor_ = 0;      // result offset of the next descriptor
+    uint64_t open_begin_ = 0, open_dst_ = 0;
+    uint32_t open_n_ = 0, open_bytes_ = 0;
+
+    void close_chunk() {
+        if (open_n_ == 0) return;
+        chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_n_) << 48)});
+        open_n_ = 0; open_bytes_ = 0;
+    }
+    void push(unsigned space, uint64_t src, uint32_t len) {
+        if (open_n_ == chunk_tasks || (open_n_ && open_bytes_ + len > chunk_bytes)) close_chunk();
+        if (open_n_ == 0) { open_begin_ = desc.size(); open_dst_ = arena_cursor_; }
+        desc.push_back(pack_desc(src, len, space));
+        ++open_n_; open_bytes_ += len; arena_cursor_ += len;
+    }
+};
+
+// Maps an offset inside a haplotype's private ref_stream (the concatenation of its
+// mutated transcripts' references, haplotype_instruction.rs:118,130) to the resident
+// proteome.  seg_ref_begin is ascending with seg_ref_begin[0] == 0.
+struct RefSegments {
+    const uint64_t* seg_ref_begin;   // [n_seg + 1], last = ref_stream length
+    const uint64_t* seg_proteome_off;// [n_seg]
+    uint64_t n_seg;
+    mutable uint64_t hint = 0;
+    // returns false when [pos, pos+len) is not inside one segment
+    bool map(uint64_t pos, uint64_t len, uint64_t* out) const {
+        if (n_seg == 0) return false;
+        uint64_t s = hint < n_seg ? hint : 0;
+        if (!(seg_ref_begin[s] <= pos && pos < seg_ref_begin[s + 1])) {
+            // tasks walk the tape forward, so try the next segment before searching
+            if (s + 1 < n_seg && seg_ref_begin[s + 1] <= pos && pos < seg_ref_begin[s + 2]) ++s;
+            else {
+                uint64_t lo = 0, hi = n_seg;          // last segment with begin <= pos
+                while (hi - lo > 1) { uint64_t mid = (lo + hi) / 2; if (seg_ref_begin[mid] <= pos) lo = mid; else hi = mid; }
+                s = lo;
+            }
+        }
+        // zero-length tasks may sit exactly on a segment end
+        if (pos + len > seg_ref_begin[s + 1] || pos < seg_ref_begin[s]) {
+            if (len == 0 && pos == seg_ref_begin[n_seg]) { *out = seg_proteome_off[n_seg - 1] + (pos - seg_ref_begin[n_seg - 1]); return true; }
+            return false;
+        }
+        hint = s;
+        *out = seg_proteome_off[s] + (pos - seg_ref_begin[s]);
+        return true;
+    }
+};
+
+}  // namespace v2p

@@ -1,0 +1,66 @@
+// stitch_kernels.h -- argument blocks and host launchers of the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sir_pack.hpp"
+
+namespace v2p {
+
+// device status word: min over offending rows of (row << 8 | reason); ~0ull = clean
+enum : uint32_t {
+    STATUS_BAD_CODE = 1,        // exe_code not in {0,1}
+    STATUS_RES_OOB = 2,         // result range outside the result tape / arena
+    STATUS_SRC_OOB = 3,         // source range outside its tape
+    STATUS_NOT_CONTIGUOUS = 4   // gir.rs:208-226 predicate
+};
+constexpr unsigned long long STATUS_CLEAN = ~0ull;
+
+struct StitchArgs {
+    const uint64_t* desc;      // packed descriptors (sir_pack.hpp)
+    const Chunk*    chunks;
+    uint32_t        n_chunks;
+    const uint8_t*  src0;      // space 0: resident proteome / the GIR's ref tape; 16 readable bytes either side
+    uint64_t        src0_len;
+    const uint8_t*  src1;      // space 1: payload arena / the GIR's alt tape;    16 readable bytes either side
+    uint64_t        src1_len;
+    uint8_t*        out;       // result arena, 16-byte aligned
+    uint64_t        out_len;
+    unsigned long long* status;
+};
+
+struct OrderedArgs {
+    const uint8_t*  code;
+    const uint64_t* start_pos;
+    const uint64_t* length;
+    const uint64_t* start_pos_res;
+    uint64_t        n_tasks;
+    const uint8_t*  ref;
+    const uint8_t*  alt;
+    uint8_t*        res;
+    uint64_t        esize;     // bytes per tape element
+};
+
+struct ValidateArgs {
+    const uint8_t*  code;
+    const uint64_t* start_pos;
+    const uint64_t* length;
+    const uint64_t* start_pos_res;
+    uint64_t        n_tasks;
+    uint64_t        n_ref, n_alt, n_res;
+    unsigned long long* status;
+};
+
+struct DigestArgs {
+    const uint8_t*  out;
+    const uint64_t* hap_begin;   // [n_haps + 1]
+    uint64_t        n_haps;
+    uint64_t*       digest;      // [n_haps], zeroed by the caller
+};
+
+hipError_t launch_stitch(const StitchArgs& a, hipStream_t stream, int nontemporal, uint32_t max_blocks);
+hipError_t launch_ordered(const OrderedArgs& a, hipStream_t stream);
+hipError_t launch_validate(const ValidateArgs& a, hipStream_t stream);
+hipError_t launch_digest(const DigestArgs& a, uint64_t out_bytes, hipStream_t stream);
+hipError_t launch_fill(uint8_t* out, uint64_t bytes, uint32_t word, int nontemporal, hipStream_t stream);
+
+}  // namespace v2p

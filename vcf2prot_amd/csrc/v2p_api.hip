@@ -1,0 +1,622 @@
+// v2p_api.hip -- the C ABI of include/vcf2prot_hip.h on top of the gfx950 kernels.
+// Host side of the engine: packs reference-shaped Task vectors (gir.rs:283-299) into
+// the device image (sir_pack.hpp), owns device memory, launches, maps device status
+// words back to the reference's panic conditions.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/vcf2prot_hip.h"
+#include "sir_pack.hpp"
+#include "stitch_kernels.h"
+
+using namespace v2p;
+
+namespace {
+
+thread_local std::string g_init_error;
+
+struct DevBuf {
+    uint8_t* base = nullptr;
+    size_t cap = 0;
+    // n usable bytes at ptr(), with PAD_BYTES readable before and after
+    hipError_t ensure(size_t n) {
+        const size_t need = n + 2 * PAD_BYTES;
+        if (need <= cap) return hipSuccess;
+        if (base) { (void)hipFree(base); base = nullptr; cap = 0; }
+        size_t want = need + need / 4;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), want);
+        if (e != hipSuccess) { want = need; e = hipMalloc(reinterpret_cast<void**>(&base), want); }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    uint8_t* ptr() const { return base ? base + PAD_BYTES : nullptr; }
+    void release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; }
+};
+
+struct PinnedBuf {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), n + n / 4 + 64, hipHostMallocDefault);
+        if (e == hipSuccess) cap = n + n / 4 + 64;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+int reason_to_err(uint32_t reason)
+{
+    switch (reason) {
+        case STATUS_BAD_CODE: return V2P_ERR_BAD_CODE;
+        case STATUS_RES_OOB: return V2P_ERR_RES_OOB;
+        case STATUS_SRC_OOB: return V2P_ERR_SRC_OOB;
+        case STATUS_NOT_CONTIGUOUS: return V2P_ERR_NOT_CONTIGUOUS;
+        default: return V2P_ERR_INVALID_ARG;
+    }
+}
+
+int pack_to_err(int ps)
+{
+    switch (ps) {
+        case PACK_OK: return V2P_OK;
+        case PACK_BAD_CODE: return V2P_ERR_BAD_CODE;
+        case PACK_RES_OOB: return V2P_ERR_RES_OOB;
+        case PACK_SRC_OOB: return V2P_ERR_SRC_OOB;
+        case PACK_NOT_CANONICAL: return V2P_ERR_NOT_CANONICAL;
+        default: return V2P_ERR_UNSUPPORTED;
+    }
+}
+
+const char* err_name(int e)
+{
+    switch (e) {
+        case V2P_ERR_BAD_CODE: return "unsupported stream code (exe_code not in {0,1})";
+        case V2P_ERR_RES_OOB: return "task writes beyond the result tape";
+        case V2P_ERR_SRC_OOB: return "task reads beyond its source tape";
+        case V2P_ERR_NOT_CONTIGUOUS: return "start_pos_res does not equal the previous start_pos_res + length";
+        case V2P_ERR_NOT_CANONICAL: return "result ranges overlap or are not ascending";
+        case V2P_ERR_NON_BYTE_CHAR: return "char above 0xFF cannot enter the 1-byte image";
+        default: return "error";
+    }
+}
+
+}  // namespace
+
+struct v2p_ctx {
+    int device = 0;
+    unsigned flags = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    mutable std::mutex mu;
+    std::string err;
+    int64_t err_index = -1;
+    DevBuf proteome; uint64_t proteome_len = 0;
+    // GIR-mode scratch (grow-only)
+    DevBuf d_ref, d_alt, d_res, d_desc, d_chunks, d_soa, d_status;
+    PinnedBuf h_stage;
+
+    int fail(int code, const std::string& msg, int64_t index = -1) { err = msg; err_index = index; return code; }
+    int hip_fail(hipError_t e, const char* what) {
+        return fail(V2P_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    }
+};
+
+struct v2p_batch {
+    v2p_ctx* ctx = nullptr;
+    ImageBuilder img;
+    bool finalized = false;
+    bool uses_proteome = false;
+    DevBuf d_desc, d_chunks, d_payload, d_out, d_hap, d_digest, d_status;
+    uint64_t n_desc = 0, n_chunks = 0, n_payload = 0, out_bytes = 0, n_haps = 0;
+};
+
+#define HIP_TRY(ctx, expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return (ctx)->hip_fail(e__, what); } while (0)
+
+extern "C" {
+
+const char* v2p_version(void) { return "vcf2prot-hip 0.1.0 (gfx950)"; }
+
+int v2p_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return V2P_ERR_HIP;
+    return n;
+}
+
+int v2p_engine_from_str(const char* name, int* engine)
+{
+    if (!name || !engine) return V2P_ERR_INVALID_ARG;
+    if (!strcmp(name, "st") || !strcmp(name, "ST")) { *engine = V2P_ENGINE_ST; return V2P_OK; }
+    if (!strcmp(name, "mt") || !strcmp(name, "MT")) { *engine = V2P_ENGINE_MT; return V2P_OK; }
+    if (!strcmp(name, "gpu") || !strcmp(name, "GPU")) { *engine = V2P_ENGINE_GPU; return V2P_OK; }
+    g_init_error = std::string(name) + " is not a supported engine";   // engines.rs:27
+    return V2P_ERR_INVALID_ARG;
+}
+
+int v2p_init(int device_ordinal, unsigned flags, v2p_ctx** out)
+{
+    if (!out) return V2P_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_init_error = "no HIP device available: the gpu engine needs an MI355X (there is no CPU fallback)";
+        return V2P_ERR_HIP;
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) { g_init_error = "device ordinal out of range"; return V2P_ERR_INVALID_ARG; }
+    e = hipSetDevice(device_ordinal);
+    if (e != hipSuccess) { g_init_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return V2P_ERR_HIP; }
+    v2p_ctx* c = new (std::nothrow) v2p_ctx();
+    if (!c) return V2P_ERR_HIP;
+    c->device = device_ordinal;
+    c->flags = flags;
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_init_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return V2P_ERR_HIP; }
+    c->stream = c->own_stream;
+    *out = c;
+    return V2P_OK;
+}
+
+void v2p_destroy(v2p_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->proteome.release(); c->d_ref.release(); c->d_alt.release(); c->d_res.release();
+    c->d_desc.release(); c->d_chunks.release(); c->d_soa.release(); c->d_status.release();
+    c->h_stage.release();
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* v2p_last_error(const v2p_ctx* c) { return c ? c->err.c_str() : g_init_error.c_str(); }
+int64_t v2p_last_error_index(const v2p_ctx* c) { return c ? c->err_index : -1; }
+
+int v2p_set_stream(v2p_ctx* c, void* hip_stream)
+{
+    if (!c) return V2P_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return V2P_OK;
+}
+
+int v2p_upload_proteome(v2p_ctx* c, const uint8_t* aa, uint64_t n)
+{
+    if (!c || (!aa && n)) return V2P_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    HIP_TRY(c, c->proteome.ensure(n), "hipMalloc(proteome)");
+    HIP_TRY(c, hipMemsetAsync(c->proteome.base, 0, c->proteome.cap, c->stream), "hipMemset(proteome)");
+    if (n) HIP_TRY(c, hipMemcpyAsync(c->proteome.ptr(), aa, n, hipMemcpyHostToDevice, c->stream), "H2D(proteome)");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
+    c->proteome_len = n;
+    return V2P_OK;
+}
+
+// reads the device status word after a sync; returns V2P_OK or the mapped task error
+static int collect_status(v2p_ctx* c, DevBuf& d_status)
+{
+    unsigned long long st = STATUS_CLEAN;
+    HIP_TRY(c, hipMemcpyAsync(&st, d_status.ptr(), sizeof(st), hipMemcpyDeviceToHost, c->stream), "D2H(status)");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    if (st == STATUS_CLEAN) return V2P_OK;
+    const int code = reason_to_err(uint32_t(st & 0xFFu));
+    return c->fail(code, std::string("device: ") + err_name(code) + " at descriptor " + std::to_string(st >> 8), int64_t(st >> 8));
+}
+
+static int init_status(v2p_ctx* c, DevBuf& d_status)
+{
+    HIP_TRY(c, d_status.ensure(sizeof(unsigned long long)), "hipMalloc(status)");
+    HIP_TRY(c, hipMemsetAsync(d_status.ptr(), 0xFF, sizeof(unsigned long long), c->stream), "hipMemset(status)");
+    return V2P_OK;
+}
+
+int v2p_validate_gir(v2p_ctx* c,
+                     const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
+                     const uint64_t* start_pos_res, uint64_t n_tasks,
+                     uint64_t n_ref, uint64_t n_alt, uint64_t n_res,
+                     int64_t* first_bad, int* reason)
+{
+    if (!c || !first_bad || !reason || (n_tasks && (!code || !start_pos || !length || !start_pos_res))) return V2P_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    *first_bad = -1; *reason = 0;
+    if (n_tasks == 0) return V2P_OK;
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    const size_t n8 = size_t(n_tasks) * 8, ncode = (size_t(n_tasks) + 7) & ~size_t(7);
+    HIP_TRY(c, c->d_soa.ensure(3 * n8 + ncode), "hipMalloc(soa)");
+    uint8_t* d = c->d_soa.ptr();
+    uint64_t* d_sp = reinterpret_cast<uint64_t*>(d);
+    uint64_t* d_ln = reinterpret_cast<uint64_t*>(d + n8);
+    uint64_t* d_sr = reinterpret_cast<uint64_t*>(d + 2 * n8);
+    uint8_t* d_code = d + 3 * n8;
+    HIP_TRY(c, hipMemcpyAsync(d_sp, start_pos, n8, hipMemcpyHostToDevice, c->stream), "H2D(start_pos)");
+    HIP_TRY(c, hipMemcpyAsync(d_ln, length, n8, hipMemcpyHostToDevice, c->stream), "H2D(length)");
+    HIP_TRY(c, hipMemcpyAsync(d_sr, start_pos_res, n8, hipMemcpyHostToDevice, c->stream), "H2D(start_pos_res)");
+    HIP_TRY(c, hipMemcpyAsync(d_code, code, n_tasks, hipMemcpyHostToDevice, c->stream), "H2D(code)");
+    int rc = init_status(c, c->d_status);
+    if (rc) return rc;
+    ValidateArgs a{d_code, d_sp, d_ln, d_sr, n_tasks, n_ref, n_alt, n_res,
+                   reinterpret_cast<unsigned long long*>(c->d_status.ptr())};
+    HIP_TRY(c, launch_validate(a, c->stream), "launch(validate)");
+    unsigned long long st = STATUS_CLEAN;
+    HIP_TRY(c, hipMemcpyAsync(&st, c->d_status.ptr(), sizeof(st), hipMemcpyDeviceToHost, c->stream), "D2H(status)");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    if (st != STATUS_CLEAN) { *first_bad = int64_t(st >> 8); *reason = reason_to_err(uint32_t(st & 0xFFu)); }
+    return V2P_OK;
+}
+
+int v2p_execute_gir(v2p_ctx* c,
+                    const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
+                    const uint64_t* start_pos_res, uint64_t n_tasks,
+                    const uint32_t* ref, uint64_t n_ref,
+                    const uint32_t* alt, uint64_t n_alt,
+                    uint32_t* res, uint64_t n_res)
+{
+    if (!c) return V2P_ERR_INVALID_ARG;
+    if ((n_tasks && (!code || !start_pos || !length || !start_pos_res)) || (n_ref && !ref) || (n_alt && !alt) || (n_res && !res))
+        return c->fail(V2P_ERR_INVALID_ARG, "null argument");
+    if (c->flags & V2P_FLAG_DEBUG_GPU) {          // gir.rs:203-229 / README.md:156-157
+        int64_t bad = -1; int reason = 0;
+        int rc = v2p_validate_gir(c, code, start_pos, length, start_pos_res, n_tasks, n_ref, n_alt, n_res, &bad, &reason);
+        if (rc) return rc;
+        if (bad >= 0) {
+            std::lock_guard<std::mutex> lk(c->mu);
+            return c->fail(reason, std::string("DEBUG_GPU: ") + err_name(reason) + " at row " + std::to_string(bad), bad);
+        }
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (n_tasks == 0) return V2P_OK;
+    constexpr uint64_t E = sizeof(uint32_t);
+    // bounds of every task first: the reference would panic, nothing may be written out of range
+    bool canonical = true;
+    uint64_t cursor = 0;
+    for (uint64_t i = 0; i < n_tasks; ++i) {
+        const uint64_t n_src = code[i] == 0 ? n_ref : n_alt;      // task.rs:42-49
+        if (start_pos_res[i] + length[i] > n_res || start_pos_res[i] + length[i] < length[i])
+            return c->fail(V2P_ERR_RES_OOB, std::string(err_name(V2P_ERR_RES_OOB)) + " at row " + std::to_string(i), int64_t(i));
+        if (start_pos[i] + length[i] > n_src || start_pos[i] + length[i] < length[i])
+            return c->fail(V2P_ERR_SRC_OOB, std::string(err_name(V2P_ERR_SRC_OOB)) + " at row " + std::to_string(i), int64_t(i));
+        if (start_pos_res[i] < cursor) canonical = false;
+        cursor = start_pos_res[i] + length[i];
+    }
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    HIP_TRY(c, c->d_ref.ensure(n_ref * E), "hipMalloc(ref)");
+    HIP_TRY(c, c->d_alt.ensure(n_alt * E), "hipMalloc(alt)");
+    HIP_TRY(c, c->d_res.ensure(n_res * E), "hipMalloc(res)");
+    if (n_ref) HIP_TRY(c, hipMemcpyAsync(c->d_ref.ptr(), ref, n_ref * E, hipMemcpyHostToDevice, c->stream), "H2D(ref)");
+    if (n_alt) HIP_TRY(c, hipMemcpyAsync(c->d_alt.ptr(), alt, n_alt * E, hipMemcpyHostToDevice, c->stream), "H2D(alt)");
+    int rc = init_status(c, c->d_status);
+    if (rc) return rc;
+
+    if (canonical) {
+        ImageBuilder img;
+        img.desc.reserve(n_tasks + 16);
+        bool gaps = false;
+        uint64_t cur = 0;
+        for (uint64_t i = 0; i < n_tasks; ++i) {
+            if (start_pos_res[i] > cur) gaps = true;
+            const int ps = img.add_task(code[i] == 0 ? SPACE_PROTEOME : SPACE_PAYLOAD, start_pos[i] * E, length[i] * E,
+                                        start_pos_res[i] * E, n_res * E);
+            if (ps != PACK_OK) return c->fail(pack_to_err(ps), "pack failed", int64_t(i));
+            cur = start_pos_res[i] + length[i];
+        }
+        if (cur < n_res) gaps = true;
+        img.end_haplotype(n_res * E);
+        img.finish();
+        HIP_TRY(c, c->d_desc.ensure(img.desc.size() * 8), "hipMalloc(desc)");
+        HIP_TRY(c, c->d_chunks.ensure(img.chunks.size() * sizeof(Chunk)), "hipMalloc(chunks)");
+        HIP_TRY(c, hipMemcpyAsync(c->d_desc.ptr(), img.desc.data(), img.desc.size() * 8, hipMemcpyHostToDevice, c->stream), "H2D(desc)");
+        HIP_TRY(c, hipMemcpyAsync(c->d_chunks.ptr(), img.chunks.data(), img.chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice, c->stream), "H2D(chunks)");
+        StitchArgs a{reinterpret_cast<const uint64_t*>(c->d_desc.ptr()), reinterpret_cast<const Chunk*>(c->d_chunks.ptr()),
+                     uint32_t(img.chunks.size()), c->d_ref.ptr(), n_ref * E, c->d_alt.ptr(), n_alt * E,
+                     c->d_res.ptr(), n_res * E, reinterpret_cast<unsigned long long*>(c->d_status.ptr())};
+        HIP_TRY(c, launch_stitch(a, c->stream, !(c->flags & V2P_FLAG_TEMPORAL), 0), "launch(stitch)");
+        if (!gaps) {
+            HIP_TRY(c, hipMemcpyAsync(res, c->d_res.ptr(), n_res * E, hipMemcpyDeviceToHost, c->stream), "D2H(res)");
+            return collect_status(c, c->d_status);
+        }
+        // cells no task covers keep the caller's content: bring the tape back to a
+        // staging buffer and copy only the covered ranges
+        HIP_TRY(c, c->h_stage.ensure(n_res * E), "hipHostMalloc(stage)");
+        HIP_TRY(c, hipMemcpyAsync(c->h_stage.p, c->d_res.ptr(), n_res * E, hipMemcpyDeviceToHost, c->stream), "D2H(res)");
+        rc = collect_status(c, c->d_status);
+        if (rc) return rc;
+        const uint32_t* st = reinterpret_cast<const uint32_t*>(c->h_stage.p);
+        for (uint64_t i = 0; i < n_tasks; ++i)
+            memcpy(res + start_pos_res[i], st + start_pos_res[i], size_t(length[i]) * E);
+        return V2P_OK;
+    }
+
+    // ordered path: overlapping / descending result ranges, executed in task order
+    const size_t n8 = size_t(n_tasks) * 8, ncode = (size_t(n_tasks) + 7) & ~size_t(7);
+    HIP_TRY(c, c->d_soa.ensure(3 * n8 + ncode), "hipMalloc(soa)");
+    uint8_t* d = c->d_soa.ptr();
+    HIP_TRY(c, hipMemcpyAsync(d, start_pos, n8, hipMemcpyHostToDevice, c->stream), "H2D(start_pos)");
+    HIP_TRY(c, hipMemcpyAsync(d + n8, length, n8, hipMemcpyHostToDevice, c->stream), "H2D(length)");
+    HIP_TRY(c, hipMemcpyAsync(d + 2 * n8, start_pos_res, n8, hipMemcpyHostToDevice, c->stream), "H2D(start_pos_res)");
+    HIP_TRY(c, hipMemcpyAsync(d + 3 * n8, code, n_tasks, hipMemcpyHostToDevice, c->stream), "H2D(code)");
+    HIP_TRY(c, hipMemcpyAsync(c->d_res.ptr(), res, n_res * E, hipMemcpyHostToDevice, c->stream), "H2D(res)");
+    OrderedArgs oa{d + 3 * n8, reinterpret_cast<const uint64_t*>(d), reinterpret_cast<const uint64_t*>(d + n8),
+                   reinterpret_cast<const uint64_t*>(d + 2 * n8), n_tasks, c->d_ref.ptr(), c->d_alt.ptr(), c->d_res.ptr(), E};
+    HIP_TRY(c, launch_ordered(oa, c->stream), "launch(ordered)");
+    HIP_TRY(c, hipMemcpyAsync(res, c->d_res.ptr(), n_res * E, hipMemcpyDeviceToHost, c->stream), "D2H(res)");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    return V2P_OK;
+}
+
+// ---- batch -------------------------------------------------------------------
+
+int v2p_batch_create(v2p_ctx* c, v2p_batch** out)
+{
+    if (!c || !out) return V2P_ERR_INVALID_ARG;
+    v2p_batch* b = new (std::nothrow) v2p_batch();
+    if (!b) return c->fail(V2P_ERR_HIP, "out of host memory");
+    b->ctx = c;
+    *out = b;
+    return V2P_OK;
+}
+
+void v2p_batch_destroy(v2p_batch* b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    b->d_desc.release(); b->d_chunks.release(); b->d_payload.release(); b->d_out.release();
+    b->d_hap.release(); b->d_digest.release(); b->d_status.release();
+    delete b;
+}
+
+// shared pre-check of one haplotype's tasks; returns V2P_OK or the error with its row
+static int precheck(v2p_ctx* c, const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
+                    const uint64_t* start_pos_res, uint64_t n_tasks, uint64_t n_ref, uint64_t n_alt, uint64_t n_res)
+{
+    uint64_t cursor = 0;
+    for (uint64_t i = 0; i < n_tasks; ++i) {
+        if (code[i] > 1) return c->fail(V2P_ERR_BAD_CODE, std::string(err_name(V2P_ERR_BAD_CODE)) + " at row " + std::to_string(i), int64_t(i));
+        const uint64_t n_src = code[i] == 0 ? n_ref : n_alt;
+        if (start_pos_res[i] + length[i] > n_res || start_pos_res[i] + length[i] < length[i])
+            return c->fail(V2P_ERR_RES_OOB, std::string(err_name(V2P_ERR_RES_OOB)) + " at row " + std::to_string(i), int64_t(i));
+        if (start_pos[i] + length[i] > n_src || start_pos[i] + length[i] < length[i])
+            return c->fail(V2P_ERR_SRC_OOB, std::string(err_name(V2P_ERR_SRC_OOB)) + " at row " + std::to_string(i), int64_t(i));
+        if (start_pos_res[i] < cursor)
+            return c->fail(V2P_ERR_NOT_CANONICAL, std::string(err_name(V2P_ERR_NOT_CANONICAL)) + " at row " + std::to_string(i), int64_t(i));
+        cursor = start_pos_res[i] + length[i];
+    }
+    return V2P_OK;
+}
+
+int v2p_batch_add_gir(v2p_batch* b,
+                      const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
+                      const uint64_t* start_pos_res, uint64_t n_tasks,
+                      const uint32_t* ref, uint64_t n_ref,
+                      const uint32_t* alt, uint64_t n_alt,
+                      uint64_t n_res)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
+    if ((n_tasks && (!code || !start_pos || !length || !start_pos_res)) || (n_ref && !ref) || (n_alt && !alt))
+        return c->fail(V2P_ERR_INVALID_ARG, "null argument");
+    int rc = precheck(c, code, start_pos, length, start_pos_res, n_tasks, n_ref, n_alt, n_res);
+    if (rc) return rc;
+    for (uint64_t i = 0; i < n_ref; ++i) if (ref[i] > 0xFFu) return c->fail(V2P_ERR_NON_BYTE_CHAR, err_name(V2P_ERR_NON_BYTE_CHAR), int64_t(i));
+    for (uint64_t i = 0; i < n_alt; ++i) if (alt[i] > 0xFFu) return c->fail(V2P_ERR_NON_BYTE_CHAR, err_name(V2P_ERR_NON_BYTE_CHAR), int64_t(i));
+    const uint64_t off_ref = b->img.payload_alloc(n_ref);
+    for (uint64_t i = 0; i < n_ref; ++i) b->img.payload[off_ref + i] = uint8_t(ref[i]);
+    const uint64_t off_alt = b->img.payload_alloc(n_alt);
+    for (uint64_t i = 0; i < n_alt; ++i) b->img.payload[off_alt + i] = uint8_t(alt[i]);
+    for (uint64_t i = 0; i < n_tasks; ++i)
+        (void)b->img.add_task(SPACE_PAYLOAD, (code[i] == 0 ? off_ref : off_alt) + start_pos[i], length[i], start_pos_res[i], n_res);
+    b->img.end_haplotype(n_res);
+    return V2P_OK;
+}
+
+int v2p_batch_add_haplotype(v2p_batch* b,
+                            const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
+                            const uint64_t* start_pos_res, uint64_t n_tasks,
+                            const uint64_t* seg_ref_begin, const uint64_t* seg_proteome_off, uint64_t n_seg,
+                            const uint8_t* alt, uint64_t n_alt,
+                            uint64_t n_res)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
+    if ((n_tasks && (!code || !start_pos || !length || !start_pos_res)) || (n_seg && (!seg_ref_begin || !seg_proteome_off)) || (n_alt && !alt))
+        return c->fail(V2P_ERR_INVALID_ARG, "null argument");
+    const uint64_t n_ref = n_seg ? seg_ref_begin[n_seg] : 0;
+    int rc = precheck(c, code, start_pos, length, start_pos_res, n_tasks, n_ref, n_alt, n_res);
+    if (rc) return rc;
+    RefSegments segs{seg_ref_begin, seg_proteome_off, n_seg};
+    // map every reference task before touching the image so a failure leaves the batch unchanged
+    std::vector<uint64_t> mapped(n_tasks);
+    for (uint64_t i = 0; i < n_tasks; ++i) {
+        if (code[i] != 0) continue;
+        if (length[i] == 0) { mapped[i] = 0; continue; }
+        if (!segs.map(start_pos[i], length[i], &mapped[i]))
+            return c->fail(V2P_ERR_SRC_OOB, "reference task crosses a transcript boundary at row " + std::to_string(i), int64_t(i));
+        if (mapped[i] + length[i] > c->proteome_len)
+            return c->fail(V2P_ERR_SRC_OOB, "reference task beyond the resident proteome at row " + std::to_string(i), int64_t(i));
+    }
+    const uint64_t off_alt = b->img.payload_alloc(n_alt);
+    if (n_alt) memcpy(&b->img.payload[off_alt], alt, n_alt);
+    for (uint64_t i = 0; i < n_tasks; ++i) {
+        if (code[i] == 0) (void)b->img.add_task(SPACE_PROTEOME, mapped[i], length[i], start_pos_res[i], n_res);
+        else              (void)b->img.add_task(SPACE_PAYLOAD, off_alt + start_pos[i], length[i], start_pos_res[i], n_res);
+    }
+    b->img.end_haplotype(n_res);
+    b->uses_proteome = true;
+    return V2P_OK;
+}
+
+int v2p_batch_set_packed(v2p_batch* b,
+                         const uint64_t* desc, uint64_t n_desc,
+                         const v2p_chunk* chunks, uint64_t n_chunks,
+                         const uint8_t* payload, uint64_t n_payload,
+                         const uint64_t* hap_out_begin, uint64_t n_haps)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
+    if ((n_desc && !desc) || (n_chunks && !chunks) || (n_payload && !payload) || !hap_out_begin)
+        return c->fail(V2P_ERR_INVALID_ARG, "null argument");
+    b->img = ImageBuilder();
+    b->img.desc.assign(desc, desc + n_desc);
+    b->img.chunks.resize(n_chunks);
+    if (n_chunks) memcpy(b->img.chunks.data(), chunks, n_chunks * sizeof(Chunk));
+    b->img.payload.assign(payload, payload + n_payload);
+    b->img.hap_out_begin.assign(hap_out_begin, hap_out_begin + n_haps + 1);
+    b->uses_proteome = true;
+    return V2P_OK;
+}
+
+int v2p_batch_finalize(v2p_batch* b)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
+    b->img.finish();
+    if (b->img.chunks.size() > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch");
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    b->n_desc = b->img.desc.size(); b->n_chunks = b->img.chunks.size(); b->n_payload = b->img.payload.size();
+    b->out_bytes = b->img.out_size(); b->n_haps = b->img.n_haplotypes();
+    HIP_TRY(c, b->d_desc.ensure(b->n_desc * 8), "hipMalloc(desc)");
+    HIP_TRY(c, b->d_chunks.ensure(b->n_chunks * sizeof(Chunk)), "hipMalloc(chunks)");
+    HIP_TRY(c, b->d_payload.ensure(b->n_payload), "hipMalloc(payload)");
+    HIP_TRY(c, b->d_out.ensure((b->out_bytes + 15) & ~15ull), "hipMalloc(out)");
+    HIP_TRY(c, b->d_hap.ensure((b->n_haps + 1) * 8), "hipMalloc(hap_begin)");
+    HIP_TRY(c, b->d_digest.ensure((b->n_haps ? b->n_haps : 1) * 8), "hipMalloc(digest)");
+    if (b->n_desc) HIP_TRY(c, hipMemcpyAsync(b->d_desc.ptr(), b->img.desc.data(), b->n_desc * 8, hipMemcpyHostToDevice, c->stream), "H2D(desc)");
+    if (b->n_chunks) HIP_TRY(c, hipMemcpyAsync(b->d_chunks.ptr(), b->img.chunks.data(), b->n_chunks * sizeof(Chunk), hipMemcpyHostToDevice, c->stream), "H2D(chunks)");
+    if (b->n_payload) HIP_TRY(c, hipMemcpyAsync(b->d_payload.ptr(), b->img.payload.data(), b->n_payload, hipMemcpyHostToDevice, c->stream), "H2D(payload)");
+    HIP_TRY(c, hipMemcpyAsync(b->d_hap.ptr(), b->img.hap_out_begin.data(), (b->n_haps + 1) * 8, hipMemcpyHostToDevice, c->stream), "H2D(hap_begin)");
+    int rc = init_status(c, b->d_status);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    // the host copy of the image is no longer needed
+    std::vector<uint64_t>().swap(b->img.desc);
+    std::vector<Chunk>().swap(b->img.chunks);
+    std::vector<uint8_t>().swap(b->img.payload);
+    b->finalized = true;
+    return V2P_OK;
+}
+
+int v2p_batch_execute(v2p_batch* b)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    StitchArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), reinterpret_cast<const Chunk*>(b->d_chunks.ptr()),
+                 uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len, b->d_payload.ptr(), b->n_payload,
+                 b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
+    HIP_TRY(c, launch_stitch(a, c->stream, !(c->flags & V2P_FLAG_TEMPORAL), 0), "launch(stitch)");
+    return V2P_OK;
+}
+
+int v2p_batch_sync(v2p_batch* b)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    int rc = collect_status(c, b->d_status);
+    if (rc) (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, sizeof(unsigned long long), c->stream);
+    return rc;
+}
+
+int v2p_batch_counts(const v2p_batch* b, uint64_t* n_haps, uint64_t* n_desc, uint64_t* n_chunks,
+                     uint64_t* out_bytes, uint64_t* payload_bytes)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    const bool f = b->finalized;
+    if (n_haps) *n_haps = f ? b->n_haps : b->img.n_haplotypes();
+    if (n_desc) *n_desc = f ? b->n_desc : b->img.desc.size();
+    if (n_chunks) *n_chunks = f ? b->n_chunks : b->img.chunks.size();
+    if (out_bytes) *out_bytes = f ? b->out_bytes : b->img.out_size();
+    if (payload_bytes) *payload_bytes = f ? b->n_payload : b->img.payload.size();
+    return V2P_OK;
+}
+
+int v2p_batch_hap_range(const v2p_batch* b, uint64_t h, uint64_t* begin, uint64_t* len)
+{
+    if (!b || !begin || !len) return V2P_ERR_INVALID_ARG;
+    const std::vector<uint64_t>& hb = b->img.hap_out_begin;
+    if (h + 1 >= hb.size()) return V2P_ERR_INVALID_ARG;
+    *begin = hb[h]; *len = hb[h + 1] - hb[h];
+    return V2P_OK;
+}
+
+int v2p_batch_download(v2p_batch* b, uint64_t begin, uint64_t len, uint8_t* out)
+{
+    if (!b || (len && !out)) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
+    if (begin + len > b->out_bytes) return c->fail(V2P_ERR_INVALID_ARG, "range outside the arena");
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    if (len) HIP_TRY(c, hipMemcpyAsync(out, b->d_out.ptr() + begin, len, hipMemcpyDeviceToHost, c->stream), "D2H(out)");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    return V2P_OK;
+}
+
+int v2p_batch_digests(v2p_batch* b, uint64_t* digests, uint64_t n_haps)
+{
+    if (!b || (n_haps && !digests)) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
+    if (n_haps != b->n_haps) return c->fail(V2P_ERR_INVALID_ARG, "n_haps mismatch");
+    if (n_haps == 0) return V2P_OK;
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    HIP_TRY(c, hipMemsetAsync(b->d_digest.ptr(), 0, n_haps * 8, c->stream), "hipMemset(digest)");
+    DigestArgs a{b->d_out.ptr(), reinterpret_cast<const uint64_t*>(b->d_hap.ptr()), n_haps, reinterpret_cast<uint64_t*>(b->d_digest.ptr())};
+    HIP_TRY(c, launch_digest(a, b->out_bytes, c->stream), "launch(digest)");
+    HIP_TRY(c, hipMemcpyAsync(digests, b->d_digest.ptr(), n_haps * 8, hipMemcpyDeviceToHost, c->stream), "D2H(digest)");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    return V2P_OK;
+}
+
+void* v2p_batch_device_out(v2p_batch* b) { return (b && b->finalized) ? b->d_out.ptr() : nullptr; }
+
+// ---- raw launchers -------------------------------------------------------------
+
+int v2p_stitch_launch(void* hip_stream,
+                      const uint64_t* d_desc, const v2p_chunk* d_chunks, uint32_t n_chunks,
+                      const uint8_t* d_src0, uint64_t src0_len,
+                      const uint8_t* d_src1, uint64_t src1_len,
+                      uint8_t* d_out, uint64_t out_len,
+                      uint64_t* d_status, int nontemporal, uint32_t max_blocks)
+{
+    if ((reinterpret_cast<uintptr_t>(d_out) & 15u) || !d_status) return V2P_ERR_INVALID_ARG;
+    StitchArgs a{d_desc, reinterpret_cast<const Chunk*>(d_chunks), n_chunks, d_src0, src0_len, d_src1, src1_len,
+                 d_out, out_len, reinterpret_cast<unsigned long long*>(d_status)};
+    return launch_stitch(a, reinterpret_cast<hipStream_t>(hip_stream), nontemporal, max_blocks) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
+}
+
+int v2p_digest_launch(void* hip_stream, const uint8_t* d_out, const uint64_t* d_hap_begin, uint64_t n_haps,
+                      uint64_t out_bytes, uint64_t* d_digests)
+{
+    DigestArgs a{d_out, d_hap_begin, n_haps, d_digests};
+    return launch_digest(a, out_bytes, reinterpret_cast<hipStream_t>(hip_stream)) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
+}
+
+int v2p_fill_launch(void* hip_stream, uint8_t* d_out, uint64_t bytes, uint32_t word, int nontemporal)
+{
+    return launch_fill(d_out, bytes, word, nontemporal, reinterpret_cast<hipStream_t>(hip_stream)) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
+}
+
+}  // extern "C"

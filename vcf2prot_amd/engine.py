@@ -1,0 +1,269 @@
+"""Host-side mirror of the reference's step-6 interface on top of the C ABI.
+
+Names and argument meaning follow the reference so parity tests read like its
+own tests (paths under /root/reference/src/data_structures/InternalRep):
+
+* ``Engine``  -- engines.rs:15-29 (``Engine.from_str("gpu")``)
+* ``Task``    -- task.rs:2-18
+* ``GIR``     -- gir.rs:15-46; ``GIR.execute(engine)`` is gir.rs:197-241 with the
+  ``Engine::GPU`` arm implemented (it panics in the reference, gir.rs:236-239).
+  ``Engine.ST``/``Engine.MT`` are NOT implemented here: this package is the gpu
+  plugin only, the CPU engines stay in the Rust host.
+* ``Context`` / ``Batch`` -- thin owners of ``v2p_ctx`` / ``v2p_batch``.
+
+Error behaviour: the reference panics (process abort); here a ``V2PError`` is
+raised with the same condition (bounds, stream code, contiguity under DEBUG_GPU).
+"""
+from __future__ import annotations
+
+import ctypes
+import enum
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as N
+from ._native import V2PError
+
+
+class Engine(enum.Enum):
+    ST = 0
+    MT = 1
+    GPU = 2
+
+    @staticmethod
+    def from_str(name: str) -> "Engine":
+        out = ctypes.c_int(-1)
+        rc = N.hip_lib().v2p_engine_from_str(name.encode(), ctypes.byref(out))
+        if rc != N.V2P_OK:
+            raise ValueError(f"{name} is not a supported engine")  # engines.rs:27
+        return Engine(out.value)
+
+
+@dataclass(frozen=True)
+class Task:
+    exe_code: int
+    start_pos: int
+    length: int
+    start_pos_res: int
+
+
+def _soa(tasks: Sequence[Task]):
+    n = len(tasks)
+    code = np.fromiter((t.exe_code for t in tasks), dtype=np.uint8, count=n)
+    sp = np.fromiter((t.start_pos for t in tasks), dtype=np.uint64, count=n)
+    ln = np.fromiter((t.length for t in tasks), dtype=np.uint64, count=n)
+    sr = np.fromiter((t.start_pos_res for t in tasks), dtype=np.uint64, count=n)
+    return code, sp, ln, sr
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None or a.size == 0 else a.ctypes.data
+
+
+class Context:
+    """One ``v2p_ctx`` (one HIP stream on one GPU).  Not thread-safe by design: one per worker."""
+
+    def __init__(self, device: int = 0, debug_gpu: Optional[bool] = None, temporal_stores: bool = False):
+        self._lib = N.hip_lib()
+        if debug_gpu is None:  # README.md:156-157: DEBUG_GPU is an environment flag
+            debug_gpu = "DEBUG_GPU" in os.environ
+        flags = (N.V2P_FLAG_DEBUG_GPU if debug_gpu else 0) | (N.V2P_FLAG_TEMPORAL if temporal_stores else 0)
+        h = ctypes.c_void_p()
+        rc = self._lib.v2p_init(device, flags, ctypes.byref(h))
+        if rc != N.V2P_OK:
+            raise V2PError(rc, (self._lib.v2p_last_error(None) or b"").decode())
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.v2p_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != N.V2P_OK:
+            raise V2PError(rc, (self._lib.v2p_last_error(self._h) or b"").decode(),
+                           int(self._lib.v2p_last_error_index(self._h)))
+
+    def set_stream(self, hip_stream: int):
+        self._check(self._lib.v2p_set_stream(self._h, ctypes.c_void_p(hip_stream)))
+
+    def upload_proteome(self, aa: np.ndarray):
+        aa = np.ascontiguousarray(aa, dtype=np.uint8)
+        self._check(self._lib.v2p_upload_proteome(self._h, _p(aa), aa.size))
+
+    # -- GIR-faithful mode --------------------------------------------------
+    def execute_gir(self, code, start_pos, length, start_pos_res, ref: np.ndarray, alt: np.ndarray,
+                    res: np.ndarray) -> np.ndarray:
+        code = np.ascontiguousarray(code, dtype=np.uint8)
+        sp = np.ascontiguousarray(start_pos, dtype=np.uint64)
+        ln = np.ascontiguousarray(length, dtype=np.uint64)
+        sr = np.ascontiguousarray(start_pos_res, dtype=np.uint64)
+        assert ref.dtype == np.uint32 and alt.dtype == np.uint32 and res.dtype == np.uint32
+        assert res.flags.c_contiguous and res.flags.writeable
+        ref = np.ascontiguousarray(ref)
+        alt = np.ascontiguousarray(alt)
+        self._check(self._lib.v2p_execute_gir(self._h, _p(code), _p(sp), _p(ln), _p(sr), code.size,
+                                              _p(ref), ref.size, _p(alt), alt.size, _p(res), res.size))
+        return res
+
+    def validate_gir(self, code, start_pos, length, start_pos_res, n_ref: int, n_alt: int, n_res: int) -> Tuple[int, int]:
+        """DEBUG_GPU inspection: (first bad row or -1, reason status)."""
+        code = np.ascontiguousarray(code, dtype=np.uint8)
+        sp = np.ascontiguousarray(start_pos, dtype=np.uint64)
+        ln = np.ascontiguousarray(length, dtype=np.uint64)
+        sr = np.ascontiguousarray(start_pos_res, dtype=np.uint64)
+        bad, reason = ctypes.c_int64(-1), ctypes.c_int(0)
+        self._check(self._lib.v2p_validate_gir(self._h, _p(code), _p(sp), _p(ln), _p(sr), code.size,
+                                               n_ref, n_alt, n_res, ctypes.byref(bad), ctypes.byref(reason)))
+        return int(bad.value), int(reason.value)
+
+    def batch(self) -> "Batch":
+        return Batch(self)
+
+
+class Batch:
+    """Many haplotypes executed per launch from one concatenated device image."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        h = ctypes.c_void_p()
+        ctx._check(self._lib.v2p_batch_create(ctx._h, ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            self._lib.v2p_batch_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_gir(self, code, start_pos, length, start_pos_res, ref: np.ndarray, alt: np.ndarray, n_res: int):
+        code = np.ascontiguousarray(code, dtype=np.uint8)
+        sp = np.ascontiguousarray(start_pos, dtype=np.uint64)
+        ln = np.ascontiguousarray(length, dtype=np.uint64)
+        sr = np.ascontiguousarray(start_pos_res, dtype=np.uint64)
+        ref = np.ascontiguousarray(ref, dtype=np.uint32)
+        alt = np.ascontiguousarray(alt, dtype=np.uint32)
+        self.ctx._check(self._lib.v2p_batch_add_gir(self._h, _p(code), _p(sp), _p(ln), _p(sr), code.size,
+                                                    _p(ref), ref.size, _p(alt), alt.size, n_res))
+
+    def add_haplotype(self, code, start_pos, length, start_pos_res, seg_ref_begin, seg_proteome_off,
+                      alt: np.ndarray, n_res: int):
+        code = np.ascontiguousarray(code, dtype=np.uint8)
+        sp = np.ascontiguousarray(start_pos, dtype=np.uint64)
+        ln = np.ascontiguousarray(length, dtype=np.uint64)
+        sr = np.ascontiguousarray(start_pos_res, dtype=np.uint64)
+        sb = np.ascontiguousarray(seg_ref_begin, dtype=np.uint64)
+        so = np.ascontiguousarray(seg_proteome_off, dtype=np.uint64)
+        assert sb.size == so.size + 1 or (sb.size == 0 and so.size == 0)
+        alt = np.ascontiguousarray(alt, dtype=np.uint8)
+        self.ctx._check(self._lib.v2p_batch_add_haplotype(self._h, _p(code), _p(sp), _p(ln), _p(sr), code.size,
+                                                          _p(sb), _p(so), so.size, _p(alt), alt.size, n_res))
+
+    def set_packed(self, desc: np.ndarray, chunks: np.ndarray, payload: np.ndarray, hap_out_begin: np.ndarray):
+        desc = np.ascontiguousarray(desc, dtype=np.uint64)
+        chunks = np.ascontiguousarray(chunks, dtype=np.uint64).reshape(-1, 2)
+        payload = np.ascontiguousarray(payload, dtype=np.uint8)
+        hb = np.ascontiguousarray(hap_out_begin, dtype=np.uint64)
+        self.ctx._check(self._lib.v2p_batch_set_packed(self._h, _p(desc), desc.size, _p(chunks), chunks.shape[0],
+                                                       _p(payload), payload.size, hb.ctypes.data, hb.size - 1))
+
+    def finalize(self):
+        self.ctx._check(self._lib.v2p_batch_finalize(self._h))
+
+    def execute(self):
+        self.ctx._check(self._lib.v2p_batch_execute(self._h))
+
+    def sync(self):
+        self.ctx._check(self._lib.v2p_batch_sync(self._h))
+
+    def counts(self) -> Dict[str, int]:
+        v = [ctypes.c_uint64() for _ in range(5)]
+        self.ctx._check(self._lib.v2p_batch_counts(self._h, *[ctypes.byref(x) for x in v]))
+        return dict(zip(("n_haps", "n_desc", "n_chunks", "out_bytes", "payload_bytes"), (int(x.value) for x in v)))
+
+    def hap_range(self, h: int) -> Tuple[int, int]:
+        b, ln = ctypes.c_uint64(), ctypes.c_uint64()
+        self.ctx._check(self._lib.v2p_batch_hap_range(self._h, h, ctypes.byref(b), ctypes.byref(ln)))
+        return int(b.value), int(ln.value)
+
+    def download(self, begin: int, length: int) -> np.ndarray:
+        out = np.empty(length, dtype=np.uint8)
+        self.ctx._check(self._lib.v2p_batch_download(self._h, begin, length, _p(out)))
+        return out
+
+    def download_hap(self, h: int) -> np.ndarray:
+        return self.download(*self.hap_range(h))
+
+    def digests(self) -> np.ndarray:
+        n = self.counts()["n_haps"]
+        out = np.zeros(n, dtype=np.uint64)
+        self.ctx._check(self._lib.v2p_batch_digests(self._h, _p(out), n))
+        return out
+
+    def device_out(self) -> int:
+        return int(self._lib.v2p_batch_device_out(self._h) or 0)
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None or _default_ctx._h is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class GIR:
+    """gir.rs:15-23.  Tapes are sequences of characters, like the reference's Vec<char>."""
+
+    def __init__(self, g_rep: Sequence[Task], annotation: Dict[str, Tuple[int, int]], alt_stream: Sequence[str],
+                 ref_stream: Sequence[str], res_array: Sequence[str]):
+        self.g_rep = list(g_rep)
+        self.annotation = dict(annotation)
+        self.alt_stream = list(alt_stream)
+        self.ref_stream = list(ref_stream)
+        self.res_array = list(res_array)
+
+    def get_tasks(self) -> List[Task]:
+        return self.g_rep
+
+    def get_annotation(self):
+        return self.annotation
+
+    def get_results_max(self) -> int:  # gir.rs:156-167
+        return max((v[1] for v in self.annotation.values()), default=0)
+
+    def execute(self, engine: Engine, ctx: Optional[Context] = None):
+        """gir.rs:197-241 -> (res_array, annotation).  Only Engine.GPU lives in this package."""
+        if engine is not Engine.GPU:
+            raise NotImplementedError("the st/mt engines are the reference's own CPU code; this package is the gpu engine")
+        ctx = ctx or default_context()
+        code, sp, ln, sr = _soa(self.g_rep)
+        ref = np.fromiter((ord(c) for c in self.ref_stream), dtype=np.uint32, count=len(self.ref_stream))
+        alt = np.fromiter((ord(c) for c in self.alt_stream), dtype=np.uint32, count=len(self.alt_stream))
+        res = np.fromiter((ord(c) for c in self.res_array), dtype=np.uint32, count=len(self.res_array))
+        ctx.execute_gir(code, sp, ln, sr, ref, alt, res)
+        return [chr(int(c)) for c in res], self.annotation
