@@ -1,0 +1,106 @@
+/*
+ * v2p_cohort.h -- synthetic cohorts at the Task boundary (plain C ABI, no HIP).
+ *
+ * Produces, per haplotype, exactly what the reference's steps 4-5 hand to the
+ * step-6 executor: the rebased Vec<Task> in SoA form (gir.rs:283-299), the alt
+ * tape, the layout of the private ref tape, and the result annotation
+ * (haplotype_instruction.rs:75-137).  Task shapes follow
+ * transcript_instructions.rs:335-780 for the alteration kinds the generator
+ * draws (missense, inframe insertion/deletion, frameshift, stop gained,
+ * stop lost, start lost); SURVEY.md Appendix A tabulates them.  The shapes are
+ * pinned against the reference binary by tests/golden/c1_example.* (the same
+ * cohort written as a VCF and run through bins/Linux/vcf2prot).
+ *
+ * Used by bench.py, the tests, and as the feeder of v2p_batch_set_packed().
+ */
+#ifndef V2P_COHORT_H
+#define V2P_COHORT_H
+
+#include <stdint.h>
+#include "vcf2prot_hip.h"   /* v2p_chunk */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct v2p_cohort v2p_cohort;
+typedef struct v2p_hapbuf v2p_hapbuf;
+
+enum { V2P_ALT_MISSENSE = 0, V2P_ALT_INSERTION = 1, V2P_ALT_DELETION = 2, V2P_ALT_FRAMESHIFT = 3,
+       V2P_ALT_STOP_GAINED = 4, V2P_ALT_STOP_LOST = 5, V2P_ALT_KINDS = 6 };
+
+typedef struct {
+    uint64_t seed_proteome;    /* 7 in every preset                                             */
+    uint64_t seed_cohort;
+    uint32_t n_samples;        /* haplotypes = 2 * n_samples                                    */
+    uint32_t n_transcripts;
+    double   mean_len;
+    uint32_t len_model;        /* 0: max(50, round(N(L, L/4)))   1: log-normal, median L         */
+    uint32_t fixed_len;        /* != 0: every transcript has this length                         */
+    uint32_t altered_per_hap;  /* 0: every transcript is altered in every haplotype              */
+    uint32_t alts_fixed;       /* != 0: this many alterations per altered transcript             */
+    double   alts_poisson;     /* else 1 + Poisson(lambda)                                       */
+    double   mix[V2P_ALT_KINDS];
+    uint32_t max_ins, max_del, max_fs_tail, max_sl_ext;
+    double   p_start_lost;     /* altered transcript is a start_lost (empty record) instead      */
+    double   p_empty_hap;      /* haplotype carries nothing                                      */
+} v2p_cohort_params;
+
+/* One haplotype as the executor receives it.  Pointers stay valid until the next
+ * v2p_cohort_generate() on the same hapbuf. */
+typedef struct {
+    uint64_t n_tasks;
+    const uint8_t*  code;
+    const uint64_t* start_pos;
+    const uint64_t* length;
+    const uint64_t* start_pos_res;
+    uint64_t n_alt;  const uint8_t* alt;          /* alt tape, 1 byte per residue                  */
+    uint64_t n_res;                                /* result tape length                            */
+    uint64_t n_ref;                                /* private ref tape length                       */
+    uint64_t n_seg;                                /* transcripts concatenated in the ref tape      */
+    const uint64_t* seg_ref_begin;                 /* [n_seg + 1]                                   */
+    const uint64_t* seg_proteome_off;              /* [n_seg]                                       */
+    uint64_t n_tx;                                 /* annotation: altered transcripts incl. empty ones */
+    const uint32_t* tx_id;                         /* [n_tx]                                        */
+    const uint64_t* tx_res_begin;                  /* [n_tx]                                        */
+    const uint64_t* tx_res_end;                    /* [n_tx]                                        */
+} v2p_hap_view;
+
+typedef struct {
+    uint64_t* desc;          uint64_t n_desc;
+    v2p_chunk* chunks;       uint64_t n_chunks;
+    uint8_t*  payload;       uint64_t n_payload;
+    uint64_t* hap_out_begin; uint64_t n_haps;      /* [n_haps + 1] */
+    uint64_t  n_tasks;       /* N: reference Task descriptors consumed (zero-length ones included) */
+    uint64_t  n_copy_bytes;  /* A: residues written = Sum task.length                              */
+} v2p_packed_image;
+
+/* "C1".."C5" (BASELINE.json configs, concretised in SURVEY.md section 8d) */
+int  v2p_cohort_preset(const char* name, v2p_cohort_params* out);
+int  v2p_cohort_create(const v2p_cohort_params* p, v2p_cohort** out);
+void v2p_cohort_destroy(v2p_cohort* c);
+
+uint64_t        v2p_cohort_n_haplotypes(const v2p_cohort* c);
+uint32_t        v2p_cohort_n_transcripts(const v2p_cohort* c);
+uint64_t        v2p_cohort_proteome_len(const v2p_cohort* c);
+const uint8_t*  v2p_cohort_proteome(const v2p_cohort* c);      /* transcripts back to back         */
+const uint64_t* v2p_cohort_tx_offsets(const v2p_cohort* c);    /* [n_transcripts + 1]              */
+
+v2p_hapbuf* v2p_hapbuf_create(void);
+void        v2p_hapbuf_destroy(v2p_hapbuf* b);
+/* haplotype index h = 2 * sample + (0|1) */
+int v2p_cohort_generate(const v2p_cohort* c, uint64_t hap, v2p_hapbuf* buf, v2p_hap_view* view);
+/* the private ref tape step 5 would build for this haplotype, as Rust chars */
+int v2p_cohort_ref_tape_u32(const v2p_cohort* c, const v2p_hap_view* view, uint32_t* out);
+/* alterations of one haplotype as text, one per line: "<transcript index>\t<csq type>\t<aa change>\n"
+ * (aa change in BCFtools/csq notation, e.g. 13I>13F).  Returns the bytes needed (excluding NUL). */
+int64_t v2p_cohort_describe(const v2p_cohort* c, uint64_t hap, char* buf, uint64_t cap);
+
+/* Device image of haplotypes [h0, h1) against the resident proteome, built on n_threads threads. */
+int  v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads, v2p_packed_image* out);
+void v2p_packed_free(v2p_packed_image* img);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* V2P_COHORT_H */

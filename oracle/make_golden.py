@@ -216,6 +216,51 @@ def check_with_oracle(case):
     return "".join(res)
 
 
+def harvest_cohort_example(out_dir, preset="C1", stem="c1_example"):
+    """BASELINE.json config 1 stand-in: the synthetic cohort written as example.vcf +
+    reference_sequences.fasta, run through the reference binary with -g mt and -g st."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    sys.path.insert(0, root)
+    from vcf2prot_amd import build
+    build.build_cohort()
+    from vcf2prot_amd.cohort import Cohort
+    c = Cohort.preset(preset)
+    n_samples = c.n_haplotypes // 2
+    samples = [f"SAMPLE{s:04d}" for s in range(n_samples)]
+    prot, off = c.proteome(), c.tx_offsets()
+    seqs = {c.tx_name(t): prot[int(off[t]):int(off[t + 1])].tobytes().decode() for t in range(c.n_transcripts)}
+    records = {}     # csq string -> mask per sample
+    order = []
+    for h in range(c.n_haplotypes):
+        for t, kind, aa in c.describe(h):
+            csq = f"{kind}|GENE{t}|{c.tx_name(t)}|protein_coding|+|{aa}|{1000 + t}A>T"
+            if csq not in records:
+                records[csq] = [0] * n_samples
+                order.append(csq)
+            records[csq][h // 2] |= 1 << (h % 2)
+    vcf_path, fa_path = os.path.join(out_dir, stem + ".vcf"), os.path.join(out_dir, stem + "_reference.fasta")
+    write_vcf(vcf_path, samples, [(csq, records[csq]) for csq in order])
+    write_fasta(fa_path, seqs)
+    result = {"generator": "oracle/make_golden.py", "preset": preset, "samples": samples, "n_records": len(order),
+              "oracle_binary": "vcf2prot 0.1.2 (bins/Linux)", "fasta": {}}
+    with tempfile.TemporaryDirectory() as tmp:
+        per_engine = {}
+        for engine in ("st", "mt"):
+            out = os.path.join(tmp, engine)
+            os.makedirs(out)
+            rc, log = run_reference(vcf_path, fa_path, out, engine)
+            if rc != 0:
+                sys.exit(f"reference binary failed on the cohort example with -g {engine}:\n{log[-800:]}")
+            per_engine[engine] = {s: read_fasta_records(os.path.join(out, s + ".fasta")) for s in samples}
+        if per_engine["st"] != per_engine["mt"]:
+            sys.exit("reference -g st and -g mt disagree on the cohort example")
+        result["fasta"] = per_engine["mt"]
+    with open(os.path.join(out_dir, stem + ".json"), "w") as f:
+        json.dump(result, f, indent=1)
+    n = sum(len(v) for v in result["fasta"].values())
+    print(f"cohort example {preset}: {len(order)} VCF records, {n} FASTA records from the reference (-g st == -g mt)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
@@ -274,6 +319,7 @@ def main():
     bad = [c["name"] for c in cases if not c["matches_source_unit_test"]]
     if bad:
         print("  binary(0.1.2) vs source(0.1.5) unit-test skew on:", bad)
+    harvest_cohort_example(args.out)
 
 
 if __name__ == "__main__":

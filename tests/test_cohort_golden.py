@@ -1,0 +1,156 @@
+"""The synthetic cohort generator's Task shapes, pinned against the reference binary.
+
+tests/golden/c1_example.{vcf,json} hold the C1 cohort written as a VCF and the FASTA
+records the reference's CPU engines (-g st and -g mt, identical) produced from it.
+Here the generator's Task vectors for the same cohort are executed (CPU suite: by
+the oracle; GPU suite: by the HIP engine) and must give the same set of records.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def c1(built):
+    from vcf2prot_amd.cohort import Cohort
+    with open(os.path.join(ROOT, "tests", "golden", "c1_example.json")) as f:
+        gold = json.load(f)
+    return Cohort.preset(gold["preset"]), gold
+
+
+def _records(cohort, hap, res_bytes):
+    """personalized_genome.rs:90-113: '>{name}_{1|2}' + seq[start..end]."""
+    s = bytes(res_bytes).decode()
+    h = hap.index % 2 + 1
+    return [(f"{cohort.tx_name(int(t))}_{h}", s[int(a):int(b)]) for t, a, b in zip(hap.tx_id, hap.tx_res_begin, hap.tx_res_end)]
+
+
+def test_generator_plus_oracle_reproduces_reference_fasta(c1, coracle):
+    cohort, gold = c1
+    kinds = set()
+    for s, sample in enumerate(gold["samples"]):
+        recs = []
+        for h in (2 * s, 2 * s + 1):
+            hap = cohort.haplotype(h)
+            kinds |= {k for _, k, _ in cohort.describe(h)}
+            ref = cohort.ref_tape_u32(h)
+            assert ref.size == hap.n_ref
+            t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+            res = np.full(hap.n_res, ord("."), dtype=np.uint32)
+            coracle.gir_execute(t, ref, hap.alt.astype(np.uint32), res, debug_cpu_exec=True)
+            recs += _records(cohort, hap, res.astype(np.uint8))
+        assert sorted(recs) == sorted(tuple(r) for r in gold["fasta"][sample]), sample
+    # the example exercises every kind the generator can draw
+    assert kinds == {"missense", "inframe_insertion", "inframe_deletion", "frameshift", "stop_gained", "stop_lost", "start_lost"}
+
+
+def test_packed_image_equals_oracle(c1, coracle):
+    """sir_pack.hpp image (resident proteome, 8-byte descriptors, chunks) interpreted on the CPU
+    in numpy == the oracle on the reference-shaped tasks.  Host logic only, no GPU."""
+    cohort, _ = c1
+    n = cohort.n_haplotypes
+    img = cohort.pack(0, n, n_threads=3)
+    prot = cohort.proteome()
+    out = np.zeros(img.out_bytes, dtype=np.uint8)
+    for tb, dn in img.chunks:
+        nt, dst = int(dn) >> 48, int(dn) & ((1 << 48) - 1)
+        for d in img.desc[int(tb):int(tb) + nt]:
+            d = int(d)
+            src, ln, space = d & ((1 << 40) - 1), (d >> 40) & ((1 << 22) - 1), d >> 62
+            if space == 0:
+                out[dst:dst + ln] = prot[src:src + ln]
+            elif space == 1:
+                out[dst:dst + ln] = img.payload[src:src + ln]
+            else:
+                out[dst:dst + ln] = ord(".")
+            dst += ln
+    tot_tasks = tot_bytes = 0
+    for h in range(n):
+        hap = cohort.haplotype(h)
+        t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+        want = coracle.gir_execute_u8(t, cohort.ref_tape_u32(h).astype(np.uint8), hap.alt,
+                                      np.full(hap.n_res, ord("."), dtype=np.uint8))
+        a, b = int(img.hap_out_begin[h]), int(img.hap_out_begin[h + 1])
+        assert b - a == hap.n_res and np.array_equal(out[a:b], want), h
+        tot_tasks += hap.n_tasks
+        tot_bytes += int(hap.length.sum())
+    assert img.n_tasks == tot_tasks and img.n_copy_bytes == tot_bytes
+
+
+@pytest.mark.parametrize("preset,haps", [("C2", [0, 1, 777]), ("C3", [0, 5, 19999]), ("C5", [0, 3, 99999])])
+def test_generator_invariants_at_config_shapes(built, coracle, preset, haps):
+    """Per-haplotype invariants of the big presets (a few haplotypes each, CPU only):
+    contiguity (gir.rs:208-226 holds), bounds, annotation tiles the result, zero-length tasks exist."""
+    from vcf2prot_amd.cohort import Cohort
+    c = Cohort.preset(preset)
+    zero = 0
+    for h in haps:
+        hap = c.haplotype(h)
+        t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+        assert coracle.validate(t) == -1
+        assert int(hap.length.sum()) == hap.n_res
+        assert np.all(hap.tx_res_begin[1:] == hap.tx_res_end[:-1]) and int(hap.tx_res_end[-1]) == hap.n_res
+        src_len = np.where(hap.code == 0, hap.n_ref, hap.alt.size)
+        assert np.all(hap.start_pos + hap.length <= src_len)
+        zero += int((hap.length == 0).sum())
+        if preset == "C2":      # 3 tasks per transcript, doubled missense payload (transcript_instructions.rs:659-660)
+            assert hap.n_tasks == 3 * c.n_transcripts and hap.alt.size == 2 * c.n_transcripts
+            assert np.array_equal(hap.alt[0::2], hap.alt[1::2])
+    assert zero > 0
+
+
+@pytest.mark.gpu
+def test_hip_engine_reproduces_reference_fasta(c1, gpu_ctx):
+    """Config 1 end to end on the GPU: GIR mode per haplotype, and the batched image."""
+    cohort, gold = c1
+    gpu_ctx.upload_proteome(cohort.proteome())
+    b = gpu_ctx.batch()
+    per_sample = {}
+    haps = [cohort.haplotype(h) for h in range(cohort.n_haplotypes)]
+    for hap in haps:
+        res = np.full(hap.n_res, ord("."), dtype=np.uint32)
+        gpu_ctx.execute_gir(hap.code, hap.start_pos, hap.length, hap.start_pos_res,
+                            cohort.ref_tape_u32(hap.index), hap.alt.astype(np.uint32), res)
+        per_sample.setdefault(hap.index // 2, []).extend(_records(cohort, hap, res.astype(np.uint8)))
+        b.add_haplotype(hap.code, hap.start_pos, hap.length, hap.start_pos_res, hap.seg_ref_begin, hap.seg_proteome_off,
+                        hap.alt, hap.n_res)
+    for s, sample in enumerate(gold["samples"]):
+        assert sorted(per_sample[s]) == sorted(tuple(r) for r in gold["fasta"][sample]), sample
+    b.finalize()
+    b.execute()
+    b.sync()
+    per_sample = {}
+    for hap in haps:
+        per_sample.setdefault(hap.index // 2, []).extend(_records(cohort, hap, b.download_hap(hap.index)))
+    for s, sample in enumerate(gold["samples"]):
+        assert sorted(per_sample[s]) == sorted(tuple(r) for r in gold["fasta"][sample]), sample
+    b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,h0,n", [("C2", 10, 6), ("C3", 100, 40), ("C5", 50, 300)])
+def test_packed_cohort_on_gpu_matches_oracle(built, gpu_ctx, coracle, preset, h0, n):
+    """A slice of each big config through set_packed -> stitch kernel -> per-haplotype bytes and digests."""
+    from vcf2prot_amd.cohort import Cohort
+    c = Cohort.preset(preset)
+    gpu_ctx.upload_proteome(c.proteome())
+    img = c.pack(h0, h0 + n, n_threads=4)
+    b = gpu_ctx.batch()
+    b.set_packed(img.desc, img.chunks, img.payload, img.hap_out_begin)
+    b.finalize()
+    b.execute()
+    b.sync()
+    dig = b.digests()
+    for i in range(n):
+        hap = c.haplotype(h0 + i)
+        t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+        want = coracle.gir_execute_u8(t, c.ref_tape_u32(h0 + i).astype(np.uint8), hap.alt,
+                                      np.full(hap.n_res, ord("."), dtype=np.uint8))
+        assert int(dig[i]) == coracle.digest_u8(want), (preset, i)
+        if i % 7 == 0:
+            assert np.array_equal(b.download_hap(i), want), (preset, i)
+    b.close()

@@ -1,0 +1,50 @@
+"""ctypes view of include/v2p_cohort.h."""
+import ctypes
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_uint8, c_uint32, c_uint64, c_void_p
+
+from ._native import v2p_chunk
+
+ALT_KINDS = 6
+
+
+class CohortParams(ctypes.Structure):
+    _fields_ = [("seed_proteome", c_uint64), ("seed_cohort", c_uint64), ("n_samples", c_uint32),
+                ("n_transcripts", c_uint32), ("mean_len", c_double), ("len_model", c_uint32), ("fixed_len", c_uint32),
+                ("altered_per_hap", c_uint32), ("alts_fixed", c_uint32), ("alts_poisson", c_double),
+                ("mix", c_double * ALT_KINDS), ("max_ins", c_uint32), ("max_del", c_uint32),
+                ("max_fs_tail", c_uint32), ("max_sl_ext", c_uint32), ("p_start_lost", c_double),
+                ("p_empty_hap", c_double)]
+
+
+class HapView(ctypes.Structure):
+    _fields_ = [("n_tasks", c_uint64), ("code", POINTER(c_uint8)), ("start_pos", POINTER(c_uint64)),
+                ("length", POINTER(c_uint64)), ("start_pos_res", POINTER(c_uint64)),
+                ("n_alt", c_uint64), ("alt", POINTER(c_uint8)), ("n_res", c_uint64), ("n_ref", c_uint64),
+                ("n_seg", c_uint64), ("seg_ref_begin", POINTER(c_uint64)), ("seg_proteome_off", POINTER(c_uint64)),
+                ("n_tx", c_uint64), ("tx_id", POINTER(c_uint32)), ("tx_res_begin", POINTER(c_uint64)),
+                ("tx_res_end", POINTER(c_uint64))]
+
+
+class PackedImage(ctypes.Structure):
+    _fields_ = [("desc", POINTER(c_uint64)), ("n_desc", c_uint64), ("chunks", POINTER(v2p_chunk)), ("n_chunks", c_uint64),
+                ("payload", POINTER(c_uint8)), ("n_payload", c_uint64), ("hap_out_begin", POINTER(c_uint64)),
+                ("n_haps", c_uint64), ("n_tasks", c_uint64), ("n_copy_bytes", c_uint64)]
+
+
+COHORT_API = {
+    "v2p_cohort_preset": (c_int, [c_char_p, POINTER(CohortParams)]),
+    "v2p_cohort_create": (c_int, [POINTER(CohortParams), POINTER(c_void_p)]),
+    "v2p_cohort_destroy": (None, [c_void_p]),
+    "v2p_cohort_n_haplotypes": (c_uint64, [c_void_p]),
+    "v2p_cohort_n_transcripts": (c_uint32, [c_void_p]),
+    "v2p_cohort_proteome_len": (c_uint64, [c_void_p]),
+    "v2p_cohort_proteome": (POINTER(c_uint8), [c_void_p]),
+    "v2p_cohort_tx_offsets": (POINTER(c_uint64), [c_void_p]),
+    "v2p_hapbuf_create": (c_void_p, []),
+    "v2p_hapbuf_destroy": (None, [c_void_p]),
+    "v2p_cohort_generate": (c_int, [c_void_p, c_uint64, c_void_p, POINTER(HapView)]),
+    "v2p_cohort_ref_tape_u32": (c_int, [c_void_p, POINTER(HapView), c_void_p]),
+    "v2p_cohort_describe": (c_int64, [c_void_p, c_uint64, c_void_p, c_uint64]),
+    "v2p_cohort_pack": (c_int, [c_void_p, c_uint64, c_uint64, c_int, POINTER(PackedImage)]),
+    "v2p_packed_free": (None, [POINTER(PackedImage)]),
+}
