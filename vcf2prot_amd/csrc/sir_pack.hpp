@@ -40,7 +40,7 @@ constexpr uint64_t SRC_MASK   = (1ull << 40) - 1;
 constexpr uint32_t LEN_BITS   = 22;
 constexpr uint32_t LEN_MASK   = (1u << LEN_BITS) - 1;
 constexpr uint32_t CHUNK_TASKS = 256;          // descriptors per work item (one per lane of a 256-thread workgroup)
-constexpr uint32_t CHUNK_BYTES = 64u * 1024u;  // result bytes per work item
+constexpr uint32_t CHUNK_BYTES = 64u * 1024u - 16u;  // result bytes per work item (<= 4096 16-byte blocks incl. ragged head)
 constexpr uint64_t DST_MASK   = (1ull << 48) - 1;
 constexpr uint32_t PAD_BYTES  = 16;            // readable slack each side of a source arena (16-byte gathers)
 

@@ -14,6 +14,7 @@ enum : uint32_t {
     STATUS_NOT_CONTIGUOUS = 4   // gir.rs:208-226 predicate
 };
 constexpr unsigned long long STATUS_CLEAN = ~0ull;
+constexpr int STITCH_DEFAULT_ILP = 2;     // 16-byte result blocks per lane per round (stitch_kernel<U>)
 
 struct StitchArgs {
     const uint64_t* desc;      // packed descriptors (sir_pack.hpp)

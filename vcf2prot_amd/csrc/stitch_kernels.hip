@@ -7,15 +7,14 @@
 //
 // Kernels
 //   stitch_kernel   K2 (+K0 fused, +in-chunk K1): one 256-lane workgroup per chunk of
-//                   <=256 descriptors / <=64 KiB of result.  Lanes load one 8-byte
-//                   descriptor each (coalesced), a wave64 DPP prefix scan + a 4-entry
-//                   LDS carry turn lengths into result offsets, then every lane owns
-//                   16-byte aligned result blocks: it finds the covering task by a
-//                   branch-free search of the offsets in LDS, gathers 16 source bytes
-//                   with one unaligned dwordx4 load per overlapping task and merges them
-//                   with v_bfi byte masks, and writes one aligned dwordx4 store.  Result
-//                   stores are therefore full 16-byte, fully coalesced (1 KiB per wave
-//                   instruction) whatever the source alignments are.
+//                   <=256 descriptors / <64 KiB of result.  Lanes load one 8-byte
+//                   descriptor each (coalesced); a wave64 DPP prefix scan + ballot ranks
+//                   turn lengths into result offsets and compact the non-empty tasks in
+//                   LDS; a scatter + SWAR prefix sum builds a block->task map; then every
+//                   lane owns 16-byte aligned result blocks: one unaligned dwordx4 gather
+//                   per overlapping task, tail-overwrite merge with 64-bit masks, and one
+//                   aligned dwordx4 store.  Result stores are full 16-byte and fully
+//                   coalesced (1 KiB per wave instruction) whatever the source alignments.
 //   ordered_kernel  reference-order execution for non-canonical Task vectors
 //                   (overlapping / descending result ranges): one workgroup, tasks in
 //                   order, barrier between tasks => "later task wins" as on the CPU.
@@ -43,123 +42,192 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
     return x;
 }
 
-__device__ __forceinline__ uint32_t byte_mask_below(uint32_t k)  // bytes [0,k) of a dword, k in 0..4
-{
-    return k >= 4u ? 0xFFFFFFFFu : ((1u << (8u * k)) - 1u);
-}
-
-// v[j] = ld[j] for bytes j in [a,b) of the 16-byte block
-__device__ __forceinline__ u32x4 merge_bytes(u32x4 v, u32x4 ld, uint32_t a, uint32_t b)
-{
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        uint32_t lo = a > 4u * w ? a - 4u * w : 0u;
-        uint32_t hi = b > 4u * w ? b - 4u * w : 0u;
-        uint32_t m = byte_mask_below(hi) & ~byte_mask_below(lo);
-        v[w] = (v[w] & ~m) | (ld[w] & m);
-    }
-    return v;
-}
-
 __device__ __forceinline__ void report(unsigned long long* status, uint64_t index, uint32_t reason)
 {
     atomicMin(status, (unsigned long long)((index << 8) | reason));
 }
 
-template <bool NT>
+// U = 16-byte result blocks each lane assembles concurrently (lock-step rounds).
+//
+// Per chunk (one workgroup, 256 lanes, one descriptor per lane):
+//   A  decode + bounds-check the descriptor; wave64 DPP scan of the lengths; ballot/mbcnt
+//      rank among the non-empty tasks; zero the block map
+//   B  compact the non-empty tasks by rank into LDS: s_off[r] (result offset inside the
+//      chunk) and s_adj[r] (source address minus that offset, bit 63 = '.' fill), and
+//      scatter "+1" into the block map at the first 16-byte block that starts inside
+//      or after task r (r >= 1)
+//   C,D prefix-sum the block map (16 one-byte counters per lane, SWAR + wave scan), so
+//      map[k] = rank of the task covering the first byte of result block k -- the
+//      per-block search costs one LDS byte read instead of a binary search
+//   K2 every lane assembles aligned 16-byte result blocks: round 0 gathers 16 bytes of
+//      task map[k] (one unaligned dwordx4 load at s_adj + block offset), later rounds
+//      gather task r+1, r+2, .. and overwrite the block's tail bytes; then one aligned
+//      (non-temporal) dwordx4 store.
+template <int U, bool NT>
 __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
 {
-    __shared__ uint64_t s_desc[256];
-    __shared__ uint32_t s_off[257];
-    __shared__ uint32_t s_wsum[4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_map32[1024 + 4];
+    __shared__ uint64_t s_adj[258];
+    __shared__ uint32_t s_off[260];
+    __shared__ uint32_t s_w[3][4];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    const uint8_t* const base0 = a.src0;
-    const uint8_t* const base1 = a.src1;
+    const uint8_t* const safe = reinterpret_cast<const uint8_t*>(a.chunks);   // 16 readable bytes for masked-out gathers
     const u32x4 dots = {0x2E2E2E2Eu, 0x2E2E2E2Eu, 0x2E2E2E2Eu, 0x2E2E2E2Eu};
+    const uint8_t* const s_map = reinterpret_cast<const uint8_t*>(s_map32);
 
     for (uint32_t c = blockIdx.x; c < a.n_chunks; c += gridDim.x) {
         const uint64_t tb = a.chunks[c].task_begin;
         const uint64_t dn = a.chunks[c].dst_n;
-        const uint32_t n = uint32_t(dn >> 48);
+        uint32_t n = uint32_t(dn >> 48);
+        n = n > 256u ? 256u : n;
         const uint64_t dst = dn & ((1ull << 48) - 1);
+        const uint32_t head = uint32_t(dst & 15ull);
 
-        // ---- K1: descriptors -> result offsets (one descriptor per lane) ----
-        uint64_t d = uint64_t(SPACE_FILL) << 62;
+        // ---- A ----
+        uint64_t adj = 1ull << 63;
         uint32_t len = 0;
         if (tid < n) {
-            d = a.desc[tb + tid];
+            const uint64_t d = a.desc[tb + tid];
             len = uint32_t(d >> 40) & ((1u << 22) - 1u);
             const uint32_t space = uint32_t(d >> 62);
             const uint64_t src = d & ((1ull << 40) - 1);
             const uint64_t limit = space == SPACE_PROTEOME ? a.src0_len : (space == SPACE_PAYLOAD ? a.src1_len : ~0ull);
             if (space == 3u || src + len > limit) {          // never read out of bounds: task.rs would panic
                 report(a.status, tb + tid, STATUS_SRC_OOB);
-                d = (d & ~(3ull << 62)) | (uint64_t(SPACE_FILL) << 62);
+            } else if (space != SPACE_FILL) {
+                adj = reinterpret_cast<uint64_t>(space == SPACE_PROTEOME ? a.src0 : a.src1) + src;
             }
         }
+        *reinterpret_cast<u32x4*>(&s_map32[4u * tid]) = u32x4{0u, 0u, 0u, 0u};
         const uint32_t incl = wave_incl_scan(len);
-        if (lane == 63u) s_wsum[wid] = incl;
-        __syncthreads();
-        const uint32_t w0 = s_wsum[0], w1 = s_wsum[1], w2 = s_wsum[2], w3 = s_wsum[3];
-        const uint32_t wave_base = (wid > 0 ? w0 : 0u) + (wid > 1 ? w1 : 0u) + (wid > 2 ? w2 : 0u);
-        const uint32_t excl = incl - len + wave_base;
-        const uint32_t total = w0 + w1 + w2 + w3;
-        s_desc[tid] = d;
-        s_off[tid] = excl;
-        if (tid == 255u) s_off[256] = total;
+        const unsigned long long nzmask = __ballot(len != 0u);
+        const uint32_t nz_before = __builtin_amdgcn_mbcnt_hi(uint32_t(nzmask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(nzmask), 0u));
+        if (lane == 63u) { s_w[0][wid] = incl; s_w[1][wid] = uint32_t(__popcll(nzmask)); }
         __syncthreads();
 
-        if (dst + total > a.out_len) {                        // never write out of bounds
+        // ---- B ----
+        const uint32_t l0 = s_w[0][0], l1 = s_w[0][1], l2 = s_w[0][2], l3 = s_w[0][3];
+        const uint32_t z0 = s_w[1][0], z1 = s_w[1][1], z2 = s_w[1][2], z3 = s_w[1][3];
+        const uint32_t total = l0 + l1 + l2 + l3;
+        const uint32_t nz = z0 + z1 + z2 + z3;
+        const uint32_t excl = incl - len + (wid > 0 ? l0 : 0u) + (wid > 1 ? l1 : 0u) + (wid > 2 ? l2 : 0u);
+        const uint32_t rank = nz_before + (wid > 0 ? z0 : 0u) + (wid > 1 ? z1 : 0u) + (wid > 2 ? z2 : 0u);
+        const uint32_t nblk = total ? (head + total + 15u) >> 4 : 0u;
+        const bool chunk_ok = dst + total <= a.out_len && nblk <= 4096u;
+        if (len != 0u) {
+            s_off[rank] = excl;
+            s_adj[rank] = (adj >> 63) ? adj : adj - excl;
+            if (rank >= 1u && chunk_ok) {
+                const uint32_t kmin = (excl + head + 15u) >> 4;    // first block starting at or after the task start
+                if (kmin < nblk) atomicAdd(&s_map32[kmin >> 2], 1u << (8u * (kmin & 3u)));
+            }
+        }
+        if (tid == 0u) { s_off[nz] = total; s_off[nz + 1u] = total; }
+        __syncthreads();
+
+        // ---- C: per-lane 16 one-byte counters -> in-lane prefix sums ----
+        u32x4 y = *reinterpret_cast<const u32x4*>(&s_map32[4u * tid]);
+        y[0] *= 0x01010101u; y[1] *= 0x01010101u; y[2] *= 0x01010101u; y[3] *= 0x01010101u;
+        const uint32_t p1 = y[0] >> 24, p2 = p1 + (y[1] >> 24), p3 = p2 + (y[2] >> 24), tsum = p3 + (y[3] >> 24);
+        const uint32_t tincl = wave_incl_scan(tsum);
+        if (lane == 63u) s_w[2][wid] = tincl;
+        __syncthreads();
+
+        // ---- D: add the lanes/waves before; every byte stays < 256 because ranks are < 256 ----
+        {
+            const uint32_t m0 = s_w[2][0], m1 = s_w[2][1], m2 = s_w[2][2];
+            const uint32_t mb = tincl - tsum + (wid > 0 ? m0 : 0u) + (wid > 1 ? m1 : 0u) + (wid > 2 ? m2 : 0u);
+            y[0] += mb * 0x01010101u; y[1] += (mb + p1) * 0x01010101u;
+            y[2] += (mb + p2) * 0x01010101u; y[3] += (mb + p3) * 0x01010101u;
+            *reinterpret_cast<u32x4*>(&s_map32[4u * tid]) = y;
+        }
+        __syncthreads();
+
+        if (!chunk_ok) {                                      // never write out of bounds
             if (tid == 0) report(a.status, tb, STATUS_RES_OOB);
         } else {
-            // ---- K2: every lane owns 16-byte aligned blocks of the chunk's result range ----
-            const uint32_t head = uint32_t(dst & 15ull);
-            const uint32_t nblk = (head + total + 15u) >> 4;
+            // ---- K2 ----
             uint8_t* const out0 = a.out + (dst - head);
-            for (uint32_t b = tid; b < nblk; b += 256u) {
-                const int32_t rel = int32_t(b << 4) - int32_t(head);          // block start relative to dst
-                const uint32_t lo = rel < 0 ? 0u : uint32_t(rel);
-                const uint32_t hi = uint32_t(rel + 16) < total ? uint32_t(rel + 16) : total;
-                // covering task: largest i with s_off[i] <= lo (zero-length tasks share an offset
-                // with their successor, so the last of equal offsets is the non-empty one)
-                uint32_t ti = 0;
+            for (uint32_t b0 = tid; b0 < nblk; b0 += 256u * U) {
+                int32_t rel[U];
+                uint32_t hi[U], r[U], pos[U];
+                u32x4 v[U];
+                bool more = false;
+                // round 0: the task covering the block's first byte; no merge needed
+                {
+                    const uint8_t* p[U];
+                    bool isfill[U];
 #pragma unroll
-                for (uint32_t step = 128u; step >= 1u; step >>= 1)
-                    if (s_off[ti + step] <= lo) ti += step;
-
-                u32x4 v = {0u, 0u, 0u, 0u};
-                uint32_t pos = lo;
-                while (pos < hi) {
-                    const uint32_t t_off = s_off[ti], t_end = s_off[ti + 1];
-                    const uint32_t seg_end = t_end < hi ? t_end : hi;
-                    if (seg_end > pos) {
-                        const uint64_t dd = s_desc[ti];
-                        const uint32_t space = uint32_t(dd >> 62);
-                        u32x4 ld = dots;
-                        if (space != SPACE_FILL) {
-                            // byte j of this load is result byte rel + j
-                            const uint8_t* p = (space == SPACE_PROTEOME ? base0 : base1)
-                                             + (dd & ((1ull << 40) - 1)) + (int64_t(rel) - int64_t(t_off));
-                            ld = reinterpret_cast<const unaligned16*>(p)->v;
-                        }
-                        const uint32_t ja = uint32_t(int32_t(pos) - rel), jb = uint32_t(int32_t(seg_end) - rel);
-                        if (ja == 0u && jb == 16u) v = ld;
-                        else v = merge_bytes(v, ld, ja, jb);
-                        pos = seg_end;
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t b = b0 + 256u * u;
+                        const bool act = b < nblk;
+                        rel[u] = int32_t(b << 4) - int32_t(head);              // block start relative to dst
+                        hi[u] = uint32_t(rel[u] + 16) < total ? uint32_t(rel[u] + 16) : total;
+                        r[u] = act ? uint32_t(s_map[b]) : 0u;
+                        const uint64_t aj = s_adj[r[u]];
+                        const uint32_t o1 = s_off[r[u] + 1u];
+                        isfill[u] = (aj >> 63) != 0;
+                        p[u] = (act && !isfill[u]) ? reinterpret_cast<const uint8_t*>(aj + int64_t(rel[u])) : safe;
+                        pos[u] = act ? (o1 < hi[u] ? o1 : hi[u]) : hi[u];
+                        ++r[u];
                     }
-                    ++ti;
-                }
-                uint8_t* o = out0 + (uint64_t(b) << 4);
-                if (rel >= 0 && uint32_t(rel) + 16u <= total) {
-                    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(o));
-                    else *reinterpret_cast<u32x4*>(o) = v;
-                } else {
-                    // ragged first/last block of the chunk: neighbours own the other bytes
-                    const uint32_t ja = uint32_t(int32_t(lo) - rel), jb = uint32_t(int32_t(hi) - rel);
 #pragma unroll
-                    for (uint32_t j = 0; j < 16u; ++j)
-                        if (j >= ja && j < jb) o[j] = uint8_t(v[j >> 2] >> (8u * (j & 3u)));
+                    for (int u = 0; u < U; ++u) {
+                        const u32x4 ld = reinterpret_cast<const unaligned16*>(p[u])->v;
+                        v[u] = isfill[u] ? dots : ld;
+                        more |= pos[u] < hi[u];
+                    }
+                }
+                // rounds >= 1: next task overwrites the block's bytes from its start onwards
+                while (more) {
+                    const uint8_t* p[U];
+                    bool isfill[U], take[U];
+                    uint32_t ja[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        take[u] = pos[u] < hi[u];
+                        const uint32_t rr = take[u] ? r[u] : 0u;
+                        const uint64_t aj = s_adj[rr];
+                        const uint32_t o1 = s_off[rr + 1u];
+                        isfill[u] = (aj >> 63) != 0;
+                        p[u] = (take[u] && !isfill[u]) ? reinterpret_cast<const uint8_t*>(aj + int64_t(rel[u])) : safe;
+                        ja[u] = uint32_t(int32_t(pos[u]) - rel[u]);        // 1..15
+                        if (take[u]) { pos[u] = o1 < hi[u] ? o1 : hi[u]; ++r[u]; }
+                    }
+                    more = false;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        u32x4 ld = reinterpret_cast<const unaligned16*>(p[u])->v;
+                        ld = isfill[u] ? dots : ld;
+                        // bytes >= ja come from this task
+                        const uint64_t x = ~0ull << (8u * (ja[u] & 7u));
+                        const uint64_t mlo = (take[u] && ja[u] < 8u) ? x : 0ull;
+                        const uint64_t mhi = take[u] ? (ja[u] < 8u ? ~0ull : x) : 0ull;
+                        const uint32_t k0 = uint32_t(mlo), k1 = uint32_t(mlo >> 32), k2 = uint32_t(mhi), k3 = uint32_t(mhi >> 32);
+                        v[u][0] = (v[u][0] & ~k0) | (ld[0] & k0);
+                        v[u][1] = (v[u][1] & ~k1) | (ld[1] & k1);
+                        v[u][2] = (v[u][2] & ~k2) | (ld[2] & k2);
+                        v[u][3] = (v[u][3] & ~k3) | (ld[3] & k3);
+                        more |= pos[u] < hi[u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t b = b0 + 256u * u;
+                    if (b < nblk) {
+                        uint8_t* o = out0 + (uint64_t(b) << 4);
+                        if (rel[u] >= 0 && uint32_t(rel[u]) + 16u <= total) {
+                            if (NT) __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(o));
+                            else *reinterpret_cast<u32x4*>(o) = v[u];
+                        } else {
+                            // ragged first/last block of the chunk: neighbours own the other bytes
+                            const uint32_t ka = rel[u] < 0 ? uint32_t(-rel[u]) : 0u, kb = uint32_t(int32_t(hi[u]) - rel[u]);
+#pragma unroll
+                            for (uint32_t j = 0; j < 16u; ++j)
+                                if (j >= ka && j < kb) o[j] = uint8_t(v[u][j >> 2] >> (8u * (j & 3u)));
+                        }
+                    }
                 }
             }
         }
@@ -288,8 +356,19 @@ hipError_t launch_stitch(const StitchArgs& a, hipStream_t stream, int nontempora
 {
     if (a.n_chunks == 0) return hipSuccess;
     const uint32_t grid = grid_for(a.n_chunks, max_blocks ? max_blocks : 0x7FFFFFFFu);
-    if (nontemporal) hipLaunchKernelGGL(stitch_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
-    else             hipLaunchKernelGGL(stitch_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
+    // `nontemporal` bit 0: nt result stores; bits 8..15: blocks per lane (0 = default)
+    const int nt = nontemporal & 1;
+    int u = (nontemporal >> 8) & 0xFF;
+    if (u == 0) u = STITCH_DEFAULT_ILP;
+#define V2P_LAUNCH(UU) do { if (nt) hipLaunchKernelGGL((stitch_kernel<UU, true>), dim3(grid), dim3(256), 0, stream, a); \
+                            else    hipLaunchKernelGGL((stitch_kernel<UU, false>), dim3(grid), dim3(256), 0, stream, a); } while (0)
+    switch (u) {
+        case 1: V2P_LAUNCH(1); break;
+        case 2: V2P_LAUNCH(2); break;
+        case 3: V2P_LAUNCH(3); break;
+        default: V2P_LAUNCH(4); break;
+    }
+#undef V2P_LAUNCH
     return hipGetLastError();
 }
 
