@@ -37,6 +37,10 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--temporal", action="store_true", help="plain result stores instead of non-temporal")
     ap.add_argument("--max-blocks", type=int, default=0)
+    ap.add_argument("--chunk-tasks", type=int, default=0)
+    ap.add_argument("--chunk-bytes", type=int, default=0)
+    ap.add_argument("--kernel", type=int, default=0, help="0: library default, 1: workgroup-per-chunk, 2: wave-per-chunk")
+    ap.add_argument("--dbg", type=int, default=0, help="timing-only kernel ablation (results are wrong; implies --no-verify)")
     ap.add_argument("--ilp", type=int, default=0, help="16-byte result blocks per lane per round (0 = library default)")
     ap.add_argument("--xcd-order", type=int, default=-1, help="1: deal chunks to XCDs by proteome slice, 0: result order (default: library default)")
     return ap.parse_args()
@@ -97,6 +101,8 @@ def cpu_baseline(cohort, n_threads, budget_s=12.0):
 
 def main():
     args = parse_args()
+    if args.dbg:
+        args.no_verify = True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,7 +135,7 @@ def main():
     h0, h1 = 2 * samples * rank, 2 * samples * (rank + 1)
     n_threads = max(1, (os.cpu_count() or 1) // world)
     t_gen = time.perf_counter()
-    img = cohort.pack(h0, h1, n_threads=min(n_threads, 64))
+    img = cohort.pack(h0, h1, n_threads=min(n_threads, 64), chunk_tasks=args.chunk_tasks, chunk_bytes=args.chunk_bytes)
     t_gen = time.perf_counter() - t_gen
     A, NT = img.n_copy_bytes, img.n_tasks
     b_alg = 2 * A + 16 * NT
@@ -161,7 +167,7 @@ def main():
         rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), d_desc.data_ptr(), d_chunks.data_ptr(), n_chunks,
                                    d_prot.data_ptr() + 16, proteome.size, d_payload.data_ptr() + 16, img.payload.size,
                                    d_out.data_ptr(), out_bytes, d_status.data_ptr(),
-                                   (0 if args.temporal else 1) | (args.ilp << 8), args.max_blocks)
+                                   (0 if args.temporal else 1) | (args.ilp << 8) | (args.dbg << 16) | (args.kernel << 24), args.max_blocks)
         if rc != 0:
             raise RuntimeError(f"v2p_stitch_launch failed: {rc}")
         if world > 1:                                          # the path's only exchange: result sizes for the global offsets

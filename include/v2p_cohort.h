@@ -96,8 +96,10 @@ int v2p_cohort_ref_tape_u32(const v2p_cohort* c, const v2p_hap_view* view, uint3
  * (aa change in BCFtools/csq notation, e.g. 13I>13F).  Returns the bytes needed (excluding NUL). */
 int64_t v2p_cohort_describe(const v2p_cohort* c, uint64_t hap, char* buf, uint64_t cap);
 
-/* Device image of haplotypes [h0, h1) against the resident proteome, built on n_threads threads. */
-int  v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads, v2p_packed_image* out);
+/* Device image of haplotypes [h0, h1) against the resident proteome, built on n_threads threads.
+ * chunk_tasks / chunk_bytes = 0 select the library defaults (sir_pack.hpp). */
+int  v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads,
+                     uint32_t chunk_tasks, uint32_t chunk_bytes, v2p_packed_image* out);
 void v2p_packed_free(v2p_packed_image* img);
 
 #ifdef __cplusplus

@@ -38,6 +38,10 @@ def main():
     for name, nt in (("fill_nt", 1), ("fill_plain", 0)):
         ms = timed(lambda: lib.v2p_fill_launch(ctypes.c_void_p(s), out.data_ptr(), n, 0x2E2E2E2E, nt))
         res[name + "_GBs"] = n / ms / 1e6
+    for span in (256, 1024, 2048, 4096):          # 16-byte blocks per workgroup: 4, 16, 32, 64 KiB
+        for nt in (1, 0):
+            ms = timed(lambda: lib.v2p_fill_launch(ctypes.c_void_p(s), out.data_ptr(), n, 0x2E2E2E2E, nt | (span << 8)))
+            res[f"fill_span{span * 16 // 1024}K_{'nt' if nt else 'plain'}_GBs"] = round(n / ms / 1e6, 1)
     ms = timed(lambda: out.copy_(src))
     res["torch_copy_GBs_read_plus_write"] = 2 * n / ms / 1e6
     ms = timed(lambda: out.fill_(46))

@@ -428,7 +428,8 @@ int64_t v2p_cohort_describe(const v2p_cohort* c, uint64_t hap, char* buf, uint64
     return int64_t(text.size());
 }
 
-int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads, v2p_packed_image* out)
+int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads,
+                    uint32_t chunk_tasks, uint32_t chunk_bytes, v2p_packed_image* out)
 {
     if (!c || !out || h1 < h0) return -1;
     memset(out, 0, sizeof *out);
@@ -436,6 +437,10 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
     if (n_threads < 1) n_threads = 1;
     if (uint64_t(n_threads) > n && n) n_threads = int(n);
     std::vector<v2p::ImageBuilder> parts(size_t(n_threads ? n_threads : 1));
+    for (auto& im : parts) {
+        if (chunk_tasks) im.chunk_tasks = chunk_tasks;
+        if (chunk_bytes) im.chunk_bytes = chunk_bytes;
+    }
     std::vector<int> status(parts.size(), 0);
     auto work = [&](int w) {
         const uint64_t a = h0 + n * uint64_t(w) / uint64_t(n_threads), e = h0 + n * uint64_t(w + 1) / uint64_t(n_threads);

@@ -127,11 +127,37 @@ private:
         chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_n_) << 48)});
         open_n_ = 0; open_bytes_ = 0;
     }
-    void push(unsigned space, uint64_t src, uint32_t len) {
-        if (open_n_ == chunk_tasks || (open_n_ && open_bytes_ + len > chunk_bytes)) close_chunk();
+    void append(unsigned space, uint64_t src, uint32_t len) {
         if (open_n_ == 0) { open_begin_ = desc.size(); open_dst_ = arena_cursor_; }
         desc.push_back(pack_desc(src, len, space));
         ++open_n_; open_bytes_ += len; arena_cursor_ += len;
+    }
+    // Chunks are cut at 16-byte aligned result offsets whenever possible (the task that
+    // straddles the cut is split into two descriptors), so a workgroup's first and last
+    // 16-byte result blocks are whole and the kernel never needs byte-granular edge stores.
+    // A chunk enters "closing mode" 8 descriptors / 16 bytes before its hard limits; if the
+    // cut is still unaligned at the hard limit it is made anyway (the kernel handles ragged edges).
+    void push(unsigned space, uint64_t src, uint32_t len) {
+        const uint32_t soft_tasks = chunk_tasks > 8 ? chunk_tasks - 8 : chunk_tasks;
+        const uint32_t soft_bytes = chunk_bytes - 16;
+        for (;;) {
+            const bool closing = open_n_ >= soft_tasks || open_bytes_ + len > soft_bytes;
+            if (!closing) { append(space, src, len); return; }
+            const uint32_t misal = uint32_t(arena_cursor_ & 15u);
+            if (open_n_ == chunk_tasks) { close_chunk(); continue; }          // ragged cut (many tiny tasks)
+            if (misal == 0 && open_n_ > 0) { close_chunk(); continue; }       // aligned cut
+            const uint32_t r = 16u - misal;
+            if (len <= r && open_bytes_ + len <= chunk_bytes) { append(space, src, len); return; }
+            if (misal != 0 && open_bytes_ + r <= chunk_bytes) {               // split the straddling task at the boundary
+                append(space, src, r);
+                if (space != SPACE_FILL) src += r;
+                len -= r;
+                close_chunk();
+                continue;
+            }
+            if (open_n_ == 0) { append(space, src, len); return; }            // a single piece always fits an empty chunk
+            close_chunk();
+        }
     }
 };
 

@@ -14,7 +14,7 @@ enum : uint32_t {
     STATUS_NOT_CONTIGUOUS = 4   // gir.rs:208-226 predicate
 };
 constexpr unsigned long long STATUS_CLEAN = ~0ull;
-constexpr int STITCH_DEFAULT_ILP = 2;     // 16-byte result blocks per lane per round (stitch_kernel<U>)
+constexpr uint32_t DOTS_BYTES = 64u * 1024u + 64u;   // per-device buffer of '.' that fill descriptors gather from
 
 struct StitchArgs {
     const uint64_t* desc;      // packed descriptors (sir_pack.hpp)
@@ -27,6 +27,7 @@ struct StitchArgs {
     uint8_t*        out;       // result arena, 16-byte aligned
     uint64_t        out_len;
     unsigned long long* status;
+    const uint8_t*  dots;      // set by launch_stitch(): DOTS_BYTES of '.'
 };
 
 struct OrderedArgs {

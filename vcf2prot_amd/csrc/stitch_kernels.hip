@@ -23,6 +23,7 @@
 //   digest_kernel   per-haplotype position-sensitive checksum of the result arena.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include "stitch_kernels.h"
 
 namespace v2p {
@@ -47,34 +48,47 @@ __device__ __forceinline__ void report(unsigned long long* status, uint64_t inde
     atomicMin(status, (unsigned long long)((index << 8) | reason));
 }
 
-// U = 16-byte result blocks each lane assembles concurrently (lock-step rounds).
-//
 // Per chunk (one workgroup, 256 lanes, one descriptor per lane):
 //   A  decode + bounds-check the descriptor; wave64 DPP scan of the lengths; ballot/mbcnt
 //      rank among the non-empty tasks; zero the block map
 //   B  compact the non-empty tasks by rank into LDS: s_off[r] (result offset inside the
-//      chunk) and s_adj[r] (source address minus that offset, bit 63 = '.' fill), and
-//      scatter "+1" into the block map at the first 16-byte block that starts inside
-//      or after task r (r >= 1)
+//      chunk) and s_adj[r] (source address minus that offset; '.' fill tasks point into a
+//      device buffer of dots), and scatter "+1" into the block map at the first 16-byte
+//      block that starts inside or after task r (r >= 1)
 //   C,D prefix-sum the block map (16 one-byte counters per lane, SWAR + wave scan), so
 //      map[k] = rank of the task covering the first byte of result block k -- the
 //      per-block search costs one LDS byte read instead of a binary search
-//   K2 every lane assembles aligned 16-byte result blocks: round 0 gathers 16 bytes of
-//      task map[k] (one unaligned dwordx4 load at s_adj + block offset), later rounds
-//      gather task r+1, r+2, .. and overwrite the block's tail bytes; then one aligned
-//      (non-temporal) dwordx4 store.
-template <int U, bool NT>
+//   K2 every lane assembles aligned 16-byte result blocks.  The ranks r, r+1, r+2 of the
+//      tasks that can overlap a block are known from one map read, so up to three
+//      unaligned dwordx4 gathers (s_adj[r+i] + block offset) are issued back to back and
+//      merged by tail-overwrite with 64-bit byte masks; only blocks cut by four or more
+//      tasks take the extra loop.  Then one aligned, non-temporal dwordx4 store.
+// DBG != 0: timing-only ablations (results are wrong): 1 = no gathers, 2 = no stores.
+__device__ __forceinline__ u32x4 overwrite_tail(u32x4 v, u32x4 ld, uint32_t ja, bool take)
+{
+    // bytes >= ja of the block come from ld (ja in 1..15)
+    const uint64_t x = ~0ull << (8u * (ja & 7u));
+    const uint64_t mlo = (take && ja < 8u) ? x : 0ull;
+    const uint64_t mhi = take ? (ja < 8u ? ~0ull : x) : 0ull;
+    const uint32_t k0 = uint32_t(mlo), k1 = uint32_t(mlo >> 32), k2 = uint32_t(mhi), k3 = uint32_t(mhi >> 32);
+    v[0] = (v[0] & ~k0) | (ld[0] & k0);
+    v[1] = (v[1] & ~k1) | (ld[1] & k1);
+    v[2] = (v[2] & ~k2) | (ld[2] & k2);
+    v[3] = (v[3] & ~k3) | (ld[3] & k3);
+    return v;
+}
+
+template <bool NT, int DBG = 0>
 __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_map32[1024 + 4];
-    __shared__ uint64_t s_adj[258];
-    __shared__ uint32_t s_off[260];
+    __shared__ uint64_t s_adj[264];
+    __shared__ uint32_t s_off[264];
     __shared__ uint32_t s_w[3][4];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    const uint8_t* const safe = reinterpret_cast<const uint8_t*>(a.chunks);   // 16 readable bytes for masked-out gathers
-    const u32x4 dots = {0x2E2E2E2Eu, 0x2E2E2E2Eu, 0x2E2E2E2Eu, 0x2E2E2E2Eu};
     const uint8_t* const s_map = reinterpret_cast<const uint8_t*>(s_map32);
+    const uint64_t dots16 = reinterpret_cast<uint64_t>(a.dots) + 16u;
 
     for (uint32_t c = blockIdx.x; c < a.n_chunks; c += gridDim.x) {
         const uint64_t tb = a.chunks[c].task_begin;
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
         const uint32_t head = uint32_t(dst & 15ull);
 
         // ---- A ----
-        uint64_t adj = 1ull << 63;
+        uint64_t adj = dots16;
         uint32_t len = 0;
         if (tid < n) {
             const uint64_t d = a.desc[tb + tid];
@@ -114,16 +128,16 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
         const uint32_t excl = incl - len + (wid > 0 ? l0 : 0u) + (wid > 1 ? l1 : 0u) + (wid > 2 ? l2 : 0u);
         const uint32_t rank = nz_before + (wid > 0 ? z0 : 0u) + (wid > 1 ? z1 : 0u) + (wid > 2 ? z2 : 0u);
         const uint32_t nblk = total ? (head + total + 15u) >> 4 : 0u;
-        const bool chunk_ok = dst + total <= a.out_len && nblk <= 4096u;
+        const bool chunk_ok = dst + total <= a.out_len && nblk <= 4096u && total <= DOTS_BYTES - 64u;
         if (len != 0u) {
             s_off[rank] = excl;
-            s_adj[rank] = (adj >> 63) ? adj : adj - excl;
+            s_adj[rank] = adj - excl;
             if (rank >= 1u && chunk_ok) {
                 const uint32_t kmin = (excl + head + 15u) >> 4;    // first block starting at or after the task start
                 if (kmin < nblk) atomicAdd(&s_map32[kmin >> 2], 1u << (8u * (kmin & 3u)));
             }
         }
-        if (tid == 0u) { s_off[nz] = total; s_off[nz + 1u] = total; }
+        if (tid < 4u) { s_off[nz + tid] = total; s_adj[nz + tid] = dots16 - total; }   // sentinels past the last task
         __syncthreads();
 
         // ---- C: per-lane 16 one-byte counters -> in-lane prefix sums ----
@@ -149,85 +163,52 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
         } else {
             // ---- K2 ----
             uint8_t* const out0 = a.out + (dst - head);
-            for (uint32_t b0 = tid; b0 < nblk; b0 += 256u * U) {
-                int32_t rel[U];
-                uint32_t hi[U], r[U], pos[U];
-                u32x4 v[U];
-                bool more = false;
-                // round 0: the task covering the block's first byte; no merge needed
-                {
-                    const uint8_t* p[U];
-                    bool isfill[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const uint32_t b = b0 + 256u * u;
-                        const bool act = b < nblk;
-                        rel[u] = int32_t(b << 4) - int32_t(head);              // block start relative to dst
-                        hi[u] = uint32_t(rel[u] + 16) < total ? uint32_t(rel[u] + 16) : total;
-                        r[u] = act ? uint32_t(s_map[b]) : 0u;
-                        const uint64_t aj = s_adj[r[u]];
-                        const uint32_t o1 = s_off[r[u] + 1u];
-                        isfill[u] = (aj >> 63) != 0;
-                        p[u] = (act && !isfill[u]) ? reinterpret_cast<const uint8_t*>(aj + int64_t(rel[u])) : safe;
-                        pos[u] = act ? (o1 < hi[u] ? o1 : hi[u]) : hi[u];
-                        ++r[u];
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const u32x4 ld = reinterpret_cast<const unaligned16*>(p[u])->v;
-                        v[u] = isfill[u] ? dots : ld;
-                        more |= pos[u] < hi[u];
+            for (uint32_t b = tid; b < nblk; b += 256u) {
+                const int32_t rel = int32_t(b << 4) - int32_t(head);          // block start relative to dst
+                const uint32_t hi = uint32_t(rel + 16) < total ? uint32_t(rel + 16) : total;
+                uint32_t r = s_map[b];
+                const uint32_t e0 = s_off[r + 1u], e1 = s_off[r + 2u], e2 = s_off[r + 3u];
+                const uint64_t a0 = s_adj[r], a1 = s_adj[r + 1u], a2 = s_adj[r + 2u];
+                const bool need1 = e0 < hi, need2 = e1 < hi;
+                // the sentinels make r+1, r+2 readable (dots) even when they are past the last task
+                const uint8_t* p0 = reinterpret_cast<const uint8_t*>(a0 + int64_t(rel));
+                const uint8_t* p1g = reinterpret_cast<const uint8_t*>(need1 ? a1 + int64_t(rel) : dots16);
+                const uint8_t* p2g = reinterpret_cast<const uint8_t*>(need2 ? a2 + int64_t(rel) : dots16);
+                u32x4 v, g1, g2;
+                if (DBG != 1) {
+                    v = reinterpret_cast<const unaligned16*>(p0)->v;
+                    g1 = reinterpret_cast<const unaligned16*>(p1g)->v;
+                    g2 = reinterpret_cast<const unaligned16*>(p2g)->v;
+                } else {
+                    v = u32x4{uint32_t(a0), e0, r, hi};
+                    g1 = u32x4{uint32_t(a1), e1, r, hi};
+                    g2 = u32x4{uint32_t(a2), e2, r, hi};
+                }
+                v = overwrite_tail(v, g1, uint32_t(int32_t(e0) - rel), need1);
+                v = overwrite_tail(v, g2, uint32_t(int32_t(e1) - rel), need2);
+                if (e2 < hi) {                                 // four or more tasks cut this block
+                    uint32_t pos = e2;
+                    r += 3u;
+                    while (pos < hi) {
+                        const uint64_t aj = s_adj[r];
+                        const uint32_t o1 = s_off[r + 1u];
+                        const u32x4 g = reinterpret_cast<const unaligned16*>(aj + int64_t(rel))->v;
+                        v = overwrite_tail(v, g, uint32_t(int32_t(pos) - rel), true);
+                        pos = o1;
+                        ++r;
                     }
                 }
-                // rounds >= 1: next task overwrites the block's bytes from its start onwards
-                while (more) {
-                    const uint8_t* p[U];
-                    bool isfill[U], take[U];
-                    uint32_t ja[U];
+                uint8_t* o = out0 + (uint64_t(b) << 4);
+                if (DBG == 2) { if (v[0] == 0x12345678u && v[3] == 0x9abcdef0u) o[0] = 1; }
+                else if (rel >= 0 && uint32_t(rel) + 16u <= total) {
+                    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(o));
+                    else *reinterpret_cast<u32x4*>(o) = v;
+                } else {
+                    // ragged first/last block of a chunk whose cut is not 16-byte aligned
+                    const uint32_t ka = rel < 0 ? uint32_t(-rel) : 0u, kb = uint32_t(int32_t(hi) - rel);
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        take[u] = pos[u] < hi[u];
-                        const uint32_t rr = take[u] ? r[u] : 0u;
-                        const uint64_t aj = s_adj[rr];
-                        const uint32_t o1 = s_off[rr + 1u];
-                        isfill[u] = (aj >> 63) != 0;
-                        p[u] = (take[u] && !isfill[u]) ? reinterpret_cast<const uint8_t*>(aj + int64_t(rel[u])) : safe;
-                        ja[u] = uint32_t(int32_t(pos[u]) - rel[u]);        // 1..15
-                        if (take[u]) { pos[u] = o1 < hi[u] ? o1 : hi[u]; ++r[u]; }
-                    }
-                    more = false;
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        u32x4 ld = reinterpret_cast<const unaligned16*>(p[u])->v;
-                        ld = isfill[u] ? dots : ld;
-                        // bytes >= ja come from this task
-                        const uint64_t x = ~0ull << (8u * (ja[u] & 7u));
-                        const uint64_t mlo = (take[u] && ja[u] < 8u) ? x : 0ull;
-                        const uint64_t mhi = take[u] ? (ja[u] < 8u ? ~0ull : x) : 0ull;
-                        const uint32_t k0 = uint32_t(mlo), k1 = uint32_t(mlo >> 32), k2 = uint32_t(mhi), k3 = uint32_t(mhi >> 32);
-                        v[u][0] = (v[u][0] & ~k0) | (ld[0] & k0);
-                        v[u][1] = (v[u][1] & ~k1) | (ld[1] & k1);
-                        v[u][2] = (v[u][2] & ~k2) | (ld[2] & k2);
-                        v[u][3] = (v[u][3] & ~k3) | (ld[3] & k3);
-                        more |= pos[u] < hi[u];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const uint32_t b = b0 + 256u * u;
-                    if (b < nblk) {
-                        uint8_t* o = out0 + (uint64_t(b) << 4);
-                        if (rel[u] >= 0 && uint32_t(rel[u]) + 16u <= total) {
-                            if (NT) __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(o));
-                            else *reinterpret_cast<u32x4*>(o) = v[u];
-                        } else {
-                            // ragged first/last block of the chunk: neighbours own the other bytes
-                            const uint32_t ka = rel[u] < 0 ? uint32_t(-rel[u]) : 0u, kb = uint32_t(int32_t(hi[u]) - rel[u]);
-#pragma unroll
-                            for (uint32_t j = 0; j < 16u; ++j)
-                                if (j >= ka && j < kb) o[j] = uint8_t(v[u][j >> 2] >> (8u * (j & 3u)));
-                        }
-                    }
+                    for (uint32_t j = 0; j < 16u; ++j)
+                        if (j >= ka && j < kb) o[j] = uint8_t(v[j >> 2] >> (8u * (j & 3u)));
                 }
             }
         }
@@ -337,12 +318,20 @@ __global__ __launch_bounds__(256) void digest_kernel(DigestArgs a)
 // fill_kernel: 16-byte streaming stores; used to measure the write ceiling the
 // stitch kernel is compared against (profiles/).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fill_kernel(uint8_t* out, uint64_t n16, uint32_t word, int nt)
+__global__ __launch_bounds__(256) void fill_kernel(uint8_t* out, uint64_t n16, uint32_t word, int nt, uint32_t span16)
 {
     const u32x4 v = {word, word, word, word};
     u32x4* o = reinterpret_cast<u32x4*>(out);
-    for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += uint64_t(gridDim.x) * blockDim.x) {
-        if (nt) __builtin_nontemporal_store(v, o + i); else o[i] = v;
+    if (span16 == 0) {     // grid-stride
+        for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += uint64_t(gridDim.x) * blockDim.x) {
+            if (nt) __builtin_nontemporal_store(v, o + i); else o[i] = v;
+        }
+    } else {               // one workgroup per contiguous span (the stitch kernel's store pattern)
+        const uint64_t b = uint64_t(blockIdx.x) * span16;
+        const uint64_t e = b + span16 < n16 ? b + span16 : n16;
+        for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+            if (nt) __builtin_nontemporal_store(v, o + i); else o[i] = v;
+        }
     }
 }
 
@@ -352,23 +341,42 @@ static inline uint32_t grid_for(uint64_t work_items, uint32_t cap)
     return uint32_t(work_items < cap ? (work_items ? work_items : 1) : cap);
 }
 
-hipError_t launch_stitch(const StitchArgs& a, hipStream_t stream, int nontemporal, uint32_t max_blocks)
+// One buffer of '.' per device: '.'-fill descriptors gather from it like any other source.
+static const uint8_t* device_dots(hipError_t* err)
 {
-    if (a.n_chunks == 0) return hipSuccess;
-    const uint32_t grid = grid_for(a.n_chunks, max_blocks ? max_blocks : 0x7FFFFFFFu);
-    // `nontemporal` bit 0: nt result stores; bits 8..15: blocks per lane (0 = default)
-    const int nt = nontemporal & 1;
-    int u = (nontemporal >> 8) & 0xFF;
-    if (u == 0) u = STITCH_DEFAULT_ILP;
-#define V2P_LAUNCH(UU) do { if (nt) hipLaunchKernelGGL((stitch_kernel<UU, true>), dim3(grid), dim3(256), 0, stream, a); \
-                            else    hipLaunchKernelGGL((stitch_kernel<UU, false>), dim3(grid), dim3(256), 0, stream, a); } while (0)
-    switch (u) {
-        case 1: V2P_LAUNCH(1); break;
-        case 2: V2P_LAUNCH(2); break;
-        case 3: V2P_LAUNCH(3); break;
-        default: V2P_LAUNCH(4); break;
+    static std::mutex mu;
+    static uint8_t* bufs[64] = {};
+    int dev = 0;
+    *err = hipGetDevice(&dev);
+    if (*err != hipSuccess || dev < 0 || dev >= 64) { if (*err == hipSuccess) *err = hipErrorInvalidDevice; return nullptr; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (!bufs[dev]) {
+        uint8_t* p = nullptr;
+        *err = hipMalloc(reinterpret_cast<void**>(&p), DOTS_BYTES);
+        if (*err != hipSuccess) return nullptr;
+        *err = hipMemset(p, '.', DOTS_BYTES);
+        if (*err == hipSuccess) *err = hipDeviceSynchronize();
+        if (*err != hipSuccess) { (void)hipFree(p); return nullptr; }
+        bufs[dev] = p;
     }
-#undef V2P_LAUNCH
+    return bufs[dev];
+}
+
+hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemporal, uint32_t max_blocks)
+{
+    if (args.n_chunks == 0) return hipSuccess;
+    StitchArgs a = args;
+    hipError_t err = hipSuccess;
+    a.dots = device_dots(&err);
+    if (!a.dots) return err;
+    // `nontemporal` bit 0: nt result stores; bits 16..23: timing-only ablation
+    const int nt = nontemporal & 1;
+    const int dbg = (nontemporal >> 16) & 0xFF;
+    const uint32_t grid = grid_for(a.n_chunks, max_blocks ? max_blocks : 0x7FFFFFFFu);
+    if (dbg == 1) hipLaunchKernelGGL((stitch_kernel<true, 1>), dim3(grid), dim3(256), 0, stream, a);
+    else if (dbg == 2) hipLaunchKernelGGL((stitch_kernel<true, 2>), dim3(grid), dim3(256), 0, stream, a);
+    else if (nt) hipLaunchKernelGGL((stitch_kernel<true, 0>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((stitch_kernel<false, 0>), dim3(grid), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -399,7 +407,10 @@ hipError_t launch_fill(uint8_t* out, uint64_t bytes, uint32_t word, int nontempo
 {
     const uint64_t n16 = bytes / 16;
     if (n16 == 0) return hipSuccess;
-    hipLaunchKernelGGL(fill_kernel, dim3(grid_for((n16 + 255) / 256, 256u * 8u)), dim3(256), 0, stream, out, n16, word, nontemporal);
+    const uint32_t span16 = uint32_t(nontemporal >> 8);          // bits 8..: 16-byte blocks per workgroup (0 = grid-stride)
+    const int nt = nontemporal & 1;
+    if (span16) hipLaunchKernelGGL(fill_kernel, dim3(uint32_t((n16 + span16 - 1) / span16)), dim3(256), 0, stream, out, n16, word, nt, span16);
+    else hipLaunchKernelGGL(fill_kernel, dim3(grid_for((n16 + 255) / 256, 256u * 8u)), dim3(256), 0, stream, out, n16, word, nt, 0u);
     return hipGetLastError();
 }
 
