@@ -39,36 +39,12 @@ def parse_args():
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--chunk-tasks", type=int, default=0)
     ap.add_argument("--chunk-bytes", type=int, default=0)
-    ap.add_argument("--kernel", type=int, default=0, help="0: library default, 1: workgroup-per-chunk, 2: wave-per-chunk")
     ap.add_argument("--dbg", type=int, default=0, help="timing-only kernel ablation (results are wrong; implies --no-verify)")
-    ap.add_argument("--ilp", type=int, default=0, help="16-byte result blocks per lane per round (0 = library default)")
-    ap.add_argument("--xcd-order", type=int, default=-1, help="1: deal chunks to XCDs by proteome slice, 0: result order (default: library default)")
+    ap.add_argument("--xcd-order", type=int, default=-1, help="0: launch chunks in result order instead of dealing them to XCDs by proteome slice")
     return ap.parse_args()
 
 
 DEFAULT_SAMPLES = {"C2": 1000, "C3": 2000, "C5": 10000}   # per GPU; C3/C5 full cohorts are processed in HBM-sized batches
-
-
-def xcd_order(np, chunks, desc, proteome_len, n_xcd=8):
-    """Deal chunks to the 8 XCDs by proteome slice: workgroup b runs on XCD b % 8 (observed round-robin
-    dispatch), so chunk order[8*j + x] is the j-th chunk whose reference reads fall in slice x.
-    Placement only changes L2 hit rate, never results."""
-    tb = chunks[:, 0].astype(np.int64)
-    key = np.zeros(tb.size, dtype=np.int64)
-    found = np.zeros(tb.size, dtype=bool)
-    for k in range(3):
-        d = desc[np.minimum(tb + k, desc.size - 1)]
-        is_ref = (d >> np.uint64(62)) == 0
-        take = is_ref & ~found
-        key[take] = (d[take] & np.uint64((1 << 40) - 1)).astype(np.int64)
-        found |= is_ref
-    bucket = np.minimum(key * n_xcd // max(proteome_len, 1), n_xcd - 1)
-    rank = np.zeros(tb.size, dtype=np.int64)
-    for x in range(n_xcd):
-        m = bucket == x
-        rank[m] = np.arange(int(m.sum()))
-    order = np.lexsort((bucket, rank))
-    return chunks[order]
 
 
 def cpu_baseline(cohort, n_threads, budget_s=12.0):
@@ -149,8 +125,10 @@ def main():
 
     d_prot, d_payload = padded(proteome), padded(img.payload)
     d_desc = torch.from_numpy(img.desc.view(np.int64)).to(dev)
-    if args.xcd_order == 1:
-        img.chunks = xcd_order(np, img.chunks, img.desc, proteome.size)
+    img.chunks = np.ascontiguousarray(img.chunks)
+    if args.xcd_order != 0:           # XCD-aware launch order (speed only; chunks are independent)
+        rc = lib.v2p_order_chunks_for_xcds(img.chunks.ctypes.data, img.chunks.shape[0], img.desc.ctypes.data, img.desc.size, proteome.size)
+        assert rc == 0
     d_chunks = torch.from_numpy(np.ascontiguousarray(img.chunks).view(np.int64)).to(dev)
     d_hap = torch.from_numpy(img.hap_out_begin.view(np.int64)).to(dev)
     out_bytes = img.out_bytes
@@ -167,7 +145,7 @@ def main():
         rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), d_desc.data_ptr(), d_chunks.data_ptr(), n_chunks,
                                    d_prot.data_ptr() + 16, proteome.size, d_payload.data_ptr() + 16, img.payload.size,
                                    d_out.data_ptr(), out_bytes, d_status.data_ptr(),
-                                   (0 if args.temporal else 1) | (args.ilp << 8) | (args.dbg << 16) | (args.kernel << 24), args.max_blocks)
+                                   (0 if args.temporal else 1) | (args.dbg << 16), args.max_blocks)
         if rc != 0:
             raise RuntimeError(f"v2p_stitch_launch failed: {rc}")
         if world > 1:                                          # the path's only exchange: result sizes for the global offsets

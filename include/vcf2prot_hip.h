@@ -55,6 +55,7 @@ extern "C" {
 /* v2p_init flags */
 #define V2P_FLAG_DEBUG_GPU   1u   /* validate every GIR on the device before executing it (DEBUG_GPU) */
 #define V2P_FLAG_TEMPORAL    2u   /* plain result stores instead of non-temporal ones                  */
+#define V2P_FLAG_RESULT_ORDER 4u  /* launch chunks in result order instead of the XCD-aware order      */
 
 typedef struct v2p_ctx v2p_ctx;
 typedef struct v2p_batch v2p_batch;
@@ -163,6 +164,10 @@ int v2p_stitch_launch(void* hip_stream,
                       const uint8_t* d_src1, uint64_t src1_len,
                       uint8_t* d_out, uint64_t out_len,
                       uint64_t* d_status, int nontemporal, uint32_t max_blocks);
+/* Host-side: reorder a chunk table so that workgroup 8*j + x (XCD x) works on proteome slice x.
+ * v2p_batch_finalize() does this itself; callers of v2p_stitch_launch() may want it too. */
+int v2p_order_chunks_for_xcds(v2p_chunk* chunks, uint64_t n_chunks, const uint64_t* desc, uint64_t n_desc,
+                              uint64_t proteome_len);
 int v2p_digest_launch(void* hip_stream, const uint8_t* d_out, const uint64_t* d_hap_begin, uint64_t n_haps,
                       uint64_t out_bytes, uint64_t* d_digests);
 int v2p_fill_launch(void* hip_stream, uint8_t* d_out, uint64_t bytes, uint32_t word, int nontemporal);

@@ -21,7 +21,7 @@ ERR_NAMES = {
 }
 V2P_ERR_INVALID_ARG, V2P_ERR_HIP, V2P_ERR_BAD_CODE, V2P_ERR_RES_OOB, V2P_ERR_SRC_OOB = -1, -2, -3, -4, -5
 V2P_ERR_NOT_CONTIGUOUS, V2P_ERR_NOT_CANONICAL, V2P_ERR_NON_BYTE_CHAR, V2P_ERR_UNSUPPORTED, V2P_ERR_STATE = -6, -7, -8, -9, -10
-V2P_FLAG_DEBUG_GPU, V2P_FLAG_TEMPORAL = 1, 2
+V2P_FLAG_DEBUG_GPU, V2P_FLAG_TEMPORAL, V2P_FLAG_RESULT_ORDER = 1, 2, 4
 
 
 class v2p_chunk(ctypes.Structure):
@@ -62,6 +62,7 @@ HIP_API = {
     "v2p_batch_device_out": (c_void_p, [c_void_p]),
     "v2p_stitch_launch": (c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, c_uint64,
                                   c_void_p, c_uint64, c_void_p, c_int, c_uint32]),
+    "v2p_order_chunks_for_xcds": (c_int, [c_void_p, c_uint64, c_void_p, c_uint64, c_uint64]),
     "v2p_digest_launch": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
     "v2p_fill_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_int]),
 }

@@ -31,6 +31,15 @@ namespace v2p {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(1))) unaligned16 { u32x4 v; };
 
+// 16 bytes from an arbitrary (unaligned) global address held as an integer.  The explicit global
+// address space matters: a pointer rebuilt from an integer would otherwise be a FLAT access
+// (counts on vmcnt AND lgkmcnt, returns out of order).
+__device__ __forceinline__ u32x4 gather16(uint64_t addr)
+{
+    typedef const __attribute__((address_space(1))) unaligned16* gptr;
+    return reinterpret_cast<gptr>(addr)->v;
+}
+
 // ---- wave64 inclusive add-scan with DPP (row_shr 1/2/4/8, row_bcast 15/31) ----
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
 {
@@ -78,6 +87,15 @@ __device__ __forceinline__ u32x4 overwrite_tail(u32x4 v, u32x4 ld, uint32_t ja, 
     return v;
 }
 
+// Workgroup barrier that orders LDS only.  __syncthreads() also waits for vmcnt(0), i.e. for
+// every result store the wave has in flight; nothing in this kernel re-reads its own stores.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <bool NT, int DBG = 0>
 __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
 {
@@ -91,6 +109,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
     const uint64_t dots16 = reinterpret_cast<uint64_t>(a.dots) + 16u;
 
     for (uint32_t c = blockIdx.x; c < a.n_chunks; c += gridDim.x) {
+        if (c != blockIdx.x) lds_barrier();            // LDS is reused by the next chunk
         const uint64_t tb = a.chunks[c].task_begin;
         const uint64_t dn = a.chunks[c].dst_n;
         uint32_t n = uint32_t(dn >> 48);
@@ -118,7 +137,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
         const unsigned long long nzmask = __ballot(len != 0u);
         const uint32_t nz_before = __builtin_amdgcn_mbcnt_hi(uint32_t(nzmask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(nzmask), 0u));
         if (lane == 63u) { s_w[0][wid] = incl; s_w[1][wid] = uint32_t(__popcll(nzmask)); }
-        __syncthreads();
+        lds_barrier();
 
         // ---- B ----
         const uint32_t l0 = s_w[0][0], l1 = s_w[0][1], l2 = s_w[0][2], l3 = s_w[0][3];
@@ -138,7 +157,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
             }
         }
         if (tid < 4u) { s_off[nz + tid] = total; s_adj[nz + tid] = dots16 - total; }   // sentinels past the last task
-        __syncthreads();
+        lds_barrier();
 
         // ---- C: per-lane 16 one-byte counters -> in-lane prefix sums ----
         u32x4 y = *reinterpret_cast<const u32x4*>(&s_map32[4u * tid]);
@@ -146,7 +165,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
         const uint32_t p1 = y[0] >> 24, p2 = p1 + (y[1] >> 24), p3 = p2 + (y[2] >> 24), tsum = p3 + (y[3] >> 24);
         const uint32_t tincl = wave_incl_scan(tsum);
         if (lane == 63u) s_w[2][wid] = tincl;
-        __syncthreads();
+        lds_barrier();
 
         // ---- D: add the lanes/waves before; every byte stays < 256 because ranks are < 256 ----
         {
@@ -156,7 +175,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
             y[2] += (mb + p2) * 0x01010101u; y[3] += (mb + p3) * 0x01010101u;
             *reinterpret_cast<u32x4*>(&s_map32[4u * tid]) = y;
         }
-        __syncthreads();
+        lds_barrier();
 
         if (!chunk_ok) {                                      // never write out of bounds
             if (tid == 0) report(a.status, tb, STATUS_RES_OOB);
@@ -171,14 +190,13 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
                 const uint64_t a0 = s_adj[r], a1 = s_adj[r + 1u], a2 = s_adj[r + 2u];
                 const bool need1 = e0 < hi, need2 = e1 < hi;
                 // the sentinels make r+1, r+2 readable (dots) even when they are past the last task
-                const uint8_t* p0 = reinterpret_cast<const uint8_t*>(a0 + int64_t(rel));
-                const uint8_t* p1g = reinterpret_cast<const uint8_t*>(need1 ? a1 + int64_t(rel) : dots16);
-                const uint8_t* p2g = reinterpret_cast<const uint8_t*>(need2 ? a2 + int64_t(rel) : dots16);
-                u32x4 v, g1, g2;
+                // the address path (TA) is the busiest unit of this kernel: lanes that do not need a
+                // second/third task stay masked off instead of gathering from a dummy address
+                u32x4 v, g1 = {0u, 0u, 0u, 0u}, g2 = {0u, 0u, 0u, 0u};
                 if (DBG != 1) {
-                    v = reinterpret_cast<const unaligned16*>(p0)->v;
-                    g1 = reinterpret_cast<const unaligned16*>(p1g)->v;
-                    g2 = reinterpret_cast<const unaligned16*>(p2g)->v;
+                    v = gather16(a0 + int64_t(rel));
+                    if (need1) g1 = gather16(a1 + int64_t(rel));
+                    if (need2) g2 = gather16(a2 + int64_t(rel));
                 } else {
                     v = u32x4{uint32_t(a0), e0, r, hi};
                     g1 = u32x4{uint32_t(a1), e1, r, hi};
@@ -192,7 +210,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
                     while (pos < hi) {
                         const uint64_t aj = s_adj[r];
                         const uint32_t o1 = s_off[r + 1u];
-                        const u32x4 g = reinterpret_cast<const unaligned16*>(aj + int64_t(rel))->v;
+                        const u32x4 g = gather16(aj + int64_t(rel));
                         v = overwrite_tail(v, g, uint32_t(int32_t(pos) - rel), true);
                         pos = o1;
                         ++r;
@@ -212,7 +230,6 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
                 }
             }
         }
-        __syncthreads();   // LDS is reused by the next chunk
     }
 }
 
@@ -373,10 +390,11 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     const int nt = nontemporal & 1;
     const int dbg = (nontemporal >> 16) & 0xFF;
     const uint32_t grid = grid_for(a.n_chunks, max_blocks ? max_blocks : 0x7FFFFFFFu);
-    if (dbg == 1) hipLaunchKernelGGL((stitch_kernel<true, 1>), dim3(grid), dim3(256), 0, stream, a);
-    else if (dbg == 2) hipLaunchKernelGGL((stitch_kernel<true, 2>), dim3(grid), dim3(256), 0, stream, a);
-    else if (nt) hipLaunchKernelGGL((stitch_kernel<true, 0>), dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((stitch_kernel<false, 0>), dim3(grid), dim3(256), 0, stream, a);
+    const uint32_t dyn = 0;
+    if (dbg == 1) hipLaunchKernelGGL((stitch_kernel<true, 1>), dim3(grid), dim3(256), dyn, stream, a);
+    else if (dbg == 2) hipLaunchKernelGGL((stitch_kernel<true, 2>), dim3(grid), dim3(256), dyn, stream, a);
+    else if (nt) hipLaunchKernelGGL((stitch_kernel<true, 0>), dim3(grid), dim3(256), dyn, stream, a);
+    else hipLaunchKernelGGL((stitch_kernel<false, 0>), dim3(grid), dim3(256), dyn, stream, a);
     return hipGetLastError();
 }
 

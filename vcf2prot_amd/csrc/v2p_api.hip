@@ -487,6 +487,8 @@ int v2p_batch_finalize(v2p_batch* b)
     std::lock_guard<std::mutex> lk(c->mu);
     if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
     b->img.finish();
+    if (b->uses_proteome && !(c->flags & V2P_FLAG_RESULT_ORDER))
+        order_chunks_for_xcds(b->img.chunks.data(), b->img.chunks.size(), b->img.desc.data(), b->img.desc.size(), c->proteome_len);
     if (b->img.chunks.size() > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     b->n_desc = b->img.desc.size(); b->n_chunks = b->img.chunks.size(); b->n_payload = b->img.payload.size();
@@ -612,6 +614,13 @@ int v2p_digest_launch(void* hip_stream, const uint8_t* d_out, const uint64_t* d_
 {
     DigestArgs a{d_out, d_hap_begin, n_haps, d_digests};
     return launch_digest(a, out_bytes, reinterpret_cast<hipStream_t>(hip_stream)) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
+}
+
+int v2p_order_chunks_for_xcds(v2p_chunk* chunks, uint64_t n_chunks, const uint64_t* desc, uint64_t n_desc, uint64_t proteome_len)
+{
+    if ((n_chunks && !chunks) || (n_desc && !desc)) return V2P_ERR_INVALID_ARG;
+    order_chunks_for_xcds(reinterpret_cast<Chunk*>(chunks), n_chunks, desc, n_desc, proteome_len);
+    return V2P_OK;
 }
 
 int v2p_fill_launch(void* hip_stream, uint8_t* d_out, uint64_t bytes, uint32_t word, int nontemporal)
