@@ -13,5 +13,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- p
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 bench.py --no-cpu-baseline --no-verify --steps 3 --warmup 1 "$@" > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python3 bench.py --no-cpu-baseline --no-verify --steps 3 --warmup 1 "$@" > $OUT/bench_write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_l2 -o l2 -- python3 bench.py --no-cpu-baseline --no-verify --steps 3 --warmup 1 "$@" > $OUT/bench_l2.log 2>&1
-find $OUT -name "*.csv" | head -30
-ls -la $OUT $OUT/trace 2>/dev/null | head -40
+python3 tools/summarize_profile.py $OUT $TAG $ROOT/gpurun_out/profiles_$TAG
