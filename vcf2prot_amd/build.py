@@ -71,8 +71,27 @@ def build_cohort(force: bool = False, verbose: bool = False) -> str:
     return COHORT_LIB
 
 
+HARNESS_BIN = os.path.join(LIBDIR, "v2p_harness")
+HARNESS_DEPS = [os.path.join("host", "v2p_harness.cpp"), os.path.join("host", "ppgg_gpu.hpp"),
+                os.path.join(ROOT, "include", "vcf2prot_hip.h"), os.path.join(ROOT, "include", "v2p_cohort.h")]
+
+
+def build_harness(force: bool = False, verbose: bool = False) -> str:
+    """C++ host harness (the role of the reference's exec::execute) linked against both libraries."""
+    if force or _stale(HARNESS_BIN, HARNESS_DEPS) or _stale(HARNESS_BIN, [HIP_LIB, COHORT_LIB]):
+        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-Wall", os.path.join(CSRC, "host", "v2p_harness.cpp"),
+               "-L" + LIBDIR, "-lvcf2prot_hip", "-lv2p_cohort", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib",
+               "-o", HARNESS_BIN]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HARNESS_BIN
+
+
 def build_all(force: bool = False, verbose: bool = False):
-    return build_hip(force, verbose), build_cohort(force, verbose)
+    libs = build_hip(force, verbose), build_cohort(force, verbose)
+    build_harness(force, verbose)
+    return libs
 
 
 if __name__ == "__main__":

@@ -1,0 +1,128 @@
+// ppgg_gpu.hpp -- C++ mirror of the reference's step-6 host interface, gpu arm implemented.
+//
+// The reference host is Rust (crate `ppgg`); this image has no Rust toolchain, so the host
+// side above the C ABI is written in C++ with the reference's names, argument meaning and
+// error behaviour (paths under /root/reference/src/data_structures/InternalRep):
+//   Engine, Engine::from_str      engines.rs:15-29
+//   Task                          task.rs:2-18
+//   GIR, GIR::execute(engine)     gir.rs:15-46, 197-241   (Engine::GPU arm = v2p_execute_gir)
+//   execute(probands, engine)     parts/exec.rs:23-42     (thread pool over probands, one
+//                                 engine context per worker, as Rayon workers would hold)
+// A reference panic!() is a C++ exception here (`Panic`); the Rust shim in INTEGRATION.md
+// turns the same status codes back into panic!().
+#pragma once
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "../../../include/vcf2prot_hip.h"
+
+namespace ppgg {
+
+struct Panic : std::runtime_error {
+    int code; int64_t index;
+    Panic(int c, const std::string& m, int64_t i = -1) : std::runtime_error(m), code(c), index(i) {}
+};
+
+enum class Engine { ST = V2P_ENGINE_ST, MT = V2P_ENGINE_MT, GPU = V2P_ENGINE_GPU };
+
+inline Engine engine_from_str(const std::string& name)          // engines.rs:17-29
+{
+    int e = 0;
+    if (v2p_engine_from_str(name.c_str(), &e) != V2P_OK) throw std::invalid_argument(name + " is not a supported engine");
+    return static_cast<Engine>(e);
+}
+
+struct Task {                                                    // task.rs:2-9
+    uint8_t exe_code; uint64_t start_pos, length, start_pos_res;
+    Task(uint8_t c, uint64_t s, uint64_t l, uint64_t r) : exe_code(c), start_pos(s), length(l), start_pos_res(r) {}
+};
+
+// One engine context per worker thread (the C ABI's threading contract).
+class GpuContext {
+public:
+    explicit GpuContext(int device = 0, bool debug_gpu = std::getenv("DEBUG_GPU") != nullptr)   // README.md:156-157
+    {
+        if (v2p_init(device, debug_gpu ? V2P_FLAG_DEBUG_GPU : 0u, &ctx_) != V2P_OK)
+            throw Panic(V2P_ERR_HIP, v2p_last_error(nullptr));
+    }
+    ~GpuContext() { v2p_destroy(ctx_); }
+    GpuContext(const GpuContext&) = delete;
+    GpuContext& operator=(const GpuContext&) = delete;
+    v2p_ctx* raw() const { return ctx_; }
+private:
+    v2p_ctx* ctx_ = nullptr;
+};
+
+using Annotation = std::map<std::string, std::pair<uint64_t, uint64_t>>;
+
+class GIR {                                                      // gir.rs:15-23
+public:
+    GIR(std::vector<Task> g_rep, Annotation annotation, std::u32string alt_stream, std::u32string ref_stream,
+        std::u32string res_array)
+        : g_rep_(std::move(g_rep)), annotation_(std::move(annotation)), alt_(std::move(alt_stream)),
+          ref_(std::move(ref_stream)), res_(std::move(res_array)) {}
+
+    const std::vector<Task>& get_tasks() const { return g_rep_; }
+    const Annotation& get_annotation() const { return annotation_; }
+    uint64_t get_results_max() const                              // gir.rs:156-167
+    {
+        uint64_t m = 0;
+        for (const auto& kv : annotation_) m = kv.second.second > m ? kv.second.second : m;
+        return m;
+    }
+
+    // gir.rs:197-241: consumes the representation, returns (res_array, annotation).
+    // Only the GPU arm lives here; ST/MT are the reference's own CPU code.
+    std::pair<std::u32string, Annotation> execute(Engine engine, GpuContext& ctx) &&
+    {
+        if (engine != Engine::GPU) throw std::logic_error("the st/mt engines are the reference's CPU code");
+        const size_t n = g_rep_.size();
+        std::vector<uint8_t> code(n);
+        std::vector<uint64_t> sp(n), ln(n), sr(n);
+        for (size_t i = 0; i < n; ++i) {                          // gir.rs:283-299
+            code[i] = g_rep_[i].exe_code; sp[i] = g_rep_[i].start_pos; ln[i] = g_rep_[i].length; sr[i] = g_rep_[i].start_pos_res;
+        }
+        const int rc = v2p_execute_gir(ctx.raw(), code.data(), sp.data(), ln.data(), sr.data(), n,
+                                       reinterpret_cast<const uint32_t*>(ref_.data()), ref_.size(),
+                                       reinterpret_cast<const uint32_t*>(alt_.data()), alt_.size(),
+                                       reinterpret_cast<uint32_t*>(&res_[0]), res_.size());
+        if (rc != V2P_OK) throw Panic(rc, v2p_last_error(ctx.raw()), v2p_last_error_index(ctx.raw()));
+        return {std::move(res_), std::move(annotation_)};
+    }
+
+private:
+    std::vector<Task> g_rep_;
+    Annotation annotation_;
+    std::u32string alt_, ref_, res_;
+};
+
+// parts/exec.rs:23-42 for Engine::GPU: jobs (haplotype GIRs) are pulled by a pool of workers,
+// each worker owning one engine context, the way Rayon workers would each hold one.
+template <class MakeGir, class Consume>
+void execute(uint64_t n_jobs, int n_threads, int device, MakeGir make_gir, Consume consume)
+{
+    std::atomic<uint64_t> next{0};
+    std::vector<std::thread> pool;
+    std::vector<std::string> errors(size_t(n_threads > 0 ? n_threads : 1));
+    for (int t = 0; t < (n_threads > 0 ? n_threads : 1); ++t)
+        pool.emplace_back([&, t] {
+            try {
+                GpuContext ctx(device);
+                for (uint64_t j = next++; j < n_jobs; j = next++) {
+                    auto out = make_gir(j).execute(Engine::GPU, ctx);
+                    consume(j, std::move(out.first), std::move(out.second));
+                }
+            } catch (const std::exception& e) { errors[size_t(t)] = e.what(); }
+        });
+    for (auto& th : pool) th.join();
+    for (const auto& e : errors) if (!e.empty()) throw Panic(V2P_ERR_HIP, e);
+}
+
+}  // namespace ppgg
