@@ -1,2 +1,6 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-for t in 1 4 16; do vcf2prot_amd/lib/v2p_harness run C2 64 $t | cut -c1-260; done
+run() { python bench.py --no-cpu-baseline --steps 10 "$@" 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); r=j['roofline']; print('$*','ms',round(r['kernel_ms_avg'],3),'min',round(r['kernel_ms_min'],3))"; }
+run
+run --dbg 3
+run --dbg 4
+run --dbg 1
+run

@@ -193,7 +193,12 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
                 // the address path (TA) is the busiest unit of this kernel: lanes that do not need a
                 // second/third task stay masked off instead of gathering from a dummy address
                 u32x4 v, g1 = {0u, 0u, 0u, 0u}, g2 = {0u, 0u, 0u, 0u};
-                if (DBG != 1) {
+                if (DBG == 3 || DBG == 4) {            // timing only: 16-byte (3) / 4-byte (4) aligned gathers
+                    const uint64_t am = DBG == 3 ? ~15ull : ~3ull;
+                    v = gather16((a0 + int64_t(rel)) & am);
+                    if (need1) g1 = gather16((a1 + int64_t(rel)) & am);
+                    if (need2) g2 = gather16((a2 + int64_t(rel)) & am);
+                } else if (DBG != 1) {
                     v = gather16(a0 + int64_t(rel));
                     if (need1) g1 = gather16(a1 + int64_t(rel));
                     if (need2) g2 = gather16(a2 + int64_t(rel));
@@ -393,6 +398,8 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     const uint32_t dyn = 0;
     if (dbg == 1) hipLaunchKernelGGL((stitch_kernel<true, 1>), dim3(grid), dim3(256), dyn, stream, a);
     else if (dbg == 2) hipLaunchKernelGGL((stitch_kernel<true, 2>), dim3(grid), dim3(256), dyn, stream, a);
+    else if (dbg == 3) hipLaunchKernelGGL((stitch_kernel<true, 3>), dim3(grid), dim3(256), dyn, stream, a);
+    else if (dbg == 4) hipLaunchKernelGGL((stitch_kernel<true, 4>), dim3(grid), dim3(256), dyn, stream, a);
     else if (nt) hipLaunchKernelGGL((stitch_kernel<true, 0>), dim3(grid), dim3(256), dyn, stream, a);
     else hipLaunchKernelGGL((stitch_kernel<false, 0>), dim3(grid), dim3(256), dyn, stream, a);
     return hipGetLastError();
