@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--temporal", action="store_true", help="plain result stores instead of non-temporal")
     ap.add_argument("--max-blocks", type=int, default=0)
+    ap.add_argument("--fasta", action="store_true", help="FASTA-emitting image: headers and line feeds fused into the scatter (SURVEY 8f rank 1)")
     ap.add_argument("--chunk-tasks", type=int, default=0)
     ap.add_argument("--chunk-bytes", type=int, default=0)
     ap.add_argument("--dbg", type=int, default=0, help="timing-only kernel ablation (results are wrong; implies --no-verify)")
@@ -111,11 +112,15 @@ def main():
     h0, h1 = 2 * samples * rank, 2 * samples * (rank + 1)
     n_threads = max(1, (os.cpu_count() or 1) // world)
     t_gen = time.perf_counter()
-    img = cohort.pack(h0, h1, n_threads=min(n_threads, 64), chunk_tasks=args.chunk_tasks, chunk_bytes=args.chunk_bytes)
+    img = cohort.pack(h0, h1, n_threads=min(n_threads, 64), chunk_tasks=args.chunk_tasks, chunk_bytes=args.chunk_bytes, fasta=args.fasta)
     t_gen = time.perf_counter() - t_gen
     A, NT = img.n_copy_bytes, img.n_tasks
     b_alg = 2 * A + 16 * NT
     proteome = cohort.proteome()
+    n_proteome = proteome.size
+    if args.fasta:                                             # resident reference = proteome + record headers
+        proteome = np.concatenate([proteome, cohort.fasta_headers()])
+        args.no_verify = True                                  # digests are defined on the plain result tape
 
     def padded(arr):                                           # 16 readable bytes either side (16-byte gathers)
         t = torch.zeros(arr.size + 32, dtype=torch.uint8, device=dev)
@@ -127,7 +132,7 @@ def main():
     d_desc = torch.from_numpy(img.desc.view(np.int64)).to(dev)
     img.chunks = np.ascontiguousarray(img.chunks)
     if args.xcd_order != 0:           # XCD-aware launch order (speed only; chunks are independent)
-        rc = lib.v2p_order_chunks_for_xcds(img.chunks.ctypes.data, img.chunks.shape[0], img.desc.ctypes.data, img.desc.size, proteome.size)
+        rc = lib.v2p_order_chunks_for_xcds(img.chunks.ctypes.data, img.chunks.shape[0], img.desc.ctypes.data, img.desc.size, n_proteome)
         assert rc == 0
     d_chunks = torch.from_numpy(np.ascontiguousarray(img.chunks).view(np.int64)).to(dev)
     d_hap = torch.from_numpy(img.hap_out_begin.view(np.int64)).to(dev)

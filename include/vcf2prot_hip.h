@@ -105,6 +105,9 @@ int v2p_validate_gir(v2p_ctx* ctx,
 /* Upload the reference proteome once (1 byte per residue, transcripts back to back).
  * Batches built with v2p_batch_add_haplotype() read reference residues from it. */
 int v2p_upload_proteome(v2p_ctx* ctx, const uint8_t* aa, uint64_t n);
+/* Same, plus a resident table of FASTA record headers (">NAME_1\n" ... each ending in '\n') stored
+ * behind the proteome; needed by v2p_batch_add_haplotype_fasta(). */
+int v2p_upload_reference(v2p_ctx* ctx, const uint8_t* aa, uint64_t n, const uint8_t* record_headers, uint64_t n_headers);
 
 /* ---- batched native mode: many haplotypes per launch -------------------------- */
 int  v2p_batch_create(v2p_ctx* ctx, v2p_batch** out);
@@ -128,6 +131,19 @@ int v2p_batch_add_haplotype(v2p_batch* b,
                             const uint64_t* seg_ref_begin, const uint64_t* seg_proteome_off, uint64_t n_seg,
                             const uint8_t* alt, uint64_t n_alt,
                             uint64_t n_res);
+
+/* FASTA emit fused into the scatter (replaces personalized_genome.rs:66-67,90-113 +
+ * sequence_tape.rs:77-89 on the host): like v2p_batch_add_haplotype(), but the haplotype's arena
+ * range holds file-ready bytes -- for every record i, in order, header bytes, the residues of
+ * result range [rec_res_end[i-1], rec_res_end[i]), '\n'.  Records must tile the result tape;
+ * rec_header_off/len address the resident header table of v2p_upload_reference(). */
+int v2p_batch_add_haplotype_fasta(v2p_batch* b,
+                                  const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
+                                  const uint64_t* start_pos_res, uint64_t n_tasks,
+                                  const uint64_t* seg_ref_begin, const uint64_t* seg_proteome_off, uint64_t n_seg,
+                                  const uint8_t* alt, uint64_t n_alt, uint64_t n_res,
+                                  const uint64_t* rec_res_end, const uint64_t* rec_header_off, const uint32_t* rec_header_len,
+                                  uint64_t n_rec);
 
 /* Adopt an already packed image (descriptors, chunks, payload, haplotype result ranges),
  * e.g. from the synthetic cohort generator (include/v2p_cohort.h). */

@@ -150,11 +150,21 @@ class Cohort:
                 out.append((int(t), kind, aa))
         return out
 
-    def pack(self, h0: int, h1: int, n_threads: int = 0, chunk_tasks: int = 0, chunk_bytes: int = 0) -> Packed:
+    HEADER_BYTES = 19
+
+    def fasta_headers(self) -> np.ndarray:
+        """Resident header table for FASTA emit: '>ENST%011d_h\\n' at (2*t + parity) * 19."""
+        need = int(self._lib.v2p_cohort_fasta_headers(self._h, None, 0))
+        out = np.empty(need, dtype=np.uint8)
+        self._lib.v2p_cohort_fasta_headers(self._h, out.ctypes.data, need)
+        return out
+
+    def pack(self, h0: int, h1: int, n_threads: int = 0, chunk_tasks: int = 0, chunk_bytes: int = 0,
+             fasta: bool = False) -> Packed:
         import os
         img = PackedImage()
         nt = n_threads or min(32, os.cpu_count() or 1)
-        rc = self._lib.v2p_cohort_pack(self._h, h0, h1, nt, chunk_tasks, chunk_bytes, ctypes.byref(img))
+        rc = self._lib.v2p_cohort_pack(self._h, h0, h1, nt, chunk_tasks, chunk_bytes, 1 if fasta else 0, ctypes.byref(img))
         if rc != 0:
             raise RuntimeError(f"v2p_cohort_pack failed ({rc})")
         try:

@@ -294,24 +294,36 @@ void fill_view(const v2p_hapbuf& b, v2p_hap_view* v)
     v->n_tx = b.tx_id.size(); v->tx_id = b.tx_id.data(); v->tx_res_begin = b.tx_res_begin.data(); v->tx_res_end = b.tx_res_end.data();
 }
 
-// appends one generated haplotype to a device image (resident-proteome form)
-int pack_hap(const v2p_hapbuf& b, v2p::ImageBuilder& img)
+constexpr uint32_t HEADER_BYTES = 19;     // ">ENST%011u_h\n"
+
+// appends one generated haplotype to a device image (resident-proteome form); with `fasta`
+// the haplotype's arena range is file-ready: header, residues, line feed per record
+int pack_hap(const v2p_cohort& c, uint64_t hap, const v2p_hapbuf& b, v2p::ImageBuilder& img, bool fasta)
 {
     v2p::RefSegments segs{b.seg_ref_begin.data(), b.seg_proteome_off.data(), b.seg_proteome_off.size()};
     const uint64_t n_res = b.tx_res_end.empty() ? 0 : b.tx_res_end.back();
     const uint64_t off_alt = img.payload_alloc(b.alt.size());
     if (!b.alt.empty()) memcpy(&img.payload[off_alt], b.alt.data(), b.alt.size());
-    for (size_t i = 0; i < b.code.size(); ++i) {
-        int rc;
+    auto emit_task = [&](uint64_t i) -> int {
         if (b.code[i] == 0) {
             uint64_t src = 0;
             if (b.length[i] && !segs.map(b.start_pos[i], b.length[i], &src)) return v2p::PACK_SRC_OOB;
-            rc = img.add_task(v2p::SPACE_PROTEOME, src, b.length[i], b.start_pos_res[i], n_res);
-        } else {
-            rc = img.add_task(v2p::SPACE_PAYLOAD, off_alt + b.start_pos[i], b.length[i], b.start_pos_res[i], n_res);
+            return img.add_task(v2p::SPACE_PROTEOME, src, b.length[i], b.start_pos_res[i], n_res);
         }
-        if (rc != v2p::PACK_OK) return rc;
+        return img.add_task(v2p::SPACE_PAYLOAD, off_alt + b.start_pos[i], b.length[i], b.start_pos_res[i], n_res);
+    };
+    int rc = v2p::PACK_OK;
+    if (fasta) {
+        std::vector<uint64_t> hdr_src(b.tx_id.size());
+        std::vector<uint32_t> hdr_len(b.tx_id.size(), HEADER_BYTES);
+        for (size_t r = 0; r < b.tx_id.size(); ++r)            // header table sits behind the proteome
+            hdr_src[r] = c.proteome.size() + (2ull * b.tx_id[r] + (hap & 1ull)) * HEADER_BYTES;
+        rc = v2p::interleave_fasta(img, b.start_pos_res.data(), b.length.data(), b.code.size(), b.tx_res_end.data(),
+                                   hdr_src.data(), hdr_len.data(), b.tx_id.size(), v2p::SPACE_PROTEOME, emit_task);
+    } else {
+        for (size_t i = 0; i < b.code.size() && rc == v2p::PACK_OK; ++i) rc = emit_task(i);
     }
+    if (rc != v2p::PACK_OK) return rc;
     img.end_haplotype(n_res);
     return v2p::PACK_OK;
 }
@@ -429,8 +441,9 @@ int64_t v2p_cohort_describe(const v2p_cohort* c, uint64_t hap, char* buf, uint64
 }
 
 int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads,
-                    uint32_t chunk_tasks, uint32_t chunk_bytes, v2p_packed_image* out)
+                    uint32_t chunk_tasks, uint32_t chunk_bytes, uint32_t flags, v2p_packed_image* out)
 {
+    const bool fasta = (flags & V2P_PACK_FASTA) != 0;
     if (!c || !out || h1 < h0) return -1;
     memset(out, 0, sizeof *out);
     const uint64_t n = h1 - h0;
@@ -447,7 +460,7 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
         v2p_hapbuf b;
         for (uint64_t h = a; h < e; ++h) {
             generate_into(*c, h, b, false, nullptr);
-            const int rc = pack_hap(b, parts[size_t(w)]);
+            const int rc = pack_hap(*c, h, b, parts[size_t(w)], fasta);
             if (rc) { status[size_t(w)] = rc; return; }
         }
         parts[size_t(w)].finish();
@@ -498,6 +511,20 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
     out->hap_out_begin[n] = oo;
     out->n_desc = nd; out->n_chunks = nc; out->n_payload = np; out->n_haps = n;
     return 0;
+}
+
+uint64_t v2p_cohort_fasta_headers(const v2p_cohort* c, uint8_t* out, uint64_t cap)
+{
+    if (!c) return 0;
+    const uint64_t need = 2ull * c->p.n_transcripts * HEADER_BYTES;
+    if (!out || cap < need) return need;
+    for (uint32_t t = 0; t < c->p.n_transcripts; ++t)
+        for (int h = 0; h < 2; ++h) {
+            char buf[32];
+            snprintf(buf, sizeof buf, ">ENST%011u_%d\n", t, h + 1);          // personalized_genome.rs:92,97
+            memcpy(out + (2ull * t + h) * HEADER_BYTES, buf, HEADER_BYTES);
+        }
+    return need;
 }
 
 void v2p_packed_free(v2p_packed_image* img)

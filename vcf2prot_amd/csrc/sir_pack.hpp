@@ -99,9 +99,16 @@ public:
     }
     void end_haplotype(uint64_t n_res) {
         if (cursor_ < n_res) emit(SPACE_FILL, 0, n_res - cursor_);
-        hap_out_begin.push_back(hap_out_begin.back() + n_res);
+        hap_out_begin.push_back(hap_out_begin.back() + n_res + extra_);
         cursor_ = 0;
+        extra_ = 0;
     }
+    // FASTA emit (personalized_genome.rs:90-113 fused into the scatter): bytes that are not
+    // part of the result tape -- record headers and line feeds -- are ordinary descriptors
+    // placed between the tasks; they advance the arena but not the tape cursor.
+    void add_literal(unsigned space, uint64_t src, uint32_t len) { emit(space, src, len); extra_ += len; }
+    // '.'-fill the result tape up to `dst` (cells no task covers before a record ends)
+    void fill_to(uint64_t dst) { if (dst > cursor_) { emit(SPACE_FILL, 0, dst - cursor_); cursor_ = dst; } }
     // Close the open chunk; call once after the last haplotype.
     void finish() { close_chunk(); }
 
@@ -118,6 +125,7 @@ public:
 
 private:
     uint64_t cursor_ = 0;            // next uncovered cell of the current haplotype
+    uint64_t extra_ = 0;             // literal bytes (FASTA headers, line feeds) added to the current haplotype
     uint64_t arena_cursor_ = 0;      // result offset of the next descriptor
     uint64_t open_begin_ = 0, open_dst_ = 0;
     uint32_t open_n_ = 0, open_bytes_ = 0;
@@ -177,8 +185,8 @@ inline void order_chunks_for_xcds(Chunk* chunks, uint64_t n_chunks, const uint64
         const uint64_t tb = chunks[c].task_begin;
         const uint32_t n = uint32_t(chunks[c].dst_n >> 48);
         uint64_t key = 0;
-        for (uint32_t k = 0; k < n && k < 4 && tb + k < n_desc; ++k)
-            if (desc_space(desc[tb + k]) == SPACE_PROTEOME) { key = desc_src(desc[tb + k]); break; }
+        for (uint32_t k = 0; k < n && k < 6 && tb + k < n_desc; ++k)       // skip FASTA literals stored behind the proteome
+            if (desc_space(desc[tb + k]) == SPACE_PROTEOME && desc_src(desc[tb + k]) < proteome_len) { key = desc_src(desc[tb + k]); break; }
         uint64_t b = key / ((proteome_len + n_xcd - 1) / n_xcd);
         bucket[c] = uint32_t(b < n_xcd ? b : n_xcd - 1);
         ++count[bucket[c]];
@@ -198,6 +206,32 @@ inline void order_chunks_for_xcds(Chunk* chunks, uint64_t n_chunks, const uint64
             if (r < count[x]) out[pos++] = chunks[idx[x][r]];
     for (uint64_t c = 0; c < n_chunks; ++c) chunks[c] = out[c];
     (void)start; (void)seen;
+}
+
+// Interleaves one haplotype's tasks with FASTA record literals.  Records tile the result tape
+// in ascending order (annotation of haplotype_instruction.rs:120-125); record i covers
+// [rec_res_end[i-1], rec_res_end[i]) and is written as header bytes, its tasks, '\n'.
+// emit_task(i) must call ImageBuilder::add_task for task i.  Returns PACK_OK or PACK_RES_OOB
+// when a task straddles a record boundary.
+template <class EmitTask>
+int interleave_fasta(ImageBuilder& img, const uint64_t* start_pos_res, const uint64_t* length, uint64_t n_tasks,
+                     const uint64_t* rec_res_end, const uint64_t* rec_header_src, const uint32_t* rec_header_len,
+                     uint64_t n_rec, unsigned header_space, EmitTask&& emit_task)
+{
+    uint64_t i = 0;
+    for (uint64_t r = 0; r < n_rec; ++r) {
+        const uint64_t end = rec_res_end[r];
+        img.add_literal(header_space, rec_header_src[r], rec_header_len[r]);
+        while (i < n_tasks && (start_pos_res[i] < end || (length[i] == 0 && start_pos_res[i] == end && r + 1 == n_rec))) {
+            if (start_pos_res[i] + length[i] > end) return PACK_RES_OOB;
+            const int rc = emit_task(i);
+            if (rc != PACK_OK) return rc;
+            ++i;
+        }
+        img.fill_to(end);
+        img.add_literal(header_space, rec_header_src[r] + rec_header_len[r] - 1, 1);   // the header's own line feed
+    }
+    return i == n_tasks ? PACK_OK : PACK_RES_OOB;
 }
 
 // Maps an offset inside a haplotype's private ref_stream (the concatenation of its

@@ -97,7 +97,8 @@ struct v2p_ctx {
     mutable std::mutex mu;
     std::string err;
     int64_t err_index = -1;
-    DevBuf proteome; uint64_t proteome_len = 0;
+    DevBuf proteome; uint64_t proteome_len = 0;      // resident reference: [proteome | FASTA record headers]
+    uint64_t headers_len = 0;
     // GIR-mode scratch (grow-only)
     DevBuf d_ref, d_alt, d_res, d_desc, d_chunks, d_soa, d_status;
     PinnedBuf h_stage;
@@ -188,18 +189,22 @@ int v2p_set_stream(v2p_ctx* c, void* hip_stream)
     return V2P_OK;
 }
 
-int v2p_upload_proteome(v2p_ctx* c, const uint8_t* aa, uint64_t n)
+int v2p_upload_reference(v2p_ctx* c, const uint8_t* aa, uint64_t n, const uint8_t* headers, uint64_t n_headers)
 {
-    if (!c || (!aa && n)) return V2P_ERR_INVALID_ARG;
+    if (!c || (!aa && n) || (!headers && n_headers)) return V2P_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
-    HIP_TRY(c, c->proteome.ensure(n), "hipMalloc(proteome)");
-    HIP_TRY(c, hipMemsetAsync(c->proteome.base, 0, c->proteome.cap, c->stream), "hipMemset(proteome)");
+    HIP_TRY(c, c->proteome.ensure(n + n_headers), "hipMalloc(reference)");
+    HIP_TRY(c, hipMemsetAsync(c->proteome.base, 0, c->proteome.cap, c->stream), "hipMemset(reference)");
     if (n) HIP_TRY(c, hipMemcpyAsync(c->proteome.ptr(), aa, n, hipMemcpyHostToDevice, c->stream), "H2D(proteome)");
+    if (n_headers) HIP_TRY(c, hipMemcpyAsync(c->proteome.ptr() + n, headers, n_headers, hipMemcpyHostToDevice, c->stream), "H2D(headers)");
     HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
     c->proteome_len = n;
+    c->headers_len = n_headers;
     return V2P_OK;
 }
+
+int v2p_upload_proteome(v2p_ctx* c, const uint8_t* aa, uint64_t n) { return v2p_upload_reference(c, aa, n, nullptr, 0); }
 
 // reads the device status word after a sync; returns V2P_OK or the mapped task error
 static int collect_status(v2p_ctx* c, DevBuf& d_status)
@@ -420,18 +425,20 @@ int v2p_batch_add_gir(v2p_batch* b,
     return V2P_OK;
 }
 
-int v2p_batch_add_haplotype(v2p_batch* b,
-                            const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
-                            const uint64_t* start_pos_res, uint64_t n_tasks,
-                            const uint64_t* seg_ref_begin, const uint64_t* seg_proteome_off, uint64_t n_seg,
-                            const uint8_t* alt, uint64_t n_alt,
-                            uint64_t n_res)
+static int add_haplotype_impl(v2p_batch* b,
+                              const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
+                              const uint64_t* start_pos_res, uint64_t n_tasks,
+                              const uint64_t* seg_ref_begin, const uint64_t* seg_proteome_off, uint64_t n_seg,
+                              const uint8_t* alt, uint64_t n_alt, uint64_t n_res,
+                              const uint64_t* rec_res_end, const uint64_t* rec_header_off, const uint32_t* rec_header_len, uint64_t n_rec,
+                              bool fasta)
 {
     if (!b) return V2P_ERR_INVALID_ARG;
     v2p_ctx* c = b->ctx;
     std::lock_guard<std::mutex> lk(c->mu);
     if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
-    if ((n_tasks && (!code || !start_pos || !length || !start_pos_res)) || (n_seg && (!seg_ref_begin || !seg_proteome_off)) || (n_alt && !alt))
+    if ((n_tasks && (!code || !start_pos || !length || !start_pos_res)) || (n_seg && (!seg_ref_begin || !seg_proteome_off)) || (n_alt && !alt)
+        || (fasta && n_rec && (!rec_res_end || !rec_header_off || !rec_header_len)))
         return c->fail(V2P_ERR_INVALID_ARG, "null argument");
     const uint64_t n_ref = n_seg ? seg_ref_begin[n_seg] : 0;
     int rc = precheck(c, code, start_pos, length, start_pos_res, n_tasks, n_ref, n_alt, n_res);
@@ -447,15 +454,60 @@ int v2p_batch_add_haplotype(v2p_batch* b,
         if (mapped[i] + length[i] > c->proteome_len)
             return c->fail(V2P_ERR_SRC_OOB, "reference task beyond the resident proteome at row " + std::to_string(i), int64_t(i));
     }
+    std::vector<uint64_t> hdr_src;
+    if (fasta) {
+        uint64_t prev = 0, ti = 0;
+        hdr_src.resize(n_rec);
+        for (uint64_t r = 0; r < n_rec; ++r) {                  // records must tile the result tape, headers must be resident
+            if (rec_res_end[r] < prev || rec_res_end[r] > n_res) return c->fail(V2P_ERR_INVALID_ARG, "records are not ascending inside the result tape", int64_t(r));
+            if (rec_header_len[r] == 0 || rec_header_off[r] + rec_header_len[r] > c->headers_len)
+                return c->fail(V2P_ERR_SRC_OOB, "record header outside the resident header table", int64_t(r));
+            while (ti < n_tasks && start_pos_res[ti] < rec_res_end[r]) {
+                if (start_pos_res[ti] + length[ti] > rec_res_end[r]) return c->fail(V2P_ERR_INVALID_ARG, "task straddles a record boundary", int64_t(ti));
+                ++ti;
+            }
+            prev = rec_res_end[r];
+            hdr_src[r] = c->proteome_len + rec_header_off[r];
+        }
+        if ((n_rec ? rec_res_end[n_rec - 1] : 0) != n_res) return c->fail(V2P_ERR_INVALID_ARG, "records do not cover the result tape");
+    }
     const uint64_t off_alt = b->img.payload_alloc(n_alt);
     if (n_alt) memcpy(&b->img.payload[off_alt], alt, n_alt);
-    for (uint64_t i = 0; i < n_tasks; ++i) {
-        if (code[i] == 0) (void)b->img.add_task(SPACE_PROTEOME, mapped[i], length[i], start_pos_res[i], n_res);
-        else              (void)b->img.add_task(SPACE_PAYLOAD, off_alt + start_pos[i], length[i], start_pos_res[i], n_res);
+    auto emit_task = [&](uint64_t i) {
+        return code[i] == 0 ? b->img.add_task(SPACE_PROTEOME, mapped[i], length[i], start_pos_res[i], n_res)
+                            : b->img.add_task(SPACE_PAYLOAD, off_alt + start_pos[i], length[i], start_pos_res[i], n_res);
+    };
+    if (fasta) {
+        (void)interleave_fasta(b->img, start_pos_res, length, n_tasks, rec_res_end, hdr_src.data(), rec_header_len, n_rec, SPACE_PROTEOME, emit_task);
+    } else {
+        for (uint64_t i = 0; i < n_tasks; ++i) (void)emit_task(i);
     }
     b->img.end_haplotype(n_res);
     b->uses_proteome = true;
     return V2P_OK;
+}
+
+int v2p_batch_add_haplotype(v2p_batch* b,
+                            const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
+                            const uint64_t* start_pos_res, uint64_t n_tasks,
+                            const uint64_t* seg_ref_begin, const uint64_t* seg_proteome_off, uint64_t n_seg,
+                            const uint8_t* alt, uint64_t n_alt,
+                            uint64_t n_res)
+{
+    return add_haplotype_impl(b, code, start_pos, length, start_pos_res, n_tasks, seg_ref_begin, seg_proteome_off, n_seg,
+                              alt, n_alt, n_res, nullptr, nullptr, nullptr, 0, false);
+}
+
+int v2p_batch_add_haplotype_fasta(v2p_batch* b,
+                                  const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
+                                  const uint64_t* start_pos_res, uint64_t n_tasks,
+                                  const uint64_t* seg_ref_begin, const uint64_t* seg_proteome_off, uint64_t n_seg,
+                                  const uint8_t* alt, uint64_t n_alt, uint64_t n_res,
+                                  const uint64_t* rec_res_end, const uint64_t* rec_header_off, const uint32_t* rec_header_len,
+                                  uint64_t n_rec)
+{
+    return add_haplotype_impl(b, code, start_pos, length, start_pos_res, n_tasks, seg_ref_begin, seg_proteome_off, n_seg,
+                              alt, n_alt, n_res, rec_res_end, rec_header_off, rec_header_len, n_rec, true);
 }
 
 int v2p_batch_set_packed(v2p_batch* b,
@@ -522,7 +574,7 @@ int v2p_batch_execute(v2p_batch* b)
     if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     StitchArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), reinterpret_cast<const Chunk*>(b->d_chunks.ptr()),
-                 uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len, b->d_payload.ptr(), b->n_payload,
+                 uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->d_payload.ptr(), b->n_payload,
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
     HIP_TRY(c, launch_stitch(a, c->stream, !(c->flags & V2P_FLAG_TEMPORAL), 0), "launch(stitch)");
     return V2P_OK;

@@ -107,6 +107,12 @@ class Context:
         aa = np.ascontiguousarray(aa, dtype=np.uint8)
         self._check(self._lib.v2p_upload_proteome(self._h, _p(aa), aa.size))
 
+    def upload_reference(self, aa: np.ndarray, record_headers: np.ndarray):
+        """Proteome + resident FASTA record headers (for Batch.add_haplotype_fasta)."""
+        aa = np.ascontiguousarray(aa, dtype=np.uint8)
+        hd = np.ascontiguousarray(record_headers, dtype=np.uint8)
+        self._check(self._lib.v2p_upload_reference(self._h, _p(aa), aa.size, _p(hd), hd.size))
+
     # -- GIR-faithful mode --------------------------------------------------
     def execute_gir(self, code, start_pos, length, start_pos_res, ref: np.ndarray, alt: np.ndarray,
                     res: np.ndarray) -> np.ndarray:
@@ -180,6 +186,23 @@ class Batch:
         alt = np.ascontiguousarray(alt, dtype=np.uint8)
         self.ctx._check(self._lib.v2p_batch_add_haplotype(self._h, _p(code), _p(sp), _p(ln), _p(sr), code.size,
                                                           _p(sb), _p(so), so.size, _p(alt), alt.size, n_res))
+
+    def add_haplotype_fasta(self, code, start_pos, length, start_pos_res, seg_ref_begin, seg_proteome_off,
+                            alt: np.ndarray, n_res: int, rec_res_end, rec_header_off, rec_header_len):
+        """FASTA emit: the haplotype's arena range becomes header / residues / line feed per record."""
+        code = np.ascontiguousarray(code, dtype=np.uint8)
+        sp = np.ascontiguousarray(start_pos, dtype=np.uint64)
+        ln = np.ascontiguousarray(length, dtype=np.uint64)
+        sr = np.ascontiguousarray(start_pos_res, dtype=np.uint64)
+        sb = np.ascontiguousarray(seg_ref_begin, dtype=np.uint64)
+        so = np.ascontiguousarray(seg_proteome_off, dtype=np.uint64)
+        alt = np.ascontiguousarray(alt, dtype=np.uint8)
+        re_ = np.ascontiguousarray(rec_res_end, dtype=np.uint64)
+        ho = np.ascontiguousarray(rec_header_off, dtype=np.uint64)
+        hl = np.ascontiguousarray(rec_header_len, dtype=np.uint32)
+        self.ctx._check(self._lib.v2p_batch_add_haplotype_fasta(
+            self._h, _p(code), _p(sp), _p(ln), _p(sr), code.size, _p(sb), _p(so), so.size, _p(alt), alt.size, n_res,
+            _p(re_), _p(ho), _p(hl), re_.size))
 
     def set_packed(self, desc: np.ndarray, chunks: np.ndarray, payload: np.ndarray, hap_out_begin: np.ndarray):
         desc = np.ascontiguousarray(desc, dtype=np.uint64)
