@@ -101,8 +101,8 @@ int64_t v2p_cohort_describe(const v2p_cohort* c, uint64_t hap, char* buf, uint64
 #define V2P_PACK_FASTA 1u   /* file-ready arena: ">ENST..._h\n" + residues + "\n" per record (needs the header table resident) */
 int  v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads,
                      uint32_t chunk_tasks, uint32_t chunk_bytes, uint32_t flags, v2p_packed_image* out);
-/* FASTA record headers of every transcript and haplotype parity, 19 bytes each, header of
- * (transcript t, parity p) at (2*t + p) * 19.  Returns the bytes needed; fills `out` when cap suffices. */
+/* FASTA record headers of every transcript and haplotype parity: one leading '\n', then 19 bytes each;
+ * header of (transcript t, parity p) at 1 + (2*t + p) * 19.  Returns the bytes needed; fills `out` when cap suffices. */
 uint64_t v2p_cohort_fasta_headers(const v2p_cohort* c, uint8_t* out, uint64_t cap);
 void v2p_packed_free(v2p_packed_image* img);
 

@@ -136,7 +136,9 @@ int v2p_batch_add_haplotype(v2p_batch* b,
  * sequence_tape.rs:77-89 on the host): like v2p_batch_add_haplotype(), but the haplotype's arena
  * range holds file-ready bytes -- for every record i, in order, header bytes, the residues of
  * result range [rec_res_end[i-1], rec_res_end[i]), '\n'.  Records must tile the result tape;
- * rec_header_off/len address the resident header table of v2p_upload_reference(). */
+ * rec_header_off/len address the resident header table of v2p_upload_reference(); every header
+ * ends in '\n', and when the byte in front of each header is '\n' too (headers stored back to back
+ * behind one leading line feed) the closing line feed and the next header are emitted as one descriptor. */
 int v2p_batch_add_haplotype_fasta(v2p_batch* b,
                                   const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
                                   const uint64_t* start_pos_res, uint64_t n_tasks,

@@ -65,7 +65,7 @@ def test_fasta_emit_on_gpu_matches_reference_files(c1, gpu_ctx):
     b = gpu_ctx.batch()
     for h in range(cohort.n_haplotypes):
         hap = cohort.haplotype(h)
-        hdr_off = (2 * hap.tx_id.astype(np.uint64) + np.uint64(h & 1)) * np.uint64(cohort.HEADER_BYTES)
+        hdr_off = np.uint64(1) + (2 * hap.tx_id.astype(np.uint64) + np.uint64(h & 1)) * np.uint64(cohort.HEADER_BYTES)
         b.add_haplotype_fasta(hap.code, hap.start_pos, hap.length, hap.start_pos_res, hap.seg_ref_begin, hap.seg_proteome_off,
                               hap.alt, hap.n_res, hap.tx_res_end, hdr_off, np.full(hap.tx_id.size, cohort.HEADER_BYTES, np.uint32))
     b.finalize()

@@ -153,7 +153,7 @@ class Cohort:
     HEADER_BYTES = 19
 
     def fasta_headers(self) -> np.ndarray:
-        """Resident header table for FASTA emit: '>ENST%011d_h\\n' at (2*t + parity) * 19."""
+        """Resident header table for FASTA emit: a leading line feed, then '>ENST%011d_h\\n' at 1 + (2*t + parity) * 19."""
         need = int(self._lib.v2p_cohort_fasta_headers(self._h, None, 0))
         out = np.empty(need, dtype=np.uint8)
         self._lib.v2p_cohort_fasta_headers(self._h, out.ctypes.data, need)

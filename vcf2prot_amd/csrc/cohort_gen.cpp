@@ -317,9 +317,9 @@ int pack_hap(const v2p_cohort& c, uint64_t hap, const v2p_hapbuf& b, v2p::ImageB
         std::vector<uint64_t> hdr_src(b.tx_id.size());
         std::vector<uint32_t> hdr_len(b.tx_id.size(), HEADER_BYTES);
         for (size_t r = 0; r < b.tx_id.size(); ++r)            // header table sits behind the proteome
-            hdr_src[r] = c.proteome.size() + (2ull * b.tx_id[r] + (hap & 1ull)) * HEADER_BYTES;
+            hdr_src[r] = c.proteome.size() + 1 + (2ull * b.tx_id[r] + (hap & 1ull)) * HEADER_BYTES;   // table starts with a line feed
         rc = v2p::interleave_fasta(img, b.start_pos_res.data(), b.length.data(), b.code.size(), b.tx_res_end.data(),
-                                   hdr_src.data(), hdr_len.data(), b.tx_id.size(), v2p::SPACE_PROTEOME, emit_task);
+                                   hdr_src.data(), hdr_len.data(), b.tx_id.size(), v2p::SPACE_PROTEOME, true, emit_task);
     } else {
         for (size_t i = 0; i < b.code.size() && rc == v2p::PACK_OK; ++i) rc = emit_task(i);
     }
@@ -516,8 +516,9 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
 uint64_t v2p_cohort_fasta_headers(const v2p_cohort* c, uint8_t* out, uint64_t cap)
 {
     if (!c) return 0;
-    const uint64_t need = 2ull * c->p.n_transcripts * HEADER_BYTES;
+    const uint64_t need = 1 + 2ull * c->p.n_transcripts * HEADER_BYTES;
     if (!out || cap < need) return need;
+    *out++ = '\n';                                  // every header is preceded by a line feed (see interleave_fasta)
     for (uint32_t t = 0; t < c->p.n_transcripts; ++t)
         for (int h = 0; h < 2; ++h) {
             char buf[32];

@@ -216,12 +216,15 @@ inline void order_chunks_for_xcds(Chunk* chunks, uint64_t n_chunks, const uint64
 template <class EmitTask>
 int interleave_fasta(ImageBuilder& img, const uint64_t* start_pos_res, const uint64_t* length, uint64_t n_tasks,
                      const uint64_t* rec_res_end, const uint64_t* rec_header_src, const uint32_t* rec_header_len,
-                     uint64_t n_rec, unsigned header_space, EmitTask&& emit_task)
+                     uint64_t n_rec, unsigned header_space, bool lf_precedes_headers, EmitTask&& emit_task)
 {
+    // lf_precedes_headers: the byte in front of every header in its table is '\n', so the line feed
+    // that closes record r-1 and the header of record r are ONE literal (one descriptor less per record)
     uint64_t i = 0;
     for (uint64_t r = 0; r < n_rec; ++r) {
         const uint64_t end = rec_res_end[r];
-        img.add_literal(header_space, rec_header_src[r], rec_header_len[r]);
+        if (r == 0 || !lf_precedes_headers) img.add_literal(header_space, rec_header_src[r], rec_header_len[r]);
+        else img.add_literal(header_space, rec_header_src[r] - 1, rec_header_len[r] + 1);
         while (i < n_tasks && (start_pos_res[i] < end || (length[i] == 0 && start_pos_res[i] == end && r + 1 == n_rec))) {
             if (start_pos_res[i] + length[i] > end) return PACK_RES_OOB;
             const int rc = emit_task(i);
@@ -229,7 +232,8 @@ int interleave_fasta(ImageBuilder& img, const uint64_t* start_pos_res, const uin
             ++i;
         }
         img.fill_to(end);
-        img.add_literal(header_space, rec_header_src[r] + rec_header_len[r] - 1, 1);   // the header's own line feed
+        if (r + 1 == n_rec || !lf_precedes_headers)
+            img.add_literal(header_space, rec_header_src[r] + rec_header_len[r] - 1, 1);   // the header's own line feed
     }
     return i == n_tasks ? PACK_OK : PACK_RES_OOB;
 }

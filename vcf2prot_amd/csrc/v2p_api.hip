@@ -99,6 +99,7 @@ struct v2p_ctx {
     int64_t err_index = -1;
     DevBuf proteome; uint64_t proteome_len = 0;      // resident reference: [proteome | FASTA record headers]
     uint64_t headers_len = 0;
+    std::vector<uint8_t> headers_host;               // host copy of the header table (a few MB at most)
     // GIR-mode scratch (grow-only)
     DevBuf d_ref, d_alt, d_res, d_desc, d_chunks, d_soa, d_status;
     PinnedBuf h_stage;
@@ -201,6 +202,7 @@ int v2p_upload_reference(v2p_ctx* c, const uint8_t* aa, uint64_t n, const uint8_
     HIP_TRY(c, hipStreamSynchronize(c->stream), "sync");
     c->proteome_len = n;
     c->headers_len = n_headers;
+    c->headers_host.assign(headers, headers + n_headers);
     return V2P_OK;
 }
 
@@ -455,6 +457,7 @@ static int add_haplotype_impl(v2p_batch* b,
             return c->fail(V2P_ERR_SRC_OOB, "reference task beyond the resident proteome at row " + std::to_string(i), int64_t(i));
     }
     std::vector<uint64_t> hdr_src;
+    bool lf_before = fasta;
     if (fasta) {
         uint64_t prev = 0, ti = 0;
         hdr_src.resize(n_rec);
@@ -468,6 +471,9 @@ static int add_haplotype_impl(v2p_batch* b,
             }
             prev = rec_res_end[r];
             hdr_src[r] = c->proteome_len + rec_header_off[r];
+            if (c->headers_host[rec_header_off[r] + rec_header_len[r] - 1] != '\n')
+                return c->fail(V2P_ERR_INVALID_ARG, "a record header must end in a line feed", int64_t(r));
+            if (r > 0 && (rec_header_off[r] == 0 || c->headers_host[rec_header_off[r] - 1] != '\n')) lf_before = false;
         }
         if ((n_rec ? rec_res_end[n_rec - 1] : 0) != n_res) return c->fail(V2P_ERR_INVALID_ARG, "records do not cover the result tape");
     }
@@ -478,7 +484,7 @@ static int add_haplotype_impl(v2p_batch* b,
                             : b->img.add_task(SPACE_PAYLOAD, off_alt + start_pos[i], length[i], start_pos_res[i], n_res);
     };
     if (fasta) {
-        (void)interleave_fasta(b->img, start_pos_res, length, n_tasks, rec_res_end, hdr_src.data(), rec_header_len, n_rec, SPACE_PROTEOME, emit_task);
+        (void)interleave_fasta(b->img, start_pos_res, length, n_tasks, rec_res_end, hdr_src.data(), rec_header_len, n_rec, SPACE_PROTEOME, lf_before, emit_task);
     } else {
         for (uint64_t i = 0; i < n_tasks; ++i) (void)emit_task(i);
     }
