@@ -159,7 +159,7 @@ def main():
     for _ in range(max(args.warmup, 1) if not args.no_verify else args.warmup):
         launch()
     torch.cuda.synchronize()
-    if int(d_status.item()) != -1:
+    if int(d_status.item()) != -1 and not args.dbg:
         sys.exit(f"device reported a task error: status={int(d_status.item()):#x}")
 
     # ---- parity before timing: per-haplotype digests vs the oracle on a sample --------
@@ -198,7 +198,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b) for a, b in ev]
-    if int(d_status.item()) != -1:
+    if int(d_status.item()) != -1 and not args.dbg:
         sys.exit(f"device reported a task error: status={int(d_status.item()):#x}")
 
     tot = torch.tensor([elapsed, float(A), float(NT)], dtype=torch.float64, device=dev)
