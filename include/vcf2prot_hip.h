@@ -173,6 +173,24 @@ int v2p_batch_digests(v2p_batch* b, uint64_t* digests, uint64_t n_haps);
 /* device pointer of the result arena (for callers that keep consuming on the GPU) */
 void* v2p_batch_device_out(v2p_batch* b);
 
+/* ---- streamed pipeline: results that must return to the host ------------------------------ */
+/* n_slots images are in flight at once, each on its own HIP stream: while image k's results
+ * travel D2H, image k+1 executes and image k+2's descriptors travel H2D (pinned staging on both
+ * sides).  Images are packed device images (v2p_cohort_pack(), or a batch builder's output)
+ * against the resident reference.  Tickets are slot numbers and are reused round-robin; a slot
+ * must be released before it is submitted to again. */
+typedef struct v2p_pipeline v2p_pipeline;
+int  v2p_pipeline_create(v2p_ctx* ctx, uint32_t n_slots, v2p_pipeline** out);
+void v2p_pipeline_destroy(v2p_pipeline* p);
+int  v2p_pipeline_submit(v2p_pipeline* p,
+                         const uint64_t* desc, uint64_t n_desc,
+                         const v2p_chunk* chunks, uint64_t n_chunks,
+                         const uint8_t* payload, uint64_t n_payload,
+                         uint64_t out_bytes, uint32_t* ticket);
+/* blocks until the image's results are in host memory; *result stays valid until release */
+int  v2p_pipeline_wait(v2p_pipeline* p, uint32_t ticket, const uint8_t** result, uint64_t* n);
+int  v2p_pipeline_release(v2p_pipeline* p, uint32_t ticket);
+
 /* ---- raw launchers on caller-owned device memory (torch tensors, other runtimes) ----- */
 /* src0/src1 must have 16 readable bytes before and after; out must be 16-byte aligned;
  * status is one device uint64 initialised to ~0. */

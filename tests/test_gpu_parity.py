@@ -276,3 +276,32 @@ def test_two_contexts_from_two_threads(built, coracle):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errors, errors
+
+
+def test_streamed_pipeline_matches_oracle(built, gpu_ctx, coracle):
+    """v2p_pipeline_*: several images in flight (H2D / kernel / D2H overlap), results byte-exact."""
+    from vcf2prot_amd.cohort import Cohort
+    from vcf2prot_amd.engine import Pipeline
+    c = Cohort.preset("C3", n_samples=6)
+    gpu_ctx.upload_proteome(c.proteome())
+    imgs = [c.pack(h, h + 3, n_threads=2) for h in range(0, 12, 3)]
+    pipe = Pipeline(gpu_ctx, 2)
+    tickets, got = [], []
+    for img in imgs:
+        if len(tickets) == 2:
+            t = tickets.pop(0)
+            got.append(pipe.wait(t).copy())
+            pipe.release(t)
+        tickets.append(pipe.submit(img.desc, img.chunks, img.payload, img.out_bytes))
+    for t in tickets:
+        got.append(pipe.wait(t).copy())
+        pipe.release(t)
+    pipe.close()
+    for k, img in enumerate(imgs):
+        for i in range(3):
+            h = 3 * k + i
+            hap = c.haplotype(h)
+            t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+            want = coracle.gir_execute_u8(t, c.ref_tape_u32(h).astype(np.uint8), hap.alt, np.full(hap.n_res, ord("."), dtype=np.uint8))
+            a, b = int(img.hap_out_begin[i]), int(img.hap_out_begin[i + 1])
+            assert np.array_equal(got[k][a:b], want), h

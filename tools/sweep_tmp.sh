@@ -1,4 +1,3 @@
-run() { python bench.py --no-cpu-baseline --steps 10 "$@" 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); r=j['roofline']; print('$*','ms',round(r['kernel_ms_avg'],3),'min',round(r['kernel_ms_min'],3))"; }
-run --dbg 1
-run --dbg 6
-run --dbg 7
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+python tools/pcie_pipeline.py --samples 500 --images 10 --slots 3
+python tools/pcie_pipeline.py --samples 500 --images 10 --slots 3 --fasta

@@ -64,6 +64,12 @@ HIP_API = {
     "v2p_batch_download": (c_int, [c_void_p, c_uint64, c_uint64, c_void_p]),
     "v2p_batch_digests": (c_int, [c_void_p, c_void_p, c_uint64]),
     "v2p_batch_device_out": (c_void_p, [c_void_p]),
+    "v2p_pipeline_create": (c_int, [c_void_p, c_uint32, POINTER(c_void_p)]),
+    "v2p_pipeline_destroy": (None, [c_void_p]),
+    "v2p_pipeline_submit": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_uint64, c_uint64,
+                                    POINTER(c_uint32)]),
+    "v2p_pipeline_wait": (c_int, [c_void_p, c_uint32, POINTER(c_void_p), POINTER(c_uint64)]),
+    "v2p_pipeline_release": (c_int, [c_void_p, c_uint32]),
     "v2p_stitch_launch": (c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, c_uint64,
                                   c_void_p, c_uint64, c_void_p, c_int, c_uint32]),
     "v2p_order_chunks_for_xcds": (c_int, [c_void_p, c_uint64, c_void_p, c_uint64, c_uint64]),

@@ -652,6 +652,131 @@ int v2p_batch_digests(v2p_batch* b, uint64_t* digests, uint64_t n_haps)
 
 void* v2p_batch_device_out(v2p_batch* b) { return (b && b->finalized) ? b->d_out.ptr() : nullptr; }
 
+// ---- streamed pipeline: H2D / kernel / D2H of successive images overlap ---------------
+
+struct PipeSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    DevBuf d_desc, d_chunks, d_payload, d_out, d_status;
+    PinnedBuf h_in, h_out;
+    uint64_t out_bytes = 0;
+    unsigned long long status = STATUS_CLEAN;
+    bool busy = false;
+};
+
+struct v2p_pipeline {
+    v2p_ctx* ctx = nullptr;
+    std::vector<PipeSlot> slots;
+    uint32_t next = 0;
+};
+
+int v2p_pipeline_create(v2p_ctx* c, uint32_t n_slots, v2p_pipeline** out)
+{
+    if (!c || !out || n_slots == 0 || n_slots > 16) return V2P_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    v2p_pipeline* p = new (std::nothrow) v2p_pipeline();
+    if (!p) return c->fail(V2P_ERR_HIP, "out of host memory");
+    p->ctx = c;
+    p->slots.resize(n_slots);
+    for (PipeSlot& s : p->slots) {
+        hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+        if (e != hipSuccess) { delete p; return c->hip_fail(e, "pipeline stream/event"); }
+    }
+    *out = p;
+    return V2P_OK;
+}
+
+void v2p_pipeline_destroy(v2p_pipeline* p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    for (PipeSlot& s : p->slots) {
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        s.d_desc.release(); s.d_chunks.release(); s.d_payload.release(); s.d_out.release(); s.d_status.release();
+        s.h_in.release(); s.h_out.release();
+        if (s.done) (void)hipEventDestroy(s.done);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    delete p;
+}
+
+int v2p_pipeline_submit(v2p_pipeline* p,
+                        const uint64_t* desc, uint64_t n_desc,
+                        const v2p_chunk* chunks, uint64_t n_chunks,
+                        const uint8_t* payload, uint64_t n_payload,
+                        uint64_t out_bytes, uint32_t* ticket)
+{
+    if (!p || !ticket || (n_desc && !desc) || (n_chunks && !chunks) || (n_payload && !payload)) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = p->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (n_chunks > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one image");
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    const uint32_t t = p->next;
+    PipeSlot& s = p->slots[t];
+    if (s.busy) return c->fail(V2P_ERR_STATE, "pipeline slot still holds an unreleased result");
+    const size_t b_desc = size_t(n_desc) * 8, b_chunks = size_t(n_chunks) * sizeof(Chunk);
+    const size_t o_chunks = (b_desc + 15) & ~size_t(15), o_payload = (o_chunks + b_chunks + 15) & ~size_t(15);
+    HIP_TRY(c, s.h_in.ensure(o_payload + n_payload), "hipHostMalloc(in)");
+    HIP_TRY(c, s.h_out.ensure(out_bytes + 8), "hipHostMalloc(out)");
+    HIP_TRY(c, s.d_desc.ensure(b_desc), "hipMalloc(desc)");
+    HIP_TRY(c, s.d_chunks.ensure(b_chunks), "hipMalloc(chunks)");
+    HIP_TRY(c, s.d_payload.ensure(n_payload), "hipMalloc(payload)");
+    HIP_TRY(c, s.d_out.ensure((out_bytes + 15) & ~15ull), "hipMalloc(out)");
+    HIP_TRY(c, s.d_status.ensure(sizeof(unsigned long long)), "hipMalloc(status)");
+    // stage the image in pinned memory so the three copies are truly asynchronous
+    if (b_desc) memcpy(s.h_in.p, desc, b_desc);
+    if (b_chunks) {
+        memcpy(s.h_in.p + o_chunks, chunks, b_chunks);
+        if (!(c->flags & V2P_FLAG_RESULT_ORDER))
+            order_chunks_for_xcds(reinterpret_cast<Chunk*>(s.h_in.p + o_chunks), n_chunks, desc, n_desc, c->proteome_len);
+    }
+    if (n_payload) memcpy(s.h_in.p + o_payload, payload, n_payload);
+    if (b_desc) HIP_TRY(c, hipMemcpyAsync(s.d_desc.ptr(), s.h_in.p, b_desc, hipMemcpyHostToDevice, s.stream), "H2D(desc)");
+    if (b_chunks) HIP_TRY(c, hipMemcpyAsync(s.d_chunks.ptr(), s.h_in.p + o_chunks, b_chunks, hipMemcpyHostToDevice, s.stream), "H2D(chunks)");
+    if (n_payload) HIP_TRY(c, hipMemcpyAsync(s.d_payload.ptr(), s.h_in.p + o_payload, n_payload, hipMemcpyHostToDevice, s.stream), "H2D(payload)");
+    HIP_TRY(c, hipMemsetAsync(s.d_status.ptr(), 0xFF, sizeof(unsigned long long), s.stream), "hipMemset(status)");
+    StitchArgs a{reinterpret_cast<const uint64_t*>(s.d_desc.ptr()), reinterpret_cast<const Chunk*>(s.d_chunks.ptr()),
+                 uint32_t(n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, s.d_payload.ptr(), n_payload,
+                 s.d_out.ptr(), out_bytes, reinterpret_cast<unsigned long long*>(s.d_status.ptr())};
+    HIP_TRY(c, launch_stitch(a, s.stream, !(c->flags & V2P_FLAG_TEMPORAL), 0), "launch(stitch)");
+    if (out_bytes) HIP_TRY(c, hipMemcpyAsync(s.h_out.p, s.d_out.ptr(), out_bytes, hipMemcpyDeviceToHost, s.stream), "D2H(out)");
+    HIP_TRY(c, hipMemcpyAsync(s.h_out.p + ((out_bytes + 7) & ~7ull), s.d_status.ptr(), sizeof(unsigned long long), hipMemcpyDeviceToHost, s.stream), "D2H(status)");
+    HIP_TRY(c, hipEventRecord(s.done, s.stream), "hipEventRecord");
+    s.out_bytes = out_bytes;
+    s.busy = true;
+    *ticket = t;
+    p->next = (t + 1) % uint32_t(p->slots.size());
+    return V2P_OK;
+}
+
+int v2p_pipeline_wait(v2p_pipeline* p, uint32_t ticket, const uint8_t** result, uint64_t* n)
+{
+    if (!p || ticket >= p->slots.size() || !result || !n) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = p->ctx;
+    PipeSlot& s = p->slots[ticket];
+    if (!s.busy) return c->fail(V2P_ERR_STATE, "nothing submitted on this ticket");
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    HIP_TRY(c, hipEventSynchronize(s.done), "hipEventSynchronize");
+    unsigned long long st;
+    memcpy(&st, s.h_out.p + ((s.out_bytes + 7) & ~7ull), sizeof st);
+    *result = s.h_out.p;
+    *n = s.out_bytes;
+    if (st != STATUS_CLEAN) {
+        const int code = reason_to_err(uint32_t(st & 0xFFu));
+        return c->fail(code, std::string("device: ") + err_name(code) + " at descriptor " + std::to_string(st >> 8), int64_t(st >> 8));
+    }
+    return V2P_OK;
+}
+
+int v2p_pipeline_release(v2p_pipeline* p, uint32_t ticket)
+{
+    if (!p || ticket >= p->slots.size()) return V2P_ERR_INVALID_ARG;
+    p->slots[ticket].busy = false;
+    return V2P_OK;
+}
+
 // ---- raw launchers -------------------------------------------------------------
 
 int v2p_stitch_launch(void* hip_stream,

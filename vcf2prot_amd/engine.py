@@ -290,3 +290,47 @@ class GIR:
         res = np.fromiter((ord(c) for c in self.res_array), dtype=np.uint32, count=len(self.res_array))
         ctx.execute_gir(code, sp, ln, sr, ref, alt, res)
         return [chr(int(c)) for c in res], self.annotation
+
+
+class Pipeline:
+    """Streamed execution of successive packed images with H2D / kernel / D2H overlap
+    (v2p_pipeline_*): the way results reach the host when a cohort is larger than one image."""
+
+    def __init__(self, ctx: Context, n_slots: int = 3):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        h = ctypes.c_void_p()
+        ctx._check(self._lib.v2p_pipeline_create(ctx._h, n_slots, ctypes.byref(h)))
+        self._h = h
+        self.n_slots = n_slots
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            self._lib.v2p_pipeline_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, desc: np.ndarray, chunks: np.ndarray, payload: np.ndarray, out_bytes: int) -> int:
+        desc = np.ascontiguousarray(desc, dtype=np.uint64)
+        chunks = np.ascontiguousarray(chunks, dtype=np.uint64).reshape(-1, 2)
+        payload = np.ascontiguousarray(payload, dtype=np.uint8)
+        t = ctypes.c_uint32()
+        self.ctx._check(self._lib.v2p_pipeline_submit(self._h, _p(desc), desc.size, _p(chunks), chunks.shape[0],
+                                                      _p(payload), payload.size, out_bytes, ctypes.byref(t)))
+        return int(t.value)
+
+    def wait(self, ticket: int) -> np.ndarray:
+        """View of the slot's pinned result buffer (valid until release(ticket))."""
+        ptr, n = ctypes.c_void_p(), ctypes.c_uint64()
+        self.ctx._check(self._lib.v2p_pipeline_wait(self._h, ticket, ctypes.byref(ptr), ctypes.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=np.uint8)
+        return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(int(n.value),))
+
+    def release(self, ticket: int):
+        self.ctx._check(self._lib.v2p_pipeline_release(self._h, ticket))
