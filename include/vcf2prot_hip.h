@@ -147,6 +147,22 @@ int v2p_batch_add_haplotype_fasta(v2p_batch* b,
                                   const uint64_t* rec_res_end, const uint64_t* rec_header_off, const uint32_t* rec_header_len,
                                   uint64_t n_rec);
 
+/* Step 5 folded into the builder (replaces the host loop haplotype_instruction.rs:94-133): feed the
+ * per-transcript GIRs exactly as TranscriptInstruction::get_g_rep returns them
+ * (transcript_instructions.rs:335-427: offsets relative to the transcript, its own small alt tape),
+ * in the order they should appear in the result.  Reference tasks read the resident proteome at
+ * tx_proteome_off; no private ref tape is built, no counters are kept by the caller.  An empty GIR
+ * (start-lost transcript, :338-343) is n_tasks = 0, res_len = 0.  header_len != 0 additionally emits
+ * the FASTA record text (header from the resident table, residues, line feed). */
+int v2p_batch_begin_haplotype(v2p_batch* b);
+int v2p_batch_add_transcript(v2p_batch* b,
+                             const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
+                             const uint64_t* start_pos_res, uint64_t n_tasks,
+                             uint64_t tx_proteome_off, uint64_t tx_ref_len,
+                             const uint8_t* alt, uint64_t n_alt, uint64_t res_len,
+                             uint64_t header_off, uint32_t header_len);
+int v2p_batch_end_haplotype(v2p_batch* b);
+
 /* Adopt an already packed image (descriptors, chunks, payload, haplotype result ranges),
  * e.g. from the synthetic cohort generator (include/v2p_cohort.h). */
 int v2p_batch_set_packed(v2p_batch* b,

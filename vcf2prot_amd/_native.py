@@ -47,6 +47,10 @@ HIP_API = {
     "v2p_batch_add_haplotype_fasta": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
                                               c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_uint64,
                                               c_void_p, c_void_p, c_void_p, c_uint64]),
+    "v2p_batch_begin_haplotype": (c_int, [c_void_p]),
+    "v2p_batch_add_transcript": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_uint64,
+                                         c_void_p, c_uint64, c_uint64, c_uint64, c_uint32]),
+    "v2p_batch_end_haplotype": (c_int, [c_void_p]),
     "v2p_batch_create": (c_int, [c_void_p, POINTER(c_void_p)]),
     "v2p_batch_destroy": (None, [c_void_p]),
     "v2p_batch_add_gir": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,

@@ -115,6 +115,11 @@ struct v2p_batch {
     ImageBuilder img;
     bool finalized = false;
     bool uses_proteome = false;
+    // step-5-on-the-fly state (v2p_batch_begin_haplotype / add_transcript / end_haplotype)
+    bool hap_open = false;
+    uint64_t hap_res = 0;          // res_counter of haplotype_instruction.rs:90,132
+    uint64_t hap_records = 0;
+    uint64_t last_hdr_src = 0; uint32_t last_hdr_len = 0;
     DevBuf d_desc, d_chunks, d_payload, d_out, d_hap, d_digest, d_status;
     uint64_t n_desc = 0, n_chunks = 0, n_payload = 0, out_bytes = 0, n_haps = 0;
 };
@@ -516,6 +521,78 @@ int v2p_batch_add_haplotype_fasta(v2p_batch* b,
                               alt, n_alt, n_res, rec_res_end, rec_header_off, rec_header_len, n_rec, true);
 }
 
+// ---- step 5 folded into the image builder ------------------------------------------------
+// The reference concatenates per-transcript GIRs into a haplotype GIR on the host
+// (haplotype_instruction.rs:94-133): it copies every transcript's reference into a private tape
+// and rebases start_pos by ref_counter / alt_counter and start_pos_res by res_counter.  Here a
+// transcript GIR goes straight into the image: reference tasks are rebased onto the resident
+// proteome (no tape copy, no ref_counter), alt tasks onto the payload arena, and result
+// offsets are implicit (device prefix sum), so the three running sums disappear.
+
+int v2p_batch_begin_haplotype(v2p_batch* b)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
+    if (b->hap_open) return c->fail(V2P_ERR_STATE, "previous haplotype not ended");
+    b->hap_open = true; b->hap_res = 0; b->hap_records = 0;
+    return V2P_OK;
+}
+
+int v2p_batch_add_transcript(v2p_batch* b,
+                             const uint8_t* code, const uint64_t* start_pos, const uint64_t* length,
+                             const uint64_t* start_pos_res, uint64_t n_tasks,
+                             uint64_t tx_proteome_off, uint64_t tx_ref_len,
+                             const uint8_t* alt, uint64_t n_alt, uint64_t res_len,
+                             uint64_t header_off, uint32_t header_len)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (b->finalized || !b->hap_open) return c->fail(V2P_ERR_STATE, "no open haplotype");
+    if ((n_tasks && (!code || !start_pos || !length || !start_pos_res)) || (n_alt && !alt)) return c->fail(V2P_ERR_INVALID_ARG, "null argument");
+    if (tx_proteome_off + tx_ref_len > c->proteome_len) return c->fail(V2P_ERR_SRC_OOB, "transcript outside the resident proteome");
+    int rc = precheck(c, code, start_pos, length, start_pos_res, n_tasks, tx_ref_len, n_alt, res_len);   // update_task :140-158 + task.rs bounds
+    if (rc) return rc;
+    const bool fasta = header_len != 0;
+    if (fasta) {
+        if (header_off + header_len > c->headers_len) return c->fail(V2P_ERR_SRC_OOB, "record header outside the resident header table");
+        if (c->headers_host[header_off + header_len - 1] != '\n') return c->fail(V2P_ERR_INVALID_ARG, "a record header must end in a line feed");
+        const uint64_t src = c->proteome_len + header_off;
+        const bool merge = b->hap_records > 0 && header_off > 0 && c->headers_host[header_off - 1] == '\n';
+        if (b->hap_records > 0 && !merge) b->img.add_literal(SPACE_PROTEOME, b->last_hdr_src + b->last_hdr_len - 1, 1);
+        if (merge) b->img.add_literal(SPACE_PROTEOME, src - 1, header_len + 1);     // previous record's line feed + this header
+        else b->img.add_literal(SPACE_PROTEOME, src, header_len);
+        b->last_hdr_src = src; b->last_hdr_len = header_len;
+    }
+    const uint64_t off_alt = b->img.payload_alloc(n_alt);
+    if (n_alt) memcpy(&b->img.payload[off_alt], alt, n_alt);
+    const uint64_t base = b->hap_res, n_res = b->hap_res + res_len;
+    for (uint64_t i = 0; i < n_tasks; ++i) {
+        if (code[i] == 0) (void)b->img.add_task(SPACE_PROTEOME, tx_proteome_off + start_pos[i], length[i], base + start_pos_res[i], n_res);
+        else              (void)b->img.add_task(SPACE_PAYLOAD, off_alt + start_pos[i], length[i], base + start_pos_res[i], n_res);
+    }
+    b->img.fill_to(n_res);                 // cells of this transcript no task covers keep '.'
+    b->hap_res = n_res;
+    ++b->hap_records;
+    b->uses_proteome = true;
+    return V2P_OK;
+}
+
+int v2p_batch_end_haplotype(v2p_batch* b)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (b->finalized || !b->hap_open) return c->fail(V2P_ERR_STATE, "no open haplotype");
+    if (b->hap_records > 0 && b->last_hdr_len != 0)
+        b->img.add_literal(SPACE_PROTEOME, b->last_hdr_src + b->last_hdr_len - 1, 1);     // line feed of the last record
+    b->img.end_haplotype(b->hap_res);
+    b->hap_open = false; b->last_hdr_len = 0;
+    return V2P_OK;
+}
+
 int v2p_batch_set_packed(v2p_batch* b,
                          const uint64_t* desc, uint64_t n_desc,
                          const v2p_chunk* chunks, uint64_t n_chunks,
@@ -544,6 +621,7 @@ int v2p_batch_finalize(v2p_batch* b)
     v2p_ctx* c = b->ctx;
     std::lock_guard<std::mutex> lk(c->mu);
     if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
+    if (b->hap_open) return c->fail(V2P_ERR_STATE, "a haplotype is still open");
     b->img.finish();
     if (b->uses_proteome && !(c->flags & V2P_FLAG_RESULT_ORDER))
         order_chunks_for_xcds(b->img.chunks.data(), b->img.chunks.size(), b->img.desc.data(), b->img.desc.size(), c->proteome_len);

@@ -204,6 +204,24 @@ class Batch:
             self._h, _p(code), _p(sp), _p(ln), _p(sr), code.size, _p(sb), _p(so), so.size, _p(alt), alt.size, n_res,
             _p(re_), _p(ho), _p(hl), re_.size))
 
+    def begin_haplotype(self):
+        self.ctx._check(self._lib.v2p_batch_begin_haplotype(self._h))
+
+    def add_transcript(self, code, start_pos, length, start_pos_res, tx_proteome_off: int, tx_ref_len: int,
+                       alt: np.ndarray, res_len: int, header_off: int = 0, header_len: int = 0):
+        """One TranscriptInstruction::get_g_rep result (per-transcript offsets); step 5 happens in the builder."""
+        code = np.ascontiguousarray(code, dtype=np.uint8)
+        sp = np.ascontiguousarray(start_pos, dtype=np.uint64)
+        ln = np.ascontiguousarray(length, dtype=np.uint64)
+        sr = np.ascontiguousarray(start_pos_res, dtype=np.uint64)
+        alt = np.ascontiguousarray(alt, dtype=np.uint8)
+        self.ctx._check(self._lib.v2p_batch_add_transcript(self._h, _p(code), _p(sp), _p(ln), _p(sr), code.size,
+                                                           tx_proteome_off, tx_ref_len, _p(alt), alt.size, res_len,
+                                                           header_off, header_len))
+
+    def end_haplotype(self):
+        self.ctx._check(self._lib.v2p_batch_end_haplotype(self._h))
+
     def set_packed(self, desc: np.ndarray, chunks: np.ndarray, payload: np.ndarray, hap_out_begin: np.ndarray):
         desc = np.ascontiguousarray(desc, dtype=np.uint64)
         chunks = np.ascontiguousarray(chunks, dtype=np.uint64).reshape(-1, 2)
