@@ -31,7 +31,15 @@ class PackedImage(ctypes.Structure):
                 ("n_haps", c_uint64), ("n_tasks", c_uint64), ("n_copy_bytes", c_uint64)]
 
 
+class Instruction(ctypes.Structure):
+    """instruction.rs:6-15 (include/v2p_step4b.h)"""
+    _fields_ = [("code", ctypes.c_char), ("s_state", c_uint8), ("pos_ref", c_uint64), ("pos_res", c_uint64),
+                ("len", c_uint64), ("data", c_char_p), ("data_len", c_uint64)]
+
+
 COHORT_API = {
+    "v2p_transcript_g_rep": (c_int, [POINTER(Instruction), c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
+                                     POINTER(c_uint64), c_void_p, c_uint64, POINTER(c_uint64), POINTER(c_uint64)]),
     "v2p_cohort_preset": (c_int, [c_char_p, POINTER(CohortParams)]),
     "v2p_cohort_create": (c_int, [POINTER(CohortParams), POINTER(c_void_p)]),
     "v2p_cohort_destroy": (None, [c_void_p]),

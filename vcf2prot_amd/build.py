@@ -24,8 +24,9 @@ COHORT_LIB = os.path.join(LIBDIR, "libv2p_cohort.so")
 
 HIP_SOURCES = ["stitch_kernels.hip", "v2p_api.hip"]
 HIP_DEPS = HIP_SOURCES + ["stitch_kernels.h", "sir_pack.hpp", os.path.join(ROOT, "include", "vcf2prot_hip.h")]
-COHORT_SOURCES = ["cohort_gen.cpp"]
-COHORT_DEPS = COHORT_SOURCES + ["sir_pack.hpp", os.path.join(ROOT, "include", "v2p_cohort.h")]
+COHORT_SOURCES = ["cohort_gen.cpp", os.path.join("host", "transcript_tasks.cpp")]
+COHORT_DEPS = COHORT_SOURCES + ["sir_pack.hpp", os.path.join(ROOT, "include", "v2p_cohort.h"),
+                                os.path.join(ROOT, "include", "v2p_step4b.h")]
 
 
 def _stale(target: str, deps) -> bool:
