@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--temporal", action="store_true", help="plain result stores instead of non-temporal")
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--fasta", action="store_true", help="FASTA-emitting image: headers and line feeds fused into the scatter (SURVEY 8f rank 1)")
+    ap.add_argument("--cut-align", type=int, default=0)
     ap.add_argument("--chunk-tasks", type=int, default=0)
     ap.add_argument("--chunk-bytes", type=int, default=0)
     ap.add_argument("--dbg", type=int, default=0, help="timing-only kernel ablation (results are wrong; implies --no-verify)")
@@ -112,7 +113,7 @@ def main():
     h0, h1 = 2 * samples * rank, 2 * samples * (rank + 1)
     n_threads = max(1, (os.cpu_count() or 1) // world)
     t_gen = time.perf_counter()
-    img = cohort.pack(h0, h1, n_threads=min(n_threads, 64), chunk_tasks=args.chunk_tasks, chunk_bytes=args.chunk_bytes, fasta=args.fasta)
+    img = cohort.pack(h0, h1, n_threads=min(n_threads, 64), chunk_tasks=args.chunk_tasks, chunk_bytes=args.chunk_bytes, fasta=args.fasta, cut_align=args.cut_align)
     t_gen = time.perf_counter() - t_gen
     A, NT = img.n_copy_bytes, img.n_tasks
     b_alg = 2 * A + 16 * NT

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of stitch-kernel variants in ONE process (perf deltas between separate
+runs/boxes are within the noise; cdna guide rule 24).
+
+    python tools/ab.py --rounds 15 "cut_align=16" "cut_align=4096" "cut_align=4096,chunk_tasks=192"
+
+Each variant is a comma-separated list of key=value: pack options (chunk_tasks, chunk_bytes,
+cut_align, fasta, xcd=0/1) and launch options (nt=0/1, dbg=N).  Prints median/min ms per variant.
+"""
+import argparse
+import ctypes
+import json
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from vcf2prot_amd import _native as N  # noqa: E402
+from vcf2prot_amd.cohort import Cohort  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("variants", nargs="+")
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--samples", type=int, default=1000)
+    ap.add_argument("--rounds", type=int, default=15)
+    a = ap.parse_args()
+    lib = N.hip_lib()
+    dev = torch.device("cuda", 0)
+    cohort = Cohort.preset(a.workload, n_samples=a.samples)
+    prot = cohort.proteome()
+    n_prot = prot.size
+    resident = np.concatenate([prot, cohort.fasta_headers()])
+    d_prot = torch.zeros(resident.size + 32, dtype=torch.uint8, device=dev)
+    d_prot[16:16 + resident.size] = torch.from_numpy(resident).to(dev)
+    stream = torch.cuda.current_stream()
+    d_status = torch.full((1,), -1, dtype=torch.int64, device=dev)
+    vs, max_out = [], 0
+    for spec in a.variants:
+        kv = dict(x.split("=") for x in spec.split(",") if x)
+        pack = {k: int(kv[k]) for k in ("chunk_tasks", "chunk_bytes", "cut_align", "soft_window") if k in kv}
+        img = cohort.pack(0, cohort.n_haplotypes, n_threads=min(64, os.cpu_count() or 1), fasta=bool(int(kv.get("fasta", 0))), **pack)
+        chunks = np.ascontiguousarray(img.chunks)
+        if int(kv.get("xcd", 1)):
+            lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, n_prot)
+        d_pay = torch.zeros(img.payload.size + 32, dtype=torch.uint8, device=dev)
+        d_pay[16:16 + img.payload.size] = torch.from_numpy(img.payload).to(dev)
+        v = dict(spec=spec, d_desc=torch.from_numpy(img.desc.view(np.int64)).to(dev), d_chunks=torch.from_numpy(chunks.view(np.int64)).to(dev),
+                 d_pay=d_pay, n_pay=img.payload.size, n_chunks=chunks.shape[0], out=img.out_bytes,
+                 flags=int(kv.get("nt", 1)) | (int(kv.get("dbg", 0)) << 16), ms=[])
+        vs.append(v)
+        max_out = max(max_out, img.out_bytes)
+    d_out = torch.empty(max_out + 32, dtype=torch.uint8, device=dev)
+
+    def launch(v):
+        rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), v["d_desc"].data_ptr(), v["d_chunks"].data_ptr(), v["n_chunks"],
+                                   d_prot.data_ptr() + 16, resident.size, v["d_pay"].data_ptr() + 16, v["n_pay"],
+                                   d_out.data_ptr(), v["out"], d_status.data_ptr(), v["flags"], 0)
+        assert rc == 0
+    for v in vs:
+        launch(v)
+        launch(v)
+    torch.cuda.synchronize()
+    # identical variants differ by up to ~6 % with the placement of their buffers in HBM, so every round
+    # re-places all input buffers (fresh allocations behind a random-sized spacer) before timing
+    rng = np.random.default_rng(1)
+    spacers = []
+    for rnd in range(a.rounds):
+        spacers.append(torch.empty(int(rng.integers(1, 64)) * (1 << 20) + int(rng.integers(0, 4096)) * 256, dtype=torch.uint8, device=dev))
+        for v in vs:
+            for k in ("d_desc", "d_chunks", "d_pay"):
+                v[k] = v[k].clone()
+        if len(spacers) > 3:
+            spacers.pop(0)
+        for v in vs:
+            launch(v)
+        torch.cuda.synchronize()
+        for v in vs:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            launch(v)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            v["ms"].append(e0.elapsed_time(e1))
+    for v in vs:
+        ms = v["ms"]
+        print(f"{v['spec']:48s} mean {statistics.mean(ms):.3f} +- {statistics.pstdev(ms):.3f}  median {statistics.median(ms):.3f}  min {min(ms):.3f}  chunks {v['n_chunks']}")
+
+
+if __name__ == "__main__":
+    main()

@@ -453,6 +453,8 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
     for (auto& im : parts) {
         if (chunk_tasks) im.chunk_tasks = chunk_tasks;
         if (chunk_bytes) im.chunk_bytes = chunk_bytes;
+        if ((flags >> 8) & 0xFFFF) im.cut_align = (flags >> 8) & 0xFFFF;   // experiment knobs: bits 8..23 cut alignment,
+        if (flags >> 24) im.soft_window = flags >> 24;                     //                   bits 24..31 closing window
     }
     std::vector<int> status(parts.size(), 0);
     auto work = [&](int w) {
