@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--temporal", action="store_true", help="plain result stores instead of non-temporal")
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--fasta", action="store_true", help="FASTA-emitting image: headers and line feeds fused into the scatter (SURVEY 8f rank 1)")
+    ap.add_argument("--tpt", type=int, default=0, help="descriptors per lane (chunks of up to 256*tpt tasks; 0 = library default)")
     ap.add_argument("--cut-align", type=int, default=0)
     ap.add_argument("--chunk-tasks", type=int, default=0)
     ap.add_argument("--chunk-bytes", type=int, default=0)
@@ -151,7 +152,7 @@ def main():
         rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), d_desc.data_ptr(), d_chunks.data_ptr(), n_chunks,
                                    d_prot.data_ptr() + 16, proteome.size, d_payload.data_ptr() + 16, img.payload.size,
                                    d_out.data_ptr(), out_bytes, d_status.data_ptr(),
-                                   (0 if args.temporal else 1) | (args.dbg << 16), args.max_blocks)
+                                   (0 if args.temporal else 1) | ((args.tpt or img.tasks_per_lane) << 8) | (args.dbg << 16), args.max_blocks)
         if rc != 0:
             raise RuntimeError(f"v2p_stitch_launch failed: {rc}")
         if world > 1:                                          # the path's only exchange: result sizes for the global offsets
@@ -231,7 +232,7 @@ def main():
             "config": {"workload": f"{args.workload}: {samples} samples/GPU ({2 * samples} haplotypes) x "
                                    f"{cohort.n_transcripts} transcripts, SIR Task vectors at the step-6 boundary",
                        "haplotypes_per_gpu": n_haps, "tasks_per_gpu": NT, "aa_per_gpu": A, "chunks_per_gpu": n_chunks,
-                       "descriptor_bytes": 8, "parallelism": f"haplotype-sharded x{world}, no data-path collective"},
+                       "descriptor_bytes": 8, "descriptors_per_lane": args.tpt or img.tasks_per_lane, "parallelism": f"haplotype-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_alg, "kernel": "stitch_kernel", "kernel_ms_avg": avg_ms,

@@ -73,6 +73,7 @@ typedef struct {
     uint64_t* hap_out_begin; uint64_t n_haps;      /* [n_haps + 1] */
     uint64_t  n_tasks;       /* N: reference Task descriptors consumed (zero-length ones included) */
     uint64_t  n_copy_bytes;  /* A: residues written = Sum task.length                              */
+    uint64_t  max_chunk_tasks; /* largest descriptor count of a chunk: v2p_stitch_launch needs ceil(this/256) per lane */
 } v2p_packed_image;
 
 /* "C1".."C5" (BASELINE.json configs, concretised in SURVEY.md section 8d) */

@@ -51,7 +51,7 @@ def main():
         d_pay[16:16 + img.payload.size] = torch.from_numpy(img.payload).to(dev)
         v = dict(spec=spec, d_desc=torch.from_numpy(img.desc.view(np.int64)).to(dev), d_chunks=torch.from_numpy(chunks.view(np.int64)).to(dev),
                  d_pay=d_pay, n_pay=img.payload.size, n_chunks=chunks.shape[0], out=img.out_bytes,
-                 flags=int(kv.get("nt", 1)) | (int(kv.get("dbg", 0)) << 16), ms=[])
+                 flags=int(kv.get("nt", 1)) | (int(kv.get("tpt", img.tasks_per_lane)) << 8) | (int(kv.get("dbg", 0)) << 16), ms=[])
         vs.append(v)
         max_out = max(max_out, img.out_bytes)
     d_out = torch.empty(max_out + 32, dtype=torch.uint8, device=dev)

@@ -28,7 +28,7 @@ class HapView(ctypes.Structure):
 class PackedImage(ctypes.Structure):
     _fields_ = [("desc", POINTER(c_uint64)), ("n_desc", c_uint64), ("chunks", POINTER(v2p_chunk)), ("n_chunks", c_uint64),
                 ("payload", POINTER(c_uint8)), ("n_payload", c_uint64), ("hap_out_begin", POINTER(c_uint64)),
-                ("n_haps", c_uint64), ("n_tasks", c_uint64), ("n_copy_bytes", c_uint64)]
+                ("n_haps", c_uint64), ("n_tasks", c_uint64), ("n_copy_bytes", c_uint64), ("max_chunk_tasks", c_uint64)]
 
 
 class Instruction(ctypes.Structure):

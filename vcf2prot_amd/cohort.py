@@ -52,6 +52,11 @@ class Packed:
     hap_out_begin: np.ndarray
     n_tasks: int                 # N of the roofline formula
     n_copy_bytes: int            # A of the roofline formula
+    max_chunk_tasks: int = 0     # largest chunk (selects the kernel's descriptors per lane)
+
+    @property
+    def tasks_per_lane(self) -> int:
+        return 1 if self.max_chunk_tasks <= 256 else (2 if self.max_chunk_tasks <= 512 else 4)
 
     @property
     def out_bytes(self) -> int:
@@ -174,6 +179,6 @@ class Cohort:
                       if img.n_chunks else np.zeros((0, 2), dtype=np.uint64))
             payload = _arr(img.payload, img.n_payload, np.uint8)
             hb = _arr(img.hap_out_begin, img.n_haps + 1, np.uint64)
-            return Packed(desc, chunks, payload, hb, int(img.n_tasks), int(img.n_copy_bytes))
+            return Packed(desc, chunks, payload, hb, int(img.n_tasks), int(img.n_copy_bytes), int(img.max_chunk_tasks))
         finally:
             self._lib.v2p_packed_free(ctypes.byref(img))

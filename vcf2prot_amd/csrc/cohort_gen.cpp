@@ -451,7 +451,7 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
     if (uint64_t(n_threads) > n && n) n_threads = int(n);
     std::vector<v2p::ImageBuilder> parts(size_t(n_threads ? n_threads : 1));
     for (auto& im : parts) {
-        if (chunk_tasks) im.chunk_tasks = chunk_tasks;
+        if (chunk_tasks) { im.chunk_tasks = chunk_tasks; im.adaptive_tasks = false; }
         if (chunk_bytes) im.chunk_bytes = chunk_bytes;
         if ((flags >> 8) & 0xFFFF) im.cut_align = (flags >> 8) & 0xFFFF;   // experiment knobs: bits 8..23 cut alignment,
         if (flags >> 24) im.soft_window = flags >> 24;                     //                   bits 24..31 closing window
@@ -487,6 +487,7 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
         od += parts[w].desc.size(); oc += parts[w].chunks.size(); op += parts[w].payload.size();
         oo += parts[w].out_size(); oh += parts[w].n_haplotypes();
         out->n_tasks += parts[w].n_ref_tasks; out->n_copy_bytes += parts[w].n_copy_bytes;
+        if (parts[w].max_chunk_tasks > out->max_chunk_tasks) out->max_chunk_tasks = parts[w].max_chunk_tasks;
     }
     auto merge = [&](int w) {
         v2p::ImageBuilder& im = parts[size_t(w)];

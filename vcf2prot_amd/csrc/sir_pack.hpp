@@ -11,7 +11,7 @@
 //                               1 = batch payload arena (alt bytes, private ref tapes),
 //                               2 = fill with '.' (cells no task covers keep the
 //                                   '.' of haplotype_instruction.rs:78)
-//   chunks[C]    work items of <= 256 consecutive descriptors and <= 64 KiB of
+//   chunks[C]    work items of <= 256 (deep Task vectors: 1024) consecutive descriptors and < 64 KiB of
 //                result: {first descriptor, result offset, descriptor count}.
 //                Inside a chunk result offsets are the exclusive prefix sum of the
 //                lengths (computed on the device by a wave64 scan), so the 8-byte
@@ -39,8 +39,9 @@ constexpr unsigned SPACE_FILL     = 2;
 constexpr uint64_t SRC_MASK   = (1ull << 40) - 1;
 constexpr uint32_t LEN_BITS   = 22;
 constexpr uint32_t LEN_MASK   = (1u << LEN_BITS) - 1;
-constexpr uint32_t CHUNK_TASKS = 256;          // descriptors per work item (one per lane of a 256-thread workgroup)
-constexpr uint32_t CHUNK_BYTES = 64u * 1024u - 16u;  // result bytes per work item (<= 4096 16-byte blocks incl. ragged head)
+constexpr uint32_t CHUNK_TASKS = 256;          // descriptors per work item for long-run images (one per lane)
+constexpr uint32_t CHUNK_TASKS_DEEP = 1024;    // ... for deep Task vectors (< 32 result bytes per descriptor): 4 per lane
+constexpr uint32_t CHUNK_BYTES = 64u * 1024u - 16u;  // result bytes per work item (<= 4096 16-byte blocks incl. a ragged head)
 constexpr uint32_t CUT_ALIGN  = 4096;          // preferred chunk cut: 4 KiB multiples = full 256-lane passes of 16-byte blocks
 constexpr uint64_t DST_MASK   = (1ull << 48) - 1;
 constexpr uint32_t PAD_BYTES  = 16;            // readable slack each side of a source arena (16-byte gathers)
@@ -77,8 +78,10 @@ public:
     uint64_t n_copy_bytes = 0;     // A: residues written by copy tasks (Sum task.length)
     uint64_t n_ref_tasks = 0;      // N: Task descriptors consumed, zero-length ones included
     uint32_t chunk_tasks = CHUNK_TASKS;
+    bool adaptive_tasks = true;       // pick the next chunk's descriptor limit from the last chunk's bytes per descriptor
     uint32_t chunk_bytes = CHUNK_BYTES;
     uint32_t cut_align = CUT_ALIGN;   // power of two >= 16
+    uint32_t max_chunk_tasks = 0;     // largest descriptor count of any chunk (selects the kernel's descriptors per lane)
     uint32_t soft_window = 8;         // descriptors before the hard limit at which a chunk starts looking for its cut
 
     uint64_t out_size() const { return hap_out_begin.back(); }
@@ -136,6 +139,10 @@ private:
     void close_chunk() {
         if (open_n_ == 0) return;
         chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_n_) << 48)});
+        if (open_n_ > max_chunk_tasks) max_chunk_tasks = open_n_;
+        // measured on MI355X: ~250-task / ~34 KiB chunks are fastest for long runs (C2, C3); images with only a few
+        // result bytes per descriptor (C5: ~7) are set-up bound and run 27 % faster with 1024-task chunks
+        if (adaptive_tasks) chunk_tasks = (open_bytes_ / open_n_ >= 32u) ? CHUNK_TASKS : CHUNK_TASKS_DEEP;
         open_n_ = 0; open_bytes_ = 0;
     }
     void append(unsigned space, uint64_t src, uint32_t len) {

@@ -14,6 +14,7 @@ enum : uint32_t {
     STATUS_NOT_CONTIGUOUS = 4   // gir.rs:208-226 predicate
 };
 constexpr unsigned long long STATUS_CLEAN = ~0ull;
+constexpr int STITCH_TASKS_PER_LANE = 4;               // default descriptors per lane (any chunk <= 1024 tasks is legal)
 constexpr uint32_t DOTS_BYTES = 64u * 1024u + 64u;   // per-device buffer of '.' that fill descriptors gather from
 
 struct StitchArgs {
@@ -66,3 +67,8 @@ hipError_t launch_digest(const DigestArgs& a, uint64_t out_bytes, hipStream_t st
 hipError_t launch_fill(uint8_t* out, uint64_t bytes, uint32_t word, int nontemporal, hipStream_t stream);
 
 }  // namespace v2p
+
+namespace v2p {
+// descriptors per lane the stitch kernel needs for chunks of at most `max_chunk_tasks` descriptors
+inline int tasks_per_lane_for(uint32_t max_chunk_tasks) { return max_chunk_tasks <= 256u ? 1 : (max_chunk_tasks <= 512u ? 2 : 4); }
+}

@@ -96,47 +96,59 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("" ::: "memory");
 }
 
-template <bool NT, int DBG = 0>
+// TPT = descriptors per lane: a chunk holds up to 256*TPT tasks.  The per-chunk set-up (two
+// dependent HBM latencies, four barriers) is the same for any TPT, so larger chunks amortise it.
+template <int TPT, bool NT, int DBG = 0>
 __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_map32[1024 + 4];
-    __shared__ uint64_t s_adj[264];
-    __shared__ uint32_t s_off[264];
+    constexpr uint32_t K = 256u * TPT;
+    __shared__ __attribute__((aligned(16))) uint32_t s_map32[2048 + 8];     // 4096 two-byte block->rank entries
+    __shared__ uint64_t s_adj[K + 8];
+    __shared__ uint32_t s_off[K + 8];
     __shared__ uint32_t s_w[3][4];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    const uint8_t* const s_map = reinterpret_cast<const uint8_t*>(s_map32);
+    const uint16_t* const s_map = reinterpret_cast<const uint16_t*>(s_map32);
     const uint64_t dots16 = reinterpret_cast<uint64_t>(a.dots) + 16u;
 
     for (uint32_t c = blockIdx.x; c < a.n_chunks; c += gridDim.x) {
         if (c != blockIdx.x) lds_barrier();            // LDS is reused by the next chunk
         const uint64_t tb = a.chunks[c].task_begin;
         const uint64_t dn = a.chunks[c].dst_n;
-        uint32_t n = uint32_t(dn >> 48);
-        n = n > 256u ? 256u : n;
+        const uint32_t n_hdr = uint32_t(dn >> 48);
+        const uint32_t n = n_hdr > K ? K : n_hdr;
         const uint64_t dst = dn & ((1ull << 48) - 1);
         const uint32_t head = uint32_t(dst & 15ull);
 
-        // ---- A ----
-        uint64_t adj = dots16;
-        uint32_t len = 0;
-        if (tid < n) {
-            const uint64_t d = a.desc[tb + tid];
-            len = uint32_t(d >> 40) & ((1u << 22) - 1u);
-            const uint32_t space = uint32_t(d >> 62);
-            const uint64_t src = d & ((1ull << 40) - 1);
-            const uint64_t limit = space == SPACE_PROTEOME ? a.src0_len : (space == SPACE_PAYLOAD ? a.src1_len : ~0ull);
-            if (space == 3u || src + len > limit) {          // never read out of bounds: task.rs would panic
-                report(a.status, tb + tid, STATUS_SRC_OOB);
-            } else if (space != SPACE_FILL) {
-                adj = reinterpret_cast<uint64_t>(space == SPACE_PROTEOME ? a.src0 : a.src1) + src;
+        // ---- A: TPT consecutive descriptors per lane ----
+        uint64_t adj[TPT];
+        uint32_t len[TPT];
+        uint32_t lsum = 0, lnz = 0;
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            adj[k] = dots16;
+            len[k] = 0;
+            const uint32_t i = tid * TPT + k;
+            if (i < n) {
+                const uint64_t d = a.desc[tb + i];
+                len[k] = uint32_t(d >> 40) & ((1u << 22) - 1u);
+                const uint32_t space = uint32_t(d >> 62);
+                const uint64_t src = d & ((1ull << 40) - 1);
+                const uint64_t limit = space == SPACE_PROTEOME ? a.src0_len : (space == SPACE_PAYLOAD ? a.src1_len : ~0ull);
+                if (space == 3u || src + len[k] > limit) {       // never read out of bounds: task.rs would panic
+                    report(a.status, tb + i, STATUS_SRC_OOB);
+                } else if (space != SPACE_FILL) {
+                    adj[k] = reinterpret_cast<uint64_t>(space == SPACE_PROTEOME ? a.src0 : a.src1) + src;
+                }
             }
+            lsum += len[k];
+            lnz += len[k] != 0u ? 1u : 0u;
         }
-        *reinterpret_cast<u32x4*>(&s_map32[4u * tid]) = u32x4{0u, 0u, 0u, 0u};
-        const uint32_t incl = wave_incl_scan(len);
-        const unsigned long long nzmask = __ballot(len != 0u);
-        const uint32_t nz_before = __builtin_amdgcn_mbcnt_hi(uint32_t(nzmask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(nzmask), 0u));
-        if (lane == 63u) { s_w[0][wid] = incl; s_w[1][wid] = uint32_t(__popcll(nzmask)); }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s_map32[8u * tid + q] = 0u;
+        const uint32_t incl = wave_incl_scan(lsum);
+        const uint32_t nzincl = wave_incl_scan(lnz);
+        if (lane == 63u) { s_w[0][wid] = incl; s_w[1][wid] = nzincl; }
         lds_barrier();
 
         // ---- B ----
@@ -144,36 +156,45 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
         const uint32_t z0 = s_w[1][0], z1 = s_w[1][1], z2 = s_w[1][2], z3 = s_w[1][3];
         const uint32_t total = l0 + l1 + l2 + l3;
         const uint32_t nz = z0 + z1 + z2 + z3;
-        const uint32_t excl = incl - len + (wid > 0 ? l0 : 0u) + (wid > 1 ? l1 : 0u) + (wid > 2 ? l2 : 0u);
-        const uint32_t rank = nz_before + (wid > 0 ? z0 : 0u) + (wid > 1 ? z1 : 0u) + (wid > 2 ? z2 : 0u);
+        uint32_t excl = incl - lsum + (wid > 0 ? l0 : 0u) + (wid > 1 ? l1 : 0u) + (wid > 2 ? l2 : 0u);
+        uint32_t rank = nzincl - lnz + (wid > 0 ? z0 : 0u) + (wid > 1 ? z1 : 0u) + (wid > 2 ? z2 : 0u);
         const uint32_t nblk = total ? (head + total + 15u) >> 4 : 0u;
-        const bool chunk_ok = dst + total <= a.out_len && nblk <= 4096u && total <= DOTS_BYTES - 64u;
-        if (len != 0u) {
-            s_off[rank] = excl;
-            s_adj[rank] = adj - excl;
-            if (rank >= 1u && chunk_ok) {
-                const uint32_t kmin = (excl + head + 15u) >> 4;    // first block starting at or after the task start
-                if (kmin < nblk) atomicAdd(&s_map32[kmin >> 2], 1u << (8u * (kmin & 3u)));
+        const bool chunk_ok = n_hdr <= K && dst + total <= a.out_len && nblk <= 4096u && total <= DOTS_BYTES - 64u;
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            if (len[k] != 0u) {
+                s_off[rank] = excl;
+                s_adj[rank] = adj[k] - excl;
+                if (rank >= 1u && chunk_ok) {
+                    const uint32_t kmin = (excl + head + 15u) >> 4;    // first block starting at or after the task start
+                    if (kmin < nblk) atomicAdd(&s_map32[kmin >> 1], 1u << (16u * (kmin & 1u)));
+                }
+                ++rank;
             }
+            excl += len[k];
         }
         if (tid < 4u) { s_off[nz + tid] = total; s_adj[nz + tid] = dots16 - total; }   // sentinels past the last task
         lds_barrier();
 
-        // ---- C: per-lane 16 one-byte counters -> in-lane prefix sums ----
-        u32x4 y = *reinterpret_cast<const u32x4*>(&s_map32[4u * tid]);
-        y[0] *= 0x01010101u; y[1] *= 0x01010101u; y[2] *= 0x01010101u; y[3] *= 0x01010101u;
-        const uint32_t p1 = y[0] >> 24, p2 = p1 + (y[1] >> 24), p3 = p2 + (y[2] >> 24), tsum = p3 + (y[3] >> 24);
+        // ---- C: per-lane 16 two-byte counters -> in-lane prefix sums ----
+        uint32_t y[8], pre[8];
+        uint32_t tsum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            y[q] = s_map32[8u * tid + q] * 0x00010001u;          // low half: first counter, high half: sum of both
+            pre[q] = tsum;
+            tsum += y[q] >> 16;
+        }
         const uint32_t tincl = wave_incl_scan(tsum);
         if (lane == 63u) s_w[2][wid] = tincl;
         lds_barrier();
 
-        // ---- D: add the lanes/waves before; every byte stays < 256 because ranks are < 256 ----
+        // ---- D: add the lanes/waves before; ranks stay below 256*TPT < 65536 ----
         {
             const uint32_t m0 = s_w[2][0], m1 = s_w[2][1], m2 = s_w[2][2];
             const uint32_t mb = tincl - tsum + (wid > 0 ? m0 : 0u) + (wid > 1 ? m1 : 0u) + (wid > 2 ? m2 : 0u);
-            y[0] += mb * 0x01010101u; y[1] += (mb + p1) * 0x01010101u;
-            y[2] += (mb + p2) * 0x01010101u; y[3] += (mb + p3) * 0x01010101u;
-            *reinterpret_cast<u32x4*>(&s_map32[4u * tid]) = y;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s_map32[8u * tid + q] = y[q] + (mb + pre[q]) * 0x00010001u;
         }
         lds_barrier();
 
@@ -185,7 +206,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
             for (uint32_t b = tid; b < nblk; b += 256u) {
                 const int32_t rel = int32_t(b << 4) - int32_t(head);          // block start relative to dst
                 const uint32_t hi = uint32_t(rel + 16) < total ? uint32_t(rel + 16) : total;
-                uint32_t r = s_map[b];
+                uint32_t r = s_map[b];                 // two-byte entries
                 const uint32_t e0 = s_off[r + 1u], e1 = s_off[r + 2u], e2 = s_off[r + 3u];
                 const uint64_t a0 = s_adj[r], a1 = s_adj[r + 1u], a2 = s_adj[r + 2u];
                 const bool need1 = e0 < hi, need2 = e1 < hi;
@@ -193,11 +214,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
                 // the address path (TA) is the busiest unit of this kernel: lanes that do not need a
                 // second/third task stay masked off instead of gathering from a dummy address
                 u32x4 v, g1 = {0u, 0u, 0u, 0u}, g2 = {0u, 0u, 0u, 0u};
-                if (DBG == 3 || DBG == 4) {            // timing only: 16-byte (3) / 4-byte (4) aligned gathers
-                    const uint64_t am = DBG == 3 ? ~15ull : ~3ull;
-                    v = gather16((a0 + int64_t(rel)) & am);
-                    if (need1) g1 = gather16((a1 + int64_t(rel)) & am);
-                    if (need2) g2 = gather16((a2 + int64_t(rel)) & am);
+                if (false) {
                 } else if (DBG != 1) {
                     v = gather16(a0 + int64_t(rel));
                     if (need1) g1 = gather16(a1 + int64_t(rel));
@@ -396,12 +413,19 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     const int dbg = (nontemporal >> 16) & 0xFF;
     const uint32_t grid = grid_for(a.n_chunks, max_blocks ? max_blocks : 0x7FFFFFFFu);
     const uint32_t dyn = 0;
-    if (dbg == 1) hipLaunchKernelGGL((stitch_kernel<true, 1>), dim3(grid), dim3(256), dyn, stream, a);
-    else if (dbg == 2) hipLaunchKernelGGL((stitch_kernel<true, 2>), dim3(grid), dim3(256), dyn, stream, a);
-    else if (dbg == 3) hipLaunchKernelGGL((stitch_kernel<true, 3>), dim3(grid), dim3(256), dyn, stream, a);
-    else if (dbg == 4) hipLaunchKernelGGL((stitch_kernel<true, 4>), dim3(grid), dim3(256), dyn, stream, a);
-    else if (nt) hipLaunchKernelGGL((stitch_kernel<true, 0>), dim3(grid), dim3(256), dyn, stream, a);
-    else hipLaunchKernelGGL((stitch_kernel<false, 0>), dim3(grid), dim3(256), dyn, stream, a);
+    int tpt = (nontemporal >> 8) & 0xF;                 // bits 8..11: descriptors per lane (chunks hold <= 256*tpt tasks)
+    if (tpt == 0) tpt = STITCH_TASKS_PER_LANE;
+#define V2P_LAUNCH(TT) do { \
+        if (dbg == 1) hipLaunchKernelGGL((stitch_kernel<TT, true, 1>), dim3(grid), dim3(256), dyn, stream, a); \
+        else if (dbg == 2) hipLaunchKernelGGL((stitch_kernel<TT, true, 2>), dim3(grid), dim3(256), dyn, stream, a); \
+        else if (nt) hipLaunchKernelGGL((stitch_kernel<TT, true, 0>), dim3(grid), dim3(256), dyn, stream, a); \
+        else hipLaunchKernelGGL((stitch_kernel<TT, false, 0>), dim3(grid), dim3(256), dyn, stream, a); } while (0)
+    switch (tpt) {
+        case 1: V2P_LAUNCH(1); break;
+        case 2: V2P_LAUNCH(2); break;
+        default: V2P_LAUNCH(4); break;
+    }
+#undef V2P_LAUNCH
     return hipGetLastError();
 }
 

@@ -122,6 +122,7 @@ struct v2p_batch {
     uint64_t last_hdr_src = 0; uint32_t last_hdr_len = 0;
     DevBuf d_desc, d_chunks, d_payload, d_out, d_hap, d_digest, d_status;
     uint64_t n_desc = 0, n_chunks = 0, n_payload = 0, out_bytes = 0, n_haps = 0;
+    uint32_t max_chunk_tasks = 0;
 };
 
 #define HIP_TRY(ctx, expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return (ctx)->hip_fail(e__, what); } while (0)
@@ -330,7 +331,7 @@ int v2p_execute_gir(v2p_ctx* c,
         StitchArgs a{reinterpret_cast<const uint64_t*>(c->d_desc.ptr()), reinterpret_cast<const Chunk*>(c->d_chunks.ptr()),
                      uint32_t(img.chunks.size()), c->d_ref.ptr(), n_ref * E, c->d_alt.ptr(), n_alt * E,
                      c->d_res.ptr(), n_res * E, reinterpret_cast<unsigned long long*>(c->d_status.ptr())};
-        HIP_TRY(c, launch_stitch(a, c->stream, !(c->flags & V2P_FLAG_TEMPORAL), 0), "launch(stitch)");
+        HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | (tasks_per_lane_for(img.max_chunk_tasks) << 8), 0), "launch(stitch)");
         if (!gaps) {
             HIP_TRY(c, hipMemcpyAsync(res, c->d_res.ptr(), n_res * E, hipMemcpyDeviceToHost, c->stream), "D2H(res)");
             return collect_status(c, c->d_status);
@@ -628,6 +629,8 @@ int v2p_batch_finalize(v2p_batch* b)
     if (b->img.chunks.size() > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     b->n_desc = b->img.desc.size(); b->n_chunks = b->img.chunks.size(); b->n_payload = b->img.payload.size();
+    b->max_chunk_tasks = 0;
+    for (const Chunk& ch : b->img.chunks) { const uint32_t n = uint32_t(ch.dst_n >> 48); if (n > b->max_chunk_tasks) b->max_chunk_tasks = n; }
     b->out_bytes = b->img.out_size(); b->n_haps = b->img.n_haplotypes();
     HIP_TRY(c, b->d_desc.ensure(b->n_desc * 8), "hipMalloc(desc)");
     HIP_TRY(c, b->d_chunks.ensure(b->n_chunks * sizeof(Chunk)), "hipMalloc(chunks)");
@@ -660,7 +663,7 @@ int v2p_batch_execute(v2p_batch* b)
     StitchArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), reinterpret_cast<const Chunk*>(b->d_chunks.ptr()),
                  uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->d_payload.ptr(), b->n_payload,
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
-    HIP_TRY(c, launch_stitch(a, c->stream, !(c->flags & V2P_FLAG_TEMPORAL), 0), "launch(stitch)");
+    HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | (tasks_per_lane_for(b->max_chunk_tasks) << 8), 0), "launch(stitch)");
     return V2P_OK;
 }
 
@@ -818,7 +821,9 @@ int v2p_pipeline_submit(v2p_pipeline* p,
     StitchArgs a{reinterpret_cast<const uint64_t*>(s.d_desc.ptr()), reinterpret_cast<const Chunk*>(s.d_chunks.ptr()),
                  uint32_t(n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, s.d_payload.ptr(), n_payload,
                  s.d_out.ptr(), out_bytes, reinterpret_cast<unsigned long long*>(s.d_status.ptr())};
-    HIP_TRY(c, launch_stitch(a, s.stream, !(c->flags & V2P_FLAG_TEMPORAL), 0), "launch(stitch)");
+    uint32_t max_n = 0;
+    for (uint64_t i = 0; i < n_chunks; ++i) { const uint32_t n = uint32_t(chunks[i].dst_n >> 48); if (n > max_n) max_n = n; }
+    HIP_TRY(c, launch_stitch(a, s.stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | (tasks_per_lane_for(max_n) << 8), 0), "launch(stitch)");
     if (out_bytes) HIP_TRY(c, hipMemcpyAsync(s.h_out.p, s.d_out.ptr(), out_bytes, hipMemcpyDeviceToHost, s.stream), "D2H(out)");
     HIP_TRY(c, hipMemcpyAsync(s.h_out.p + ((out_bytes + 7) & ~7ull), s.d_status.ptr(), sizeof(unsigned long long), hipMemcpyDeviceToHost, s.stream), "D2H(status)");
     HIP_TRY(c, hipEventRecord(s.done, s.stream), "hipEventRecord");
