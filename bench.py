@@ -94,18 +94,26 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from vcf2prot_amd import _native as N
-    from vcf2prot_amd import build
-    build.build_all()
-    from vcf2prot_amd.cohort import Cohort
-
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the gpu engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    # native pieces: built once per node (local rank 0), everybody else waits
+    from vcf2prot_amd import build
+    if local_rank == 0:
+        build.build_all()
+        if not args.no_verify or not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import sir_oracle
+            sir_oracle.build_c_oracle()
+    if dist_on:
+        dist.barrier()
+    from vcf2prot_amd import _native as N
+    from vcf2prot_amd.cohort import Cohort
     lib = N.hip_lib()
 
     # ---- synthetic cohort at the Task boundary; this rank's shard --------------------
@@ -155,7 +163,7 @@ def main():
                                    (0 if args.temporal else 1) | ((args.tpt or img.tasks_per_lane) << 8) | (args.dbg << 16), args.max_blocks)
         if rc != 0:
             raise RuntimeError(f"v2p_stitch_launch failed: {rc}")
-        if world > 1:                                          # the path's only exchange: result sizes for the global offsets
+        if dist_on:                                            # the path's only exchange: result sizes for the global offsets
             dist.all_gather_into_tensor(all_sizes, sizes)
 
     for _ in range(max(args.warmup, 1) if not args.no_verify else args.warmup):
@@ -187,7 +195,7 @@ def main():
 
     # ---- timed region -------------------------------------------------------------
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -196,7 +204,7 @@ def main():
         launch()
         ev[k][1].record(stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b) for a, b in ev]
@@ -204,7 +212,7 @@ def main():
         sys.exit(f"device reported a task error: status={int(d_status.item()):#x}")
 
     tot = torch.tensor([elapsed, float(A), float(NT)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -243,7 +251,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cohort, os.cpu_count() or 1)
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
