@@ -305,3 +305,70 @@ def test_streamed_pipeline_matches_oracle(built, gpu_ctx, coracle):
             want = coracle.gir_execute_u8(t, c.ref_tape_u32(h).astype(np.uint8), hap.alt, np.full(hap.n_res, ord("."), dtype=np.uint8))
             a, b = int(img.hap_out_begin[i]), int(img.hap_out_begin[i + 1])
             assert np.array_equal(got[k][a:b], want), h
+
+
+def _adversarial_gir(rng, kind):
+    """Task vectors that stress the chunker and the block map."""
+    n_ref, n_alt = 70000, 5000
+    if kind == "tiny":            # thousands of 1-3 residue tasks: >256 tasks without reaching a 16-byte cut (ragged cuts)
+        ln = rng.integers(1, 4, size=6000)
+    elif kind == "zero_runs":     # long runs of zero-length tasks, whole chunks of them
+        ln = np.where(rng.random(5000) < 0.9, 0, rng.integers(1, 300, size=5000))
+        ln[1000:1700] = 0
+    elif kind == "mixed":         # bimodal: 1-residue alt tasks between long reference runs, some > 64 KiB/4 chars
+        ln = np.where(rng.random(3000) < 0.5, 1, rng.integers(100, 900, size=3000))
+        ln[::500] = 20000
+    elif kind == "block_edges":   # lengths that are multiples of 4 chars (16 bytes) and off-by-one around them
+        ln = rng.choice([3, 4, 5, 8, 12, 16, 1024, 1023, 1025], size=4000)
+    else:                         # "all_zero"
+        ln = np.zeros(700, dtype=np.int64)
+    ln = ln.astype(np.uint64)
+    n = ln.size
+    code = (rng.random(n) < 0.5).astype(np.uint8)
+    n_src = np.where(code == 0, n_ref, n_alt).astype(np.uint64)
+    ln = np.minimum(ln, n_src)
+    sp = (rng.random(n) * (n_src - ln + 1)).astype(np.uint64)
+    sp = np.minimum(sp, n_src - ln)
+    sr = np.concatenate([[0], np.cumsum(ln)[:-1]]).astype(np.uint64)
+    return dict(code=code, start_pos=sp, length=ln, start_pos_res=sr, n_res=int(ln.sum())), n_ref, n_alt
+
+
+@pytest.mark.parametrize("kind", ["tiny", "zero_runs", "mixed", "block_edges", "all_zero"])
+def test_adversarial_task_vectors(gpu_ctx, coracle, kind):
+    rng = np.random.default_rng({"tiny": 51, "zero_runs": 52, "mixed": 53, "block_edges": 54, "all_zero": 55}[kind])
+    g, n_ref, n_alt = _adversarial_gir(rng, kind)
+    ref, alt = random_tape(rng, n_ref), random_tape(rng, n_alt)
+    want = oracle_run(coracle, g, ref, alt)
+    res = np.full(g["n_res"], ord("."), dtype=np.uint32)
+    gpu_ctx.execute_gir(g["code"], g["start_pos"], g["length"], g["start_pos_res"], ref, alt, res)      # u32 tapes: offsets x4
+    assert np.array_equal(res, want)
+    b = gpu_ctx.batch()                                                                                # u8 image: odd byte offsets
+    for _ in range(3):
+        b.add_gir(g["code"], g["start_pos"], g["length"], g["start_pos_res"], ref, alt, g["n_res"])
+    b.finalize()
+    b.execute()
+    b.sync()
+    want8 = want.astype(np.uint8)
+    for h in range(3):
+        assert np.array_equal(b.download_hap(h), want8), (kind, h)
+    b.close()
+
+
+def test_empty_batch_and_empty_haplotypes(gpu_ctx):
+    b = gpu_ctx.batch()
+    b.finalize()
+    b.execute()
+    b.sync()
+    assert b.counts()["n_haps"] == 0 and b.counts()["out_bytes"] == 0
+    b.close()
+    b = gpu_ctx.batch()
+    e8, e64, e32 = np.zeros(0, np.uint8), np.zeros(0, np.uint64), np.zeros(0, np.uint32)
+    for _ in range(5):
+        b.add_gir(e8, e64, e64, e64, e32, e32, 0)
+    b.finalize()
+    b.execute()
+    b.sync()
+    assert b.counts()["n_haps"] == 5 and b.digests().tolist() == [0] * 5
+    b.close()
+    res = np.zeros(0, dtype=np.uint32)
+    gpu_ctx.execute_gir(e8, e64, e64, e64, e32, e32, res)      # empty GIR (start-lost only haplotype)
