@@ -40,7 +40,7 @@ constexpr uint64_t SRC_MASK   = (1ull << 40) - 1;
 constexpr uint32_t LEN_BITS   = 22;
 constexpr uint32_t LEN_MASK   = (1u << LEN_BITS) - 1;
 constexpr uint32_t CHUNK_TASKS = 256;          // descriptors per work item for long-run images (one per lane)
-constexpr uint32_t CHUNK_TASKS_DEEP = 1024;    // ... for deep Task vectors (< 32 result bytes per descriptor): 4 per lane
+constexpr uint32_t CHUNK_TASKS_DEEP = 1024;    // ... for images with < 100 result bytes per descriptor: 4 per lane
 constexpr uint32_t CHUNK_BYTES = 64u * 1024u - 16u;  // result bytes per work item (<= 4096 16-byte blocks incl. a ragged head)
 constexpr uint32_t CUT_ALIGN  = 4096;          // preferred chunk cut: 4 KiB multiples = full 256-lane passes of 16-byte blocks
 constexpr uint64_t DST_MASK   = (1ull << 48) - 1;
@@ -140,9 +140,9 @@ private:
         if (open_n_ == 0) return;
         chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_n_) << 48)});
         if (open_n_ > max_chunk_tasks) max_chunk_tasks = open_n_;
-        // measured on MI355X: ~250-task / ~34 KiB chunks are fastest for long runs (C2, C3); images with only a few
-        // result bytes per descriptor (C5: ~7) are set-up bound and run 27 % faster with 1024-task chunks
-        if (adaptive_tasks) chunk_tasks = (open_bytes_ / open_n_ >= 32u) ? CHUNK_TASKS : CHUNK_TASKS_DEEP;
+        // measured on MI355X (tools/ab.py): with >= ~130 result bytes per descriptor (C2) 256-task chunks are 2-3 %
+        // faster; below ~85 (C3, FASTA images, C5) 1024-task chunks win by 7 %, 11 % and 27 %
+        if (adaptive_tasks) chunk_tasks = (open_bytes_ / open_n_ >= 100u) ? CHUNK_TASKS : CHUNK_TASKS_DEEP;
         open_n_ = 0; open_bytes_ = 0;
     }
     void append(unsigned space, uint64_t src, uint32_t len) {
