@@ -1,3 +1,4 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-for w in C2 C3 C5; do python bench.py --no-cpu-baseline --steps 8 --workload $w 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); r=j['roofline']; print('$w ms',round(r['kernel_ms_avg'],3),'frac',round(r['frac'],3),'chunks',j['config']['chunks_per_gpu'],'tpt',j['config']['descriptors_per_lane'],'verified',j['verified'] is not None)"; done
-python bench.py --no-cpu-baseline --steps 8 --fasta 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); r=j['roofline']; print('C2 fasta ms',round(r['kernel_ms_avg'],3),'tpt',j['config']['descriptors_per_lane'])"
+for i in 1 2; do
+python tools/lib_batch_bench.py
+python bench.py --no-cpu-baseline --no-verify --steps 20 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('bench ms_per_step', round(j['ms_per_step'],3), 'kernel avg', round(j['roofline']['kernel_ms_avg'],3))"
+done

@@ -214,8 +214,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
                 // the address path (TA) is the busiest unit of this kernel: lanes that do not need a
                 // second/third task stay masked off instead of gathering from a dummy address
                 u32x4 v, g1 = {0u, 0u, 0u, 0u}, g2 = {0u, 0u, 0u, 0u};
-                if (false) {
-                } else if (DBG != 1) {
+                if (DBG != 1) {
                     v = gather16(a0 + int64_t(rel));
                     if (need1) g1 = gather16(a1 + int64_t(rel));
                     if (need2) g2 = gather16(a2 + int64_t(rel));

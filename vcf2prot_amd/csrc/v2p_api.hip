@@ -24,9 +24,12 @@ thread_local std::string g_init_error;
 struct DevBuf {
     uint8_t* base = nullptr;
     size_t cap = 0;
-    // n usable bytes at ptr(), with PAD_BYTES readable before and after
+    // n usable bytes at ptr(), with at least PAD_BYTES readable before and after.  The front pad is a
+    // whole 256 bytes so ptr() keeps hipMalloc's alignment: result arenas must start on a cache line
+    // (a 1 KiB wave store that straddles lines turns into partial-line writes).
+    static constexpr size_t FRONT = 256;
     hipError_t ensure(size_t n) {
-        const size_t need = n + 2 * PAD_BYTES;
+        const size_t need = n + FRONT + PAD_BYTES;
         if (need <= cap) return hipSuccess;
         if (base) { (void)hipFree(base); base = nullptr; cap = 0; }
         size_t want = need + need / 4;
@@ -35,7 +38,7 @@ struct DevBuf {
         if (e == hipSuccess) cap = want;
         return e;
     }
-    uint8_t* ptr() const { return base ? base + PAD_BYTES : nullptr; }
+    uint8_t* ptr() const { return base ? base + FRONT : nullptr; }
     void release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; }
 };
 
