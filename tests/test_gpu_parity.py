@@ -372,3 +372,5 @@ def test_empty_batch_and_empty_haplotypes(gpu_ctx):
     b.close()
     res = np.zeros(0, dtype=np.uint32)
     gpu_ctx.execute_gir(e8, e64, e64, e64, e32, e32, res)      # empty GIR (start-lost only haplotype)
+    z = np.zeros(3, dtype=np.uint64)                          # only zero-length tasks, empty result tape
+    gpu_ctx.execute_gir(np.array([0, 1, 0], np.uint8), z, z, z, e32, e32, res)

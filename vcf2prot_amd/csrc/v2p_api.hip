@@ -336,13 +336,13 @@ int v2p_execute_gir(v2p_ctx* c,
                      c->d_res.ptr(), n_res * E, reinterpret_cast<unsigned long long*>(c->d_status.ptr())};
         HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | (tasks_per_lane_for(img.max_chunk_tasks) << 8), 0), "launch(stitch)");
         if (!gaps) {
-            HIP_TRY(c, hipMemcpyAsync(res, c->d_res.ptr(), n_res * E, hipMemcpyDeviceToHost, c->stream), "D2H(res)");
+            if (n_res) HIP_TRY(c, hipMemcpyAsync(res, c->d_res.ptr(), n_res * E, hipMemcpyDeviceToHost, c->stream), "D2H(res)");
             return collect_status(c, c->d_status);
         }
         // cells no task covers keep the caller's content: bring the tape back to a
         // staging buffer and copy only the covered ranges
         HIP_TRY(c, c->h_stage.ensure(n_res * E), "hipHostMalloc(stage)");
-        HIP_TRY(c, hipMemcpyAsync(c->h_stage.p, c->d_res.ptr(), n_res * E, hipMemcpyDeviceToHost, c->stream), "D2H(res)");
+        if (n_res) HIP_TRY(c, hipMemcpyAsync(c->h_stage.p, c->d_res.ptr(), n_res * E, hipMemcpyDeviceToHost, c->stream), "D2H(res)");
         rc = collect_status(c, c->d_status);
         if (rc) return rc;
         const uint32_t* st = reinterpret_cast<const uint32_t*>(c->h_stage.p);
@@ -359,11 +359,11 @@ int v2p_execute_gir(v2p_ctx* c,
     HIP_TRY(c, hipMemcpyAsync(d + n8, length, n8, hipMemcpyHostToDevice, c->stream), "H2D(length)");
     HIP_TRY(c, hipMemcpyAsync(d + 2 * n8, start_pos_res, n8, hipMemcpyHostToDevice, c->stream), "H2D(start_pos_res)");
     HIP_TRY(c, hipMemcpyAsync(d + 3 * n8, code, n_tasks, hipMemcpyHostToDevice, c->stream), "H2D(code)");
-    HIP_TRY(c, hipMemcpyAsync(c->d_res.ptr(), res, n_res * E, hipMemcpyHostToDevice, c->stream), "H2D(res)");
+    if (n_res) HIP_TRY(c, hipMemcpyAsync(c->d_res.ptr(), res, n_res * E, hipMemcpyHostToDevice, c->stream), "H2D(res)");
     OrderedArgs oa{d + 3 * n8, reinterpret_cast<const uint64_t*>(d), reinterpret_cast<const uint64_t*>(d + n8),
                    reinterpret_cast<const uint64_t*>(d + 2 * n8), n_tasks, c->d_ref.ptr(), c->d_alt.ptr(), c->d_res.ptr(), E};
     HIP_TRY(c, launch_ordered(oa, c->stream), "launch(ordered)");
-    HIP_TRY(c, hipMemcpyAsync(res, c->d_res.ptr(), n_res * E, hipMemcpyDeviceToHost, c->stream), "D2H(res)");
+    if (n_res) HIP_TRY(c, hipMemcpyAsync(res, c->d_res.ptr(), n_res * E, hipMemcpyDeviceToHost, c->stream), "D2H(res)");
     HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     return V2P_OK;
 }
