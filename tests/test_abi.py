@@ -24,6 +24,18 @@ def test_hip_library_exports_every_declared_symbol(built):
     assert set(names) == set(N.HIP_API), "python binding table out of sync with the header"
 
 
+def test_host_library_exports_every_declared_symbol(built):
+    """include/v2p_cohort.h and include/v2p_step4b.h live in libv2p_cohort.so (plain C++, no HIP)."""
+    from vcf2prot_amd import _native as N
+    from vcf2prot_amd._cohort_api import COHORT_API
+    lib = ctypes.CDLL(N.COHORT_LIB_PATH)
+    names = _declared("v2p_cohort.h") + _declared("v2p_step4b.h")
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared but not exported"
+    assert set(names) == set(COHORT_API), "python binding table out of sync with the headers"
+
+
 def test_engine_from_str_is_engines_rs(built):
     # engines.rs:17-29
     from vcf2prot_amd.engine import Engine

@@ -31,6 +31,14 @@ def test_reference_unit_test_task_tuples(built):
     assert rc == 0 and tasks.tolist() == [[0, 0, 488, 0], [1, 0, 1, 488]] and alt == b"S" and res_len == 489
 
 
+def test_expected_result_array_length_kat(built):
+    """transcript_instructions.rs:790-804: frameshift 40VGLHFWTM*>40VDSTFGQC on a 50-residue reference -> 47."""
+    from vcf2prot_amd.step4b import transcript_g_rep
+    rc, tasks, alt, res_len = transcript_g_rep([dict(code="F", s_state=False, pos_ref=39, pos_res=39, len=8, data="VDSTFGQC")], 50)
+    assert rc == 0 and res_len == 47 and alt == b"VDSTFGQC"
+    assert tasks.tolist() == [[0, 0, 39, 0], [1, 0, 8, 39]]      # :806-822: the frameshift task copies all 8 payload residues
+
+
 def test_error_paths(built):
     from vcf2prot_amd.step4b import transcript_g_rep
     fs = dict(code="F", s_state=False, pos_ref=9, pos_res=9, len=3, data="VAB")
