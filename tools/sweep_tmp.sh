@@ -1,4 +1,4 @@
-for i in 1 2; do
-python tools/lib_batch_bench.py
-python bench.py --no-cpu-baseline --no-verify --steps 20 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('bench ms_per_step', round(j['ms_per_step'],3), 'kernel avg', round(j['roofline']['kernel_ms_avg'],3))"
+for v in old new old new; do
+cp tools/variants/$v.hip vcf2prot_amd/csrc/stitch_kernels.hip; python -m vcf2prot_amd.build > /dev/null 2>&1
+echo "== $v"; python tools/ab.py --rounds 9 "dbg=0" | tail -1
 done

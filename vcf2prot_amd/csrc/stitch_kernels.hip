@@ -99,8 +99,18 @@ __device__ __forceinline__ void lds_barrier()
 // TPT = descriptors per lane: a chunk holds up to 256*TPT tasks.  The per-chunk set-up (two
 // dependent HBM latencies, four barriers) is the same for any TPT, so larger chunks amortise it.
 template <int TPT, bool NT, int DBG = 0>
-__global__ __launch_bounds__(256) void stitch_kernel(StitchArgs a)
+__global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict__ p_desc, const Chunk* __restrict__ p_chunks,
+                                                     const uint8_t* __restrict__ p_src0, const uint8_t* __restrict__ p_src1,
+                                                     uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
+                                                     const uint8_t* __restrict__ p_dots,
+                                                     uint32_t n_chunks, uint64_t src0_len, uint64_t src1_len, uint64_t out_len)
 {
+    // explicit __restrict__ pointers (not a by-value struct): the chunk header becomes a scalar
+    // (s_load) access, because the compiler can prove the result stores never clobber the inputs
+    struct { const uint64_t* desc; const Chunk* chunks; uint32_t n_chunks; const uint8_t* src0; uint64_t src0_len;
+             const uint8_t* src1; uint64_t src1_len; uint8_t* out; uint64_t out_len; unsigned long long* status; const uint8_t* dots; }
+        a{p_desc, p_chunks, n_chunks, p_src0, src0_len, p_src1, src1_len, p_out, out_len, p_status, p_dots};
+
     constexpr uint32_t K = 256u * TPT;
     __shared__ __attribute__((aligned(16))) uint32_t s_map32[2048 + 8];     // 4096 two-byte block->rank entries
     __shared__ uint64_t s_adj[K + 8];
@@ -414,17 +424,19 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     const uint32_t dyn = 0;
     int tpt = (nontemporal >> 8) & 0xF;                 // bits 8..11: descriptors per lane (chunks hold <= 256*tpt tasks)
     if (tpt == 0) tpt = STITCH_TASKS_PER_LANE;
+#define V2P_KARGS a.desc, a.chunks, a.src0, a.src1, a.out, a.status, a.dots, a.n_chunks, a.src0_len, a.src1_len, a.out_len
 #define V2P_LAUNCH(TT) do { \
-        if (dbg == 1) hipLaunchKernelGGL((stitch_kernel<TT, true, 1>), dim3(grid), dim3(256), dyn, stream, a); \
-        else if (dbg == 2) hipLaunchKernelGGL((stitch_kernel<TT, true, 2>), dim3(grid), dim3(256), dyn, stream, a); \
-        else if (nt) hipLaunchKernelGGL((stitch_kernel<TT, true, 0>), dim3(grid), dim3(256), dyn, stream, a); \
-        else hipLaunchKernelGGL((stitch_kernel<TT, false, 0>), dim3(grid), dim3(256), dyn, stream, a); } while (0)
+        if (dbg == 1) hipLaunchKernelGGL((stitch_kernel<TT, true, 1>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
+        else if (dbg == 2) hipLaunchKernelGGL((stitch_kernel<TT, true, 2>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
+        else if (nt) hipLaunchKernelGGL((stitch_kernel<TT, true, 0>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
+        else hipLaunchKernelGGL((stitch_kernel<TT, false, 0>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); } while (0)
     switch (tpt) {
         case 1: V2P_LAUNCH(1); break;
         case 2: V2P_LAUNCH(2); break;
         default: V2P_LAUNCH(4); break;
     }
 #undef V2P_LAUNCH
+#undef V2P_KARGS
     return hipGetLastError();
 }
 
