@@ -223,6 +223,10 @@ int v2p_order_chunks_for_xcds(v2p_chunk* chunks, uint64_t n_chunks, const uint64
 int v2p_digest_launch(void* hip_stream, const uint8_t* d_out, const uint64_t* d_hap_begin, uint64_t n_haps,
                       uint64_t out_bytes, uint64_t* d_digests);
 int v2p_fill_launch(void* hip_stream, uint8_t* d_out, uint64_t bytes, uint32_t word, int nontemporal);
+/* microbenchmark: `blocks` workgroups x 4 waves each issue `iters` 16-byte-per-lane gathers (1 KiB per wave
+ * instruction) from a window of `window` bytes at byte misalignment `misalign` (0 = aligned); d_sink: one u32 per wave */
+int v2p_gather_bench_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t misalign, uint32_t iters,
+                            uint32_t blocks, uint32_t* d_sink);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""In-kernel s_memtime stamps of the stitch kernel (diagnostic build, DBG=20): where a workgroup's
+lifetime goes.  Never quote this build's run time; read the shares."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from vcf2prot_amd import _native as N
+from vcf2prot_amd.cohort import Cohort
+lib = N.hip_lib(); dev = torch.device("cuda", 0)
+c = Cohort.preset("C2", n_samples=1000)
+img = c.pack(0, c.n_haplotypes, n_threads=64)
+prot = c.proteome()
+chunks = np.ascontiguousarray(img.chunks)
+lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, prot.size)
+def padded(a):
+    t = torch.zeros(a.size + 32, dtype=torch.uint8, device=dev); t[16:16 + a.size] = torch.from_numpy(a).to(dev); return t
+d_prot, d_pay = padded(prot), padded(img.payload)
+d_desc = torch.from_numpy(img.desc.view(np.int64)).to(dev); d_chunks = torch.from_numpy(chunks.view(np.int64)).to(dev)
+nch = chunks.shape[0]
+dbg_bytes = nch * 4 * 64
+d_out = torch.zeros(img.out_bytes + 512 + dbg_bytes, dtype=torch.uint8, device=dev)
+d_status = torch.full((1,), -1, dtype=torch.int64, device=dev)
+s = torch.cuda.current_stream().cuda_stream
+for flags in (1, 1 | (20 << 16)):
+    lib.v2p_stitch_launch(ctypes.c_void_p(s), d_desc.data_ptr(), d_chunks.data_ptr(), nch, d_prot.data_ptr() + 16, prot.size,
+                          d_pay.data_ptr() + 16, img.payload.size, d_out.data_ptr(), img.out_bytes, d_status.data_ptr(), flags | (1 << 8), 0)
+torch.cuda.synchronize()
+off = (img.out_bytes + 255) // 256 * 256
+st = d_out[off:off + dbg_bytes].cpu().numpy().view(np.uint64).reshape(nch, 4, 8).astype(np.int64)
+t0, t1, t2, t3, t4 = (st[:, :, k] for k in range(5))
+ok = (t4 > t0).all(axis=1)
+print("chunks stamped:", int(ok.sum()), "of", nch)
+def show(name, x):
+    x = x[ok].reshape(-1)
+    print(f"{name:34s} median {np.median(x):9.0f}  mean {x.mean():9.0f}  p90 {np.percentile(x, 90):9.0f} cycles")
+show("entry -> descriptors arrived", t1 - t0)
+show("descriptors -> tables ready (A-D)", t2 - t1)
+show("K2: tables ready -> last store issued", t3 - t2)
+show("last store issued -> stores acked", t4 - t3)
+show("whole wave", t4 - t0)
+show("K2 sum: block lookup (LDS chain)", st[:, :, 5])
+show("K2 sum: gather issue -> data", st[:, :, 6])
+show("K2 sum: merge + store issue", st[:, :, 7])

@@ -78,6 +78,7 @@ HIP_API = {
                                   c_void_p, c_uint64, c_void_p, c_int, c_uint32]),
     "v2p_order_chunks_for_xcds": (c_int, [c_void_p, c_uint64, c_void_p, c_uint64, c_uint64]),
     "v2p_digest_launch": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
+    "v2p_gather_bench_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_uint32, c_uint32, c_void_p]),
     "v2p_fill_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_int]),
 }
 

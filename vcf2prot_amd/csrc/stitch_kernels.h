@@ -64,6 +64,8 @@ hipError_t launch_stitch(const StitchArgs& a, hipStream_t stream, int nontempora
 hipError_t launch_ordered(const OrderedArgs& a, hipStream_t stream);
 hipError_t launch_validate(const ValidateArgs& a, hipStream_t stream);
 hipError_t launch_digest(const DigestArgs& a, uint64_t out_bytes, hipStream_t stream);
+hipError_t launch_gather_bench(const uint8_t* src, uint64_t window, uint32_t misalign, uint32_t iters, uint32_t blocks,
+                               uint32_t* sink, hipStream_t stream);
 hipError_t launch_fill(uint8_t* out, uint64_t bytes, uint32_t word, int nontemporal, hipStream_t stream);
 
 }  // namespace v2p

@@ -121,6 +121,8 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
     const uint16_t* const s_map = reinterpret_cast<const uint16_t*>(s_map32);
     const uint64_t dots16 = reinterpret_cast<uint64_t>(a.dots) + 16u;
 
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, acc_lds = 0, acc_wait = 0, acc_rest = 0;
+    if (DBG == 20) st0 = __builtin_amdgcn_s_memtime();
     for (uint32_t c = blockIdx.x; c < a.n_chunks; c += gridDim.x) {
         if (c != blockIdx.x) lds_barrier();            // LDS is reused by the next chunk
         const uint64_t tb = a.chunks[c].task_begin;
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) s_map32[8u * tid + q] = 0u;
+        if (DBG == 20) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st1 = __builtin_amdgcn_s_memtime(); }
         const uint32_t incl = wave_incl_scan(lsum);
         const uint32_t nzincl = wave_incl_scan(lnz);
         if (lane == 63u) { s_w[0][wid] = incl; s_w[1][wid] = nzincl; }
@@ -208,12 +211,15 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
         }
         lds_barrier();
 
+        if (DBG == 20) st2 = __builtin_amdgcn_s_memtime();
         if (!chunk_ok) {                                      // never write out of bounds
             if (tid == 0) report(a.status, tb, STATUS_RES_OOB);
         } else {
             // ---- K2 ----
             uint8_t* const out0 = a.out + (dst - head);
             for (uint32_t b = tid; b < nblk; b += 256u) {
+                unsigned long long k0 = 0, k1 = 0, k2 = 0;
+                if (DBG == 20) k0 = __builtin_amdgcn_s_memtime();
                 const int32_t rel = int32_t(b << 4) - int32_t(head);          // block start relative to dst
                 const uint32_t hi = uint32_t(rel + 16) < total ? uint32_t(rel + 16) : total;
                 uint32_t r = s_map[b];                 // two-byte entries
@@ -224,10 +230,12 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                 // the address path (TA) is the busiest unit of this kernel: lanes that do not need a
                 // second/third task stay masked off instead of gathering from a dummy address
                 u32x4 v, g1 = {0u, 0u, 0u, 0u}, g2 = {0u, 0u, 0u, 0u};
+                if (DBG == 20) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); k1 = __builtin_amdgcn_s_memtime(); }
                 if (DBG != 1) {
                     v = gather16(a0 + int64_t(rel));
                     if (need1) g1 = gather16(a1 + int64_t(rel));
                     if (need2) g2 = gather16(a2 + int64_t(rel));
+                    if (DBG == 20) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k2 = __builtin_amdgcn_s_memtime(); }
                 } else {
                     v = u32x4{uint32_t(a0), e0, r, hi};
                     g1 = u32x4{uint32_t(a1), e1, r, hi};
@@ -259,6 +267,16 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                     for (uint32_t j = 0; j < 16u; ++j)
                         if (j >= ka && j < kb) o[j] = uint8_t(v[j >> 2] >> (8u * (j & 3u)));
                 }
+                if (DBG == 20) { const unsigned long long k3 = __builtin_amdgcn_s_memtime(); acc_lds += k1 - k0; acc_wait += k2 - k1; acc_rest += k3 - k2; }
+            }
+        }
+        if (DBG == 20) {
+            st3 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long st4 = __builtin_amdgcn_s_memtime();
+            if (lane == 0u) {
+                unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.out + ((a.out_len + 255ull) & ~255ull)) + (uint64_t(c) * 4u + wid) * 8u;
+                dbg[0] = st0; dbg[1] = st1; dbg[2] = st2; dbg[3] = st3; dbg[4] = st4; dbg[5] = acc_lds; dbg[6] = acc_wait; dbg[7] = acc_rest;
             }
         }
     }
@@ -383,6 +401,33 @@ __global__ __launch_bounds__(256) void fill_kernel(uint8_t* out, uint64_t n16, u
     }
 }
 
+// gather_bench_kernel: 16-byte-per-lane gathers from an L2-resident window at a chosen misalignment
+// (address path / L1 ceiling the stitch kernel's gathers are compared against).
+__global__ __launch_bounds__(256) void gather_bench_kernel(const uint8_t* __restrict__ src, uint64_t window, uint32_t misalign,
+                                                           uint32_t iters, uint32_t* __restrict__ sink)
+{
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    uint64_t off = (uint64_t(wave) * 4096ull) % window;
+    for (uint32_t i = 0; i < iters; i += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t o = (off + uint64_t(u) * 1024ull + lane * 16u) % (window - 64u);
+            const u32x4 v = gather16(reinterpret_cast<uint64_t>(src) + o + misalign);
+            acc[0] ^= v[0]; acc[1] ^= v[1]; acc[2] ^= v[2]; acc[3] ^= v[3];
+        }
+        off = (off + 4096ull * 17ull) % window;
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[wave] = acc[0];
+}
+
+hipError_t launch_gather_bench(const uint8_t* src, uint64_t window, uint32_t misalign, uint32_t iters, uint32_t blocks,
+                               uint32_t* sink, hipStream_t stream)
+{
+    hipLaunchKernelGGL(gather_bench_kernel, dim3(blocks), dim3(256), 0, stream, src, window, misalign, iters, sink);
+    return hipGetLastError();
+}
+
 // ---- launchers (host) -------------------------------------------------------
 static inline uint32_t grid_for(uint64_t work_items, uint32_t cap)
 {
@@ -428,6 +473,7 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
 #define V2P_LAUNCH(TT) do { \
         if (dbg == 1) hipLaunchKernelGGL((stitch_kernel<TT, true, 1>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
         else if (dbg == 2) hipLaunchKernelGGL((stitch_kernel<TT, true, 2>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
+        else if (dbg == 20) hipLaunchKernelGGL((stitch_kernel<TT, true, 20>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
         else if (nt) hipLaunchKernelGGL((stitch_kernel<TT, true, 0>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
         else hipLaunchKernelGGL((stitch_kernel<TT, false, 0>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); } while (0)
     switch (tpt) {
