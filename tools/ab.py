@@ -22,6 +22,45 @@ from vcf2prot_amd import _native as N  # noqa: E402
 from vcf2prot_amd.cohort import Cohort  # noqa: E402
 
 
+def l1_order(chunks, desc, n_prot, R, n_xcd=8):
+    """Experiment: XCD slices as usual, but every (haplotype, slice) run is padded with empty chunks to a multiple
+    of R entries, so that workgroups R*8 apart in launch order work on the same proteome region of consecutive
+    haplotypes (candidates for sharing a CU and its L1)."""
+    tb = chunks[:, 0].astype(np.int64)
+    key = np.zeros(tb.size, dtype=np.int64)
+    found = np.zeros(tb.size, dtype=bool)
+    for k in range(4):
+        d = desc[np.minimum(tb + k, desc.size - 1)]
+        is_ref = ((d >> np.uint64(62)) == 0) & ((d & np.uint64((1 << 40) - 1)) < np.uint64(n_prot))
+        take = is_ref & ~found
+        key[take] = (d[take] & np.uint64((1 << 40) - 1)).astype(np.int64)
+        found |= is_ref
+    per = (n_prot + n_xcd - 1) // n_xcd
+    bucket = np.minimum(key // per, n_xcd - 1)
+    seqs = []
+    for x in range(n_xcd):
+        idx = np.nonzero(bucket == x)[0]
+        k = key[idx]
+        starts = np.concatenate([[0], np.nonzero(np.diff(k) < 0)[0] + 1, [idx.size]])
+        out = []
+        for a, b in zip(starts[:-1], starts[1:]):
+            run = idx[a:b]
+            pad = (-run.size) % R
+            out.append(run)
+            if pad:
+                out.append(np.full(pad, -1, dtype=np.int64))
+        seqs.append(np.concatenate(out) if out else np.zeros(0, np.int64))
+    L = max(s.size for s in seqs)
+    grid = np.full((L, n_xcd), -1, dtype=np.int64)
+    for x, sq in enumerate(seqs):
+        grid[:sq.size, x] = sq
+    order = grid.reshape(-1)
+    res = np.zeros((order.size, 2), dtype=np.uint64)
+    ok = order >= 0
+    res[ok] = chunks[order[ok]]
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("variants", nargs="+")
@@ -45,7 +84,9 @@ def main():
         pack = {k: int(kv[k]) for k in ("chunk_tasks", "chunk_bytes", "cut_align", "soft_window") if k in kv}
         img = cohort.pack(0, cohort.n_haplotypes, n_threads=min(64, os.cpu_count() or 1), fasta=bool(int(kv.get("fasta", 0))), **pack)
         chunks = np.ascontiguousarray(img.chunks)
-        if int(kv.get("xcd", 1)):
+        if int(kv.get("l1", 0)):
+            chunks = l1_order(chunks, img.desc, n_prot, int(kv["l1"]))
+        elif int(kv.get("xcd", 1)):
             lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, n_prot)
         d_pay = torch.zeros(img.payload.size + 32, dtype=torch.uint8, device=dev)
         d_pay[16:16 + img.payload.size] = torch.from_numpy(img.payload).to(dev)

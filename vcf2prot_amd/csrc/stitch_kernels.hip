@@ -243,16 +243,22 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                 }
                 v = overwrite_tail(v, g1, uint32_t(int32_t(e0) - rel), need1);
                 v = overwrite_tail(v, g2, uint32_t(int32_t(e1) - rel), need2);
-                if (e2 < hi) {                                 // four or more tasks cut this block
-                    uint32_t pos = e2;
+                if (e2 < hi) {                                 // four or more tasks cut this block: three more per round,
+                    uint32_t pos = e2;                         // their gathers in flight together
                     r += 3u;
                     while (pos < hi) {
-                        const uint64_t aj = s_adj[r];
-                        const uint32_t o1 = s_off[r + 1u];
-                        const u32x4 g = gather16(aj + int64_t(rel));
-                        v = overwrite_tail(v, g, uint32_t(int32_t(pos) - rel), true);
-                        pos = o1;
-                        ++r;
+                        const uint32_t o1 = s_off[r + 1u], o2 = s_off[r + 2u], o3 = s_off[r + 3u];
+                        const uint64_t b0 = s_adj[r], b1 = s_adj[r + 1u], b2 = s_adj[r + 2u];
+                        const bool n1 = o1 < hi, n2 = o2 < hi;
+                        const u32x4 h0 = gather16(b0 + int64_t(rel));
+                        u32x4 h1 = {0u, 0u, 0u, 0u}, h2 = {0u, 0u, 0u, 0u};
+                        if (n1) h1 = gather16(b1 + int64_t(rel));
+                        if (n2) h2 = gather16(b2 + int64_t(rel));
+                        v = overwrite_tail(v, h0, uint32_t(int32_t(pos) - rel), true);
+                        v = overwrite_tail(v, h1, uint32_t(int32_t(o1) - rel), n1);
+                        v = overwrite_tail(v, h2, uint32_t(int32_t(o2) - rel), n2);
+                        pos = o3;                              // >= hi unless all three tasks ended inside the block
+                        r += 3u;
                     }
                 }
                 uint8_t* o = out0 + (uint64_t(b) << 4);
