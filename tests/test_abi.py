@@ -36,6 +36,19 @@ def test_host_library_exports_every_declared_symbol(built):
     assert set(names) == set(COHORT_API), "python binding table out of sync with the headers"
 
 
+def test_frontend_header_symbols_are_exported(built):
+    """include/v2p_frontend.h: the decode lives in the HIP library, the record index and the grouping in the host library."""
+    from vcf2prot_amd import _native as N
+    from vcf2prot_amd.frontend import DECODE_API, HOST_API
+    names = _declared("v2p_frontend.h")
+    hip, host = ctypes.CDLL(N.HIP_LIB_PATH), ctypes.CDLL(N.COHORT_LIB_PATH)
+    assert len(names) >= 30
+    for n in names:
+        lib = hip if n.startswith("v2p_decode_") else host
+        assert hasattr(lib, n), f"{n} declared in include/v2p_frontend.h but not exported"
+    assert set(names) == set(DECODE_API) | set(HOST_API), "python binding table out of sync with the header"
+
+
 def test_engine_from_str_is_engines_rs(built):
     # engines.rs:17-29
     from vcf2prot_amd.engine import Engine

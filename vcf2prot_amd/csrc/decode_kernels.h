@@ -1,0 +1,55 @@
+// decode_kernels.h -- argument block and host launcher of the BCSQ bitmask decode (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace v2p {
+
+// reasons in the low byte of the decode status word
+enum : uint32_t {
+    DEC_MASK_NEGATIVE = 1,     // text_parser.rs:210,244
+    DEC_MASK_PARSE = 2,        // MaskDecoder.rs:41,47
+    DEC_MASK_INDEX = 3,        // vcf_ds.rs:321,324
+    DEC_COLUMNS = 4,           // vcf_ds.rs:148
+    DEC_FIELD_TOO_LONG = 5,
+    DEC_CAPACITY = 6
+};
+
+constexpr uint32_t DEC_ROWBLOCK = 256;      // records per row block (count / emit granularity)
+constexpr uint32_t DEC_TILE = 4096;         // text bytes per parse step of one workgroup
+constexpr uint32_t DEC_EMIT_SAMPLES = 32;   // sample columns per emit workgroup
+constexpr uint32_t DEC_MULTI = 0x80000000u; // mask-matrix entry: bit 31 set -> low 31 bits index the multi-word list
+
+struct DecodeArgs {
+    const uint8_t*  text;          // 16 readable bytes either side
+    uint64_t        n_text;
+    const uint64_t* row_begin;     // [n_rows]
+    const uint64_t* row_end;       // [n_rows]
+    uint32_t        n_rows;
+    uint32_t        n_samples;
+    const uint32_t* csq_begin;     // [n_rows + 1]
+    const uint32_t* sup_pairs;     // [n_rows]
+    const uint32_t* sup_bits;      // bitset over consequence ids
+    // workspace
+    uint32_t*       masks;         // [n_rows][n_samples] filtered first word, or DEC_MULTI | offset into ovf
+    uint32_t*       cnt;           // [n_rowblocks][2*n_samples] per-block counts, then exclusive prefix down the blocks
+    uint32_t*       ovf;           // multi-word list: {n_words, words...} records
+    uint64_t        ovf_capacity;  // in u32 words
+    unsigned long long* ovf_used;  // device counter
+    // outputs
+    uint64_t*       hap_begin;     // [2*n_samples + 1]
+    uint32_t*       ids;
+    uint64_t        ids_capacity;
+    unsigned long long* status;    // [0] min((row*n_samples + sample) << 8 | reason), [1] multi-word words needed
+};
+
+struct DecodeLayout {
+    uint64_t masks_off, cnt_off, ovf_off, ovf_used_off, total;
+    uint32_t n_rowblocks;
+};
+DecodeLayout decode_layout(uint64_t n_rows, uint64_t n_samples, uint64_t ovf_words);
+
+// phases: bit 0 parse, bit 1 count, bit 2 scan, bit 3 emit
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, unsigned phases);
+
+}  // namespace v2p

@@ -1,0 +1,431 @@
+// decode_kernels.hip -- BCSQ bitmask decode on gfx950.
+//
+// What the reference does per proband (vcf_ds.rs:192-329): split every record line at tabs, take the proband's
+// column, keep the text after its last ':' (text_parser.rs:163-197), read it as one or more 32-bit words
+// (MaskDecoder.rs:33-51), turn bit pairs into consequence indices (MaskDecoder.rs:95-153), index the record's
+// consequence list (vcf_ds.rs:311-327) and keep supported types (vcf_ds.rs:262-292).  Result: per haplotype the list of
+// consequences in record order.  Here the whole table is done in four streaming passes, HBM-bound, no MFMA:
+//
+//   parse   one workgroup per record.  The record's sample columns stream through a two-tile LDS ring, 16 B per lane
+//           per step; tab positions are found with byte SWAR, ranked with a wave64 DPP scan, and lane j then owns the
+//           j-th column that ENDS in the tile: it walks back to the last ':' and parses the words.  Output: one u32
+//           per (record, sample), already filtered to supported consequences.  Multi-word masks (records with more
+//           than 15 consequences) go to a side list.
+//   count   per (256-record block, haplotype) popcounts, coalesced over samples.
+//   scan    exclusive prefix down the record blocks per haplotype, then over haplotypes: every (block, haplotype)
+//           knows where its ids go.
+//   emit    a workgroup transposes a 256-record x 32-sample tile through LDS; a wave takes one haplotype column,
+//           lane = record, DPP scan of the popcounts, and writes that haplotype's ids as one contiguous run.
+#include "decode_kernels.h"
+
+namespace v2p {
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t dec_wave_incl_scan(uint32_t x)
+{
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x143, 0xc, 0xf, false);  // row_bcast:31
+    return x;
+}
+
+__device__ __forceinline__ void dec_report(unsigned long long* status, uint64_t field, uint32_t reason)
+{
+    atomicMin(status, (static_cast<unsigned long long>(field) << 8) | reason);
+}
+
+// 4-bit mask of the bytes of w equal to '\t'
+__device__ __forceinline__ uint32_t tab_bits(uint32_t w)
+{
+    const uint32_t y = w ^ 0x09090909u;
+    const uint32_t z = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);     // 0x80 in every zero byte of y, exact
+    const uint32_t x = z >> 7;
+    return (x | (x >> 7) | (x >> 14) | (x >> 21)) & 0xFu;
+}
+
+struct Num { bool valid; bool neg; uint64_t val; };
+
+constexpr uint32_t RING = 2u * DEC_TILE;
+
+__device__ __forceinline__ uint8_t rq(const uint8_t* ring, uint32_t q) { return ring[q & (RING - 1u)]; }
+
+// Rust integer from_str on ring[b, e): optional sign, at least one digit, digits only (value saturates far above u32)
+__device__ __forceinline__ Num parse_num(const uint8_t* ring, uint32_t b, uint32_t e)
+{
+    Num n{false, false, 0};
+    if (b < e) {
+        const uint8_t c = rq(ring, b);
+        if (c == '+' || c == '-') { n.neg = (c == '-'); ++b; }
+    }
+    if (b >= e) return n;
+    uint64_t v = 0;
+    for (uint32_t q = b; q < e; ++q) {
+        const uint32_t d = uint32_t(rq(ring, q)) - uint32_t('0');
+        if (d > 9u) return n;
+        v = v * 10u + d;
+        if (v > (1ull << 40)) v = 1ull << 40;
+    }
+    n.valid = true;
+    n.val = v;
+    return n;
+}
+
+// text_parser::parse_fields + BitMask::from_string on one element: 0 = no consequences; aborts reported through err
+__device__ __forceinline__ uint32_t single_word(const uint8_t* ring, uint32_t b, uint32_t e, uint32_t& err)
+{
+    const Num n = parse_num(ring, b, e);
+    if (!n.valid) return 0u;                                   // parse::<i32>() Err -> DEF_CONSEQ (text_parser.rs:216)
+    if (n.neg) {
+        if (n.val > (1ull << 31)) return 0u;                   // below i32::MIN: Err as well
+        err = n.val ? DEC_MASK_NEGATIVE : DEC_MASK_PARSE;      // "-5" panics at text_parser.rs:210, "-0" at MaskDecoder.rs:41
+        return 0u;
+    }
+    return n.val <= 0x7FFFFFFFull ? uint32_t(n.val) : 0u;
+}
+
+__device__ __forceinline__ uint32_t top_pair(uint32_t w) { return (31u - uint32_t(__builtin_clz(w))) >> 1; }
+
+// keep the pairs of w whose consequence (ids base .. base+15) is supported
+__device__ __forceinline__ uint32_t filter_word(uint32_t w, uint32_t base, const uint32_t* __restrict__ sup_bits)
+{
+    uint32_t out = 0u, pairs = (w | (w >> 1)) & 0x55555555u;
+    while (pairs) {
+        const uint32_t b = uint32_t(__builtin_ctz(pairs));
+        pairs &= pairs - 1u;
+        const uint32_t id = base + (b >> 1);
+        if ((sup_bits[id >> 5] >> (id & 31u)) & 1u) out |= w & (3u << b);
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------- parse
+__global__ __launch_bounds__(256) void parse_rows_kernel(DecodeArgs a)
+{
+    __shared__ __align__(16) uint8_t ring[RING];
+    __shared__ uint16_t tabpos[DEC_TILE + 2];
+    __shared__ uint32_t wave_tot[4];
+
+    const uint32_t row = blockIdx.x;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    const uint64_t rb = a.row_begin[row], re = a.row_end[row];
+    const uintptr_t first = reinterpret_cast<uintptr_t>(a.text) + rb;
+    const uintptr_t base = first & ~uintptr_t(15);
+    const uint32_t q0 = uint32_t(first - base);                 // stream position of the first row byte
+    const uint32_t Lq = uint32_t(re - rb) + q0;                 // stream position one past the last row byte
+    const uint32_t n_tiles = Lq ? (Lq + DEC_TILE - 1u) / DEC_TILE : 1u;
+    const uint32_t c0 = a.csq_begin[row], n_csq = a.csq_begin[row + 1] - c0;
+    const uint32_t sup = a.sup_pairs[row];
+    const uint64_t field0 = uint64_t(row) * a.n_samples;
+    uint32_t fields_before = 0;
+
+    auto load_tile = [&](uint32_t t) -> u32x4 {
+        const uint32_t qs = t * DEC_TILE + tid * 16u;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (qs < Lq) v = *reinterpret_cast<const u32x4 __attribute__((address_space(1)))*>(base + qs);
+        return v;
+    };
+
+    u32x4 cur = load_tile(0);
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        const uint32_t tile0 = t * DEC_TILE;
+        *reinterpret_cast<u32x4*>(&ring[(tile0 & (RING - 1u)) + tid * 16u]) = cur;
+        u32x4 nxt = {0u, 0u, 0u, 0u};
+        if (t + 1u < n_tiles) nxt = load_tile(t + 1u);
+
+        // tabs among this lane's 16 bytes that belong to the row
+        const uint32_t qs = tile0 + tid * 16u;
+        uint32_t tm = tab_bits(cur.x) | (tab_bits(cur.y) << 4) | (tab_bits(cur.z) << 8) | (tab_bits(cur.w) << 12);
+        {
+            const uint32_t lo = q0 > qs ? min(q0 - qs, 16u) : 0u;
+            const uint32_t hi = Lq > qs ? min(Lq - qs, 16u) : 0u;
+            tm &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        }
+        const uint32_t cnt = uint32_t(__builtin_popcount(tm));
+        const uint32_t incl = dec_wave_incl_scan(cnt);
+        if ((tid & 63u) == 63u) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, tile_tabs = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4; ++w) {
+            const uint32_t x = wave_tot[w];
+            if (w < wave) wbase += x;
+            tile_tabs += x;
+        }
+        uint32_t slot = wbase + incl - cnt;
+        while (tm) {
+            const uint32_t b = uint32_t(__builtin_ctz(tm));
+            tm &= tm - 1u;
+            tabpos[slot++] = uint16_t(tid * 16u + b);
+        }
+        const bool last = (t + 1u == n_tiles);
+        if (last && tid == 0) tabpos[tile_tabs] = uint16_t(Lq - tile0);       // the end of the line closes the last column
+        const uint32_t n_ends = tile_tabs + (last ? 1u : 0u);
+        __syncthreads();
+
+        const uint32_t lo = max(q0, t ? tile0 - DEC_TILE : 0u);               // oldest stream position still in the ring
+        for (uint32_t j = tid; j < n_ends; j += 256u) {
+            const uint32_t p = tile0 + tabpos[j];                              // one past the column's last byte
+            const uint32_t f = fields_before + j;
+            uint32_t q = p, err = 0u, entry = 0u;
+            bool colon = false;
+            while (q > lo) {
+                const uint8_t c = rq(ring, q - 1u);
+                if (c == ':') { colon = true; break; }
+                if (c == '\t') break;
+                --q;
+            }
+            if (!colon && q == lo && lo > q0) err = DEC_FIELD_TOO_LONG;
+            if (colon) {
+                const uint32_t s = q;                                          // tail = ring[s, p)
+                const uint32_t len = p - s;
+                if (len == 0u || (len == 1u && rq(ring, s) == '.')) {
+                    entry = 0u;                                                // "" parses to Err, "." is the missing value
+                } else {
+                    // elements, how many survive remove_leading_zeros (it strips trailing "0" elements), any '-'
+                    uint32_t n_el = 1u, kept = 0u, es = s, first_end = p;
+                    bool minus = false;
+                    for (uint32_t k = s; k < p; ++k) {
+                        const uint8_t c = rq(ring, k);
+                        if (c == ',') {
+                            if (!(k - es == 1u && rq(ring, es) == '0')) kept = n_el;
+                            if (n_el == 1u) first_end = k;
+                            ++n_el;
+                            es = k + 1u;
+                        } else if (c == '-') {
+                            minus = true;
+                        }
+                    }
+                    if (!(p - es == 1u && rq(ring, es) == '0')) kept = n_el;
+                    if (n_el == 1u) {
+                        entry = single_word(ring, s, p, err);                  // text_parser.rs:179-182
+                    } else if (kept == 0u) {
+                        entry = 0u;                                            // "0,0" (text_parser.rs:240-243)
+                    } else if (minus) {
+                        err = DEC_MASK_NEGATIVE;                               // text_parser.rs:244
+                    } else if (kept == 1u) {
+                        entry = single_word(ring, s, first_end, err);          // "x,0" falls back to parse_fields (text_parser.rs:189-192)
+                    } else {
+                        // MaskDecoder.rs:45-50: every kept element must be a u32; word k covers indices 15k .. 15k+15
+                        uint32_t any = 0u;
+                        bool bad_index = false;                                // every word is parsed before any is used as an index
+                        for (int pass = 0; pass < 2 && !err; ++pass) {
+                            uint32_t off = 0u;
+                            if (pass == 1) {
+                                if (!any) break;
+                                const unsigned long long o = atomicAdd(a.ovf_used, static_cast<unsigned long long>(kept + 1u));
+                                if (o + kept + 1u > a.ovf_capacity) { err = DEC_CAPACITY; break; }
+                                off = uint32_t(o);
+                                a.ovf[off] = kept;
+                                entry = DEC_MULTI | off;
+                            }
+                            uint32_t eb = s, k = 0u;
+                            for (uint32_t x = s; x <= p && k < kept; ++x) {
+                                if (x == p || rq(ring, x) == ',') {
+                                    const Num n = parse_num(ring, eb, x);
+                                    if (!n.valid || n.neg || n.val > 0xFFFFFFFFull) { err = DEC_MASK_PARSE; break; }
+                                    const uint32_t w = uint32_t(n.val);
+                                    const bool oob = w && 15u * k + top_pair(w) >= n_csq;
+                                    bad_index |= oob;
+                                    const uint32_t fw = (w && !oob) ? filter_word(w, c0 + 15u * k, a.sup_bits) : 0u;
+                                    if (pass == 0) any |= fw; else a.ovf[off + 1u + k] = fw;
+                                    ++k;
+                                    eb = x + 1u;
+                                }
+                            }
+                            if (!err && bad_index) err = DEC_MASK_INDEX;
+                        }
+                    }
+                    if (!(entry & DEC_MULTI) && entry) {
+                        if (top_pair(entry) >= n_csq) err = DEC_MASK_INDEX;    // vcf_ds.rs:321: splitted_csq[idx] out of range
+                        entry &= sup;
+                    }
+                }
+            }
+            if (f >= a.n_samples) err = err ? err : DEC_COLUMNS;
+            if (err) dec_report(a.status, field0 + min(f, a.n_samples - 1u), err);
+            else a.masks[field0 + f] = entry;
+        }
+        fields_before += n_ends;
+        __syncthreads();
+        cur = nxt;
+    }
+    if (tid == 0 && fields_before != a.n_samples) dec_report(a.status, field0 + min(fields_before, a.n_samples - 1u), DEC_COLUMNS);
+}
+
+// counts of one matrix entry for haplotype bit h (0/1)
+__device__ __forceinline__ uint32_t entry_count(uint32_t m, uint32_t h, const uint32_t* __restrict__ ovf)
+{
+    if (!(m & DEC_MULTI)) return uint32_t(__builtin_popcount((m >> h) & 0x55555555u));
+    const uint32_t off = m & ~DEC_MULTI, n = ovf[off];
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < n; ++k) c += uint32_t(__builtin_popcount((ovf[off + 1u + k] >> h) & 0x55555555u));
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------------------- count
+__global__ __launch_bounds__(256) void count_kernel(DecodeArgs a, uint32_t sample_blocks)
+{
+    const uint32_t rbk = blockIdx.x / sample_blocks, sb = blockIdx.x % sample_blocks;
+    const uint32_t s = sb * 256u + threadIdx.x;
+    if (s >= a.n_samples) return;
+    const uint32_t r0 = rbk * DEC_ROWBLOCK, r1 = min(r0 + DEC_ROWBLOCK, a.n_rows);
+    uint32_t c1 = 0, c2 = 0;
+    const uint32_t* m = a.masks + uint64_t(r0) * a.n_samples + s;
+#pragma unroll 8
+    for (uint32_t r = r0; r < r1; ++r, m += a.n_samples) {
+        const uint32_t v = *m;
+        if (v & DEC_MULTI) { c1 += entry_count(v, 0, a.ovf); c2 += entry_count(v, 1, a.ovf); }
+        else { c1 += uint32_t(__builtin_popcount(v & 0x55555555u)); c2 += uint32_t(__builtin_popcount(v & 0xAAAAAAAAu)); }
+    }
+    uint2* out = reinterpret_cast<uint2*>(a.cnt + uint64_t(rbk) * 2u * a.n_samples) + s;
+    *out = make_uint2(c1, c2);
+}
+
+// ---------------------------------------------------------------------------------------------------------- scan
+// one thread per haplotype: exclusive prefix down the record blocks, in place; the total goes to hap_begin[h + 1]
+__global__ __launch_bounds__(256) void scan_blocks_kernel(DecodeArgs a, uint32_t n_rowblocks)
+{
+    const uint32_t h = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t n_haps = 2u * a.n_samples;
+    if (h >= n_haps) return;
+    uint32_t* c = a.cnt + h;
+    uint64_t run = 0;
+#pragma unroll 8
+    for (uint32_t b = 0; b < n_rowblocks; ++b, c += n_haps) {
+        const uint32_t v = *c;
+        *c = uint32_t(run);
+        run += v;
+    }
+    a.hap_begin[h + 1u] = run;
+    if (run > 0xFFFFFFFFull) dec_report(a.status, uint64_t(h >> 1), DEC_CAPACITY);   // a haplotype list beyond 2^32 ids
+}
+
+// one workgroup: exclusive prefix over the haplotype totals (hap_begin[1..] holds the totals on entry)
+__global__ __launch_bounds__(1024) void scan_haps_kernel(DecodeArgs a)
+{
+    __shared__ uint64_t part[16];
+    __shared__ uint64_t carry;
+    const uint32_t n_haps = 2u * a.n_samples, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) { carry = 0; a.hap_begin[0] = 0; }
+    __syncthreads();
+    for (uint32_t b = 0; b < n_haps; b += 1024u) {
+        const uint32_t h = b + tid;
+        const uint64_t v = h < n_haps ? a.hap_begin[h + 1u] : 0ull;
+        unsigned long long x = v;                                 // wave inclusive scan, 64-bit, via shuffles
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const unsigned long long y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63u) part[wave] = x;
+        __syncthreads();
+        uint64_t wb = carry;
+        for (uint32_t w = 0; w < wave; ++w) wb += part[w];
+        if (h < n_haps) a.hap_begin[h + 1u] = wb + x;
+        __syncthreads();
+        if (tid == 1023u) carry = wb + x;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.status[1] = *a.ovf_used;
+        if (carry > a.ids_capacity) dec_report(a.status, 0, DEC_CAPACITY);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- emit
+__global__ __launch_bounds__(256) void emit_kernel(DecodeArgs a, uint32_t sample_blocks)
+{
+    constexpr uint32_t TS = DEC_EMIT_SAMPLES, STRIDE = TS + 1u;
+    __shared__ uint32_t tile[DEC_ROWBLOCK * STRIDE];
+    __shared__ uint32_t csq0[DEC_ROWBLOCK];
+    const uint32_t rbk = blockIdx.x / sample_blocks, sb = blockIdx.x % sample_blocks;
+    const uint32_t r0 = rbk * DEC_ROWBLOCK, s0 = sb * TS;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_haps = 2u * a.n_samples;
+    if (a.hap_begin[n_haps] > a.ids_capacity) return;
+    csq0[tid] = (r0 + tid < a.n_rows) ? a.csq_begin[r0 + tid] : 0u;
+    for (uint32_t i = tid; i < DEC_ROWBLOCK * TS; i += 256u) {
+        const uint32_t r = i / TS, sc = i % TS;
+        uint32_t v = 0u;
+        if (r0 + r < a.n_rows && s0 + sc < a.n_samples) v = a.masks[uint64_t(r0 + r) * a.n_samples + s0 + sc];
+        tile[r * STRIDE + sc] = v;
+    }
+    __syncthreads();
+    for (uint32_t hc = wave; hc < 2u * TS; hc += 4u) {
+        const uint32_t sc = hc >> 1, h = hc & 1u, s = s0 + sc;
+        if (s >= a.n_samples) continue;
+        const uint32_t hap = 2u * s + h;
+        uint64_t out = a.hap_begin[hap] + a.cnt[uint64_t(rbk) * n_haps + hap];
+#pragma unroll
+        for (uint32_t g = 0; g < DEC_ROWBLOCK / 64u; ++g) {
+            const uint32_t r = g * 64u + lane;
+            const uint32_t m = tile[r * STRIDE + sc];
+            const uint32_t c = entry_count(m, h, a.ovf);
+            const uint32_t incl = dec_wave_incl_scan(c);
+            const uint32_t tot = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+            if (c) {
+                uint32_t* o = a.ids + out + (incl - c);
+                const uint32_t id0 = csq0[r];
+                if (!(m & DEC_MULTI)) {
+                    uint32_t bits = (m >> h) & 0x55555555u;
+                    while (bits) { const uint32_t b = uint32_t(__builtin_ctz(bits)); bits &= bits - 1u; *o++ = id0 + (b >> 1); }
+                } else {
+                    const uint32_t off = m & ~DEC_MULTI, n = a.ovf[off];
+                    for (uint32_t k = 0; k < n; ++k) {
+                        uint32_t bits = (a.ovf[off + 1u + k] >> h) & 0x55555555u;
+                        while (bits) { const uint32_t b = uint32_t(__builtin_ctz(bits)); bits &= bits - 1u; *o++ = id0 + 15u * k + (b >> 1); }
+                    }
+                }
+            }
+            out += tot;
+        }
+    }
+}
+
+}  // namespace
+
+DecodeLayout decode_layout(uint64_t n_rows, uint64_t n_samples, uint64_t ovf_words)
+{
+    auto up = [](uint64_t x) { return (x + 255ull) & ~255ull; };
+    DecodeLayout L{};
+    L.n_rowblocks = uint32_t((n_rows + DEC_ROWBLOCK - 1) / DEC_ROWBLOCK);
+    uint64_t o = 0;
+    L.masks_off = o; o += up(n_rows * n_samples * 4ull);
+    L.cnt_off = o; o += up(uint64_t(L.n_rowblocks) * 2ull * n_samples * 4ull);
+    L.ovf_off = o; o += up(ovf_words * 4ull);
+    L.ovf_used_off = o; o += 256;
+    L.total = o;
+    return L;
+}
+
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, unsigned phases)
+{
+    if (a.n_rows == 0 || a.n_samples == 0) return hipErrorInvalidValue;
+    const uint32_t n_rowblocks = (a.n_rows + DEC_ROWBLOCK - 1u) / DEC_ROWBLOCK;
+    const uint32_t n_haps = 2u * a.n_samples;
+    if (phases & 1u) {
+        hipError_t e = hipMemsetAsync(a.ovf_used, 0, sizeof(unsigned long long), stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(parse_rows_kernel, dim3(a.n_rows), dim3(256), 0, stream, a);
+    }
+    if (phases & 2u) {
+        const uint32_t sbk = (a.n_samples + 255u) / 256u;
+        hipLaunchKernelGGL(count_kernel, dim3(n_rowblocks * sbk), dim3(256), 0, stream, a, sbk);
+    }
+    if (phases & 4u) {
+        hipLaunchKernelGGL(scan_blocks_kernel, dim3((n_haps + 255u) / 256u), dim3(256), 0, stream, a, n_rowblocks);
+        hipLaunchKernelGGL(scan_haps_kernel, dim3(1), dim3(1024), 0, stream, a);
+    }
+    if (phases & 8u) {
+        const uint32_t sbk = (a.n_samples + DEC_EMIT_SAMPLES - 1u) / DEC_EMIT_SAMPLES;
+        hipLaunchKernelGGL(emit_kernel, dim3(n_rowblocks * sbk), dim3(256), 0, stream, a, sbk);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace v2p

@@ -14,6 +14,7 @@
 #include "../../include/vcf2prot_hip.h"
 #include "sir_pack.hpp"
 #include "stitch_kernels.h"
+#include "v2p_ctx_internal.h"
 
 using namespace v2p;
 
@@ -127,6 +128,14 @@ struct v2p_batch {
     uint64_t n_desc = 0, n_chunks = 0, n_payload = 0, out_bytes = 0, n_haps = 0;
     uint32_t max_chunk_tasks = 0;
 };
+
+namespace v2p {
+hipStream_t ctx_stream(v2p_ctx* c) { return c->stream; }
+int ctx_device(v2p_ctx* c) { return c->device; }
+int ctx_fail(v2p_ctx* c, int code, const std::string& msg, int64_t index) { return c->fail(code, msg, index); }
+void ctx_lock(v2p_ctx* c) { c->mu.lock(); }
+void ctx_unlock(v2p_ctx* c) { c->mu.unlock(); }
+}  // namespace v2p
 
 #define HIP_TRY(ctx, expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return (ctx)->hip_fail(e__, what); } while (0)
 
