@@ -377,3 +377,50 @@ def parse_vcf(text: str):
         m2 = [split[r][i] for r, i in h2]
         out.append((name, group_muts_per_transcript(m1), group_muts_per_transcript(m2)))
     return out
+
+
+# ---------------------------------------------------------------- C restatement (oracle/frontend_oracle.c): CPU baseline
+def build_c_frontend(force: bool = False) -> str:
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src, so = os.path.join(here, "frontend_oracle.c"), os.path.join(here, "libfrontend_oracle.so")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O3", "-march=x86-64-v2", "-fPIC", "-shared", "-pthread", "-o", so, src])
+    return so
+
+
+class CFrontend:
+    """ctypes wrapper of fe_decode: same inputs as the device decode (record ranges, consequence table)."""
+    CODES = {1: "negative", 2: "parse", 3: "index", 4: "columns", 5: "nomem"}
+
+    def __init__(self):
+        import ctypes
+        self.ct = ctypes
+
+        class Input(ctypes.Structure):
+            _fields_ = [("text", ctypes.c_void_p), ("row_begin", ctypes.c_void_p), ("row_end", ctypes.c_void_p),
+                        ("n_rows", ctypes.c_uint64), ("n_samples", ctypes.c_uint64), ("csq_begin", ctypes.c_void_p),
+                        ("csq_supported", ctypes.c_void_p)]
+        self.Input = Input
+        self.lib = ctypes.CDLL(build_c_frontend())
+        self.lib.fe_decode.restype = ctypes.c_int
+        self.lib.fe_decode.argtypes = [ctypes.POINTER(Input), ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
+                                       ctypes.POINTER(ctypes.c_int64)]
+        self.lib.fe_free.argtypes = [ctypes.c_void_p]
+
+    def decode(self, text, row_begin, row_end, n_samples, csq_begin, csq_supported, n_threads=1):
+        """numpy arrays in (uint8 text, uint64 ranges, uint32 csq_begin, uint8 supported) -> (rc, hap_begin, ids, err_field)"""
+        import numpy as np
+        ct = self.ct
+        inp = self.Input(text.ctypes.data, row_begin.ctypes.data, row_end.ctypes.data, row_begin.size, n_samples,
+                         csq_begin.ctypes.data, csq_supported.ctypes.data)
+        hap_begin = np.zeros(2 * n_samples + 1, dtype=np.uint64)
+        out, err = ct.c_void_p(), ct.c_int64(-1)
+        rc = self.lib.fe_decode(ct.byref(inp), int(n_threads), hap_begin.ctypes.data, ct.byref(out), ct.byref(err))
+        ids = None
+        if rc == 0:
+            n = int(hap_begin[-1])
+            ids = np.ctypeslib.as_array(ct.cast(out, ct.POINTER(ct.c_uint32)), shape=(max(n, 1),))[:n].copy()
+            self.lib.fe_free(out)
+        return rc, hap_begin, ids, err.value

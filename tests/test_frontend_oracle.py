@@ -142,3 +142,37 @@ def test_drop_replicate_semantics_from_source():
         F.group_muts_per_transcript([a, b, c])
     # the 16th pair of word k and the first pair of word k+1 name the same consequence (MaskDecoder.rs:123-153)
     assert F.get_indices([1 << 30, 1]) == ([15, 15], [])
+
+
+def test_c_restatement_agrees_with_the_python_one(decode_cases):
+    """oracle/frontend_oracle.c (the CPU baseline of the decode bench) on the golden VCFs and random ones."""
+    import numpy as np
+    from frontend_util import oracle_index, oracle_lists, random_vcf
+    C = F.CFrontend()
+    texts = [c["vcf"] for c in decode_cases] + [random_vcf(s, 80, 11, unique_positions=False) for s in range(4)]
+    n_abort = 0
+    for text in texts:
+        names, recs, split, begin = oracle_index(text)
+        raw = text.encode()
+        rb, re_, pos = [], [], 0
+        for rec in recs:                                  # sample-column ranges of the supported records
+            at = raw.index(rec.encode(), pos)
+            cols = at + len("\t".join(rec.split("\t")[:9]).encode()) + 1
+            rb.append(cols)
+            re_.append(at + len(rec.encode()))
+            pos = at + 1
+        flat = [c for x in split for c in x]
+        sup = np.array([int(F.get_type(c) in F.SUP_TYPE) for c in flat], dtype=np.uint8)
+        for threads in (1, 3):
+            rc, hb, ids, err = C.decode(np.frombuffer(raw, dtype=np.uint8), np.array(rb, dtype=np.uint64), np.array(re_, dtype=np.uint64),
+                                        len(names), begin.astype(np.uint32), sup, threads)
+            try:
+                want = oracle_lists(text)[4]
+            except F.ReferencePanic:
+                assert rc in (1, 2, 3)
+                n_abort += 1
+                continue
+            assert rc == 0
+            assert hb.tolist() == np.concatenate([[0], np.cumsum([len(x) for x in want])]).tolist()
+            assert ids.tolist() == [i for x in want for i in x]
+    assert n_abort >= 16

@@ -15,7 +15,8 @@ enum : uint32_t {
     DEC_CAPACITY = 6
 };
 
-constexpr uint32_t DEC_ROWBLOCK = 256;      // records per row block (count / emit granularity)
+constexpr uint32_t DEC_ROWBLOCK = 64;       // records per row block (count / emit granularity): one wave, lane = record
+constexpr uint32_t DEC_SCAN_GROUPS = 64;    // the prefix down the row blocks runs in this many independent groups
 constexpr uint32_t DEC_TILE = 4096;         // text bytes per parse step of one workgroup
 constexpr uint32_t DEC_EMIT_SAMPLES = 32;   // sample columns per emit workgroup
 constexpr uint32_t DEC_MULTI = 0x80000000u; // mask-matrix entry: bit 31 set -> low 31 bits index the multi-word list
@@ -31,8 +32,11 @@ struct DecodeArgs {
     const uint32_t* sup_pairs;     // [n_rows]
     const uint32_t* sup_bits;      // bitset over consequence ids
     // workspace
-    uint32_t*       masks;         // [n_rows][n_samples] filtered first word, or DEC_MULTI | offset into ovf
+    uint32_t*       masks;         // [n_rows][mask_stride] filtered first word, or DEC_MULTI | offset into ovf
+    uint32_t        mask_stride;   // n_samples rounded up to 32 entries: every row starts on a 128-byte line
+    uint8_t*        tile_flags;    // [n_rowblocks * ceil(n_samples / 32)] emit tiles that hold multi-word entries
     uint32_t*       cnt;           // [n_rowblocks][2*n_samples] per-block counts, then exclusive prefix down the blocks
+    uint32_t*       group_tot;     // [DEC_SCAN_GROUPS][2*n_samples] scratch of the scan
     uint32_t*       ovf;           // multi-word list: {n_words, words...} records
     uint64_t        ovf_capacity;  // in u32 words
     unsigned long long* ovf_used;  // device counter
@@ -44,8 +48,8 @@ struct DecodeArgs {
 };
 
 struct DecodeLayout {
-    uint64_t masks_off, cnt_off, ovf_off, ovf_used_off, total;
-    uint32_t n_rowblocks;
+    uint64_t masks_off, cnt_off, group_off, ovf_off, ovf_used_off, flags_off, total;
+    uint32_t n_rowblocks, mask_stride;
 };
 DecodeLayout decode_layout(uint64_t n_rows, uint64_t n_samples, uint64_t ovf_words);
 

@@ -11,11 +11,12 @@
 //           j-th column that ENDS in the tile: it walks back to the last ':' and parses the words.  Output: one u32
 //           per (record, sample), already filtered to supported consequences.  Multi-word masks (records with more
 //           than 15 consequences) go to a side list.
-//   count   per (256-record block, haplotype) popcounts, coalesced over samples.
+//   count   per (64-record block, haplotype) popcounts, coalesced over samples.
 //   scan    exclusive prefix down the record blocks per haplotype, then over haplotypes: every (block, haplotype)
 //           knows where its ids go.
-//   emit    a workgroup transposes a 256-record x 32-sample tile through LDS; a wave takes one haplotype column,
-//           lane = record, DPP scan of the popcounts, and writes that haplotype's ids as one contiguous run.
+//   emit    a wave owns 64 records x 32 samples, lane = record, the record's 32 entries (one 128-byte line) in
+//           registers; per haplotype column a DPP scan of the popcounts places the ids as one contiguous run.
+//           Tiles with multi-word entries go through a second kernel that transposes them in LDS.
 #include "decode_kernels.h"
 
 namespace v2p {
@@ -46,6 +47,13 @@ __device__ __forceinline__ uint32_t tab_bits(uint32_t w)
     const uint32_t z = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);     // 0x80 in every zero byte of y, exact
     const uint32_t x = z >> 7;
     return (x | (x >> 7) | (x >> 14) | (x >> 21)) & 0xFu;
+}
+
+// 0x80 in every byte of w that equals the byte replicated in pat, exact
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t w, uint32_t pat)
+{
+    const uint32_t y = w ^ pat;
+    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
 }
 
 struct Num { bool valid; bool neg; uint64_t val; };
@@ -172,7 +180,36 @@ __global__ __launch_bounds__(256) void parse_rows_kernel(DecodeArgs a)
             const uint32_t p = tile0 + tabpos[j];                              // one past the column's last byte
             const uint32_t f = fields_before + j;
             uint32_t q = p, err = 0u, entry = 0u;
-            bool colon = false;
+            bool colon = false, slow = true;
+            if (p >= lo + 8u) {
+                // fast path: the last eight bytes of the column in registers.  Settles every column whose text after the
+                // last ':' is at most seven digits (or '.'), and every column without a ':' that starts inside the window.
+                const uint32_t* ring32 = reinterpret_cast<const uint32_t*>(ring);
+                const uint32_t a8 = (p - 8u) & (RING - 1u), i0 = a8 >> 2, sh = a8 & 3u;
+                const uint32_t w0 = ring32[i0], w1 = ring32[(i0 + 1u) & (RING / 4u - 1u)], w2 = ring32[(i0 + 2u) & (RING / 4u - 1u)];
+                const uint32_t lo32 = __builtin_amdgcn_alignbyte(w1, w0, sh), hi32 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                const uint32_t c_hi = eq_bytes(hi32, 0x3A3A3A3Au), c_lo = eq_bytes(lo32, 0x3A3A3A3Au);
+                const uint32_t t_hi = eq_bytes(hi32, 0x09090909u), t_lo = eq_bytes(lo32, 0x09090909u);
+                const int ci = c_hi ? 4 + int((31u - uint32_t(__builtin_clz(c_hi))) >> 3) : (c_lo ? int((31u - uint32_t(__builtin_clz(c_lo))) >> 3) : -1);
+                const int ti = t_hi ? 4 + int((31u - uint32_t(__builtin_clz(t_hi))) >> 3) : (t_lo ? int((31u - uint32_t(__builtin_clz(t_lo))) >> 3) : -1);
+                if (ti > ci) {
+                    slow = false;                                              // the column starts after the window's last ':'
+                } else if (ci >= 0) {
+                    const uint32_t L = 7u - uint32_t(ci);
+                    uint64_t T = L ? ((uint64_t(hi32) << 32) | lo32) >> (8u * uint32_t(ci + 1)) : 0ull;
+                    uint32_t v = 0u;
+                    bool digits = true;
+                    for (uint32_t k = 0; k < L; ++k) {
+                        const uint32_t d = (uint32_t(T) & 0xFFu) - uint32_t('0');
+                        digits = digits && d <= 9u;
+                        v = v * 10u + d;
+                        T >>= 8;
+                    }
+                    if (digits) { entry = v; slow = false; }                   // L == 0: "" -> nothing; v < 10^7 is a valid i32
+                    else if (L == 1u && hi32 >> 24 == uint32_t('.')) slow = false;
+                }
+            }
+            if (slow) {
             while (q > lo) {
                 const uint8_t c = rq(ring, q - 1u);
                 if (c == ':') { colon = true; break; }
@@ -180,6 +217,7 @@ __global__ __launch_bounds__(256) void parse_rows_kernel(DecodeArgs a)
                 --q;
             }
             if (!colon && q == lo && lo > q0) err = DEC_FIELD_TOO_LONG;
+            }
             if (colon) {
                 const uint32_t s = q;                                          // tail = ring[s, p)
                 const uint32_t len = p - s;
@@ -240,15 +278,15 @@ __global__ __launch_bounds__(256) void parse_rows_kernel(DecodeArgs a)
                             if (!err && bad_index) err = DEC_MASK_INDEX;
                         }
                     }
-                    if (!(entry & DEC_MULTI) && entry) {
-                        if (top_pair(entry) >= n_csq) err = DEC_MASK_INDEX;    // vcf_ds.rs:321: splitted_csq[idx] out of range
-                        entry &= sup;
-                    }
                 }
+            }
+            if (!err && entry && !(entry & DEC_MULTI)) {
+                if (top_pair(entry) >= n_csq) err = DEC_MASK_INDEX;            // vcf_ds.rs:321: splitted_csq[idx] out of range
+                entry &= sup;
             }
             if (f >= a.n_samples) err = err ? err : DEC_COLUMNS;
             if (err) dec_report(a.status, field0 + min(f, a.n_samples - 1u), err);
-            else a.masks[field0 + f] = entry;
+            else a.masks[uint64_t(row) * a.mask_stride + f] = entry;
         }
         fields_before += n_ends;
         __syncthreads();
@@ -275,9 +313,9 @@ __global__ __launch_bounds__(256) void count_kernel(DecodeArgs a, uint32_t sampl
     if (s >= a.n_samples) return;
     const uint32_t r0 = rbk * DEC_ROWBLOCK, r1 = min(r0 + DEC_ROWBLOCK, a.n_rows);
     uint32_t c1 = 0, c2 = 0;
-    const uint32_t* m = a.masks + uint64_t(r0) * a.n_samples + s;
+    const uint32_t* m = a.masks + uint64_t(r0) * a.mask_stride + s;
 #pragma unroll 8
-    for (uint32_t r = r0; r < r1; ++r, m += a.n_samples) {
+    for (uint32_t r = r0; r < r1; ++r, m += a.mask_stride) {
         const uint32_t v = *m;
         if (v & DEC_MULTI) { c1 += entry_count(v, 0, a.ovf); c2 += entry_count(v, 1, a.ovf); }
         else { c1 += uint32_t(__builtin_popcount(v & 0x55555555u)); c2 += uint32_t(__builtin_popcount(v & 0xAAAAAAAAu)); }
@@ -287,22 +325,41 @@ __global__ __launch_bounds__(256) void count_kernel(DecodeArgs a, uint32_t sampl
 }
 
 // ---------------------------------------------------------------------------------------------------------- scan
-// one thread per haplotype: exclusive prefix down the record blocks, in place; the total goes to hap_begin[h + 1]
-__global__ __launch_bounds__(256) void scan_blocks_kernel(DecodeArgs a, uint32_t n_rowblocks)
+// Exclusive prefix down the record blocks per haplotype, in DEC_SCAN_GROUPS independent groups of blocks so that the
+// chain a thread walks stays short: (1) every (group, haplotype) sums its blocks, (2) every (group, haplotype) adds the
+// groups above and rewrites its blocks as prefixes; the last group leaves the haplotype total in hap_begin[h + 1].
+__global__ __launch_bounds__(256) void scan_groups_kernel(DecodeArgs a, uint32_t n_rowblocks, uint32_t per_group, uint32_t hap_blocks)
 {
-    const uint32_t h = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t g = blockIdx.x / hap_blocks, h = (blockIdx.x % hap_blocks) * 256u + threadIdx.x;
     const uint32_t n_haps = 2u * a.n_samples;
     if (h >= n_haps) return;
-    uint32_t* c = a.cnt + h;
-    uint64_t run = 0;
+    const uint32_t b0 = g * per_group, b1 = min(b0 + per_group, n_rowblocks);
+    const uint32_t* c = a.cnt + uint64_t(b0) * n_haps + h;
+    uint32_t sum = 0;
 #pragma unroll 8
-    for (uint32_t b = 0; b < n_rowblocks; ++b, c += n_haps) {
+    for (uint32_t b = b0; b < b1; ++b, c += n_haps) sum += *c;
+    a.group_tot[uint64_t(g) * n_haps + h] = sum;
+}
+
+__global__ __launch_bounds__(256) void scan_blocks_kernel(DecodeArgs a, uint32_t n_rowblocks, uint32_t per_group, uint32_t hap_blocks, uint32_t n_groups)
+{
+    const uint32_t g = blockIdx.x / hap_blocks, h = (blockIdx.x % hap_blocks) * 256u + threadIdx.x;
+    const uint32_t n_haps = 2u * a.n_samples;
+    if (h >= n_haps) return;
+    uint64_t run = 0;
+    for (uint32_t k = 0; k < g; ++k) run += a.group_tot[uint64_t(k) * n_haps + h];
+    const uint32_t b0 = g * per_group, b1 = min(b0 + per_group, n_rowblocks);
+    uint32_t* c = a.cnt + uint64_t(b0) * n_haps + h;
+#pragma unroll 8
+    for (uint32_t b = b0; b < b1; ++b, c += n_haps) {
         const uint32_t v = *c;
         *c = uint32_t(run);
         run += v;
     }
-    a.hap_begin[h + 1u] = run;
-    if (run > 0xFFFFFFFFull) dec_report(a.status, uint64_t(h >> 1), DEC_CAPACITY);   // a haplotype list beyond 2^32 ids
+    if (g + 1u == n_groups) {
+        a.hap_begin[h + 1u] = run;
+        if (run > 0xFFFFFFFFull) dec_report(a.status, uint64_t(h >> 1), DEC_CAPACITY);   // a haplotype list beyond 2^32 ids
+    }
 }
 
 // one workgroup: exclusive prefix over the haplotype totals (hap_begin[1..] holds the totals on entry)
@@ -338,9 +395,11 @@ __global__ __launch_bounds__(1024) void scan_haps_kernel(DecodeArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------- emit
-__global__ __launch_bounds__(256) void emit_kernel(DecodeArgs a, uint32_t sample_blocks)
+// the tiles the register kernel below leaves alone (they hold multi-word entries): transposed through LDS
+__global__ __launch_bounds__(256) void emit_generic_kernel(DecodeArgs a, uint32_t sample_blocks)
 {
     constexpr uint32_t TS = DEC_EMIT_SAMPLES, STRIDE = TS + 1u;
+    if (!a.tile_flags[blockIdx.x]) return;
     __shared__ uint32_t tile[DEC_ROWBLOCK * STRIDE];
     __shared__ uint32_t csq0[DEC_ROWBLOCK];
     const uint32_t rbk = blockIdx.x / sample_blocks, sb = blockIdx.x % sample_blocks;
@@ -348,11 +407,11 @@ __global__ __launch_bounds__(256) void emit_kernel(DecodeArgs a, uint32_t sample
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_haps = 2u * a.n_samples;
     if (a.hap_begin[n_haps] > a.ids_capacity) return;
-    csq0[tid] = (r0 + tid < a.n_rows) ? a.csq_begin[r0 + tid] : 0u;
+    if (tid < DEC_ROWBLOCK) csq0[tid] = (r0 + tid < a.n_rows) ? a.csq_begin[r0 + tid] : 0u;
     for (uint32_t i = tid; i < DEC_ROWBLOCK * TS; i += 256u) {
         const uint32_t r = i / TS, sc = i % TS;
         uint32_t v = 0u;
-        if (r0 + r < a.n_rows && s0 + sc < a.n_samples) v = a.masks[uint64_t(r0 + r) * a.n_samples + s0 + sc];
+        if (r0 + r < a.n_rows && s0 + sc < a.n_samples) v = a.masks[uint64_t(r0 + r) * a.mask_stride + s0 + sc];
         tile[r * STRIDE + sc] = v;
     }
     __syncthreads();
@@ -366,10 +425,18 @@ __global__ __launch_bounds__(256) void emit_kernel(DecodeArgs a, uint32_t sample
             const uint32_t r = g * 64u + lane;
             const uint32_t m = tile[r * STRIDE + sc];
             const uint32_t c = entry_count(m, h, a.ovf);
-            const uint32_t incl = dec_wave_incl_scan(c);
-            const uint32_t tot = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+            uint32_t excl, tot;
+            if (!__builtin_amdgcn_ballot_w64(c > 1u)) {                        // the usual case: one bit per record at most
+                const uint64_t b = __builtin_amdgcn_ballot_w64(c != 0u);
+                excl = __builtin_amdgcn_mbcnt_hi(uint32_t(b >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(b), 0u));
+                tot = uint32_t(__builtin_popcountll(b));
+            } else {
+                const uint32_t incl = dec_wave_incl_scan(c);
+                excl = incl - c;
+                tot = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+            }
             if (c) {
-                uint32_t* o = a.ids + out + (incl - c);
+                uint32_t* o = a.ids + out + excl;
                 const uint32_t id0 = csq0[r];
                 if (!(m & DEC_MULTI)) {
                     uint32_t bits = (m >> h) & 0x55555555u;
@@ -387,6 +454,57 @@ __global__ __launch_bounds__(256) void emit_kernel(DecodeArgs a, uint32_t sample
     }
 }
 
+// A wave owns 64 records x 32 samples, lane = record.  The lane keeps its record's 32 entries (one 128-byte line) in
+// registers, so a haplotype column is a DPP scan over the wave: no transposition, no LDS, no barrier.
+__global__ __launch_bounds__(256, 4) void emit_kernel(DecodeArgs a, uint32_t sample_blocks, uint32_t n_rowblocks)
+{
+    constexpr uint32_t TS = DEC_EMIT_SAMPLES;
+    static_assert(TS == 32u && DEC_ROWBLOCK == 64u, "one 128-byte line per lane, one record block per wave");
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6)));
+    const uint32_t rbk = (blockIdx.x / sample_blocks) * 4u + wave, sb = blockIdx.x % sample_blocks;
+    if (rbk >= n_rowblocks) return;
+    const uint32_t s0 = sb * TS;
+    const uint32_t n_haps = 2u * a.n_samples;
+    if (a.hap_begin[n_haps] > a.ids_capacity) return;
+    const uint32_t r = rbk * DEC_ROWBLOCK + lane;
+    const bool row_ok = r < a.n_rows;
+    const uint32_t n_cols = min(TS, a.n_samples - s0);
+    uint32_t m[TS];
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.masks + uint64_t(row_ok ? r : 0u) * a.mask_stride + s0);
+#pragma unroll
+        for (uint32_t k = 0; k < TS / 4u; ++k) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row_ok) v = src[k];
+            m[4u * k] = v.x; m[4u * k + 1u] = v.y; m[4u * k + 2u] = v.z; m[4u * k + 3u] = v.w;
+        }
+    }
+    uint32_t any = 0u;
+#pragma unroll
+    for (uint32_t sc = 0; sc < TS; ++sc) {
+        if (sc >= n_cols) m[sc] = 0u;                                          // the padding of the row is not initialised
+        any |= m[sc];
+    }
+    const bool multi = __builtin_amdgcn_ballot_w64((any & DEC_MULTI) != 0u) != 0ull;
+    if (lane == 0u) a.tile_flags[uint64_t(rbk) * sample_blocks + sb] = multi ? 1 : 0;
+    if (multi || !__builtin_amdgcn_ballot_w64(any != 0u)) return;             // multi-word entries: emit_generic_kernel
+    const uint32_t id0 = row_ok ? a.csq_begin[r] : 0u;
+    const uint64_t* hb = a.hap_begin + 2u * s0;
+    const uint32_t* cb = a.cnt + uint64_t(rbk) * n_haps + 2u * s0;
+#pragma unroll
+    for (uint32_t sc = 0; sc < TS; ++sc) {
+        if (!__builtin_amdgcn_ballot_w64(m[sc] != 0u)) continue;               // nobody in these 64 records carries anything here
+#pragma unroll
+        for (uint32_t h = 0; h < 2u; ++h) {
+            uint32_t bits = (m[sc] >> h) & 0x55555555u;
+            const uint32_t c = uint32_t(__builtin_popcount(bits));
+            const uint32_t excl = dec_wave_incl_scan(c) - c;
+            uint32_t* o = a.ids + (hb[2u * sc + h] + cb[2u * sc + h]) + excl;
+            while (bits) { const uint32_t b = uint32_t(__builtin_ctz(bits)); bits &= bits - 1u; *o++ = id0 + (b >> 1); }
+        }
+    }
+}
+
 }  // namespace
 
 DecodeLayout decode_layout(uint64_t n_rows, uint64_t n_samples, uint64_t ovf_words)
@@ -395,10 +513,13 @@ DecodeLayout decode_layout(uint64_t n_rows, uint64_t n_samples, uint64_t ovf_wor
     DecodeLayout L{};
     L.n_rowblocks = uint32_t((n_rows + DEC_ROWBLOCK - 1) / DEC_ROWBLOCK);
     uint64_t o = 0;
-    L.masks_off = o; o += up(n_rows * n_samples * 4ull);
+    L.mask_stride = uint32_t((n_samples + 31ull) & ~31ull);
+    L.masks_off = o; o += up(n_rows * uint64_t(L.mask_stride) * 4ull);
     L.cnt_off = o; o += up(uint64_t(L.n_rowblocks) * 2ull * n_samples * 4ull);
+    L.group_off = o; o += up(uint64_t(DEC_SCAN_GROUPS) * 2ull * n_samples * 4ull);
     L.ovf_off = o; o += up(ovf_words * 4ull);
     L.ovf_used_off = o; o += 256;
+    L.flags_off = o; o += up(uint64_t(L.n_rowblocks) * ((n_samples + DEC_EMIT_SAMPLES - 1) / DEC_EMIT_SAMPLES));
     L.total = o;
     return L;
 }
@@ -418,12 +539,16 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, unsigned phase
         hipLaunchKernelGGL(count_kernel, dim3(n_rowblocks * sbk), dim3(256), 0, stream, a, sbk);
     }
     if (phases & 4u) {
-        hipLaunchKernelGGL(scan_blocks_kernel, dim3((n_haps + 255u) / 256u), dim3(256), 0, stream, a, n_rowblocks);
+        const uint32_t n_groups = min(DEC_SCAN_GROUPS, n_rowblocks), per_group = (n_rowblocks + n_groups - 1u) / n_groups;
+        const uint32_t groups = (n_rowblocks + per_group - 1u) / per_group, hbk = (n_haps + 255u) / 256u;
+        hipLaunchKernelGGL(scan_groups_kernel, dim3(groups * hbk), dim3(256), 0, stream, a, n_rowblocks, per_group, hbk);
+        hipLaunchKernelGGL(scan_blocks_kernel, dim3(groups * hbk), dim3(256), 0, stream, a, n_rowblocks, per_group, hbk, groups);
         hipLaunchKernelGGL(scan_haps_kernel, dim3(1), dim3(1024), 0, stream, a);
     }
     if (phases & 8u) {
         const uint32_t sbk = (a.n_samples + DEC_EMIT_SAMPLES - 1u) / DEC_EMIT_SAMPLES;
-        hipLaunchKernelGGL(emit_kernel, dim3(n_rowblocks * sbk), dim3(256), 0, stream, a, sbk);
+        hipLaunchKernelGGL(emit_kernel, dim3(((n_rowblocks + 3u) / 4u) * sbk), dim3(256), 0, stream, a, sbk, n_rowblocks);
+        hipLaunchKernelGGL(emit_generic_kernel, dim3(n_rowblocks * sbk), dim3(256), 0, stream, a, sbk);
     }
     return hipGetLastError();
 }

@@ -78,7 +78,10 @@ void fill_args(DecodeArgs& a, const uint8_t* d_text, uint64_t n_text, const uint
     a.n_rows = uint32_t(n_records); a.n_samples = uint32_t(n_samples);
     a.csq_begin = d_csq_begin; a.sup_pairs = d_sup_pairs; a.sup_bits = d_sup_bits;
     a.masks = reinterpret_cast<uint32_t*>(d_work + L.masks_off);
+    a.mask_stride = L.mask_stride;
+    a.tile_flags = d_work + L.flags_off;
     a.cnt = reinterpret_cast<uint32_t*>(d_work + L.cnt_off);
+    a.group_tot = reinterpret_cast<uint32_t*>(d_work + L.group_off);
     a.ovf = reinterpret_cast<uint32_t*>(d_work + L.ovf_off);
     a.ovf_capacity = ovf_words;
     a.ovf_used = reinterpret_cast<unsigned long long*>(d_work + L.ovf_used_off);
