@@ -424,3 +424,241 @@ class CFrontend:
             ids = np.ctypeslib.as_array(ct.cast(out, ct.POINTER(ct.c_uint32)), shape=(max(n, 1),))[:n].copy()
             self.lib.fe_free(out)
         return rc, hap_begin, ids, err.value
+
+
+# ================================================================ step 4a: Mutation -> Instruction (instruction.rs)
+# instruction.rs:20-53 (from_mutation dispatch), :86-...(interpret_*), validate_s_state (last fn of the impl),
+# transcript_instructions.rs:33-160 (TranscriptInstruction::from_alt_transcript with the INSPECT_INS_GEN checks that
+# cli.rs:337-368 switches on by default).
+@dataclass
+class Instruction:
+    code: str
+    s_state: bool
+    pos_ref: int
+    pos_res: int
+    len: int
+    data: str
+
+    def as_dict(self):
+        return dict(code=self.code, s_state=self.s_state, pos_ref=self.pos_ref, pos_res=self.pos_res, len=self.len, data=self.data)
+
+
+def _kind(aa: str) -> str:
+    """MutatedString::from_str (mutation_ds.rs:58-76)."""
+    if aa == "*":
+        return "NotSeq"
+    return "End" if "*" in aa else "Seq"
+
+
+def _chars(aa: str) -> str:
+    """Sequence -> all characters; EndSequence -> all but the last one (data.remove(data.len()-1))."""
+    return aa if _kind(aa) == "Seq" else aa[:-1]
+
+
+def _phi():
+    return Instruction("E", False, 0, 0, 0, "")
+
+
+def validate_s_state(m: Mutation, vec) -> bool:
+    index = next(i for i, e in enumerate(vec) if e.mut_aa_position == m.mut_aa_position)    # PartialEq compares mut_aa_position only
+    for e in vec[:index]:
+        if e.mut_type in ("stop_gained", "frameshift", "*stop_gained"):
+            return False
+        if e.mut_type in ("inframe_insertion", "inframe_deletion") and _kind(e.mut_aa) in ("NotSeq", "End"):
+            return False
+    return True
+
+
+def _stop_gained(m):
+    return Instruction("G", False, m.ref_aa_position, m.mut_aa_position, 0, "")
+
+
+def _stop_lost(m):
+    if _kind(m.mut_aa) == "NotSeq":
+        raise ReferencePanic("Something went wrong, interpreting (stop_lost)")
+    d = _chars(m.mut_aa)
+    return Instruction("L", False, m.ref_aa_position, m.mut_aa_position, len(d), d)
+
+
+def _frameshift(m):
+    if _kind(m.mut_aa) == "NotSeq":
+        return _phi()
+    d = _chars(m.mut_aa)
+    return Instruction("F", False, m.ref_aa_position, m.mut_aa_position, len(d), d)
+
+
+def _block_substitution(m, on_mut_notseq, on_ref_notseq):
+    """the '2' / '3' branch shared by insertion, deletion and missense&inframe_altering: positions are taken crosswise"""
+    pos_res, pos_ref = m.ref_aa_position, m.mut_aa_position
+    if _kind(m.mut_aa) == "NotSeq":
+        return on_mut_notseq()
+    data = _chars(m.mut_aa)
+    if _kind(m.ref_aa) == "NotSeq":
+        return on_ref_notseq()
+    ref_seq = _chars(m.ref_aa)
+    if len(data) != len(ref_seq):
+        return Instruction("3", False, pos_ref, pos_res, len(ref_seq), data)
+    return Instruction("2", False, pos_ref, pos_res, len(data), data)
+
+
+def _panic(what):
+    def f():
+        raise ReferencePanic(what)
+    return f
+
+
+def _missense(m):
+    if _kind(m.mut_aa) == "NotSeq":
+        raise ReferencePanic("Something went wrong, interpreting (missense)")
+    return Instruction("M", False, m.ref_aa_position, m.mut_aa_position, 1, _chars(m.mut_aa))
+
+
+def _inframe_insertion(m):
+    k = _kind(m.ref_aa)
+    if k == "Seq":
+        if len(m.ref_aa) != 1:
+            return _block_substitution(m, lambda: _stop_gained(m), lambda: _stop_lost(m))
+    elif k == "End":
+        return _frameshift(m)
+    else:
+        raise ReferencePanic("In interpreting an inframe insertion the reference amino acids was just an asterisk")
+    km = _kind(m.mut_aa)
+    if km == "End":
+        return _frameshift(m)
+    if km == "NotSeq":
+        return _stop_gained(m)
+    return Instruction("I", False, m.ref_aa_position, m.mut_aa_position, len(m.mut_aa), m.mut_aa)
+
+
+def _inframe_deletion(m):
+    if _kind(m.ref_aa) == "NotSeq":
+        return _stop_gained(m)
+    ln = len(_chars(m.ref_aa))
+    km = _kind(m.mut_aa)
+    if km == "Seq":
+        if len(m.mut_aa) == 1:
+            data = m.mut_aa
+        else:
+            return _block_substitution(m, _panic("interpreting failed"), _panic("interpreting failed"))
+    elif km == "End":
+        data = m.mut_aa[:-1]
+        if len(data) != 1:
+            return _frameshift(m)
+    else:
+        return _stop_gained(m)
+    return Instruction("D", False, m.ref_aa_position, m.mut_aa_position, ln - len(data), data)
+
+
+def _s(m, vec, inner, code):
+    if not validate_s_state(m, vec):
+        return _phi()
+    n = inner(m)
+    n.code, n.s_state = code, True
+    return n
+
+
+def _s_frameshift(m, vec):
+    if not validate_s_state(m, vec):
+        return _phi()
+    if _kind(m.mut_aa) == "NotSeq":
+        return _stop_gained(m)
+    n = _frameshift(m)
+    n.code, n.s_state = "R", True
+    return n
+
+
+def _recode(n, code):
+    if n.code != "E":
+        n.code = code
+    return n
+
+
+def instruction_from_mutation(m: Mutation, vec) -> Instruction:
+    t = m.mut_type
+    if t == "missense":
+        return _missense(m)
+    if t == "*missense":
+        return _s(m, vec, _missense, "N")
+    if t == "frameshift":
+        return _frameshift(m)
+    if t == "*frameshift":
+        return _s_frameshift(m, vec)
+    if t == "inframe_insertion":
+        return _inframe_insertion(m)
+    if t == "*inframe_insertion":
+        if not validate_s_state(m, vec):
+            return _phi()
+        n = _inframe_insertion(m)
+        if n.code == "I":
+            n.code, n.s_state = "J", True
+        return n
+    if t == "inframe_deletion":
+        return _inframe_deletion(m)
+    if t == "*inframe_deletion":
+        return _s(m, vec, _inframe_deletion, "C")                      # recoded to 'C' whatever the inner call returned
+    if t == "start_lost":
+        return Instruction("0", False, 0, 0, 0, "")
+    if t == "stop_lost":
+        return _stop_lost(m)
+    if t == "stop_gained":
+        return _stop_gained(m)
+    if t == "*stop_gained":
+        return _s(m, vec, _stop_gained, "X")
+    if t == "*missense&inframe_altering":
+        return _recode(_s_frameshift(m, vec), "K")
+    if t == "*frameshift&stop_retained":
+        if _kind(m.mut_aa) == "NotSeq":
+            if validate_s_state(m, vec):
+                return Instruction("Q", True, m.ref_aa_position, m.mut_aa_position, 0, "")
+            return _phi()
+        return _s_frameshift(m, vec)
+    if t == "*stop_gained&inframe_altering":
+        return _recode(_s(m, vec, _stop_gained, "X"), "A")
+    if t == "frameshift&stop_retained":
+        return _recode(_frameshift(m), "B")
+    if t == "inframe_deletion&stop_retained":
+        n = _stop_gained(m)
+        n.code = "P"
+        if _kind(m.ref_aa) == "End":
+            n.len = len(m.ref_aa) - 1
+        return n
+    if t == "inframe_insertion&stop_retained":
+        return _phi()
+    if t == "stop_gained&inframe_altering":
+        return _recode(_stop_gained(m), "T")
+    if t == "stop_lost&frameshift":
+        return _stop_lost(m) if _kind(m.ref_aa) == "NotSeq" else _frameshift(m)
+    if t == "missense&inframe_altering":
+        if _kind(m.mut_aa) == "NotSeq":
+            return _recode(_frameshift(m), "Y")
+        return _block_substitution(m, _panic("unreachable"), _panic("interpreting failed"))
+    if t == "start_lost&splice_region":
+        return Instruction("U", False, 0, 0, 0, "")
+    raise ReferencePanic(f"unknown mutation type {t}")
+
+
+U64 = (1 << 64) - 1
+
+
+def transcript_instructions(name, alts, inspect=True, panic_inspect=True):
+    """TranscriptInstruction::from_alt_transcript after the reference lookup: list of Instructions, or None where the
+    reference returns Err (the transcript is skipped).  alts must already be sorted (drop_replicate's order)."""
+    alts = sorted(alts, key=lambda m: m.mut_aa_position)
+    ins = [i for i in (instruction_from_mutation(m, alts) for m in alts) if i.code != "E"]
+    if not ins:
+        return None
+
+    def trouble(msg):
+        if panic_inspect:
+            raise ReferencePanic(f"Critical error was encountered: for transcript: {name}: {msg}")
+        return None
+    if inspect:
+        if len({i.pos_ref for i in ins}) != len(ins):
+            return trouble("some mutations at the same position")
+        if len(ins) > 1 and not any(i.code == "0" for i in ins):
+            for a, b in zip(ins[:-1], ins[1:]):
+                if b.pos_res <= ((a.pos_res + len(a.data) - 1) & U64):
+                    return trouble("some mutations overlap")
+                if a.code in "CD" and b.pos_ref <= ((a.pos_res + a.len - 1) & U64):
+                    return trouble("some mutations overlap")
+    return ins

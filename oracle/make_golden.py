@@ -216,7 +216,7 @@ def check_with_oracle(case):
     return "".join(res)
 
 
-def harvest_cohort_example(out_dir, preset="C1", stem="c1_example"):
+def harvest_cohort_example(out_dir, preset="C1", stem="c1_example", **overrides):
     """BASELINE.json config 1 stand-in: the synthetic cohort written as example.vcf +
     reference_sequences.fasta, run through the reference binary with -g mt and -g st."""
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -224,7 +224,7 @@ def harvest_cohort_example(out_dir, preset="C1", stem="c1_example"):
     from vcf2prot_amd import build
     build.build_cohort()
     from vcf2prot_amd.cohort import Cohort
-    c = Cohort.preset(preset)
+    c = Cohort.preset(preset, **overrides)
     n_samples = c.n_haplotypes // 2
     samples = [f"SAMPLE{s:04d}" for s in range(n_samples)]
     prot, off = c.proteome(), c.tx_offsets()
@@ -241,7 +241,7 @@ def harvest_cohort_example(out_dir, preset="C1", stem="c1_example"):
     vcf_path, fa_path = os.path.join(out_dir, stem + ".vcf"), os.path.join(out_dir, stem + "_reference.fasta")
     write_vcf(vcf_path, samples, [(csq, records[csq]) for csq in order])
     write_fasta(fa_path, seqs)
-    result = {"generator": "oracle/make_golden.py", "preset": preset, "samples": samples, "n_records": len(order),
+    result = {"generator": "oracle/make_golden.py", "preset": preset, "overrides": overrides, "samples": samples, "n_records": len(order),
               "oracle_binary": "vcf2prot 0.1.2 (bins/Linux)", "fasta": {}}
     with tempfile.TemporaryDirectory() as tmp:
         per_engine = {}
@@ -320,6 +320,10 @@ def main():
     if bad:
         print("  binary(0.1.2) vs source(0.1.5) unit-test skew on:", bad)
     harvest_cohort_example(args.out)
+    # wider mixes for the VCF -> FASTA test of the whole stack (tests/test_gpu_vcf_to_fasta.py)
+    harvest_cohort_example(args.out, "C1", "e2e_dense", seed_cohort=21, n_samples=6, n_transcripts=48, altered_per_hap=30, alts_poisson=2.5)
+    harvest_cohort_example(args.out, "C1", "e2e_long", seed_cohort=22, n_samples=5, n_transcripts=24, fixed_len=0, mean_len=320.0,
+                           altered_per_hap=16, alts_poisson=5.0, max_fs_tail=40, max_sl_ext=25, p_empty_hap=0.1)
 
 
 if __name__ == "__main__":

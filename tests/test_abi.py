@@ -49,6 +49,16 @@ def test_frontend_header_symbols_are_exported(built):
     assert set(names) == set(DECODE_API) | set(HOST_API), "python binding table out of sync with the header"
 
 
+def test_step4a_header_symbols_are_exported(built):
+    from vcf2prot_amd import _native as N
+    from vcf2prot_amd.step4a import STEP4A_API
+    names = _declared("v2p_step4a.h")
+    host = ctypes.CDLL(N.COHORT_LIB_PATH)
+    for n in names:
+        assert hasattr(host, n), f"{n} declared in include/v2p_step4a.h but not exported"
+    assert set(names) == set(STEP4A_API)
+
+
 def test_engine_from_str_is_engines_rs(built):
     # engines.rs:17-29
     from vcf2prot_amd.engine import Engine

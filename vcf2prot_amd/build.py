@@ -26,10 +26,10 @@ HIP_SOURCES = ["stitch_kernels.hip", "v2p_api.hip", "decode_kernels.hip", "v2p_d
 HIP_DEPS = HIP_SOURCES + ["stitch_kernels.h", "decode_kernels.h", "v2p_ctx_internal.h", "sir_pack.hpp",
                           os.path.join(ROOT, "include", "vcf2prot_hip.h"), os.path.join(ROOT, "include", "v2p_frontend.h")]
 COHORT_SOURCES = ["cohort_gen.cpp", os.path.join("host", "transcript_tasks.cpp"), os.path.join("host", "vcf_index.cpp"),
-                  os.path.join("host", "group_muts.cpp")]
+                  os.path.join("host", "group_muts.cpp"), os.path.join("host", "instructions.cpp")]
 COHORT_DEPS = COHORT_SOURCES + ["sir_pack.hpp", os.path.join(ROOT, "include", "v2p_cohort.h"),
                                 os.path.join(ROOT, "include", "v2p_step4b.h"), os.path.join(ROOT, "include", "v2p_frontend.h"),
-                                os.path.join("host", "frontend_common.hpp")]
+                                os.path.join(ROOT, "include", "v2p_step4a.h"), os.path.join("host", "frontend_common.hpp")]
 
 
 def _stale(target: str, deps) -> bool:

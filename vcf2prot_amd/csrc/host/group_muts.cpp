@@ -18,10 +18,14 @@
 #include <vector>
 
 #include "../../../include/v2p_frontend.h"
+#include "../../../include/v2p_step4a.h"
 #include "frontend_common.hpp"
+
+struct ParsedText { std::string ref_aa, mut_aa; };
 
 struct v2p_groups {
     std::string error;
+    std::vector<ParsedText> aa;                                       // per consequence: the two amino-acid strings of a valid Mutation
     int64_t error_hap = -1;
     std::vector<uint64_t> tx_begin; std::vector<uint32_t> tx_len;      // unique transcript ids (text ranges), sorted
     std::vector<v2p_mutation> muts;
@@ -149,6 +153,7 @@ int v2p_groups_build(const v2p_vcf_index* x, const uint8_t* text_u8, const uint6
     T.rank.assign(n_csq, ~0u);
     T.ident.assign(n_csq, ~0u);
     g->muts.resize(n_csq);
+    g->aa.resize(n_csq);
     {
         std::unordered_map<std::string, uint32_t> classes;
         std::string key;
@@ -166,6 +171,7 @@ int v2p_groups_build(const v2p_vcf_index* x, const uint8_t* text_u8, const uint6
                 T.ident[i] = classes.emplace(key, uint32_t(classes.size())).first->second;
             }
             g->muts[i] = m;
+            if (p.mut_ok) { g->aa[i].ref_aa = p.ref_aa; g->aa[i].mut_aa = p.mut_aa; }
         }
     }
     // str::contains of vcf_tools.rs:91: which OTHER transcript ids occur somewhere in a consequence's text
@@ -318,6 +324,16 @@ int v2p_groups_transcript(const v2p_groups* g, uint64_t rank, uint64_t* begin, u
     return 0;
 }
 const v2p_mutation* v2p_groups_mutations(const v2p_groups* g) { return g ? g->muts.data() : nullptr; }
+int v2p_groups_mutation_view(const v2p_groups* g, uint32_t id, v2p_mutation_view* out)
+{
+    if (!g || !out || id >= g->muts.size() || !g->muts[id].valid) return -1;
+    out->type = g->muts[id].type;
+    out->ref_aa_position = g->muts[id].ref_aa_position;
+    out->mut_aa_position = g->muts[id].mut_aa_position;
+    out->ref_aa = g->aa[id].ref_aa.data(); out->ref_aa_len = uint32_t(g->aa[id].ref_aa.size());
+    out->mut_aa = g->aa[id].mut_aa.data(); out->mut_aa_len = uint32_t(g->aa[id].mut_aa.size());
+    return 0;
+}
 const uint64_t* v2p_groups_hap_group_begin(const v2p_groups* g) { return g ? g->hap_group_begin.data() : nullptr; }
 const uint32_t* v2p_groups_group_transcript(const v2p_groups* g) { return g ? g->group_transcript.data() : nullptr; }
 const uint64_t* v2p_groups_group_member_begin(const v2p_groups* g) { return g ? g->group_member_begin.data() : nullptr; }

@@ -1,0 +1,93 @@
+"""VCF text + reference FASTA -> personalized FASTA text per proband, without the Rust host: the record index, the GPU
+bitmask decode, the grouping (include/v2p_frontend.h), step 4a and 4b restated in C++ (include/v2p_step4a.h,
+v2p_step4b.h), step 5 in the image builder and step 6 + FASTA emit on the GPU (include/vcf2prot_hip.h).
+
+This is the whole of `vcf2prot -f in.vcf -r ref.fasta -g gpu` (main.rs:10-61) as far as the bytes written are concerned;
+records come out in transcript order per haplotype where the reference iterates a HashMap.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+
+from . import _native as N
+from . import step4a
+from .frontend import VcfIndex, decode_bitmasks, group_per_transcript
+from .step4b import transcript_g_rep
+
+
+def read_fasta(text: str) -> Dict[str, str]:
+    """readers.rs:37-76: header = the whole line after '>', sequence = the following lines joined."""
+    lines = text.split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    records, header, seq, started = {}, "", [], False
+    for line in lines:
+        if line.endswith("\r"):
+            line = line[:-1]
+        if line.startswith(">"):
+            if header == "" and not started:
+                header = line[1:]
+            else:
+                records[header] = "".join(seq)
+                header, seq = line[1:], []
+            started = True
+        else:
+            seq.append(line)
+    records[header] = "".join(seq)
+    return records
+
+
+def vcf_to_fasta(ctx, vcf: bytes, reference_fasta: str, flags: int = step4a.DEFAULT_FLAGS) -> Dict[str, bytes]:
+    """{proband: text of <proband>.fasta} (personalized_genome.rs:72-117, altered transcripts only)."""
+    ref = read_fasta(reference_fasta)
+    idx = VcfIndex(vcf)
+    lists = decode_bitmasks(ctx, idx)
+    groups = group_per_transcript(idx, lists)
+    names = [groups.transcript_name(r) for r in range(groups.n_transcripts)]
+    # resident reference: the transcripts the file touches, and their two record headers each
+    off, pieces, hdr, hdr_off = {}, [], ["\n"], {}
+    pos, hpos = 0, 1
+    for nm in names:
+        if nm in ref:
+            off[nm] = pos
+            pieces.append(ref[nm])
+            pos += len(ref[nm])
+            for h in (1, 2):
+                text = f">{nm}_{h}\n"
+                hdr_off[(nm, h)] = (hpos, len(text))
+                hdr.append(text)
+                hpos += len(text)
+    proteome = np.frombuffer("".join(pieces).encode(), dtype=np.uint8) if pieces else np.zeros(0, np.uint8)
+    ctx.upload_reference(proteome, np.frombuffer("".join(hdr).encode(), dtype=np.uint8))
+    b = ctx.batch()
+    try:
+        for hap in range(lists.n_haplotypes):
+            b.begin_haplotype()
+            for tx, members in groups.of(hap):
+                if tx not in ref:
+                    continue                                           # transcript_instructions.rs:37-41: Err -> skipped
+                rc, ins = step4a.group_instructions(groups, members, flags)
+                if rc == step4a.SKIP:
+                    continue
+                if rc != step4a.OK:
+                    raise N.V2PError(-28, f"instruction generation aborts for transcript {tx} (haplotype list {hap})", hap)
+                rc, t, alt, res_len = transcript_g_rep(ins, len(ref[tx]))
+                if rc == 1:
+                    continue                                           # haplotype_instruction.rs:100-104: Err -> skipped
+                if rc != 0:
+                    raise N.V2PError(-28, f"task generation aborts for transcript {tx} (status {rc})", hap)
+                ho, hl = hdr_off[(tx, 1 + hap % 2)]
+                b.add_transcript(t[:, 0].astype(np.uint8), t[:, 1], t[:, 2], t[:, 3], off[tx], len(ref[tx]),
+                                 np.frombuffer(alt, dtype=np.uint8), res_len, ho, hl)
+            b.end_haplotype()
+        b.finalize()
+        b.execute()
+        b.sync()
+        out = {}
+        for s, name in enumerate(idx.sample_names()):
+            out[name] = b.download_hap(2 * s).tobytes() + b.download_hap(2 * s + 1).tobytes()
+        return out
+    finally:
+        b.close()
