@@ -38,3 +38,33 @@ def test_harness_thread_pool_matches_oracle(harness, coracle, preset, n, threads
         t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
         want = coracle.gir_execute(t, c.ref_tape_u32(h), hap.alt.astype(np.uint32), np.full(hap.n_res, ord("."), dtype=np.uint32))
         assert out["digests"][h] == coracle.digest_u32(want), (preset, h)
+
+
+@pytest.mark.parametrize("stem", ["c1_example", "e2e_dense", "e2e_long"])
+def test_harness_vcf_mode_writes_the_reference_files(harness, tmp_path, stem):
+    """`v2p_harness vcf in.vcf ref.fasta outdir --no-test`: the reference's command line with no Rust behind it; the files it
+    writes hold the same records as the reference binary's."""
+    golden = os.path.join(ROOT, "tests", "golden")
+    want = json.load(open(os.path.join(golden, stem + ".json")))["fasta"]
+    p = subprocess.run([harness, "vcf", os.path.join(golden, stem + ".vcf"), os.path.join(golden, stem + "_reference.fasta"), str(tmp_path), "--no-test"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    for sample, recs in want.items():
+        lines = open(os.path.join(tmp_path, sample + ".fasta")).read().split("\n")[:-1]
+        got = sorted([lines[i][1:], lines[i + 1]] for i in range(0, len(lines), 2))
+        assert got == sorted(recs), sample
+
+
+def test_harness_vcf_mode_aborts_like_the_reference(harness, tmp_path):
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "decode_cases.json")))["cases"]
+    n = 0
+    for c in cases:
+        if not c["panics"]:
+            continue
+        vcf, fa = tmp_path / "in.vcf", tmp_path / "ref.fasta"
+        vcf.write_text(c["vcf"])
+        fa.write_text(c["reference_fasta"])
+        p = subprocess.run([harness, "vcf", str(vcf), str(fa), str(tmp_path), "--no-test"], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 101 and "panicked" in p.stderr, (c["name"], p.stdout, p.stderr)    # a Rust panic exits with 101
+        n += 1
+    assert n >= 9

@@ -1,1 +1,1 @@
-timeout 900 python -m pytest tests/test_gpu_vcf_to_fasta.py -x -q 2>&1 | tail -30
+timeout 900 python -m pytest tests/test_gpu_harness.py -x -q 2>&1 | tail -20

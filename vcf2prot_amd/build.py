@@ -77,7 +77,9 @@ def build_cohort(force: bool = False, verbose: bool = False) -> str:
 
 HARNESS_BIN = os.path.join(LIBDIR, "v2p_harness")
 HARNESS_DEPS = [os.path.join("host", "v2p_harness.cpp"), os.path.join("host", "ppgg_gpu.hpp"),
-                os.path.join(ROOT, "include", "vcf2prot_hip.h"), os.path.join(ROOT, "include", "v2p_cohort.h")]
+                os.path.join(ROOT, "include", "vcf2prot_hip.h"), os.path.join(ROOT, "include", "v2p_cohort.h"),
+                os.path.join(ROOT, "include", "v2p_frontend.h"), os.path.join(ROOT, "include", "v2p_step4a.h"),
+                os.path.join(ROOT, "include", "v2p_step4b.h")]
 
 
 def build_harness(force: bool = False, verbose: bool = False) -> str:

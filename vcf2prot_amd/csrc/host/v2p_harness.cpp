@@ -6,13 +6,21 @@
 //
 //   v2p_harness kat                          reference known-answer tests through the mirror
 //   v2p_harness run <preset> <haps> <threads>   e.g. run C2 64 8
+//   v2p_harness vcf <in.vcf> <reference.fasta> <outdir> [--no-test]   VCF -> one FASTA per proband, no Rust anywhere
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <map>
 #include <mutex>
+#include <sstream>
+#include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "../../../include/v2p_cohort.h"
+#include "../../../include/v2p_step4a.h"
 #include "ppgg_gpu.hpp"
 
 using namespace ppgg;
@@ -110,8 +118,163 @@ static int run(const char* preset, uint64_t n_haps, int threads)
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// vcf <in.vcf> <reference.fasta> <outdir> [--no-test]: the whole of `vcf2prot -f .. -r .. -o .. -g gpu` (main.rs:10-61)
+// above the C ABI: record index, GPU bitmask decode, grouping (v2p_frontend.h), steps 4a / 4b (v2p_step4a.h, v2p_step4b.h),
+// step 5 in the image builder, step 6 + FASTA emit on the GPU, one <proband>.fasta per proband (personalized_genome.rs:72-117).
+static std::string slurp(const char* path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error(std::string("could not read ") + path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+// readers.rs:37-76
+static std::map<std::string, std::string> read_fasta(const std::string& text)
+{
+    std::map<std::string, std::string> rec;
+    std::string header, seq;
+    bool started = false;
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t e = text.find('\n', pos);
+        if (e == std::string::npos) e = text.size();
+        std::string line = text.substr(pos, e - pos);
+        pos = e + 1;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (!line.empty() && line[0] == '>') {
+            if (header.empty() && !started) header = line.substr(1);
+            else { rec[header] = seq; header = line.substr(1); seq.clear(); }
+            started = true;
+        } else {
+            seq += line;
+        }
+    }
+    rec[header] = seq;
+    return rec;
+}
+
+static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* outdir, bool no_test)
+{
+    const std::string vcf = slurp(vcf_path);
+    const auto ref = read_fasta(slurp(fasta_path));
+    const uint8_t* text = reinterpret_cast<const uint8_t*>(vcf.data());
+    v2p_vcf_index* idx = nullptr;
+    if (v2p_vcf_index_build(text, vcf.size(), &idx) != 0) {
+        std::fprintf(stderr, "reading the file failed: %s\n", v2p_vcf_index_error(idx));
+        return 101;
+    }
+    const uint64_t S = v2p_vcf_index_n_samples(idx), R = v2p_vcf_index_n_records(idx);
+    GpuContext ctx;
+    v2p_decode* dec = nullptr;
+    if (v2p_decode_run(ctx.raw(), text, vcf.size(), v2p_vcf_index_row_begin(idx), v2p_vcf_index_row_end(idx), R, S,
+                       v2p_vcf_index_csq_begin(idx), v2p_vcf_index_csq_supported(idx), &dec) != V2P_OK) {
+        std::fprintf(stderr, "panicked: %s\n", v2p_last_error(ctx.raw()));
+        return 101;
+    }
+    std::vector<uint64_t> hap_begin(2 * S + 1);
+    v2p_decode_counts(dec, hap_begin.data());
+    std::vector<uint32_t> ids(hap_begin.back() + 1);
+    v2p_decode_download(dec, ids.data());
+    v2p_decode_destroy(dec);
+    v2p_groups* g = nullptr;
+    if (v2p_groups_build(idx, text, hap_begin.data(), ids.data(), 2 * S, 0, &g) != 0) {
+        std::fprintf(stderr, "panicked: %s\n", v2p_groups_error(g));
+        return 101;
+    }
+    // resident reference: the transcripts the file touches + their two record headers
+    const uint64_t n_tx = v2p_groups_n_transcripts(g);
+    std::vector<std::string> names(n_tx);
+    std::vector<int64_t> tx_off(n_tx, -1);
+    std::vector<uint64_t> tx_len(n_tx, 0), hdr_off(2 * n_tx, 0);
+    std::string proteome, headers = "\n";
+    for (uint64_t r = 0; r < n_tx; ++r) {
+        uint64_t b, n;
+        v2p_groups_transcript(g, r, &b, &n);
+        names[r] = vcf.substr(b, n);
+        auto it = ref.find(names[r]);
+        if (it == ref.end()) continue;
+        tx_off[r] = int64_t(proteome.size());
+        tx_len[r] = it->second.size();
+        proteome += it->second;
+        for (int h = 0; h < 2; ++h) { hdr_off[2 * r + h] = headers.size(); headers += ">" + names[r] + "_" + char('1' + h) + "\n"; }
+    }
+    auto chk = [&](int rc) { if (rc != V2P_OK) { std::fprintf(stderr, "panicked: %s\n", v2p_last_error(ctx.raw())); std::exit(101); } };
+    chk(v2p_upload_reference(ctx.raw(), reinterpret_cast<const uint8_t*>(proteome.data()), proteome.size(),
+                             reinterpret_cast<const uint8_t*>(headers.data()), headers.size()));
+    v2p_batch* b = nullptr;
+    chk(v2p_batch_create(ctx.raw(), &b));
+    const uint64_t* hgb = v2p_groups_hap_group_begin(g);
+    const uint32_t* gtx = v2p_groups_group_transcript(g);
+    const uint64_t* gmb = v2p_groups_group_member_begin(g);
+    const uint32_t* mid = v2p_groups_member_ids(g);
+    const uint32_t flags = no_test ? 0u : (V2P_4A_INSPECT_INS_GEN | V2P_4A_PANIC_INSPECT_ERR);     // cli.rs:275-368
+    std::vector<v2p_mutation_view> views;
+    std::vector<v2p_instruction> ins;
+    std::vector<uint8_t> code, alt;
+    std::vector<uint64_t> sp, ln, sr;
+    for (uint64_t hap = 0; hap < 2 * S; ++hap) {
+        chk(v2p_batch_begin_haplotype(b));
+        for (uint64_t k = hgb[hap]; k < hgb[hap + 1]; ++k) {
+            const uint32_t r = gtx[k];
+            if (tx_off[r] < 0) continue;                                       // transcript_instructions.rs:37-41
+            const uint64_t n = gmb[k + 1] - gmb[k];
+            views.resize(n); ins.resize(n + 1);
+            for (uint64_t i = 0; i < n; ++i) v2p_groups_mutation_view(g, mid[gmb[k] + i], &views[i]);
+            uint64_t n_ins = 0;
+            const int rc4a = v2p_transcript_instructions(views.data(), n, flags, ins.data(), ins.size(), &n_ins);
+            if (rc4a == V2P_4A_SKIP) continue;
+            if (rc4a != V2P_4A_OK) { std::fprintf(stderr, "panicked: instruction generation for transcript %s\n", names[r].c_str()); return 101; }
+            uint64_t payload = 8;
+            for (uint64_t i = 0; i < n_ins; ++i) payload += 2 * ins[i].data_len;
+            const uint64_t cap = 3 * n_ins + 4;
+            code.resize(cap); sp.resize(cap); ln.resize(cap); sr.resize(cap); alt.resize(payload);
+            uint64_t n_tasks = 0, n_alt = 0, res_len = 0;
+            const int rc4b = v2p_transcript_g_rep(ins.data(), n_ins, tx_len[r], code.data(), sp.data(), ln.data(), sr.data(), cap, &n_tasks,
+                                                  alt.data(), payload, &n_alt, &res_len);
+            if (rc4b == V2P_4B_MUST_BE_LAST) continue;                         // haplotype_instruction.rs:100-104
+            if (rc4b != V2P_4B_OK) { std::fprintf(stderr, "panicked: task generation for transcript %s (%d)\n", names[r].c_str(), rc4b); return 101; }
+            chk(v2p_batch_add_transcript(b, code.data(), sp.data(), ln.data(), sr.data(), n_tasks, uint64_t(tx_off[r]), tx_len[r],
+                                         alt.data(), n_alt, res_len, hdr_off[2 * r + (hap & 1)], uint32_t(names[r].size() + 4)));
+        }
+        chk(v2p_batch_end_haplotype(b));
+    }
+    chk(v2p_batch_finalize(b));
+    chk(v2p_batch_execute(b));
+    chk(v2p_batch_sync(b));
+    uint64_t written = 0;
+    std::vector<uint8_t> buf;
+    for (uint64_t s = 0; s < S; ++s) {
+        uint64_t nb, nl;
+        v2p_vcf_index_sample(idx, s, &nb, &nl);
+        const std::string path = std::string(outdir) + "/" + vcf.substr(nb, nl) + ".fasta";
+        std::ofstream f(path, std::ios::binary);
+        if (!f) { std::fprintf(stderr, "Could not create %s\n", path.c_str()); return 101; }
+        for (int h = 0; h < 2; ++h) {
+            uint64_t begin, len;
+            chk(v2p_batch_hap_range(b, 2 * s + h, &begin, &len));
+            buf.resize(len);
+            if (len) chk(v2p_batch_download(b, begin, len, buf.data()));
+            f.write(reinterpret_cast<const char*>(buf.data()), std::streamsize(len));
+            written += len;
+        }
+    }
+    std::printf("vcf: %llu records, %llu probands, %llu bytes of FASTA written to %s\n", (unsigned long long)R, (unsigned long long)S,
+                (unsigned long long)written, outdir);
+    v2p_batch_destroy(b);
+    v2p_groups_destroy(g);
+    v2p_vcf_index_destroy(idx);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc >= 5 && !std::strcmp(argv[1], "vcf")) {
+        try { return vcf_mode(argv[2], argv[3], argv[4], argc >= 6 && !std::strcmp(argv[5], "--no-test")); }
+        catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 101; }
+    }
     if (argc >= 2 && !std::strcmp(argv[1], "kat")) return kat();
     if (argc >= 5 && !std::strcmp(argv[1], "run")) return run(argv[2], std::strtoull(argv[3], nullptr, 10), std::atoi(argv[4]));
     std::fprintf(stderr, "usage: v2p_harness kat | run <preset> <haplotypes> <threads>\n");
