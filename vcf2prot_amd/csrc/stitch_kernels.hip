@@ -40,6 +40,24 @@ __device__ __forceinline__ u32x4 gather16(uint64_t addr)
     return reinterpret_cast<gptr>(addr)->v;
 }
 
+// Same 16 bytes through dword-aligned loads (x4 + x1) and four v_alignbyte.
+struct __attribute__((packed, aligned(4))) dwaligned16 { u32x4 v; };
+__device__ __forceinline__ u32x4 gather16_dw(uint64_t addr)
+{
+    typedef const __attribute__((address_space(1))) dwaligned16* gptr;
+    typedef const __attribute__((address_space(1))) uint32_t* dptr;
+    const uint64_t base = addr & ~3ull;
+    const uint32_t sh = uint32_t(addr) & 3u;
+    const u32x4 v = reinterpret_cast<gptr>(base)->v;
+    const uint32_t e = *reinterpret_cast<dptr>(base + 16u);
+    u32x4 o;
+    o.x = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
+    o.y = __builtin_amdgcn_alignbyte(v.z, v.y, sh);
+    o.z = __builtin_amdgcn_alignbyte(v.w, v.z, sh);
+    o.w = __builtin_amdgcn_alignbyte(e, v.w, sh);
+    return o;
+}
+
 // ---- wave64 inclusive add-scan with DPP (row_shr 1/2/4/8, row_bcast 15/31) ----
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
 {
@@ -72,7 +90,8 @@ __device__ __forceinline__ void report(unsigned long long* status, uint64_t inde
 //      unaligned dwordx4 gathers (s_adj[r+i] + block offset) are issued back to back and
 //      merged by tail-overwrite with 64-bit byte masks; only blocks cut by four or more
 //      tasks take the extra loop.  Then one aligned, non-temporal dwordx4 store.
-// DBG != 0: timing-only ablations (results are wrong): 1 = no gathers, 2 = no stores.
+// DBG != 0: timing-only ablations (results are wrong): 1 = no gathers, 2 = no stores; A/B switches with correct
+// results: 3 = dword-aligned gathers everywhere, 4 = byte-aligned gathers everywhere.
 __device__ __forceinline__ u32x4 overwrite_tail(u32x4 v, u32x4 ld, uint32_t ja, bool take)
 {
     // bytes >= ja of the block come from ld (ja in 1..15)
@@ -232,9 +251,15 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                 u32x4 v, g1 = {0u, 0u, 0u, 0u}, g2 = {0u, 0u, 0u, 0u};
                 if (DBG == 20) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); k1 = __builtin_amdgcn_s_memtime(); }
                 if (DBG != 1) {
+                    if (DBG == 3 || (TPT >= 4 && DBG != 4)) {                  // dense descriptors (short tasks): dword-aligned loads win
+                        v = gather16_dw(a0 + int64_t(rel));
+                        if (need1) g1 = gather16_dw(a1 + int64_t(rel));
+                        if (need2) g2 = gather16_dw(a2 + int64_t(rel));
+                    } else {
                     v = gather16(a0 + int64_t(rel));
                     if (need1) g1 = gather16(a1 + int64_t(rel));
                     if (need2) g2 = gather16(a2 + int64_t(rel));
+                    }
                     if (DBG == 20) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k2 = __builtin_amdgcn_s_memtime(); }
                 } else {
                     v = u32x4{uint32_t(a0), e0, r, hi};
@@ -250,10 +275,10 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                         const uint32_t o1 = s_off[r + 1u], o2 = s_off[r + 2u], o3 = s_off[r + 3u];
                         const uint64_t b0 = s_adj[r], b1 = s_adj[r + 1u], b2 = s_adj[r + 2u];
                         const bool n1 = o1 < hi, n2 = o2 < hi;
-                        const u32x4 h0 = gather16(b0 + int64_t(rel));
+                        const u32x4 h0 = (TPT >= 4 && DBG != 4) ? gather16_dw(b0 + int64_t(rel)) : gather16(b0 + int64_t(rel));
                         u32x4 h1 = {0u, 0u, 0u, 0u}, h2 = {0u, 0u, 0u, 0u};
-                        if (n1) h1 = gather16(b1 + int64_t(rel));
-                        if (n2) h2 = gather16(b2 + int64_t(rel));
+                        if (n1) h1 = (TPT >= 4 && DBG != 4) ? gather16_dw(b1 + int64_t(rel)) : gather16(b1 + int64_t(rel));
+                        if (n2) h2 = (TPT >= 4 && DBG != 4) ? gather16_dw(b2 + int64_t(rel)) : gather16(b2 + int64_t(rel));
                         v = overwrite_tail(v, h0, uint32_t(int32_t(pos) - rel), true);
                         v = overwrite_tail(v, h1, uint32_t(int32_t(o1) - rel), n1);
                         v = overwrite_tail(v, h2, uint32_t(int32_t(o2) - rel), n2);
@@ -479,6 +504,8 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
 #define V2P_LAUNCH(TT) do { \
         if (dbg == 1) hipLaunchKernelGGL((stitch_kernel<TT, true, 1>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
         else if (dbg == 2) hipLaunchKernelGGL((stitch_kernel<TT, true, 2>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
+        else if (dbg == 3) hipLaunchKernelGGL((stitch_kernel<TT, true, 3>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
+        else if (dbg == 4) hipLaunchKernelGGL((stitch_kernel<TT, true, 4>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
         else if (dbg == 20) hipLaunchKernelGGL((stitch_kernel<TT, true, 20>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
         else if (nt) hipLaunchKernelGGL((stitch_kernel<TT, true, 0>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
         else hipLaunchKernelGGL((stitch_kernel<TT, false, 0>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); } while (0)

@@ -167,8 +167,12 @@ int v2p_decode_run(v2p_ctx* ctx, const uint8_t* text, uint64_t n_text,
     DTRY(hipMemcpyAsync(d->d_rows + n_records, row_end, n_records * sizeof(uint64_t), hipMemcpyHostToDevice, st), "H2D(row_end)");
     DTRY(hipMemcpyAsync(d->d_csq, csq.data(), csq.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st), "H2D(csq)");
 
-    hipEvent_t ev[5];
-    for (auto& e : ev) DTRY(hipEventCreate(&e), "hipEventCreate");
+    struct Events {                                     // destroyed on every exit path
+        hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        ~Events() { for (auto x : e) if (x) (void)hipEventDestroy(x); }
+    } evs;
+    hipEvent_t* ev = evs.e;
+    for (int k = 0; k < 5; ++k) DTRY(hipEventCreate(&ev[k]), "hipEventCreate");
     // multi-word masks are rare; start with room for one field in 16 and retry with the exact need if that was short
     uint64_t ovf_words = n_records * n_samples / 4 + (1u << 16);
     if (ovf_words >= (1ull << 31)) ovf_words = (1ull << 31) - 1;
@@ -210,7 +214,6 @@ int v2p_decode_run(v2p_ctx* ctx, const uint8_t* text, uint64_t n_text,
         for (int k = 0; k < 4; ++k) (void)hipEventElapsedTime(&d->ms[k], ev[k], ev[k + 1]);
         break;
     }
-    for (auto& e : ev) (void)hipEventDestroy(e);
     if (rc != V2P_OK) { d->release(); delete d; return rc; }
     *out = d;
     return V2P_OK;
