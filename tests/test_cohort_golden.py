@@ -154,3 +154,43 @@ def test_packed_cohort_on_gpu_matches_oracle(built, gpu_ctx, coracle, preset, h0
         if i % 7 == 0:
             assert np.array_equal(b.download_hap(i), want), (preset, i)
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,n,min_bytes", [("C2", 2000, 15 * 10 ** 9), ("C3", 2500, 4 * 10 ** 9), ("C5", 12500, 9 * 10 ** 8)])
+def test_full_size_shard_every_haplotype_by_digest(built, gpu_ctx, coracle, preset, n, min_bytes):
+    """One GPU's share of BASELINE configs[1] / [2] / [4] in a single launch (C2: all 1 000 samples x 20 000 transcripts,
+    1.6e10 residues; C3: 2 500 of the 20 000 haplotypes = the 8-GPU shard; C5: 12 500 of the 100 000 deep haplotypes):
+    the digest of EVERY haplotype equals the digest of the oracle's result for that haplotype."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from vcf2prot_amd.cohort import Cohort
+    c = Cohort.preset(preset)
+    assert c.n_haplotypes >= n
+    gpu_ctx.upload_proteome(c.proteome())
+    img = c.pack(0, n, n_threads=min(64, os.cpu_count() or 1))
+    assert img.out_bytes > min_bytes
+    b = gpu_ctx.batch()
+    b.set_packed(img.desc, img.chunks, img.payload, img.hap_out_begin)
+    b.finalize()
+    b.execute()
+    b.sync()
+    dig = b.digests()
+    workers = min(32, os.cpu_count() or 1)
+
+    def oracle_digests(w):
+        cc = Cohort.preset(preset)                     # own generator state per thread
+        out = {}
+        for h in range(w, n, workers):
+            hap = cc.haplotype(h)
+            t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+            want = coracle.gir_execute_u8(t, cc.ref_tape_u32(h).astype(np.uint8), hap.alt, np.full(hap.n_res, ord("."), dtype=np.uint8))
+            out[h] = coracle.digest_u8(want)
+        return out
+    want = {}
+    with ThreadPoolExecutor(workers) as pool:
+        for part in pool.map(oracle_digests, range(workers)):
+            want.update(part)
+    bad = [h for h in range(n) if int(dig[h]) != want[h]]
+    assert not bad, (preset, bad[:10])
+    b.close()
