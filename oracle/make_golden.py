@@ -129,6 +129,7 @@ def harvest_single_transcript(name, ref_seq, csqs, tmp):
     result["fasta"] = read_fasta_records(fpath) if os.path.exists(fpath) else None
     if rc != 0:
         result["log_tail"] = log[-600:]
+        result["panic_line"] = next((ln for ln in log.split("\n") if "panicked at" in ln), "")
     return result
 
 

@@ -1,0 +1,89 @@
+"""600 random single-transcript cases answered by the reference binary (oracle/make_random_kats.py ->
+tests/golden/kat_random.json; every other case with neighbouring / colliding mutation ranges): the Instruction list, the
+Vec<Task> and the FASTA record it produced, or its abort -- 54 of the 55 aborts are slice panics inside Task::execute
+(task.rs:44,48), i.e. on the hot path itself, with the Task vector already printed.
+
+Steps 4a (restatement and C++), 4b (C++) and the executor (GPU) must reproduce all of it."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+import frontend_oracle as F  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def cases():
+    with open(os.path.join(HERE, "golden", "kat_random.json")) as f:
+        return json.load(f)["cases"]
+
+
+def chain(c):
+    """('panic' | 'skip' | instruction dicts, 4b status, tasks, alt, res_len) of the product for one case (checks off, like the binary)."""
+    from vcf2prot_amd import step4a
+    from vcf2prot_amd.step4b import transcript_g_rep
+    groups = F.group_muts_per_transcript(c["mutations"])
+    assert len(groups) == 1
+    muts = groups[0][1]
+    try:
+        o = F.transcript_instructions(c["transcript"], muts, inspect=False, panic_inspect=False)
+        o = "skip" if o is None else [i.as_dict() for i in o]
+    except F.ReferencePanic:
+        o = "panic"
+    rc, p = step4a.transcript_instructions([(m.mut_type, m.ref_aa_position, m.mut_aa_position, m.ref_aa, m.mut_aa) for m in muts], 0)
+    p = {0: p, 1: "skip", 2: "panic"}[rc]
+    assert o == p, c["name"]                                   # restatement == C++ on every case
+    if not isinstance(p, list):
+        return p, None, None, None, None
+    rc, t, alt, res_len = transcript_g_rep(p, len(c["ref"]))
+    return p, rc, t, alt, res_len
+
+
+def test_steps_4a_4b_reproduce_the_reference(built, cases):
+    n_ok = n_abort_early = n_abort_exec = 0
+    codes = set()
+    for c in cases:
+        ins, rc, t, alt, res_len = chain(c)
+        if not c["panics"]:
+            assert ins == c["instructions"], c["name"]
+            assert rc == 0 and t.tolist() == c["tasks"] and res_len == len(c["record"]), c["name"]
+            if c["tasks"]:
+                assert alt.decode() == c["alt"], c["name"]
+            codes |= {i["code"] for i in ins}
+            n_ok += 1
+        elif isinstance(ins, list) and rc == 0:
+            # the reference printed this very Task vector and then died executing it
+            assert c["panic_in_executor"] and ins == c["instructions"] and t.tolist() == c["tasks"], c["name"]
+            n_abort_exec += 1
+        else:
+            n_abort_early += 1                                  # refused before the executor (usize arithmetic the release binary let wrap)
+    assert n_ok >= 500 and n_abort_exec >= 10 and n_abort_early >= 10
+    assert {"M", "N", "I", "J", "D", "C", "F", "R", "G", "X", "L", "0", "U", "K", "A", "B", "P", "T", "2", "3"} <= codes
+
+
+@pytest.mark.gpu
+def test_executor_reproduces_records_and_slice_panics(built, gpu_ctx, cases):
+    from vcf2prot_amd import _native as N
+    n_rec = n_panic = 0
+    for c in cases:
+        ins, rc, t, alt, res_len = chain(c)
+        if not isinstance(ins, list) or rc != 0:
+            continue
+        ref = np.frombuffer(c["ref"].encode(), dtype=np.uint8).astype(np.uint32)
+        a32 = np.frombuffer(alt, dtype=np.uint8).astype(np.uint32)
+        out = np.full(res_len, ord("."), dtype=np.uint32)
+        args = (t[:, 0].astype(np.uint8), t[:, 1], t[:, 2], t[:, 3], ref, a32, out)
+        if c["panics"]:
+            with pytest.raises(N.V2PError) as e:               # task.rs:44,48: the slice panics of Task::execute
+                gpu_ctx.execute_gir(*args)
+            assert e.value.code in (N.V2P_ERR_RES_OOB, N.V2P_ERR_SRC_OOB), c["name"]
+            n_panic += 1
+        else:
+            gpu_ctx.execute_gir(*args)
+            assert "".join(map(chr, out)) == c["record"], c["name"]
+            n_rec += 1
+    assert n_rec >= 500 and n_panic >= 10

@@ -1,2 +1,1 @@
-python tools/ab.py --rounds 12 "dbg=0" "strided=1" "dbg=0" "strided=1" | tail -4
-python tools/ab.py --workload C5 --samples 10000 --rounds 8 "dbg=0" "strided=1" | tail -2
+timeout 900 python -m pytest tests/test_random_kats.py -x -q 2>&1 | tail -12
