@@ -157,3 +157,22 @@ def test_cohort_scale_counts(built, gpu_ctx):
         for h in (0, 1):
             assert got.of(2 * s + h).tolist() == np.nonzero((m[:, s] >> h) & 1)[0].tolist()
     assert int(got.hap_begin[-1]) == int(((m & 1) != 0).sum() + ((m & 2) != 0).sum())
+
+
+def test_many_multi_word_masks_force_the_capacity_retry(built, gpu_ctx):
+    """Every column carries a four-word mask: the side list outgrows its first allocation and v2p_decode_run runs again
+    with the exact size."""
+    import random
+    rng = random.Random(8)
+    S, R, n = 64, 330, 50
+    head = "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(f"S{i}" for i in range(S)) + "\n"
+    rows = []
+    for r in range(R):
+        csq = ",".join(f"missense|G|T{(r * n + j) % 997}|protein_coding|+|{1 + j}A>{1 + j}C|1A>C" for j in range(n))
+        cols = []
+        for s in range(S):
+            w = [rng.randrange(1, 1 << 30) for _ in range(3)] + [rng.randrange(1, 1 << 10)]      # indices 45..49 in the last word
+            cols.append("0|1:" + ",".join(map(str, w)))
+        rows.append(f"1\t{r}\t.\tA\tC\t.\t.\tBCSQ={csq}\tGT:BCSQ\t" + "\t".join(cols))
+    assert R * S * 5 > R * S // 4 + 65536
+    assert_same_lists(gpu_ctx, head + "\n".join(rows) + "\n")

@@ -1,1 +1,1 @@
-timeout 900 python -m pytest tests/test_random_kats.py -x -q 2>&1 | tail -12
+timeout 900 python -m pytest tests/test_gpu_decode.py -x -q -k "capacity" 2>&1 | tail -12
