@@ -812,7 +812,7 @@ int v2p_pipeline_submit(v2p_pipeline* p,
     const size_t b_desc = size_t(n_desc) * 8, b_chunks = size_t(n_chunks) * sizeof(Chunk);
     const size_t o_chunks = (b_desc + 15) & ~size_t(15), o_payload = (o_chunks + b_chunks + 15) & ~size_t(15);
     HIP_TRY(c, s.h_in.ensure(o_payload + n_payload), "hipHostMalloc(in)");
-    HIP_TRY(c, s.h_out.ensure(out_bytes + 8), "hipHostMalloc(out)");
+    HIP_TRY(c, s.h_out.ensure(out_bytes + 16), "hipHostMalloc(out)");            // result + the 8-byte status word behind it, 8-aligned
     HIP_TRY(c, s.d_desc.ensure(b_desc), "hipMalloc(desc)");
     HIP_TRY(c, s.d_chunks.ensure(b_chunks), "hipMalloc(chunks)");
     HIP_TRY(c, s.d_payload.ensure(n_payload), "hipMalloc(payload)");
