@@ -127,6 +127,14 @@ def test_grouping_random(built):
         compare_groups(random_vcf(100 + seed, 60, 9, n_tx=12 if seed % 2 else 50), n_threads=1 + seed % 4)
 
 
+def test_grouping_large_table_uses_the_worker_threads(built):
+    """More than 8 192 consequences: the per-file table (parse + substring matches) is built on several threads."""
+    text = random_vcf(77, 1200, 5, n_tx=400)
+    from frontend_util import oracle_index
+    assert oracle_index(text)[3][-1] > 3 * 4096
+    compare_groups(text, n_threads=7)
+
+
 def test_grouping_abort_on_two_mutations_one_position(built):
     from vcf2prot_amd import _native as N
     a = "missense|G|TX|protein_coding|+|12C>12I|1A>T"

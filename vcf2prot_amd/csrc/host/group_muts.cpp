@@ -130,10 +130,23 @@ int v2p_groups_build(const v2p_vcf_index* x, const uint8_t* text_u8, const uint6
     const uint32_t* tl = v2p_vcf_index_csq_text_len(x);
     const uint8_t* sup = v2p_vcf_index_csq_supported(x);
 
+    if (!n_threads) n_threads = std::max(1u, std::thread::hardware_concurrency());
+    // run f(begin, end) over [0, n_csq) on the worker threads
+    auto parallel_csq = [&](auto&& f) {
+        const uint32_t nt = uint32_t(std::min<uint64_t>(n_threads, std::max<uint64_t>(1, n_csq / 4096)));
+        std::vector<std::thread> th;
+        for (uint32_t t = 1; t < nt; ++t) th.emplace_back([&, t] { f(n_csq * t / nt, n_csq * (t + 1) / nt, t); });
+        f(0, n_csq / nt, 0u);
+        for (auto& x : th) x.join();
+        return nt;
+    };
+
     Table T;
     T.parsed.resize(n_csq);
-    for (uint64_t i = 0; i < n_csq; ++i)
-        if (sup[i]) T.parsed[i] = parse_csq(std::string_view(text + tb[i], tl[i]));      // unsupported ones never reach a haplotype
+    parallel_csq([&](uint64_t b, uint64_t e, uint32_t) {
+        for (uint64_t i = b; i < e; ++i)
+            if (sup[i]) T.parsed[i] = parse_csq(std::string_view(text + tb[i], tl[i]));  // unsupported ones never reach a haplotype
+    });
 
     // unique transcript ids of the file, bytewise sorted (Vec<String>::sort of vcf_tools.rs:126-128, file-wide)
     {
@@ -183,29 +196,43 @@ int v2p_groups_build(const v2p_vcf_index* x, const uint8_t* text_u8, const uint6
             by_len[T.names[r].size()][h].push_back(r);
         }
         T.extra_begin.assign(n_csq + 1, 0);
-        std::vector<uint32_t> found;
-        for (uint64_t i = 0; i < n_csq; ++i) {
-            T.extra_begin[i] = uint32_t(T.extra.size());
-            if (!T.parsed[i].split_ok) continue;                  // a consequence that does not split never becomes a Mutation
-            std::string_view s(text + tb[i], tl[i]);
-            found.clear();
-            for (auto& [len, table] : by_len) {
-                if (len == 0 || len > s.size()) continue;
-                uint64_t pw = 1, h = 0;
-                for (size_t k = 0; k + 1 < len; ++k) pw *= HB;
-                for (size_t k = 0; k < len; ++k) h = h * HB + uint8_t(s[k]);
-                for (size_t k = 0;; ++k) {
-                    auto it = table.find(h);
-                    if (it != table.end())
-                        for (uint32_t r : it->second)
-                            if (r != T.rank[i] && T.names[r] == s.substr(k, len)) found.push_back(r);
-                    if (k + len >= s.size()) break;
-                    h = (h - uint8_t(s[k]) * pw) * HB + uint8_t(s[k + len]);
+        std::vector<std::vector<uint32_t>> part_extra(n_threads), part_count(n_threads);
+        std::vector<uint64_t> part_begin(n_threads, 0);
+        const uint32_t used = parallel_csq([&](uint64_t cb, uint64_t ce, uint32_t t) {
+            std::vector<uint32_t> found;
+            part_begin[t] = cb;
+            part_count[t].assign(ce - cb, 0);
+            for (uint64_t i = cb; i < ce; ++i) {
+                if (!T.parsed[i].split_ok) continue;              // a consequence that does not split never becomes a Mutation
+                std::string_view s(text + tb[i], tl[i]);
+                found.clear();
+                for (auto& [len, table] : by_len) {
+                    if (len == 0 || len > s.size()) continue;
+                    uint64_t pw = 1, h = 0;
+                    for (size_t k = 0; k + 1 < len; ++k) pw *= HB;
+                    for (size_t k = 0; k < len; ++k) h = h * HB + uint8_t(s[k]);
+                    for (size_t k = 0;; ++k) {
+                        auto it = table.find(h);
+                        if (it != table.end())
+                            for (uint32_t r : it->second)
+                                if (r != T.rank[i] && T.names[r] == s.substr(k, len)) found.push_back(r);
+                        if (k + len >= s.size()) break;
+                        h = (h - uint8_t(s[k]) * pw) * HB + uint8_t(s[k + len]);
+                    }
                 }
+                std::sort(found.begin(), found.end());
+                found.erase(std::unique(found.begin(), found.end()), found.end());
+                part_count[t][i - cb] = uint32_t(found.size());
+                part_extra[t].insert(part_extra[t].end(), found.begin(), found.end());
             }
-            std::sort(found.begin(), found.end());
-            found.erase(std::unique(found.begin(), found.end()), found.end());
-            T.extra.insert(T.extra.end(), found.begin(), found.end());
+        });
+        for (uint32_t t = 0; t < used; ++t) {                     // parts are consecutive ranges: stitch them in order
+            size_t o = 0;
+            for (size_t k = 0; k < part_count[t].size(); ++k) {
+                T.extra_begin[part_begin[t] + k] = uint32_t(T.extra.size());
+                T.extra.insert(T.extra.end(), part_extra[t].begin() + o, part_extra[t].begin() + o + part_count[t][k]);
+                o += part_count[t][k];
+            }
         }
         T.extra_begin[n_csq] = uint32_t(T.extra.size());
     }

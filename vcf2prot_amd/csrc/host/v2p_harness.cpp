@@ -124,11 +124,16 @@ static int run(const char* preset, uint64_t n_haps, int threads)
 // step 5 in the image builder, step 6 + FASTA emit on the GPU, one <proband>.fasta per proband (personalized_genome.rs:72-117).
 static std::string slurp(const char* path)
 {
-    std::ifstream f(path, std::ios::binary);
+    FILE* f = std::fopen(path, "rb");
     if (!f) throw std::runtime_error(std::string("could not read ") + path);
-    std::stringstream ss;
-    ss << f.rdbuf();
-    return ss.str();
+    std::fseek(f, 0, SEEK_END);
+    const long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::string s(size_t(n < 0 ? 0 : n), '\0');
+    const size_t got = s.empty() ? 0 : std::fread(&s[0], 1, s.size(), f);
+    std::fclose(f);
+    if (got != s.size()) throw std::runtime_error(std::string("short read on ") + path);
+    return s;
 }
 
 // readers.rs:37-76
@@ -158,15 +163,22 @@ static std::map<std::string, std::string> read_fasta(const std::string& text)
 
 static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* outdir, bool no_test)
 {
+    using clk = std::chrono::steady_clock;
+    auto since = [](clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); };
+    const auto t_start = clk::now();
+    auto t0 = clk::now();
+    double t_read, t_index, t_decode, t_group, t_build, t_exec, t_write;
     const std::string vcf = slurp(vcf_path);
     const auto ref = read_fasta(slurp(fasta_path));
     const uint8_t* text = reinterpret_cast<const uint8_t*>(vcf.data());
+    t_read = since(t0); t0 = clk::now();
     v2p_vcf_index* idx = nullptr;
     if (v2p_vcf_index_build(text, vcf.size(), &idx) != 0) {
         std::fprintf(stderr, "reading the file failed: %s\n", v2p_vcf_index_error(idx));
         return 101;
     }
     const uint64_t S = v2p_vcf_index_n_samples(idx), R = v2p_vcf_index_n_records(idx);
+    t_index = since(t0); t0 = clk::now();
     GpuContext ctx;
     v2p_decode* dec = nullptr;
     if (v2p_decode_run(ctx.raw(), text, vcf.size(), v2p_vcf_index_row_begin(idx), v2p_vcf_index_row_end(idx), R, S,
@@ -178,12 +190,16 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
     v2p_decode_counts(dec, hap_begin.data());
     std::vector<uint32_t> ids(hap_begin.back() + 1);
     v2p_decode_download(dec, ids.data());
+    float kms[4] = {0, 0, 0, 0};
+    v2p_decode_timing(dec, &kms[0], &kms[1], &kms[2], &kms[3]);
     v2p_decode_destroy(dec);
+    t_decode = since(t0); t0 = clk::now();
     v2p_groups* g = nullptr;
     if (v2p_groups_build(idx, text, hap_begin.data(), ids.data(), 2 * S, 0, &g) != 0) {
         std::fprintf(stderr, "panicked: %s\n", v2p_groups_error(g));
         return 101;
     }
+    t_group = since(t0); t0 = clk::now();
     // resident reference: the transcripts the file touches + their two record headers
     const uint64_t n_tx = v2p_groups_n_transcripts(g);
     std::vector<std::string> names(n_tx);
@@ -241,9 +257,11 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
         }
         chk(v2p_batch_end_haplotype(b));
     }
+    t_build = since(t0); t0 = clk::now();
     chk(v2p_batch_finalize(b));
     chk(v2p_batch_execute(b));
     chk(v2p_batch_sync(b));
+    t_exec = since(t0); t0 = clk::now();
     uint64_t written = 0;
     std::vector<uint8_t> buf;
     for (uint64_t s = 0; s < S; ++s) {
@@ -261,8 +279,14 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
             written += len;
         }
     }
+    t_write = since(t0);
     std::printf("vcf: %llu records, %llu probands, %llu bytes of FASTA written to %s\n", (unsigned long long)R, (unsigned long long)S,
                 (unsigned long long)written, outdir);
+    std::printf("{\"records\": %llu, \"probands\": %llu, \"fasta_bytes\": %llu, \"seconds\": {\"read_files\": %.4f, \"index\": %.4f, "
+                "\"decode_incl_h2d\": %.4f, \"grouping\": %.4f, \"steps_4a_4b_5\": %.4f, \"h2d_step6_sync\": %.4f, \"d2h_write\": %.4f, \"total\": %.4f}, "
+                "\"decode_kernels_ms\": {\"parse\": %.3f, \"count\": %.3f, \"scan\": %.3f, \"emit\": %.3f}}\n",
+                (unsigned long long)R, (unsigned long long)S, (unsigned long long)written, t_read, t_index, t_decode, t_group, t_build, t_exec, t_write,
+                since(t_start), kms[0], kms[1], kms[2], kms[3]);
     v2p_batch_destroy(b);
     v2p_groups_destroy(g);
     v2p_vcf_index_destroy(idx);
