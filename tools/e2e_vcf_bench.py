@@ -27,7 +27,7 @@ def main():
         out = os.path.join(tmp, "out")
         os.makedirs(out)
         runs = []
-        for _ in range(2):                                   # the second run has the files in the page cache, like the reference's run had
+        for _ in range(int(os.environ.get("V2P_E2E_RUNS", "2"))):    # the second run has the files in the page cache, like the reference's run had
             t0 = time.time()
             p = subprocess.run([harness, "vcf", os.path.join(tmp, "cohort.vcf"), os.path.join(tmp, "cohort_reference.fasta"), out, "--no-test"],
                                capture_output=True, text=True)
