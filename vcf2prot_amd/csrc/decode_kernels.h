@@ -17,7 +17,7 @@ enum : uint32_t {
 
 constexpr uint32_t DEC_ROWBLOCK = 64;       // records per row block (count / emit granularity): one wave, lane = record
 constexpr uint32_t DEC_SCAN_GROUPS = 64;    // the prefix down the row blocks runs in this many independent groups
-constexpr uint32_t DEC_TILE = 4096;         // text bytes per parse step of one workgroup
+constexpr uint32_t DEC_TILE = 4096;         // text bytes per parse step of a 256-thread workgroup (16 per thread)
 constexpr uint32_t DEC_EMIT_SAMPLES = 32;   // sample columns per emit workgroup
 constexpr uint32_t DEC_MULTI = 0x80000000u; // mask-matrix entry: bit 31 set -> low 31 bits index the multi-word list
 
@@ -28,6 +28,7 @@ struct DecodeArgs {
     const uint64_t* row_end;       // [n_rows]
     uint32_t        n_rows;
     uint32_t        n_samples;
+    uint32_t        parse_threads;  // 64 / 128 / 256 threads per record in the parse kernel, 0 = pick from n_samples
     const uint32_t* csq_begin;     // [n_rows + 1]
     const uint32_t* sup_pairs;     // [n_rows]
     const uint32_t* sup_bits;      // bitset over consequence ids

@@ -58,22 +58,24 @@ __device__ __forceinline__ uint32_t eq_bytes(uint32_t w, uint32_t pat)
 
 struct Num { bool valid; bool neg; uint64_t val; };
 
-constexpr uint32_t RING = 2u * DEC_TILE;
 
-__device__ __forceinline__ uint8_t rq(const uint8_t* ring, uint32_t q) { return ring[q & (RING - 1u)]; }
+// ring buffer of 2 tiles; RM = its size - 1
+template <uint32_t RM>
+__device__ __forceinline__ uint8_t rq(const uint8_t* ring, uint32_t q) { return ring[q & RM]; }
 
 // Rust integer from_str on ring[b, e): optional sign, at least one digit, digits only (value saturates far above u32)
+template <uint32_t RM>
 __device__ __forceinline__ Num parse_num(const uint8_t* ring, uint32_t b, uint32_t e)
 {
     Num n{false, false, 0};
     if (b < e) {
-        const uint8_t c = rq(ring, b);
+        const uint8_t c = rq<RM>(ring, b);
         if (c == '+' || c == '-') { n.neg = (c == '-'); ++b; }
     }
     if (b >= e) return n;
     uint64_t v = 0;
     for (uint32_t q = b; q < e; ++q) {
-        const uint32_t d = uint32_t(rq(ring, q)) - uint32_t('0');
+        const uint32_t d = uint32_t(rq<RM>(ring, q)) - uint32_t('0');
         if (d > 9u) return n;
         v = v * 10u + d;
         if (v > (1ull << 40)) v = 1ull << 40;
@@ -84,9 +86,10 @@ __device__ __forceinline__ Num parse_num(const uint8_t* ring, uint32_t b, uint32
 }
 
 // text_parser::parse_fields + BitMask::from_string on one element: 0 = no consequences; aborts reported through err
+template <uint32_t RM>
 __device__ __forceinline__ uint32_t single_word(const uint8_t* ring, uint32_t b, uint32_t e, uint32_t& err)
 {
-    const Num n = parse_num(ring, b, e);
+    const Num n = parse_num<RM>(ring, b, e);
     if (!n.valid) return 0u;                                   // parse::<i32>() Err -> DEF_CONSEQ (text_parser.rs:216)
     if (n.neg) {
         if (n.val > (1ull << 31)) return 0u;                   // below i32::MIN: Err as well
@@ -112,11 +115,14 @@ __device__ __forceinline__ uint32_t filter_word(uint32_t w, uint32_t base, const
 }
 
 // ---------------------------------------------------------------------------------------------------------- parse
-__global__ __launch_bounds__(256) void parse_rows_kernel(DecodeArgs a)
+// BS threads per record: 256 for wide cohorts, fewer when a record's sample columns are shorter than a 4 KiB tile
+template <uint32_t BS>
+__global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
 {
+    constexpr uint32_t TILE = BS * 16u, RING = 2u * TILE, RM = RING - 1u, NW = BS / 64u;
     __shared__ __align__(16) uint8_t ring[RING];
-    __shared__ uint16_t tabpos[DEC_TILE + 2];
-    __shared__ uint32_t wave_tot[4];
+    __shared__ uint16_t tabpos[TILE + 2];
+    __shared__ uint32_t wave_tot[NW];
 
     const uint32_t row = blockIdx.x;
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
@@ -125,14 +131,14 @@ __global__ __launch_bounds__(256) void parse_rows_kernel(DecodeArgs a)
     const uintptr_t base = first & ~uintptr_t(15);
     const uint32_t q0 = uint32_t(first - base);                 // stream position of the first row byte
     const uint32_t Lq = uint32_t(re - rb) + q0;                 // stream position one past the last row byte
-    const uint32_t n_tiles = Lq ? (Lq + DEC_TILE - 1u) / DEC_TILE : 1u;
+    const uint32_t n_tiles = Lq ? (Lq + TILE - 1u) / TILE : 1u;
     const uint32_t c0 = a.csq_begin[row], n_csq = a.csq_begin[row + 1] - c0;
     const uint32_t sup = a.sup_pairs[row];
     const uint64_t field0 = uint64_t(row) * a.n_samples;
     uint32_t fields_before = 0;
 
     auto load_tile = [&](uint32_t t) -> u32x4 {
-        const uint32_t qs = t * DEC_TILE + tid * 16u;
+        const uint32_t qs = t * TILE + tid * 16u;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (qs < Lq) v = *reinterpret_cast<const u32x4 __attribute__((address_space(1)))*>(base + qs);
         return v;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256) void parse_rows_kernel(DecodeArgs a)
 
     u32x4 cur = load_tile(0);
     for (uint32_t t = 0; t < n_tiles; ++t) {
-        const uint32_t tile0 = t * DEC_TILE;
+        const uint32_t tile0 = t * TILE;
         *reinterpret_cast<u32x4*>(&ring[(tile0 & (RING - 1u)) + tid * 16u]) = cur;
         u32x4 nxt = {0u, 0u, 0u, 0u};
         if (t + 1u < n_tiles) nxt = load_tile(t + 1u);
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(256) void parse_rows_kernel(DecodeArgs a)
         __syncthreads();
         uint32_t wbase = 0, tile_tabs = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < 4; ++w) {
+        for (uint32_t w = 0; w < NW; ++w) {
             const uint32_t x = wave_tot[w];
             if (w < wave) wbase += x;
             tile_tabs += x;
@@ -175,8 +181,8 @@ __global__ __launch_bounds__(256) void parse_rows_kernel(DecodeArgs a)
         const uint32_t n_ends = tile_tabs + (last ? 1u : 0u);
         __syncthreads();
 
-        const uint32_t lo = max(q0, t ? tile0 - DEC_TILE : 0u);               // oldest stream position still in the ring
-        for (uint32_t j = tid; j < n_ends; j += 256u) {
+        const uint32_t lo = max(q0, t ? tile0 - TILE : 0u);               // oldest stream position still in the ring
+        for (uint32_t j = tid; j < n_ends; j += BS) {
             const uint32_t p = tile0 + tabpos[j];                              // one past the column's last byte
             const uint32_t f = fields_before + j;
             uint32_t q = p, err = 0u, entry = 0u;
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(256) void parse_rows_kernel(DecodeArgs a)
             }
             if (slow) {
             while (q > lo) {
-                const uint8_t c = rq(ring, q - 1u);
+                const uint8_t c = rq<RM>(ring, q - 1u);
                 if (c == ':') { colon = true; break; }
                 if (c == '\t') break;
                 --q;
@@ -221,16 +227,16 @@ __global__ __launch_bounds__(256) void parse_rows_kernel(DecodeArgs a)
             if (colon) {
                 const uint32_t s = q;                                          // tail = ring[s, p)
                 const uint32_t len = p - s;
-                if (len == 0u || (len == 1u && rq(ring, s) == '.')) {
+                if (len == 0u || (len == 1u && rq<RM>(ring, s) == '.')) {
                     entry = 0u;                                                // "" parses to Err, "." is the missing value
                 } else {
                     // elements, how many survive remove_leading_zeros (it strips trailing "0" elements), any '-'
                     uint32_t n_el = 1u, kept = 0u, es = s, first_end = p;
                     bool minus = false;
                     for (uint32_t k = s; k < p; ++k) {
-                        const uint8_t c = rq(ring, k);
+                        const uint8_t c = rq<RM>(ring, k);
                         if (c == ',') {
-                            if (!(k - es == 1u && rq(ring, es) == '0')) kept = n_el;
+                            if (!(k - es == 1u && rq<RM>(ring, es) == '0')) kept = n_el;
                             if (n_el == 1u) first_end = k;
                             ++n_el;
                             es = k + 1u;
@@ -238,15 +244,15 @@ __global__ __launch_bounds__(256) void parse_rows_kernel(DecodeArgs a)
                             minus = true;
                         }
                     }
-                    if (!(p - es == 1u && rq(ring, es) == '0')) kept = n_el;
+                    if (!(p - es == 1u && rq<RM>(ring, es) == '0')) kept = n_el;
                     if (n_el == 1u) {
-                        entry = single_word(ring, s, p, err);                  // text_parser.rs:179-182
+                        entry = single_word<RM>(ring, s, p, err);                  // text_parser.rs:179-182
                     } else if (kept == 0u) {
                         entry = 0u;                                            // "0,0" (text_parser.rs:240-243)
                     } else if (minus) {
                         err = DEC_MASK_NEGATIVE;                               // text_parser.rs:244
                     } else if (kept == 1u) {
-                        entry = single_word(ring, s, first_end, err);          // "x,0" falls back to parse_fields (text_parser.rs:189-192)
+                        entry = single_word<RM>(ring, s, first_end, err);          // "x,0" falls back to parse_fields (text_parser.rs:189-192)
                     } else {
                         // MaskDecoder.rs:45-50: every kept element must be a u32; word k covers indices 15k .. 15k+15
                         uint32_t any = 0u;
@@ -263,8 +269,8 @@ __global__ __launch_bounds__(256) void parse_rows_kernel(DecodeArgs a)
                             }
                             uint32_t eb = s, k = 0u;
                             for (uint32_t x = s; x <= p && k < kept; ++x) {
-                                if (x == p || rq(ring, x) == ',') {
-                                    const Num n = parse_num(ring, eb, x);
+                                if (x == p || rq<RM>(ring, x) == ',') {
+                                    const Num n = parse_num<RM>(ring, eb, x);
                                     if (!n.valid || n.neg || n.val > 0xFFFFFFFFull) { err = DEC_MASK_PARSE; break; }
                                     const uint32_t w = uint32_t(n.val);
                                     const bool oob = w && 15u * k + top_pair(w) >= n_csq;
@@ -532,7 +538,11 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, unsigned phase
     if (phases & 1u) {
         hipError_t e = hipMemsetAsync(a.ovf_used, 0, sizeof(unsigned long long), stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(parse_rows_kernel, dim3(a.n_rows), dim3(256), 0, stream, a);
+        // a record of S samples is about 6..30 S bytes of text; a tile is 16 bytes per thread
+        const uint32_t bs = a.parse_threads ? a.parse_threads : (a.n_samples <= 96u ? 64u : (a.n_samples <= 320u ? 128u : 256u));
+        if (bs <= 64u) hipLaunchKernelGGL(parse_rows_kernel<64>, dim3(a.n_rows), dim3(64), 0, stream, a);
+        else if (bs <= 128u) hipLaunchKernelGGL(parse_rows_kernel<128>, dim3(a.n_rows), dim3(128), 0, stream, a);
+        else hipLaunchKernelGGL(parse_rows_kernel<256>, dim3(a.n_rows), dim3(256), 0, stream, a);
     }
     if (phases & 2u) {
         const uint32_t sbk = (a.n_samples + 255u) / 256u;

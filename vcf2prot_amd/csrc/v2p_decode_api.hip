@@ -176,8 +176,12 @@ int v2p_decode_run(v2p_ctx* ctx, const uint8_t* text, uint64_t n_text,
     // multi-word masks are rare; start with room for one field in 16 and retry with the exact need if that was short
     uint64_t ovf_words = n_records * n_samples / 4 + (1u << 16);
     if (ovf_words >= (1ull << 31)) ovf_words = (1ull << 31) - 1;
+    uint64_t row_bytes = 0;
+    for (uint64_t r = 0; r < n_records; ++r) row_bytes += row_end[r] - row_begin[r];
+    const uint64_t avg_row = row_bytes / n_records;
+    uint32_t parse_threads = avg_row <= 1536 ? 64u : (avg_row <= 3072 ? 128u : 256u);     // a tile = 16 bytes per thread
     int rc = V2P_OK;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 3; ++attempt) {
         if (d->d_work) { (void)hipFree(d->d_work); d->d_work = nullptr; }
         const DecodeLayout L = decode_layout(n_records, n_samples, ovf_words);
         DTRY(hipMalloc(reinterpret_cast<void**>(&d->d_work), L.total), "hipMalloc(decode workspace)");
@@ -185,6 +189,7 @@ int v2p_decode_run(v2p_ctx* ctx, const uint8_t* text, uint64_t n_text,
         DecodeArgs a{};
         fill_args(a, d_text, n_text, d->d_rows, d->d_rows + n_records, n_records, n_samples, d->d_csq, d->d_csq + n_records + 1,
                   d->d_csq + 2 * n_records + 1, d->d_work, ovf_words, d->d_hap_begin, nullptr, ~0ull, d->d_status);
+        a.parse_threads = parse_threads;
         DTRY(hipEventRecord(ev[0], st), "hipEventRecord");
         DTRY(launch_decode(a, st, 1u), "parse_rows_kernel");
         DTRY(hipEventRecord(ev[1], st), "hipEventRecord");
@@ -199,7 +204,8 @@ int v2p_decode_run(v2p_ctx* ctx, const uint8_t* text, uint64_t n_text,
         DTRY(hipStreamSynchronize(st), "hipStreamSynchronize");
         if (status[0] != ~0ull) {
             const uint32_t reason = uint32_t(status[0] & 0xFF);
-            if (reason == DEC_CAPACITY && attempt == 0 && status[1] > ovf_words && status[1] < (1ull << 31)) { ovf_words = status[1]; continue; }
+            if (reason == DEC_CAPACITY && status[1] > ovf_words && status[1] < (1ull << 31)) { ovf_words = status[1]; continue; }
+            if (reason == DEC_FIELD_TOO_LONG && parse_threads != 256u) { parse_threads = 256u; continue; }     // the narrow kernels look back 1-2 KiB only
             rc = ctx_fail(ctx, reason_to_code(reason), std::string("decode: ") + reason_text(reason) + " at record " +
                           std::to_string((status[0] >> 8) / n_samples) + ", sample " + std::to_string((status[0] >> 8) % n_samples),
                           int64_t(status[0] >> 8));
