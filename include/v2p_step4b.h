@@ -39,6 +39,15 @@ int v2p_transcript_g_rep(const v2p_instruction* ins, uint64_t n_ins, uint64_t re
                          uint64_t cap_tasks, uint64_t* n_tasks,
                          uint8_t* alt, uint64_t cap_alt, uint64_t* n_alt, uint64_t* res_len);
 
+/* The INSPECT_TXP validation at the end of get_g_rep (transcript_instructions.rs:386-421; on unless NO_TEST is exported,
+ * cli.rs:337-368): every task must start where the previous one ended and the lengths must add up to the expected
+ * result size.  Returns 0, or 1 (not contiguous at task *first_bad: panic :404) or 2 (size mismatch: panic :413). */
+#define V2P_4B_INSPECT_OK            0
+#define V2P_4B_INSPECT_NOT_CONTIGUOUS 1
+#define V2P_4B_INSPECT_SIZE_MISMATCH  2
+int v2p_inspect_transcript_tasks(const uint64_t* length, const uint64_t* start_pos_res, uint64_t n_tasks, uint64_t res_len,
+                                 int64_t* first_bad);
+
 #ifdef __cplusplus
 }
 #endif

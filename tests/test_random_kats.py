@@ -87,3 +87,25 @@ def test_executor_reproduces_records_and_slice_panics(built, gpu_ctx, cases):
             assert "".join(map(chr, out)) == c["record"], c["name"]
             n_rec += 1
     assert n_rec >= 500 and n_panic >= 10
+
+
+def test_inspect_txp_flags_the_task_vectors_the_executor_dies_on(built, cases):
+    """transcript_instructions.rs:386-421 (INSPECT_TXP, default on in the current source): the validation that would stop
+    the inconsistent Task vectors one step before the executor."""
+    from vcf2prot_amd.step4b import inspect_transcript_tasks
+    n_bad = 0
+    for c in cases:
+        ins, rc, t, alt, res_len = chain(c)
+        if not isinstance(ins, list) or rc != 0:
+            continue
+        status, at = inspect_transcript_tasks(t, res_len)
+        if c["panics"]:
+            assert status in (1, 2), c["name"]
+            n_bad += 1
+        else:
+            assert status == 0, c["name"]              # every Task vector the reference executed tiles its result exactly
+    assert n_bad >= 10
+    assert inspect_transcript_tasks(np.array([[0, 0, 4, 0], [1, 0, 1, 4]]), 5) == (0, -1)
+    assert inspect_transcript_tasks(np.array([[0, 0, 4, 0], [1, 0, 1, 5]]), 6) == (1, 1)
+    assert inspect_transcript_tasks(np.array([[0, 0, 4, 0], [1, 0, 1, 4]]), 6) == (2, -1)
+    assert inspect_transcript_tasks(np.zeros((0, 4)), 0) == (0, -1)

@@ -38,6 +38,7 @@ class Instruction(ctypes.Structure):
 
 
 COHORT_API = {
+    "v2p_inspect_transcript_tasks": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, POINTER(ctypes.c_int64)]),
     "v2p_transcript_g_rep": (c_int, [POINTER(Instruction), c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
                                      POINTER(c_uint64), c_void_p, c_uint64, POINTER(c_uint64), POINTER(c_uint64)]),
     "v2p_cohort_preset": (c_int, [c_char_p, POINTER(CohortParams)]),

@@ -230,3 +230,21 @@ extern "C" int v2p_transcript_g_rep(const v2p_instruction* ins, uint64_t n_ins, 
     *n_tasks = tasks.size(); *n_alt = alt_s.size(); *res_len = size;
     return V2P_4B_OK;
 }
+
+// transcript_instructions.rs:386-421
+extern "C" int v2p_inspect_transcript_tasks(const uint64_t* length, const uint64_t* start_pos_res, uint64_t n_tasks, uint64_t res_len,
+                                            int64_t* first_bad)
+{
+    if (first_bad) *first_bad = -1;
+    if (n_tasks == 0) return V2P_4B_INSPECT_OK;                 // the empty GIR returns before the validation (:338-343)
+    uint64_t counter = 0;
+    for (uint64_t i = 1; i < n_tasks; ++i) {
+        if (start_pos_res[i] != start_pos_res[i - 1] + length[i - 1]) {
+            if (first_bad) *first_bad = int64_t(i);
+            return V2P_4B_INSPECT_NOT_CONTIGUOUS;
+        }
+        counter += length[i];
+    }
+    counter += length[0];
+    return counter == res_len ? V2P_4B_INSPECT_OK : V2P_4B_INSPECT_SIZE_MISMATCH;
+}

@@ -252,6 +252,10 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
                                                   alt.data(), payload, &n_alt, &res_len);
             if (rc4b == V2P_4B_MUST_BE_LAST) continue;                         // haplotype_instruction.rs:100-104
             if (rc4b != V2P_4B_OK) { std::fprintf(stderr, "panicked: task generation for transcript %s (%d)\n", names[r].c_str(), rc4b); return 101; }
+            if (!no_test && v2p_inspect_transcript_tasks(ln.data(), sr.data(), n_tasks, res_len, nullptr) != V2P_4B_INSPECT_OK) {   // INSPECT_TXP
+                std::fprintf(stderr, "panicked: size mismatched / non-contiguous tasks in transcript %s\n", names[r].c_str());
+                return 101;
+            }
             chk(v2p_batch_add_transcript(b, code.data(), sp.data(), ln.data(), sr.data(), n_tasks, uint64_t(tx_off[r]), tx_len[r],
                                          alt.data(), n_alt, res_len, hdr_off[2 * r + (hap & 1)], uint32_t(names[r].size() + 4)));
         }

@@ -14,7 +14,7 @@ import numpy as np
 from . import _native as N
 from . import step4a
 from .frontend import VcfIndex, decode_bitmasks, group_per_transcript
-from .step4b import transcript_g_rep
+from .step4b import inspect_transcript_tasks, transcript_g_rep
 
 
 def read_fasta(text: str) -> Dict[str, str]:
@@ -78,6 +78,10 @@ def vcf_to_fasta(ctx, vcf: bytes, reference_fasta: str, flags: int = step4a.DEFA
                     continue                                           # haplotype_instruction.rs:100-104: Err -> skipped
                 if rc != 0:
                     raise N.V2PError(-28, f"task generation aborts for transcript {tx} (status {rc})", hap)
+                if flags & step4a.INSPECT_INS_GEN:                   # the QC switches travel together (cli.rs:337-368): INSPECT_TXP
+                    bad, at = inspect_transcript_tasks(t, res_len)
+                    if bad:
+                        raise N.V2PError(-28, f"INSPECT_TXP fails for transcript {tx} (status {bad}, task {at})", hap)
                 ho, hl = hdr_off[(tx, 1 + hap % 2)]
                 b.add_transcript(t[:, 0].astype(np.uint8), t[:, 1], t[:, 2], t[:, 3], off[tx], len(ref[tx]),
                                  np.frombuffer(alt, dtype=np.uint8), res_len, ho, hl)

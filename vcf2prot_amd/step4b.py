@@ -35,3 +35,14 @@ def transcript_g_rep(instructions: Sequence[Dict], ref_len: int) -> Tuple[int, n
     k = int(nt.value)
     tasks = np.stack([code[:k].astype(np.uint64), sp[:k], ln[:k], sr[:k]], axis=1) if k else np.zeros((0, 4), np.uint64)
     return rc, tasks, alt[:int(na.value)].tobytes(), int(rl.value)
+
+
+def inspect_transcript_tasks(tasks: np.ndarray, res_len: int) -> Tuple[int, int]:
+    """INSPECT_TXP (transcript_instructions.rs:386-421) on tasks[n,4] = (exe_code, start_pos, length, start_pos_res):
+    (0, -1) ok, (1, i) task i does not start where task i-1 ended, (2, -1) the lengths do not add up to res_len."""
+    lib = N.cohort_lib()
+    t = np.ascontiguousarray(tasks, dtype=np.uint64).reshape(-1, 4)
+    ln, sr = np.ascontiguousarray(t[:, 2]), np.ascontiguousarray(t[:, 3])
+    bad = ctypes.c_int64(-1)
+    rc = lib.v2p_inspect_transcript_tasks(ln.ctypes.data, sr.ctypes.data, t.shape[0], int(res_len), ctypes.byref(bad))
+    return int(rc), int(bad.value)
