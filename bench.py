@@ -133,7 +133,7 @@ def main():
         args.no_verify = True                                  # digests are defined on the plain result tape
 
     def padded(arr):                                           # 16 readable bytes either side (16-byte gathers)
-        t = torch.zeros(arr.size + 32, dtype=torch.uint8, device=dev)
+        t = torch.zeros(arr.size + 48, dtype=torch.uint8, device=dev)
         if arr.size:
             t[16:16 + arr.size] = torch.from_numpy(arr).to(dev)
         return t

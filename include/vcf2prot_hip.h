@@ -208,7 +208,7 @@ int  v2p_pipeline_wait(v2p_pipeline* p, uint32_t ticket, const uint8_t** result,
 int  v2p_pipeline_release(v2p_pipeline* p, uint32_t ticket);
 
 /* ---- raw launchers on caller-owned device memory (torch tensors, other runtimes) ----- */
-/* src0/src1 must have 16 readable bytes before and after; out must be 16-byte aligned;
+/* src0/src1 must have 16 readable bytes before and 32 after; out must be 16-byte aligned;
  * status is one device uint64 initialised to ~0. */
 int v2p_stitch_launch(void* hip_stream,
                       const uint64_t* d_desc, const v2p_chunk* d_chunks, uint32_t n_chunks,

@@ -74,7 +74,7 @@ def main():
     prot = cohort.proteome()
     n_prot = prot.size
     resident = np.concatenate([prot, cohort.fasta_headers()])
-    d_prot = torch.zeros(resident.size + 32, dtype=torch.uint8, device=dev)
+    d_prot = torch.zeros(resident.size + 48, dtype=torch.uint8, device=dev)
     d_prot[16:16 + resident.size] = torch.from_numpy(resident).to(dev)
     stream = torch.cuda.current_stream()
     d_status = torch.full((1,), -1, dtype=torch.int64, device=dev)
@@ -88,7 +88,7 @@ def main():
             chunks = l1_order(chunks, img.desc, n_prot, int(kv["l1"]))
         elif int(kv.get("xcd", 1)):
             lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, n_prot)
-        d_pay = torch.zeros(img.payload.size + 32, dtype=torch.uint8, device=dev)
+        d_pay = torch.zeros(img.payload.size + 48, dtype=torch.uint8, device=dev)
         d_pay[16:16 + img.payload.size] = torch.from_numpy(img.payload).to(dev)
         v = dict(spec=spec, d_desc=torch.from_numpy(img.desc.view(np.int64)).to(dev), d_chunks=torch.from_numpy(chunks.view(np.int64)).to(dev),
                  d_pay=d_pay, n_pay=img.payload.size, n_chunks=chunks.shape[0], out=img.out_bytes,

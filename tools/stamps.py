@@ -14,7 +14,7 @@ prot = c.proteome()
 chunks = np.ascontiguousarray(img.chunks)
 lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, prot.size)
 def padded(a):
-    t = torch.zeros(a.size + 32, dtype=torch.uint8, device=dev); t[16:16 + a.size] = torch.from_numpy(a).to(dev); return t
+    t = torch.zeros(a.size + 48, dtype=torch.uint8, device=dev); t[16:16 + a.size] = torch.from_numpy(a).to(dev); return t
 d_prot, d_pay = padded(prot), padded(img.payload)
 d_desc = torch.from_numpy(img.desc.view(np.int64)).to(dev); d_chunks = torch.from_numpy(chunks.view(np.int64)).to(dev)
 nch = chunks.shape[0]

@@ -44,7 +44,7 @@ constexpr uint32_t CHUNK_TASKS_DEEP = 1024;    // ... for images with < 100 resu
 constexpr uint32_t CHUNK_BYTES = 64u * 1024u - 16u;  // result bytes per work item (<= 4096 16-byte blocks incl. a ragged head)
 constexpr uint32_t CUT_ALIGN  = 4096;          // preferred chunk cut: 4 KiB multiples = full 256-lane passes of 16-byte blocks
 constexpr uint64_t DST_MASK   = (1ull << 48) - 1;
-constexpr uint32_t PAD_BYTES  = 16;            // readable slack each side of a source arena (16-byte gathers)
+constexpr uint32_t PAD_BYTES  = 32;            // readable slack after a source arena (16-byte gathers; the dword-aligned form reads up to 19 bytes on)
 
 struct Chunk {
     uint64_t task_begin;   // index of the first descriptor

@@ -21,9 +21,9 @@ struct StitchArgs {
     const uint64_t* desc;      // packed descriptors (sir_pack.hpp)
     const Chunk*    chunks;
     uint32_t        n_chunks;
-    const uint8_t*  src0;      // space 0: resident proteome / the GIR's ref tape; 16 readable bytes either side
+    const uint8_t*  src0;      // space 0: resident proteome / the GIR's ref tape; 16 readable bytes before, 32 after
     uint64_t        src0_len;
-    const uint8_t*  src1;      // space 1: payload arena / the GIR's alt tape;    16 readable bytes either side
+    const uint8_t*  src1;      // space 1: payload arena / the GIR's alt tape;    16 readable bytes before, 32 after
     uint64_t        src1_len;
     uint8_t*        out;       // result arena, 16-byte aligned
     uint64_t        out_len;
