@@ -73,13 +73,13 @@ INS_RE = re.compile(r"Instruction \{ code: '(.)', s_state: (true|false), pos_ref
 TASK_RE = re.compile(r"Task \{\s*exe_code: (\d+),\s*start_pos: (\d+),\s*length: (\d+),\s*start_pos_res: (\d+),\s*\}")
 
 
-def run_reference(vcf, fasta, outdir, engine="st", debug_txp=None):
+def run_reference(vcf, fasta, outdir, engine="st", debug_txp=None, extra=()):
     env = dict(os.environ)
     for k in ("DEBUG_CPU_EXEC", "INSPECT_TXP", "INSPECT_INS_GEN", "PANIC_INSPECT_ERR", "DEBUG_TXP", "DEBUG_GPU"):
         env.pop(k, None)
     if debug_txp:
         env["DEBUG_TXP"] = debug_txp
-    p = subprocess.run([BIN, "-f", vcf, "-r", fasta, "-o", outdir, "-g", engine],
+    p = subprocess.run([BIN, "-f", vcf, "-r", fasta, "-o", outdir, "-g", engine, *extra],
                        env=env, capture_output=True, text=True, timeout=300)
     return p.returncode, p.stdout + p.stderr
 
@@ -256,6 +256,13 @@ def harvest_cohort_example(out_dir, preset="C1", stem="c1_example", **overrides)
         if per_engine["st"] != per_engine["mt"]:
             sys.exit("reference -g st and -g mt disagree on the cohort example")
         result["fasta"] = per_engine["mt"]
+    with tempfile.TemporaryDirectory() as tmp:                # -a / --write_all_proteins (personalized_genome.rs:118-204)
+        out = os.path.join(tmp, "all")
+        os.makedirs(out)
+        rc, log = run_reference(vcf_path, fa_path, out, "st", extra=("-a",))
+        if rc != 0:
+            sys.exit(f"reference binary failed on the cohort example with -a:\n{log[-800:]}")
+        result["fasta_write_all"] = {s: read_fasta_records(os.path.join(out, s + ".fasta")) for s in samples}
     with open(os.path.join(out_dir, stem + ".json"), "w") as f:
         json.dump(result, f, indent=1)
     n = sum(len(v) for v in result["fasta"].values())

@@ -68,3 +68,19 @@ def test_harness_vcf_mode_aborts_like_the_reference(harness, tmp_path):
         assert p.returncode == 101 and "panicked" in p.stderr, (c["name"], p.stdout, p.stderr)    # a Rust panic exits with 101
         n += 1
     assert n >= 9
+
+
+def test_harness_vcf_mode_write_all(harness, tmp_path):
+    """-a / --write_all_proteins: every transcript of the reference per haplotype (personalized_genome.rs:118-204)."""
+    golden = os.path.join(ROOT, "tests", "golden")
+    for stem in ("c1_example", "e2e_long"):
+        want = json.load(open(os.path.join(golden, stem + ".json")))["fasta_write_all"]
+        out = tmp_path / stem
+        out.mkdir()
+        p = subprocess.run([harness, "vcf", os.path.join(golden, stem + ".vcf"), os.path.join(golden, stem + "_reference.fasta"), str(out), "--no-test", "-a"],
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        for sample, recs in want.items():
+            lines = open(os.path.join(out, sample + ".fasta")).read().split("\n")[:-1]
+            got = sorted([lines[i][1:], lines[i + 1]] for i in range(0, len(lines), 2))
+            assert got == sorted(recs), (stem, sample)

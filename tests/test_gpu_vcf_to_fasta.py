@@ -62,3 +62,15 @@ def test_decode_golden_vcfs_give_the_reference_fasta(built, gpu_ctx):
         for sample in c["samples"]:
             assert records(got[sample]) == (c["fasta"][sample] or []), (c["name"], sample)
     assert n_abort >= 9
+
+
+@pytest.mark.parametrize("stem", cohort_examples())
+def test_write_all_proteins(built, gpu_ctx, stem):
+    """-a / --write_all_proteins (personalized_genome.rs:118-204): every transcript of the reference per haplotype."""
+    from vcf2prot_amd.pipeline import vcf_to_fasta
+    want = json.load(open(os.path.join(GOLDEN, stem + ".json")))["fasta_write_all"]
+    vcf = open(os.path.join(GOLDEN, stem + ".vcf"), "rb").read()
+    ref = open(os.path.join(GOLDEN, stem + "_reference.fasta")).read()
+    got = vcf_to_fasta(gpu_ctx, vcf, ref, flags=0, write_all=True)
+    for sample, recs in want.items():
+        assert records(got[sample]) == sorted(recs), (stem, sample)

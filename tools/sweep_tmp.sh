@@ -1,1 +1,1 @@
-python tools/ab.py --workload C5 --samples 10000 --rounds 8 "dbg=6" "dbg=7" | tail -2
+timeout 900 python -m pytest tests/test_gpu_harness.py -x -q 2>&1 | tail -12

@@ -6,7 +6,7 @@
 //
 //   v2p_harness kat                          reference known-answer tests through the mirror
 //   v2p_harness run <preset> <haps> <threads>   e.g. run C2 64 8
-//   v2p_harness vcf <in.vcf> <reference.fasta> <outdir> [--no-test]   VCF -> one FASTA per proband, no Rust anywhere
+//   v2p_harness vcf <in.vcf> <reference.fasta> <outdir> [--no-test] [-a]   VCF -> one FASTA per proband, no Rust anywhere
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -161,7 +161,7 @@ static std::map<std::string, std::string> read_fasta(const std::string& text)
     return rec;
 }
 
-static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* outdir, bool no_test)
+static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* outdir, bool no_test, bool write_all)
 {
     using clk = std::chrono::steady_clock;
     auto since = [](clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); };
@@ -206,17 +206,29 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
     std::vector<int64_t> tx_off(n_tx, -1);
     std::vector<uint64_t> tx_len(n_tx, 0), hdr_off(2 * n_tx, 0);
     std::string proteome, headers = "\n";
+    struct RefTx { uint64_t off, len, hdr[2]; int64_t rank; };
+    std::map<std::string, RefTx> all;                              // -a: every transcript of the reference, sorted like the groups
     for (uint64_t r = 0; r < n_tx; ++r) {
         uint64_t b, n;
         v2p_groups_transcript(g, r, &b, &n);
         names[r] = vcf.substr(b, n);
+    }
+    auto place = [&](const std::string& name, const std::string& seq, int64_t rank) {
+        RefTx t{proteome.size(), seq.size(), {0, 0}, rank};
+        proteome += seq;
+        for (int h = 0; h < 2; ++h) { t.hdr[h] = headers.size(); headers += ">" + name + "_" + char('1' + h) + "\n"; }
+        all.emplace(name, t);
+        return t;
+    };
+    for (uint64_t r = 0; r < n_tx; ++r) {
         auto it = ref.find(names[r]);
         if (it == ref.end()) continue;
-        tx_off[r] = int64_t(proteome.size());
-        tx_len[r] = it->second.size();
-        proteome += it->second;
-        for (int h = 0; h < 2; ++h) { hdr_off[2 * r + h] = headers.size(); headers += ">" + names[r] + "_" + char('1' + h) + "\n"; }
+        const RefTx t = place(names[r], it->second, int64_t(r));
+        tx_off[r] = int64_t(t.off); tx_len[r] = t.len; hdr_off[2 * r] = t.hdr[0]; hdr_off[2 * r + 1] = t.hdr[1];
     }
+    if (write_all)
+        for (const auto& kv : ref)
+            if (!all.count(kv.first)) place(kv.first, kv.second, -1);
     auto chk = [&](int rc) { if (rc != V2P_OK) { std::fprintf(stderr, "panicked: %s\n", v2p_last_error(ctx.raw())); std::exit(101); } };
     chk(v2p_upload_reference(ctx.raw(), reinterpret_cast<const uint8_t*>(proteome.data()), proteome.size(),
                              reinterpret_cast<const uint8_t*>(headers.data()), headers.size()));
@@ -231,9 +243,25 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
     std::vector<v2p_instruction> ins;
     std::vector<uint8_t> code, alt;
     std::vector<uint64_t> sp, ln, sr;
+    const uint8_t ref_code = 0;
+    const uint64_t zero = 0;
+    auto reference_copy = [&](const RefTx& t, uint64_t hap, size_t name_len) {        // personalized_genome.rs:176-183: not altered -> as in the reference
+        chk(v2p_batch_add_transcript(b, &ref_code, &zero, &t.len, &zero, 1, t.off, t.len, nullptr, 0, t.len, t.hdr[hap & 1], uint32_t(name_len + 4)));
+    };
     for (uint64_t hap = 0; hap < 2 * S; ++hap) {
         chk(v2p_batch_begin_haplotype(b));
-        for (uint64_t k = hgb[hap]; k < hgb[hap + 1]; ++k) {
+        // the haplotype's groups, and with -a the rest of the reference around them, in sorted transcript order
+        std::vector<std::pair<const std::pair<const std::string, RefTx>*, int64_t>> todo;     // (reference entry, group index or -1)
+        if (write_all) {
+            std::map<std::string, int64_t> mine;
+            for (uint64_t k = hgb[hap]; k < hgb[hap + 1]; ++k) mine[names[gtx[k]]] = int64_t(k);
+            for (const auto& kv : all) { auto it = mine.find(kv.first); todo.emplace_back(&kv, it == mine.end() ? -1 : it->second); }
+        } else {
+            for (uint64_t k = hgb[hap]; k < hgb[hap + 1]; ++k) { auto it = all.find(names[gtx[k]]); if (it != all.end()) todo.emplace_back(&*it, int64_t(k)); }
+        }
+        for (const auto& td : todo) {
+            if (td.second < 0) { reference_copy(td.first->second, hap, td.first->first.size()); continue; }
+            const uint64_t k = uint64_t(td.second);
             const uint32_t r = gtx[k];
             if (tx_off[r] < 0) continue;                                       // transcript_instructions.rs:37-41
             const uint64_t n = gmb[k + 1] - gmb[k];
@@ -241,7 +269,7 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
             for (uint64_t i = 0; i < n; ++i) v2p_groups_mutation_view(g, mid[gmb[k] + i], &views[i]);
             uint64_t n_ins = 0;
             const int rc4a = v2p_transcript_instructions(views.data(), n, flags, ins.data(), ins.size(), &n_ins);
-            if (rc4a == V2P_4A_SKIP) continue;
+            if (rc4a == V2P_4A_SKIP) { if (write_all) reference_copy(td.first->second, hap, names[r].size()); continue; }
             if (rc4a != V2P_4A_OK) { std::fprintf(stderr, "panicked: instruction generation for transcript %s\n", names[r].c_str()); return 101; }
             uint64_t payload = 8;
             for (uint64_t i = 0; i < n_ins; ++i) payload += 2 * ins[i].data_len;
@@ -250,7 +278,7 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
             uint64_t n_tasks = 0, n_alt = 0, res_len = 0;
             const int rc4b = v2p_transcript_g_rep(ins.data(), n_ins, tx_len[r], code.data(), sp.data(), ln.data(), sr.data(), cap, &n_tasks,
                                                   alt.data(), payload, &n_alt, &res_len);
-            if (rc4b == V2P_4B_MUST_BE_LAST) continue;                         // haplotype_instruction.rs:100-104
+            if (rc4b == V2P_4B_MUST_BE_LAST) { if (write_all) reference_copy(td.first->second, hap, names[r].size()); continue; }   // haplotype_instruction.rs:100-104
             if (rc4b != V2P_4B_OK) { std::fprintf(stderr, "panicked: task generation for transcript %s (%d)\n", names[r].c_str(), rc4b); return 101; }
             if (!no_test && v2p_inspect_transcript_tasks(ln.data(), sr.data(), n_tasks, res_len, nullptr) != V2P_4B_INSPECT_OK) {   // INSPECT_TXP
                 std::fprintf(stderr, "panicked: size mismatched / non-contiguous tasks in transcript %s\n", names[r].c_str());
@@ -300,7 +328,9 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
 int main(int argc, char** argv)
 {
     if (argc >= 5 && !std::strcmp(argv[1], "vcf")) {
-        try { return vcf_mode(argv[2], argv[3], argv[4], argc >= 6 && !std::strcmp(argv[5], "--no-test")); }
+        bool no_test = false, write_all = false;
+        for (int i = 5; i < argc; ++i) { no_test |= !std::strcmp(argv[i], "--no-test"); write_all |= !std::strcmp(argv[i], "--write-all") || !std::strcmp(argv[i], "-a"); }
+        try { return vcf_mode(argv[2], argv[3], argv[4], no_test, write_all); }
         catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 101; }
     }
     if (argc >= 2 && !std::strcmp(argv[1], "kat")) return kat();

@@ -39,13 +39,16 @@ def read_fasta(text: str) -> Dict[str, str]:
     return records
 
 
-def vcf_to_fasta(ctx, vcf: bytes, reference_fasta: str, flags: int = step4a.DEFAULT_FLAGS) -> Dict[str, bytes]:
-    """{proband: text of <proband>.fasta} (personalized_genome.rs:72-117, altered transcripts only)."""
+def vcf_to_fasta(ctx, vcf: bytes, reference_fasta: str, flags: int = step4a.DEFAULT_FLAGS, write_all: bool = False) -> Dict[str, bytes]:
+    """{proband: text of <proband>.fasta}: the altered transcripts (personalized_genome.rs:72-117) or, with write_all
+    (-a / --write_all_proteins, :118-204), every transcript of the reference per haplotype, unaltered ones as they are."""
     ref = read_fasta(reference_fasta)
     idx = VcfIndex(vcf)
     lists = decode_bitmasks(ctx, idx)
     groups = group_per_transcript(idx, lists)
     names = [groups.transcript_name(r) for r in range(groups.n_transcripts)]
+    if write_all:
+        names = sorted(set(names) | set(ref), key=lambda x: x.encode())
     # resident reference: the transcripts the file touches, and their two record headers each
     off, pieces, hdr, hdr_off = {}, [], ["\n"], {}
     pos, hpos = 0, 1
@@ -65,16 +68,30 @@ def vcf_to_fasta(ctx, vcf: bytes, reference_fasta: str, flags: int = step4a.DEFA
     try:
         for hap in range(lists.n_haplotypes):
             b.begin_haplotype()
-            for tx, members in groups.of(hap):
+            altered = dict(groups.of(hap))
+            todo = [(tx, altered.get(tx)) for tx in names if tx in ref] if write_all else list(altered.items())
+            for tx, members in todo:
                 if tx not in ref:
                     continue                                           # transcript_instructions.rs:37-41: Err -> skipped
+                def reference_copy():                                  # -a: an unaltered transcript is one copy of its reference
+                    ho, hl = hdr_off[(tx, 1 + hap % 2)]
+                    n = len(ref[tx])
+                    b.add_transcript(np.zeros(1, np.uint8), np.zeros(1, np.uint64), np.array([n], np.uint64), np.zeros(1, np.uint64),
+                                     off[tx], n, np.zeros(0, np.uint8), n, ho, hl)
+                if members is None:
+                    reference_copy()
+                    continue
                 rc, ins = step4a.group_instructions(groups, members, flags)
                 if rc == step4a.SKIP:
+                    if write_all:
+                        reference_copy()                               # not in the haplotype's annotation -> written as reference (:176-183)
                     continue
                 if rc != step4a.OK:
                     raise N.V2PError(-28, f"instruction generation aborts for transcript {tx} (haplotype list {hap})", hap)
                 rc, t, alt, res_len = transcript_g_rep(ins, len(ref[tx]))
                 if rc == 1:
+                    if write_all:
+                        reference_copy()
                     continue                                           # haplotype_instruction.rs:100-104: Err -> skipped
                 if rc != 0:
                     raise N.V2PError(-28, f"task generation aborts for transcript {tx} (status {rc})", hap)
