@@ -194,3 +194,28 @@ def test_full_size_shard_every_haplotype_by_digest(built, gpu_ctx, coracle, pres
     bad = [h for h in range(n) if int(dig[h]) != want[h]]
     assert not bad, (preset, bad[:10])
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,h0,n", [("C1", 0, 8), ("C3", 40, 6), ("C5", 7, 40)])
+@pytest.mark.parametrize("chunk_tasks,chunk_bytes,cut_align,soft_window", [
+    (3, 64, 16, 0), (17, 1000, 16, 2), (64, 4096, 64, 8), (255, 65520, 4096, 8), (256, 300, 16, 0), (1000, 65520, 16, 0),
+    (1024, 8192, 4096, 16), (5, 65520, 4096, 1)])
+def test_any_chunking_gives_the_same_bytes(built, gpu_ctx, coracle, preset, h0, n, chunk_tasks, chunk_bytes, cut_align, soft_window):
+    """The image builder may cut chunks anywhere (task limit, byte limit, preferred alignment, soft window): the result
+    tape never depends on it."""
+    from vcf2prot_amd.cohort import Cohort
+    c = Cohort.preset(preset)
+    gpu_ctx.upload_proteome(c.proteome())
+    img = c.pack(h0, h0 + n, n_threads=3, chunk_tasks=chunk_tasks, chunk_bytes=chunk_bytes, cut_align=cut_align, soft_window=soft_window)
+    b = gpu_ctx.batch()
+    b.set_packed(img.desc, img.chunks, img.payload, img.hap_out_begin)
+    b.finalize()
+    b.execute()
+    b.sync()
+    for i in range(n):
+        hap = c.haplotype(h0 + i)
+        t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+        want = coracle.gir_execute_u8(t, c.ref_tape_u32(h0 + i).astype(np.uint8), hap.alt, np.full(hap.n_res, ord("."), dtype=np.uint8))
+        assert np.array_equal(b.download_hap(i), want), (preset, i)
+    b.close()
