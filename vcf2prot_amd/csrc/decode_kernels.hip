@@ -292,7 +292,7 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
             }
             if (f >= a.n_samples) err = err ? err : DEC_COLUMNS;
             if (err) dec_report(a.status, field0 + min(f, a.n_samples - 1u), err);
-            else a.masks[uint64_t(row) * a.mask_stride + f] = entry;
+            if (f < a.n_samples) a.masks[uint64_t(row) * a.mask_stride + f] = err ? 0u : entry;
         }
         fields_before += n_ends;
         __syncthreads();
@@ -314,6 +314,7 @@ __device__ __forceinline__ uint32_t entry_count(uint32_t m, uint32_t h, const ui
 // ---------------------------------------------------------------------------------------------------------- count
 __global__ __launch_bounds__(256) void count_kernel(DecodeArgs a, uint32_t sample_blocks)
 {
+    if (a.status[0] != ~0ull) return;                                           // a failed parse leaves the matrix incomplete
     const uint32_t rbk = blockIdx.x / sample_blocks, sb = blockIdx.x % sample_blocks;
     const uint32_t s = sb * 256u + threadIdx.x;
     if (s >= a.n_samples) return;
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(1024) void scan_haps_kernel(DecodeArgs a)
 __global__ __launch_bounds__(256) void emit_generic_kernel(DecodeArgs a, uint32_t sample_blocks)
 {
     constexpr uint32_t TS = DEC_EMIT_SAMPLES, STRIDE = TS + 1u;
-    if (!a.tile_flags[blockIdx.x]) return;
+    if (a.status[0] != ~0ull || !a.tile_flags[blockIdx.x]) return;
     __shared__ uint32_t tile[DEC_ROWBLOCK * STRIDE];
     __shared__ uint32_t csq0[DEC_ROWBLOCK];
     const uint32_t rbk = blockIdx.x / sample_blocks, sb = blockIdx.x % sample_blocks;
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(256, 4) void emit_kernel(DecodeArgs a, uint32_t sam
     static_assert(TS == 32u && DEC_ROWBLOCK == 64u, "one 128-byte line per lane, one record block per wave");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6)));
     const uint32_t rbk = (blockIdx.x / sample_blocks) * 4u + wave, sb = blockIdx.x % sample_blocks;
-    if (rbk >= n_rowblocks) return;
+    if (rbk >= n_rowblocks || a.status[0] != ~0ull) return;
     const uint32_t s0 = sb * TS;
     const uint32_t n_haps = 2u * a.n_samples;
     if (a.hap_begin[n_haps] > a.ids_capacity) return;
