@@ -109,3 +109,42 @@ def test_inspect_txp_flags_the_task_vectors_the_executor_dies_on(built, cases):
     assert inspect_transcript_tasks(np.array([[0, 0, 4, 0], [1, 0, 1, 5]]), 6) == (1, 1)
     assert inspect_transcript_tasks(np.array([[0, 0, 4, 0], [1, 0, 1, 4]]), 6) == (2, -1)
     assert inspect_transcript_tasks(np.zeros((0, 4)), 0) == (0, -1)
+
+
+@pytest.mark.gpu
+def test_all_records_through_the_step5_builder_with_fasta_emit(built, gpu_ctx, cases):
+    """The 545 answered cases as transcripts of two haplotypes: un-rebased Task vectors into v2p_batch_add_transcript
+    (step 5), record headers resident behind the proteome, one launch; the arena must be the FASTA text."""
+    good = [c for c in cases if not c["panics"]]
+    refs, off, pos = [], {}, 0
+    for c in good:
+        off[c["name"]] = pos
+        refs.append(c["ref"])
+        pos += len(c["ref"])
+    hdr, hoff, hpos = ["\n"], {}, 1
+    for c in good:
+        for h in (1, 2):
+            t = f">{c['transcript']}_{h}\n"
+            hoff[(c["name"], h)] = (hpos, len(t))
+            hdr.append(t)
+            hpos += len(t)
+    gpu_ctx.upload_reference(np.frombuffer("".join(refs).encode(), dtype=np.uint8), np.frombuffer("".join(hdr).encode(), dtype=np.uint8))
+    b = gpu_ctx.batch()
+    want = []
+    for h, subset in ((1, good[0::2]), (2, good[1::3])):
+        b.begin_haplotype()
+        text = []
+        for c in subset:
+            ins, rc, t, alt, res_len = chain(c)
+            ho, hl = hoff[(c["name"], h)]
+            b.add_transcript(t[:, 0].astype(np.uint8), t[:, 1], t[:, 2], t[:, 3], off[c["name"]], len(c["ref"]),
+                             np.frombuffer(alt, dtype=np.uint8), res_len, ho, hl)
+            text.append(f">{c['transcript']}_{h}\n{c['record']}\n")
+        b.end_haplotype()
+        want.append("".join(text))
+    b.finalize()
+    b.execute()
+    b.sync()
+    for h in range(2):
+        assert b.download_hap(h).tobytes().decode() == want[h]
+    b.close()
