@@ -86,9 +86,10 @@ def _host():
 
 
 def _arr(ptr, n, dtype):
+    """A copy of a library-owned array (the handle may be closed while the array is still in use)."""
     if n == 0:
         return np.zeros(0, dtype=dtype)
-    return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).view(dtype).copy()
 
 
 class VcfIndex:
@@ -199,7 +200,7 @@ class Groups:
         self.member_ids = _arr(L.v2p_groups_member_ids(h), int(self.group_member_begin[-1]), np.uint32)
         m = L.v2p_groups_mutations(h)
         self.mutations = np.ctypeslib.as_array(ctypes.cast(m, POINTER(c_uint8)), shape=(idx.n_consequences * ctypes.sizeof(v2p_mutation),)).view(
-            np.dtype([("transcript", "<u4"), ("ref_aa_position", "<u2"), ("mut_aa_position", "<u2"), ("type", "u1"), ("valid", "u1"), ("pad", "u1", 2)])) \
+            np.dtype([("transcript", "<u4"), ("ref_aa_position", "<u2"), ("mut_aa_position", "<u2"), ("type", "u1"), ("valid", "u1"), ("pad", "u1", 2)])).copy() \
             if idx.n_consequences else None
 
     def transcript_name(self, rank: int) -> str:
