@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X SIR executor (vcf2prot step 6) -- driver contract in the task brief.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C5] [--samples S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C4|C5] [--samples S]
 
 One "step" = one pass of the hot path (stitch kernel: K0 fill + K1 in-chunk scan + K2
 gather/scatter) over the whole synthetic batch, inputs already resident in HBM.  At N=1
@@ -31,7 +31,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C5"])
+    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--samples", type=int, default=0, help="samples per GPU (default: the config's own size, capped to fit HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -47,7 +47,7 @@ def parse_args():
     return ap.parse_args()
 
 
-DEFAULT_SAMPLES = {"C2": 1000, "C3": 2000, "C5": 10000}   # per GPU; C3/C5 full cohorts are processed in HBM-sized batches
+DEFAULT_SAMPLES = {"C2": 1000, "C3": 2000, "C4": 313, "C5": 10000}   # per GPU; C3/C5 full cohorts are processed in HBM-sized batches
 
 
 def cpu_baseline(cohort, n_threads, budget_s=12.0):

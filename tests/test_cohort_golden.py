@@ -157,10 +157,12 @@ def test_packed_cohort_on_gpu_matches_oracle(built, gpu_ctx, coracle, preset, h0
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("preset,n,min_bytes", [("C2", 2000, 15 * 10 ** 9), ("C3", 2500, 4 * 10 ** 9), ("C5", 12500, 9 * 10 ** 8)])
+@pytest.mark.parametrize("preset,n,min_bytes", [("C2", 2000, 15 * 10 ** 9), ("C3", 2500, 4 * 10 ** 9), ("C4", 626, 35 * 10 ** 8),
+                                                ("C5", 12500, 9 * 10 ** 8)])
 def test_full_size_shard_every_haplotype_by_digest(built, gpu_ctx, coracle, preset, n, min_bytes):
-    """One GPU's share of BASELINE configs[1] / [2] / [4] in a single launch (C2: all 1 000 samples x 20 000 transcripts,
-    1.6e10 residues; C3: 2 500 of the 20 000 haplotypes = the 8-GPU shard; C5: 12 500 of the 100 000 deep haplotypes):
+    """One GPU's share of BASELINE configs[1..4] in a single launch (C2: all 1 000 samples x 20 000 transcripts, 1.6e10
+    residues; C3: 2 500 of the 20 000 haplotypes = the 8-GPU shard; C4: 626 of the 5 008 haplotypes over the 100 000-transcript
+    proteome; C5: 12 500 of the 100 000 deep haplotypes):
     the digest of EVERY haplotype equals the digest of the oracle's result for that haplotype."""
     import os
     from concurrent.futures import ThreadPoolExecutor
