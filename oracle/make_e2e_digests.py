@@ -25,11 +25,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=200)
     ap.add_argument("--transcripts", type=int, default=2000)
+    ap.add_argument("--preset", default="C2")
+    ap.add_argument("--altered-per-hap", type=int, default=0)
+    ap.add_argument("--stem", default="")
     a = ap.parse_args()
+    overrides = {"altered_per_hap": a.altered_per_hap} if a.altered_per_hap else {}
     if not os.path.exists(BIN):
         sys.exit("reference binary not found: this script only runs in the build container")
     with tempfile.TemporaryDirectory() as tmp:
-        info = E.write_cohort(a.samples, a.transcripts, os.path.join(tmp, "cohort"))
+        info = E.write_cohort(a.samples, a.transcripts, os.path.join(tmp, "cohort"), a.preset, **overrides)
         out = os.path.join(tmp, "out")
         os.makedirs(out)
         env = {k: v for k, v in os.environ.items() if k not in ("DEBUG_CPU_EXEC", "INSPECT_TXP", "INSPECT_INS_GEN", "PANIC_INSPECT_ERR", "DEBUG_TXP", "DEBUG_GPU")}
@@ -43,11 +47,11 @@ def main():
         secs = [int(h) * 3600 + int(m) * 60 + float(s) for h, m, s in stamps]
         digests = {s: E.sample_digest(os.path.join(out, s + ".fasta")) for s in info["samples"]}
         fasta_bytes = sum(os.path.getsize(os.path.join(out, s + ".fasta")) for s in info["samples"])
-    res = dict(generator="oracle/make_e2e_digests.py", samples=a.samples, transcripts=a.transcripts, records=info["records"],
+    res = dict(generator="oracle/make_e2e_digests.py", preset=a.preset, overrides=overrides, samples=a.samples, transcripts=a.transcripts, records=info["records"],
                alterations=info["alterations"], vcf_bytes=info["vcf_bytes"], fasta_bytes=fasta_bytes, digests=digests,
                reference=dict(binary="vcf2prot 0.1.2 (bins/Linux), -g mt -v", host_cores=os.cpu_count(), wall_seconds=wall,
                               stage_seconds=dict(parse_vcf=secs[1] - secs[0], fasta_and_steps_4_to_6=secs[3] - secs[1], write=secs[5] - secs[4]) if len(secs) >= 6 else None))
-    with open(os.path.join(ROOT, "tests", "golden", f"e2e_{a.samples}x{a.transcripts}_digests.json"), "w") as f:
+    with open(os.path.join(ROOT, "tests", "golden", (a.stem or f"e2e_{a.samples}x{a.transcripts}") + "_digests.json"), "w") as f:
         json.dump(res, f, indent=0)
     print({k: v for k, v in res.items() if k != "digests"})
 

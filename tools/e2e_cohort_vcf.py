@@ -13,10 +13,10 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def write_cohort(n_samples: int, n_transcripts: int, prefix: str, preset: str = "C2") -> dict:
+def write_cohort(n_samples: int, n_transcripts: int, prefix: str, preset: str = "C2", **overrides) -> dict:
     from vcf2prot_amd.cohort import Cohort
     t0 = time.time()
-    c = Cohort.preset(preset, n_samples=n_samples, n_transcripts=n_transcripts)
+    c = Cohort.preset(preset, n_samples=n_samples, n_transcripts=n_transcripts, **overrides)
     samples = [f"SAMPLE{s:04d}" for s in range(n_samples)]
     prot, off = c.proteome(), c.tx_offsets()
     with open(prefix + "_reference.fasta", "w") as f:

@@ -18,11 +18,12 @@ from vcf2prot_amd import build  # noqa: E402
 
 
 def main():
-    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_200x2000_digests.json")))
+    stem = sys.argv[1] if len(sys.argv) > 1 else "e2e_200x2000"
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", stem + "_digests.json")))
     build.build_all()
     harness = build.build_harness()
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
-        info = E.write_cohort(gold["samples"], gold["transcripts"], os.path.join(tmp, "cohort"))
+        info = E.write_cohort(gold["samples"], gold["transcripts"], os.path.join(tmp, "cohort"), gold.get("preset", "C2"), **gold.get("overrides", {}))
         assert info["vcf_bytes"] == gold["vcf_bytes"] and info["records"] == gold["records"], "the generator is not reproducing the fixture's VCF"
         out = os.path.join(tmp, "out")
         os.makedirs(out)
