@@ -84,3 +84,16 @@ def test_harness_vcf_mode_write_all(harness, tmp_path):
             lines = open(os.path.join(out, sample + ".fasta")).read().split("\n")[:-1]
             got = sorted([lines[i][1:], lines[i + 1]] for i in range(0, len(lines), 2))
             assert got == sorted(recs), (stem, sample)
+
+
+def test_module_command_line(built, tmp_path):
+    """python -m vcf2prot_amd -f .. -r .. -o .. -g gpu --no-test"""
+    import sys
+    golden = os.path.join(ROOT, "tests", "golden")
+    p = subprocess.run([sys.executable, "-m", "vcf2prot_amd", "-f", os.path.join(golden, "c1_example.vcf"), "-r", os.path.join(golden, "c1_example_reference.fasta"),
+                        "-o", str(tmp_path), "-g", "gpu", "--no-test"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0, p.stdout + p.stderr
+    want = json.load(open(os.path.join(golden, "c1_example.json")))["fasta"]
+    assert sorted(f[:-6] for f in os.listdir(tmp_path)) == sorted(want)
+    p = subprocess.run([sys.executable, "-m", "vcf2prot_amd", "-f", "x", "-r", "y", "-o", str(tmp_path), "-g", "mt"], capture_output=True, text=True, cwd=ROOT)
+    assert p.returncode != 0
