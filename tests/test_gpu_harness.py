@@ -97,3 +97,41 @@ def test_module_command_line(built, tmp_path):
     assert sorted(f[:-6] for f in os.listdir(tmp_path)) == sorted(want)
     p = subprocess.run([sys.executable, "-m", "vcf2prot_amd", "-f", "x", "-r", "y", "-o", str(tmp_path), "-g", "mt"], capture_output=True, text=True, cwd=ROOT)
     assert p.returncode != 0
+
+
+def test_harness_and_python_pipeline_agree_on_random_vcfs(harness, gpu_ctx, tmp_path):
+    """Two hosts over the same C ABI (C++ harness, Python pipeline) on random VCFs with every consequence kind, with and
+    without -a, checks on and off: same files, or both abort."""
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from frontend_util import random_vcf
+    from vcf2prot_amd import _native as N
+    from vcf2prot_amd import step4a
+    from vcf2prot_amd.pipeline import vcf_to_fasta
+    rng = random.Random(3)
+    n_ok = n_abort = 0
+    for trial in range(12):
+        text = random_vcf(500 + trial, 40 + 10 * (trial % 3), 3 + trial % 4, max_csq=6, n_tx=25)
+        aa = "ACDEFGHIKLMNPQRSTVWY"
+        ref = "".join(f">ENST{i:011d}\n{'M' + ''.join(rng.choice(aa) for _ in range(700))}\n" for i in range(0, 25, 1 if trial % 2 else 2))
+        vcf, fa = tmp_path / f"t{trial}.vcf", tmp_path / f"t{trial}.fasta"
+        vcf.write_text(text)
+        fa.write_text(ref)
+        for write_all in (False, True):
+            for no_test in (True, False):
+                out = tmp_path / f"o{trial}_{int(write_all)}_{int(no_test)}"
+                out.mkdir()
+                cmd = [harness, "vcf", str(vcf), str(fa), str(out)] + (["--no-test"] if no_test else []) + (["-a"] if write_all else [])
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+                try:
+                    want = vcf_to_fasta(gpu_ctx, text.encode(), ref, flags=0 if no_test else step4a.DEFAULT_FLAGS, write_all=write_all)
+                except N.V2PError:
+                    assert p.returncode == 101, (trial, write_all, no_test, p.stdout, p.stderr)
+                    n_abort += 1
+                    continue
+                assert p.returncode == 0, (trial, write_all, no_test, p.stdout, p.stderr)
+                for sample, data in want.items():
+                    assert open(out / (sample + ".fasta"), "rb").read() == data, (trial, sample, write_all, no_test)
+                n_ok += 1
+    assert n_ok >= 10 and n_abort >= 4
