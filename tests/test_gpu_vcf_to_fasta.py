@@ -74,3 +74,23 @@ def test_write_all_proteins(built, gpu_ctx, stem):
     got = vcf_to_fasta(gpu_ctx, vcf, ref, flags=0, write_all=True)
     for sample, recs in want.items():
         assert records(got[sample]) == sorted(recs), (stem, sample)
+
+
+def test_random_vcfs_answered_by_the_reference_binary(built, gpu_ctx):
+    """24 random multi-sample VCFs (every consequence kind, several consequences per record, multi-word masks) that the
+    reference binary gets through (oracle/make_random_vcf_golden.py): same records per proband, by length and digest."""
+    import hashlib
+    import random
+    from vcf2prot_amd.pipeline import vcf_to_fasta
+    cases = json.load(open(os.path.join(GOLDEN, "random_vcfs.json")))["cases"]
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    n = 0
+    for c in cases:
+        rng = random.Random(c["reference_seed"])
+        ref = "".join(f">ENST{i:011d}\n{'M' + ''.join(rng.choice(aa) for _ in range(699))}\n" for i in range(20))
+        got = vcf_to_fasta(gpu_ctx, c["vcf"].encode(), ref, flags=0)
+        for sample in c["samples"]:
+            mine = [[h, len(q), hashlib.sha256(q.encode()).hexdigest()[:16]] for h, q in records(got[sample])]
+            assert mine == c["fasta"][sample], (c["name"], sample)
+            n += len(mine)
+    assert n > 1000
