@@ -135,3 +135,16 @@ def test_harness_and_python_pipeline_agree_on_random_vcfs(harness, gpu_ctx, tmp_
                     assert open(out / (sample + ".fasta"), "rb").read() == data, (trial, sample, write_all, no_test)
                 n_ok += 1
     assert n_ok >= 10 and n_abort >= 4
+
+
+def test_harness_vcf_mode_write_compressed(harness, tmp_path):
+    """-c / --write_compressed: <proband>.fasta.gz (personalized_genome.rs:76-108), same records after gunzip."""
+    import gzip
+    golden = os.path.join(ROOT, "tests", "golden")
+    want = json.load(open(os.path.join(golden, "c1_example.json")))["fasta"]
+    p = subprocess.run([harness, "vcf", os.path.join(golden, "c1_example.vcf"), os.path.join(golden, "c1_example_reference.fasta"), str(tmp_path), "--no-test", "-c"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    for sample, recs in want.items():
+        lines = gzip.open(os.path.join(tmp_path, sample + ".fasta.gz"), "rt").read().split("\n")[:-1]
+        assert sorted([lines[i][1:], lines[i + 1]] for i in range(0, len(lines), 2)) == sorted(recs), sample

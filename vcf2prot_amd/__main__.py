@@ -1,5 +1,5 @@
 """`python -m vcf2prot_amd -f in.vcf -r reference.fasta -o outdir [-g gpu] [-a] [--no-test]`: the reference's command line
-(parts/cli.rs:70-140: -f/--vcf_file, -r/--fasta_ref, -o/--output_path, -g/--engine, -a/--write_all_proteins) on top of
+(parts/cli.rs:70-140: -f/--vcf_file, -r/--fasta_ref, -o/--output_path, -g/--engine, -a/--write_all_proteins, -c/--write_compressed) on top of
 `v2p_harness vcf`, i.e. the whole program without Rust.  Only the gpu engine exists here: `-g st|mt` is the reference's own
 CPU code and is refused."""
 import argparse
@@ -15,6 +15,7 @@ def main() -> int:
     ap.add_argument("-o", "--output_path", required=True)
     ap.add_argument("-g", "--engine", default="gpu")
     ap.add_argument("-a", "--write_all_proteins", action="store_true")
+    ap.add_argument("-c", "--write_compressed", action="store_true")
     ap.add_argument("--no-test", action="store_true", help="like exporting NO_TEST=1 (cli.rs:275-335): no INSPECT_* checks")
     a = ap.parse_args()
     from .engine import Engine
@@ -28,6 +29,8 @@ def main() -> int:
         cmd.append("--no-test")
     if a.write_all_proteins:
         cmd.append("-a")
+    if a.write_compressed:
+        cmd.append("-c")
     return subprocess.run(cmd).returncode
 
 

@@ -86,7 +86,7 @@ def build_harness(force: bool = False, verbose: bool = False) -> str:
     """C++ host harness (the role of the reference's exec::execute) linked against both libraries."""
     if force or _stale(HARNESS_BIN, HARNESS_DEPS) or _stale(HARNESS_BIN, [HIP_LIB, COHORT_LIB]):
         cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-Wall", os.path.join(CSRC, "host", "v2p_harness.cpp"),
-               "-L" + LIBDIR, "-lvcf2prot_hip", "-lv2p_cohort", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib",
+               "-L" + LIBDIR, "-lvcf2prot_hip", "-lv2p_cohort", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib",
                "-o", HARNESS_BIN]
         if verbose:
             print(" ".join(cmd))

@@ -6,7 +6,8 @@
 //
 //   v2p_harness kat                          reference known-answer tests through the mirror
 //   v2p_harness run <preset> <haps> <threads>   e.g. run C2 64 8
-//   v2p_harness vcf <in.vcf> <reference.fasta> <outdir> [--no-test] [-a]   VCF -> one FASTA per proband, no Rust anywhere
+//   v2p_harness vcf <in.vcf> <reference.fasta> <outdir> [--no-test] [-a] [-c]   VCF -> one FASTA(.gz) per proband, no Rust anywhere
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +19,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include <zlib.h>
 
 #include "../../../include/v2p_cohort.h"
 #include "../../../include/v2p_step4a.h"
@@ -161,7 +164,7 @@ static std::map<std::string, std::string> read_fasta(const std::string& text)
     return rec;
 }
 
-static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* outdir, bool no_test, bool write_all)
+static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* outdir, bool no_test, bool write_all, bool compressed)
 {
     using clk = std::chrono::steady_clock;
     auto since = [](clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); };
@@ -299,17 +302,22 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
     for (uint64_t s = 0; s < S; ++s) {
         uint64_t nb, nl;
         v2p_vcf_index_sample(idx, s, &nb, &nl);
-        const std::string path = std::string(outdir) + "/" + vcf.substr(nb, nl) + ".fasta";
-        std::ofstream f(path, std::ios::binary);
-        if (!f) { std::fprintf(stderr, "Could not create %s\n", path.c_str()); return 101; }
+        const std::string path = std::string(outdir) + "/" + vcf.substr(nb, nl) + (compressed ? ".fasta.gz" : ".fasta");   // personalized_genome.rs:76-80
+        std::ofstream f;
+        gzFile gz = nullptr;
+        if (compressed) gz = gzopen(path.c_str(), "wb9");                        // GzEncoder, Compression::best() (:90)
+        else f.open(path, std::ios::binary);
+        if (compressed ? gz == nullptr : !f) { std::fprintf(stderr, "Could not create %s\n", path.c_str()); return 101; }
         for (int h = 0; h < 2; ++h) {
             uint64_t begin, len;
             chk(v2p_batch_hap_range(b, 2 * s + h, &begin, &len));
             buf.resize(len);
             if (len) chk(v2p_batch_download(b, begin, len, buf.data()));
-            f.write(reinterpret_cast<const char*>(buf.data()), std::streamsize(len));
+            if (compressed) { for (uint64_t o = 0; o < len; o += 1u << 30) gzwrite(gz, buf.data() + o, unsigned(std::min<uint64_t>(len - o, 1u << 30))); }
+            else f.write(reinterpret_cast<const char*>(buf.data()), std::streamsize(len));
             written += len;
         }
+        if (gz) gzclose(gz);
     }
     t_write = since(t0);
     std::printf("vcf: %llu records, %llu probands, %llu bytes of FASTA written to %s\n", (unsigned long long)R, (unsigned long long)S,
@@ -328,9 +336,13 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
 int main(int argc, char** argv)
 {
     if (argc >= 5 && !std::strcmp(argv[1], "vcf")) {
-        bool no_test = false, write_all = false;
-        for (int i = 5; i < argc; ++i) { no_test |= !std::strcmp(argv[i], "--no-test"); write_all |= !std::strcmp(argv[i], "--write-all") || !std::strcmp(argv[i], "-a"); }
-        try { return vcf_mode(argv[2], argv[3], argv[4], no_test, write_all); }
+        bool no_test = false, write_all = false, compressed = false;
+        for (int i = 5; i < argc; ++i) {
+            no_test |= !std::strcmp(argv[i], "--no-test");
+            write_all |= !std::strcmp(argv[i], "--write-all") || !std::strcmp(argv[i], "-a");
+            compressed |= !std::strcmp(argv[i], "--write-compressed") || !std::strcmp(argv[i], "-c");
+        }
+        try { return vcf_mode(argv[2], argv[3], argv[4], no_test, write_all, compressed); }
         catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 101; }
     }
     if (argc >= 2 && !std::strcmp(argv[1], "kat")) return kat();
