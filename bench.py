@@ -2,14 +2,21 @@
 """Benchmark of the MI355X SIR executor (vcf2prot step 6) -- driver contract in the task brief.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C4|C5] [--samples S]
+                    [--scaling weak|strong]
 
 One "step" = one pass of the hot path (stitch kernel: K0 fill + K1 in-chunk scan + K2
-gather/scatter) over the whole synthetic batch, inputs already resident in HBM.  At N=1
-the workload is BASELINE.json configs[1] ("C2": 1 000 samples x 20 k transcripts x ~400 aa,
-one missense per transcript => 2 000 haplotypes, A = 1.6e10 residues, N = 1.2e8 tasks).
-For N>1 every rank executes its own 1 000-sample shard of a 1 000*N-sample cohort
-(weak scaling; haplotypes are independent, the only collective is the all-gather of
-per-rank {haplotypes, result bytes} over RCCL).  Rank 0 prints ONE JSON line.
+gather/scatter) over this rank's whole shard, inputs already resident in HBM.  At N=1 the
+workload is BASELINE.json configs[1] ("C2": 1 000 samples x 20 k transcripts x ~400 aa, one
+missense per transcript => 2 000 haplotypes, A = 1.6e10 residues, N = 1.2e8 tasks).
+
+--gpus N > 1 launches itself: the parent spawns `python -m torch.distributed.run` with N ranks
+(one per GPU, RCCL) before it touches any GPU, and exits with the children's code; under an
+external launcher (RANK/WORLD_SIZE set) it just runs as a rank.
+  --scaling weak   (default) every rank executes its own `--samples`-sample shard of a samples*N cohort
+  --scaling strong one cohort of `--samples` samples (C3: the 10 000-sample cohort of the north star),
+                   cut into contiguous haplotype ranges of equal result bytes (shard.shard_by_bytes)
+Haplotypes are independent: no data-path collective; the step's only exchange is the all-gather of
+{haplotypes, result bytes} per rank.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -17,110 +24,214 @@ import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s is achievable by a copy)
+
+# samples per GPU (weak) / per cohort (strong)
+DEFAULT_SAMPLES = {"weak": {"C2": 1000, "C3": 2000, "C4": 313, "C5": 10000},
+                   "strong": {"C2": 1000, "C3": 10000, "C4": 2504, "C5": 50000}}
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C4", "C5"])
-    ap.add_argument("--samples", type=int, default=0, help="samples per GPU (default: the config's own size, capped to fit HBM)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--samples", type=int, default=0, help="weak: samples per GPU; strong: samples of the whole cohort (0 = the config's own size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the transfers-inclusive leg (v2p_pipeline_*)")
+    ap.add_argument("--verify", default="all", choices=["all", "sample", "none"],
+                    help="haplotypes whose digest is compared with the oracle before timing")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--temporal", action="store_true", help="plain result stores instead of non-temporal")
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--fasta", action="store_true", help="FASTA-emitting image: headers and line feeds fused into the scatter (SURVEY 8f rank 1)")
-    ap.add_argument("--tpt", type=int, default=0, help="descriptors per lane (chunks of up to 256*tpt tasks; 0 = library default)")
+    ap.add_argument("--tpt", type=int, default=0, help="descriptors per lane (chunks of up to 256*tpt tasks; 0 = what the image needs)")
+    ap.add_argument("--var", type=int, default=0, help="K2 variant (0 = default, 1 = legacy byte-granular gathers)")
     ap.add_argument("--cut-align", type=int, default=0)
     ap.add_argument("--chunk-tasks", type=int, default=0)
     ap.add_argument("--chunk-bytes", type=int, default=0)
-    ap.add_argument("--dbg", type=int, default=0, help="timing-only kernel ablation (results are wrong; implies --no-verify)")
+    ap.add_argument("--dbg", type=int, default=0, help="timing-only kernel ablation (results are wrong; implies --verify none)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise launch, sharding and the size all-gather over gloo (CPU test of the N-rank path)")
     ap.add_argument("--xcd-order", type=int, default=-1, help="0: launch chunks in result order instead of dealing them to XCDs by proteome slice")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.no_verify or a.dbg or a.dry_run:
+        a.verify = "none"
+    return a
 
 
-DEFAULT_SAMPLES = {"C2": 1000, "C3": 2000, "C4": 313, "C5": 10000}   # per GPU; C3/C5 full cohorts are processed in HBM-sized batches
+def self_launch(n: int) -> int:
+    """Parent of an N-rank run: nothing here touches torch.cuda or HIP."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(cohort, n_threads, budget_s=12.0):
-    """Oracle (C restatement of task.rs:38-50 / gir.rs:230-234 / exec.rs:34-40), reference-faithful
-    flavour: u32 chars, 32-byte AoS tasks, '.' fill, haplotypes over a thread pool."""
+def oracle_digests(workload, n_samples, haps, workers):
+    """Digest of the oracle's result tape for every haplotype index in `haps` (thread pool; the C oracle
+    and the generator release the GIL)."""
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from concurrent.futures import ThreadPoolExecutor
+    from sir_oracle import COracle
+    from vcf2prot_amd.cohort import Cohort
+    orc = COracle()
+    workers = max(1, min(workers, len(haps)))
+
+    def work(w):
+        cc = Cohort.preset(workload, n_samples=n_samples)       # own generator state per thread
+        out = {}
+        for h in haps[w::workers]:
+            hap = cc.haplotype(h)
+            t = orc.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+            want = orc.gir_execute_u8(t, cc.ref_tape_u32(h).astype(np.uint8), hap.alt, np.full(hap.n_res, ord("."), dtype=np.uint8))
+            out[h] = orc.digest_u8(want)
+        return out
+    res = {}
+    with ThreadPoolExecutor(workers) as pool:
+        for part in pool.map(work, range(workers)):
+            res.update(part)
+    return res
+
+
+def cpu_baseline(cohort, h0, n_haps, n_threads, budget_s=12.0):
+    """Oracle (C restatement of task.rs:38-50 / gir.rs:230-234 / exec.rs:34-40), reference-faithful
+    flavour: u32 chars, 32-byte AoS tasks, '.' fill, haplotypes over a persistent thread pool."""
+    import numpy as np
+    import psutil
     from sir_oracle import COracle
     orc = COracle()
-    n_h = max(2, min(cohort.n_haplotypes, 2 * n_threads, 48))
-    jobs, jobs8, aa = [], [], 0
-    for h in range(n_h):
+    first = cohort.haplotype(h0)
+    per_job = 8 * max(first.n_res, 1) + 32 * max(first.n_tasks, 1)          # u32 ref + u32 result + AoS tasks
+    fit = int(0.25 * psutil.virtual_memory().available // per_job)
+    n_h = max(2, min(n_haps, 2 * n_threads, fit))
+    jobs, jobs8, aa, host_bytes = [], [], 0, 0
+    for h in range(h0, h0 + n_h):
         hap = cohort.haplotype(h)
         t = orc.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
         ref = cohort.ref_tape_u32(h)
         jobs.append((t, ref, hap.alt.astype(np.uint32), np.empty(hap.n_res, dtype=np.uint32)))
-        jobs8.append((t, ref.astype(np.uint8), hap.alt, np.empty(hap.n_res, dtype=np.uint8)))
         aa += int(hap.length.sum())
+        host_bytes += 8 * int(hap.length.sum()) + 4 * hap.n_res + 32 * hap.n_tasks     # read + write 4 B per residue, '.' fill, tasks
     t1 = orc.mt_execute(jobs, n_threads, wide=True, reps=1)
     reps = max(1, min(200, int(budget_s / max(t1, 1e-3))))
     secs = orc.mt_execute(jobs, n_threads, wide=True, reps=reps)
+    for (t, ref, alt, res) in jobs[:max(2, n_h // 4)]:                                   # the 1-byte flavour on a quarter of the jobs
+        jobs8.append((t, ref.astype(np.uint8), alt.astype(np.uint8), np.empty(res.size, dtype=np.uint8)))
+    aa8 = sum(int(j[3].size) for j in jobs8)
     t8 = orc.mt_execute(jobs8, n_threads, wide=False, reps=1)
-    reps8 = max(1, min(200, int(0.4 * budget_s / max(t8, 1e-3))))
+    reps8 = max(1, min(200, int(0.3 * budget_s / max(t8, 1e-3))))
     secs8 = orc.mt_execute(jobs8, n_threads, wide=False, reps=reps8)
     return {"value": aa * reps / secs, "unit": "aa/s", "cores": n_threads, "kind": "port",
             "sample": f"first {n_h} haplotypes of the workload ({aa:.3e} aa) x {reps} passes, u32 chars + 32-B tasks + '.' fill, "
-                      f"thread pool over haplotypes (Rayon-MT equivalent)",
-            "cpu_best_u8_memcpy": aa * reps8 / secs8}
+                      f"persistent thread pool over haplotypes (Rayon-MT equivalent), {n_h / n_threads:.1f} jobs per thread",
+            "host_GBps": host_bytes * reps / secs / 1e9,
+            "cpu_best_u8_memcpy": aa8 * reps8 / secs8}
+
+
+def pcie_inclusive(cohort, h0, h1, n_threads, slots=3, target_image_bytes=2 << 30):
+    """Transfers-inclusive rate through the C ABI's streamed pipeline (v2p_pipeline_*): H2D of descriptors + alt bytes,
+    stitch kernel, D2H of the result into pinned host memory, `slots` images in flight.  Not `value`."""
+    from vcf2prot_amd.engine import Context, Pipeline
+    sizes = cohort.result_sizes(h0, h1)
+    total = int(sizes.sum())
+    n_img = max(2, min(16, (total + target_image_bytes - 1) // target_image_bytes))
+    per = (h1 - h0 + n_img - 1) // n_img
+    imgs = [cohort.pack(h, min(h1, h + per), n_threads=n_threads) for h in range(h0, h1, per)]
+    aa = sum(i.n_copy_bytes for i in imgs)
+    out_total = sum(i.out_bytes for i in imgs)
+    h2d = sum(i.desc.nbytes + i.chunks.nbytes + i.payload.nbytes for i in imgs)
+    best = None
+    with Context(0) as ctx:
+        ctx.upload_proteome(cohort.proteome())
+        pipe = Pipeline(ctx, slots)
+        for rep in range(3):                           # the first pass allocates and pins
+            t0 = time.perf_counter()
+            inflight = []
+            for img in imgs:
+                if len(inflight) == slots:
+                    t = inflight.pop(0)
+                    pipe.wait(t)
+                    pipe.release(t)
+                inflight.append(pipe.submit(img.desc, img.chunks, img.payload, img.out_bytes))
+            for t in inflight:
+                pipe.wait(t)
+                pipe.release(t)
+            secs = time.perf_counter() - t0
+            if rep and (best is None or secs < best):
+                best = secs
+        pipe.close()
+    return {"aa_per_s": aa / best, "seconds": best, "images": len(imgs), "slots": slots, "h2d_bytes": h2d, "d2h_bytes": out_total,
+            "d2h_GBps": out_total / best / 1e9, "what": "packed images -> pinned H2D -> stitch kernel -> D2H into pinned host memory"}
 
 
 def main():
     args = parse_args()
-    if args.dbg:
-        args.no_verify = True
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
-        args.gpus = world
+    args.gpus = world
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X: the gpu engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if args.dry_run:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs an MI355X: the gpu engine has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist_on = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dry_run:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     # native pieces: built once per node (local rank 0), everybody else waits
     from vcf2prot_amd import build
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     if local_rank == 0:
         build.build_all()
-        if not args.no_verify or not args.no_cpu_baseline:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        if args.verify != "none" or not args.no_cpu_baseline:
             import sir_oracle
             sir_oracle.build_c_oracle()
     if dist_on:
         dist.barrier()
     from vcf2prot_amd import _native as N
     from vcf2prot_amd.cohort import Cohort
-    lib = N.hip_lib()
+    from vcf2prot_amd.shard import shard_by_bytes
+    lib = None if args.dry_run else N.hip_lib()
 
     # ---- synthetic cohort at the Task boundary; this rank's shard --------------------
-    samples = args.samples or DEFAULT_SAMPLES[args.workload]
-    cohort = Cohort.preset(args.workload, n_samples=samples * world)
-    h0, h1 = 2 * samples * rank, 2 * samples * (rank + 1)
+    samples = args.samples or DEFAULT_SAMPLES[args.scaling][args.workload]
     n_threads = max(1, (os.cpu_count() or 1) // world)
+    if args.scaling == "weak":
+        cohort_samples = samples * world
+        cohort = Cohort.preset(args.workload, n_samples=cohort_samples)
+        h0, h1 = 2 * samples * rank, 2 * samples * (rank + 1)
+    else:
+        cohort_samples = samples
+        cohort = Cohort.preset(args.workload, n_samples=cohort_samples)
+        sizes = cohort.result_sizes(0, cohort.n_haplotypes, n_threads=min(n_threads, 64))
+        h0, h1 = shard_by_bytes(sizes.tolist(), world)[rank]              # SURVEY 8e: equal result bytes per rank
     t_gen = time.perf_counter()
     img = cohort.pack(h0, h1, n_threads=min(n_threads, 64), chunk_tasks=args.chunk_tasks, chunk_bytes=args.chunk_bytes, fasta=args.fasta, cut_align=args.cut_align)
     t_gen = time.perf_counter() - t_gen
@@ -130,18 +241,21 @@ def main():
     n_proteome = proteome.size
     if args.fasta:                                             # resident reference = proteome + record headers
         proteome = np.concatenate([proteome, cohort.fasta_headers()])
-        args.no_verify = True                                  # digests are defined on the plain result tape
+        args.verify = "none"                                   # digests are defined on the plain result tape
 
-    def padded(arr):                                           # 16 readable bytes either side (16-byte gathers)
-        t = torch.zeros(arr.size + 48, dtype=torch.uint8, device=dev)
+    PAD = 64                                                   # the ABI asks for 32 readable bytes either side
+
+    def padded(arr):
+        t = torch.zeros(arr.size + 2 * PAD, dtype=torch.uint8, device=dev)
         if arr.size:
-            t[16:16 + arr.size] = torch.from_numpy(arr).to(dev)
+            t[PAD:PAD + arr.size] = torch.from_numpy(arr).to(dev)
         return t
 
     d_prot, d_payload = padded(proteome), padded(img.payload)
     d_desc = torch.from_numpy(img.desc.view(np.int64)).to(dev)
+    n_desc = int(img.desc.size)
     img.chunks = np.ascontiguousarray(img.chunks)
-    if args.xcd_order != 0:           # XCD-aware launch order (speed only; chunks are independent)
+    if args.xcd_order != 0 and not args.dry_run:           # XCD-aware launch order (speed only; chunks are independent)
         rc = lib.v2p_order_chunks_for_xcds(img.chunks.ctypes.data, img.chunks.shape[0], img.desc.ctypes.data, img.desc.size, n_proteome)
         assert rc == 0
     d_chunks = torch.from_numpy(np.ascontiguousarray(img.chunks).view(np.int64)).to(dev)
@@ -151,105 +265,144 @@ def main():
     d_status = torch.full((1,), -1, dtype=torch.int64, device=dev)
     n_chunks = int(img.chunks.shape[0])
     n_haps = int(img.hap_out_begin.size - 1)
+    # immediate descriptors carry their bytes; what the kernel can touch of the payload arena is the rest
+    spaces = (img.desc >> np.uint64(62)).astype(np.uint8)
+    lens = ((img.desc >> np.uint64(40)) & np.uint64((1 << 22) - 1)).astype(np.int64)
+    payload_touched = int(lens[spaces == 1].sum())
+    n_imm = int((spaces == 3).sum())
+    # bytes that must cross the HBM interface per launch: every result byte written once, every descriptor and chunk
+    # header read once, the alt bytes that are not inside a descriptor, the proteome once
+    hbm_min = out_bytes + 8 * n_desc + 16 * n_chunks + payload_touched + int(proteome.size)
+    del spaces, lens
     assert d_out.data_ptr() % 16 == 0
-    stream = torch.cuda.current_stream()
-    sizes = torch.tensor([n_haps, out_bytes], dtype=torch.int64, device=dev)
+    stream = None if args.dry_run else torch.cuda.current_stream()
+    sizes_t = torch.tensor([n_haps, out_bytes], dtype=torch.int64, device=dev)
     all_sizes = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+    flags = (0 if args.temporal else 1) | ((args.tpt or img.tasks_per_lane) << 8) | (args.var << 12) | (args.dbg << 16)
 
     def launch():
-        rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), d_desc.data_ptr(), d_chunks.data_ptr(), n_chunks,
-                                   d_prot.data_ptr() + 16, proteome.size, d_payload.data_ptr() + 16, img.payload.size,
-                                   d_out.data_ptr(), out_bytes, d_status.data_ptr(),
-                                   (0 if args.temporal else 1) | ((args.tpt or img.tasks_per_lane) << 8) | (args.dbg << 16), args.max_blocks)
+        if args.dry_run:
+            if dist_on:
+                dist.all_gather_into_tensor(all_sizes, sizes_t)
+            return
+        rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), d_desc.data_ptr(), n_desc, d_chunks.data_ptr(), n_chunks,
+                                   d_prot.data_ptr() + PAD, proteome.size, d_payload.data_ptr() + PAD, img.payload.size,
+                                   d_out.data_ptr(), out_bytes, d_status.data_ptr(), flags, args.max_blocks)
         if rc != 0:
             raise RuntimeError(f"v2p_stitch_launch failed: {rc}")
         if dist_on:                                            # the path's only exchange: result sizes for the global offsets
-            dist.all_gather_into_tensor(all_sizes, sizes)
+            dist.all_gather_into_tensor(all_sizes, sizes_t)
 
-    for _ in range(max(args.warmup, 1) if not args.no_verify else args.warmup):
+    sync = (lambda: None) if args.dry_run else torch.cuda.synchronize
+    for _ in range(max(args.warmup, 1) if args.verify != "none" else args.warmup):
         launch()
-    torch.cuda.synchronize()
+    sync()
     if int(d_status.item()) != -1 and not args.dbg:
         sys.exit(f"device reported a task error: status={int(d_status.item()):#x}")
 
-    # ---- parity before timing: per-haplotype digests vs the oracle on a sample --------
+    # ---- parity before timing: per-haplotype digests vs the oracle --------------------
     verified = None
-    if not args.no_verify:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        from sir_oracle import COracle
-        orc = COracle()
+    if args.verify != "none":
         d_dig = torch.zeros(n_haps, dtype=torch.int64, device=dev)
         lib.v2p_digest_launch(ctypes.c_void_p(stream.cuda_stream), d_out.data_ptr(), d_hap.data_ptr(), n_haps, out_bytes, d_dig.data_ptr())
         torch.cuda.synchronize()
         dig = d_dig.cpu().numpy().view(np.uint64)
-        check = sorted({0, n_haps // 2, n_haps - 1})
-        for i in check:
-            hap = cohort.haplotype(h0 + i)
-            t = orc.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
-            want = orc.gir_execute_u8(t, cohort.ref_tape_u32(h0 + i).astype(np.uint8), hap.alt,
-                                      np.full(hap.n_res, ord("."), dtype=np.uint8))
-            if int(dig[i]) != orc.digest_u8(want):
-                sys.exit(f"PARITY FAILURE: haplotype {h0 + i} differs from the oracle")
-        verified = {"haplotypes_checked": [int(h0 + i) for i in check],
-                    "digest_of_digests": f"{int(np.bitwise_xor.reduce(dig)):016x}"}
+        every = args.verify == "all" and out_bytes <= 24 * 10 ** 9
+        check = list(range(n_haps)) if every else sorted(set(np.linspace(0, n_haps - 1, min(n_haps, 512)).astype(int).tolist()))
+        t_v = time.perf_counter()
+        want = oracle_digests(args.workload, cohort_samples, [h0 + i for i in check], min(n_threads, 64))
+        bad = [h0 + i for i in check if int(dig[i]) != want[h0 + i]]
+        if bad:
+            sys.exit(f"PARITY FAILURE: haplotypes {bad[:8]} differ from the oracle ({len(bad)} of {len(check)})")
+        verified = {"haplotypes_checked": len(check), "of": n_haps, "every_haplotype": bool(len(check) == n_haps),
+                    "digest_of_digests": f"{int(np.bitwise_xor.reduce(dig)):016x}", "oracle_seconds": time.perf_counter() - t_v}
 
     # ---- timed region -------------------------------------------------------------
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [] if args.dry_run else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if dist_on:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record(stream)
+        if ev:
+            ev[k][0].record(stream)
         launch()
-        ev[k][1].record(stream)
-    torch.cuda.synchronize()
+        if ev:
+            ev[k][1].record(stream)
+    sync()
     if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_ms = [a.elapsed_time(b) for a, b in ev] or [1e3 * elapsed / max(args.steps, 1)]
     if int(d_status.item()) != -1 and not args.dbg:
         sys.exit(f"device reported a task error: status={int(d_status.item()):#x}")
 
-    tot = torch.tensor([elapsed, float(A), float(NT)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([elapsed, float(A), float(NT), float(n_haps), float(out_bytes)], dtype=torch.float64, device=dev)
+    per_rank = None
     if dist_on:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        gathered = torch.zeros(5 * world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(gathered, tot)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         elapsed = float(mx[0].item())
         A_all, NT_all = float(tot[1].item()), float(tot[2].item())
+        g = gathered.cpu().view(world, 5).tolist()
+        per_rank = [{"rank": r, "seconds": g[r][0], "aa": int(g[r][1]), "haplotypes": int(g[r][3]), "result_bytes": int(g[r][4])} for r in range(world)]
+        seen = all_sizes.cpu().view(world, 2).tolist()          # what the in-step all-gather delivered: every rank's sizes
+        assert [int(x[0]) for x in seen] == [p["haplotypes"] for p in per_rank], "all-gather of result sizes disagrees"
     else:
         A_all, NT_all = float(A), float(NT)
 
     if rank == 0:
         avg_ms = sum(kern_ms) / len(kern_ms)
-        achieved = b_alg / (avg_ms * 1e-3) / 1e9
+        achieved = hbm_min / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload and tj.get("samples_per_gpu") == samples:
+                tj = tj.get(args.workload, tj)
+                if tj.get("workload") == args.workload and tj.get("haplotypes") == n_haps:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
             "metric": "amino-acids written/sec", "value": A_all * args.steps / elapsed, "unit": "aa/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {samples} samples/GPU ({2 * samples} haplotypes) x "
-                                   f"{cohort.n_transcripts} transcripts, SIR Task vectors at the step-6 boundary",
-                       "haplotypes_per_gpu": n_haps, "tasks_per_gpu": NT, "aa_per_gpu": A, "chunks_per_gpu": n_chunks,
-                       "descriptor_bytes": 8, "descriptors_per_lane": args.tpt or img.tasks_per_lane, "parallelism": f"haplotype-sharded x{world}, no data-path collective"},
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: " + (f"{samples} samples/GPU x {world} GPU(s)" if args.scaling == "weak" else f"one {samples}-sample cohort over {world} GPU(s), equal result bytes per rank")
+                                   + f" ({int(A_all):.3e} aa) x {cohort.n_transcripts} transcripts, SIR Task vectors at the step-6 boundary",
+                       "haplotypes_rank0": n_haps, "tasks_rank0": NT, "aa_rank0": A, "chunks_rank0": n_chunks,
+                       "descriptor_bytes": 8, "immediate_descriptors_rank0": n_imm, "descriptors_per_lane": args.tpt or img.tasks_per_lane,
+                       "parallelism": f"haplotype-sharded x{world}, no data-path collective; per step one all-gather of 16 B per rank (RCCL)" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": b_alg, "kernel": "stitch_kernel", "kernel_ms_avg": avg_ms,
-                         "kernel_ms_min": min(kern_ms)},
-            "kernel_only_aa_per_s_per_gpu": A / (avg_ms * 1e-3),
+                         "bytes": "achieved = hbm_bytes_min / kernel time: result bytes written once + 8 B per descriptor + 16 B per chunk + alt bytes "
+                                  "outside descriptors + the proteome once (reference reads are served by L2 and not counted)",
+                         "hbm_bytes_min_per_launch": hbm_min,
+                         "algorithmic_bytes_per_launch": b_alg, "algorithmic_GBps": b_alg / (avg_ms * 1e-3) / 1e9,
+                         "kernel": "stitch_kernel", "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms)},
+            "kernel_only_aa_per_s_rank0": A / (avg_ms * 1e-3),
             "verified": verified, "image_build_s": t_gen,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cohort, os.cpu_count() or 1)
+        if per_rank:
+            line["per_rank"] = per_rank
+        if args.dry_run:
+            line["data"] = "synthetic (dry run: no kernel was launched, value is meaningless)"
+        # free the big device buffers before the host-side legs
+        del d_out
+        if not args.dry_run:
+            torch.cuda.empty_cache()
+        if world == 1 and not args.no_pcie and not args.fasta and not args.dbg and not args.dry_run:
+            try:
+                pc = pcie_inclusive(cohort, h0, h1, min(n_threads, 64))
+                line["incl_transfers_aa_per_s"] = pc.pop("aa_per_s")
+                line["incl_transfers"] = pc
+            except Exception as e:           # never lose the bench line to the secondary leg
+                line["incl_transfers"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu_baseline and not args.dry_run:
+            line["cpu_baseline"] = cpu_baseline(cohort, h0, n_haps, os.cpu_count() or 1)
         print(json.dumps(line))
     if dist_on:
         dist.barrier()

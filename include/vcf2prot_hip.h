@@ -208,10 +208,12 @@ int  v2p_pipeline_wait(v2p_pipeline* p, uint32_t ticket, const uint8_t** result,
 int  v2p_pipeline_release(v2p_pipeline* p, uint32_t ticket);
 
 /* ---- raw launchers on caller-owned device memory (torch tensors, other runtimes) ----- */
-/* src0/src1 must have 16 readable bytes before and 32 after; out must be 16-byte aligned;
- * status is one device uint64 initialised to ~0. */
+/* src0/src1 must have 32 readable bytes before and after (the kernel loads whole aligned 16-byte
+ * blocks around a task's bytes); out must be 16-byte aligned; status is one device uint64 initialised
+ * to ~0; chunks that point outside d_desc[0, n_desc) are reported in it, never followed.
+ * `nontemporal`: bit 0 non-temporal result stores, bits 8..11 descriptors per lane (1, 2, 4). */
 int v2p_stitch_launch(void* hip_stream,
-                      const uint64_t* d_desc, const v2p_chunk* d_chunks, uint32_t n_chunks,
+                      const uint64_t* d_desc, uint64_t n_desc, const v2p_chunk* d_chunks, uint32_t n_chunks,
                       const uint8_t* d_src0, uint64_t src0_len,
                       const uint8_t* d_src1, uint64_t src1_len,
                       uint8_t* d_out, uint64_t out_len,
@@ -225,6 +227,12 @@ int v2p_digest_launch(void* hip_stream, const uint8_t* d_out, const uint64_t* d_
 int v2p_fill_launch(void* hip_stream, uint8_t* d_out, uint64_t bytes, uint32_t word, int nontemporal);
 /* microbenchmark: `blocks` workgroups x 4 waves each issue `iters` 16-byte-per-lane gathers (1 KiB per wave
  * instruction) from a window of `window` bytes at byte misalignment `misalign` (0 = aligned); d_sink: one u32 per wave */
+/* microbenchmark: the stitch kernel's data movement without its bookkeeping -- a cache-resident window of `window` bytes
+ * (>= 1 MiB + 64 KiB, 64 readable bytes of slack around it) read at byte misalignment `shift` and streamed into d_out with
+ * non-temporal stores; mode 0 byte-granular gathers, 1 aligned loads + lane exchange, 2 two aligned loads, 3 dword-aligned
+ * loads, 4 stores only, 5 loads only; d_sink: one u32 per 32 KiB of d_out */
+int v2p_copy_bench_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t shift, uint8_t* d_out, uint64_t bytes,
+                          int mode, uint32_t* d_sink);
 int v2p_gather_bench_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t misalign, uint32_t iters,
                             uint32_t blocks, uint32_t* d_sink);
 

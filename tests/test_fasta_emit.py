@@ -32,7 +32,10 @@ def interpret(img, resident):
         for d in img.desc[int(tb):int(tb) + nt]:
             d = int(d)
             src, ln, space = d & ((1 << 40) - 1), (d >> 40) & ((1 << 22) - 1), d >> 62
-            out[dst:dst + ln] = resident[src:src + ln] if space == 0 else (img.payload[src:src + ln] if space == 1 else ord("."))
+            if space == 3:                        # immediate descriptor: the source field holds the bytes
+                out[dst:dst + ln] = [(src >> (8 * k)) & 0xFF for k in range(ln)]
+            else:
+                out[dst:dst + ln] = resident[src:src + ln] if space == 0 else (img.payload[src:src + ln] if space == 1 else ord("."))
             dst += ln
     return out
 

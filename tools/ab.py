@@ -74,32 +74,32 @@ def main():
     prot = cohort.proteome()
     n_prot = prot.size
     resident = np.concatenate([prot, cohort.fasta_headers()])
-    d_prot = torch.zeros(resident.size + 48, dtype=torch.uint8, device=dev)
-    d_prot[16:16 + resident.size] = torch.from_numpy(resident).to(dev)
+    d_prot = torch.zeros(resident.size + 128, dtype=torch.uint8, device=dev)
+    d_prot[64:64 + resident.size] = torch.from_numpy(resident).to(dev)
     stream = torch.cuda.current_stream()
     d_status = torch.full((1,), -1, dtype=torch.int64, device=dev)
     vs, max_out = [], 0
     for spec in a.variants:
         kv = dict(x.split("=") for x in spec.split(",") if x)
         pack = {k: int(kv[k]) for k in ("chunk_tasks", "chunk_bytes", "cut_align", "soft_window") if k in kv}
-        img = cohort.pack(0, cohort.n_haplotypes, n_threads=min(64, os.cpu_count() or 1), fasta=bool(int(kv.get("fasta", 0))), **pack)
+        img = cohort.pack(0, cohort.n_haplotypes, n_threads=min(64, os.cpu_count() or 1), fasta=bool(int(kv.get("fasta", 0))), inline_payload=bool(int(kv.get("imm", 1))), **pack)
         chunks = np.ascontiguousarray(img.chunks)
         if int(kv.get("l1", 0)):
             chunks = l1_order(chunks, img.desc, n_prot, int(kv["l1"]))
         elif int(kv.get("xcd", 1)):
             lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, n_prot)
-        d_pay = torch.zeros(img.payload.size + 48, dtype=torch.uint8, device=dev)
-        d_pay[16:16 + img.payload.size] = torch.from_numpy(img.payload).to(dev)
+        d_pay = torch.zeros(img.payload.size + 128, dtype=torch.uint8, device=dev)
+        d_pay[64:64 + img.payload.size] = torch.from_numpy(img.payload).to(dev)
         v = dict(spec=spec, d_desc=torch.from_numpy(img.desc.view(np.int64)).to(dev), d_chunks=torch.from_numpy(chunks.view(np.int64)).to(dev),
                  d_pay=d_pay, n_pay=img.payload.size, n_chunks=chunks.shape[0], out=img.out_bytes,
-                 flags=int(kv.get("nt", 1)) | (int(kv.get("tpt", img.tasks_per_lane)) << 8) | (int(kv.get("dbg", 0)) << 16), ms=[])
+                 flags=int(kv.get("nt", 1)) | (int(kv.get("tpt", img.tasks_per_lane)) << 8) | (int(kv.get("var", 0)) << 12) | (int(kv.get("dbg", 0)) << 16), ms=[])
         vs.append(v)
         max_out = max(max_out, img.out_bytes)
     d_out = torch.empty(max_out + 32, dtype=torch.uint8, device=dev)
 
     def launch(v):
-        rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), v["d_desc"].data_ptr(), v["d_chunks"].data_ptr(), v["n_chunks"],
-                                   d_prot.data_ptr() + 16, resident.size, v["d_pay"].data_ptr() + 16, v["n_pay"],
+        rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), v["d_desc"].data_ptr(), v["d_desc"].numel(), v["d_chunks"].data_ptr(), v["n_chunks"],
+                                   d_prot.data_ptr() + 64, resident.size, v["d_pay"].data_ptr() + 64, v["n_pay"],
                                    d_out.data_ptr(), v["out"], d_status.data_ptr(), v["flags"], 0)
         assert rc == 0
     for v in vs:

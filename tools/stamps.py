@@ -14,7 +14,7 @@ prot = c.proteome()
 chunks = np.ascontiguousarray(img.chunks)
 lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, prot.size)
 def padded(a):
-    t = torch.zeros(a.size + 48, dtype=torch.uint8, device=dev); t[16:16 + a.size] = torch.from_numpy(a).to(dev); return t
+    t = torch.zeros(a.size + 128, dtype=torch.uint8, device=dev); t[64:64 + a.size] = torch.from_numpy(a).to(dev); return t
 d_prot, d_pay = padded(prot), padded(img.payload)
 d_desc = torch.from_numpy(img.desc.view(np.int64)).to(dev); d_chunks = torch.from_numpy(chunks.view(np.int64)).to(dev)
 nch = chunks.shape[0]
@@ -24,8 +24,8 @@ d_out = torch.zeros(img.out_bytes + 512 + dbg_bytes, dtype=torch.uint8, device=d
 d_status = torch.full((1,), -1, dtype=torch.int64, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 for flags in (1, 1 | (20 << 16)):
-    lib.v2p_stitch_launch(ctypes.c_void_p(s), d_desc.data_ptr(), d_chunks.data_ptr(), nch, d_prot.data_ptr() + 16, prot.size,
-                          d_pay.data_ptr() + 16, img.payload.size, d_out.data_ptr(), img.out_bytes, d_status.data_ptr(), flags | (img.tasks_per_lane << 8), 0)
+    lib.v2p_stitch_launch(ctypes.c_void_p(s), d_desc.data_ptr(), d_desc.numel(), d_chunks.data_ptr(), nch, d_prot.data_ptr() + 64, prot.size,
+                          d_pay.data_ptr() + 64, img.payload.size, d_out.data_ptr(), img.out_bytes, d_status.data_ptr(), flags | (img.tasks_per_lane << 8), 0)
 torch.cuda.synchronize()
 off = (img.out_bytes + 255) // 256 * 256
 st = d_out[off:off + dbg_bytes].cpu().numpy().view(np.uint64).reshape(nch, 4, 8).astype(np.int64)

@@ -56,5 +56,6 @@ COHORT_API = {
     "v2p_cohort_describe": (c_int64, [c_void_p, c_uint64, c_void_p, c_uint64]),
     "v2p_cohort_pack": (c_int, [c_void_p, c_uint64, c_uint64, c_int, c_uint32, c_uint32, c_uint32, POINTER(PackedImage)]),
     "v2p_cohort_fasta_headers": (c_uint64, [c_void_p, c_void_p, c_uint64]),
+    "v2p_cohort_result_sizes": (c_int, [c_void_p, c_uint64, c_uint64, c_int, c_void_p]),
     "v2p_packed_free": (None, [POINTER(PackedImage)]),
 }

@@ -155,6 +155,15 @@ class Cohort:
                 out.append((int(t), kind, aa))
         return out
 
+    def result_sizes(self, h0: int = 0, h1: int = -1, n_threads: int = 0) -> np.ndarray:
+        """Result tape length of every haplotype in [h0, h1) (for byte-balanced sharding, shard.shard_by_bytes)."""
+        import os
+        h1 = self.n_haplotypes if h1 < 0 else h1
+        out = np.zeros(max(h1 - h0, 0), dtype=np.uint64)
+        if out.size and self._lib.v2p_cohort_result_sizes(self._h, h0, h1, n_threads or min(64, os.cpu_count() or 1), out.ctypes.data) != 0:
+            raise RuntimeError("v2p_cohort_result_sizes failed")
+        return out
+
     HEADER_BYTES = 19
 
     def fasta_headers(self) -> np.ndarray:
@@ -165,11 +174,11 @@ class Cohort:
         return out
 
     def pack(self, h0: int, h1: int, n_threads: int = 0, chunk_tasks: int = 0, chunk_bytes: int = 0,
-             fasta: bool = False, cut_align: int = 0, soft_window: int = 0) -> Packed:
+             fasta: bool = False, cut_align: int = 0, soft_window: int = 0, inline_payload: bool = True) -> Packed:
         import os
         img = PackedImage()
         nt = n_threads or min(32, os.cpu_count() or 1)
-        rc = self._lib.v2p_cohort_pack(self._h, h0, h1, nt, chunk_tasks, chunk_bytes, (1 if fasta else 0) | (cut_align << 8) | (soft_window << 24), ctypes.byref(img))
+        rc = self._lib.v2p_cohort_pack(self._h, h0, h1, nt, chunk_tasks, chunk_bytes, (1 if fasta else 0) | (0 if inline_payload else 2) | (cut_align << 8) | (soft_window << 24), ctypes.byref(img))
         if rc != 0:
             raise RuntimeError(f"v2p_cohort_pack failed ({rc})")
         try:

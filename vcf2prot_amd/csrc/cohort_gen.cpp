@@ -453,6 +453,7 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
     for (auto& im : parts) {
         if (chunk_tasks) { im.chunk_tasks = chunk_tasks; im.adaptive_tasks = false; }
         if (chunk_bytes) im.chunk_bytes = chunk_bytes;
+        if (flags & V2P_PACK_NO_IMM) im.inline_payload = false;
         if ((flags >> 8) & 0xFFFF) im.cut_align = (flags >> 8) & 0xFFFF;   // experiment knobs: bits 8..23 cut alignment,
         if (flags >> 24) im.soft_window = flags >> 24;                     //                   bits 24..31 closing window
     }
@@ -513,6 +514,26 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
     for (auto& t : th) t.join();
     out->hap_out_begin[n] = oo;
     out->n_desc = nd; out->n_chunks = nc; out->n_payload = np; out->n_haps = n;
+    return 0;
+}
+
+int v2p_cohort_result_sizes(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads, uint64_t* out)
+{
+    if (!c || !out || h1 < h0 || h1 > v2p_cohort_n_haplotypes(c)) return -1;
+    const uint64_t n = h1 - h0;
+    if (n_threads < 1) n_threads = 1;
+    if (uint64_t(n_threads) > n && n) n_threads = int(n);
+    auto work = [&](int w) {
+        v2p_hapbuf b;
+        for (uint64_t h = h0 + uint64_t(w); h < h1; h += uint64_t(n_threads)) {
+            generate_into(*c, h, b, false, nullptr);
+            out[h - h0] = b.tx_res_end.empty() ? 0 : b.tx_res_end.back();
+        }
+    };
+    std::vector<std::thread> th;
+    for (int w = 1; w < n_threads; ++w) th.emplace_back(work, w);
+    work(0);
+    for (auto& t : th) t.join();
     return 0;
 }
 

@@ -11,6 +11,10 @@
 //                               1 = batch payload arena (alt bytes, private ref tapes),
 //                               2 = fill with '.' (cells no task covers keep the
 //                                   '.' of haplotype_instruction.rs:78)
+//                               3 = immediate: the low 40 bits ARE the bytes (1..5 of them,
+//                                   first byte lowest) -- alt payloads of missense /
+//                                   deletion / short insertion tasks travel inside their
+//                                   descriptor and need no gather at all
 //   chunks[C]    work items of <= 256 (deep Task vectors: 1024) consecutive descriptors and < 64 KiB of
 //                result: {first descriptor, result offset, descriptor count}.
 //                Inside a chunk result offsets are the exclusive prefix sum of the
@@ -35,6 +39,8 @@ namespace v2p {
 constexpr unsigned SPACE_PROTEOME = 0;
 constexpr unsigned SPACE_PAYLOAD  = 1;
 constexpr unsigned SPACE_FILL     = 2;
+constexpr unsigned SPACE_IMM      = 3;
+constexpr uint32_t IMM_MAX_BYTES  = 5;         // literal bytes that fit the 40-bit source field
 
 constexpr uint64_t SRC_MASK   = (1ull << 40) - 1;
 constexpr uint32_t LEN_BITS   = 22;
@@ -44,7 +50,8 @@ constexpr uint32_t CHUNK_TASKS_DEEP = 1024;    // ... for images with < 100 resu
 constexpr uint32_t CHUNK_BYTES = 64u * 1024u - 16u;  // result bytes per work item (<= 4096 16-byte blocks incl. a ragged head)
 constexpr uint32_t CUT_ALIGN  = 4096;          // preferred chunk cut: 4 KiB multiples = full 256-lane passes of 16-byte blocks
 constexpr uint64_t DST_MASK   = (1ull << 48) - 1;
-constexpr uint32_t PAD_BYTES  = 32;            // readable slack after a source arena (16-byte gathers; the dword-aligned form reads up to 19 bytes on)
+constexpr uint32_t PAD_BYTES  = 32;            // readable slack before AND after a source arena: the kernel loads whole 16-byte aligned blocks
+                                               // around a task's bytes (up to 30 bytes before its first byte in a chunk's ragged head block, 31 after its last)
 
 struct Chunk {
     uint64_t task_begin;   // index of the first descriptor
@@ -83,6 +90,7 @@ public:
     uint32_t cut_align = CUT_ALIGN;   // power of two >= 16
     uint32_t max_chunk_tasks = 0;     // largest descriptor count of any chunk (selects the kernel's descriptors per lane)
     uint32_t soft_window = 8;         // descriptors before the hard limit at which a chunk starts looking for its cut
+    bool inline_payload = true;       // payload tasks of <= IMM_MAX_BYTES bytes become immediate descriptors
 
     uint64_t out_size() const { return hap_out_begin.back(); }
     uint64_t n_haplotypes() const { return hap_out_begin.size() - 1; }
@@ -99,7 +107,13 @@ public:
         if (src + len > SRC_MASK) return PACK_TOO_LARGE;
         ++n_ref_tasks;
         n_copy_bytes += len;
-        emit(space, src, len);
+        if (inline_payload && space == SPACE_PAYLOAD && len >= 1 && len <= IMM_MAX_BYTES && src + len <= payload.size()) {
+            uint64_t lit = 0;
+            for (uint64_t k = 0; k < len; ++k) lit |= uint64_t(payload[src + k]) << (8 * k);
+            emit(SPACE_IMM, lit, len);
+        } else {
+            emit(space, src, len);
+        }
         cursor_ = dst + len;
         return PACK_OK;
     }
@@ -124,9 +138,16 @@ public:
         while (len) {
             uint32_t piece = uint32_t(len < chunk_bytes ? len : chunk_bytes);
             push(space, src, piece);
-            if (space != SPACE_FILL) src += piece;
+            src = advance(space, src, piece);
             len -= piece;
         }
+    }
+
+    // source field of the remainder of a task after its first `n` bytes went into another descriptor
+    static uint64_t advance(unsigned space, uint64_t src, uint32_t n) {
+        if (space == SPACE_FILL) return src;
+        if (space == SPACE_IMM) return n >= 8 ? 0 : src >> (8 * n);
+        return src + n;
     }
 
 private:
@@ -173,7 +194,7 @@ private:
             if (len <= r && open_bytes_ + len <= chunk_bytes) { append(space, src, len); return; }
             if (misal != 0 && open_bytes_ + r <= chunk_bytes) {               // split the straddling task at the boundary
                 append(space, src, r);
-                if (space != SPACE_FILL) src += r;
+                src = advance(space, src, r);
                 len -= r;
                 close_chunk();
                 continue;

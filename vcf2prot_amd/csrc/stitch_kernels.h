@@ -15,15 +15,16 @@ enum : uint32_t {
 };
 constexpr unsigned long long STATUS_CLEAN = ~0ull;
 constexpr int STITCH_TASKS_PER_LANE = 4;               // default descriptors per lane (any chunk <= 1024 tasks is legal)
-constexpr uint32_t DOTS_BYTES = 64u * 1024u + 64u;   // per-device buffer of '.' that fill descriptors gather from
+constexpr uint32_t DOTS_BYTES = 64u * 1024u + 128u;   // per-device buffer of '.' that fill descriptors gather from
 
 struct StitchArgs {
     const uint64_t* desc;      // packed descriptors (sir_pack.hpp)
+    uint64_t        n_desc;    // chunks pointing outside desc[0, n_desc) are refused on the device
     const Chunk*    chunks;
     uint32_t        n_chunks;
-    const uint8_t*  src0;      // space 0: resident proteome / the GIR's ref tape; 16 readable bytes before, 32 after
+    const uint8_t*  src0;      // space 0: resident proteome / the GIR's ref tape; 32 readable bytes before and after
     uint64_t        src0_len;
-    const uint8_t*  src1;      // space 1: payload arena / the GIR's alt tape;    16 readable bytes before, 32 after
+    const uint8_t*  src1;      // space 1: payload arena / the GIR's alt tape;    32 readable bytes before and after
     uint64_t        src1_len;
     uint8_t*        out;       // result arena, 16-byte aligned
     uint64_t        out_len;
@@ -66,6 +67,8 @@ hipError_t launch_validate(const ValidateArgs& a, hipStream_t stream);
 hipError_t launch_digest(const DigestArgs& a, uint64_t out_bytes, hipStream_t stream);
 hipError_t launch_gather_bench(const uint8_t* src, uint64_t window, uint32_t misalign, uint32_t iters, uint32_t blocks,
                                uint32_t* sink, hipStream_t stream);
+hipError_t launch_copy_bench(const uint8_t* src, uint64_t window, uint32_t shift, uint8_t* out, uint64_t bytes, int mode,
+                             uint32_t* sink, hipStream_t stream);
 hipError_t launch_fill(uint8_t* out, uint64_t bytes, uint32_t word, int nontemporal, hipStream_t stream);
 
 }  // namespace v2p

@@ -58,6 +58,53 @@ __device__ __forceinline__ u32x4 gather16_dw(uint64_t addr)
     return o;
 }
 
+// 16 bytes from a 16-byte aligned global address: a wave whose lanes read consecutive blocks touches every
+// 128-byte line exactly once (the byte-granular gather16 touches every line from two neighbouring lane quads).
+__device__ __forceinline__ u32x4 load16_aligned(uint64_t addr)
+{
+    typedef const __attribute__((address_space(1))) u32x4* gptr;
+    return *reinterpret_cast<gptr>(addr);
+}
+
+// DPP wave_shl:1 -- lane i receives lane i+1's value (lane 63 keeps `old`).
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t old, uint32_t x)
+{
+    return uint32_t(__builtin_amdgcn_update_dpp(int(old), int(x), 0x130, 0xf, 0xf, false));
+}
+
+// bytes d .. d+15 of the 32 bytes {v, n}, d in 0..15 (two select stages pick the dwords, v_alignbyte the bytes)
+__device__ __forceinline__ u32x4 funnel16(u32x4 v, u32x4 n, uint32_t d)
+{
+    const bool s8 = (d & 8u) != 0u, s4 = (d & 4u) != 0u;
+    const uint32_t t0 = s8 ? v[2] : v[0], t1 = s8 ? v[3] : v[1], t2 = s8 ? n[0] : v[2],
+                   t3 = s8 ? n[1] : v[3], t4 = s8 ? n[2] : n[0], t5 = s8 ? n[3] : n[1];
+    const uint32_t u0 = s4 ? t1 : t0, u1 = s4 ? t2 : t1, u2 = s4 ? t3 : t2, u3 = s4 ? t4 : t3, u4 = s4 ? t5 : t4;
+    const uint32_t r = d & 3u;
+    u32x4 o;
+    o.x = __builtin_amdgcn_alignbyte(u1, u0, r);
+    o.y = __builtin_amdgcn_alignbyte(u2, u1, r);
+    o.z = __builtin_amdgcn_alignbyte(u3, u2, r);
+    o.w = __builtin_amdgcn_alignbyte(u4, u3, r);
+    return o;
+}
+
+// An immediate descriptor's literal bytes (<= 5, first byte lowest) placed at byte position q of a
+// 16-byte block, q in -4..15 (negative: the task began in the previous block).
+__device__ __forceinline__ u32x4 imm_block(uint64_t lit, int32_t q)
+{
+    const uint32_t sh = 8u * (uint32_t(q) & 7u);
+    const uint64_t x = lit << sh;
+    const uint64_t y = sh ? lit >> (64u - sh) : 0ull;
+    uint64_t lo, hi;
+    if (q < 0) { lo = lit >> (8u * uint32_t(-q)); hi = 0ull; }
+    else if (q < 8) { lo = x; hi = y; }
+    else { lo = 0ull; hi = x; }
+    return u32x4{uint32_t(lo), uint32_t(lo >> 32), uint32_t(hi), uint32_t(hi >> 32)};
+}
+
+constexpr uint64_t ADJ_IMM = 1ull << 63;       // s_adj entry of an immediate task: flag | literal bytes
+constexpr uint64_t ADJ_LIT = (1ull << 40) - 1;
+
 // ---- wave64 inclusive add-scan with DPP (row_shr 1/2/4/8, row_bcast 15/31) ----
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
 {
@@ -75,23 +122,29 @@ __device__ __forceinline__ void report(unsigned long long* status, uint64_t inde
     atomicMin(status, (unsigned long long)((index << 8) | reason));
 }
 
-// Per chunk (one workgroup, 256 lanes, one descriptor per lane):
-//   A  decode + bounds-check the descriptor; wave64 DPP scan of the lengths; ballot/mbcnt
+// Per chunk (one workgroup, 256 lanes, TPT consecutive descriptors per lane):
+//   A  decode + bounds-check the descriptors; wave64 DPP scan of the lengths; ballot/mbcnt
 //      rank among the non-empty tasks; zero the block map
 //   B  compact the non-empty tasks by rank into LDS: s_off[r] (result offset inside the
 //      chunk) and s_adj[r] (source address minus that offset; '.' fill tasks point into a
-//      device buffer of dots), and scatter "+1" into the block map at the first 16-byte
-//      block that starts inside or after task r (r >= 1)
-//   C,D prefix-sum the block map (16 one-byte counters per lane, SWAR + wave scan), so
+//      device buffer of dots; immediate tasks keep their literal bytes), and scatter "+1" into
+//      the block map at the first 16-byte block that starts inside or after task r (r >= 1)
+//   C,D prefix-sum the block map (16 two-byte counters per lane, SWAR + wave scan), so
 //      map[k] = rank of the task covering the first byte of result block k -- the
-//      per-block search costs one LDS byte read instead of a binary search
-//   K2 every lane assembles aligned 16-byte result blocks.  The ranks r, r+1, r+2 of the
-//      tasks that can overlap a block are known from one map read, so up to three
-//      unaligned dwordx4 gathers (s_adj[r+i] + block offset) are issued back to back and
-//      merged by tail-overwrite with 64-bit byte masks; only blocks cut by four or more
-//      tasks take the extra loop.  Then one aligned, non-temporal dwordx4 store.
-// DBG != 0: timing-only ablations (results are wrong): 1 = no gathers, 2 = no stores; A/B switches with correct
-// results: 3 = dword-aligned gathers everywhere, 4 = byte-aligned gathers everywhere.
+//      per-block search costs one LDS read instead of a binary search
+//   K2 every lane assembles aligned 16-byte result blocks, 64 consecutive blocks per wave and pass.
+//      The task r covering a block's first byte is its *primary* stream: the lane loads the ALIGNED
+//      16-byte source block holding that byte (a wave touches every 128-byte line once) and takes the
+//      rest from the next lane, which holds the following aligned block of the same stream
+//      (DPP wave_shl:1 + a funnel shift by the stream's misalignment); only lanes whose neighbour is on
+//      another stream (task boundaries, lane 63) load a second block themselves.  Tasks r+1, r+2 that
+//      begin inside the block are merged over it by tail-overwrite with 64-bit byte masks: immediate
+//      tasks (SNV / short indel payloads) come out of the LDS table with no memory access, a task that
+//      continues the primary stream (the reference after an SNV) reuses the primary bytes, everything
+//      else is one exec-masked unaligned gather.  Blocks cut by four or more tasks take an extra loop.
+//      Then one aligned, non-temporal dwordx4 store -- 1 KiB per wave instruction.
+// VAR 1 = legacy K2 (one byte-granular dwordx4 gather per overlapping task), kept for A/B runs.
+// DBG != 0: timing-only ablations (results are wrong): 1 = no loads, 2 = no stores; 20 = s_memtime stamps.
 __device__ __forceinline__ u32x4 overwrite_tail(u32x4 v, u32x4 ld, uint32_t ja, bool take)
 {
     // bytes >= ja of the block come from ld (ja in 1..15)
@@ -115,22 +168,31 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("" ::: "memory");
 }
 
+// 16 bytes of a non-primary task for the block at `rel`: literal bytes placed at block position q, or a gather
+template <bool DW>
+__device__ __forceinline__ u32x4 fetch_task(uint64_t a, int32_t rel, int32_t q)
+{
+    if (a & ADJ_IMM) return imm_block(a & ADJ_LIT, q);
+    return DW ? gather16_dw(a + int64_t(rel)) : gather16(a + int64_t(rel));
+}
+
 // TPT = descriptors per lane: a chunk holds up to 256*TPT tasks.  The per-chunk set-up (two
 // dependent HBM latencies, four barriers) is the same for any TPT, so larger chunks amortise it.
-template <int TPT, bool NT, int DBG = 0>
+template <int TPT, bool NT, int VAR = 0, int DBG = 0>
 __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict__ p_desc, const Chunk* __restrict__ p_chunks,
                                                      const uint8_t* __restrict__ p_src0, const uint8_t* __restrict__ p_src1,
                                                      uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
                                                      const uint8_t* __restrict__ p_dots,
-                                                     uint32_t n_chunks, uint64_t src0_len, uint64_t src1_len, uint64_t out_len)
+                                                     uint32_t n_chunks, uint64_t n_desc, uint64_t src0_len, uint64_t src1_len, uint64_t out_len)
 {
     // explicit __restrict__ pointers (not a by-value struct): the chunk header becomes a scalar
     // (s_load) access, because the compiler can prove the result stores never clobber the inputs
-    struct { const uint64_t* desc; const Chunk* chunks; uint32_t n_chunks; const uint8_t* src0; uint64_t src0_len;
+    struct { const uint64_t* desc; const Chunk* chunks; uint32_t n_chunks; uint64_t n_desc; const uint8_t* src0; uint64_t src0_len;
              const uint8_t* src1; uint64_t src1_len; uint8_t* out; uint64_t out_len; unsigned long long* status; const uint8_t* dots; }
-        a{p_desc, p_chunks, n_chunks, p_src0, src0_len, p_src1, src1_len, p_out, out_len, p_status, p_dots};
+        a{p_desc, p_chunks, n_chunks, n_desc, p_src0, src0_len, p_src1, src1_len, p_out, out_len, p_status, p_dots};
 
     constexpr uint32_t K = 256u * TPT;
+    constexpr bool DW = TPT >= 4;                         // dense descriptors (short tasks): dword-aligned gathers win
     __shared__ __attribute__((aligned(16))) uint32_t s_map32[2048 + 8];     // 4096 two-byte block->rank entries
     __shared__ uint64_t s_adj[K + 8];
     __shared__ uint32_t s_off[K + 8];
@@ -138,7 +200,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint16_t* const s_map = reinterpret_cast<const uint16_t*>(s_map32);
-    const uint64_t dots16 = reinterpret_cast<uint64_t>(a.dots) + 16u;
+    const uint64_t dots16 = reinterpret_cast<uint64_t>(a.dots) + 32u;
 
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, acc_lds = 0, acc_wait = 0, acc_rest = 0;
     if (DBG == 20) st0 = __builtin_amdgcn_s_memtime();
@@ -147,9 +209,11 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
         const uint64_t tb = a.chunks[c].task_begin;
         const uint64_t dn = a.chunks[c].dst_n;
         const uint32_t n_hdr = uint32_t(dn >> 48);
-        const uint32_t n = n_hdr > K ? K : n_hdr;
         const uint64_t dst = dn & ((1ull << 48) - 1);
         const uint32_t head = uint32_t(dst & 15ull);
+        // a chunk table that points outside the descriptor array is refused, not followed
+        const bool hdr_ok = n_hdr <= K && tb <= a.n_desc && n_hdr <= a.n_desc - tb;
+        const uint32_t n = hdr_ok ? n_hdr : 0u;
 
         // ---- A: TPT consecutive descriptors per lane ----
         uint64_t adj[TPT];
@@ -165,11 +229,16 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                 len[k] = uint32_t(d >> 40) & ((1u << 22) - 1u);
                 const uint32_t space = uint32_t(d >> 62);
                 const uint64_t src = d & ((1ull << 40) - 1);
-                const uint64_t limit = space == SPACE_PROTEOME ? a.src0_len : (space == SPACE_PAYLOAD ? a.src1_len : ~0ull);
-                if (space == 3u || src + len[k] > limit) {       // never read out of bounds: task.rs would panic
-                    report(a.status, tb + i, STATUS_SRC_OOB);
-                } else if (space != SPACE_FILL) {
-                    adj[k] = reinterpret_cast<uint64_t>(space == SPACE_PROTEOME ? a.src0 : a.src1) + src;
+                if (space == SPACE_IMM) {
+                    if (len[k] > IMM_MAX_BYTES) report(a.status, tb + i, STATUS_SRC_OOB);
+                    else adj[k] = ADJ_IMM | src;
+                } else {
+                    const uint64_t limit = space == SPACE_PROTEOME ? a.src0_len : (space == SPACE_PAYLOAD ? a.src1_len : ~0ull);
+                    if (src + len[k] > limit) {                  // never read out of bounds: task.rs would panic
+                        report(a.status, tb + i, STATUS_SRC_OOB);
+                    } else if (space != SPACE_FILL) {
+                        adj[k] = reinterpret_cast<uint64_t>(space == SPACE_PROTEOME ? a.src0 : a.src1) + src;
+                    }
                 }
             }
             lsum += len[k];
@@ -191,12 +260,12 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
         uint32_t excl = incl - lsum + (wid > 0 ? l0 : 0u) + (wid > 1 ? l1 : 0u) + (wid > 2 ? l2 : 0u);
         uint32_t rank = nzincl - lnz + (wid > 0 ? z0 : 0u) + (wid > 1 ? z1 : 0u) + (wid > 2 ? z2 : 0u);
         const uint32_t nblk = total ? (head + total + 15u) >> 4 : 0u;
-        const bool chunk_ok = n_hdr <= K && dst + total <= a.out_len && nblk <= 4096u && total <= DOTS_BYTES - 64u;
+        const bool chunk_ok = hdr_ok && dst + total <= a.out_len && nblk <= 4096u && total <= DOTS_BYTES - 96u;
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
             if (len[k] != 0u) {
                 s_off[rank] = excl;
-                s_adj[rank] = adj[k] - excl;
+                s_adj[rank] = (adj[k] & ADJ_IMM) ? adj[k] : adj[k] - excl;
                 if (rank >= 1u && chunk_ok) {
                     const uint32_t kmin = (excl + head + 15u) >> 4;    // first block starting at or after the task start
                     if (kmin < nblk) atomicAdd(&s_map32[kmin >> 1], 1u << (16u * (kmin & 1u)));
@@ -234,51 +303,88 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
         if (!chunk_ok) {                                      // never write out of bounds
             if (tid == 0) report(a.status, tb, STATUS_RES_OOB);
         } else {
-            // ---- K2 ----
+            // ---- K2: wave `wid` takes the 64-block rows wid, wid+4, ... (a workgroup pass = 4 KiB of result) ----
             uint8_t* const out0 = a.out + (dst - head);
-            for (uint32_t b = tid; b < nblk; b += 256u) {
+            const uint32_t nrow = (nblk + 63u) >> 6;
+            for (uint32_t row = wid; row < nrow; row += 4u) {
                 unsigned long long k0 = 0, k1 = 0, k2 = 0;
                 if (DBG == 20) k0 = __builtin_amdgcn_s_memtime();
+                const uint32_t b = (row << 6) + lane;
+                const bool active = b < nblk;
                 const int32_t rel = int32_t(b << 4) - int32_t(head);          // block start relative to dst
                 const uint32_t hi = uint32_t(rel + 16) < total ? uint32_t(rel + 16) : total;
-                uint32_t r = s_map[b];                 // two-byte entries
-                const uint32_t e0 = s_off[r + 1u], e1 = s_off[r + 2u], e2 = s_off[r + 3u];
+                uint32_t r = active ? uint32_t(s_map[b]) : 0u;                 // two-byte entries
+                const uint32_t o0 = s_off[r], e0 = s_off[r + 1u], e1 = s_off[r + 2u], e2 = s_off[r + 3u];
                 const uint64_t a0 = s_adj[r], a1 = s_adj[r + 1u], a2 = s_adj[r + 2u];
-                const bool need1 = e0 < hi, need2 = e1 < hi;
                 // the sentinels make r+1, r+2 readable (dots) even when they are past the last task
-                // the address path (TA) is the busiest unit of this kernel: lanes that do not need a
-                // second/third task stay masked off instead of gathering from a dummy address
-                u32x4 v, g1 = {0u, 0u, 0u, 0u}, g2 = {0u, 0u, 0u, 0u};
-                if (DBG == 20) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); k1 = __builtin_amdgcn_s_memtime(); }
-                if (DBG != 1) {
-                    if (DBG == 3 || (TPT >= 4 && DBG != 4)) {                  // dense descriptors (short tasks): dword-aligned loads win
-                        v = gather16_dw(a0 + int64_t(rel));
-                        if (need1) g1 = gather16_dw(a1 + int64_t(rel));
-                        if (need2) g2 = gather16_dw(a2 + int64_t(rel));
+                const bool need1 = active && e0 < hi, need2 = active && e1 < hi;
+                const bool imm0 = (a0 & ADJ_IMM) != 0ull;
+                u32x4 v;
+                if (VAR == 1) {
+                    // legacy: one byte-granular gather per overlapping task; lanes that need no second/third task stay masked off
+                    u32x4 g1 = {0u, 0u, 0u, 0u}, g2 = {0u, 0u, 0u, 0u};
+                    if (DBG == 20) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); k1 = __builtin_amdgcn_s_memtime(); }
+                    v = g1;
+                    if (DBG != 1) {
+                        if (active) v = fetch_task<DW>(a0, rel, int32_t(o0) - rel);
+                        if (need1) g1 = fetch_task<DW>(a1, rel, int32_t(e0) - rel);
+                        if (need2) g2 = fetch_task<DW>(a2, rel, int32_t(e1) - rel);
+                        if (DBG == 20) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k2 = __builtin_amdgcn_s_memtime(); }
                     } else {
-                    v = gather16(a0 + int64_t(rel));
-                    if (need1) g1 = gather16(a1 + int64_t(rel));
-                    if (need2) g2 = gather16(a2 + int64_t(rel));
+                        v = u32x4{uint32_t(a0), e0, r, hi};
+                        g1 = u32x4{uint32_t(a1), e1, r, hi};
+                        g2 = u32x4{uint32_t(a2), e2, r, hi};
                     }
-                    if (DBG == 20) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k2 = __builtin_amdgcn_s_memtime(); }
+                    v = overwrite_tail(v, g1, uint32_t(int32_t(e0) - rel), need1);
+                    v = overwrite_tail(v, g2, uint32_t(int32_t(e1) - rel), need2);
                 } else {
-                    v = u32x4{uint32_t(a0), e0, r, hi};
-                    g1 = u32x4{uint32_t(a1), e1, r, hi};
-                    g2 = u32x4{uint32_t(a2), e2, r, hi};
+                    // tasks r+1 / r+2 that continue the primary stream (same source-minus-result offset) reuse its bytes
+                    const bool same1 = need1 && !imm0 && a1 == a0;
+                    const bool same2 = need2 && !imm0 && a2 == a0;
+                    const uint64_t X = a0 + uint64_t(int64_t(rel));             // source address of the block's first byte
+                    const uint32_t dlt = uint32_t(X) & 15u;
+                    const uint64_t G = (active && !imm0) ? X - dlt : 0ull;      // its aligned 16-byte block (0: no primary load)
+                    uint32_t pend = e0 < hi ? e0 : hi;                          // end of the bytes stream 0 supplies
+                    if (same1) pend = e1 < hi ? e1 : hi;
+                    if (same2) pend = e2 < hi ? e2 : hi;
+                    const uint32_t pcount = uint32_t(int32_t(pend) - rel);
+                    // does the next lane hold the following aligned block of the same stream?  (lane 63 and lanes
+                    // next to an idle lane receive 0)
+                    const uint64_t Gn = uint64_t(from_next_lane(0u, uint32_t(G))) | (uint64_t(from_next_lane(0u, uint32_t(G >> 32))) << 32);
+                    const bool own_n = G != 0ull && dlt != 0u && pcount + dlt > 16u && Gn != G + 16ull;
+                    u32x4 n_own = {0u, 0u, 0u, 0u}, g1 = {0u, 0u, 0u, 0u}, g2 = {0u, 0u, 0u, 0u};
+                    v = n_own;
+                    if (DBG == 20) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); k1 = __builtin_amdgcn_s_memtime(); }
+                    if (DBG != 1) {
+                        if (G != 0ull) v = load16_aligned(G);
+                        if (own_n) n_own = load16_aligned(G + 16ull);
+                        if (need1 && !same1) g1 = fetch_task<DW>(a1, rel, int32_t(e0) - rel);
+                        if (need2 && !same2) g2 = fetch_task<DW>(a2, rel, int32_t(e1) - rel);
+                        if (DBG == 20) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k2 = __builtin_amdgcn_s_memtime(); }
+                    } else {
+                        v = u32x4{uint32_t(a0), e0, r, hi};
+                        g1 = u32x4{uint32_t(a1), e1, r, hi};
+                        g2 = u32x4{uint32_t(a2), e2, r, hi};
+                    }
+                    u32x4 nx;
+                    nx[0] = from_next_lane(0u, v[0]); nx[1] = from_next_lane(0u, v[1]);
+                    nx[2] = from_next_lane(0u, v[2]); nx[3] = from_next_lane(0u, v[3]);
+                    if (own_n) nx = n_own;
+                    const u32x4 p = imm0 ? imm_block(a0 & ADJ_LIT, int32_t(o0) - rel) : funnel16(v, nx, dlt);
+                    v = overwrite_tail(p, g1, uint32_t(int32_t(e0) - rel), need1 && !same1);
+                    v = overwrite_tail(v, same2 ? p : g2, uint32_t(int32_t(e1) - rel), need2);
                 }
-                v = overwrite_tail(v, g1, uint32_t(int32_t(e0) - rel), need1);
-                v = overwrite_tail(v, g2, uint32_t(int32_t(e1) - rel), need2);
-                if (e2 < hi) {                                 // four or more tasks cut this block: three more per round,
+                if (active && e2 < hi) {                       // four or more tasks cut this block: three more per round,
                     uint32_t pos = e2;                         // their gathers in flight together
                     r += 3u;
                     while (pos < hi) {
                         const uint32_t o1 = s_off[r + 1u], o2 = s_off[r + 2u], o3 = s_off[r + 3u];
                         const uint64_t b0 = s_adj[r], b1 = s_adj[r + 1u], b2 = s_adj[r + 2u];
                         const bool n1 = o1 < hi, n2 = o2 < hi;
-                        const u32x4 h0 = (TPT >= 4 && DBG != 4) ? gather16_dw(b0 + int64_t(rel)) : gather16(b0 + int64_t(rel));
+                        const u32x4 h0 = fetch_task<DW>(b0, rel, int32_t(pos) - rel);
                         u32x4 h1 = {0u, 0u, 0u, 0u}, h2 = {0u, 0u, 0u, 0u};
-                        if (n1) h1 = (TPT >= 4 && DBG != 4) ? gather16_dw(b1 + int64_t(rel)) : gather16(b1 + int64_t(rel));
-                        if (n2) h2 = (TPT >= 4 && DBG != 4) ? gather16_dw(b2 + int64_t(rel)) : gather16(b2 + int64_t(rel));
+                        if (n1) h1 = fetch_task<DW>(b1, rel, int32_t(o1) - rel);
+                        if (n2) h2 = fetch_task<DW>(b2, rel, int32_t(o2) - rel);
                         v = overwrite_tail(v, h0, uint32_t(int32_t(pos) - rel), true);
                         v = overwrite_tail(v, h1, uint32_t(int32_t(o1) - rel), n1);
                         v = overwrite_tail(v, h2, uint32_t(int32_t(o2) - rel), n2);
@@ -286,17 +392,19 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                         r += 3u;
                     }
                 }
-                uint8_t* o = out0 + (uint64_t(b) << 4);
-                if (DBG == 2) { if (v[0] == 0x12345678u && v[3] == 0x9abcdef0u) o[0] = 1; }
-                else if (rel >= 0 && uint32_t(rel) + 16u <= total) {
-                    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(o));
-                    else *reinterpret_cast<u32x4*>(o) = v;
-                } else {
-                    // ragged first/last block of a chunk whose cut is not 16-byte aligned
-                    const uint32_t ka = rel < 0 ? uint32_t(-rel) : 0u, kb = uint32_t(int32_t(hi) - rel);
+                if (active) {
+                    uint8_t* o = out0 + (uint64_t(b) << 4);
+                    if (DBG == 2) { if (v[0] == 0x12345678u && v[3] == 0x9abcdef0u) o[0] = 1; }
+                    else if (rel >= 0 && uint32_t(rel) + 16u <= total) {
+                        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(o));
+                        else *reinterpret_cast<u32x4*>(o) = v;
+                    } else {
+                        // ragged first/last block of a chunk whose cut is not 16-byte aligned
+                        const uint32_t ka = rel < 0 ? uint32_t(-rel) : 0u, kb = uint32_t(int32_t(hi) - rel);
 #pragma unroll
-                    for (uint32_t j = 0; j < 16u; ++j)
-                        if (j >= ka && j < kb) o[j] = uint8_t(v[j >> 2] >> (8u * (j & 3u)));
+                        for (uint32_t j = 0; j < 16u; ++j)
+                            if (j >= ka && j < kb) o[j] = uint8_t(v[j >> 2] >> (8u * (j & 3u)));
+                    }
                 }
                 if (DBG == 20) { const unsigned long long k3 = __builtin_amdgcn_s_memtime(); acc_lds += k1 - k0; acc_wait += k2 - k1; acc_rest += k3 - k2; }
             }
@@ -452,6 +560,107 @@ __global__ __launch_bounds__(256) void gather_bench_kernel(const uint8_t* __rest
     if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[wave] = acc[0];
 }
 
+// copy_bench_kernel: the stitch kernel's data movement with all bookkeeping removed -- one workgroup per 32 KiB span of
+// `out`, 1 KiB per wave and pass, source = a cache-resident window (slice b % 8 for workgroup b, as the XCD-aware chunk
+// order arranges) read at byte misalignment `shift`, streamed out with non-temporal 16-byte stores.  Ceiling the K2 phase is
+// compared against, per load flavour:
+//   0 byte-granular dwordx4 gather   1 aligned dwordx4 + next lane's block (DPP wave_shl:1) + funnel shift
+//   2 two aligned dwordx4 + funnel   3 dword-aligned x4 + x1 + v_alignbyte   4 stores only   5 loads only (mode 1 loads)
+template <int MODE>
+__global__ __launch_bounds__(256) void copy_bench_kernel(const uint8_t* __restrict__ src, uint64_t window, uint32_t shift_delay,
+                                                         uint8_t* __restrict__ out, uint64_t n16, uint32_t* __restrict__ sink)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t shift = shift_delay & 15u, delay = shift_delay >> 4;     // delay: cycles every wave idles before its first load
+    const uint64_t slice = (window / 8u) & ~4095ull;
+    const uint64_t span = 2048u;                                            // 16-byte blocks per workgroup
+    const uint64_t b0 = uint64_t(blockIdx.x) * span;
+    const uint64_t e = b0 + span < n16 ? b0 + span : n16;
+    const uint64_t base = reinterpret_cast<uint64_t>(src) + 64u + (blockIdx.x & 7u) * slice
+                        + ((uint64_t(blockIdx.x >> 3) * span * 16u) % (slice - span * 16u - 64u));
+    if (delay) {                                                            // stands for the stitch kernel's per-chunk set-up
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(8);
+    }
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    if (MODE == 6 || MODE == 7) {
+        // two aligned loads per block; 6: load -> store per pass, 7: the next pass's loads are issued before this pass's store,
+        // so the wait for them (vmcnt(1)) leaves the store in flight
+        if (b0 + threadIdx.x >= e) return;
+        uint64_t b = b0 + threadIdx.x;
+        uint64_t X = base + ((b - b0) << 4) + shift;
+        uint32_t d = uint32_t(X) & 15u;
+        u32x4 lo = load16_aligned(X - d), hi = load16_aligned(X - d + 16u);
+        if (MODE == 7) {
+            u32x4 v = funnel16(lo, hi, d);                                  // peeled first pass
+            uint64_t bn = b + 256u;
+            const bool more = bn < e;
+            if (more) { X = base + ((bn - b0) << 4) + shift; d = uint32_t(X) & 15u; lo = load16_aligned(X - d); hi = load16_aligned(X - d + 16u); }
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out) + b);
+            if (!more) return;
+            b = bn;
+        }
+#pragma unroll 1
+        for (;;) {
+            const u32x4 v = funnel16(lo, hi, d);
+            const uint64_t bn = b + 256u;
+            const bool more = bn < e;
+            if (MODE == 7 && more) { X = base + ((bn - b0) << 4) + shift; d = uint32_t(X) & 15u; lo = load16_aligned(X - d); hi = load16_aligned(X - d + 16u); }
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out) + b);
+            if (!more) break;
+            if (MODE == 6) { X = base + ((bn - b0) << 4) + shift; d = uint32_t(X) & 15u; lo = load16_aligned(X - d); hi = load16_aligned(X - d + 16u); }
+            b = bn;
+        }
+        return;
+    }
+#pragma unroll 1
+    for (uint64_t b = b0 + threadIdx.x; b < e; b += 256u) {
+        const uint64_t X = base + ((b - b0) << 4) + shift;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (MODE == 0) v = gather16(X);
+        else if (MODE == 3) v = gather16_dw(X);
+        else if (MODE == 2) {
+            const uint32_t d = uint32_t(X) & 15u;
+            const u32x4 lo = load16_aligned(X - d), hi = load16_aligned(X - d + 16u);
+            v = funnel16(lo, hi, d);
+        } else if (MODE == 1 || MODE == 5) {
+            const uint32_t d = uint32_t(X) & 15u;
+            const u32x4 lo = load16_aligned(X - d);
+            u32x4 own = {0u, 0u, 0u, 0u};
+            if (lane == 63u && d != 0u) own = load16_aligned(X - d + 16u);
+            u32x4 nx;
+            nx[0] = from_next_lane(0u, lo[0]); nx[1] = from_next_lane(0u, lo[1]);
+            nx[2] = from_next_lane(0u, lo[2]); nx[3] = from_next_lane(0u, lo[3]);
+            if (lane == 63u) nx = own;
+            v = funnel16(lo, nx, d);
+        } else v = u32x4{uint32_t(b), shift, 0u, 0u};
+        if (MODE == 5) { acc[0] ^= v[0]; acc[1] ^= v[1]; acc[2] ^= v[2]; acc[3] ^= v[3]; }
+        else __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out) + b);
+    }
+    if (MODE == 5 && (acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[blockIdx.x] = acc[0];
+}
+
+hipError_t launch_copy_bench(const uint8_t* src, uint64_t window, uint32_t shift, uint8_t* out, uint64_t bytes, int mode,
+                             uint32_t* sink, hipStream_t stream)
+{
+    const uint64_t n16 = bytes / 16;
+    if (n16 == 0 || window < (1u << 20)) return hipErrorInvalidValue;
+    const uint32_t grid = uint32_t((n16 + 2047) / 2048);
+#define V2P_CB(M) hipLaunchKernelGGL((copy_bench_kernel<M>), dim3(grid), dim3(256), 0, stream, src, window, shift, out, n16, sink)
+    switch (mode) {
+        case 0: V2P_CB(0); break;
+        case 1: V2P_CB(1); break;
+        case 2: V2P_CB(2); break;
+        case 3: V2P_CB(3); break;
+        case 4: V2P_CB(4); break;
+        case 5: V2P_CB(5); break;
+        case 6: V2P_CB(6); break;
+        default: V2P_CB(7); break;
+    }
+#undef V2P_CB
+    return hipGetLastError();
+}
+
 hipError_t launch_gather_bench(const uint8_t* src, uint64_t window, uint32_t misalign, uint32_t iters, uint32_t blocks,
                                uint32_t* sink, hipStream_t stream)
 {
@@ -493,28 +702,33 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     hipError_t err = hipSuccess;
     a.dots = device_dots(&err);
     if (!a.dots) return err;
-    // `nontemporal` bit 0: nt result stores; bits 16..23: timing-only ablation
+    // `nontemporal` bit 0: nt result stores; bits 8..11: descriptors per lane; bits 12..15: K2 variant
+    // (0 = aligned loads + lane exchange, 1 = legacy byte-granular gathers); bits 16..23: timing-only ablation
     const int nt = nontemporal & 1;
+    const int var = (nontemporal >> 12) & 0xF;
     const int dbg = (nontemporal >> 16) & 0xFF;
     const uint32_t grid = grid_for(a.n_chunks, max_blocks ? max_blocks : 0x7FFFFFFFu);
-    const uint32_t dyn = 0;
-    int tpt = (nontemporal >> 8) & 0xF;                 // bits 8..11: descriptors per lane (chunks hold <= 256*tpt tasks)
+    int tpt = (nontemporal >> 8) & 0xF;                 // chunks hold <= 256*tpt tasks
     if (tpt == 0) tpt = STITCH_TASKS_PER_LANE;
-#define V2P_KARGS a.desc, a.chunks, a.src0, a.src1, a.out, a.status, a.dots, a.n_chunks, a.src0_len, a.src1_len, a.out_len
+#define V2P_KARGS a.desc, a.chunks, a.src0, a.src1, a.out, a.status, a.dots, a.n_chunks, a.n_desc, a.src0_len, a.src1_len, a.out_len
+#define V2P_L(TT, NTT, VV, DD) hipLaunchKernelGGL((stitch_kernel<TT, NTT, VV, DD>), dim3(grid), dim3(256), 0, stream, V2P_KARGS)
+#define V2P_LAUNCH_V(TT, VV) do { \
+        if (dbg == 1) V2P_L(TT, true, VV, 1); \
+        else if (dbg == 2) V2P_L(TT, true, VV, 2); \
+        else if (dbg == 20) V2P_L(TT, true, VV, 20); \
+        else V2P_L(TT, true, VV, 0); } while (0)
 #define V2P_LAUNCH(TT) do { \
-        if (dbg == 1) hipLaunchKernelGGL((stitch_kernel<TT, true, 1>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
-        else if (dbg == 2) hipLaunchKernelGGL((stitch_kernel<TT, true, 2>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
-        else if (dbg == 3) hipLaunchKernelGGL((stitch_kernel<TT, true, 3>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
-        else if (dbg == 4) hipLaunchKernelGGL((stitch_kernel<TT, true, 4>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
-        else if (dbg == 20) hipLaunchKernelGGL((stitch_kernel<TT, true, 20>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
-        else if (nt) hipLaunchKernelGGL((stitch_kernel<TT, true, 0>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); \
-        else hipLaunchKernelGGL((stitch_kernel<TT, false, 0>), dim3(grid), dim3(256), dyn, stream, V2P_KARGS); } while (0)
+        if (!nt) V2P_L(TT, false, 0, 0); \
+        else if (var == 1) V2P_LAUNCH_V(TT, 1); \
+        else V2P_LAUNCH_V(TT, 0); } while (0)
     switch (tpt) {
         case 1: V2P_LAUNCH(1); break;
         case 2: V2P_LAUNCH(2); break;
         default: V2P_LAUNCH(4); break;
     }
 #undef V2P_LAUNCH
+#undef V2P_LAUNCH_V
+#undef V2P_L
 #undef V2P_KARGS
     return hipGetLastError();
 }

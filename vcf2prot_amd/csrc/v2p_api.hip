@@ -340,7 +340,7 @@ int v2p_execute_gir(v2p_ctx* c,
         HIP_TRY(c, c->d_chunks.ensure(img.chunks.size() * sizeof(Chunk)), "hipMalloc(chunks)");
         HIP_TRY(c, hipMemcpyAsync(c->d_desc.ptr(), img.desc.data(), img.desc.size() * 8, hipMemcpyHostToDevice, c->stream), "H2D(desc)");
         HIP_TRY(c, hipMemcpyAsync(c->d_chunks.ptr(), img.chunks.data(), img.chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice, c->stream), "H2D(chunks)");
-        StitchArgs a{reinterpret_cast<const uint64_t*>(c->d_desc.ptr()), reinterpret_cast<const Chunk*>(c->d_chunks.ptr()),
+        StitchArgs a{reinterpret_cast<const uint64_t*>(c->d_desc.ptr()), img.desc.size(), reinterpret_cast<const Chunk*>(c->d_chunks.ptr()),
                      uint32_t(img.chunks.size()), c->d_ref.ptr(), n_ref * E, c->d_alt.ptr(), n_alt * E,
                      c->d_res.ptr(), n_res * E, reinterpret_cast<unsigned long long*>(c->d_status.ptr())};
         HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | (tasks_per_lane_for(img.max_chunk_tasks) << 8), 0), "launch(stitch)");
@@ -378,6 +378,27 @@ int v2p_execute_gir(v2p_ctx* c,
 }
 
 // ---- batch -------------------------------------------------------------------
+
+// Tables of a caller-packed image: every chunk's descriptors inside desc[0, n_desc), its result offset inside the
+// arena, haplotype ranges ascending (digest_kernel walks hap_out_begin[h + 1]).  `out_bytes` = hap_out_begin[n_haps]
+// unless given.  The result length of a chunk is only known on the device (in-chunk scan), which re-checks it.
+static int check_packed(v2p_ctx* c, uint64_t n_desc, const Chunk* chunks, uint64_t n_chunks,
+                        const uint64_t* hap_out_begin, uint64_t n_haps, uint64_t out_bytes = ~0ull)
+{
+    if (hap_out_begin) {
+        for (uint64_t h = 0; h < n_haps; ++h)
+            if (hap_out_begin[h + 1] < hap_out_begin[h]) return c->fail(V2P_ERR_INVALID_ARG, "hap_out_begin is not ascending", int64_t(h));
+        if (out_bytes == ~0ull) out_bytes = hap_out_begin[n_haps];
+    }
+    for (uint64_t i = 0; i < n_chunks; ++i) {
+        const uint64_t n = chunks[i].dst_n >> 48, dst = chunks[i].dst_n & DST_MASK;
+        if (chunks[i].task_begin > n_desc || n > n_desc - chunks[i].task_begin)
+            return c->fail(V2P_ERR_INVALID_ARG, "chunk " + std::to_string(i) + " points outside the descriptor array", int64_t(i));
+        if (n > CHUNK_TASKS_DEEP) return c->fail(V2P_ERR_INVALID_ARG, "chunk " + std::to_string(i) + " holds more than 1024 descriptors", int64_t(i));
+        if (out_bytes != ~0ull && dst > out_bytes) return c->fail(V2P_ERR_INVALID_ARG, "chunk " + std::to_string(i) + " starts outside the result arena", int64_t(i));
+    }
+    return V2P_OK;
+}
 
 int v2p_batch_create(v2p_ctx* c, v2p_batch** out)
 {
@@ -618,6 +639,10 @@ int v2p_batch_set_packed(v2p_batch* b,
     if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
     if ((n_desc && !desc) || (n_chunks && !chunks) || (n_payload && !payload) || !hap_out_begin)
         return c->fail(V2P_ERR_INVALID_ARG, "null argument");
+    {   // a caller-packed image is checked before it is adopted: the kernels trust these tables
+        const int rc = check_packed(c, n_desc, reinterpret_cast<const Chunk*>(chunks), n_chunks, hap_out_begin, n_haps);
+        if (rc) return rc;
+    }
     b->img = ImageBuilder();
     b->img.desc.assign(desc, desc + n_desc);
     b->img.chunks.resize(n_chunks);
@@ -672,7 +697,7 @@ int v2p_batch_execute(v2p_batch* b)
     std::lock_guard<std::mutex> lk(c->mu);
     if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
-    StitchArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), reinterpret_cast<const Chunk*>(b->d_chunks.ptr()),
+    StitchArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), b->n_desc, reinterpret_cast<const Chunk*>(b->d_chunks.ptr()),
                  uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->d_payload.ptr(), b->n_payload,
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
     HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | (tasks_per_lane_for(b->max_chunk_tasks) << 8), 0), "launch(stitch)");
@@ -695,6 +720,7 @@ int v2p_batch_counts(const v2p_batch* b, uint64_t* n_haps, uint64_t* n_desc, uin
                      uint64_t* out_bytes, uint64_t* payload_bytes)
 {
     if (!b) return V2P_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(b->ctx->mu);
     const bool f = b->finalized;
     if (n_haps) *n_haps = f ? b->n_haps : b->img.n_haplotypes();
     if (n_desc) *n_desc = f ? b->n_desc : b->img.desc.size();
@@ -707,6 +733,7 @@ int v2p_batch_counts(const v2p_batch* b, uint64_t* n_haps, uint64_t* n_desc, uin
 int v2p_batch_hap_range(const v2p_batch* b, uint64_t h, uint64_t* begin, uint64_t* len)
 {
     if (!b || !begin || !len) return V2P_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(b->ctx->mu);
     const std::vector<uint64_t>& hb = b->img.hap_out_begin;
     if (h + 1 >= hb.size()) return V2P_ERR_INVALID_ARG;
     *begin = hb[h]; *len = hb[h + 1] - hb[h];
@@ -754,7 +781,8 @@ struct PipeSlot {
     PinnedBuf h_in, h_out;
     uint64_t out_bytes = 0;
     unsigned long long status = STATUS_CLEAN;
-    bool busy = false;
+    bool busy = false;        // holds a result the caller has not released
+    bool in_flight = false;   // work was enqueued on `stream` and `done` has not been waited for
 };
 
 struct v2p_pipeline {
@@ -809,6 +837,13 @@ int v2p_pipeline_submit(v2p_pipeline* p,
     const uint32_t t = p->next;
     PipeSlot& s = p->slots[t];
     if (s.busy) return c->fail(V2P_ERR_STATE, "pipeline slot still holds an unreleased result");
+    {
+        const int rc = check_packed(c, n_desc, reinterpret_cast<const Chunk*>(chunks), n_chunks, nullptr, 0, out_bytes);
+        if (rc) return rc;
+    }
+    // the slot's staging and device buffers are about to be rewritten (and possibly reallocated): whatever was
+    // enqueued on it before -- a submit that failed half way, a result released without a wait -- must be done
+    if (s.in_flight) { HIP_TRY(c, hipStreamSynchronize(s.stream), "hipStreamSynchronize(slot)"); s.in_flight = false; }
     const size_t b_desc = size_t(n_desc) * 8, b_chunks = size_t(n_chunks) * sizeof(Chunk);
     const size_t o_chunks = (b_desc + 15) & ~size_t(15), o_payload = (o_chunks + b_chunks + 15) & ~size_t(15);
     HIP_TRY(c, s.h_in.ensure(o_payload + n_payload), "hipHostMalloc(in)");
@@ -826,11 +861,12 @@ int v2p_pipeline_submit(v2p_pipeline* p,
             order_chunks_for_xcds(reinterpret_cast<Chunk*>(s.h_in.p + o_chunks), n_chunks, desc, n_desc, c->proteome_len);
     }
     if (n_payload) memcpy(s.h_in.p + o_payload, payload, n_payload);
+    s.in_flight = true;       // from here on the stream may hold work that reads h_in / writes h_out
     if (b_desc) HIP_TRY(c, hipMemcpyAsync(s.d_desc.ptr(), s.h_in.p, b_desc, hipMemcpyHostToDevice, s.stream), "H2D(desc)");
     if (b_chunks) HIP_TRY(c, hipMemcpyAsync(s.d_chunks.ptr(), s.h_in.p + o_chunks, b_chunks, hipMemcpyHostToDevice, s.stream), "H2D(chunks)");
     if (n_payload) HIP_TRY(c, hipMemcpyAsync(s.d_payload.ptr(), s.h_in.p + o_payload, n_payload, hipMemcpyHostToDevice, s.stream), "H2D(payload)");
     HIP_TRY(c, hipMemsetAsync(s.d_status.ptr(), 0xFF, sizeof(unsigned long long), s.stream), "hipMemset(status)");
-    StitchArgs a{reinterpret_cast<const uint64_t*>(s.d_desc.ptr()), reinterpret_cast<const Chunk*>(s.d_chunks.ptr()),
+    StitchArgs a{reinterpret_cast<const uint64_t*>(s.d_desc.ptr()), n_desc, reinterpret_cast<const Chunk*>(s.d_chunks.ptr()),
                  uint32_t(n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, s.d_payload.ptr(), n_payload,
                  s.d_out.ptr(), out_bytes, reinterpret_cast<unsigned long long*>(s.d_status.ptr())};
     uint32_t max_n = 0;
@@ -850,10 +886,12 @@ int v2p_pipeline_wait(v2p_pipeline* p, uint32_t ticket, const uint8_t** result, 
 {
     if (!p || ticket >= p->slots.size() || !result || !n) return V2P_ERR_INVALID_ARG;
     v2p_ctx* c = p->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
     PipeSlot& s = p->slots[ticket];
     if (!s.busy) return c->fail(V2P_ERR_STATE, "nothing submitted on this ticket");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     HIP_TRY(c, hipEventSynchronize(s.done), "hipEventSynchronize");
+    s.in_flight = false;
     unsigned long long st;
     memcpy(&st, s.h_out.p + ((s.out_bytes + 7) & ~7ull), sizeof st);
     *result = s.h_out.p;
@@ -868,21 +906,29 @@ int v2p_pipeline_wait(v2p_pipeline* p, uint32_t ticket, const uint8_t** result, 
 int v2p_pipeline_release(v2p_pipeline* p, uint32_t ticket)
 {
     if (!p || ticket >= p->slots.size()) return V2P_ERR_INVALID_ARG;
-    p->slots[ticket].busy = false;
+    v2p_ctx* c = p->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PipeSlot& s = p->slots[ticket];
+    if (s.in_flight) {          // released without a wait: the copies into / out of the pinned buffers must end first
+        HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+        HIP_TRY(c, hipEventSynchronize(s.done), "hipEventSynchronize");
+        s.in_flight = false;
+    }
+    s.busy = false;
     return V2P_OK;
 }
 
 // ---- raw launchers -------------------------------------------------------------
 
 int v2p_stitch_launch(void* hip_stream,
-                      const uint64_t* d_desc, const v2p_chunk* d_chunks, uint32_t n_chunks,
+                      const uint64_t* d_desc, uint64_t n_desc, const v2p_chunk* d_chunks, uint32_t n_chunks,
                       const uint8_t* d_src0, uint64_t src0_len,
                       const uint8_t* d_src1, uint64_t src1_len,
                       uint8_t* d_out, uint64_t out_len,
                       uint64_t* d_status, int nontemporal, uint32_t max_blocks)
 {
     if ((reinterpret_cast<uintptr_t>(d_out) & 15u) || !d_status) return V2P_ERR_INVALID_ARG;
-    StitchArgs a{d_desc, reinterpret_cast<const Chunk*>(d_chunks), n_chunks, d_src0, src0_len, d_src1, src1_len,
+    StitchArgs a{d_desc, n_desc, reinterpret_cast<const Chunk*>(d_chunks), n_chunks, d_src0, src0_len, d_src1, src1_len,
                  d_out, out_len, reinterpret_cast<unsigned long long*>(d_status)};
     return launch_stitch(a, reinterpret_cast<hipStream_t>(hip_stream), nontemporal, max_blocks) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
 }
@@ -905,6 +951,12 @@ int v2p_gather_bench_launch(void* hip_stream, const uint8_t* d_src, uint64_t win
                             uint32_t blocks, uint32_t* d_sink)
 {
     return launch_gather_bench(d_src, window, misalign, iters, blocks, d_sink, reinterpret_cast<hipStream_t>(hip_stream)) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
+}
+
+int v2p_copy_bench_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t shift, uint8_t* d_out, uint64_t bytes,
+                          int mode, uint32_t* d_sink)
+{
+    return launch_copy_bench(d_src, window, shift, d_out, bytes, mode, d_sink, reinterpret_cast<hipStream_t>(hip_stream)) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
 }
 
 int v2p_fill_launch(void* hip_stream, uint8_t* d_out, uint64_t bytes, uint32_t word, int nontemporal)
