@@ -233,6 +233,15 @@ int v2p_fill_launch(void* hip_stream, uint8_t* d_out, uint64_t bytes, uint32_t w
  * loads, 4 stores only, 5 loads only; d_sink: one u32 per 32 KiB of d_out */
 int v2p_copy_bench_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t shift, uint8_t* d_out, uint64_t bytes,
                           int mode, uint32_t* d_sink);
+/* microbenchmark: the same copy with persistent workgroups (`grid` of them) whose per-span "descriptor" (desc_bytes = 8, 4 or 0
+ * bytes per lane, streamed from HBM behind d_out) is requested `depth` spans before it is used */
+int v2p_copy_prefetch_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t shift, uint8_t* d_out, uint64_t bytes,
+                             int depth, int desc_bytes, uint32_t grid);
+/* microbenchmark: the copy of v2p_copy_bench_launch (mode 0) plus a streamed read of `bytes_per_lane` (4, 8, 16) bytes per lane by
+ * every `every`-th workgroup from d_desc (pieces `stride` bytes apart); flags bit 0 non-temporal loads, bit 1 one wave only,
+ * bit 2 read issued after the first store */
+int v2p_copy_mix_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t shift, uint8_t* d_out, uint64_t bytes,
+                        const uint8_t* d_desc, uint32_t bytes_per_lane, uint32_t every, uint32_t stride, uint32_t flags);
 int v2p_gather_bench_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t misalign, uint32_t iters,
                             uint32_t blocks, uint32_t* d_sink);
 

@@ -67,10 +67,17 @@ def main():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--rounds", type=int, default=15)
+    ap.add_argument("--mean-len", type=float, default=0.0, help="override the preset's mean transcript length")
+    ap.add_argument("--transcripts", type=int, default=0, help="override the preset's transcript count")
     a = ap.parse_args()
     lib = N.hip_lib()
     dev = torch.device("cuda", 0)
-    cohort = Cohort.preset(a.workload, n_samples=a.samples)
+    over = {}
+    if a.mean_len:
+        over["mean_len"] = a.mean_len
+    if a.transcripts:
+        over["n_transcripts"] = a.transcripts
+    cohort = Cohort.preset(a.workload, n_samples=a.samples, **over)
     prot = cohort.proteome()
     n_prot = prot.size
     resident = np.concatenate([prot, cohort.fasta_headers()])
@@ -92,7 +99,7 @@ def main():
         d_pay[64:64 + img.payload.size] = torch.from_numpy(img.payload).to(dev)
         v = dict(spec=spec, d_desc=torch.from_numpy(img.desc.view(np.int64)).to(dev), d_chunks=torch.from_numpy(chunks.view(np.int64)).to(dev),
                  d_pay=d_pay, n_pay=img.payload.size, n_chunks=chunks.shape[0], out=img.out_bytes,
-                 flags=int(kv.get("nt", 1)) | (int(kv.get("tpt", img.tasks_per_lane)) << 8) | (int(kv.get("var", 0)) << 12) | (int(kv.get("dbg", 0)) << 16), ms=[])
+                 flags=int(kv.get("nt", 1)) | (int(kv.get("tpt", img.tasks_per_lane)) << 8) | (int(kv.get("var", 0)) << 12) | (int(kv.get("dbg", 0)) << 16) | (int(kv.get("wgs", 0)) << 24), ms=[])
         vs.append(v)
         max_out = max(max_out, img.out_bytes)
     d_out = torch.empty(max_out + 32, dtype=torch.uint8, device=dev)

@@ -18,7 +18,8 @@ from vcf2prot_amd import _native as N  # noqa: E402
 
 MODES = {0: "byte-granular gather", 1: "aligned + lane exchange", 2: "two aligned loads", 3: "dword-aligned x4+x1",
          4: "stores only", 5: "loads only (aligned + lane exchange)", 6: "two aligned, load->store per pass",
-         7: "two aligned, next loads before store"}
+         7: "two aligned, next loads before store", 8: "gather + 8 B/lane descriptor stream",
+         9: "gather + header -> descriptor stream"}
 
 
 def main():
@@ -33,12 +34,12 @@ def main():
     nbytes = int(a.gb * (1 << 30)) // (32 << 10) * (32 << 10)
     window = int(a.window_mb * (1 << 20))
     src = torch.randint(0, 255, (window + (1 << 17),), dtype=torch.uint8, device=dev)
-    out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out = torch.zeros(nbytes + 4096 + nbytes // 16 + nbytes // 1024 + (1 << 20), dtype=torch.uint8, device=dev)   # + descriptor and header streams (zeros)
     sink = torch.zeros(nbytes // (32 << 10) + 1, dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream()
     res = []
     cases = [(4, 0, 0), (0, 0, 0), (0, 5, 0), (1, 5, 0), (2, 5, 0), (3, 5, 0), (5, 5, 0), (6, 5, 0), (7, 5, 0),
-             (4, 0, 7000), (0, 5, 7000), (2, 5, 7000), (6, 5, 7000), (7, 5, 7000), (6, 5, 14000), (7, 5, 14000)]
+             (0, 5, 7000), (7, 5, 7000), (8, 5, 0), (9, 5, 0), (0, 5, 0)]
     for mode, shift, delay in cases:
         ms = []
         for r in range(a.rounds + 1):
@@ -54,6 +55,21 @@ def main():
         row = {"mode": mode, "what": MODES[mode], "shift": shift, "delay_cycles": delay, "ms_median": med, "ms_min": min(ms), "TBps": nbytes / med / 1e9}
         res.append(row)
         print(f"mode {mode} ({MODES[mode]:38s}) shift {shift:2d} delay {delay:5d}: median {med:7.3f} ms  min {min(ms):7.3f} ms  {row['TBps']:6.2f} TB/s")
+    # persistent workgroups with the descriptor requested `depth` spans ahead
+    for depth, db, grid in [(1, 0, 2048), (1, 8, 2048), (2, 8, 2048), (4, 8, 2048), (8, 8, 2048), (1, 4, 2048), (4, 4, 2048), (4, 8, 1024), (8, 8, 1024)]:
+        ms = []
+        for r in range(a.rounds + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = lib.v2p_copy_prefetch_launch(ctypes.c_void_p(st.cuda_stream), src.data_ptr(), window, 5, out.data_ptr(), nbytes, depth, db, grid)
+            assert rc == 0
+            e1.record(st)
+            torch.cuda.synchronize()
+            if r:
+                ms.append(e0.elapsed_time(e1))
+        med = statistics.median(ms)
+        res.append({"mode": "persistent", "depth": depth, "desc_bytes_per_lane": db, "grid": grid, "ms_median": med, "TBps": nbytes / med / 1e9})
+        print(f"persistent grid {grid} desc {db} B/lane requested {depth} span(s) ahead: median {med:7.3f} ms  {nbytes / med / 1e9:6.2f} TB/s")
     # mode 1 must reproduce mode 0 bit for bit
     for shift in (0, 3, 5, 12):
         outs = []

@@ -23,7 +23,8 @@ print(wl, 'chunks', nch, 'tasks/lane', img.tasks_per_lane, 'out', img.out_bytes)
 d_out = torch.zeros(img.out_bytes + 512 + dbg_bytes, dtype=torch.uint8, device=dev)
 d_status = torch.full((1,), -1, dtype=torch.int64, device=dev)
 s = torch.cuda.current_stream().cuda_stream
-for flags in (1, 1 | (20 << 16)):
+var = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+for flags in (1 | (var << 12), 1 | (var << 12) | (20 << 16)):
     lib.v2p_stitch_launch(ctypes.c_void_p(s), d_desc.data_ptr(), d_desc.numel(), d_chunks.data_ptr(), nch, d_prot.data_ptr() + 64, prot.size,
                           d_pay.data_ptr() + 64, img.payload.size, d_out.data_ptr(), img.out_bytes, d_status.data_ptr(), flags | (img.tasks_per_lane << 8), 0)
 torch.cuda.synchronize()

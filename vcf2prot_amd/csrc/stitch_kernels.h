@@ -69,6 +69,10 @@ hipError_t launch_gather_bench(const uint8_t* src, uint64_t window, uint32_t mis
                                uint32_t* sink, hipStream_t stream);
 hipError_t launch_copy_bench(const uint8_t* src, uint64_t window, uint32_t shift, uint8_t* out, uint64_t bytes, int mode,
                              uint32_t* sink, hipStream_t stream);
+hipError_t launch_copy_prefetch(const uint8_t* src, uint64_t window, uint32_t shift, uint8_t* out, uint64_t bytes, int depth, int desc_bytes,
+                                uint32_t grid, hipStream_t stream);
+hipError_t launch_copy_mix(const uint8_t* src, uint64_t window, uint32_t shift, uint8_t* out, uint64_t bytes, const uint8_t* dsc,
+                           uint32_t bytes_per_lane, uint32_t every, uint32_t stride, uint32_t flags, hipStream_t stream);
 hipError_t launch_fill(uint8_t* out, uint64_t bytes, uint32_t word, int nontemporal, hipStream_t stream);
 
 }  // namespace v2p

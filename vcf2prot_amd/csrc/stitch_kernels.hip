@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
             // ---- K2: wave `wid` takes the 64-block rows wid, wid+4, ... (a workgroup pass = 4 KiB of result) ----
             uint8_t* const out0 = a.out + (dst - head);
             const uint32_t nrow = (nblk + 63u) >> 6;
-            for (uint32_t row = wid; row < nrow; row += 4u) {
+            for (uint32_t row = wid; row < (DBG == 4 ? 0u : nrow); row += 4u) {
                 unsigned long long k0 = 0, k1 = 0, k2 = 0;
                 if (DBG == 20) k0 = __builtin_amdgcn_s_memtime();
                 const uint32_t b = (row << 6) + lane;
@@ -317,8 +317,8 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                 const uint32_t o0 = s_off[r], e0 = s_off[r + 1u], e1 = s_off[r + 2u], e2 = s_off[r + 3u];
                 const uint64_t a0 = s_adj[r], a1 = s_adj[r + 1u], a2 = s_adj[r + 2u];
                 // the sentinels make r+1, r+2 readable (dots) even when they are past the last task
-                const bool need1 = active && e0 < hi, need2 = active && e1 < hi;
-                const bool imm0 = (a0 & ADJ_IMM) != 0ull;
+                const bool need1 = DBG != 3 && active && e0 < hi, need2 = DBG != 3 && active && e1 < hi;
+                const bool imm0 = DBG != 3 && (a0 & ADJ_IMM) != 0ull;
                 u32x4 v;
                 if (VAR == 1) {
                     // legacy: one byte-granular gather per overlapping task; lanes that need no second/third task stay masked off
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                     v = overwrite_tail(p, g1, uint32_t(int32_t(e0) - rel), need1 && !same1);
                     v = overwrite_tail(v, same2 ? p : g2, uint32_t(int32_t(e1) - rel), need2);
                 }
-                if (active && e2 < hi) {                       // four or more tasks cut this block: three more per round,
+                if (DBG != 3 && active && e2 < hi) {           // four or more tasks cut this block: three more per round,
                     uint32_t pos = e2;                         // their gathers in flight together
                     r += 3u;
                     while (pos < hi) {
@@ -418,6 +418,244 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                 dbg[0] = st0; dbg[1] = st1; dbg[2] = st2; dbg[3] = st3; dbg[4] = st4; dbg[5] = acc_lds; dbg[6] = acc_wait; dbg[7] = acc_rest;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// stitch3_kernel: the same contract as stitch_kernel, organised around latency instead of per-block work.
+// Measured on MI355X (profiles/r02_*): the per-block kernel is bound by neither HBM, the address path nor instruction
+// count -- a workgroup's life is one serial chain (chunk header -> descriptors -> four barriers -> eight times
+// [LDS look-ups -> gather -> merge -> store]) and eight workgroups per CU do not cover it.  Here
+//   * workgroups are persistent: while a chunk is processed, the next chunk's header (scalar) and descriptors (one per
+//     lane) are already on their way;
+//   * blocks cut by a task boundary are assembled ONCE PER TASK in a compacted pass P (lane = task, every lane does
+//     merge work) and parked in an LDS patch table indexed by the first task that starts inside the block;
+//   * the bulk pass B is lean: per 16-byte block one look-up of the covering task, one byte-granular gather of the
+//     primary stream (or the patch), one aligned non-temporal store -- and a wave takes FOUR 1 KiB rows per round, all
+//     look-ups first, four gathers in flight, then four stores.
+// Chunks of up to 256*TPT descriptors, TPT in {1, 2}; dense images (TPT 4) stay on stitch_kernel.
+// ---------------------------------------------------------------------------
+struct __attribute__((aligned(16))) TaskRec { uint64_t adj; uint32_t end; uint32_t off; };   // source address minus result offset (or
+                                                                                              // ADJ_IMM | literal), result range [off, end)
+template <int TPT, bool NT, int DBG = 0>
+__global__ __launch_bounds__(256, 8) void stitch3_kernel(const uint64_t* __restrict__ p_desc, const Chunk* __restrict__ p_chunks,
+                                                      const uint8_t* __restrict__ p_src0, const uint8_t* __restrict__ p_src1,
+                                                      uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
+                                                      const uint8_t* __restrict__ p_dots,
+                                                      uint32_t n_chunks, uint64_t n_desc, uint64_t src0_len, uint64_t src1_len, uint64_t out_len)
+{
+    constexpr uint32_t K = 256u * TPT;
+    constexpr uint32_t R = 4;                               // rows per wave and round in the bulk pass
+    __shared__ __attribute__((aligned(16))) uint32_t s_map32[2048 + 8];     // 4096 two-byte block->rank entries
+    __shared__ TaskRec s_task[K + 8];
+    __shared__ u32x4 s_patch[K + 8];
+    __shared__ uint32_t s_w[3][4];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint16_t* const s_map = reinterpret_cast<const uint16_t*>(s_map32);
+    const uint64_t dots16 = reinterpret_cast<uint64_t>(p_dots) + 32u;
+
+    uint32_t c = blockIdx.x;
+    if (c >= n_chunks) return;
+    // header and descriptors of the first chunk
+    uint64_t tb = p_chunks[c].task_begin, dn = p_chunks[c].dst_n;
+    uint64_t d[TPT];
+    {
+        const uint32_t n_hdr = uint32_t(dn >> 48);
+        const bool ok = n_hdr <= K && tb <= n_desc && n_hdr <= n_desc - tb;
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) { const uint32_t i = tid * TPT + k; d[k] = (ok && i < n_hdr) ? p_desc[tb + i] : 0ull; }
+    }
+    for (;;) {
+        const uint32_t n_hdr = uint32_t(dn >> 48);
+        const uint64_t dst = dn & ((1ull << 48) - 1);
+        const uint32_t head = uint32_t(dst & 15ull);
+        // a chunk table that points outside the descriptor array is refused, not followed
+        const bool hdr_ok = n_hdr <= K && tb <= n_desc && n_hdr <= n_desc - tb;
+        const uint32_t n = hdr_ok ? n_hdr : 0u;
+        // the next chunk of this workgroup: header now (scalar), descriptors as soon as this chunk's are decoded
+        const uint32_t cn = c + gridDim.x;
+        const bool has_next = cn < n_chunks;
+        uint64_t tb_n = 0, dn_n = 0;
+        if (has_next) { tb_n = p_chunks[cn].task_begin; dn_n = p_chunks[cn].dst_n; }
+
+        // ---- A: decode TPT consecutive descriptors per lane ----
+        uint64_t adj[TPT];
+        uint32_t len[TPT];
+        uint32_t lsum = 0, lnz = 0;
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            adj[k] = dots16;
+            len[k] = 0;
+            const uint32_t i = tid * TPT + k;
+            if (i < n) {
+                const uint64_t dd = d[k];
+                len[k] = uint32_t(dd >> 40) & ((1u << 22) - 1u);
+                const uint32_t space = uint32_t(dd >> 62);
+                const uint64_t src = dd & ((1ull << 40) - 1);
+                if (space == SPACE_IMM) {
+                    if (len[k] > IMM_MAX_BYTES) report(p_status, tb + i, STATUS_SRC_OOB);
+                    else adj[k] = ADJ_IMM | src;
+                } else {
+                    const uint64_t limit = space == SPACE_PROTEOME ? src0_len : (space == SPACE_PAYLOAD ? src1_len : ~0ull);
+                    if (src + len[k] > limit) report(p_status, tb + i, STATUS_SRC_OOB);      // never read out of bounds: task.rs would panic
+                    else if (space != SPACE_FILL) adj[k] = reinterpret_cast<uint64_t>(space == SPACE_PROTEOME ? p_src0 : p_src1) + src;
+                }
+            }
+            lsum += len[k];
+            lnz += len[k] != 0u ? 1u : 0u;
+        }
+        // descriptors of the next chunk (consumed at the top of the next round; they are older than every store below)
+        uint64_t d_n[TPT];
+        {
+            const uint32_t nn = uint32_t(dn_n >> 48);
+            const bool ok = has_next && nn <= K && tb_n <= n_desc && nn <= n_desc - tb_n;
+#pragma unroll
+            for (int k = 0; k < TPT; ++k) { const uint32_t i = tid * TPT + k; d_n[k] = (ok && i < nn) ? p_desc[tb_n + i] : 0ull; }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s_map32[8u * tid + q] = 0u;
+        const uint32_t incl = wave_incl_scan(lsum);
+        const uint32_t nzincl = wave_incl_scan(lnz);
+        if (lane == 63u) { s_w[0][wid] = incl; s_w[1][wid] = nzincl; }
+        lds_barrier();
+
+        // ---- B: compact the non-empty tasks by rank; mark the first block starting inside or after each ----
+        const uint32_t l0 = s_w[0][0], l1 = s_w[0][1], l2 = s_w[0][2], l3 = s_w[0][3];
+        const uint32_t z0 = s_w[1][0], z1 = s_w[1][1], z2 = s_w[1][2], z3 = s_w[1][3];
+        const uint32_t total = l0 + l1 + l2 + l3;
+        const uint32_t nz = z0 + z1 + z2 + z3;
+        uint32_t excl = incl - lsum + (wid > 0 ? l0 : 0u) + (wid > 1 ? l1 : 0u) + (wid > 2 ? l2 : 0u);
+        uint32_t rank = nzincl - lnz + (wid > 0 ? z0 : 0u) + (wid > 1 ? z1 : 0u) + (wid > 2 ? z2 : 0u);
+        const uint32_t nblk = total ? (head + total + 15u) >> 4 : 0u;
+        const bool chunk_ok = hdr_ok && dst + total <= out_len && nblk <= 4096u && total <= DOTS_BYTES - 96u;
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            if (len[k] != 0u) {
+                s_task[rank] = TaskRec{(adj[k] & ADJ_IMM) ? adj[k] : adj[k] - excl, excl + len[k], excl};
+                if (rank >= 1u && chunk_ok) {
+                    const uint32_t kmin = (excl + head + 15u) >> 4;    // first block starting at or after the task start
+                    if (kmin < nblk) atomicAdd(&s_map32[kmin >> 1], 1u << (16u * (kmin & 1u)));
+                }
+                ++rank;
+            }
+            excl += len[k];
+        }
+        if (tid < 4u) s_task[nz + tid] = TaskRec{dots16 - total, total, total};          // sentinels past the last task
+        lds_barrier();
+
+        // ---- C: per-lane 16 two-byte counters -> in-lane prefix sums ----
+        uint32_t y[8], pre[8];
+        uint32_t tsum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            y[q] = s_map32[8u * tid + q] * 0x00010001u;          // low half: first counter, high half: sum of both
+            pre[q] = tsum;
+            tsum += y[q] >> 16;
+        }
+        const uint32_t tincl = wave_incl_scan(tsum);
+        if (lane == 63u) s_w[2][wid] = tincl;
+        lds_barrier();
+
+        // ---- D: add the lanes/waves before; ranks stay below 256*TPT < 65536 ----
+        {
+            const uint32_t m0 = s_w[2][0], m1 = s_w[2][1], m2 = s_w[2][2];
+            const uint32_t mb = tincl - tsum + (wid > 0 ? m0 : 0u) + (wid > 1 ? m1 : 0u) + (wid > 2 ? m2 : 0u);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s_map32[8u * tid + q] = y[q] + (mb + pre[q]) * 0x00010001u;
+        }
+
+        // ---- P: lane = task.  Task t owns the block it starts in when it is the first task to start there (at a
+        //      non-zero offset): it assembles that block from task t-1 (which covers the block's first byte), itself and
+        //      whatever else begins before the block ends, and parks it in s_patch[t]. ----
+        if (chunk_ok) {
+#pragma unroll
+            for (int k = 0; k < TPT; ++k) {
+                const uint32_t t = tid + 256u * uint32_t(k);
+                if (t >= 1u && t < nz) {
+                    const TaskRec tp = s_task[t - 1u], t0 = s_task[t];
+                    const uint32_t s = head + t0.off, blk = s >> 4;
+                    const bool owner = (s & 15u) != 0u && (blk == 0u ? t == 1u : head + tp.off <= (blk << 4));
+                    if (owner) {
+                        const TaskRec t1 = s_task[t + 1u];
+                        const int32_t rel = int32_t(blk << 4) - int32_t(head);
+                        const uint32_t hi = uint32_t(rel + 16) < total ? uint32_t(rel + 16) : total;
+                        const bool need2 = t0.end < hi;
+                        const bool same2 = need2 && t1.adj == tp.adj && !(tp.adj & ADJ_IMM);   // the reference again after an SNV
+                        u32x4 v = fetch_task<false>(tp.adj, rel, int32_t(tp.off) - rel);
+                        const u32x4 g1 = fetch_task<false>(t0.adj, rel, int32_t(t0.off) - rel);
+                        u32x4 g2 = v;
+                        if (need2 && !same2) g2 = fetch_task<false>(t1.adj, rel, int32_t(t1.off) - rel);
+                        v = overwrite_tail(v, g1, uint32_t(int32_t(t0.off) - rel), true);
+                        v = overwrite_tail(v, g2, uint32_t(int32_t(t1.off) - rel), need2);
+                        uint32_t pos = t1.end, r = t + 2u;
+                        while (need2 && pos < hi) {                        // four or more tasks in this block
+                            const TaskRec tx = s_task[r];
+                            const u32x4 h = fetch_task<false>(tx.adj, rel, int32_t(tx.off) - rel);
+                            v = overwrite_tail(v, h, uint32_t(int32_t(tx.off) - rel), true);
+                            pos = tx.end;
+                            ++r;
+                        }
+                        s_patch[t] = v;
+                    }
+                }
+            }
+        }
+        lds_barrier();
+
+        if (!chunk_ok) {                                      // never write out of bounds
+            if (tid == 0) report(p_status, tb, STATUS_RES_OOB);
+        } else if (DBG != 4) {
+            // ---- bulk: wave `wid` takes the 64-block rows wid, wid+4, ...; R of them per round ----
+            uint8_t* const out0 = p_out + (dst - head);
+            const uint32_t nrow = (nblk + 63u) >> 6;
+            for (uint32_t row0 = wid; row0 < nrow; row0 += 4u * R) {
+                u32x4 v[R];
+                uint32_t pidx[R];                                           // patch index | 0x80000000, 0x40000000: immediate primary
+#pragma unroll
+                for (uint32_t j = 0; j < R; ++j) {
+                    const uint32_t b = ((row0 + 4u * j) << 6) + lane;
+                    const bool active = b < nblk;
+                    const int32_t rel = int32_t(b << 4) - int32_t(head);
+                    const uint32_t hi = uint32_t(rel + 16) < total ? uint32_t(rel + 16) : total;
+                    const uint32_t r = active ? uint32_t(s_map[b]) : 0u;
+                    const TaskRec tr = s_task[r];
+                    const bool dirty = active && tr.end < hi;
+                    const bool imm0 = (tr.adj & ADJ_IMM) != 0ull;
+                    pidx[j] = dirty ? (0x80000000u | (r + 1u)) : ((active && imm0) ? (0x40000000u | r) : 0u);
+                    const uint64_t X = (dirty || imm0 || !active) ? dots16 : tr.adj + uint64_t(int64_t(rel));
+                    v[j] = (DBG == 1) ? u32x4{uint32_t(X), r, hi, 0u} : gather16(X);
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < R; ++j) {
+                    const uint32_t b = ((row0 + 4u * j) << 6) + lane;
+                    if (b < nblk) {
+                        const int32_t rel = int32_t(b << 4) - int32_t(head);
+                        u32x4 o = v[j];
+                        if (pidx[j] & 0x80000000u) o = s_patch[pidx[j] & 0xFFFFu];
+                        else if (pidx[j] & 0x40000000u) { const TaskRec tr = s_task[pidx[j] & 0xFFFFu]; o = imm_block(tr.adj & ADJ_LIT, int32_t(tr.off) - rel); }
+                        uint8_t* op = out0 + (uint64_t(b) << 4);
+                        if (DBG == 2) { if (o[0] == 0x12345678u && o[3] == 0x9abcdef0u) op[0] = 1; }
+                        else if (rel >= 0 && uint32_t(rel) + 16u <= total) {
+                            if (NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(op));
+                            else *reinterpret_cast<u32x4*>(op) = o;
+                        } else {
+                            // ragged first/last block of a chunk whose cut is not 16-byte aligned
+                            const uint32_t hi = uint32_t(rel + 16) < total ? uint32_t(rel + 16) : total;
+                            const uint32_t ka = rel < 0 ? uint32_t(-rel) : 0u, kb = uint32_t(int32_t(hi) - rel);
+#pragma unroll
+                            for (uint32_t q = 0; q < 16u; ++q)
+                                if (q >= ka && q < kb) op[q] = uint8_t(o[q >> 2] >> (8u * (q & 3u)));
+                        }
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        c = cn; tb = tb_n; dn = dn_n;
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) d[k] = d_n[k];
+        lds_barrier();                                         // LDS is reused by the next chunk
     }
 }
 
@@ -582,6 +820,18 @@ __global__ __launch_bounds__(256) void copy_bench_kernel(const uint8_t* __restri
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         while (__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(8);
     }
+    uint64_t extra = 0;
+    if (MODE == 8 || MODE == 9) {
+        // the stitch kernel's descriptor traffic: 8 bytes per lane streamed from HBM (read once, never cached), used before the
+        // first store; mode 9 first reads a 16-byte header whose value the descriptor address depends on (two dependent misses)
+        const uint64_t* dsc = reinterpret_cast<const uint64_t*>(out + ((n16 * 16u + 4095u) & ~4095ull));
+        uint64_t off = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+        if (MODE == 9) {
+            const uint64_t* hdr = dsc + ((n16 + 2047u) / 2048u) * 256u + 2u * blockIdx.x;
+            off += (hdr[0] | hdr[1]) & 1u;                                  // header words are zero
+        }
+        extra = dsc[off] & 15u;                                             // descriptor words are zero too
+    }
     u32x4 acc = {0u, 0u, 0u, 0u};
     if (MODE == 6 || MODE == 7) {
         // two aligned loads per block; 6: load -> store per pass, 7: the next pass's loads are issued before this pass's store,
@@ -615,9 +865,9 @@ __global__ __launch_bounds__(256) void copy_bench_kernel(const uint8_t* __restri
     }
 #pragma unroll 1
     for (uint64_t b = b0 + threadIdx.x; b < e; b += 256u) {
-        const uint64_t X = base + ((b - b0) << 4) + shift;
+        const uint64_t X = base + ((b - b0) << 4) + shift + extra;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (MODE == 0) v = gather16(X);
+        if (MODE == 0 || MODE == 8 || MODE == 9) v = gather16(X);
         else if (MODE == 3) v = gather16_dw(X);
         else if (MODE == 2) {
             const uint32_t d = uint32_t(X) & 15u;
@@ -640,6 +890,128 @@ __global__ __launch_bounds__(256) void copy_bench_kernel(const uint8_t* __restri
     if (MODE == 5 && (acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[blockIdx.x] = acc[0];
 }
 
+// copy_prefetch_kernel: persistent workgroups (grid = resident set); span k of a workgroup uses a "descriptor" (8 B per lane,
+// streamed from HBM) that was requested DEPTH spans earlier.  BYTES: descriptor bytes per lane actually loaded (8, 4 or 0).
+template <int DEPTH, int BYTES>
+__global__ __launch_bounds__(256) void copy_prefetch_kernel(const uint8_t* __restrict__ src, uint64_t window, uint32_t shift,
+                                                            uint8_t* __restrict__ out, uint64_t n16)
+{
+    const uint64_t slice = (window / 8u) & ~4095ull;
+    const uint64_t span = 2048u;
+    const uint64_t n_span = (n16 + span - 1) / span;
+    const uint8_t* dsc = out + ((n16 * 16u + 4095u) & ~4095ull);
+    uint64_t ring[DEPTH];
+    auto fetch = [&](uint64_t sp) -> uint64_t {
+        if (sp >= n_span || BYTES == 0) return 0ull;
+        if (BYTES == 8) return reinterpret_cast<const uint64_t*>(dsc)[sp * 256u + threadIdx.x];
+        return uint64_t(reinterpret_cast<const uint32_t*>(dsc)[sp * 256u + threadIdx.x]);
+    };
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) ring[k] = fetch(uint64_t(blockIdx.x) + uint64_t(k) * gridDim.x);
+    for (uint64_t sp = blockIdx.x; sp < n_span; sp += uint64_t(gridDim.x) * DEPTH) {
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) {
+            const uint64_t cur = sp + uint64_t(k) * gridDim.x;
+            if (cur >= n_span) break;
+            const uint64_t extra = ring[k] & 15u;                                  // descriptor words are zero
+            ring[k] = fetch(cur + uint64_t(DEPTH) * gridDim.x);                    // request the descriptor DEPTH spans ahead
+            const uint64_t b0 = cur * span;
+            const uint64_t e = b0 + span < n16 ? b0 + span : n16;
+            const uint64_t base = reinterpret_cast<uint64_t>(src) + 64u + (cur & 7u) * slice + (((cur >> 3) * span * 16u) % (slice - span * 16u - 64u));
+#pragma unroll 1
+            for (uint64_t b = b0 + threadIdx.x; b < e; b += 256u) {
+                const u32x4 v = gather16(base + ((b - b0) << 4) + shift + extra);
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out) + b);
+            }
+        }
+    }
+}
+
+// copy_mix_kernel: non-persistent copy (one workgroup per 32 KiB span) whose workgroups additionally stream "descriptor"
+// bytes from HBM; everything about that read stream is a run-time parameter:
+//   p.x bytes per lane (4, 8, 16)   p.y every p.y-th workgroup reads (1 = all)   p.z bytes between two workgroups' pieces
+//   p.w bit 0: non-temporal loads; bit 1: lanes 0..63 only; bit 2: the read is issued after the first pass's store instead of before
+__global__ __launch_bounds__(256) void copy_mix_kernel(const uint8_t* __restrict__ src, uint64_t window, uint32_t shift,
+                                                       uint8_t* __restrict__ out, uint64_t n16, const uint8_t* __restrict__ dsc, uint4 p)
+{
+    const uint64_t slice = (window / 8u) & ~4095ull;
+    const uint64_t span = 2048u;
+    uint64_t sp = blockIdx.x;
+    if (p.w & 8u) {
+        // the stitch kernel's XCD-aware order: workgroup 8j + x takes the j-th span of "proteome slice" x; a "haplotype" is
+        // 240 spans (7.5 MiB), a slice 30 of them
+        const uint64_t x = sp & 7u, j = sp >> 3;
+        const uint64_t perm = (j / 30u) * 240u + x * 30u + (j % 30u);
+        if (perm < (n16 + span - 1) / span && ((n16 + span - 1) / span) % 240u == 0u) sp = perm;
+    }
+    const uint64_t b0 = sp * span;
+    const uint64_t e = b0 + span < n16 ? b0 + span : n16;
+    const uint64_t base = reinterpret_cast<uint64_t>(src) + 64u + (blockIdx.x & 7u) * slice
+                        + ((uint64_t(blockIdx.x >> 3) * span * 16u) % (slice - span * 16u - 64u));
+    uint64_t extra = 0;
+    const bool reader = p.x != 0u && (blockIdx.x % p.y) == 0u && (!(p.w & 2u) || threadIdx.x < 64u);
+    auto rd = [&]() {
+        const uint8_t* q = dsc + uint64_t(blockIdx.x / p.y) * (p.z & 0xFFFFu) + uint64_t(threadIdx.x) * p.x;
+        uint32_t x;
+        if (p.x == 4u) x = (p.w & 1u) ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(q)) : *reinterpret_cast<const uint32_t*>(q);
+        else if (p.x == 8u) { const uint64_t y = (p.w & 1u) ? __builtin_nontemporal_load(reinterpret_cast<const uint64_t*>(q)) : *reinterpret_cast<const uint64_t*>(q); x = uint32_t(y) | uint32_t(y >> 32); }
+        else { const u32x4 y = (p.w & 1u) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(q)) : *reinterpret_cast<const u32x4*>(q); x = y[0] | y[1] | y[2] | y[3]; }
+        return uint64_t(x & 15u);
+    };
+    if (reader && !(p.w & 4u)) extra = rd();
+    bool first = true;
+    // ballast that stands for the stitch kernel's bookkeeping: p.w bits 8..15 = VALU instructions (x8) per pass and wave,
+    // bits 16..23 = LDS round trips per pass, bits 24..27 = workgroup barriers before the first pass
+    const uint32_t n_valu = ((p.w >> 8) & 0xFFu), n_lds = (p.w >> 16) & 0xFFu, n_bar = (p.w >> 24) & 0xFu;
+    __shared__ uint32_t s_ballast[1024];
+    s_ballast[threadIdx.x] = threadIdx.x; s_ballast[threadIdx.x + 256u] = threadIdx.x + 1u;
+    s_ballast[threadIdx.x + 512u] = threadIdx.x + 2u; s_ballast[threadIdx.x + 768u] = threadIdx.x + 3u;
+    for (uint32_t k = 0; k < n_bar; ++k) __syncthreads();
+    uint32_t acc = threadIdx.x;
+#pragma unroll 1
+    for (uint64_t b = b0 + threadIdx.x; b < e; b += 256u) {
+#pragma unroll 1
+        for (uint32_t k = 0; k < n_lds; ++k) acc = s_ballast[acc & 1023u] + uint32_t(b);          // dependent LDS reads
+#pragma unroll 1
+        for (uint32_t k = 0; k < n_valu; ++k) {
+            acc = acc * 3u + 1u; acc ^= acc >> 3; acc += uint32_t(b); acc = (acc << 1) | (acc >> 31);
+            acc ^= 0x9E3779B9u; acc += acc >> 5; acc ^= acc << 7; acc += 11u;
+        }
+        u32x4 v = gather16(base + ((b - b0) << 4) + shift + extra + (acc == 0xFFFFFFFFu ? 1u : 0u));
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out) + b);
+        if (first && reader && (p.w & 4u)) extra = rd();
+        first = false;
+    }
+}
+
+hipError_t launch_copy_mix(const uint8_t* src, uint64_t window, uint32_t shift, uint8_t* out, uint64_t bytes, const uint8_t* dsc,
+                           uint32_t bytes_per_lane, uint32_t every, uint32_t stride, uint32_t flags, hipStream_t stream)
+{
+    const uint64_t n16 = bytes / 16;
+    if (n16 == 0 || window < (1u << 20) || every == 0) return hipErrorInvalidValue;
+    const uint32_t grid = uint32_t((n16 + 2047) / 2048);
+    const uint32_t lds_pad = (flags >> 8) * 1024u;                   // flags bits 8..: KiB of (unused) dynamic LDS per workgroup, to cap the workgroups per CU
+    // stride bits 16..: ballast (VALU x8 per pass: 8 bits, LDS round trips per pass: 8 bits, barriers: 4 bits)
+    hipLaunchKernelGGL(copy_mix_kernel, dim3(grid), dim3(256), lds_pad, stream, src, window, shift, out, n16, dsc, make_uint4(bytes_per_lane, every, stride, (flags & 0xFFu) | (stride >> 16 << 8)));
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_prefetch(const uint8_t* src, uint64_t window, uint32_t shift, uint8_t* out, uint64_t bytes, int depth, int desc_bytes,
+                                uint32_t grid, hipStream_t stream)
+{
+    const uint64_t n16 = bytes / 16;
+    if (n16 == 0 || window < (1u << 20)) return hipErrorInvalidValue;
+#define V2P_CP(D, B) hipLaunchKernelGGL((copy_prefetch_kernel<D, B>), dim3(grid), dim3(256), 0, stream, src, window, shift, out, n16)
+    if (desc_bytes == 0) V2P_CP(1, 0);
+    else if (desc_bytes == 4) { if (depth <= 1) V2P_CP(1, 4); else V2P_CP(4, 4); }
+    else if (depth <= 1) V2P_CP(1, 8);
+    else if (depth == 2) V2P_CP(2, 8);
+    else if (depth <= 4) V2P_CP(4, 8);
+    else V2P_CP(8, 8);
+#undef V2P_CP
+    return hipGetLastError();
+}
+
 hipError_t launch_copy_bench(const uint8_t* src, uint64_t window, uint32_t shift, uint8_t* out, uint64_t bytes, int mode,
                              uint32_t* sink, hipStream_t stream)
 {
@@ -655,7 +1027,9 @@ hipError_t launch_copy_bench(const uint8_t* src, uint64_t window, uint32_t shift
         case 4: V2P_CB(4); break;
         case 5: V2P_CB(5); break;
         case 6: V2P_CB(6); break;
-        default: V2P_CB(7); break;
+        case 7: V2P_CB(7); break;
+        case 8: V2P_CB(8); break;
+        default: V2P_CB(9); break;
     }
 #undef V2P_CB
     return hipGetLastError();
@@ -695,6 +1069,31 @@ static const uint8_t* device_dots(hipError_t* err)
     return bufs[dev];
 }
 
+// Grid of a persistent kernel: every workgroup resident at once (what the occupancy calculator says fits, 8 per CU at
+// most), a multiple of 8 so that chunk c and chunk c + grid run on the same XCD (the chunk table is dealt to XCDs by
+// proteome slice, entry 8j + x to XCD x).
+static uint32_t persistent_grid(const void* kernel, uint32_t n_chunks, uint32_t per_cu, uint32_t max_blocks)
+{
+    static std::mutex mu;
+    static const void* seen[32]; static int occ_of[32]; static int n_seen = 0; static int cus = 0;
+    int occ = 0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+        for (int i = 0; i < n_seen; ++i) if (seen[i] == kernel) occ = occ_of[i];
+        if (!occ) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ <= 0) occ = 4;
+            if (occ > 8) occ = 8;
+            if (n_seen < 32) { seen[n_seen] = kernel; occ_of[n_seen++] = occ; }
+        }
+    }
+    if (per_cu && int(per_cu) < occ) occ = int(per_cu);
+    uint32_t want = uint32_t(cus) * uint32_t(occ);
+    if (max_blocks && max_blocks < want) want = max_blocks;
+    if (want >= 8u) want &= ~7u;
+    return n_chunks < want ? n_chunks : want;
+}
+
 hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemporal, uint32_t max_blocks)
 {
     if (args.n_chunks == 0) return hipSuccess;
@@ -715,17 +1114,36 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
 #define V2P_LAUNCH_V(TT, VV) do { \
         if (dbg == 1) V2P_L(TT, true, VV, 1); \
         else if (dbg == 2) V2P_L(TT, true, VV, 2); \
+        else if (dbg == 3) V2P_L(TT, true, VV, 3); \
+        else if (dbg == 4) V2P_L(TT, true, VV, 4); \
         else if (dbg == 20) V2P_L(TT, true, VV, 20); \
         else V2P_L(TT, true, VV, 0); } while (0)
 #define V2P_LAUNCH(TT) do { \
         if (!nt) V2P_L(TT, false, 0, 0); \
         else if (var == 1) V2P_LAUNCH_V(TT, 1); \
         else V2P_LAUNCH_V(TT, 0); } while (0)
+    // persistent latency-organised kernel for long-run images (<= 512 descriptors per chunk); variant 2 and 1 force the per-block kernel
+#define V2P_L3(TT, NTT, DD) do { \
+        const uint32_t grid3 = persistent_grid(reinterpret_cast<const void*>(&stitch3_kernel<TT, NTT, DD>), a.n_chunks, per_cu, max_blocks); \
+        hipLaunchKernelGGL((stitch3_kernel<TT, NTT, DD>), dim3(grid3), dim3(256), 0, stream, V2P_KARGS); } while (0)
+#define V2P_LAUNCH3(TT) do { \
+        if (!nt) V2P_L3(TT, false, 0); \
+        else if (dbg == 1) V2P_L3(TT, true, 1); \
+        else if (dbg == 2) V2P_L3(TT, true, 2); \
+        else if (dbg == 4) V2P_L3(TT, true, 4); \
+        else V2P_L3(TT, true, 0); } while (0)
+    if (tpt <= 2 && var != 1 && var != 2 && dbg != 20 && dbg != 3) {
+        const uint32_t per_cu = (nontemporal >> 24) & 0x3F;    // bits 24..29: resident workgroups per CU (0 = what fits)
+        if (tpt == 1) V2P_LAUNCH3(1); else V2P_LAUNCH3(2);
+        return hipGetLastError();
+    }
     switch (tpt) {
         case 1: V2P_LAUNCH(1); break;
         case 2: V2P_LAUNCH(2); break;
         default: V2P_LAUNCH(4); break;
     }
+#undef V2P_LAUNCH3
+#undef V2P_L3
 #undef V2P_LAUNCH
 #undef V2P_LAUNCH_V
 #undef V2P_L
