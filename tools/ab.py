@@ -91,6 +91,21 @@ def main():
         pack = {k: int(kv[k]) for k in ("chunk_tasks", "chunk_bytes", "cut_align", "soft_window") if k in kv}
         img = cohort.pack(0, cohort.n_haplotypes, n_threads=min(64, os.cpu_count() or 1), fasta=bool(int(kv.get("fasta", 0))), inline_payload=bool(int(kv.get("imm", 1))), **pack)
         chunks = np.ascontiguousarray(img.chunks)
+        rep = int(kv.get("rep", 0))
+        if rep:
+            # experiment: the first `rep` haplotypes' image replicated over the whole arena -- every copy reads the SAME descriptors
+            # (cache-resident), so the HBM descriptor stream disappears while everything else stays
+            hb = img.hap_out_begin
+            nbytes = int(hb[rep])
+            sel = (chunks[:, 1] & np.uint64((1 << 48) - 1)) < np.uint64(nbytes)
+            base = chunks[sel]
+            n_desc_rep = int(base[:, 0].max()) + 256
+            copies = int(img.out_bytes // ((nbytes + 15) // 16 * 16))
+            stride = (nbytes + 15) // 16 * 16
+            allc = np.concatenate([np.stack([base[:, 0], base[:, 1] + np.uint64(k * stride)], axis=1) for k in range(copies)])
+            chunks = np.ascontiguousarray(allc)
+            img.desc = img.desc[:n_desc_rep].copy()
+            print(f"rep={rep}: {copies} copies of {base.shape[0]} chunks, {n_desc_rep * 8 / 1e6:.2f} MB of descriptors")
         if int(kv.get("l1", 0)):
             chunks = l1_order(chunks, img.desc, n_prot, int(kv["l1"]))
         elif int(kv.get("xcd", 1)):

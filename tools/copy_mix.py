@@ -37,12 +37,20 @@ def run(bpl, every, stride, flags, label):
         if r:
             ms.append(e0.elapsed_time(e1))
     med = statistics.median(ms)
-    read_mb = (n_span // every) * (64 if flags & 2 else 256) * bpl / 1e6 if bpl else 0
+    lanes = (every >> 16) or (64 if flags & 2 else 256)
+    read_mb = (n_span // (every & 0xFFFF)) * lanes * bpl / 1e6 if bpl else 0
     rows.append({"label": label, "bytes_per_lane": bpl, "every": every, "stride": stride, "flags": flags, "ms": med, "TBps_written": nbytes / med / 1e9, "read_MB": read_mb})
     print(f"{label:58s} read {read_mb:7.1f} MB  {med:7.3f} ms  {nbytes / med / 1e9:5.2f} TB/s")
 
 
 run(0, 1, 0, 0, "no descriptor stream")
+for L in (64, 72, 80, 88, 96, 104, 112, 128):
+    run(16, 1 | (L << 16), 16 * L, 16, f"16 B x {L} lanes per workgroup ({16 * L} B = {100 * 16 * L / 32768:.1f} %), 8 gathers then 8 stores")
+run(0, 1, 0, 16, "no descriptor stream, 8 gathers then 8 stores per wave")
+run(4, 1, 1024, 16, "4 B/lane, 8 gathers then 8 stores per wave")
+run(8, 1, 2048, 16, "8 B/lane, 8 gathers then 8 stores per wave")
+run(8, 1, 2048, 16 | 8, "8 B/lane, 8 gathers then 8 stores, XCD-permuted spans")
+run(8, 1, 2048, 16 | (40 << 8), "8 B/lane, 8 gathers then 8 stores, 4 workgroups per CU")
 run(0, 1, 0, 8, "no descriptor stream, XCD-permuted span order")
 run(4, 1, 1024, 8, "4 B/lane, XCD-permuted span order")
 run(8, 1, 2048, 8, "8 B/lane, XCD-permuted span order")

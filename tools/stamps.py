@@ -30,6 +30,24 @@ for flags in (1 | (var << 12), 1 | (var << 12) | (20 << 16)):
 torch.cuda.synchronize()
 off = (img.out_bytes + 255) // 256 * 256
 st = d_out[off:off + dbg_bytes].cpu().numpy().view(np.uint64).reshape(nch, 4, 8).astype(np.int64)
+if var == 0 and img.tasks_per_lane <= 2:          # persistent kernel (stitch4): its own stamp layout
+    q = [st[:, :, k] for k in range(7)]
+    ok = (q[6] > q[0]).all(axis=1)
+    print("chunks stamped:", int(ok.sum()), "of", nch)
+    def show4(name, x):
+        x = x[ok].reshape(-1)
+        print(f"{name:44s} median {np.median(x):9.0f}  mean {x.mean():9.0f}  p90 {np.percentile(x, 90):9.0f} cycles")
+    show4("round start -> A done, scans issued", q[1] - q[0])
+    show4("barrier + B + barrier + C/D", q[2] - q[1])
+    show4("P (merge pass)", q[3] - q[2])
+    show4("barrier after P", q[4] - q[3])
+    show4("bulk: first look-up -> last store issued", q[5] - q[4])
+    show4("  of which look-ups + gather issue", st[:, :, 7] >> 32)
+    show4("  of which gathers / patches arriving", st[:, :, 7] & 0xFFFFFFFF)
+    show4("  of which store issue", (q[5] - q[4]) - (st[:, :, 7] >> 32) - (st[:, :, 7] & 0xFFFFFFFF))
+    show4("last store issued -> stores acked", q[6] - q[5])
+    show4("whole round", q[6] - q[0])
+    sys.exit(0)
 t0, t1, t2, t3, t4 = (st[:, :, k] for k in range(5))
 ok = (t4 > t0).all(axis=1)
 print("chunks stamped:", int(ok.sum()), "of", nch)

@@ -422,240 +422,360 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------
-// stitch3_kernel: the same contract as stitch_kernel, organised around latency instead of per-block work.
-// Measured on MI355X (profiles/r02_*): the per-block kernel is bound by neither HBM, the address path nor instruction
-// count -- a workgroup's life is one serial chain (chunk header -> descriptors -> four barriers -> eight times
-// [LDS look-ups -> gather -> merge -> store]) and eight workgroups per CU do not cover it.  Here
-//   * workgroups are persistent: while a chunk is processed, the next chunk's header (scalar) and descriptors (one per
-//     lane) are already on their way;
-//   * blocks cut by a task boundary are assembled ONCE PER TASK in a compacted pass P (lane = task, every lane does
-//     merge work) and parked in an LDS patch table indexed by the first task that starts inside the block;
-//   * the bulk pass B is lean: per 16-byte block one look-up of the covering task, one byte-granular gather of the
-//     primary stream (or the patch), one aligned non-temporal store -- and a wave takes FOUR 1 KiB rows per round, all
-//     look-ups first, four gathers in flight, then four stores.
-// Chunks of up to 256*TPT descriptors, TPT in {1, 2}; dense images (TPT 4) stay on stitch_kernel.
+// stitch4_kernel: the same contract as stitch_kernel, built around what limits it on MI355X (DESIGN.md section 4,
+// profiles/r02_*): gfx950 counts loads and stores in ONE in-order counter (vmcnt), and under a saturated write stream a
+// store is acknowledged thousands of cycles after it was issued -- so a load issued after a store waits for that store.
+// The per-block kernel alternates gather and store per 1 KiB row and parks its waves ~90 % of the time.  Here
+//   * EVERY load of a workgroup precedes its first store: descriptors, the gathers of the merge pass, then up to eight 1 KiB
+//     rows of gathers per wave held in registers (4 VGPRs a row), and only then the stores, back to back;
+//   * that is affordable because the bulk pass is lean: blocks cut by a task boundary are assembled once per TASK in a
+//     compacted pass P (lane = task, every lane does merge work, byte masks from a 17-entry LDS table) and parked in an LDS
+//     patch table; the bulk pass needs per 16-byte block one map read, one 16-byte task record, one byte-granular gather
+//     of the covering task's stream (or the patch) -- about 13 VALU instructions per KiB row (the per-block kernel: ~100;
+//     a SIMD issues one wave instruction in about four cycles, which makes ~100 per KiB the budget of a CU at the HBM
+//     store ceiling, profiles/r02_copy_mix_ballast.json);
+//   * set-up: ranks by ballot + mbcnt, one DPP scan, block map by packed 16-bit adds.
+// Chunks of up to 256*TPT descriptors, TPT in {1, 2}, best with <= 32 KiB of result (2048 blocks = one round of eight rows per
+// wave); larger chunks take a second round whose gathers wait for the first round's stores.  Dense images (TPT 4) stay on
+// stitch_kernel.
 // ---------------------------------------------------------------------------
-struct __attribute__((aligned(16))) TaskRec { uint64_t adj; uint32_t end; uint32_t off; };   // source address minus result offset (or
-                                                                                              // ADJ_IMM | literal), result range [off, end)
-template <int TPT, bool NT, int DBG = 0>
-__global__ __launch_bounds__(256, 8) void stitch3_kernel(const uint64_t* __restrict__ p_desc, const Chunk* __restrict__ p_chunks,
+struct __attribute__((aligned(16))) TaskRec {
+    // Everything is kept in BLOCK SPACE: position p = (chunk's result offset & 15) + offset inside the chunk, so that 16-byte result
+    // block b covers positions [16b, 16b + 16) and no signed arithmetic is needed.
+    uint32_t adj_lo, adj_hi;   // source address minus the task's start position (immediate tasks: a readable dummy, their bytes sit in s_lit[rank])
+    uint32_t end, off;         // positions [off & REC_OFF, end); REC_IMM in `off` marks an immediate task
+};
+constexpr uint32_t REC_IMM = 0x80000000u, REC_OFF = 0x7FFFFFFFu;
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint64_t rec_adj(const TaskRec& t) { return (uint64_t(t.adj_hi) << 32) | t.adj_lo; }
+
+// bytes >= ja of v come from ld; mask = s_mask[ja] (ja = 16: nothing)
+__device__ __forceinline__ u32x4 merge_tail(u32x4 v, u32x4 ld, u32x4 m)
+{
+    v[0] = (ld[0] & m[0]) | (v[0] & ~m[0]);
+    v[1] = (ld[1] & m[1]) | (v[1] & ~m[1]);
+    v[2] = (ld[2] & m[2]) | (v[2] & ~m[2]);
+    v[3] = (ld[3] & m[3]) | (v[3] & ~m[3]);
+    return v;
+}
+
+// 16 bytes of task `t` (rank r) for the block at position b16 (bytes before the task's start / after its end are whatever lies there)
+__device__ __forceinline__ u32x4 rec_fetch(const TaskRec& t, const uint64_t* s_lit, uint32_t r, uint32_t b16)
+{
+    if (t.off & REC_IMM) return imm_block(s_lit[r], int32_t((t.off & REC_OFF) - b16));
+    return gather16(rec_adj(t) + b16);
+}
+
+// The block at position b16 whose first byte lies in task r: that task's stream, overwritten from their start on by every task
+// that begins before the block (or the chunk) ends.  The first three sources are fetched together; more take a loop.
+__device__ __forceinline__ u32x4 assemble_block(const TaskRec* s_rec, const uint64_t* s_lit, const u32x4* s_mask, uint32_t r, uint32_t b16, uint32_t ptotal)
+{
+    const uint32_t hi = b16 + 16u < ptotal ? b16 + 16u : ptotal;
+    const TaskRec t0 = s_rec[r], t1 = s_rec[r + 1u], t2 = s_rec[r + 2u];
+    const bool need1 = t0.end < hi, need2 = need1 && t1.end < hi;
+    u32x4 v = rec_fetch(t0, s_lit, r, b16), g1 = v, g2 = v;
+    if (need1) g1 = rec_fetch(t1, s_lit, r + 1u, b16);
+    if (need2) g2 = rec_fetch(t2, s_lit, r + 2u, b16);
+    v = merge_tail(v, g1, s_mask[need1 ? (t1.off & REC_OFF) - b16 : 16u]);
+    v = merge_tail(v, g2, s_mask[need2 ? (t2.off & REC_OFF) - b16 : 16u]);
+    if (need2 && t2.end < hi) {                               // four or more tasks in this block
+        r += 2u;
+        TaskRec t = t2;
+        while (t.end < hi) {
+            t = s_rec[++r];
+            const u32x4 g = rec_fetch(t, s_lit, r, b16);
+            v = merge_tail(v, g, s_mask[(t.off & REC_OFF) - b16]);
+        }
+    }
+    return v;
+}
+
+// assemble_block in two halves, so that the gathers of many blocks are in flight together: `issue` starts the fetches of
+// the first three sources, `finish` merges them (and loops over a fourth and later source).
+struct BlockFetch { u32x4 v, g1, g2; uint32_t ja1, ja2, next; };   // ja: position inside the block where source 1 / 2 starts (16: unused); next: rank to go on with (0: done)
+__device__ __forceinline__ BlockFetch block_issue(const TaskRec* s_rec, const uint64_t* s_lit, uint32_t r, uint32_t b16, uint32_t ptotal)
+{
+    const uint32_t hi = b16 + 16u < ptotal ? b16 + 16u : ptotal;
+    const TaskRec t0 = s_rec[r], t1 = s_rec[r + 1u], t2 = s_rec[r + 2u];
+    const bool need1 = t0.end < hi, need2 = need1 && t1.end < hi;
+    BlockFetch f;
+    f.v = rec_fetch(t0, s_lit, r, b16); f.g1 = f.v; f.g2 = f.v;
+    if (need1) f.g1 = rec_fetch(t1, s_lit, r + 1u, b16);
+    if (need2) f.g2 = rec_fetch(t2, s_lit, r + 2u, b16);
+    f.ja1 = need1 ? (t1.off & REC_OFF) - b16 : 16u;
+    f.ja2 = need2 ? (t2.off & REC_OFF) - b16 : 16u;
+    f.next = (need2 && t2.end < hi) ? r + 2u : 0u;
+    return f;
+}
+__device__ __forceinline__ u32x4 block_finish(const BlockFetch& f, const TaskRec* s_rec, const uint64_t* s_lit, const u32x4* s_mask, uint32_t b16, uint32_t ptotal)
+{
+    u32x4 v = merge_tail(f.v, f.g1, s_mask[f.ja1]);
+    v = merge_tail(v, f.g2, s_mask[f.ja2]);
+    if (f.next) {                                             // four or more tasks in this block
+        const uint32_t hi = b16 + 16u < ptotal ? b16 + 16u : ptotal;
+        uint32_t r = f.next;
+        TaskRec t = s_rec[r];
+        while (t.end < hi) {
+            t = s_rec[++r];
+            const u32x4 g = rec_fetch(t, s_lit, r, b16);
+            v = merge_tail(v, g, s_mask[(t.off & REC_OFF) - b16]);
+        }
+    }
+    return v;
+}
+
+// An edge block of a chunk whose cut is not 16-byte aligned: only the chunk's own bytes [head, ptotal) are written.
+__device__ __forceinline__ void ragged_block(const TaskRec* s_rec, const uint64_t* s_lit, const u32x4* s_mask, uint32_t r, uint32_t b16, uint32_t head,
+                                             uint32_t ptotal, uint8_t* op)
+{
+    const u32x4 o = assemble_block(s_rec, s_lit, s_mask, r, b16, ptotal);
+    const uint32_t ka = b16 < head ? head - b16 : 0u, kb = (b16 + 16u < ptotal ? b16 + 16u : ptotal) - b16;
+    for (uint32_t q = ka; q < kb; ++q) op[q] = uint8_t(o[q >> 2] >> (8u * (q & 3u)));
+}
+
+template <int TPT, bool NT, int DBG = 0, int ROWS = 8>
+__global__ __launch_bounds__(256) void stitch4_kernel(const uint64_t* __restrict__ p_desc, const Chunk* __restrict__ p_chunks,
                                                       const uint8_t* __restrict__ p_src0, const uint8_t* __restrict__ p_src1,
                                                       uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
                                                       const uint8_t* __restrict__ p_dots,
                                                       uint32_t n_chunks, uint64_t n_desc, uint64_t src0_len, uint64_t src1_len, uint64_t out_len)
 {
     constexpr uint32_t K = 256u * TPT;
-    constexpr uint32_t R = 4;                               // rows per wave and round in the bulk pass
+    constexpr uint32_t R = ROWS;                            // rows per wave and pass in the bulk phase: 8 x 4 waves x 1 KiB = 32 KiB
     __shared__ __attribute__((aligned(16))) uint32_t s_map32[2048 + 8];     // 4096 two-byte block->rank entries
-    __shared__ TaskRec s_task[K + 8];
+    __shared__ TaskRec s_rec[K + 8];
     __shared__ u32x4 s_patch[K + 8];
-    __shared__ uint32_t s_w[3][4];
+    __shared__ uint64_t s_lit[K + 8];                                        // bytes of immediate tasks, by rank
+    __shared__ u32x4 s_mask[17];
+    __shared__ __attribute__((aligned(16))) uint32_t s_wt[TPT][4];           // per wave and round: bytes (low 20 bits) | non-empty tasks
+    __shared__ __attribute__((aligned(16))) uint32_t s_w[2][4];              // [0] block-map counts per wave, [1][0] bad-descriptor flag
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint16_t* const s_map = reinterpret_cast<const uint16_t*>(s_map32);
     const uint64_t dots16 = reinterpret_cast<uint64_t>(p_dots) + 32u;
 
-    uint32_t c = blockIdx.x;
-    if (c >= n_chunks) return;
-    // header and descriptors of the first chunk
-    uint64_t tb = p_chunks[c].task_begin, dn = p_chunks[c].dst_n;
-    uint64_t d[TPT];
-    {
-        const uint32_t n_hdr = uint32_t(dn >> 48);
-        const bool ok = n_hdr <= K && tb <= n_desc && n_hdr <= n_desc - tb;
-#pragma unroll
-        for (int k = 0; k < TPT; ++k) { const uint32_t i = tid * TPT + k; d[k] = (ok && i < n_hdr) ? p_desc[tb + i] : 0ull; }
-    }
-    for (;;) {
+    {                                                                       // one chunk per workgroup: a fresh wave has no store in flight
+        const uint32_t c = blockIdx.x;
+        if (c >= n_chunks) return;
+        unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q7 = 0, q8 = 0;
+        if (DBG == 20) q0 = __builtin_amdgcn_s_memtime();
+        const uint64_t tb = p_chunks[c].task_begin, dn = p_chunks[c].dst_n;
         const uint32_t n_hdr = uint32_t(dn >> 48);
         const uint64_t dst = dn & ((1ull << 48) - 1);
-        const uint32_t head = uint32_t(dst & 15ull);
+        const uint32_t head = uint32_t(dst) & 15u;
         // a chunk table that points outside the descriptor array is refused, not followed
         const bool hdr_ok = n_hdr <= K && tb <= n_desc && n_hdr <= n_desc - tb;
         const uint32_t n = hdr_ok ? n_hdr : 0u;
-        // the next chunk of this workgroup: header now (scalar), descriptors as soon as this chunk's are decoded
-        const uint32_t cn = c + gridDim.x;
-        const bool has_next = cn < n_chunks;
-        uint64_t tb_n = 0, dn_n = 0;
-        if (has_next) { tb_n = p_chunks[cn].task_begin; dn_n = p_chunks[cn].dst_n; }
+        uint64_t d[TPT];
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) { const uint32_t i = tid + 256u * uint32_t(k); d[k] = i < n ? p_desc[tb + i] : 0ull; }
+        if (tid < 17u) {                                        // s_mask[j]: bytes >= j of a block
+            u32x4 m;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) m[k] = tid <= 4u * k ? 0xFFFFFFFFu : (tid >= 4u * k + 4u ? 0u : 0xFFFFFFFFu << (8u * (tid - 4u * k)));
+            s_mask[tid] = m;
+        }
+        if (tid == 0u) s_w[1][0] = 0u;
+        {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            reinterpret_cast<u32x4*>(s_map32)[2u * tid] = z;
+            reinterpret_cast<u32x4*>(s_map32)[2u * tid + 1u] = z;
+        }
+        lds_barrier();                                          // (the bad flag is cleared before anybody can raise it)
 
-        // ---- A: decode TPT consecutive descriptors per lane ----
-        uint64_t adj[TPT];
-        uint32_t len[TPT];
-        uint32_t lsum = 0, lnz = 0;
+        // ---- A: lane `tid` decodes descriptors tid, tid + 256, ... (so ranks follow lane order within each round) ----
+        uint32_t adj_lo[TPT], adj_hi[TPT], len[TPT];
+        uint64_t lit[TPT];
+        bool imm[TPT];
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
-            adj[k] = dots16;
-            len[k] = 0;
-            const uint32_t i = tid * TPT + k;
-            if (i < n) {
-                const uint64_t dd = d[k];
-                len[k] = uint32_t(dd >> 40) & ((1u << 22) - 1u);
-                const uint32_t space = uint32_t(dd >> 62);
-                const uint64_t src = dd & ((1ull << 40) - 1);
-                if (space == SPACE_IMM) {
-                    if (len[k] > IMM_MAX_BYTES) report(p_status, tb + i, STATUS_SRC_OOB);
-                    else adj[k] = ADJ_IMM | src;
-                } else {
-                    const uint64_t limit = space == SPACE_PROTEOME ? src0_len : (space == SPACE_PAYLOAD ? src1_len : ~0ull);
-                    if (src + len[k] > limit) report(p_status, tb + i, STATUS_SRC_OOB);      // never read out of bounds: task.rs would panic
-                    else if (space != SPACE_FILL) adj[k] = reinterpret_cast<uint64_t>(space == SPACE_PROTEOME ? p_src0 : p_src1) + src;
-                }
+            const uint32_t i = tid + 256u * uint32_t(k);
+            const uint32_t dlo = uint32_t(d[k]), dhi = uint32_t(d[k] >> 32);
+            len[k] = i < n ? (dhi >> 8) & 0x3FFFFFu : 0u;
+            const uint32_t space = dhi >> 30;
+            const uint64_t src = (uint64_t(dhi & 0xFFu) << 32) | dlo;
+            uint64_t a = dots16;
+            bool bad = len[k] > CHUNK_BYTES;
+            imm[k] = space == SPACE_IMM;
+            lit[k] = src;
+            if (space == SPACE_IMM) {
+                bad = bad || len[k] > IMM_MAX_BYTES;
+            } else if (space != SPACE_FILL) {
+                const uint64_t limit = space == SPACE_PROTEOME ? src0_len : src1_len;
+                bad = bad || src + len[k] > limit;                          // never read out of bounds: task.rs would panic
+                a = reinterpret_cast<uint64_t>(space == SPACE_PROTEOME ? p_src0 : p_src1) + src;
             }
-            lsum += len[k];
-            lnz += len[k] != 0u ? 1u : 0u;
+            if (bad && len[k] != 0u) {                                      // reported, and the chunk is not executed
+                report(p_status, tb + i, STATUS_SRC_OOB);
+                atomicOr(&s_w[1][0], 1u);
+                len[k] = 0u;
+            }
+            adj_lo[k] = uint32_t(a); adj_hi[k] = uint32_t(a >> 32);
         }
-        // descriptors of the next chunk (consumed at the top of the next round; they are older than every store below)
-        uint64_t d_n[TPT];
-        {
-            const uint32_t nn = uint32_t(dn_n >> 48);
-            const bool ok = has_next && nn <= K && tb_n <= n_desc && nn <= n_desc - tb_n;
+        // result offsets: one DPP scan of the lengths; ranks among the non-empty tasks: ballot + mbcnt.  With TPT > 1 the tasks
+        // of round k all precede those of round k + 1, so the rounds are scanned one after the other.
+        uint32_t incl[TPT], rk[TPT];
 #pragma unroll
-            for (int k = 0; k < TPT; ++k) { const uint32_t i = tid * TPT + k; d_n[k] = (ok && i < nn) ? p_desc[tb_n + i] : 0ull; }
+        for (int k = 0; k < TPT; ++k) {
+            incl[k] = wave_incl_scan(len[k]);
+            const unsigned long long nzb = __ballot(len[k] != 0u);
+            rk[k] = __builtin_amdgcn_mbcnt_hi(uint32_t(nzb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(nzb), 0u));
+            if (lane == 63u) s_wt[k][wid] = incl[k] + (uint32_t(__popcll(nzb)) << 20);
         }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s_map32[8u * tid + q] = 0u;
-        const uint32_t incl = wave_incl_scan(lsum);
-        const uint32_t nzincl = wave_incl_scan(lnz);
-        if (lane == 63u) { s_w[0][wid] = incl; s_w[1][wid] = nzincl; }
+        if (DBG == 20) q1 = __builtin_amdgcn_s_memtime();
         lds_barrier();
 
         // ---- B: compact the non-empty tasks by rank; mark the first block starting inside or after each ----
-        const uint32_t l0 = s_w[0][0], l1 = s_w[0][1], l2 = s_w[0][2], l3 = s_w[0][3];
-        const uint32_t z0 = s_w[1][0], z1 = s_w[1][1], z2 = s_w[1][2], z3 = s_w[1][3];
-        const uint32_t total = l0 + l1 + l2 + l3;
-        const uint32_t nz = z0 + z1 + z2 + z3;
-        uint32_t excl = incl - lsum + (wid > 0 ? l0 : 0u) + (wid > 1 ? l1 : 0u) + (wid > 2 ? l2 : 0u);
-        uint32_t rank = nzincl - lnz + (wid > 0 ? z0 : 0u) + (wid > 1 ? z1 : 0u) + (wid > 2 ? z2 : 0u);
-        const uint32_t nblk = total ? (head + total + 15u) >> 4 : 0u;
-        const bool chunk_ok = hdr_ok && dst + total <= out_len && nblk <= 4096u && total <= DOTS_BYTES - 96u;
+        const bool chunk_bad = s_w[1][0] != 0u;
+        uint32_t total_pk = 0u;                                             // packed totals of the chunk
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
-            if (len[k] != 0u) {
-                s_task[rank] = TaskRec{(adj[k] & ADJ_IMM) ? adj[k] : adj[k] - excl, excl + len[k], excl};
-                if (rank >= 1u && chunk_ok) {
-                    const uint32_t kmin = (excl + head + 15u) >> 4;    // first block starting at or after the task start
-                    if (kmin < nblk) atomicAdd(&s_map32[kmin >> 1], 1u << (16u * (kmin & 1u)));
-                }
-                ++rank;
-            }
-            excl += len[k];
-        }
-        if (tid < 4u) s_task[nz + tid] = TaskRec{dots16 - total, total, total};          // sentinels past the last task
-        lds_barrier();
-
-        // ---- C: per-lane 16 two-byte counters -> in-lane prefix sums ----
-        uint32_t y[8], pre[8];
-        uint32_t tsum = 0;
+            const u32x4 wt = *reinterpret_cast<const u32x4*>(&s_wt[k][0]);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            y[q] = s_map32[8u * tid + q] * 0x00010001u;          // low half: first counter, high half: sum of both
-            pre[q] = tsum;
-            tsum += y[q] >> 16;
+            for (uint32_t w = 0; w < 4u; ++w) total_pk += wt[w];
         }
-        const uint32_t tincl = wave_incl_scan(tsum);
-        if (lane == 63u) s_w[2][wid] = tincl;
-        lds_barrier();
-
-        // ---- D: add the lanes/waves before; ranks stay below 256*TPT < 65536 ----
+        const uint32_t total = total_pk & 0xFFFFFu;
+        const uint32_t ptotal = head + total;                               // end of the chunk in block space
+        const uint32_t nz = total_pk >> 20;
+        const uint32_t nblk = total ? (ptotal + 15u) >> 4 : 0u;
+        const bool chunk_ok = hdr_ok && !chunk_bad && dst + total <= out_len && nblk <= 4096u && total <= CHUNK_BYTES && nz <= K;
         {
-            const uint32_t m0 = s_w[2][0], m1 = s_w[2][1], m2 = s_w[2][2];
-            const uint32_t mb = tincl - tsum + (wid > 0 ? m0 : 0u) + (wid > 1 ? m1 : 0u) + (wid > 2 ? m2 : 0u);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) s_map32[8u * tid + q] = y[q] + (mb + pre[q]) * 0x00010001u;
-        }
-
-        // ---- P: lane = task.  Task t owns the block it starts in when it is the first task to start there (at a
-        //      non-zero offset): it assembles that block from task t-1 (which covers the block's first byte), itself and
-        //      whatever else begins before the block ends, and parks it in s_patch[t]. ----
-        if (chunk_ok) {
+            uint32_t before = 0u;                                           // packed totals of the rounds before round k
 #pragma unroll
             for (int k = 0; k < TPT; ++k) {
-                const uint32_t t = tid + 256u * uint32_t(k);
-                if (t >= 1u && t < nz) {
-                    const TaskRec tp = s_task[t - 1u], t0 = s_task[t];
-                    const uint32_t s = head + t0.off, blk = s >> 4;
-                    const bool owner = (s & 15u) != 0u && (blk == 0u ? t == 1u : head + tp.off <= (blk << 4));
-                    if (owner) {
-                        const TaskRec t1 = s_task[t + 1u];
-                        const int32_t rel = int32_t(blk << 4) - int32_t(head);
-                        const uint32_t hi = uint32_t(rel + 16) < total ? uint32_t(rel + 16) : total;
-                        const bool need2 = t0.end < hi;
-                        const bool same2 = need2 && t1.adj == tp.adj && !(tp.adj & ADJ_IMM);   // the reference again after an SNV
-                        u32x4 v = fetch_task<false>(tp.adj, rel, int32_t(tp.off) - rel);
-                        const u32x4 g1 = fetch_task<false>(t0.adj, rel, int32_t(t0.off) - rel);
-                        u32x4 g2 = v;
-                        if (need2 && !same2) g2 = fetch_task<false>(t1.adj, rel, int32_t(t1.off) - rel);
-                        v = overwrite_tail(v, g1, uint32_t(int32_t(t0.off) - rel), true);
-                        v = overwrite_tail(v, g2, uint32_t(int32_t(t1.off) - rel), need2);
-                        uint32_t pos = t1.end, r = t + 2u;
-                        while (need2 && pos < hi) {                        // four or more tasks in this block
-                            const TaskRec tx = s_task[r];
-                            const u32x4 h = fetch_task<false>(tx.adj, rel, int32_t(tx.off) - rel);
-                            v = overwrite_tail(v, h, uint32_t(int32_t(tx.off) - rel), true);
-                            pos = tx.end;
-                            ++r;
-                        }
-                        s_patch[t] = v;
-                    }
+                const u32x4 wt = *reinterpret_cast<const u32x4*>(&s_wt[k][0]);
+                const uint32_t base_pk = before + (wid > 0u ? wt[0] : 0u) + (wid > 1u ? wt[1] : 0u) + (wid > 2u ? wt[2] : 0u);
+                before += wt[0] + wt[1] + wt[2] + wt[3];
+                const uint32_t pos = head + incl[k] - len[k] + (base_pk & 0xFFFFFu);      // the task's start in block space
+                const uint32_t rank = rk[k] + (base_pk >> 20);
+                if (len[k] != 0u && chunk_ok) {
+                    const uint64_t a = ((uint64_t(adj_hi[k]) << 32) | adj_lo[k]) - pos;
+                    s_rec[rank] = TaskRec{uint32_t(a), uint32_t(a >> 32), pos + len[k], imm[k] ? (pos | REC_IMM) : pos};
+                    if (imm[k]) s_lit[rank] = lit[k];
+                    const uint32_t kmin = (pos + 15u) >> 4;                // first block starting at or after the task start
+                    if (rank >= 1u && kmin < nblk) atomicAdd(&s_map32[kmin >> 1], (kmin & 1u) ? 0x10000u : 1u);
+                }
+            }
+        }
+        // sentinels past the last task (dots; their ends lie beyond every block of the chunk)
+        if (tid < 4u && chunk_ok) s_rec[nz + tid] = TaskRec{uint32_t(dots16 - ptotal), uint32_t((dots16 - ptotal) >> 32), 0x40000000u, ptotal};
+        lds_barrier();
+
+        // ---- C/D: block map = inclusive prefix sum of the marks, 16 two-byte counters per lane, packed 16-bit adds ----
+        const u32x4 x0 = reinterpret_cast<const u32x4*>(s_map32)[2u * tid], x1 = reinterpret_cast<const u32x4*>(s_map32)[2u * tid + 1u];
+        uint32_t y[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { y[q] = x0[q] + (x0[q] << 16); y[4 + q] = x1[q] + (x1[q] << 16); }   // (c0, c0 + c1)
+        uint32_t tsum = 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tsum += y[q] >> 16;
+        const uint32_t tincl = wave_incl_scan(tsum);
+        if (lane == 63u) s_w[0][wid] = tincl;
+
+        // ---- P (the map is not needed): lane = task.  Task t owns the block it starts in when it is the first task to start
+        //      there (at a non-zero offset): it assembles that block from task t-1 (which covers the block's first byte) on; its
+        //      gathers fly while the map is finished. ----
+        if (DBG == 20) q2 = __builtin_amdgcn_s_memtime();
+        u32x4 patch[TPT];
+        bool owner[TPT];
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            const uint32_t t = tid + 256u * uint32_t(k);
+            owner[k] = false;
+            if (chunk_ok && t >= 1u && t < nz) {
+                const uint32_t s = s_rec[t].off & REC_OFF, b16 = s & ~15u;
+                owner[k] = s != b16 && (b16 == 0u ? t == 1u : (s_rec[t - 1u].off & REC_OFF) <= b16);
+                if (owner[k]) {
+                    const BlockFetch f = block_issue(s_rec, s_lit, t - 1u, b16, ptotal);
+                    patch[k] = block_finish(f, s_rec, s_lit, s_mask, b16, ptotal);
                 }
             }
         }
         lds_barrier();
+        {
+            const u32x4 mt = *reinterpret_cast<const u32x4*>(&s_w[0][0]);
+            uint32_t run = tincl - tsum + (wid > 0u ? mt[0] : 0u) + (wid > 1u ? mt[1] : 0u) + (wid > 2u ? mt[2] : 0u);
+            run |= run << 16;                                               // the running rank in both halves
+            u32x4 o0, o1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const u16x2 yy = __builtin_bit_cast(u16x2, y[q]);
+                const u16x2 rr = __builtin_bit_cast(u16x2, run);
+                const uint32_t o = __builtin_bit_cast(uint32_t, u16x2(yy + rr));
+                if (q < 4) o0[q] = o; else o1[q - 4] = o;
+                run = __builtin_bit_cast(uint32_t, u16x2(rr + yy.yy));      // += c0 + c1 in both halves
+            }
+            reinterpret_cast<u32x4*>(s_map32)[2u * tid] = o0;
+            reinterpret_cast<u32x4*>(s_map32)[2u * tid + 1u] = o1;
+        }
+#pragma unroll
+        for (int k = 0; k < TPT; ++k)
+            if (owner[k]) s_patch[tid + 256u * uint32_t(k)] = patch[k];
+        if (DBG == 20) q3 = __builtin_amdgcn_s_memtime();
+        lds_barrier();
+        if (DBG == 20) q4 = __builtin_amdgcn_s_memtime();
 
         if (!chunk_ok) {                                      // never write out of bounds
-            if (tid == 0) report(p_status, tb, STATUS_RES_OOB);
+            if (tid == 0u) report(p_status, tb, STATUS_RES_OOB);
         } else if (DBG != 4) {
-            // ---- bulk: wave `wid` takes the 64-block rows wid, wid+4, ...; R of them per round ----
-            uint8_t* const out0 = p_out + (dst - head);
-            const uint32_t nrow = (nblk + 63u) >> 6;
-            for (uint32_t row0 = wid; row0 < nrow; row0 += 4u * R) {
-                u32x4 v[R];
-                uint32_t pidx[R];                                           // patch index | 0x80000000, 0x40000000: immediate primary
+            // ---- bulk: per pass wave `wid` takes the 64-block rows wid, wid+4, ..., wid+28 of the pass's 32: R gathers, then R stores ----
+            uint8_t* const out0 = p_out + (dst - head);                     // 16-byte aligned
+            const uint32_t npass = (nblk + 256u * R - 1u) / (256u * R);
+#pragma unroll 1
+            for (uint32_t pass = 0; pass < npass; ++pass) {
+                // position of the wave's first row in this pass (readfirstlane: a scalar, and opaque enough that eight sets of per-row
+                // induction registers are not hoisted)
+                const uint32_t pbase = __builtin_amdgcn_readfirstlane(pass * (4096u * R) + (wid << 10));
+                const uint32_t p0 = pbase + (lane << 4);
+                // look-ups first (LDS only), then the R gathers back to back: issued one by one, each would queue separately behind
+                // the other waves' stores in the CU's memory pipeline
+                uint64_t X[R];
 #pragma unroll
                 for (uint32_t j = 0; j < R; ++j) {
-                    const uint32_t b = ((row0 + 4u * j) << 6) + lane;
-                    const bool active = b < nblk;
-                    const int32_t rel = int32_t(b << 4) - int32_t(head);
-                    const uint32_t hi = uint32_t(rel + 16) < total ? uint32_t(rel + 16) : total;
-                    const uint32_t r = active ? uint32_t(s_map[b]) : 0u;
-                    const TaskRec tr = s_task[r];
-                    const bool dirty = active && tr.end < hi;
-                    const bool imm0 = (tr.adj & ADJ_IMM) != 0ull;
-                    pidx[j] = dirty ? (0x80000000u | (r + 1u)) : ((active && imm0) ? (0x40000000u | r) : 0u);
-                    const uint64_t X = (dirty || imm0 || !active) ? dots16 : tr.adj + uint64_t(int64_t(rel));
-                    v[j] = (DBG == 1) ? u32x4{uint32_t(X), r, hi, 0u} : gather16(X);
+                    const uint32_t b16 = p0 + 4096u * j;
+                    const uint32_t r = b16 < ptotal ? uint32_t(s_map[b16 >> 4]) : nz;   // idle lanes look at a sentinel (dots)
+                    const TaskRec tr = s_rec[r];
+                    // a task ends inside the block: the block the next task parked is taken instead (address 0 | patch index)
+                    X[j] = tr.end <= b16 + 15u ? uint64_t(r + 1u) : rec_adj(tr) + b16;
                 }
+                u32x4 v[R];
 #pragma unroll
                 for (uint32_t j = 0; j < R; ++j) {
-                    const uint32_t b = ((row0 + 4u * j) << 6) + lane;
-                    if (b < nblk) {
-                        const int32_t rel = int32_t(b << 4) - int32_t(head);
-                        u32x4 o = v[j];
-                        if (pidx[j] & 0x80000000u) o = s_patch[pidx[j] & 0xFFFFu];
-                        else if (pidx[j] & 0x40000000u) { const TaskRec tr = s_task[pidx[j] & 0xFFFFu]; o = imm_block(tr.adj & ADJ_LIT, int32_t(tr.off) - rel); }
-                        uint8_t* op = out0 + (uint64_t(b) << 4);
-                        if (DBG == 2) { if (o[0] == 0x12345678u && o[3] == 0x9abcdef0u) op[0] = 1; }
-                        else if (rel >= 0 && uint32_t(rel) + 16u <= total) {
-                            if (NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(op));
-                            else *reinterpret_cast<u32x4*>(op) = o;
-                        } else {
-                            // ragged first/last block of a chunk whose cut is not 16-byte aligned
-                            const uint32_t hi = uint32_t(rel + 16) < total ? uint32_t(rel + 16) : total;
-                            const uint32_t ka = rel < 0 ? uint32_t(-rel) : 0u, kb = uint32_t(int32_t(hi) - rel);
+                    // (if / else, not a select: gather and patch land in the same registers, lanes disjoint)
+                    if (uint32_t(X[j] >> 32) == 0u) v[j] = s_patch[uint32_t(X[j])];
+                    else v[j] = (DBG == 1) ? u32x4{uint32_t(X[j]), 0u, 0u, 0u} : gather16(X[j]);
+                }
+                if (DBG == 20) q7 = __builtin_amdgcn_s_memtime();
+                if (DBG == 20) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); q8 = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
-                            for (uint32_t q = 0; q < 16u; ++q)
-                                if (q >= ka && q < kb) op[q] = uint8_t(o[q >> 2] >> (8u * (q & 3u)));
-                        }
+                for (uint32_t j = 0; j < R; ++j) {
+                    const uint32_t b16 = p0 + 4096u * j;
+                    if (b16 >= head && b16 + 16u <= ptotal) {               // whole blocks of the chunk; ragged edge blocks are written below
+                        uint8_t* op = out0 + b16;
+                        if (DBG == 2) { if (v[j][0] == 0x12345678u && v[j][3] == 0x9abcdef0u) op[0] = 1; }
+                        else if (NT) __builtin_nontemporal_store(v[j], reinterpret_cast<u32x4*>(op));
+                        else *reinterpret_cast<u32x4*>(op) = v[j];
                     }
                 }
             }
+            // ragged first / last block of a chunk whose cut is not 16-byte aligned (rare): one lane each, byte stores; these loads
+            // do queue behind the two waves' stores
+            if (DBG != 2 && (tid == 0u || tid == 64u)) {
+                const uint32_t b16 = tid == 0u ? 0u : (nblk - 1u) << 4;
+                if ((b16 < head || b16 + 16u > ptotal) && (tid == 0u || b16 != 0u))
+                    ragged_block(s_rec, s_lit, s_mask, uint32_t(s_map[b16 >> 4]), b16, head, ptotal, out0 + b16);
+            }
         }
-        if (!has_next) break;
-        c = cn; tb = tb_n; dn = dn_n;
-#pragma unroll
-        for (int k = 0; k < TPT; ++k) d[k] = d_n[k];
-        lds_barrier();                                         // LDS is reused by the next chunk
+        if (DBG == 20) {
+            q5 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long q6 = __builtin_amdgcn_s_memtime();
+            if (lane == 0u) {
+                unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p_out + ((out_len + 255ull) & ~255ull)) + (uint64_t(c) * 4u + wid) * 8u;
+                dbg[0] = q0; dbg[1] = q1; dbg[2] = q2; dbg[3] = q3; dbg[4] = q4; dbg[5] = q5; dbg[6] = q6; dbg[7] = ((q7 - q4) << 32) | ((q8 - q7) & 0xFFFFFFFFull);
+            }
+        }
     }
 }
 
@@ -949,7 +1069,9 @@ __global__ __launch_bounds__(256) void copy_mix_kernel(const uint8_t* __restrict
     const uint64_t base = reinterpret_cast<uint64_t>(src) + 64u + (blockIdx.x & 7u) * slice
                         + ((uint64_t(blockIdx.x >> 3) * span * 16u) % (slice - span * 16u - 64u));
     uint64_t extra = 0;
-    const bool reader = p.x != 0u && (blockIdx.x % p.y) == 0u && (!(p.w & 2u) || threadIdx.x < 64u);
+    const uint32_t n_lanes = (p.y >> 16) ? (p.y >> 16) : 256u;               // p.y bits 16..: lanes that read (0 = all)
+    p.y &= 0xFFFFu;
+    const bool reader = p.x != 0u && (blockIdx.x % p.y) == 0u && (!(p.w & 2u) || threadIdx.x < 64u) && threadIdx.x < n_lanes;
     auto rd = [&]() {
         const uint8_t* q = dsc + uint64_t(blockIdx.x / p.y) * (p.z & 0xFFFFu) + uint64_t(threadIdx.x) * p.x;
         uint32_t x;
@@ -968,6 +1090,21 @@ __global__ __launch_bounds__(256) void copy_mix_kernel(const uint8_t* __restrict
     s_ballast[threadIdx.x + 512u] = threadIdx.x + 2u; s_ballast[threadIdx.x + 768u] = threadIdx.x + 3u;
     for (uint32_t k = 0; k < n_bar; ++k) __syncthreads();
     uint32_t acc = threadIdx.x;
+    if (p.w & 16u) {
+        // the stitch4 order: all eight rows of a wave gathered first, then stored back to back
+        u32x4 v[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) {
+            const uint64_t b = b0 + threadIdx.x + 256u * j;
+            v[j] = gather16(base + ((b - b0) << 4) + shift + extra);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) {
+            const uint64_t b = b0 + threadIdx.x + 256u * j;
+            if (b < e) __builtin_nontemporal_store(v[j], reinterpret_cast<u32x4*>(out) + b);
+        }
+        return;
+    }
 #pragma unroll 1
     for (uint64_t b = b0 + threadIdx.x; b < e; b += 256u) {
 #pragma unroll 1
@@ -988,7 +1125,7 @@ hipError_t launch_copy_mix(const uint8_t* src, uint64_t window, uint32_t shift, 
                            uint32_t bytes_per_lane, uint32_t every, uint32_t stride, uint32_t flags, hipStream_t stream)
 {
     const uint64_t n16 = bytes / 16;
-    if (n16 == 0 || window < (1u << 20) || every == 0) return hipErrorInvalidValue;
+    if (n16 == 0 || window < (1u << 20) || (every & 0xFFFFu) == 0) return hipErrorInvalidValue;
     const uint32_t grid = uint32_t((n16 + 2047) / 2048);
     const uint32_t lds_pad = (flags >> 8) * 1024u;                   // flags bits 8..: KiB of (unused) dynamic LDS per workgroup, to cap the workgroups per CU
     // stride bits 16..: ballast (VALU x8 per pass: 8 bits, LDS round trips per pass: 8 bits, barriers: 4 bits)
@@ -1069,31 +1206,6 @@ static const uint8_t* device_dots(hipError_t* err)
     return bufs[dev];
 }
 
-// Grid of a persistent kernel: every workgroup resident at once (what the occupancy calculator says fits, 8 per CU at
-// most), a multiple of 8 so that chunk c and chunk c + grid run on the same XCD (the chunk table is dealt to XCDs by
-// proteome slice, entry 8j + x to XCD x).
-static uint32_t persistent_grid(const void* kernel, uint32_t n_chunks, uint32_t per_cu, uint32_t max_blocks)
-{
-    static std::mutex mu;
-    static const void* seen[32]; static int occ_of[32]; static int n_seen = 0; static int cus = 0;
-    int occ = 0;
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
-        for (int i = 0; i < n_seen; ++i) if (seen[i] == kernel) occ = occ_of[i];
-        if (!occ) {
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ <= 0) occ = 4;
-            if (occ > 8) occ = 8;
-            if (n_seen < 32) { seen[n_seen] = kernel; occ_of[n_seen++] = occ; }
-        }
-    }
-    if (per_cu && int(per_cu) < occ) occ = int(per_cu);
-    uint32_t want = uint32_t(cus) * uint32_t(occ);
-    if (max_blocks && max_blocks < want) want = max_blocks;
-    if (want >= 8u) want &= ~7u;
-    return n_chunks < want ? n_chunks : want;
-}
-
 hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemporal, uint32_t max_blocks)
 {
     if (args.n_chunks == 0) return hipSuccess;
@@ -1122,18 +1234,21 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
         if (!nt) V2P_L(TT, false, 0, 0); \
         else if (var == 1) V2P_LAUNCH_V(TT, 1); \
         else V2P_LAUNCH_V(TT, 0); } while (0)
-    // persistent latency-organised kernel for long-run images (<= 512 descriptors per chunk); variant 2 and 1 force the per-block kernel
+    // loads-before-stores kernel for long-run images (<= 512 descriptors per chunk); variants 1 and 2 force the per-block kernel
 #define V2P_L3(TT, NTT, DD) do { \
-        const uint32_t grid3 = persistent_grid(reinterpret_cast<const void*>(&stitch3_kernel<TT, NTT, DD>), a.n_chunks, per_cu, max_blocks); \
-        hipLaunchKernelGGL((stitch3_kernel<TT, NTT, DD>), dim3(grid3), dim3(256), 0, stream, V2P_KARGS); } while (0)
+        if (var == 4) hipLaunchKernelGGL((stitch4_kernel<TT, NTT, DD, 1>), dim3(grid), dim3(256), lds_pad, stream, V2P_KARGS); \
+        else if (var == 5) hipLaunchKernelGGL((stitch4_kernel<TT, NTT, DD, 2>), dim3(grid), dim3(256), lds_pad, stream, V2P_KARGS); \
+        else if (var == 6) hipLaunchKernelGGL((stitch4_kernel<TT, NTT, DD, 4>), dim3(grid), dim3(256), lds_pad, stream, V2P_KARGS); \
+        else hipLaunchKernelGGL((stitch4_kernel<TT, NTT, DD, 8>), dim3(grid), dim3(256), lds_pad, stream, V2P_KARGS); } while (0)
 #define V2P_LAUNCH3(TT) do { \
         if (!nt) V2P_L3(TT, false, 0); \
         else if (dbg == 1) V2P_L3(TT, true, 1); \
         else if (dbg == 2) V2P_L3(TT, true, 2); \
         else if (dbg == 4) V2P_L3(TT, true, 4); \
+        else if (dbg == 20) V2P_L3(TT, true, 20); \
         else V2P_L3(TT, true, 0); } while (0)
-    if (tpt <= 2 && var != 1 && var != 2 && dbg != 20 && dbg != 3) {
-        const uint32_t per_cu = (nontemporal >> 24) & 0x3F;    // bits 24..29: resident workgroups per CU (0 = what fits)
+    if (tpt <= 2 && var != 1 && var != 2 && dbg != 3 && !max_blocks) {
+        const uint32_t lds_pad = uint32_t((nontemporal >> 24) & 0x7F) * 1024u;   // bits 24..30: KiB of unused dynamic LDS (caps the workgroups per CU; experiments)
         if (tpt == 1) V2P_LAUNCH3(1); else V2P_LAUNCH3(2);
         return hipGetLastError();
     }
