@@ -211,7 +211,8 @@ int  v2p_pipeline_release(v2p_pipeline* p, uint32_t ticket);
 /* src0/src1 must have 32 readable bytes before and after (the kernel loads whole aligned 16-byte
  * blocks around a task's bytes); out must be 16-byte aligned; status is one device uint64 initialised
  * to ~0; chunks that point outside d_desc[0, n_desc) are reported in it, never followed.
- * `nontemporal`: bit 0 non-temporal result stores, bits 8..11 descriptors per lane (1, 2, 4). */
+ * `nontemporal`: bit 0 non-temporal result stores; bits 8..11 ceil(most descriptors of a chunk / 256) rounded up to 1, 2 or 4;
+ * bit 4 (optional hint) no chunk holds <= 512 descriptors. */
 int v2p_stitch_launch(void* hip_stream,
                       const uint64_t* d_desc, uint64_t n_desc, const v2p_chunk* d_chunks, uint32_t n_chunks,
                       const uint8_t* d_src0, uint64_t src0_len,

@@ -37,3 +37,34 @@ def oracle_run(coracle, g, ref, alt, fill=ord(".")):
     if ref.dtype == np.uint32:
         return coracle.gir_execute(t, ref, alt, res)
     return coracle.gir_execute_u8(t, ref, alt, res)
+
+
+def interpret_image(desc, chunks, resident, payload, out_bytes):
+    """Pure-Python reading of the device image format (vcf2prot_amd/csrc/sir_pack.hpp): what the stitch kernels must write.
+    desc: uint64 descriptors; chunks: (n, 2) uint64 {first descriptor, result offset:48 | descriptors:16}."""
+    import numpy as np
+    out = np.zeros(out_bytes, dtype=np.uint8)
+    for tb, dn in chunks:
+        nd, dst = int(dn) >> 48, int(dn) & ((1 << 48) - 1)
+        for d in desc[int(tb):int(tb) + nd]:
+            d = int(d)
+            space = d >> 62
+            if space == 3 and (d >> 61) & 1:          # fused substitution: reference copy, one literal byte, reference copy one residue on
+                src, len1, len2, byte = d & ((1 << 29) - 1), (d >> 29) & 0xFFF, (d >> 41) & 0xFFF, (d >> 53) & 0xFF
+                out[dst:dst + len1] = resident[src:src + len1]
+                out[dst + len1] = byte
+                out[dst + len1 + 1:dst + len1 + 1 + len2] = resident[src + len1 + 1:src + len1 + 1 + len2]
+                dst += len1 + 1 + len2
+                continue
+            src, ln = d & ((1 << 40) - 1), (d >> 40) & ((1 << 22) - 1)
+            if space == 0:
+                out[dst:dst + ln] = resident[src:src + ln]
+            elif space == 1:
+                out[dst:dst + ln] = payload[src:src + ln]
+            elif space == 3:                          # immediate: the source field holds the bytes themselves
+                assert 1 <= ln <= 5
+                out[dst:dst + ln] = [(src >> (8 * k)) & 0xFF for k in range(ln)]
+            else:
+                out[dst:dst + ln] = ord(".")
+            dst += ln
+    return out

@@ -55,22 +55,9 @@ def test_packed_image_equals_oracle(c1, coracle):
     n = cohort.n_haplotypes
     img = cohort.pack(0, n, n_threads=3)
     prot = cohort.proteome()
-    out = np.zeros(img.out_bytes, dtype=np.uint8)
-    for tb, dn in img.chunks:
-        nt, dst = int(dn) >> 48, int(dn) & ((1 << 48) - 1)
-        for d in img.desc[int(tb):int(tb) + nt]:
-            d = int(d)
-            src, ln, space = d & ((1 << 40) - 1), (d >> 40) & ((1 << 22) - 1), d >> 62
-            if space == 0:
-                out[dst:dst + ln] = prot[src:src + ln]
-            elif space == 1:
-                out[dst:dst + ln] = img.payload[src:src + ln]
-            elif space == 3:                      # immediate: the source field holds the bytes themselves
-                assert 1 <= ln <= 5
-                out[dst:dst + ln] = [(src >> (8 * k)) & 0xFF for k in range(ln)]
-            else:
-                out[dst:dst + ln] = ord(".")
-            dst += ln
+    from gen_util import interpret_image
+    out = interpret_image(img.desc, img.chunks, prot, img.payload, img.out_bytes)
+    assert (img.desc >> np.uint64(61) == 7).any(), 'the C1 cohort has missense transcripts: fused descriptors expected'
     tot_tasks = tot_bytes = 0
     for h in range(n):
         hap = cohort.haplotype(h)

@@ -25,19 +25,9 @@ def parse_fasta(text: bytes):
 
 
 def interpret(img, resident):
-    """CPU reading of the packed image (host logic check, numpy)."""
-    out = np.zeros(img.out_bytes, dtype=np.uint8)
-    for tb, dn in img.chunks:
-        nt, dst = int(dn) >> 48, int(dn) & ((1 << 48) - 1)
-        for d in img.desc[int(tb):int(tb) + nt]:
-            d = int(d)
-            src, ln, space = d & ((1 << 40) - 1), (d >> 40) & ((1 << 22) - 1), d >> 62
-            if space == 3:                        # immediate descriptor: the source field holds the bytes
-                out[dst:dst + ln] = [(src >> (8 * k)) & 0xFF for k in range(ln)]
-            else:
-                out[dst:dst + ln] = resident[src:src + ln] if space == 0 else (img.payload[src:src + ln] if space == 1 else ord("."))
-            dst += ln
-    return out
+    """CPU reading of the packed image (host logic check)."""
+    from gen_util import interpret_image
+    return interpret_image(img.desc, img.chunks, resident, img.payload, img.out_bytes)
 
 
 @pytest.fixture(scope="module")

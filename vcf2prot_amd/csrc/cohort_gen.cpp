@@ -452,8 +452,9 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
     std::vector<v2p::ImageBuilder> parts(size_t(n_threads ? n_threads : 1));
     for (auto& im : parts) {
         if (chunk_tasks) { im.chunk_tasks = chunk_tasks; im.adaptive_tasks = false; }
-        if (chunk_bytes) im.chunk_bytes = chunk_bytes;
+        if (chunk_bytes) { im.chunk_bytes = chunk_bytes; im.adaptive_bytes = false; }
         if (flags & V2P_PACK_NO_IMM) im.inline_payload = false;
+        if (flags & V2P_PACK_NO_FUSE) im.fuse_snv = false;
         if ((flags >> 8) & 0xFFFF) im.cut_align = (flags >> 8) & 0xFFFF;   // experiment knobs: bits 8..23 cut alignment,
         if (flags >> 24) im.soft_window = flags >> 24;                     //                   bits 24..31 closing window
     }

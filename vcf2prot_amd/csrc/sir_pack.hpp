@@ -15,6 +15,14 @@
 //                                   first byte lowest) -- alt payloads of missense /
 //                                   deletion / short insertion tasks travel inside their
 //                                   descriptor and need no gather at all
+//                  space 3 with bit 61 set = a fused single-residue substitution ("SNV3"), the commonest
+//                  Task triple of all (transcript_instructions.rs:654-663 between two reference copies):
+//                    copy len1 residues of the proteome from src, write one literal byte, copy len2
+//                    residues from src + len1 + 1
+//                  bits 0..28 src, 29..40 len1, 41..52 len2, 53..60 the byte.  One descriptor instead of
+//                  three: the descriptor stream of an SNV-only cohort drops from 6 % to 2 % of the result
+//                  bytes (a streamed HBM read above 1/32 of a saturated write stream costs that stream 40 %
+//                  on MI355X, profiles/r02_copy_mix_*.json).  The kernel expands it back into three tasks.
 //   chunks[C]    work items of <= 256 (deep Task vectors: 1024) consecutive descriptors and < 64 KiB of
 //                result: {first descriptor, result offset, descriptor count}.
 //                Inside a chunk result offsets are the exclusive prefix sum of the
@@ -41,13 +49,18 @@ constexpr unsigned SPACE_PAYLOAD  = 1;
 constexpr unsigned SPACE_FILL     = 2;
 constexpr unsigned SPACE_IMM      = 3;
 constexpr uint32_t IMM_MAX_BYTES  = 5;         // literal bytes that fit the 40-bit source field
+constexpr uint64_t SNV3_MARK      = (3ull << 62) | (1ull << 61);
+constexpr uint32_t SNV3_MAX_LEN   = 4095;      // len1, len2 (12 bits each)
+constexpr uint64_t SNV3_MAX_SRC   = (1ull << 29) - 1;
 
 constexpr uint64_t SRC_MASK   = (1ull << 40) - 1;
 constexpr uint32_t LEN_BITS   = 22;
 constexpr uint32_t LEN_MASK   = (1u << LEN_BITS) - 1;
-constexpr uint32_t CHUNK_TASKS = 256;          // descriptors per work item for long-run images (one per lane)
-constexpr uint32_t CHUNK_TASKS_DEEP = 1024;    // ... for images with < 100 result bytes per descriptor: 4 per lane
-constexpr uint32_t CHUNK_BYTES = 64u * 1024u - 16u;  // result bytes per work item (<= 4096 16-byte blocks incl. a ragged head)
+constexpr uint32_t CHUNK_TASKS = 256;          // tasks per work item for long-run images (one per lane)
+constexpr uint32_t CHUNK_TASKS_DEEP = 1024;    // ... for dense images (a few result bytes per task): 4 per lane
+constexpr uint32_t CHUNK_BYTES = 64u * 1024u - 16u;  // most result bytes a work item may hold (<= 4096 16-byte blocks incl. a ragged head)
+constexpr uint32_t CHUNK_BYTES_LONG = 32u * 1024u;   // ... of a long-run work item: 2048 blocks = eight 1 KiB rows per wave, all gathered before the first store
+constexpr uint32_t DENSE_BELOW = 40;           // a chunk with fewer result bytes per task than this switches the builder to dense chunks
 constexpr uint32_t CUT_ALIGN  = 4096;          // preferred chunk cut: 4 KiB multiples = full 256-lane passes of 16-byte blocks
 constexpr uint64_t DST_MASK   = (1ull << 48) - 1;
 constexpr uint32_t PAD_BYTES  = 32;            // readable slack before AND after a source arena: the kernel loads whole 16-byte aligned blocks
@@ -62,9 +75,15 @@ static_assert(sizeof(Chunk) == 16, "Chunk is 16 bytes");
 inline uint64_t pack_desc(uint64_t src, uint32_t len, unsigned space) {
     return (src & SRC_MASK) | (uint64_t(len & LEN_MASK) << 40) | (uint64_t(space & 3u) << 62);
 }
-inline uint64_t desc_src(uint64_t d)   { return d & SRC_MASK; }
-inline uint32_t desc_len(uint64_t d)   { return uint32_t(d >> 40) & LEN_MASK; }
-inline unsigned desc_space(uint64_t d) { return unsigned(d >> 62); }
+inline bool     desc_is_snv3(uint64_t d) { return (d & SNV3_MARK) == SNV3_MARK; }
+inline uint64_t pack_snv3(uint64_t src, uint32_t len1, uint32_t len2, uint8_t byte) {
+    return SNV3_MARK | (uint64_t(byte) << 53) | (uint64_t(len2 & 0xFFFu) << 41) | (uint64_t(len1 & 0xFFFu) << 29) | (src & SNV3_MAX_SRC);
+}
+inline uint64_t desc_src(uint64_t d)   { return desc_is_snv3(d) ? (d & SNV3_MAX_SRC) : (d & SRC_MASK); }
+// result bytes a descriptor produces
+inline uint32_t desc_len(uint64_t d)   { return desc_is_snv3(d) ? uint32_t((d >> 29) & 0xFFFu) + 1u + uint32_t((d >> 41) & 0xFFFu) : uint32_t(d >> 40) & LEN_MASK; }
+// source space; a fused substitution reads the proteome
+inline unsigned desc_space(uint64_t d) { return desc_is_snv3(d) ? SPACE_PROTEOME : unsigned(d >> 62); }
 
 enum PackStatus : int {
     PACK_OK = 0,
@@ -84,13 +103,16 @@ public:
     std::vector<uint64_t> hap_out_begin{0};
     uint64_t n_copy_bytes = 0;     // A: residues written by copy tasks (Sum task.length)
     uint64_t n_ref_tasks = 0;      // N: Task descriptors consumed, zero-length ones included
-    uint32_t chunk_tasks = CHUNK_TASKS;
-    bool adaptive_tasks = true;       // pick the next chunk's descriptor limit from the last chunk's bytes per descriptor
-    uint32_t chunk_bytes = CHUNK_BYTES;
+    uint32_t chunk_tasks = CHUNK_TASKS;   // tasks per chunk (a fused substitution counts as the tasks it expands to)
+    bool adaptive_tasks = true;       // switch between long-run and dense chunks by the last chunk's bytes per task
+    uint32_t chunk_bytes = CHUNK_BYTES_LONG;
+    bool adaptive_bytes = true;       // chunk_bytes follows the mode (CHUNK_BYTES_LONG / CHUNK_BYTES); false once the caller sets it
     uint32_t cut_align = CUT_ALIGN;   // power of two >= 16
-    uint32_t max_chunk_tasks = 0;     // largest descriptor count of any chunk (selects the kernel's descriptors per lane)
-    uint32_t soft_window = 8;         // descriptors before the hard limit at which a chunk starts looking for its cut
+    uint32_t max_chunk_tasks = 0;     // most tasks of any chunk (selects the kernel: <= 512 long-run, else dense)
+    uint32_t soft_window = 8;         // tasks before the hard limit at which a chunk starts looking for its cut
     bool inline_payload = true;       // payload tasks of <= IMM_MAX_BYTES bytes become immediate descriptors
+    bool fuse_snv = true;             // reference copy + 1-byte literal + reference copy going on one residue later -> one descriptor
+    uint64_t n_fused = 0;             // fused substitutions in the image
 
     uint64_t out_size() const { return hap_out_begin.back(); }
     uint64_t n_haplotypes() const { return hap_out_begin.size() - 1; }
@@ -103,21 +125,22 @@ public:
     int add_task(unsigned space, uint64_t src, uint64_t len, uint64_t dst, uint64_t n_res) {
         if (dst < cursor_) return PACK_NOT_CANONICAL;
         if (dst + len > n_res || dst + len < dst) return PACK_RES_OOB;
-        if (dst > cursor_) emit(SPACE_FILL, 0, dst - cursor_);
+        if (dst > cursor_) { flush(); emit(SPACE_FILL, 0, dst - cursor_); }
         if (src + len > SRC_MASK) return PACK_TOO_LARGE;
         ++n_ref_tasks;
         n_copy_bytes += len;
         if (inline_payload && space == SPACE_PAYLOAD && len >= 1 && len <= IMM_MAX_BYTES && src + len <= payload.size()) {
             uint64_t lit = 0;
             for (uint64_t k = 0; k < len; ++k) lit |= uint64_t(payload[src + k]) << (8 * k);
-            emit(SPACE_IMM, lit, len);
+            stage(SPACE_IMM, lit, len);
         } else {
-            emit(space, src, len);
+            stage(space, src, len);
         }
         cursor_ = dst + len;
         return PACK_OK;
     }
     void end_haplotype(uint64_t n_res) {
+        flush();
         if (cursor_ < n_res) emit(SPACE_FILL, 0, n_res - cursor_);
         hap_out_begin.push_back(hap_out_begin.back() + n_res + extra_);
         cursor_ = 0;
@@ -126,13 +149,13 @@ public:
     // FASTA emit (personalized_genome.rs:90-113 fused into the scatter): bytes that are not
     // part of the result tape -- record headers and line feeds -- are ordinary descriptors
     // placed between the tasks; they advance the arena but not the tape cursor.
-    void add_literal(unsigned space, uint64_t src, uint32_t len) { emit(space, src, len); extra_ += len; }
+    void add_literal(unsigned space, uint64_t src, uint32_t len) { flush(); emit(space, src, len); extra_ += len; }
     // '.'-fill the result tape up to `dst` (cells no task covers before a record ends)
-    void fill_to(uint64_t dst) { if (dst > cursor_) { emit(SPACE_FILL, 0, dst - cursor_); cursor_ = dst; } }
+    void fill_to(uint64_t dst) { if (dst > cursor_) { flush(); emit(SPACE_FILL, 0, dst - cursor_); cursor_ = dst; } }
     // Close the open chunk; call once after the last haplotype.
-    void finish() { close_chunk(); }
+    void finish() { flush(); close_chunk(); }
 
-    // Raw append used by generators that already produce canonical descriptors.
+    // Raw append of one canonical descriptor (tasks staged for fusion must have been flushed).
     void emit(unsigned space, uint64_t src, uint64_t len) {
         if (len == 0) { push(space, src, 0); return; }
         while (len) {
@@ -155,21 +178,71 @@ private:
     uint64_t extra_ = 0;             // literal bytes (FASTA headers, line feeds) added to the current haplotype
     uint64_t arena_cursor_ = 0;      // result offset of the next descriptor
     uint64_t open_begin_ = 0, open_dst_ = 0;
-    uint32_t open_n_ = 0, open_bytes_ = 0;
+    uint32_t open_n_ = 0, open_bytes_ = 0;   // tasks / result bytes of the open chunk
+    uint32_t open_desc_ = 0;                 // descriptors of the open chunk (<= open_n_)
+    struct Staged { unsigned space; uint64_t src; uint64_t len; };
+    Staged st_[2];                   // tasks held back because the next one may complete a fused substitution
+    int st_n_ = 0;
+
+    bool long_run_mode() const { return chunk_tasks <= CHUNK_TASKS; }
+    void flush() {
+        const int n = st_n_;
+        st_n_ = 0;
+        for (int i = 0; i < n; ++i) emit(st_[i].space, st_[i].src, st_[i].len);
+    }
+    // One task in canonical order.  [reference copy] [1-byte literal] [reference copy one residue further on] becomes one
+    // descriptor when it fits the open chunk whole; everything else goes in as it is.
+    void stage(unsigned space, uint64_t src, uint64_t len) {
+        if (!fuse_snv || !long_run_mode()) { flush(); emit(space, src, len); return; }
+        if (st_n_ == 2) {
+            if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && src == st_[0].src + st_[0].len + 1) {
+                const Staged a = st_[0], b = st_[1];
+                st_n_ = 0;
+                emit_fused(a.src, uint32_t(a.len), uint8_t(b.src), uint32_t(len));
+                return;
+            }
+            flush();
+        }
+        if (st_n_ == 1) {
+            if (space == SPACE_IMM && len == 1) { st_[1] = Staged{space, src, len}; st_n_ = 2; return; }
+            flush();
+        }
+        if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && src + len + 1 + SNV3_MAX_LEN <= SNV3_MAX_SRC) { st_[0] = Staged{space, src, len}; st_n_ = 1; return; }
+        emit(space, src, len);
+    }
+    void emit_fused(uint64_t src, uint32_t len1, uint8_t byte, uint32_t len2) {
+        const uint32_t total = len1 + 1u + len2, cnt = (len1 ? 1u : 0u) + 1u + (len2 ? 1u : 0u);
+        const uint32_t soft_tasks = chunk_tasks > soft_window ? chunk_tasks - soft_window : chunk_tasks;
+        const uint32_t soft_bytes = chunk_bytes > cut_align ? chunk_bytes - cut_align : chunk_bytes;
+        if (open_n_ + cnt <= soft_tasks && open_bytes_ + total <= soft_bytes) {
+            if (open_n_ == 0) { open_begin_ = desc.size(); open_dst_ = arena_cursor_; }
+            desc.push_back(pack_snv3(src, len1, len2, byte));
+            ++open_desc_; open_n_ += cnt; open_bytes_ += total; arena_cursor_ += total;
+            ++n_fused;
+            return;
+        }
+        // close to a cut: the three tasks go in one by one (the cut may split one of them)
+        emit(SPACE_PROTEOME, src, len1);
+        emit(SPACE_IMM, byte, 1);
+        emit(SPACE_PROTEOME, src + len1 + 1, len2);
+    }
 
     void close_chunk() {
         if (open_n_ == 0) return;
-        chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_n_) << 48)});
+        chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_desc_) << 48)});
         if (open_n_ > max_chunk_tasks) max_chunk_tasks = open_n_;
-        // measured on MI355X (tools/ab.py): with >= ~130 result bytes per descriptor (C2) 256-task chunks are 2-3 %
-        // faster; below ~85 (C3, FASTA images, C5) 1024-task chunks win by 7 %, 11 % and 27 %
-        if (adaptive_tasks) chunk_tasks = (open_bytes_ / open_n_ >= 100u) ? CHUNK_TASKS : CHUNK_TASKS_DEEP;
-        open_n_ = 0; open_bytes_ = 0;
+        // long-run chunks (<= 256 tasks, <= 32 KiB: one round of eight rows per wave in stitch4_kernel) unless the image is dense
+        // (a few bytes per task: 1024-task chunks of up to 64 KiB for the per-block kernel)
+        if (adaptive_tasks) {
+            chunk_tasks = (open_bytes_ / open_n_ >= DENSE_BELOW) ? CHUNK_TASKS : CHUNK_TASKS_DEEP;
+            if (adaptive_bytes) chunk_bytes = long_run_mode() ? CHUNK_BYTES_LONG : CHUNK_BYTES;
+        }
+        open_n_ = 0; open_bytes_ = 0; open_desc_ = 0;
     }
     void append(unsigned space, uint64_t src, uint32_t len) {
         if (open_n_ == 0) { open_begin_ = desc.size(); open_dst_ = arena_cursor_; }
         desc.push_back(pack_desc(src, len, space));
-        ++open_n_; open_bytes_ += len; arena_cursor_ += len;
+        ++open_n_; ++open_desc_; open_bytes_ += len; arena_cursor_ += len;
     }
     // Chunks are cut at aligned result offsets whenever possible (the task that straddles the
     // cut is split into two descriptors): with a 16-byte multiple a workgroup's first and last

@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                                                      const uint8_t* __restrict__ p_src0, const uint8_t* __restrict__ p_src1,
                                                      uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
                                                      const uint8_t* __restrict__ p_dots,
-                                                     uint32_t n_chunks, uint64_t n_desc, uint64_t src0_len, uint64_t src1_len, uint64_t out_len)
+                                                     uint32_t n_chunks, uint64_t n_desc, uint64_t src0_len, uint64_t src1_len, uint64_t out_len,
+                                                     uint32_t filter)
 {
     // explicit __restrict__ pointers (not a by-value struct): the chunk header becomes a scalar
     // (s_load) access, because the compiler can prove the result stores never clobber the inputs
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
         const uint64_t tb = a.chunks[c].task_begin;
         const uint64_t dn = a.chunks[c].dst_n;
         const uint32_t n_hdr = uint32_t(dn >> 48);
+        if (filter == 2u && n_hdr <= 512u) continue;   // mixed image: chunks of <= 512 descriptors belong to stitch4_kernel
         const uint64_t dst = dn & ((1ull << 48) - 1);
         const uint32_t head = uint32_t(dst & 15ull);
         // a chunk table that points outside the descriptor array is refused, not followed
@@ -499,10 +501,12 @@ __device__ __forceinline__ BlockFetch block_issue(const TaskRec* s_rec, const ui
     const uint32_t hi = b16 + 16u < ptotal ? b16 + 16u : ptotal;
     const TaskRec t0 = s_rec[r], t1 = s_rec[r + 1u], t2 = s_rec[r + 2u];
     const bool need1 = t0.end < hi, need2 = need1 && t1.end < hi;
+    // the reference going on after a substituted residue is the same stream as before it: its bytes are already in `v`
+    const bool same2 = need2 && !((t0.off | t2.off) & REC_IMM) && t2.adj_lo == t0.adj_lo && t2.adj_hi == t0.adj_hi;
     BlockFetch f;
     f.v = rec_fetch(t0, s_lit, r, b16); f.g1 = f.v; f.g2 = f.v;
     if (need1) f.g1 = rec_fetch(t1, s_lit, r + 1u, b16);
-    if (need2) f.g2 = rec_fetch(t2, s_lit, r + 2u, b16);
+    if (need2 && !same2) f.g2 = rec_fetch(t2, s_lit, r + 2u, b16);
     f.ja1 = need1 ? (t1.off & REC_OFF) - b16 : 16u;
     f.ja2 = need2 ? (t2.off & REC_OFF) - b16 : 16u;
     f.next = (need2 && t2.end < hi) ? r + 2u : 0u;
@@ -539,7 +543,8 @@ __global__ __launch_bounds__(256) void stitch4_kernel(const uint64_t* __restrict
                                                       const uint8_t* __restrict__ p_src0, const uint8_t* __restrict__ p_src1,
                                                       uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
                                                       const uint8_t* __restrict__ p_dots,
-                                                      uint32_t n_chunks, uint64_t n_desc, uint64_t src0_len, uint64_t src1_len, uint64_t out_len)
+                                                      uint32_t n_chunks, uint64_t n_desc, uint64_t src0_len, uint64_t src1_len, uint64_t out_len,
+                                                      uint32_t filter)
 {
     constexpr uint32_t K = 256u * TPT;
     constexpr uint32_t R = ROWS;                            // rows per wave and pass in the bulk phase: 8 x 4 waves x 1 KiB = 32 KiB
@@ -562,6 +567,7 @@ __global__ __launch_bounds__(256) void stitch4_kernel(const uint64_t* __restrict
         if (DBG == 20) q0 = __builtin_amdgcn_s_memtime();
         const uint64_t tb = p_chunks[c].task_begin, dn = p_chunks[c].dst_n;
         const uint32_t n_hdr = uint32_t(dn >> 48);
+        if (filter == 1u && n_hdr > K) return;             // mixed image: the dense chunks belong to stitch_kernel
         const uint64_t dst = dn & ((1ull << 48) - 1);
         const uint32_t head = uint32_t(dst) & 15u;
         // a chunk table that points outside the descriptor array is refused, not followed
@@ -584,44 +590,57 @@ __global__ __launch_bounds__(256) void stitch4_kernel(const uint64_t* __restrict
         }
         lds_barrier();                                          // (the bad flag is cleared before anybody can raise it)
 
-        // ---- A: lane `tid` decodes descriptors tid, tid + 256, ... (so ranks follow lane order within each round) ----
-        uint32_t adj_lo[TPT], adj_hi[TPT], len[TPT];
-        uint64_t lit[TPT];
-        bool imm[TPT];
+        // ---- A: lane `tid` decodes descriptors tid, tid + 256, ... (so ranks follow lane order within each round).  A descriptor
+        //      is one task, or -- the fused substitution -- up to three: reference copy, one literal byte, reference copy. ----
+        uint64_t adr[TPT];                                                  // source address of the (first) copy
+        uint32_t part0[TPT], part2[TPT], lit_lo[TPT], lit_hi[TPT];         // bytes of the first / third task (the second is 1 byte when fused)
+        bool imm[TPT], snv[TPT];
+        uint32_t pk[TPT];                                                   // bytes (low 20 bits) | tasks
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
             const uint32_t i = tid + 256u * uint32_t(k);
             const uint32_t dlo = uint32_t(d[k]), dhi = uint32_t(d[k] >> 32);
-            len[k] = i < n ? (dhi >> 8) & 0x3FFFFFu : 0u;
             const uint32_t space = dhi >> 30;
-            const uint64_t src = (uint64_t(dhi & 0xFFu) << 32) | dlo;
-            uint64_t a = dots16;
-            bool bad = len[k] > CHUNK_BYTES;
-            imm[k] = space == SPACE_IMM;
-            lit[k] = src;
-            if (space == SPACE_IMM) {
-                bad = bad || len[k] > IMM_MAX_BYTES;
-            } else if (space != SPACE_FILL) {
-                const uint64_t limit = space == SPACE_PROTEOME ? src0_len : src1_len;
-                bad = bad || src + len[k] > limit;                          // never read out of bounds: task.rs would panic
-                a = reinterpret_cast<uint64_t>(space == SPACE_PROTEOME ? p_src0 : p_src1) + src;
+            snv[k] = i < n && (dhi >> 29) == 7u;
+            uint32_t len = i < n ? (dhi >> 8) & 0x3FFFFFu : 0u;
+            uint64_t src = (uint64_t(dhi & 0xFFu) << 32) | dlo;
+            part2[k] = 0u;
+            if (snv[k]) {                                                   // src 0..28, len1 29..40, len2 41..52, byte 53..60
+                src = dlo & 0x1FFFFFFFu;
+                len = (dlo >> 29) | ((dhi & 0x1FFu) << 3);
+                part2[k] = (dhi >> 9) & 0xFFFu;
             }
-            if (bad && len[k] != 0u) {                                      // reported, and the chunk is not executed
+            const uint32_t bytes = snv[k] ? len + 1u + part2[k] : len;
+            uint64_t a = dots16;
+            bool bad = bytes > CHUNK_BYTES;
+            imm[k] = !snv[k] && space == SPACE_IMM;
+            lit_lo[k] = snv[k] ? (dhi >> 21) & 0xFFu : dlo;
+            lit_hi[k] = snv[k] ? 0u : dhi & 0xFFu;
+            if (imm[k]) {
+                bad = bad || len > IMM_MAX_BYTES;
+            } else if (snv[k] || space != SPACE_FILL) {
+                const bool ref = snv[k] || space == SPACE_PROTEOME;
+                bad = bad || src + bytes > (ref ? src0_len : src1_len);      // never read out of bounds: task.rs would panic
+                a = reinterpret_cast<uint64_t>(ref ? p_src0 : p_src1) + src;
+            }
+            if (bad && bytes != 0u) {                                       // reported, and the chunk is not executed
                 report(p_status, tb + i, STATUS_SRC_OOB);
                 atomicOr(&s_w[1][0], 1u);
-                len[k] = 0u;
+                len = 0u; part2[k] = 0u; snv[k] = false;
             }
-            adj_lo[k] = uint32_t(a); adj_hi[k] = uint32_t(a >> 32);
+            adr[k] = a;
+            part0[k] = len;
+            const uint32_t total_k = snv[k] ? len + 1u + part2[k] : len;
+            const uint32_t tasks_k = snv[k] ? (len ? 1u : 0u) + 1u + (part2[k] ? 1u : 0u) : (len ? 1u : 0u);
+            pk[k] = total_k | (tasks_k << 20);
         }
-        // result offsets: one DPP scan of the lengths; ranks among the non-empty tasks: ballot + mbcnt.  With TPT > 1 the tasks
+        // result offsets and ranks among the non-empty tasks: ONE DPP scan of (bytes | tasks << 20).  With TPT > 1 the descriptors
         // of round k all precede those of round k + 1, so the rounds are scanned one after the other.
-        uint32_t incl[TPT], rk[TPT];
+        uint32_t incl[TPT];
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
-            incl[k] = wave_incl_scan(len[k]);
-            const unsigned long long nzb = __ballot(len[k] != 0u);
-            rk[k] = __builtin_amdgcn_mbcnt_hi(uint32_t(nzb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(nzb), 0u));
-            if (lane == 63u) s_wt[k][wid] = incl[k] + (uint32_t(__popcll(nzb)) << 20);
+            incl[k] = wave_incl_scan(pk[k]);
+            if (lane == 63u) s_wt[k][wid] = incl[k];
         }
         if (DBG == 20) q1 = __builtin_amdgcn_s_memtime();
         lds_barrier();
@@ -647,14 +666,24 @@ __global__ __launch_bounds__(256) void stitch4_kernel(const uint64_t* __restrict
                 const u32x4 wt = *reinterpret_cast<const u32x4*>(&s_wt[k][0]);
                 const uint32_t base_pk = before + (wid > 0u ? wt[0] : 0u) + (wid > 1u ? wt[1] : 0u) + (wid > 2u ? wt[2] : 0u);
                 before += wt[0] + wt[1] + wt[2] + wt[3];
-                const uint32_t pos = head + incl[k] - len[k] + (base_pk & 0xFFFFFu);      // the task's start in block space
-                const uint32_t rank = rk[k] + (base_pk >> 20);
-                if (len[k] != 0u && chunk_ok) {
-                    const uint64_t a = ((uint64_t(adj_hi[k]) << 32) | adj_lo[k]) - pos;
-                    s_rec[rank] = TaskRec{uint32_t(a), uint32_t(a >> 32), pos + len[k], imm[k] ? (pos | REC_IMM) : pos};
-                    if (imm[k]) s_lit[rank] = lit[k];
-                    const uint32_t kmin = (pos + 15u) >> 4;                // first block starting at or after the task start
-                    if (rank >= 1u && kmin < nblk) atomicAdd(&s_map32[kmin >> 1], (kmin & 1u) ? 0x10000u : 1u);
+                const uint32_t ex = incl[k] - pk[k] + base_pk;
+                uint32_t pos = head + (ex & 0xFFFFFu);                      // the descriptor's start in block space
+                uint32_t rank = ex >> 20;
+                if (!chunk_ok) continue;
+                // its tasks, in order: (part0 from adr) [one literal byte] [part2 from adr + part0 + 1]
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const uint32_t plen = q == 0 ? part0[k] : (q == 1 ? (snv[k] ? 1u : 0u) : part2[k]);
+                    if (plen != 0u) {
+                        const bool lit = q == 1 || (q == 0 && imm[k]);
+                        const uint64_t a = (lit ? dots16 : (q == 2 ? adr[k] + part0[k] + 1u : adr[k])) - pos;
+                        s_rec[rank] = TaskRec{uint32_t(a), uint32_t(a >> 32), pos + plen, lit ? (pos | REC_IMM) : pos};
+                        if (lit) s_lit[rank] = (uint64_t(lit_hi[k]) << 32) | lit_lo[k];
+                        const uint32_t kmin = (pos + 15u) >> 4;            // first block starting at or after the task start
+                        if (rank >= 1u && kmin < nblk) atomicAdd(&s_map32[kmin >> 1], (kmin & 1u) ? 0x10000u : 1u);
+                        ++rank;
+                        pos += plen;
+                    }
                 }
             }
         }
@@ -677,19 +706,19 @@ __global__ __launch_bounds__(256) void stitch4_kernel(const uint64_t* __restrict
         //      there (at a non-zero offset): it assembles that block from task t-1 (which covers the block's first byte) on; its
         //      gathers fly while the map is finished. ----
         if (DBG == 20) q2 = __builtin_amdgcn_s_memtime();
-        u32x4 patch[TPT];
+        BlockFetch pf[TPT];
+        uint32_t pb16[TPT];
         bool owner[TPT];
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
             const uint32_t t = tid + 256u * uint32_t(k);
             owner[k] = false;
+            pb16[k] = 0u;
             if (chunk_ok && t >= 1u && t < nz) {
                 const uint32_t s = s_rec[t].off & REC_OFF, b16 = s & ~15u;
                 owner[k] = s != b16 && (b16 == 0u ? t == 1u : (s_rec[t - 1u].off & REC_OFF) <= b16);
-                if (owner[k]) {
-                    const BlockFetch f = block_issue(s_rec, s_lit, t - 1u, b16, ptotal);
-                    patch[k] = block_finish(f, s_rec, s_lit, s_mask, b16, ptotal);
-                }
+                pb16[k] = b16;
+                if (owner[k]) pf[k] = block_issue(s_rec, s_lit, t - 1u, b16, ptotal);
             }
         }
         lds_barrier();
@@ -709,9 +738,10 @@ __global__ __launch_bounds__(256) void stitch4_kernel(const uint64_t* __restrict
             reinterpret_cast<u32x4*>(s_map32)[2u * tid] = o0;
             reinterpret_cast<u32x4*>(s_map32)[2u * tid + 1u] = o1;
         }
+        // P, second half: merge and park the cut blocks
 #pragma unroll
         for (int k = 0; k < TPT; ++k)
-            if (owner[k]) s_patch[tid + 256u * uint32_t(k)] = patch[k];
+            if (owner[k]) s_patch[tid + 256u * uint32_t(k)] = block_finish(pf[k], s_rec, s_lit, s_mask, pb16[k], ptotal);
         if (DBG == 20) q3 = __builtin_amdgcn_s_memtime();
         lds_barrier();
         if (DBG == 20) q4 = __builtin_amdgcn_s_memtime();
@@ -1213,52 +1243,57 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     hipError_t err = hipSuccess;
     a.dots = device_dots(&err);
     if (!a.dots) return err;
-    // `nontemporal` bit 0: nt result stores; bits 8..11: descriptors per lane; bits 12..15: K2 variant
-    // (0 = aligned loads + lane exchange, 1 = legacy byte-granular gathers); bits 16..23: timing-only ablation
+    // `nontemporal` bit 0: nt result stores; bit 4: the image has no chunk of <= 512 descriptors; bits 8..11: tasks per lane of the
+    // largest chunk (1, 2: long-run image -> stitch4_kernel; 4: dense or mixed image); bits 12..15: variant (0 = default, 1 / 2 =
+    // the per-block kernel with byte-granular / aligned gathers for every chunk -- images without fused descriptors only, A/B runs;
+    // 4..6: stitch4 with 1 / 2 / 4 rows per round); bits 16..23: timing-only ablation; bits 24..30: KiB of idle LDS (experiments)
     const int nt = nontemporal & 1;
     const int var = (nontemporal >> 12) & 0xF;
     const int dbg = (nontemporal >> 16) & 0xFF;
     const uint32_t grid = grid_for(a.n_chunks, max_blocks ? max_blocks : 0x7FFFFFFFu);
     int tpt = (nontemporal >> 8) & 0xF;                 // chunks hold <= 256*tpt tasks
     if (tpt == 0) tpt = STITCH_TASKS_PER_LANE;
+    const uint32_t lds_pad = uint32_t((nontemporal >> 24) & 0x7F) * 1024u;
 #define V2P_KARGS a.desc, a.chunks, a.src0, a.src1, a.out, a.status, a.dots, a.n_chunks, a.n_desc, a.src0_len, a.src1_len, a.out_len
-#define V2P_L(TT, NTT, VV, DD) hipLaunchKernelGGL((stitch_kernel<TT, NTT, VV, DD>), dim3(grid), dim3(256), 0, stream, V2P_KARGS)
-#define V2P_LAUNCH_V(TT, VV) do { \
-        if (dbg == 1) V2P_L(TT, true, VV, 1); \
-        else if (dbg == 2) V2P_L(TT, true, VV, 2); \
-        else if (dbg == 3) V2P_L(TT, true, VV, 3); \
-        else if (dbg == 4) V2P_L(TT, true, VV, 4); \
-        else if (dbg == 20) V2P_L(TT, true, VV, 20); \
-        else V2P_L(TT, true, VV, 0); } while (0)
-#define V2P_LAUNCH(TT) do { \
-        if (!nt) V2P_L(TT, false, 0, 0); \
-        else if (var == 1) V2P_LAUNCH_V(TT, 1); \
-        else V2P_LAUNCH_V(TT, 0); } while (0)
-    // loads-before-stores kernel for long-run images (<= 512 descriptors per chunk); variants 1 and 2 force the per-block kernel
-#define V2P_L3(TT, NTT, DD) do { \
-        if (var == 4) hipLaunchKernelGGL((stitch4_kernel<TT, NTT, DD, 1>), dim3(grid), dim3(256), lds_pad, stream, V2P_KARGS); \
-        else if (var == 5) hipLaunchKernelGGL((stitch4_kernel<TT, NTT, DD, 2>), dim3(grid), dim3(256), lds_pad, stream, V2P_KARGS); \
-        else if (var == 6) hipLaunchKernelGGL((stitch4_kernel<TT, NTT, DD, 4>), dim3(grid), dim3(256), lds_pad, stream, V2P_KARGS); \
-        else hipLaunchKernelGGL((stitch4_kernel<TT, NTT, DD, 8>), dim3(grid), dim3(256), lds_pad, stream, V2P_KARGS); } while (0)
-#define V2P_LAUNCH3(TT) do { \
-        if (!nt) V2P_L3(TT, false, 0); \
-        else if (dbg == 1) V2P_L3(TT, true, 1); \
-        else if (dbg == 2) V2P_L3(TT, true, 2); \
-        else if (dbg == 4) V2P_L3(TT, true, 4); \
-        else if (dbg == 20) V2P_L3(TT, true, 20); \
-        else V2P_L3(TT, true, 0); } while (0)
-    if (tpt <= 2 && var != 1 && var != 2 && dbg != 3 && !max_blocks) {
-        const uint32_t lds_pad = uint32_t((nontemporal >> 24) & 0x7F) * 1024u;   // bits 24..30: KiB of unused dynamic LDS (caps the workgroups per CU; experiments)
-        if (tpt == 1) V2P_LAUNCH3(1); else V2P_LAUNCH3(2);
-        return hipGetLastError();
-    }
-    switch (tpt) {
-        case 1: V2P_LAUNCH(1); break;
-        case 2: V2P_LAUNCH(2); break;
-        default: V2P_LAUNCH(4); break;
+#define V2P_L(TT, NTT, VV, DD, FF) hipLaunchKernelGGL((stitch_kernel<TT, NTT, VV, DD>), dim3(grid), dim3(256), 0, stream, V2P_KARGS, uint32_t(FF))
+#define V2P_LAUNCH_V(TT, VV, FF) do { \
+        if (dbg == 1) V2P_L(TT, true, VV, 1, FF); \
+        else if (dbg == 2) V2P_L(TT, true, VV, 2, FF); \
+        else if (dbg == 3) V2P_L(TT, true, VV, 3, FF); \
+        else if (dbg == 4) V2P_L(TT, true, VV, 4, FF); \
+        else if (dbg == 20) V2P_L(TT, true, VV, 20, FF); \
+        else V2P_L(TT, true, VV, 0, FF); } while (0)
+#define V2P_LAUNCH(TT, FF) do { \
+        if (!nt) V2P_L(TT, false, 0, 0, FF); \
+        else if (var == 1) V2P_LAUNCH_V(TT, 1, FF); \
+        else V2P_LAUNCH_V(TT, 0, FF); } while (0)
+#define V2P_L4(TT, NTT, DD, RR, FF) hipLaunchKernelGGL((stitch4_kernel<TT, NTT, DD, RR>), dim3(grid), dim3(256), lds_pad, stream, V2P_KARGS, uint32_t(FF))
+#define V2P_L3(TT, NTT, DD, FF) do { \
+        if (var == 4) V2P_L4(TT, NTT, DD, 1, FF); \
+        else if (var == 5) V2P_L4(TT, NTT, DD, 2, FF); \
+        else if (var == 6) V2P_L4(TT, NTT, DD, 4, FF); \
+        else V2P_L4(TT, NTT, DD, 8, FF); } while (0)
+#define V2P_LAUNCH3(TT, FF) do { \
+        if (!nt) V2P_L3(TT, false, 0, FF); \
+        else if (dbg == 1) V2P_L3(TT, true, 1, FF); \
+        else if (dbg == 2) V2P_L3(TT, true, 2, FF); \
+        else if (dbg == 4) V2P_L3(TT, true, 4, FF); \
+        else if (dbg == 20) V2P_L3(TT, true, 20, FF); \
+        else V2P_L3(TT, true, 0, FF); } while (0)
+    const bool per_block_only = var == 1 || var == 2 || dbg == 3 || max_blocks != 0;
+    if (per_block_only) {                               // every chunk on the per-block kernel (no fused descriptors in such images)
+        switch (tpt) { case 1: V2P_LAUNCH(1, 0); break; case 2: V2P_LAUNCH(2, 0); break; default: V2P_LAUNCH(4, 0); break; }
+    } else if (tpt <= 2) {                              // long-run image: loads-before-stores kernel
+        if (tpt == 1) V2P_LAUNCH3(1, 0); else V2P_LAUNCH3(2, 0);
+    } else {
+        // dense or mixed image: chunks of more than 512 descriptors on the per-block kernel, the others (which may hold fused
+        // descriptors) on stitch4_kernel; a workgroup that finds a chunk of the other kind returns at once
+        V2P_LAUNCH(4, 2);
+        if (!(nontemporal & 16)) V2P_LAUNCH3(2, 1);
     }
 #undef V2P_LAUNCH3
 #undef V2P_L3
+#undef V2P_L4
 #undef V2P_LAUNCH
 #undef V2P_LAUNCH_V
 #undef V2P_L

@@ -127,6 +127,7 @@ struct v2p_batch {
     DevBuf d_desc, d_chunks, d_payload, d_out, d_hap, d_digest, d_status;
     uint64_t n_desc = 0, n_chunks = 0, n_payload = 0, out_bytes = 0, n_haps = 0;
     uint32_t max_chunk_tasks = 0;
+    int launch_hint = 0;           // bit 4: no chunk of <= 512 descriptors (dense image: skip the long-run kernel's pass)
 };
 
 namespace v2p {
@@ -667,7 +668,9 @@ int v2p_batch_finalize(v2p_batch* b)
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     b->n_desc = b->img.desc.size(); b->n_chunks = b->img.chunks.size(); b->n_payload = b->img.payload.size();
     b->max_chunk_tasks = 0;
-    for (const Chunk& ch : b->img.chunks) { const uint32_t n = uint32_t(ch.dst_n >> 48); if (n > b->max_chunk_tasks) b->max_chunk_tasks = n; }
+    bool any_small = false;
+    for (const Chunk& ch : b->img.chunks) { const uint32_t n = uint32_t(ch.dst_n >> 48); if (n > b->max_chunk_tasks) b->max_chunk_tasks = n; any_small = any_small || n <= 512u; }
+    b->launch_hint = any_small ? 0 : 16;
     b->out_bytes = b->img.out_size(); b->n_haps = b->img.n_haplotypes();
     HIP_TRY(c, b->d_desc.ensure(b->n_desc * 8), "hipMalloc(desc)");
     HIP_TRY(c, b->d_chunks.ensure(b->n_chunks * sizeof(Chunk)), "hipMalloc(chunks)");
@@ -700,7 +703,7 @@ int v2p_batch_execute(v2p_batch* b)
     StitchArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), b->n_desc, reinterpret_cast<const Chunk*>(b->d_chunks.ptr()),
                  uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->d_payload.ptr(), b->n_payload,
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
-    HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | (tasks_per_lane_for(b->max_chunk_tasks) << 8), 0), "launch(stitch)");
+    HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint | (tasks_per_lane_for(b->max_chunk_tasks) << 8), 0), "launch(stitch)");
     return V2P_OK;
 }
 
@@ -870,8 +873,9 @@ int v2p_pipeline_submit(v2p_pipeline* p,
                  uint32_t(n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, s.d_payload.ptr(), n_payload,
                  s.d_out.ptr(), out_bytes, reinterpret_cast<unsigned long long*>(s.d_status.ptr())};
     uint32_t max_n = 0;
-    for (uint64_t i = 0; i < n_chunks; ++i) { const uint32_t n = uint32_t(chunks[i].dst_n >> 48); if (n > max_n) max_n = n; }
-    HIP_TRY(c, launch_stitch(a, s.stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | (tasks_per_lane_for(max_n) << 8), 0), "launch(stitch)");
+    bool any_small = false;
+    for (uint64_t i = 0; i < n_chunks; ++i) { const uint32_t n = uint32_t(chunks[i].dst_n >> 48); if (n > max_n) max_n = n; any_small = any_small || n <= 512u; }
+    HIP_TRY(c, launch_stitch(a, s.stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | (any_small ? 0 : 16) | (tasks_per_lane_for(max_n) << 8), 0), "launch(stitch)");
     if (out_bytes) HIP_TRY(c, hipMemcpyAsync(s.h_out.p, s.d_out.ptr(), out_bytes, hipMemcpyDeviceToHost, s.stream), "D2H(out)");
     HIP_TRY(c, hipMemcpyAsync(s.h_out.p + ((out_bytes + 7) & ~7ull), s.d_status.ptr(), sizeof(unsigned long long), hipMemcpyDeviceToHost, s.stream), "D2H(status)");
     HIP_TRY(c, hipEventRecord(s.done, s.stream), "hipEventRecord");
