@@ -54,7 +54,6 @@ def parse_args():
     ap.add_argument("--temporal", action="store_true", help="plain result stores instead of non-temporal")
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--fasta", action="store_true", help="FASTA-emitting image: headers and line feeds fused into the scatter (SURVEY 8f rank 1)")
-    ap.add_argument("--tpt", type=int, default=0, help="descriptors per lane (chunks of up to 256*tpt tasks; 0 = what the image needs)")
     ap.add_argument("--var", type=int, default=0, help="K2 variant (0 = default, 1 = legacy byte-granular gathers)")
     ap.add_argument("--no-fuse", action="store_true", help="one descriptor per task (no fused substitutions)")
     ap.add_argument("--cut-align", type=int, default=0)
@@ -235,7 +234,7 @@ def main():
         h0, h1 = shard_by_bytes(sizes.tolist(), world)[rank]              # equal result bytes per rank
     t_gen = time.perf_counter()
     img = cohort.pack(h0, h1, n_threads=min(n_threads, 64), chunk_tasks=args.chunk_tasks, chunk_bytes=args.chunk_bytes, fasta=args.fasta, cut_align=args.cut_align,
-                      fuse=not args.no_fuse and args.var not in (1, 2))
+                      fuse=not args.no_fuse and args.var not in (1, 2), kernel=2 if args.var in (1, 2) else 0)
     t_gen = time.perf_counter() - t_gen
     A, NT = img.n_copy_bytes, img.n_tasks
     b_alg = 2 * A + 16 * NT
@@ -281,7 +280,7 @@ def main():
     stream = None if args.dry_run else torch.cuda.current_stream()
     sizes_t = torch.tensor([n_haps, out_bytes], dtype=torch.int64, device=dev)
     all_sizes = torch.zeros(2 * world, dtype=torch.int64, device=dev)
-    flags = (0 if args.temporal else 1) | img.launch_hint | ((args.tpt or img.tasks_per_lane) << 8) | (args.var << 12) | (args.dbg << 16)
+    flags = (0 if args.temporal else 1) | img.launch_bits | (args.var << 12) | (args.dbg << 16)
 
     def launch():
         if args.dry_run:
@@ -377,7 +376,7 @@ def main():
             "config": {"workload": f"{args.workload}: " + (f"{samples} samples/GPU x {world} GPU(s)" if args.scaling == "weak" else f"one {samples}-sample cohort over {world} GPU(s), equal result bytes per rank")
                                    + f" ({int(A_all):.3e} aa) x {cohort.n_transcripts} transcripts, SIR Task vectors at the step-6 boundary",
                        "haplotypes_rank0": n_haps, "tasks_rank0": NT, "aa_rank0": A, "chunks_rank0": n_chunks,
-                       "descriptor_bytes": 8, "immediate_descriptors_rank0": n_imm, "fused_substitution_descriptors_rank0": n_fused, "descriptors_rank0": n_desc, "descriptors_per_lane": args.tpt or img.tasks_per_lane,
+                       "descriptor_bytes": 8, "long_run_chunks_rank0": int((img.chunks[:, 1] >> np.uint64(63)).sum()), "immediate_descriptors_rank0": n_imm, "fused_substitution_descriptors_rank0": n_fused, "descriptors_rank0": n_desc, 
                        "parallelism": f"haplotype-sharded x{world}, no data-path collective; per step one all-gather of 16 B per rank (RCCL)" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -60,7 +60,8 @@ extern "C" {
 typedef struct v2p_ctx v2p_ctx;
 typedef struct v2p_batch v2p_batch;
 
-/* 16-byte work item of the device image (see vcf2prot_amd/csrc/sir_pack.hpp) */
+/* 16-byte work item of the device image (see vcf2prot_amd/csrc/sir_pack.hpp): first descriptor; result offset (48 bits) |
+ * descriptor count (11 bits) | kernel routing flags (top 2 bits, set by the image builder) */
 typedef struct { uint64_t task_begin; uint64_t dst_n; } v2p_chunk;
 
 /* ---- library / context ------------------------------------------------------- */
@@ -211,14 +212,15 @@ int  v2p_pipeline_release(v2p_pipeline* p, uint32_t ticket);
 /* src0/src1 must have 32 readable bytes before and after (the kernel loads whole aligned 16-byte
  * blocks around a task's bytes); out must be 16-byte aligned; status is one device uint64 initialised
  * to ~0; chunks that point outside d_desc[0, n_desc) are reported in it, never followed.
- * `nontemporal`: bit 0 non-temporal result stores; bits 8..11 ceil(most descriptors of a chunk / 256) rounded up to 1, 2 or 4;
- * bit 4 (optional hint) no chunk holds <= 512 descriptors. */
+ * `nontemporal`: bit 0 non-temporal result stores | v2p_stitch_launch_bits() of the (host copy of the) chunk table. */
 int v2p_stitch_launch(void* hip_stream,
                       const uint64_t* d_desc, uint64_t n_desc, const v2p_chunk* d_chunks, uint32_t n_chunks,
                       const uint8_t* d_src0, uint64_t src0_len,
                       const uint8_t* d_src1, uint64_t src1_len,
                       uint8_t* d_out, uint64_t out_len,
                       uint64_t* d_status, int nontemporal, uint32_t max_blocks);
+/* Host-side: which of the two stitch kernels a chunk table needs and their tasks per lane (bits 4..11 of `nontemporal`). */
+int v2p_stitch_launch_bits(const v2p_chunk* chunks, uint64_t n_chunks);
 /* Host-side: reorder a chunk table so that workgroup 8*j + x (XCD x) works on proteome slice x.
  * v2p_batch_finalize() does this itself; callers of v2p_stitch_launch() may want it too. */
 int v2p_order_chunks_for_xcds(v2p_chunk* chunks, uint64_t n_chunks, const uint64_t* desc, uint64_t n_desc,

@@ -45,7 +45,7 @@ def interpret_image(desc, chunks, resident, payload, out_bytes):
     import numpy as np
     out = np.zeros(out_bytes, dtype=np.uint8)
     for tb, dn in chunks:
-        nd, dst = int(dn) >> 48, int(dn) & ((1 << 48) - 1)
+        nd, dst = (int(dn) >> 48) & 0x7FF, int(dn) & ((1 << 48) - 1)       # the top bits route the chunk to a kernel
         for d in desc[int(tb):int(tb) + nd]:
             d = int(d)
             space = d >> 62

@@ -57,7 +57,11 @@ def test_packed_image_equals_oracle(c1, coracle):
     prot = cohort.proteome()
     from gen_util import interpret_image
     out = interpret_image(img.desc, img.chunks, prot, img.payload, img.out_bytes)
-    assert (img.desc >> np.uint64(61) == 7).any(), 'the C1 cohort has missense transcripts: fused descriptors expected'
+    # the same cohort as a long-run image: missense transcripts become fused descriptors, the bytes stay the same
+    fused = cohort.pack(0, n, n_threads=3, kernel=1)
+    assert (fused.desc >> np.uint64(61) == 7).any() and fused.desc.size < img.desc.size
+    assert np.array_equal(interpret_image(fused.desc, fused.chunks, prot, fused.payload, fused.out_bytes), out)
+    assert (fused.chunks[:, 1] >> np.uint64(63)).all()              # every chunk routed to the long-run kernel
     tot_tasks = tot_bytes = 0
     for h in range(n):
         hap = cohort.haplotype(h)

@@ -9,7 +9,8 @@ from vcf2prot_amd.cohort import Cohort
 lib = N.hip_lib(); dev = torch.device("cuda", 0)
 wl = sys.argv[1] if len(sys.argv) > 1 else "C2"
 c = Cohort.preset(wl, n_samples=int(sys.argv[2]) if len(sys.argv) > 2 else 1000)
-img = c.pack(0, c.n_haplotypes, n_threads=64)
+var = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+img = c.pack(0, c.n_haplotypes, n_threads=64, kernel=2 if var in (1, 2) else 1)
 prot = c.proteome()
 chunks = np.ascontiguousarray(img.chunks)
 lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, prot.size)
@@ -19,18 +20,18 @@ d_prot, d_pay = padded(prot), padded(img.payload)
 d_desc = torch.from_numpy(img.desc.view(np.int64)).to(dev); d_chunks = torch.from_numpy(chunks.view(np.int64)).to(dev)
 nch = chunks.shape[0]
 dbg_bytes = nch * 4 * 64
-print(wl, 'chunks', nch, 'tasks/lane', img.tasks_per_lane, 'out', img.out_bytes)
+bits = int(lib.v2p_stitch_launch_bits(chunks.ctypes.data, nch))
+print(wl, 'chunks', nch, 'launch bits', hex(bits), 'out', img.out_bytes)
 d_out = torch.zeros(img.out_bytes + 512 + dbg_bytes, dtype=torch.uint8, device=dev)
 d_status = torch.full((1,), -1, dtype=torch.int64, device=dev)
 s = torch.cuda.current_stream().cuda_stream
-var = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 for flags in (1 | (var << 12), 1 | (var << 12) | (20 << 16)):
     lib.v2p_stitch_launch(ctypes.c_void_p(s), d_desc.data_ptr(), d_desc.numel(), d_chunks.data_ptr(), nch, d_prot.data_ptr() + 64, prot.size,
-                          d_pay.data_ptr() + 64, img.payload.size, d_out.data_ptr(), img.out_bytes, d_status.data_ptr(), flags | (img.tasks_per_lane << 8), 0)
+                          d_pay.data_ptr() + 64, img.payload.size, d_out.data_ptr(), img.out_bytes, d_status.data_ptr(), flags | bits, 0)
 torch.cuda.synchronize()
 off = (img.out_bytes + 255) // 256 * 256
 st = d_out[off:off + dbg_bytes].cpu().numpy().view(np.uint64).reshape(nch, 4, 8).astype(np.int64)
-if var == 0 and img.tasks_per_lane <= 2:          # persistent kernel (stitch4): its own stamp layout
+if var == 0:          # stitch4: its own stamp layout
     q = [st[:, :, k] for k in range(7)]
     ok = (q[6] > q[0]).all(axis=1)
     print("chunks stamped:", int(ok.sum()), "of", nch)

@@ -79,6 +79,7 @@ HIP_API = {
     "v2p_copy_prefetch_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int, c_int, c_uint32]),
     "v2p_copy_mix_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_void_p, c_uint32, c_uint32, c_uint32, c_uint32]),
     "v2p_copy_bench_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int, c_void_p]),
+    "v2p_stitch_launch_bits": (c_int, [c_void_p, c_uint64]),
     "v2p_order_chunks_for_xcds": (c_int, [c_void_p, c_uint64, c_void_p, c_uint64, c_uint64]),
     "v2p_digest_launch": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
     "v2p_gather_bench_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_uint32, c_uint32, c_void_p]),

@@ -56,14 +56,13 @@ class Packed:
 
     @property
     def tasks_per_lane(self) -> int:
-        return 1 if self.max_chunk_tasks <= 256 else (2 if self.max_chunk_tasks <= 512 else 4)
+        return (self.launch_bits >> 8) & 15
 
     @property
-    def launch_hint(self) -> int:
-        """Bit 4 of v2p_stitch_launch's flags: no chunk of <= 512 descriptors (a dense image)."""
-        if self.chunks.shape[0] == 0:
-            return 0
-        return 0 if int((self.chunks[:, 1] >> np.uint64(48)).min()) <= 512 else 16
+    def launch_bits(self) -> int:
+        """Bits 4..11 of v2p_stitch_launch's flags: which kernels the chunk table needs and their tasks per lane."""
+        ch = np.ascontiguousarray(self.chunks)
+        return int(N.hip_lib().v2p_stitch_launch_bits(ch.ctypes.data if ch.size else None, ch.shape[0]))
 
     @property
     def out_bytes(self) -> int:
@@ -181,11 +180,12 @@ class Cohort:
         return out
 
     def pack(self, h0: int, h1: int, n_threads: int = 0, chunk_tasks: int = 0, chunk_bytes: int = 0,
-             fasta: bool = False, cut_align: int = 0, soft_window: int = 0, inline_payload: bool = True, fuse: bool = True) -> Packed:
+             fasta: bool = False, cut_align: int = 0, soft_window: int = 0, inline_payload: bool = True, fuse: bool = True,
+             kernel: int = 0) -> Packed:
         import os
         img = PackedImage()
         nt = n_threads or min(32, os.cpu_count() or 1)
-        rc = self._lib.v2p_cohort_pack(self._h, h0, h1, nt, chunk_tasks, chunk_bytes, (1 if fasta else 0) | (0 if inline_payload else 2) | (0 if fuse else 4) | (cut_align << 8) | (soft_window << 24), ctypes.byref(img))
+        rc = self._lib.v2p_cohort_pack(self._h, h0, h1, nt, chunk_tasks, chunk_bytes, (1 if fasta else 0) | (0 if inline_payload else 2) | (0 if fuse else 4) | (16 if kernel == 2 else (32 if kernel == 1 else 0)) | (cut_align << 8) | (soft_window << 24), ctypes.byref(img))
         if rc != 0:
             raise RuntimeError(f"v2p_cohort_pack failed ({rc})")
         try:

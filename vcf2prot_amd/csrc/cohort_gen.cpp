@@ -455,8 +455,19 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
         if (chunk_bytes) { im.chunk_bytes = chunk_bytes; im.adaptive_bytes = false; }
         if (flags & V2P_PACK_NO_IMM) im.inline_payload = false;
         if (flags & V2P_PACK_NO_FUSE) im.fuse_snv = false;
+        if (flags & V2P_PACK_PER_BLOCK) im.kernel_choice = 2;
+        if (flags & V2P_PACK_LONG_RUN) im.kernel_choice = 1;
         if ((flags >> 8) & 0xFFFF) im.cut_align = (flags >> 8) & 0xFFFF;   // experiment knobs: bits 8..23 cut alignment,
         if (flags >> 24) im.soft_window = flags >> 24;                     //                   bits 24..31 closing window
+    }
+    // one kernel per image (sir_pack.hpp): every thread's builder takes the decision the first haplotype's shape asks for
+    if (n && !(flags & (V2P_PACK_PER_BLOCK | V2P_PACK_LONG_RUN)) && !chunk_tasks) {
+        v2p_hapbuf b;
+        generate_into(*c, h0, b, false, nullptr);
+        uint64_t bytes = 0, tasks = 0;
+        for (size_t i = 0; i < b.length.size(); ++i) { bytes += b.length[i]; tasks += b.length[i] ? 1 : 0; }
+        const int choice = (tasks && bytes / tasks >= v2p::LONG_RUN_BYTES_PER_TASK) ? 1 : 2;
+        for (auto& im : parts) im.kernel_choice = choice;
     }
     std::vector<int> status(parts.size(), 0);
     auto work = [&](int w) {
@@ -490,6 +501,7 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
         oo += parts[w].out_size(); oh += parts[w].n_haplotypes();
         out->n_tasks += parts[w].n_ref_tasks; out->n_copy_bytes += parts[w].n_copy_bytes;
         if (parts[w].max_chunk_tasks > out->max_chunk_tasks) out->max_chunk_tasks = parts[w].max_chunk_tasks;
+        if (parts[w].max_long_tasks > out->max_chunk_tasks) out->max_chunk_tasks = parts[w].max_long_tasks;
     }
     auto merge = [&](int w) {
         v2p::ImageBuilder& im = parts[size_t(w)];

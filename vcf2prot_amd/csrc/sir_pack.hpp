@@ -24,7 +24,9 @@
 //                  bytes (a streamed HBM read above 1/32 of a saturated write stream costs that stream 40 %
 //                  on MI355X, profiles/r02_copy_mix_*.json).  The kernel expands it back into three tasks.
 //   chunks[C]    work items of <= 256 (deep Task vectors: 1024) consecutive descriptors and < 64 KiB of
-//                result: {first descriptor, result offset, descriptor count}.
+//                result: {first descriptor, result offset:48 | descriptor count:11 | 0:4 | long-run flag:1}.
+//                The flag routes the chunk: set = stitch4_kernel (<= 512 tasks, may hold fused descriptors),
+//                clear = the per-block stitch_kernel (<= 1024 descriptors, one task each).
 //                Inside a chunk result offsets are the exclusive prefix sum of the
 //                lengths (computed on the device by a wave64 scan), so the 8-byte
 //                start_pos_res of every Task never crosses PCIe or HBM.
@@ -57,12 +59,18 @@ constexpr uint64_t SRC_MASK   = (1ull << 40) - 1;
 constexpr uint32_t LEN_BITS   = 22;
 constexpr uint32_t LEN_MASK   = (1u << LEN_BITS) - 1;
 constexpr uint32_t CHUNK_TASKS = 256;          // tasks per work item for long-run images (one per lane)
+constexpr uint32_t CHUNK_TASKS_MID = 512;      // ... for images with 40..110 result bytes per task: 2 per lane, per-block kernel
 constexpr uint32_t CHUNK_TASKS_DEEP = 1024;    // ... for dense images (a few result bytes per task): 4 per lane
 constexpr uint32_t CHUNK_BYTES = 64u * 1024u - 16u;  // most result bytes a work item may hold (<= 4096 16-byte blocks incl. a ragged head)
 constexpr uint32_t CHUNK_BYTES_LONG = 32u * 1024u;   // ... of a long-run work item: 2048 blocks = eight 1 KiB rows per wave, all gathered before the first store
 constexpr uint32_t DENSE_BELOW = 40;           // a chunk with fewer result bytes per task than this switches the builder to dense chunks
 constexpr uint32_t CUT_ALIGN  = 4096;          // preferred chunk cut: 4 KiB multiples = full 256-lane passes of 16-byte blocks
 constexpr uint64_t DST_MASK   = (1ull << 48) - 1;
+constexpr uint64_t CHUNK_LONG = 1ull << 63;    // chunk header flag: long-run chunk
+constexpr uint64_t CHUNK_LONG2 = 1ull << 62;   // ... holding 257..512 tasks (two task records per lane)
+constexpr uint32_t CHUNK_N_MASK = 0x7FF;       // descriptor count: bits 48..58 of dst_n
+inline uint32_t chunk_n(uint64_t dst_n) { return uint32_t(dst_n >> 48) & CHUNK_N_MASK; }
+constexpr uint32_t LONG_RUN_BYTES_PER_TASK = 120;   // an image whose first chunk has at least this many result bytes per task goes to stitch4_kernel
 constexpr uint32_t PAD_BYTES  = 32;            // readable slack before AND after a source arena: the kernel loads whole 16-byte aligned blocks
                                                // around a task's bytes (up to 30 bytes before its first byte in a chunk's ragged head block, 31 after its last)
 
@@ -108,7 +116,10 @@ public:
     uint32_t chunk_bytes = CHUNK_BYTES_LONG;
     bool adaptive_bytes = true;       // chunk_bytes follows the mode (CHUNK_BYTES_LONG / CHUNK_BYTES); false once the caller sets it
     uint32_t cut_align = CUT_ALIGN;   // power of two >= 16
-    uint32_t max_chunk_tasks = 0;     // most tasks of any chunk (selects the kernel: <= 512 long-run, else dense)
+    uint32_t max_chunk_tasks = 0;     // most tasks of any chunk routed to the per-block kernel (selects its tasks per lane)
+    uint32_t max_long_tasks = 0;      // most tasks of any long-run chunk (<= 256: one task record per lane in stitch4_kernel, else two)
+    uint64_t n_long_chunks = 0;       // chunks routed to stitch4_kernel
+    int kernel_choice = 0;            // 0: undecided (adaptive images decide at their first chunk); 1: every chunk of <= 512 tasks long-run; 2: per-block kernel only, no fusion
     uint32_t soft_window = 8;         // tasks before the hard limit at which a chunk starts looking for its cut
     bool inline_payload = true;       // payload tasks of <= IMM_MAX_BYTES bytes become immediate descriptors
     bool fuse_snv = true;             // reference copy + 1-byte literal + reference copy going on one residue later -> one descriptor
@@ -180,6 +191,7 @@ private:
     uint64_t open_begin_ = 0, open_dst_ = 0;
     uint32_t open_n_ = 0, open_bytes_ = 0;   // tasks / result bytes of the open chunk
     uint32_t open_desc_ = 0;                 // descriptors of the open chunk (<= open_n_)
+    bool open_fused_ = false;                // it holds a fused descriptor
     struct Staged { unsigned space; uint64_t src; uint64_t len; };
     Staged st_[2];                   // tasks held back because the next one may complete a fused substitution
     int st_n_ = 0;
@@ -193,12 +205,16 @@ private:
     // One task in canonical order.  [reference copy] [1-byte literal] [reference copy one residue further on] becomes one
     // descriptor when it fits the open chunk whole; everything else goes in as it is.
     void stage(unsigned space, uint64_t src, uint64_t len) {
-        if (!fuse_snv || !long_run_mode()) { flush(); emit(space, src, len); return; }
+        // fusion needs a long-run chunk: decided images only (the first chunk of an adaptive image goes in unfused)
+        if (!fuse_snv || !long_run_mode() || kernel_choice == 2 || (adaptive_tasks && kernel_choice == 0)) { flush(); emit(space, src, len); return; }
         if (st_n_ == 2) {
-            if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && src == st_[0].src + st_[0].len + 1) {
+            // the copy after the literal goes on one residue behind the copy before it; an EMPTY copy (substitution at the first
+            // or last residue: transcript_instructions.rs:734, :648-649) has no source to speak of and fits any neighbour
+            const bool fits = st_[0].len == 0 ? (len > 0 && src >= 1 && src - 1 + 1 + len <= SNV3_MAX_SRC) : (len == 0 || src == st_[0].src + st_[0].len + 1);
+            if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && fits) {
                 const Staged a = st_[0], b = st_[1];
                 st_n_ = 0;
-                emit_fused(a.src, uint32_t(a.len), uint8_t(b.src), uint32_t(len));
+                emit_fused(a.len == 0 ? src - 1 : a.src, uint32_t(a.len), uint8_t(b.src), uint32_t(len));
                 return;
             }
             flush();
@@ -218,7 +234,7 @@ private:
             if (open_n_ == 0) { open_begin_ = desc.size(); open_dst_ = arena_cursor_; }
             desc.push_back(pack_snv3(src, len1, len2, byte));
             ++open_desc_; open_n_ += cnt; open_bytes_ += total; arena_cursor_ += total;
-            ++n_fused;
+            ++n_fused; open_fused_ = true;
             return;
         }
         // close to a cut: the three tasks go in one by one (the cut may split one of them)
@@ -229,15 +245,23 @@ private:
 
     void close_chunk() {
         if (open_n_ == 0) return;
-        chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_desc_) << 48)});
-        if (open_n_ > max_chunk_tasks) max_chunk_tasks = open_n_;
-        // long-run chunks (<= 256 tasks, <= 32 KiB: one round of eight rows per wave in stitch4_kernel) unless the image is dense
-        // (a few bytes per task: 1024-task chunks of up to 64 KiB for the per-block kernel)
+        // Which kernel takes the image is decided ONCE, when its first chunk closes (mixing costs: every workgroup of the other
+        // kind still launches).  Measured on MI355X (tools/ab.py, profiles/r02_*): stitch4_kernel on chunks of <= 256 tasks / 32 KiB
+        // wins for long runs that fuse (C2: -20 %); the per-block kernel wins on 256-task / 32 KiB chunks for C4 (112 bytes per
+        // task, a proteome larger than L2), on 512-task / 32 KiB chunks for C3 (90), on 1024-task / 64 KiB chunks for dense images
+        // (C5: 7).  An explicit chunk_tasks (adaptive_tasks off) keeps the choice per chunk: <= 256 tasks -> long-run.
+        const uint32_t bpt = open_bytes_ / open_n_;
+        if (adaptive_tasks && kernel_choice == 0) kernel_choice = bpt >= LONG_RUN_BYTES_PER_TASK ? 1 : 2;
+        const bool to_long = open_fused_ || (open_n_ <= 2u * CHUNK_TASKS && (kernel_choice == 1 || (kernel_choice == 0 && long_run_mode())));
+        chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_desc_) << 48) | (to_long ? CHUNK_LONG : 0ull)
+                                            | (to_long && open_n_ > CHUNK_TASKS ? CHUNK_LONG2 : 0ull)});
+        if (to_long) { ++n_long_chunks; if (open_n_ > max_long_tasks) max_long_tasks = open_n_; }
+        else if (open_n_ > max_chunk_tasks) max_chunk_tasks = open_n_;
         if (adaptive_tasks) {
-            chunk_tasks = (open_bytes_ / open_n_ >= DENSE_BELOW) ? CHUNK_TASKS : CHUNK_TASKS_DEEP;
-            if (adaptive_bytes) chunk_bytes = long_run_mode() ? CHUNK_BYTES_LONG : CHUNK_BYTES;
+            chunk_tasks = kernel_choice == 1 ? CHUNK_TASKS : (bpt >= LONG_RUN_BYTES_PER_TASK ? CHUNK_TASKS : (bpt >= DENSE_BELOW ? CHUNK_TASKS_MID : CHUNK_TASKS_DEEP));
+            if (adaptive_bytes) chunk_bytes = chunk_tasks <= CHUNK_TASKS_MID ? CHUNK_BYTES_LONG : CHUNK_BYTES;
         }
-        open_n_ = 0; open_bytes_ = 0; open_desc_ = 0;
+        open_n_ = 0; open_bytes_ = 0; open_desc_ = 0; open_fused_ = false;
     }
     void append(unsigned space, uint64_t src, uint32_t len) {
         if (open_n_ == 0) { open_begin_ = desc.size(); open_dst_ = arena_cursor_; }
@@ -278,6 +302,21 @@ private:
     }
 };
 
+// Launch bits of v2p_stitch_launch / launch_stitch for a chunk table: which kernels have work and how many tasks per lane they
+// need (bit 4: no long-run chunk, bit 5: no per-block chunk, bits 6..7: tasks per lane of stitch4_kernel, bits 8..11: of stitch_kernel).
+inline int stitch_launch_bits(const Chunk* chunks, uint64_t n_chunks)
+{
+    uint32_t max_pb = 0;
+    bool any_long = false, any_long2 = false, any_pb = false;
+    for (uint64_t i = 0; i < n_chunks; ++i) {
+        const uint64_t dn = chunks[i].dst_n;
+        if (dn & CHUNK_LONG) { any_long = true; any_long2 = any_long2 || (dn & CHUNK_LONG2) != 0; }
+        else { any_pb = true; const uint32_t n = chunk_n(dn); if (n > max_pb) max_pb = n; }
+    }
+    const int tpt = max_pb <= 256u ? 1 : (max_pb <= 512u ? 2 : 4);
+    return (any_long ? 0 : 16) | (any_pb ? 0 : 32) | ((any_long2 ? 2 : 1) << 6) | (tpt << 8);
+}
+
 // XCD-aware launch order.  Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on
 // XCD b % 8, observed dispatch behaviour), each XCD has its own 4 MiB L2, and every haplotype
 // re-reads the same proteome.  Reordering the chunk table so that entry 8*j + x is the j-th
@@ -292,7 +331,7 @@ inline void order_chunks_for_xcds(Chunk* chunks, uint64_t n_chunks, const uint64
     std::vector<uint64_t> count(n_xcd, 0);
     for (uint64_t c = 0; c < n_chunks; ++c) {
         const uint64_t tb = chunks[c].task_begin;
-        const uint32_t n = uint32_t(chunks[c].dst_n >> 48);
+        const uint32_t n = chunk_n(chunks[c].dst_n);
         uint64_t key = 0;
         for (uint32_t k = 0; k < n && k < 6 && tb + k < n_desc; ++k)       // skip FASTA literals stored behind the proteome
             if (desc_space(desc[tb + k]) == SPACE_PROTEOME && desc_src(desc[tb + k]) < proteome_len) { key = desc_src(desc[tb + k]); break; }

@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
         if (c != blockIdx.x) lds_barrier();            // LDS is reused by the next chunk
         const uint64_t tb = a.chunks[c].task_begin;
         const uint64_t dn = a.chunks[c].dst_n;
-        const uint32_t n_hdr = uint32_t(dn >> 48);
-        if (filter == 2u && n_hdr <= 512u) continue;   // mixed image: chunks of <= 512 descriptors belong to stitch4_kernel
+        const uint32_t n_hdr = uint32_t(dn >> 48) & CHUNK_N_MASK;
+        if (filter == 2u && (dn & CHUNK_LONG)) continue;   // long-run chunks belong to stitch4_kernel
         const uint64_t dst = dn & ((1ull << 48) - 1);
         const uint32_t head = uint32_t(dst & 15ull);
         // a chunk table that points outside the descriptor array is refused, not followed
@@ -566,8 +566,8 @@ __global__ __launch_bounds__(256) void stitch4_kernel(const uint64_t* __restrict
         unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q7 = 0, q8 = 0;
         if (DBG == 20) q0 = __builtin_amdgcn_s_memtime();
         const uint64_t tb = p_chunks[c].task_begin, dn = p_chunks[c].dst_n;
-        const uint32_t n_hdr = uint32_t(dn >> 48);
-        if (filter == 1u && n_hdr > K) return;             // mixed image: the dense chunks belong to stitch_kernel
+        const uint32_t n_hdr = uint32_t(dn >> 48) & CHUNK_N_MASK;
+        if (filter == 1u && !(dn & CHUNK_LONG)) return;    // the other chunks belong to the per-block stitch_kernel
         const uint64_t dst = dn & ((1ull << 48) - 1);
         const uint32_t head = uint32_t(dst) & 15u;
         // a chunk table that points outside the descriptor array is refused, not followed
@@ -1243,8 +1243,8 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     hipError_t err = hipSuccess;
     a.dots = device_dots(&err);
     if (!a.dots) return err;
-    // `nontemporal` bit 0: nt result stores; bit 4: the image has no chunk of <= 512 descriptors; bits 8..11: tasks per lane of the
-    // largest chunk (1, 2: long-run image -> stitch4_kernel; 4: dense or mixed image); bits 12..15: variant (0 = default, 1 / 2 =
+    // `nontemporal` bit 0: nt result stores; bits 4 / 5: no long-run / no per-block chunk in the image; bits 6..7: tasks per lane
+    // of the largest long-run chunk; bits 8..11: tasks per lane of the largest per-block chunk; bits 12..15: variant (0 = default, 1 / 2 =
     // the per-block kernel with byte-granular / aligned gathers for every chunk -- images without fused descriptors only, A/B runs;
     // 4..6: stitch4 with 1 / 2 / 4 rows per round); bits 16..23: timing-only ablation; bits 24..30: KiB of idle LDS (experiments)
     const int nt = nontemporal & 1;
@@ -1280,16 +1280,15 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
         else if (dbg == 4) V2P_L3(TT, true, 4, FF); \
         else if (dbg == 20) V2P_L3(TT, true, 20, FF); \
         else V2P_L3(TT, true, 0, FF); } while (0)
-    const bool per_block_only = var == 1 || var == 2 || dbg == 3 || max_blocks != 0;
-    if (per_block_only) {                               // every chunk on the per-block kernel (no fused descriptors in such images)
+    // which kernels run: bits 4 / 5 of `nontemporal` say the image has no long-run / no per-block chunk (hints: a workgroup
+    // that finds a chunk of the other kind returns at once)
+    const bool per_block_only = var == 1 || var == 2 || dbg == 3 || max_blocks != 0;   // A/B: every chunk on the per-block kernel (unfused images)
+    const int tpt_long = (nontemporal >> 6) & 3;        // bits 6..7: tasks per lane of the largest long-run chunk (0 = 2)
+    if (per_block_only) {
         switch (tpt) { case 1: V2P_LAUNCH(1, 0); break; case 2: V2P_LAUNCH(2, 0); break; default: V2P_LAUNCH(4, 0); break; }
-    } else if (tpt <= 2) {                              // long-run image: loads-before-stores kernel
-        if (tpt == 1) V2P_LAUNCH3(1, 0); else V2P_LAUNCH3(2, 0);
     } else {
-        // dense or mixed image: chunks of more than 512 descriptors on the per-block kernel, the others (which may hold fused
-        // descriptors) on stitch4_kernel; a workgroup that finds a chunk of the other kind returns at once
-        V2P_LAUNCH(4, 2);
-        if (!(nontemporal & 16)) V2P_LAUNCH3(2, 1);
+        if (!(nontemporal & 32)) { switch (tpt) { case 1: V2P_LAUNCH(1, 2); break; case 2: V2P_LAUNCH(2, 2); break; default: V2P_LAUNCH(4, 2); break; } }
+        if (!(nontemporal & 16)) { if (tpt_long == 1) V2P_LAUNCH3(1, 1); else V2P_LAUNCH3(2, 1); }
     }
 #undef V2P_LAUNCH3
 #undef V2P_L3

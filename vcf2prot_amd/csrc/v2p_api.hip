@@ -127,7 +127,7 @@ struct v2p_batch {
     DevBuf d_desc, d_chunks, d_payload, d_out, d_hap, d_digest, d_status;
     uint64_t n_desc = 0, n_chunks = 0, n_payload = 0, out_bytes = 0, n_haps = 0;
     uint32_t max_chunk_tasks = 0;
-    int launch_hint = 0;           // bit 4: no chunk of <= 512 descriptors (dense image: skip the long-run kernel's pass)
+    int launch_hint = 0;           // stitch_launch_bits() of the chunk table
 };
 
 namespace v2p {
@@ -344,7 +344,7 @@ int v2p_execute_gir(v2p_ctx* c,
         StitchArgs a{reinterpret_cast<const uint64_t*>(c->d_desc.ptr()), img.desc.size(), reinterpret_cast<const Chunk*>(c->d_chunks.ptr()),
                      uint32_t(img.chunks.size()), c->d_ref.ptr(), n_ref * E, c->d_alt.ptr(), n_alt * E,
                      c->d_res.ptr(), n_res * E, reinterpret_cast<unsigned long long*>(c->d_status.ptr())};
-        HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | (tasks_per_lane_for(img.max_chunk_tasks) << 8), 0), "launch(stitch)");
+        HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | stitch_launch_bits(img.chunks.data(), img.chunks.size()), 0), "launch(stitch)");
         if (!gaps) {
             if (n_res) HIP_TRY(c, hipMemcpyAsync(res, c->d_res.ptr(), n_res * E, hipMemcpyDeviceToHost, c->stream), "D2H(res)");
             return collect_status(c, c->d_status);
@@ -392,7 +392,7 @@ static int check_packed(v2p_ctx* c, uint64_t n_desc, const Chunk* chunks, uint64
         if (out_bytes == ~0ull) out_bytes = hap_out_begin[n_haps];
     }
     for (uint64_t i = 0; i < n_chunks; ++i) {
-        const uint64_t n = chunks[i].dst_n >> 48, dst = chunks[i].dst_n & DST_MASK;
+        const uint64_t n = chunk_n(chunks[i].dst_n), dst = chunks[i].dst_n & DST_MASK;
         if (chunks[i].task_begin > n_desc || n > n_desc - chunks[i].task_begin)
             return c->fail(V2P_ERR_INVALID_ARG, "chunk " + std::to_string(i) + " points outside the descriptor array", int64_t(i));
         if (n > CHUNK_TASKS_DEEP) return c->fail(V2P_ERR_INVALID_ARG, "chunk " + std::to_string(i) + " holds more than 1024 descriptors", int64_t(i));
@@ -667,10 +667,7 @@ int v2p_batch_finalize(v2p_batch* b)
     if (b->img.chunks.size() > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     b->n_desc = b->img.desc.size(); b->n_chunks = b->img.chunks.size(); b->n_payload = b->img.payload.size();
-    b->max_chunk_tasks = 0;
-    bool any_small = false;
-    for (const Chunk& ch : b->img.chunks) { const uint32_t n = uint32_t(ch.dst_n >> 48); if (n > b->max_chunk_tasks) b->max_chunk_tasks = n; any_small = any_small || n <= 512u; }
-    b->launch_hint = any_small ? 0 : 16;
+    b->launch_hint = stitch_launch_bits(b->img.chunks.data(), b->img.chunks.size());
     b->out_bytes = b->img.out_size(); b->n_haps = b->img.n_haplotypes();
     HIP_TRY(c, b->d_desc.ensure(b->n_desc * 8), "hipMalloc(desc)");
     HIP_TRY(c, b->d_chunks.ensure(b->n_chunks * sizeof(Chunk)), "hipMalloc(chunks)");
@@ -703,7 +700,7 @@ int v2p_batch_execute(v2p_batch* b)
     StitchArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), b->n_desc, reinterpret_cast<const Chunk*>(b->d_chunks.ptr()),
                  uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->d_payload.ptr(), b->n_payload,
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
-    HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint | (tasks_per_lane_for(b->max_chunk_tasks) << 8), 0), "launch(stitch)");
+    HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint, 0), "launch(stitch)");
     return V2P_OK;
 }
 
@@ -872,10 +869,7 @@ int v2p_pipeline_submit(v2p_pipeline* p,
     StitchArgs a{reinterpret_cast<const uint64_t*>(s.d_desc.ptr()), n_desc, reinterpret_cast<const Chunk*>(s.d_chunks.ptr()),
                  uint32_t(n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, s.d_payload.ptr(), n_payload,
                  s.d_out.ptr(), out_bytes, reinterpret_cast<unsigned long long*>(s.d_status.ptr())};
-    uint32_t max_n = 0;
-    bool any_small = false;
-    for (uint64_t i = 0; i < n_chunks; ++i) { const uint32_t n = uint32_t(chunks[i].dst_n >> 48); if (n > max_n) max_n = n; any_small = any_small || n <= 512u; }
-    HIP_TRY(c, launch_stitch(a, s.stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | (any_small ? 0 : 16) | (tasks_per_lane_for(max_n) << 8), 0), "launch(stitch)");
+    HIP_TRY(c, launch_stitch(a, s.stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | stitch_launch_bits(reinterpret_cast<const Chunk*>(chunks), n_chunks), 0), "launch(stitch)");
     if (out_bytes) HIP_TRY(c, hipMemcpyAsync(s.h_out.p, s.d_out.ptr(), out_bytes, hipMemcpyDeviceToHost, s.stream), "D2H(out)");
     HIP_TRY(c, hipMemcpyAsync(s.h_out.p + ((out_bytes + 7) & ~7ull), s.d_status.ptr(), sizeof(unsigned long long), hipMemcpyDeviceToHost, s.stream), "D2H(status)");
     HIP_TRY(c, hipEventRecord(s.done, s.stream), "hipEventRecord");
@@ -942,6 +936,12 @@ int v2p_digest_launch(void* hip_stream, const uint8_t* d_out, const uint64_t* d_
 {
     DigestArgs a{d_out, d_hap_begin, n_haps, d_digests};
     return launch_digest(a, out_bytes, reinterpret_cast<hipStream_t>(hip_stream)) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
+}
+
+int v2p_stitch_launch_bits(const v2p_chunk* chunks, uint64_t n_chunks)
+{
+    if (n_chunks && !chunks) return V2P_ERR_INVALID_ARG;
+    return stitch_launch_bits(reinterpret_cast<const Chunk*>(chunks), n_chunks);
 }
 
 int v2p_order_chunks_for_xcds(v2p_chunk* chunks, uint64_t n_chunks, const uint64_t* desc, uint64_t n_desc, uint64_t proteome_len)
