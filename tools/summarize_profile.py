@@ -11,10 +11,10 @@ os.makedirs(out, exist_ok=True)
 
 
 def stitch_rows(path):
-    return [r for r in csv.DictReader(open(path)) if "stitch_kernel" in r["Kernel_Name"]]
+    return [r for r in csv.DictReader(open(path)) if "stitch" in r["Kernel_Name"] and "_kernel" in r["Kernel_Name"]]
 
 
-summary = {"tag": tag, "command": "python3 bench.py --no-cpu-baseline (C2, 1000 samples, 1 GPU)"}
+summary = {"tag": tag, "command": "python3 bench.py --no-cpu-baseline --no-pcie " + " ".join(sys.argv[4:])}
 stats = os.path.join(src, "trace", "trace_kernel_stats.csv")
 if os.path.exists(stats):
     rows = list(csv.DictReader(open(stats)))
@@ -25,9 +25,9 @@ if os.path.exists(stats):
             r["Name"] = r["Name"][:110]
             w.writerow(r)
     for r in rows:
-        if "stitch_kernel" in r["Name"]:
-            summary["stitch_kernel"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
-                                        "max_ns": float(r["MaxNs"]), "pct_of_gpu_time": float(r["Percentage"])}
+        if "stitch" in r["Name"] and "_kernel" in r["Name"]:
+            summary.setdefault("stitch_kernels", []).append({"name": r["Name"][:60], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                                              "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "pct_of_gpu_time": float(r["Percentage"])})
 counters = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv")):
     for r in stitch_rows(f):
@@ -55,6 +55,10 @@ if os.path.exists(log):
 json.dump(summary, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
 if "hbm" in summary:
     bl = summary.get("bench_line_under_profiler", {})
-    json.dump({"workload": "C2", "samples_per_gpu": 1000, "hbm_bytes_per_launch": summary["hbm"]["traffic_bytes_per_launch"],
-               "source": f"profiles/{tag}_summary.json"}, open(os.path.join(out, "traffic_latest.json"), "w"))
+    wl = (bl.get("config", {}).get("workload", "C2:") or "C2:").split(":")[0]
+    tpath = os.path.join(out, "traffic_latest.json")
+    allw = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    allw[wl] = {"workload": wl, "haplotypes": bl.get("config", {}).get("haplotypes_rank0"),
+                "hbm_bytes_per_launch": summary["hbm"]["traffic_bytes_per_launch"], "source": f"profiles/{tag}_summary.json"}
+    json.dump(allw, open(tpath, "w"), indent=1)
 print(json.dumps({k: summary[k] for k in summary if k not in ("bench_line_under_profiler",)}, indent=1)[:3000])
