@@ -125,6 +125,15 @@ public:
     bool fuse_snv = true;             // reference copy + 1-byte literal + reference copy going on one residue later -> one descriptor
     uint64_t n_fused = 0;             // fused substitutions in the image
 
+    // Empty the image for another build; the vectors keep their capacity, the settings return to their defaults.
+    void reset() {
+        desc.clear(); chunks.clear(); payload.clear(); hap_out_begin.assign(1, 0);
+        n_copy_bytes = n_ref_tasks = n_fused = n_long_chunks = 0;
+        chunk_tasks = CHUNK_TASKS; adaptive_tasks = true; chunk_bytes = CHUNK_BYTES_LONG; adaptive_bytes = true; cut_align = CUT_ALIGN;
+        max_chunk_tasks = max_long_tasks = 0; soft_window = 8; inline_payload = true; fuse_snv = true; kernel_choice = 0;
+        cursor_ = extra_ = arena_cursor_ = open_begin_ = open_dst_ = 0;
+        open_n_ = open_bytes_ = open_desc_ = 0; open_fused_ = false; st_n_ = 0;
+    }
     uint64_t out_size() const { return hap_out_begin.back(); }
     uint64_t n_haplotypes() const { return hap_out_begin.size() - 1; }
 

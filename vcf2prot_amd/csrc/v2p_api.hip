@@ -106,7 +106,8 @@ struct v2p_ctx {
     std::vector<uint8_t> headers_host;               // host copy of the header table (a few MB at most)
     // GIR-mode scratch (grow-only)
     DevBuf d_ref, d_alt, d_res, d_desc, d_chunks, d_soa, d_status;
-    PinnedBuf h_stage;
+    PinnedBuf h_stage, h_in;                         // pinned staging: results coming back / narrowed tapes going out
+    ImageBuilder gir_img;                            // reused across v2p_execute_gir calls (its vectors keep their capacity)
 
     int fail(int code, const std::string& msg, int64_t index = -1) { err = msg; err_index = index; return code; }
     int hip_fail(hipError_t e, const char* what) {
@@ -193,7 +194,7 @@ void v2p_destroy(v2p_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     c->proteome.release(); c->d_ref.release(); c->d_alt.release(); c->d_res.release();
     c->d_desc.release(); c->d_chunks.release(); c->d_soa.release(); c->d_status.release();
-    c->h_stage.release();
+    c->h_stage.release(); c->h_in.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -300,7 +301,6 @@ int v2p_execute_gir(v2p_ctx* c,
     }
     std::lock_guard<std::mutex> lk(c->mu);
     if (n_tasks == 0) return V2P_OK;
-    constexpr uint64_t E = sizeof(uint32_t);
     // bounds of every task first: the reference would panic, nothing may be written out of range
     bool canonical = true;
     uint64_t cursor = 0;
@@ -314,27 +314,45 @@ int v2p_execute_gir(v2p_ctx* c,
         cursor = start_pos_res[i] + length[i];
     }
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    // Char width: the boundary speaks Rust chars (u32), the device 1 byte per residue.  Amino-acid alphabets are
+    // ASCII, so the tapes are narrowed on the host straight into pinned staging (4x fewer bytes over PCIe, no pageable bounce)
+    // and the result is widened on the way back; a tape holding a char above 0xFF takes the 4-byte path below.
+    uint64_t E = 1;
+    {
+        HIP_TRY(c, c->h_in.ensure(((n_ref + 15) & ~uint64_t(15)) + n_alt + 64), "hipHostMalloc(in)");
+        uint8_t* const h8 = c->h_in.p;
+        uint8_t* const a8 = h8 + ((n_ref + 15) & ~uint64_t(15));
+        uint32_t seen = 0;
+        for (uint64_t i = 0; i < n_ref; ++i) { seen |= ref[i]; h8[i] = uint8_t(ref[i]); }
+        for (uint64_t i = 0; i < n_alt; ++i) { seen |= alt[i]; a8[i] = uint8_t(alt[i]); }
+        if (seen > 0xFFu) E = sizeof(uint32_t);
+    }
     HIP_TRY(c, c->d_ref.ensure(n_ref * E), "hipMalloc(ref)");
     HIP_TRY(c, c->d_alt.ensure(n_alt * E), "hipMalloc(alt)");
     HIP_TRY(c, c->d_res.ensure(n_res * E), "hipMalloc(res)");
-    if (n_ref) HIP_TRY(c, hipMemcpyAsync(c->d_ref.ptr(), ref, n_ref * E, hipMemcpyHostToDevice, c->stream), "H2D(ref)");
-    if (n_alt) HIP_TRY(c, hipMemcpyAsync(c->d_alt.ptr(), alt, n_alt * E, hipMemcpyHostToDevice, c->stream), "H2D(alt)");
+    if (E == 1) {
+        const uint8_t* h8 = c->h_in.p;
+        if (n_ref) HIP_TRY(c, hipMemcpyAsync(c->d_ref.ptr(), h8, n_ref, hipMemcpyHostToDevice, c->stream), "H2D(ref)");
+        if (n_alt) HIP_TRY(c, hipMemcpyAsync(c->d_alt.ptr(), h8 + ((n_ref + 15) & ~uint64_t(15)), n_alt, hipMemcpyHostToDevice, c->stream), "H2D(alt)");
+    } else {
+        if (n_ref) HIP_TRY(c, hipMemcpyAsync(c->d_ref.ptr(), ref, n_ref * E, hipMemcpyHostToDevice, c->stream), "H2D(ref)");
+        if (n_alt) HIP_TRY(c, hipMemcpyAsync(c->d_alt.ptr(), alt, n_alt * E, hipMemcpyHostToDevice, c->stream), "H2D(alt)");
+    }
     int rc = init_status(c, c->d_status);
     if (rc) return rc;
+    HIP_TRY(c, c->h_stage.ensure(n_res * E + 16), "hipHostMalloc(stage)");
 
     if (canonical) {
-        ImageBuilder img;
+        ImageBuilder& img = c->gir_img;
+        img.reset();
+        img.inline_payload = false;                 // the tapes are this call's own device buffers: plain descriptors
+        img.fuse_snv = false;
         img.desc.reserve(n_tasks + 16);
-        bool gaps = false;
-        uint64_t cur = 0;
         for (uint64_t i = 0; i < n_tasks; ++i) {
-            if (start_pos_res[i] > cur) gaps = true;
             const int ps = img.add_task(code[i] == 0 ? SPACE_PROTEOME : SPACE_PAYLOAD, start_pos[i] * E, length[i] * E,
                                         start_pos_res[i] * E, n_res * E);
             if (ps != PACK_OK) return c->fail(pack_to_err(ps), "pack failed", int64_t(i));
-            cur = start_pos_res[i] + length[i];
         }
-        if (cur < n_res) gaps = true;
         img.end_haplotype(n_res * E);
         img.finish();
         HIP_TRY(c, c->d_desc.ensure(img.desc.size() * 8), "hipMalloc(desc)");
@@ -345,36 +363,37 @@ int v2p_execute_gir(v2p_ctx* c,
                      uint32_t(img.chunks.size()), c->d_ref.ptr(), n_ref * E, c->d_alt.ptr(), n_alt * E,
                      c->d_res.ptr(), n_res * E, reinterpret_cast<unsigned long long*>(c->d_status.ptr())};
         HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | stitch_launch_bits(img.chunks.data(), img.chunks.size()), 0), "launch(stitch)");
-        if (!gaps) {
-            if (n_res) HIP_TRY(c, hipMemcpyAsync(res, c->d_res.ptr(), n_res * E, hipMemcpyDeviceToHost, c->stream), "D2H(res)");
-            return collect_status(c, c->d_status);
+    } else {
+        // ordered path: overlapping / descending result ranges, executed in task order
+        const size_t n8 = size_t(n_tasks) * 8, ncode = (size_t(n_tasks) + 7) & ~size_t(7);
+        HIP_TRY(c, c->d_soa.ensure(3 * n8 + ncode), "hipMalloc(soa)");
+        uint8_t* d = c->d_soa.ptr();
+        HIP_TRY(c, hipMemcpyAsync(d, start_pos, n8, hipMemcpyHostToDevice, c->stream), "H2D(start_pos)");
+        HIP_TRY(c, hipMemcpyAsync(d + n8, length, n8, hipMemcpyHostToDevice, c->stream), "H2D(length)");
+        HIP_TRY(c, hipMemcpyAsync(d + 2 * n8, start_pos_res, n8, hipMemcpyHostToDevice, c->stream), "H2D(start_pos_res)");
+        HIP_TRY(c, hipMemcpyAsync(d + 3 * n8, code, n_tasks, hipMemcpyHostToDevice, c->stream), "H2D(code)");
+        OrderedArgs oa{d + 3 * n8, reinterpret_cast<const uint64_t*>(d), reinterpret_cast<const uint64_t*>(d + n8),
+                       reinterpret_cast<const uint64_t*>(d + 2 * n8), n_tasks, c->d_ref.ptr(), c->d_alt.ptr(), c->d_res.ptr(), E};
+        HIP_TRY(c, launch_ordered(oa, c->stream), "launch(ordered)");
+    }
+    // the tape comes back to pinned staging; only cells some task covers go to the caller (the others keep the caller's content:
+    // haplotype_instruction.rs:78 filled them with '.')
+    if (n_res) HIP_TRY(c, hipMemcpyAsync(c->h_stage.p, c->d_res.ptr(), n_res * E, hipMemcpyDeviceToHost, c->stream), "D2H(res)");
+    rc = collect_status(c, c->d_status);
+    if (rc) return rc;
+    if (E == 1) {
+        const uint8_t* st = c->h_stage.p;
+        for (uint64_t i = 0; i < n_tasks;) {                               // runs of tasks that tile the tape are widened in one sweep
+            const uint64_t b = start_pos_res[i];
+            uint64_t e = b + length[i];
+            for (++i; i < n_tasks && start_pos_res[i] == e; ++i) e += length[i];
+            for (uint64_t k = b; k < e; ++k) res[k] = st[k];
         }
-        // cells no task covers keep the caller's content: bring the tape back to a
-        // staging buffer and copy only the covered ranges
-        HIP_TRY(c, c->h_stage.ensure(n_res * E), "hipHostMalloc(stage)");
-        if (n_res) HIP_TRY(c, hipMemcpyAsync(c->h_stage.p, c->d_res.ptr(), n_res * E, hipMemcpyDeviceToHost, c->stream), "D2H(res)");
-        rc = collect_status(c, c->d_status);
-        if (rc) return rc;
+    } else {
         const uint32_t* st = reinterpret_cast<const uint32_t*>(c->h_stage.p);
         for (uint64_t i = 0; i < n_tasks; ++i)
-            memcpy(res + start_pos_res[i], st + start_pos_res[i], size_t(length[i]) * E);
-        return V2P_OK;
+            memcpy(res + start_pos_res[i], st + start_pos_res[i], size_t(length[i]) * sizeof(uint32_t));
     }
-
-    // ordered path: overlapping / descending result ranges, executed in task order
-    const size_t n8 = size_t(n_tasks) * 8, ncode = (size_t(n_tasks) + 7) & ~size_t(7);
-    HIP_TRY(c, c->d_soa.ensure(3 * n8 + ncode), "hipMalloc(soa)");
-    uint8_t* d = c->d_soa.ptr();
-    HIP_TRY(c, hipMemcpyAsync(d, start_pos, n8, hipMemcpyHostToDevice, c->stream), "H2D(start_pos)");
-    HIP_TRY(c, hipMemcpyAsync(d + n8, length, n8, hipMemcpyHostToDevice, c->stream), "H2D(length)");
-    HIP_TRY(c, hipMemcpyAsync(d + 2 * n8, start_pos_res, n8, hipMemcpyHostToDevice, c->stream), "H2D(start_pos_res)");
-    HIP_TRY(c, hipMemcpyAsync(d + 3 * n8, code, n_tasks, hipMemcpyHostToDevice, c->stream), "H2D(code)");
-    if (n_res) HIP_TRY(c, hipMemcpyAsync(c->d_res.ptr(), res, n_res * E, hipMemcpyHostToDevice, c->stream), "H2D(res)");
-    OrderedArgs oa{d + 3 * n8, reinterpret_cast<const uint64_t*>(d), reinterpret_cast<const uint64_t*>(d + n8),
-                   reinterpret_cast<const uint64_t*>(d + 2 * n8), n_tasks, c->d_ref.ptr(), c->d_alt.ptr(), c->d_res.ptr(), E};
-    HIP_TRY(c, launch_ordered(oa, c->stream), "launch(ordered)");
-    if (n_res) HIP_TRY(c, hipMemcpyAsync(res, c->d_res.ptr(), n_res * E, hipMemcpyDeviceToHost, c->stream), "D2H(res)");
-    HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     return V2P_OK;
 }
 
