@@ -1,0 +1,73 @@
+"""Cohorts that do not fit one device image: vcf2prot_amd.driver.run_batched cuts the haplotypes into HBM-sized images and streams
+them through v2p_pipeline_*; and BASELINE config 2 (C3: 10 000 samples) whole on ONE MI355X in a single launch."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cut_by_bytes_is_contiguous_and_bounded():
+    from vcf2prot_amd.driver import cut_by_bytes
+    sizes = [5, 1, 9, 3, 3, 3, 20, 1]
+    cuts = cut_by_bytes(sizes, 10)
+    assert cuts[0][0] == 0 and cuts[-1][1] == len(sizes) and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    assert all(sum(sizes[a:b]) <= 10 or b - a == 1 for a, b in cuts)
+
+
+@pytest.mark.parametrize("preset,n,budget", [("C4", 48, 64 << 20), ("C3", 300, 96 << 20), ("C5", 900, 16 << 20)])
+def test_batched_driver_every_haplotype_equals_the_oracle(built, gpu_ctx, coracle, preset, n, budget):
+    from vcf2prot_amd.cohort import Cohort
+    from vcf2prot_amd.driver import run_batched
+    c = Cohort.preset(preset)
+    gpu_ctx.upload_proteome(c.proteome())
+    sizes = c.result_sizes(0, n)
+    seen, batches = 0, 0
+    for br in run_batched(gpu_ctx, lambda a, b: c.pack(a, b, n_threads=8), sizes.tolist(), budget):
+        batches += 1
+        for h in range(br.h_begin, br.h_end):
+            hap = c.haplotype(h)
+            t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+            want = coracle.gir_execute_u8(t, c.ref_tape_u32(h).astype(np.uint8), hap.alt, np.full(hap.n_res, ord("."), dtype=np.uint8))
+            assert np.array_equal(br.haplotype(h), want), (preset, h)
+            seen += 1
+    assert seen == n and batches >= 3
+
+
+def test_c3_whole_cohort_on_one_gpu_every_haplotype_by_digest(built, gpu_ctx, coracle):
+    """BASELINE configs[2]: 10 000 samples = 20 000 haplotypes, about 38 GB of result, one launch on one MI355X (288 GB HBM);
+    the digest of EVERY haplotype equals the digest of the oracle's result."""
+    from concurrent.futures import ThreadPoolExecutor
+    from vcf2prot_amd.cohort import Cohort
+    c = Cohort.preset("C3")
+    n = c.n_haplotypes
+    assert n == 20000
+    gpu_ctx.upload_proteome(c.proteome())
+    img = c.pack(0, n, n_threads=min(64, os.cpu_count() or 1))
+    assert img.out_bytes > 35 * 10 ** 9
+    b = gpu_ctx.batch()
+    b.set_packed(img.desc, img.chunks, img.payload, img.hap_out_begin)
+    del img
+    b.finalize()
+    b.execute()
+    b.sync()
+    dig = b.digests()
+    workers = min(64, os.cpu_count() or 1)
+
+    def oracle_digests(w):
+        cc = Cohort.preset("C3")
+        out = {}
+        for h in range(w, n, workers):
+            hap = cc.haplotype(h)
+            t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+            want = coracle.gir_execute_u8(t, cc.ref_tape_u32(h).astype(np.uint8), hap.alt, np.full(hap.n_res, ord("."), dtype=np.uint8))
+            out[h] = coracle.digest_u8(want)
+        return out
+    want = {}
+    with ThreadPoolExecutor(workers) as pool:
+        for part in pool.map(oracle_digests, range(workers)):
+            want.update(part)
+    bad = [h for h in range(n) if int(dig[h]) != want[h]]
+    assert not bad, bad[:10]
+    b.close()
