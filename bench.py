@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--samples", type=int, default=0, help="weak: samples per GPU; strong: samples of the whole cohort (0 = the config's own size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the transfers-inclusive leg (v2p_pipeline_*)")
+    ap.add_argument("--no-device-build", action="store_true", help="skip the device-side image build leg (v2p_batch_build_on_device)")
     ap.add_argument("--verify", default="all", choices=["all", "sample", "none"],
                     help="haplotypes whose digest is compared with the oracle before timing")
     ap.add_argument("--no-verify", action="store_true")
@@ -178,6 +179,36 @@ def pcie_inclusive(cohort, h0, h1, n_threads, slots=3, target_image_bytes=2 << 3
             "d2h_GBps": out_total / best / 1e9, "what": "packed images -> pinned H2D -> stitch kernel -> D2H into pinned host memory"}
 
 
+def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests):
+    """the same shard's image built ON the device from the per-transcript GIRs of step 4b (v2p_batch_build_on_device:
+    step 5's running sums as prefix scans, descriptors, chunk table, XCD order).  Returns the build kernels' time and whether the
+    image executes to the same per-haplotype digests."""
+    import numpy as np
+    from vcf2prot_amd.engine import Context
+    t0 = time.perf_counter()
+    stream = cohort.txstream(h0, h1, n_threads=n_threads)
+    t_stream = time.perf_counter() - t0
+    window = 28672 if long_run else 32768
+    with Context(0) as ctx:
+        ctx.upload_proteome(cohort.proteome())
+        b = ctx.batch()
+        t0 = time.perf_counter()
+        ms = b.build_on_device(stream, window, 1 if long_run else 2)
+        t_call = time.perf_counter() - t0
+        cn = b.counts()
+        same = None
+        if want_digests is not None:
+            b.execute()
+            b.sync()
+            same = bool(np.array_equal(b.digests(), want_digests))
+        b.close()
+    res = {"build_kernels_ms": ms, "call_s_incl_h2d_of_the_stream": t_call, "stream_bytes": stream.nbytes, "stream_generation_s": t_stream,
+           "window_bytes": window, "descriptors": cn["n_desc"], "chunks": cn["n_chunks"], "digests_equal_host_built_image": same,
+           "what": "per-transcript GIRs (un-rebased Task SoA, transcript offsets, alt bytes) -> descriptors + chunk table + hap_out_begin in HBM"}
+    stream.close()
+    return res
+
+
 def main():
     args = parse_args()
     if "RANK" not in os.environ and args.gpus > 1:
@@ -304,11 +335,13 @@ def main():
 
     # ---- parity before timing: per-haplotype digests vs the oracle --------------------
     verified = None
+    dig_all = None
     if args.verify != "none":
         d_dig = torch.zeros(n_haps, dtype=torch.int64, device=dev)
         lib.v2p_digest_launch(ctypes.c_void_p(stream.cuda_stream), d_out.data_ptr(), d_hap.data_ptr(), n_haps, out_bytes, d_dig.data_ptr())
         torch.cuda.synchronize()
         dig = d_dig.cpu().numpy().view(np.uint64)
+        dig_all = dig.copy()
         every = args.verify == "all" and out_bytes <= 24 * 10 ** 9
         check = list(range(n_haps)) if every else sorted(set(np.linspace(0, n_haps - 1, min(n_haps, 512)).astype(int).tolist()))
         t_v = time.perf_counter()
@@ -403,6 +436,11 @@ def main():
                 line["incl_transfers"] = pc
             except Exception as e:           # never lose the bench line to the secondary leg
                 line["incl_transfers"] = {"error": repr(e)}
+        if world == 1 and not args.no_device_build and not args.fasta and not args.dbg and not args.dry_run:
+            try:
+                line["device_image_build"] = device_image_build(cohort, h0, h1, min(n_threads, 64), not (img.launch_bits & 16), dig_all)
+            except Exception as e:
+                line["device_image_build"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             line["cpu_baseline"] = cpu_baseline(cohort, h0, n_haps, os.cpu_count() or 1)
         print(json.dumps(line))

@@ -108,6 +108,19 @@ int  v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_thread
                      uint32_t chunk_tasks, uint32_t chunk_bytes, uint32_t flags, v2p_packed_image* out);
 /* result tape length (residues) of haplotypes [h0, h1): what SURVEY 8e's byte-balanced sharding cuts its prefix sum over */
 int  v2p_cohort_result_sizes(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads, uint64_t* out);
+/* The same haplotypes one step EARLIER: the per-transcript GIRs of step 4b, un-rebased (offsets relative to the transcript and to
+ * its own alt tape), concatenated -- the input of v2p_batch_build_on_device (its field order; free with v2p_txstream_free). */
+typedef struct {
+    uint64_t n_haps, n_tx, n_tasks, n_alt;
+    uint64_t* hap_tx_begin; uint64_t* tx_proteome_off; uint32_t* tx_ref_len; uint32_t* tx_res_len;
+    uint64_t* tx_task_begin; uint64_t* tx_alt_begin;
+    uint8_t* code; uint32_t* start_pos; uint32_t* length; uint32_t* start_pos_res; uint8_t* alt;
+} v2p_txstream_buf;
+int  v2p_cohort_txstream(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads, v2p_txstream_buf* out);
+void v2p_txstream_free(v2p_txstream_buf* s);
+/* Host image of haplotypes [h0, h1) cut on a fixed result grid (what the device builder produces): v2p_cohort_pack with
+ * ImageBuilder::grid_bytes = window_bytes; kernel 1 = long-run routing, 2 = per block */
+int  v2p_cohort_pack_grid(const v2p_cohort* c, uint64_t h0, uint64_t h1, uint32_t window_bytes, int kernel, v2p_packed_image* out);
 /* FASTA record headers of every transcript and haplotype parity: one leading '\n', then 19 bytes each;
  * header of (transcript t, parity p) at 1 + (2*t + p) * 19.  Returns the bytes needed; fills `out` when cap suffices. */
 uint64_t v2p_cohort_fasta_headers(const v2p_cohort* c, uint8_t* out, uint64_t cap);

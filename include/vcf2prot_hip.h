@@ -164,6 +164,35 @@ int v2p_batch_add_transcript(v2p_batch* b,
                              uint64_t header_off, uint32_t header_len);
 int v2p_batch_end_haplotype(v2p_batch* b);
 
+/* ---- image build ON THE DEVICE (step 5 and the packer as kernels) ----------------------------
+ * Input: the per-transcript GIRs exactly as TranscriptInstruction::get_g_rep returns them (transcript_instructions.rs:335-427:
+ * task offsets relative to the transcript and to its own alt tape), concatenated over the transcripts of every haplotype of the
+ * batch, in result order.  The device does the reference's step 5 (haplotype_instruction.rs:94-133: the three running sums become
+ * prefix scans; reference tasks are rebased onto the resident proteome) and the image packing (result-order descriptors, '.'
+ * fill for cells no task covers, immediate descriptors, chunk table, XCD-aware order, hap_out_begin).  Chunks are cut on a fixed
+ * grid of `window_bytes` of result (a multiple of 4096, <= 65536 - 4096); a window holding more than 1024 descriptors is refused
+ * (V2P_ERR_UNSUPPORTED: pick a smaller window). */
+typedef struct {
+    uint64_t n_haps, n_tx, n_tasks, n_alt;
+    const uint64_t* hap_tx_begin;      /* [n_haps + 1] transcripts of each haplotype                                   */
+    const uint64_t* tx_proteome_off;   /* [n_tx] where the transcript's reference sits in the resident proteome        */
+    const uint32_t* tx_ref_len;        /* [n_tx] its length (bounds of code-0 tasks)                                    */
+    const uint32_t* tx_res_len;        /* [n_tx] result length of the transcript GIR (cells no task covers keep '.')    */
+    const uint64_t* tx_task_begin;     /* [n_tx + 1]                                                                    */
+    const uint64_t* tx_alt_begin;      /* [n_tx + 1]                                                                    */
+    const uint8_t*  code;              /* [n_tasks] task.rs:2-9, un-rebased                                             */
+    const uint32_t* start_pos;         /* [n_tasks]                                                                     */
+    const uint32_t* length;            /* [n_tasks]                                                                     */
+    const uint32_t* start_pos_res;     /* [n_tasks]                                                                     */
+    const uint8_t*  alt;               /* [n_alt] alt tapes of the transcripts back to back, 1 byte per residue         */
+} v2p_txstream;
+/* kernel: 1 = route every chunk to the long-run kernel (<= 512 descriptors per window), 2 = per-block kernel.
+ * On success the batch is finalized (execute / sync / download / digests work as after v2p_batch_finalize).
+ * *build_ms (optional): time of the build kernels alone (HIP events), the stream already on the device. */
+int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t window_bytes, int kernel, float* build_ms);
+/* the image as it sits on the device (for checkers): sizes first (any pointer may be NULL), then the arrays */
+int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, uint64_t* hap_out_begin);
+
 /* Adopt an already packed image (descriptors, chunks, payload, haplotype result ranges),
  * e.g. from the synthetic cohort generator (include/v2p_cohort.h). */
 int v2p_batch_set_packed(v2p_batch* b,

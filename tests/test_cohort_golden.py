@@ -215,3 +215,26 @@ def test_any_chunking_gives_the_same_bytes(built, gpu_ctx, coracle, preset, h0, 
         want = coracle.gir_execute_u8(t, c.ref_tape_u32(h0 + i).astype(np.uint8), hap.alt, np.full(hap.n_res, ord("."), dtype=np.uint8))
         assert np.array_equal(b.download_hap(i), want), (preset, i)
     b.close()
+
+
+@pytest.mark.parametrize("window,kernel", [(4096, 2), (8192, 1)])
+def test_grid_cut_image_equals_oracle(c1, coracle, window, kernel):
+    """Host logic of the grid cutter (ImageBuilder::grid_bytes, the rule the device builder implements): chunk k holds exactly the
+    result bytes [k*W, (k+1)*W); interpreted in numpy the image equals the oracle."""
+    from gen_util import interpret_image
+    cohort, _ = c1
+    n = cohort.n_haplotypes
+    img = cohort.pack_grid(0, n, window, kernel)
+    dst = (img.chunks[:, 1] & np.uint64((1 << 48) - 1)).astype(np.int64)
+    assert np.array_equal(dst, np.arange(dst.size) * window)
+    out = interpret_image(img.desc, img.chunks, cohort.proteome(), img.payload, img.out_bytes)
+    for h in range(n):
+        hap = cohort.haplotype(h)
+        t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+        want = coracle.gir_execute_u8(t, cohort.ref_tape_u32(h).astype(np.uint8), hap.alt, np.full(hap.n_res, ord("."), dtype=np.uint8))
+        a, b = int(img.hap_out_begin[h]), int(img.hap_out_begin[h + 1])
+        assert np.array_equal(out[a:b], want), h
+    stream = cohort.txstream(0, n, n_threads=2)                        # the stream itself: offsets add up, tasks are un-rebased
+    s = stream.struct
+    assert s.n_haps == n and s.hap_tx_begin[n] == s.n_tx and s.tx_task_begin[s.n_tx] == s.n_tasks
+    assert all(s.start_pos_res[s.tx_task_begin[t]] == 0 for t in range(int(s.n_tx)) if s.tx_task_begin[t + 1] > s.tx_task_begin[t])

@@ -1,0 +1,68 @@
+"""step 5 (haplotype_instruction.rs:94-133) and the image packing ON THE DEVICE (csrc/build_kernels.hip).
+The device-built image must equal, byte for byte, the image the host builder cuts on the same result grid, and the result tapes
+must equal the oracle's."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_hap(c, coracle, h):
+    hap = c.haplotype(h)
+    t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+    return coracle.gir_execute_u8(t, c.ref_tape_u32(h).astype(np.uint8), hap.alt, np.full(hap.n_res, ord("."), dtype=np.uint8))
+
+
+@pytest.mark.parametrize("preset,h0,n,window,kernel", [
+    ("C1", 0, 8, 4096, 2), ("C1", 0, 8, 4096, 1), ("C2", 5, 3, 28672, 1), ("C2", 5, 3, 32768, 2),
+    ("C3", 100, 40, 16384, 2), ("C3", 100, 40, 16384, 1), ("C4", 7, 3, 32768, 2), ("C5", 50, 300, 4096, 2)])
+def test_device_built_image_equals_host_grid_image(built, gpu_ctx, coracle, preset, h0, n, window, kernel):
+    from vcf2prot_amd.cohort import Cohort
+    c = Cohort.preset(preset)
+    gpu_ctx.upload_proteome(c.proteome())
+    want = c.pack_grid(h0, h0 + n, window, kernel)
+    stream = c.txstream(h0, h0 + n, n_threads=3)
+    b = gpu_ctx.batch()
+    ms = b.build_on_device(stream, window, kernel)
+    assert ms > 0
+    desc, chunks, hb = b.download_image()
+    assert np.array_equal(hb, want.hap_out_begin)
+    assert desc.size == want.desc.size and np.array_equal(desc, want.desc)
+    # the host table is in result order until finalize() deals it to the XCDs; order both the same way
+    wc = np.ascontiguousarray(want.chunks)
+    gpu_ctx._lib.v2p_order_chunks_for_xcds(wc.ctypes.data, wc.shape[0], want.desc.ctypes.data, want.desc.size, c.proteome().size)
+    assert chunks.shape == wc.shape and np.array_equal(chunks, wc)
+    b.execute()
+    b.sync()
+    for i in range(n):
+        assert np.array_equal(b.download_hap(i), oracle_hap(c, coracle, h0 + i)), (preset, h0 + i)
+    b.close()
+    stream.close()
+
+
+def test_device_build_reports_what_the_reference_would_panic_on(built, gpu_ctx):
+    """A task that reads beyond its transcript (task.rs:43/47) is found by the count pass; nothing is emitted."""
+    from vcf2prot_amd._native import V2PError
+    from vcf2prot_amd.cohort import Cohort
+    c = Cohort.preset("C3")
+    gpu_ctx.upload_proteome(c.proteome())
+    stream = c.txstream(0, 4, n_threads=1)
+    s = stream.struct
+    victim = 1234 % int(s.n_tasks)
+    while s.code[victim] != 0:
+        victim += 1
+    old = s.length[victim]
+    s.length[victim] = 1 << 30
+    b = gpu_ctx.batch()
+    with pytest.raises(V2PError) as e:
+        b.build_on_device(stream, 16384, 2)
+    assert e.value.index == victim
+    s.length[victim] = old
+    b.close()
+    b2 = gpu_ctx.batch()                                   # a window too dense for one chunk is refused, not mis-built
+    dense = Cohort.preset("C5")
+    gpu_ctx.upload_proteome(dense.proteome())
+    st2 = dense.txstream(0, 20, n_threads=1)
+    with pytest.raises(V2PError):
+        b2.build_on_device(st2, 32768, 2)
+    b2.close()

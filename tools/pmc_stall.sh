@@ -2,7 +2,7 @@
 # Memory-side stall counters for the stitch kernel (separate --pmc passes; kernel-trace only).
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-stall}; shift || true
 OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd $ROOT
-run() { n=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -o $n -- python3 bench.py --no-cpu-baseline --no-pcie --no-verify --steps 2 --warmup 1 > $OUT/$n.log 2>&1; }
+run() { n=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -o $n -- python3 bench.py --no-cpu-baseline --no-pcie --no-device-build --no-verify --steps 2 --warmup 1 > $OUT/$n.log 2>&1; }
 run a TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_EA0_WRREQ_sum
 run b TCC_TAG_STALL_sum TCC_IB_STALL_sum TCC_EA0_RDREQ_sum GRBM_GUI_ACTIVE
 run c TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum

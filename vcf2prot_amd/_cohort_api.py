@@ -31,6 +31,15 @@ class PackedImage(ctypes.Structure):
                 ("n_haps", c_uint64), ("n_tasks", c_uint64), ("n_copy_bytes", c_uint64), ("max_chunk_tasks", c_uint64)]
 
 
+class TxStreamBuf(ctypes.Structure):
+    """v2p_txstream_buf (include/v2p_cohort.h) == the field order of v2p_txstream (include/vcf2prot_hip.h)"""
+    _fields_ = [("n_haps", c_uint64), ("n_tx", c_uint64), ("n_tasks", c_uint64), ("n_alt", c_uint64),
+                ("hap_tx_begin", POINTER(c_uint64)), ("tx_proteome_off", POINTER(c_uint64)), ("tx_ref_len", POINTER(c_uint32)),
+                ("tx_res_len", POINTER(c_uint32)), ("tx_task_begin", POINTER(c_uint64)), ("tx_alt_begin", POINTER(c_uint64)),
+                ("code", POINTER(c_uint8)), ("start_pos", POINTER(c_uint32)), ("length", POINTER(c_uint32)),
+                ("start_pos_res", POINTER(c_uint32)), ("alt", POINTER(c_uint8))]
+
+
 class Instruction(ctypes.Structure):
     """instruction.rs:6-15 (include/v2p_step4b.h)"""
     _fields_ = [("code", ctypes.c_char), ("s_state", c_uint8), ("pos_ref", c_uint64), ("pos_res", c_uint64),
@@ -58,4 +67,7 @@ COHORT_API = {
     "v2p_cohort_fasta_headers": (c_uint64, [c_void_p, c_void_p, c_uint64]),
     "v2p_cohort_result_sizes": (c_int, [c_void_p, c_uint64, c_uint64, c_int, c_void_p]),
     "v2p_packed_free": (None, [POINTER(PackedImage)]),
+    "v2p_cohort_txstream": (c_int, [c_void_p, c_uint64, c_uint64, c_int, POINTER(TxStreamBuf)]),
+    "v2p_txstream_free": (None, [POINTER(TxStreamBuf)]),
+    "v2p_cohort_pack_grid": (c_int, [c_void_p, c_uint64, c_uint64, c_uint32, c_int, POINTER(PackedImage)]),
 }

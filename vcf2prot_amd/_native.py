@@ -57,6 +57,8 @@ HIP_API = {
                                   c_void_p, c_uint64, c_void_p, c_uint64, c_uint64]),
     "v2p_batch_add_haplotype": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
                                         c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_uint64]),
+    "v2p_batch_build_on_device": (c_int, [c_void_p, c_void_p, c_uint32, c_int, POINTER(ctypes.c_float)]),
+    "v2p_batch_download_image": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "v2p_batch_set_packed": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_uint64,
                                      c_void_p, c_uint64]),
     "v2p_batch_finalize": (c_int, [c_void_p]),

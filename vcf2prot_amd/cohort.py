@@ -14,7 +14,7 @@ from typing import List, Tuple
 import numpy as np
 
 from . import _native as N
-from ._cohort_api import CohortParams, HapView, PackedImage
+from ._cohort_api import CohortParams, HapView, PackedImage, TxStreamBuf
 
 
 def _arr(ptr, n, dtype):
@@ -170,6 +170,31 @@ class Cohort:
             raise RuntimeError("v2p_cohort_result_sizes failed")
         return out
 
+    def txstream(self, h0: int, h1: int, n_threads: int = 0) -> "TxStream":
+        """Haplotypes [h0, h1) one step before the image: per-transcript GIRs as step 4b returns them (un-rebased), concatenated --
+        the input of Batch.build_on_device."""
+        import os
+        buf = TxStreamBuf()
+        if self._lib.v2p_cohort_txstream(self._h, h0, h1, n_threads or min(64, os.cpu_count() or 1), ctypes.byref(buf)) != 0:
+            raise RuntimeError("v2p_cohort_txstream failed")
+        return TxStream(self._lib, buf)
+
+    def pack_grid(self, h0: int, h1: int, window_bytes: int, kernel: int = 2) -> Packed:
+        """The host image cut on a fixed result grid -- what the device-side builder must reproduce byte for byte."""
+        img = PackedImage()
+        rc = self._lib.v2p_cohort_pack_grid(self._h, h0, h1, window_bytes, kernel, ctypes.byref(img))
+        if rc != 0:
+            raise RuntimeError(f"v2p_cohort_pack_grid failed ({rc})")
+        try:
+            desc = _arr(img.desc, img.n_desc, np.uint64)
+            chunks = (np.ctypeslib.as_array(ctypes.cast(img.chunks, ctypes.POINTER(ctypes.c_uint64)),
+                                            shape=(int(img.n_chunks) * 2,)).astype(np.uint64, copy=True).reshape(-1, 2)
+                      if img.n_chunks else np.zeros((0, 2), dtype=np.uint64))
+            return Packed(desc, chunks, _arr(img.payload, img.n_payload, np.uint8), _arr(img.hap_out_begin, img.n_haps + 1, np.uint64),
+                          int(img.n_tasks), int(img.n_copy_bytes), int(img.max_chunk_tasks))
+        finally:
+            self._lib.v2p_packed_free(ctypes.byref(img))
+
     HEADER_BYTES = 19
 
     def fasta_headers(self) -> np.ndarray:
@@ -198,3 +223,34 @@ class Cohort:
             return Packed(desc, chunks, payload, hb, int(img.n_tasks), int(img.n_copy_bytes), int(img.max_chunk_tasks))
         finally:
             self._lib.v2p_packed_free(ctypes.byref(img))
+
+
+class TxStream:
+    """Owner of a v2p_txstream_buf; `.struct` is what v2p_batch_build_on_device takes."""
+
+    def __init__(self, lib, buf: TxStreamBuf):
+        self._lib, self.struct = lib, buf
+
+    @property
+    def n_tasks(self) -> int:
+        return int(self.struct.n_tasks)
+
+    @property
+    def n_tx(self) -> int:
+        return int(self.struct.n_tx)
+
+    @property
+    def nbytes(self) -> int:
+        s = self.struct
+        return int((s.n_haps + 1) * 8 + s.n_tx * 32 + 16 + s.n_tasks * 13 + s.n_alt)
+
+    def close(self):
+        if self.struct is not None:
+            self._lib.v2p_txstream_free(ctypes.byref(self.struct))
+            self.struct = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

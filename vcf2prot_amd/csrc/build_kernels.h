@@ -1,0 +1,47 @@
+// build_kernels.h -- argument block and host launchers of the device-side image builder (build_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sir_pack.hpp"
+#include "stitch_kernels.h"
+
+namespace v2p {
+
+constexpr uint32_t STATUS_TOO_MANY = 5;     // a grid window holds more descriptors than a chunk may
+
+struct BuildArgs {
+    // the transcript stream (v2p_txstream), on the device
+    uint64_t n_haps, n_tx;
+    const uint64_t* hap_tx_begin;
+    const uint64_t* tx_proteome_off;
+    const uint32_t* tx_ref_len;
+    const uint32_t* tx_res_len;
+    const uint64_t* tx_task_begin;
+    const uint64_t* tx_alt_begin;
+    const uint8_t*  code;
+    const uint32_t* start_pos;
+    const uint32_t* length;
+    const uint32_t* start_pos_res;
+    const uint8_t*  alt;
+    uint64_t proteome_len;
+    uint32_t window;              // result bytes per chunk (grid)
+    int      long_run;            // route every chunk to stitch4_kernel
+    // scans and outputs
+    const uint64_t* tx_res_base;  // [n_tx + 1] exclusive prefix of tx_res_len
+    uint32_t* tx_desc_count;      // [n_tx]
+    const uint64_t* desc_base;    // [n_tx + 1] exclusive prefix of tx_desc_count
+    uint64_t* desc;
+    uint64_t* chunk_first;        // [n_windows] index of the first descriptor of each chunk
+    Chunk*    chunks_tmp;         // [n_windows] in result order
+    uint8_t*  bucket;             // [n_windows] proteome slice of each chunk
+    uint64_t* hap_out_begin;      // [n_haps + 1]
+    uint32_t* meta;               // [4]: any long-run chunk, any with > 256 descriptors, any per-block chunk, most descriptors of a per-block chunk
+    unsigned long long* status;
+};
+
+hipError_t launch_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* tile_scratch, hipStream_t stream);
+// phase 0: count descriptors per transcript (and validate); phase 1: emit descriptors + chunk table + hap_out_begin
+hipError_t launch_build(const BuildArgs& a, uint64_t n_windows, uint64_t n_desc, uint64_t out_bytes, int phase, hipStream_t stream);
+hipError_t launch_xcd_order(const Chunk* in, const uint8_t* bucket, uint64_t n, uint32_t* hist, Chunk* out, hipStream_t stream);
+
+}  // namespace v2p

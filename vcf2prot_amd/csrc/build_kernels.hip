@@ -1,0 +1,327 @@
+// build_kernels.hip -- the device image of a batch, built ON the device.
+//
+// Input: per-transcript GIRs as TranscriptInstruction::get_g_rep returns them (transcript_instructions.rs:335-427), un-rebased,
+// concatenated over the transcripts of every haplotype in result order (v2p_txstream, include/vcf2prot_hip.h).
+// What the reference does on the host in HaplotypeInstruction::get_g_rep (haplotype_instruction.rs:94-133) -- three running sums
+// (ref_counter, alt_counter, res_counter), update_task (:140-158) -- and what sir_pack.hpp's ImageBuilder does after it become:
+//   scan        tx_res_base   = exclusive prefix sum of the transcripts' result lengths (res_counter; haplotypes lie back to back,
+//                               so hap_out_begin[h] = tx_res_base[first transcript of h]); ref_counter disappears (reference tasks
+//                               read the resident proteome at tx_proteome_off), alt_counter is tx_alt_begin (given)
+//   count       one lane per transcript walks its tasks, checks what update_task / Task::execute would panic on, and counts the
+//               descriptors it will emit: a '.' fill for every gap, the task itself, each cut wherever it crosses a multiple
+//               of the grid (chunk k = result bytes [k*W, (k+1)*W): membership is a pure function of result offsets)
+//   scan        desc_base = exclusive prefix sum of those counts
+//   emit        the same walk writes the descriptors; the piece that starts exactly on a grid line records its index as the
+//               first descriptor of that chunk
+//   chunks      one lane per chunk: descriptor count, routing flag, proteome slice of its first reference read
+//   xcd order   stable counting sort of the chunk table into the launch order of sir_pack.hpp's order_chunks_for_xcds
+// Integer/index work only; every kernel streams its arrays once (HBM-bound, tiny next to the stitch kernel).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "build_kernels.h"
+
+namespace v2p {
+
+__device__ __forceinline__ void breport(unsigned long long* status, uint64_t index, uint32_t reason)
+{
+    atomicMin(status, (unsigned long long)((index << 8) | reason));
+}
+
+// ---- exclusive scan u32 -> u64, three passes over 1024-element tiles -------------------------------------------------------
+constexpr uint32_t SCAN_TILE = 1024;
+
+__global__ __launch_bounds__(256) void scan_tile_sums(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ tile_sum)
+{
+    __shared__ uint64_t s[4];
+    const uint64_t base = uint64_t(blockIdx.x) * SCAN_TILE;
+    uint64_t v = 0;
+    for (uint32_t k = 0; k < 4; ++k) { const uint64_t i = base + threadIdx.x * 4u + k; if (i < n) v += in[i]; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63u) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+// one workgroup: tile_sum[i] <- exclusive prefix; tile_sum[n_tiles] <- total
+__global__ __launch_bounds__(1024) void scan_tiles(uint64_t* __restrict__ tile_sum, uint64_t n_tiles)
+{
+    __shared__ uint64_t s_w[16];
+    __shared__ uint64_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint64_t b = 0; b < n_tiles; b += 1024) {
+        const uint64_t i = b + threadIdx.x;
+        const uint64_t x = i < n_tiles ? tile_sum[i] : 0;
+        uint64_t v = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint64_t y = __shfl_up(v, o); if ((threadIdx.x & 63u) >= uint32_t(o)) v += y; }
+        if ((threadIdx.x & 63u) == 63u) s_w[threadIdx.x >> 6] = v;
+        __syncthreads();
+        uint64_t before = s_carry;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += s_w[w];
+        if (i < n_tiles) tile_sum[i] = before + v - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_sum[n_tiles] = s_carry;
+}
+
+__global__ __launch_bounds__(256) void scan_apply(const uint32_t* __restrict__ in, uint64_t n, const uint64_t* __restrict__ tile_sum,
+                                                  uint64_t* __restrict__ out)
+{
+    __shared__ uint64_t s[4];
+    const uint64_t base = uint64_t(blockIdx.x) * SCAN_TILE;
+    uint32_t x[4];
+    uint64_t v = 0;
+    for (uint32_t k = 0; k < 4; ++k) { const uint64_t i = base + threadIdx.x * 4u + k; x[k] = i < n ? in[i] : 0u; v += x[k]; }
+    uint64_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint64_t y = __shfl_up(incl, o); if ((threadIdx.x & 63u) >= uint32_t(o)) incl += y; }
+    if ((threadIdx.x & 63u) == 63u) s[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t before = tile_sum[blockIdx.x];
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += s[w];
+    uint64_t run = before + incl - v;
+    for (uint32_t k = 0; k < 4; ++k) { const uint64_t i = base + threadIdx.x * 4u + k; if (i < n) out[i] = run; run += x[k]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = tile_sum[gridDim.x];      // the total, one past the end
+}
+
+hipError_t launch_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* tile_scratch, hipStream_t stream)
+{
+    const uint64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (n == 0) return hipMemsetAsync(out, 0, 8, stream);
+    hipLaunchKernelGGL(scan_tile_sums, dim3(uint32_t(n_tiles)), dim3(256), 0, stream, in, n, tile_scratch);
+    hipLaunchKernelGGL(scan_tiles, dim3(1), dim3(1024), 0, stream, tile_scratch, n_tiles);
+    hipLaunchKernelGGL(scan_apply, dim3(uint32_t(n_tiles)), dim3(256), 0, stream, in, n, tile_scratch, out);
+    return hipGetLastError();
+}
+
+// ---- the walk over one transcript's tasks: EMIT = false counts descriptors, true writes them -------------------------------
+__device__ __forceinline__ uint32_t pieces(uint64_t dst, uint64_t len, uint32_t W) { return uint32_t((dst + len - 1) / W - dst / W) + 1u; }
+
+template <bool EMIT>
+__device__ __forceinline__ uint32_t put(const BuildArgs& a, uint64_t& k, uint64_t dst, uint64_t len, unsigned space, uint64_t src)
+{
+    // one run of result bytes [dst, dst + len) from (space, src), cut at every multiple of the grid
+    uint32_t n = 0;
+    while (len) {
+        const uint64_t room = a.window - dst % a.window;
+        const uint32_t piece = uint32_t(len < room ? len : room);
+        if (EMIT) {
+            a.desc[k] = (src & SRC_MASK) | (uint64_t(piece & LEN_MASK) << 40) | (uint64_t(space) << 62);
+            if (dst % a.window == 0) a.chunk_first[dst / a.window] = k;
+        }
+        ++k; ++n;
+        if (space == SPACE_IMM) src = piece >= 8 ? 0 : src >> (8 * piece);
+        else if (space != SPACE_FILL) src += piece;
+        dst += piece; len -= piece;
+    }
+    return n;
+}
+
+// sir_pack.hpp's ImageBuilder::stage() as a per-lane state machine: a reference copy, a 1-byte literal and a reference copy going on
+// one residue later fuse into one descriptor when the three lie inside one grid window (long-run routing only).
+struct Staged { uint32_t space; uint64_t src, len, dst; };
+
+template <bool EMIT>
+struct Walker {
+    const BuildArgs& a;
+    uint64_t k;          // next descriptor index (EMIT) / unused
+    uint32_t cnt = 0;    // descriptors so far
+    uint32_t tasks_in_window = 0;
+    Staged st[2];
+    int st_n = 0;
+    __device__ Walker(const BuildArgs& a_, uint64_t k_) : a(a_), k(k_) {}
+    __device__ void out(uint32_t space, uint64_t src, uint64_t len, uint64_t dst) { if (len) cnt += put<EMIT>(a, k, dst, len, space, src); }
+    __device__ void flush() { const int n = st_n; st_n = 0; for (int i = 0; i < n; ++i) out(st[i].space, st[i].src, st[i].len, st[i].dst); }
+    __device__ void fused(uint64_t src, uint32_t len1, uint32_t byte, uint32_t len2, uint64_t dst)
+    {
+        const uint64_t total = uint64_t(len1) + 1u + len2;
+        if (dst / a.window == (dst + total - 1) / a.window) {
+            if (EMIT) {
+                a.desc[k] = SNV3_MARK | (uint64_t(byte & 0xFFu) << 53) | (uint64_t(len2 & 0xFFFu) << 41) | (uint64_t(len1 & 0xFFFu) << 29) | (src & SNV3_MAX_SRC);
+                if (dst % a.window == 0) a.chunk_first[dst / a.window] = k;
+            }
+            ++k; ++cnt;
+        } else {
+            out(SPACE_PROTEOME, src, len1, dst);
+            out(SPACE_IMM, byte, 1, dst + len1);
+            out(SPACE_PROTEOME, src + len1 + 1, len2, dst + len1 + 1);
+        }
+    }
+    __device__ void stage(uint32_t space, uint64_t src, uint64_t len, uint64_t dst)
+    {
+        if (!a.long_run) { out(space, src, len, dst); return; }
+        if (st_n == 2) {
+            const bool fits = st[0].len == 0 ? (len > 0 && src >= 1 && src - 1 + 1 + len <= SNV3_MAX_SRC) : (len == 0 || src == st[0].src + st[0].len + 1);
+            if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && fits) {
+                const Staged r1 = st[0], lit = st[1];
+                st_n = 0;
+                fused(r1.len == 0 ? src - 1 : r1.src, uint32_t(r1.len), uint32_t(lit.src), uint32_t(len), r1.dst);
+                return;
+            }
+            flush();
+        }
+        if (st_n == 1) {
+            if (space == SPACE_IMM && len == 1) { st[1] = Staged{space, src, len, dst}; st_n = 2; return; }
+            flush();
+        }
+        if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && src + len + 1 + SNV3_MAX_LEN <= SNV3_MAX_SRC) { st[0] = Staged{space, src, len, dst}; st_n = 1; return; }
+        out(space, src, len, dst);
+    }
+};
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void walk_kernel(BuildArgs a)
+{
+    const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= a.n_tx) return;
+    const uint64_t base = a.tx_res_base[t], i0 = a.tx_task_begin[t], i1 = a.tx_task_begin[t + 1];
+    const uint64_t alt0 = a.tx_alt_begin[t], n_alt = a.tx_alt_begin[t + 1] - alt0;
+    const uint64_t poff = a.tx_proteome_off[t];
+    const uint32_t ref_len = a.tx_ref_len[t], res_len = a.tx_res_len[t];
+    Walker<EMIT> w(a, EMIT ? a.desc_base[t] : 0);
+    uint64_t cur = 0;
+    bool ok = true;
+    if (!EMIT && poff + ref_len > a.proteome_len) { breport(a.status, i0, STATUS_SRC_OOB); ok = false; }   // transcript outside the resident proteome
+    for (uint64_t i = i0; i < i1 && ok; ++i) {
+        const uint32_t code = a.code[i];
+        const uint64_t sp = a.start_pos[i], ln = a.length[i], sr = a.start_pos_res[i];
+        if (!EMIT) {
+            // haplotype_instruction.rs:154 (stream code), task.rs:43/47 (slices), and the canonical order the image needs
+            uint32_t why = 0;
+            if (code > 1u) why = STATUS_BAD_CODE;
+            else if (sr + ln > res_len) why = STATUS_RES_OOB;
+            else if (sp + ln > (code == 0 ? uint64_t(ref_len) : n_alt)) why = STATUS_SRC_OOB;
+            else if (sr < cur) why = STATUS_NOT_CONTIGUOUS;                  // result ranges overlap or go backwards
+            if (why) { breport(a.status, i, why); ok = false; break; }
+        }
+        if (sr > cur) { w.flush(); w.out(SPACE_FILL, 0, sr - cur, base + cur); }              // cells no task covers keep '.'
+        if (code == 0) w.stage(SPACE_PROTEOME, poff + sp, ln, base + sr);
+        else if (ln >= 1 && ln <= IMM_MAX_BYTES) {                           // short alt payloads travel inside their descriptor
+            uint64_t lit = 0;
+            for (uint32_t q = 0; q < ln; ++q) lit |= uint64_t(a.alt[alt0 + sp + q]) << (8 * q);
+            w.stage(SPACE_IMM, lit, ln, base + sr);
+        } else w.stage(SPACE_PAYLOAD, alt0 + sp, ln, base + sr);
+        cur = sr + ln;
+    }
+    w.flush();
+    if (ok && cur < res_len) w.out(SPACE_FILL, 0, res_len - cur, base + cur);
+    if (!EMIT) a.tx_desc_count[t] = ok ? w.cnt : 0u;
+}
+
+// ---- chunk table on the grid ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chunk_kernel(BuildArgs a, uint64_t n_windows, uint64_t n_desc, uint64_t out_bytes)
+{
+    const uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k <= a.n_haps) a.hap_out_begin[k] = k < a.n_haps ? a.tx_res_base[a.hap_tx_begin[k]] : out_bytes;   // res_counter at the haplotype's first transcript
+    if (k >= n_windows) return;
+    const uint64_t tb = a.chunk_first[k];
+    const uint64_t tb_next = k + 1 < n_windows ? a.chunk_first[k + 1] : n_desc;
+    const uint64_t n = tb_next - tb;
+    if (n > CHUNK_TASKS_DEEP) { breport(a.status, tb, STATUS_TOO_MANY); return; }   // too many descriptors in one window: pick a smaller grid
+    // tasks of the window (a fused substitution is up to three) and the proteome slice of its first reference read
+    // (order_chunks_for_xcds looks at the first six descriptors)
+    uint64_t key = 0, tasks = 0;
+    bool have_key = false;
+    for (uint32_t q = 0; q < n; ++q) {
+        const uint64_t d = a.desc[tb + q];
+        const bool snv = (d & SNV3_MARK) == SNV3_MARK;
+        tasks += snv ? (((d >> 29) & 0xFFFu) ? 1u : 0u) + 1u + (((d >> 41) & 0xFFFu) ? 1u : 0u) : 1u;
+        if (!have_key && q < 6u) {
+            const uint64_t src = snv ? (d & SNV3_MAX_SRC) : (d & SRC_MASK);
+            if ((snv || (d >> 62) == SPACE_PROTEOME) && src < a.proteome_len) { key = src; have_key = true; }
+        }
+    }
+    if (a.long_run && tasks > 2u * CHUNK_TASKS) { breport(a.status, tb, STATUS_TOO_MANY); return; }
+    uint64_t flags = 0;
+    if (a.long_run) flags = CHUNK_LONG | (tasks > CHUNK_TASKS ? CHUNK_LONG2 : 0ull);
+    a.chunks_tmp[k] = Chunk{tb, (k * a.window) | (n << 48) | flags};
+    const uint64_t per = (a.proteome_len + 7) / 8;
+    const uint64_t bk = per ? key / per : 0;
+    a.bucket[k] = uint8_t(bk < 8 ? bk : 7);
+    // what the launcher needs to know about the table
+    if (a.long_run) { atomicOr(&a.meta[0], 1u); if (tasks > CHUNK_TASKS) atomicOr(&a.meta[1], 1u); }
+    else { atomicOr(&a.meta[2], 1u); atomicMax(&a.meta[3], uint32_t(n)); }
+}
+
+// ---- XCD-aware order: entry 8j + x = j-th chunk of slice x (stable) ---------------------------------------------------------
+__global__ __launch_bounds__(256) void xcd_hist_kernel(const uint8_t* __restrict__ bucket, uint64_t n, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t s[8];
+    if (threadIdx.x < 8) s[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t k = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    if (k < n) atomicAdd(&s[bucket[k]], 1u);
+    __syncthreads();
+    if (threadIdx.x < 8) hist[uint64_t(blockIdx.x) * 8u + threadIdx.x] = s[threadIdx.x];
+}
+
+// one workgroup of 8 lanes x ...: exclusive prefix of each slice's counts over the blocks; totals behind the last block
+__global__ __launch_bounds__(64) void xcd_scan_kernel(uint32_t* __restrict__ hist, uint64_t n_blocks)
+{
+    const uint32_t x = threadIdx.x;
+    if (x >= 8) return;
+    uint32_t run = 0;
+    for (uint64_t b = 0; b < n_blocks; ++b) { const uint32_t c = hist[b * 8u + x]; hist[b * 8u + x] = run; run += c; }
+    hist[n_blocks * 8u + x] = run;
+}
+
+__global__ __launch_bounds__(256) void xcd_scatter_kernel(const Chunk* __restrict__ in, const uint8_t* __restrict__ bucket, uint64_t n,
+                                                          const uint32_t* __restrict__ hist, uint64_t n_blocks, Chunk* __restrict__ out)
+{
+    __shared__ uint32_t s_wave[4][8];
+    const uint64_t k = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const bool live = k < n;
+    const uint32_t x = live ? bucket[k] : 8u;
+    // rank inside the block among the chunks of the same slice: ballot per slice
+    uint32_t in_wave = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 8; ++q) {
+        const unsigned long long m = __ballot(x == q);
+        if (x == q) in_wave = uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+        if (lane == 0) s_wave[wid][q] = uint32_t(__popcll(m));
+    }
+    __syncthreads();
+    if (!live) return;
+    uint32_t r = hist[uint64_t(blockIdx.x) * 8u + x] + in_wave;
+    for (uint32_t w = 0; w < wid; ++w) r += s_wave[w][x];
+    // position of (rank r, slice x) in rank-major order: every slice contributes min(count, r) entries before rank r, and the
+    // slices below x that still have a rank-r entry come first
+    uint64_t pos = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 8; ++q) {
+        const uint32_t c = hist[n_blocks * 8u + q];
+        pos += c < r ? c : r;
+        if (q < x && c > r) ++pos;
+    }
+    out[pos] = in[k];
+}
+
+hipError_t launch_build(const BuildArgs& a, uint64_t n_windows, uint64_t n_desc, uint64_t out_bytes, int phase, hipStream_t stream)
+{
+    const uint32_t tx_blocks = uint32_t((a.n_tx + 255) / 256);
+    if (phase == 0) {                       // count
+        if (a.n_tx) hipLaunchKernelGGL(walk_kernel<false>, dim3(tx_blocks), dim3(256), 0, stream, a);
+    } else if (phase == 1) {                // emit + chunk table
+        if (a.n_tx) hipLaunchKernelGGL(walk_kernel<true>, dim3(tx_blocks), dim3(256), 0, stream, a);
+        const uint64_t m = n_windows > a.n_haps + 1 ? n_windows : a.n_haps + 1;
+        hipLaunchKernelGGL(chunk_kernel, dim3(uint32_t((m + 255) / 256)), dim3(256), 0, stream, a, n_windows, n_desc, out_bytes);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_xcd_order(const Chunk* in, const uint8_t* bucket, uint64_t n, uint32_t* hist, Chunk* out, hipStream_t stream)
+{
+    const uint64_t n_blocks = (n + 255) / 256;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(xcd_hist_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, stream, bucket, n, hist);
+    hipLaunchKernelGGL(xcd_scan_kernel, dim3(1), dim3(64), 0, stream, hist, n_blocks);
+    hipLaunchKernelGGL(xcd_scatter_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, stream, in, bucket, n, hist, n_blocks, out);
+    return hipGetLastError();
+}
+
+}  // namespace v2p

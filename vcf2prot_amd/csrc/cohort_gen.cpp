@@ -550,6 +550,138 @@ int v2p_cohort_result_sizes(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n
     return 0;
 }
 
+int v2p_cohort_txstream(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads, v2p_txstream_buf* out)
+{
+    if (!c || !out || h1 < h0 || h1 > v2p_cohort_n_haplotypes(c)) return -1;
+    memset(out, 0, sizeof *out);
+    const uint64_t n = h1 - h0;
+    if (n_threads < 1) n_threads = 1;
+    if (uint64_t(n_threads) > n && n) n_threads = int(n);
+    struct Part {
+        std::vector<uint64_t> hap_ntx, tx_off; std::vector<uint32_t> tx_ref, tx_res, tx_ntask, tx_nalt;
+        std::vector<uint8_t> code, alt; std::vector<uint32_t> sp, ln, sr;
+    };
+    std::vector<Part> parts(size_t(n_threads ? n_threads : 1));
+    auto work = [&](int w) {
+        Part& p = parts[size_t(w)];
+        const uint64_t a = h0 + n * uint64_t(w) / uint64_t(n_threads), e = h0 + n * uint64_t(w + 1) / uint64_t(n_threads);
+        const v2p_cohort_params& cp = c->p;
+        const uint32_t T = cp.n_transcripts;
+        std::vector<uint32_t> picked;
+        std::vector<Alteration> alts;
+        std::vector<uint8_t> tape;
+        for (uint64_t hap = a; hap < e; ++hap) {                       // the draws of generate_into(), transcript by transcript
+            Rng rng(cp.seed_cohort, hap);
+            picked.clear();
+            const bool empty = cp.p_empty_hap > 0 && rng.uniform() < cp.p_empty_hap;
+            if (!empty) {
+                if (cp.altered_per_hap == 0 || cp.altered_per_hap >= T) { picked.resize(T); for (uint32_t t = 0; t < T; ++t) picked[t] = t; }
+                else { uint32_t need = cp.altered_per_hap; for (uint32_t t = 0; t < T && need; ++t) if (rng.below(T - t) < need) { picked.push_back(t); --need; } }
+            }
+            p.hap_ntx.push_back(picked.size());
+            for (uint32_t t : picked) {
+                const uint32_t R = uint32_t(c->tx_off[t + 1] - c->tx_off[t]);
+                draw_alterations(*c, rng, c->proteome.data() + c->tx_off[t], R, alts);
+                tape.clear();
+                const size_t task0 = p.code.size();
+                auto sink = [&](uint8_t code, uint64_t sp, uint64_t len, uint64_t sr) {   // ref_counter = res_counter = 0, own alt tape
+                    p.code.push_back(code); p.sp.push_back(uint32_t(sp)); p.ln.push_back(uint32_t(len)); p.sr.push_back(uint32_t(sr));
+                };
+                const uint64_t res_len = emit_transcript(alts, R, tape, 0, 0, sink);
+                p.tx_off.push_back(c->tx_off[t]); p.tx_ref.push_back(R); p.tx_res.push_back(uint32_t(res_len));
+                p.tx_ntask.push_back(uint32_t(p.code.size() - task0)); p.tx_nalt.push_back(uint32_t(tape.size()));
+                p.alt.insert(p.alt.end(), tape.begin(), tape.end());
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int w = 1; w < n_threads; ++w) th.emplace_back(work, w);
+    work(0);
+    for (auto& t : th) t.join();
+    uint64_t ntx = 0, ntask = 0, nalt = 0;
+    for (auto& p : parts) { ntx += p.tx_off.size(); ntask += p.code.size(); nalt += p.alt.size(); }
+    out->n_haps = n; out->n_tx = ntx; out->n_tasks = ntask; out->n_alt = nalt;
+    auto A = [](uint64_t count, size_t sz) { return malloc((count ? count : 1) * sz); };
+    out->hap_tx_begin = (uint64_t*)A(n + 1, 8); out->tx_proteome_off = (uint64_t*)A(ntx, 8); out->tx_ref_len = (uint32_t*)A(ntx, 4);
+    out->tx_res_len = (uint32_t*)A(ntx, 4); out->tx_task_begin = (uint64_t*)A(ntx + 1, 8); out->tx_alt_begin = (uint64_t*)A(ntx + 1, 8);
+    out->code = (uint8_t*)A(ntask, 1); out->start_pos = (uint32_t*)A(ntask, 4); out->length = (uint32_t*)A(ntask, 4);
+    out->start_pos_res = (uint32_t*)A(ntask, 4); out->alt = (uint8_t*)A(nalt, 1);
+    if (!out->hap_tx_begin || !out->tx_proteome_off || !out->tx_ref_len || !out->tx_res_len || !out->tx_task_begin || !out->tx_alt_begin ||
+        !out->code || !out->start_pos || !out->length || !out->start_pos_res || !out->alt) { v2p_txstream_free(out); return -2; }
+    uint64_t hx = 0, tx = 0, tk = 0, al = 0;
+    out->hap_tx_begin[0] = 0;
+    for (auto& p : parts) {
+        for (uint64_t k : p.hap_ntx) { out->hap_tx_begin[hx + 1] = out->hap_tx_begin[hx] + k; ++hx; }
+        for (size_t i = 0; i < p.tx_off.size(); ++i) {
+            out->tx_proteome_off[tx] = p.tx_off[i]; out->tx_ref_len[tx] = p.tx_ref[i]; out->tx_res_len[tx] = p.tx_res[i];
+            out->tx_task_begin[tx] = tk; out->tx_alt_begin[tx] = al;
+            tk += p.tx_ntask[i]; al += p.tx_nalt[i]; ++tx;
+        }
+    }
+    out->tx_task_begin[ntx] = tk; out->tx_alt_begin[ntx] = al;
+    tk = 0; al = 0;
+    for (auto& p : parts) {
+        if (!p.code.empty()) {
+            memcpy(out->code + tk, p.code.data(), p.code.size());
+            memcpy(out->start_pos + tk, p.sp.data(), p.sp.size() * 4); memcpy(out->length + tk, p.ln.data(), p.ln.size() * 4);
+            memcpy(out->start_pos_res + tk, p.sr.data(), p.sr.size() * 4);
+        }
+        if (!p.alt.empty()) memcpy(out->alt + al, p.alt.data(), p.alt.size());
+        tk += p.code.size(); al += p.alt.size();
+    }
+    return 0;
+}
+
+void v2p_txstream_free(v2p_txstream_buf* s)
+{
+    if (!s) return;
+    free(s->hap_tx_begin); free(s->tx_proteome_off); free(s->tx_ref_len); free(s->tx_res_len); free(s->tx_task_begin); free(s->tx_alt_begin);
+    free(s->code); free(s->start_pos); free(s->length); free(s->start_pos_res); free(s->alt);
+    memset(s, 0, sizeof *s);
+}
+
+// The host image the device builder must reproduce: the transcript stream through ImageBuilder's step-5 folding with grid cutting.
+int v2p_cohort_pack_grid(const v2p_cohort* c, uint64_t h0, uint64_t h1, uint32_t window_bytes, int kernel, v2p_packed_image* out)
+{
+    if (!c || !out || h1 < h0 || window_bytes == 0 || window_bytes % 4096u) return -1;
+    memset(out, 0, sizeof *out);
+    v2p_txstream_buf s;
+    int rc = v2p_cohort_txstream(c, h0, h1, 8, &s);
+    if (rc) return rc;
+    v2p::ImageBuilder im;
+    im.grid_bytes = window_bytes; im.kernel_choice = kernel == 1 ? 1 : 2; im.adaptive_tasks = false;
+    im.payload.assign(s.alt, s.alt + s.n_alt);                        // the alt tapes ARE the payload arena
+    for (uint64_t h = 0; h < s.n_haps && rc == 0; ++h) {
+        uint64_t res = 0;                                             // res_counter of haplotype_instruction.rs:90,132
+        for (uint64_t t = s.hap_tx_begin[h]; t < s.hap_tx_begin[h + 1] && rc == 0; ++t) {
+            const uint64_t n_res = res + s.tx_res_len[t];
+            for (uint64_t i = s.tx_task_begin[t]; i < s.tx_task_begin[t + 1] && rc == 0; ++i) {
+                if (s.code[i] == 0) rc = im.add_task(v2p::SPACE_PROTEOME, s.tx_proteome_off[t] + s.start_pos[i], s.length[i], res + s.start_pos_res[i], n_res);
+                else rc = im.add_task(v2p::SPACE_PAYLOAD, s.tx_alt_begin[t] + s.start_pos[i], s.length[i], res + s.start_pos_res[i], n_res);
+            }
+            im.fill_to(n_res);
+            res = n_res;
+        }
+        im.end_haplotype(res);
+    }
+    im.finish();
+    v2p_txstream_free(&s);
+    if (rc) return rc;
+    out->n_desc = im.desc.size(); out->n_chunks = im.chunks.size(); out->n_payload = im.payload.size(); out->n_haps = im.n_haplotypes();
+    out->desc = static_cast<uint64_t*>(malloc((out->n_desc ? out->n_desc : 1) * 8));
+    out->chunks = static_cast<v2p_chunk*>(malloc((out->n_chunks ? out->n_chunks : 1) * sizeof(v2p_chunk)));
+    out->payload = static_cast<uint8_t*>(malloc(out->n_payload ? out->n_payload : 1));
+    out->hap_out_begin = static_cast<uint64_t*>(malloc((out->n_haps + 1) * 8));
+    if (!out->desc || !out->chunks || !out->payload || !out->hap_out_begin) { v2p_packed_free(out); return -2; }
+    memcpy(out->desc, im.desc.data(), out->n_desc * 8);
+    memcpy(out->chunks, im.chunks.data(), out->n_chunks * sizeof(v2p_chunk));
+    if (out->n_payload) memcpy(out->payload, im.payload.data(), out->n_payload);
+    memcpy(out->hap_out_begin, im.hap_out_begin.data(), (out->n_haps + 1) * 8);
+    out->n_tasks = im.n_ref_tasks; out->n_copy_bytes = im.n_copy_bytes;
+    out->max_chunk_tasks = im.max_chunk_tasks > im.max_long_tasks ? im.max_chunk_tasks : im.max_long_tasks;
+    return 0;
+}
+
 uint64_t v2p_cohort_fasta_headers(const v2p_cohort* c, uint8_t* out, uint64_t cap)
 {
     if (!c) return 0;

@@ -122,6 +122,9 @@ public:
     int kernel_choice = 0;            // 0: undecided (adaptive images decide at their first chunk); 1: every chunk of <= 512 tasks long-run; 2: per-block kernel only, no fusion
     uint32_t soft_window = 8;         // tasks before the hard limit at which a chunk starts looking for its cut
     bool inline_payload = true;       // payload tasks of <= IMM_MAX_BYTES bytes become immediate descriptors
+    uint32_t grid_bytes = 0;          // != 0: GRID cutting -- chunk k holds exactly the result bytes [k*grid, (k+1)*grid) (a multiple of 4 KiB; tasks
+                                      // that straddle a grid line are split, zero-length tasks and fusion are dropped).  Chunk membership is then a pure
+                                      // function of result offsets, which is what the device-side image builder (build_kernels.hip) computes in parallel
     bool fuse_snv = true;             // reference copy + 1-byte literal + reference copy going on one residue later -> one descriptor
     uint64_t n_fused = 0;             // fused substitutions in the image
 
@@ -130,7 +133,7 @@ public:
         desc.clear(); chunks.clear(); payload.clear(); hap_out_begin.assign(1, 0);
         n_copy_bytes = n_ref_tasks = n_fused = n_long_chunks = 0;
         chunk_tasks = CHUNK_TASKS; adaptive_tasks = true; chunk_bytes = CHUNK_BYTES_LONG; adaptive_bytes = true; cut_align = CUT_ALIGN;
-        max_chunk_tasks = max_long_tasks = 0; soft_window = 8; inline_payload = true; fuse_snv = true; kernel_choice = 0;
+        max_chunk_tasks = max_long_tasks = 0; soft_window = 8; inline_payload = true; fuse_snv = true; kernel_choice = 0; grid_bytes = 0;
         cursor_ = extra_ = arena_cursor_ = open_begin_ = open_dst_ = 0;
         open_n_ = open_bytes_ = open_desc_ = 0; open_fused_ = false; st_n_ = 0;
     }
@@ -171,12 +174,14 @@ public:
     // placed between the tasks; they advance the arena but not the tape cursor.
     void add_literal(unsigned space, uint64_t src, uint32_t len) { flush(); emit(space, src, len); extra_ += len; }
     // '.'-fill the result tape up to `dst` (cells no task covers before a record ends)
-    void fill_to(uint64_t dst) { if (dst > cursor_) { flush(); emit(SPACE_FILL, 0, dst - cursor_); cursor_ = dst; } }
+    // (also the end of a transcript: tasks held back for fusion never pair up with the next transcript's)
+    void fill_to(uint64_t dst) { flush(); if (dst > cursor_) { emit(SPACE_FILL, 0, dst - cursor_); cursor_ = dst; } }
     // Close the open chunk; call once after the last haplotype.
     void finish() { flush(); close_chunk(); }
 
     // Raw append of one canonical descriptor (tasks staged for fusion must have been flushed).
     void emit(unsigned space, uint64_t src, uint64_t len) {
+        if (grid_bytes) { emit_grid(space, src, len); return; }
         if (len == 0) { push(space, src, 0); return; }
         while (len) {
             uint32_t piece = uint32_t(len < chunk_bytes ? len : chunk_bytes);
@@ -206,6 +211,17 @@ private:
     int st_n_ = 0;
 
     bool long_run_mode() const { return chunk_tasks <= CHUNK_TASKS; }
+    // GRID cutting: pieces never cross a multiple of grid_bytes; a chunk closes exactly on the grid
+    void emit_grid(unsigned space, uint64_t src, uint64_t len) {
+        while (len) {
+            const uint64_t room = grid_bytes - (arena_cursor_ % grid_bytes);
+            const uint32_t piece = uint32_t(len < room ? len : room);
+            append(space, src, piece);
+            src = advance(space, src, piece);
+            len -= piece;
+            if (arena_cursor_ % grid_bytes == 0) close_chunk();
+        }
+    }
     void flush() {
         const int n = st_n_;
         st_n_ = 0;
@@ -215,7 +231,8 @@ private:
     // descriptor when it fits the open chunk whole; everything else goes in as it is.
     void stage(unsigned space, uint64_t src, uint64_t len) {
         // fusion needs a long-run chunk: decided images only (the first chunk of an adaptive image goes in unfused)
-        if (!fuse_snv || !long_run_mode() || kernel_choice == 2 || (adaptive_tasks && kernel_choice == 0)) { flush(); emit(space, src, len); return; }
+        // (on a grid, fusion is a local rule: long-run routing chosen by the caller, the triple inside one window)
+        if (!fuse_snv || (grid_bytes ? kernel_choice != 1 : (!long_run_mode() || kernel_choice == 2 || (adaptive_tasks && kernel_choice == 0)))) { flush(); emit(space, src, len); return; }
         if (st_n_ == 2) {
             // the copy after the literal goes on one residue behind the copy before it; an EMPTY copy (substitution at the first
             // or last residue: transcript_instructions.rs:734, :648-649) has no source to speak of and fits any neighbour
@@ -237,6 +254,20 @@ private:
     }
     void emit_fused(uint64_t src, uint32_t len1, uint8_t byte, uint32_t len2) {
         const uint32_t total = len1 + 1u + len2, cnt = (len1 ? 1u : 0u) + 1u + (len2 ? 1u : 0u);
+        if (grid_bytes) {
+            if (arena_cursor_ / grid_bytes == (arena_cursor_ + total - 1) / grid_bytes) {
+                if (open_n_ == 0) { open_begin_ = desc.size(); open_dst_ = arena_cursor_; }
+                desc.push_back(pack_snv3(src, len1, len2, byte));
+                ++open_desc_; open_n_ += cnt; open_bytes_ += total; arena_cursor_ += total;
+                ++n_fused; open_fused_ = true;
+                if (arena_cursor_ % grid_bytes == 0) close_chunk();
+            } else {
+                emit(SPACE_PROTEOME, src, len1);
+                emit(SPACE_IMM, byte, 1);
+                emit(SPACE_PROTEOME, src + len1 + 1, len2);
+            }
+            return;
+        }
         const uint32_t soft_tasks = chunk_tasks > soft_window ? chunk_tasks - soft_window : chunk_tasks;
         const uint32_t soft_bytes = chunk_bytes > cut_align ? chunk_bytes - cut_align : chunk_bytes;
         if (open_n_ + cnt <= soft_tasks && open_bytes_ + total <= soft_bytes) {
@@ -260,6 +291,13 @@ private:
         // task, a proteome larger than L2), on 512-task / 32 KiB chunks for C3 (90), on 1024-task / 64 KiB chunks for dense images
         // (C5: 7).  An explicit chunk_tasks (adaptive_tasks off) keeps the choice per chunk: <= 256 tasks -> long-run.
         const uint32_t bpt = open_bytes_ / open_n_;
+        if (grid_bytes) {                              // the caller chose the kernel (1: long-run, else per block); nothing adapts
+            const bool lg = kernel_choice == 1 && open_n_ <= 2u * CHUNK_TASKS;
+            chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_desc_) << 48) | (lg ? CHUNK_LONG : 0ull) | (lg && open_n_ > CHUNK_TASKS ? CHUNK_LONG2 : 0ull)});
+            if (lg) { ++n_long_chunks; if (open_n_ > max_long_tasks) max_long_tasks = open_n_; } else if (open_n_ > max_chunk_tasks) max_chunk_tasks = open_n_;
+            open_n_ = 0; open_bytes_ = 0; open_desc_ = 0; open_fused_ = false;
+            return;
+        }
         if (adaptive_tasks && kernel_choice == 0) kernel_choice = bpt >= LONG_RUN_BYTES_PER_TASK ? 1 : 2;
         const bool to_long = open_fused_ || (open_n_ <= 2u * CHUNK_TASKS && (kernel_choice == 1 || (kernel_choice == 0 && long_run_mode())));
         chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_desc_) << 48) | (to_long ? CHUNK_LONG : 0ull)

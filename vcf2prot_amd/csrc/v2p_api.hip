@@ -14,6 +14,7 @@
 #include "../../include/vcf2prot_hip.h"
 #include "sir_pack.hpp"
 #include "stitch_kernels.h"
+#include "build_kernels.h"
 #include "v2p_ctx_internal.h"
 
 using namespace v2p;
@@ -63,6 +64,7 @@ int reason_to_err(uint32_t reason)
         case STATUS_RES_OOB: return V2P_ERR_RES_OOB;
         case STATUS_SRC_OOB: return V2P_ERR_SRC_OOB;
         case STATUS_NOT_CONTIGUOUS: return V2P_ERR_NOT_CONTIGUOUS;
+        case STATUS_TOO_MANY: return V2P_ERR_UNSUPPORTED;
         default: return V2P_ERR_INVALID_ARG;
     }
 }
@@ -126,6 +128,7 @@ struct v2p_batch {
     uint64_t hap_records = 0;
     uint64_t last_hdr_src = 0; uint32_t last_hdr_len = 0;
     DevBuf d_desc, d_chunks, d_payload, d_out, d_hap, d_digest, d_status;
+    DevBuf d_build;                // the transcript stream and the builder's scratch (v2p_batch_build_on_device)
     uint64_t n_desc = 0, n_chunks = 0, n_payload = 0, out_bytes = 0, n_haps = 0;
     uint32_t max_chunk_tasks = 0;
     int launch_hint = 0;           // stitch_launch_bits() of the chunk table
@@ -436,7 +439,7 @@ void v2p_batch_destroy(v2p_batch* b)
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     b->d_desc.release(); b->d_chunks.release(); b->d_payload.release(); b->d_out.release();
-    b->d_hap.release(); b->d_digest.release(); b->d_status.release();
+    b->d_hap.release(); b->d_digest.release(); b->d_status.release(); b->d_build.release();
     delete b;
 }
 
@@ -644,6 +647,127 @@ int v2p_batch_end_haplotype(v2p_batch* b)
         b->img.add_literal(SPACE_PROTEOME, b->last_hdr_src + b->last_hdr_len - 1, 1);     // line feed of the last record
     b->img.end_haplotype(b->hap_res);
     b->hap_open = false; b->last_hdr_len = 0;
+    return V2P_OK;
+}
+
+// ---- image build on the device ---------------------------------------------------------------------------------------------
+int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t window_bytes, int kernel, float* build_ms)
+{
+    if (!b || !s) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
+    if (b->hap_open || b->img.n_haplotypes()) return c->fail(V2P_ERR_STATE, "the batch already holds host-built haplotypes");
+    if (window_bytes == 0 || window_bytes % 4096u || window_bytes > CHUNK_BYTES - 4080u) return c->fail(V2P_ERR_INVALID_ARG, "window_bytes must be a multiple of 4096, at most 61440");
+    if (kernel == 1 && window_bytes > CHUNK_BYTES_LONG) return c->fail(V2P_ERR_INVALID_ARG, "the long-run kernel takes windows of at most 32768 bytes");
+    if (!s->hap_tx_begin || (s->n_tx && (!s->tx_proteome_off || !s->tx_ref_len || !s->tx_res_len || !s->tx_task_begin || !s->tx_alt_begin)) ||
+        (s->n_tasks && (!s->code || !s->start_pos || !s->length || !s->start_pos_res)) || (s->n_alt && !s->alt))
+        return c->fail(V2P_ERR_INVALID_ARG, "null argument");
+    if (s->hap_tx_begin[s->n_haps] != s->n_tx || (s->n_tx && (s->tx_task_begin[s->n_tx] != s->n_tasks || s->tx_alt_begin[s->n_tx] != s->n_alt)))
+        return c->fail(V2P_ERR_INVALID_ARG, "stream offsets do not add up");
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    const uint64_t n_tx = s->n_tx, n_tk = s->n_tasks, n_h = s->n_haps;
+    const uint64_t n_tiles = (n_tx + 1023) / 1024 + 2;
+    // one device allocation, carved: stream arrays, then scratch
+    auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
+    uint64_t off = 0;
+    auto carve = [&](uint64_t bytes) { const uint64_t o = off; off += up8(bytes); return o; };
+    const uint64_t o_hap = carve((n_h + 1) * 8), o_poff = carve(n_tx * 8), o_rlen = carve(n_tx * 4), o_res = carve(n_tx * 4),
+                   o_tb = carve((n_tx + 1) * 8), o_ab = carve((n_tx + 1) * 8), o_code = carve(n_tk), o_sp = carve(n_tk * 4), o_ln = carve(n_tk * 4),
+                   o_sr = carve(n_tk * 4), o_base = carve((n_tx + 1) * 8), o_cnt = carve(n_tx * 4), o_dbase = carve((n_tx + 1) * 8),
+                   o_tiles = carve(n_tiles * 8), o_meta = carve(16);
+    HIP_TRY(c, b->d_build.ensure(off), "hipMalloc(build)");
+    uint8_t* const d = b->d_build.ptr();
+    HIP_TRY(c, b->d_payload.ensure(s->n_alt), "hipMalloc(alt)");
+#define UP(dst_off, src, bytes, what) do { if (bytes) HIP_TRY(c, hipMemcpyAsync(d + (dst_off), (src), (bytes), hipMemcpyHostToDevice, c->stream), what); } while (0)
+    UP(o_hap, s->hap_tx_begin, (n_h + 1) * 8, "H2D(hap_tx_begin)"); UP(o_poff, s->tx_proteome_off, n_tx * 8, "H2D(tx_proteome_off)");
+    UP(o_rlen, s->tx_ref_len, n_tx * 4, "H2D(tx_ref_len)"); UP(o_res, s->tx_res_len, n_tx * 4, "H2D(tx_res_len)");
+    UP(o_tb, s->tx_task_begin, (n_tx + 1) * 8, "H2D(tx_task_begin)"); UP(o_ab, s->tx_alt_begin, (n_tx + 1) * 8, "H2D(tx_alt_begin)");
+    UP(o_code, s->code, n_tk, "H2D(code)"); UP(o_sp, s->start_pos, n_tk * 4, "H2D(start_pos)"); UP(o_ln, s->length, n_tk * 4, "H2D(length)");
+    UP(o_sr, s->start_pos_res, n_tk * 4, "H2D(start_pos_res)");
+#undef UP
+    if (s->n_alt) HIP_TRY(c, hipMemcpyAsync(b->d_payload.ptr(), s->alt, s->n_alt, hipMemcpyHostToDevice, c->stream), "H2D(alt)");
+    HIP_TRY(c, hipMemsetAsync(d + o_meta, 0, 16, c->stream), "hipMemset(meta)");
+    int rc = init_status(c, b->d_status);
+    if (rc) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(c, hipEventCreate(&e0), "hipEventCreate");
+    HIP_TRY(c, hipEventCreate(&e1), "hipEventCreate");
+    BuildArgs a{};
+    a.n_haps = n_h; a.n_tx = n_tx;
+    a.hap_tx_begin = reinterpret_cast<const uint64_t*>(d + o_hap); a.tx_proteome_off = reinterpret_cast<const uint64_t*>(d + o_poff);
+    a.tx_ref_len = reinterpret_cast<const uint32_t*>(d + o_rlen); a.tx_res_len = reinterpret_cast<const uint32_t*>(d + o_res);
+    a.tx_task_begin = reinterpret_cast<const uint64_t*>(d + o_tb); a.tx_alt_begin = reinterpret_cast<const uint64_t*>(d + o_ab);
+    a.code = d + o_code; a.start_pos = reinterpret_cast<const uint32_t*>(d + o_sp); a.length = reinterpret_cast<const uint32_t*>(d + o_ln);
+    a.start_pos_res = reinterpret_cast<const uint32_t*>(d + o_sr); a.alt = b->d_payload.ptr();
+    a.proteome_len = c->proteome_len; a.window = window_bytes; a.long_run = kernel == 1;
+    a.tx_res_base = reinterpret_cast<const uint64_t*>(d + o_base); a.tx_desc_count = reinterpret_cast<uint32_t*>(d + o_cnt);
+    a.desc_base = reinterpret_cast<const uint64_t*>(d + o_dbase); a.meta = reinterpret_cast<uint32_t*>(d + o_meta);
+    a.status = reinterpret_cast<unsigned long long*>(b->d_status.ptr());
+    // step 5: res_counter as a prefix scan; then count, scan, emit
+    HIP_TRY(c, hipEventRecord(e0, c->stream), "hipEventRecord");
+    HIP_TRY(c, launch_scan_u32(a.tx_res_len, n_tx, reinterpret_cast<uint64_t*>(d + o_base), reinterpret_cast<uint64_t*>(d + o_tiles), c->stream), "launch(scan)");
+    HIP_TRY(c, launch_build(a, 0, 0, 0, 0, c->stream), "launch(count)");
+    HIP_TRY(c, launch_scan_u32(a.tx_desc_count, n_tx, reinterpret_cast<uint64_t*>(d + o_dbase), reinterpret_cast<uint64_t*>(d + o_tiles), c->stream), "launch(scan)");
+    uint64_t totals[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(&totals[0], d + o_base + n_tx * 8, 8, hipMemcpyDeviceToHost, c->stream), "D2H(out_bytes)");
+    HIP_TRY(c, hipMemcpyAsync(&totals[1], d + o_dbase + n_tx * 8, 8, hipMemcpyDeviceToHost, c->stream), "D2H(n_desc)");
+    rc = collect_status(c, b->d_status);                  // what the reference would panic on surfaces here, before anything is emitted
+    if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return rc; }
+    const uint64_t out_bytes = totals[0], n_desc = totals[1];
+    const uint64_t n_windows = (out_bytes + window_bytes - 1) / window_bytes;
+    if (n_windows > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch");
+    DevBuf scratch;                                       // chunk_first, chunks in result order, slices, per-block histograms
+    const uint64_t n_blocks = (n_windows + 255) / 256;
+    const uint64_t s_first = 0, s_tmp = up8(n_windows * 8), s_bucket = s_tmp + up8(n_windows * 16), s_hist = s_bucket + up8(n_windows),
+                   s_end = s_hist + up8((n_blocks + 1) * 8 * 4);
+    HIP_TRY(c, scratch.ensure(s_end), "hipMalloc(build scratch)");
+    HIP_TRY(c, b->d_desc.ensure(n_desc * 8), "hipMalloc(desc)");
+    HIP_TRY(c, b->d_chunks.ensure(n_windows * sizeof(Chunk)), "hipMalloc(chunks)");
+    HIP_TRY(c, b->d_out.ensure((out_bytes + 15) & ~15ull), "hipMalloc(out)");
+    HIP_TRY(c, b->d_hap.ensure((n_h + 1) * 8), "hipMalloc(hap_begin)");
+    HIP_TRY(c, b->d_digest.ensure((n_h ? n_h : 1) * 8), "hipMalloc(digest)");
+    a.desc = reinterpret_cast<uint64_t*>(b->d_desc.ptr());
+    a.chunk_first = reinterpret_cast<uint64_t*>(scratch.ptr() + s_first);
+    a.chunks_tmp = reinterpret_cast<Chunk*>(scratch.ptr() + s_tmp);
+    a.bucket = scratch.ptr() + s_bucket;
+    a.hap_out_begin = reinterpret_cast<uint64_t*>(b->d_hap.ptr());
+    HIP_TRY(c, launch_build(a, n_windows, n_desc, out_bytes, 1, c->stream), "launch(emit)");
+    const bool reorder = !(c->flags & V2P_FLAG_RESULT_ORDER) && n_windows >= 16 && c->proteome_len != 0 && n_desc != 0;
+    if (reorder) HIP_TRY(c, launch_xcd_order(a.chunks_tmp, a.bucket, n_windows, reinterpret_cast<uint32_t*>(scratch.ptr() + s_hist),
+                                             reinterpret_cast<Chunk*>(b->d_chunks.ptr()), c->stream), "launch(xcd order)");
+    else if (n_windows) HIP_TRY(c, hipMemcpyAsync(b->d_chunks.ptr(), a.chunks_tmp, n_windows * sizeof(Chunk), hipMemcpyDeviceToDevice, c->stream), "D2D(chunks)");
+    HIP_TRY(c, hipEventRecord(e1, c->stream), "hipEventRecord");
+    uint32_t meta[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(meta, d + o_meta, 16, hipMemcpyDeviceToHost, c->stream), "D2H(meta)");
+    b->img.hap_out_begin.assign(n_h + 1, 0);
+    HIP_TRY(c, hipMemcpyAsync(b->img.hap_out_begin.data(), b->d_hap.ptr(), (n_h + 1) * 8, hipMemcpyDeviceToHost, c->stream), "D2H(hap_begin)");
+    rc = collect_status(c, b->d_status);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    scratch.release();
+    if (rc) { (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return rc; }
+    if (build_ms) *build_ms = ms;
+    b->n_desc = n_desc; b->n_chunks = n_windows; b->n_payload = s->n_alt; b->out_bytes = out_bytes; b->n_haps = n_h;
+    const int tpt = meta[3] <= 256u ? 1 : (meta[3] <= 512u ? 2 : 4);
+    b->launch_hint = (meta[0] ? 0 : 16) | (meta[2] ? 0 : 32) | ((meta[1] ? 2 : 1) << 6) | (tpt << 8);
+    b->uses_proteome = true;
+    b->finalized = true;
+    return V2P_OK;
+}
+
+int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, uint64_t* hap_out_begin)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    if (desc && b->n_desc) HIP_TRY(c, hipMemcpyAsync(desc, b->d_desc.ptr(), b->n_desc * 8, hipMemcpyDeviceToHost, c->stream), "D2H(desc)");
+    if (chunks && b->n_chunks) HIP_TRY(c, hipMemcpyAsync(chunks, b->d_chunks.ptr(), b->n_chunks * sizeof(Chunk), hipMemcpyDeviceToHost, c->stream), "D2H(chunks)");
+    if (hap_out_begin) HIP_TRY(c, hipMemcpyAsync(hap_out_begin, b->d_hap.ptr(), (b->n_haps + 1) * 8, hipMemcpyDeviceToHost, c->stream), "D2H(hap_begin)");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     return V2P_OK;
 }
 

@@ -233,6 +233,24 @@ class Batch:
     def finalize(self):
         self.ctx._check(self._lib.v2p_batch_finalize(self._h))
 
+    def build_on_device(self, stream, window_bytes: int, kernel: int = 2) -> float:
+        """Step 5 and the image packing as kernels (v2p_batch_build_on_device): `stream` is a cohort.TxStream (or anything with a
+        `.struct` laid out like v2p_txstream).  Returns the time of the build kernels in ms; the batch is finalized."""
+        ms = ctypes.c_float(0.0)
+        self.ctx._check(self._lib.v2p_batch_build_on_device(self._h, ctypes.byref(stream.struct), window_bytes, kernel, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def download_image(self):
+        """(desc, chunks, hap_out_begin) as they sit on the device."""
+        cn = self.counts()
+        n_haps, n_desc, n_chunks = cn["n_haps"], cn["n_desc"], cn["n_chunks"]
+        desc = np.zeros(n_desc, dtype=np.uint64)
+        chunks = np.zeros((n_chunks, 2), dtype=np.uint64)
+        hb = np.zeros(n_haps + 1, dtype=np.uint64)
+        self.ctx._check(self._lib.v2p_batch_download_image(self._h, desc.ctypes.data if n_desc else None,
+                                                           chunks.ctypes.data if n_chunks else None, hb.ctypes.data))
+        return desc, chunks, hb
+
     def execute(self):
         self.ctx._check(self._lib.v2p_batch_execute(self._h))
 
