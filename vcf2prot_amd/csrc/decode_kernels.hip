@@ -337,6 +337,8 @@ __global__ __launch_bounds__(256) void count_kernel(DecodeArgs a, uint32_t sampl
 // groups above and rewrites its blocks as prefixes; the last group leaves the haplotype total in hap_begin[h + 1].
 __global__ __launch_bounds__(256) void scan_groups_kernel(DecodeArgs a, uint32_t n_rowblocks, uint32_t per_group, uint32_t hap_blocks)
 {
+    if (a.status[0] != ~0ull) return;                       // after a failed parse `cnt` was never written: nothing to scan, and nothing that may
+                                                            // overwrite the error the parse reported
     const uint32_t g = blockIdx.x / hap_blocks, h = (blockIdx.x % hap_blocks) * 256u + threadIdx.x;
     const uint32_t n_haps = 2u * a.n_samples;
     if (h >= n_haps) return;
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(256) void scan_groups_kernel(DecodeArgs a, uint32_t
 
 __global__ __launch_bounds__(256) void scan_blocks_kernel(DecodeArgs a, uint32_t n_rowblocks, uint32_t per_group, uint32_t hap_blocks, uint32_t n_groups)
 {
+    if (a.status[0] != ~0ull) return;
     const uint32_t g = blockIdx.x / hap_blocks, h = (blockIdx.x % hap_blocks) * 256u + threadIdx.x;
     const uint32_t n_haps = 2u * a.n_samples;
     if (h >= n_haps) return;
@@ -372,6 +375,10 @@ __global__ __launch_bounds__(256) void scan_blocks_kernel(DecodeArgs a, uint32_t
 // one workgroup: exclusive prefix over the haplotype totals (hap_begin[1..] holds the totals on entry)
 __global__ __launch_bounds__(1024) void scan_haps_kernel(DecodeArgs a)
 {
+    if (a.status[0] != ~0ull) {                             // (the host still wants the overflow words the parse asked for: it may retry)
+        if (threadIdx.x == 0) a.status[1] = *a.ovf_used;
+        return;
+    }
     __shared__ uint64_t part[16];
     __shared__ uint64_t carry;
     const uint32_t n_haps = 2u * a.n_samples, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;

@@ -181,7 +181,9 @@ int v2p_decode_run(v2p_ctx* ctx, const uint8_t* text, uint64_t n_text,
     const uint64_t avg_row = row_bytes / n_records;
     uint32_t parse_threads = avg_row <= 1536 ? 64u : (avg_row <= 3072 ? 128u : 256u);     // a tile = 16 bytes per thread
     int rc = V2P_OK;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    bool done = false;                                  // set only after the emit pass: a retry that runs out of attempts is an error
+    std::string last_reason = "decode: retries exhausted";
+    for (int attempt = 0; attempt < 4 && !done; ++attempt) {
         if (d->d_work) { (void)hipFree(d->d_work); d->d_work = nullptr; }
         const DecodeLayout L = decode_layout(n_records, n_samples, ovf_words);
         DTRY(hipMalloc(reinterpret_cast<void**>(&d->d_work), L.total), "hipMalloc(decode workspace)");
@@ -204,6 +206,7 @@ int v2p_decode_run(v2p_ctx* ctx, const uint8_t* text, uint64_t n_text,
         DTRY(hipStreamSynchronize(st), "hipStreamSynchronize");
         if (status[0] != ~0ull) {
             const uint32_t reason = uint32_t(status[0] & 0xFF);
+            last_reason = std::string("decode: ") + reason_text(reason) + " (after a retry)";
             if (reason == DEC_CAPACITY && status[1] > ovf_words && status[1] < (1ull << 31)) { ovf_words = status[1]; continue; }
             if (reason == DEC_FIELD_TOO_LONG && parse_threads != 256u) { parse_threads = 256u; continue; }     // the narrow kernels look back 1-2 KiB only
             rc = ctx_fail(ctx, reason_to_code(reason), std::string("decode: ") + reason_text(reason) + " at record " +
@@ -218,8 +221,9 @@ int v2p_decode_run(v2p_ctx* ctx, const uint8_t* text, uint64_t n_text,
         DTRY(hipEventRecord(ev[4], st), "hipEventRecord");
         DTRY(hipStreamSynchronize(st), "hipStreamSynchronize");
         for (int k = 0; k < 4; ++k) (void)hipEventElapsedTime(&d->ms[k], ev[k], ev[k + 1]);
-        break;
+        done = true;
     }
+    if (rc == V2P_OK && !done) rc = ctx_fail(ctx, V2P_ERR_UNSUPPORTED, last_reason, -1);     // never hand back a decode whose emit pass did not run
     if (rc != V2P_OK) { d->release(); delete d; return rc; }
     *out = d;
     return V2P_OK;
