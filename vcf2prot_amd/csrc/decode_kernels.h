@@ -15,11 +15,15 @@ enum : uint32_t {
     DEC_CAPACITY = 6
 };
 
-constexpr uint32_t DEC_ROWBLOCK = 64;       // records per row block (count / emit granularity): one wave, lane = record
+constexpr uint32_t DEC_ROWBLOCK = 64;       // records per row block (count / emit granularity)
+constexpr uint32_t DEC_RANGE_HAPS = 6144;   // haplotypes one count / emit workgroup keeps in LDS (48 KiB of 64-bit cursors)
 constexpr uint32_t DEC_SCAN_GROUPS = 64;    // the prefix down the row blocks runs in this many independent groups
 constexpr uint32_t DEC_TILE = 4096;         // text bytes per parse step of a 256-thread workgroup (16 per thread)
-constexpr uint32_t DEC_EMIT_SAMPLES = 32;   // sample columns per emit workgroup
-constexpr uint32_t DEC_MULTI = 0x80000000u; // mask-matrix entry: bit 31 set -> low 31 bits index the multi-word list
+constexpr uint32_t DEC_MULTI = 0x80000000u; // carrier entry: bit 31 set -> low 31 bits index the multi-word list
+
+// One carrier: a (record, sample) whose filtered mask is not empty.  x = sample, y = the first word filtered to the
+// supported consequences, or DEC_MULTI | offset into the multi-word list.
+struct DecCarrier { uint32_t sample, entry; };
 
 struct DecodeArgs {
     const uint8_t*  text;          // 16 readable bytes either side
@@ -33,9 +37,8 @@ struct DecodeArgs {
     const uint32_t* sup_pairs;     // [n_rows]
     const uint32_t* sup_bits;      // bitset over consequence ids
     // workspace
-    uint32_t*       masks;         // [n_rows][mask_stride] filtered first word, or DEC_MULTI | offset into ovf
-    uint32_t        mask_stride;   // n_samples rounded up to 32 entries: every row starts on a 128-byte line
-    uint8_t*        tile_flags;    // [n_rowblocks * ceil(n_samples / 32)] emit tiles that hold multi-word entries
+    DecCarrier*     carriers;      // [n_rows][n_samples] slots; record r uses the first row_nnz[r] of its row, in no particular order
+    uint32_t*       row_nnz;       // [n_rows]
     uint32_t*       cnt;           // [n_rowblocks][2*n_samples] per-block counts, then exclusive prefix down the blocks
     uint32_t*       group_tot;     // [DEC_SCAN_GROUPS][2*n_samples] scratch of the scan
     uint32_t*       ovf;           // multi-word list: {n_words, words...} records
@@ -49,8 +52,8 @@ struct DecodeArgs {
 };
 
 struct DecodeLayout {
-    uint64_t masks_off, cnt_off, group_off, ovf_off, ovf_used_off, flags_off, total;
-    uint32_t n_rowblocks, mask_stride;
+    uint64_t carriers_off, nnz_off, cnt_off, group_off, ovf_off, ovf_used_off, total;
+    uint32_t n_rowblocks;
 };
 DecodeLayout decode_layout(uint64_t n_rows, uint64_t n_samples, uint64_t ovf_words);
 

@@ -4,19 +4,21 @@
 // column, keep the text after its last ':' (text_parser.rs:163-197), read it as one or more 32-bit words
 // (MaskDecoder.rs:33-51), turn bit pairs into consequence indices (MaskDecoder.rs:95-153), index the record's
 // consequence list (vcf_ds.rs:311-327) and keep supported types (vcf_ds.rs:262-292).  Result: per haplotype the list of
-// consequences in record order.  Here the whole table is done in four streaming passes, HBM-bound, no MFMA:
+// consequences in record order.  Here the whole table is done in four passes, no MFMA:
 //
 //   parse   one workgroup per record.  The record's sample columns stream through a two-tile LDS ring, 16 B per lane
 //           per step; tab positions are found with byte SWAR, ranked with a wave64 DPP scan, and lane j then owns the
-//           j-th column that ENDS in the tile: it walks back to the last ':' and parses the words.  Output: one u32
-//           per (record, sample), already filtered to supported consequences.  Multi-word masks (records with more
-//           than 15 consequences) go to a side list.
-//   count   per (64-record block, haplotype) popcounts, coalesced over samples.
+//           j-th column that ENDS in the tile: it walks back to the last ':' and parses the words.  Output: the record's
+//           CARRIERS -- (sample, filtered first word) of every column whose mask is not empty, compacted per wave into
+//           the record's row of the carrier table.  Real cohorts are sparse (a few percent of the columns carry anything),
+//           so the table costs a tenth of the text to write and to read back, where a dense matrix costs two thirds of it.
+//           Multi-word masks (records with more than 15 consequences) go to a side list.
+//   count   one workgroup per 64-record block: LDS histogram of the block's carriers per haplotype.
 //   scan    exclusive prefix down the record blocks per haplotype, then over haplotypes: every (block, haplotype)
 //           knows where its ids go.
-//   emit    a wave owns 64 records x 32 samples, lane = record, the record's 32 entries (one 128-byte line) in
-//           registers; per haplotype column a DPP scan of the popcounts places the ids as one contiguous run.
-//           Tiles with multi-word entries go through a second kernel that transposes them in LDS.
+//   emit    one workgroup per 64-record block with a write cursor per haplotype in LDS.  Records are taken in order;
+//           inside a record every sample appears once, so its carriers are placed in parallel; wave w owns the samples
+//           with (sample & 3) == w, which keeps every cursor inside one wave and the kernel free of barriers.
 #include "decode_kernels.h"
 
 namespace v2p {
@@ -40,13 +42,14 @@ __device__ __forceinline__ void dec_report(unsigned long long* status, uint64_t 
     atomicMin(status, (static_cast<unsigned long long>(field) << 8) | reason);
 }
 
-// 4-bit mask of the bytes of w equal to '\t'
-__device__ __forceinline__ uint32_t tab_bits(uint32_t w)
+// 8-bit mask (<< 7) of the bytes of the word pair (w0, w1) equal to '\t': exact 0x80 flags per byte, then one dot product per
+// word weighs byte k with 2^k
+__device__ __forceinline__ uint32_t tab_bits8(uint32_t w0, uint32_t w1)
 {
-    const uint32_t y = w ^ 0x09090909u;
-    const uint32_t z = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);     // 0x80 in every zero byte of y, exact
-    const uint32_t x = z >> 7;
-    return (x | (x >> 7) | (x >> 14) | (x >> 21)) & 0xFu;
+    const uint32_t y0 = w0 ^ 0x09090909u, y1 = w1 ^ 0x09090909u;
+    const uint32_t z0 = ~(((y0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y0 | 0x7F7F7F7Fu);
+    const uint32_t z1 = ~(((y1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y1 | 0x7F7F7F7Fu);
+    return __builtin_amdgcn_udot4(z1, 0x80402010u, __builtin_amdgcn_udot4(z0, 0x08040201u, 0u, false), false);
 }
 
 // 0x80 in every byte of w that equals the byte replicated in pat, exact
@@ -121,8 +124,10 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
 {
     constexpr uint32_t TILE = BS * 16u, RING = 2u * TILE, RM = RING - 1u, NW = BS / 64u;
     __shared__ __align__(16) uint8_t ring[RING];
-    __shared__ uint16_t tabpos[TILE + 2];
+    __shared__ uint32_t list[TILE + 2];                         // the columns of this step that need parsing: end position | rank << 16
+    __shared__ uint32_t s_nlist;
     __shared__ uint32_t wave_tot[NW];
+    __shared__ uint32_t s_nnz;
 
     const uint32_t row = blockIdx.x;
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
@@ -136,6 +141,8 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
     const uint32_t sup = a.sup_pairs[row];
     const uint64_t field0 = uint64_t(row) * a.n_samples;
     uint32_t fields_before = 0;
+    DecCarrier* const carriers = a.carriers + uint64_t(row) * a.n_samples;
+    if (tid == 0) s_nnz = 0u;                                   // (two barriers before the first append)
 
     auto load_tile = [&](uint32_t t) -> u32x4 {
         const uint32_t qs = t * TILE + tid * 16u;
@@ -153,7 +160,8 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
 
         // tabs among this lane's 16 bytes that belong to the row
         const uint32_t qs = tile0 + tid * 16u;
-        uint32_t tm = tab_bits(cur.x) | (tab_bits(cur.y) << 4) | (tab_bits(cur.z) << 8) | (tab_bits(cur.w) << 12);
+        uint32_t tm = (tab_bits8(cur.x, cur.y) >> 7) | ((tab_bits8(cur.z, cur.w) >> 7) << 8);
+        if (tid == 0) s_nlist = 0u;                                            // (the previous step ended on a barrier)
         {
             const uint32_t lo = q0 > qs ? min(q0 - qs, 16u) : 0u;
             const uint32_t hi = Lq > qs ? min(Lq - qs, 16u) : 0u;
@@ -170,21 +178,39 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
             if (w < wave) wbase += x;
             tile_tabs += x;
         }
+        const uint32_t lo = max(q0, t ? tile0 - TILE : 0u);               // oldest stream position still in the ring
+        // Almost every column of a real cohort carries nothing: its text ends in ":0" or ":.".  Those are settled here with
+        // two byte reads; only the others go on the list that the parser below works through, so the parser's cost scales with
+        // the carriers and not with the columns.
+        auto consider = [&](uint32_t pos, uint32_t rank) {
+            const uint32_t p = tile0 + pos;
+            const uint8_t c1 = rq<RM>(ring, p - 1u), c2 = rq<RM>(ring, p - 2u);
+            const bool work = !(p >= lo + 2u && c2 == ':' && (c1 == '0' || c1 == '.'));
+            const uint64_t wb = __builtin_amdgcn_ballot_w64(work);
+            if (wb) {
+                const uint32_t k = __builtin_amdgcn_mbcnt_hi(uint32_t(wb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(wb), 0u));
+                uint32_t at = 0u;
+                if (work && k == 0u) at = atomicAdd(&s_nlist, uint32_t(__builtin_popcountll(wb)));
+                at = uint32_t(__builtin_amdgcn_readlane(int(at), int(__builtin_ctzll(wb))));
+                if (work) list[at + k] = pos | (rank << 16);
+            }
+        };
         uint32_t slot = wbase + incl - cnt;
         while (tm) {
             const uint32_t b = uint32_t(__builtin_ctz(tm));
             tm &= tm - 1u;
-            tabpos[slot++] = uint16_t(tid * 16u + b);
+            consider(tid * 16u + b, slot++);
         }
         const bool last = (t + 1u == n_tiles);
-        if (last && tid == 0) tabpos[tile_tabs] = uint16_t(Lq - tile0);       // the end of the line closes the last column
+        if (last && tid == 0) consider(Lq - tile0, tile_tabs);                 // the end of the line closes the last column
         const uint32_t n_ends = tile_tabs + (last ? 1u : 0u);
         __syncthreads();
+        const uint32_t n_list = s_nlist;
 
-        const uint32_t lo = max(q0, t ? tile0 - TILE : 0u);               // oldest stream position still in the ring
-        for (uint32_t j = tid; j < n_ends; j += BS) {
-            const uint32_t p = tile0 + tabpos[j];                              // one past the column's last byte
-            const uint32_t f = fields_before + j;
+        for (uint32_t j = tid; j < n_list; j += BS) {
+            const uint32_t le = list[j];
+            const uint32_t p = tile0 + (le & 0xFFFFu);                         // one past the column's last byte
+            const uint32_t f = fields_before + (le >> 16);
             uint32_t q = p, err = 0u, entry = 0u;
             bool colon = false, slow = true;
             if (p >= lo + 8u) {
@@ -292,13 +318,25 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
             }
             if (f >= a.n_samples) err = err ? err : DEC_COLUMNS;
             if (err) dec_report(a.status, field0 + min(f, a.n_samples - 1u), err);
-            if (f < a.n_samples) a.masks[uint64_t(row) * a.mask_stride + f] = err ? 0u : entry;
+            // append the carriers of this step to the record's row: one LDS atomic per wave, order inside a record is free
+            const bool keep = !err && entry != 0u;
+            const uint64_t kb = __builtin_amdgcn_ballot_w64(keep);
+            if (kb) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(kb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(kb), 0u));
+                uint32_t at = 0u;
+                if (keep && rank == 0u) at = atomicAdd(&s_nnz, uint32_t(__builtin_popcountll(kb)));
+                at = uint32_t(__builtin_amdgcn_readlane(int(at), int(__builtin_ctzll(kb))));
+                if (keep) carriers[at + rank] = DecCarrier{f, entry};
+            }
         }
         fields_before += n_ends;
         __syncthreads();
         cur = nxt;
     }
-    if (tid == 0 && fields_before != a.n_samples) dec_report(a.status, field0 + min(fields_before, a.n_samples - 1u), DEC_COLUMNS);
+    if (tid == 0) {
+        a.row_nnz[row] = s_nnz;                                                 // (the loop ends on a barrier)
+        if (fields_before != a.n_samples) dec_report(a.status, field0 + min(fields_before, a.n_samples - 1u), DEC_COLUMNS);
+    }
 }
 
 // counts of one matrix entry for haplotype bit h (0/1)
@@ -312,23 +350,33 @@ __device__ __forceinline__ uint32_t entry_count(uint32_t m, uint32_t h, const ui
 }
 
 // ---------------------------------------------------------------------------------------------------------- count
-__global__ __launch_bounds__(256) void count_kernel(DecodeArgs a, uint32_t sample_blocks)
+// One workgroup per (64-record block, range of DEC_RANGE_HAPS haplotypes): histogram of the block's carriers in LDS.
+__global__ __launch_bounds__(256) void count_kernel(DecodeArgs a, uint32_t n_ranges)
 {
-    if (a.status[0] != ~0ull) return;                                           // a failed parse leaves the matrix incomplete
-    const uint32_t rbk = blockIdx.x / sample_blocks, sb = blockIdx.x % sample_blocks;
-    const uint32_t s = sb * 256u + threadIdx.x;
-    if (s >= a.n_samples) return;
+    extern __shared__ uint32_t hist[];
+    if (a.status[0] != ~0ull) return;                                           // a failed parse leaves the table incomplete
+    const uint32_t rbk = blockIdx.x / n_ranges, rg = blockIdx.x % n_ranges;
+    const uint32_t n_haps = 2u * a.n_samples, h0 = rg * DEC_RANGE_HAPS, hn = min(DEC_RANGE_HAPS, n_haps - h0);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t i = tid; i < hn; i += 256u) hist[i] = 0u;
+    __syncthreads();
     const uint32_t r0 = rbk * DEC_ROWBLOCK, r1 = min(r0 + DEC_ROWBLOCK, a.n_rows);
-    uint32_t c1 = 0, c2 = 0;
-    const uint32_t* m = a.masks + uint64_t(r0) * a.mask_stride + s;
-#pragma unroll 8
-    for (uint32_t r = r0; r < r1; ++r, m += a.mask_stride) {
-        const uint32_t v = *m;
-        if (v & DEC_MULTI) { c1 += entry_count(v, 0, a.ovf); c2 += entry_count(v, 1, a.ovf); }
-        else { c1 += uint32_t(__builtin_popcount(v & 0x55555555u)); c2 += uint32_t(__builtin_popcount(v & 0xAAAAAAAAu)); }
+    for (uint32_t r = r0 + wave; r < r1; r += 4u) {
+        const uint32_t n = a.row_nnz[r];
+        const DecCarrier* e = a.carriers + uint64_t(r) * a.n_samples;
+        for (uint32_t k = lane; k < n; k += 64u) {
+            const DecCarrier v = e[k];
+            const uint32_t h = 2u * v.sample - h0;
+            if (h < hn) {                                                       // (h0 is even: both haplotypes of a sample share a range)
+                const uint32_t c0 = entry_count(v.entry, 0, a.ovf), c1 = entry_count(v.entry, 1, a.ovf);
+                if (c0) atomicAdd(&hist[h], c0);
+                if (c1) atomicAdd(&hist[h + 1u], c1);
+            }
+        }
     }
-    uint2* out = reinterpret_cast<uint2*>(a.cnt + uint64_t(rbk) * 2u * a.n_samples) + s;
-    *out = make_uint2(c1, c2);
+    __syncthreads();
+    uint32_t* out = a.cnt + uint64_t(rbk) * n_haps + h0;
+    for (uint32_t i = tid; i < hn; i += 256u) out[i] = hist[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------- scan
@@ -409,112 +457,76 @@ __global__ __launch_bounds__(1024) void scan_haps_kernel(DecodeArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------- emit
-// the tiles the register kernel below leaves alone (they hold multi-word entries): transposed through LDS
-__global__ __launch_bounds__(256) void emit_generic_kernel(DecodeArgs a, uint32_t sample_blocks)
+// One workgroup per (64-record block, haplotype range), a 64-bit write cursor per haplotype in LDS.  All four waves walk
+// the block's records in order and read every carrier; wave w places those with (sample & 3) == w, so a cursor is only
+// ever touched by one wave, whose LDS accesses are ordered: no barrier after the set-up.
+__global__ __launch_bounds__(256) void emit_kernel(DecodeArgs a, uint32_t n_ranges)
 {
-    constexpr uint32_t TS = DEC_EMIT_SAMPLES, STRIDE = TS + 1u;
-    if (a.status[0] != ~0ull || !a.tile_flags[blockIdx.x]) return;
-    __shared__ uint32_t tile[DEC_ROWBLOCK * STRIDE];
-    __shared__ uint32_t csq0[DEC_ROWBLOCK];
-    const uint32_t rbk = blockIdx.x / sample_blocks, sb = blockIdx.x % sample_blocks;
-    const uint32_t r0 = rbk * DEC_ROWBLOCK, s0 = sb * TS;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t n_haps = 2u * a.n_samples;
+    extern __shared__ __align__(16) uint64_t cursor[];
+    typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+    constexpr uint32_t G = 8u;                                                  // records whose first 128 carriers are in flight together
+    if (a.status[0] != ~0ull) return;
+    const uint32_t rbk = blockIdx.x / n_ranges, rg = blockIdx.x % n_ranges;
+    const uint32_t n_haps = 2u * a.n_samples, h0 = rg * DEC_RANGE_HAPS, hn = min(DEC_RANGE_HAPS, n_haps - h0);
     if (a.hap_begin[n_haps] > a.ids_capacity) return;
-    if (tid < DEC_ROWBLOCK) csq0[tid] = (r0 + tid < a.n_rows) ? a.csq_begin[r0 + tid] : 0u;
-    for (uint32_t i = tid; i < DEC_ROWBLOCK * TS; i += 256u) {
-        const uint32_t r = i / TS, sc = i % TS;
-        uint32_t v = 0u;
-        if (r0 + r < a.n_rows && s0 + sc < a.n_samples) v = a.masks[uint64_t(r0 + r) * a.mask_stride + s0 + sc];
-        tile[r * STRIDE + sc] = v;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6)));
+    {
+        const uint32_t* c = a.cnt + uint64_t(rbk) * n_haps + h0;
+        for (uint32_t i = tid; i < hn; i += 256u) cursor[i] = a.hap_begin[h0 + i] + c[i];
     }
     __syncthreads();
-    for (uint32_t hc = wave; hc < 2u * TS; hc += 4u) {
-        const uint32_t sc = hc >> 1, h = hc & 1u, s = s0 + sc;
-        if (s >= a.n_samples) continue;
-        const uint32_t hap = 2u * s + h;
-        uint64_t out = a.hap_begin[hap] + a.cnt[uint64_t(rbk) * n_haps + hap];
+    const uint32_t r0 = rbk * DEC_ROWBLOCK, r1 = min(r0 + DEC_ROWBLOCK, a.n_rows);
+    const DecCarrier none{~0u, 0u};
+
+    auto place = [&](const DecCarrier v, uint32_t id0) {
+        const uint32_t h = 2u * v.sample - h0;                                  // (h0 is even: a sample's two cursors are one 16-byte pair)
+        if ((v.sample & 3u) != wave || v.sample == ~0u || h >= hn) return;
+        const uint32_t c0 = entry_count(v.entry, 0, a.ovf), c1 = entry_count(v.entry, 1, a.ovf);
+        u64x2* cp = reinterpret_cast<u64x2*>(cursor + h);
+        const u64x2 at = *cp;
+        u64x2 nx = at;
+        nx.x += c0; nx.y += c1;
+        *cp = nx;
 #pragma unroll
-        for (uint32_t g = 0; g < DEC_ROWBLOCK / 64u; ++g) {
-            const uint32_t r = g * 64u + lane;
-            const uint32_t m = tile[r * STRIDE + sc];
-            const uint32_t c = entry_count(m, h, a.ovf);
-            uint32_t excl, tot;
-            if (!__builtin_amdgcn_ballot_w64(c > 1u)) {                        // the usual case: one bit per record at most
-                const uint64_t b = __builtin_amdgcn_ballot_w64(c != 0u);
-                excl = __builtin_amdgcn_mbcnt_hi(uint32_t(b >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(b), 0u));
-                tot = uint32_t(__builtin_popcountll(b));
+        for (uint32_t hb = 0; hb < 2u; ++hb) {
+            uint32_t* o = a.ids + (hb ? at.y : at.x);
+            if (!(v.entry & DEC_MULTI)) {
+                uint32_t bits = (v.entry >> hb) & 0x55555555u;
+                while (bits) { const uint32_t b = uint32_t(__builtin_ctz(bits)); bits &= bits - 1u; *o++ = id0 + (b >> 1); }
             } else {
-                const uint32_t incl = dec_wave_incl_scan(c);
-                excl = incl - c;
-                tot = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
-            }
-            if (c) {
-                uint32_t* o = a.ids + out + excl;
-                const uint32_t id0 = csq0[r];
-                if (!(m & DEC_MULTI)) {
-                    uint32_t bits = (m >> h) & 0x55555555u;
-                    while (bits) { const uint32_t b = uint32_t(__builtin_ctz(bits)); bits &= bits - 1u; *o++ = id0 + (b >> 1); }
-                } else {
-                    const uint32_t off = m & ~DEC_MULTI, n = a.ovf[off];
-                    for (uint32_t k = 0; k < n; ++k) {
-                        uint32_t bits = (a.ovf[off + 1u + k] >> h) & 0x55555555u;
-                        while (bits) { const uint32_t b = uint32_t(__builtin_ctz(bits)); bits &= bits - 1u; *o++ = id0 + 15u * k + (b >> 1); }
-                    }
+                const uint32_t off = v.entry & ~DEC_MULTI, nw = a.ovf[off];
+                for (uint32_t w = 0; w < nw; ++w) {
+                    uint32_t bits = (a.ovf[off + 1u + w] >> hb) & 0x55555555u;
+                    while (bits) { const uint32_t b = uint32_t(__builtin_ctz(bits)); bits &= bits - 1u; *o++ = id0 + 15u * w + (b >> 1); }
                 }
             }
-            out += tot;
         }
-    }
-}
+    };
 
-// A wave owns 64 records x 32 samples, lane = record.  The lane keeps its record's 32 entries (one 128-byte line) in
-// registers, so a haplotype column is a DPP scan over the wave: no transposition, no LDS, no barrier.
-__global__ __launch_bounds__(256, 4) void emit_kernel(DecodeArgs a, uint32_t sample_blocks, uint32_t n_rowblocks)
-{
-    constexpr uint32_t TS = DEC_EMIT_SAMPLES;
-    static_assert(TS == 32u && DEC_ROWBLOCK == 64u, "one 128-byte line per lane, one record block per wave");
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6)));
-    const uint32_t rbk = (blockIdx.x / sample_blocks) * 4u + wave, sb = blockIdx.x % sample_blocks;
-    if (rbk >= n_rowblocks || a.status[0] != ~0ull) return;
-    const uint32_t s0 = sb * TS;
-    const uint32_t n_haps = 2u * a.n_samples;
-    if (a.hap_begin[n_haps] > a.ids_capacity) return;
-    const uint32_t r = rbk * DEC_ROWBLOCK + lane;
-    const bool row_ok = r < a.n_rows;
-    const uint32_t n_cols = min(TS, a.n_samples - s0);
-    uint32_t m[TS];
-    {
-        const u32x4* src = reinterpret_cast<const u32x4*>(a.masks + uint64_t(row_ok ? r : 0u) * a.mask_stride + s0);
+    for (uint32_t g0 = r0; g0 < r1; g0 += G) {
+        uint32_t n[G], id0[G];
+        DecCarrier v[G][2];
 #pragma unroll
-        for (uint32_t k = 0; k < TS / 4u; ++k) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (row_ok) v = src[k];
-            m[4u * k] = v.x; m[4u * k + 1u] = v.y; m[4u * k + 2u] = v.z; m[4u * k + 3u] = v.w;
+        for (uint32_t i = 0; i < G; ++i) {
+            const bool in = g0 + i < r1;
+            n[i] = in ? a.row_nnz[g0 + i] : 0u;
+            id0[i] = in ? a.csq_begin[g0 + i] : 0u;
         }
-    }
-    uint32_t any = 0u;
 #pragma unroll
-    for (uint32_t sc = 0; sc < TS; ++sc) {
-        if (sc >= n_cols) m[sc] = 0u;                                          // the padding of the row is not initialised
-        any |= m[sc];
-    }
-    const bool multi = __builtin_amdgcn_ballot_w64((any & DEC_MULTI) != 0u) != 0ull;
-    if (lane == 0u) a.tile_flags[uint64_t(rbk) * sample_blocks + sb] = multi ? 1 : 0;
-    if (multi || !__builtin_amdgcn_ballot_w64(any != 0u)) return;             // multi-word entries: emit_generic_kernel
-    const uint32_t id0 = row_ok ? a.csq_begin[r] : 0u;
-    const uint64_t* hb = a.hap_begin + 2u * s0;
-    const uint32_t* cb = a.cnt + uint64_t(rbk) * n_haps + 2u * s0;
+        for (uint32_t i = 0; i < G; ++i) {
+            const DecCarrier* e = a.carriers + uint64_t(g0 + i) * a.n_samples;
+            v[i][0] = lane < n[i] ? e[lane] : none;
+            v[i][1] = lane + 64u < n[i] ? e[lane + 64u] : none;
+        }
 #pragma unroll
-    for (uint32_t sc = 0; sc < TS; ++sc) {
-        if (!__builtin_amdgcn_ballot_w64(m[sc] != 0u)) continue;               // nobody in these 64 records carries anything here
-#pragma unroll
-        for (uint32_t h = 0; h < 2u; ++h) {
-            uint32_t bits = (m[sc] >> h) & 0x55555555u;
-            const uint32_t c = uint32_t(__builtin_popcount(bits));
-            const uint32_t excl = dec_wave_incl_scan(c) - c;
-            uint32_t* o = a.ids + (hb[2u * sc + h] + cb[2u * sc + h]) + excl;
-            while (bits) { const uint32_t b = uint32_t(__builtin_ctz(bits)); bits &= bits - 1u; *o++ = id0 + (b >> 1); }
+        for (uint32_t i = 0; i < G; ++i) {
+            place(v[i][0], id0[i]);
+            const uint32_t ni = uint32_t(__builtin_amdgcn_readfirstlane(int(n[i])));
+            if (ni > 64u) place(v[i][1], id0[i]);
+            if (ni > 128u) {                                                    // dense records: the rest on demand
+                const DecCarrier* e = a.carriers + uint64_t(g0 + i) * a.n_samples;
+                for (uint32_t k0 = 128u; k0 < ni; k0 += 64u) place(k0 + lane < ni ? e[k0 + lane] : none, id0[i]);
+            }
         }
     }
 }
@@ -527,13 +539,12 @@ DecodeLayout decode_layout(uint64_t n_rows, uint64_t n_samples, uint64_t ovf_wor
     DecodeLayout L{};
     L.n_rowblocks = uint32_t((n_rows + DEC_ROWBLOCK - 1) / DEC_ROWBLOCK);
     uint64_t o = 0;
-    L.mask_stride = uint32_t((n_samples + 31ull) & ~31ull);
-    L.masks_off = o; o += up(n_rows * uint64_t(L.mask_stride) * 4ull);
+    L.carriers_off = o; o += up(n_rows * n_samples * sizeof(DecCarrier));
+    L.nnz_off = o; o += up(n_rows * 4ull);
     L.cnt_off = o; o += up(uint64_t(L.n_rowblocks) * 2ull * n_samples * 4ull);
     L.group_off = o; o += up(uint64_t(DEC_SCAN_GROUPS) * 2ull * n_samples * 4ull);
     L.ovf_off = o; o += up(ovf_words * 4ull);
     L.ovf_used_off = o; o += 256;
-    L.flags_off = o; o += up(uint64_t(L.n_rowblocks) * ((n_samples + DEC_EMIT_SAMPLES - 1) / DEC_EMIT_SAMPLES));
     L.total = o;
     return L;
 }
@@ -552,10 +563,8 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, unsigned phase
         else if (bs <= 128u) hipLaunchKernelGGL(parse_rows_kernel<128>, dim3(a.n_rows), dim3(128), 0, stream, a);
         else hipLaunchKernelGGL(parse_rows_kernel<256>, dim3(a.n_rows), dim3(256), 0, stream, a);
     }
-    if (phases & 2u) {
-        const uint32_t sbk = (a.n_samples + 255u) / 256u;
-        hipLaunchKernelGGL(count_kernel, dim3(n_rowblocks * sbk), dim3(256), 0, stream, a, sbk);
-    }
+    const uint32_t n_ranges = (n_haps + DEC_RANGE_HAPS - 1u) / DEC_RANGE_HAPS, range_haps = min(n_haps, DEC_RANGE_HAPS);
+    if (phases & 2u) hipLaunchKernelGGL(count_kernel, dim3(n_rowblocks * n_ranges), dim3(256), range_haps * 4u, stream, a, n_ranges);
     if (phases & 4u) {
         const uint32_t n_groups = min(DEC_SCAN_GROUPS, n_rowblocks), per_group = (n_rowblocks + n_groups - 1u) / n_groups;
         const uint32_t groups = (n_rowblocks + per_group - 1u) / per_group, hbk = (n_haps + 255u) / 256u;
@@ -563,11 +572,7 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, unsigned phase
         hipLaunchKernelGGL(scan_blocks_kernel, dim3(groups * hbk), dim3(256), 0, stream, a, n_rowblocks, per_group, hbk, groups);
         hipLaunchKernelGGL(scan_haps_kernel, dim3(1), dim3(1024), 0, stream, a);
     }
-    if (phases & 8u) {
-        const uint32_t sbk = (a.n_samples + DEC_EMIT_SAMPLES - 1u) / DEC_EMIT_SAMPLES;
-        hipLaunchKernelGGL(emit_kernel, dim3(((n_rowblocks + 3u) / 4u) * sbk), dim3(256), 0, stream, a, sbk, n_rowblocks);
-        hipLaunchKernelGGL(emit_generic_kernel, dim3(n_rowblocks * sbk), dim3(256), 0, stream, a, sbk);
-    }
+    if (phases & 8u) hipLaunchKernelGGL(emit_kernel, dim3(n_rowblocks * n_ranges), dim3(256), range_haps * 8u, stream, a, n_ranges);
     return hipGetLastError();
 }
 

@@ -77,9 +77,8 @@ void fill_args(DecodeArgs& a, const uint8_t* d_text, uint64_t n_text, const uint
     a.row_begin = d_row_begin; a.row_end = d_row_end;
     a.n_rows = uint32_t(n_records); a.n_samples = uint32_t(n_samples);
     a.csq_begin = d_csq_begin; a.sup_pairs = d_sup_pairs; a.sup_bits = d_sup_bits;
-    a.masks = reinterpret_cast<uint32_t*>(d_work + L.masks_off);
-    a.mask_stride = L.mask_stride;
-    a.tile_flags = d_work + L.flags_off;
+    a.carriers = reinterpret_cast<DecCarrier*>(d_work + L.carriers_off);
+    a.row_nnz = reinterpret_cast<uint32_t*>(d_work + L.nnz_off);
     a.cnt = reinterpret_cast<uint32_t*>(d_work + L.cnt_off);
     a.group_tot = reinterpret_cast<uint32_t*>(d_work + L.group_off);
     a.ovf = reinterpret_cast<uint32_t*>(d_work + L.ovf_off);
