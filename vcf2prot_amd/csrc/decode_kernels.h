@@ -19,6 +19,7 @@ constexpr uint32_t DEC_ROWBLOCK = 64;       // records per row block (count / em
 constexpr uint32_t DEC_RANGE_HAPS = 6144;   // haplotypes one count / emit workgroup keeps in LDS (48 KiB of 64-bit cursors)
 constexpr uint32_t DEC_SCAN_GROUPS = 64;    // the prefix down the row blocks runs in this many independent groups
 constexpr uint32_t DEC_TILE = 4096;         // text bytes per parse step of a 256-thread workgroup (16 per thread)
+constexpr uint32_t DEC_EMIT_GROUP = 8;      // records whose first 128 carriers the emit kernel fetches ahead together
 constexpr uint32_t DEC_MULTI = 0x80000000u; // carrier entry: bit 31 set -> low 31 bits index the multi-word list
 
 // One carrier: a (record, sample) whose filtered mask is not empty.  x = sample, y = the first word filtered to the
