@@ -141,9 +141,9 @@ def main():
                         "algorithmic_bytes_per_pass": alg_bytes, "traffic": None,
                         "parse_only_GBs": col_bytes / (float(np.mean(ms["parse"])) * 1e-3) / 1e9},
            "verified": "list lengths of all haplotypes and the ids of 6 haplotypes against numpy", "host_index_s": t_index, "vcf_generate_s": t_gen}
-    prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_decode_summary.json")
+    prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_decode_summary.json")
     if os.path.exists(prof) and (R, S, a.format, a.density) == (100000, 2504, "min", 0.05):
-        # HBM bytes of the six kernels from the PMC passes of tools/profile_decode.sh (same workload)
+        # HBM bytes of the kernels from the PMC passes of tools/profile_decode.sh (same workload)
         out["roofline"]["traffic"] = json.load(open(prof)).get("hbm_bytes_per_pass")
     if not a.no_cpu_baseline:
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))

@@ -12,6 +12,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python3 tools/decode_bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > $OUT/bench_write.log 2>&1
 python3 - <<'PY'
 import csv, glob, json, os, re
+def kname(k):
+    m = re.search(r"(\w+_kernel)(<[^>]*>)?", k)
+    return m.group(1) + (m.group(2) or "").replace("unsigned int", "u32").replace("unsigned long", "u64")
 out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "prof_decode")
 per = {}
 for f in glob.glob(os.path.join(out, "pmc_*", "*counter_collection.csv")):
@@ -19,7 +22,7 @@ for f in glob.glob(os.path.join(out, "pmc_*", "*counter_collection.csv")):
         k = r["Kernel_Name"]
         if "v2p::" not in k:
             continue
-        name = re.search(r"(\w+_kernel)", k).group(1)
+        name = kname(k)
         per.setdefault(name, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 summary = {"command": "python3 tools/decode_bench.py --no-cpu-baseline", "kernels": {}}
 tot = 0.0
@@ -33,7 +36,7 @@ stats = os.path.join(out, "trace", "decode_kernel_stats.csv")
 if os.path.exists(stats):
     for r in csv.DictReader(open(stats)):
         if "v2p::" in r["Name"]:
-            name = re.search(r"(\w+_kernel)", r["Name"]).group(1)
+            name = kname(r["Name"])
             summary["kernels"].setdefault(name, {})["avg_ns"] = float(r["AverageNs"])
 try:
     summary["bench_line"] = json.loads(open(os.path.join(out, "bench.json")).read().strip().split("\n")[-1])

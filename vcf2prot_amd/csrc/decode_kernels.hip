@@ -28,10 +28,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t dec_wave_incl_scan(uint32_t x)
 {
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, false);  // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, false);  // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xf, 0xf, false);  // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, true);   // row_shr:1 (lanes shifted in from outside the row read 0)
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, true);   // row_shr:8
     x += __builtin_amdgcn_update_dpp(0u, x, 0x142, 0xa, 0xf, false);  // row_bcast:15
     x += __builtin_amdgcn_update_dpp(0u, x, 0x143, 0xc, 0xf, false);  // row_bcast:31
     return x;
@@ -182,27 +182,36 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
         // Almost every column of a real cohort carries nothing: its text ends in ":0" or ":.".  Those are settled here with
         // two byte reads; only the others go on the list that the parser below works through, so the parser's cost scales with
         // the carriers and not with the columns.
-        auto consider = [&](uint32_t pos, uint32_t rank) {
+        // (the rank of a column among the step's columns is only worked out for the few that go on the list)
+        auto consider = [&](uint32_t pos, bool inside, auto rank) {
             const uint32_t p = tile0 + pos;
             const uint8_t c1 = rq<RM>(ring, p - 1u), c2 = rq<RM>(ring, p - 2u);
-            const bool work = !(p >= lo + 2u && c2 == ':' && (c1 == '0' || c1 == '.'));
+            const bool work = !(inside && c2 == ':' && (c1 == '0' || c1 == '.'));
             const uint64_t wb = __builtin_amdgcn_ballot_w64(work);
             if (wb) {
                 const uint32_t k = __builtin_amdgcn_mbcnt_hi(uint32_t(wb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(wb), 0u));
                 uint32_t at = 0u;
                 if (work && k == 0u) at = atomicAdd(&s_nlist, uint32_t(__builtin_popcountll(wb)));
                 at = uint32_t(__builtin_amdgcn_readlane(int(at), int(__builtin_ctzll(wb))));
-                if (work) list[at + k] = pos | (rank << 16);
+                if (work) list[at + k] = pos | (rank() << 16);
             }
         };
-        uint32_t slot = wbase + incl - cnt;
-        while (tm) {
-            const uint32_t b = uint32_t(__builtin_ctz(tm));
-            tm &= tm - 1u;
-            consider(tid * 16u + b, slot++);
+        const uint32_t tm0 = tm, slot0 = wbase + incl - cnt;
+        if (t == 0u) {                                                         // only the first step can meet the start of the row
+            while (tm) {
+                const uint32_t b = uint32_t(__builtin_ctz(tm));
+                tm &= tm - 1u;
+                consider(tid * 16u + b, tile0 + tid * 16u + b >= lo + 2u, [&] { return slot0 + uint32_t(__builtin_popcount(tm0 & ((1u << b) - 1u))); });
+            }
+        } else {
+            while (tm) {
+                const uint32_t b = uint32_t(__builtin_ctz(tm));
+                tm &= tm - 1u;
+                consider(tid * 16u + b, true, [&] { return slot0 + uint32_t(__builtin_popcount(tm0 & ((1u << b) - 1u))); });
+            }
         }
         const bool last = (t + 1u == n_tiles);
-        if (last && tid == 0) consider(Lq - tile0, tile_tabs);                 // the end of the line closes the last column
+        if (last && tid == 0) consider(Lq - tile0, Lq >= lo + 2u, [&] { return tile_tabs; });   // the end of the line closes the last column
         const uint32_t n_ends = tile_tabs + (last ? 1u : 0u);
         __syncthreads();
         const uint32_t n_list = s_nlist;
