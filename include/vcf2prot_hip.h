@@ -248,7 +248,9 @@ int v2p_stitch_launch(void* hip_stream,
                       const uint8_t* d_src1, uint64_t src1_len,
                       uint8_t* d_out, uint64_t out_len,
                       uint64_t* d_status, int nontemporal, uint32_t max_blocks);
-/* Host-side: which of the two stitch kernels a chunk table needs and their tasks per lane (bits 4..11 of `nontemporal`). */
+/* Host-side: which stitch kernels a chunk table needs and their tasks per lane (bits 4..11 of `nontemporal`): long-run chunks go to
+ * stitch4_kernel, the others to stitch_kernel (per block) or, when chunks hold more than 512 descriptors (short tasks), to
+ * stitch_dense_kernel. */
 int v2p_stitch_launch_bits(const v2p_chunk* chunks, uint64_t n_chunks);
 /* Host-side: reorder a chunk table so that workgroup 8*j + x (XCD x) works on proteome slice x.
  * v2p_batch_finalize() does this itself; callers of v2p_stitch_launch() may want it too. */

@@ -98,3 +98,38 @@ def test_long_run_kernel_handles_ragged_and_split_cuts(built, gpu_ctx, coracle, 
         got = run_image(gpu_ctx, img)
         for i in range(4):
             assert np.array_equal(got[i], want[i]), (chunk_tasks, i)
+
+
+@pytest.mark.parametrize("preset,h0,n", [("C5", 3, 24), ("C3", 7, 3), ("C1", 0, 8)])
+def test_dense_kernel_on_any_per_block_image(built, coracle, preset, h0, n):
+    """stitch_dense_kernel (lane = task, LDS image, piece list) is picked for images of short tasks; forced (variant 8, and 9 =
+    dword-aligned gathers) it must also be exact on images it is not picked for: long tasks go through the piece list, chunks
+    larger than the LDS image through several windows, literals may be cut by a window."""
+    from hip_util import DevBuf
+    from vcf2prot_amd import _native as N
+    from vcf2prot_amd.cohort import Cohort
+    lib = N.hip_lib()
+    c = Cohort.preset(preset)
+    prot = c.proteome()
+    want = np.concatenate(oracle_haps(c, coracle, h0, n))
+    d_prot = DevBuf.of(prot)
+    for pack in (dict(kernel=2), dict(kernel=2, chunk_tasks=1000, chunk_bytes=65520), dict(kernel=2, chunk_tasks=700, chunk_bytes=20000, cut_align=16)):
+        img = c.pack(h0, h0 + n, n_threads=2, **pack)
+        chunks = np.ascontiguousarray(img.chunks)
+        d_desc, d_chunks, d_pay = DevBuf.of(img.desc), DevBuf.of(chunks), DevBuf.of(img.payload)
+        bits = int(lib.v2p_stitch_launch_bits(chunks.ctypes.data, chunks.shape[0]))
+        for var in (8, 9):
+            d_out = DevBuf(img.out_bytes + 32, fill=0x2E)
+            d_status = DevBuf.of(np.full(1, -1, dtype=np.int64))
+            rc = lib.v2p_stitch_launch(None, d_desc.ptr, img.desc.size, d_chunks.ptr, chunks.shape[0], d_prot.ptr, prot.size, d_pay.ptr, img.payload.size,
+                                       d_out.ptr, img.out_bytes, d_status.ptr, 1 | bits | (var << 12), 0)
+            assert rc == 0
+            assert d_status.download().view(np.int64)[0] == -1
+            got = d_out.download()
+            hb = img.hap_out_begin.astype(np.int64)
+            res = np.concatenate([got[hb[i]:hb[i] + c.haplotype(h0 + i).n_res] for i in range(n)])
+            assert np.array_equal(res, want), (preset, pack, var)
+            d_out.free(); d_status.free()
+        for b in (d_desc, d_chunks, d_pay):
+            b.free()
+    d_prot.free()

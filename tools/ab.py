@@ -69,7 +69,10 @@ def main():
     ap.add_argument("--rounds", type=int, default=15)
     ap.add_argument("--mean-len", type=float, default=0.0, help="override the preset's mean transcript length")
     ap.add_argument("--transcripts", type=int, default=0, help="override the preset's transcript count")
+    ap.add_argument("--lib", default="", help="load this build of libvcf2prot_hip.so (tools/build_variant.sh) instead of the in-tree one")
     a = ap.parse_args()
+    if a.lib:
+        N.HIP_LIB_PATH = os.path.abspath(a.lib)
     lib = N.hip_lib()
     dev = torch.device("cuda", 0)
     over = {}

@@ -15,6 +15,8 @@
 //                   per overlapping task, tail-overwrite merge with 64-bit masks, and one
 //                   aligned dwordx4 store.  Result stores are full 16-byte and fully
 //                   coalesced (1 KiB per wave instruction) whatever the source alignments.
+//   stitch4_kernel  long-run images (C2): see the comment at the kernel.
+//   stitch_dense_kernel  images of short tasks (C5): lane = task, LDS image of the chunk, see the comment at the kernel.
 //   ordered_kernel  reference-order execution for non-canonical Task vectors
 //                   (overlapping / descending result ranges): one workgroup, tasks in
 //                   order, barrier between tasks => "later task wins" as on the CPU.
@@ -420,6 +422,208 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                 dbg[0] = st0; dbg[1] = st1; dbg[2] = st2; dbg[3] = st3; dbg[4] = st4; dbg[5] = acc_lds; dbg[6] = acc_wait; dbg[7] = acc_rest;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// stitch_dense_kernel: the same contract as stitch_kernel for images of SHORT tasks (a few result bytes each: deep Task
+// vectors, C5).  There a 16-byte result block is cut by three or four tasks and the per-block kernel pays a gather and a
+// masked merge for each of them.  Here the work follows the tasks instead, one chunk per workgroup:
+//   A  lane = 4 consecutive descriptors: decode, bounds-check, and at once the gather of every task's first 16 bytes (it does
+//      not depend on the offsets); wave64 DPP scan of the lengths -> result offsets
+//   B  every task ORs its first piece into an LDS image of the chunk's result (same 16-byte phase as the arena): the bytes
+//      masked to the task's length, shifted to the destination's dword phase, up to five ds_or_b32 into the zeroed image --
+//      tasks never overlap in the result, so the ORs of neighbouring tasks compose whatever their order and no byte-granular
+//      LDS access is needed.  What a task has beyond 16 bytes goes on an LDS list of 16-byte pieces (ranked by a second scan);
+//      the workgroup then takes the list with lane = piece, all gathers of a lane in flight together: one more memory
+//      latency per chunk however long the tasks are.
+//   C  the image leaves as aligned 16-byte non-temporal stores, 1 KiB per wave instruction; each block is zeroed as it goes.
+// A chunk larger than the 8 KiB image is done in windows (B and C per window); dense chunks are about 7 KiB.
+constexpr uint32_t DENSE_STAGE = 8192u;                    // bytes of the LDS image
+constexpr uint32_t DENSE_PIECES = DENSE_STAGE / 16u + 8u;  // continuation pieces of one window
+
+// up to n (1..16) bytes x, first byte lowest, OR-ed into the LDS image at byte offset o
+__device__ __forceinline__ void dense_put(uint32_t* img, uint32_t o, u32x4 x, uint32_t n)
+{
+    if (n < 16u) {                                          // keep bytes 0..n-1
+        const uint64_t m = ~0ull >> (8u * (8u - (n & 7u)) & 63u);      // the low n & 7 bytes (n & 7 == 0: all, not used then)
+        const uint64_t mlo = n >= 8u ? ~0ull : (n ? m : 0ull);
+        const uint64_t mhi = n > 8u ? m : 0ull;
+        x[0] &= uint32_t(mlo); x[1] &= uint32_t(mlo >> 32); x[2] &= uint32_t(mhi); x[3] &= uint32_t(mhi >> 32);
+    }
+    // five dwords from wb on; the data begin at byte bo = 1..4 of them (alignbyte shifts by 0..3 bytes only, so a dword-aligned
+    // destination is taken as "shifted by four": dword 0 then holds nothing)
+    const uint32_t wb = ((o + 3u) >> 2) - 1u, s2 = (4u - o) & 3u, bo = o - 4u * wb, end = bo + n;
+    const uint32_t e0 = __builtin_amdgcn_alignbyte(x[0], 0u, s2);
+    const uint32_t e1 = __builtin_amdgcn_alignbyte(x[1], x[0], s2);
+    const uint32_t e2 = __builtin_amdgcn_alignbyte(x[2], x[1], s2);
+    const uint32_t e3 = __builtin_amdgcn_alignbyte(x[3], x[2], s2);
+    const uint32_t e4 = __builtin_amdgcn_alignbyte(0u, x[3], s2);
+    if (bo < 4u) atomicOr(&img[wb], e0);
+    atomicOr(&img[wb + 1u], e1);
+    if (end > 8u) atomicOr(&img[wb + 2u], e2);
+    if (end > 12u) atomicOr(&img[wb + 3u], e3);
+    if (end > 16u) atomicOr(&img[wb + 4u], e4);
+}
+
+// DBG != 0: timing-only ablations (results are wrong): 1 = no gathers, 2 = no stores, 3 = no LDS puts
+template <bool NT, bool DW, int DBG = 0>
+__global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __restrict__ p_desc, const Chunk* __restrict__ p_chunks,
+                                                              const uint8_t* __restrict__ p_src0, const uint8_t* __restrict__ p_src1,
+                                                              uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
+                                                              const uint8_t* __restrict__ p_dots,
+                                                              uint32_t n_chunks, uint64_t n_desc, uint64_t src0_len, uint64_t src1_len, uint64_t out_len,
+                                                              uint32_t filter)
+{
+    struct { const uint64_t* desc; const Chunk* chunks; uint32_t n_chunks; uint64_t n_desc; const uint8_t* src0; uint64_t src0_len;
+             const uint8_t* src1; uint64_t src1_len; uint8_t* out; uint64_t out_len; unsigned long long* status; const uint8_t* dots; }
+        a{p_desc, p_chunks, n_chunks, n_desc, p_src0, src0_len, p_src1, src1_len, p_out, out_len, p_status, p_dots};
+    constexpr int TPT = 4;
+    constexpr uint32_t K = 256u * TPT;
+    constexpr uint64_t OFF40 = (1ull << 40) - 1;
+    __shared__ __attribute__((aligned(16))) uint32_t s_img[DENSE_STAGE / 4u + 8u];
+    __shared__ uint64_t s_piece[DENSE_PIECES];              // space:2 | source offset:40 | (bytes - 1) << 42 | image offset << 46
+    __shared__ uint32_t s_w[2][4];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t c = blockIdx.x;
+    if (c >= a.n_chunks) return;
+    const uint64_t tb = a.chunks[c].task_begin;
+    const uint64_t dn = a.chunks[c].dst_n;
+    if (filter == 2u && (dn & CHUNK_LONG)) return;         // long-run chunks belong to stitch4_kernel
+    const uint32_t n_hdr = uint32_t(dn >> 48) & CHUNK_N_MASK;
+    const uint64_t dst = dn & ((1ull << 48) - 1);
+    const uint32_t head = uint32_t(dst & 15ull);
+    const bool hdr_ok = n_hdr <= K && tb <= a.n_desc && n_hdr <= a.n_desc - tb;
+    const uint32_t n = hdr_ok ? n_hdr : 0u;
+
+    // 16 bytes at offset `so` of a source space (descriptor layout: space in bits 40..41 here)
+    auto piece = [&](uint64_t sw) -> u32x4 {
+        const uint32_t space = uint32_t(sw >> 40) & 3u;
+        const uint64_t so = sw & OFF40;
+        if (space == SPACE_IMM) return u32x4{uint32_t(so), uint32_t(so >> 32), 0u, 0u};
+        if (space == SPACE_FILL) return u32x4{0x2E2E2E2Eu, 0x2E2E2E2Eu, 0x2E2E2E2Eu, 0x2E2E2E2Eu};
+        const uint64_t addr = reinterpret_cast<uint64_t>(space == SPACE_PROTEOME ? a.src0 : a.src1) + so;
+        return DW ? gather16_dw(addr) : gather16(addr);
+    };
+
+    // ---- A: descriptors, and at once the first 16 bytes of every task (they do not depend on the offsets) ----
+    u32x4 g[TPT];
+    uint32_t len[TPT];
+    uint64_t sw[TPT];                                       // space << 40 | source offset (the literal of an immediate task)
+    uint32_t lsum = 0, bad = 0u;
+    {
+        uint64_t d[TPT];
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) d[k] = tid * TPT + k < n ? a.desc[tb + tid * TPT + k] : 0ull;   // (0: an empty task)
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            len[k] = uint32_t(d[k] >> 40) & ((1u << 22) - 1u);
+            const uint32_t space = uint32_t(d[k] >> 62);
+            const uint64_t so = d[k] & OFF40;
+            const uint64_t limit = space == SPACE_PROTEOME ? a.src0_len : (space == SPACE_PAYLOAD ? a.src1_len : ~0ull);
+            if (space == SPACE_IMM ? len[k] > IMM_MAX_BYTES : so + len[k] > limit) { bad |= 1u << k; len[k] = 0; }   // never read out of bounds
+            sw[k] = (uint64_t(space) << 40) | so;
+            lsum += len[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) g[k] = (len[k] && DBG != 1) ? piece(sw[k]) : u32x4{uint32_t(sw[k]), 0u, 0u, 0u};
+    if (bad) report(a.status, tb + tid * TPT + uint32_t(__builtin_ctz(bad)), STATUS_SRC_OOB);        // task.rs would panic
+    {   // zero the image: 2 x 16 B per lane, and the few dwords a put may touch past its end
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (uint32_t q = 0; q < DENSE_STAGE / 4096u; ++q) *reinterpret_cast<u32x4*>(&s_img[(q * 256u + tid) * 4u]) = z;
+        if (tid < 2u) *reinterpret_cast<u32x4*>(&s_img[DENSE_STAGE / 4u + tid * 4u]) = z;
+    }
+    const uint32_t incl = wave_incl_scan(lsum);
+    if (lane == 63u) s_w[0][wid] = incl;
+    lds_barrier();
+    const uint32_t l0 = s_w[0][0], l1 = s_w[0][1], l2 = s_w[0][2], l3 = s_w[0][3];
+    const uint32_t total = l0 + l1 + l2 + l3;
+    const uint32_t excl = incl - lsum + (wid > 0 ? l0 : 0u) + (wid > 1 ? l1 : 0u) + (wid > 2 ? l2 : 0u);
+    if (!(hdr_ok && dst + total <= a.out_len)) {            // never write out of bounds
+        if (tid == 0) report(a.status, tb, STATUS_RES_OOB);
+        return;
+    }
+    const uint32_t span = head + total;                     // image bytes of the whole chunk (the image starts at the block-aligned dst - head)
+    uint8_t* const out0 = a.out + (dst - head);
+    const uint32_t off0 = head + excl;                      // image position of the lane's first task
+
+    for (uint32_t w0 = 0; w0 < span; w0 += DENSE_STAGE) {   // one window for a dense chunk
+        const uint32_t w1 = min(w0 + DENSE_STAGE, span);
+        // ---- B: the first piece of every task; count the pieces beyond it ----
+        uint32_t off = off0, npc = 0;
+        uint32_t qs[TPT], qn[TPT];                            // what a task has in this window beyond its first piece: image position, bytes
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            const uint32_t b = max(off, w0), e = min(off + len[k], w1);
+            qs[k] = b; qn[k] = 0u;
+            if (b < e) {
+                uint32_t first = 0u;
+                if (b == off) {                               // the task begins in this window: its first piece is in registers
+                    first = min(e - b, 16u);
+                    if (DBG != 3) dense_put(s_img, b - w0, g[k], first);
+                    else if (g[k][0] == 0x12345678u) s_img[0] = 1u;
+                }
+                qs[k] = b + first; qn[k] = e - b - first;
+                npc += (qn[k] + 15u) >> 4;
+            }
+            off += len[k];
+        }
+        const uint32_t pincl = wave_incl_scan(npc);
+        if (lane == 63u) s_w[1][wid] = pincl;
+        lds_barrier();
+        const uint32_t p0 = s_w[1][0], p1 = s_w[1][1], p2 = s_w[1][2], p3 = s_w[1][3];
+        const uint32_t n_pieces = p0 + p1 + p2 + p3;          // <= (w1 - w0) / 16 + 1 by construction
+        uint32_t pi = pincl - npc + (wid > 0 ? p0 : 0u) + (wid > 1 ? p1 : 0u) + (wid > 2 ? p2 : 0u);
+        off = off0;
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            for (uint32_t p = 0; p < qn[k]; p += 16u) {       // (no trip for most tasks)
+                const uint32_t space = uint32_t(sw[k] >> 40) & 3u, skip = qs[k] + p - off;                          // bytes of the task before this piece
+                const uint64_t so = space == SPACE_IMM ? (sw[k] & OFF40) >> (8u * skip)                               // (a literal cut by the window)
+                                                       : (sw[k] & OFF40) + (space == SPACE_FILL ? 0ull : uint64_t(skip));
+                s_piece[pi++] = (sw[k] & ~OFF40) | so | (uint64_t(min(qn[k] - p, 16u) - 1u) << 42) | (uint64_t(qs[k] + p - w0) << 46);
+            }
+            off += len[k];
+        }
+        lds_barrier();
+        // ---- B': lane = piece, a lane's gathers in flight together ----
+        for (uint32_t j0 = tid; j0 < n_pieces; j0 += 1024u) {
+            uint64_t r[4];
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t j = j0 + 256u * uint32_t(u);
+                r[u] = j < n_pieces ? s_piece[j] : ~0ull;
+                v[u] = u32x4{0u, 0u, 0u, 0u};
+                if (r[u] != ~0ull && DBG != 1) v[u] = piece(r[u] & ((1ull << 42) - 1));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r[u] != ~0ull && DBG != 3) dense_put(s_img, uint32_t(r[u] >> 46), v[u], (uint32_t(r[u] >> 42) & 15u) + 1u);
+        }
+        lds_barrier();
+        // ---- C: the window's blocks leave; the image is zero again behind them ----
+        const uint32_t nblk = (w1 - w0 + 15u) >> 4;
+        for (uint32_t b = tid; b < nblk; b += 256u) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(&s_img[b * 4u]);
+            *reinterpret_cast<u32x4*>(&s_img[b * 4u]) = u32x4{0u, 0u, 0u, 0u};
+            const uint32_t q = w0 + (b << 4);                 // image position of the block
+            uint8_t* o = out0 + q;
+            if (DBG == 2) { if (v[0] == 0x12345678u && v[3] == 0x9abcdef0u) o[0] = 1; }
+            else if (q >= head && q + 16u <= span) {
+                if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(o));
+                else *reinterpret_cast<u32x4*>(o) = v;
+            } else {                                          // ragged first/last block of a chunk whose cut is not 16-byte aligned
+                const uint32_t ka = q < head ? head - q : 0u, kb = min(span - q, 16u);
+#pragma unroll
+                for (uint32_t j = 0; j < 16u; ++j)
+                    if (j >= ka && j < kb) o[j] = uint8_t(v[j >> 2] >> (8u * (j & 3u)));
+            }
+        }
+        if (w1 < span) lds_barrier();                         // another window: the image is reused
     }
 }
 
@@ -1246,7 +1450,8 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     // `nontemporal` bit 0: nt result stores; bits 4 / 5: no long-run / no per-block chunk in the image; bits 6..7: tasks per lane
     // of the largest long-run chunk; bits 8..11: tasks per lane of the largest per-block chunk; bits 12..15: variant (0 = default, 1 / 2 =
     // the per-block kernel with byte-granular / aligned gathers for every chunk -- images without fused descriptors only, A/B runs;
-    // 4..6: stitch4 with 1 / 2 / 4 rows per round); bits 16..23: timing-only ablation; bits 24..30: KiB of idle LDS (experiments)
+    // 3 = the per-block kernel also where the dense kernel would be picked; 4..6: stitch4 with 1 / 2 / 4 rows per round; 8 / 9 =
+    // the dense kernel for every per-block chunk, with byte-granular / dword-aligned gathers); bits 16..23: timing-only ablation; bits 24..30: KiB of idle LDS (experiments)
     const int nt = nontemporal & 1;
     const int var = (nontemporal >> 12) & 0xF;
     const int dbg = (nontemporal >> 16) & 0xFF;
@@ -1282,14 +1487,25 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
         else V2P_L3(TT, true, 0, FF); } while (0)
     // which kernels run: bits 4 / 5 of `nontemporal` say the image has no long-run / no per-block chunk (hints: a workgroup
     // that finds a chunk of the other kind returns at once)
-    const bool per_block_only = var == 1 || var == 2 || dbg == 3 || max_blocks != 0;   // A/B: every chunk on the per-block kernel (unfused images)
+    const bool dense = (var == 8 || var == 9 || (tpt > 2 && var == 0)) && max_blocks == 0;    // 9: dword-aligned gathers
+    const bool per_block_only = var == 1 || var == 2 || var == 3 || (dbg == 3 && !dense) || max_blocks != 0;   // A/B: every chunk on the per-block kernel (unfused images)
     const int tpt_long = (nontemporal >> 6) & 3;        // bits 6..7: tasks per lane of the largest long-run chunk (0 = 2)
+    // dense images (chunks of more than 512 short tasks) go to stitch_dense_kernel; variant 3 keeps them on the per-block kernel and
+    // variant 8 sends every per-block chunk of any image there (A/B runs)
+#define V2P_LDD(NTT, DWW, DD, FF) hipLaunchKernelGGL((stitch_dense_kernel<NTT, DWW, DD>), dim3(a.n_chunks), dim3(256), 0, stream, V2P_KARGS, uint32_t(FF))
+#define V2P_LD(NTT, FF) do { if (var == 9) V2P_LDD(NTT, true, 0, FF); else if (dbg == 1) V2P_LDD(NTT, false, 1, FF); else if (dbg == 2) V2P_LDD(NTT, false, 2, FF); \
+        else if (dbg == 3) V2P_LDD(NTT, false, 3, FF); else V2P_LDD(NTT, false, 0, FF); } while (0)
     if (per_block_only) {
         switch (tpt) { case 1: V2P_LAUNCH(1, 0); break; case 2: V2P_LAUNCH(2, 0); break; default: V2P_LAUNCH(4, 0); break; }
     } else {
-        if (!(nontemporal & 32)) { switch (tpt) { case 1: V2P_LAUNCH(1, 2); break; case 2: V2P_LAUNCH(2, 2); break; default: V2P_LAUNCH(4, 2); break; } }
+        if (!(nontemporal & 32)) {
+            if (dense) { if (nt) V2P_LD(true, 2); else V2P_LD(false, 2); }
+            else switch (tpt) { case 1: V2P_LAUNCH(1, 2); break; case 2: V2P_LAUNCH(2, 2); break; default: V2P_LAUNCH(4, 2); break; }
+        }
         if (!(nontemporal & 16)) { if (tpt_long == 1) V2P_LAUNCH3(1, 1); else V2P_LAUNCH3(2, 1); }
     }
+#undef V2P_LD
+#undef V2P_LDD
 #undef V2P_LAUNCH3
 #undef V2P_L3
 #undef V2P_L4
