@@ -265,7 +265,7 @@ def main():
         h0, h1 = shard_by_bytes(sizes.tolist(), world)[rank]              # equal result bytes per rank
     t_gen = time.perf_counter()
     img = cohort.pack(h0, h1, n_threads=min(n_threads, 64), chunk_tasks=args.chunk_tasks, chunk_bytes=args.chunk_bytes, fasta=args.fasta, cut_align=args.cut_align,
-                      fuse=not args.no_fuse and args.var not in (1, 2), kernel=2 if args.var in (1, 2) else 0)
+                      fuse=not args.no_fuse and args.var not in (1, 2, 3), kernel=2 if args.var in (1, 2, 3) else 0)
     t_gen = time.perf_counter() - t_gen
     A, NT = img.n_copy_bytes, img.n_tasks
     b_alg = 2 * A + 16 * NT
@@ -417,7 +417,7 @@ def main():
                                   "outside descriptors + the proteome once (reference reads are served by L2 and not counted)",
                          "hbm_bytes_min_per_launch": hbm_min,
                          "algorithmic_bytes_per_launch": b_alg, "algorithmic_GBps": b_alg / (avg_ms * 1e-3) / 1e9,
-                         "kernel": "stitch4_kernel (long-run image)" if not (img.launch_bits & 16) else ("stitch_dense_kernel (short tasks)" if ((img.launch_bits >> 8) & 15) > 2 and not a.var else "stitch_kernel (per-block)"), "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms)},
+                         "kernel": "stitch4_kernel (long-run image)" if not (img.launch_bits & 16) else ("stitch_dense_kernel (short tasks)" if ((img.launch_bits >> 8) & 15) > 2 and args.var in (0, 8, 9) else "stitch_kernel (per-block)"), "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms)},
             "kernel_only_aa_per_s_rank0": A / (avg_ms * 1e-3),
             "verified": verified, "image_build_s": t_gen,
         }

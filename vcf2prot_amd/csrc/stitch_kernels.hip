@@ -508,12 +508,14 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
     };
 
     // ---- A: descriptors, and at once the first 16 bytes of every task (they do not depend on the offsets) ----
+    // (later windows of a chunk larger than the image come back here with the descriptors in L2: nothing of a window stays in
+    // registers while the next is worked on)
     u32x4 g[TPT];
     uint32_t len[TPT];
     uint64_t sw[TPT];                                       // space << 40 | source offset (the literal of an immediate task)
-    uint32_t lsum = 0, bad = 0u;
-    {
+    auto load_tasks = [&](bool first_time) -> uint32_t {
         uint64_t d[TPT];
+        uint32_t lsum = 0, bad = 0u;
 #pragma unroll
         for (int k = 0; k < TPT; ++k) d[k] = tid * TPT + k < n ? a.desc[tb + tid * TPT + k] : 0ull;   // (0: an empty task)
 #pragma unroll
@@ -526,10 +528,12 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
             sw[k] = (uint64_t(space) << 40) | so;
             lsum += len[k];
         }
-    }
 #pragma unroll
-    for (int k = 0; k < TPT; ++k) g[k] = (len[k] && DBG != 1) ? piece(sw[k]) : u32x4{uint32_t(sw[k]), 0u, 0u, 0u};
-    if (bad) report(a.status, tb + tid * TPT + uint32_t(__builtin_ctz(bad)), STATUS_SRC_OOB);        // task.rs would panic
+        for (int k = 0; k < TPT; ++k) g[k] = (len[k] && DBG != 1) ? piece(sw[k]) : u32x4{uint32_t(sw[k]), 0u, 0u, 0u};
+        if (bad && first_time) report(a.status, tb + tid * TPT + uint32_t(__builtin_ctz(bad)), STATUS_SRC_OOB);   // task.rs would panic
+        return lsum;
+    };
+    const uint32_t lsum = load_tasks(true);
     {   // zero the image: 2 x 16 B per lane, and the few dwords a put may touch past its end
         const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -550,15 +554,13 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
     uint8_t* const out0 = a.out + (dst - head);
     const uint32_t off0 = head + excl;                      // image position of the lane's first task
 
-    for (uint32_t w0 = 0; w0 < span; w0 += DENSE_STAGE) {   // one window for a dense chunk
+    auto window = [&](const uint32_t w0) {
         const uint32_t w1 = min(w0 + DENSE_STAGE, span);
-        // ---- B: the first piece of every task; count the pieces beyond it ----
+        // ---- B: the first piece of every task; the pieces beyond it go on the list ----
         uint32_t off = off0, npc = 0;
-        uint32_t qs[TPT], qn[TPT];                            // what a task has in this window beyond its first piece: image position, bytes
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
             const uint32_t b = max(off, w0), e = min(off + len[k], w1);
-            qs[k] = b; qn[k] = 0u;
             if (b < e) {
                 uint32_t first = 0u;
                 if (b == off) {                               // the task begins in this window: its first piece is in registers
@@ -566,8 +568,7 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
                     if (DBG != 3) dense_put(s_img, b - w0, g[k], first);
                     else if (g[k][0] == 0x12345678u) s_img[0] = 1u;
                 }
-                qs[k] = b + first; qn[k] = e - b - first;
-                npc += (qn[k] + 15u) >> 4;
+                npc += (e - b - first + 15u) >> 4;
             }
             off += len[k];
         }
@@ -576,35 +577,42 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
         lds_barrier();
         const uint32_t p0 = s_w[1][0], p1 = s_w[1][1], p2 = s_w[1][2], p3 = s_w[1][3];
         const uint32_t n_pieces = p0 + p1 + p2 + p3;          // <= (w1 - w0) / 16 + 1 by construction
-        uint32_t pi = pincl - npc + (wid > 0 ? p0 : 0u) + (wid > 1 ? p1 : 0u) + (wid > 2 ? p2 : 0u);
-        off = off0;
+        if (n_pieces) {                                       // (uniform)
+            uint32_t pi = pincl - npc + (wid > 0 ? p0 : 0u) + (wid > 1 ? p1 : 0u) + (wid > 2 ? p2 : 0u);
+            off = off0;
 #pragma unroll
-        for (int k = 0; k < TPT; ++k) {
-            for (uint32_t p = 0; p < qn[k]; p += 16u) {       // (no trip for most tasks)
-                const uint32_t space = uint32_t(sw[k] >> 40) & 3u, skip = qs[k] + p - off;                          // bytes of the task before this piece
-                const uint64_t so = space == SPACE_IMM ? (sw[k] & OFF40) >> (8u * skip)                               // (a literal cut by the window)
-                                                       : (sw[k] & OFF40) + (space == SPACE_FILL ? 0ull : uint64_t(skip));
-                s_piece[pi++] = (sw[k] & ~OFF40) | so | (uint64_t(min(qn[k] - p, 16u) - 1u) << 42) | (uint64_t(qs[k] + p - w0) << 46);
+            for (int k = 0; k < TPT; ++k) {
+                const uint32_t b = max(off, w0), e = min(off + len[k], w1);
+                if (b < e) {
+                    const uint32_t qs = b + (b == off ? min(e - b, 16u) : 0u);
+                    const uint32_t space = uint32_t(sw[k] >> 40) & 3u;
+                    for (uint32_t q = qs; q < e; q += 16u) {  // (no trip for most tasks)
+                        const uint32_t skip = q - off;        // bytes of the task before this piece
+                        const uint64_t so = space == SPACE_IMM ? (sw[k] & OFF40) >> (8u * skip)                       // (a literal cut by the window)
+                                                               : (sw[k] & OFF40) + (space == SPACE_FILL ? 0ull : uint64_t(skip));
+                        s_piece[pi++] = (sw[k] & ~OFF40) | so | (uint64_t(min(e - q, 16u) - 1u) << 42) | (uint64_t(q - w0) << 46);
+                    }
+                }
+                off += len[k];
             }
-            off += len[k];
-        }
-        lds_barrier();
-        // ---- B': lane = piece, a lane's gathers in flight together ----
-        for (uint32_t j0 = tid; j0 < n_pieces; j0 += 1024u) {
-            uint64_t r[4];
-            u32x4 v[4];
+            lds_barrier();
+            // ---- B': lane = piece, a lane's gathers in flight together ----
+            for (uint32_t j0 = tid; j0 < n_pieces; j0 += 512u) {
+                uint64_t r[2];
+                u32x4 v[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t j = j0 + 256u * uint32_t(u);
-                r[u] = j < n_pieces ? s_piece[j] : ~0ull;
-                v[u] = u32x4{0u, 0u, 0u, 0u};
-                if (r[u] != ~0ull && DBG != 1) v[u] = piece(r[u] & ((1ull << 42) - 1));
+                for (int u = 0; u < 2; ++u) {
+                    const uint32_t j = j0 + 256u * uint32_t(u);
+                    r[u] = j < n_pieces ? s_piece[j] : ~0ull;
+                    v[u] = u32x4{0u, 0u, 0u, 0u};
+                    if (r[u] != ~0ull && DBG != 1) v[u] = piece(r[u] & ((1ull << 42) - 1));
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (r[u] != ~0ull && DBG != 3) dense_put(s_img, uint32_t(r[u] >> 46), v[u], (uint32_t(r[u] >> 42) & 15u) + 1u);
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (r[u] != ~0ull && DBG != 3) dense_put(s_img, uint32_t(r[u] >> 46), v[u], (uint32_t(r[u] >> 42) & 15u) + 1u);
+            lds_barrier();
         }
-        lds_barrier();
         // ---- C: the window's blocks leave; the image is zero again behind them ----
         const uint32_t nblk = (w1 - w0 + 15u) >> 4;
         for (uint32_t b = tid; b < nblk; b += 256u) {
@@ -623,7 +631,12 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
                     if (j >= ka && j < kb) o[j] = uint8_t(v[j >> 2] >> (8u * (j & 3u)));
             }
         }
-        if (w1 < span) lds_barrier();                         // another window: the image is reused
+    };
+    window(0u);
+    for (uint32_t w0 = DENSE_STAGE; w0 < span; w0 += DENSE_STAGE) {   // (not for a dense chunk)
+        lds_barrier();                                        // the image is reused
+        (void)load_tasks(false);
+        window(w0);
     }
 }
 
