@@ -179,7 +179,7 @@ def pcie_inclusive(cohort, h0, h1, n_threads, slots=3, target_image_bytes=2 << 3
             "d2h_GBps": out_total / best / 1e9, "what": "packed images -> pinned H2D -> stitch kernel -> D2H into pinned host memory"}
 
 
-def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests):
+def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests, dense=False):
     """the same shard's image built ON the device from the per-transcript GIRs of step 4b (v2p_batch_build_on_device:
     step 5's running sums as prefix scans, descriptors, chunk table, XCD order).  Returns the build kernels' time and whether the
     image executes to the same per-haplotype digests."""
@@ -188,12 +188,12 @@ def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests):
     t0 = time.perf_counter()
     stream = cohort.txstream(h0, h1, n_threads=n_threads)
     t_stream = time.perf_counter() - t0
-    window = 28672 if long_run else 32768
+    window = 4096 if dense else (28672 if long_run else 32768)      # a dense image: <= 1024 descriptors per window
     with Context(0) as ctx:
         ctx.upload_proteome(cohort.proteome())
         b = ctx.batch()
         t0 = time.perf_counter()
-        ms = b.build_on_device(stream, window, 1 if long_run else 2)
+        ms = b.build_on_device(stream, window, 3 if dense else (1 if long_run else 2))
         t_call = time.perf_counter() - t0
         cn = b.counts()
         same = None
@@ -417,7 +417,7 @@ def main():
                                   "outside descriptors + the proteome once (reference reads are served by L2 and not counted)",
                          "hbm_bytes_min_per_launch": hbm_min,
                          "algorithmic_bytes_per_launch": b_alg, "algorithmic_GBps": b_alg / (avg_ms * 1e-3) / 1e9,
-                         "kernel": "stitch4_kernel (long-run image)" if not (img.launch_bits & 16) else ("stitch_dense_kernel (short tasks)" if ((img.launch_bits >> 8) & 15) > 2 and args.var in (0, 8, 9) else "stitch_kernel (per-block)"), "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms)},
+                         "kernel": "stitch4_kernel (long-run image)" if not (img.launch_bits & 16) else ("stitch_dense_kernel (short tasks)" if ((img.launch_bits & 2) or ((img.launch_bits >> 8) & 15) > 2) and args.var in (0, 8, 9) else "stitch_kernel (per-block)"), "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms)},
             "kernel_only_aa_per_s_rank0": A / (avg_ms * 1e-3),
             "verified": verified, "image_build_s": t_gen,
         }
@@ -438,7 +438,7 @@ def main():
                 line["incl_transfers"] = {"error": repr(e)}
         if world == 1 and not args.no_device_build and not args.fasta and not args.dbg and not args.dry_run:
             try:
-                line["device_image_build"] = device_image_build(cohort, h0, h1, min(n_threads, 64), not (img.launch_bits & 16), dig_all)
+                line["device_image_build"] = device_image_build(cohort, h0, h1, min(n_threads, 64), not (img.launch_bits & 16), dig_all, dense=bool(img.launch_bits & 2))
             except Exception as e:
                 line["device_image_build"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:

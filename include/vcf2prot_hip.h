@@ -186,7 +186,8 @@ typedef struct {
     const uint32_t* start_pos_res;     /* [n_tasks]                                                                     */
     const uint8_t*  alt;               /* [n_alt] alt tapes of the transcripts back to back, 1 byte per residue         */
 } v2p_txstream;
-/* kernel: 1 = route every chunk to the long-run kernel (<= 512 descriptors per window), 2 = per-block kernel.
+/* kernel: 1 = route every chunk to the long-run kernel (<= 512 descriptors per window), 2 = per-block kernel, 3 = dense image
+ * (stitch_dense_kernel: short tasks, fused substitutions, <= 1024 descriptors per window: windows of 4 or 8 KiB).
  * On success the batch is finalized (execute / sync / download / digests work as after v2p_batch_finalize).
  * *build_ms (optional): time of the build kernels alone (HIP events), the stream already on the device. */
 int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t window_bytes, int kernel, float* build_ms);

@@ -53,15 +53,22 @@ def test_packed_image_equals_oracle(c1, coracle):
     in numpy == the oracle on the reference-shaped tasks.  Host logic only, no GPU."""
     cohort, _ = c1
     n = cohort.n_haplotypes
-    img = cohort.pack(0, n, n_threads=3)
+    img = cohort.pack(0, n, n_threads=3, kernel=2)                  # one descriptor per task, per-block kernel
     prot = cohort.proteome()
     from gen_util import interpret_image
     out = interpret_image(img.desc, img.chunks, prot, img.payload, img.out_bytes)
+    assert not (img.desc >> np.uint64(61) == 7).any() and not (img.chunks[:, 1] >> np.uint64(61)).any()
     # the same cohort as a long-run image: missense transcripts become fused descriptors, the bytes stay the same
     fused = cohort.pack(0, n, n_threads=3, kernel=1)
     assert (fused.desc >> np.uint64(61) == 7).any() and fused.desc.size < img.desc.size
     assert np.array_equal(interpret_image(fused.desc, fused.chunks, prot, fused.payload, fused.out_bytes), out)
     assert (fused.chunks[:, 1] >> np.uint64(63)).all()              # every chunk routed to the long-run kernel
+    # ... and as the builder's own choice for 16 result bytes per task: a dense image, fused as well, flagged for the dense kernel
+    dense = cohort.pack(0, n, n_threads=3)
+    assert (dense.desc >> np.uint64(61) == 7).any() and dense.desc.size < img.desc.size
+    assert np.array_equal(interpret_image(dense.desc, dense.chunks, prot, dense.payload, dense.out_bytes), out)
+    assert ((dense.chunks[:, 1] >> np.uint64(61)) == 1).all() and (dense.launch_bits & 2) and (dense.launch_bits & 48) == 48
+    assert np.array_equal(dense.hap_out_begin, img.hap_out_begin)
     tot_tasks = tot_bytes = 0
     for h in range(n):
         hap = cohort.haplotype(h)

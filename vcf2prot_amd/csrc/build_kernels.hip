@@ -153,7 +153,7 @@ struct Walker {
     }
     __device__ void stage(uint32_t space, uint64_t src, uint64_t len, uint64_t dst)
     {
-        if (!a.long_run) { out(space, src, len, dst); return; }
+        if (!a.long_run && !a.dense) { out(space, src, len, dst); return; }
         if (st_n == 2) {
             const bool fits = st[0].len == 0 ? (len > 0 && src >= 1 && src - 1 + 1 + len <= SNV3_MAX_SRC) : (len == 0 || src == st[0].src + st[0].len + 1);
             if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && fits) {
@@ -238,12 +238,14 @@ __global__ __launch_bounds__(256) void chunk_kernel(BuildArgs a, uint64_t n_wind
     if (a.long_run && tasks > 2u * CHUNK_TASKS) { breport(a.status, tb, STATUS_TOO_MANY); return; }
     uint64_t flags = 0;
     if (a.long_run) flags = CHUNK_LONG | (tasks > CHUNK_TASKS ? CHUNK_LONG2 : 0ull);
+    else if (a.dense) flags = CHUNK_DENSE;
     a.chunks_tmp[k] = Chunk{tb, (k * a.window) | (n << 48) | flags};
     const uint64_t per = (a.proteome_len + 7) / 8;
     const uint64_t bk = per ? key / per : 0;
     a.bucket[k] = uint8_t(bk < 8 ? bk : 7);
     // what the launcher needs to know about the table
     if (a.long_run) { atomicOr(&a.meta[0], 1u); if (tasks > CHUNK_TASKS) atomicOr(&a.meta[1], 1u); }
+    else if (a.dense) atomicOr(&a.meta[0], 2u);
     else { atomicOr(&a.meta[2], 1u); atomicMax(&a.meta[3], uint32_t(n)); }
 }
 

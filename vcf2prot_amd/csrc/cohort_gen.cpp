@@ -457,16 +457,17 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
         if (flags & V2P_PACK_NO_FUSE) im.fuse_snv = false;
         if (flags & V2P_PACK_PER_BLOCK) im.kernel_choice = 2;
         if (flags & V2P_PACK_LONG_RUN) im.kernel_choice = 1;
+        if (flags & V2P_PACK_DENSE) im.kernel_choice = 3;
         if ((flags >> 8) & 0xFFFF) im.cut_align = (flags >> 8) & 0xFFFF;   // experiment knobs: bits 8..23 cut alignment,
         if (flags >> 24) im.soft_window = flags >> 24;                     //                   bits 24..31 closing window
     }
     // one kernel per image (sir_pack.hpp): every thread's builder takes the decision the first haplotype's shape asks for
-    if (n && !(flags & (V2P_PACK_PER_BLOCK | V2P_PACK_LONG_RUN)) && !chunk_tasks) {
+    if (n && !(flags & (V2P_PACK_PER_BLOCK | V2P_PACK_LONG_RUN | V2P_PACK_DENSE)) && !chunk_tasks) {
         v2p_hapbuf b;
         generate_into(*c, h0, b, false, nullptr);
         uint64_t bytes = 0, tasks = 0;
         for (size_t i = 0; i < b.length.size(); ++i) { bytes += b.length[i]; tasks += b.length[i] ? 1 : 0; }
-        const int choice = (tasks && bytes / tasks >= v2p::LONG_RUN_BYTES_PER_TASK) ? 1 : 2;
+        const int choice = !tasks ? 2 : (bytes / tasks >= v2p::LONG_RUN_BYTES_PER_TASK ? 1 : (bytes / tasks < v2p::DENSE_BELOW ? 3 : 2));
         for (auto& im : parts) im.kernel_choice = choice;
     }
     std::vector<int> status(parts.size(), 0);
@@ -649,7 +650,7 @@ int v2p_cohort_pack_grid(const v2p_cohort* c, uint64_t h0, uint64_t h1, uint32_t
     int rc = v2p_cohort_txstream(c, h0, h1, 8, &s);
     if (rc) return rc;
     v2p::ImageBuilder im;
-    im.grid_bytes = window_bytes; im.kernel_choice = kernel == 1 ? 1 : 2; im.adaptive_tasks = false;
+    im.grid_bytes = window_bytes; im.kernel_choice = kernel == 1 ? 1 : (kernel == 3 ? 3 : 2); im.adaptive_tasks = false;
     im.payload.assign(s.alt, s.alt + s.n_alt);                        // the alt tapes ARE the payload arena
     for (uint64_t h = 0; h < s.n_haps && rc == 0; ++h) {
         uint64_t res = 0;                                             // res_counter of haplotype_instruction.rs:90,132

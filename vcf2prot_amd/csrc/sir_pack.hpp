@@ -63,11 +63,13 @@ constexpr uint32_t CHUNK_TASKS_MID = 512;      // ... for images with 40..110 re
 constexpr uint32_t CHUNK_TASKS_DEEP = 1024;    // ... for dense images (a few result bytes per task): 4 per lane
 constexpr uint32_t CHUNK_BYTES = 64u * 1024u - 16u;  // most result bytes a work item may hold (<= 4096 16-byte blocks incl. a ragged head)
 constexpr uint32_t CHUNK_BYTES_LONG = 32u * 1024u;   // ... of a long-run work item: 2048 blocks = eight 1 KiB rows per wave, all gathered before the first store
+constexpr uint32_t CHUNK_BYTES_DENSE = 12272;  // ... of a dense image: the 12 KiB LDS image of stitch_dense_kernel takes the chunk in one window
 constexpr uint32_t DENSE_BELOW = 40;           // a chunk with fewer result bytes per task than this switches the builder to dense chunks
 constexpr uint32_t CUT_ALIGN  = 4096;          // preferred chunk cut: 4 KiB multiples = full 256-lane passes of 16-byte blocks
 constexpr uint64_t DST_MASK   = (1ull << 48) - 1;
 constexpr uint64_t CHUNK_LONG = 1ull << 63;    // chunk header flag: long-run chunk
 constexpr uint64_t CHUNK_LONG2 = 1ull << 62;   // ... holding 257..512 tasks (two task records per lane)
+constexpr uint64_t CHUNK_DENSE = 1ull << 61;   // chunk header flag: chunk of a dense image (short tasks, fused descriptors allowed): stitch_dense_kernel
 constexpr uint32_t CHUNK_N_MASK = 0x7FF;       // descriptor count: bits 48..58 of dst_n
 inline uint32_t chunk_n(uint64_t dst_n) { return uint32_t(dst_n >> 48) & CHUNK_N_MASK; }
 constexpr uint32_t LONG_RUN_BYTES_PER_TASK = 120;   // an image whose first chunk has at least this many result bytes per task goes to stitch4_kernel
@@ -119,7 +121,9 @@ public:
     uint32_t max_chunk_tasks = 0;     // most tasks of any chunk routed to the per-block kernel (selects its tasks per lane)
     uint32_t max_long_tasks = 0;      // most tasks of any long-run chunk (<= 256: one task record per lane in stitch4_kernel, else two)
     uint64_t n_long_chunks = 0;       // chunks routed to stitch4_kernel
-    int kernel_choice = 0;            // 0: undecided (adaptive images decide at their first chunk); 1: every chunk of <= 512 tasks long-run; 2: per-block kernel only, no fusion
+    int kernel_choice = 0;            // 0: undecided (adaptive images decide at their first chunk); 1: every chunk of <= 512 tasks long-run; 2: per-block kernel only, no fusion;
+                                      // 3: dense image (stitch_dense_kernel, fusion on)
+    uint64_t n_dense_chunks = 0;      // chunks flagged for stitch_dense_kernel
     uint32_t soft_window = 8;         // tasks before the hard limit at which a chunk starts looking for its cut
     bool inline_payload = true;       // payload tasks of <= IMM_MAX_BYTES bytes become immediate descriptors
     uint32_t grid_bytes = 0;          // != 0: GRID cutting -- chunk k holds exactly the result bytes [k*grid, (k+1)*grid) (a multiple of 4 KiB; tasks
@@ -131,7 +135,7 @@ public:
     // Empty the image for another build; the vectors keep their capacity, the settings return to their defaults.
     void reset() {
         desc.clear(); chunks.clear(); payload.clear(); hap_out_begin.assign(1, 0);
-        n_copy_bytes = n_ref_tasks = n_fused = n_long_chunks = 0;
+        n_copy_bytes = n_ref_tasks = n_fused = n_long_chunks = n_dense_chunks = 0;
         chunk_tasks = CHUNK_TASKS; adaptive_tasks = true; chunk_bytes = CHUNK_BYTES_LONG; adaptive_bytes = true; cut_align = CUT_ALIGN;
         max_chunk_tasks = max_long_tasks = 0; soft_window = 8; inline_payload = true; fuse_snv = true; kernel_choice = 0; grid_bytes = 0;
         cursor_ = extra_ = arena_cursor_ = open_begin_ = open_dst_ = 0;
@@ -205,6 +209,10 @@ private:
     uint64_t open_begin_ = 0, open_dst_ = 0;
     uint32_t open_n_ = 0, open_bytes_ = 0;   // tasks / result bytes of the open chunk
     uint32_t open_desc_ = 0;                 // descriptors of the open chunk (<= open_n_)
+    // what chunk_tasks limits: tasks, or -- in a dense image, whose kernel has one lane slot per DESCRIPTOR -- descriptors
+    uint32_t open_units() const { return kernel_choice == 3 ? open_desc_ : open_n_; }
+    // ... and a dense image cuts at any multiple of 16 (its chunks are a few KiB: a 4 KiB preference would cost a third of them)
+    uint32_t cut_pref() const { return kernel_choice == 3 && adaptive_bytes ? 16u : cut_align; }
     bool open_fused_ = false;                // it holds a fused descriptor
     struct Staged { unsigned space; uint64_t src; uint64_t len; };
     Staged st_[2];                   // tasks held back because the next one may complete a fused substitution
@@ -232,7 +240,10 @@ private:
     void stage(unsigned space, uint64_t src, uint64_t len) {
         // fusion needs a long-run chunk: decided images only (the first chunk of an adaptive image goes in unfused)
         // (on a grid, fusion is a local rule: long-run routing chosen by the caller, the triple inside one window)
-        if (!fuse_snv || (grid_bytes ? kernel_choice != 1 : (!long_run_mode() || kernel_choice == 2 || (adaptive_tasks && kernel_choice == 0)))) { flush(); emit(space, src, len); return; }
+        // (a dense image fuses as well: its kernel takes the triple as one reference run with one byte patched)
+        const bool may_fuse = fuse_snv && (grid_bytes ? (kernel_choice == 1 || kernel_choice == 3)
+                                                      : (kernel_choice == 3 || (long_run_mode() && kernel_choice != 2 && !(adaptive_tasks && kernel_choice == 0))));
+        if (!may_fuse) { flush(); emit(space, src, len); return; }
         if (st_n_ == 2) {
             // the copy after the literal goes on one residue behind the copy before it; an EMPTY copy (substitution at the first
             // or last residue: transcript_instructions.rs:734, :648-649) has no source to speak of and fits any neighbour
@@ -269,8 +280,8 @@ private:
             return;
         }
         const uint32_t soft_tasks = chunk_tasks > soft_window ? chunk_tasks - soft_window : chunk_tasks;
-        const uint32_t soft_bytes = chunk_bytes > cut_align ? chunk_bytes - cut_align : chunk_bytes;
-        if (open_n_ + cnt <= soft_tasks && open_bytes_ + total <= soft_bytes) {
+        const uint32_t soft_bytes = chunk_bytes > cut_pref() ? chunk_bytes - cut_pref() : chunk_bytes;
+        if (open_units() + (kernel_choice == 3 ? 1u : cnt) <= soft_tasks && open_bytes_ + total <= soft_bytes) {
             if (open_n_ == 0) { open_begin_ = desc.size(); open_dst_ = arena_cursor_; }
             desc.push_back(pack_snv3(src, len1, len2, byte));
             ++open_desc_; open_n_ += cnt; open_bytes_ += total; arena_cursor_ += total;
@@ -292,21 +303,25 @@ private:
         // (C5: 7).  An explicit chunk_tasks (adaptive_tasks off) keeps the choice per chunk: <= 256 tasks -> long-run.
         const uint32_t bpt = open_bytes_ / open_n_;
         if (grid_bytes) {                              // the caller chose the kernel (1: long-run, else per block); nothing adapts
-            const bool lg = kernel_choice == 1 && open_n_ <= 2u * CHUNK_TASKS;
-            chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_desc_) << 48) | (lg ? CHUNK_LONG : 0ull) | (lg && open_n_ > CHUNK_TASKS ? CHUNK_LONG2 : 0ull)});
-            if (lg) { ++n_long_chunks; if (open_n_ > max_long_tasks) max_long_tasks = open_n_; } else if (open_n_ > max_chunk_tasks) max_chunk_tasks = open_n_;
+            const bool lg = kernel_choice == 1 && open_n_ <= 2u * CHUNK_TASKS, dn = kernel_choice == 3;
+            chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_desc_) << 48) | (lg ? CHUNK_LONG : 0ull) | (lg && open_n_ > CHUNK_TASKS ? CHUNK_LONG2 : 0ull)
+                                                | (dn ? CHUNK_DENSE : 0ull)});
+            if (lg) { ++n_long_chunks; if (open_n_ > max_long_tasks) max_long_tasks = open_n_; } else if (dn) ++n_dense_chunks; else if (open_n_ > max_chunk_tasks) max_chunk_tasks = open_n_;
             open_n_ = 0; open_bytes_ = 0; open_desc_ = 0; open_fused_ = false;
             return;
         }
-        if (adaptive_tasks && kernel_choice == 0) kernel_choice = bpt >= LONG_RUN_BYTES_PER_TASK ? 1 : 2;
-        const bool to_long = open_fused_ || (open_n_ <= 2u * CHUNK_TASKS && (kernel_choice == 1 || (kernel_choice == 0 && long_run_mode())));
+        if (adaptive_tasks && kernel_choice == 0) kernel_choice = bpt >= LONG_RUN_BYTES_PER_TASK ? 1 : (bpt < DENSE_BELOW ? 3 : 2);
+        const bool to_dense = kernel_choice == 3;
+        const bool to_long = !to_dense && (open_fused_ || (open_n_ <= 2u * CHUNK_TASKS && (kernel_choice == 1 || (kernel_choice == 0 && long_run_mode()))));
         chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_desc_) << 48) | (to_long ? CHUNK_LONG : 0ull)
-                                            | (to_long && open_n_ > CHUNK_TASKS ? CHUNK_LONG2 : 0ull)});
+                                            | (to_long && open_n_ > CHUNK_TASKS ? CHUNK_LONG2 : 0ull) | (to_dense ? CHUNK_DENSE : 0ull)});
         if (to_long) { ++n_long_chunks; if (open_n_ > max_long_tasks) max_long_tasks = open_n_; }
+        else if (to_dense) ++n_dense_chunks;
         else if (open_n_ > max_chunk_tasks) max_chunk_tasks = open_n_;
         if (adaptive_tasks) {
-            chunk_tasks = kernel_choice == 1 ? CHUNK_TASKS : (bpt >= LONG_RUN_BYTES_PER_TASK ? CHUNK_TASKS : (bpt >= DENSE_BELOW ? CHUNK_TASKS_MID : CHUNK_TASKS_DEEP));
-            if (adaptive_bytes) chunk_bytes = chunk_tasks <= CHUNK_TASKS_MID ? CHUNK_BYTES_LONG : CHUNK_BYTES;
+            chunk_tasks = kernel_choice == 1 ? CHUNK_TASKS : (kernel_choice == 3 ? CHUNK_TASKS_DEEP
+                          : (bpt >= LONG_RUN_BYTES_PER_TASK ? CHUNK_TASKS : (bpt >= DENSE_BELOW ? CHUNK_TASKS_MID : CHUNK_TASKS_DEEP)));
+            if (adaptive_bytes) chunk_bytes = kernel_choice == 3 ? CHUNK_BYTES_DENSE : (chunk_tasks <= CHUNK_TASKS_MID ? CHUNK_BYTES_LONG : CHUNK_BYTES);
         }
         open_n_ = 0; open_bytes_ = 0; open_desc_ = 0; open_fused_ = false;
     }
@@ -323,15 +338,15 @@ private:
     // cut is still unaligned at the hard limit it is made anyway (the kernel handles ragged edges).
     void push(unsigned space, uint64_t src, uint32_t len) {
         const uint32_t soft_tasks = chunk_tasks > soft_window ? chunk_tasks - soft_window : chunk_tasks;
-        const uint32_t soft_bytes = chunk_bytes > cut_align ? chunk_bytes - cut_align : chunk_bytes;
+        const uint32_t soft_bytes = chunk_bytes > cut_pref() ? chunk_bytes - cut_pref() : chunk_bytes;
         for (;;) {
-            const bool closing = open_n_ >= soft_tasks || open_bytes_ + len > soft_bytes;
+            const bool closing = open_units() >= soft_tasks || open_bytes_ + len > soft_bytes;
             if (!closing) { append(space, src, len); return; }
-            if (open_n_ == chunk_tasks) { close_chunk(); continue; }          // ragged cut (many tiny tasks)
+            if (open_units() == chunk_tasks) { close_chunk(); continue; }     // ragged cut (many tiny tasks)
             // preferred cut: a multiple of cut_align (4 KiB = one full 256-lane pass of 16-byte blocks, so no
             // partially filled pass); when that cannot be reached any more, a multiple of 16
-            uint32_t align = cut_align;
-            if (open_n_ + 6 >= chunk_tasks || open_bytes_ + (align - uint32_t(arena_cursor_ & uint64_t(align - 1))) > chunk_bytes) align = 16;
+            uint32_t align = cut_pref();
+            if (open_units() + 6 >= chunk_tasks || open_bytes_ + (align - uint32_t(arena_cursor_ & uint64_t(align - 1))) > chunk_bytes) align = 16;
             const uint32_t misal = uint32_t(arena_cursor_ & uint64_t(align - 1));
             if (misal == 0 && open_n_ > 0) { close_chunk(); continue; }       // aligned cut
             const uint32_t r = align - misal;
@@ -350,18 +365,20 @@ private:
 };
 
 // Launch bits of v2p_stitch_launch / launch_stitch for a chunk table: which kernels have work and how many tasks per lane they
-// need (bit 4: no long-run chunk, bit 5: no per-block chunk, bits 6..7: tasks per lane of stitch4_kernel, bits 8..11: of stitch_kernel).
+// need (bit 1: chunks flagged for stitch_dense_kernel, bit 4: no long-run chunk, bit 5: no per-block chunk, bits 6..7: tasks per
+// lane of stitch4_kernel, bits 8..11: of stitch_kernel).
 inline int stitch_launch_bits(const Chunk* chunks, uint64_t n_chunks)
 {
     uint32_t max_pb = 0;
-    bool any_long = false, any_long2 = false, any_pb = false;
+    bool any_long = false, any_long2 = false, any_pb = false, any_dense = false;
     for (uint64_t i = 0; i < n_chunks; ++i) {
         const uint64_t dn = chunks[i].dst_n;
         if (dn & CHUNK_LONG) { any_long = true; any_long2 = any_long2 || (dn & CHUNK_LONG2) != 0; }
+        else if (dn & CHUNK_DENSE) any_dense = true;
         else { any_pb = true; const uint32_t n = chunk_n(dn); if (n > max_pb) max_pb = n; }
     }
     const int tpt = max_pb <= 256u ? 1 : (max_pb <= 512u ? 2 : 4);
-    return (any_long ? 0 : 16) | (any_pb ? 0 : 32) | ((any_long2 ? 2 : 1) << 6) | (tpt << 8);
+    return (any_dense ? 2 : 0) | (any_long ? 0 : 16) | (any_pb ? 0 : 32) | ((any_long2 ? 2 : 1) << 6) | (tpt << 8);
 }
 
 // XCD-aware launch order.  Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
         const uint64_t tb = a.chunks[c].task_begin;
         const uint64_t dn = a.chunks[c].dst_n;
         const uint32_t n_hdr = uint32_t(dn >> 48) & CHUNK_N_MASK;
-        if (filter == 2u && (dn & CHUNK_LONG)) continue;   // long-run chunks belong to stitch4_kernel
+        if (filter == 2u && (dn & (CHUNK_LONG | CHUNK_DENSE))) continue;   // long-run chunks belong to stitch4_kernel, dense ones to stitch_dense_kernel
         const uint64_t dst = dn & ((1ull << 48) - 1);
         const uint32_t head = uint32_t(dst & 15ull);
         // a chunk table that points outside the descriptor array is refused, not followed
@@ -438,8 +438,9 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
 //      the workgroup then takes the list with lane = piece, all gathers of a lane in flight together: one more memory
 //      latency per chunk however long the tasks are.
 //   C  the image leaves as aligned 16-byte non-temporal stores, 1 KiB per wave instruction; each block is zeroed as it goes.
-// A chunk larger than the 8 KiB image is done in windows (B and C per window); dense chunks are about 7 KiB.
-constexpr uint32_t DENSE_STAGE = 8192u;                    // bytes of the LDS image
+// A chunk larger than the 12 KiB image is done in windows (B and C per window); the packer keeps the chunks of a dense image
+// below it (1024 descriptors or 12 KiB, whichever comes first).
+constexpr uint32_t DENSE_STAGE = 12288u;                   // bytes of the LDS image (CHUNK_BYTES_DENSE + 16)
 constexpr uint32_t DENSE_PIECES = DENSE_STAGE / 16u + 8u;  // continuation pieces of one window
 
 // up to n (1..16) bytes x, first byte lowest, OR-ed into the LDS image at byte offset o
@@ -490,7 +491,9 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
     if (c >= a.n_chunks) return;
     const uint64_t tb = a.chunks[c].task_begin;
     const uint64_t dn = a.chunks[c].dst_n;
-    if (filter == 2u && (dn & CHUNK_LONG)) return;         // long-run chunks belong to stitch4_kernel
+    if (dn & CHUNK_LONG) return;                           // long-run chunks belong to stitch4_kernel
+    if (filter == 3u && !(dn & CHUNK_DENSE)) return;       // (the other chunks of this image go to the per-block kernel)
+    const bool fused = (dn & CHUNK_DENSE) != 0ull;         // the chunk may hold fused substitution descriptors
     const uint32_t n_hdr = uint32_t(dn >> 48) & CHUNK_N_MASK;
     const uint64_t dst = dn & ((1ull << 48) - 1);
     const uint32_t head = uint32_t(dst & 15ull);
@@ -513,6 +516,7 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
     u32x4 g[TPT];
     uint32_t len[TPT];
     uint64_t sw[TPT];                                       // space << 40 | source offset (the literal of an immediate task)
+    uint32_t patch[TPT];                                    // fused substitution: bytes before the literal | literal << 12 | 1 << 20
     auto load_tasks = [&](bool first_time) -> uint32_t {
         uint64_t d[TPT];
         uint32_t lsum = 0, bad = 0u;
@@ -520,12 +524,23 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
         for (int k = 0; k < TPT; ++k) d[k] = tid * TPT + k < n ? a.desc[tb + tid * TPT + k] : 0ull;   // (0: an empty task)
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
-            len[k] = uint32_t(d[k] >> 40) & ((1u << 22) - 1u);
-            const uint32_t space = uint32_t(d[k] >> 62);
-            const uint64_t so = d[k] & OFF40;
-            const uint64_t limit = space == SPACE_PROTEOME ? a.src0_len : (space == SPACE_PAYLOAD ? a.src1_len : ~0ull);
-            if (space == SPACE_IMM ? len[k] > IMM_MAX_BYTES : so + len[k] > limit) { bad |= 1u << k; len[k] = 0; }   // never read out of bounds
-            sw[k] = (uint64_t(space) << 40) | so;
+            patch[k] = 0u;
+            if ((d[k] & SNV3_MARK) == SNV3_MARK) {
+                // a fused substitution is ONE reference run of len1 + 1 + len2 bytes whose byte len1 is replaced afterwards
+                const uint32_t len1 = uint32_t(d[k] >> 29) & 0xFFFu, len2 = uint32_t(d[k] >> 41) & 0xFFFu;
+                const uint64_t so = d[k] & SNV3_MAX_SRC;
+                len[k] = len1 + 1u + len2;
+                patch[k] = len1 | (uint32_t(d[k] >> 53) & 0xFFu) << 12 | 1u << 20;
+                if (!fused || so + len1 > a.src0_len || (len2 && so + len[k] > a.src0_len)) { bad |= 1u << k; len[k] = 0; patch[k] = 0u; }
+                sw[k] = (uint64_t(SPACE_PROTEOME) << 40) | so;
+            } else {
+                len[k] = uint32_t(d[k] >> 40) & ((1u << 22) - 1u);
+                const uint32_t space = uint32_t(d[k] >> 62);
+                const uint64_t so = d[k] & OFF40;
+                const uint64_t limit = space == SPACE_PROTEOME ? a.src0_len : (space == SPACE_PAYLOAD ? a.src1_len : ~0ull);
+                if (space == SPACE_IMM ? len[k] > IMM_MAX_BYTES : so + len[k] > limit) { bad |= 1u << k; len[k] = 0; }   // never read out of bounds
+                sw[k] = (uint64_t(space) << 40) | so;
+            }
             lsum += len[k];
         }
 #pragma unroll
@@ -534,7 +549,7 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
         return lsum;
     };
     const uint32_t lsum = load_tasks(true);
-    {   // zero the image: 2 x 16 B per lane, and the few dwords a put may touch past its end
+    {   // zero the image: 3 x 16 B per lane, and the few dwords a put may touch past its end
         const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (uint32_t q = 0; q < DENSE_STAGE / 4096u; ++q) *reinterpret_cast<u32x4*>(&s_img[(q * 256u + tid) * 4u]) = z;
@@ -610,6 +625,17 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     if (r[u] != ~0ull && DBG != 3) dense_put(s_img, uint32_t(r[u] >> 46), v[u], (uint32_t(r[u] >> 42) & 15u) + 1u);
+            }
+            lds_barrier();
+        }
+        if (fused) {                                          // (uniform) the literals of the fused substitutions replace the reference bytes under them
+                                                              // (every put is in the image: the barrier after the scan, or the one that ends B')
+            off = off0;
+#pragma unroll
+            for (int k = 0; k < TPT; ++k) {
+                const uint32_t q = off + (patch[k] & 0xFFFu);
+                if ((patch[k] >> 20) && q >= w0 && q < w1) reinterpret_cast<uint8_t*>(s_img)[q - w0] = uint8_t(patch[k] >> 12);
+                off += len[k];
             }
             lds_barrier();
         }
@@ -1511,10 +1537,10 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     if (per_block_only) {
         switch (tpt) { case 1: V2P_LAUNCH(1, 0); break; case 2: V2P_LAUNCH(2, 0); break; default: V2P_LAUNCH(4, 0); break; }
     } else {
-        if (!(nontemporal & 32)) {
-            if (dense) { if (nt) V2P_LD(true, 2); else V2P_LD(false, 2); }
-            else switch (tpt) { case 1: V2P_LAUNCH(1, 2); break; case 2: V2P_LAUNCH(2, 2); break; default: V2P_LAUNCH(4, 2); break; }
-        }
+        // chunks flagged dense (bit 1) always go to the dense kernel; the plain ones follow `dense`
+        const bool plain = !(nontemporal & 32), flagged = (nontemporal & 2) != 0, plain_to_dense = plain && dense;
+        if (flagged || plain_to_dense) { if (nt) V2P_LD(true, plain_to_dense ? 2 : 3); else V2P_LD(false, plain_to_dense ? 2 : 3); }
+        if (plain && !plain_to_dense) switch (tpt) { case 1: V2P_LAUNCH(1, 2); break; case 2: V2P_LAUNCH(2, 2); break; default: V2P_LAUNCH(4, 2); break; }
         if (!(nontemporal & 16)) { if (tpt_long == 1) V2P_LAUNCH3(1, 1); else V2P_LAUNCH3(2, 1); }
     }
 #undef V2P_LD

@@ -700,7 +700,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     a.tx_task_begin = reinterpret_cast<const uint64_t*>(d + o_tb); a.tx_alt_begin = reinterpret_cast<const uint64_t*>(d + o_ab);
     a.code = d + o_code; a.start_pos = reinterpret_cast<const uint32_t*>(d + o_sp); a.length = reinterpret_cast<const uint32_t*>(d + o_ln);
     a.start_pos_res = reinterpret_cast<const uint32_t*>(d + o_sr); a.alt = b->d_payload.ptr();
-    a.proteome_len = c->proteome_len; a.window = window_bytes; a.long_run = kernel == 1;
+    a.proteome_len = c->proteome_len; a.window = window_bytes; a.long_run = kernel == 1; a.dense = kernel == 3;
     a.tx_res_base = reinterpret_cast<const uint64_t*>(d + o_base); a.tx_desc_count = reinterpret_cast<uint32_t*>(d + o_cnt);
     a.desc_base = reinterpret_cast<const uint64_t*>(d + o_dbase); a.meta = reinterpret_cast<uint32_t*>(d + o_meta);
     a.status = reinterpret_cast<unsigned long long*>(b->d_status.ptr());
@@ -751,7 +751,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     if (build_ms) *build_ms = ms;
     b->n_desc = n_desc; b->n_chunks = n_windows; b->n_payload = s->n_alt; b->out_bytes = out_bytes; b->n_haps = n_h;
     const int tpt = meta[3] <= 256u ? 1 : (meta[3] <= 512u ? 2 : 4);
-    b->launch_hint = (meta[0] ? 0 : 16) | (meta[2] ? 0 : 32) | ((meta[1] ? 2 : 1) << 6) | (tpt << 8);
+    b->launch_hint = ((meta[0] & 2u) ? 2 : 0) | ((meta[0] & 1u) ? 0 : 16) | (meta[2] ? 0 : 32) | ((meta[1] ? 2 : 1) << 6) | (tpt << 8);
     b->uses_proteome = true;
     b->finalized = true;
     return V2P_OK;
