@@ -226,9 +226,9 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
         return 101;
     }
     std::vector<uint64_t> hap_begin(2 * S + 1);
-    v2p_decode_counts(dec, hap_begin.data());
+    if (v2p_decode_counts(dec, hap_begin.data()) != V2P_OK) { std::fprintf(stderr, "panicked: decode counts unavailable\n"); return 101; }
     std::vector<uint32_t> ids(hap_begin.back() + 1);
-    v2p_decode_download(dec, ids.data());
+    if (v2p_decode_download(dec, ids.data()) != V2P_OK) { std::fprintf(stderr, "panicked: %s\n", v2p_last_error(ctx.raw())); return 101; }
     float kms[4] = {0, 0, 0, 0};
     v2p_decode_timing(dec, &kms[0], &kms[1], &kms[2], &kms[3]);
     v2p_decode_destroy(dec);
@@ -349,11 +349,21 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
             chk(v2p_batch_hap_range(b, 2 * s + h, &begin, &len));
             buf.resize(len);
             if (len) chk(v2p_batch_download(b, begin, len, buf.data()));
-            if (compressed) { for (uint64_t o = 0; o < len; o += 1u << 30) gzwrite(gz, buf.data() + o, unsigned(std::min<uint64_t>(len - o, 1u << 30))); }
-            else f.write(reinterpret_cast<const char*>(buf.data()), std::streamsize(len));
+            bool ok = true;
+            if (compressed) {
+                for (uint64_t o = 0; o < len && ok; o += 1u << 30) {
+                    const unsigned part = unsigned(std::min<uint64_t>(len - o, 1u << 30));
+                    ok = gzwrite(gz, buf.data() + o, part) == int(part);
+                }
+            } else {
+                f.write(reinterpret_cast<const char*>(buf.data()), std::streamsize(len));
+                ok = bool(f);
+            }
+            if (!ok) { std::fprintf(stderr, "Could not write %s\n", path.c_str()); if (gz) gzclose(gz); return 101; }   // (a full disk is an error, not a short file)
             written += len;
         }
-        if (gz) gzclose(gz);
+        if (gz && gzclose(gz) != Z_OK) { std::fprintf(stderr, "Could not write %s\n", path.c_str()); return 101; }
+        if (!compressed) { f.close(); if (!f) { std::fprintf(stderr, "Could not write %s\n", path.c_str()); return 101; } }
     }
     t_write = since(t0);
     std::printf("vcf: %llu records, %llu probands, %llu bytes of FASTA written to %s\n", (unsigned long long)R, (unsigned long long)S,
