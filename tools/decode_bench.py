@@ -122,9 +122,10 @@ def main():
     assert st[0] == np.uint64(0xFFFFFFFFFFFFFFFF), f"device status {st[0]:x}"
     hb = d_hb.cpu().numpy().astype(np.int64)
     ids = d_ids.cpu().numpy().view(np.uint32)
-    assert int(hb[-1]) == n_ids_expected
-    for h in (0, 1):
-        assert (np.diff(hb)[h::2] == ((m >> h) & 1).sum(axis=0)).all()
+    if not os.environ.get("V2P_DECODE_DBG"):
+        assert int(hb[-1]) == n_ids_expected
+        for h in (0, 1):
+            assert (np.diff(hb)[h::2] == ((m >> h) & 1).sum(axis=0)).all()
     for s in (() if os.environ.get("V2P_DECODE_DBG") else (0, S // 2, S - 1)):
         for h in (0, 1):
             assert (ids[hb[2 * s + h]:hb[2 * s + h + 1]] == np.nonzero((m[:, s] >> h) & 1)[0]).all()

@@ -42,6 +42,15 @@ __device__ __forceinline__ void dec_report(unsigned long long* status, uint64_t 
     atomicMin(status, (static_cast<unsigned long long>(field) << 8) | reason);
 }
 
+// Workgroup barrier that orders LDS only.  __syncthreads() also waits for vmcnt(0): in the parse kernel that is the NEXT tile's
+// prefetch (a full HBM latency at every barrier) and the carrier stores; in the emit kernel every id store in flight.
+__device__ __forceinline__ void dec_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // 8-bit mask (<< 7) of the bytes of the word pair (w0, w1) equal to '\t': exact 0x80 flags per byte, then one dot product per
 // word weighs byte k with 2^k
 __device__ __forceinline__ uint32_t tab_bits8(uint32_t w0, uint32_t w1)
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
         const uint32_t cnt = uint32_t(__builtin_popcount(tm));
         const uint32_t incl = dec_wave_incl_scan(cnt);
         if ((tid & 63u) == 63u) wave_tot[wave] = incl;
-        __syncthreads();
+        dec_lds_barrier();
         uint32_t wbase = 0, tile_tabs = 0;
 #pragma unroll
         for (uint32_t w = 0; w < NW; ++w) {
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
         const bool last = (t + 1u == n_tiles);
         if (last && tid == 0) consider(Lq - tile0, Lq >= lo + 2u, [&] { return tile_tabs; });   // the end of the line closes the last column
         const uint32_t n_ends = tile_tabs + (last ? 1u : 0u);
-        __syncthreads();
+        dec_lds_barrier();
         const uint32_t n_list = s_nlist;
 
         for (uint32_t j = tid; j < n_list; j += BS) {
@@ -229,26 +238,29 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
                 const uint32_t a8 = (p - 8u) & (RING - 1u), i0 = a8 >> 2, sh = a8 & 3u;
                 const uint32_t w0 = ring32[i0], w1 = ring32[(i0 + 1u) & (RING / 4u - 1u)], w2 = ring32[(i0 + 2u) & (RING / 4u - 1u)];
                 const uint32_t lo32 = __builtin_amdgcn_alignbyte(w1, w0, sh), hi32 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                // Straight-line: the parser is the heaviest part of the kernel (a third of its VALU work before this form).
                 const uint32_t c_hi = eq_bytes(hi32, 0x3A3A3A3Au), c_lo = eq_bytes(lo32, 0x3A3A3A3Au);
-                const uint32_t t_hi = eq_bytes(hi32, 0x09090909u), t_lo = eq_bytes(lo32, 0x09090909u);
-                const int ci = c_hi ? 4 + int((31u - uint32_t(__builtin_clz(c_hi))) >> 3) : (c_lo ? int((31u - uint32_t(__builtin_clz(c_lo))) >> 3) : -1);
-                const int ti = t_hi ? 4 + int((31u - uint32_t(__builtin_clz(t_hi))) >> 3) : (t_lo ? int((31u - uint32_t(__builtin_clz(t_lo))) >> 3) : -1);
-                if (ti > ci) {
-                    slow = false;                                              // the column starts after the window's last ':'
-                } else if (ci >= 0) {
-                    const uint32_t L = 7u - uint32_t(ci);
-                    uint64_t T = L ? ((uint64_t(hi32) << 32) | lo32) >> (8u * uint32_t(ci + 1)) : 0ull;
-                    uint32_t v = 0u;
-                    bool digits = true;
-                    for (uint32_t k = 0; k < L; ++k) {
-                        const uint32_t d = (uint32_t(T) & 0xFFu) - uint32_t('0');
-                        digits = digits && d <= 9u;
-                        v = v * 10u + d;
-                        T >>= 8;
-                    }
-                    if (digits) { entry = v; slow = false; }                   // L == 0: "" -> nothing; v < 10^7 is a valid i32
-                    else if (L == 1u && hi32 >> 24 == uint32_t('.')) slow = false;
-                }
+                const uint32_t d_hi = c_hi | eq_bytes(hi32, 0x09090909u), d_lo = c_lo | eq_bytes(lo32, 0x09090909u);   // ':' or tab, 0x80 per byte
+                const bool in_hi = d_hi != 0u;
+                const uint32_t dsel = in_hi ? d_hi : d_lo, csel = in_hi ? c_hi : c_lo;   // the word that holds the window's last delimiter
+                const bool any = dsel != 0u;
+                const uint32_t top = 31u - uint32_t(__builtin_clz(dsel | 1u));         // bit of its flag (7, 15, 23, 31)
+                const bool is_colon = any && ((csel >> top) & 1u) != 0u;
+                const uint32_t bi = (top >> 3) + (in_hi ? 4u : 0u);                     // its byte in the window, 0..7
+                // the bytes behind it as digit values, everything up to the delimiter as leading zeros
+                const uint64_t X = (uint64_t(hi32) << 32) | lo32;
+                const uint64_t D = (X ^ 0x3030303030303030ull) & ((~0ull << (8u * bi)) << 8);
+                const uint32_t Dl = uint32_t(D), Dh = uint32_t(D >> 32);
+                const bool digits = (((((Dl & 0x7F7F7F7Fu) + 0x76767676u) | Dl) | (((Dh & 0x7F7F7F7Fu) + 0x76767676u) | Dh)) & 0x80808080u) == 0u;   // every byte <= 9
+                // eight decimal digits, the first character the most significant: pairs, then fours
+                const uint32_t tl = ((Dl << 3) + (Dl << 1)) + (Dl >> 8), th = ((Dh << 3) + (Dh << 1)) + (Dh >> 8);
+                const uint32_t vl = (tl & 0xFFu) * 100u + ((tl >> 16) & 0xFFu), vh = (th & 0xFFu) * 100u + ((th >> 16) & 0xFFu);
+                const uint32_t value = vl * 10000u + vh;                                // < 10^7: a valid i32
+                const bool no_colon = any && !is_colon;                                 // the column starts after the window's last ':': nothing
+                const bool dot = is_colon && bi == 6u && (hi32 >> 24) == uint32_t('.');
+                const bool number = is_colon && digits;                                 // (no digits at all: "" -> nothing)
+                entry = number ? value : 0u;
+                slow = !(no_colon || dot || number);
             }
             if (slow) {
             while (q > lo) {
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
             }
         }
         fields_before += n_ends;
-        __syncthreads();
+        dec_lds_barrier();
         cur = nxt;
     }
     if (tid == 0) {
@@ -466,14 +478,6 @@ __global__ __launch_bounds__(1024) void scan_haps_kernel(DecodeArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------- emit
-// Workgroup barrier that orders LDS only (__syncthreads() would also wait for every id store in flight).
-__device__ __forceinline__ void dec_lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
 // One workgroup per (64-record block, haplotype range), a write cursor per haplotype in LDS.  The block's records are
 // taken in order, one step each: inside a record every sample appears once, so thread k places carrier k (cursor
 // read-modify-write, then the id stores) with no conflict, and an LDS-only barrier separates the records.  The first 256
