@@ -89,6 +89,24 @@ def test_random_vcfs(built, gpu_ctx, seed, n_records, n_samples, p_zero):
     assert_same_lists(gpu_ctx, random_vcf(seed, n_records, n_samples, p_zero=p_zero, unique_positions=False))
 
 
+def test_more_haplotypes_than_one_cursor_range_and_dense_records(built, gpu_ctx):
+    """count / emit keep 6 144 haplotype cursors in LDS per workgroup: 3 300 samples take two ranges; with no empty column a record
+    has more carriers than the 256 an emit step fetches ahead."""
+    assert_same_lists(gpu_ctx, random_vcf(11, 70, 3300, p_zero=0.7, unique_positions=False))
+    assert_same_lists(gpu_ctx, random_vcf(12, 130, 900, p_zero=0.0, unique_positions=False))
+
+
+def test_64_bit_cursors(built, gpu_ctx):
+    """Calls with 2^32 ids or more switch emit to 64-bit cursors; V2P_DECODE_CURSOR64 forces that kernel for a small call."""
+    import os
+    os.environ["V2P_DECODE_CURSOR64"] = "1"
+    try:
+        assert_same_lists(gpu_ctx, random_vcf(13, 200, 300, p_zero=0.4, unique_positions=False))
+        assert_same_lists(gpu_ctx, random_vcf(14, 66, 3300, p_zero=0.8, unique_positions=False))
+    finally:
+        del os.environ["V2P_DECODE_CURSOR64"]
+
+
 def test_columns_longer_than_a_tile_and_rows_at_every_alignment(built, gpu_ctx):
     """Sample columns with kilobytes of FORMAT text before the mask, so that columns straddle the 4 KiB parse tiles."""
     head = "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tA\tB\tC\tD\tE\n"

@@ -20,6 +20,7 @@
 //           step each; inside a record every sample appears once, so thread k places carrier k with no conflict and an
 //           LDS-only barrier separates the records.
 #include "decode_kernels.h"
+#include <cstdlib>
 
 namespace v2p {
 namespace {
@@ -497,12 +498,14 @@ __global__ __launch_bounds__(256) void emit_kernel(DecodeArgs a, uint32_t n_rang
     // Workgroup b runs on XCD b % 8: every XCD takes a contiguous eighth of the record blocks, so the partial lines that
     // neighbouring blocks write into a haplotype's list meet in one L2 (measured: 0.27 ms against 0.31 ms in launch order).
     const uint32_t n_rowblocks = (a.n_rows + DEC_ROWBLOCK - 1u) / DEC_ROWBLOCK, per_xcd = (n_rowblocks + 7u) / 8u;
+    const bool force64 = (n_ranges >> 31) != 0u;                                // (tests: the 64-bit cursors for a small call)
+    n_ranges &= 0x7FFFFFFFu;
     const uint32_t unit = blockIdx.x / n_ranges, rg = blockIdx.x % n_ranges;
     const uint32_t rbk = (unit & 7u) * per_xcd + (unit >> 3);
     if (rbk >= n_rowblocks) return;
     const uint32_t n_haps = 2u * a.n_samples, h0 = rg * DEC_RANGE_HAPS, hn = min(DEC_RANGE_HAPS, n_haps - h0);
     const uint64_t total = a.hap_begin[n_haps];
-    if (total > a.ids_capacity || ((total >> 32) != 0ull) != (sizeof(CUR) == 8)) return;
+    if (total > a.ids_capacity || ((total >> 32) != 0ull || force64) != (sizeof(CUR) == 8)) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t r0 = rbk * DEC_ROWBLOCK, r1 = min(r0 + DEC_ROWBLOCK, a.n_rows);
     {
@@ -626,8 +629,10 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, unsigned phase
     }
     if (phases & 8u) {
         const uint32_t units = 8u * ((n_rowblocks + 7u) / 8u);
-        hipLaunchKernelGGL(emit_kernel<uint32_t>, dim3(units * n_ranges), dim3(256), range_haps * 4u, stream, a, n_ranges);
-        hipLaunchKernelGGL(emit_kernel<uint64_t>, dim3(units * n_ranges), dim3(256), range_haps * 8u, stream, a, n_ranges);
+        const bool force64 = getenv("V2P_DECODE_CURSOR64") != nullptr;            // test hook: exercise the 64-bit cursor kernel on small inputs
+        const uint32_t nr = n_ranges | (force64 ? 0x80000000u : 0u);
+        hipLaunchKernelGGL(emit_kernel<uint32_t>, dim3(units * n_ranges), dim3(256), range_haps * 4u, stream, a, nr);
+        hipLaunchKernelGGL(emit_kernel<uint64_t>, dim3(units * n_ranges), dim3(256), range_haps * 8u, stream, a, nr);
     }
     return hipGetLastError();
 }
