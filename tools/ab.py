@@ -132,7 +132,12 @@ def main():
                                    d_out.data_ptr(), v["out"], d_status.data_ptr(), v["flags"], 0)
         assert rc == 0
     for v in vs:
+        d_out.zero_()
         launch(v)
+        torch.cuda.synchronize()
+        n8 = (v["out"] // 8) * 8
+        w = d_out[:n8].view(torch.int64)
+        v["chk"] = (int(w.sum().item()) ^ int(w[::7].sum().item() << 1)) & 0xFFFFFFFFFFFF     # all variants of one workload must agree
         launch(v)
     torch.cuda.synchronize()
     # identical variants differ by up to ~6 % with the placement of their buffers in HBM, so every round
@@ -158,7 +163,7 @@ def main():
             v["ms"].append(e0.elapsed_time(e1))
     for v in vs:
         ms = v["ms"]
-        print(f"{v['spec']:48s} mean {statistics.mean(ms):.3f} +- {statistics.pstdev(ms):.3f}  median {statistics.median(ms):.3f}  min {min(ms):.3f}  chunks {v['n_chunks']}")
+        print(f"{v['spec']:48s} mean {statistics.mean(ms):.3f} +- {statistics.pstdev(ms):.3f}  median {statistics.median(ms):.3f}  min {min(ms):.3f}  chunks {v['n_chunks']}  chk {v['chk']:012x}")
 
 
 if __name__ == "__main__":
