@@ -115,6 +115,7 @@ def main():
         if int(kv.get("l1", 0)):
             chunks = l1_order(chunks, img.desc, n_prot, int(kv["l1"]))
         elif int(kv.get("xcd", 1)):
+            os.environ["V2P_XCD_SUB"] = str(int(kv.get("sub", 1)))
             lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, n_prot)
         d_pay = torch.zeros(img.payload.size + 128, dtype=torch.uint8, device=dev)
         d_pay[64:64 + img.payload.size] = torch.from_numpy(img.payload).to(dev)

@@ -35,6 +35,7 @@ struct BuildArgs {
     uint64_t* chunk_first;        // [n_windows] index of the first descriptor of each chunk
     Chunk*    chunks_tmp;         // [n_windows] in result order
     uint8_t*  bucket;             // [n_windows] proteome slice of each chunk
+    uint8_t*  sub;                // [n_windows] window of that slice (xcd_sub_window)
     uint64_t* hap_out_begin;      // [n_haps + 1]
     uint32_t* meta;               // [4]: any long-run chunk, any with > 256 descriptors, any per-block chunk, most descriptors of a per-block chunk
     unsigned long long* status;
@@ -44,5 +45,10 @@ hipError_t launch_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, uint64
 // phase 0: count descriptors per transcript (and validate); phase 1: emit descriptors + chunk table + hap_out_begin
 hipError_t launch_build(const BuildArgs& a, uint64_t n_windows, uint64_t n_desc, uint64_t out_bytes, int phase, hipStream_t stream);
 hipError_t launch_xcd_order(const Chunk* in, const uint8_t* bucket, uint64_t n, uint32_t* hist, Chunk* out, hipStream_t stream);
+// stable counting sort of the table by window (the pass before launch_xcd_order): hist = XCD_SUB * n_blocks u32, start = that many
+// + 1 u64, tiles = scratch of launch_scan_u32 for that many entries; out / out_bucket receive the permuted table and slices
+hipError_t launch_sub_order(const Chunk* in, const uint8_t* bucket, const uint8_t* sub, uint64_t n, uint32_t* hist, uint64_t* start, uint64_t* tiles,
+                            Chunk* out, uint8_t* out_bucket, hipStream_t stream);
+uint64_t scan_tiles_for(uint64_t n);
 
 }  // namespace v2p

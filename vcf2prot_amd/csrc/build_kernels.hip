@@ -243,10 +243,42 @@ __global__ __launch_bounds__(256) void chunk_kernel(BuildArgs a, uint64_t n_wind
     const uint64_t per = (a.proteome_len + 7) / 8;
     const uint64_t bk = per ? key / per : 0;
     a.bucket[k] = uint8_t(bk < 8 ? bk : 7);
+    a.sub[k] = xcd_sub_window(key, a.bucket[k], per);
     // what the launcher needs to know about the table
     if (a.long_run) { atomicOr(&a.meta[0], 1u); if (tasks > CHUNK_TASKS) atomicOr(&a.meta[1], 1u); }
     else if (a.dense) atomicOr(&a.meta[0], 2u);
     else { atomicOr(&a.meta[2], 1u); atomicMax(&a.meta[3], uint32_t(n)); }
+}
+
+// ---- inside a slice, window-major: stable counting sort by window (sir_pack.hpp: order_chunks_for_xcds) ----------------------
+__global__ __launch_bounds__(256) void sub_hist_kernel(const uint8_t* __restrict__ sub, uint64_t n, uint32_t* __restrict__ hist, uint64_t n_blocks)
+{
+    static_assert(XCD_SUB == 256, "one counter per thread");
+    __shared__ uint32_t s[XCD_SUB];
+    s[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t k = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    if (k < n) atomicAdd(&s[sub[k]], 1u);
+    __syncthreads();
+    hist[uint64_t(threadIdx.x) * n_blocks + blockIdx.x] = s[threadIdx.x];        // window-major: one scan gives every (window, block) its start
+}
+
+__global__ __launch_bounds__(256) void sub_scatter_kernel(const Chunk* __restrict__ in, const uint8_t* __restrict__ bucket, const uint8_t* __restrict__ sub,
+                                                          uint64_t n, const uint64_t* __restrict__ start, uint64_t n_blocks,
+                                                          Chunk* __restrict__ out, uint8_t* __restrict__ out_bucket)
+{
+    __shared__ uint8_t s_sub[256];
+    const uint64_t k = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    const bool live = k < n;
+    const uint8_t mine = live ? sub[k] : 0;
+    s_sub[threadIdx.x] = mine;
+    __syncthreads();
+    if (!live) return;
+    uint32_t rank = 0;                                                           // chunks of the same window earlier in this block
+    for (uint32_t t = 0; t < threadIdx.x; ++t) rank += s_sub[t] == mine ? 1u : 0u;
+    const uint64_t pos = start[uint64_t(mine) * n_blocks + blockIdx.x] + rank;
+    out[pos] = in[k];
+    out_bucket[pos] = bucket[k];
 }
 
 // ---- XCD-aware order: entry 8j + x = j-th chunk of slice x (stable) ---------------------------------------------------------
@@ -313,6 +345,20 @@ hipError_t launch_build(const BuildArgs& a, uint64_t n_windows, uint64_t n_desc,
         const uint64_t m = n_windows > a.n_haps + 1 ? n_windows : a.n_haps + 1;
         hipLaunchKernelGGL(chunk_kernel, dim3(uint32_t((m + 255) / 256)), dim3(256), 0, stream, a, n_windows, n_desc, out_bytes);
     }
+    return hipGetLastError();
+}
+
+uint64_t scan_tiles_for(uint64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 1; }
+
+hipError_t launch_sub_order(const Chunk* in, const uint8_t* bucket, const uint8_t* sub, uint64_t n, uint32_t* hist, uint64_t* start, uint64_t* tiles,
+                            Chunk* out, uint8_t* out_bucket, hipStream_t stream)
+{
+    const uint64_t n_blocks = (n + 255) / 256;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sub_hist_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, stream, sub, n, hist, n_blocks);
+    hipError_t e = launch_scan_u32(hist, uint64_t(XCD_SUB) * n_blocks, start, tiles, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sub_scatter_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, stream, in, bucket, sub, n, start, n_blocks, out, out_bucket);
     return hipGetLastError();
 }
 

@@ -40,6 +40,11 @@
 // "later task wins" semantics only on the ordered path (v2p_execute_gir).
 #pragma once
 #include <cstdint>
+#if defined(__HIPCC__)
+#define V2P_HOST_DEVICE __host__ __device__     // (this header is also compiled by g++ for the host-only library)
+#else
+#define V2P_HOST_DEVICE
+#endif
 #include <cstring>
 #include <vector>
 #include <string>
@@ -382,6 +387,15 @@ inline int stitch_launch_bits(const Chunk* chunks, uint64_t n_chunks)
     return (any_dense ? 2 : 0) | (any_long ? 0 : 16) | (any_pb ? 0 : 32) | ((any_long2 ? 2 : 1) << 6) | (tpt << 8);
 }
 
+constexpr uint32_t XCD_SUB = 256;                  // windows per proteome slice in the launch order
+// window of reference position `key` inside slice `slice` (slices are `per` bytes): host and device builders must agree
+V2P_HOST_DEVICE inline uint8_t xcd_sub_window(uint64_t key, uint32_t slice, uint64_t per)
+{
+    const uint64_t w = (per + XCD_SUB - 1) / XCD_SUB, in = key - uint64_t(slice) * per;
+    const uint64_t q = w ? in / w : 0;
+    return uint8_t(q < XCD_SUB ? q : XCD_SUB - 1);
+}
+
 // XCD-aware launch order.  Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on
 // XCD b % 8, observed dispatch behaviour), each XCD has its own 4 MiB L2, and every haplotype
 // re-reads the same proteome.  Reordering the chunk table so that entry 8*j + x is the j-th
@@ -393,6 +407,7 @@ inline void order_chunks_for_xcds(Chunk* chunks, uint64_t n_chunks, const uint64
 {
     if (n_chunks < 2 * n_xcd || proteome_len == 0 || n_desc == 0) return;
     std::vector<uint32_t> bucket(n_chunks);
+    std::vector<uint8_t> sub(n_chunks);
     std::vector<uint64_t> count(n_xcd, 0);
     for (uint64_t c = 0; c < n_chunks; ++c) {
         const uint64_t tb = chunks[c].task_begin;
@@ -400,8 +415,10 @@ inline void order_chunks_for_xcds(Chunk* chunks, uint64_t n_chunks, const uint64
         uint64_t key = 0;
         for (uint32_t k = 0; k < n && k < 6 && tb + k < n_desc; ++k)       // skip FASTA literals stored behind the proteome
             if (desc_space(desc[tb + k]) == SPACE_PROTEOME && desc_src(desc[tb + k]) < proteome_len) { key = desc_src(desc[tb + k]); break; }
-        uint64_t b = key / ((proteome_len + n_xcd - 1) / n_xcd);
+        const uint64_t per = (proteome_len + n_xcd - 1) / n_xcd;
+        uint64_t b = key / per;
         bucket[c] = uint32_t(b < n_xcd ? b : n_xcd - 1);
+        sub[c] = xcd_sub_window(key, bucket[c], per);
         ++count[bucket[c]];
     }
     // rank inside the bucket, then interleave: sort key = (rank, bucket)
@@ -409,9 +426,19 @@ inline void order_chunks_for_xcds(Chunk* chunks, uint64_t n_chunks, const uint64
     std::vector<Chunk> out(n_chunks);
     // position of (rank r, bucket x) = number of chunks with rank < r over all buckets + buckets < x holding rank r
     // computed by a counting pass over ranks: ranks are dense per bucket, so iterate rank-major
+    // inside a slice: one window of the proteome after the other (XCD_SUB per slice), every haplotype's chunk of a window
+    // together -- the workgroups an XCD runs at any time then read the SAME few tens of KiB of reference (C2: -5 % at 1 000
+    // samples, -10 % at 250).  Stable counting sort by window, then the stable deal by slice below.
+    std::vector<uint64_t> by_sub(n_chunks);
+    {
+        std::vector<uint64_t> start(XCD_SUB + 1, 0);
+        for (uint64_t c = 0; c < n_chunks; ++c) ++start[sub[c] + 1u];
+        for (uint32_t q = 0; q < XCD_SUB; ++q) start[q + 1] += start[q];
+        for (uint64_t c = 0; c < n_chunks; ++c) by_sub[start[sub[c]]++] = c;
+    }
     std::vector<std::vector<uint64_t>> idx(n_xcd);
     for (unsigned x = 0; x < n_xcd; ++x) idx[x].reserve(count[x]);
-    for (uint64_t c = 0; c < n_chunks; ++c) idx[bucket[c]].push_back(c);
+    for (uint64_t q = 0; q < n_chunks; ++q) idx[bucket[by_sub[q]]].push_back(by_sub[q]);
     uint64_t pos = 0, max_count = 0;
     for (unsigned x = 0; x < n_xcd; ++x) max_count = count[x] > max_count ? count[x] : max_count;
     for (uint64_t r = 0; r < max_count; ++r)

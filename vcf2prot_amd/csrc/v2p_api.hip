@@ -719,8 +719,11 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     if (n_windows > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch");
     DevBuf scratch;                                       // chunk_first, chunks in result order, slices, per-block histograms
     const uint64_t n_blocks = (n_windows + 255) / 256;
+    const uint64_t n_sub = uint64_t(XCD_SUB) * n_blocks;      // counters of the window sort
     const uint64_t s_first = 0, s_tmp = up8(n_windows * 8), s_bucket = s_tmp + up8(n_windows * 16), s_hist = s_bucket + up8(n_windows),
-                   s_end = s_hist + up8((n_blocks + 1) * 8 * 4);
+                   s_sub = s_hist + up8((n_blocks + 1) * 8 * 4), s_tmp2 = s_sub + up8(n_windows), s_bucket2 = s_tmp2 + up8(n_windows * 16),
+                   s_subhist = s_bucket2 + up8(n_windows), s_substart = s_subhist + up8(n_sub * 4), s_subtiles = s_substart + up8((n_sub + 1) * 8),
+                   s_end = s_subtiles + up8(scan_tiles_for(n_sub) * 8);
     HIP_TRY(c, scratch.ensure(s_end), "hipMalloc(build scratch)");
     HIP_TRY(c, b->d_desc.ensure(n_desc * 8), "hipMalloc(desc)");
     HIP_TRY(c, b->d_chunks.ensure(n_windows * sizeof(Chunk)), "hipMalloc(chunks)");
@@ -731,11 +734,18 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     a.chunk_first = reinterpret_cast<uint64_t*>(scratch.ptr() + s_first);
     a.chunks_tmp = reinterpret_cast<Chunk*>(scratch.ptr() + s_tmp);
     a.bucket = scratch.ptr() + s_bucket;
+    a.sub = scratch.ptr() + s_sub;
     a.hap_out_begin = reinterpret_cast<uint64_t*>(b->d_hap.ptr());
     HIP_TRY(c, launch_build(a, n_windows, n_desc, out_bytes, 1, c->stream), "launch(emit)");
     const bool reorder = !(c->flags & V2P_FLAG_RESULT_ORDER) && n_windows >= 16 && c->proteome_len != 0 && n_desc != 0;
-    if (reorder) HIP_TRY(c, launch_xcd_order(a.chunks_tmp, a.bucket, n_windows, reinterpret_cast<uint32_t*>(scratch.ptr() + s_hist),
-                                             reinterpret_cast<Chunk*>(b->d_chunks.ptr()), c->stream), "launch(xcd order)");
+    if (reorder) {
+        Chunk* by_window = reinterpret_cast<Chunk*>(scratch.ptr() + s_tmp2);
+        HIP_TRY(c, launch_sub_order(a.chunks_tmp, a.bucket, a.sub, n_windows, reinterpret_cast<uint32_t*>(scratch.ptr() + s_subhist),
+                                    reinterpret_cast<uint64_t*>(scratch.ptr() + s_substart), reinterpret_cast<uint64_t*>(scratch.ptr() + s_subtiles),
+                                    by_window, scratch.ptr() + s_bucket2, c->stream), "launch(window order)");
+        HIP_TRY(c, launch_xcd_order(by_window, scratch.ptr() + s_bucket2, n_windows, reinterpret_cast<uint32_t*>(scratch.ptr() + s_hist),
+                                    reinterpret_cast<Chunk*>(b->d_chunks.ptr()), c->stream), "launch(xcd order)");
+    }
     else if (n_windows) HIP_TRY(c, hipMemcpyAsync(b->d_chunks.ptr(), a.chunks_tmp, n_windows * sizeof(Chunk), hipMemcpyDeviceToDevice, c->stream), "D2D(chunks)");
     HIP_TRY(c, hipEventRecord(e1, c->stream), "hipEventRecord");
     uint32_t meta[4] = {0, 0, 0, 0};
