@@ -117,10 +117,18 @@ def main():
         elif int(kv.get("xcd", 1)):
             os.environ["V2P_XCD_SUB"] = str(int(kv.get("sub", 1)))
             lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, n_prot)
+        desc_arr = img.desc
+        if int(kv.get("relayout", 0)):            # experiment: the descriptors physically in launch order (chunk after chunk)
+            nd = ((chunks[:, 1] >> np.uint64(48)) & np.uint64(0x7FF)).astype(np.int64)
+            tb = chunks[:, 0].astype(np.int64)
+            new_tb = np.concatenate([[0], np.cumsum(nd)[:-1]])
+            src_idx = np.repeat(tb - new_tb, nd) + np.arange(int(nd.sum()), dtype=np.int64)
+            desc_arr = np.ascontiguousarray(img.desc[src_idx])
+            chunks = np.ascontiguousarray(np.stack([new_tb.astype(np.uint64), chunks[:, 1]], axis=1))
         d_pay = torch.zeros(img.payload.size + 128, dtype=torch.uint8, device=dev)
         d_pay[64:64 + img.payload.size] = torch.from_numpy(img.payload).to(dev)
         v_bits = int(lib.v2p_stitch_launch_bits(chunks.ctypes.data, chunks.shape[0]))
-        v = dict(spec=spec, d_desc=torch.from_numpy(img.desc.view(np.int64)).to(dev), d_chunks=torch.from_numpy(chunks.view(np.int64)).to(dev),
+        v = dict(spec=spec, d_desc=torch.from_numpy(desc_arr.view(np.int64)).to(dev), d_chunks=torch.from_numpy(chunks.view(np.int64)).to(dev),
                  d_pay=d_pay, n_pay=img.payload.size, n_chunks=chunks.shape[0], out=img.out_bytes,
                  flags=int(kv.get("nt", 1)) | v_bits | (int(kv.get("var", 0)) << 12) | (int(kv.get("dbg", 0)) << 16) | (int(kv.get("wgs", 0)) << 24), ms=[])
         vs.append(v)
