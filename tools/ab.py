@@ -112,7 +112,21 @@ def main():
             chunks = np.ascontiguousarray(allc)
             img.desc = img.desc[:n_desc_rep].copy()
             print(f"rep={rep}: {copies} copies of {base.shape[0]} chunks, {n_desc_rep * 8 / 1e6:.2f} MB of descriptors")
-        if int(kv.get("l1", 0)):
+        if int(kv.get("gwin", 0)):               # experiment: window-major over the WHOLE proteome (no per-XCD slices): every XCD sweeps the same windows
+            tb = chunks[:, 0].astype(np.int64)
+            key = np.zeros(tb.size, dtype=np.int64)
+            found = np.zeros(tb.size, dtype=bool)
+            for k in range(6):
+                d = img.desc[np.minimum(tb + k, img.desc.size - 1)]
+                snv = (d >> np.uint64(61)) == np.uint64(7)
+                src = np.where(snv, d & np.uint64((1 << 29) - 1), d & np.uint64((1 << 40) - 1)).astype(np.int64)
+                is_ref = (snv | ((d >> np.uint64(62)) == 0)) & (src < n_prot)
+                take = is_ref & ~found
+                key[take] = src[take]
+                found |= is_ref
+            w = max(1, n_prot // int(kv["gwin"]))
+            chunks = np.ascontiguousarray(chunks[np.argsort(key // w, kind="stable")])
+        elif int(kv.get("l1", 0)):
             chunks = l1_order(chunks, img.desc, n_prot, int(kv["l1"]))
         elif int(kv.get("xcd", 1)):
             os.environ["V2P_XCD_SUB"] = str(int(kv.get("sub", 1)))
