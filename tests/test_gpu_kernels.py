@@ -133,3 +133,37 @@ def test_dense_kernel_on_any_per_block_image(built, coracle, preset, h0, n):
         for b in (d_desc, d_chunks, d_pay):
             b.free()
     d_prot.free()
+
+
+@pytest.mark.parametrize("preset,h0,n", [("C2", 1, 2), ("C3", 5, 4), ("C1", 0, 8)])
+def test_lds_staged_reference_variant_is_exact(built, coracle, preset, h0, n):
+    """stitch4_kernel with the chunk's reference span staged in LDS by global_load_lds_dwordx4 (variants 7 / 11: 36 / 20 KiB windows;
+    the design brief's "LDS-staged reference tile", measured 2-4x slower than the L2 gathers and kept only as that measurement):
+    same bytes, also where a chunk's span does not fit the window and the gathers take over."""
+    from hip_util import DevBuf
+    from vcf2prot_amd import _native as N
+    from vcf2prot_amd.cohort import Cohort
+    lib = N.hip_lib()
+    c = Cohort.preset(preset)
+    prot = c.proteome()
+    want = np.concatenate(oracle_haps(c, coracle, h0, n))
+    d_prot = DevBuf.of(prot)
+    img = c.pack(h0, h0 + n, n_threads=2, kernel=1)
+    chunks = np.ascontiguousarray(img.chunks)
+    assert (chunks[:, 1] >> np.uint64(63)).all()
+    d_desc, d_chunks, d_pay = DevBuf.of(img.desc), DevBuf.of(chunks), DevBuf.of(img.payload)
+    bits = int(lib.v2p_stitch_launch_bits(chunks.ctypes.data, chunks.shape[0]))
+    for var in (7, 11):
+        d_out = DevBuf(img.out_bytes + 32, fill=0x2E)
+        d_status = DevBuf.of(np.full(1, -1, dtype=np.int64))
+        rc = lib.v2p_stitch_launch(None, d_desc.ptr, img.desc.size, d_chunks.ptr, chunks.shape[0], d_prot.ptr, prot.size, d_pay.ptr, img.payload.size,
+                                   d_out.ptr, img.out_bytes, d_status.ptr, 1 | bits | (var << 12), 0)
+        assert rc == 0
+        assert d_status.download().view(np.int64)[0] == -1
+        got = d_out.download()
+        hb = img.hap_out_begin.astype(np.int64)
+        res = np.concatenate([got[hb[i]:hb[i] + c.haplotype(h0 + i).n_res] for i in range(n)])
+        assert np.array_equal(res, want), (preset, var)
+        d_out.free(); d_status.free()
+    for b in (d_desc, d_chunks, d_pay, d_prot):
+        b.free()

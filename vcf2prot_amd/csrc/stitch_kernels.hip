@@ -781,7 +781,7 @@ __device__ __forceinline__ void ragged_block(const TaskRec* s_rec, const uint64_
     for (uint32_t q = ka; q < kb; ++q) op[q] = uint8_t(o[q >> 2] >> (8u * (q & 3u)));
 }
 
-template <int TPT, bool NT, int DBG = 0, int ROWS = 8>
+template <int TPT, bool NT, int DBG = 0, int ROWS = 8, uint32_t WIN = 0>
 __global__ __launch_bounds__(256) void stitch4_kernel(const uint64_t* __restrict__ p_desc, const Chunk* __restrict__ p_chunks,
                                                       const uint8_t* __restrict__ p_src0, const uint8_t* __restrict__ p_src1,
                                                       uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
@@ -798,6 +798,12 @@ __global__ __launch_bounds__(256) void stitch4_kernel(const uint64_t* __restrict
     __shared__ u32x4 s_mask[17];
     __shared__ __attribute__((aligned(16))) uint32_t s_wt[TPT][4];           // per wave and round: bytes (low 20 bits) | non-empty tasks
     __shared__ __attribute__((aligned(16))) uint32_t s_w[2][4];              // [0] block-map counts per wave, [1][0] bad-descriptor flag
+    // WIN != 0 (variant 7, the "LDS-staged reference tile" of the design brief): the span of the proteome that the chunk's reference
+    // copies read is brought into LDS with wave-contiguous 16-byte direct loads (global_load_lds_dwordx4: 1 KiB per wave instruction,
+    // every line touched once, no VGPRs) and the bulk phase assembles its blocks from LDS (two aligned 16-byte reads + a funnel shift)
+    // instead of one unaligned gather each.  Chunks whose span does not fit keep the gathers.
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[WIN ? WIN + 32u : 16u];
+    __shared__ uint32_t s_span[2];                                           // [0] first, [1] one past the last 16-byte block of that span
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint16_t* const s_map = reinterpret_cast<const uint16_t*>(s_map32);
@@ -825,7 +831,7 @@ __global__ __launch_bounds__(256) void stitch4_kernel(const uint64_t* __restrict
             for (uint32_t k = 0; k < 4u; ++k) m[k] = tid <= 4u * k ? 0xFFFFFFFFu : (tid >= 4u * k + 4u ? 0u : 0xFFFFFFFFu << (8u * (tid - 4u * k)));
             s_mask[tid] = m;
         }
-        if (tid == 0u) s_w[1][0] = 0u;
+        if (tid == 0u) { s_w[1][0] = 0u; s_span[0] = ~0u; s_span[1] = 0u; }
         {
             u32x4 z = {0u, 0u, 0u, 0u};
             reinterpret_cast<u32x4*>(s_map32)[2u * tid] = z;
@@ -865,6 +871,10 @@ __global__ __launch_bounds__(256) void stitch4_kernel(const uint64_t* __restrict
                 const bool ref = snv[k] || space == SPACE_PROTEOME;
                 bad = bad || src + bytes > (ref ? src0_len : src1_len);      // never read out of bounds: task.rs would panic
                 a = reinterpret_cast<uint64_t>(ref ? p_src0 : p_src1) + src;
+                if (WIN && ref && !bad && bytes != 0u) {
+                    atomicMin(&s_span[0], uint32_t(src >> 4));
+                    atomicMax(&s_span[1], uint32_t((src + bytes + 15u) >> 4));
+                }
             }
             if (bad && bytes != 0u) {                                       // reported, and the chunk is not executed
                 report(p_status, tb + i, STATUS_SRC_OOB);
@@ -888,6 +898,17 @@ __global__ __launch_bounds__(256) void stitch4_kernel(const uint64_t* __restrict
         if (DBG == 20) q1 = __builtin_amdgcn_s_memtime();
         lds_barrier();
 
+        uint64_t win_lo = 0ull, win_hi = 0ull;                               // addresses the LDS window covers (none: empty)
+        if (WIN) {
+            const uint32_t b0 = s_span[0], b1 = s_span[1];
+            if (b1 > b0 && (b1 - b0) * 16u <= WIN) {
+                const uint8_t* g = p_src0 + (uint64_t(b0) << 4);
+                win_lo = reinterpret_cast<uint64_t>(g); win_hi = win_lo + (uint64_t(b1 - b0) << 4);
+                for (uint32_t off = tid * 16u; off < (b1 - b0) * 16u; off += 4096u)        // (whole waves: the LDS side is wave base + lane * 16)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + off),
+                                                     (__attribute__((address_space(3))) void*)(s_win + (off & ~1023u)), 16, 0, 0);
+            }
+        }
         // ---- B: compact the non-empty tasks by rank; mark the first block starting inside or after each ----
         const bool chunk_bad = s_w[1][0] != 0u;
         uint32_t total_pk = 0u;                                             // packed totals of the chunk
@@ -986,6 +1007,7 @@ __global__ __launch_bounds__(256) void stitch4_kernel(const uint64_t* __restrict
         for (int k = 0; k < TPT; ++k)
             if (owner[k]) s_patch[tid + 256u * uint32_t(k)] = block_finish(pf[k], s_rec, s_lit, s_mask, pb16[k], ptotal);
         if (DBG == 20) q3 = __builtin_amdgcn_s_memtime();
+        if (WIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's direct-to-LDS loads have landed (lds_barrier waits for LDS operations only)
         lds_barrier();
         if (DBG == 20) q4 = __builtin_amdgcn_s_memtime();
 
@@ -1017,6 +1039,11 @@ __global__ __launch_bounds__(256) void stitch4_kernel(const uint64_t* __restrict
                 for (uint32_t j = 0; j < R; ++j) {
                     // (if / else, not a select: gather and patch land in the same registers, lanes disjoint)
                     if (uint32_t(X[j] >> 32) == 0u) v[j] = s_patch[uint32_t(X[j])];
+                    else if (WIN && X[j] >= win_lo && X[j] + 16u <= win_hi + 16u && X[j] < win_hi) {
+                        const uint32_t o = uint32_t(X[j] - win_lo);            // byte offset in the LDS window
+                        const u32x4* w16 = reinterpret_cast<const u32x4*>(s_win);
+                        v[j] = funnel16(w16[o >> 4], w16[(o >> 4) + 1u], o & 15u);
+                    }
                     else v[j] = (DBG == 1) ? u32x4{uint32_t(X[j]), 0u, 0u, 0u} : gather16(X[j]);
                 }
                 if (DBG == 20) q7 = __builtin_amdgcn_s_memtime();
@@ -1489,8 +1516,9 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     // `nontemporal` bit 0: nt result stores; bits 4 / 5: no long-run / no per-block chunk in the image; bits 6..7: tasks per lane
     // of the largest long-run chunk; bits 8..11: tasks per lane of the largest per-block chunk; bits 12..15: variant (0 = default, 1 / 2 =
     // the per-block kernel with byte-granular / aligned gathers for every chunk -- images without fused descriptors only, A/B runs;
-    // 3 = the per-block kernel also where the dense kernel would be picked; 4..6: stitch4 with 1 / 2 / 4 rows per round; 8 / 9 =
-    // the dense kernel for every per-block chunk, with byte-granular / dword-aligned gathers); bits 16..23: timing-only ablation; bits 24..30: KiB of idle LDS (experiments)
+    // 3 = the per-block kernel also where the dense kernel would be picked; 4..6: stitch4 with 1 / 2 / 4 rows per round; 7 / 11 =
+    // stitch4 with the chunk's reference span staged in a 36 / 20 KiB LDS window; 8 / 9 = the dense kernel for every per-block
+    // chunk, with byte-granular / dword-aligned gathers); bits 16..23: timing-only ablation; bits 24..30: KiB of idle LDS (experiments)
     const int nt = nontemporal & 1;
     const int var = (nontemporal >> 12) & 0xF;
     const int dbg = (nontemporal >> 16) & 0xFF;
@@ -1514,6 +1542,8 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
 #define V2P_L4(TT, NTT, DD, RR, FF) hipLaunchKernelGGL((stitch4_kernel<TT, NTT, DD, RR>), dim3(grid), dim3(256), lds_pad, stream, V2P_KARGS, uint32_t(FF))
 #define V2P_L3(TT, NTT, DD, FF) do { \
         if (var == 4) V2P_L4(TT, NTT, DD, 1, FF); \
+        else if (var == 7) hipLaunchKernelGGL((stitch4_kernel<TT, NTT, DD, 8, 36864u>), dim3(grid), dim3(256), lds_pad, stream, V2P_KARGS, uint32_t(FF)); \
+        else if (var == 11) hipLaunchKernelGGL((stitch4_kernel<TT, NTT, DD, 8, 20480u>), dim3(grid), dim3(256), lds_pad, stream, V2P_KARGS, uint32_t(FF)); \
         else if (var == 5) V2P_L4(TT, NTT, DD, 2, FF); \
         else if (var == 6) V2P_L4(TT, NTT, DD, 4, FF); \
         else V2P_L4(TT, NTT, DD, 8, FF); } while (0)
