@@ -96,6 +96,21 @@ def test_more_haplotypes_than_one_cursor_range_and_dense_records(built, gpu_ctx)
     assert_same_lists(gpu_ctx, random_vcf(12, 130, 900, p_zero=0.0, unique_positions=False))
 
 
+def test_record_block_with_more_than_65536_consequences(built, gpu_ctx):
+    """The staged emit kernel keeps a block's ids as 16-bit offsets from the block's first consequence; a block whose records list
+    more than 65 535 consequences between them goes through the direct kernel."""
+    from frontend_util import HEADER
+    rng = np.random.default_rng(5)
+    n_rec, n_smp, n_csq = 70, 6, 1100
+    rows = [HEADER, "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(f"S{i}" for i in range(n_smp)) + "\n"]
+    for r in range(n_rec):
+        csq = ",".join(f"missense|G{j}|ENST{(r * 7 + j) % 90:011d}|protein_coding|+|{1 + j % 400}A>{1 + j % 400}C|{r}A>T" for j in range(n_csq))
+        cols = [f"0|1:{int(rng.integers(0, 64)) if rng.random() < 0.7 else 0}" for _ in range(n_smp)]
+        rows.append(f"1\t{100 + r}\t.\tA\tT\t.\tPASS\tBCSQ={csq}\tGT:BCSQ\t" + "\t".join(cols) + "\n")
+    idx, _ = assert_same_lists(gpu_ctx, "".join(rows))
+    assert int(idx.csq_begin[64]) - int(idx.csq_begin[0]) > 0xFFFF
+
+
 def test_64_bit_cursors(built, gpu_ctx):
     """Calls with 2^32 ids or more switch emit to 64-bit cursors; V2P_DECODE_CURSOR64 forces that kernel for a small call."""
     import os

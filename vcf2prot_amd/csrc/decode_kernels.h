@@ -20,6 +20,7 @@ constexpr uint32_t DEC_RANGE_HAPS = 6144;   // haplotypes one count / emit workg
 constexpr uint32_t DEC_SCAN_GROUPS = 64;    // the prefix down the row blocks runs in this many independent groups
 constexpr uint32_t DEC_TILE = 4096;         // text bytes per parse step of a 256-thread workgroup (16 per thread)
 constexpr uint32_t DEC_EMIT_GROUP = 8;      // records whose first 128 carriers the emit kernel fetches ahead together
+constexpr uint32_t DEC_STAGE_IDS = 12288;  // ids of one (record block, haplotype range) that the staged emit kernel keeps in LDS (48 KiB)
 constexpr uint32_t DEC_MULTI = 0x80000000u; // carrier entry: bit 31 set -> low 31 bits index the multi-word list
 
 // One carrier: a (record, sample) whose filtered mask is not empty.  x = sample, y = the first word filtered to the
@@ -42,6 +43,7 @@ struct DecodeArgs {
     uint32_t*       row_nnz;       // [n_rows]
     uint32_t*       cnt;           // [n_rowblocks][2*n_samples] per-block counts, then exclusive prefix down the blocks
     uint32_t*       group_tot;     // [DEC_SCAN_GROUPS][2*n_samples] scratch of the scan
+    uint32_t*       blk_total;     // [n_rowblocks * n_ranges] ids of each (record block, haplotype range): which emit kernel takes it
     uint32_t*       ovf;           // multi-word list: {n_words, words...} records
     uint64_t        ovf_capacity;  // in u32 words
     unsigned long long* ovf_used;  // device counter
@@ -53,7 +55,7 @@ struct DecodeArgs {
 };
 
 struct DecodeLayout {
-    uint64_t carriers_off, nnz_off, cnt_off, group_off, ovf_off, ovf_used_off, total;
+    uint64_t carriers_off, nnz_off, cnt_off, group_off, blk_off, ovf_off, ovf_used_off, total;
     uint32_t n_rowblocks;
 };
 DecodeLayout decode_layout(uint64_t n_rows, uint64_t n_samples, uint64_t ovf_words);

@@ -398,7 +398,16 @@ __global__ __launch_bounds__(256) void count_kernel(DecodeArgs a, uint32_t n_ran
     }
     __syncthreads();
     uint32_t* out = a.cnt + uint64_t(rbk) * n_haps + h0;
-    for (uint32_t i = tid; i < hn; i += 256u) out[i] = hist[i];
+    uint32_t mine = 0u;
+    for (uint32_t i = tid; i < hn; i += 256u) { const uint32_t v = hist[i]; out[i] = v; mine += v; }
+    // the block's ids in this range: the staged emit kernel takes it when they fit its LDS stage
+    __shared__ uint32_t s_tot;
+    if (tid == 0) s_tot = 0u;
+    __syncthreads();
+    const uint32_t wsum = dec_wave_incl_scan(mine);
+    if (lane == 63u) atomicAdd(&s_tot, wsum);
+    __syncthreads();
+    if (tid == 0) a.blk_total[blockIdx.x] = s_tot;                              // (index = record block * n_ranges + range)
 }
 
 // ---------------------------------------------------------------------------------------------------------- scan
@@ -506,6 +515,8 @@ __global__ __launch_bounds__(256) void emit_kernel(DecodeArgs a, uint32_t n_rang
     const uint32_t n_haps = 2u * a.n_samples, h0 = rg * DEC_RANGE_HAPS, hn = min(DEC_RANGE_HAPS, n_haps - h0);
     const uint64_t total = a.hap_begin[n_haps];
     if (total > a.ids_capacity || ((total >> 32) != 0ull || force64) != (sizeof(CUR) == 8)) return;
+    if (!force64 && a.blk_total[rbk * n_ranges + rg] <= DEC_STAGE_IDS &&
+        a.csq_begin[min(rbk * DEC_ROWBLOCK + DEC_ROWBLOCK, a.n_rows)] - a.csq_begin[rbk * DEC_ROWBLOCK] <= 0xFFFFu) return;   // emit_staged_kernel takes this block
     const uint32_t tid = threadIdx.x;
     const uint32_t r0 = rbk * DEC_ROWBLOCK, r1 = min(r0 + DEC_ROWBLOCK, a.n_rows);
     {
@@ -586,6 +597,120 @@ __global__ __launch_bounds__(256) void emit_kernel(DecodeArgs a, uint32_t n_rang
     }
 }
 
+// The same walk with the block's ids STAGED in LDS, haplotype after haplotype, and written out at the end with lane = haplotype:
+// a haplotype's two or three ids of this block then leave within a few instructions of each other and the L2 merges them into one
+// write, where the direct kernel above writes each id when its record comes by (tens of microseconds apart: 0.67 GB of HBM
+// writes for 67 MB of ids).  Local cursors are 16-bit positions in the stage (a block here has at most DEC_STAGE_IDS ids; blocks
+// with more, blocks whose consequence ids span more than 2^16 -- the stage holds 16-bit offsets from the block's first -- and calls
+// that force the 64-bit cursors keep the direct kernel).  34 KB of LDS: four workgroups per CU.
+__global__ __launch_bounds__(256) void emit_staged_kernel(DecodeArgs a, uint32_t n_ranges)
+{
+    extern __shared__ __align__(16) uint8_t emit_lds[];
+    constexpr uint32_t G = DEC_EMIT_GROUP;
+    __shared__ uint32_t s_n[DEC_ROWBLOCK], s_id0[DEC_ROWBLOCK], s_ws[4];
+    if (a.status[0] != ~0ull) return;
+    const uint32_t n_rowblocks = (a.n_rows + DEC_ROWBLOCK - 1u) / DEC_ROWBLOCK, per_xcd = (n_rowblocks + 7u) / 8u;
+    const uint32_t unit = blockIdx.x / n_ranges, rg = blockIdx.x % n_ranges;
+    const uint32_t rbk = (unit & 7u) * per_xcd + (unit >> 3);
+    if (rbk >= n_rowblocks) return;
+    const uint32_t n_haps = 2u * a.n_samples, h0 = rg * DEC_RANGE_HAPS, hn = min(DEC_RANGE_HAPS, n_haps - h0);
+    if (a.hap_begin[n_haps] > a.ids_capacity) return;
+    const uint32_t bt = a.blk_total[rbk * n_ranges + rg];
+    if (bt == 0u || bt > DEC_STAGE_IDS) return;
+    const uint32_t r0 = rbk * DEC_ROWBLOCK, r1 = min(r0 + DEC_ROWBLOCK, a.n_rows);
+    const uint32_t id_base = a.csq_begin[r0];
+    if (a.csq_begin[r1] - id_base > 0xFFFFu) return;                           // the stage keeps ids as 16-bit offsets from the block's first consequence
+    uint16_t* const lcur = reinterpret_cast<uint16_t*>(emit_lds);              // [hn + 1] local cursors
+    uint16_t* const st = reinterpret_cast<uint16_t*>(emit_lds + ((2u * (hn + 2u) + 15u) & ~15u));   // [bt] the block's ids, haplotype-major
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t* const c = a.cnt + uint64_t(rbk) * n_haps + h0;
+    const bool last_block = rbk + 1u == n_rowblocks;
+    for (uint32_t i = tid; i < DEC_ROWBLOCK; i += 256u) {
+        s_n[i] = r0 + i < r1 ? a.row_nnz[r0 + i] : 0u;
+        s_id0[i] = r0 + i < r1 ? a.csq_begin[r0 + i] - id_base : 0u;
+    }
+    // the block's count per haplotype: the next block's prefix minus this one's (the last block: the haplotype's total)
+    for (uint32_t i = tid; i < hn; i += 256u) {
+        const uint32_t nxt = last_block ? uint32_t(a.hap_begin[h0 + i + 1u] - a.hap_begin[h0 + i]) : c[n_haps + i];
+        lcur[i] = uint16_t(nxt - c[i]);
+    }
+    __syncthreads();
+    {   // exclusive prefix over the haplotypes: a segment per thread, a DPP scan of the segment sums
+        const uint32_t seg = (hn + 255u) / 256u, b = min(tid * seg, hn), e = min(b + seg, hn);
+        uint32_t sum = 0u;
+        for (uint32_t i = b; i < e; ++i) sum += lcur[i];
+        const uint32_t incl = dec_wave_incl_scan(sum);
+        if (lane == 63u) s_ws[wid] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (uint32_t w = 0; w < wid; ++w) run += s_ws[w];
+        for (uint32_t i = b; i < e; ++i) { const uint32_t v = lcur[i]; lcur[i] = uint16_t(run); run += v; }
+    }
+    __syncthreads();
+
+    struct Placed { uint32_t sample, entry; };
+    auto place = [&](const Placed v, bool valid, uint32_t id0) {
+        const uint32_t h = 2u * v.sample - h0;                                  // (h0 is even: a sample's two cursors are one aligned 32-bit pair)
+        if (!valid || h >= hn) return;
+        const uint32_t c0 = entry_count(v.entry, 0, a.ovf), c1 = entry_count(v.entry, 1, a.ovf);
+        uint32_t* cp = reinterpret_cast<uint32_t*>(lcur + h);
+        const uint32_t at = *cp;
+        *cp = at + c0 + (c1 << 16);                                             // (no carry between the halves: positions stay below 2^16)
+#pragma unroll
+        for (uint32_t hb = 0; hb < 2u; ++hb) {
+            uint16_t* o = st + (hb ? at >> 16 : at & 0xFFFFu);
+            if (!(v.entry & DEC_MULTI)) {
+                uint32_t bits = (v.entry >> hb) & 0x55555555u;
+                while (bits) { const uint32_t b = uint32_t(__builtin_ctz(bits)); bits &= bits - 1u; *o++ = uint16_t(id0 + (b >> 1)); }
+            } else {
+                const uint32_t off = v.entry & ~DEC_MULTI, nw = a.ovf[off];
+                for (uint32_t w = 0; w < nw; ++w) {
+                    uint32_t bits = (a.ovf[off + 1u + w] >> hb) & 0x55555555u;
+                    while (bits) { const uint32_t b = uint32_t(__builtin_ctz(bits)); bits &= bits - 1u; *o++ = uint16_t(id0 + 15u * w + (b >> 1)); }
+                }
+            }
+        }
+    };
+    const Placed none{0u, 0u};
+    Placed cur[G], nxt[G];
+    auto fetch = [&](uint32_t g0, Placed (&x)[G]) {
+#pragma unroll
+        for (uint32_t i = 0; i < G; ++i) {
+            x[i] = none;
+            if (g0 + i < r1 && tid < a.n_samples) { const DecCarrier w = a.carriers[uint64_t(g0 + i) * a.n_samples + tid]; x[i] = Placed{w.sample, w.entry}; }
+        }
+    };
+    fetch(r0, cur);
+    for (uint32_t g0 = r0; g0 < r1; g0 += G) {
+        fetch(g0 + G, nxt);
+#pragma unroll
+        for (uint32_t i = 0; i < G; ++i) {
+            if (g0 + i >= r1) break;
+            const uint32_t ni = uint32_t(__builtin_amdgcn_readfirstlane(int(s_n[g0 + i - r0])));
+            const uint32_t id0 = uint32_t(__builtin_amdgcn_readfirstlane(int(s_id0[g0 + i - r0])));
+            place(cur[i], tid < ni, id0);
+            if (ni > 256u) {
+                const DecCarrier* e = a.carriers + uint64_t(g0 + i) * a.n_samples;
+                for (uint32_t k0 = 256u; k0 < ni; k0 += 256u) {
+                    Placed w = none;
+                    if (k0 + tid < ni) { const DecCarrier x = e[k0 + tid]; w = Placed{x.sample, x.entry}; }
+                    place(w, k0 + tid < ni, id0);
+                }
+            }
+            dec_lds_barrier();
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < G; ++i) cur[i] = nxt[i];
+    }
+    // flush: lane = haplotype; its run is st[end of the previous haplotype's run, its own end)
+    for (uint32_t h = tid; h < hn; h += 256u) {
+        const uint32_t b = h ? lcur[h - 1u] : 0u, e = lcur[h];
+        if (b == e) continue;
+        uint32_t* o = a.ids + (a.hap_begin[h0 + h] + c[h]);
+        for (uint32_t k = b; k < e; ++k) *o++ = id_base + st[k];
+    }
+}
+
 }  // namespace
 
 DecodeLayout decode_layout(uint64_t n_rows, uint64_t n_samples, uint64_t ovf_words)
@@ -598,6 +723,7 @@ DecodeLayout decode_layout(uint64_t n_rows, uint64_t n_samples, uint64_t ovf_wor
     L.nnz_off = o; o += up(n_rows * 4ull);
     L.cnt_off = o; o += up(uint64_t(L.n_rowblocks) * 2ull * n_samples * 4ull);
     L.group_off = o; o += up(uint64_t(DEC_SCAN_GROUPS) * 2ull * n_samples * 4ull);
+    L.blk_off = o; o += up(uint64_t(L.n_rowblocks) * ((2ull * n_samples + DEC_RANGE_HAPS - 1) / DEC_RANGE_HAPS) * 4ull);
     L.ovf_off = o; o += up(ovf_words * 4ull);
     L.ovf_used_off = o; o += 256;
     L.total = o;
@@ -631,6 +757,8 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream, unsigned phase
         const uint32_t units = 8u * ((n_rowblocks + 7u) / 8u);
         const bool force64 = getenv("V2P_DECODE_CURSOR64") != nullptr;            // test hook: exercise the 64-bit cursor kernel on small inputs
         const uint32_t nr = n_ranges | (force64 ? 0x80000000u : 0u);
+        if (!force64) hipLaunchKernelGGL(emit_staged_kernel, dim3(units * n_ranges), dim3(256), ((2u * (range_haps + 2u) + 15u) & ~15u) + DEC_STAGE_IDS * 2u,
+                                         stream, a, n_ranges);
         hipLaunchKernelGGL(emit_kernel<uint32_t>, dim3(units * n_ranges), dim3(256), range_haps * 4u, stream, a, nr);
         hipLaunchKernelGGL(emit_kernel<uint64_t>, dim3(units * n_ranges), dim3(256), range_haps * 8u, stream, a, nr);
     }

@@ -81,6 +81,7 @@ void fill_args(DecodeArgs& a, const uint8_t* d_text, uint64_t n_text, const uint
     a.row_nnz = reinterpret_cast<uint32_t*>(d_work + L.nnz_off);
     a.cnt = reinterpret_cast<uint32_t*>(d_work + L.cnt_off);
     a.group_tot = reinterpret_cast<uint32_t*>(d_work + L.group_off);
+    a.blk_total = reinterpret_cast<uint32_t*>(d_work + L.blk_off);
     a.ovf = reinterpret_cast<uint32_t*>(d_work + L.ovf_off);
     a.ovf_capacity = ovf_words;
     a.ovf_used = reinterpret_cast<unsigned long long*>(d_work + L.ovf_used_off);
