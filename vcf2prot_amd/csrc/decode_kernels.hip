@@ -134,7 +134,7 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
 {
     constexpr uint32_t TILE = BS * 16u, RING = 2u * TILE, RM = RING - 1u, NW = BS / 64u;
     __shared__ __align__(16) uint8_t ring[RING];
-    __shared__ uint32_t list[TILE + 2];                         // the columns of this step that need parsing: end position | rank << 16
+    __shared__ uint32_t list[TILE + 2];                         // the columns of this step that need parsing: end position | (one-digit mask + 1) << 13 | rank << 17
     __shared__ uint32_t s_nlist;
     __shared__ uint32_t wave_tot[NW];
     __shared__ uint32_t s_nnz;
@@ -203,7 +203,11 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
                 uint32_t at = 0u;
                 if (work && k == 0u) at = atomicAdd(&s_nlist, uint32_t(__builtin_popcountll(wb)));
                 at = uint32_t(__builtin_amdgcn_readlane(int(at), int(__builtin_ctzll(wb))));
-                if (work) list[at + k] = pos | (rank() << 16);
+                // a one-digit mask (a record with one or two consequences: the commonest carrier) is read off right here; the list
+                // entry carries it and the parser pass below leaves such columns alone
+                const uint32_t digit = uint32_t(c1) - uint32_t('1');
+                const uint32_t pre = (inside && c2 == ':' && digit < 9u) ? digit + 2u : 0u;
+                if (work) list[at + k] = pos | (pre << 13) | (rank() << 17);
             }
         };
         const uint32_t tm0 = tm, slot0 = wbase + incl - cnt;
@@ -228,11 +232,14 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
 
         for (uint32_t j = tid; j < n_list; j += BS) {
             const uint32_t le = list[j];
-            const uint32_t p = tile0 + (le & 0xFFFFu);                         // one past the column's last byte
-            const uint32_t f = fields_before + (le >> 16);
-            uint32_t q = p, err = 0u, entry = 0u;
-            bool colon = false, slow = true;
-            if (p >= lo + 8u) {
+            const uint32_t p = tile0 + (le & 0x1FFFu);                         // one past the column's last byte
+            const uint32_t f = fields_before + (le >> 17);
+            const uint32_t pre = (le >> 13) & 15u;                              // one-digit mask + 1, or 0
+            uint32_t q = p, err = 0u, entry = pre ? pre - 1u : 0u;
+            bool colon = false, slow = pre == 0u;
+            if (__builtin_amdgcn_ballot_w64(slow) == 0ull) {
+                // (every column of this round came with its value)
+            } else if (slow && p >= lo + 8u) {
                 // fast path: the last eight bytes of the column in registers.  Settles every column whose text after the
                 // last ':' is at most seven digits (or '.'), and every column without a ':' that starts inside the window.
                 const uint32_t* ring32 = reinterpret_cast<const uint32_t*>(ring);
