@@ -387,17 +387,37 @@ __global__ __launch_bounds__(256) void count_kernel(DecodeArgs a, uint32_t n_ran
     const uint32_t rbk = blockIdx.x / n_ranges, rg = blockIdx.x % n_ranges;
     const uint32_t n_haps = 2u * a.n_samples, h0 = rg * DEC_RANGE_HAPS, hn = min(DEC_RANGE_HAPS, n_haps - h0);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t i = tid; i < hn; i += 256u) hist[i] = 0u;
-    __syncthreads();
+    __shared__ uint32_t s_pre[DEC_ROWBLOCK + 1];
+    constexpr uint32_t G = 4u;                                                  // carriers a lane has in flight together
     const uint32_t r0 = rbk * DEC_ROWBLOCK, r1 = min(r0 + DEC_ROWBLOCK, a.n_rows);
-    for (uint32_t r = r0 + wave; r < r1; r += 4u) {
-        const uint32_t n = a.row_nnz[r];
-        const DecCarrier* e = a.carriers + uint64_t(r) * a.n_samples;
-        for (uint32_t k = lane; k < n; k += 64u) {
-            const DecCarrier v = e[k];
-            const uint32_t h = 2u * v.sample - h0;
-            if (h < hn) {                                                       // (h0 is even: both haplotypes of a sample share a range)
-                const uint32_t c0 = entry_count(v.entry, 0, a.ovf), c1 = entry_count(v.entry, 1, a.ovf);
+    for (uint32_t i = tid; i < hn; i += 256u) hist[i] = 0u;
+    if (tid < 64u) {                                                            // exclusive prefix of the block's 64 record sizes (one wave)
+        static_assert(DEC_ROWBLOCK == 64u, "one wave scans the block's record sizes");
+        const uint32_t n = r0 + tid < r1 ? a.row_nnz[r0 + tid] : 0u, incl = dec_wave_incl_scan(n);
+        s_pre[tid] = incl - n;
+        if (tid == 63u) s_pre[64] = incl;
+    }
+    __syncthreads();
+    // the block's carriers as ONE list (a binary search per carrier finds its record): every lane has work whatever the records'
+    // sizes, and a lane's G loads are in flight together
+    const uint32_t total = s_pre[DEC_ROWBLOCK];
+    (void)wave;
+    for (uint32_t base = 0; base < total; base += 256u * G) {
+        DecCarrier v[G];
+#pragma unroll
+        for (uint32_t u = 0; u < G; ++u) {
+            const uint32_t idx = base + 256u * u + tid;
+            uint32_t lo = 0u;                                                   // largest i with s_pre[i] <= idx
+#pragma unroll
+            for (uint32_t step = DEC_ROWBLOCK / 2u; step; step >>= 1) if (s_pre[lo + step] <= idx) lo += step;
+            v[u] = DecCarrier{~0u, 0u};
+            if (idx < total) v[u] = a.carriers[uint64_t(r0 + lo) * a.n_samples + (idx - s_pre[lo])];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < G; ++u) {
+            const uint32_t h = 2u * v[u].sample - h0;
+            if (v[u].sample != ~0u && h < hn) {                                 // (h0 is even: both haplotypes of a sample share a range)
+                const uint32_t c0 = entry_count(v[u].entry, 0, a.ovf), c1 = entry_count(v[u].entry, 1, a.ovf);
                 if (c0) atomicAdd(&hist[h], c0);
                 if (c1) atomicAdd(&hist[h + 1u], c1);
             }
