@@ -101,75 +101,95 @@ hipError_t launch_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, uint64
 // ---- the walk over one transcript's tasks: EMIT = false counts descriptors, true writes them -------------------------------
 __device__ __forceinline__ uint32_t pieces(uint64_t dst, uint64_t len, uint32_t W) { return uint32_t((dst + len - 1) / W - dst / W) + 1u; }
 
-template <bool EMIT>
-__device__ __forceinline__ uint32_t put(const BuildArgs& a, uint64_t& k, uint64_t dst, uint64_t len, unsigned space, uint64_t src)
+// A position in the result arena as (grid window, offset inside it).  64-bit division is ~100 instructions on this GPU and the
+// walk needs window arithmetic for every piece: the transcript's base is divided once, everything after is 32-bit.
+struct WinPos { uint64_t win; uint32_t off; };
+__device__ __forceinline__ WinPos win_pos(const WinPos& base, uint64_t rel, uint32_t W)
 {
-    // one run of result bytes [dst, dst + len) from (space, src), cut at every multiple of the grid
+    const uint64_t x = uint64_t(base.off) + rel;
+    if (x <= 0xFFFFFFFFull) { const uint32_t x32 = uint32_t(x); return WinPos{base.win + x32 / W, x32 % W}; }
+    return WinPos{base.win + x / W, uint32_t(x % W)};                              // (a transcript of more than 4 GiB of result)
+}
+
+template <bool EMIT>
+__device__ __forceinline__ uint32_t put(const BuildArgs& a, uint64_t& k, WinPos at, uint64_t len, unsigned space, uint64_t src)
+{
+    // one run of result bytes from (space, src) starting at `at`, cut at every multiple of the grid
+    const uint32_t W = a.window;
     uint32_t n = 0;
     while (len) {
-        const uint64_t room = a.window - dst % a.window;
+        const uint32_t room = W - at.off;
         const uint32_t piece = uint32_t(len < room ? len : room);
         if (EMIT) {
             a.desc[k] = (src & SRC_MASK) | (uint64_t(piece & LEN_MASK) << 40) | (uint64_t(space) << 62);
-            if (dst % a.window == 0) a.chunk_first[dst / a.window] = k;
+            if (at.off == 0u) a.chunk_first[at.win] = k;
         }
         ++k; ++n;
         if (space == SPACE_IMM) src = piece >= 8 ? 0 : src >> (8 * piece);
         else if (space != SPACE_FILL) src += piece;
-        dst += piece; len -= piece;
+        at.off += piece; len -= piece;
+        if (at.off == W) { at.off = 0u; ++at.win; }
     }
     return n;
 }
 
 // sir_pack.hpp's ImageBuilder::stage() as a per-lane state machine: a reference copy, a 1-byte literal and a reference copy going on
-// one residue later fuse into one descriptor when the three lie inside one grid window (long-run routing only).
-struct Staged { uint32_t space; uint64_t src, len, dst; };
+// one residue later fuse into one descriptor when the three lie inside one grid window (long-run and dense routing).  Result
+// positions are relative to the transcript's first result byte (`rel`).
+struct Staged { uint32_t space; uint64_t src, len, rel; };
 
 template <bool EMIT>
 struct Walker {
     const BuildArgs& a;
     uint64_t k;          // next descriptor index (EMIT) / unused
+    WinPos base;         // window position of the transcript's first result byte
     uint32_t cnt = 0;    // descriptors so far
-    uint32_t tasks_in_window = 0;
-    Staged st[2];
+    Staged s0{0, 0, 0, 0}, s1{0, 0, 0, 0};                                          // (two named slots: an indexed array lives in scratch memory)
     int st_n = 0;
-    __device__ Walker(const BuildArgs& a_, uint64_t k_) : a(a_), k(k_) {}
-    __device__ void out(uint32_t space, uint64_t src, uint64_t len, uint64_t dst) { if (len) cnt += put<EMIT>(a, k, dst, len, space, src); }
-    __device__ void flush() { const int n = st_n; st_n = 0; for (int i = 0; i < n; ++i) out(st[i].space, st[i].src, st[i].len, st[i].dst); }
-    __device__ void fused(uint64_t src, uint32_t len1, uint32_t byte, uint32_t len2, uint64_t dst)
+    __device__ Walker(const BuildArgs& a_, uint64_t k_, uint64_t base_) : a(a_), k(k_), base{base_ / a_.window, uint32_t(base_ % a_.window)} {}
+    __device__ void out(uint32_t space, uint64_t src, uint64_t len, uint64_t rel) { if (len) cnt += put<EMIT>(a, k, win_pos(base, rel, a.window), len, space, src); }
+    __device__ void flush()
+    {
+        const int n = st_n;
+        st_n = 0;
+        if (n >= 1) out(s0.space, s0.src, s0.len, s0.rel);
+        if (n == 2) out(s1.space, s1.src, s1.len, s1.rel);
+    }
+    __device__ void fused(uint64_t src, uint32_t len1, uint32_t byte, uint32_t len2, uint64_t rel)
     {
         const uint64_t total = uint64_t(len1) + 1u + len2;
-        if (dst / a.window == (dst + total - 1) / a.window) {
+        const WinPos at = win_pos(base, rel, a.window);
+        if (uint64_t(at.off) + total <= a.window) {                              // the three inside one window
             if (EMIT) {
                 a.desc[k] = SNV3_MARK | (uint64_t(byte & 0xFFu) << 53) | (uint64_t(len2 & 0xFFFu) << 41) | (uint64_t(len1 & 0xFFFu) << 29) | (src & SNV3_MAX_SRC);
-                if (dst % a.window == 0) a.chunk_first[dst / a.window] = k;
+                if (at.off == 0u) a.chunk_first[at.win] = k;
             }
             ++k; ++cnt;
         } else {
-            out(SPACE_PROTEOME, src, len1, dst);
-            out(SPACE_IMM, byte, 1, dst + len1);
-            out(SPACE_PROTEOME, src + len1 + 1, len2, dst + len1 + 1);
+            out(SPACE_PROTEOME, src, len1, rel);
+            out(SPACE_IMM, byte, 1, rel + len1);
+            out(SPACE_PROTEOME, src + len1 + 1, len2, rel + len1 + 1);
         }
     }
-    __device__ void stage(uint32_t space, uint64_t src, uint64_t len, uint64_t dst)
+    __device__ void stage(uint32_t space, uint64_t src, uint64_t len, uint64_t rel)
     {
-        if (!a.long_run && !a.dense) { out(space, src, len, dst); return; }
+        if (!a.long_run && !a.dense) { out(space, src, len, rel); return; }
         if (st_n == 2) {
-            const bool fits = st[0].len == 0 ? (len > 0 && src >= 1 && src - 1 + 1 + len <= SNV3_MAX_SRC) : (len == 0 || src == st[0].src + st[0].len + 1);
+            const bool fits = s0.len == 0 ? (len > 0 && src >= 1 && src - 1 + 1 + len <= SNV3_MAX_SRC) : (len == 0 || src == s0.src + s0.len + 1);
             if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && fits) {
-                const Staged r1 = st[0], lit = st[1];
+                const Staged r1 = s0, lit = s1;
                 st_n = 0;
-                fused(r1.len == 0 ? src - 1 : r1.src, uint32_t(r1.len), uint32_t(lit.src), uint32_t(len), r1.dst);
+                fused(r1.len == 0 ? src - 1 : r1.src, uint32_t(r1.len), uint32_t(lit.src), uint32_t(len), r1.rel);
                 return;
             }
             flush();
         }
         if (st_n == 1) {
-            if (space == SPACE_IMM && len == 1) { st[1] = Staged{space, src, len, dst}; st_n = 2; return; }
+            if (space == SPACE_IMM && len == 1) { s1 = Staged{space, src, len, rel}; st_n = 2; return; }
             flush();
         }
-        if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && src + len + 1 + SNV3_MAX_LEN <= SNV3_MAX_SRC) { st[0] = Staged{space, src, len, dst}; st_n = 1; return; }
-        out(space, src, len, dst);
+        if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && src + len + 1 + SNV3_MAX_LEN <= SNV3_MAX_SRC) { s0 = Staged{space, src, len, rel}; st_n = 1; return; }
+        out(space, src, len, rel);
     }
 };
 
@@ -182,13 +202,19 @@ __global__ __launch_bounds__(256) void walk_kernel(BuildArgs a)
     const uint64_t alt0 = a.tx_alt_begin[t], n_alt = a.tx_alt_begin[t + 1] - alt0;
     const uint64_t poff = a.tx_proteome_off[t];
     const uint32_t ref_len = a.tx_ref_len[t], res_len = a.tx_res_len[t];
-    Walker<EMIT> w(a, EMIT ? a.desc_base[t] : 0);
+    Walker<EMIT> w(a, EMIT ? a.desc_base[t] : 0, base);
     uint64_t cur = 0;
     bool ok = true;
     if (!EMIT && poff + ref_len > a.proteome_len) { breport(a.status, i0, STATUS_SRC_OOB); ok = false; }   // transcript outside the resident proteome
+    // The next task's fields are requested BEFORE this task's descriptors are stored: gfx950 counts loads and stores in one in-order
+    // counter, so a load issued behind a store is only consumed after that store has been acknowledged (the emit pass took 3.9 ms for
+    // C2 against 0.9 ms for the counting pass over the same arrays before this).
+    uint32_t n_code = 0, n_sp = 0, n_ln = 0, n_sr = 0;
+    if (i0 < i1) { n_code = a.code[i0]; n_sp = a.start_pos[i0]; n_ln = a.length[i0]; n_sr = a.start_pos_res[i0]; }
     for (uint64_t i = i0; i < i1 && ok; ++i) {
-        const uint32_t code = a.code[i];
-        const uint64_t sp = a.start_pos[i], ln = a.length[i], sr = a.start_pos_res[i];
+        const uint32_t code = n_code;
+        const uint64_t sp = n_sp, ln = n_ln, sr = n_sr;
+        if (i + 1 < i1) { n_code = a.code[i + 1]; n_sp = a.start_pos[i + 1]; n_ln = a.length[i + 1]; n_sr = a.start_pos_res[i + 1]; }
         if (!EMIT) {
             // haplotype_instruction.rs:154 (stream code), task.rs:43/47 (slices), and the canonical order the image needs
             uint32_t why = 0;
@@ -198,43 +224,56 @@ __global__ __launch_bounds__(256) void walk_kernel(BuildArgs a)
             else if (sr < cur) why = STATUS_NOT_CONTIGUOUS;                  // result ranges overlap or go backwards
             if (why) { breport(a.status, i, why); ok = false; break; }
         }
-        if (sr > cur) { w.flush(); w.out(SPACE_FILL, 0, sr - cur, base + cur); }              // cells no task covers keep '.'
-        if (code == 0) w.stage(SPACE_PROTEOME, poff + sp, ln, base + sr);
+        if (sr > cur) { w.flush(); w.out(SPACE_FILL, 0, sr - cur, cur); }                     // cells no task covers keep '.'
+        if (code == 0) w.stage(SPACE_PROTEOME, poff + sp, ln, sr);
         else if (ln >= 1 && ln <= IMM_MAX_BYTES) {                           // short alt payloads travel inside their descriptor
             uint64_t lit = 0;
             for (uint32_t q = 0; q < ln; ++q) lit |= uint64_t(a.alt[alt0 + sp + q]) << (8 * q);
-            w.stage(SPACE_IMM, lit, ln, base + sr);
-        } else w.stage(SPACE_PAYLOAD, alt0 + sp, ln, base + sr);
+            w.stage(SPACE_IMM, lit, ln, sr);
+        } else w.stage(SPACE_PAYLOAD, alt0 + sp, ln, sr);
         cur = sr + ln;
     }
     w.flush();
-    if (ok && cur < res_len) w.out(SPACE_FILL, 0, res_len - cur, base + cur);
+    if (ok && cur < res_len) w.out(SPACE_FILL, 0, res_len - cur, cur);
     if (!EMIT) a.tx_desc_count[t] = ok ? w.cnt : 0u;
 }
 
 // ---- chunk table on the grid ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chunk_kernel(BuildArgs a, uint64_t n_windows, uint64_t n_desc, uint64_t out_bytes)
+__global__ __launch_bounds__(256) void hap_begin_kernel(BuildArgs a, uint64_t out_bytes)
 {
     const uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (k <= a.n_haps) a.hap_out_begin[k] = k < a.n_haps ? a.tx_res_base[a.hap_tx_begin[k]] : out_bytes;   // res_counter at the haplotype's first transcript
+}
+
+// one WAVE per window: its descriptors read 64 at a time (a lane per window walked them one by one: 0.62 ms for C2's 559 k windows)
+__global__ __launch_bounds__(256) void chunk_kernel(BuildArgs a, uint64_t n_windows, uint64_t n_desc, uint64_t out_bytes)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t k = uint64_t(blockIdx.x) * 4u + (threadIdx.x >> 6);
     if (k >= n_windows) return;
     const uint64_t tb = a.chunk_first[k];
     const uint64_t tb_next = k + 1 < n_windows ? a.chunk_first[k + 1] : n_desc;
     const uint64_t n = tb_next - tb;
-    if (n > CHUNK_TASKS_DEEP) { breport(a.status, tb, STATUS_TOO_MANY); return; }   // too many descriptors in one window: pick a smaller grid
+    if (n > CHUNK_TASKS_DEEP) { if (lane == 0) breport(a.status, tb, STATUS_TOO_MANY); return; }   // too many descriptors in one window: pick a smaller grid
     // tasks of the window (a fused substitution is up to three) and the proteome slice of its first reference read
     // (order_chunks_for_xcds looks at the first six descriptors)
-    uint64_t key = 0, tasks = 0;
-    bool have_key = false;
-    for (uint32_t q = 0; q < n; ++q) {
-        const uint64_t d = a.desc[tb + q];
+    uint32_t tasks = 0;
+    uint64_t key = 0;
+    for (uint32_t q0 = 0; q0 < n; q0 += 64u) {
+        const uint32_t q = q0 + lane;
+        const uint64_t d = q < n ? a.desc[tb + q] : 0ull;
         const bool snv = (d & SNV3_MARK) == SNV3_MARK;
-        tasks += snv ? (((d >> 29) & 0xFFFu) ? 1u : 0u) + 1u + (((d >> 41) & 0xFFFu) ? 1u : 0u) : 1u;
-        if (!have_key && q < 6u) {
+        if (q < n) tasks += snv ? (((d >> 29) & 0xFFFu) ? 1u : 0u) + 1u + (((d >> 41) & 0xFFFu) ? 1u : 0u) : 1u;
+        if (q0 == 0u) {
             const uint64_t src = snv ? (d & SNV3_MAX_SRC) : (d & SRC_MASK);
-            if ((snv || (d >> 62) == SPACE_PROTEOME) && src < a.proteome_len) { key = src; have_key = true; }
+            const bool cand = q < n && q < 6u && (snv || (d >> 62) == SPACE_PROTEOME) && src < a.proteome_len;
+            const unsigned long long m = __ballot(cand);
+            if (m) { const int first = __ffsll(static_cast<long long>(m)) - 1; key = (uint64_t(uint32_t(__shfl(int(uint32_t(src >> 32)), first, 64))) << 32) | uint32_t(__shfl(int(uint32_t(src)), first, 64)); }
         }
     }
+#pragma unroll
+    for (uint32_t dlt = 32u; dlt; dlt >>= 1) tasks += uint32_t(__shfl_xor(int(tasks), int(dlt), 64));
+    if (lane != 0) return;
     if (a.long_run && tasks > 2u * CHUNK_TASKS) { breport(a.status, tb, STATUS_TOO_MANY); return; }
     uint64_t flags = 0;
     if (a.long_run) flags = CHUNK_LONG | (tasks > CHUNK_TASKS ? CHUNK_LONG2 : 0ull);
@@ -244,10 +283,12 @@ __global__ __launch_bounds__(256) void chunk_kernel(BuildArgs a, uint64_t n_wind
     const uint64_t bk = per ? key / per : 0;
     a.bucket[k] = uint8_t(bk < 8 ? bk : 7);
     a.sub[k] = xcd_sub_window(key, a.bucket[k], per);
-    // what the launcher needs to know about the table
-    if (a.long_run) { atomicOr(&a.meta[0], 1u); if (tasks > CHUNK_TASKS) atomicOr(&a.meta[1], 1u); }
-    else if (a.dense) atomicOr(&a.meta[0], 2u);
-    else { atomicOr(&a.meta[2], 1u); atomicMax(&a.meta[3], uint32_t(n)); }
+    // what the launcher needs to know about the table (one lane per window gets here: the atomics are only issued while they would
+    // still change something -- half a million same-address atomics took 6 ms)
+    volatile uint32_t* meta = a.meta;
+    if (a.long_run) { if (!(meta[0] & 1u)) atomicOr(&a.meta[0], 1u); if (tasks > CHUNK_TASKS && !(meta[1] & 1u)) atomicOr(&a.meta[1], 1u); }
+    else if (a.dense) { if (!(meta[0] & 2u)) atomicOr(&a.meta[0], 2u); }
+    else { if (!(meta[2] & 1u)) atomicOr(&a.meta[2], 1u); if (meta[3] < uint32_t(n)) atomicMax(&a.meta[3], uint32_t(n)); }
 }
 
 // ---- inside a slice, window-major: stable counting sort by window (sir_pack.hpp: order_chunks_for_xcds) ----------------------
@@ -293,14 +334,21 @@ __global__ __launch_bounds__(256) void xcd_hist_kernel(const uint8_t* __restrict
     if (threadIdx.x < 8) hist[uint64_t(blockIdx.x) * 8u + threadIdx.x] = s[threadIdx.x];
 }
 
-// one workgroup of 8 lanes x ...: exclusive prefix of each slice's counts over the blocks; totals behind the last block
-__global__ __launch_bounds__(64) void xcd_scan_kernel(uint32_t* __restrict__ hist, uint64_t n_blocks)
+// exclusive prefix of each slice's counts over the blocks, totals behind the last block: one wave per slice, 64 blocks per step
+__global__ __launch_bounds__(512) void xcd_scan_kernel(uint32_t* __restrict__ hist, uint64_t n_blocks)
 {
-    const uint32_t x = threadIdx.x;
-    if (x >= 8) return;
+    const uint32_t x = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t run = 0;
-    for (uint64_t b = 0; b < n_blocks; ++b) { const uint32_t c = hist[b * 8u + x]; hist[b * 8u + x] = run; run += c; }
-    hist[n_blocks * 8u + x] = run;
+    for (uint64_t b0 = 0; b0 < n_blocks; b0 += 64u) {
+        const uint64_t b = b0 + lane;
+        const uint32_t c = b < n_blocks ? hist[b * 8u + x] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+        if (b < n_blocks) hist[b * 8u + x] = run + incl - c;
+        run += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) hist[n_blocks * 8u + x] = run;
 }
 
 __global__ __launch_bounds__(256) void xcd_scatter_kernel(const Chunk* __restrict__ in, const uint8_t* __restrict__ bucket, uint64_t n,
@@ -342,8 +390,8 @@ hipError_t launch_build(const BuildArgs& a, uint64_t n_windows, uint64_t n_desc,
         if (a.n_tx) hipLaunchKernelGGL(walk_kernel<false>, dim3(tx_blocks), dim3(256), 0, stream, a);
     } else if (phase == 1) {                // emit + chunk table
         if (a.n_tx) hipLaunchKernelGGL(walk_kernel<true>, dim3(tx_blocks), dim3(256), 0, stream, a);
-        const uint64_t m = n_windows > a.n_haps + 1 ? n_windows : a.n_haps + 1;
-        hipLaunchKernelGGL(chunk_kernel, dim3(uint32_t((m + 255) / 256)), dim3(256), 0, stream, a, n_windows, n_desc, out_bytes);
+        hipLaunchKernelGGL(hap_begin_kernel, dim3(uint32_t((a.n_haps + 1 + 255) / 256)), dim3(256), 0, stream, a, out_bytes);
+        if (n_windows) hipLaunchKernelGGL(chunk_kernel, dim3(uint32_t((n_windows + 3) / 4)), dim3(256), 0, stream, a, n_windows, n_desc, out_bytes);
     }
     return hipGetLastError();
 }
@@ -367,7 +415,7 @@ hipError_t launch_xcd_order(const Chunk* in, const uint8_t* bucket, uint64_t n, 
     const uint64_t n_blocks = (n + 255) / 256;
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(xcd_hist_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, stream, bucket, n, hist);
-    hipLaunchKernelGGL(xcd_scan_kernel, dim3(1), dim3(64), 0, stream, hist, n_blocks);
+    hipLaunchKernelGGL(xcd_scan_kernel, dim3(1), dim3(512), 0, stream, hist, n_blocks);
     hipLaunchKernelGGL(xcd_scatter_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, stream, in, bucket, n, hist, n_blocks, out);
     return hipGetLastError();
 }
