@@ -189,7 +189,8 @@ typedef struct {
 /* kernel: 1 = route every chunk to the long-run kernel (<= 512 descriptors per window), 2 = per-block kernel, 3 = dense image
  * (stitch_dense_kernel: short tasks, fused substitutions, <= 1024 descriptors per window: windows of 4 or 8 KiB).
  * On success the batch is finalized (execute / sync / download / digests work as after v2p_batch_finalize).
- * *build_ms (optional): time of the build kernels alone (HIP events), the stream already on the device. */
+ * *build_ms (optional): time of the build kernels alone (two HIP event brackets: counting passes, emitting passes; not the
+ * allocation of the image in between), the stream already on the device. */
 int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t window_bytes, int kernel, float* build_ms);
 /* the image as it sits on the device (for checkers): sizes first (any pointer may be NULL), then the arrays */
 int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, uint64_t* hap_out_begin);

@@ -690,9 +690,12 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     HIP_TRY(c, hipMemsetAsync(d + o_meta, 0, 16, c->stream), "hipMemset(meta)");
     int rc = init_status(c, b->d_status);
     if (rc) return rc;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    // two brackets: the counting kernels, then -- after the host has read the two totals and allocated the image -- the emitting ones
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
     HIP_TRY(c, hipEventCreate(&e0), "hipEventCreate");
     HIP_TRY(c, hipEventCreate(&e1), "hipEventCreate");
+    HIP_TRY(c, hipEventCreate(&e2), "hipEventCreate");
+    HIP_TRY(c, hipEventCreate(&e3), "hipEventCreate");
     BuildArgs a{};
     a.n_haps = n_h; a.n_tx = n_tx;
     a.hap_tx_begin = reinterpret_cast<const uint64_t*>(d + o_hap); a.tx_proteome_off = reinterpret_cast<const uint64_t*>(d + o_poff);
@@ -709,11 +712,12 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     HIP_TRY(c, launch_scan_u32(a.tx_res_len, n_tx, reinterpret_cast<uint64_t*>(d + o_base), reinterpret_cast<uint64_t*>(d + o_tiles), c->stream), "launch(scan)");
     HIP_TRY(c, launch_build(a, 0, 0, 0, 0, c->stream), "launch(count)");
     HIP_TRY(c, launch_scan_u32(a.tx_desc_count, n_tx, reinterpret_cast<uint64_t*>(d + o_dbase), reinterpret_cast<uint64_t*>(d + o_tiles), c->stream), "launch(scan)");
+    HIP_TRY(c, hipEventRecord(e1, c->stream), "hipEventRecord");
     uint64_t totals[2] = {0, 0};
     HIP_TRY(c, hipMemcpyAsync(&totals[0], d + o_base + n_tx * 8, 8, hipMemcpyDeviceToHost, c->stream), "D2H(out_bytes)");
     HIP_TRY(c, hipMemcpyAsync(&totals[1], d + o_dbase + n_tx * 8, 8, hipMemcpyDeviceToHost, c->stream), "D2H(n_desc)");
     rc = collect_status(c, b->d_status);                  // what the reference would panic on surfaces here, before anything is emitted
-    if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return rc; }
+    if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3); (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return rc; }
     const uint64_t out_bytes = totals[0], n_desc = totals[1];
     const uint64_t n_windows = (out_bytes + window_bytes - 1) / window_bytes;
     if (n_windows > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch");
@@ -736,6 +740,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     a.bucket = scratch.ptr() + s_bucket;
     a.sub = scratch.ptr() + s_sub;
     a.hap_out_begin = reinterpret_cast<uint64_t*>(b->d_hap.ptr());
+    HIP_TRY(c, hipEventRecord(e2, c->stream), "hipEventRecord");
     HIP_TRY(c, launch_build(a, n_windows, n_desc, out_bytes, 1, c->stream), "launch(emit)");
     const bool reorder = !(c->flags & V2P_FLAG_RESULT_ORDER) && n_windows >= 16 && c->proteome_len != 0 && n_desc != 0;
     if (reorder) {
@@ -747,15 +752,17 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
                                     reinterpret_cast<Chunk*>(b->d_chunks.ptr()), c->stream), "launch(xcd order)");
     }
     else if (n_windows) HIP_TRY(c, hipMemcpyAsync(b->d_chunks.ptr(), a.chunks_tmp, n_windows * sizeof(Chunk), hipMemcpyDeviceToDevice, c->stream), "D2D(chunks)");
-    HIP_TRY(c, hipEventRecord(e1, c->stream), "hipEventRecord");
+    HIP_TRY(c, hipEventRecord(e3, c->stream), "hipEventRecord");
     uint32_t meta[4] = {0, 0, 0, 0};
     HIP_TRY(c, hipMemcpyAsync(meta, d + o_meta, 16, hipMemcpyDeviceToHost, c->stream), "D2H(meta)");
     b->img.hap_out_begin.assign(n_h + 1, 0);
     HIP_TRY(c, hipMemcpyAsync(b->img.hap_out_begin.data(), b->d_hap.ptr(), (n_h + 1) * 8, hipMemcpyDeviceToHost, c->stream), "D2H(hap_begin)");
     rc = collect_status(c, b->d_status);
-    float ms = 0.f;
+    float ms = 0.f, ms2 = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipEventElapsedTime(&ms2, e2, e3);
+    ms += ms2;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
     scratch.release();
     if (rc) { (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return rc; }
     if (build_ms) *build_ms = ms;
