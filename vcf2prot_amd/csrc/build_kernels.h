@@ -11,7 +11,7 @@ constexpr uint32_t STATUS_TOO_MANY = 5;     // a grid window holds more descript
 
 struct BuildArgs {
     // the transcript stream (v2p_txstream), on the device
-    uint64_t n_haps, n_tx;
+    uint64_t n_haps, n_tx, n_tasks;
     const uint64_t* hap_tx_begin;
     const uint64_t* tx_proteome_off;
     const uint32_t* tx_ref_len;

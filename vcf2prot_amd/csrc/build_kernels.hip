@@ -193,7 +193,7 @@ struct Walker {
     }
 };
 
-template <bool EMIT>
+template <bool EMIT, uint32_t SLAB>
 __global__ __launch_bounds__(256) void walk_kernel(BuildArgs a)
 {
     const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -206,15 +206,39 @@ __global__ __launch_bounds__(256) void walk_kernel(BuildArgs a)
     uint64_t cur = 0;
     bool ok = true;
     if (!EMIT && poff + ref_len > a.proteome_len) { breport(a.status, i0, STATUS_SRC_OOB); ok = false; }   // transcript outside the resident proteome
-    // The next task's fields are requested BEFORE this task's descriptors are stored: gfx950 counts loads and stores in one in-order
-    // counter, so a load issued behind a store is only consumed after that store has been acknowledged (the emit pass took 3.9 ms for
-    // C2 against 0.9 ms for the counting pass over the same arrays before this).
-    uint32_t n_code = 0, n_sp = 0, n_ln = 0, n_sr = 0;
-    if (i0 < i1) { n_code = a.code[i0]; n_sp = a.start_pos[i0]; n_ln = a.length[i0]; n_sr = a.start_pos_res[i0]; }
-    for (uint64_t i = i0; i < i1 && ok; ++i) {
-        const uint32_t code = n_code;
-        const uint64_t sp = n_sp, ln = n_ln, sr = n_sr;
-        if (i + 1 < i1) { n_code = a.code[i + 1]; n_sp = a.start_pos[i + 1]; n_ln = a.length[i + 1]; n_sr = a.start_pos_res[i + 1]; }
+    // A lane reads its transcript's tasks SLAB at a time: sixteen tasks as four unaligned 16-byte loads per array, parked in the lane's own
+    // column of an LDS tile and taken from there one by one.  Read one per step, a deep Task vector (C5: 129 tasks per transcript) had
+    // every lane of a wave on its own cache line in four arrays at every step, lines that did not survive until the next step: the
+    // task arrays came over the HBM interface some thirty times (38 ms for C5's build).  (The arrays sit back to back in one device
+    // buffer with more behind them: reading a few entries past a transcript's last task is harmless.)
+    // (SLAB = 4 for shallow vectors -- C2 has three tasks per transcript -- keeps eight workgroups per CU; 16 for deep ones)
+    __shared__ uint32_t s_sp[SLAB][256], s_ln[SLAB][256], s_sr[SLAB][256];
+    __shared__ uint8_t s_cd[SLAB][256];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    struct __attribute__((packed, aligned(4))) Q4 { u32x4 v; };
+    struct __attribute__((packed, aligned(1))) B16 { u32x4 v; };
+    const uint32_t lane_col = threadIdx.x;
+    for (uint64_t ib = i0; ib < i1 && ok; ib += SLAB) {
+        const uint32_t m = uint32_t(i1 - ib < SLAB ? i1 - ib : SLAB);
+        {
+            const u32x4 cd = reinterpret_cast<const B16*>(a.code + ib)->v;
+#pragma unroll
+            for (uint32_t q = 0; q < SLAB / 4u; ++q) {
+                if (4u * q >= m) break;
+                const u32x4 vsp = reinterpret_cast<const Q4*>(a.start_pos + ib + 4u * q)->v;
+                const u32x4 vln = reinterpret_cast<const Q4*>(a.length + ib + 4u * q)->v;
+                const u32x4 vsr = reinterpret_cast<const Q4*>(a.start_pos_res + ib + 4u * q)->v;
+#pragma unroll
+                for (uint32_t e = 0; e < 4u; ++e) {
+                    s_sp[4u * q + e][lane_col] = vsp[e]; s_ln[4u * q + e][lane_col] = vln[e]; s_sr[4u * q + e][lane_col] = vsr[e];
+                    s_cd[4u * q + e][lane_col] = uint8_t(cd[q] >> (8u * e));
+                }
+            }
+        }
+        for (uint32_t j = 0; j < m && ok; ++j) {
+        const uint64_t i = ib + j;
+        const uint32_t code = s_cd[j][lane_col];
+        const uint64_t sp = s_sp[j][lane_col], ln = s_ln[j][lane_col], sr = s_sr[j][lane_col];
         if (!EMIT) {
             // haplotype_instruction.rs:154 (stream code), task.rs:43/47 (slices), and the canonical order the image needs
             uint32_t why = 0;
@@ -233,6 +257,7 @@ __global__ __launch_bounds__(256) void walk_kernel(BuildArgs a)
             w.stage(SPACE_IMM, lit, ln, sr);
         } else w.stage(SPACE_PAYLOAD, alt0 + sp, ln, sr);
         cur = sr + ln;
+        }
     }
     w.flush();
     if (ok && cur < res_len) w.out(SPACE_FILL, 0, res_len - cur, cur);
@@ -388,9 +413,13 @@ hipError_t launch_build(const BuildArgs& a, uint64_t n_windows, uint64_t n_desc,
 {
     const uint32_t tx_blocks = uint32_t((a.n_tx + 255) / 256);
     if (phase == 0) {                       // count
-        if (a.n_tx) hipLaunchKernelGGL(walk_kernel<false>, dim3(tx_blocks), dim3(256), 0, stream, a);
+        const bool deep = a.n_tx && a.n_tasks / a.n_tx > 6u;
+        if (a.n_tx) { if (deep) hipLaunchKernelGGL((walk_kernel<false, 16u>), dim3(tx_blocks), dim3(256), 0, stream, a);
+                      else hipLaunchKernelGGL((walk_kernel<false, 4u>), dim3(tx_blocks), dim3(256), 0, stream, a); }
     } else if (phase == 1) {                // emit + chunk table
-        if (a.n_tx) hipLaunchKernelGGL(walk_kernel<true>, dim3(tx_blocks), dim3(256), 0, stream, a);
+        const bool deep = a.n_tx && a.n_tasks / a.n_tx > 6u;
+        if (a.n_tx) { if (deep) hipLaunchKernelGGL((walk_kernel<true, 16u>), dim3(tx_blocks), dim3(256), 0, stream, a);
+                      else hipLaunchKernelGGL((walk_kernel<true, 4u>), dim3(tx_blocks), dim3(256), 0, stream, a); }
         hipLaunchKernelGGL(hap_begin_kernel, dim3(uint32_t((a.n_haps + 1 + 255) / 256)), dim3(256), 0, stream, a, out_bytes);
         if (n_windows) hipLaunchKernelGGL(chunk_kernel, dim3(uint32_t((n_windows + 3) / 4)), dim3(256), 0, stream, a, n_windows, n_desc, out_bytes);
     }

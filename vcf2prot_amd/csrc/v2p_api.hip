@@ -697,7 +697,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     HIP_TRY(c, hipEventCreate(&e2), "hipEventCreate");
     HIP_TRY(c, hipEventCreate(&e3), "hipEventCreate");
     BuildArgs a{};
-    a.n_haps = n_h; a.n_tx = n_tx;
+    a.n_haps = n_h; a.n_tx = n_tx; a.n_tasks = s->n_tasks;
     a.hap_tx_begin = reinterpret_cast<const uint64_t*>(d + o_hap); a.tx_proteome_off = reinterpret_cast<const uint64_t*>(d + o_poff);
     a.tx_ref_len = reinterpret_cast<const uint32_t*>(d + o_rlen); a.tx_res_len = reinterpret_cast<const uint32_t*>(d + o_res);
     a.tx_task_begin = reinterpret_cast<const uint64_t*>(d + o_tb); a.tx_alt_begin = reinterpret_cast<const uint64_t*>(d + o_ab);
