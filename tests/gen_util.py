@@ -56,6 +56,16 @@ def interpret_image(desc, chunks, resident, payload, out_bytes):
                 out[dst + len1 + 1:dst + len1 + 1 + len2] = resident[src + len1 + 1:src + len1 + 1 + len2]
                 dst += len1 + 1 + len2
                 continue
+            if (d >> 60) == 0xD:                      # two substitutions in a row (dense images): copy, byte, copy, byte, copy
+                src, l1, l2, l3 = d & ((1 << 29) - 1), (d >> 29) & 31, (d >> 34) & 31, (d >> 39) & 31
+                b1, b2 = (d >> 44) & 0xFF, (d >> 52) & 0xFF
+                out[dst:dst + l1] = resident[src:src + l1]
+                out[dst + l1] = b1
+                out[dst + l1 + 1:dst + l1 + 1 + l2] = resident[src + l1 + 1:src + l1 + 1 + l2]
+                out[dst + l1 + 1 + l2] = b2
+                out[dst + l1 + l2 + 2:dst + l1 + l2 + 2 + l3] = resident[src + l1 + l2 + 2:src + l1 + l2 + 2 + l3]
+                dst += l1 + l2 + l3 + 2
+                continue
             src, ln = d & ((1 << 40) - 1), (d >> 40) & ((1 << 22) - 1)
             if space == 0:
                 out[dst:dst + ln] = resident[src:src + ln]

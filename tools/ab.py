@@ -95,7 +95,7 @@ def main():
         if int(kv.get("grid", 0)):            # chunks cut on a fixed result grid (the device builder's rule)
             img = cohort.pack_grid(0, cohort.n_haplotypes, int(kv["grid"]), 2 if int(kv.get("var", 0)) in (1, 2) else 1)
         else:
-          img = cohort.pack(0, cohort.n_haplotypes, n_threads=min(64, os.cpu_count() or 1), fasta=bool(int(kv.get("fasta", 0))), inline_payload=bool(int(kv.get("imm", 1))), fuse=bool(int(kv.get("fuse", 1))), kernel=(2 if int(kv.get("var", 0)) in (1, 2) else int(kv.get("kernel", 0))), **pack)
+          img = cohort.pack(0, cohort.n_haplotypes, n_threads=min(64, os.cpu_count() or 1), fasta=bool(int(kv.get("fasta", 0))), inline_payload=bool(int(kv.get("imm", 1))), fuse=bool(int(kv.get("fuse", 1))), double=bool(int(kv.get("double", 1))), kernel=(2 if int(kv.get("var", 0)) in (1, 2) else int(kv.get("kernel", 0))), **pack)
         chunks = np.ascontiguousarray(img.chunks)
         rep = int(kv.get("rep", 0))
         if rep:

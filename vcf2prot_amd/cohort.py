@@ -205,12 +205,12 @@ class Cohort:
         return out
 
     def pack(self, h0: int, h1: int, n_threads: int = 0, chunk_tasks: int = 0, chunk_bytes: int = 0,
-             fasta: bool = False, cut_align: int = 0, soft_window: int = 0, inline_payload: bool = True, fuse: bool = True,
+             fasta: bool = False, cut_align: int = 0, soft_window: int = 0, inline_payload: bool = True, fuse: bool = True, double: bool = True,
              kernel: int = 0) -> Packed:
         import os
         img = PackedImage()
         nt = n_threads or min(32, os.cpu_count() or 1)
-        rc = self._lib.v2p_cohort_pack(self._h, h0, h1, nt, chunk_tasks, chunk_bytes, (1 if fasta else 0) | (0 if inline_payload else 2) | (0 if fuse else 4) | (16 if kernel == 2 else (32 if kernel == 1 else (64 if kernel == 3 else 0))) | (cut_align << 8) | (soft_window << 24), ctypes.byref(img))
+        rc = self._lib.v2p_cohort_pack(self._h, h0, h1, nt, chunk_tasks, chunk_bytes, (1 if fasta else 0) | (0 if inline_payload else 2) | (0 if fuse else 4) | (0 if double else 8) | (16 if kernel == 2 else (32 if kernel == 1 else (64 if kernel == 3 else 0))) | (cut_align << 8) | (soft_window << 24), ctypes.byref(img))
         if rc != 0:
             raise RuntimeError(f"v2p_cohort_pack failed ({rc})")
         try:

@@ -160,8 +160,9 @@ struct Walker {
     uint64_t k;          // next descriptor index (EMIT) / unused
     WinPos base;         // window position of the transcript's first result byte
     uint32_t cnt = 0;    // descriptors so far
-    Staged s0{0, 0, 0, 0}, s1{0, 0, 0, 0};                                          // (two named slots: an indexed array lives in scratch memory)
+    Staged s0{0, 0, 0, 0}, s1{0, 0, 0, 0}, s2{0, 0, 0, 0}, s3{0, 0, 0, 0};          // (named slots: an indexed array lives in scratch memory)
     int st_n = 0;
+    uint64_t run_src = 0;                                                            // st_n >= 3: where the fused run of s0..s2 starts
     PairSink sink;
     __device__ Walker(const BuildArgs& a_, uint64_t k_, uint64_t base_) : a(a_), k(k_), base{base_ / a_.window, uint32_t(base_ % a_.window)} {}
     __device__ void out(uint32_t space, uint64_t src, uint64_t len, uint64_t rel) { if (len) cnt += put<EMIT>(a, sink, k, win_pos(base, rel, a.window), len, space, src); }
@@ -169,6 +170,11 @@ struct Walker {
     {
         const int n = st_n;
         st_n = 0;
+        if (n >= 3) {                                                            // a complete substitution that waited for a second one
+            fused(run_src, uint32_t(s0.len), uint32_t(s1.src), uint32_t(s2.len), s0.rel);
+            if (n == 4) out(s3.space, s3.src, s3.len, s3.rel);
+            return;
+        }
         if (n >= 1) out(s0.space, s0.src, s0.len, s0.rel);
         if (n == 2) out(s1.space, s1.src, s1.len, s1.rel);
     }
@@ -188,15 +194,47 @@ struct Walker {
             out(SPACE_PROTEOME, src + len1 + 1, len2, rel + len1 + 1);
         }
     }
+    // two substitutions in a row (sir_pack.hpp's emit_fused2): five tasks, one descriptor when they lie inside one window
+    __device__ void fused2(uint64_t src, uint32_t len1, uint32_t b1, uint32_t len2, uint32_t b2, uint32_t len3, uint64_t rel)
+    {
+        const uint64_t total = uint64_t(len1) + 1u + len2 + 1u + len3;
+        const WinPos at = win_pos(base, rel, a.window);
+        if (uint64_t(at.off) + total <= a.window) {
+            if (EMIT) {
+                sink.store(a.desc, k, SNV5_MARK | (uint64_t(b2 & 0xFFu) << 52) | (uint64_t(b1 & 0xFFu) << 44) | (uint64_t(len3 & 31u) << 39) | (uint64_t(len2 & 31u) << 34)
+                                          | (uint64_t(len1 & 31u) << 29) | (src & SNV3_MAX_SRC));
+                if (at.off == 0u) a.chunk_first[at.win] = k;
+            }
+            ++k; ++cnt;
+        } else {
+            fused(src, len1, b1, len2, rel);
+            out(SPACE_IMM, b2, 1, rel + len1 + 1 + len2);
+            out(SPACE_PROTEOME, src + len1 + 1 + len2 + 1, len3, rel + len1 + 1 + len2 + 1);
+        }
+    }
     __device__ void stage(uint32_t space, uint64_t src, uint64_t len, uint64_t rel)
     {
         if (!a.long_run && !a.dense) { out(space, src, len, rel); return; }
+        if (st_n == 4) {
+            const uint64_t want = run_src + s0.len + 1 + s2.len + 1;
+            if (space == SPACE_PROTEOME && len <= SNV5_MAX_LEN && (len == 0 || src == want) && want + len <= SNV3_MAX_SRC) {
+                st_n = 0;
+                fused2(run_src, uint32_t(s0.len), uint32_t(s1.src), uint32_t(s2.len), uint32_t(s3.src), uint32_t(len), s0.rel);
+                return;
+            }
+            flush();
+        }
+        if (st_n == 3) {
+            if (space == SPACE_IMM && len == 1) { s3 = Staged{space, src, len, rel}; st_n = 4; return; }
+            flush();
+        }
         if (st_n == 2) {
             const bool fits = s0.len == 0 ? (len > 0 && src >= 1 && src - 1 + 1 + len <= SNV3_MAX_SRC) : (len == 0 || src == s0.src + s0.len + 1);
             if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && fits) {
-                const Staged r1 = s0, lit = s1;
+                const uint64_t run = s0.len == 0 ? src - 1 : s0.src;
+                if (a.dense && s0.len <= SNV5_MAX_LEN && len <= SNV5_MAX_LEN) { s2 = Staged{space, src, len, rel}; run_src = run; st_n = 3; return; }   // a dense image waits for a second one
                 st_n = 0;
-                fused(r1.len == 0 ? src - 1 : r1.src, uint32_t(r1.len), uint32_t(lit.src), uint32_t(len), r1.rel);
+                fused(run, uint32_t(s0.len), uint32_t(s1.src), uint32_t(len), s0.rel);
                 return;
             }
             flush();
@@ -306,8 +344,9 @@ __global__ __launch_bounds__(256) void chunk_kernel(BuildArgs a, uint64_t n_wind
     for (uint32_t q0 = 0; q0 < n; q0 += 64u) {
         const uint32_t q = q0 + lane;
         const uint64_t d = q < n ? a.desc[tb + q] : 0ull;
-        const bool snv = (d & SNV3_MARK) == SNV3_MARK;
-        if (q < n) tasks += snv ? (((d >> 29) & 0xFFFu) ? 1u : 0u) + 1u + (((d >> 41) & 0xFFFu) ? 1u : 0u) : 1u;
+        const bool snv3 = (d & SNV3_MARK) == SNV3_MARK, snv5 = (d >> 60) == 0xDull, snv = snv3 || snv5;
+        if (q < n) tasks += snv3 ? (((d >> 29) & 0xFFFu) ? 1u : 0u) + 1u + (((d >> 41) & 0xFFFu) ? 1u : 0u)
+                          : (snv5 ? (((d >> 29) & 31u) ? 1u : 0u) + (((d >> 34) & 31u) ? 1u : 0u) + (((d >> 39) & 31u) ? 1u : 0u) + 2u : 1u);
         if (q0 == 0u) {
             const uint64_t src = snv ? (d & SNV3_MAX_SRC) : (d & SRC_MASK);
             const bool cand = q < n && q < 6u && (snv || (d >> 62) == SPACE_PROTEOME) && src < a.proteome_len;

@@ -455,6 +455,7 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
         if (chunk_bytes) { im.chunk_bytes = chunk_bytes; im.adaptive_bytes = false; }
         if (flags & V2P_PACK_NO_IMM) im.inline_payload = false;
         if (flags & V2P_PACK_NO_FUSE) im.fuse_snv = false;
+        if (flags & V2P_PACK_NO_DOUBLE) im.fuse_double = false;
         if (flags & V2P_PACK_PER_BLOCK) im.kernel_choice = 2;
         if (flags & V2P_PACK_LONG_RUN) im.kernel_choice = 1;
         if (flags & V2P_PACK_DENSE) im.kernel_choice = 3;

@@ -23,6 +23,10 @@
 //                  three: the descriptor stream of an SNV-only cohort drops from 6 % to 2 % of the result
 //                  bytes (a streamed HBM read above 1/32 of a saturated write stream costs that stream 40 %
 //                  on MI355X, profiles/r02_copy_mix_*.json).  The kernel expands it back into three tasks.
+//                  space 3 with bits 61..60 = 01 (an immediate's length field can never reach bit 60) = TWO
+//                  substitutions in a row ("SNV5", dense images only: deep Task vectors are copy / literal / copy /
+//                  literal / copy with a handful of residues between the literals): bits 0..28 src, 29..33 len1,
+//                  34..38 len2, 39..43 len3, 44..51 the first byte, 52..59 the second -- five tasks in one descriptor.
 //   chunks[C]    work items of <= 256 (deep Task vectors: 1024) consecutive descriptors and < 64 KiB of
 //                result: {first descriptor, result offset:48 | descriptor count:11 | 0:4 | long-run flag:1}.
 //                The flag routes the chunk: set = stitch4_kernel (<= 512 tasks, may hold fused descriptors),
@@ -59,6 +63,8 @@ constexpr uint32_t IMM_MAX_BYTES  = 5;         // literal bytes that fit the 40-
 constexpr uint64_t SNV3_MARK      = (3ull << 62) | (1ull << 61);
 constexpr uint32_t SNV3_MAX_LEN   = 4095;      // len1, len2 (12 bits each)
 constexpr uint64_t SNV3_MAX_SRC   = (1ull << 29) - 1;
+constexpr uint64_t SNV5_MARK      = (3ull << 62) | (1ull << 60);     // bits 63..60 = 1101
+constexpr uint32_t SNV5_MAX_LEN   = 31;        // len1, len2, len3 (5 bits each)
 
 constexpr uint64_t SRC_MASK   = (1ull << 40) - 1;
 constexpr uint32_t LEN_BITS   = 22;
@@ -94,11 +100,18 @@ inline bool     desc_is_snv3(uint64_t d) { return (d & SNV3_MARK) == SNV3_MARK; 
 inline uint64_t pack_snv3(uint64_t src, uint32_t len1, uint32_t len2, uint8_t byte) {
     return SNV3_MARK | (uint64_t(byte) << 53) | (uint64_t(len2 & 0xFFFu) << 41) | (uint64_t(len1 & 0xFFFu) << 29) | (src & SNV3_MAX_SRC);
 }
-inline uint64_t desc_src(uint64_t d)   { return desc_is_snv3(d) ? (d & SNV3_MAX_SRC) : (d & SRC_MASK); }
+inline bool     desc_is_snv5(uint64_t d) { return (d >> 60) == 0xDull; }
+inline uint64_t pack_snv5(uint64_t src, uint32_t len1, uint8_t b1, uint32_t len2, uint8_t b2, uint32_t len3) {
+    return SNV5_MARK | (uint64_t(b2) << 52) | (uint64_t(b1) << 44) | (uint64_t(len3 & 31u) << 39) | (uint64_t(len2 & 31u) << 34) | (uint64_t(len1 & 31u) << 29) | (src & SNV3_MAX_SRC);
+}
+inline uint64_t desc_src(uint64_t d)   { return desc_is_snv3(d) || desc_is_snv5(d) ? (d & SNV3_MAX_SRC) : (d & SRC_MASK); }
 // result bytes a descriptor produces
-inline uint32_t desc_len(uint64_t d)   { return desc_is_snv3(d) ? uint32_t((d >> 29) & 0xFFFu) + 1u + uint32_t((d >> 41) & 0xFFFu) : uint32_t(d >> 40) & LEN_MASK; }
+inline uint32_t desc_len(uint64_t d)   {
+    if (desc_is_snv5(d)) return uint32_t((d >> 29) & 31u) + 1u + uint32_t((d >> 34) & 31u) + 1u + uint32_t((d >> 39) & 31u);
+    return desc_is_snv3(d) ? uint32_t((d >> 29) & 0xFFFu) + 1u + uint32_t((d >> 41) & 0xFFFu) : uint32_t(d >> 40) & LEN_MASK;
+}
 // source space; a fused substitution reads the proteome
-inline unsigned desc_space(uint64_t d) { return desc_is_snv3(d) ? SPACE_PROTEOME : unsigned(d >> 62); }
+inline unsigned desc_space(uint64_t d) { return desc_is_snv3(d) || desc_is_snv5(d) ? SPACE_PROTEOME : unsigned(d >> 62); }
 
 enum PackStatus : int {
     PACK_OK = 0,
@@ -135,6 +148,7 @@ public:
                                       // that straddle a grid line are split, zero-length tasks and fusion are dropped).  Chunk membership is then a pure
                                       // function of result offsets, which is what the device-side image builder (build_kernels.hip) computes in parallel
     bool fuse_snv = true;             // reference copy + 1-byte literal + reference copy going on one residue later -> one descriptor
+    bool fuse_double = true;          // dense images: two substitutions in a row -> one descriptor
     uint64_t n_fused = 0;             // fused substitutions in the image
 
     // Empty the image for another build; the vectors keep their capacity, the settings return to their defaults.
@@ -142,7 +156,7 @@ public:
         desc.clear(); chunks.clear(); payload.clear(); hap_out_begin.assign(1, 0);
         n_copy_bytes = n_ref_tasks = n_fused = n_long_chunks = n_dense_chunks = 0;
         chunk_tasks = CHUNK_TASKS; adaptive_tasks = true; chunk_bytes = CHUNK_BYTES_LONG; adaptive_bytes = true; cut_align = CUT_ALIGN;
-        max_chunk_tasks = max_long_tasks = 0; soft_window = 8; inline_payload = true; fuse_snv = true; kernel_choice = 0; grid_bytes = 0;
+        max_chunk_tasks = max_long_tasks = 0; soft_window = 8; inline_payload = true; fuse_snv = true; fuse_double = true; kernel_choice = 0; grid_bytes = 0;
         cursor_ = extra_ = arena_cursor_ = open_begin_ = open_dst_ = 0;
         open_n_ = open_bytes_ = open_desc_ = 0; open_fused_ = false; st_n_ = 0;
     }
@@ -220,8 +234,9 @@ private:
     uint32_t cut_pref() const { return kernel_choice == 3 && adaptive_bytes ? 16u : cut_align; }
     bool open_fused_ = false;                // it holds a fused descriptor
     struct Staged { unsigned space; uint64_t src; uint64_t len; };
-    Staged st_[2];                   // tasks held back because the next one may complete a fused substitution
+    Staged st_[4];                   // tasks held back because the next one may complete a fused substitution (dense images: a second one)
     int st_n_ = 0;
+    uint64_t run_src_ = 0;           // st_n_ >= 3: where the fused run of st_[0..2] starts in the proteome
 
     bool long_run_mode() const { return chunk_tasks <= CHUNK_TASKS; }
     // GRID cutting: pieces never cross a multiple of grid_bytes; a chunk closes exactly on the grid
@@ -238,6 +253,11 @@ private:
     void flush() {
         const int n = st_n_;
         st_n_ = 0;
+        if (n >= 3) {                // a complete substitution that waited for a second one
+            emit_fused(run_src_, uint32_t(st_[0].len), uint8_t(st_[1].src), uint32_t(st_[2].len));
+            if (n == 4) emit(st_[3].space, st_[3].src, st_[3].len);
+            return;
+        }
         for (int i = 0; i < n; ++i) emit(st_[i].space, st_[i].src, st_[i].len);
     }
     // One task in canonical order.  [reference copy] [1-byte literal] [reference copy one residue further on] becomes one
@@ -249,14 +269,32 @@ private:
         const bool may_fuse = fuse_snv && (grid_bytes ? (kernel_choice == 1 || kernel_choice == 3)
                                                       : (kernel_choice == 3 || (long_run_mode() && kernel_choice != 2 && !(adaptive_tasks && kernel_choice == 0))));
         if (!may_fuse) { flush(); emit(space, src, len); return; }
+        if (st_n_ == 4) {            // [copy][byte][copy][byte] + the copy going on one residue behind the third: two substitutions, one descriptor
+            const uint64_t want = run_src_ + st_[0].len + 1 + st_[2].len + 1;
+            if (space == SPACE_PROTEOME && len <= SNV5_MAX_LEN && (len == 0 || src == want) && want + len <= SNV3_MAX_SRC) {
+                st_n_ = 0;
+                emit_fused2(run_src_, uint32_t(st_[0].len), uint8_t(st_[1].src), uint32_t(st_[2].len), uint8_t(st_[3].src), uint32_t(len));
+                return;
+            }
+            flush();                 // the first substitution as it is, the literal on its own
+        }
+        if (st_n_ == 3) {
+            if (space == SPACE_IMM && len == 1) { st_[3] = Staged{space, src, len}; st_n_ = 4; return; }
+            flush();
+        }
         if (st_n_ == 2) {
             // the copy after the literal goes on one residue behind the copy before it; an EMPTY copy (substitution at the first
             // or last residue: transcript_instructions.rs:734, :648-649) has no source to speak of and fits any neighbour
             const bool fits = st_[0].len == 0 ? (len > 0 && src >= 1 && src - 1 + 1 + len <= SNV3_MAX_SRC) : (len == 0 || src == st_[0].src + st_[0].len + 1);
             if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && fits) {
                 const Staged a = st_[0], b = st_[1];
+                const uint64_t run = a.len == 0 ? src - 1 : a.src;
+                if (kernel_choice == 3 && fuse_double && a.len <= SNV5_MAX_LEN && len <= SNV5_MAX_LEN) {      // a dense image waits for a second substitution
+                    st_[2] = Staged{space, src, len}; run_src_ = run; st_n_ = 3;
+                    return;
+                }
                 st_n_ = 0;
-                emit_fused(a.len == 0 ? src - 1 : a.src, uint32_t(a.len), uint8_t(b.src), uint32_t(len));
+                emit_fused(run, uint32_t(a.len), uint8_t(b.src), uint32_t(len));
                 return;
             }
             flush();
@@ -267,6 +305,28 @@ private:
         }
         if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && src + len + 1 + SNV3_MAX_LEN <= SNV3_MAX_SRC) { st_[0] = Staged{space, src, len}; st_n_ = 1; return; }
         emit(space, src, len);
+    }
+    void emit_fused2(uint64_t src, uint32_t len1, uint8_t b1, uint32_t len2, uint8_t b2, uint32_t len3) {
+        const uint32_t total = len1 + 1u + len2 + 1u + len3, cnt = (len1 ? 1u : 0u) + 1u + (len2 ? 1u : 0u) + 1u + (len3 ? 1u : 0u);
+        bool whole;
+        if (grid_bytes) whole = arena_cursor_ / grid_bytes == (arena_cursor_ + total - 1) / grid_bytes;
+        else {
+            const uint32_t soft_tasks = chunk_tasks > soft_window ? chunk_tasks - soft_window : chunk_tasks;
+            const uint32_t soft_bytes = chunk_bytes > cut_pref() ? chunk_bytes - cut_pref() : chunk_bytes;
+            whole = open_units() + 1u <= soft_tasks && open_bytes_ + total <= soft_bytes;
+        }
+        if (whole) {
+            if (open_n_ == 0) { open_begin_ = desc.size(); open_dst_ = arena_cursor_; }
+            desc.push_back(pack_snv5(src, len1, b1, len2, b2, len3));
+            ++open_desc_; open_n_ += cnt; open_bytes_ += total; arena_cursor_ += total;
+            n_fused += 2; open_fused_ = true;
+            if (grid_bytes && arena_cursor_ % grid_bytes == 0) close_chunk();
+            return;
+        }
+        // across a cut: the first substitution on its own (it may still fit), then the rest task by task
+        emit_fused(src, len1, b1, len2);
+        emit(SPACE_IMM, b2, 1);
+        emit(SPACE_PROTEOME, src + len1 + 1 + len2 + 1, len3);
     }
     void emit_fused(uint64_t src, uint32_t len1, uint8_t byte, uint32_t len2) {
         const uint32_t total = len1 + 1u + len2, cnt = (len1 ? 1u : 0u) + 1u + (len2 ? 1u : 0u);

@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
     u32x4 g[TPT];
     uint32_t len[TPT];
     uint64_t sw[TPT];                                       // space << 40 | source offset (the literal of an immediate task)
-    uint32_t patch[TPT];                                    // fused substitution: bytes before the literal | literal << 12 | 1 << 20
+    uint32_t patch[TPT];                                    // fused substitution: bytes before the literal | literal << 12 | 1 << 20 [| position of a second literal << 21 | 1 << 28]
     auto load_tasks = [&](bool first_time) -> uint32_t {
         uint64_t d[TPT];
         uint32_t lsum = 0, bad = 0u;
@@ -525,7 +525,17 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
             patch[k] = 0u;
-            if ((d[k] & SNV3_MARK) == SNV3_MARK) {
+            if ((d[k] >> 60) == 0xDull) {
+                // two substitutions in a row (sir_pack.hpp "SNV5"): ONE reference run of len1 + 1 + len2 + 1 + len3 bytes, two bytes of it replaced
+                const uint32_t len1 = uint32_t(d[k] >> 29) & 31u, len2 = uint32_t(d[k] >> 34) & 31u, len3 = uint32_t(d[k] >> 39) & 31u;
+                const uint64_t so = d[k] & SNV3_MAX_SRC;
+                len[k] = len1 + 1u + len2 + 1u + len3;
+                patch[k] = len1 | (uint32_t(d[k] >> 44) & 0xFFu) << 12 | 1u << 20 | (len1 + 1u + len2) << 21 | 1u << 28;
+                // the reference bytes actually used end with the last non-empty copy
+                const uint32_t used = len3 ? len[k] : (len2 ? len1 + 1u + len2 : len1);
+                if (!fused || so + used > a.src0_len) { bad |= 1u << k; len[k] = 0; patch[k] = 0u; }
+                sw[k] = (uint64_t(d[k] >> 52) & 0xFFull) << 48 | (uint64_t(SPACE_PROTEOME) << 40) | so;      // (the second byte rides in bits 48..55)
+            } else if ((d[k] & SNV3_MARK) == SNV3_MARK) {
                 // a fused substitution is ONE reference run of len1 + 1 + len2 bytes whose byte len1 is replaced afterwards
                 const uint32_t len1 = uint32_t(d[k] >> 29) & 0xFFFu, len2 = uint32_t(d[k] >> 41) & 0xFFFu;
                 const uint64_t so = d[k] & SNV3_MAX_SRC;
@@ -605,7 +615,7 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
                         const uint32_t skip = q - off;        // bytes of the task before this piece
                         const uint64_t so = space == SPACE_IMM ? (sw[k] & OFF40) >> (8u * skip)                       // (a literal cut by the window)
                                                                : (sw[k] & OFF40) + (space == SPACE_FILL ? 0ull : uint64_t(skip));
-                        s_piece[pi++] = (sw[k] & ~OFF40) | so | (uint64_t(min(e - q, 16u) - 1u) << 42) | (uint64_t(q - w0) << 46);
+                        s_piece[pi++] = (sw[k] & (3ull << 40)) | so | (uint64_t(min(e - q, 16u) - 1u) << 42) | (uint64_t(q - w0) << 46);
                     }
                 }
                 off += len[k];
@@ -634,7 +644,9 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
 #pragma unroll
             for (int k = 0; k < TPT; ++k) {
                 const uint32_t q = off + (patch[k] & 0xFFFu);
-                if ((patch[k] >> 20) && q >= w0 && q < w1) reinterpret_cast<uint8_t*>(s_img)[q - w0] = uint8_t(patch[k] >> 12);
+                if (((patch[k] >> 20) & 1u) && q >= w0 && q < w1) reinterpret_cast<uint8_t*>(s_img)[q - w0] = uint8_t(patch[k] >> 12);
+                const uint32_t q2 = off + ((patch[k] >> 21) & 0x7Fu);
+                if ((patch[k] >> 28) && q2 >= w0 && q2 < w1) reinterpret_cast<uint8_t*>(s_img)[q2 - w0] = uint8_t(sw[k] >> 48);
                 off += len[k];
             }
             lds_barrier();
