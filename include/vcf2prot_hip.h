@@ -187,7 +187,8 @@ typedef struct {
     const uint8_t*  alt;               /* [n_alt] alt tapes of the transcripts back to back, 1 byte per residue         */
 } v2p_txstream;
 /* kernel: 1 = route every chunk to the long-run kernel (<= 512 descriptors per window), 2 = per-block kernel, 3 = dense image
- * (stitch_dense_kernel: short tasks, fused substitutions, <= 1024 descriptors per window: windows of 4 or 8 KiB).
+ * (stitch_dense_kernel: short tasks, fused substitutions, <= 1024 descriptors per window: windows of 4 or 8 KiB, larger ones are
+ * V2P_ERR_INVALID_ARG).
  * On success the batch is finalized (execute / sync / download / digests work as after v2p_batch_finalize).
  * *build_ms (optional): time of the build kernels alone (two HIP event brackets: counting passes, emitting passes; not the
  * allocation of the image in between), the stream already on the device. */
@@ -252,7 +253,9 @@ int v2p_stitch_launch(void* hip_stream,
                       uint64_t* d_status, int nontemporal, uint32_t max_blocks);
 /* Host-side: which stitch kernels a chunk table needs and their tasks per lane (bits 4..11 of `nontemporal`): long-run chunks go to
  * stitch4_kernel, the others to stitch_kernel (per block) or, when chunks hold more than 512 descriptors (short tasks), to
- * stitch_dense_kernel. */
+ * stitch_dense_kernel.  A chunk flagged dense (bit 61 of dst_n) must hold at most 12288 bytes of result incl. its 16-byte phase --
+ * the kernel's LDS image; the builders never make a larger one, and the kernel refuses one (status: result out of bounds) rather
+ * than executing it. */
 int v2p_stitch_launch_bits(const v2p_chunk* chunks, uint64_t n_chunks);
 /* Host-side: reorder a chunk table so that workgroup 8*j + x (XCD x) works on proteome slice x.
  * v2p_batch_finalize() does this itself; callers of v2p_stitch_launch() may want it too. */

@@ -135,6 +135,35 @@ def test_dense_kernel_on_any_per_block_image(built, coracle, preset, h0, n):
     d_prot.free()
 
 
+def test_oversized_dense_chunk_is_refused_not_executed(built):
+    """A chunk flagged dense must fit the kernel's 12 KiB LDS image; the builders never make a larger one, and one that arrives
+    through v2p_stitch_launch is reported in the status word and nothing of it is written."""
+    from hip_util import DevBuf
+    from vcf2prot_amd import _native as N
+    from vcf2prot_amd.cohort import Cohort
+    lib = N.hip_lib()
+    c = Cohort.preset("C3")
+    prot = c.proteome()
+    img = c.pack(0, 2, n_threads=1, kernel=2, chunk_tasks=1000, chunk_bytes=65520)
+    chunks = np.ascontiguousarray(img.chunks)
+    assert (((chunks[:, 1] >> np.uint64(48)) & np.uint64(0x7FF)).max() > 0)
+    chunks[:, 1] |= np.uint64(1 << 61)                                   # CHUNK_DENSE on 64 KiB chunks
+    d_prot, d_desc, d_chunks, d_pay = DevBuf.of(prot), DevBuf.of(img.desc), DevBuf.of(chunks), DevBuf.of(img.payload)
+    d_out = DevBuf(img.out_bytes + 32, fill=0x2E)
+    d_status = DevBuf.of(np.full(1, -1, dtype=np.int64))
+    bits = int(lib.v2p_stitch_launch_bits(chunks.ctypes.data, chunks.shape[0]))
+    assert bits & 2
+    rc = lib.v2p_stitch_launch(None, d_desc.ptr, img.desc.size, d_chunks.ptr, chunks.shape[0], d_prot.ptr, prot.size, d_pay.ptr, img.payload.size,
+                               d_out.ptr, img.out_bytes, d_status.ptr, 1 | bits, 0)
+    assert rc == 0
+    assert d_status.download().view(np.int64)[0] != -1                   # reported
+    got = d_out.download()[:img.out_bytes]
+    big = ((chunks[:, 1] & np.uint64((1 << 48) - 1)).astype(np.int64))
+    assert np.all(got[big[0]:big[0] + 13000] == 0x2E)                    # the first (oversized) chunk's range is untouched
+    for b in (d_prot, d_desc, d_chunks, d_pay, d_out, d_status):
+        b.free()
+
+
 @pytest.mark.parametrize("preset,h0,n", [("C2", 1, 2), ("C3", 5, 4), ("C1", 0, 8)])
 def test_lds_staged_reference_variant_is_exact(built, coracle, preset, h0, n):
     """stitch4_kernel with the chunk's reference span staged in LDS by global_load_lds_dwordx4 (variants 7 / 11: 36 / 20 KiB windows;

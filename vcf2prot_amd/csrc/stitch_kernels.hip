@@ -443,24 +443,21 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
 constexpr uint32_t DENSE_STAGE = 12288u;                   // bytes of the LDS image (CHUNK_BYTES_DENSE + 16)
 constexpr uint32_t DENSE_PIECES = DENSE_STAGE / 16u + 8u;  // continuation pieces of one window
 
-// up to n (1..16) bytes x, first byte lowest, OR-ed into the LDS image at byte offset o
-__device__ __forceinline__ void dense_put(uint32_t* img, uint32_t o, u32x4 x, uint32_t n)
+// up to n (1..16) bytes x, first byte lowest, OR-ed into the LDS image at byte offset o.  `lowmask[n]` = the low n bytes of a block
+// (an LDS table: one ds_read_b128 instead of a dozen 64-bit shift / select instructions -- the kernel is VALU-bound).
+__device__ __forceinline__ void dense_put(uint32_t* img, const u32x4* lowmask, uint32_t o, u32x4 x, uint32_t n)
 {
-    if (n < 16u) {                                          // keep bytes 0..n-1
-        const uint64_t m = ~0ull >> (8u * (8u - (n & 7u)) & 63u);      // the low n & 7 bytes (n & 7 == 0: all, not used then)
-        const uint64_t mlo = n >= 8u ? ~0ull : (n ? m : 0ull);
-        const uint64_t mhi = n > 8u ? m : 0ull;
-        x[0] &= uint32_t(mlo); x[1] &= uint32_t(mlo >> 32); x[2] &= uint32_t(mhi); x[3] &= uint32_t(mhi >> 32);
-    }
+    const u32x4 m = lowmask[n];
+    x[0] &= m[0]; x[1] &= m[1]; x[2] &= m[2]; x[3] &= m[3];
     // five dwords from wb on; the data begin at byte bo = 1..4 of them (alignbyte shifts by 0..3 bytes only, so a dword-aligned
     // destination is taken as "shifted by four": dword 0 then holds nothing)
-    const uint32_t wb = ((o + 3u) >> 2) - 1u, s2 = (4u - o) & 3u, bo = o - 4u * wb, end = bo + n;
+    const uint32_t wb = ((o + 3u) >> 2) - 1u, s2 = (0u - o) & 3u, end = o - 4u * wb + n;
     const uint32_t e0 = __builtin_amdgcn_alignbyte(x[0], 0u, s2);
     const uint32_t e1 = __builtin_amdgcn_alignbyte(x[1], x[0], s2);
     const uint32_t e2 = __builtin_amdgcn_alignbyte(x[2], x[1], s2);
     const uint32_t e3 = __builtin_amdgcn_alignbyte(x[3], x[2], s2);
     const uint32_t e4 = __builtin_amdgcn_alignbyte(0u, x[3], s2);
-    if (bo < 4u) atomicOr(&img[wb], e0);
+    if (s2 != 0u) atomicOr(&img[wb], e0);
     atomicOr(&img[wb + 1u], e1);
     if (end > 8u) atomicOr(&img[wb + 2u], e2);
     if (end > 12u) atomicOr(&img[wb + 3u], e3);
@@ -468,7 +465,9 @@ __device__ __forceinline__ void dense_put(uint32_t* img, uint32_t o, u32x4 x, ui
 }
 
 // DBG != 0: timing-only ablations (results are wrong): 1 = no gathers, 2 = no stores, 3 = no LDS puts
-template <bool NT, bool DW, int DBG = 0>
+// ONE: every chunk is a single window (the chunks a dense image flags; a larger one is refused) -- its own instance, because with
+// the multi-window path in the same kernel the compiler keeps 95 VGPRs live instead of 58
+template <bool NT, bool DW, int DBG = 0, bool ONE = false>
 __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __restrict__ p_desc, const Chunk* __restrict__ p_chunks,
                                                               const uint8_t* __restrict__ p_src0, const uint8_t* __restrict__ p_src1,
                                                               uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
@@ -485,10 +484,17 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
     __shared__ __attribute__((aligned(16))) uint32_t s_img[DENSE_STAGE / 4u + 8u];
     __shared__ uint64_t s_piece[DENSE_PIECES];              // space:2 | source offset:40 | (bytes - 1) << 42 | image offset << 46
     __shared__ uint32_t s_w[2][4];
+    __shared__ u32x4 s_low[17];                             // s_low[j]: the low j bytes of a 16-byte block
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t c = blockIdx.x;
     if (c >= a.n_chunks) return;
+    if (tid < 17u) {
+        u32x4 m;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) m[k] = tid >= 4u * k + 4u ? 0xFFFFFFFFu : (tid <= 4u * k ? 0u : (1u << (8u * (tid - 4u * k))) - 1u);
+        s_low[tid] = m;
+    }
     const uint64_t tb = a.chunks[c].task_begin;
     const uint64_t dn = a.chunks[c].dst_n;
     if (dn & CHUNK_LONG) return;                           // long-run chunks belong to stitch4_kernel
@@ -524,33 +530,29 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
         for (int k = 0; k < TPT; ++k) d[k] = tid * TPT + k < n ? a.desc[tb + tid * TPT + k] : 0ull;   // (0: an empty task)
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
-            patch[k] = 0u;
-            if ((d[k] >> 60) == 0xDull) {
-                // two substitutions in a row (sir_pack.hpp "SNV5"): ONE reference run of len1 + 1 + len2 + 1 + len3 bytes, two bytes of it replaced
-                const uint32_t len1 = uint32_t(d[k] >> 29) & 31u, len2 = uint32_t(d[k] >> 34) & 31u, len3 = uint32_t(d[k] >> 39) & 31u;
-                const uint64_t so = d[k] & SNV3_MAX_SRC;
-                len[k] = len1 + 1u + len2 + 1u + len3;
-                patch[k] = len1 | (uint32_t(d[k] >> 44) & 0xFFu) << 12 | 1u << 20 | (len1 + 1u + len2) << 21 | 1u << 28;
-                // the reference bytes actually used end with the last non-empty copy
-                const uint32_t used = len3 ? len[k] : (len2 ? len1 + 1u + len2 : len1);
-                if (!fused || so + used > a.src0_len) { bad |= 1u << k; len[k] = 0; patch[k] = 0u; }
-                sw[k] = (uint64_t(d[k] >> 52) & 0xFFull) << 48 | (uint64_t(SPACE_PROTEOME) << 40) | so;      // (the second byte rides in bits 48..55)
-            } else if ((d[k] & SNV3_MARK) == SNV3_MARK) {
-                // a fused substitution is ONE reference run of len1 + 1 + len2 bytes whose byte len1 is replaced afterwards
-                const uint32_t len1 = uint32_t(d[k] >> 29) & 0xFFFu, len2 = uint32_t(d[k] >> 41) & 0xFFFu;
-                const uint64_t so = d[k] & SNV3_MAX_SRC;
-                len[k] = len1 + 1u + len2;
-                patch[k] = len1 | (uint32_t(d[k] >> 53) & 0xFFu) << 12 | 1u << 20;
-                if (!fused || so + len1 > a.src0_len || (len2 && so + len[k] > a.src0_len)) { bad |= 1u << k; len[k] = 0; patch[k] = 0u; }
-                sw[k] = (uint64_t(SPACE_PROTEOME) << 40) | so;
-            } else {
-                len[k] = uint32_t(d[k] >> 40) & ((1u << 22) - 1u);
-                const uint32_t space = uint32_t(d[k] >> 62);
-                const uint64_t so = d[k] & OFF40;
-                const uint64_t limit = space == SPACE_PROTEOME ? a.src0_len : (space == SPACE_PAYLOAD ? a.src1_len : ~0ull);
-                if (space == SPACE_IMM ? len[k] > IMM_MAX_BYTES : so + len[k] > limit) { bad |= 1u << k; len[k] = 0; }   // never read out of bounds
-                sw[k] = (uint64_t(space) << 40) | so;
-            }
+            // One branch-free decode for the three descriptor kinds (a wave runs every branch some lane takes: three separate paths cost
+            // their sum).  Fused substitutions (sir_pack.hpp SNV3: bits 63..61 = 111; SNV5, two in a row: bits 63..60 = 1101) are ONE
+            // reference run of len1 + 1 + len2 [+ 1 + len3] bytes of which one or two bytes are replaced afterwards.
+            const uint32_t dlo = uint32_t(d[k]), dhi = uint32_t(d[k] >> 32);
+            const bool is5 = (dhi >> 28) == 0xDu, is3 = (dhi >> 29) == 7u, fz = is5 || is3;
+            const uint32_t f29 = __builtin_amdgcn_alignbit(dhi, dlo, 29);          // bits 29..60 of the descriptor
+            const uint32_t l1 = f29 & (is5 ? 31u : 0xFFFu);
+            const uint32_t l2 = is5 ? (f29 >> 5) & 31u : (f29 >> 12) & 0xFFFu;
+            const uint32_t l3 = is5 ? (f29 >> 10) & 31u : 0u;
+            const uint32_t b1 = (is5 ? f29 >> 15 : f29 >> 24) & 0xFFu, b2 = (f29 >> 23) & 0xFFu;
+            uint32_t ln = fz ? l1 + 1u + l2 + (is5 ? 1u + l3 : 0u) : (dhi >> 8) & 0x3FFFFFu;
+            // source bytes actually read: a fused run ends with its last non-empty copy (the literal may sit on the last residue)
+            const uint32_t used = fz ? (l3 ? ln : (l2 ? l1 + 1u + l2 : l1)) : ln;
+            const uint32_t space = fz ? SPACE_PROTEOME : dhi >> 30;
+            const uint32_t so_lo = fz ? dlo & 0x1FFFFFFFu : dlo, so_hi = fz ? 0u : dhi & 0xFFu;
+            const uint64_t so = (uint64_t(so_hi) << 32) | so_lo;
+            const uint64_t limit = space == SPACE_PROTEOME ? a.src0_len : (space == SPACE_PAYLOAD ? a.src1_len : ~0ull);
+            // never read out of bounds (task.rs would panic); a fused descriptor outside a dense image's chunk is refused too
+            const bool bd = so + used > limit || (space == SPACE_IMM && ln > IMM_MAX_BYTES) || (fz && !fused);
+            if (bd) { bad |= 1u << k; ln = 0u; }
+            patch[k] = (fz && !bd) ? (l1 | b1 << 12 | 1u << 20 | (is5 ? (l1 + 1u + l2) << 21 | 1u << 28 : 0u)) : 0u;
+            len[k] = ln;
+            sw[k] = (uint64_t((is5 ? b2 << 16 : 0u) | space << 8 | so_hi) << 32) | so_lo;   // (the second literal rides in bits 48..55)
             lsum += len[k];
         }
 #pragma unroll
@@ -579,18 +581,20 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
     uint8_t* const out0 = a.out + (dst - head);
     const uint32_t off0 = head + excl;                      // image position of the lane's first task
 
-    auto window = [&](const uint32_t w0) {
-        const uint32_t w1 = min(w0 + DENSE_STAGE, span);
+    // `single`: the chunk is one window (every chunk of a dense image) -- nothing is clipped, and no immediate task has a second piece
+    auto window = [&](const uint32_t w0_) {
+        const uint32_t w0 = ONE ? 0u : w0_;
+        const uint32_t w1 = ONE ? span : min(w0 + DENSE_STAGE, span);
         // ---- B: the first piece of every task; the pieces beyond it go on the list ----
         uint32_t off = off0, npc = 0;
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
-            const uint32_t b = max(off, w0), e = min(off + len[k], w1);
+            const uint32_t b = ONE ? off : max(off, w0), e = ONE ? off + len[k] : min(off + len[k], w1);
             if (b < e) {
                 uint32_t first = 0u;
-                if (b == off) {                               // the task begins in this window: its first piece is in registers
+                if (ONE || b == off) {                        // the task begins in this window: its first piece is in registers
                     first = min(e - b, 16u);
-                    if (DBG != 3) dense_put(s_img, b - w0, g[k], first);
+                    if (DBG != 3) dense_put(s_img, s_low, b - w0, g[k], first);
                     else if (g[k][0] == 0x12345678u) s_img[0] = 1u;
                 }
                 npc += (e - b - first + 15u) >> 4;
@@ -607,15 +611,21 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
             off = off0;
 #pragma unroll
             for (int k = 0; k < TPT; ++k) {
-                const uint32_t b = max(off, w0), e = min(off + len[k], w1);
+                const uint32_t b = ONE ? off : max(off, w0), e = ONE ? off + len[k] : min(off + len[k], w1);
                 if (b < e) {
-                    const uint32_t qs = b + (b == off ? min(e - b, 16u) : 0u);
+                    const uint32_t qs = b + ((ONE || b == off) ? min(e - b, 16u) : 0u);
                     const uint32_t space = uint32_t(sw[k] >> 40) & 3u;
-                    for (uint32_t q = qs; q < e; q += 16u) {  // (no trip for most tasks)
-                        const uint32_t skip = q - off;        // bytes of the task before this piece
-                        const uint64_t so = space == SPACE_IMM ? (sw[k] & OFF40) >> (8u * skip)                       // (a literal cut by the window)
+                    if (qs < e) {                             // (not for most tasks)
+                        // the wave runs this loop as often as its longest task has pieces: the record of a piece is the one before it
+                        // plus a constant (source and image offset 16 bytes on), the last piece is shorter
+                        const uint32_t skip = qs - off;       // bytes of the task before the first listed piece
+                        const uint64_t so = (!ONE && space == SPACE_IMM) ? (sw[k] & OFF40) >> (8u * skip)             // (a literal cut by the window)
                                                                : (sw[k] & OFF40) + (space == SPACE_FILL ? 0ull : uint64_t(skip));
-                        s_piece[pi++] = (sw[k] & (3ull << 40)) | so | (uint64_t(min(e - q, 16u) - 1u) << 42) | (uint64_t(q - w0) << 46);
+                        uint64_t rec = (sw[k] & (3ull << 40)) | so | (15ull << 42) | (uint64_t(qs - w0) << 46);
+                        const uint64_t step = (space == SPACE_FILL ? 0ull : 16ull) | (16ull << 46);
+                        uint32_t q = qs;
+                        for (; q + 16u < e; q += 16u) { s_piece[pi++] = rec; rec += step; }
+                        s_piece[pi++] = rec - (uint64_t(16u - (e - q)) << 42);
                     }
                 }
                 off += len[k];
@@ -634,7 +644,7 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
-                    if (r[u] != ~0ull && DBG != 3) dense_put(s_img, uint32_t(r[u] >> 46), v[u], (uint32_t(r[u] >> 42) & 15u) + 1u);
+                    if (r[u] != ~0ull && DBG != 3) dense_put(s_img, s_low, uint32_t(r[u] >> 46), v[u], (uint32_t(r[u] >> 42) & 15u) + 1u);
             }
             lds_barrier();
         }
@@ -644,9 +654,9 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
 #pragma unroll
             for (int k = 0; k < TPT; ++k) {
                 const uint32_t q = off + (patch[k] & 0xFFFu);
-                if (((patch[k] >> 20) & 1u) && q >= w0 && q < w1) reinterpret_cast<uint8_t*>(s_img)[q - w0] = uint8_t(patch[k] >> 12);
+                if (((patch[k] >> 20) & 1u) && (ONE || (q >= w0 && q < w1))) reinterpret_cast<uint8_t*>(s_img)[q - w0] = uint8_t(patch[k] >> 12);
                 const uint32_t q2 = off + ((patch[k] >> 21) & 0x7Fu);
-                if ((patch[k] >> 28) && q2 >= w0 && q2 < w1) reinterpret_cast<uint8_t*>(s_img)[q2 - w0] = uint8_t(sw[k] >> 48);
+                if ((patch[k] >> 28) && (ONE || (q2 >= w0 && q2 < w1))) reinterpret_cast<uint8_t*>(s_img)[q2 - w0] = uint8_t(sw[k] >> 48);
                 off += len[k];
             }
             lds_barrier();
@@ -670,6 +680,11 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
             }
         }
     };
+    if (ONE) {
+        if (span > DENSE_STAGE) { if (tid == 0) report(a.status, tb, STATUS_RES_OOB); return; }   // not a chunk of a dense image: refused, nothing written
+        window(0u);
+        return;
+    }
     window(0u);
     for (uint32_t w0 = DENSE_STAGE; w0 < span; w0 += DENSE_STAGE) {   // (not for a dense chunk)
         lds_barrier();                                        // the image is reused
@@ -1573,7 +1588,8 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     const int tpt_long = (nontemporal >> 6) & 3;        // bits 6..7: tasks per lane of the largest long-run chunk (0 = 2)
     // dense images (chunks of more than 512 short tasks) go to stitch_dense_kernel; variant 3 keeps them on the per-block kernel and
     // variant 8 sends every per-block chunk of any image there (A/B runs)
-#define V2P_LDD(NTT, DWW, DD, FF) hipLaunchKernelGGL((stitch_dense_kernel<NTT, DWW, DD>), dim3(a.n_chunks), dim3(256), 0, stream, V2P_KARGS, uint32_t(FF))
+#define V2P_LDD(NTT, DWW, DD, FF) do { if ((FF) == 3) hipLaunchKernelGGL((stitch_dense_kernel<NTT, DWW, DD, true>), dim3(a.n_chunks), dim3(256), 0, stream, V2P_KARGS, uint32_t(FF)); \
+        else hipLaunchKernelGGL((stitch_dense_kernel<NTT, DWW, DD, false>), dim3(a.n_chunks), dim3(256), 0, stream, V2P_KARGS, uint32_t(FF)); } while (0)
 #define V2P_LD(NTT, FF) do { if (var == 9) V2P_LDD(NTT, true, 0, FF); else if (dbg == 1) V2P_LDD(NTT, false, 1, FF); else if (dbg == 2) V2P_LDD(NTT, false, 2, FF); \
         else if (dbg == 3) V2P_LDD(NTT, false, 3, FF); else V2P_LDD(NTT, false, 0, FF); } while (0)
     if (per_block_only) {
