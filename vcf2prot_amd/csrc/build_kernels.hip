@@ -154,31 +154,35 @@ __device__ __forceinline__ uint32_t put(const BuildArgs& a, PairSink& sink, uint
 // positions are relative to the transcript's first result byte (`rel`).
 struct Staged { uint32_t space; uint64_t src, len, rel; };
 
-template <bool EMIT>
+// MODE: 0 = per-block image (no fusion), 1 = long-run image (fused substitutions), 2 = dense image (and two in a row) -- template
+// parameters, so that an image's walk carries only its own state machine
+template <bool EMIT, int MODE>
 struct Walker {
     const BuildArgs& a;
     uint64_t k;          // next descriptor index (EMIT) / unused
     WinPos base;         // window position of the transcript's first result byte
     uint32_t cnt = 0;    // descriptors so far
-    Staged s0{0, 0, 0, 0}, s1{0, 0, 0, 0}, s2{0, 0, 0, 0}, s3{0, 0, 0, 0};          // (named slots: an indexed array lives in scratch memory)
+    Staged s0{0, 0, 0, 0}, s1{0, 0, 0, 0};                                          // (named slots: an indexed array lives in scratch memory)
+    uint32_t len2 = 0, byte2 = 0;                                                    // st_n >= 3: length of the copy after the first literal; st_n == 4: the second literal
+                                                                                     // (staged tasks are contiguous in the result: a gap flushes them, so their positions follow from s0.rel)
     int st_n = 0;
     uint64_t run_src = 0;                                                            // st_n >= 3: where the fused run of s0..s2 starts
     PairSink sink;
     __device__ Walker(const BuildArgs& a_, uint64_t k_, uint64_t base_) : a(a_), k(k_), base{base_ / a_.window, uint32_t(base_ % a_.window)} {}
-    __device__ void out(uint32_t space, uint64_t src, uint64_t len, uint64_t rel) { if (len) cnt += put<EMIT>(a, sink, k, win_pos(base, rel, a.window), len, space, src); }
-    __device__ void flush()
+    __device__ __forceinline__ void out(uint32_t space, uint64_t src, uint64_t len, uint64_t rel) { if (len) cnt += put<EMIT>(a, sink, k, win_pos(base, rel, a.window), len, space, src); }
+    __device__ __forceinline__ void flush()
     {
         const int n = st_n;
         st_n = 0;
-        if (n >= 3) {                                                            // a complete substitution that waited for a second one
-            fused(run_src, uint32_t(s0.len), uint32_t(s1.src), uint32_t(s2.len), s0.rel);
-            if (n == 4) out(s3.space, s3.src, s3.len, s3.rel);
+        if (MODE == 2 && n >= 3) {                                               // a complete substitution that waited for a second one
+            fused(run_src, uint32_t(s0.len), uint32_t(s1.src), len2, s0.rel);
+            if (n == 4) out(SPACE_IMM, byte2, 1, s0.rel + s0.len + 1u + len2);
             return;
         }
         if (n >= 1) out(s0.space, s0.src, s0.len, s0.rel);
         if (n == 2) out(s1.space, s1.src, s1.len, s1.rel);
     }
-    __device__ void fused(uint64_t src, uint32_t len1, uint32_t byte, uint32_t len2, uint64_t rel)
+    __device__ __forceinline__ void fused(uint64_t src, uint32_t len1, uint32_t byte, uint32_t len2, uint64_t rel)
     {
         const uint64_t total = uint64_t(len1) + 1u + len2;
         const WinPos at = win_pos(base, rel, a.window);
@@ -195,7 +199,7 @@ struct Walker {
         }
     }
     // two substitutions in a row (sir_pack.hpp's emit_fused2): five tasks, one descriptor when they lie inside one window
-    __device__ void fused2(uint64_t src, uint32_t len1, uint32_t b1, uint32_t len2, uint32_t b2, uint32_t len3, uint64_t rel)
+    __device__ __forceinline__ void fused2(uint64_t src, uint32_t len1, uint32_t b1, uint32_t len2, uint32_t b2, uint32_t len3, uint64_t rel)
     {
         const uint64_t total = uint64_t(len1) + 1u + len2 + 1u + len3;
         const WinPos at = win_pos(base, rel, a.window);
@@ -212,27 +216,27 @@ struct Walker {
             out(SPACE_PROTEOME, src + len1 + 1 + len2 + 1, len3, rel + len1 + 1 + len2 + 1);
         }
     }
-    __device__ void stage(uint32_t space, uint64_t src, uint64_t len, uint64_t rel)
+    __device__ __forceinline__ void stage(uint32_t space, uint64_t src, uint64_t len, uint64_t rel)
     {
-        if (!a.long_run && !a.dense) { out(space, src, len, rel); return; }
-        if (st_n == 4) {
-            const uint64_t want = run_src + s0.len + 1 + s2.len + 1;
+        if (MODE == 0) { out(space, src, len, rel); return; }
+        if (MODE == 2 && st_n == 4) {
+            const uint64_t want = run_src + s0.len + 1 + len2 + 1;
             if (space == SPACE_PROTEOME && len <= SNV5_MAX_LEN && (len == 0 || src == want) && want + len <= SNV3_MAX_SRC) {
                 st_n = 0;
-                fused2(run_src, uint32_t(s0.len), uint32_t(s1.src), uint32_t(s2.len), uint32_t(s3.src), uint32_t(len), s0.rel);
+                fused2(run_src, uint32_t(s0.len), uint32_t(s1.src), len2, byte2, uint32_t(len), s0.rel);
                 return;
             }
             flush();
         }
-        if (st_n == 3) {
-            if (space == SPACE_IMM && len == 1) { s3 = Staged{space, src, len, rel}; st_n = 4; return; }
+        if (MODE == 2 && st_n == 3) {
+            if (space == SPACE_IMM && len == 1) { byte2 = uint32_t(src); st_n = 4; return; }
             flush();
         }
         if (st_n == 2) {
             const bool fits = s0.len == 0 ? (len > 0 && src >= 1 && src - 1 + 1 + len <= SNV3_MAX_SRC) : (len == 0 || src == s0.src + s0.len + 1);
             if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && fits) {
                 const uint64_t run = s0.len == 0 ? src - 1 : s0.src;
-                if (a.dense && s0.len <= SNV5_MAX_LEN && len <= SNV5_MAX_LEN) { s2 = Staged{space, src, len, rel}; run_src = run; st_n = 3; return; }   // a dense image waits for a second one
+                if (MODE == 2 && s0.len <= SNV5_MAX_LEN && len <= SNV5_MAX_LEN) { len2 = uint32_t(len); run_src = run; st_n = 3; return; }   // a dense image waits for a second one
                 st_n = 0;
                 fused(run, uint32_t(s0.len), uint32_t(s1.src), uint32_t(len), s0.rel);
                 return;
@@ -248,7 +252,8 @@ struct Walker {
     }
 };
 
-template <bool EMIT, uint32_t SLAB>
+// (Walker's methods are force-inlined: out of line, the Walker and the BuildArgs lived in scratch memory -- C5's build 8.6 -> 30 ms)
+template <bool EMIT, uint32_t SLAB, int MODE>
 __global__ __launch_bounds__(256) void walk_kernel(BuildArgs a)
 {
     const uint64_t t = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256) void walk_kernel(BuildArgs a)
     const uint64_t alt0 = a.tx_alt_begin[t], n_alt = a.tx_alt_begin[t + 1] - alt0;
     const uint64_t poff = a.tx_proteome_off[t];
     const uint32_t ref_len = a.tx_ref_len[t], res_len = a.tx_res_len[t];
-    Walker<EMIT> w(a, EMIT ? a.desc_base[t] : 0, base);
+    Walker<EMIT, MODE> w(a, EMIT ? a.desc_base[t] : 0, base);
     uint64_t cur = 0;
     bool ok = true;
     if (!EMIT && poff + ref_len > a.proteome_len) { breport(a.status, i0, STATUS_SRC_OOB); ok = false; }   // transcript outside the resident proteome
@@ -318,6 +323,16 @@ __global__ __launch_bounds__(256) void walk_kernel(BuildArgs a)
     if (ok && cur < res_len) w.out(SPACE_FILL, 0, res_len - cur, cur);
     if (EMIT) w.sink.finish(a.desc, w.k);
     if (!EMIT) a.tx_desc_count[t] = ok ? w.cnt : 0u;
+}
+
+template <bool EMIT>
+static void launch_walk(const BuildArgs& a, bool deep, uint32_t tx_blocks, hipStream_t stream)
+{
+    const int mode = a.dense ? 2 : (a.long_run ? 1 : 0);
+#define V2P_WALK(SL, MD) hipLaunchKernelGGL((walk_kernel<EMIT, SL, MD>), dim3(tx_blocks), dim3(256), 0, stream, a)
+    if (deep) { if (mode == 2) V2P_WALK(16u, 2); else if (mode == 1) V2P_WALK(16u, 1); else V2P_WALK(16u, 0); }
+    else      { if (mode == 2) V2P_WALK(4u, 2); else if (mode == 1) V2P_WALK(4u, 1); else V2P_WALK(4u, 0); }
+#undef V2P_WALK
 }
 
 // ---- chunk table on the grid ----------------------------------------------------------------------------------------------
@@ -471,12 +486,10 @@ hipError_t launch_build(const BuildArgs& a, uint64_t n_windows, uint64_t n_desc,
     const uint32_t tx_blocks = uint32_t((a.n_tx + 255) / 256);
     if (phase == 0) {                       // count
         const bool deep = a.n_tx && a.n_tasks / a.n_tx > 6u;
-        if (a.n_tx) { if (deep) hipLaunchKernelGGL((walk_kernel<false, 16u>), dim3(tx_blocks), dim3(256), 0, stream, a);
-                      else hipLaunchKernelGGL((walk_kernel<false, 4u>), dim3(tx_blocks), dim3(256), 0, stream, a); }
+        if (a.n_tx) launch_walk<false>(a, deep, tx_blocks, stream);
     } else if (phase == 1) {                // emit + chunk table
         const bool deep = a.n_tx && a.n_tasks / a.n_tx > 6u;
-        if (a.n_tx) { if (deep) hipLaunchKernelGGL((walk_kernel<true, 16u>), dim3(tx_blocks), dim3(256), 0, stream, a);
-                      else hipLaunchKernelGGL((walk_kernel<true, 4u>), dim3(tx_blocks), dim3(256), 0, stream, a); }
+        if (a.n_tx) launch_walk<true>(a, deep, tx_blocks, stream);
         hipLaunchKernelGGL(hap_begin_kernel, dim3(uint32_t((a.n_haps + 1 + 255) / 256)), dim3(256), 0, stream, a, out_bytes);
         if (n_windows) hipLaunchKernelGGL(chunk_kernel, dim3(uint32_t((n_windows + 3) / 4)), dim3(256), 0, stream, a, n_windows, n_desc, out_bytes);
     }
