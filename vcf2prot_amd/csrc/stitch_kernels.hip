@@ -200,8 +200,51 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
     __shared__ uint64_t s_adj[K + 8];
     __shared__ uint32_t s_off[K + 8];
     __shared__ uint32_t s_w[3][4];
+    // The kernel is VALU-bound (SQ_INSTS_VALU x 4 cycles / 1024 SIMDs = its duration): byte masks and literal placement come out
+    // of two small LDS tables instead of 64-bit shift / select sequences (13 -> 6 and 17 -> 6 VALU instructions per use).
+    __shared__ u32x4 s_tail[17];                          // s_tail[j]: bytes >= j of a 16-byte block (j = 16: none)
+    __shared__ u32x4 s_sel[20];                           // s_sel[q + 4]: v_perm_b32 selectors that place a literal's bytes at block position q (-4..15)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    if (tid < 17u) {
+        u32x4 m;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) m[k] = tid <= 4u * k ? 0xFFFFFFFFu : (tid >= 4u * k + 4u ? 0u : 0xFFFFFFFFu << (8u * (tid - 4u * k)));
+        s_tail[tid] = m;
+    } else if (tid >= 32u && tid < 52u) {
+        const int32_t q = int32_t(tid) - 36;             // block position of the literal's first byte
+        u32x4 sel;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t w = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int32_t t = 4 * k + j - q;          // which literal byte lands on block byte 4k + j (the literal is 8 bytes {hi, lo}, bytes 5..7 zero)
+                w |= ((t >= 0 && t < 8) ? uint32_t(t) : 0x0Cu) << (8 * j);     // selector 0x0C: constant zero
+            }
+            sel[k] = w;
+        }
+        s_sel[tid - 32u] = sel;
+    }
+    // literal bytes (<= 5, first byte lowest) placed at byte position q of a block
+    auto place = [&](uint64_t lit, int32_t q) -> u32x4 {
+        const uint32_t qi = uint32_t(q + 4) < 19u ? uint32_t(q + 4) : 19u;      // (idle lanes may come with anything)
+        const u32x4 sel = s_sel[qi];
+        const uint32_t lo = uint32_t(lit), hi = uint32_t(lit >> 32);
+        return u32x4{__builtin_amdgcn_perm(hi, lo, sel[0]), __builtin_amdgcn_perm(hi, lo, sel[1]), __builtin_amdgcn_perm(hi, lo, sel[2]), __builtin_amdgcn_perm(hi, lo, sel[3])};
+    };
+    // bytes >= ja of the block come from ld (ja in 1..15) when `take`
+    auto tail = [&](u32x4 v, u32x4 ld, uint32_t ja, bool take) -> u32x4 {
+        const u32x4 m = s_tail[take ? (ja & 15u) : 16u];
+        v[0] = (v[0] & ~m[0]) | (ld[0] & m[0]); v[1] = (v[1] & ~m[1]) | (ld[1] & m[1]);
+        v[2] = (v[2] & ~m[2]) | (ld[2] & m[2]); v[3] = (v[3] & ~m[3]) | (ld[3] & m[3]);
+        return v;
+    };
+    // 16 bytes of a non-primary task for the block at `rel`: literal bytes placed at block position q, or a gather
+    auto fetch = [&](uint64_t adj, int32_t rel, int32_t q) -> u32x4 {
+        if (adj & ADJ_IMM) return place(adj & ADJ_LIT, q);
+        return DW ? gather16_dw(adj + int64_t(rel)) : gather16(adj + int64_t(rel));
+    };
     const uint16_t* const s_map = reinterpret_cast<const uint16_t*>(s_map32);
     const uint64_t dots16 = reinterpret_cast<uint64_t>(a.dots) + 32u;
 
@@ -330,17 +373,17 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                     if (DBG == 20) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); k1 = __builtin_amdgcn_s_memtime(); }
                     v = g1;
                     if (DBG != 1) {
-                        if (active) v = fetch_task<DW>(a0, rel, int32_t(o0) - rel);
-                        if (need1) g1 = fetch_task<DW>(a1, rel, int32_t(e0) - rel);
-                        if (need2) g2 = fetch_task<DW>(a2, rel, int32_t(e1) - rel);
+                        if (active) v = fetch(a0, rel, int32_t(o0) - rel);
+                        if (need1) g1 = fetch(a1, rel, int32_t(e0) - rel);
+                        if (need2) g2 = fetch(a2, rel, int32_t(e1) - rel);
                         if (DBG == 20) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k2 = __builtin_amdgcn_s_memtime(); }
                     } else {
                         v = u32x4{uint32_t(a0), e0, r, hi};
                         g1 = u32x4{uint32_t(a1), e1, r, hi};
                         g2 = u32x4{uint32_t(a2), e2, r, hi};
                     }
-                    v = overwrite_tail(v, g1, uint32_t(int32_t(e0) - rel), need1);
-                    v = overwrite_tail(v, g2, uint32_t(int32_t(e1) - rel), need2);
+                    v = tail(v, g1, uint32_t(int32_t(e0) - rel), need1);
+                    v = tail(v, g2, uint32_t(int32_t(e1) - rel), need2);
                 } else {
                     // tasks r+1 / r+2 that continue the primary stream (same source-minus-result offset) reuse its bytes
                     const bool same1 = need1 && !imm0 && a1 == a0;
@@ -362,8 +405,8 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                     if (DBG != 1) {
                         if (G != 0ull) v = load16_aligned(G);
                         if (own_n) n_own = load16_aligned(G + 16ull);
-                        if (need1 && !same1) g1 = fetch_task<DW>(a1, rel, int32_t(e0) - rel);
-                        if (need2 && !same2) g2 = fetch_task<DW>(a2, rel, int32_t(e1) - rel);
+                        if (need1 && !same1) g1 = fetch(a1, rel, int32_t(e0) - rel);
+                        if (need2 && !same2) g2 = fetch(a2, rel, int32_t(e1) - rel);
                         if (DBG == 20) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); k2 = __builtin_amdgcn_s_memtime(); }
                     } else {
                         v = u32x4{uint32_t(a0), e0, r, hi};
@@ -374,9 +417,9 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                     nx[0] = from_next_lane(0u, v[0]); nx[1] = from_next_lane(0u, v[1]);
                     nx[2] = from_next_lane(0u, v[2]); nx[3] = from_next_lane(0u, v[3]);
                     if (own_n) nx = n_own;
-                    const u32x4 p = imm0 ? imm_block(a0 & ADJ_LIT, int32_t(o0) - rel) : funnel16(v, nx, dlt);
-                    v = overwrite_tail(p, g1, uint32_t(int32_t(e0) - rel), need1 && !same1);
-                    v = overwrite_tail(v, same2 ? p : g2, uint32_t(int32_t(e1) - rel), need2);
+                    const u32x4 p = imm0 ? place(a0 & ADJ_LIT, int32_t(o0) - rel) : funnel16(v, nx, dlt);
+                    v = tail(p, g1, uint32_t(int32_t(e0) - rel), need1 && !same1);
+                    v = tail(v, same2 ? p : g2, uint32_t(int32_t(e1) - rel), need2);
                 }
                 if (DBG != 3 && active && e2 < hi) {           // four or more tasks cut this block: three more per round,
                     uint32_t pos = e2;                         // their gathers in flight together
@@ -385,13 +428,13 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                         const uint32_t o1 = s_off[r + 1u], o2 = s_off[r + 2u], o3 = s_off[r + 3u];
                         const uint64_t b0 = s_adj[r], b1 = s_adj[r + 1u], b2 = s_adj[r + 2u];
                         const bool n1 = o1 < hi, n2 = o2 < hi;
-                        const u32x4 h0 = fetch_task<DW>(b0, rel, int32_t(pos) - rel);
+                        const u32x4 h0 = fetch(b0, rel, int32_t(pos) - rel);
                         u32x4 h1 = {0u, 0u, 0u, 0u}, h2 = {0u, 0u, 0u, 0u};
-                        if (n1) h1 = fetch_task<DW>(b1, rel, int32_t(o1) - rel);
-                        if (n2) h2 = fetch_task<DW>(b2, rel, int32_t(o2) - rel);
-                        v = overwrite_tail(v, h0, uint32_t(int32_t(pos) - rel), true);
-                        v = overwrite_tail(v, h1, uint32_t(int32_t(o1) - rel), n1);
-                        v = overwrite_tail(v, h2, uint32_t(int32_t(o2) - rel), n2);
+                        if (n1) h1 = fetch(b1, rel, int32_t(o1) - rel);
+                        if (n2) h2 = fetch(b2, rel, int32_t(o2) - rel);
+                        v = tail(v, h0, uint32_t(int32_t(pos) - rel), true);
+                        v = tail(v, h1, uint32_t(int32_t(o1) - rel), n1);
+                        v = tail(v, h2, uint32_t(int32_t(o2) - rel), n2);
                         pos = o3;                              // >= hi unless all three tasks ended inside the block
                         r += 3u;
                     }
