@@ -228,8 +228,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
     }
     // literal bytes (<= 5, first byte lowest) placed at byte position q of a block
     auto place = [&](uint64_t lit, int32_t q) -> u32x4 {
-        const uint32_t qi = uint32_t(q + 4) < 19u ? uint32_t(q + 4) : 19u;      // (idle lanes may come with anything)
-        const u32x4 sel = s_sel[qi];
+        const u32x4 sel = s_sel[uint32_t(q + 4)];        // (callers are lanes with a block of the chunk: q is in -4..15)
         const uint32_t lo = uint32_t(lit), hi = uint32_t(lit >> 32);
         return u32x4{__builtin_amdgcn_perm(hi, lo, sel[0]), __builtin_amdgcn_perm(hi, lo, sel[1]), __builtin_amdgcn_perm(hi, lo, sel[2]), __builtin_amdgcn_perm(hi, lo, sel[3])};
     };
@@ -365,7 +364,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
                 const uint64_t a0 = s_adj[r], a1 = s_adj[r + 1u], a2 = s_adj[r + 2u];
                 // the sentinels make r+1, r+2 readable (dots) even when they are past the last task
                 const bool need1 = DBG != 3 && active && e0 < hi, need2 = DBG != 3 && active && e1 < hi;
-                const bool imm0 = DBG != 3 && (a0 & ADJ_IMM) != 0ull;
+                const bool imm0 = DBG != 3 && active && (a0 & ADJ_IMM) != 0ull;
                 u32x4 v;
                 if (VAR == 1) {
                     // legacy: one byte-granular gather per overlapping task; lanes that need no second/third task stay masked off
