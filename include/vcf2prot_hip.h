@@ -197,7 +197,14 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
 int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, uint64_t* hap_out_begin);
 
 /* Adopt an already packed image (descriptors, chunks, payload, haplotype result ranges),
- * e.g. from the synthetic cohort generator (include/v2p_cohort.h). */
+ * e.g. from the synthetic cohort generator (include/v2p_cohort.h).
+ * Image format (vcf2prot_amd/csrc/sir_pack.hpp): 8-byte descriptors in result order -- src:40 | len:22 |
+ * space:2 (0 resident proteome, 1 payload arena, 2 '.' fill, 3 immediate: the source field holds 1..5 literal bytes); space 3
+ * with bit 61 = a fused substitution (src:29 | len1:12 | len2:12 | byte:8: copy, one literal byte, copy one residue on;
+ * long-run and dense chunks only); space 3 with bits 61..60 = 01 = two substitutions in a row (src:29 | len1:5 | len2:5 | len3:5 |
+ * byte1:8 | byte2:8; dense chunks only).  Chunks: {first descriptor, result offset:48 | descriptors:11 | flags: bit 63 long-run
+ * (stitch4_kernel), bit 62 long-run with 257..512 tasks, bit 61 dense (stitch_dense_kernel)}.  A descriptor a chunk's kernel does
+ * not know is reported (source out of bounds) and the chunk is not executed. */
 int v2p_batch_set_packed(v2p_batch* b,
                          const uint64_t* desc, uint64_t n_desc,
                          const v2p_chunk* chunks, uint64_t n_chunks,
