@@ -248,6 +248,8 @@ struct Walker {
             flush();
         }
         if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && src + len + 1 + SNV3_MAX_LEN <= SNV3_MAX_SRC) { s0 = Staged{space, src, len, rel}; st_n = 1; return; }
+        // a dense image: a lone literal may open a fused run (the copy before it is empty: flush() writes nothing for it)
+        if (MODE == 2 && space == SPACE_IMM && len == 1) { s0 = Staged{SPACE_PROTEOME, 0, 0, rel}; s1 = Staged{space, src, len, rel}; st_n = 2; return; }
         out(space, src, len, rel);
     }
 };

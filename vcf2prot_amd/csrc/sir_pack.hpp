@@ -158,7 +158,7 @@ public:
         chunk_tasks = CHUNK_TASKS; adaptive_tasks = true; chunk_bytes = CHUNK_BYTES_LONG; adaptive_bytes = true; cut_align = CUT_ALIGN;
         max_chunk_tasks = max_long_tasks = 0; soft_window = 8; inline_payload = true; fuse_snv = true; fuse_double = true; kernel_choice = 0; grid_bytes = 0;
         cursor_ = extra_ = arena_cursor_ = open_begin_ = open_dst_ = 0;
-        open_n_ = open_bytes_ = open_desc_ = 0; open_fused_ = false; st_n_ = 0;
+        open_n_ = open_bytes_ = open_desc_ = 0; open_fused_ = false; st_n_ = 0; st0_virtual_ = false;
     }
     uint64_t out_size() const { return hap_out_begin.back(); }
     uint64_t n_haplotypes() const { return hap_out_begin.size() - 1; }
@@ -237,6 +237,7 @@ private:
     Staged st_[4];                   // tasks held back because the next one may complete a fused substitution (dense images: a second one)
     int st_n_ = 0;
     uint64_t run_src_ = 0;           // st_n_ >= 3: where the fused run of st_[0..2] starts in the proteome
+    bool st0_virtual_ = false;       // st_[0] is not a task: a literal opened the run (dense images), the copy before it is empty
 
     bool long_run_mode() const { return chunk_tasks <= CHUNK_TASKS; }
     // GRID cutting: pieces never cross a multiple of grid_bytes; a chunk closes exactly on the grid
@@ -256,9 +257,11 @@ private:
         if (n >= 3) {                // a complete substitution that waited for a second one
             emit_fused(run_src_, uint32_t(st_[0].len), uint8_t(st_[1].src), uint32_t(st_[2].len));
             if (n == 4) emit(st_[3].space, st_[3].src, st_[3].len);
+            st0_virtual_ = false;
             return;
         }
-        for (int i = 0; i < n; ++i) emit(st_[i].space, st_[i].src, st_[i].len);
+        for (int i = 0; i < n; ++i) if (!(i == 0 && st0_virtual_)) emit(st_[i].space, st_[i].src, st_[i].len);
+        st0_virtual_ = false;
     }
     // One task in canonical order.  [reference copy] [1-byte literal] [reference copy one residue further on] becomes one
     // descriptor when it fits the open chunk whole; everything else goes in as it is.
@@ -272,7 +275,7 @@ private:
         if (st_n_ == 4) {            // [copy][byte][copy][byte] + the copy going on one residue behind the third: two substitutions, one descriptor
             const uint64_t want = run_src_ + st_[0].len + 1 + st_[2].len + 1;
             if (space == SPACE_PROTEOME && len <= SNV5_MAX_LEN && (len == 0 || src == want) && want + len <= SNV3_MAX_SRC) {
-                st_n_ = 0;
+                st_n_ = 0; st0_virtual_ = false;
                 emit_fused2(run_src_, uint32_t(st_[0].len), uint8_t(st_[1].src), uint32_t(st_[2].len), uint8_t(st_[3].src), uint32_t(len));
                 return;
             }
@@ -293,7 +296,7 @@ private:
                     st_[2] = Staged{space, src, len}; run_src_ = run; st_n_ = 3;
                     return;
                 }
-                st_n_ = 0;
+                st_n_ = 0; st0_virtual_ = false;
                 emit_fused(run, uint32_t(a.len), uint8_t(b.src), uint32_t(len));
                 return;
             }
@@ -303,7 +306,13 @@ private:
             if (space == SPACE_IMM && len == 1) { st_[1] = Staged{space, src, len}; st_n_ = 2; return; }
             flush();
         }
-        if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && src + len + 1 + SNV3_MAX_LEN <= SNV3_MAX_SRC) { st_[0] = Staged{space, src, len}; st_n_ = 1; return; }
+        if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && src + len + 1 + SNV3_MAX_LEN <= SNV3_MAX_SRC) { st_[0] = Staged{space, src, len}; st_n_ = 1; st0_virtual_ = false; return; }
+        // a dense image: a lone literal may open a fused run -- [byte][copy] and [byte][copy][byte][copy] are the fused forms with an empty
+        // first copy (in a chain of substitutions every descriptor then carries two of them)
+        if (kernel_choice == 3 && fuse_double && space == SPACE_IMM && len == 1) {
+            st_[0] = Staged{SPACE_PROTEOME, 0, 0}; st_[1] = Staged{space, src, len}; st_n_ = 2; st0_virtual_ = true;
+            return;
+        }
         emit(space, src, len);
     }
     void emit_fused2(uint64_t src, uint32_t len1, uint8_t b1, uint32_t len2, uint8_t b2, uint32_t len3) {
