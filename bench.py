@@ -188,22 +188,38 @@ def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests, dense=
     t0 = time.perf_counter()
     stream = cohort.txstream(h0, h1, n_threads=n_threads)
     t_stream = time.perf_counter() - t0
-    window = 4096 if dense else (28672 if long_run else 32768)      # a dense image: <= 1024 descriptors per window
+    from vcf2prot_amd._native import V2PError
+    # a dense image: one window = the kernel's 12 KiB LDS image when its descriptors fit (<= 1024 per window), else smaller windows
+    windows = (12288, 8192, 4096) if dense else ((28672,) if long_run else (32768,))
     with Context(0) as ctx:
         ctx.upload_proteome(cohort.proteome())
-        b = ctx.batch()
-        t0 = time.perf_counter()
-        ms = b.build_on_device(stream, window, 3 if dense else (1 if long_run else 2))
-        t_call = time.perf_counter() - t0
+        for window in windows:
+            b = ctx.batch()
+            try:
+                t0 = time.perf_counter()
+                ms = b.build_on_device(stream, window, 3 if dense else (1 if long_run else 2))
+                t_call = time.perf_counter() - t0
+                break
+            except V2PError:
+                b.close()
+                if window == windows[-1]:
+                    raise
         cn = b.counts()
         same = None
+        exec_ms = None
         if want_digests is not None:
             b.execute()
             b.sync()
             same = bool(np.array_equal(b.digests(), want_digests))
+            t0 = time.perf_counter()
+            for _ in range(5):
+                b.execute()
+            b.sync()
+            exec_ms = (time.perf_counter() - t0) * 1e3 / 5
         b.close()
     res = {"build_kernels_ms": ms, "call_s_incl_h2d_of_the_stream": t_call, "stream_bytes": stream.nbytes, "stream_generation_s": t_stream,
            "window_bytes": window, "descriptors": cn["n_desc"], "chunks": cn["n_chunks"], "digests_equal_host_built_image": same,
+           "execute_ms_device_built_image": exec_ms,
            "what": "per-transcript GIRs (un-rebased Task SoA, transcript offsets, alt bytes) -> descriptors + chunk table + hap_out_begin in HBM"}
     stream.close()
     return res

@@ -187,7 +187,7 @@ typedef struct {
     const uint8_t*  alt;               /* [n_alt] alt tapes of the transcripts back to back, 1 byte per residue         */
 } v2p_txstream;
 /* kernel: 1 = route every chunk to the long-run kernel (<= 512 descriptors per window), 2 = per-block kernel, 3 = dense image
- * (stitch_dense_kernel: short tasks, fused substitutions, <= 1024 descriptors per window: windows of 4 or 8 KiB, larger ones are
+ * (stitch_dense_kernel: short tasks, fused substitutions, <= 1024 descriptors per window: windows of 4, 8 or 12 KiB, larger ones are
  * V2P_ERR_INVALID_ARG).
  * On success the batch is finalized (execute / sync / download / digests work as after v2p_batch_finalize).
  * *build_ms (optional): time of the build kernels alone (two HIP event brackets: counting passes, emitting passes; not the

@@ -24,7 +24,7 @@ def main():
         window = int(rng.choice([4096, 8192, 12288, 16384, 28672, 32768, 61440]))
         kernel = int(rng.integers(1, 4))
         if kernel == 3:
-            window = int(rng.choice([4096, 8192]))       # (a dense image's window is its 12 KiB LDS image at most)
+            window = int(rng.choice([4096, 8192, 12288]))       # (a dense image's window is its 12 KiB LDS image at most)
         proteome, stream, want = random_stream(rng, n_haps=int(rng.integers(1, 80)), n_ref_tx=int(rng.integers(1, 40)), shape=shape, window=window)
         ctx.upload_proteome(proteome)
         b = ctx.batch()
