@@ -93,7 +93,7 @@ def main():
         kv = dict(x.split("=") for x in spec.split(",") if x)
         pack = {k: int(kv[k]) for k in ("chunk_tasks", "chunk_bytes", "cut_align", "soft_window") if k in kv}
         if int(kv.get("grid", 0)):            # chunks cut on a fixed result grid (the device builder's rule)
-            img = cohort.pack_grid(0, cohort.n_haplotypes, int(kv["grid"]), 2 if int(kv.get("var", 0)) in (1, 2) else 1)
+            img = cohort.pack_grid(0, cohort.n_haplotypes, int(kv["grid"]), 2 if int(kv.get("var", 0)) in (1, 2) else int(kv.get("kernel", 1)))
         else:
           img = cohort.pack(0, cohort.n_haplotypes, n_threads=min(64, os.cpu_count() or 1), fasta=bool(int(kv.get("fasta", 0))), inline_payload=bool(int(kv.get("imm", 1))), fuse=bool(int(kv.get("fuse", 1))), double=bool(int(kv.get("double", 1))), kernel=(2 if int(kv.get("var", 0)) in (1, 2) else int(kv.get("kernel", 0))), **pack)
         chunks = np.ascontiguousarray(img.chunks)
@@ -144,7 +144,7 @@ def main():
         v_bits = int(lib.v2p_stitch_launch_bits(chunks.ctypes.data, chunks.shape[0]))
         v = dict(spec=spec, d_desc=torch.from_numpy(desc_arr.view(np.int64)).to(dev), d_chunks=torch.from_numpy(chunks.view(np.int64)).to(dev),
                  d_pay=d_pay, n_pay=img.payload.size, n_chunks=chunks.shape[0], out=img.out_bytes,
-                 flags=int(kv.get("nt", 1)) | v_bits | (int(kv.get("var", 0)) << 12) | (int(kv.get("dbg", 0)) << 16) | (int(kv.get("wgs", 0)) << 24), ms=[])
+                 flags=int(kv.get("nt", 1)) | v_bits | (int(kv.get("var", 0)) << 12) | (int(kv.get("dbg", 0)) << 16) | (int(kv.get("wgs", 0)) << 24) | (int(kv.get("wpg", 0)) << 28), ms=[])
         vs.append(v)
         max_out = max(max_out, img.out_bytes)
     d_out = torch.empty(max_out + 32, dtype=torch.uint8, device=dev)

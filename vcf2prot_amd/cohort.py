@@ -210,7 +210,7 @@ class Cohort:
         import os
         img = PackedImage()
         nt = n_threads or min(32, os.cpu_count() or 1)
-        rc = self._lib.v2p_cohort_pack(self._h, h0, h1, nt, chunk_tasks, chunk_bytes, (1 if fasta else 0) | (0 if inline_payload else 2) | (0 if fuse else 4) | (0 if double else 8) | (16 if kernel == 2 else (32 if kernel == 1 else (64 if kernel == 3 else 0))) | (cut_align << 8) | (soft_window << 24), ctypes.byref(img))
+        rc = self._lib.v2p_cohort_pack(self._h, h0, h1, nt, chunk_tasks, chunk_bytes, (1 if fasta else 0) | (0 if inline_payload else 2) | (0 if fuse else 4) | (0 if double else 8) | {2: 16, 1: 32, 3: 64, 4: 128}.get(kernel, 0) | (cut_align << 8) | (soft_window << 24), ctypes.byref(img))
         if rc != 0:
             raise RuntimeError(f"v2p_cohort_pack failed ({rc})")
         try:

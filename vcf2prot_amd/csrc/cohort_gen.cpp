@@ -451,6 +451,11 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
     if (uint64_t(n_threads) > n && n) n_threads = int(n);
     std::vector<v2p::ImageBuilder> parts(size_t(n_threads ? n_threads : 1));
     for (auto& im : parts) {
+        if (flags & V2P_PACK_WAVE) {            // (explicit limits below stay inside what one wave takes)
+            im.set_kernel(4);
+            if (chunk_tasks > v2p::CHUNK_TASKS_WAVE) chunk_tasks = v2p::CHUNK_TASKS_WAVE;
+            if (chunk_bytes > v2p::CHUNK_BYTES_WAVE) chunk_bytes = v2p::CHUNK_BYTES_WAVE;
+        }
         if (chunk_tasks) { im.chunk_tasks = chunk_tasks; im.adaptive_tasks = false; }
         if (chunk_bytes) { im.chunk_bytes = chunk_bytes; im.adaptive_bytes = false; }
         if (flags & V2P_PACK_NO_IMM) im.inline_payload = false;
@@ -463,7 +468,7 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
         if (flags >> 24) im.soft_window = flags >> 24;                     //                   bits 24..31 closing window
     }
     // one kernel per image (sir_pack.hpp): every thread's builder takes the decision the first haplotype's shape asks for
-    if (n && !(flags & (V2P_PACK_PER_BLOCK | V2P_PACK_LONG_RUN | V2P_PACK_DENSE)) && !chunk_tasks) {
+    if (n && !(flags & (V2P_PACK_PER_BLOCK | V2P_PACK_LONG_RUN | V2P_PACK_DENSE | V2P_PACK_WAVE)) && !chunk_tasks) {
         v2p_hapbuf b;
         generate_into(*c, h0, b, false, nullptr);
         uint64_t bytes = 0, tasks = 0;
@@ -472,6 +477,27 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
         for (auto& im : parts) im.kernel_choice = choice;
     }
     std::vector<int> status(parts.size(), 0);
+    // where every thread's part begins in the arena (its haplotypes' result sizes, FASTA text included): chunk cuts are aligned in
+    // the arena, so a part must know its absolute offset before it cuts anything
+    std::vector<uint64_t> origin(parts.size() + 1, 0);
+    {
+        auto size_work = [&](int w) {
+            const uint64_t a = h0 + n * uint64_t(w) / uint64_t(n_threads), e = h0 + n * uint64_t(w + 1) / uint64_t(n_threads);
+            v2p_hapbuf b;
+            uint64_t sum = 0;
+            for (uint64_t h = a; h < e; ++h) {
+                generate_into(*c, h, b, false, nullptr);
+                sum += (b.tx_res_end.empty() ? 0 : b.tx_res_end.back()) + (fasta ? uint64_t(HEADER_BYTES + 1) * b.tx_id.size() : 0);
+            }
+            origin[size_t(w) + 1] = sum;
+        };
+        std::vector<std::thread> ts;
+        for (int w = 1; w < n_threads; ++w) ts.emplace_back(size_work, w);
+        size_work(0);
+        for (auto& t : ts) t.join();
+        for (size_t w = 0; w < parts.size(); ++w) origin[w + 1] += origin[w];
+        for (size_t w = 0; w < parts.size(); ++w) parts[w].set_origin(origin[w]);
+    }
     auto work = [&](int w) {
         const uint64_t a = h0 + n * uint64_t(w) / uint64_t(n_threads), e = h0 + n * uint64_t(w + 1) / uint64_t(n_threads);
         v2p_hapbuf b;
@@ -487,6 +513,7 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
     work(0);
     for (auto& t : th) t.join();
     for (int s : status) if (s) return s;
+    for (size_t w = 0; w < parts.size(); ++w) if (parts[w].out_size() != origin[w + 1] - origin[w]) return -3;   // (the size pass and the packer disagree)
     uint64_t nd = 0, nc = 0, np = 0;
     for (auto& im : parts) { nd += im.desc.size(); nc += im.chunks.size(); np += im.payload.size(); }
     out->desc = static_cast<uint64_t*>(malloc((nd ? nd : 1) * 8));
@@ -517,10 +544,10 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
         for (size_t i = 0; i < im.chunks.size(); ++i) {
             ch[i].task_begin = im.chunks[i].task_begin + bd[size_t(w)];
             const uint64_t dn = im.chunks[i].dst_n;
-            ch[i].dst_n = (((dn & v2p::DST_MASK) + bo[size_t(w)]) & v2p::DST_MASK) | (dn & ~v2p::DST_MASK);
+            ch[i].dst_n = dn;                                      // (absolute already: ImageBuilder::set_origin)
         }
         if (!im.payload.empty()) memcpy(out->payload + bp[size_t(w)], im.payload.data(), im.payload.size());
-        for (size_t i = 0; i + 1 < im.hap_out_begin.size(); ++i) out->hap_out_begin[bh[size_t(w)] + i] = im.hap_out_begin[i] + bo[size_t(w)];
+        for (size_t i = 0; i + 1 < im.hap_out_begin.size(); ++i) out->hap_out_begin[bh[size_t(w)] + i] = im.hap_out_begin[i];
         im = v2p::ImageBuilder();      // release early
     };
     th.clear();
@@ -651,7 +678,7 @@ int v2p_cohort_pack_grid(const v2p_cohort* c, uint64_t h0, uint64_t h1, uint32_t
     int rc = v2p_cohort_txstream(c, h0, h1, 8, &s);
     if (rc) return rc;
     v2p::ImageBuilder im;
-    im.grid_bytes = window_bytes; im.kernel_choice = kernel == 1 ? 1 : (kernel == 3 ? 3 : 2); im.adaptive_tasks = false;
+    im.grid_bytes = window_bytes; im.kernel_choice = kernel == 1 ? 1 : (kernel == 3 ? 3 : (kernel == 4 ? 4 : 2)); im.adaptive_tasks = false;
     im.payload.assign(s.alt, s.alt + s.n_alt);                        // the alt tapes ARE the payload arena
     for (uint64_t h = 0; h < s.n_haps && rc == 0; ++h) {
         uint64_t res = 0;                                             // res_counter of haplotype_instruction.rs:90,132

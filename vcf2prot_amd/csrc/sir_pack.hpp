@@ -72,8 +72,11 @@ constexpr uint32_t LEN_MASK   = (1u << LEN_BITS) - 1;
 constexpr uint32_t CHUNK_TASKS = 256;          // tasks per work item for long-run images (one per lane)
 constexpr uint32_t CHUNK_TASKS_MID = 512;      // ... for images with 40..110 result bytes per task: 2 per lane, per-block kernel
 constexpr uint32_t CHUNK_TASKS_DEEP = 1024;    // ... for dense images (a few result bytes per task): 4 per lane
+constexpr uint32_t CHUNK_TASKS_WAVE = 64;      // DESCRIPTORS per work item of a wave image (stitchw_kernel: one wave per chunk, one descriptor per lane)
 constexpr uint32_t CHUNK_BYTES = 64u * 1024u - 16u;  // most result bytes a work item may hold (<= 4096 16-byte blocks incl. a ragged head)
 constexpr uint32_t CHUNK_BYTES_LONG = 32u * 1024u;   // ... of a long-run work item: 2048 blocks = eight 1 KiB rows per wave, all gathered before the first store
+constexpr uint32_t CHUNK_BYTES_WAVE = 8192;    // ... of a wave image, ragged head included: 512 blocks = eight 1 KiB rows of ONE wave
+constexpr uint32_t CUT_ALIGN_WAVE = 1024;      // preferred cut of a wave image: whole 1 KiB rows
 constexpr uint32_t CHUNK_BYTES_DENSE = 12272;  // ... of a dense image: the 12 KiB LDS image of stitch_dense_kernel takes the chunk in one window
 constexpr uint32_t DENSE_BELOW = 40;           // a chunk with fewer result bytes per task than this switches the builder to dense chunks
 constexpr uint32_t CUT_ALIGN  = 4096;          // preferred chunk cut: 4 KiB multiples = full 256-lane passes of 16-byte blocks
@@ -81,6 +84,7 @@ constexpr uint64_t DST_MASK   = (1ull << 48) - 1;
 constexpr uint64_t CHUNK_LONG = 1ull << 63;    // chunk header flag: long-run chunk
 constexpr uint64_t CHUNK_LONG2 = 1ull << 62;   // ... holding 257..512 tasks (two task records per lane)
 constexpr uint64_t CHUNK_DENSE = 1ull << 61;   // chunk header flag: chunk of a dense image (short tasks, fused descriptors allowed): stitch_dense_kernel
+constexpr uint64_t CHUNK_WAVE = 1ull << 60;    // chunk header flag: chunk of a wave image (<= 64 descriptors, <= 8 KiB, fused substitutions allowed): stitchw_kernel
 constexpr uint32_t CHUNK_N_MASK = 0x7FF;       // descriptor count: bits 48..58 of dst_n
 inline uint32_t chunk_n(uint64_t dst_n) { return uint32_t(dst_n >> 48) & CHUNK_N_MASK; }
 constexpr uint32_t LONG_RUN_BYTES_PER_TASK = 120;   // an image whose first chunk has at least this many result bytes per task goes to stitch4_kernel
@@ -140,7 +144,8 @@ public:
     uint32_t max_long_tasks = 0;      // most tasks of any long-run chunk (<= 256: one task record per lane in stitch4_kernel, else two)
     uint64_t n_long_chunks = 0;       // chunks routed to stitch4_kernel
     int kernel_choice = 0;            // 0: undecided (adaptive images decide at their first chunk); 1: every chunk of <= 512 tasks long-run; 2: per-block kernel only, no fusion;
-                                      // 3: dense image (stitch_dense_kernel, fusion on)
+                                      // 3: dense image (stitch_dense_kernel, fusion on); 4: wave image (stitchw_kernel, fusion on) -- set with set_kernel()
+    uint64_t n_wave_chunks = 0;       // chunks flagged for stitchw_kernel
     uint64_t n_dense_chunks = 0;      // chunks flagged for stitch_dense_kernel
     uint32_t soft_window = 8;         // tasks before the hard limit at which a chunk starts looking for its cut
     bool inline_payload = true;       // payload tasks of <= IMM_MAX_BYTES bytes become immediate descriptors
@@ -154,13 +159,22 @@ public:
     // Empty the image for another build; the vectors keep their capacity, the settings return to their defaults.
     void reset() {
         desc.clear(); chunks.clear(); payload.clear(); hap_out_begin.assign(1, 0);
-        n_copy_bytes = n_ref_tasks = n_fused = n_long_chunks = n_dense_chunks = 0;
+        n_copy_bytes = n_ref_tasks = n_fused = n_long_chunks = n_dense_chunks = n_wave_chunks = 0;
         chunk_tasks = CHUNK_TASKS; adaptive_tasks = true; chunk_bytes = CHUNK_BYTES_LONG; adaptive_bytes = true; cut_align = CUT_ALIGN;
         max_chunk_tasks = max_long_tasks = 0; soft_window = 8; inline_payload = true; fuse_snv = true; fuse_double = true; kernel_choice = 0; grid_bytes = 0;
         cursor_ = extra_ = arena_cursor_ = open_begin_ = open_dst_ = 0;
         open_n_ = open_bytes_ = open_desc_ = 0; open_fused_ = false; st_n_ = 0; st0_virtual_ = false;
     }
-    uint64_t out_size() const { return hap_out_begin.back(); }
+    // Fix the kernel of the whole image up front (before the first task): chunk limits follow it.
+    void set_kernel(int k) {
+        kernel_choice = k;
+        if (k == 4) { chunk_tasks = CHUNK_TASKS_WAVE; chunk_bytes = CHUNK_BYTES_WAVE; adaptive_tasks = false; adaptive_bytes = false; }
+    }
+    // Build a PART of a larger arena (threads packing haplotype ranges side by side): the part's first result byte sits at absolute
+    // arena offset `o`, so that chunk cuts are aligned in the arena the kernels write, not in the part.  Call before the first task;
+    // chunk offsets and hap_out_begin are then absolute.
+    void set_origin(uint64_t o) { arena_cursor_ = o; hap_out_begin.assign(1, o); }
+    uint64_t out_size() const { return hap_out_begin.back() - hap_out_begin.front(); }
     uint64_t n_haplotypes() const { return hap_out_begin.size() - 1; }
 
     // Reserve `n` payload bytes for the haplotype being added; returns their arena offset.
@@ -206,8 +220,9 @@ public:
     void emit(unsigned space, uint64_t src, uint64_t len) {
         if (grid_bytes) { emit_grid(space, src, len); return; }
         if (len == 0) { push(space, src, 0); return; }
+        const uint32_t most = kernel_choice == 4 ? chunk_bytes - 16u : chunk_bytes;      // (a piece must fit an empty chunk whatever its start)
         while (len) {
-            uint32_t piece = uint32_t(len < chunk_bytes ? len : chunk_bytes);
+            uint32_t piece = uint32_t(len < most ? len : most);
             push(space, src, piece);
             src = advance(space, src, piece);
             len -= piece;
@@ -229,10 +244,21 @@ private:
     uint32_t open_n_ = 0, open_bytes_ = 0;   // tasks / result bytes of the open chunk
     uint32_t open_desc_ = 0;                 // descriptors of the open chunk (<= open_n_)
     // what chunk_tasks limits: tasks, or -- in a dense image, whose kernel has one lane slot per DESCRIPTOR -- descriptors
-    uint32_t open_units() const { return kernel_choice == 3 ? open_desc_ : open_n_; }
+    uint32_t open_units() const { return kernel_choice == 3 || kernel_choice == 4 ? open_desc_ : open_n_; }
     // ... and a dense image cuts at any multiple of 16 (its chunks are a few KiB: a 4 KiB preference would cost a third of them)
-    uint32_t cut_pref() const { return kernel_choice == 3 && adaptive_bytes ? 16u : cut_align; }
+    // a wave image at whole 1 KiB rows (its chunks are at most eight of them)
+    uint32_t cut_pref() const { return kernel_choice == 3 && adaptive_bytes ? 16u : (kernel_choice == 4 && cut_align > CUT_ALIGN_WAVE ? CUT_ALIGN_WAVE : cut_align); }
     bool open_fused_ = false;                // it holds a fused descriptor
+    // most result bytes the open (or next) chunk may hold: a wave chunk is eight rows INCLUDING the ragged head of an unaligned start
+    uint32_t byte_limit() const { return kernel_choice == 4 ? chunk_bytes - uint32_t((open_n_ ? open_dst_ : arena_cursor_) & 15u) : chunk_bytes; }
+    // wave image: the LAST preferred boundary (whole 1 KiB rows) the open chunk can reach -- where it is cut unless it runs out of
+    // descriptor slots first
+    uint64_t wave_target() const {
+        const uint64_t base = open_n_ ? open_dst_ : arena_cursor_, end = base + byte_limit();
+        uint64_t t = end & ~uint64_t(cut_pref() - 1u);
+        if (t <= base) t = end & ~15ull;         // (explicit tiny limits, tests: no whole row fits)
+        return t <= base ? end : t;
+    }
     struct Staged { unsigned space; uint64_t src; uint64_t len; };
     Staged st_[4];                   // tasks held back because the next one may complete a fused substitution (dense images: a second one)
     int st_n_ = 0;
@@ -269,8 +295,8 @@ private:
         // fusion needs a long-run chunk: decided images only (the first chunk of an adaptive image goes in unfused)
         // (on a grid, fusion is a local rule: long-run routing chosen by the caller, the triple inside one window)
         // (a dense image fuses as well: its kernel takes the triple as one reference run with one byte patched)
-        const bool may_fuse = fuse_snv && (grid_bytes ? (kernel_choice == 1 || kernel_choice == 3)
-                                                      : (kernel_choice == 3 || (long_run_mode() && kernel_choice != 2 && !(adaptive_tasks && kernel_choice == 0))));
+        const bool may_fuse = fuse_snv && (grid_bytes ? (kernel_choice == 1 || kernel_choice == 3 || kernel_choice == 4)
+                                                      : (kernel_choice == 3 || kernel_choice == 4 || (long_run_mode() && kernel_choice != 2 && !(adaptive_tasks && kernel_choice == 0))));
         if (!may_fuse) { flush(); emit(space, src, len); return; }
         if (st_n_ == 4) {            // [copy][byte][copy][byte] + the copy going on one residue behind the third: two substitutions, one descriptor
             const uint64_t want = run_src_ + st_[0].len + 1 + st_[2].len + 1;
@@ -321,7 +347,7 @@ private:
         if (grid_bytes) whole = arena_cursor_ / grid_bytes == (arena_cursor_ + total - 1) / grid_bytes;
         else {
             const uint32_t soft_tasks = chunk_tasks > soft_window ? chunk_tasks - soft_window : chunk_tasks;
-            const uint32_t soft_bytes = chunk_bytes > cut_pref() ? chunk_bytes - cut_pref() : chunk_bytes;
+            const uint32_t soft_bytes = byte_limit() > cut_pref() ? byte_limit() - cut_pref() : byte_limit();
             whole = open_units() + 1u <= soft_tasks && open_bytes_ + total <= soft_bytes;
         }
         if (whole) {
@@ -354,8 +380,22 @@ private:
             return;
         }
         const uint32_t soft_tasks = chunk_tasks > soft_window ? chunk_tasks - soft_window : chunk_tasks;
-        const uint32_t soft_bytes = chunk_bytes > cut_pref() ? chunk_bytes - cut_pref() : chunk_bytes;
-        if (open_units() + (kernel_choice == 3 ? 1u : cnt) <= soft_tasks && open_bytes_ + total <= soft_bytes) {
+        if (kernel_choice == 4) {
+            if (open_n_ && arena_cursor_ == wave_target()) close_chunk();      // (the run opens the next chunk fused)
+            if (open_units() + 1u <= soft_tasks && arena_cursor_ + total <= wave_target()) {
+                if (open_n_ == 0) { open_begin_ = desc.size(); open_dst_ = arena_cursor_; }
+                desc.push_back(pack_snv3(src, len1, len2, byte));
+                ++open_desc_; open_n_ += cnt; open_bytes_ += total; arena_cursor_ += total;
+                ++n_fused; open_fused_ = true;
+                return;
+            }
+            emit(SPACE_PROTEOME, src, len1);
+            emit(SPACE_IMM, byte, 1);
+            emit(SPACE_PROTEOME, src + len1 + 1, len2);
+            return;
+        }
+        const uint32_t soft_bytes = byte_limit() > cut_pref() ? byte_limit() - cut_pref() : byte_limit();
+        if (open_units() + (kernel_choice == 3 || kernel_choice == 4 ? 1u : cnt) <= soft_tasks && open_bytes_ + total <= soft_bytes) {
             if (open_n_ == 0) { open_begin_ = desc.size(); open_dst_ = arena_cursor_; }
             desc.push_back(pack_snv3(src, len1, len2, byte));
             ++open_desc_; open_n_ += cnt; open_bytes_ += total; arena_cursor_ += total;
@@ -377,20 +417,21 @@ private:
         // (C5: 7).  An explicit chunk_tasks (adaptive_tasks off) keeps the choice per chunk: <= 256 tasks -> long-run.
         const uint32_t bpt = open_bytes_ / open_n_;
         if (grid_bytes) {                              // the caller chose the kernel (1: long-run, else per block); nothing adapts
-            const bool lg = kernel_choice == 1 && open_n_ <= 2u * CHUNK_TASKS, dn = kernel_choice == 3;
+            const bool lg = kernel_choice == 1 && open_n_ <= 2u * CHUNK_TASKS, dn = kernel_choice == 3, wv = kernel_choice == 4;
             chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_desc_) << 48) | (lg ? CHUNK_LONG : 0ull) | (lg && open_n_ > CHUNK_TASKS ? CHUNK_LONG2 : 0ull)
-                                                | (dn ? CHUNK_DENSE : 0ull)});
-            if (lg) { ++n_long_chunks; if (open_n_ > max_long_tasks) max_long_tasks = open_n_; } else if (dn) ++n_dense_chunks; else if (open_n_ > max_chunk_tasks) max_chunk_tasks = open_n_;
+                                                | (dn ? CHUNK_DENSE : 0ull) | (wv ? CHUNK_WAVE : 0ull)});
+            if (lg) { ++n_long_chunks; if (open_n_ > max_long_tasks) max_long_tasks = open_n_; } else if (dn) ++n_dense_chunks; else if (wv) ++n_wave_chunks; else if (open_n_ > max_chunk_tasks) max_chunk_tasks = open_n_;
             open_n_ = 0; open_bytes_ = 0; open_desc_ = 0; open_fused_ = false;
             return;
         }
         if (adaptive_tasks && kernel_choice == 0) kernel_choice = bpt >= LONG_RUN_BYTES_PER_TASK ? 1 : (bpt < DENSE_BELOW ? 3 : 2);
-        const bool to_dense = kernel_choice == 3;
-        const bool to_long = !to_dense && (open_fused_ || (open_n_ <= 2u * CHUNK_TASKS && (kernel_choice == 1 || (kernel_choice == 0 && long_run_mode()))));
+        const bool to_dense = kernel_choice == 3, to_wave = kernel_choice == 4;
+        const bool to_long = !to_dense && !to_wave && (open_fused_ || (open_n_ <= 2u * CHUNK_TASKS && (kernel_choice == 1 || (kernel_choice == 0 && long_run_mode()))));
         chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_desc_) << 48) | (to_long ? CHUNK_LONG : 0ull)
-                                            | (to_long && open_n_ > CHUNK_TASKS ? CHUNK_LONG2 : 0ull) | (to_dense ? CHUNK_DENSE : 0ull)});
+                                            | (to_long && open_n_ > CHUNK_TASKS ? CHUNK_LONG2 : 0ull) | (to_dense ? CHUNK_DENSE : 0ull) | (to_wave ? CHUNK_WAVE : 0ull)});
         if (to_long) { ++n_long_chunks; if (open_n_ > max_long_tasks) max_long_tasks = open_n_; }
         else if (to_dense) ++n_dense_chunks;
+        else if (to_wave) ++n_wave_chunks;
         else if (open_n_ > max_chunk_tasks) max_chunk_tasks = open_n_;
         if (adaptive_tasks) {
             chunk_tasks = kernel_choice == 1 ? CHUNK_TASKS : (kernel_choice == 3 ? CHUNK_TASKS_DEEP
@@ -413,8 +454,22 @@ private:
     // cut is still unaligned at the hard limit it is made anyway (the kernel handles ragged edges).
     void push(unsigned space, uint64_t src, uint32_t len) {
         const uint32_t soft_tasks = chunk_tasks > soft_window ? chunk_tasks - soft_window : chunk_tasks;
-        const uint32_t soft_bytes = chunk_bytes > cut_pref() ? chunk_bytes - cut_pref() : chunk_bytes;
         for (;;) {
+            const uint32_t chunk_bytes = byte_limit();                         // (shadows the member: the limit of the chunk this piece goes to)
+            if (kernel_choice == 4 && open_units() < soft_tasks) {
+                // a wave chunk with descriptor slots to spare runs up to the last whole-row boundary it can reach; the piece that
+                // straddles it is split there
+                const uint64_t target = wave_target();
+                if (open_n_ && arena_cursor_ == target) { close_chunk(); continue; }
+                if (arena_cursor_ + len <= target) { append(space, src, len); return; }
+                const uint32_t r = uint32_t(target - arena_cursor_);
+                append(space, src, r);
+                src = advance(space, src, r);
+                len -= r;
+                close_chunk();
+                continue;
+            }
+            const uint32_t soft_bytes = chunk_bytes > cut_pref() ? chunk_bytes - cut_pref() : chunk_bytes;
             const bool closing = open_units() >= soft_tasks || open_bytes_ + len > soft_bytes;
             if (!closing) { append(space, src, len); return; }
             if (open_units() == chunk_tasks) { close_chunk(); continue; }     // ragged cut (many tiny tasks)
@@ -440,20 +495,21 @@ private:
 };
 
 // Launch bits of v2p_stitch_launch / launch_stitch for a chunk table: which kernels have work and how many tasks per lane they
-// need (bit 1: chunks flagged for stitch_dense_kernel, bit 4: no long-run chunk, bit 5: no per-block chunk, bits 6..7: tasks per
+// need (bit 1: chunks flagged for stitch_dense_kernel, bit 2: chunks flagged for stitchw_kernel, bit 4: no long-run chunk, bit 5: no per-block chunk, bits 6..7: tasks per
 // lane of stitch4_kernel, bits 8..11: of stitch_kernel).
 inline int stitch_launch_bits(const Chunk* chunks, uint64_t n_chunks)
 {
     uint32_t max_pb = 0;
-    bool any_long = false, any_long2 = false, any_pb = false, any_dense = false;
+    bool any_long = false, any_long2 = false, any_pb = false, any_dense = false, any_wave = false;
     for (uint64_t i = 0; i < n_chunks; ++i) {
         const uint64_t dn = chunks[i].dst_n;
         if (dn & CHUNK_LONG) { any_long = true; any_long2 = any_long2 || (dn & CHUNK_LONG2) != 0; }
         else if (dn & CHUNK_DENSE) any_dense = true;
+        else if (dn & CHUNK_WAVE) any_wave = true;
         else { any_pb = true; const uint32_t n = chunk_n(dn); if (n > max_pb) max_pb = n; }
     }
     const int tpt = max_pb <= 256u ? 1 : (max_pb <= 512u ? 2 : 4);
-    return (any_dense ? 2 : 0) | (any_long ? 0 : 16) | (any_pb ? 0 : 32) | ((any_long2 ? 2 : 1) << 6) | (tpt << 8);
+    return (any_dense ? 2 : 0) | (any_wave ? 4 : 0) | (any_long ? 0 : 16) | (any_pb ? 0 : 32) | ((any_long2 ? 2 : 1) << 6) | (tpt << 8);
 }
 
 constexpr uint32_t XCD_SUB = 256;                  // windows per proteome slice in the launch order

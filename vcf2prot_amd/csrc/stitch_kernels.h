@@ -62,6 +62,7 @@ struct DigestArgs {
 };
 
 hipError_t launch_stitch(const StitchArgs& a, hipStream_t stream, int nontemporal, uint32_t max_blocks);
+hipError_t launch_stitch_wave(const StitchArgs& a, hipStream_t stream, bool nt, int waves_per_group);   // stitch_wave.hip; `a.dots` set by the caller
 hipError_t launch_ordered(const OrderedArgs& a, hipStream_t stream);
 hipError_t launch_validate(const ValidateArgs& a, hipStream_t stream);
 hipError_t launch_digest(const DigestArgs& a, uint64_t out_bytes, hipStream_t stream);

@@ -27,102 +27,9 @@
 #include <stdint.h>
 #include <mutex>
 #include "stitch_kernels.h"
+#include "stitch_device.hpp"
 
 namespace v2p {
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-struct __attribute__((packed, aligned(1))) unaligned16 { u32x4 v; };
-
-// 16 bytes from an arbitrary (unaligned) global address held as an integer.  The explicit global
-// address space matters: a pointer rebuilt from an integer would otherwise be a FLAT access
-// (counts on vmcnt AND lgkmcnt, returns out of order).
-__device__ __forceinline__ u32x4 gather16(uint64_t addr)
-{
-    typedef const __attribute__((address_space(1))) unaligned16* gptr;
-    return reinterpret_cast<gptr>(addr)->v;
-}
-
-// Same 16 bytes through dword-aligned loads (x4 + x1) and four v_alignbyte.
-struct __attribute__((packed, aligned(4))) dwaligned16 { u32x4 v; };
-__device__ __forceinline__ u32x4 gather16_dw(uint64_t addr)
-{
-    typedef const __attribute__((address_space(1))) dwaligned16* gptr;
-    typedef const __attribute__((address_space(1))) uint32_t* dptr;
-    const uint64_t base = addr & ~3ull;
-    const uint32_t sh = uint32_t(addr) & 3u;
-    const u32x4 v = reinterpret_cast<gptr>(base)->v;
-    const uint32_t e = *reinterpret_cast<dptr>(base + 16u);
-    u32x4 o;
-    o.x = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
-    o.y = __builtin_amdgcn_alignbyte(v.z, v.y, sh);
-    o.z = __builtin_amdgcn_alignbyte(v.w, v.z, sh);
-    o.w = __builtin_amdgcn_alignbyte(e, v.w, sh);
-    return o;
-}
-
-// 16 bytes from a 16-byte aligned global address: a wave whose lanes read consecutive blocks touches every
-// 128-byte line exactly once (the byte-granular gather16 touches every line from two neighbouring lane quads).
-__device__ __forceinline__ u32x4 load16_aligned(uint64_t addr)
-{
-    typedef const __attribute__((address_space(1))) u32x4* gptr;
-    return *reinterpret_cast<gptr>(addr);
-}
-
-// DPP wave_shl:1 -- lane i receives lane i+1's value (lane 63 keeps `old`).
-__device__ __forceinline__ uint32_t from_next_lane(uint32_t old, uint32_t x)
-{
-    return uint32_t(__builtin_amdgcn_update_dpp(int(old), int(x), 0x130, 0xf, 0xf, false));
-}
-
-// bytes d .. d+15 of the 32 bytes {v, n}, d in 0..15 (two select stages pick the dwords, v_alignbyte the bytes)
-__device__ __forceinline__ u32x4 funnel16(u32x4 v, u32x4 n, uint32_t d)
-{
-    const bool s8 = (d & 8u) != 0u, s4 = (d & 4u) != 0u;
-    const uint32_t t0 = s8 ? v[2] : v[0], t1 = s8 ? v[3] : v[1], t2 = s8 ? n[0] : v[2],
-                   t3 = s8 ? n[1] : v[3], t4 = s8 ? n[2] : n[0], t5 = s8 ? n[3] : n[1];
-    const uint32_t u0 = s4 ? t1 : t0, u1 = s4 ? t2 : t1, u2 = s4 ? t3 : t2, u3 = s4 ? t4 : t3, u4 = s4 ? t5 : t4;
-    const uint32_t r = d & 3u;
-    u32x4 o;
-    o.x = __builtin_amdgcn_alignbyte(u1, u0, r);
-    o.y = __builtin_amdgcn_alignbyte(u2, u1, r);
-    o.z = __builtin_amdgcn_alignbyte(u3, u2, r);
-    o.w = __builtin_amdgcn_alignbyte(u4, u3, r);
-    return o;
-}
-
-// An immediate descriptor's literal bytes (<= 5, first byte lowest) placed at byte position q of a
-// 16-byte block, q in -4..15 (negative: the task began in the previous block).
-__device__ __forceinline__ u32x4 imm_block(uint64_t lit, int32_t q)
-{
-    const uint32_t sh = 8u * (uint32_t(q) & 7u);
-    const uint64_t x = lit << sh;
-    const uint64_t y = sh ? lit >> (64u - sh) : 0ull;
-    uint64_t lo, hi;
-    if (q < 0) { lo = lit >> (8u * uint32_t(-q)); hi = 0ull; }
-    else if (q < 8) { lo = x; hi = y; }
-    else { lo = 0ull; hi = x; }
-    return u32x4{uint32_t(lo), uint32_t(lo >> 32), uint32_t(hi), uint32_t(hi >> 32)};
-}
-
-constexpr uint64_t ADJ_IMM = 1ull << 63;       // s_adj entry of an immediate task: flag | literal bytes
-constexpr uint64_t ADJ_LIT = (1ull << 40) - 1;
-
-// ---- wave64 inclusive add-scan with DPP (row_shr 1/2/4/8, row_bcast 15/31) ----
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
-{
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, false);  // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, false);  // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xf, 0xf, false);  // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, false);  // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
-    x += __builtin_amdgcn_update_dpp(0u, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
-    return x;
-}
-
-__device__ __forceinline__ void report(unsigned long long* status, uint64_t index, uint32_t reason)
-{
-    atomicMin(status, (unsigned long long)((index << 8) | reason));
-}
 
 // Per chunk (one workgroup, 256 lanes, TPT consecutive descriptors per lane):
 //   A  decode + bounds-check the descriptors; wave64 DPP scan of the lengths; ballot/mbcnt
@@ -159,15 +66,6 @@ __device__ __forceinline__ u32x4 overwrite_tail(u32x4 v, u32x4 ld, uint32_t ja, 
     v[2] = (v[2] & ~k2) | (ld[2] & k2);
     v[3] = (v[3] & ~k3) | (ld[3] & k3);
     return v;
-}
-
-// Workgroup barrier that orders LDS only.  __syncthreads() also waits for vmcnt(0), i.e. for
-// every result store the wave has in flight; nothing in this kernel re-reads its own stores.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
 }
 
 // 16 bytes of a non-primary task for the block at `rel`: literal bytes placed at block position q, or a gather
@@ -254,7 +152,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(const uint64_t* __restrict_
         const uint64_t tb = a.chunks[c].task_begin;
         const uint64_t dn = a.chunks[c].dst_n;
         const uint32_t n_hdr = uint32_t(dn >> 48) & CHUNK_N_MASK;
-        if (filter == 2u && (dn & (CHUNK_LONG | CHUNK_DENSE))) continue;   // long-run chunks belong to stitch4_kernel, dense ones to stitch_dense_kernel
+        if (filter == 2u && (dn & (CHUNK_LONG | CHUNK_DENSE | CHUNK_WAVE))) continue;   // long-run chunks belong to stitch4_kernel, dense ones to stitch_dense_kernel, wave chunks to stitchw_kernel
         const uint64_t dst = dn & ((1ull << 48) - 1);
         const uint32_t head = uint32_t(dst & 15ull);
         // a chunk table that points outside the descriptor array is refused, not followed
@@ -539,7 +437,7 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
     }
     const uint64_t tb = a.chunks[c].task_begin;
     const uint64_t dn = a.chunks[c].dst_n;
-    if (dn & CHUNK_LONG) return;                           // long-run chunks belong to stitch4_kernel
+    if (dn & (CHUNK_LONG | CHUNK_WAVE)) return;            // long-run chunks belong to stitch4_kernel, wave chunks to stitchw_kernel
     if (filter == 3u && !(dn & CHUNK_DENSE)) return;       // (the other chunks of this image go to the per-block kernel)
     const bool fused = (dn & CHUNK_DENSE) != 0ull;         // the chunk may hold fused substitution descriptors
     const uint32_t n_hdr = uint32_t(dn >> 48) & CHUNK_N_MASK;
@@ -1634,6 +1532,13 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
         else hipLaunchKernelGGL((stitch_dense_kernel<NTT, DWW, DD, false>), dim3(a.n_chunks), dim3(256), 0, stream, V2P_KARGS, uint32_t(FF)); } while (0)
 #define V2P_LD(NTT, FF) do { if (var == 9) V2P_LDD(NTT, true, 0, FF); else if (dbg == 1) V2P_LDD(NTT, false, 1, FF); else if (dbg == 2) V2P_LDD(NTT, false, 2, FF); \
         else if (dbg == 3) V2P_LDD(NTT, false, 3, FF); else V2P_LDD(NTT, false, 0, FF); } while (0)
+    // chunks flagged for stitchw_kernel (bit 2): one wave per chunk; bits 28..29: waves per workgroup (0 = 1, 1 = 2, 2 = 4; A/B runs)
+    if ((nontemporal & 4) && !max_blocks) {
+        const int wsel = (nontemporal >> 28) & 3;
+        err = launch_stitch_wave(a, stream, nt != 0, wsel == 2 ? 4 : (wsel == 1 ? 2 : 1));
+        if (err != hipSuccess) return err;
+        if ((nontemporal & 48) == 48 && !(nontemporal & 2)) return hipSuccess;      // a pure wave image: no other kernel has work
+    }
     if (per_block_only) {
         switch (tpt) { case 1: V2P_LAUNCH(1, 0); break; case 2: V2P_LAUNCH(2, 0); break; default: V2P_LAUNCH(4, 0); break; }
     } else {
