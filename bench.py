@@ -56,6 +56,8 @@ def parse_args():
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--fasta", action="store_true", help="FASTA-emitting image: headers and line feeds fused into the scatter (SURVEY 8f rank 1)")
     ap.add_argument("--var", type=int, default=0, help="K2 variant (0 = default, 1 = legacy byte-granular gathers)")
+    ap.add_argument("--kernel", type=int, default=0, help="image routing: 0 = the packer's choice, 1 = long-run (stitch4_kernel), 2 = per block, 3 = dense, 4 = wave (stitchw_kernel)")
+    ap.add_argument("--wpg", type=int, default=0, help="stitchw_kernel: waves per workgroup selector (0 = 1, 1 = 2, 2 = 4)")
     ap.add_argument("--no-fuse", action="store_true", help="one descriptor per task (no fused substitutions)")
     ap.add_argument("--cut-align", type=int, default=0)
     ap.add_argument("--chunk-tasks", type=int, default=0)
@@ -281,7 +283,7 @@ def main():
         h0, h1 = shard_by_bytes(sizes.tolist(), world)[rank]              # equal result bytes per rank
     t_gen = time.perf_counter()
     img = cohort.pack(h0, h1, n_threads=min(n_threads, 64), chunk_tasks=args.chunk_tasks, chunk_bytes=args.chunk_bytes, fasta=args.fasta, cut_align=args.cut_align,
-                      fuse=not args.no_fuse and args.var not in (1, 2, 3), kernel=2 if args.var in (1, 2, 3) else 0)
+                      fuse=not args.no_fuse and args.var not in (1, 2, 3), kernel=2 if args.var in (1, 2, 3) else args.kernel)
     t_gen = time.perf_counter() - t_gen
     A, NT = img.n_copy_bytes, img.n_tasks
     b_alg = 2 * A + 16 * NT
@@ -327,7 +329,7 @@ def main():
     stream = None if args.dry_run else torch.cuda.current_stream()
     sizes_t = torch.tensor([n_haps, out_bytes], dtype=torch.int64, device=dev)
     all_sizes = torch.zeros(2 * world, dtype=torch.int64, device=dev)
-    flags = (0 if args.temporal else 1) | img.launch_bits | (args.var << 12) | (args.dbg << 16)
+    flags = (0 if args.temporal else 1) | img.launch_bits | (args.var << 12) | (args.dbg << 16) | (args.wpg << 28)
 
     def launch():
         if args.dry_run:
@@ -433,7 +435,7 @@ def main():
                                   "outside descriptors + the proteome once (reference reads are served by L2 and not counted)",
                          "hbm_bytes_min_per_launch": hbm_min,
                          "algorithmic_bytes_per_launch": b_alg, "algorithmic_GBps": b_alg / (avg_ms * 1e-3) / 1e9,
-                         "kernel": "stitch4_kernel (long-run image)" if not (img.launch_bits & 16) else ("stitch_dense_kernel (short tasks)" if ((img.launch_bits & 2) or ((img.launch_bits >> 8) & 15) > 2) and args.var in (0, 8, 9) else "stitch_kernel (per-block)"), "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms)},
+                         "kernel": "stitchw_kernel (wave image: one wave per chunk)" if (img.launch_bits & 4) else "stitch4_kernel (long-run image)" if not (img.launch_bits & 16) else ("stitch_dense_kernel (short tasks)" if ((img.launch_bits & 2) or ((img.launch_bits >> 8) & 15) > 2) and args.var in (0, 8, 9) else "stitch_kernel (per-block)"), "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms)},
             "kernel_only_aa_per_s_rank0": A / (avg_ms * 1e-3),
             "verified": verified, "image_build_s": t_gen,
         }

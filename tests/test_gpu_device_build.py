@@ -67,3 +67,49 @@ def test_device_build_reports_what_the_reference_would_panic_on(built, gpu_ctx):
     with pytest.raises(V2PError):
         b2.build_on_device(st2, 32768, 2)
     b2.close()
+
+
+def test_device_build_refuses_broken_offset_tables(built, gpu_ctx):
+    """The kernels index device memory through every entry of hap_tx_begin / tx_task_begin / tx_alt_begin: a table that is not
+    ascending from 0 or leaves its array is refused on the host, with the offending index, and the batch stays usable."""
+    from vcf2prot_amd._native import V2PError
+    from vcf2prot_amd.cohort import Cohort
+    c = Cohort.preset("C3")
+    gpu_ctx.upload_proteome(c.proteome())
+    stream = c.txstream(0, 3, n_threads=1)
+    s = stream.struct
+    n_tx = int(s.n_tx)
+    b = gpu_ctx.batch()
+    for name, idx, value in [("tx_task_begin", 7, int(s.n_tasks) + 5), ("tx_task_begin", 9, 0), ("tx_alt_begin", 11, int(s.n_alt) + 1),
+                             ("tx_alt_begin", 12, 0), ("hap_tx_begin", 1, n_tx + 3), ("hap_tx_begin", 2, 0), ("tx_proteome_off", 5, (1 << 64) - 1)]:
+        arr = getattr(s, name)
+        old = arr[idx]
+        arr[idx] = value
+        with pytest.raises(V2PError) as e:
+            b.build_on_device(stream, 16384, 2)
+        assert e.value.code == -1, name                                    # V2P_ERR_INVALID_ARG, nothing was launched
+        arr[idx] = old
+    ms = b.build_on_device(stream, 16384, 2)                              # the same batch builds once the stream is whole again
+    assert ms > 0 and b.counts()["n_haps"] == 3
+    b.close()
+    stream.close()
+
+
+def test_device_build_can_be_retried_with_a_smaller_window(built, gpu_ctx):
+    """A window with too many descriptors is refused (V2P_ERR_UNSUPPORTED); the header says "pick a smaller window", and the same
+    batch then takes one."""
+    from vcf2prot_amd._native import V2PError
+    from vcf2prot_amd.cohort import Cohort
+    dense = Cohort.preset("C5")
+    gpu_ctx.upload_proteome(dense.proteome())
+    st = dense.txstream(0, 20, n_threads=1)
+    b = gpu_ctx.batch()
+    with pytest.raises(V2PError):
+        b.build_on_device(st, 32768, 2)
+    assert b.counts()["n_haps"] == 0
+    b.build_on_device(st, 4096, 3)
+    assert b.counts()["n_haps"] == 20
+    b.execute()
+    b.sync()
+    b.close()
+    st.close()

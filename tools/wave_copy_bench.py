@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Ceilings of stitchw_kernel's data movement (vcf2prot_amd/csrc/bench/wave_copy_bench.hip): TB/s written per source pattern,
+extra gathers, descriptor stream, workgroup shape.
+
+    python tools/wave_copy_bench.py [--gb 8] [--rounds 5]
+"""
+import argparse
+import ctypes
+import json
+import os
+import statistics
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SRC = os.path.join(ROOT, "vcf2prot_amd", "csrc", "bench", "wave_copy_bench.hip")
+LIB = os.path.join(ROOT, "build_ab", "libv2p_wavebench.so")
+
+
+def build():
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", SRC, "-o", LIB])
+    return LIB
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gb", type=float, default=8.0)
+    ap.add_argument("--window-mb", type=float, default=8.0)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--json", default="")
+    ap.add_argument("--build-only", action="store_true")
+    a = ap.parse_args()
+    path = build()
+    if a.build_only:
+        return
+    import torch                                   # (first: the library then binds to the HIP runtime torch has loaded)
+    lib = ctypes.CDLL(path)
+    lib.v2p_bench_wave_copy.restype = ctypes.c_int
+    lib.v2p_bench_wave_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                        ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int,
+                                        ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    dev = torch.device("cuda", 0)
+    nbytes = int(a.gb * (1 << 30)) // 8192 * 8192
+    window = int(a.window_mb * (1 << 20))
+    src = torch.randint(0, 255, (window + (1 << 17),), dtype=torch.uint8, device=dev)
+    out = torch.zeros(nbytes + 4096, dtype=torch.uint8, device=dev)
+    dsc = torch.zeros(nbytes // 8192 * 64 + 64, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream()
+    rows = []
+    # (wpg, pattern, label, shift, extra gathers, descriptor lanes, descriptor table wrap, store policy, prefetch distance)
+    C2, C3, ONE = 0, 1, 2
+    S = 1 << 31
+    cases = [(1, C2, "contiguous (C2)", 5, 0, 0, 0, 2, 0), (1, C2, "C2, sc1 nt stores", 5, 0, 0, 0, 18, 0),
+             (1, C2, "C2 + 192 B desc", 5, 0, 24, 0, 2, 0), (1, C2, "C2 + 192 B desc, sc1 nt stores", 5, 0, 24, 0, 18, 0),
+             (1, C2, "C2 + 512 B desc", 5, 0, 64, 0, 2, 0),
+             (1, C2, "C2 + 512 B desc, prefetch 2048", 5, 0, 64, 0, 2, 2048), (1, C2, "C2 + 512 B desc, prefetch 16384", 5, 0, 64, 0, 2, 16384),
+             (1, C2, "C2 + 512 B desc, prefetch 65536", 5, 0, 64, 0, 2, 65536),
+             (1, C2, "C2 + 512 B desc, scalar prefetch 2048", 5, 0, 64, 0, 2, S | 2048), (1, C2, "C2 + 512 B desc, scalar prefetch 16384", 5, 0, 64, 0, 2, S | 16384),
+             (1, C2, "C2 + 512 B desc, scalar prefetch 65536", 5, 0, 64, 0, 2, S | 65536),
+             (1, C2, "C2 + 512 B desc, table of 4096 chunks (cached)", 5, 0, 64, 4096, 2, 0),
+             (1, C2, "C2 + 512 B desc, table of 65536 chunks (32 MB)", 5, 0, 64, 65536, 2, 0),
+             (1, C2, "C2 + 384 B desc", 5, 0, 48, 0, 2, 0), (1, C2, "C2 + 320 B desc", 5, 0, 40, 0, 2, 0),
+             (1, C3, "C3 + 448 B desc", 5, 0, 56, 0, 2, 0), (1, C3, "C3 + 448 B desc, prefetch 16384", 5, 0, 56, 0, 2, 16384),
+             (1, C3, "C3 + 448 B desc, scalar prefetch 16384", 5, 0, 56, 0, 2, S | 16384),
+             (1, C3, "C3 + 448 B desc, scalar prefetch 16384, sc1 nt stores", 5, 0, 56, 0, 18, S | 16384),
+             (1, C3, "C3 + 256 B desc", 5, 0, 32, 0, 2, 0), (1, C3, "C3 + 320 B desc", 5, 0, 40, 0, 2, 0)]
+    for wpg, pattern, label, shift, n_p, dl, dmod, aux, pf in cases:
+        ms = []
+        for r in range(a.rounds + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = lib.v2p_bench_wave_copy(ctypes.c_void_p(st.cuda_stream), src.data_ptr(), window, out.data_ptr(), nbytes, dsc.data_ptr() if dl else None,
+                                         pattern, shift, n_p, 26, 0, wpg, dl, dmod, aux, pf)
+            assert rc == 0, rc
+            e1.record(st)
+            torch.cuda.synchronize()
+            if r:
+                ms.append(e0.elapsed_time(e1))
+        med = statistics.median(ms)
+        rows.append({"wpg": wpg, "what": label, "extra_gathers": n_p, "descriptor_bytes": dl * 8, "descriptor_table_chunks": dmod, "store_aux": aux, "prefetch": pf, "ms": med, "TBps_written": nbytes / med / 1e9})
+        print(f"{label:58s}: {med:7.3f} ms  {nbytes / med / 1e9:6.2f} TB/s")
+    if a.json:
+        json.dump({"bytes": nbytes, "window": window, "cases": rows}, open(a.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

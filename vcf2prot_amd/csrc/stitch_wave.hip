@@ -50,14 +50,35 @@ __device__ __forceinline__ u32x4 put_byte(u32x4 v, uint32_t q, uint32_t byte)
     return v;
 }
 
-// 16 bytes of record `t` for the block at position b16 (bytes before the record's start / after its end are whatever lies there)
-__device__ __forceinline__ u32x4 wrec_fetch(const WRec& t, uint32_t b16)
+// Development builds only (tools/build_variant.sh -DV2P_WAVE_CHECK): every gather is checked against the readable range of the
+// three source buffers; an address outside them is reported (reason 100 + site) and not followed.  The product build has no such code.
+struct WChk {
+#ifdef V2P_WAVE_CHECK
+    uint64_t lo[3], hi[3];
+    unsigned long long* status;
+    uint64_t tb;
+#endif
+};
+// (V2P_WAVE_ABLATE, development builds only, results are wrong: bit 0 the copy phase gathers the dots, bit 1 the patch phase does,
+// bit 2 no result store)
+#ifndef V2P_WAVE_ABLATE
+#define V2P_WAVE_ABLATE 0
+#endif
+__device__ __forceinline__ u32x4 wgather(uint64_t addr, const WChk& k, uint32_t site)
 {
-    if (t.lit & WREC_IMM) return imm_block(wrec_adj(t), int32_t((t.se & 0xFFFFu) - b16));
-    u32x4 v = gather16(wrec_adj(t) + b16);
-    const uint32_t q = (t.lit & 0xFFFFu) - b16;
-    if (q < 16u) v = put_byte(v, q, (t.lit >> 16) & 0xFFu);
-    return v;
+#ifdef V2P_WAVE_CHECK
+    bool ok = false;
+    for (int q = 0; q < 3; ++q) ok = ok || (addr >= k.lo[q] && addr + 16u <= k.hi[q]);
+    if (!ok) { report(k.status, (k.tb << 8) | (threadIdx.x & 63u), 100u + site); return u32x4{0u, 0u, 0u, 0u}; }
+#endif
+    (void)k; (void)site;
+    return gather16(addr);
+}
+
+// byte q of v replaced by the residue of `lit` when it lies in the block at b16 (no-op otherwise: q >= 16 matches no dword)
+__device__ __forceinline__ u32x4 wrec_lit(u32x4 v, uint32_t lit, uint32_t b16)
+{
+    return put_byte(v, (lit & 0xFFFFu) - b16, (lit >> 16) & 0xFFu);
 }
 
 __device__ __forceinline__ u32x4 wmerge(u32x4 v, u32x4 ld, u32x4 m)      // bytes of ld where m is set
@@ -69,57 +90,42 @@ __device__ __forceinline__ u32x4 wmerge(u32x4 v, u32x4 ld, u32x4 m)      // byte
     return v;
 }
 
-// The block at position b16 whose first byte lies in record r: that record's stream, overwritten from their start on by every
-// record that begins before the block (or the chunk) ends.  In two halves, so that a lane's gathers are in flight together and
-// under other work: `issue` starts the fetches of the first three sources, `finish` merges them (a fourth and later source: a loop).
-struct WFetch { u32x4 v, g1, g2; uint32_t ja1, ja2, next; };   // ja: where source 1 / 2 starts inside the block (16: unused); next: rank to go on with (0: done)
-__device__ __forceinline__ WFetch wblock_issue(const WRec* rec, uint32_t r, uint32_t b16, uint32_t ptotal)
+// An immediate record's literal bytes (<= 5, first byte lowest) placed at byte position q (-4..15) of a block: v_perm_b32
+// selectors from an LDS table (s_sel[(q + 4) & 31]; entries 20..31 select nothing)
+__device__ __forceinline__ u32x4 wplace(const u32x4* s_sel, uint64_t lit, uint32_t q)
 {
-    const uint32_t hi = b16 + 16u < ptotal ? b16 + 16u : ptotal;
-    const WRec t0 = rec[r], t1 = rec[r + 1u], t2 = rec[r + 2u];
-    const bool need1 = (t0.se >> 16) < hi, need2 = need1 && (t1.se >> 16) < hi;
-    WFetch f;
-    f.v = wrec_fetch(t0, b16); f.g1 = f.v; f.g2 = f.v;
-    if (need1) f.g1 = wrec_fetch(t1, b16);
-    if (need2) f.g2 = wrec_fetch(t2, b16);
-    f.ja1 = need1 ? (t1.se & 0xFFFFu) - b16 : 16u;
-    f.ja2 = need2 ? (t2.se & 0xFFFFu) - b16 : 16u;
-    f.next = (need2 && (t2.se >> 16) < hi) ? r + 2u : 0u;
-    return f;
-}
-__device__ __forceinline__ u32x4 wblock_finish(const WFetch& f, const WRec* rec, const u32x4* s_mask, uint32_t b16, uint32_t ptotal)
-{
-    u32x4 v = wmerge(f.v, f.g1, s_mask[f.ja1]);
-    v = wmerge(v, f.g2, s_mask[f.ja2]);
-    if (f.next) {                                             // four or more records in this block
-        const uint32_t hi = b16 + 16u < ptotal ? b16 + 16u : ptotal;
-        uint32_t r = f.next;
-        WRec t = rec[r];
-        while ((t.se >> 16) < hi) {
-            t = rec[++r];
-            v = wmerge(v, wrec_fetch(t, b16), s_mask[(t.se & 0xFFFFu) - b16]);
-        }
-    }
-    return v;
+    const u32x4 sel = s_sel[(q + 4u) & 31u];
+    const uint32_t lo = uint32_t(lit), hi = uint32_t(lit >> 32);
+    return u32x4{__builtin_amdgcn_perm(hi, lo, sel[0]), __builtin_amdgcn_perm(hi, lo, sel[1]), __builtin_amdgcn_perm(hi, lo, sel[2]), __builtin_amdgcn_perm(hi, lo, sel[3])};
 }
 
 // WPG waves per workgroup, each with its own chunk and its own LDS tables; the waves of a workgroup share nothing but the
-// (identical) byte-mask table.  WPG = 1: a wave slot is refilled the moment its wave ends.
+// (identical) mask and selector tables.
+//
+// (__launch_bounds__(.., 8): eight waves per SIMD, i.e. 64 VGPRs -- the kernel lives on occupancy; it fits without scratch.)
+// Everything between the descriptor load and the last store is STRAIGHT-LINE code: selects, dummy addresses (a readable buffer of
+// dots) and range-checked buffer stores instead of branches.  hipcc cannot count outstanding memory operations across a branch
+// that may or may not issue one; it then waits vmcnt(0) at the next use -- round 2's stitch4_kernel had "if (patch) read LDS
+// else gather" per row and a lane-conditional store per row, and its code waited for every gather before issuing the next one
+// and for every store's acknowledgement before issuing the next store (its own stamps: 7 500 + 4 900 cycles of a workgroup's
+// 24 400).  Here the eight gathers issue back to back and every wait is a counted one.
 template <int WPG, bool NT>
-__global__ __launch_bounds__(64 * WPG) void stitchw_kernel(const uint64_t* __restrict__ p_desc, const Chunk* __restrict__ p_chunks,
+__global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __restrict__ p_desc, const Chunk* __restrict__ p_chunks,
                                                             const uint8_t* __restrict__ p_src0, const uint8_t* __restrict__ p_src1,
                                                             uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
                                                             const uint8_t* __restrict__ p_dots,
                                                             uint32_t n_chunks, uint64_t n_desc, uint64_t src0_len, uint64_t src1_len, uint64_t out_len)
 {
     constexpr uint32_t ROWS = CHUNK_BYTES_WAVE / 1024u;              // 1 KiB rows of a chunk: all gathered before the first store
+    static_assert(ROWS == 8, "the patch indices of a lane's eight blocks are packed into two registers");
     struct WaveLds {
         uint32_t map32[CHUNK_BYTES_WAVE / 64u];                      // one byte per 16-byte block: record covering its first byte
         WRec rec[CHUNK_TASKS_WAVE + 4];                              // + sentinels
-        u32x4 patch[2 * CHUNK_TASKS_WAVE];                           // [t]: the block record t is the first to start in; [64 + r]: the block of r's substituted residue
+        u32x4 patch[2 * CHUNK_TASKS_WAVE];                           // [t]: the block record t is the first to start in; [64 + r]: the block of r's substituted residue; [0]: scrap
     };
     __shared__ __attribute__((aligned(16))) WaveLds s_all[WPG];
     __shared__ u32x4 s_mask[17];                                     // s_mask[j]: bytes >= j of a block
+    __shared__ u32x4 s_sel[32];                                      // s_sel[q + 4]: v_perm_b32 selectors placing a literal at block position q
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = WPG == 1 ? 0u : uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
@@ -140,6 +146,20 @@ __global__ __launch_bounds__(64 * WPG) void stitchw_kernel(const uint64_t* __res
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) m[k] = lane <= 4u * k ? 0xFFFFFFFFu : (lane >= 4u * k + 4u ? 0u : 0xFFFFFFFFu << (8u * (lane - 4u * k)));
         s_mask[lane] = m;
+    } else if (lane >= 32u) {
+        const int32_t q = int32_t(lane) - 36;                        // block position of the literal's first byte
+        u32x4 sel;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t w = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int32_t t = 4 * k + j - q;                     // which literal byte lands on block byte 4k + j (the literal is 8 bytes {hi, lo}, bytes 5..7 zero)
+                w |= ((t >= 0 && t < 8 && q <= 15) ? uint32_t(t) : 0x0Cu) << (8 * j);     // selector 0x0C: constant zero
+            }
+            sel[k] = w;
+        }
+        s_sel[lane - 32u] = sel;
     }
     reinterpret_cast<uint64_t*>(L.map32)[lane] = 0ull;
 
@@ -152,34 +172,39 @@ __global__ __launch_bounds__(64 * WPG) void stitchw_kernel(const uint64_t* __res
     const uint32_t len1 = snv ? (dlo >> 29) | ((dhi & 0x1FFu) << 3) : (dhi >> 8) & 0x3FFFFFu;
     const uint32_t bytes = snv ? len1 + 1u + ((dhi >> 9) & 0xFFFu) : len1;
     const uint64_t src = snv ? uint64_t(dlo & 0x1FFFFFFFu) : ((uint64_t(dhi & 0xFFu) << 32) | dlo);
-    uint64_t a = dots16;                                             // '.' fill, idle lanes, empty records, immediates (a readable dummy)
-    bool bad = false;
-    if (imm) bad = len1 > IMM_MAX_BYTES;
-    else if (bytes != 0u && (snv || space != SPACE_FILL)) {
-        const bool ref = snv || space == SPACE_PROTEOME;
-        bad = src + bytes > (ref ? src0_len : src1_len);             // never read out of bounds: task.rs would panic
-        a = reinterpret_cast<uint64_t>(ref ? p_src0 : p_src1) + src;
-    }
+    const bool gathers = !imm && bytes != 0u && (snv || space != SPACE_FILL);       // ('.' fill, idle lanes, empty records and immediates read the dots)
+    const bool ref = snv || space == SPACE_PROTEOME;
+    const bool bad = imm ? len1 > IMM_MAX_BYTES : (gathers && src + bytes > (ref ? src0_len : src1_len));   // never read out of bounds: task.rs would panic
+    const uint64_t a = gathers ? reinterpret_cast<uint64_t>(ref ? p_src0 : p_src1) + src : dots16;
     const uint32_t incl = wave_incl_scan(bad ? 0u : bytes);
     const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
     const uint32_t ptotal = head + total;                            // end of the chunk in block space
     const uint32_t nblk = total ? (ptotal + 15u) >> 4 : 0u;
     const bool any_bad = __ballot(bad) != 0ull;
-    if (bad) report(p_status, tb + lane, STATUS_SRC_OOB);            // reported, and the chunk is not executed
     if (!(hdr_ok && dst + total <= out_len && nblk <= CHUNK_BYTES_WAVE / 16u) || any_bad) {     // never write out of bounds
+        if (bad) report(p_status, tb + lane, STATUS_SRC_OOB);        // reported, and the chunk is not executed
         if (!any_bad && lane == 0u) report(p_status, tb, STATUS_RES_OOB);
         return;
     }
     if (total == 0u) return;
+    WChk chk;
+#ifdef V2P_WAVE_CHECK
+    chk.lo[0] = reinterpret_cast<uint64_t>(p_src0) - PAD_BYTES; chk.hi[0] = reinterpret_cast<uint64_t>(p_src0) + src0_len + PAD_BYTES;
+    chk.lo[1] = reinterpret_cast<uint64_t>(p_src1) - PAD_BYTES; chk.hi[1] = reinterpret_cast<uint64_t>(p_src1) + src1_len + PAD_BYTES;
+    chk.lo[2] = reinterpret_cast<uint64_t>(p_dots); chk.hi[2] = reinterpret_cast<uint64_t>(p_dots) + DOTS_BYTES;
+    chk.status = p_status; chk.tb = c;
+#endif
     const uint32_t start = ptotal - (total - (incl - bytes));        // = head + exclusive prefix; lanes >= n sit at ptotal
     const uint32_t end = start + bytes;
     const uint32_t lit_pos = start + len1;                           // (fused substitutions only)
+    const uint32_t lit_byte = (dhi >> 21) & 0xFFu;
+    const uint64_t adj = imm ? src : a - start;                      // (an immediate record keeps its literal bytes here)
+    const uint32_t my_lit = (snv ? lit_pos | (lit_byte << 16) : WREC_NOLIT) | (imm ? WREC_IMM : 0u);
     {
-        const uint64_t adj = imm ? src : a - start;
         WRec t;
         t.a_lo = uint32_t(adj); t.a_hi = uint32_t(adj >> 32);
         t.se = lane < n ? start | (end << 16) : ptotal | 0xFFFF0000u;     // sentinels past the last record: dots, ends beyond every block
-        t.lit = (snv ? lit_pos | (((dhi >> 21) & 0xFFu) << 16) : WREC_NOLIT) | (imm ? WREC_IMM : 0u);
+        t.lit = my_lit;
         L.rec[lane] = t;
         if (lane < 4u) L.rec[CHUNK_TASKS_WAVE + lane] = WRec{uint32_t(dots16 - ptotal), uint32_t((dots16 - ptotal) >> 32), ptotal | 0xFFFF0000u, WREC_NOLIT};
         const uint32_t kmin = (start + 15u) >> 4;                    // first block starting at or after the record's start
@@ -188,16 +213,23 @@ __global__ __launch_bounds__(64 * WPG) void stitchw_kernel(const uint64_t* __res
     asm volatile("" ::: "memory");                                   // (one wave: its LDS operations execute in order; this only pins the compiler)
 
     // ---- P, first half: lane = record.  Record t owns the block it starts in when it is the first record to start there (at a
-    //      non-zero offset); a fused substitution owns the block of its replaced residue when it covers that block whole. ----
-    const uint32_t prev_start = uint32_t(__builtin_amdgcn_update_dpp(0, int(start), 0x138, 0xf, 0xf, false));   // wave_shr:1
+    //      non-zero offset): it assembles that block from record t-1 (which covers the block's first byte), itself and record t+1;
+    //      a fused substitution owns the block of its replaced residue when it covers that block whole.  Four gathers per lane,
+    //      unconditionally (a lane with nothing to fetch reads the dots): no branch, they fly under C. ----
+    const WRec tp = L.rec[lane - (lane != 0u ? 1u : 0u)], tn = L.rec[lane + 1u];
     const uint32_t sb16 = start & ~15u;
-    const bool owner = lane >= 1u && lane < n && start != sb16 && (sb16 == 0u ? lane == 1u : prev_start <= sb16);
+    // (in block 0 of a chunk with a ragged head record 0 itself starts inside the block: record 1 owns it)
+    const bool owner = lane >= 1u && lane < n && start != sb16 && ((tp.se & 0xFFFFu) <= sb16 || (sb16 == 0u && lane == 1u));
+    const uint32_t phi = sb16 + 16u < ptotal ? sb16 + 16u : ptotal;
+    const bool need1 = owner && start < phi, need2 = need1 && end < phi;
+    const bool more = need2 && (tn.se >> 16) < phi;                  // a fourth record begins in the block (rare): finished in a loop
     const uint32_t lb16 = lit_pos & ~15u;
     const bool lit_owner = snv && start <= lb16 && end >= lb16 + 16u;
-    WFetch pf;
-    u32x4 lv = {0u, 0u, 0u, 0u};
-    if (owner) pf = wblock_issue(L.rec, lane - 1u, sb16, ptotal);
-    if (lit_owner) lv = gather16(a - start + lb16);
+    constexpr bool PG = !(V2P_WAVE_ABLATE & 2);
+    const u32x4 g0 = wgather(PG && owner && !(tp.lit & WREC_IMM) ? wrec_adj(tp) + sb16 : dots16, chk, 0u);
+    const u32x4 g1 = wgather(PG && need1 && !imm ? adj + sb16 : dots16, chk, 1u);
+    const u32x4 g2 = wgather(PG && need2 && !(tn.lit & WREC_IMM) ? wrec_adj(tn) + sb16 : dots16, chk, 2u);
+    const u32x4 g3 = wgather(PG && lit_owner ? adj + lb16 : dots16, chk, 3u);
 
     // ---- C: block map = inclusive prefix sum of the marks; 8 one-byte counters per lane (a chunk has at most 63 marks) ----
     {
@@ -211,50 +243,95 @@ __global__ __launch_bounds__(64 * WPG) void stitchw_kernel(const uint64_t* __res
         y0 += before; y1 += before;
         reinterpret_cast<uint64_t*>(L.map32)[lane] = (uint64_t(y1) << 32) | y0;
     }
-    // ---- P, second half: merge and park ----
-    if (owner) L.patch[lane] = wblock_finish(pf, L.rec, s_mask, sb16, ptotal);
-    if (lit_owner) L.patch[CHUNK_TASKS_WAVE + lane] = put_byte(lv, lit_pos & 15u, (dhi >> 21) & 0xFFu);
+    // ---- P, second half: merge, place the replaced residues (a record's residue lies inside its own range: it survives the
+    //      merges), park ----
+    {
+        const u32x4 v0 = (tp.lit & WREC_IMM) ? wplace(s_sel, wrec_adj(tp), (tp.se & 0xFFFFu) - sb16) : g0;
+        const u32x4 v1 = imm ? wplace(s_sel, src, start - sb16) : g1;
+        const u32x4 v2 = (tn.lit & WREC_IMM) ? wplace(s_sel, wrec_adj(tn), end - sb16) : g2;
+        u32x4 v = wmerge(v0, v1, s_mask[need1 ? start - sb16 : 16u]);
+        v = wmerge(v, v2, s_mask[need2 ? end - sb16 : 16u]);
+        v = wrec_lit(v, tp.lit, sb16);
+        v = wrec_lit(v, need1 ? my_lit : WREC_NOLIT, sb16);
+        v = wrec_lit(v, need2 ? tn.lit : WREC_NOLIT, sb16);
+        if (more) {
+            uint32_t r = lane + 1u;
+            WRec t = tn;
+            while ((t.se >> 16) < phi) {
+                t = L.rec[++r];
+                const u32x4 g = (t.lit & WREC_IMM) ? wplace(s_sel, wrec_adj(t), (t.se & 0xFFFFu) - sb16) : wgather(wrec_adj(t) + sb16, chk, 4u);
+                v = wmerge(v, g, s_mask[(t.se & 0xFFFFu) - sb16]);
+                v = wrec_lit(v, t.lit, sb16);
+            }
+        }
+        L.patch[owner ? lane : 0u] = v;
+        L.patch[lit_owner ? CHUNK_TASKS_WAVE + lane : 0u] = put_byte(g3, lit_pos & 15u, lit_byte);
+    }
     asm volatile("" ::: "memory");
 
-    // ---- K: lane = block.  Look-ups first (LDS only), then the gathers back to back, then the stores back to back. ----
+    // ---- K: lane = block.  Look-ups (LDS only), the eight gathers back to back, then per row: patch select, store. ----
     const uint8_t* const map8 = reinterpret_cast<const uint8_t*>(L.map32);
     uint8_t* const out0 = p_out + (dst - head);                      // 16-byte aligned
-    uint64_t X[ROWS];
+    uint32_t rr[ROWS];
 #pragma unroll
     for (uint32_t j = 0; j < ROWS; ++j) {
         const uint32_t b16 = (j << 10) + (lane << 4);
-        const uint32_t r = b16 < ptotal ? uint32_t(map8[b16 >> 4]) : n;     // idle lanes look at a sentinel (dots)
-        const WRec t = L.rec[r];
-        X[j] = wrec_adj(t) + b16;
-        // a record ends inside the block: the block the next record parked (address 0 | patch index); a replaced residue inside it:
-        // the block its record parked
-        if ((t.se >> 16) < b16 + 16u) X[j] = uint64_t(r + 1u);
-        else if ((t.lit & 0xFFFFu) - b16 < 16u) X[j] = uint64_t(CHUNK_TASKS_WAVE + r);
+        rr[j] = b16 < ptotal ? uint32_t(map8[b16 >> 4]) : n;         // idle lanes look at a sentinel (dots)
     }
+    // the eight records first (they land in the registers the gathers will fill), then per row: classify, gather
     u32x4 v[ROWS];
 #pragma unroll
-    for (uint32_t j = 0; j < ROWS; ++j) {
-        if ((j << 10) >= ptotal) continue;                           // (uniform: rows past the chunk's end)
-        // (if / else, not a select: gather and patch land in the same registers, lanes disjoint)
-        if (uint32_t(X[j] >> 32) == 0u) v[j] = L.patch[uint32_t(X[j])];
-        else v[j] = gather16(X[j]);
-    }
+    for (uint32_t j = 0; j < ROWS; ++j) v[j] = reinterpret_cast<const u32x4*>(L.rec)[rr[j]];     // (one 16-byte read: field by field, the address half is sunk into a branch)
+    uint32_t pk[2] = {0u, 0u};                                       // patch index of the lane's block in row j: byte j & 3 of pk[j >> 2] (0: none)
+    const uint32_t lane16 = lane << 4;
 #pragma unroll
     for (uint32_t j = 0; j < ROWS; ++j) {
-        if ((j << 10) >= ptotal) continue;
-        const uint32_t b16 = (j << 10) + (lane << 4);
-        if (b16 >= head && b16 + 16u <= ptotal) {                    // whole blocks of the chunk; ragged edge blocks are written below
-            if (NT) __builtin_nontemporal_store(v[j], reinterpret_cast<u32x4*>(out0 + b16));
-            else *reinterpret_cast<u32x4*>(out0 + b16) = v[j];
-        }
+        const uint32_t b16 = (j << 10) + lane16;
+        const u32x4 t = v[j];
+        // a record ends inside the block: the block the next record parked; a replaced residue inside it: the block its record
+        // parked.  Such a lane gathers the dots and takes the parked block afterwards.  (Every arm a ready value: selects, no branch.)
+        const bool cut = (t[2] >> 16) < b16 + 16u, parked = cut || (t[3] & 0xFFFFu) - b16 < 16u;
+        const uint64_t A = ((uint64_t(t[1]) << 32) | t[0]) + b16;
+        // (an immediate record has no address: it can only "cover" the ragged head block of a chunk, which is not stored from here)
+        const uint64_t X = (parked || (t[3] & WREC_IMM) || (V2P_WAVE_ABLATE & 1)) ? dots16 : A;
+        const uint32_t i_cut = rr[j] + 1u, i_lit = rr[j] + CHUNK_TASKS_WAVE;
+        const uint32_t i_any = cut ? i_cut : i_lit;
+        const uint32_t idx = parked ? i_any : 0u;
+        pk[j >> 2] |= idx << (8u * (j & 3u));
+        v[j] = wgather(X, chk, 5u);
+    }
+    // whole blocks of the chunk leave as 16-byte stores of a buffer resource over the chunk's result range: a lane outside it
+    // (ragged edge blocks, rows past the chunk's end) gets an out-of-range offset and the hardware drops its store -- no branch
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out0, 0, int(ptotal), 0x00020000);
+    const int32_t last16 = int32_t(ptotal) - 16;                     // a block at b16 <= last16 ends inside the chunk
+#pragma unroll
+    for (uint32_t j = 0; j < ROWS; ++j) {
+        const uint32_t idx = (pk[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
+        const u32x4 p = L.patch[idx];
+        const u32x4 o = idx ? p : v[j];
+        const bool whole = int32_t(lane16) <= last16 - int32_t(j << 10) && (j != 0u || lane16 >= head);
+        const uint32_t off = (whole && !(V2P_WAVE_ABLATE & 4)) ? lane16 : 0x80000000u;
+        // (soffset stays the immediate 0: with an SGPR there, hipcc (ROCm 7.2) leaves out the wait states between a dwordx4 store and
+        // a VALU write to its data registers -- seen on gfx950: "buffer_store_dwordx4 v[10:13], .., s6 offen" followed at once by
+        // "v_mov_b32 v10, 0" stored a zero first dword in the last four lanes of every row of sixteen)
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, int(off + (j << 10)), 0, NT ? 2 : 0);
     }
     // ragged first / last block of a chunk whose cut is not 16-byte aligned (rare): one lane each, byte stores
     if (lane < 2u) {
         const uint32_t b16 = lane == 0u ? 0u : (nblk - 1u) << 4;
         if ((b16 < head || b16 + 16u > ptotal) && (lane == 0u || b16 != 0u)) {
-            const WFetch f = wblock_issue(L.rec, uint32_t(map8[b16 >> 4]), b16, ptotal);
-            const u32x4 o = wblock_finish(f, L.rec, s_mask, b16, ptotal);
-            const uint32_t ka = b16 < head ? head - b16 : 0u, kb = (b16 + 16u < ptotal ? b16 + 16u : ptotal) - b16;
+            const uint32_t hi = b16 + 16u < ptotal ? b16 + 16u : ptotal;
+            uint32_t r = uint32_t(map8[b16 >> 4]);
+            WRec t = L.rec[r];
+            u32x4 o = (t.lit & WREC_IMM) ? wplace(s_sel, wrec_adj(t), (t.se & 0xFFFFu) - b16) : wgather(wrec_adj(t) + b16, chk, 6u);
+            o = wrec_lit(o, t.lit, b16);
+            while ((t.se >> 16) < hi) {
+                t = L.rec[++r];
+                const u32x4 g = (t.lit & WREC_IMM) ? wplace(s_sel, wrec_adj(t), (t.se & 0xFFFFu) - b16) : wgather(wrec_adj(t) + b16, chk, 7u);
+                o = wmerge(o, g, s_mask[(t.se & 0xFFFFu) - b16]);
+                o = wrec_lit(o, t.lit, b16);
+            }
+            const uint32_t ka = b16 < head ? head - b16 : 0u, kb = hi - b16;
             for (uint32_t q = ka; q < kb; ++q) out0[b16 + q] = uint8_t(o[q >> 2] >> (8u * (q & 3u)));
         }
     }

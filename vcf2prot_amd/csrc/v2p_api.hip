@@ -667,6 +667,22 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
         return c->fail(V2P_ERR_INVALID_ARG, "null argument");
     if (s->hap_tx_begin[s->n_haps] != s->n_tx || (s->n_tx && (s->tx_task_begin[s->n_tx] != s->n_tasks || s->tx_alt_begin[s->n_tx] != s->n_alt)))
         return c->fail(V2P_ERR_INVALID_ARG, "stream offsets do not add up");
+    // The kernels index device memory through EVERY entry of the offset tables (16-byte slab loads of a transcript's tasks, the
+    // unaligned 8-byte load of an immediate payload, tx_res_base[hap_tx_begin[h]]): a table that is not ascending from 0 or leaves
+    // its array is refused here, with the offending index, before anything is uploaded.
+    if (s->hap_tx_begin[0] != 0) return c->fail(V2P_ERR_INVALID_ARG, "hap_tx_begin does not start at 0", 0);
+    for (uint64_t h = 0; h < s->n_haps; ++h)
+        if (s->hap_tx_begin[h + 1] < s->hap_tx_begin[h] || s->hap_tx_begin[h + 1] > s->n_tx)
+            return c->fail(V2P_ERR_INVALID_ARG, "hap_tx_begin is not ascending inside [0, n_tx] at haplotype " + std::to_string(h), int64_t(h));
+    if (s->n_tx && (s->tx_task_begin[0] != 0 || s->tx_alt_begin[0] != 0)) return c->fail(V2P_ERR_INVALID_ARG, "tx_task_begin / tx_alt_begin do not start at 0", 0);
+    for (uint64_t t = 0; t < s->n_tx; ++t) {
+        if (s->tx_task_begin[t + 1] < s->tx_task_begin[t] || s->tx_task_begin[t + 1] > s->n_tasks)
+            return c->fail(V2P_ERR_INVALID_ARG, "tx_task_begin is not ascending inside [0, n_tasks] at transcript " + std::to_string(t), int64_t(t));
+        if (s->tx_alt_begin[t + 1] < s->tx_alt_begin[t] || s->tx_alt_begin[t + 1] > s->n_alt)
+            return c->fail(V2P_ERR_INVALID_ARG, "tx_alt_begin is not ascending inside [0, n_alt] at transcript " + std::to_string(t), int64_t(t));
+        if (s->tx_proteome_off[t] + s->tx_ref_len[t] < s->tx_proteome_off[t])
+            return c->fail(V2P_ERR_INVALID_ARG, "tx_proteome_off + tx_ref_len wraps at transcript " + std::to_string(t), int64_t(t));
+    }
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     const uint64_t n_tx = s->n_tx, n_tk = s->n_tasks, n_h = s->n_haps;
     const uint64_t n_tiles = (n_tx + 1023) / 1024 + 2;
@@ -693,11 +709,23 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     int rc = init_status(c, b->d_status);
     if (rc) return rc;
     // two brackets: the counting kernels, then -- after the host has read the two totals and allocated the image -- the emitting ones
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
-    HIP_TRY(c, hipEventCreate(&e0), "hipEventCreate");
-    HIP_TRY(c, hipEventCreate(&e1), "hipEventCreate");
-    HIP_TRY(c, hipEventCreate(&e2), "hipEventCreate");
-    HIP_TRY(c, hipEventCreate(&e3), "hipEventCreate");
+    // (every return below leaves through these: the events, the scratch tables and the uploaded stream are released, and a batch
+    // that failed holds nothing -- the caller may retry it with a smaller window)
+    struct Cleanup {
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        DevBuf scratch;
+        v2p_batch* b;
+        bool ok = false;
+        explicit Cleanup(v2p_batch* b_) : b(b_) {}
+        ~Cleanup() {
+            for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+            scratch.release();
+            b->d_build.release();                         // nothing reads the stream copy after the emit pass
+            if (!ok) { b->img.hap_out_begin.assign(1, 0); b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0; }
+        }
+    } guard(b);
+    for (hipEvent_t& e : guard.ev) HIP_TRY(c, hipEventCreate(&e), "hipEventCreate");
+    hipEvent_t &e0 = guard.ev[0], &e1 = guard.ev[1], &e2 = guard.ev[2], &e3 = guard.ev[3];
     BuildArgs a{};
     a.n_haps = n_h; a.n_tx = n_tx; a.n_tasks = s->n_tasks;
     a.hap_tx_begin = reinterpret_cast<const uint64_t*>(d + o_hap); a.tx_proteome_off = reinterpret_cast<const uint64_t*>(d + o_poff);
@@ -719,11 +747,11 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     HIP_TRY(c, hipMemcpyAsync(&totals[0], d + o_base + n_tx * 8, 8, hipMemcpyDeviceToHost, c->stream), "D2H(out_bytes)");
     HIP_TRY(c, hipMemcpyAsync(&totals[1], d + o_dbase + n_tx * 8, 8, hipMemcpyDeviceToHost, c->stream), "D2H(n_desc)");
     rc = collect_status(c, b->d_status);                  // what the reference would panic on surfaces here, before anything is emitted
-    if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3); (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return rc; }
+    if (rc) { (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return rc; }
     const uint64_t out_bytes = totals[0], n_desc = totals[1];
     const uint64_t n_windows = (out_bytes + window_bytes - 1) / window_bytes;
     if (n_windows > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch");
-    DevBuf scratch;                                       // chunk_first, chunks in result order, slices, per-block histograms
+    DevBuf& scratch = guard.scratch;                      // chunk_first, chunks in result order, slices, per-block histograms
     const uint64_t n_blocks = (n_windows + 255) / 256;
     const uint64_t n_sub = uint64_t(XCD_SUB) * n_blocks;      // counters of the window sort
     const uint64_t s_first = 0, s_tmp = up8(n_windows * 8), s_bucket = s_tmp + up8(n_windows * 16), s_hist = s_bucket + up8(n_windows),
@@ -764,9 +792,8 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventElapsedTime(&ms2, e2, e3);
     ms += ms2;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
-    scratch.release();
     if (rc) { (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return rc; }
+    guard.ok = true;
     if (build_ms) *build_ms = ms;
     b->n_desc = n_desc; b->n_chunks = n_windows; b->n_payload = s->n_alt; b->out_bytes = out_bytes; b->n_haps = n_h;
     const int tpt = meta[3] <= 256u ? 1 : (meta[3] <= 512u ? 2 : 4);
