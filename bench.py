@@ -181,7 +181,7 @@ def pcie_inclusive(cohort, h0, h1, n_threads, slots=3, target_image_bytes=2 << 3
             "d2h_GBps": out_total / best / 1e9, "what": "packed images -> pinned H2D -> stitch kernel -> D2H into pinned host memory"}
 
 
-def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests, dense=False):
+def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests, dense=False, wave=False):
     """the same shard's image built ON the device from the per-transcript GIRs of step 4b (v2p_batch_build_on_device:
     step 5's running sums as prefix scans, descriptors, chunk table, XCD order).  Returns the build kernels' time and whether the
     image executes to the same per-haplotype digests."""
@@ -192,14 +192,15 @@ def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests, dense=
     t_stream = time.perf_counter() - t0
     from vcf2prot_amd._native import V2PError
     # a dense image: one window = the kernel's 12 KiB LDS image when its descriptors fit (<= 1024 per window), else smaller windows
-    windows = (12288, 8192, 4096) if dense else ((28672,) if long_run else (32768,))
+    windows = (12288, 8192, 4096) if dense else ((8192, 4096) if wave else ((28672,) if long_run else (32768,)))
+    kernel = 3 if dense else (4 if wave else (1 if long_run else 2))
     with Context(0) as ctx:
         ctx.upload_proteome(cohort.proteome())
         for window in windows:
             b = ctx.batch()
             try:
                 t0 = time.perf_counter()
-                ms = b.build_on_device(stream, window, 3 if dense else (1 if long_run else 2))
+                ms = b.build_on_device(stream, window, kernel)
                 t_call = time.perf_counter() - t0
                 break
             except V2PError:
@@ -456,7 +457,7 @@ def main():
                 line["incl_transfers"] = {"error": repr(e)}
         if world == 1 and not args.no_device_build and not args.fasta and not args.dbg and not args.dry_run:
             try:
-                line["device_image_build"] = device_image_build(cohort, h0, h1, min(n_threads, 64), not (img.launch_bits & 16), dig_all, dense=bool(img.launch_bits & 2))
+                line["device_image_build"] = device_image_build(cohort, h0, h1, min(n_threads, 64), not (img.launch_bits & 16), dig_all, dense=bool(img.launch_bits & 2), wave=bool(img.launch_bits & 4))
             except Exception as e:
                 line["device_image_build"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:

@@ -129,7 +129,7 @@ def main():
         elif int(kv.get("l1", 0)):
             chunks = l1_order(chunks, img.desc, n_prot, int(kv["l1"]))
         elif int(kv.get("xcd", 1)):
-            os.environ["V2P_XCD_SUB"] = str(int(kv.get("sub", 1)))
+            os.environ["V2P_ORDER_WINDOWS"] = str(int(kv.get("sub", 1)))
             lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, n_prot)
         desc_arr = img.desc
         if int(kv.get("relayout", 0)):            # experiment: the descriptors physically in launch order (chunk after chunk)

@@ -52,21 +52,13 @@ def main():
     rows = []
     # (wpg, pattern, label, shift, extra gathers, descriptor lanes, descriptor table wrap, store policy, prefetch distance)
     C2, C3, ONE = 0, 1, 2
-    S = 1 << 31
-    cases = [(1, C2, "contiguous (C2)", 5, 0, 0, 0, 2, 0), (1, C2, "C2, sc1 nt stores", 5, 0, 0, 0, 18, 0),
-             (1, C2, "C2 + 192 B desc", 5, 0, 24, 0, 2, 0), (1, C2, "C2 + 192 B desc, sc1 nt stores", 5, 0, 24, 0, 18, 0),
-             (1, C2, "C2 + 512 B desc", 5, 0, 64, 0, 2, 0),
-             (1, C2, "C2 + 512 B desc, prefetch 2048", 5, 0, 64, 0, 2, 2048), (1, C2, "C2 + 512 B desc, prefetch 16384", 5, 0, 64, 0, 2, 16384),
-             (1, C2, "C2 + 512 B desc, prefetch 65536", 5, 0, 64, 0, 2, 65536),
-             (1, C2, "C2 + 512 B desc, scalar prefetch 2048", 5, 0, 64, 0, 2, S | 2048), (1, C2, "C2 + 512 B desc, scalar prefetch 16384", 5, 0, 64, 0, 2, S | 16384),
-             (1, C2, "C2 + 512 B desc, scalar prefetch 65536", 5, 0, 64, 0, 2, S | 65536),
-             (1, C2, "C2 + 512 B desc, table of 4096 chunks (cached)", 5, 0, 64, 4096, 2, 0),
+    cases = [(1, C2, "contiguous (C2)", 5, 0, 0, 0, 2, 0), (1, C2, "C2 + 512 B desc", 5, 0, 64, 0, 2, 0),
              (1, C2, "C2 + 512 B desc, table of 65536 chunks (32 MB)", 5, 0, 64, 65536, 2, 0),
-             (1, C2, "C2 + 384 B desc", 5, 0, 48, 0, 2, 0), (1, C2, "C2 + 320 B desc", 5, 0, 40, 0, 2, 0),
-             (1, C3, "C3 + 448 B desc", 5, 0, 56, 0, 2, 0), (1, C3, "C3 + 448 B desc, prefetch 16384", 5, 0, 56, 0, 2, 16384),
-             (1, C3, "C3 + 448 B desc, scalar prefetch 16384", 5, 0, 56, 0, 2, S | 16384),
-             (1, C3, "C3 + 448 B desc, scalar prefetch 16384, sc1 nt stores", 5, 0, 56, 0, 18, S | 16384),
-             (1, C3, "C3 + 256 B desc", 5, 0, 32, 0, 2, 0), (1, C3, "C3 + 320 B desc", 5, 0, 40, 0, 2, 0)]
+             (1, C2, "C2 + 512 B desc, table of 131072 chunks (64 MB)", 5, 0, 64, 131072, 2, 0),
+             (1, C2, "C2 + 512 B desc, table of 262144 chunks (128 MB)", 5, 0, 64, 262144, 2, 0),
+             (1, C2, "C2 + 512 B desc, table of 393216 chunks (192 MB)", 5, 0, 64, 393216, 2, 0),
+             (1, C2, "C2 + 512 B desc, table of 524288 chunks (256 MB)", 5, 0, 64, 524288, 2, 0),
+             (1, C3, "C3 + 448 B desc", 5, 0, 56, 0, 2, 0)]
     for wpg, pattern, label, shift, n_p, dl, dmod, aux, pf in cases:
         ms = []
         for r in range(a.rounds + 1):
@@ -82,6 +74,30 @@ def main():
         med = statistics.median(ms)
         rows.append({"wpg": wpg, "what": label, "extra_gathers": n_p, "descriptor_bytes": dl * 8, "descriptor_table_chunks": dmod, "store_aux": aux, "prefetch": pf, "ms": med, "TBps_written": nbytes / med / 1e9})
         print(f"{label:58s}: {med:7.3f} ms  {nbytes / med / 1e9:6.2f} TB/s")
+    lib.v2p_bench_wave_copy_phased.restype = ctypes.c_int
+    lib.v2p_bench_wave_copy_phased.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                               ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int]
+    sink = torch.zeros(4, dtype=torch.int32, device=dev)
+    for pattern, dl, label in ((C2, 64, "C2 + 512 B desc"), (C3, 56, "C3 + 448 B desc")):
+        for phases in (1, 2, 4, 8, 16, 32, 64):
+            for touch in (0, 1):
+                if phases == 1 and touch:
+                    continue
+                ms = []
+                for r in range(a.rounds + 1):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                    rc = lib.v2p_bench_wave_copy_phased(ctypes.c_void_p(st.cuda_stream), src.data_ptr(), window, out.data_ptr(), nbytes, dsc.data_ptr(),
+                                                        pattern, dl, 2, phases, sink.data_ptr(), touch)
+                    assert rc == 0, rc
+                    e1.record(st)
+                    torch.cuda.synchronize()
+                    if r:
+                        ms.append(e0.elapsed_time(e1))
+                med = statistics.median(ms)
+                what = f"{label}, {phases} sub-launches" + (", descriptors touched before each" if touch else "")
+                rows.append({"what": what, "phases": phases, "touch": touch, "ms": med, "TBps_written": nbytes / med / 1e9})
+                print(f"{what:58s}: {med:7.3f} ms  {nbytes / med / 1e9:6.2f} TB/s")
     if a.json:
         json.dump({"bytes": nbytes, "window": window, "cases": rows}, open(a.json, "w"), indent=1)
 

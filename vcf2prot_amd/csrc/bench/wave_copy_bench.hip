@@ -93,6 +93,38 @@ __global__ __launch_bounds__(64 * WPG, 8) void wave_copy_kernel(Params p)
     }
 }
 
+// reads `bytes` from `p` (16 bytes per lane, grid-stride) and keeps nothing: pulls a range into the memory-side cache
+__global__ __launch_bounds__(256) void touch_kernel(const u32x4* __restrict__ p, uint64_t n16, uint32_t* sink)
+{
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    for (uint64_t i = uint64_t(blockIdx.x) * 256u + threadIdx.x; i < n16; i += uint64_t(gridDim.x) * 256u) {
+        const u32x4 v = __builtin_nontemporal_load(p + i);
+        acc[0] ^= v[0]; acc[1] ^= v[1]; acc[2] ^= v[2]; acc[3] ^= v[3];
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1u;
+}
+
+// the copy in `phases` sub-launches, each preceded by a kernel that reads its descriptors (dsc_lanes * 8 bytes of every 512-byte slot
+// are what the copy reads; the touch reads whole slots) -- descriptor reads then never mix with the result stores
+extern "C" int v2p_bench_wave_copy_phased(void* stream, const uint8_t* src, uint64_t window, uint8_t* out, uint64_t bytes, const uint64_t* dsc,
+                                          uint32_t pattern, uint32_t dsc_lanes, uint32_t aux, uint32_t phases, uint32_t* sink, int touch)
+{
+    const uint64_t n_chunks = bytes / 8192u;
+    if (!n_chunks || !phases || !dsc) return -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -3;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const uint64_t per = ((n_chunks + phases - 1) / phases + 7) & ~7ull;
+    for (uint64_t c0 = 0; c0 < n_chunks; c0 += per) {
+        const uint64_t n = n_chunks - c0 < per ? n_chunks - c0 : per;
+        if (touch) hipLaunchKernelGGL(touch_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<const u32x4*>(dsc + c0 * 64u), n * 32u, sink);
+        Params p{src, window, out + c0 * 8192ull, n, dsc + c0 * 64u, pattern, 5u, 0u, 26u, 0u, dsc_lanes, 0u, aux, 0u};
+        hipLaunchKernelGGL(wave_copy_kernel<1>, dim3(uint32_t(n)), dim3(64), 0, s, p);
+    }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -100 - int(e);
+}
+
 extern "C" int v2p_bench_wave_copy(void* stream, const uint8_t* src, uint64_t window, uint8_t* out, uint64_t bytes, const uint64_t* dsc,
                                    uint32_t pattern, uint32_t shift, uint32_t n_p, uint32_t run_blocks, uint32_t aligned, int wpg,
                                    uint32_t dsc_lanes, uint32_t dsc_mod, uint32_t aux, uint32_t prefetch)

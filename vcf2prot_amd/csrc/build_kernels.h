@@ -27,6 +27,7 @@ struct BuildArgs {
     uint32_t window;              // result bytes per chunk (grid)
     int      long_run;            // route every chunk to stitch4_kernel
     int      dense;               // ... to stitch_dense_kernel (fusion on as for long_run)
+    int      wave;                // with long_run: ... to stitchw_kernel instead (windows of <= 8 KiB and <= 64 descriptors)
     // scans and outputs
     const uint64_t* tx_res_base;  // [n_tx + 1] exclusive prefix of tx_res_len
     uint32_t* tx_desc_count;      // [n_tx]

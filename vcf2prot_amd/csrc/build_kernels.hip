@@ -374,9 +374,10 @@ __global__ __launch_bounds__(256) void chunk_kernel(BuildArgs a, uint64_t n_wind
 #pragma unroll
     for (uint32_t dlt = 32u; dlt; dlt >>= 1) tasks += uint32_t(__shfl_xor(int(tasks), int(dlt), 64));
     if (lane != 0) return;
-    if (a.long_run && tasks > 2u * CHUNK_TASKS) { breport(a.status, tb, STATUS_TOO_MANY); return; }
+    if (a.wave ? n > CHUNK_TASKS_WAVE : (a.long_run && tasks > 2u * CHUNK_TASKS)) { breport(a.status, tb, STATUS_TOO_MANY); return; }
     uint64_t flags = 0;
-    if (a.long_run) flags = CHUNK_LONG | (tasks > CHUNK_TASKS ? CHUNK_LONG2 : 0ull);
+    if (a.wave) flags = CHUNK_WAVE;
+    else if (a.long_run) flags = CHUNK_LONG | (tasks > CHUNK_TASKS ? CHUNK_LONG2 : 0ull);
     else if (a.dense) flags = CHUNK_DENSE;
     a.chunks_tmp[k] = Chunk{tb, (k * a.window) | (n << 48) | flags};
     const uint64_t per = (a.proteome_len + 7) / 8;
@@ -386,7 +387,8 @@ __global__ __launch_bounds__(256) void chunk_kernel(BuildArgs a, uint64_t n_wind
     // what the launcher needs to know about the table (one lane per window gets here: the atomics are only issued while they would
     // still change something -- half a million same-address atomics took 6 ms)
     volatile uint32_t* meta = a.meta;
-    if (a.long_run) { if (!(meta[0] & 1u)) atomicOr(&a.meta[0], 1u); if (tasks > CHUNK_TASKS && !(meta[1] & 1u)) atomicOr(&a.meta[1], 1u); }
+    if (a.wave) { if (!(meta[0] & 4u)) atomicOr(&a.meta[0], 4u); }
+    else if (a.long_run) { if (!(meta[0] & 1u)) atomicOr(&a.meta[0], 1u); if (tasks > CHUNK_TASKS && !(meta[1] & 1u)) atomicOr(&a.meta[1], 1u); }
     else if (a.dense) { if (!(meta[0] & 2u)) atomicOr(&a.meta[0], 2u); }
     else { if (!(meta[2] & 1u)) atomicOr(&a.meta[2], 1u); if (meta[3] < uint32_t(n)) atomicMax(&a.meta[3], uint32_t(n)); }
 }

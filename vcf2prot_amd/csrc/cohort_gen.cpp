@@ -473,8 +473,11 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
         generate_into(*c, h0, b, false, nullptr);
         uint64_t bytes = 0, tasks = 0;
         for (size_t i = 0; i < b.length.size(); ++i) { bytes += b.length[i]; tasks += b.length[i] ? 1 : 0; }
-        const int choice = !tasks ? 2 : (bytes / tasks >= v2p::LONG_RUN_BYTES_PER_TASK ? 1 : (bytes / tasks < v2p::DENSE_BELOW ? 3 : 2));
-        for (auto& im : parts) im.kernel_choice = choice;
+        const int choice = !tasks ? 2 : (bytes / tasks >= v2p::LONG_RUN_BYTES_PER_TASK ? 4 : (bytes / tasks < v2p::DENSE_BELOW ? 3 : 2));
+        for (auto& im : parts) {
+            im.set_kernel(choice);
+            if (choice == 4 && chunk_bytes) im.chunk_bytes = chunk_bytes < v2p::CHUNK_BYTES_WAVE ? chunk_bytes : v2p::CHUNK_BYTES_WAVE;
+        }
     }
     std::vector<int> status(parts.size(), 0);
     // where every thread's part begins in the arena (its haplotypes' result sizes, FASTA text included): chunk cuts are aligned in
@@ -673,6 +676,7 @@ void v2p_txstream_free(v2p_txstream_buf* s)
 int v2p_cohort_pack_grid(const v2p_cohort* c, uint64_t h0, uint64_t h1, uint32_t window_bytes, int kernel, v2p_packed_image* out)
 {
     if (!c || !out || h1 < h0 || window_bytes == 0 || window_bytes % 4096u) return -1;
+    if (kernel == 4 && window_bytes > v2p::CHUNK_BYTES_WAVE) return -1;        // a wave chunk is at most eight 1 KiB rows
     memset(out, 0, sizeof *out);
     v2p_txstream_buf s;
     int rc = v2p_cohort_txstream(c, h0, h1, 8, &s);
@@ -696,6 +700,7 @@ int v2p_cohort_pack_grid(const v2p_cohort* c, uint64_t h0, uint64_t h1, uint32_t
     im.finish();
     v2p_txstream_free(&s);
     if (rc) return rc;
+    if (im.grid_overflow) return v2p::PACK_TOO_LARGE;                      // some window holds more descriptors than its kernel takes
     out->n_desc = im.desc.size(); out->n_chunks = im.chunks.size(); out->n_payload = im.payload.size(); out->n_haps = im.n_haplotypes();
     out->desc = static_cast<uint64_t*>(malloc((out->n_desc ? out->n_desc : 1) * 8));
     out->chunks = static_cast<v2p_chunk*>(malloc((out->n_chunks ? out->n_chunks : 1) * sizeof(v2p_chunk)));

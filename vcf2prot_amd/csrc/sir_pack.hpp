@@ -75,7 +75,7 @@ constexpr uint32_t CHUNK_TASKS_DEEP = 1024;    // ... for dense images (a few re
 constexpr uint32_t CHUNK_TASKS_WAVE = 64;      // DESCRIPTORS per work item of a wave image (stitchw_kernel: one wave per chunk, one descriptor per lane)
 constexpr uint32_t CHUNK_BYTES = 64u * 1024u - 16u;  // most result bytes a work item may hold (<= 4096 16-byte blocks incl. a ragged head)
 constexpr uint32_t CHUNK_BYTES_LONG = 32u * 1024u;   // ... of a long-run work item: 2048 blocks = eight 1 KiB rows per wave, all gathered before the first store
-constexpr uint32_t CHUNK_BYTES_WAVE = 8192;    // ... of a wave image, ragged head included: 512 blocks = eight 1 KiB rows of ONE wave
+constexpr uint32_t CHUNK_BYTES_WAVE = 8192;    // ... of a wave image, ragged head included: 512 blocks = eight 1 KiB rows of ONE wave (twelve rows do not fit 64 VGPRs: hipcc spills the gathers' destination registers)
 constexpr uint32_t CUT_ALIGN_WAVE = 1024;      // preferred cut of a wave image: whole 1 KiB rows
 constexpr uint32_t CHUNK_BYTES_DENSE = 12272;  // ... of a dense image: the 12 KiB LDS image of stitch_dense_kernel takes the chunk in one window
 constexpr uint32_t DENSE_BELOW = 40;           // a chunk with fewer result bytes per task than this switches the builder to dense chunks
@@ -155,20 +155,21 @@ public:
     bool fuse_snv = true;             // reference copy + 1-byte literal + reference copy going on one residue later -> one descriptor
     bool fuse_double = true;          // dense images: two substitutions in a row -> one descriptor
     uint64_t n_fused = 0;             // fused substitutions in the image
+    bool grid_overflow = false;       // grid cutting: some window holds more descriptors than its kernel takes (PACK_TOO_LARGE)
 
     // Empty the image for another build; the vectors keep their capacity, the settings return to their defaults.
     void reset() {
         desc.clear(); chunks.clear(); payload.clear(); hap_out_begin.assign(1, 0);
         n_copy_bytes = n_ref_tasks = n_fused = n_long_chunks = n_dense_chunks = n_wave_chunks = 0;
         chunk_tasks = CHUNK_TASKS; adaptive_tasks = true; chunk_bytes = CHUNK_BYTES_LONG; adaptive_bytes = true; cut_align = CUT_ALIGN;
-        max_chunk_tasks = max_long_tasks = 0; soft_window = 8; inline_payload = true; fuse_snv = true; fuse_double = true; kernel_choice = 0; grid_bytes = 0;
+        grid_overflow = false; max_chunk_tasks = max_long_tasks = 0; soft_window = 8; inline_payload = true; fuse_snv = true; fuse_double = true; kernel_choice = 0; grid_bytes = 0;
         cursor_ = extra_ = arena_cursor_ = open_begin_ = open_dst_ = 0;
         open_n_ = open_bytes_ = open_desc_ = 0; open_fused_ = false; st_n_ = 0; st0_virtual_ = false;
     }
     // Fix the kernel of the whole image up front (before the first task): chunk limits follow it.
     void set_kernel(int k) {
         kernel_choice = k;
-        if (k == 4) { chunk_tasks = CHUNK_TASKS_WAVE; chunk_bytes = CHUNK_BYTES_WAVE; adaptive_tasks = false; adaptive_bytes = false; }
+        if (k == 4 && !grid_bytes) { chunk_tasks = CHUNK_TASKS_WAVE; chunk_bytes = CHUNK_BYTES_WAVE; adaptive_tasks = false; adaptive_bytes = false; }
     }
     // Build a PART of a larger arena (threads packing haplotype ranges side by side): the part's first result byte sits at absolute
     // arena offset `o`, so that chunk cuts are aligned in the arena the kernels write, not in the part.  Call before the first task;
@@ -417,6 +418,9 @@ private:
         // (C5: 7).  An explicit chunk_tasks (adaptive_tasks off) keeps the choice per chunk: <= 256 tasks -> long-run.
         const uint32_t bpt = open_bytes_ / open_n_;
         if (grid_bytes) {                              // the caller chose the kernel (1: long-run, else per block); nothing adapts
+            // a window with more descriptors (tasks) than its kernel takes: the image is refused (the device builder reports the same
+            // window with STATUS_TOO_MANY) -- pick a smaller window
+            if ((kernel_choice == 4 && open_desc_ > CHUNK_TASKS_WAVE) || open_desc_ > CHUNK_TASKS_DEEP || (kernel_choice == 1 && open_n_ > 2u * CHUNK_TASKS)) grid_overflow = true;
             const bool lg = kernel_choice == 1 && open_n_ <= 2u * CHUNK_TASKS, dn = kernel_choice == 3, wv = kernel_choice == 4;
             chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_desc_) << 48) | (lg ? CHUNK_LONG : 0ull) | (lg && open_n_ > CHUNK_TASKS ? CHUNK_LONG2 : 0ull)
                                                 | (dn ? CHUNK_DENSE : 0ull) | (wv ? CHUNK_WAVE : 0ull)});
@@ -424,7 +428,24 @@ private:
             open_n_ = 0; open_bytes_ = 0; open_desc_ = 0; open_fused_ = false;
             return;
         }
-        if (adaptive_tasks && kernel_choice == 0) kernel_choice = bpt >= LONG_RUN_BYTES_PER_TASK ? 1 : (bpt < DENSE_BELOW ? 3 : 2);
+        if (adaptive_tasks && kernel_choice == 0) {
+            // long runs (C2): stitchw_kernel, one wave per chunk (-5 % against stitch4_kernel, round 3); 40 .. 120 result bytes per task
+            // (C3, C4): the per-block kernel still wins by 5 .. 15 %; short tasks: the dense kernel
+            const int choice = bpt >= LONG_RUN_BYTES_PER_TASK ? 4 : (bpt < DENSE_BELOW ? 3 : 2);
+            if (choice == 4) {
+                // the first chunk was filled under the undecided limits (<= 256 tasks, 32 KiB, nothing fused): its descriptors go
+                // back and are cut again as wave chunks
+                const std::vector<uint64_t> held(desc.begin() + int64_t(open_begin_), desc.end());
+                desc.resize(open_begin_);
+                arena_cursor_ = open_dst_;
+                open_n_ = 0; open_bytes_ = 0; open_desc_ = 0; open_fused_ = false;
+                set_kernel(4);
+                for (uint64_t d : held) push(desc_space(d), desc_src(d), desc_len(d));
+                close_chunk();
+                return;
+            }
+            kernel_choice = choice;
+        }
         const bool to_dense = kernel_choice == 3, to_wave = kernel_choice == 4;
         const bool to_long = !to_dense && !to_wave && (open_fused_ || (open_n_ <= 2u * CHUNK_TASKS && (kernel_choice == 1 || (kernel_choice == 0 && long_run_mode()))));
         chunks.push_back(Chunk{open_begin_, (open_dst_ & DST_MASK) | (uint64_t(open_desc_) << 48) | (to_long ? CHUNK_LONG : 0ull)
@@ -528,7 +549,7 @@ V2P_HOST_DEVICE inline uint8_t xcd_sub_window(uint64_t key, uint32_t slice, uint
 // each L2 (measured on C2: HBM fetch 7.2 GB -> 0.6 GB per pass).  Placement only changes
 // speed, never results: chunks are independent.
 inline void order_chunks_for_xcds(Chunk* chunks, uint64_t n_chunks, const uint64_t* desc, uint64_t n_desc,
-                                  uint64_t proteome_len, unsigned n_xcd = 8)
+                                  uint64_t proteome_len, unsigned n_xcd = 8, bool window_major = true)
 {
     if (n_chunks < 2 * n_xcd || proteome_len == 0 || n_desc == 0) return;
     std::vector<uint32_t> bucket(n_chunks);
@@ -543,7 +564,7 @@ inline void order_chunks_for_xcds(Chunk* chunks, uint64_t n_chunks, const uint64
         const uint64_t per = (proteome_len + n_xcd - 1) / n_xcd;
         uint64_t b = key / per;
         bucket[c] = uint32_t(b < n_xcd ? b : n_xcd - 1);
-        sub[c] = xcd_sub_window(key, bucket[c], per);
+        sub[c] = window_major ? xcd_sub_window(key, bucket[c], per) : 0;
         ++count[bucket[c]];
     }
     // rank inside the bucket, then interleave: sort key = (rank, bucket)

@@ -24,6 +24,7 @@
 // ever read or written outside the buffers (sources carry PAD_BYTES of readable slack, as for the other kernels).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "stitch_kernels.h"
 #include "stitch_device.hpp"
 
@@ -117,7 +118,8 @@ __global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __
                                                             uint32_t n_chunks, uint64_t n_desc, uint64_t src0_len, uint64_t src1_len, uint64_t out_len)
 {
     constexpr uint32_t ROWS = CHUNK_BYTES_WAVE / 1024u;              // 1 KiB rows of a chunk: all gathered before the first store
-    static_assert(ROWS == 8, "the patch indices of a lane's eight blocks are packed into two registers");
+    static_assert(ROWS % 4u == 0u && ROWS <= 16u, "a lane's map bytes and patch indices are packed four rows to a register");
+    constexpr uint32_t ND = ROWS / 4u;                               // map dwords per lane (ROWS one-byte counters)
     struct WaveLds {
         uint32_t map32[CHUNK_BYTES_WAVE / 64u];                      // one byte per 16-byte block: record covering its first byte
         WRec rec[CHUNK_TASKS_WAVE + 4];                              // + sentinels
@@ -161,7 +163,8 @@ __global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __
         }
         s_sel[lane - 32u] = sel;
     }
-    reinterpret_cast<uint64_t*>(L.map32)[lane] = 0ull;
+#pragma unroll
+    for (uint32_t k = 0; k < ND; ++k) L.map32[ND * lane + k] = 0u;
 
     // ---- A: lane = descriptor -> one record ----
     const uint64_t dots16 = reinterpret_cast<uint64_t>(p_dots) + 32u;
@@ -231,17 +234,21 @@ __global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __
     const u32x4 g2 = wgather(PG && need2 && !(tn.lit & WREC_IMM) ? wrec_adj(tn) + sb16 : dots16, chk, 2u);
     const u32x4 g3 = wgather(PG && lit_owner ? adj + lb16 : dots16, chk, 3u);
 
-    // ---- C: block map = inclusive prefix sum of the marks; 8 one-byte counters per lane (a chunk has at most 63 marks) ----
+    // ---- C: block map = inclusive prefix sum of the marks; ROWS one-byte counters per lane (a chunk has at most 63 marks) ----
     {
-        uint64_t x = reinterpret_cast<const uint64_t*>(L.map32)[lane];
-        uint32_t y0 = uint32_t(x), y1 = uint32_t(x >> 32);
-        y0 += y0 << 8; y0 += y0 << 16;
-        y1 += y1 << 8; y1 += y1 << 16;
-        y1 += (y0 >> 24) * 0x01010101u;
-        const uint32_t tsum = y1 >> 24;
+        uint32_t y[ND];
+        uint32_t run = 0u;                                           // marks of the lane's earlier dwords, in every byte
+#pragma unroll
+        for (uint32_t k = 0; k < ND; ++k) {
+            uint32_t x = L.map32[ND * lane + k];
+            x += x << 8; x += x << 16;
+            y[k] = x + run;
+            run = (y[k] >> 24) * 0x01010101u;
+        }
+        const uint32_t tsum = run & 0xFFu;
         const uint32_t before = (wave_incl_scan(tsum) - tsum) * 0x01010101u;
-        y0 += before; y1 += before;
-        reinterpret_cast<uint64_t*>(L.map32)[lane] = (uint64_t(y1) << 32) | y0;
+#pragma unroll
+        for (uint32_t k = 0; k < ND; ++k) L.map32[ND * lane + k] = y[k] + before;
     }
     // ---- P, second half: merge, place the replaced residues (a record's residue lies inside its own range: it survives the
     //      merges), park ----
@@ -272,33 +279,39 @@ __global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __
     // ---- K: lane = block.  Look-ups (LDS only), the eight gathers back to back, then per row: patch select, store. ----
     const uint8_t* const map8 = reinterpret_cast<const uint8_t*>(L.map32);
     uint8_t* const out0 = p_out + (dst - head);                      // 16-byte aligned
-    uint32_t rr[ROWS];
-#pragma unroll
-    for (uint32_t j = 0; j < ROWS; ++j) {
-        const uint32_t b16 = (j << 10) + (lane << 4);
-        rr[j] = b16 < ptotal ? uint32_t(map8[b16 >> 4]) : n;         // idle lanes look at a sentinel (dots)
-    }
-    // the eight records first (they land in the registers the gathers will fill), then per row: classify, gather
+    // per group of four rows: the map bytes, the four records (they land in the registers the gathers will fill), then per row:
+    // classify, gather
     u32x4 v[ROWS];
-#pragma unroll
-    for (uint32_t j = 0; j < ROWS; ++j) v[j] = reinterpret_cast<const u32x4*>(L.rec)[rr[j]];     // (one 16-byte read: field by field, the address half is sunk into a branch)
-    uint32_t pk[2] = {0u, 0u};                                       // patch index of the lane's block in row j: byte j & 3 of pk[j >> 2] (0: none)
+    uint32_t pk[ND];                                                 // patch index of the lane's block in row j: byte j & 3 of pk[j >> 2] (0: none)
     const uint32_t lane16 = lane << 4;
 #pragma unroll
-    for (uint32_t j = 0; j < ROWS; ++j) {
-        const uint32_t b16 = (j << 10) + lane16;
-        const u32x4 t = v[j];
-        // a record ends inside the block: the block the next record parked; a replaced residue inside it: the block its record
-        // parked.  Such a lane gathers the dots and takes the parked block afterwards.  (Every arm a ready value: selects, no branch.)
-        const bool cut = (t[2] >> 16) < b16 + 16u, parked = cut || (t[3] & 0xFFFFu) - b16 < 16u;
-        const uint64_t A = ((uint64_t(t[1]) << 32) | t[0]) + b16;
-        // (an immediate record has no address: it can only "cover" the ragged head block of a chunk, which is not stored from here)
-        const uint64_t X = (parked || (t[3] & WREC_IMM) || (V2P_WAVE_ABLATE & 1)) ? dots16 : A;
-        const uint32_t i_cut = rr[j] + 1u, i_lit = rr[j] + CHUNK_TASKS_WAVE;
-        const uint32_t i_any = cut ? i_cut : i_lit;
-        const uint32_t idx = parked ? i_any : 0u;
-        pk[j >> 2] |= idx << (8u * (j & 3u));
-        v[j] = wgather(X, chk, 5u);
+    for (uint32_t g = 0; g < ND; ++g) {
+        uint32_t rr[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            const uint32_t b16 = ((4u * g + q) << 10) + lane16;
+            rr[q] = b16 < ptotal ? uint32_t(map8[b16 >> 4]) : n;     // idle lanes look at a sentinel (dots)
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) v[4u * g + q] = reinterpret_cast<const u32x4*>(L.rec)[rr[q]];   // (one 16-byte read: field by field, the address half is sunk into a branch)
+        uint32_t pkg = 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            const uint32_t j = 4u * g + q, b16 = (j << 10) + lane16;
+            const u32x4 t = v[j];
+            // a record ends inside the block: the block the next record parked; a replaced residue inside it: the block its record
+            // parked.  Such a lane gathers the dots and takes the parked block afterwards.  (Every arm a ready value: selects, no branch.)
+            const bool cut = (t[2] >> 16) < b16 + 16u, parked = cut || (t[3] & 0xFFFFu) - b16 < 16u;
+            const uint64_t A = ((uint64_t(t[1]) << 32) | t[0]) + b16;
+            // (an immediate record has no address: it can only "cover" the ragged head block of a chunk, which is not stored from here)
+            const uint64_t X = (parked || (t[3] & WREC_IMM) || (V2P_WAVE_ABLATE & 1)) ? dots16 : A;
+            const uint32_t i_cut = rr[q] + 1u, i_lit = rr[q] + CHUNK_TASKS_WAVE;
+            const uint32_t i_any = cut ? i_cut : i_lit;
+            const uint32_t idx = parked ? i_any : 0u;
+            pkg |= idx << (8u * q);
+            v[j] = wgather(X, chk, 5u);
+        }
+        pk[g] = pkg;
     }
     // whole blocks of the chunk leave as 16-byte stores of a buffer resource over the chunk's result range: a lane outside it
     // (ragged edge blocks, rows past the chunk's end) gets an out-of-range offset and the hardware drops its store -- no branch
@@ -314,7 +327,10 @@ __global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __
         // (soffset stays the immediate 0: with an SGPR there, hipcc (ROCm 7.2) leaves out the wait states between a dwordx4 store and
         // a VALU write to its data registers -- seen on gfx950: "buffer_store_dwordx4 v[10:13], .., s6 offen" followed at once by
         // "v_mov_b32 v10, 0" stored a zero first dword in the last four lanes of every row of sixteen)
-        __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, int(off + (j << 10)), 0, NT ? 2 : 0);
+        #ifndef V2P_WAVE_STORE_AUX
+#define V2P_WAVE_STORE_AUX 2                                         /* nt */
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, int(off + (j << 10)), 0, NT ? V2P_WAVE_STORE_AUX : 0);
     }
     // ragged first / last block of a chunk whose cut is not 16-byte aligned (rare): one lane each, byte stores
     if (lane < 2u) {
@@ -340,12 +356,22 @@ __global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __
 hipError_t launch_stitch_wave(const StitchArgs& a, hipStream_t stream, bool nt, int waves_per_group)
 {
     if (a.n_chunks == 0) return hipSuccess;
-#define V2P_LW(WW, NTT) hipLaunchKernelGGL((stitchw_kernel<WW, NTT>), dim3((a.n_chunks + (WW) - 1u) / (WW)), dim3(64 * (WW)), 0, stream, \
-        a.desc, a.chunks, a.src0, a.src1, a.out, a.status, a.dots, a.n_chunks, a.n_desc, a.src0_len, a.src1_len, a.out_len)
-    if (waves_per_group == 4) { if (nt) V2P_LW(4, true); else V2P_LW(4, false); }
-    else if (waves_per_group == 2) { if (nt) V2P_LW(2, true); else V2P_LW(2, false); }
-    else { if (nt) V2P_LW(1, true); else V2P_LW(1, false); }
+    // (one launch.  Sub-launches of 8 Ki ... 128 Ki chunks -- the waves of a fresh launch read their descriptors together and store
+    // together, which a bare copy kernel rewards: tools/wave_copy_bench.py -- cost this kernel 1 ... 17 %: V2P_WAVE_SUB, experiments only)
+    uint32_t sub = 0;
+    if (const char* e = getenv("V2P_WAVE_SUB")) sub = uint32_t(strtoul(e, nullptr, 10));
+    if (sub == 0 || sub > a.n_chunks) sub = a.n_chunks;
+    sub = (sub + 7u) & ~7u;                                          // (keeps workgroup b on the XCD the chunk order dealt chunk b to)
+    for (uint32_t c0 = 0; c0 < a.n_chunks; c0 += sub) {
+        const uint32_t nc = a.n_chunks - c0 < sub ? a.n_chunks - c0 : sub;
+        const Chunk* ch = a.chunks + c0;
+#define V2P_LW(WW, NTT) hipLaunchKernelGGL((stitchw_kernel<WW, NTT>), dim3((nc + (WW) - 1u) / (WW)), dim3(64 * (WW)), 0, stream, \
+        a.desc, ch, a.src0, a.src1, a.out, a.status, a.dots, nc, a.n_desc, a.src0_len, a.src1_len, a.out_len)
+        if (waves_per_group == 4) { if (nt) V2P_LW(4, true); else V2P_LW(4, false); }
+        else if (waves_per_group == 2) { if (nt) V2P_LW(2, true); else V2P_LW(2, false); }
+        else { if (nt) V2P_LW(1, true); else V2P_LW(1, false); }
 #undef V2P_LW
+    }
     return hipGetLastError();
 }
 

@@ -660,6 +660,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     if (b->hap_open || b->img.n_haplotypes()) return c->fail(V2P_ERR_STATE, "the batch already holds host-built haplotypes");
     if (window_bytes == 0 || window_bytes % 4096u || window_bytes > CHUNK_BYTES - 4080u) return c->fail(V2P_ERR_INVALID_ARG, "window_bytes must be a multiple of 4096, at most 61440");
     if (kernel == 1 && window_bytes > CHUNK_BYTES_LONG) return c->fail(V2P_ERR_INVALID_ARG, "the long-run kernel takes windows of at most 32768 bytes");
+    if (kernel == 4 && window_bytes > CHUNK_BYTES_WAVE) return c->fail(V2P_ERR_INVALID_ARG, "a wave image takes windows of 4096 or 8192 bytes (one chunk = eight 1 KiB rows of one wave)");
     // (a grid chunk starts on a multiple of 4096: no 16-byte phase, so 12288 bytes fill the kernel's LDS image exactly)
     if (kernel == 3 && window_bytes > 12288u) return c->fail(V2P_ERR_INVALID_ARG, "a dense image takes windows of 4096, 8192 or 12288 bytes (one chunk = one 12 KiB LDS image)");
     if (!s->hap_tx_begin || (s->n_tx && (!s->tx_proteome_off || !s->tx_ref_len || !s->tx_res_len || !s->tx_task_begin || !s->tx_alt_begin)) ||
@@ -733,7 +734,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     a.tx_task_begin = reinterpret_cast<const uint64_t*>(d + o_tb); a.tx_alt_begin = reinterpret_cast<const uint64_t*>(d + o_ab);
     a.code = d + o_code; a.start_pos = reinterpret_cast<const uint32_t*>(d + o_sp); a.length = reinterpret_cast<const uint32_t*>(d + o_ln);
     a.start_pos_res = reinterpret_cast<const uint32_t*>(d + o_sr); a.alt = b->d_payload.ptr();
-    a.proteome_len = c->proteome_len; a.window = window_bytes; a.long_run = kernel == 1; a.dense = kernel == 3;
+    a.proteome_len = c->proteome_len; a.window = window_bytes; a.long_run = kernel == 1 || kernel == 4; a.dense = kernel == 3; a.wave = kernel == 4;
     a.tx_res_base = reinterpret_cast<const uint64_t*>(d + o_base); a.tx_desc_count = reinterpret_cast<uint32_t*>(d + o_cnt);
     a.desc_base = reinterpret_cast<const uint64_t*>(d + o_dbase); a.meta = reinterpret_cast<uint32_t*>(d + o_meta);
     a.status = reinterpret_cast<unsigned long long*>(b->d_status.ptr());
@@ -797,7 +798,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     if (build_ms) *build_ms = ms;
     b->n_desc = n_desc; b->n_chunks = n_windows; b->n_payload = s->n_alt; b->out_bytes = out_bytes; b->n_haps = n_h;
     const int tpt = meta[3] <= 256u ? 1 : (meta[3] <= 512u ? 2 : 4);
-    b->launch_hint = ((meta[0] & 2u) ? 2 : 0) | ((meta[0] & 1u) ? 0 : 16) | (meta[2] ? 0 : 32) | ((meta[1] ? 2 : 1) << 6) | (tpt << 8);
+    b->launch_hint = ((meta[0] & 2u) ? 2 : 0) | ((meta[0] & 4u) ? 4 : 0) | ((meta[0] & 1u) ? 0 : 16) | (meta[2] ? 0 : 32) | ((meta[1] ? 2 : 1) << 6) | (tpt << 8);
     b->uses_proteome = true;
     b->finalized = true;
     return V2P_OK;
@@ -1136,7 +1137,8 @@ int v2p_stitch_launch_bits(const v2p_chunk* chunks, uint64_t n_chunks)
 int v2p_order_chunks_for_xcds(v2p_chunk* chunks, uint64_t n_chunks, const uint64_t* desc, uint64_t n_desc, uint64_t proteome_len)
 {
     if ((n_chunks && !chunks) || (n_desc && !desc)) return V2P_ERR_INVALID_ARG;
-    order_chunks_for_xcds(reinterpret_cast<Chunk*>(chunks), n_chunks, desc, n_desc, proteome_len);
+    const char* e = getenv("V2P_ORDER_WINDOWS");                   // (experiments: 0 = haplotype-major inside a slice)
+    order_chunks_for_xcds(reinterpret_cast<Chunk*>(chunks), n_chunks, desc, n_desc, proteome_len, 8, !(e && e[0] == '0'));
     return V2P_OK;
 }
 
