@@ -211,14 +211,20 @@ def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests, dense=
         same = None
         exec_ms = None
         if want_digests is not None:
+            import torch
             b.execute()
             b.sync()
             same = bool(np.array_equal(b.digests(), want_digests))
-            t0 = time.perf_counter()
-            for _ in range(5):
+            ts = torch.cuda.current_stream()
+            ctx.set_stream(ts.cuda_stream)                       # HIP events on the stream the kernel is launched on
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+            for e0, e1 in evs:
+                e0.record(ts)
                 b.execute()
+                e1.record(ts)
             b.sync()
-            exec_ms = (time.perf_counter() - t0) * 1e3 / 5
+            exec_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
+            ctx.set_stream(0)
         b.close()
     res = {"build_kernels_ms": ms, "call_s_incl_h2d_of_the_stream": t_call, "stream_bytes": stream.nbytes, "stream_generation_s": t_stream,
            "window_bytes": window, "descriptors": cn["n_desc"], "chunks": cn["n_chunks"], "digests_equal_host_built_image": same,
@@ -259,7 +265,10 @@ def main():
     from vcf2prot_amd import build
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     if local_rank == 0:
-        build.build_all()
+        if args.dry_run:
+            build.build_cohort()                               # host logic only: no hipcc, no HIP runtime
+        else:
+            build.build_all()
         if args.verify != "none" or not args.no_cpu_baseline:
             import sir_oracle
             sir_oracle.build_c_oracle()
@@ -268,7 +277,8 @@ def main():
     from vcf2prot_amd import _native as N
     from vcf2prot_amd.cohort import Cohort
     from vcf2prot_amd.shard import shard_by_bytes
-    lib = None if args.dry_run else N.hip_lib()
+    # (--dbg: timing-only ablations live in libv2p_bench.so, the V2P_BENCH_VARIANTS build of the engine)
+    lib = None if args.dry_run else (N.bench_lib() if args.dbg else N.hip_lib())
 
     # ---- synthetic cohort at the Task boundary; this rank's shard --------------------
     samples = args.samples or DEFAULT_SAMPLES[args.scaling][args.workload]
@@ -284,7 +294,7 @@ def main():
         h0, h1 = shard_by_bytes(sizes.tolist(), world)[rank]              # equal result bytes per rank
     t_gen = time.perf_counter()
     img = cohort.pack(h0, h1, n_threads=min(n_threads, 64), chunk_tasks=args.chunk_tasks, chunk_bytes=args.chunk_bytes, fasta=args.fasta, cut_align=args.cut_align,
-                      fuse=not args.no_fuse and args.var not in (1, 2, 3), kernel=2 if args.var in (1, 2, 3) else args.kernel)
+                      fuse=not args.no_fuse and args.var not in (1, 2, 3) and not args.max_blocks, kernel=2 if (args.var in (1, 2, 3) or args.max_blocks) else args.kernel)
     t_gen = time.perf_counter() - t_gen
     A, NT = img.n_copy_bytes, img.n_tasks
     b_alg = 2 * A + 16 * NT

@@ -128,6 +128,9 @@ int  v2p_cohort_pack_grid(const v2p_cohort* c, uint64_t h0, uint64_t h1, uint32_
  * header of (transcript t, parity p) at 1 + (2*t + p) * 19.  Returns the bytes needed; fills `out` when cap suffices. */
 uint64_t v2p_cohort_fasta_headers(const v2p_cohort* c, uint8_t* out, uint64_t cap);
 void v2p_packed_free(v2p_packed_image* img);
+/* host-only twin of v2p_stitch_launch_bits() (include/vcf2prot_hip.h): which stitch kernels a chunk table needs -- so that host-side
+ * tools and CPU tests need neither hipcc nor a HIP runtime to look at an image */
+int  v2p_cohort_launch_bits(const v2p_chunk* chunks, uint64_t n_chunks);
 
 #ifdef __cplusplus
 }

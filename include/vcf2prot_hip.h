@@ -61,7 +61,7 @@ typedef struct v2p_ctx v2p_ctx;
 typedef struct v2p_batch v2p_batch;
 
 /* 16-byte work item of the device image (see vcf2prot_amd/csrc/sir_pack.hpp): first descriptor; result offset (48 bits) |
- * descriptor count (11 bits) | kernel routing flags (top 2 bits, set by the image builder) */
+ * descriptor count (11 bits) | kernel routing flags (bits 60..63, set by the image builder) */
 typedef struct { uint64_t task_begin; uint64_t dst_n; } v2p_chunk;
 
 /* ---- library / context ------------------------------------------------------- */
@@ -188,7 +188,11 @@ typedef struct {
 } v2p_txstream;
 /* kernel: 1 = route every chunk to the long-run kernel (<= 512 descriptors per window), 2 = per-block kernel, 3 = dense image
  * (stitch_dense_kernel: short tasks, fused substitutions, <= 1024 descriptors per window: windows of 4, 8 or 12 KiB, larger ones are
- * V2P_ERR_INVALID_ARG).
+ * V2P_ERR_INVALID_ARG), 4 = wave image (stitchw_kernel, one wave per window: windows of 4 or 8 KiB with <= 64 descriptors each,
+ * fused substitutions; the choice for long reference runs).
+ * The offset tables of the stream are checked on the host before anything is uploaded (ascending from 0, inside their arrays):
+ * V2P_ERR_INVALID_ARG with the offending index.  A window that holds more descriptors than its kernel takes is
+ * V2P_ERR_UNSUPPORTED and leaves the batch empty: call again with a smaller window.
  * On success the batch is finalized (execute / sync / download / digests work as after v2p_batch_finalize).
  * *build_ms (optional): time of the build kernels alone (two HIP event brackets: counting passes, emitting passes; not the
  * allocation of the image in between), the stream already on the device. */
@@ -203,8 +207,9 @@ int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, ui
  * with bit 61 = a fused substitution (src:29 | len1:12 | len2:12 | byte:8: copy, one literal byte, copy one residue on;
  * long-run and dense chunks only); space 3 with bits 61..60 = 01 = two substitutions in a row (src:29 | len1:5 | len2:5 | len3:5 |
  * byte1:8 | byte2:8; dense chunks only).  Chunks: {first descriptor, result offset:48 | descriptors:11 | flags: bit 63 long-run
- * (stitch4_kernel), bit 62 long-run with 257..512 tasks, bit 61 dense (stitch_dense_kernel)}.  A descriptor a chunk's kernel does
- * not know is reported (source out of bounds) and the chunk is not executed. */
+ * (stitch4_kernel), bit 62 long-run with 257..512 tasks, bit 61 dense (stitch_dense_kernel), bit 60 wave (stitchw_kernel: at most 64
+ * descriptors and 8192 result bytes incl. the 16-byte phase of its offset, fused substitutions allowed)}.  A descriptor a chunk's
+ * kernel does not know is reported (source out of bounds) and the chunk is not executed. */
 int v2p_batch_set_packed(v2p_batch* b,
                          const uint64_t* desc, uint64_t n_desc,
                          const v2p_chunk* chunks, uint64_t n_chunks,
@@ -251,16 +256,19 @@ int  v2p_pipeline_release(v2p_pipeline* p, uint32_t ticket);
 /* src0/src1 must have 32 readable bytes before and after (the kernel loads whole aligned 16-byte
  * blocks around a task's bytes); out must be 16-byte aligned; status is one device uint64 initialised
  * to ~0; chunks that point outside d_desc[0, n_desc) are reported in it, never followed.
- * `nontemporal`: bit 0 non-temporal result stores | v2p_stitch_launch_bits() of the (host copy of the) chunk table. */
+ * `nontemporal`: bit 0 non-temporal result stores | v2p_stitch_launch_bits() of the (host copy of the) chunk table -- the bits say
+ * which kernels have work; a chunk whose kernel is not named by them is not executed.  max_blocks != 0 caps the grid of the
+ * per-block kernel (persistent workgroups) and is refused for images with long-run, dense or wave chunks. */
 int v2p_stitch_launch(void* hip_stream,
                       const uint64_t* d_desc, uint64_t n_desc, const v2p_chunk* d_chunks, uint32_t n_chunks,
                       const uint8_t* d_src0, uint64_t src0_len,
                       const uint8_t* d_src1, uint64_t src1_len,
                       uint8_t* d_out, uint64_t out_len,
                       uint64_t* d_status, int nontemporal, uint32_t max_blocks);
-/* Host-side: which stitch kernels a chunk table needs and their tasks per lane (bits 4..11 of `nontemporal`): long-run chunks go to
- * stitch4_kernel, the others to stitch_kernel (per block) or, when chunks hold more than 512 descriptors (short tasks), to
- * stitch_dense_kernel.  A chunk flagged dense (bit 61 of dst_n) must hold at most 12288 bytes of result incl. its 16-byte phase --
+/* Host-side: which stitch kernels a chunk table needs and their tasks per lane (bits 1..11 of `nontemporal`: bit 1 dense chunks,
+ * bit 2 wave chunks, bit 4 no long-run chunk, bit 5 no per-block chunk, 6..7 / 8..11 tasks per lane): wave chunks go to
+ * stitchw_kernel, long-run chunks to stitch4_kernel, the others to stitch_kernel (per block) or, when chunks hold more than 512
+ * descriptors (short tasks), to stitch_dense_kernel.  A chunk flagged dense (bit 61 of dst_n) must hold at most 12288 bytes of result incl. its 16-byte phase --
  * the kernel's LDS image; the builders never make a larger one, and the kernel refuses one (status: result out of bounds) rather
  * than executing it. */
 int v2p_stitch_launch_bits(const v2p_chunk* chunks, uint64_t n_chunks);
@@ -270,27 +278,6 @@ int v2p_order_chunks_for_xcds(v2p_chunk* chunks, uint64_t n_chunks, const uint64
                               uint64_t proteome_len);
 int v2p_digest_launch(void* hip_stream, const uint8_t* d_out, const uint64_t* d_hap_begin, uint64_t n_haps,
                       uint64_t out_bytes, uint64_t* d_digests);
-int v2p_fill_launch(void* hip_stream, uint8_t* d_out, uint64_t bytes, uint32_t word, int nontemporal);
-/* microbenchmark: `blocks` workgroups x 4 waves each issue `iters` 16-byte-per-lane gathers (1 KiB per wave
- * instruction) from a window of `window` bytes at byte misalignment `misalign` (0 = aligned); d_sink: one u32 per wave */
-/* microbenchmark: the stitch kernel's data movement without its bookkeeping -- a cache-resident window of `window` bytes
- * (>= 1 MiB + 64 KiB, 64 readable bytes of slack around it) read at byte misalignment `shift` and streamed into d_out with
- * non-temporal stores; mode 0 byte-granular gathers, 1 aligned loads + lane exchange, 2 two aligned loads, 3 dword-aligned
- * loads, 4 stores only, 5 loads only; d_sink: one u32 per 32 KiB of d_out */
-int v2p_copy_bench_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t shift, uint8_t* d_out, uint64_t bytes,
-                          int mode, uint32_t* d_sink);
-/* microbenchmark: the same copy with persistent workgroups (`grid` of them) whose per-span "descriptor" (desc_bytes = 8, 4 or 0
- * bytes per lane, streamed from HBM behind d_out) is requested `depth` spans before it is used */
-int v2p_copy_prefetch_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t shift, uint8_t* d_out, uint64_t bytes,
-                             int depth, int desc_bytes, uint32_t grid);
-/* microbenchmark: the copy of v2p_copy_bench_launch (mode 0) plus a streamed read of `bytes_per_lane` (4, 8, 16) bytes per lane by
- * every `every`-th workgroup from d_desc (pieces `stride` bytes apart); flags bit 0 non-temporal loads, bit 1 one wave only,
- * bit 2 read issued after the first store */
-int v2p_copy_mix_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t shift, uint8_t* d_out, uint64_t bytes,
-                        const uint8_t* d_desc, uint32_t bytes_per_lane, uint32_t every, uint32_t stride, uint32_t flags);
-int v2p_gather_bench_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t misalign, uint32_t iters,
-                            uint32_t blocks, uint32_t* d_sink);
-
 #ifdef __cplusplus
 }
 #endif

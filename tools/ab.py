@@ -73,7 +73,8 @@ def main():
     a = ap.parse_args()
     if a.lib:
         N.HIP_LIB_PATH = os.path.abspath(a.lib)
-    lib = N.hip_lib()
+    # timing-only ablations (dbg=N: results are wrong) exist only in libv2p_bench.so, the V2P_BENCH_VARIANTS build of the engine
+    lib = N.bench_lib() if (not a.lib and any("dbg=" in v for v in a.variants)) else N.hip_lib()
     dev = torch.device("cuda", 0)
     over = {}
     if a.mean_len:

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--json", default="")
     a = ap.parse_args()
-    lib = N.hip_lib()
+    lib = N.bench_lib()
     dev = torch.device("cuda", 0)
     nbytes = int(a.gb * (1 << 30)) // (32 << 10) * (32 << 10)
     window = int(a.window_mb * (1 << 20))

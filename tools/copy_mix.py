@@ -12,7 +12,7 @@ import torch  # noqa: E402
 
 from vcf2prot_amd import _native as N  # noqa: E402
 
-lib = N.hip_lib()
+lib = N.bench_lib()
 dev = torch.device("cuda", 0)
 gb = float(sys.argv[1]) if len(sys.argv) > 1 else 8.0
 nbytes = int(gb * (1 << 30)) // (240 * (32 << 10)) * (240 * (32 << 10))      # whole 'haplotypes' of 240 spans

@@ -4,7 +4,7 @@ import ctypes, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vcf2prot_amd import _native as N
-lib = N.hip_lib()
+lib = N.bench_lib()
 window = 8 << 20
 src = torch.randint(0, 255, (window + 4096,), dtype=torch.uint8, device="cuda")
 blocks, iters = 2048, 2048

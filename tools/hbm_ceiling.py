@@ -28,7 +28,7 @@ def timed(fn, reps=10):
 
 
 def main():
-    lib = N.hip_lib()
+    lib = N.bench_lib()
     gb = float(sys.argv[1]) if len(sys.argv) > 1 else 16.0
     n = int(gb * 1e9) // 16 * 16
     out = torch.empty(n, dtype=torch.uint8, device="cuda")

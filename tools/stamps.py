@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from vcf2prot_amd import _native as N
 from vcf2prot_amd.cohort import Cohort
-lib = N.hip_lib(); dev = torch.device("cuda", 0)
+lib = N.bench_lib(); dev = torch.device("cuda", 0)      # (s_memtime stamps are a V2P_BENCH_VARIANTS instantiation)
 wl = sys.argv[1] if len(sys.argv) > 1 else "C2"
 c = Cohort.preset(wl, n_samples=int(sys.argv[2]) if len(sys.argv) > 2 else 1000)
 var = int(sys.argv[3]) if len(sys.argv) > 3 else 0

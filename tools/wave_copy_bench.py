@@ -14,16 +14,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SRC = os.path.join(ROOT, "vcf2prot_amd", "csrc", "bench", "wave_copy_bench.hip")
-LIB = os.path.join(ROOT, "build_ab", "libv2p_wavebench.so")
-
-
-def build():
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", SRC, "-o", LIB])
-    return LIB
-
 
 def main():
     ap = argparse.ArgumentParser()
@@ -33,7 +23,8 @@ def main():
     ap.add_argument("--json", default="")
     ap.add_argument("--build-only", action="store_true")
     a = ap.parse_args()
-    path = build()
+    from vcf2prot_amd import build as B
+    path = B.build_bench()
     if a.build_only:
         return
     import torch                                   # (first: the library then binds to the HIP runtime torch has loaded)

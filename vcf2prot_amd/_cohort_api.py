@@ -67,6 +67,7 @@ COHORT_API = {
     "v2p_cohort_fasta_headers": (c_uint64, [c_void_p, c_void_p, c_uint64]),
     "v2p_cohort_result_sizes": (c_int, [c_void_p, c_uint64, c_uint64, c_int, c_void_p]),
     "v2p_packed_free": (None, [POINTER(PackedImage)]),
+    "v2p_cohort_launch_bits": (c_int, [c_void_p, c_uint64]),
     "v2p_cohort_txstream": (c_int, [c_void_p, c_uint64, c_uint64, c_int, POINTER(TxStreamBuf)]),
     "v2p_txstream_free": (None, [POINTER(TxStreamBuf)]),
     "v2p_cohort_pack_grid": (c_int, [c_void_p, c_uint64, c_uint64, c_uint32, c_int, POINTER(PackedImage)]),

@@ -78,14 +78,9 @@ HIP_API = {
     "v2p_pipeline_release": (c_int, [c_void_p, c_uint32]),
     "v2p_stitch_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, c_uint64,
                                   c_void_p, c_uint64, c_void_p, c_int, c_uint32]),
-    "v2p_copy_prefetch_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int, c_int, c_uint32]),
-    "v2p_copy_mix_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_void_p, c_uint32, c_uint32, c_uint32, c_uint32]),
-    "v2p_copy_bench_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int, c_void_p]),
     "v2p_stitch_launch_bits": (c_int, [c_void_p, c_uint64]),
     "v2p_order_chunks_for_xcds": (c_int, [c_void_p, c_uint64, c_void_p, c_uint64, c_uint64]),
     "v2p_digest_launch": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
-    "v2p_gather_bench_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_uint32, c_uint32, c_void_p]),
-    "v2p_fill_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_int]),
 }
 
 _hip = None
@@ -110,6 +105,29 @@ def hip_lib():
                 "(the gpu engine has no CPU fallback)")
         _hip = _bind(ctypes.CDLL(HIP_LIB_PATH), HIP_API)
     return _hip
+
+
+BENCH_LIB_PATH = os.path.join(_PKG, "lib", "libv2p_bench.so")
+BENCH_API = {
+    "v2p_copy_prefetch_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int, c_int, c_uint32]),
+    "v2p_copy_mix_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_void_p, c_uint32, c_uint32, c_uint32, c_uint32]),
+    "v2p_copy_bench_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int, c_void_p]),
+    "v2p_gather_bench_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_uint32, c_uint32, c_void_p]),
+    "v2p_fill_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_int]),
+}
+_bench = None
+
+
+def bench_lib():
+    """libv2p_bench.so (development tools): the micro-benchmarks of csrc/bench/ plus a V2P_BENCH_VARIANTS build of the engine, whose
+    v2p_stitch_launch takes the timing-only ablation bits.  Binds the engine's API too, so a tool can use it in place of hip_lib()."""
+    global _bench
+    if _bench is None:
+        if not os.path.exists(BENCH_LIB_PATH):
+            from . import build
+            build.build_bench()
+        _bench = _bind(_bind(ctypes.CDLL(BENCH_LIB_PATH), HIP_API), BENCH_API)
+    return _bench
 
 
 def cohort_lib():

@@ -75,6 +75,24 @@ def build_cohort(force: bool = False, verbose: bool = False) -> str:
     return COHORT_LIB
 
 
+BENCH_LIB = os.path.join(LIBDIR, "libv2p_bench.so")
+BENCH_SOURCES = HIP_SOURCES + [os.path.join("bench", "bench_kernels.hip"), os.path.join("bench", "wave_copy_bench.hip")]
+BENCH_DEPS = HIP_DEPS + [os.path.join("bench", "bench_kernels.hip"), os.path.join("bench", "wave_copy_bench.hip"), os.path.join("bench", "v2p_bench.h")]
+
+
+def build_bench(force: bool = False, verbose: bool = False) -> str:
+    """Development tools only (tools/*.py): the micro-benchmarks of csrc/bench/ and a V2P_BENCH_VARIANTS build of the engine that
+    accepts the timing-only kernel ablations.  Nothing in the package or the tests loads it."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    if force or _stale(BENCH_LIB, BENCH_DEPS):
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-DV2P_BENCH_VARIANTS",
+               *[os.path.join(CSRC, s) for s in BENCH_SOURCES], "-o", BENCH_LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return BENCH_LIB
+
+
 HARNESS_BIN = os.path.join(LIBDIR, "v2p_harness")
 HARNESS_DEPS = [os.path.join("host", "v2p_harness.cpp"), os.path.join("host", "ppgg_gpu.hpp"),
                 os.path.join(ROOT, "include", "vcf2prot_hip.h"), os.path.join(ROOT, "include", "v2p_cohort.h"),
@@ -97,6 +115,7 @@ def build_harness(force: bool = False, verbose: bool = False) -> str:
 def build_all(force: bool = False, verbose: bool = False):
     libs = build_hip(force, verbose), build_cohort(force, verbose)
     build_harness(force, verbose)
+    build_bench(force, verbose)
     return libs
 
 

@@ -62,7 +62,8 @@ class Packed:
     def launch_bits(self) -> int:
         """Bits 4..11 of v2p_stitch_launch's flags: which kernels the chunk table needs and their tasks per lane."""
         ch = np.ascontiguousarray(self.chunks)
-        return int(N.hip_lib().v2p_stitch_launch_bits(ch.ctypes.data if ch.size else None, ch.shape[0]))
+        # (the host-only twin in libv2p_cohort.so: looking at an image needs neither hipcc nor a HIP runtime)
+        return int(N.cohort_lib().v2p_cohort_launch_bits(ch.ctypes.data if ch.size else None, ch.shape[0]))
 
     @property
     def out_bytes(self) -> int:

@@ -731,6 +731,12 @@ uint64_t v2p_cohort_fasta_headers(const v2p_cohort* c, uint8_t* out, uint64_t ca
     return need;
 }
 
+int v2p_cohort_launch_bits(const v2p_chunk* chunks, uint64_t n_chunks)
+{
+    if (n_chunks && !chunks) return -1;
+    return v2p::stitch_launch_bits(reinterpret_cast<const v2p::Chunk*>(chunks), n_chunks);
+}
+
 void v2p_packed_free(v2p_packed_image* img)
 {
     if (!img) return;

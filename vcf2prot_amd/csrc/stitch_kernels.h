@@ -66,16 +66,6 @@ hipError_t launch_stitch_wave(const StitchArgs& a, hipStream_t stream, bool nt, 
 hipError_t launch_ordered(const OrderedArgs& a, hipStream_t stream);
 hipError_t launch_validate(const ValidateArgs& a, hipStream_t stream);
 hipError_t launch_digest(const DigestArgs& a, uint64_t out_bytes, hipStream_t stream);
-hipError_t launch_gather_bench(const uint8_t* src, uint64_t window, uint32_t misalign, uint32_t iters, uint32_t blocks,
-                               uint32_t* sink, hipStream_t stream);
-hipError_t launch_copy_bench(const uint8_t* src, uint64_t window, uint32_t shift, uint8_t* out, uint64_t bytes, int mode,
-                             uint32_t* sink, hipStream_t stream);
-hipError_t launch_copy_prefetch(const uint8_t* src, uint64_t window, uint32_t shift, uint8_t* out, uint64_t bytes, int depth, int desc_bytes,
-                                uint32_t grid, hipStream_t stream);
-hipError_t launch_copy_mix(const uint8_t* src, uint64_t window, uint32_t shift, uint8_t* out, uint64_t bytes, const uint8_t* dsc,
-                           uint32_t bytes_per_lane, uint32_t every, uint32_t stride, uint32_t flags, hipStream_t stream);
-hipError_t launch_fill(uint8_t* out, uint64_t bytes, uint32_t word, int nontemporal, hipStream_t stream);
-
 }  // namespace v2p
 
 namespace v2p {

@@ -1142,33 +1142,4 @@ int v2p_order_chunks_for_xcds(v2p_chunk* chunks, uint64_t n_chunks, const uint64
     return V2P_OK;
 }
 
-int v2p_gather_bench_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t misalign, uint32_t iters,
-                            uint32_t blocks, uint32_t* d_sink)
-{
-    return launch_gather_bench(d_src, window, misalign, iters, blocks, d_sink, reinterpret_cast<hipStream_t>(hip_stream)) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
-}
-
-int v2p_copy_bench_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t shift, uint8_t* d_out, uint64_t bytes,
-                          int mode, uint32_t* d_sink)
-{
-    return launch_copy_bench(d_src, window, shift, d_out, bytes, mode, d_sink, reinterpret_cast<hipStream_t>(hip_stream)) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
-}
-
-int v2p_copy_prefetch_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t shift, uint8_t* d_out, uint64_t bytes,
-                             int depth, int desc_bytes, uint32_t grid)
-{
-    return launch_copy_prefetch(d_src, window, shift, d_out, bytes, depth, desc_bytes, grid, reinterpret_cast<hipStream_t>(hip_stream)) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
-}
-
-int v2p_copy_mix_launch(void* hip_stream, const uint8_t* d_src, uint64_t window, uint32_t shift, uint8_t* d_out, uint64_t bytes,
-                        const uint8_t* d_desc, uint32_t bytes_per_lane, uint32_t every, uint32_t stride, uint32_t flags)
-{
-    return launch_copy_mix(d_src, window, shift, d_out, bytes, d_desc, bytes_per_lane, every, stride, flags, reinterpret_cast<hipStream_t>(hip_stream)) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
-}
-
-int v2p_fill_launch(void* hip_stream, uint8_t* d_out, uint64_t bytes, uint32_t word, int nontemporal)
-{
-    return launch_fill(d_out, bytes, word, nontemporal, reinterpret_cast<hipStream_t>(hip_stream)) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
-}
-
 }  // extern "C"
