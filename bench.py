@@ -7,14 +7,18 @@
 One "step" = one pass of the hot path (stitch kernel: K0 fill + K1 in-chunk scan + K2
 gather/scatter) over this rank's whole shard, inputs already resident in HBM.  At N=1 the
 workload is BASELINE.json configs[1] ("C2": 1 000 samples x 20 k transcripts x ~400 aa, one
-missense per transcript => 2 000 haplotypes, A = 1.6e10 residues, N = 1.2e8 tasks).
+missense per transcript => 2 000 haplotypes, A = 1.6e10 residues, N = 1.2e8 tasks); the same
+line carries `north_star_cohort`: configs[2] ("C3", the north star's 10 000-sample cohort,
+20 000 haplotypes, 36 GB of result) whole, in one launch, every haplotype verified.
 
 --gpus N > 1 launches itself: the parent spawns `python -m torch.distributed.run` with N ranks
 (one per GPU, RCCL) before it touches any GPU, and exits with the children's code; under an
-external launcher (RANK/WORLD_SIZE set) it just runs as a rank.
-  --scaling weak   (default) every rank executes its own `--samples`-sample shard of a samples*N cohort
+external launcher (RANK/WORLD_SIZE set) it just runs as a rank.  Its default is the north
+star's run: --workload C3 --scaling strong.
+  --scaling weak   every rank executes its own `--samples`-sample shard of a samples*N cohort (default at N = 1)
   --scaling strong one cohort of `--samples` samples (C3: the 10 000-sample cohort of the north star),
-                   cut into contiguous haplotype ranges of equal result bytes (shard.shard_by_bytes)
+                   cut into contiguous haplotype ranges of equal result bytes (shard.shard_by_bytes);
+                   rank 0 first times the whole cohort alone for `speedup_vs_1` (default at N > 1)
 Haplotypes are independent: no data-path collective; the step's only exchange is the all-gather of
 {haplotypes, result bytes} per rank.  Rank 0 prints ONE JSON line.
 """
@@ -43,8 +47,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C4", "C5"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--workload", default=None, choices=["C2", "C3", "C4", "C5"], help="default: C2 at one GPU, C3 (the north star's cohort) at several")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="default: weak at one GPU, strong at several")
+    ap.add_argument("--no-north-star", action="store_true", help="N = 1: skip the north_star_cohort leg (C3 whole, 36 GB, one launch)")
+    ap.add_argument("--no-speedup-ref", action="store_true", help="N > 1, strong scaling: do not time the whole cohort on rank 0 alone first")
     ap.add_argument("--samples", type=int, default=0, help="weak: samples per GPU; strong: samples of the whole cohort (0 = the config's own size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the transfers-inclusive leg (v2p_pipeline_*)")
@@ -234,6 +240,88 @@ def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests, dense=
     return res
 
 
+def whole_cohort_leg(workload, samples, steps, n_threads, verify_every=True, temporal=False):
+    """One GPU, one launch per step over a WHOLE cohort (no sharding, no collective): pack, upload, verify every haplotype's digest
+    against the oracle, then time `steps` launches with HIP events on the launch stream.  Used for the north star's 10 000-sample
+    cohort next to the N = 1 line and for `speedup_vs_1` of a strong-scaling run."""
+    import numpy as np
+    import torch
+    from vcf2prot_amd import _native as N
+    from vcf2prot_amd.cohort import Cohort
+    lib = N.hip_lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cohort = Cohort.preset(workload, n_samples=samples)
+    n_haps = cohort.n_haplotypes
+    t0 = time.perf_counter()
+    img = cohort.pack(0, n_haps, n_threads=min(n_threads, 64))
+    t_pack = time.perf_counter() - t0
+    proteome = cohort.proteome()
+    PAD = 64
+
+    def padded(arr):
+        t = torch.zeros(arr.size + 2 * PAD, dtype=torch.uint8, device=dev)
+        if arr.size:
+            t[PAD:PAD + arr.size] = torch.from_numpy(arr).to(dev)
+        return t
+    d_prot, d_payload = padded(proteome), padded(img.payload)
+    chunks = np.ascontiguousarray(img.chunks)
+    assert lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, proteome.size) == 0
+    d_desc = torch.from_numpy(img.desc.view(np.int64)).to(dev)
+    d_chunks = torch.from_numpy(chunks.view(np.int64)).to(dev)
+    d_hap = torch.from_numpy(img.hap_out_begin.view(np.int64)).to(dev)
+    out_bytes = img.out_bytes
+    d_out = torch.empty(out_bytes + 32, dtype=torch.uint8, device=dev)
+    d_status = torch.full((1,), -1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream()
+    flags = (0 if temporal else 1) | img.launch_bits
+
+    def launch():
+        rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), d_desc.data_ptr(), img.desc.size, d_chunks.data_ptr(), chunks.shape[0],
+                                   d_prot.data_ptr() + PAD, proteome.size, d_payload.data_ptr() + PAD, img.payload.size,
+                                   d_out.data_ptr(), out_bytes, d_status.data_ptr(), flags, 0)
+        if rc != 0:
+            raise RuntimeError(f"v2p_stitch_launch failed: {rc}")
+    launch()
+    launch()
+    torch.cuda.synchronize()
+    if int(d_status.item()) != -1:
+        raise RuntimeError(f"device reported a task error: status={int(d_status.item()):#x}")
+    d_dig = torch.zeros(n_haps, dtype=torch.int64, device=dev)
+    lib.v2p_digest_launch(ctypes.c_void_p(stream.cuda_stream), d_out.data_ptr(), d_hap.data_ptr(), n_haps, out_bytes, d_dig.data_ptr())
+    torch.cuda.synchronize()
+    dig = d_dig.cpu().numpy().view(np.uint64)
+    check = list(range(n_haps)) if verify_every else sorted(set(np.linspace(0, n_haps - 1, min(n_haps, 512)).astype(int).tolist()))
+    t_v = time.perf_counter()
+    want = oracle_digests(workload, samples, check, min(n_threads, 64))
+    bad = [h for h in check if int(dig[h]) != want[h]]
+    if bad:
+        raise RuntimeError(f"PARITY FAILURE: haplotypes {bad[:8]} of {workload} differ from the oracle ({len(bad)} of {len(check)})")
+    t_v = time.perf_counter() - t_v
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for e0, e1 in ev:
+        e0.record(stream)
+        launch()
+        e1.record(stream)
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in ev]
+    spaces = (img.desc >> np.uint64(62)).astype(np.uint8)
+    lens = ((img.desc >> np.uint64(40)) & np.uint64((1 << 22) - 1)).astype(np.int64)
+    n_fused = int(((img.desc >> np.uint64(61)) == 7).sum())
+    hbm_min = out_bytes + 8 * int(img.desc.size) + 16 * int(chunks.shape[0]) + int(lens[spaces == 1].sum()) + int(proteome.size)
+    avg = sum(ms) / len(ms)
+    bits = img.launch_bits
+    res = {"workload": f"{workload}: {samples} samples = {n_haps} haplotypes x {cohort.n_transcripts} transcripts, whole cohort in ONE launch on one GPU",
+           "aa": int(img.n_copy_bytes), "tasks": int(img.n_tasks), "result_bytes": int(out_bytes), "descriptors": int(img.desc.size),
+           "fused_substitution_descriptors": n_fused, "chunks": int(chunks.shape[0]),
+           "kernel": "stitchw_kernel" if bits & 4 else ("stitch4_kernel" if not (bits & 16) else ("stitch_dense_kernel" if bits & 2 else "stitch_kernel (per block)")),
+           "steps": steps, "ms": avg, "ms_min": min(ms), "aa_per_s": img.n_copy_bytes / (avg * 1e-3),
+           "hbm_bytes_min_per_launch": hbm_min, "achieved_GBps": hbm_min / (avg * 1e-3) / 1e9, "frac": hbm_min / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "every_haplotype": bool(len(check) == n_haps), "haplotypes_checked": len(check), "oracle_seconds": t_v, "image_build_s": t_pack}
+    del d_out, d_desc, d_chunks, d_payload, d_prot
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     args = parse_args()
     if "RANK" not in os.environ and args.gpus > 1:
@@ -242,6 +330,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
+    if args.workload is None:
+        args.workload = "C2" if world == 1 else "C3"
+    if args.scaling is None:
+        args.scaling = "weak" if world == 1 else "strong"
 
     import numpy as np
     import torch
@@ -292,6 +384,14 @@ def main():
         cohort = Cohort.preset(args.workload, n_samples=cohort_samples)
         sizes = cohort.result_sizes(0, cohort.n_haplotypes, n_threads=min(n_threads, 64))
         h0, h1 = shard_by_bytes(sizes.tolist(), world)[rank]              # equal result bytes per rank
+    speedup_ref = None
+    if world > 1 and args.scaling == "strong" and rank == 0 and not args.no_speedup_ref and not args.dry_run:
+        try:                                                   # the same cohort alone on this GPU, one launch (the 1-GPU point of the curve)
+            speedup_ref = whole_cohort_leg(args.workload, cohort_samples, max(3, min(args.steps, 10)), n_threads, verify_every=args.verify == "all")
+        except Exception as e:
+            speedup_ref = {"error": repr(e)}
+    if dist_on:
+        dist.barrier()
     t_gen = time.perf_counter()
     img = cohort.pack(h0, h1, n_threads=min(n_threads, 64), chunk_tasks=args.chunk_tasks, chunk_bytes=args.chunk_bytes, fasta=args.fasta, cut_align=args.cut_align,
                       fuse=not args.no_fuse and args.var not in (1, 2, 3) and not args.max_blocks, kernel=2 if (args.var in (1, 2, 3) or args.max_blocks) else args.kernel)
@@ -421,7 +521,7 @@ def main():
     if rank == 0:
         avg_ms = sum(kern_ms) / len(kern_ms)
         achieved = hbm_min / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
@@ -429,6 +529,8 @@ def main():
                 tj = tj.get(args.workload, tj)
                 if tj.get("workload") == args.workload and tj.get("haplotypes") == n_haps:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = ("replayed, not measured in this run: " + str(tj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command")) +
+                                      " (profiles/traffic_latest.json)")
             except Exception:
                 traffic = None
         line = {
@@ -441,7 +543,7 @@ def main():
                        "descriptor_bytes": 8, "long_run_chunks_rank0": int((img.chunks[:, 1] >> np.uint64(63)).sum()), "immediate_descriptors_rank0": n_imm, "fused_substitution_descriptors_rank0": n_fused, "descriptors_rank0": n_desc, 
                        "parallelism": f"haplotype-sharded x{world}, no data-path collective; per step one all-gather of 16 B per rank (RCCL)" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "bytes": "achieved = hbm_bytes_min / kernel time: result bytes written once + 8 B per descriptor + 16 B per chunk + alt bytes "
                                   "outside descriptors + the proteome once (reference reads are served by L2 and not counted)",
                          "hbm_bytes_min_per_launch": hbm_min,
@@ -452,6 +554,11 @@ def main():
         }
         if per_rank:
             line["per_rank"] = per_rank
+            line["world_size_seen_by_rccl"] = int(dist.get_world_size()) if dist_on else 1
+        if speedup_ref is not None:
+            line["one_gpu_reference"] = speedup_ref
+            if "ms" in speedup_ref:                              # same cohort, same step: time on one GPU / time on `world` GPUs
+                line["speedup_vs_1"] = speedup_ref["ms"] / (1e3 * elapsed / args.steps)
         if args.dry_run:
             line["data"] = "synthetic (dry run: no kernel was launched, value is meaningless)"
         # free the big device buffers before the host-side legs
@@ -472,6 +579,14 @@ def main():
                 line["device_image_build"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             line["cpu_baseline"] = cpu_baseline(cohort, h0, n_haps, os.cpu_count() or 1)
+        if world == 1 and not args.no_north_star and not args.dry_run and not args.dbg and not args.fasta and args.workload == "C2" and args.kernel == 0 and not args.var:
+            # the north star's own cohort (BASELINE.json configs[2]): 10 000 samples, whole, one launch, every haplotype verified
+            try:
+                del d_desc, d_chunks, d_payload
+                torch.cuda.empty_cache()
+                line["north_star_cohort"] = whole_cohort_leg("C3", DEFAULT_SAMPLES["strong"]["C3"], 5, n_threads, verify_every=True)
+            except Exception as e:
+                line["north_star_cohort"] = {"error": repr(e)}
         print(json.dumps(line))
     if dist_on:
         dist.barrier()

@@ -35,10 +35,21 @@ def test_strong_scaling_two_ranks_self_launch(built):
 
 
 def test_weak_scaling_two_ranks_self_launch(built):
-    two = run_bench("--gpus", "2", "--workload", "C2", "--samples", "3")
+    two = run_bench("--gpus", "2", "--workload", "C2", "--scaling", "weak", "--samples", "3")
     assert two["n_gpus"] == 2 and two["scaling"] == "weak"
     assert [r["haplotypes"] for r in two["per_rank"]] == [6, 6]
     assert "cpu_baseline" not in two                                                # rank 0 at N=1 only
+
+
+def test_several_gpus_default_to_the_north_star_run(built):
+    """--gpus N > 1 without --workload / --scaling is the north star's run: the C3 cohort, strong scaling (one cohort cut by result
+    bytes), with the per-rank table and the world size the collective saw; one GPU stays on BASELINE's configs[1] (C2)."""
+    two = run_bench("--gpus", "2", "--samples", "30")
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["workload"].startswith("C3")
+    assert two["world_size_seen_by_rccl"] == 2 and len(two["per_rank"]) == 2
+    assert sum(r["haplotypes"] for r in two["per_rank"]) == 60
+    one = run_bench("--samples", "2")
+    assert one["n_gpus"] == 1 and one["scaling"] == "weak" and one["config"]["workload"].startswith("C2")
 
 
 def test_child_failure_is_propagated(built):

@@ -56,6 +56,13 @@ class GlobalLayout:
         return sum(self.out_bytes)
 
 
+def layout_from_sizes(rank: int, n_haps: Sequence[int], out_bytes: Sequence[int]) -> GlobalLayout:
+    """What the size all-gather tells rank `rank`: its first global haplotype index and its byte offset in the cohort-wide stream
+    (exclusive prefix sums over the ranks before it)."""
+    nh, nb = [int(x) for x in n_haps], [int(x) for x in out_bytes]
+    return GlobalLayout(rank, len(nh), nh, nb, sum(nh[:rank]), sum(nb[:rank]))
+
+
 def exchange_sizes(n_haps: int, out_bytes: int, device=None, group=None) -> GlobalLayout:
     """All-gather {haplotypes, result bytes} (16 bytes per rank; RCCL when the tensors live on
     a GPU, gloo on CPU).  Without an initialised process group this is the 1-rank layout."""
@@ -69,4 +76,4 @@ def exchange_sizes(n_haps: int, out_bytes: int, device=None, group=None) -> Glob
     dist.all_gather_into_tensor(everyone, mine, group=group)
     flat = everyone.cpu().tolist()
     nh, nb = flat[0::2], flat[1::2]
-    return GlobalLayout(rank, world, nh, nb, sum(nh[:rank]), sum(nb[:rank]))
+    return layout_from_sizes(rank, nh, nb)
