@@ -221,7 +221,7 @@ def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests, dense=
             b.execute()
             b.sync()
             same = bool(np.array_equal(b.digests(), want_digests))
-            ts = torch.cuda.current_stream()
+            ts = torch.cuda.Stream()                             # (a stream of its own: the null stream would mean "the ctx's own" to the ABI)
             ctx.set_stream(ts.cuda_stream)                       # HIP events on the stream the kernel is launched on
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
             for e0, e1 in evs:
@@ -266,7 +266,7 @@ def whole_cohort_leg(workload, samples, steps, n_threads, verify_every=True, tem
     d_prot, d_payload = padded(proteome), padded(img.payload)
     chunks = np.ascontiguousarray(img.chunks)
     assert lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, proteome.size) == 0
-    d_desc = torch.from_numpy(img.desc.view(np.int64)).to(dev)
+    d_desc = padded(img.desc.view(np.uint8))                   # (64 readable bytes either side: the ABI asks for 16 before and 32 behind)
     d_chunks = torch.from_numpy(chunks.view(np.int64)).to(dev)
     d_hap = torch.from_numpy(img.hap_out_begin.view(np.int64)).to(dev)
     out_bytes = img.out_bytes
@@ -276,7 +276,7 @@ def whole_cohort_leg(workload, samples, steps, n_threads, verify_every=True, tem
     flags = (0 if temporal else 1) | img.launch_bits
 
     def launch():
-        rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), d_desc.data_ptr(), img.desc.size, d_chunks.data_ptr(), chunks.shape[0],
+        rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), d_desc.data_ptr() + PAD, img.desc.size, d_chunks.data_ptr(), chunks.shape[0],
                                    d_prot.data_ptr() + PAD, proteome.size, d_payload.data_ptr() + PAD, img.payload.size,
                                    d_out.data_ptr(), out_bytes, d_status.data_ptr(), flags, 0)
         if rc != 0:
@@ -413,7 +413,7 @@ def main():
         return t
 
     d_prot, d_payload = padded(proteome), padded(img.payload)
-    d_desc = torch.from_numpy(img.desc.view(np.int64)).to(dev)
+    d_desc = padded(img.desc.view(np.uint8))                   # (readable slack either side, like the source tapes: include/vcf2prot_hip.h)
     n_desc = int(img.desc.size)
     img.chunks = np.ascontiguousarray(img.chunks)
     if args.xcd_order != 0 and not args.dry_run:           # XCD-aware launch order (speed only; chunks are independent)
@@ -447,7 +447,7 @@ def main():
             if dist_on:
                 dist.all_gather_into_tensor(all_sizes, sizes_t)
             return
-        rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), d_desc.data_ptr(), n_desc, d_chunks.data_ptr(), n_chunks,
+        rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), d_desc.data_ptr() + PAD, n_desc, d_chunks.data_ptr(), n_chunks,
                                    d_prot.data_ptr() + PAD, proteome.size, d_payload.data_ptr() + PAD, img.payload.size,
                                    d_out.data_ptr(), out_bytes, d_status.data_ptr(), flags, args.max_blocks)
         if rc != 0:

@@ -254,7 +254,8 @@ int  v2p_pipeline_release(v2p_pipeline* p, uint32_t ticket);
 
 /* ---- raw launchers on caller-owned device memory (torch tensors, other runtimes) ----- */
 /* src0/src1 must have 32 readable bytes before and after (the kernel loads whole aligned 16-byte
- * blocks around a task's bytes); out must be 16-byte aligned; status is one device uint64 initialised
+ * blocks around a task's bytes), and so must d_desc (16 before, 32 after: stitchw_kernel reads an immediate descriptor's literal
+ * bytes as a stream out of the descriptor array itself); out must be 16-byte aligned; status is one device uint64 initialised
  * to ~0; chunks that point outside d_desc[0, n_desc) are reported in it, never followed.
  * `nontemporal`: bit 0 non-temporal result stores | v2p_stitch_launch_bits() of the (host copy of the) chunk table -- the bits say
  * which kernels have work; a chunk whose kernel is not named by them is not executed.  max_blocks != 0 caps the grid of the

@@ -17,7 +17,7 @@ lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctyp
 def padded(a):
     t = torch.zeros(a.size + 128, dtype=torch.uint8, device=dev); t[64:64 + a.size] = torch.from_numpy(a).to(dev); return t
 d_prot, d_pay = padded(prot), padded(img.payload)
-d_desc = torch.from_numpy(img.desc.view(np.int64)).to(dev); d_chunks = torch.from_numpy(chunks.view(np.int64)).to(dev)
+d_desc = torch.zeros(img.desc.size + 16, dtype=torch.int64, device=dev); d_desc[8:8 + img.desc.size] = torch.from_numpy(img.desc.view(np.int64)).to(dev); d_chunks = torch.from_numpy(chunks.view(np.int64)).to(dev)
 nch = chunks.shape[0]
 dbg_bytes = nch * 4 * 64
 bits = int(lib.v2p_stitch_launch_bits(chunks.ctypes.data, nch))
@@ -26,7 +26,7 @@ d_out = torch.zeros(img.out_bytes + 512 + dbg_bytes, dtype=torch.uint8, device=d
 d_status = torch.full((1,), -1, dtype=torch.int64, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 for flags in (1 | (var << 12), 1 | (var << 12) | (20 << 16)):
-    lib.v2p_stitch_launch(ctypes.c_void_p(s), d_desc.data_ptr(), d_desc.numel(), d_chunks.data_ptr(), nch, d_prot.data_ptr() + 64, prot.size,
+    lib.v2p_stitch_launch(ctypes.c_void_p(s), d_desc.data_ptr() + 64, img.desc.size, d_chunks.data_ptr(), nch, d_prot.data_ptr() + 64, prot.size,
                           d_pay.data_ptr() + 64, img.payload.size, d_out.data_ptr(), img.out_bytes, d_status.data_ptr(), flags | bits, 0)
 torch.cuda.synchronize()
 off = (img.out_bytes + 255) // 256 * 256

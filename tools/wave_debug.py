@@ -39,12 +39,13 @@ def main():
         chunks = np.ascontiguousarray(img.chunks)
         d_pay = torch.zeros(img.payload.size + 128, dtype=torch.uint8, device=dev)
         d_pay[64:64 + img.payload.size] = torch.from_numpy(img.payload).to(dev)
-        d_desc = torch.from_numpy(img.desc.view(np.int64)).to(dev)
+        d_desc = torch.zeros(img.desc.size + 16, dtype=torch.int64, device=dev)       # (64 readable bytes either side)
+        d_desc[8:8 + img.desc.size] = torch.from_numpy(img.desc.view(np.int64)).to(dev)
         d_chunks = torch.from_numpy(chunks.view(np.int64)).to(dev)
         d_out = torch.zeros(img.out_bytes + 32, dtype=torch.uint8, device=dev)
         d_status = torch.full((1,), -1, dtype=torch.int64, device=dev)
         flags = 1 | int(lib.v2p_stitch_launch_bits(chunks.ctypes.data, chunks.shape[0])) | (a.wpg << 28)
-        rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), d_desc.data_ptr(), d_desc.numel(), d_chunks.data_ptr(), chunks.shape[0],
+        rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), d_desc.data_ptr() + 64, img.desc.size, d_chunks.data_ptr(), chunks.shape[0],
                                    d_prot.data_ptr() + 64, prot.size, d_pay.data_ptr() + 64, img.payload.size, d_out.data_ptr(), img.out_bytes,
                                    d_status.data_ptr(), flags, 0)
         torch.cuda.synchronize()

@@ -13,13 +13,17 @@
 //   A  descriptor -> record {source address - start, start, end, substituted position + byte}; DPP scan of the lengths;
 //      +1 scattered into a byte-per-block map at the first block starting inside or after each record
 //   C  in-lane SWAR prefix + wave scan of the map: map[k] = record covering the first byte of block k (8 blocks per lane)
-//   P  lane = record: the first record to start strictly inside a block assembles that block once (every source that touches
-//      it, masks from a 17-entry LDS table) and parks it in an LDS patch table; a record whose substituted residue lies in a
-//      block it covers whole parks that block too (one gather + one byte insert).  Their gathers fly under C.
-//   K  lane = block, eight 1 KiB rows per wave: one map byte + one record per block; a block no record ends in and no
-//      substitution touches is 16 bytes of its record's stream (one byte-granular dwordx4 gather), anything else is read
-//      from the patch table into the same registers.  All eight rows are gathered before the first store (gfx950 counts
-//      loads and stores in one in-order counter), then leave as aligned non-temporal dwordx4 stores, 1 KiB per instruction.
+//   P  lane = record: a record that starts inside a block fetches its own stream at that block (ONE gather per lane); the first
+//      record to start inside a block overlays the pieces of the records that follow it there and parks the block's tail in LDS
+//   K  lane = block, eight 1 KiB rows per wave: one map byte + one record per block, then one byte-granular dwordx4 gather of
+//      the covering record's stream for EVERY block; at store time a block its record ends in takes the parked tail from the
+//      record's end on (mask from a 17-entry LDS table), a replaced residue inside the block is placed.  All eight rows are
+//      gathered before the first store (gfx950 counts loads and stores in one in-order counter), then leave as aligned
+//      non-temporal dwordx4 buffer stores, 1 KiB per instruction.
+// An immediate descriptor's literal bytes are read as a stream too: out of the descriptor array itself (their record's source
+// address is the descriptor's own address), which is why the array needs 16 readable bytes before and 32 behind it.
+// Ten vector-memory instructions per 8 KiB on the read side (descriptors, patch gather, eight row gathers), eight on the write
+// side: the kernel is bound by the CU's vector-memory pipeline and the latency chain of a wave, not by its ~450 VALU instructions.
 // A descriptor that would read out of bounds is reported in the device status word and its chunk is not executed; nothing is
 // ever read or written outside the buffers (sources carry PAD_BYTES of readable slack, as for the other kernels).
 #include <hip/hip_runtime.h>
@@ -32,11 +36,11 @@ namespace v2p {
 
 struct __attribute__((aligned(16))) WRec {
     // positions are in BLOCK SPACE: (chunk's result offset & 15) + offset inside the chunk, so block b covers [16b, 16b + 16)
-    uint32_t a_lo, a_hi;   // source address minus the record's start position; an immediate record: its literal bytes
+    uint32_t a_lo, a_hi;   // source address minus the record's start position (an immediate record: the address of its own descriptor, whose low bytes are the literal)
     uint32_t se;           // start | end << 16
-    uint32_t lit;          // position of the substituted residue (WREC_NOLIT: none) | its byte << 16 | WREC_IMM
+    uint32_t lit;          // position of the substituted residue (WREC_NOLIT: none) | its byte << 16
 };
-constexpr uint32_t WREC_IMM = 0x80000000u, WREC_NOLIT = 0xFFFFu;
+constexpr uint32_t WREC_NOLIT = 0xFFFFu;
 
 __device__ __forceinline__ uint64_t wrec_adj(const WRec& t) { return (uint64_t(t.a_hi) << 32) | t.a_lo; }
 
@@ -55,7 +59,7 @@ __device__ __forceinline__ u32x4 put_byte(u32x4 v, uint32_t q, uint32_t byte)
 // three source buffers; an address outside them is reported (reason 100 + site) and not followed.  The product build has no such code.
 struct WChk {
 #ifdef V2P_WAVE_CHECK
-    uint64_t lo[3], hi[3];
+    uint64_t lo[4], hi[4];
     unsigned long long* status;
     uint64_t tb;
 #endif
@@ -69,7 +73,7 @@ __device__ __forceinline__ u32x4 wgather(uint64_t addr, const WChk& k, uint32_t 
 {
 #ifdef V2P_WAVE_CHECK
     bool ok = false;
-    for (int q = 0; q < 3; ++q) ok = ok || (addr >= k.lo[q] && addr + 16u <= k.hi[q]);
+    for (int q = 0; q < 4; ++q) ok = ok || (addr >= k.lo[q] && addr + 16u <= k.hi[q]);
     if (!ok) { report(k.status, (k.tb << 8) | (threadIdx.x & 63u), 100u + site); return u32x4{0u, 0u, 0u, 0u}; }
 #endif
     (void)k; (void)site;
@@ -91,15 +95,6 @@ __device__ __forceinline__ u32x4 wmerge(u32x4 v, u32x4 ld, u32x4 m)      // byte
     return v;
 }
 
-// An immediate record's literal bytes (<= 5, first byte lowest) placed at byte position q (-4..15) of a block: v_perm_b32
-// selectors from an LDS table (s_sel[(q + 4) & 31]; entries 20..31 select nothing)
-__device__ __forceinline__ u32x4 wplace(const u32x4* s_sel, uint64_t lit, uint32_t q)
-{
-    const u32x4 sel = s_sel[(q + 4u) & 31u];
-    const uint32_t lo = uint32_t(lit), hi = uint32_t(lit >> 32);
-    return u32x4{__builtin_amdgcn_perm(hi, lo, sel[0]), __builtin_amdgcn_perm(hi, lo, sel[1]), __builtin_amdgcn_perm(hi, lo, sel[2]), __builtin_amdgcn_perm(hi, lo, sel[3])};
-}
-
 // WPG waves per workgroup, each with its own chunk and its own LDS tables; the waves of a workgroup share nothing but the
 // (identical) mask and selector tables.
 //
@@ -110,8 +105,11 @@ __device__ __forceinline__ u32x4 wplace(const u32x4* s_sel, uint64_t lit, uint32
 // else gather" per row and a lane-conditional store per row, and its code waited for every gather before issuing the next one
 // and for every store's acknowledgement before issuing the next store (its own stamps: 7 500 + 4 900 cycles of a workgroup's
 // 24 400).  Here the eight gathers issue back to back and every wait is a counted one.
+#ifndef V2P_WAVE_OCC
+#define V2P_WAVE_OCC 8
+#endif
 template <int WPG, bool NT>
-__global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __restrict__ p_desc, const Chunk* __restrict__ p_chunks,
+__global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const uint64_t* __restrict__ p_desc, const Chunk* __restrict__ p_chunks,
                                                             const uint8_t* __restrict__ p_src0, const uint8_t* __restrict__ p_src1,
                                                             uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
                                                             const uint8_t* __restrict__ p_dots,
@@ -123,11 +121,10 @@ __global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __
     struct WaveLds {
         uint32_t map32[CHUNK_BYTES_WAVE / 64u];                      // one byte per 16-byte block: record covering its first byte
         WRec rec[CHUNK_TASKS_WAVE + 4];                              // + sentinels
-        u32x4 patch[2 * CHUNK_TASKS_WAVE];                           // [t]: the block record t is the first to start in; [64 + r]: the block of r's substituted residue; [0]: scrap
+        u32x4 patch[CHUNK_TASKS_WAVE + 1];                           // [t]: record t's own piece, then (owners) the parked tail of the block it starts in; [64]: scrap
     };
     __shared__ __attribute__((aligned(16))) WaveLds s_all[WPG];
     __shared__ u32x4 s_mask[17];                                     // s_mask[j]: bytes >= j of a block
-    __shared__ u32x4 s_sel[32];                                      // s_sel[q + 4]: v_perm_b32 selectors placing a literal at block position q
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = WPG == 1 ? 0u : uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
@@ -146,25 +143,12 @@ __global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __
     // chunk's descriptor lines into the L2 from here -- 1 Ki, 4 Ki, 16 Ki chunks ahead, issued behind this load and waited for by
     // nobody before the patch phase -- was measured: C2 +3.5 %, C3 +1 % SLOWER; not kept.)
     const uint64_t d_raw = *(lane < n ? p_desc + tb + lane : reinterpret_cast<const uint64_t*>(p_chunks + c));
-    {   // the two tables, without a branch (every lane writes an entry; lanes and waves that share one write the same value)
+    {   // the byte-mask table, without a branch (every lane writes an entry; lanes and waves that share one write the same value)
         const uint32_t jm = lane < 16u ? lane : 16u;
         u32x4 m;
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) m[k] = jm <= 4u * k ? 0xFFFFFFFFu : (jm >= 4u * k + 4u ? 0u : 0xFFFFFFFFu << (8u * (jm - 4u * k)));
         s_mask[jm] = m;
-        const int32_t q = int32_t(lane & 31u) - 4;                   // block position of the literal's first byte
-        u32x4 sel;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t w = 0u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int32_t t = 4 * k + j - q;                     // which literal byte lands on block byte 4k + j (the literal is 8 bytes {hi, lo}, bytes 5..7 zero)
-                w |= ((t >= 0 && t < 8 && q <= 15) ? uint32_t(t) : 0x0Cu) << (8 * j);     // selector 0x0C: constant zero
-            }
-            sel[k] = w;
-        }
-        s_sel[lane & 31u] = sel;
     }
 #pragma unroll
     for (uint32_t k = 0; k < ND; ++k) L.map32[ND * lane + k] = 0u;
@@ -182,7 +166,8 @@ __global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __
     const bool gathers = !imm && bytes != 0u && (snv || space != SPACE_FILL);       // ('.' fill, idle lanes, empty records and immediates read the dots)
     const bool ref = snv || space == SPACE_PROTEOME;
     const bool bad = imm ? len1 > IMM_MAX_BYTES : (gathers && src + bytes > (ref ? src0_len : src1_len));   // never read out of bounds: task.rs would panic
-    const uint64_t a = gathers ? reinterpret_cast<uint64_t>(ref ? p_src0 : p_src1) + src : dots16;
+    // (an immediate record's bytes ARE in memory: the low bytes of its own descriptor, just loaded -- it is a stream like any other)
+    const uint64_t a = imm ? reinterpret_cast<uint64_t>(p_desc + tb + lane) : (gathers ? reinterpret_cast<uint64_t>(ref ? p_src0 : p_src1) + src : dots16);
     const uint32_t incl = wave_incl_scan(bad ? 0u : bytes);
     const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
     const uint32_t ptotal = head + total;                            // end of the chunk in block space
@@ -199,14 +184,15 @@ __global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __
     chk.lo[0] = reinterpret_cast<uint64_t>(p_src0) - PAD_BYTES; chk.hi[0] = reinterpret_cast<uint64_t>(p_src0) + src0_len + PAD_BYTES;
     chk.lo[1] = reinterpret_cast<uint64_t>(p_src1) - PAD_BYTES; chk.hi[1] = reinterpret_cast<uint64_t>(p_src1) + src1_len + PAD_BYTES;
     chk.lo[2] = reinterpret_cast<uint64_t>(p_dots); chk.hi[2] = reinterpret_cast<uint64_t>(p_dots) + DOTS_BYTES;
+    chk.lo[3] = reinterpret_cast<uint64_t>(p_desc) - 16u; chk.hi[3] = reinterpret_cast<uint64_t>(p_desc + n_desc) + PAD_BYTES;      // (immediate records read their own descriptors)
     chk.status = p_status; chk.tb = c;
 #endif
     const uint32_t start = ptotal - (total - (incl - bytes));        // = head + exclusive prefix; lanes >= n sit at ptotal
     const uint32_t end = start + bytes;
     const uint32_t lit_pos = start + len1;                           // (fused substitutions only)
     const uint32_t lit_byte = (dhi >> 21) & 0xFFu;
-    const uint64_t adj = imm ? src : a - start;                      // (an immediate record keeps its literal bytes here)
-    const uint32_t my_lit = (snv ? lit_pos | (lit_byte << 16) : WREC_NOLIT) | (imm ? WREC_IMM : 0u);
+    const uint64_t adj = a - start;
+    const uint32_t my_lit = snv ? lit_pos | (lit_byte << 16) : WREC_NOLIT;
     {
         WRec t;
         t.a_lo = uint32_t(adj); t.a_hi = uint32_t(adj >> 32);
@@ -219,24 +205,12 @@ __global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __
     }
     asm volatile("" ::: "memory");                                   // (one wave: its LDS operations execute in order; this only pins the compiler)
 
-    // ---- P, first half: lane = record.  Record t owns the block it starts in when it is the first record to start there (at a
-    //      non-zero offset): it assembles that block from record t-1 (which covers the block's first byte), itself and record t+1;
-    //      a fused substitution owns the block of its replaced residue when it covers that block whole.  Four gathers per lane,
-    //      unconditionally (a lane with nothing to fetch reads the dots): no branch, they fly under C. ----
-    const WRec tp = L.rec[lane - (lane != 0u ? 1u : 0u)], tn = L.rec[lane + 1u];
-    const uint32_t sb16 = start & ~15u;
-    // (in block 0 of a chunk with a ragged head record 0 itself starts inside the block: record 1 owns it)
-    const bool owner = lane >= 1u && lane < n && start != sb16 && ((tp.se & 0xFFFFu) <= sb16 || (sb16 == 0u && lane == 1u));
-    const uint32_t phi = sb16 + 16u < ptotal ? sb16 + 16u : ptotal;
-    const bool need1 = owner && start < phi, need2 = need1 && end < phi;
-    const bool more = need2 && (tn.se >> 16) < phi;                  // a fourth record begins in the block (rare): finished in a loop
-    const uint32_t lb16 = lit_pos & ~15u;
-    const bool lit_owner = snv && start <= lb16 && end >= lb16 + 16u;
+    // ---- P, first half: lane = record.  A record that starts inside a block (at a non-zero offset) fetches ITS OWN stream at that
+    //      block -- one gather per lane, unconditionally (a lane with nothing to fetch reads the dots): no branch, it flies under
+    //      the map and the copy phase's look-ups.  What precedes the record in the block is the covering record's stream, which the
+    //      copy phase gathers anyway; what follows it comes from the later records' own pieces. ----
     constexpr bool PG = !(V2P_WAVE_ABLATE & 2);
-    const u32x4 g0 = wgather(PG && owner && !(tp.lit & WREC_IMM) ? wrec_adj(tp) + sb16 : dots16, chk, 0u);
-    const u32x4 g1 = wgather(PG && need1 && !imm ? adj + sb16 : dots16, chk, 1u);
-    const u32x4 g2 = wgather(PG && need2 && !(tn.lit & WREC_IMM) ? wrec_adj(tn) + sb16 : dots16, chk, 2u);
-    const u32x4 g3 = wgather(PG && lit_owner ? adj + lb16 : dots16, chk, 3u);
+    const u32x4 g1 = wgather(PG && lane < n && (start & 15u) != 0u && bytes != 0u ? adj + (start & ~15u) : dots16, chk, 1u);
 
     // ---- C: block map = inclusive prefix sum of the marks; ROWS one-byte counters per lane (a chunk has at most 63 marks) ----
     {
@@ -254,39 +228,15 @@ __global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __
 #pragma unroll
         for (uint32_t k = 0; k < ND; ++k) L.map32[ND * lane + k] = y[k] + before;
     }
-    // ---- P, second half: merge, place the replaced residues (a record's residue lies inside its own range: it survives the
-    //      merges), park ----
-    {
-        const u32x4 v0 = (tp.lit & WREC_IMM) ? wplace(s_sel, wrec_adj(tp), (tp.se & 0xFFFFu) - sb16) : g0;
-        const u32x4 v1 = imm ? wplace(s_sel, src, start - sb16) : g1;
-        const u32x4 v2 = (tn.lit & WREC_IMM) ? wplace(s_sel, wrec_adj(tn), end - sb16) : g2;
-        u32x4 v = wmerge(v0, v1, s_mask[need1 ? start - sb16 : 16u]);
-        v = wmerge(v, v2, s_mask[need2 ? end - sb16 : 16u]);
-        v = wrec_lit(v, tp.lit, sb16);
-        v = wrec_lit(v, need1 ? my_lit : WREC_NOLIT, sb16);
-        v = wrec_lit(v, need2 ? tn.lit : WREC_NOLIT, sb16);
-        if (more) {
-            uint32_t r = lane + 1u;
-            WRec t = tn;
-            while ((t.se >> 16) < phi) {
-                t = L.rec[++r];
-                const u32x4 g = (t.lit & WREC_IMM) ? wplace(s_sel, wrec_adj(t), (t.se & 0xFFFFu) - sb16) : wgather(wrec_adj(t) + sb16, chk, 4u);
-                v = wmerge(v, g, s_mask[(t.se & 0xFFFFu) - sb16]);
-                v = wrec_lit(v, t.lit, sb16);
-            }
-        }
-        L.patch[owner ? lane : 0u] = v;
-        L.patch[lit_owner ? CHUNK_TASKS_WAVE + lane : 0u] = put_byte(g3, lit_pos & 15u, lit_byte);
-    }
     asm volatile("" ::: "memory");
 
-    // ---- K: lane = block.  Look-ups (LDS only), the eight gathers back to back, then per row: patch select, store. ----
+    // ---- K, first half: lane = block.  Per group of four rows: the map bytes, the four records (they land in the registers the
+    //      gathers will fill), then per row the gather of the covering record's stream -- for EVERY block, cut or not.  The eight
+    //      gathers issue back to back, behind the patch phase's one. ----
     const uint8_t* const map8 = reinterpret_cast<const uint8_t*>(L.map32);
     uint8_t* const out0 = p_out + (dst - head);                      // 16-byte aligned
-    // per group of four rows: the map bytes, the four records (they land in the registers the gathers will fill), then per row:
-    // classify, gather
     u32x4 v[ROWS];
-    uint32_t pk[ND];                                                 // patch index of the lane's block in row j: byte j & 3 of pk[j >> 2] (0: none)
+    uint32_t pk[ND];                                                 // record of the lane's block in row j: byte j & 3 of pk[j >> 2]
     const uint32_t lane16 = lane << 4;
 #pragma unroll
     for (uint32_t g = 0; g < ND; ++g) {
@@ -298,43 +248,78 @@ __global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __
         }
 #pragma unroll
         for (uint32_t q = 0; q < 4u; ++q) v[4u * g + q] = reinterpret_cast<const u32x4*>(L.rec)[rr[q]];   // (one 16-byte read: field by field, the address half is sunk into a branch)
-        uint32_t pkg = 0u;
+        pk[g] = rr[0] | (rr[1] << 8) | (rr[2] << 16) | (rr[3] << 24);
+        asm volatile("" : "+v"(pk[g]));                              // (packed NOW: four live registers become one)
 #pragma unroll
         for (uint32_t q = 0; q < 4u; ++q) {
             const uint32_t j = 4u * g + q, b16 = (j << 10) + lane16;
             const u32x4 t = v[j];
-            // a record ends inside the block: the block the next record parked; a replaced residue inside it: the block its record
-            // parked.  Such a lane gathers the dots and takes the parked block afterwards.  (Every arm a ready value: selects, no branch.)
-            const bool cut = (t[2] >> 16) < b16 + 16u, parked = cut || (t[3] & 0xFFFFu) - b16 < 16u;
             const uint64_t A = ((uint64_t(t[1]) << 32) | t[0]) + b16;
-            // (an immediate record has no address: it can only "cover" the ragged head block of a chunk, which is not stored from here)
-            const uint64_t X = (parked || (t[3] & WREC_IMM) || (V2P_WAVE_ABLATE & 1)) ? dots16 : A;
-            const uint32_t i_cut = rr[q] + 1u, i_lit = rr[q] + CHUNK_TASKS_WAVE;
-            const uint32_t i_any = cut ? i_cut : i_lit;
-            const uint32_t idx = parked ? i_any : 0u;
-            pkg |= idx << (8u * q);
+            const uint64_t X = (V2P_WAVE_ABLATE & 1) != 0 ? dots16 : A;
             v[j] = wgather(X, chk, 5u);
         }
-        pk[g] = pkg;
     }
-    // whole blocks of the chunk leave as 16-byte stores of a buffer resource over the chunk's result range: a lane outside it
-    // (ragged edge blocks, rows past the chunk's end) gets an out-of-range offset and the hardware drops its store -- no branch
+
+    // ---- P, second half (the copy phase's gathers are in flight): every record's own piece H[t] = its stream at the block it
+    //      starts in, its replaced residue placed; the FIRST record to start inside a block then parks the block's tail: its own
+    //      piece, overlaid from their starts on by the pieces of the records that follow it inside the same block. ----
+    {
+        // (the lane's own record comes back from LDS, field by field as it is needed: nothing of the set-up stays in registers across
+        // the copy phase's look-ups, whose 32 destination registers are in flight now)
+        const uint32_t* const rec32 = reinterpret_cast<const uint32_t*>(L.rec);
+        const uint32_t se0 = rec32[4u * lane + 2u], lit0 = rec32[4u * lane + 3u];
+        const uint32_t s0 = se0 & 0xFFFFu, e0 = se0 >> 16, b0 = s0 & ~15u;
+        L.patch[lane] = wrec_lit(g1, lit0, b0);                      // (every lane: H[t]; slot t becomes the parked block below)
+        // (in block 0 of a chunk with a ragged head record 0 itself starts inside the block: record 1 owns it)
+        const uint32_t sp = rec32[4u * (lane - (lane != 0u ? 1u : 0u)) + 2u] & 0xFFFFu;
+        const bool owner = lane >= 1u && lane < n && s0 != b0 && (sp <= b0 || (b0 == 0u && lane == 1u));
+        const uint32_t phi = b0 + 16u < ptotal ? b0 + 16u : ptotal;
+        const bool need2 = owner && e0 < phi;                        // the next record starts inside the block too
+        const uint32_t sb16 = b0;
+        u32x4 p = wmerge(L.patch[lane], L.patch[lane + 1u], s_mask[need2 ? e0 - b0 : 16u]);      // (slot 64: scrap)
+        if (need2 && (rec32[4u * (lane + 1u) + 2u] >> 16) < phi) {   // a third record begins in the block (rare)
+            uint32_t r = lane + 1u;
+            uint32_t se = rec32[4u * r + 2u];
+            while ((se >> 16) < phi) {
+                se = rec32[4u * ++r + 2u];
+                p = wmerge(p, L.patch[r], s_mask[(se & 0xFFFFu) - sb16]);
+            }
+        }
+        asm volatile("" ::: "memory");                               // (every H[] read of the wave precedes the overwrite of slot t)
+        L.patch[owner ? lane : CHUNK_TASKS_WAVE] = p;
+    }
+    asm volatile("" ::: "memory");
+
+    // ---- K, second half: per row -- the covering record again (LDS), the parked tail merged in where the record ends inside the
+    //      block, its replaced residue placed, the store.  Whole blocks of the chunk leave as 16-byte stores of a buffer resource over
+    //      the chunk's result range: a lane outside it (ragged edge blocks, rows past the chunk's end) gets an out-of-range offset
+    //      and the hardware drops its store -- no branch. ----
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out0, 0, int(ptotal), 0x00020000);
     const int32_t last16 = int32_t(ptotal) - 16;                     // a block at b16 <= last16 ends inside the chunk
+    uint32_t l16 = lane16;
+    asm volatile("" : "+v"(l16));                                    // (the rows' positions are recomputed from here, not kept in eight registers since the look-ups)
 #pragma unroll
     for (uint32_t j = 0; j < ROWS; ++j) {
-        const uint32_t idx = (pk[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
-        const u32x4 p = L.patch[idx];
-        const u32x4 o = idx ? p : v[j];
-        const bool whole = int32_t(lane16) <= last16 - int32_t(j << 10) && (j != 0u || lane16 >= head);
-        const uint32_t off = (whole && !(V2P_WAVE_ABLATE & 4)) ? lane16 : 0x80000000u;
+        const uint32_t b16 = (j << 10) + l16;
+        const uint32_t r = (pk[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
+        const u32x4 t = reinterpret_cast<const u32x4*>(L.rec)[r];
+        const uint32_t e = t[2] >> 16;
+        const bool cut = e < b16 + 16u;
+        const u32x4 p = L.patch[cut ? r + 1u : CHUNK_TASKS_WAVE];
+        const uint32_t ja = e - b16;                               // (1 .. 15 for a cut block inside the chunk)
+        const u32x4 m = s_mask[cut && ja < 16u ? ja : 16u];
+        u32x4 o = wrec_lit(v[j], t[3], b16);
+        o = wmerge(o, p, m);
+        const bool whole = int32_t(l16) <= last16 - int32_t(j << 10) && (j != 0u || l16 >= head);
+        const uint32_t off = (whole && !(V2P_WAVE_ABLATE & 4)) ? l16 : 0x80000000u;
         // (soffset stays the immediate 0: with an SGPR there, hipcc (ROCm 7.2) leaves out the wait states between a dwordx4 store and
         // a VALU write to its data registers -- seen on gfx950: "buffer_store_dwordx4 v[10:13], .., s6 offen" followed at once by
         // "v_mov_b32 v10, 0" stored a zero first dword in the last four lanes of every row of sixteen)
-        #ifndef V2P_WAVE_STORE_AUX
+#ifndef V2P_WAVE_STORE_AUX
 #define V2P_WAVE_STORE_AUX 2                                         /* nt */
 #endif
         __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, int(off + (j << 10)), 0, NT ? V2P_WAVE_STORE_AUX : 0);
+        __builtin_amdgcn_sched_barrier(0);                           // (row by row: hoisting the next rows' LDS reads here costs the registers the kernel does not have)
     }
     // ragged first / last block of a chunk whose cut is not 16-byte aligned (rare): one lane each, byte stores
     if (lane < 2u) {
@@ -343,11 +328,11 @@ __global__ __launch_bounds__(64 * WPG, 8) void stitchw_kernel(const uint64_t* __
             const uint32_t hi = b16 + 16u < ptotal ? b16 + 16u : ptotal;
             uint32_t r = uint32_t(map8[b16 >> 4]);
             WRec t = L.rec[r];
-            u32x4 o = (t.lit & WREC_IMM) ? wplace(s_sel, wrec_adj(t), (t.se & 0xFFFFu) - b16) : wgather(wrec_adj(t) + b16, chk, 6u);
+            u32x4 o = wgather(wrec_adj(t) + b16, chk, 6u);
             o = wrec_lit(o, t.lit, b16);
             while ((t.se >> 16) < hi) {
                 t = L.rec[++r];
-                const u32x4 g = (t.lit & WREC_IMM) ? wplace(s_sel, wrec_adj(t), (t.se & 0xFFFFu) - b16) : wgather(wrec_adj(t) + b16, chk, 7u);
+                const u32x4 g = wgather(wrec_adj(t) + b16, chk, 7u);
                 o = wmerge(o, g, s_mask[(t.se & 0xFFFFu) - b16]);
                 o = wrec_lit(o, t.lit, b16);
             }
