@@ -198,7 +198,7 @@ def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests, dense=
     t_stream = time.perf_counter() - t0
     from vcf2prot_amd._native import V2PError
     # a dense image: one window = the kernel's 12 KiB LDS image when its descriptors fit (<= 1024 per window), else smaller windows
-    windows = (12288, 8192, 4096) if dense else ((8192, 4096) if wave else ((28672,) if long_run else (32768,)))
+    windows = (12288, 8192, 4096) if dense else ((10240, 8192, 4096) if wave else ((28672,) if long_run else (32768,)))
     kernel = 3 if dense else (4 if wave else (1 if long_run else 2))
     with Context(0) as ctx:
         ctx.upload_proteome(cohort.proteome())

@@ -170,7 +170,7 @@ int v2p_batch_end_haplotype(v2p_batch* b);
  * batch, in result order.  The device does the reference's step 5 (haplotype_instruction.rs:94-133: the three running sums become
  * prefix scans; reference tasks are rebased onto the resident proteome) and the image packing (result-order descriptors, '.'
  * fill for cells no task covers, immediate descriptors, chunk table, XCD-aware order, hap_out_begin).  Chunks are cut on a fixed
- * grid of `window_bytes` of result (a multiple of 4096, <= 65536 - 4096); a window holding more than 1024 descriptors is refused
+ * grid of `window_bytes` of result (a multiple of 4096 -- wave images: of 1024 --, <= 65536 - 4096); a window holding more than 1024 descriptors is refused
  * (V2P_ERR_UNSUPPORTED: pick a smaller window). */
 typedef struct {
     uint64_t n_haps, n_tx, n_tasks, n_alt;
@@ -188,8 +188,8 @@ typedef struct {
 } v2p_txstream;
 /* kernel: 1 = route every chunk to the long-run kernel (<= 512 descriptors per window), 2 = per-block kernel, 3 = dense image
  * (stitch_dense_kernel: short tasks, fused substitutions, <= 1024 descriptors per window: windows of 4, 8 or 12 KiB, larger ones are
- * V2P_ERR_INVALID_ARG), 4 = wave image (stitchw_kernel, one wave per window: windows of 4 or 8 KiB with <= 64 descriptors each,
- * fused substitutions; the choice for long reference runs).
+ * V2P_ERR_INVALID_ARG), 4 = wave image (stitchw_kernel, one wave per window: windows of 1 .. 10 KiB in steps of 1 KiB with <= 64
+ * descriptors each, fused substitutions; the choice for long reference runs).
  * The offset tables of the stream are checked on the host before anything is uploaded (ascending from 0, inside their arrays):
  * V2P_ERR_INVALID_ARG with the offending index.  A window that holds more descriptors than its kernel takes is
  * V2P_ERR_UNSUPPORTED and leaves the batch empty: call again with a smaller window.
@@ -208,7 +208,7 @@ int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, ui
  * long-run and dense chunks only); space 3 with bits 61..60 = 01 = two substitutions in a row (src:29 | len1:5 | len2:5 | len3:5 |
  * byte1:8 | byte2:8; dense chunks only).  Chunks: {first descriptor, result offset:48 | descriptors:11 | flags: bit 63 long-run
  * (stitch4_kernel), bit 62 long-run with 257..512 tasks, bit 61 dense (stitch_dense_kernel), bit 60 wave (stitchw_kernel: at most 64
- * descriptors and 8192 result bytes incl. the 16-byte phase of its offset, fused substitutions allowed)}.  A descriptor a chunk's
+ * descriptors and 10240 result bytes incl. the 16-byte phase of its offset, fused substitutions allowed)}.  A descriptor a chunk's
  * kernel does not know is reported (source out of bounds) and the chunk is not executed. */
 int v2p_batch_set_packed(v2p_batch* b,
                          const uint64_t* desc, uint64_t n_desc,

@@ -1,4 +1,4 @@
-"""stitchw_kernel (one wave per chunk of <= 64 descriptors / <= 8 KiB, a fused substitution = one record): the same bytes as the
+"""stitchw_kernel (one wave per chunk of <= 64 descriptors / <= 10 KiB, a fused substitution = one record): the same bytes as the
 oracle (task.rs:38-50 restated) for the same Task vectors, through the C ABI, whatever the chunking."""
 import numpy as np
 import pytest
@@ -61,7 +61,7 @@ def test_wave_kernel_with_fasta_records(built, gpu_ctx, coracle):
 
 
 def test_wave_kernel_refuses_bad_images(built, gpu_ctx):
-    """A descriptor that would read outside its source, a chunk with more than 64 descriptors or more than 8 KiB of result, a chunk
+    """A descriptor that would read outside its source, a chunk with more than 64 descriptors or more than 10 KiB of result, a chunk
     table that points outside the descriptor array: reported (the reference would panic, task.rs:43,47), never executed."""
     from vcf2prot_amd.cohort import Cohort
     from vcf2prot_amd.engine import V2PError

@@ -1,4 +1,4 @@
-"""Host logic of wave images (sir_pack.hpp, kernel choice 4: chunks of <= 64 descriptors and <= 8 KiB for stitchw_kernel), no GPU:
+"""Host logic of wave images (sir_pack.hpp, kernel choice 4: chunks of <= 64 descriptors and <= 10 KiB for stitchw_kernel), no GPU:
 interpreted in numpy the image equals the per-block image of the same haplotypes; every chunk respects what one wave takes;
 parts packed by several threads are cut in arena coordinates."""
 import numpy as np
@@ -27,12 +27,12 @@ def test_wave_image_equals_the_per_block_image(built, preset, h0, n):
         assert np.array_equal(w.hap_out_begin, base.hap_out_begin)
         assert np.array_equal(interpret_image(w.desc, w.chunks, prot, w.payload, w.out_bytes), want), (preset, threads)
         nd, dst, nbytes = _geometry(w)
-        assert nd.max() <= 64 and ((dst & 15) + nbytes).max() <= 8192
+        assert nd.max() <= 64 and ((dst & 15) + nbytes).max() <= 10240
         assert (((w.chunks[:, 1] >> np.uint64(60)) & np.uint64(0xF)) == 1).all()              # CHUNK_WAVE and no other routing flag
         assert (w.launch_bits & 4) and (w.launch_bits & 48) == 48
-        if preset in ("C2", "C4"):
-            # cuts are aligned in the ARENA whatever part a thread packed: whole 1 KiB rows, nearly always eight of them
-            assert (dst % 1024 == 0).mean() > 0.9 and (nbytes == 8192).mean() > 0.8, (preset, threads)
+        if preset == "C2":
+            # cuts are aligned in the ARENA whatever part a thread packed: whole 1 KiB rows, nearly always ten of them
+            assert (dst % 1024 == 0).mean() > 0.9 and (nbytes == 10240).mean() > 0.8, (preset, threads)
 
 
 def test_long_run_cohorts_choose_the_wave_kernel(built):
@@ -57,17 +57,17 @@ def test_wave_image_any_chunking(built, chunk_tasks, chunk_bytes, cut_align, sof
     w = c.pack(40, 43, n_threads=2, kernel=4, chunk_tasks=chunk_tasks, chunk_bytes=chunk_bytes, cut_align=cut_align, soft_window=soft_window)
     assert np.array_equal(interpret_image(w.desc, w.chunks, prot, w.payload, w.out_bytes), want)
     nd, dst, nbytes = _geometry(w)
-    assert nd.max() <= min(chunk_tasks, 64) and nbytes.max() <= chunk_bytes and ((dst & 15) + nbytes).max() <= 8192
+    assert nd.max() <= min(chunk_tasks, 64) and nbytes.max() <= chunk_bytes and ((dst & 15) + nbytes).max() <= 10240
 
 
 def test_wave_grid_image_equals_oracle_and_refuses_overfull_windows(built, coracle):
-    """Grid cutting for the device builder: chunk k = result bytes [k*W, (k+1)*W), W <= 8 KiB; a window with more than 64 descriptors
+    """Grid cutting for the device builder: chunk k = result bytes [k*W, (k+1)*W), W <= 10 KiB; a window with more than 64 descriptors
     is refused (the device builder reports the same window)."""
     from vcf2prot_amd.cohort import Cohort
     c = Cohort.preset("C2")
-    img = c.pack_grid(0, 2, 8192, 4)
+    img = c.pack_grid(0, 2, 10240, 4)
     dst = (img.chunks[:, 1] & np.uint64((1 << 48) - 1)).astype(np.int64)
-    assert np.array_equal(dst, np.arange(dst.size) * 8192) and (img.launch_bits & 4)
+    assert np.array_equal(dst, np.arange(dst.size) * 10240) and (img.launch_bits & 4)
     out = interpret_image(img.desc, img.chunks, c.proteome(), img.payload, img.out_bytes)
     for h in range(2):
         hap = c.haplotype(h)
@@ -78,4 +78,4 @@ def test_wave_grid_image_equals_oracle_and_refuses_overfull_windows(built, corac
     with pytest.raises(RuntimeError):
         Cohort.preset("C5").pack_grid(0, 4, 8192, 4)               # ~1 000 descriptors per 8 KiB window
     with pytest.raises(RuntimeError):
-        c.pack_grid(0, 2, 12288, 4)                                 # a wave chunk is at most eight rows
+        c.pack_grid(0, 2, 12288, 4)                                 # a wave chunk is at most ten rows

@@ -60,7 +60,7 @@ def run_chunk(desc, tb, dn, spaces, out, stats):
     if total == 0:
         return
     nblk = (ptotal + 15) >> 4
-    assert nblk <= 512, nblk
+    assert nblk <= 640, nblk
     sent = dict(kind="dots", src=0, start=ptotal, end=0xFFFF, lit=NOLIT, byte=0)
     recs += [sent] * (68 - n)
 
@@ -93,7 +93,7 @@ def run_chunk(desc, tb, dn, spaces, out, stats):
         return v
 
     # map: number of records t >= 1 with start <= 16k
-    marks = np.zeros(512, np.int64)
+    marks = np.zeros(640, np.int64)
     for t in range(1, n):
         kmin = (recs[t]["start"] + 15) >> 4
         if kmin < nblk:

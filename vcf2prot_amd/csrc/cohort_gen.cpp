@@ -675,8 +675,8 @@ void v2p_txstream_free(v2p_txstream_buf* s)
 // The host image the device builder must reproduce: the transcript stream through ImageBuilder's step-5 folding with grid cutting.
 int v2p_cohort_pack_grid(const v2p_cohort* c, uint64_t h0, uint64_t h1, uint32_t window_bytes, int kernel, v2p_packed_image* out)
 {
-    if (!c || !out || h1 < h0 || window_bytes == 0 || window_bytes % 4096u) return -1;
-    if (kernel == 4 && window_bytes > v2p::CHUNK_BYTES_WAVE) return -1;        // a wave chunk is at most eight 1 KiB rows
+    if (!c || !out || h1 < h0 || window_bytes == 0 || window_bytes % (kernel == 4 ? 1024u : 4096u)) return -1;
+    if (kernel == 4 && window_bytes > v2p::CHUNK_BYTES_WAVE) return -1;        // a wave chunk is at most ten 1 KiB rows
     memset(out, 0, sizeof *out);
     v2p_txstream_buf s;
     int rc = v2p_cohort_txstream(c, h0, h1, 8, &s);

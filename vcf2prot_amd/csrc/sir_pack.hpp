@@ -75,7 +75,7 @@ constexpr uint32_t CHUNK_TASKS_DEEP = 1024;    // ... for dense images (a few re
 constexpr uint32_t CHUNK_TASKS_WAVE = 64;      // DESCRIPTORS per work item of a wave image (stitchw_kernel: one wave per chunk, one descriptor per lane)
 constexpr uint32_t CHUNK_BYTES = 64u * 1024u - 16u;  // most result bytes a work item may hold (<= 4096 16-byte blocks incl. a ragged head)
 constexpr uint32_t CHUNK_BYTES_LONG = 32u * 1024u;   // ... of a long-run work item: 2048 blocks = eight 1 KiB rows per wave, all gathered before the first store
-constexpr uint32_t CHUNK_BYTES_WAVE = 8192;    // ... of a wave image, ragged head included: 512 blocks = eight 1 KiB rows of ONE wave (twelve rows do not fit 64 VGPRs: hipcc spills the gathers' destination registers)
+constexpr uint32_t CHUNK_BYTES_WAVE = 10240;   // ... of a wave image, ragged head included: 640 blocks = ten 1 KiB rows of ONE wave (62 VGPRs; twelve rows do not fit 64: hipcc spills the gathers' destination registers)
 constexpr uint32_t CUT_ALIGN_WAVE = 1024;      // preferred cut of a wave image: whole 1 KiB rows
 constexpr uint32_t CHUNK_BYTES_DENSE = 12272;  // ... of a dense image: the 12 KiB LDS image of stitch_dense_kernel takes the chunk in one window
 constexpr uint32_t DENSE_BELOW = 40;           // a chunk with fewer result bytes per task than this switches the builder to dense chunks
@@ -84,7 +84,7 @@ constexpr uint64_t DST_MASK   = (1ull << 48) - 1;
 constexpr uint64_t CHUNK_LONG = 1ull << 63;    // chunk header flag: long-run chunk
 constexpr uint64_t CHUNK_LONG2 = 1ull << 62;   // ... holding 257..512 tasks (two task records per lane)
 constexpr uint64_t CHUNK_DENSE = 1ull << 61;   // chunk header flag: chunk of a dense image (short tasks, fused descriptors allowed): stitch_dense_kernel
-constexpr uint64_t CHUNK_WAVE = 1ull << 60;    // chunk header flag: chunk of a wave image (<= 64 descriptors, <= 8 KiB, fused substitutions allowed): stitchw_kernel
+constexpr uint64_t CHUNK_WAVE = 1ull << 60;    // chunk header flag: chunk of a wave image (<= 64 descriptors, <= 10 KiB, fused substitutions allowed): stitchw_kernel
 constexpr uint32_t CHUNK_N_MASK = 0x7FF;       // descriptor count: bits 48..58 of dst_n
 inline uint32_t chunk_n(uint64_t dst_n) { return uint32_t(dst_n >> 48) & CHUNK_N_MASK; }
 constexpr uint32_t LONG_RUN_BYTES_PER_TASK = 120;   // an image whose first chunk has at least this many result bytes per task goes to stitch4_kernel
@@ -247,10 +247,10 @@ private:
     // what chunk_tasks limits: tasks, or -- in a dense image, whose kernel has one lane slot per DESCRIPTOR -- descriptors
     uint32_t open_units() const { return kernel_choice == 3 || kernel_choice == 4 ? open_desc_ : open_n_; }
     // ... and a dense image cuts at any multiple of 16 (its chunks are a few KiB: a 4 KiB preference would cost a third of them)
-    // a wave image at whole 1 KiB rows (its chunks are at most eight of them)
+    // a wave image at whole 1 KiB rows (its chunks are at most ten of them)
     uint32_t cut_pref() const { return kernel_choice == 3 && adaptive_bytes ? 16u : (kernel_choice == 4 && cut_align > CUT_ALIGN_WAVE ? CUT_ALIGN_WAVE : cut_align); }
     bool open_fused_ = false;                // it holds a fused descriptor
-    // most result bytes the open (or next) chunk may hold: a wave chunk is eight rows INCLUDING the ragged head of an unaligned start
+    // most result bytes the open (or next) chunk may hold: a wave chunk is ten rows INCLUDING the ragged head of an unaligned start
     uint32_t byte_limit() const { return kernel_choice == 4 ? chunk_bytes - uint32_t((open_n_ ? open_dst_ : arena_cursor_) & 15u) : chunk_bytes; }
     // wave image: the LAST preferred boundary (whole 1 KiB rows) the open chunk can reach -- where it is cut unless it runs out of
     // descriptor slots first

@@ -6,23 +6,23 @@
 //     until its slowest wave has stored its last row -- a third of the long-run kernel's time was per-workgroup cost;
 //   * the per-block kernel is VALU-bound because every lane runs the multi-source merge for every block;
 //   * a fused substitution was expanded back into three tasks, which tripled every table the set-up builds.
-// Here a chunk is at most 64 descriptors and 8 KiB of result and belongs to ONE wave: lane = descriptor in the set-up, lane =
+// Here a chunk is at most 64 descriptors and 10 KiB of result and belongs to ONE wave: lane = descriptor in the set-up, lane =
 // 16-byte block in the copy.  Nothing crosses a wave, so there is no s_barrier at all (LDS operations of one wave execute in
-// order), scans are one DPP pass with the total read by v_readlane, and a wave slot is free the moment its own eight rows are
+// order), scans are one DPP pass with the total read by v_readlane, and a wave slot is free the moment its own ten rows are
 // stored.  A descriptor is ONE record -- a fused substitution is a reference run with one residue replaced, not three tasks:
 //   A  descriptor -> record {source address - start, start, end, substituted position + byte}; DPP scan of the lengths;
 //      +1 scattered into a byte-per-block map at the first block starting inside or after each record
 //   C  in-lane SWAR prefix + wave scan of the map: map[k] = record covering the first byte of block k (8 blocks per lane)
 //   P  lane = record: a record that starts inside a block fetches its own stream at that block (ONE gather per lane); the first
 //      record to start inside a block overlays the pieces of the records that follow it there and parks the block's tail in LDS
-//   K  lane = block, eight 1 KiB rows per wave: one map byte + one record per block, then one byte-granular dwordx4 gather of
+//   K  lane = block, ten 1 KiB rows per wave: one map byte + one record per block, then one byte-granular dwordx4 gather of
 //      the covering record's stream for EVERY block; at store time a block its record ends in takes the parked tail from the
-//      record's end on (mask from a 17-entry LDS table), a replaced residue inside the block is placed.  All eight rows are
+//      record's end on (mask from a 17-entry LDS table), a replaced residue inside the block is placed.  All ten rows are
 //      gathered before the first store (gfx950 counts loads and stores in one in-order counter), then leave as aligned
 //      non-temporal dwordx4 buffer stores, 1 KiB per instruction.
 // An immediate descriptor's literal bytes are read as a stream too: out of the descriptor array itself (their record's source
 // address is the descriptor's own address), which is why the array needs 16 readable bytes before and 32 behind it.
-// Ten vector-memory instructions per 8 KiB on the read side (descriptors, patch gather, eight row gathers), eight on the write
+// Twelve vector-memory instructions per 10 KiB on the read side (descriptors, patch gather, ten row gathers), ten on the write
 // side: the kernel is bound by the CU's vector-memory pipeline and the latency chain of a wave, not by its ~450 VALU instructions.
 // A descriptor that would read out of bounds is reported in the device status word and its chunk is not executed; nothing is
 // ever read or written outside the buffers (sources carry PAD_BYTES of readable slack, as for the other kernels).
@@ -98,13 +98,14 @@ __device__ __forceinline__ u32x4 wmerge(u32x4 v, u32x4 ld, u32x4 m)      // byte
 // WPG waves per workgroup, each with its own chunk and its own LDS tables; the waves of a workgroup share nothing but the
 // (identical) mask and selector tables.
 //
-// (__launch_bounds__(.., 8): eight waves per SIMD, i.e. 64 VGPRs -- the kernel lives on occupancy; it fits without scratch.)
+// (__launch_bounds__(.., 8): eight waves per SIMD, i.e. 64 VGPRs -- the kernel lives on occupancy; with ten rows in flight it
+// takes 62 and no scratch; twelve rows spill the gathers' destination registers.)
 // Everything between the descriptor load and the last store is STRAIGHT-LINE code: selects, dummy addresses (a readable buffer of
 // dots) and range-checked buffer stores instead of branches.  hipcc cannot count outstanding memory operations across a branch
 // that may or may not issue one; it then waits vmcnt(0) at the next use -- round 2's stitch4_kernel had "if (patch) read LDS
 // else gather" per row and a lane-conditional store per row, and its code waited for every gather before issuing the next one
 // and for every store's acknowledgement before issuing the next store (its own stamps: 7 500 + 4 900 cycles of a workgroup's
-// 24 400).  Here the eight gathers issue back to back and every wait is a counted one.
+// 24 400).  Here the ten gathers issue back to back and every wait is a counted one.
 #ifndef V2P_WAVE_OCC
 #define V2P_WAVE_OCC 8
 #endif
@@ -116,10 +117,10 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
                                                             uint32_t n_chunks, uint64_t n_desc, uint64_t src0_len, uint64_t src1_len, uint64_t out_len)
 {
     constexpr uint32_t ROWS = CHUNK_BYTES_WAVE / 1024u;              // 1 KiB rows of a chunk: all gathered before the first store
-    static_assert(ROWS % 4u == 0u && ROWS <= 16u, "a lane's map bytes and patch indices are packed four rows to a register");
-    constexpr uint32_t ND = ROWS / 4u;                               // map dwords per lane (ROWS one-byte counters)
+    static_assert(ROWS <= 16u, "a lane's map bytes and record indices are packed four rows to a register");
+    constexpr uint32_t ND = (ROWS + 3u) / 4u;                        // map dwords per lane (4 * ND >= ROWS one-byte counters)
     struct WaveLds {
-        uint32_t map32[CHUNK_BYTES_WAVE / 64u];                      // one byte per 16-byte block: record covering its first byte
+        uint32_t map32[64u * ND];                                    // one byte per 16-byte block: record covering its first byte
         WRec rec[CHUNK_TASKS_WAVE + 4];                              // + sentinels
         u32x4 patch[CHUNK_TASKS_WAVE + 1];                           // [t]: record t's own piece, then (owners) the parked tail of the block it starts in; [64]: scrap
     };
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
     asm volatile("" ::: "memory");
 
     // ---- K, first half: lane = block.  Per group of four rows: the map bytes, the four records (they land in the registers the
-    //      gathers will fill), then per row the gather of the covering record's stream -- for EVERY block, cut or not.  The eight
+    //      gathers will fill), then per row the gather of the covering record's stream -- for EVERY block, cut or not.  The ten
     //      gathers issue back to back, behind the patch phase's one. ----
     const uint8_t* const map8 = reinterpret_cast<const uint8_t*>(L.map32);
     uint8_t* const out0 = p_out + (dst - head);                      // 16-byte aligned
@@ -244,15 +245,16 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
 #pragma unroll
         for (uint32_t q = 0; q < 4u; ++q) {
             const uint32_t b16 = ((4u * g + q) << 10) + lane16;
-            rr[q] = b16 < ptotal ? uint32_t(map8[b16 >> 4]) : n;     // idle lanes look at a sentinel (dots)
+            rr[q] = (4u * g + q < ROWS && b16 < ptotal) ? uint32_t(map8[b16 >> 4]) : n;     // idle lanes look at a sentinel (dots)
         }
 #pragma unroll
-        for (uint32_t q = 0; q < 4u; ++q) v[4u * g + q] = reinterpret_cast<const u32x4*>(L.rec)[rr[q]];   // (one 16-byte read: field by field, the address half is sunk into a branch)
+        for (uint32_t q = 0; q < 4u; ++q) if (4u * g + q < ROWS) v[4u * g + q] = reinterpret_cast<const u32x4*>(L.rec)[rr[q]];   // (one 16-byte read: field by field, the address half is sunk into a branch)
         pk[g] = rr[0] | (rr[1] << 8) | (rr[2] << 16) | (rr[3] << 24);
         asm volatile("" : "+v"(pk[g]));                              // (packed NOW: four live registers become one)
 #pragma unroll
         for (uint32_t q = 0; q < 4u; ++q) {
             const uint32_t j = 4u * g + q, b16 = (j << 10) + lane16;
+            if (j >= ROWS) break;
             const u32x4 t = v[j];
             const uint64_t A = ((uint64_t(t[1]) << 32) | t[0]) + b16;
             const uint64_t X = (V2P_WAVE_ABLATE & 1) != 0 ? dots16 : A;
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out0, 0, int(ptotal), 0x00020000);
     const int32_t last16 = int32_t(ptotal) - 16;                     // a block at b16 <= last16 ends inside the chunk
     uint32_t l16 = lane16;
-    asm volatile("" : "+v"(l16));                                    // (the rows' positions are recomputed from here, not kept in eight registers since the look-ups)
+    asm volatile("" : "+v"(l16));                                    // (the rows' positions are recomputed from here, not kept in ten registers since the look-ups)
 #pragma unroll
     for (uint32_t j = 0; j < ROWS; ++j) {
         const uint32_t b16 = (j << 10) + l16;

@@ -658,9 +658,10 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     std::lock_guard<std::mutex> lk(c->mu);
     if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
     if (b->hap_open || b->img.n_haplotypes()) return c->fail(V2P_ERR_STATE, "the batch already holds host-built haplotypes");
-    if (window_bytes == 0 || window_bytes % 4096u || window_bytes > CHUNK_BYTES - 4080u) return c->fail(V2P_ERR_INVALID_ARG, "window_bytes must be a multiple of 4096, at most 61440");
+    if (window_bytes == 0 || window_bytes % (kernel == 4 ? 1024u : 4096u) || window_bytes > CHUNK_BYTES - 4080u)
+        return c->fail(V2P_ERR_INVALID_ARG, "window_bytes must be a multiple of 4096 (wave images: of 1024), at most 61440");
     if (kernel == 1 && window_bytes > CHUNK_BYTES_LONG) return c->fail(V2P_ERR_INVALID_ARG, "the long-run kernel takes windows of at most 32768 bytes");
-    if (kernel == 4 && window_bytes > CHUNK_BYTES_WAVE) return c->fail(V2P_ERR_INVALID_ARG, "a wave image takes windows of 4096 or 8192 bytes (one chunk = eight 1 KiB rows of one wave)");
+    if (kernel == 4 && window_bytes > CHUNK_BYTES_WAVE) return c->fail(V2P_ERR_INVALID_ARG, "a wave image takes windows of at most 10240 bytes (one chunk = ten 1 KiB rows of one wave)");
     // (a grid chunk starts on a multiple of 4096: no 16-byte phase, so 12288 bytes fill the kernel's LDS image exactly)
     if (kernel == 3 && window_bytes > 12288u) return c->fail(V2P_ERR_INVALID_ARG, "a dense image takes windows of 4096, 8192 or 12288 bytes (one chunk = one 12 KiB LDS image)");
     if (!s->hap_tx_begin || (s->n_tx && (!s->tx_proteome_off || !s->tx_ref_len || !s->tx_res_len || !s->tx_task_begin || !s->tx_alt_begin)) ||
