@@ -118,6 +118,7 @@ typedef struct {
     uint64_t* hap_tx_begin; uint64_t* tx_proteome_off; uint32_t* tx_ref_len; uint32_t* tx_res_len;
     uint64_t* tx_task_begin; uint64_t* tx_alt_begin;
     uint8_t* code; uint32_t* start_pos; uint32_t* length; uint32_t* start_pos_res; uint8_t* alt;
+    uint64_t* tx_header_off; uint32_t* tx_header_len;      /* NULL from v2p_cohort_txstream (plain result tapes) */
 } v2p_txstream_buf;
 int  v2p_cohort_txstream(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads, v2p_txstream_buf* out);
 void v2p_txstream_free(v2p_txstream_buf* s);

@@ -185,6 +185,12 @@ typedef struct {
     const uint32_t* length;            /* [n_tasks]                                                                     */
     const uint32_t* start_pos_res;     /* [n_tasks]                                                                     */
     const uint8_t*  alt;               /* [n_alt] alt tapes of the transcripts back to back, 1 byte per residue         */
+    /* FASTA emit fused into the build (personalized_genome.rs:90-113; NULL, NULL: plain result tapes).  Transcript t's arena range
+     * then holds its record: the header text at [tx_header_off[t], +tx_header_len[t]) of the resident header table
+     * (v2p_upload_reference; it ends in '\n'), its residues, '\n' -- a haplotype's arena range is file-ready.  tx_header_len[t] == 0
+     * writes the residues of that transcript alone. */
+    const uint64_t* tx_header_off;     /* [n_tx] */
+    const uint32_t* tx_header_len;     /* [n_tx] */
 } v2p_txstream;
 /* kernel: 1 = route every chunk to the long-run kernel (<= 512 descriptors per window), 2 = per-block kernel, 3 = dense image
  * (stitch_dense_kernel: short tasks, fused substitutions, <= 1024 descriptors per window: windows of 4, 8 or 12 KiB, larger ones are

@@ -37,7 +37,8 @@ class TxStreamBuf(ctypes.Structure):
                 ("hap_tx_begin", POINTER(c_uint64)), ("tx_proteome_off", POINTER(c_uint64)), ("tx_ref_len", POINTER(c_uint32)),
                 ("tx_res_len", POINTER(c_uint32)), ("tx_task_begin", POINTER(c_uint64)), ("tx_alt_begin", POINTER(c_uint64)),
                 ("code", POINTER(c_uint8)), ("start_pos", POINTER(c_uint32)), ("length", POINTER(c_uint32)),
-                ("start_pos_res", POINTER(c_uint32)), ("alt", POINTER(c_uint8))]
+                ("start_pos_res", POINTER(c_uint32)), ("alt", POINTER(c_uint8)),
+                ("tx_header_off", POINTER(c_uint64)), ("tx_header_len", POINTER(c_uint32))]
 
 
 class Instruction(ctypes.Structure):

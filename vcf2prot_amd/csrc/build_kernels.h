@@ -23,13 +23,15 @@ struct BuildArgs {
     const uint32_t* length;
     const uint32_t* start_pos_res;
     const uint8_t*  alt;
+    const uint64_t* tx_header_off;   // FASTA emit (nullptr: plain tapes): record header of transcript t in the resident header table ...
+    const uint32_t* tx_header_len;   // ... and its length (0: no record text for this transcript)
     uint64_t proteome_len;
     uint32_t window;              // result bytes per chunk (grid)
     int      long_run;            // route every chunk to stitch4_kernel
     int      dense;               // ... to stitch_dense_kernel (fusion on as for long_run)
     int      wave;                // with long_run: ... to stitchw_kernel instead (windows of <= 8 KiB and <= 64 descriptors)
     // scans and outputs
-    const uint64_t* tx_res_base;  // [n_tx + 1] exclusive prefix of tx_res_len
+    const uint64_t* tx_res_base;  // [n_tx + 1] exclusive prefix of the transcripts' arena lengths (tx_res_len, + header + line feed with FASTA emit)
     uint32_t* tx_desc_count;      // [n_tx]
     const uint64_t* desc_base;    // [n_tx + 1] exclusive prefix of tx_desc_count
     uint64_t* desc;

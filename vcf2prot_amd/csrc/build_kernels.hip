@@ -249,7 +249,7 @@ struct Walker {
         }
         if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && src + len + 1 + SNV3_MAX_LEN <= SNV3_MAX_SRC) { s0 = Staged{space, src, len, rel}; st_n = 1; return; }
         // a dense image: a lone literal may open a fused run (the copy before it is empty: flush() writes nothing for it)
-        if (MODE == 2 && space == SPACE_IMM && len == 1) { s0 = Staged{SPACE_PROTEOME, 0, 0, rel}; s1 = Staged{space, src, len, rel}; st_n = 2; return; }
+        if ((MODE == 2 || (MODE == 1 && a.wave)) && space == SPACE_IMM && len == 1) { s0 = Staged{SPACE_PROTEOME, 0, 0, rel}; s1 = Staged{space, src, len, rel}; st_n = 2; return; }
         out(space, src, len, rel);
     }
 };
@@ -265,6 +265,11 @@ __global__ __launch_bounds__(256) void walk_kernel(BuildArgs a)
     const uint64_t poff = a.tx_proteome_off[t];
     const uint32_t ref_len = a.tx_ref_len[t], res_len = a.tx_res_len[t];
     Walker<EMIT, MODE> w(a, EMIT ? a.desc_base[t] : 0, base);
+    // FASTA emit (personalized_genome.rs:90-113): the transcript's arena range is header, residues, line feed; result positions
+    // of its tasks move behind the header
+    const uint32_t hl = a.tx_header_len ? a.tx_header_len[t] : 0u;
+    const uint64_t hsrc = hl ? a.proteome_len + a.tx_header_off[t] : 0ull;
+    if (hl) w.out(SPACE_PROTEOME, hsrc, hl, 0);
     uint64_t cur = 0;
     bool ok = true;
     if (!EMIT && poff + ref_len > a.proteome_len) { breport(a.status, i0, STATUS_SRC_OOB); ok = false; }   // transcript outside the resident proteome
@@ -310,19 +315,20 @@ __global__ __launch_bounds__(256) void walk_kernel(BuildArgs a)
             else if (sr < cur) why = STATUS_NOT_CONTIGUOUS;                  // result ranges overlap or go backwards
             if (why) { breport(a.status, i, why); ok = false; break; }
         }
-        if (sr > cur) { w.flush(); w.out(SPACE_FILL, 0, sr - cur, cur); }                     // cells no task covers keep '.'
-        if (code == 0) w.stage(SPACE_PROTEOME, poff + sp, ln, sr);
+        if (sr > cur) { w.flush(); w.out(SPACE_FILL, 0, sr - cur, hl + cur); }                // cells no task covers keep '.'
+        if (code == 0) w.stage(SPACE_PROTEOME, poff + sp, ln, hl + sr);
         else if (ln >= 1 && ln <= IMM_MAX_BYTES) {                           // short alt payloads travel inside their descriptor
             // (one unaligned 8-byte load -- the payload arena has 32 readable bytes behind it -- instead of up to five dependent byte loads)
             struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
             const uint64_t lit = reinterpret_cast<const U64*>(a.alt + alt0 + sp)->v & (~0ull >> (64u - 8u * uint32_t(ln)));
-            w.stage(SPACE_IMM, lit, ln, sr);
-        } else w.stage(SPACE_PAYLOAD, alt0 + sp, ln, sr);
+            w.stage(SPACE_IMM, lit, ln, hl + sr);
+        } else w.stage(SPACE_PAYLOAD, alt0 + sp, ln, hl + sr);
         cur = sr + ln;
         }
     }
     w.flush();
-    if (ok && cur < res_len) w.out(SPACE_FILL, 0, res_len - cur, cur);
+    if (ok && cur < res_len) w.out(SPACE_FILL, 0, res_len - cur, hl + cur);
+    if (ok && hl) w.out(SPACE_PROTEOME, hsrc + hl - 1u, 1, uint64_t(hl) + res_len);              // the record's line feed = the header's own
     if (EMIT) w.sink.finish(a.desc, w.k);
     if (!EMIT) a.tx_desc_count[t] = ok ? w.cnt : 0u;
 }

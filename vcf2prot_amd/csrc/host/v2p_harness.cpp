@@ -200,7 +200,7 @@ static std::map<std::string, std::string> read_fasta(const std::string& text)
     return rec;
 }
 
-static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* outdir, bool no_test, bool write_all, bool compressed)
+static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* outdir, bool no_test, bool write_all, bool compressed, bool host_build)
 {
     using clk = std::chrono::steady_clock;
     auto since = [](clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); };
@@ -273,6 +273,27 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
                              reinterpret_cast<const uint8_t*>(headers.data()), headers.size()));
     v2p_batch* b = nullptr;
     chk(v2p_batch_create(ctx.raw(), &b));
+    // Step 5, the image packing and the record text are built ON the device (v2p_batch_build_on_device) from the per-transcript GIRs
+    // collected here as they come out of step 4b; --host-build keeps the host builder (v2p_batch_add_transcript): same bytes.
+    struct TxStreamHost {
+        std::vector<uint64_t> hap_tx_begin{0}, off, task_begin{0}, alt_begin{0}, hdr_off;
+        std::vector<uint32_t> ref_len, res_len, hdr_len, sp, ln, sr;
+        std::vector<uint8_t> code, alt;
+        uint64_t result_bytes = 0;
+        void add(const uint8_t* c, const uint64_t* p, const uint64_t* l, const uint64_t* r, uint64_t n, uint64_t o, uint64_t rl,
+                 const uint8_t* a, uint64_t na, uint64_t res, uint64_t ho, uint32_t hl) {
+            for (uint64_t i = 0; i < n; ++i) { code.push_back(c[i]); sp.push_back(uint32_t(p[i])); ln.push_back(uint32_t(l[i])); sr.push_back(uint32_t(r[i])); }
+            alt.insert(alt.end(), a, a + na);
+            off.push_back(o); ref_len.push_back(uint32_t(rl)); res_len.push_back(uint32_t(res)); hdr_off.push_back(ho); hdr_len.push_back(hl);
+            task_begin.push_back(code.size()); alt_begin.push_back(alt.size());
+            result_bytes += res + (hl ? hl + 1u : 0u);
+        }
+    } txs;
+    auto add_transcript = [&](const uint8_t* c, const uint64_t* p, const uint64_t* l, const uint64_t* r, uint64_t n, uint64_t o, uint64_t rl,
+                              const uint8_t* a, uint64_t na, uint64_t res, uint64_t ho, uint32_t hl) {
+        if (host_build) chk(v2p_batch_add_transcript(b, c, p, l, r, n, o, rl, a, na, res, ho, hl));
+        else txs.add(c, p, l, r, n, o, rl, a, na, res, ho, hl);
+    };
     const uint64_t* hgb = v2p_groups_hap_group_begin(g);
     const uint32_t* gtx = v2p_groups_group_transcript(g);
     const uint64_t* gmb = v2p_groups_group_member_begin(g);
@@ -285,10 +306,10 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
     const uint8_t ref_code = 0;
     const uint64_t zero = 0;
     auto reference_copy = [&](const RefTx& t, uint64_t hap, size_t name_len) {        // personalized_genome.rs:176-183: not altered -> as in the reference
-        chk(v2p_batch_add_transcript(b, &ref_code, &zero, &t.len, &zero, 1, t.off, t.len, nullptr, 0, t.len, t.hdr[hap & 1], uint32_t(name_len + 4)));
+        add_transcript(&ref_code, &zero, &t.len, &zero, 1, t.off, t.len, nullptr, 0, t.len, t.hdr[hap & 1], uint32_t(name_len + 4));
     };
     for (uint64_t hap = 0; hap < 2 * S; ++hap) {
-        chk(v2p_batch_begin_haplotype(b));
+        if (host_build) chk(v2p_batch_begin_haplotype(b));
         // the haplotype's groups, and with -a the rest of the reference around them, in sorted transcript order
         std::vector<std::pair<const std::pair<const std::string, RefTx>*, int64_t>> todo;     // (reference entry, group index or -1)
         if (write_all) {
@@ -323,13 +344,34 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
                 std::fprintf(stderr, "panicked: size mismatched / non-contiguous tasks in transcript %s\n", names[r].c_str());
                 return 101;
             }
-            chk(v2p_batch_add_transcript(b, code.data(), sp.data(), ln.data(), sr.data(), n_tasks, uint64_t(tx_off[r]), tx_len[r],
-                                         alt.data(), n_alt, res_len, hdr_off[2 * r + (hap & 1)], uint32_t(names[r].size() + 4)));
+            add_transcript(code.data(), sp.data(), ln.data(), sr.data(), n_tasks, uint64_t(tx_off[r]), tx_len[r],
+                           alt.data(), n_alt, res_len, hdr_off[2 * r + (hap & 1)], uint32_t(names[r].size() + 4));
         }
-        chk(v2p_batch_end_haplotype(b));
+        if (host_build) chk(v2p_batch_end_haplotype(b));
+        else txs.hap_tx_begin.push_back(txs.off.size());
     }
     t_build = since(t0); t0 = clk::now();
-    chk(v2p_batch_finalize(b));
+    if (host_build) chk(v2p_batch_finalize(b));
+    else {
+        // (the builder's slab loads read a few entries past a transcript's last task / alt byte)
+        for (int k = 0; k < 64; ++k) { txs.code.push_back(0); txs.sp.push_back(0); txs.ln.push_back(0); txs.sr.push_back(0); txs.alt.push_back(0); }
+        v2p_txstream st{};
+        st.n_haps = 2 * S; st.n_tx = txs.off.size(); st.n_tasks = txs.code.size() - 64; st.n_alt = txs.alt.size() - 64;
+        st.hap_tx_begin = txs.hap_tx_begin.data(); st.tx_proteome_off = txs.off.data(); st.tx_ref_len = txs.ref_len.data(); st.tx_res_len = txs.res_len.data();
+        st.tx_task_begin = txs.task_begin.data(); st.tx_alt_begin = txs.alt_begin.data();
+        st.code = txs.code.data(); st.start_pos = txs.sp.data(); st.length = txs.ln.data(); st.start_pos_res = txs.sr.data(); st.alt = txs.alt.data();
+        st.tx_header_off = txs.hdr_off.data(); st.tx_header_len = txs.hdr_len.data();
+        // routing as the host packer would choose it (result bytes per task); a window with too many descriptors is retried smaller
+        const double bpt = double(txs.result_bytes) / double(st.n_tasks ? st.n_tasks : 1);
+        const std::pair<int, uint32_t> long_plan[] = {{4, 10240}, {4, 4096}, {2, 32768}, {2, 16384}, {2, 4096}, {3, 12288}, {3, 8192}, {3, 4096}};
+        const std::pair<int, uint32_t> mid_plan[] = {{2, 32768}, {2, 16384}, {2, 4096}, {3, 12288}, {3, 8192}, {3, 4096}};
+        const std::pair<int, uint32_t> dense_plan[] = {{3, 12288}, {3, 8192}, {3, 4096}, {2, 4096}};
+        const std::pair<int, uint32_t>* plan = bpt >= 120 ? long_plan : (bpt >= 40 ? mid_plan : dense_plan);
+        const size_t n_plan = bpt >= 120 ? 8 : (bpt >= 40 ? 6 : 4);
+        int rc = V2P_ERR_UNSUPPORTED;
+        for (size_t k = 0; k < n_plan && rc == V2P_ERR_UNSUPPORTED; ++k) rc = v2p_batch_build_on_device(b, &st, plan[k].second, plan[k].first, nullptr);
+        chk(rc);
+    }
     chk(v2p_batch_execute(b));
     chk(v2p_batch_sync(b));
     t_exec = since(t0); t0 = clk::now();
@@ -382,13 +424,14 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
 int main(int argc, char** argv)
 {
     if (argc >= 5 && !std::strcmp(argv[1], "vcf")) {
-        bool no_test = false, write_all = false, compressed = false;
+        bool no_test = false, write_all = false, compressed = false, host_build = false;
         for (int i = 5; i < argc; ++i) {
             no_test |= !std::strcmp(argv[i], "--no-test");
+            host_build |= !std::strcmp(argv[i], "--host-build");
             write_all |= !std::strcmp(argv[i], "--write-all") || !std::strcmp(argv[i], "-a");
             compressed |= !std::strcmp(argv[i], "--write-compressed") || !std::strcmp(argv[i], "-c");
         }
-        try { return vcf_mode(argv[2], argv[3], argv[4], no_test, write_all, compressed); }
+        try { return vcf_mode(argv[2], argv[3], argv[4], no_test, write_all, compressed, host_build); }
         catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 101; }
     }
     if (argc >= 2 && !std::strcmp(argv[1], "kat")) return kat();

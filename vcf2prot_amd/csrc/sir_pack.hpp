@@ -336,7 +336,9 @@ private:
         if (space == SPACE_PROTEOME && len <= SNV3_MAX_LEN && src + len + 1 + SNV3_MAX_LEN <= SNV3_MAX_SRC) { st_[0] = Staged{space, src, len}; st_n_ = 1; st0_virtual_ = false; return; }
         // a dense image: a lone literal may open a fused run -- [byte][copy] and [byte][copy][byte][copy] are the fused forms with an empty
         // first copy (in a chain of substitutions every descriptor then carries two of them)
-        if (kernel_choice == 3 && fuse_double && space == SPACE_IMM && len == 1) {
+        // (a wave image as well: a second substitution in a transcript is then one descriptor, not two, and more of its chunks reach
+        // their ten rows before their 64 descriptor slots run out)
+        if (((kernel_choice == 3 && fuse_double) || kernel_choice == 4) && space == SPACE_IMM && len == 1) {
             st_[0] = Staged{SPACE_PROTEOME, 0, 0}; st_[1] = Staged{space, src, len}; st_n_ = 2; st0_virtual_ = true;
             return;
         }

@@ -685,6 +685,22 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
         if (s->tx_proteome_off[t] + s->tx_ref_len[t] < s->tx_proteome_off[t])
             return c->fail(V2P_ERR_INVALID_ARG, "tx_proteome_off + tx_ref_len wraps at transcript " + std::to_string(t), int64_t(t));
     }
+    // FASTA emit: every record header inside the resident header table and ending in a line feed (the record's own line feed is read
+    // from there); a transcript's arena length is then header + residues + line feed
+    const bool fasta = s->tx_header_off && s->tx_header_len;
+    if ((s->tx_header_off == nullptr) != (s->tx_header_len == nullptr)) return c->fail(V2P_ERR_INVALID_ARG, "tx_header_off and tx_header_len come together");
+    std::vector<uint32_t> arena_len;
+    if (fasta) {
+        arena_len.resize(s->n_tx);
+        for (uint64_t t = 0; t < s->n_tx; ++t) {
+            const uint64_t ho = s->tx_header_off[t], hl = s->tx_header_len[t];
+            if (hl && (ho + hl > c->headers_len || ho + hl < ho)) return c->fail(V2P_ERR_SRC_OOB, "record header outside the resident header table at transcript " + std::to_string(t), int64_t(t));
+            if (hl && c->headers_host[ho + hl - 1] != '\n') return c->fail(V2P_ERR_INVALID_ARG, "a record header must end in a line feed (transcript " + std::to_string(t) + ")", int64_t(t));
+            const uint64_t al = uint64_t(s->tx_res_len[t]) + (hl ? hl + 1u : 0u);
+            if (al > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "a record of more than 4 GiB", int64_t(t));
+            arena_len[t] = uint32_t(al);
+        }
+    }
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     const uint64_t n_tx = s->n_tx, n_tk = s->n_tasks, n_h = s->n_haps;
     const uint64_t n_tiles = (n_tx + 1023) / 1024 + 2;
@@ -695,7 +711,8 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     const uint64_t o_hap = carve((n_h + 1) * 8), o_poff = carve(n_tx * 8), o_rlen = carve(n_tx * 4), o_res = carve(n_tx * 4),
                    o_tb = carve((n_tx + 1) * 8), o_ab = carve((n_tx + 1) * 8), o_code = carve(n_tk), o_sp = carve(n_tk * 4), o_ln = carve(n_tk * 4),
                    o_sr = carve(n_tk * 4), o_base = carve((n_tx + 1) * 8), o_cnt = carve(n_tx * 4), o_dbase = carve((n_tx + 1) * 8),
-                   o_tiles = carve(n_tiles * 8), o_meta = carve(16);
+                   o_tiles = carve(n_tiles * 8), o_meta = carve(16),
+                   o_hoff = carve(fasta ? n_tx * 8 : 0), o_hlen = carve(fasta ? n_tx * 4 : 0), o_alen = carve(fasta ? n_tx * 4 : 0);
     HIP_TRY(c, b->d_build.ensure(off), "hipMalloc(build)");
     uint8_t* const d = b->d_build.ptr();
     HIP_TRY(c, b->d_payload.ensure(s->n_alt), "hipMalloc(alt)");
@@ -705,6 +722,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     UP(o_tb, s->tx_task_begin, (n_tx + 1) * 8, "H2D(tx_task_begin)"); UP(o_ab, s->tx_alt_begin, (n_tx + 1) * 8, "H2D(tx_alt_begin)");
     UP(o_code, s->code, n_tk, "H2D(code)"); UP(o_sp, s->start_pos, n_tk * 4, "H2D(start_pos)"); UP(o_ln, s->length, n_tk * 4, "H2D(length)");
     UP(o_sr, s->start_pos_res, n_tk * 4, "H2D(start_pos_res)");
+    if (fasta) { UP(o_hoff, s->tx_header_off, n_tx * 8, "H2D(tx_header_off)"); UP(o_hlen, s->tx_header_len, n_tx * 4, "H2D(tx_header_len)"); UP(o_alen, arena_len.data(), n_tx * 4, "H2D(arena_len)"); }
 #undef UP
     if (s->n_alt) HIP_TRY(c, hipMemcpyAsync(b->d_payload.ptr(), s->alt, s->n_alt, hipMemcpyHostToDevice, c->stream), "H2D(alt)");
     HIP_TRY(c, hipMemsetAsync(d + o_meta, 0, 16, c->stream), "hipMemset(meta)");
@@ -735,13 +753,15 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     a.tx_task_begin = reinterpret_cast<const uint64_t*>(d + o_tb); a.tx_alt_begin = reinterpret_cast<const uint64_t*>(d + o_ab);
     a.code = d + o_code; a.start_pos = reinterpret_cast<const uint32_t*>(d + o_sp); a.length = reinterpret_cast<const uint32_t*>(d + o_ln);
     a.start_pos_res = reinterpret_cast<const uint32_t*>(d + o_sr); a.alt = b->d_payload.ptr();
+    a.tx_header_off = fasta ? reinterpret_cast<const uint64_t*>(d + o_hoff) : nullptr;
+    a.tx_header_len = fasta ? reinterpret_cast<const uint32_t*>(d + o_hlen) : nullptr;
     a.proteome_len = c->proteome_len; a.window = window_bytes; a.long_run = kernel == 1 || kernel == 4; a.dense = kernel == 3; a.wave = kernel == 4;
     a.tx_res_base = reinterpret_cast<const uint64_t*>(d + o_base); a.tx_desc_count = reinterpret_cast<uint32_t*>(d + o_cnt);
     a.desc_base = reinterpret_cast<const uint64_t*>(d + o_dbase); a.meta = reinterpret_cast<uint32_t*>(d + o_meta);
     a.status = reinterpret_cast<unsigned long long*>(b->d_status.ptr());
     // step 5: res_counter as a prefix scan; then count, scan, emit
     HIP_TRY(c, hipEventRecord(e0, c->stream), "hipEventRecord");
-    HIP_TRY(c, launch_scan_u32(a.tx_res_len, n_tx, reinterpret_cast<uint64_t*>(d + o_base), reinterpret_cast<uint64_t*>(d + o_tiles), c->stream), "launch(scan)");
+    HIP_TRY(c, launch_scan_u32(fasta ? reinterpret_cast<const uint32_t*>(d + o_alen) : a.tx_res_len, n_tx, reinterpret_cast<uint64_t*>(d + o_base), reinterpret_cast<uint64_t*>(d + o_tiles), c->stream), "launch(scan)");
     HIP_TRY(c, launch_build(a, 0, 0, 0, 0, c->stream), "launch(count)");
     HIP_TRY(c, launch_scan_u32(a.tx_desc_count, n_tx, reinterpret_cast<uint64_t*>(d + o_dbase), reinterpret_cast<uint64_t*>(d + o_tiles), c->stream), "launch(scan)");
     HIP_TRY(c, hipEventRecord(e1, c->stream), "hipEventRecord");

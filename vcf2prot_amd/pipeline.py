@@ -39,9 +39,12 @@ def read_fasta(text: str) -> Dict[str, str]:
     return records
 
 
-def vcf_to_fasta(ctx, vcf: bytes, reference_fasta: str, flags: int = step4a.DEFAULT_FLAGS, write_all: bool = False) -> Dict[str, bytes]:
+def vcf_to_fasta(ctx, vcf: bytes, reference_fasta: str, flags: int = step4a.DEFAULT_FLAGS, write_all: bool = False,
+                 device_build: bool = True) -> Dict[str, bytes]:
     """{proband: text of <proband>.fasta}: the altered transcripts (personalized_genome.rs:72-117) or, with write_all
-    (-a / --write_all_proteins, :118-204), every transcript of the reference per haplotype, unaltered ones as they are."""
+    (-a / --write_all_proteins, :118-204), every transcript of the reference per haplotype, unaltered ones as they are.
+    device_build (default): step 5, the image packing and the FASTA record text are built ON the device from the per-transcript
+    GIRs (v2p_batch_build_on_device); False: the host builder (v2p_batch_add_transcript) -- same bytes."""
     ref = read_fasta(reference_fasta)
     idx = VcfIndex(vcf)
     lists = decode_bitmasks(ctx, idx)
@@ -65,9 +68,14 @@ def vcf_to_fasta(ctx, vcf: bytes, reference_fasta: str, flags: int = step4a.DEFA
     proteome = np.frombuffer("".join(pieces).encode(), dtype=np.uint8) if pieces else np.zeros(0, np.uint8)
     ctx.upload_reference(proteome, np.frombuffer("".join(hdr).encode(), dtype=np.uint8))
     b = ctx.batch()
+    sink = b
+    if device_build:
+        from .txstream import TxStreamBuilder, build_on_device_auto
+        sink = TxStreamBuilder(fasta=True)
     try:
         for hap in range(lists.n_haplotypes):
-            b.begin_haplotype()
+            if not device_build:
+                b.begin_haplotype()
             altered = dict(groups.of(hap))
             todo = [(tx, altered.get(tx)) for tx in names if tx in ref] if write_all else list(altered.items())
             for tx, members in todo:
@@ -76,8 +84,8 @@ def vcf_to_fasta(ctx, vcf: bytes, reference_fasta: str, flags: int = step4a.DEFA
                 def reference_copy():                                  # -a: an unaltered transcript is one copy of its reference
                     ho, hl = hdr_off[(tx, 1 + hap % 2)]
                     n = len(ref[tx])
-                    b.add_transcript(np.zeros(1, np.uint8), np.zeros(1, np.uint64), np.array([n], np.uint64), np.zeros(1, np.uint64),
-                                     off[tx], n, np.zeros(0, np.uint8), n, ho, hl)
+                    sink.add_transcript(np.zeros(1, np.uint8), np.zeros(1, np.uint64), np.array([n], np.uint64), np.zeros(1, np.uint64),
+                                        off[tx], n, np.zeros(0, np.uint8), n, ho, hl)
                 if members is None:
                     reference_copy()
                     continue
@@ -100,10 +108,15 @@ def vcf_to_fasta(ctx, vcf: bytes, reference_fasta: str, flags: int = step4a.DEFA
                     if bad:
                         raise N.V2PError(-28, f"INSPECT_TXP fails for transcript {tx} (status {bad}, task {at})", hap)
                 ho, hl = hdr_off[(tx, 1 + hap % 2)]
-                b.add_transcript(t[:, 0].astype(np.uint8), t[:, 1], t[:, 2], t[:, 3], off[tx], len(ref[tx]),
-                                 np.frombuffer(alt, dtype=np.uint8), res_len, ho, hl)
-            b.end_haplotype()
-        b.finalize()
+                sink.add_transcript(t[:, 0].astype(np.uint8), t[:, 1], t[:, 2], t[:, 3], off[tx], len(ref[tx]),
+                                    np.frombuffer(alt, dtype=np.uint8), res_len, ho, hl)
+            sink.end_haplotype()
+        if device_build:
+            stream = sink.finish()
+            build_on_device_auto(b, stream)
+            stream.close()
+        else:
+            b.finalize()
         b.execute()
         b.sync()
         out = {}

@@ -1,0 +1,137 @@
+"""A v2p_txstream (include/vcf2prot_hip.h) assembled on the host: per-transcript GIRs exactly as step 4b returns them
+(TranscriptInstruction::get_g_rep, transcript_instructions.rs:335-427: un-rebased Task SoA, the transcript's own alt tape),
+concatenated over the transcripts of every haplotype in result order -- the input of v2p_batch_build_on_device, where step 5
+(haplotype_instruction.rs:94-133) and the image packing run as kernels.  With record headers the device emits FASTA text
+(personalized_genome.rs:90-113)."""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import numpy as np
+
+from ._cohort_api import TxStreamBuf
+
+_PAD = 64          # the builder's slab loads read a few entries past a transcript's last task / alt byte
+
+
+class TxStreamBuilder:
+    def __init__(self, fasta: bool = False):
+        self.fasta = fasta
+        self.hap_tx_begin: List[int] = [0]
+        self._off: List[int] = []
+        self._ref_len: List[int] = []
+        self._res_len: List[int] = []
+        self._task_begin: List[int] = [0]
+        self._alt_begin: List[int] = [0]
+        self._hdr_off: List[int] = []
+        self._hdr_len: List[int] = []
+        self._code: List[np.ndarray] = []
+        self._sp: List[np.ndarray] = []
+        self._ln: List[np.ndarray] = []
+        self._sr: List[np.ndarray] = []
+        self._alt: List[np.ndarray] = []
+        self._n_tasks = 0
+        self._n_alt = 0
+
+    def add_transcript(self, code, start_pos, length, start_pos_res, tx_proteome_off: int, tx_ref_len: int, alt, res_len: int,
+                       header_off: int = 0, header_len: int = 0):
+        """Same arguments as v2p_batch_add_transcript (the host builder's entry point)."""
+        code = np.ascontiguousarray(code, dtype=np.uint8)
+        n = int(code.size)
+        alt = np.ascontiguousarray(alt, dtype=np.uint8)
+        for name, arr in (("start_pos", start_pos), ("length", length), ("start_pos_res", start_pos_res)):
+            if n and int(np.max(arr)) > 0xFFFFFFFF:
+                raise ValueError(f"{name} does not fit the stream's 32-bit fields")
+        self._code.append(code)
+        self._sp.append(np.asarray(start_pos, dtype=np.uint32))
+        self._ln.append(np.asarray(length, dtype=np.uint32))
+        self._sr.append(np.asarray(start_pos_res, dtype=np.uint32))
+        self._alt.append(alt)
+        self._n_tasks += n
+        self._n_alt += int(alt.size)
+        self._off.append(int(tx_proteome_off)); self._ref_len.append(int(tx_ref_len)); self._res_len.append(int(res_len))
+        self._task_begin.append(self._n_tasks); self._alt_begin.append(self._n_alt)
+        self._hdr_off.append(int(header_off)); self._hdr_len.append(int(header_len))
+
+    def end_haplotype(self):
+        self.hap_tx_begin.append(len(self._off))
+
+    @property
+    def n_tx(self) -> int:
+        return len(self._off)
+
+    @property
+    def n_tasks(self) -> int:
+        return self._n_tasks
+
+    def result_bytes(self) -> int:
+        return int(sum(self._res_len)) + (int(sum(h + 1 for h in self._hdr_len if h)) if self.fasta else 0)
+
+    def finish(self) -> "HostTxStream":
+        def cat(parts, dtype):
+            body = np.concatenate(parts) if parts else np.zeros(0, dtype)
+            return np.concatenate([body.astype(dtype, copy=False), np.zeros(_PAD, dtype)])
+        keep = [np.asarray(self.hap_tx_begin, dtype=np.uint64), np.asarray(self._off, dtype=np.uint64), np.asarray(self._ref_len, dtype=np.uint32),
+                np.asarray(self._res_len, dtype=np.uint32), np.asarray(self._task_begin, dtype=np.uint64), np.asarray(self._alt_begin, dtype=np.uint64),
+                cat(self._code, np.uint8), cat(self._sp, np.uint32), cat(self._ln, np.uint32), cat(self._sr, np.uint32), cat(self._alt, np.uint8),
+                np.asarray(self._hdr_off, dtype=np.uint64), np.asarray(self._hdr_len, dtype=np.uint32)]
+        return HostTxStream(keep, len(self.hap_tx_begin) - 1, self.n_tx, self._n_tasks, self._n_alt, self.fasta, self.result_bytes())
+
+
+class HostTxStream:
+    """Owner of the arrays; `.struct` is what v2p_batch_build_on_device takes."""
+
+    def __init__(self, keep, n_haps, n_tx, n_tasks, n_alt, fasta, result_bytes):
+        self.keep = [np.ascontiguousarray(a) for a in keep]
+        self.result_bytes = result_bytes
+        k = self.keep
+        s = TxStreamBuf()
+        s.n_haps, s.n_tx, s.n_tasks, s.n_alt = n_haps, n_tx, n_tasks, n_alt
+        P64, P32, P8 = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint8)
+        s.hap_tx_begin, s.tx_proteome_off = k[0].ctypes.data_as(P64), k[1].ctypes.data_as(P64)
+        s.tx_ref_len, s.tx_res_len = k[2].ctypes.data_as(P32), k[3].ctypes.data_as(P32)
+        s.tx_task_begin, s.tx_alt_begin = k[4].ctypes.data_as(P64), k[5].ctypes.data_as(P64)
+        s.code, s.start_pos, s.length, s.start_pos_res = k[6].ctypes.data_as(P8), k[7].ctypes.data_as(P32), k[8].ctypes.data_as(P32), k[9].ctypes.data_as(P32)
+        s.alt = k[10].ctypes.data_as(P8)
+        if fasta:
+            s.tx_header_off, s.tx_header_len = k[11].ctypes.data_as(P64), k[12].ctypes.data_as(P32)
+        self.struct = s
+
+    @property
+    def n_tasks(self) -> int:
+        return int(self.struct.n_tasks)
+
+    @property
+    def n_tx(self) -> int:
+        return int(self.struct.n_tx)
+
+    def close(self):
+        self.struct = None
+        self.keep = []
+
+
+def build_on_device_auto(batch, stream, result_bytes: Optional[int] = None) -> dict:
+    """v2p_batch_build_on_device with the routing the host packer would choose: by result bytes per task a wave image (long
+    reference runs), a per-block image or a dense one; a window that holds more descriptors than its kernel takes
+    (V2P_ERR_UNSUPPORTED) is retried smaller, then with the next kernel."""
+    from ._native import V2PError
+    n_tasks = max(int(stream.struct.n_tasks), 1)
+    rb = result_bytes if result_bytes is not None else getattr(stream, "result_bytes", 0)
+    bpt = rb / n_tasks
+    if bpt >= 120:
+        plan = [(4, 10240), (4, 4096), (2, 32768), (2, 16384), (2, 4096), (3, 12288), (3, 8192), (3, 4096)]
+    elif bpt >= 40:
+        plan = [(2, 32768), (2, 16384), (2, 4096), (3, 12288), (3, 8192), (3, 4096)]
+    else:
+        plan = [(3, 12288), (3, 8192), (3, 4096), (2, 4096)]
+    last = None
+    for kernel, window in plan:
+        try:
+            ms = batch.build_on_device(stream, window, kernel)
+            return {"kernel": kernel, "window": window, "build_ms": ms}
+        except V2PError as e:
+            if e.code != -9:                 # V2P_ERR_UNSUPPORTED: too many descriptors in some window -- anything else is final
+                raise
+            last = e
+    raise last
