@@ -13,4 +13,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- p
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 bench.py --no-cpu-baseline --no-pcie --no-device-build --no-verify --steps 3 --warmup 1 "$@" > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python3 bench.py --no-cpu-baseline --no-pcie --no-device-build --no-verify --steps 3 --warmup 1 "$@" > $OUT/bench_write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_l2 -o l2 -- python3 bench.py --no-cpu-baseline --no-pcie --no-device-build --no-verify --steps 3 --warmup 1 "$@" > $OUT/bench_l2.log 2>&1
-python3 tools/summarize_profile.py $OUT $TAG $ROOT/gpurun_out/profiles_r02 "$@"
+python3 tools/summarize_profile.py $OUT $TAG $ROOT/gpurun_out/${PROFILES_OUT:-profiles_r03} "$@"

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--json", default="")
     ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--chain-only", action="store_true")
+    ap.add_argument("--phased-only", action="store_true")
     a = ap.parse_args()
     from vcf2prot_amd import build as B
     path = B.build_bench()
@@ -50,6 +52,8 @@ def main():
              (1, C2, "C2 + 512 B desc, table of 393216 chunks (192 MB)", 5, 0, 64, 393216, 2, 0),
              (1, C2, "C2 + 512 B desc, table of 524288 chunks (256 MB)", 5, 0, 64, 524288, 2, 0),
              (1, C3, "C3 + 448 B desc", 5, 0, 56, 0, 2, 0)]
+    if a.chain_only or a.phased_only:
+        cases = cases[:2]
     for wpg, pattern, label, shift, n_p, dl, dmod, aux, pf in cases:
         ms = []
         for r in range(a.rounds + 1):
@@ -65,14 +69,41 @@ def main():
         med = statistics.median(ms)
         rows.append({"wpg": wpg, "what": label, "extra_gathers": n_p, "descriptor_bytes": dl * 8, "descriptor_table_chunks": dmod, "store_aux": aux, "prefetch": pf, "ms": med, "TBps_written": nbytes / med / 1e9})
         print(f"{label:58s}: {med:7.3f} ms  {nbytes / med / 1e9:6.2f} TB/s")
+    lib.v2p_bench_wave_chain.restype = ctypes.c_int
+    lib.v2p_bench_wave_chain.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    n_chunks = nbytes // 8192
+    rec = torch.zeros(2 * n_chunks + 16, dtype=torch.int64, device=dev)
+    rec[0:2 * n_chunks:2] = torch.arange(n_chunks, dtype=torch.int64, device=dev)
+    for pattern, dl, label in (() if a.phased_only else ((C2, 64, "chain C2 + 512 B desc"), (C3, 56, "chain C3 + 448 B desc"), (C2, 30, "chain C2 + 240 B desc"))):
+        for remap, persist in ((0, 0), (1, 0), (0, 8192), (0, 4096), (0, 6144), (0, 16384)):
+            ms = []
+            for r in range(a.rounds + 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                rc = lib.v2p_bench_wave_chain(ctypes.c_void_p(st.cuda_stream), src.data_ptr(), window, out.data_ptr(), nbytes, dsc.data_ptr(), rec.data_ptr(),
+                                              pattern, dl, remap, persist)
+                assert rc == 0, rc
+                e1.record(st)
+                torch.cuda.synchronize()
+                if r:
+                    ms.append(e0.elapsed_time(e1))
+            med = statistics.median(ms)
+            what = f"{label}" + (", XCD-contiguous chunk table" if remap else "") + (f", {persist} resident waves, loads one chunk ahead" if persist else "")
+            rows.append({"what": what, "remap": remap, "persist_waves": persist, "descriptor_bytes": dl * 8, "ms": med, "TBps_written": nbytes / med / 1e9})
+            print(f"{what:72s}: {med:7.3f} ms  {nbytes / med / 1e9:6.2f} TB/s")
+    if a.chain_only:
+        if a.json:
+            json.dump({"bytes": nbytes, "window": window, "cases": rows}, open(a.json, "w"), indent=1)
+        return
     lib.v2p_bench_wave_copy_phased.restype = ctypes.c_int
     lib.v2p_bench_wave_copy_phased.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
                                                ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int]
     sink = torch.zeros(4, dtype=torch.int32, device=dev)
     for pattern, dl, label in ((C2, 64, "C2 + 512 B desc"), (C3, 56, "C3 + 448 B desc")):
         for phases in (1, 2, 4, 8, 16, 32, 64):
-            for touch in (0, 1):
-                if phases == 1 and touch:
+            for touch in (0, 1, 2):
+                if (phases == 1 and touch) or (a.phased_only and touch == 1):
                     continue
                 ms = []
                 for r in range(a.rounds + 1):
@@ -86,7 +117,7 @@ def main():
                     if r:
                         ms.append(e0.elapsed_time(e1))
                 med = statistics.median(ms)
-                what = f"{label}, {phases} sub-launches" + (", descriptors touched before each" if touch else "")
+                what = f"{label}, {phases} sub-launches" + (", descriptors touched before each" + (" (plain loads)" if touch == 2 else " (nt loads)") if touch else "")
                 rows.append({"what": what, "phases": phases, "touch": touch, "ms": med, "TBps_written": nbytes / med / 1e9})
                 print(f"{what:58s}: {med:7.3f} ms  {nbytes / med / 1e9:6.2f} TB/s")
     if a.json:

@@ -25,6 +25,7 @@
 //   digest_kernel   per-haplotype position-sensitive checksum of the result arena.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <mutex>
 #include "stitch_kernels.h"
 #include "stitch_device.hpp"
@@ -1171,6 +1172,46 @@ static const uint8_t* device_dots(hipError_t* err)
     return bufs[dev];
 }
 
+// ---- phases ------------------------------------------------------------------
+// A launch that streams more descriptor bytes from HBM than about 1/32 of what it stores runs at 3.5 TB/s where the bare copy runs at
+// 5.9: reads that miss every cache, mixed into a saturated store stream, cost the memory system far more than their bytes
+// (tools/wave_copy_bench.py: the cliff sits between 256 and 320 descriptor bytes per 8 KiB of result; hiding their LATENCY -- resident
+// waves loading a chunk ahead -- recovers nothing).  So the two never mix: the chunk table is cut into phases of V2P_PHASE_BYTES of
+// image (chunk records + descriptors), and before a phase's stitch kernels run, touch_image_kernel reads that phase's records and
+// descriptor lines -- a read-only kernel at read speed, which leaves them in the memory-side cache (256 MB; the result stores are
+// non-temporal and do not displace them) -- and the stitch kernels then find them there.  The copy benchmark: 3.47 -> 6.04 TB/s with
+// 64 MB phases, the touch kernels' time included.
+constexpr uint64_t PHASE_BYTES_DEFAULT = 64ull << 20;
+constexpr uint32_t PHASE_MIN_CHUNKS = 16384;            // below this a launch is one phase and is not preceded by a touch
+
+__global__ __launch_bounds__(256) void touch_image_kernel(const uint64_t* __restrict__ desc, const Chunk* __restrict__ chunks, uint32_t n_chunks, uint64_t n_desc,
+                                                          const uint8_t* __restrict__ payload, uint64_t payload_len, int lines_only)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const Chunk ch = chunks[c];
+    const uint64_t n = (ch.dst_n >> 48) & uint64_t(CHUNK_N_MASK);
+    if (lines_only) {                                                // (A/B: one load per 128-byte descriptor line, payload untouched)
+        const uint64_t idx = (ch.task_begin & ~15ull) + lane * 16ull;
+        if (idx < ch.task_begin + n && idx < n_desc) { const uint64_t v = desc[idx]; asm volatile("" :: "v"(v)); }
+        return;
+    }
+    // every descriptor of the chunk (one per lane and round): its line comes in, and a payload descriptor's source lines with it
+    // (frameshift tails, long insertions: first touched by the stitch kernel they would be cold reads between its stores too)
+    for (uint64_t i = ch.task_begin + lane; i < ch.task_begin + n && i < n_desc; i += 64u) {
+        const uint64_t d = desc[i];
+        const uint64_t src = d & SRC_MASK, len = (d >> 40) & LEN_MASK;
+        if ((d >> 62) == SPACE_PAYLOAD && len != 0u && src < payload_len && len <= payload_len - src) {
+            const uint32_t b0 = payload[src], b1 = payload[src + len - 1u];
+            asm volatile("" :: "v"(b0), "v"(b1));
+        }
+        asm volatile("" :: "v"(d));                                  // (the loads are the point; nothing is kept)
+    }
+}
+
+static hipError_t launch_stitch_range(const StitchArgs& args, hipStream_t stream, int nontemporal, uint32_t max_blocks);
+
 hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemporal, uint32_t max_blocks)
 {
     if (args.n_chunks == 0) return hipSuccess;
@@ -1178,6 +1219,31 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     hipError_t err = hipSuccess;
     a.dots = device_dots(&err);
     if (!a.dots) return err;
+    uint64_t phase_bytes = PHASE_BYTES_DEFAULT;
+    if (const char* e = getenv("V2P_PHASE_BYTES")) phase_bytes = strtoull(e, nullptr, 10);      // 0: one phase, no touch (A/B runs)
+    // (the kernels of per-block and dense images are bound by their instruction stream, not by memory: phases only cost them --
+    // C3 per-block 2.00 -> 2.19 ms, C5 dense 0.53 -> 0.71; wave and long-run images gain: C2 3.26 -> 2.65 ms)
+    const bool streams = (nontemporal & 4) != 0 || (nontemporal & 16) == 0;       // the image holds wave or long-run chunks
+    if (max_blocks != 0 || phase_bytes == 0 || !streams || a.n_chunks < PHASE_MIN_CHUNKS) return launch_stitch_range(a, stream, nontemporal, max_blocks);
+    const double per_chunk = 16.0 + 8.0 * double(a.n_desc) / double(a.n_chunks);
+    uint64_t per = uint64_t(double(phase_bytes) / per_chunk);
+    per = per < 4096 ? 4096 : (per & ~7ull);                         // (a multiple of 8 keeps workgroup b on the XCD the chunk order dealt chunk b to)
+    static const bool no_touch = getenv("V2P_PHASE_NO_TOUCH") != nullptr;
+    const int lines_only = getenv("V2P_TOUCH_LINES") != nullptr;
+    for (uint64_t c0 = 0; c0 < args.n_chunks; c0 += per) {
+        const uint32_t nc = uint32_t(args.n_chunks - c0 < per ? args.n_chunks - c0 : per);
+        a.chunks = args.chunks + c0;
+        a.n_chunks = nc;
+        if (!no_touch) hipLaunchKernelGGL(touch_image_kernel, dim3((nc + 3u) / 4u), dim3(256), 0, stream, a.desc, a.chunks, nc, a.n_desc, a.src1, a.src1_len, lines_only);
+        err = launch_stitch_range(a, stream, nontemporal, 0);
+        if (err != hipSuccess) return err;
+    }
+    return hipGetLastError();
+}
+
+static hipError_t launch_stitch_range(const StitchArgs& a, hipStream_t stream, int nontemporal, uint32_t max_blocks)
+{
+    hipError_t err = hipSuccess;
     // `nontemporal` bit 0: nt result stores; bits 4 / 5: no long-run / no per-block chunk in the image; bits 6..7: tasks per lane
     // of the largest long-run chunk; bits 8..11: tasks per lane of the largest per-block chunk; bits 12..15: variant (0 = default, 1 / 2 =
     // the per-block kernel with byte-granular / aligned gathers for every chunk -- images without fused descriptors only, A/B runs;
