@@ -473,7 +473,7 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
         generate_into(*c, h0, b, false, nullptr);
         uint64_t bytes = 0, tasks = 0;
         for (size_t i = 0; i < b.length.size(); ++i) { bytes += b.length[i]; tasks += b.length[i] ? 1 : 0; }
-        const int choice = !tasks ? 2 : (bytes / tasks >= v2p::LONG_RUN_BYTES_PER_TASK ? 4 : (bytes / tasks < v2p::DENSE_BELOW ? 3 : 2));
+        const int choice = !tasks ? 2 : (bytes / tasks >= v2p::WAVE_BYTES_PER_TASK ? 4 : 3);
         for (auto& im : parts) {
             im.set_kernel(choice);
             if (choice == 4 && chunk_bytes) im.chunk_bytes = chunk_bytes < v2p::CHUNK_BYTES_WAVE ? chunk_bytes : v2p::CHUNK_BYTES_WAVE;

@@ -364,10 +364,10 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
         // routing as the host packer would choose it (result bytes per task); a window with too many descriptors is retried smaller
         const double bpt = double(txs.result_bytes) / double(st.n_tasks ? st.n_tasks : 1);
         const std::pair<int, uint32_t> long_plan[] = {{4, 10240}, {4, 4096}, {2, 32768}, {2, 16384}, {2, 4096}, {3, 12288}, {3, 8192}, {3, 4096}};
-        const std::pair<int, uint32_t> mid_plan[] = {{2, 32768}, {2, 16384}, {2, 4096}, {3, 12288}, {3, 8192}, {3, 4096}};
+        const std::pair<int, uint32_t> mid_plan[] = {{4, 4096}, {4, 2048}, {2, 32768}, {2, 16384}, {2, 4096}, {3, 12288}, {3, 8192}, {3, 4096}};
         const std::pair<int, uint32_t> dense_plan[] = {{3, 12288}, {3, 8192}, {3, 4096}, {2, 4096}};
         const std::pair<int, uint32_t>* plan = bpt >= 120 ? long_plan : (bpt >= 40 ? mid_plan : dense_plan);
-        const size_t n_plan = bpt >= 120 ? 8 : (bpt >= 40 ? 6 : 4);
+        const size_t n_plan = bpt >= 120 ? 8 : (bpt >= 40 ? 8 : 4);
         int rc = V2P_ERR_UNSUPPORTED;
         for (size_t k = 0; k < n_plan && rc == V2P_ERR_UNSUPPORTED; ++k) rc = v2p_batch_build_on_device(b, &st, plan[k].second, plan[k].first, nullptr);
         chk(rc);

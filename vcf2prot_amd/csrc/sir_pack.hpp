@@ -87,6 +87,7 @@ constexpr uint64_t CHUNK_DENSE = 1ull << 61;   // chunk header flag: chunk of a 
 constexpr uint64_t CHUNK_WAVE = 1ull << 60;    // chunk header flag: chunk of a wave image (<= 64 descriptors, <= 10 KiB, fused substitutions allowed): stitchw_kernel
 constexpr uint32_t CHUNK_N_MASK = 0x7FF;       // descriptor count: bits 48..58 of dst_n
 inline uint32_t chunk_n(uint64_t dst_n) { return uint32_t(dst_n >> 48) & CHUNK_N_MASK; }
+constexpr uint32_t WAVE_BYTES_PER_TASK = 40;    // an image whose first chunk has at least this many result bytes per task is a wave image (stitchw_kernel); below: dense
 constexpr uint32_t LONG_RUN_BYTES_PER_TASK = 120;   // an image whose first chunk has at least this many result bytes per task goes to stitch4_kernel
 constexpr uint32_t PAD_BYTES  = 32;            // readable slack before AND after a source arena: the kernel loads whole 16-byte aligned blocks
                                                // around a task's bytes (up to 30 bytes before its first byte in a chunk's ragged head block, 31 after its last)
@@ -431,9 +432,10 @@ private:
             return;
         }
         if (adaptive_tasks && kernel_choice == 0) {
-            // long runs (C2): stitchw_kernel, one wave per chunk (-5 % against stitch4_kernel, round 3); 40 .. 120 result bytes per task
-            // (C3, C4): the per-block kernel still wins by 5 .. 15 %; short tasks: the dense kernel
-            const int choice = bpt >= LONG_RUN_BYTES_PER_TASK ? 4 : (bpt < DENSE_BELOW ? 3 : 2);
+            // stitchw_kernel, one wave per chunk, from 40 result bytes per task up: with its image read ahead of it phase by phase
+            // (launch_stitch) it beats stitch4_kernel on long runs (C2: 3.7 -> 2.7 ms) and the per-block kernel on C3 (2.09 -> 1.76 ms),
+            // C4 (1.13 -> 1.05) and 200-residue transcripts (2.19 -> 1.28); short tasks: the dense kernel (a tie at ~26 bytes per task)
+            const int choice = bpt >= WAVE_BYTES_PER_TASK ? 4 : 3;
             if (choice == 4) {
                 // the first chunk was filled under the undecided limits (<= 256 tasks, 32 KiB, nothing fused): its descriptors go
                 // back and are cut again as wave chunks

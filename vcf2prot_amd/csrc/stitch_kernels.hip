@@ -1184,30 +1184,48 @@ static const uint8_t* device_dots(hipError_t* err)
 constexpr uint64_t PHASE_BYTES_DEFAULT = 64ull << 20;
 constexpr uint32_t PHASE_MIN_CHUNKS = 16384;            // below this a launch is one phase and is not preceded by a touch
 
+constexpr uint32_t TOUCH_CHUNKS_PER_WAVE = 4;      // records, then first descriptors, then payload bytes of four chunks in flight per wave
 __global__ __launch_bounds__(256) void touch_image_kernel(const uint64_t* __restrict__ desc, const Chunk* __restrict__ chunks, uint32_t n_chunks, uint64_t n_desc,
                                                           const uint8_t* __restrict__ payload, uint64_t payload_len, int lines_only)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (c >= n_chunks) return;
-    const Chunk ch = chunks[c];
-    const uint64_t n = (ch.dst_n >> 48) & uint64_t(CHUNK_N_MASK);
+    const uint32_t c0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * TOUCH_CHUNKS_PER_WAVE;
+    if (c0 >= n_chunks) return;
+    Chunk ch[TOUCH_CHUNKS_PER_WAVE];
+#pragma unroll
+    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) ch[k] = chunks[c0 + k < n_chunks ? c0 + k : c0];
     if (lines_only) {                                                // (A/B: one load per 128-byte descriptor line, payload untouched)
-        const uint64_t idx = (ch.task_begin & ~15ull) + lane * 16ull;
-        if (idx < ch.task_begin + n && idx < n_desc) { const uint64_t v = desc[idx]; asm volatile("" :: "v"(v)); }
+#pragma unroll
+        for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) {
+            const uint64_t n = (ch[k].dst_n >> 48) & uint64_t(CHUNK_N_MASK), idx = (ch[k].task_begin & ~15ull) + lane * 16ull;
+            if (idx < ch[k].task_begin + n && idx < n_desc) { const uint64_t v = desc[idx]; asm volatile("" :: "v"(v)); }
+        }
         return;
     }
-    // every descriptor of the chunk (one per lane and round): its line comes in, and a payload descriptor's source lines with it
-    // (frameshift tails, long insertions: first touched by the stitch kernel they would be cold reads between its stores too)
-    for (uint64_t i = ch.task_begin + lane; i < ch.task_begin + n && i < n_desc; i += 64u) {
-        const uint64_t d = desc[i];
-        const uint64_t src = d & SRC_MASK, len = (d >> 40) & LEN_MASK;
-        if ((d >> 62) == SPACE_PAYLOAD && len != 0u && src < payload_len && len <= payload_len - src) {
+    // every descriptor of the chunks (one per lane and round): its line comes in, and a payload descriptor's source lines with it
+    // (frameshift tails, long insertions: first touched by the stitch kernel they would be cold reads between its stores too --
+    // C3: 2.36 -> 1.93 ms)
+    uint64_t d[TOUCH_CHUNKS_PER_WAVE];
+#pragma unroll
+    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) {
+        const uint64_t n = (ch[k].dst_n >> 48) & uint64_t(CHUNK_N_MASK), i = ch[k].task_begin + lane;
+        d[k] = (i < ch[k].task_begin + n && i < n_desc) ? desc[i] : (uint64_t(SPACE_FILL) << 62);
+    }
+    auto payload_lines = [&](uint64_t dd) {
+        const uint64_t src = dd & SRC_MASK, len = (dd >> 40) & LEN_MASK;
+        if ((dd >> 62) == SPACE_PAYLOAD && len != 0u && src < payload_len && len <= payload_len - src) {
             const uint32_t b0 = payload[src], b1 = payload[src + len - 1u];
             asm volatile("" :: "v"(b0), "v"(b1));
         }
-        asm volatile("" :: "v"(d));                                  // (the loads are the point; nothing is kept)
+    };
+#pragma unroll
+    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) payload_lines(d[k]);
+    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) {           // chunks of more than 64 descriptors (per-block, dense images)
+        const uint64_t n = (ch[k].dst_n >> 48) & uint64_t(CHUNK_N_MASK);
+        for (uint64_t i = ch[k].task_begin + 64u + lane; i < ch[k].task_begin + n && i < n_desc; i += 64u) payload_lines(desc[i]);
     }
+#pragma unroll
+    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) asm volatile("" :: "v"(d[k]));      // (the loads are the point; nothing is kept)
 }
 
 static hipError_t launch_stitch_range(const StitchArgs& args, hipStream_t stream, int nontemporal, uint32_t max_blocks);
@@ -1234,7 +1252,7 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
         const uint32_t nc = uint32_t(args.n_chunks - c0 < per ? args.n_chunks - c0 : per);
         a.chunks = args.chunks + c0;
         a.n_chunks = nc;
-        if (!no_touch) hipLaunchKernelGGL(touch_image_kernel, dim3((nc + 3u) / 4u), dim3(256), 0, stream, a.desc, a.chunks, nc, a.n_desc, a.src1, a.src1_len, lines_only);
+        if (!no_touch) hipLaunchKernelGGL(touch_image_kernel, dim3((nc + 4u * TOUCH_CHUNKS_PER_WAVE - 1u) / (4u * TOUCH_CHUNKS_PER_WAVE)), dim3(256), 0, stream, a.desc, a.chunks, nc, a.n_desc, a.src1, a.src1_len, lines_only);
         err = launch_stitch_range(a, stream, nontemporal, 0);
         if (err != hipSuccess) return err;
     }

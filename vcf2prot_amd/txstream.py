@@ -122,7 +122,7 @@ def build_on_device_auto(batch, stream, result_bytes: Optional[int] = None) -> d
     if bpt >= 120:
         plan = [(4, 10240), (4, 4096), (2, 32768), (2, 16384), (2, 4096), (3, 12288), (3, 8192), (3, 4096)]
     elif bpt >= 40:
-        plan = [(2, 32768), (2, 16384), (2, 4096), (3, 12288), (3, 8192), (3, 4096)]
+        plan = [(4, 4096), (4, 2048), (2, 32768), (2, 16384), (2, 4096), (3, 12288), (3, 8192), (3, 4096)]
     else:
         plan = [(3, 12288), (3, 8192), (3, 4096), (2, 4096)]
     last = None
