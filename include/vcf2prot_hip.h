@@ -93,6 +93,25 @@ int v2p_execute_gir(v2p_ctx* ctx,
                     const uint32_t* alt, uint64_t n_alt,
                     uint32_t* res, uint64_t n_res);
 
+/* The same arm for MANY workers sharing ONE context (the reference enters GIR::execute from every Rayon worker: parts/exec.rs:36-39,
+ * personalized_genome.rs:64-65).  Thread-safe: concurrent calls are gathered for V2P_COALESCE_US microseconds (default 100) into one
+ * batch of at most V2P_COALESCE_MB megabytes of tapes (default 32) -- every caller narrows its own tapes and packs its own
+ * descriptors into the batch's pinned staging on its own thread -- then ONE upload, ONE launch and ONE download serve them all, and
+ * up to V2P_COALESCE_BATCHES batches (default 8) are alive on their own streams.  `code` holds the exec codes as the SoA marshaller has them
+ * (gir.rs:283-299, usize -> uint64_t: no narrowing copy on the Rust side); any value other than 0 / 1 is V2P_ERR_BAD_CODE
+ * (haplotype_instruction.rs:154).  Overlapping / descending Task vectors, tapes with a char above 0xFF and GIRs larger than a
+ * batch take the one-haplotype path of v2p_execute_gir, serialised on the context.  *err_row (may be NULL): the task row a task
+ * error refers to, -1 otherwise -- v2p_last_error() is shared by the callers of a context and only advisory here.
+ * A lone caller pays the gathering window on every call: single-threaded hosts use v2p_execute_gir. */
+int v2p_execute_gir_shared(v2p_ctx* ctx,
+                           const uint64_t* code, const uint64_t* start_pos, const uint64_t* length,
+                           const uint64_t* start_pos_res, uint64_t n_tasks,
+                           const uint32_t* ref, uint64_t n_ref,
+                           const uint32_t* alt, uint64_t n_alt,
+                           uint32_t* res, uint64_t n_res, int64_t* err_row);
+/* batches launched / calls served by v2p_execute_gir_shared on this context so far */
+int v2p_coalesce_stats(v2p_ctx* ctx, uint64_t* n_batches, uint64_t* n_calls);
+
 /* DEBUG_GPU: inspect the device input arrays for indexing errors.  *first_bad = first
  * offending row or -1; *reason = V2P_ERR_BAD_CODE / _RES_OOB / _SRC_OOB / _NOT_CONTIGUOUS or 0.
  * Returns V2P_OK when the inspection ran (whatever it found). */

@@ -40,6 +40,9 @@ HIP_API = {
     "v2p_set_stream": (c_int, [c_void_p, c_void_p]),
     "v2p_execute_gir": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
                                 c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_uint64]),
+    "v2p_execute_gir_shared": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
+                                       c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_uint64, POINTER(c_int64)]),
+    "v2p_coalesce_stats": (c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
     "v2p_validate_gir": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
                                  c_uint64, c_uint64, c_uint64, POINTER(c_int64), POINTER(c_int)]),
     "v2p_upload_proteome": (c_int, [c_void_p, c_void_p, c_uint64]),

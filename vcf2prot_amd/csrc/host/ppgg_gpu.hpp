@@ -97,6 +97,25 @@ public:
         return {std::move(res_), std::move(annotation_)};
     }
 
+    // The same arm when the workers share one context (the reference's own shape: every Rayon worker calls GIR::execute,
+    // parts/exec.rs:36-39): v2p_execute_gir_shared coalesces the concurrent calls; exec codes go as the marshaller has them (u64).
+    std::pair<std::u32string, Annotation> execute_shared(Engine engine, GpuContext& ctx) &&
+    {
+        if (engine != Engine::GPU) throw std::logic_error("the st/mt engines are the reference's CPU code");
+        const size_t n = g_rep_.size();
+        std::vector<uint64_t> code(n), sp(n), ln(n), sr(n);
+        for (size_t i = 0; i < n; ++i) {                          // gir.rs:283-299
+            code[i] = g_rep_[i].exe_code; sp[i] = g_rep_[i].start_pos; ln[i] = g_rep_[i].length; sr[i] = g_rep_[i].start_pos_res;
+        }
+        int64_t row = -1;
+        const int rc = v2p_execute_gir_shared(ctx.raw(), code.data(), sp.data(), ln.data(), sr.data(), n,
+                                              reinterpret_cast<const uint32_t*>(ref_.data()), ref_.size(),
+                                              reinterpret_cast<const uint32_t*>(alt_.data()), alt_.size(),
+                                              reinterpret_cast<uint32_t*>(&res_[0]), res_.size(), &row);
+        if (rc != V2P_OK) throw Panic(rc, v2p_last_error(ctx.raw()), row);
+        return {std::move(res_), std::move(annotation_)};
+    }
+
 private:
     std::vector<Task> g_rep_;
     Annotation annotation_;

@@ -77,7 +77,7 @@ static uint64_t mix64(uint64_t x)
     return x ^ (x >> 31);
 }
 
-static int run(const char* preset, uint64_t n_haps, int threads)
+static int run(const char* preset, uint64_t n_haps, int threads, bool shared)
 {
     v2p_cohort_params p;
     if (v2p_cohort_preset(preset, &p)) { std::fprintf(stderr, "unknown preset %s\n", preset); return 2; }
@@ -129,10 +129,22 @@ static int run(const char* preset, uint64_t n_haps, int threads)
     {
         // a worker = one engine context for its whole life, as a Rayon worker would hold it; its first call (stream, pinned and
         // device buffers) is a warm-up outside the clock
+        // (--shared: ONE context for all workers, the reference's own shape -- v2p_execute_gir_shared coalesces their calls)
+        std::unique_ptr<GpuContext> one(shared ? new GpuContext(0) : nullptr);
         std::vector<std::thread> pool;
         for (int t = 0; t < threads; ++t)
             pool.emplace_back([&, t] {
                 try {
+                    if (shared) {
+                        { GIR warm = make_gir(uint64_t(t) % n_haps); (void)std::move(warm).execute_shared(Engine::GPU, *one); }
+                        if (++ready == threads) t0 = std::chrono::steady_clock::now();
+                        while (ready.load() < threads) std::this_thread::yield();
+                        for (uint64_t h = next++; h < n_haps; h = next++) {
+                            auto out = std::move(*girs[h]).execute_shared(Engine::GPU, *one);
+                            results[h] = std::move(out.first);
+                        }
+                        return;
+                    }
                     GpuContext ctx(0);
                     { GIR warm = make_gir(uint64_t(t) % n_haps); (void)std::move(warm).execute(Engine::GPU, ctx); }
                     if (++ready == threads) t0 = std::chrono::steady_clock::now();
@@ -148,9 +160,10 @@ static int run(const char* preset, uint64_t n_haps, int threads)
     for (const auto& e : errors) if (!e.empty()) { std::fprintf(stderr, "engine error: %s\n", e.c_str()); return 1; }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (uint64_t h = 0; h < n_haps; ++h) consume(h, std::move(results[h]), Annotation());
-    std::printf("{\"mode\": \"gir-faithful: GIR::execute(Engine::GPU) on prebuilt GIRs (Rust chars in and out), %d worker threads, one ctx each\", \"preset\": \"%s\", "
+    std::printf("{\"mode\": \"gir-faithful: GIR::execute(Engine::GPU) on prebuilt GIRs (Rust chars in and out), %d worker threads, %s\", \"preset\": \"%s\", "
                 "\"haplotypes\": %llu, \"aa\": %llu, \"seconds\": %.6f, \"aa_per_s\": %.4e, \"digests\": [",
-                threads, preset, (unsigned long long)n_haps, (unsigned long long)aa_timed, secs, double(aa_timed) / secs);
+                threads, shared ? "ONE shared ctx, calls coalesced (v2p_execute_gir_shared)" : "one ctx each", preset,
+                (unsigned long long)n_haps, (unsigned long long)aa_timed, secs, double(aa_timed) / secs);
     for (uint64_t h = 0; h < n_haps; ++h) std::printf("%s%llu", h ? ", " : "", (unsigned long long)digest[h]);
     std::printf("]}\n");
     v2p_cohort_destroy(c);
@@ -435,7 +448,8 @@ int main(int argc, char** argv)
         catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 101; }
     }
     if (argc >= 2 && !std::strcmp(argv[1], "kat")) return kat();
-    if (argc >= 5 && !std::strcmp(argv[1], "run")) return run(argv[2], std::strtoull(argv[3], nullptr, 10), std::atoi(argv[4]));
-    std::fprintf(stderr, "usage: v2p_harness kat | run <preset> <haplotypes> <threads>\n");
+    if (argc >= 5 && !std::strcmp(argv[1], "run"))
+        return run(argv[2], std::strtoull(argv[3], nullptr, 10), std::atoi(argv[4]), argc >= 6 && !std::strcmp(argv[5], "--shared"));
+    std::fprintf(stderr, "usage: v2p_harness kat | run <preset> <haplotypes> <threads> [--shared]\n");
     return 2;
 }

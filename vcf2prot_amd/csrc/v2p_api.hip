@@ -6,6 +6,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -110,6 +115,7 @@ struct v2p_ctx {
     DevBuf d_ref, d_alt, d_res, d_desc, d_chunks, d_soa, d_status;
     PinnedBuf h_stage, h_in;                         // pinned staging: results coming back / narrowed tapes going out
     ImageBuilder gir_img;                            // reused across v2p_execute_gir calls (its vectors keep their capacity)
+    struct GirQueue* queue = nullptr;                // v2p_execute_gir_shared: batches of concurrent callers (created at the first call)
 
     int fail(int code, const std::string& msg, int64_t index = -1) { err = msg; err_index = index; return code; }
     int hip_fail(hipError_t e, const char* what) {
@@ -143,6 +149,9 @@ void ctx_unlock(v2p_ctx* c) { c->mu.unlock(); }
 }  // namespace v2p
 
 #define HIP_TRY(ctx, expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return (ctx)->hip_fail(e__, what); } while (0)
+
+struct GirQueue;
+static void queue_destroy(v2p_ctx* c);
 
 extern "C" {
 
@@ -198,6 +207,7 @@ void v2p_destroy(v2p_ctx* c)
     c->proteome.release(); c->d_ref.release(); c->d_alt.release(); c->d_res.release();
     c->d_desc.release(); c->d_chunks.release(); c->d_soa.release(); c->d_status.release();
     c->h_stage.release(); c->h_in.release();
+    queue_destroy(c);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -397,6 +407,333 @@ int v2p_execute_gir(v2p_ctx* c,
         for (uint64_t i = 0; i < n_tasks; ++i)
             memcpy(res + start_pos_res[i], st + start_pos_res[i], size_t(length[i]) * sizeof(uint32_t));
     }
+    return V2P_OK;
+}
+
+// ---- concurrent GIR::execute callers on ONE context: coalesced batches ------------------------------------------------
+// The reference enters GIR::execute from every Rayon worker (parts/exec.rs:36-39, personalized_genome.rs:64-65).  One context per
+// worker (v2p_execute_gir) gives every haplotype its own three PCIe transfers, launch and synchronisation.  Here the workers share a
+// context: a call joins the open batch -- it reserves its ranges in the batch's pinned staging buffers, narrows its own tapes and
+// writes its own descriptors and chunks there, all on the calling thread, in parallel with the other callers -- and the first caller of
+// a batch (its leader) waits a short window for company, then issues ONE upload, ONE launch over the concatenated image and ONE
+// download for all of them; every caller widens its own result back.  Up to three batches are alive, each on its own stream, so the
+// upload of one overlaps the download of the one before.
+namespace {
+
+// The char loops are the host cost of a GIR (4 bytes per residue in, 4 out): AVX2 when the CPU has it (resolved once), streaming
+// stores on the way back so that the 32-bit result tape is written without being read first.
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2")))
+static uint32_t narrow_chars_avx2(const uint32_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n)
+{
+    __m256i acc = _mm256_setzero_si256();
+    const __m256i fix = _mm256_setr_epi32(0, 4, 1, 5, 2, 6, 3, 7);
+    uint64_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(in + i)), b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(in + i + 8));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(in + i + 16)), d = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(in + i + 24));
+        acc = _mm256_or_si256(acc, _mm256_or_si256(_mm256_or_si256(a, b), _mm256_or_si256(c, d)));
+        const __m256i ab = _mm256_packus_epi32(a, b), cd = _mm256_packus_epi32(c, d);           // (lanes interleaved: fixed by the permute)
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(out + i), _mm256_permutevar8x32_epi32(_mm256_packus_epi16(ab, cd), fix));
+    }
+    alignas(32) uint32_t t[8];
+    _mm256_store_si256(reinterpret_cast<__m256i*>(t), acc);
+    uint32_t seen = t[0] | t[1] | t[2] | t[3] | t[4] | t[5] | t[6] | t[7];
+    for (; i < n; ++i) { seen |= in[i]; out[i] = uint8_t(in[i]); }
+    return seen;
+}
+__attribute__((target("avx2")))
+static void widen_chars_avx2(const uint8_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n)
+{
+    uint64_t i = 0;
+    for (; i < n && (reinterpret_cast<uintptr_t>(out + i) & 31u); ++i) out[i] = in[i];
+    for (; i + 32 <= n; i += 32) {
+        for (int k = 0; k < 4; ++k)
+            _mm256_stream_si256(reinterpret_cast<__m256i*>(out + i + 8 * k), _mm256_cvtepu8_epi32(_mm_loadl_epi64(reinterpret_cast<const __m128i*>(in + i + 8 * k))));
+    }
+    for (; i < n; ++i) out[i] = in[i];
+    _mm_sfence();
+}
+static const bool g_avx2 = __builtin_cpu_supports("avx2");
+#else
+static const bool g_avx2 = false;
+static uint32_t narrow_chars_avx2(const uint32_t*, uint8_t*, uint64_t) { return 0; }
+static void widen_chars_avx2(const uint8_t*, uint32_t*, uint64_t) {}
+#endif
+uint32_t narrow_chars(const uint32_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n)
+{
+    if (g_avx2) return narrow_chars_avx2(in, out, n);
+    uint32_t seen = 0;
+    for (uint64_t i = 0; i < n; ++i) { seen |= in[i]; out[i] = uint8_t(in[i]); }
+    return seen;
+}
+void widen_chars(const uint8_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n)
+{
+    if (g_avx2) { widen_chars_avx2(in, out, n); return; }
+    for (uint64_t i = 0; i < n; ++i) out[i] = in[i];
+}
+
+struct GirBatch {
+    enum State { FREE, OPEN, CLOSED, DONE };
+    State state = FREE;
+    uint32_t n_reqs = 0, n_ready = 0, n_left = 0;
+    uint64_t in_bytes = 0, res_bytes = 0, n_desc = 0, n_chunks = 0;
+    std::chrono::steady_clock::time_point opened;
+    int rc = V2P_OK;
+    std::string err;
+    PinnedBuf h_in, h_desc, h_chunks, h_out;
+    DevBuf d_in, d_desc, d_chunks, d_out, d_status;
+    hipStream_t stream = nullptr;
+};
+
+}  // namespace
+
+struct GirQueue {
+    static constexpr int N_BATCH = 8;
+    int n_batch = 8;                                 // batches alive at once (V2P_COALESCE_BATCHES, <= 8): one filling, the others on the GPU or being read back
+    std::mutex mu;
+    std::condition_variable cv;
+    GirBatch batch[N_BATCH];
+    GirBatch* open = nullptr;
+    uint64_t cap_bytes = 32ull << 20;                // tape bytes (and result bytes) one batch takes: V2P_COALESCE_MB (small batches, many in flight: 16 workers on C2
+                                                     // reach 1.0e10 aa/s with 128 MB x 4, 1.5e10 with 32 MB x 8, 1.9e10 with 16 MB x 8)
+    uint32_t window_us = 100;                        // how long a leader waits for company: V2P_COALESCE_US
+    uint64_t n_batches = 0, n_joined = 0;            // statistics (v2p_coalesce_stats)
+    std::atomic<uint64_t> ns_pack{0}, ns_join{0}, ns_stage{0}, ns_wait{0}, ns_widen{0}, ns_gpu{0};   // V2P_COALESCE_PROFILE: where the callers' time goes
+    uint64_t desc_cap() const { return cap_bytes / 16; }        // descriptors (8 B each: half the tape bytes at 16 result bytes per task)
+    uint64_t chunk_cap() const { return cap_bytes / 256; }      // chunk records
+};
+
+static void queue_destroy(v2p_ctx* c)
+{
+    GirQueue* q = c->queue;
+    if (!q) return;
+    if (getenv("V2P_COALESCE_PROFILE"))
+        fprintf(stderr, "coalesce: %llu calls in %llu batches; per call ms: pack %.3f join %.3f stage %.3f wait %.3f widen %.3f; gpu per batch %.3f\n",
+                (unsigned long long)q->n_joined, (unsigned long long)q->n_batches, q->ns_pack / 1e6 / double(q->n_joined ? q->n_joined : 1),
+                q->ns_join / 1e6 / double(q->n_joined ? q->n_joined : 1), q->ns_stage / 1e6 / double(q->n_joined ? q->n_joined : 1),
+                q->ns_wait / 1e6 / double(q->n_joined ? q->n_joined : 1), q->ns_widen / 1e6 / double(q->n_joined ? q->n_joined : 1),
+                q->ns_gpu / 1e6 / double(q->n_batches ? q->n_batches : 1));
+    for (auto& b : q->batch) {
+        if (b.stream) { (void)hipStreamSynchronize(b.stream); (void)hipStreamDestroy(b.stream); }
+        b.h_in.release(); b.h_desc.release(); b.h_chunks.release(); b.h_out.release();
+        b.d_in.release(); b.d_desc.release(); b.d_chunks.release(); b.d_out.release(); b.d_status.release();
+    }
+    delete q;
+    c->queue = nullptr;
+}
+
+// the leader's part: one upload, one launch, one download for the whole batch (no lock held)
+static void batch_run(v2p_ctx* c, GirBatch& b)
+{
+    auto hip = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && b.rc == V2P_OK) { b.rc = V2P_ERR_HIP; b.err = std::string(what) + ": " + hipGetErrorString(e); }
+        return e == hipSuccess;
+    };
+    if (!hip(hipSetDevice(c->device), "hipSetDevice")) return;
+    if (!b.stream && !hip(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking), "hipStreamCreate")) return;
+    // (device buffers at the batch's full capacity, once: growing them batch by batch is a hipFree + hipMalloc -- a device-wide stall -- each time)
+    const GirQueue& q = *c->queue;
+    if (!hip(b.d_in.ensure(q.cap_bytes), "hipMalloc(in)") || !hip(b.d_desc.ensure(q.desc_cap() * 8 + 64), "hipMalloc(desc)") ||
+        !hip(b.d_chunks.ensure(q.chunk_cap() * sizeof(Chunk)), "hipMalloc(chunks)") || !hip(b.d_out.ensure(q.cap_bytes), "hipMalloc(out)") ||
+        !hip(b.d_status.ensure(sizeof(unsigned long long)), "hipMalloc(status)")) return;
+    if (!hip(hipMemsetAsync(b.d_status.ptr(), 0xFF, sizeof(unsigned long long), b.stream), "hipMemset(status)")) return;
+    if (b.in_bytes && !hip(hipMemcpyAsync(b.d_in.ptr(), b.h_in.p, b.in_bytes, hipMemcpyHostToDevice, b.stream), "H2D(tapes)")) return;
+    if (b.n_desc && !hip(hipMemcpyAsync(b.d_desc.ptr(), b.h_desc.p, b.n_desc * 8, hipMemcpyHostToDevice, b.stream), "H2D(desc)")) return;
+    if (b.n_chunks && !hip(hipMemcpyAsync(b.d_chunks.ptr(), b.h_chunks.p, b.n_chunks * sizeof(Chunk), hipMemcpyHostToDevice, b.stream), "H2D(chunks)")) return;
+    if (b.n_chunks) {
+        const Chunk* hc = reinterpret_cast<const Chunk*>(b.h_chunks.p);
+        StitchArgs a{reinterpret_cast<const uint64_t*>(b.d_desc.ptr()), b.n_desc, reinterpret_cast<const Chunk*>(b.d_chunks.ptr()), uint32_t(b.n_chunks),
+                     b.d_in.ptr(), b.in_bytes, b.d_in.ptr(), b.in_bytes,          // both source spaces are the one staging blob
+                     b.d_out.ptr(), b.res_bytes, reinterpret_cast<unsigned long long*>(b.d_status.ptr())};
+        if (!hip(launch_stitch(a, b.stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | stitch_launch_bits(hc, b.n_chunks), 0), "launch(stitch)")) return;
+    }
+    if (b.res_bytes && !hip(hipMemcpyAsync(b.h_out.p, b.d_out.ptr(), b.res_bytes, hipMemcpyDeviceToHost, b.stream), "D2H(results)")) return;
+    unsigned long long st = STATUS_CLEAN;
+    if (!hip(hipMemcpyAsync(&st, b.d_status.ptr(), sizeof st, hipMemcpyDeviceToHost, b.stream), "D2H(status)")) return;
+    if (!hip(hipStreamSynchronize(b.stream), "hipStreamSynchronize")) return;
+    if (st != STATUS_CLEAN) {                            // (every task was bounds-checked by its caller: this is an engine fault, not an input error)
+        b.rc = reason_to_err(uint32_t(st & 0xFFu));
+        b.err = std::string("device: ") + err_name(b.rc) + " at descriptor " + std::to_string(st >> 8) + " of a coalesced batch";
+    }
+}
+
+extern "C" int v2p_execute_gir_shared(v2p_ctx* c,
+                                      const uint64_t* code, const uint64_t* start_pos, const uint64_t* length,
+                                      const uint64_t* start_pos_res, uint64_t n_tasks,
+                                      const uint32_t* ref, uint64_t n_ref, const uint32_t* alt, uint64_t n_alt,
+                                      uint32_t* res, uint64_t n_res, int64_t* err_row)
+{
+    if (err_row) *err_row = -1;
+    if (!c) return V2P_ERR_INVALID_ARG;
+    auto fail = [&](int code_, const std::string& msg, int64_t row) {
+        if (err_row) *err_row = row;
+        std::lock_guard<std::mutex> lk(c->mu);
+        return c->fail(code_, msg, row);
+    };
+    if ((n_tasks && (!code || !start_pos || !length || !start_pos_res)) || (n_ref && !ref) || (n_alt && !alt) || (n_res && !res))
+        return fail(V2P_ERR_INVALID_ARG, "null argument", -1);
+    if (n_tasks == 0) return V2P_OK;
+    // every task's bounds first, on the calling thread: the reference would panic (haplotype_instruction.rs:154, task.rs:42-49)
+    bool canonical = true;
+    uint64_t cursor = 0;
+    for (uint64_t i = 0; i < n_tasks; ++i) {
+        if (code[i] > 1) return fail(V2P_ERR_BAD_CODE, std::string(err_name(V2P_ERR_BAD_CODE)) + " at row " + std::to_string(i), int64_t(i));
+        const uint64_t n_src = code[i] == 0 ? n_ref : n_alt;
+        if (start_pos_res[i] + length[i] > n_res || start_pos_res[i] + length[i] < length[i])
+            return fail(V2P_ERR_RES_OOB, std::string(err_name(V2P_ERR_RES_OOB)) + " at row " + std::to_string(i), int64_t(i));
+        if (start_pos[i] + length[i] > n_src || start_pos[i] + length[i] < length[i])
+            return fail(V2P_ERR_SRC_OOB, std::string(err_name(V2P_ERR_SRC_OOB)) + " at row " + std::to_string(i), int64_t(i));
+        if (start_pos_res[i] < cursor) canonical = false;
+        cursor = start_pos_res[i] + length[i];
+    }
+    auto solo = [&]() {                                   // ordered / wide-char / oversized GIRs: the one-haplotype path, serialised on the context
+        std::vector<uint8_t> c8(n_tasks);
+        for (uint64_t i = 0; i < n_tasks; ++i) c8[i] = uint8_t(code[i]);
+        const int rc = v2p_execute_gir(c, c8.data(), start_pos, length, start_pos_res, n_tasks, ref, n_ref, alt, n_alt, res, n_res);
+        if (rc != V2P_OK && err_row) *err_row = v2p_last_error_index(c);
+        return rc;
+    };
+    GirQueue* q;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (!c->queue) {
+            c->queue = new (std::nothrow) GirQueue();
+            if (c->queue) {
+                if (const char* e = getenv("V2P_COALESCE_MB")) { const uint64_t mb = strtoull(e, nullptr, 10); if (mb >= 1 && mb <= 16384) c->queue->cap_bytes = mb << 20; }
+                if (const char* e = getenv("V2P_COALESCE_US")) c->queue->window_us = uint32_t(strtoul(e, nullptr, 10));
+                if (const char* e = getenv("V2P_COALESCE_BATCHES")) { const int k = atoi(e); if (k >= 1 && k <= GirQueue::N_BATCH) c->queue->n_batch = k; }
+            }
+        }
+        q = c->queue;
+    }
+    if (!q) return fail(V2P_ERR_HIP, "out of host memory", -1);
+    const uint64_t ref_room = (n_ref + 15) & ~15ull, in_need = ref_room + ((n_alt + 15) & ~15ull), res_need = (n_res + 4095) & ~4095ull;
+    if (!canonical || in_need > q->cap_bytes || res_need > q->cap_bytes) return solo();
+
+    using clk = std::chrono::steady_clock;
+    auto ns_since = [](clk::time_point t) { return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t).count()); };
+    clk::time_point tp = clk::now();
+    // the caller's own image, cut as if its result began the arena: batch offsets are multiples of 4 KiB, so the cuts keep their alignment
+    thread_local ImageBuilder img;
+    img.reset();
+    img.inline_payload = false;                          // the tapes travel with the batch: plain descriptors
+    img.fuse_snv = false;
+    img.desc.reserve(n_tasks + n_tasks / 4 + 64);
+    for (uint64_t i = 0; i < n_tasks; ++i) {
+        const int ps = img.add_task(code[i] == 0 ? SPACE_PROTEOME : SPACE_PAYLOAD, start_pos[i], length[i], start_pos_res[i], n_res);
+        if (ps != PACK_OK) return fail(pack_to_err(ps), "pack failed", int64_t(i));
+    }
+    img.end_haplotype(n_res);
+    img.finish();
+    const uint64_t nd = img.desc.size(), nc = img.chunks.size();
+    if (nd > q->desc_cap() || nc > q->chunk_cap()) return solo();
+
+    q->ns_pack += ns_since(tp); tp = clk::now();
+    // ---- join a batch ----
+    GirBatch* b = nullptr;
+    bool leader = false;
+    uint64_t in_off = 0, res_off = 0, desc_off = 0, chunk_off = 0;
+    {
+        std::unique_lock<std::mutex> lk(q->mu);
+        for (;;) {
+            if (q->open && (q->open->in_bytes + in_need > q->cap_bytes || q->open->res_bytes + res_need > q->cap_bytes ||
+                            q->open->n_desc + nd > q->desc_cap() || q->open->n_chunks + nc > q->chunk_cap()))
+                q->open = nullptr;                       // full: its leader closes it when the window ends; this call opens the next one
+            if (!q->open) {
+                for (int k = 0; k < q->n_batch; ++k) if (q->batch[k].state == GirBatch::FREE) { b = &q->batch[k]; break; }
+                if (!b) { q->cv.wait(lk); continue; }    // every batch is in flight
+                b->state = GirBatch::OPEN; b->n_reqs = b->n_ready = b->n_left = 0;
+                b->in_bytes = b->res_bytes = b->n_desc = b->n_chunks = 0; b->rc = V2P_OK; b->err.clear();
+                b->opened = std::chrono::steady_clock::now();
+                q->open = b; leader = true; ++q->n_batches;
+            }
+            b = q->open;
+            break;
+        }
+        in_off = b->in_bytes; res_off = b->res_bytes; desc_off = b->n_desc; chunk_off = b->n_chunks;
+        b->in_bytes += in_need; b->res_bytes += res_need; b->n_desc += nd; b->n_chunks += nc;
+        ++b->n_reqs; ++b->n_left; ++q->n_joined;
+        if (leader) {
+            // pinned staging of a batch is allocated once, at full capacity, by its first leader (callers write into it concurrently)
+            hipError_t e = hipSetDevice(c->device);
+            if (e == hipSuccess) e = b->h_in.ensure(q->cap_bytes);
+            if (e == hipSuccess) e = b->h_out.ensure(q->cap_bytes);
+            if (e == hipSuccess) e = b->h_desc.ensure(q->desc_cap() * 8);
+            if (e == hipSuccess) e = b->h_chunks.ensure(q->chunk_cap() * sizeof(Chunk));
+            if (e != hipSuccess) { b->rc = V2P_ERR_HIP; b->err = std::string("hipHostMalloc(batch staging): ") + hipGetErrorString(e); }
+        }
+    }
+    q->ns_join += ns_since(tp); tp = clk::now();
+    // ---- this caller's share of the staging, on its own thread ----
+    bool wide = false;
+    if (b->rc == V2P_OK) {
+        uint32_t seen = narrow_chars(ref, b->h_in.p + in_off, n_ref);
+        seen |= narrow_chars(alt, b->h_in.p + in_off + ref_room, n_alt);
+        wide = seen > 0xFFu;                             // a char above 0xFF: this GIR takes the 4-byte path by itself (its chunks run on garbage nobody reads)
+        uint64_t* hd = reinterpret_cast<uint64_t*>(b->h_desc.p) + desc_off;
+        for (uint64_t i = 0; i < nd; ++i) {
+            const uint64_t d = img.desc[i];
+            const unsigned sp = unsigned(d >> 62);
+            hd[i] = sp == SPACE_PROTEOME ? d + in_off : (sp == SPACE_PAYLOAD ? d + in_off + ref_room : d);     // (source offset: the low 40 bits)
+        }
+        Chunk* hc = reinterpret_cast<Chunk*>(b->h_chunks.p) + chunk_off;
+        for (uint64_t i = 0; i < nc; ++i) hc[i] = Chunk{img.chunks[i].task_begin + desc_off, img.chunks[i].dst_n + res_off};
+    }
+    q->ns_stage += ns_since(tp); tp = clk::now();
+    {
+        std::unique_lock<std::mutex> lk(q->mu);
+        ++b->n_ready;
+        if (leader) {
+            const auto deadline = b->opened + std::chrono::microseconds(q->window_us);
+            while (q->open == b && std::chrono::steady_clock::now() < deadline) q->cv.wait_until(lk, deadline);
+            if (q->open == b) q->open = nullptr;
+            b->state = GirBatch::CLOSED;
+            while (b->n_ready < b->n_reqs) q->cv.wait(lk);
+            lk.unlock();
+            const clk::time_point tg = clk::now();
+            if (b->rc == V2P_OK) batch_run(c, *b);
+            q->ns_gpu += ns_since(tg);
+            lk.lock();
+            b->state = GirBatch::DONE;
+            q->cv.notify_all();
+        } else {
+            q->cv.notify_all();                          // (the leader may be waiting for this caller's share)
+            while (b->state != GirBatch::DONE) q->cv.wait(lk);
+        }
+    }
+    q->ns_wait += ns_since(tp); tp = clk::now();
+    int rc = b->rc;
+    std::string err = rc != V2P_OK ? b->err : std::string();
+    if (rc == V2P_OK && !wide) {
+        // only cells some task covers go to the caller (the others keep the caller's content: haplotype_instruction.rs:78 filled them with '.')
+        const uint8_t* st = b->h_out.p + res_off;
+        for (uint64_t i = 0; i < n_tasks;) {
+            const uint64_t lo = start_pos_res[i];
+            uint64_t hi = lo + length[i];
+            for (++i; i < n_tasks && start_pos_res[i] == hi; ++i) hi += length[i];
+            widen_chars(st + lo, res + lo, hi - lo);
+        }
+    }
+    q->ns_widen += ns_since(tp);
+    {
+        std::lock_guard<std::mutex> lk(q->mu);
+        if (--b->n_left == 0) { b->state = GirBatch::FREE; q->cv.notify_all(); }
+    }
+    if (rc != V2P_OK) return fail(rc, err, -1);
+    return wide ? solo() : V2P_OK;
+}
+
+extern "C" int v2p_coalesce_stats(v2p_ctx* c, uint64_t* n_batches, uint64_t* n_calls)
+{
+    if (!c) return V2P_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    GirQueue* q = c->queue;
+    uint64_t nb = 0, nj = 0;
+    if (q) { std::lock_guard<std::mutex> lq(q->mu); nb = q->n_batches; nj = q->n_joined; }
+    if (n_batches) *n_batches = nb;
+    if (n_calls) *n_calls = nj;
     return V2P_OK;
 }
 

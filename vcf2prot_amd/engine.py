@@ -128,6 +128,31 @@ class Context:
                                               _p(ref), ref.size, _p(alt), alt.size, _p(res), res.size))
         return res
 
+    def execute_gir_shared(self, code, start_pos, length, start_pos_res, ref: np.ndarray, alt: np.ndarray,
+                           res: np.ndarray) -> np.ndarray:
+        """v2p_execute_gir_shared: callable from many threads on this one context (ctypes releases the GIL during the call);
+        concurrent calls are coalesced into one upload / launch / download.  Exec codes travel as uint64 (gir.rs:283-299)."""
+        code = np.ascontiguousarray(code, dtype=np.uint64)
+        sp = np.ascontiguousarray(start_pos, dtype=np.uint64)
+        ln = np.ascontiguousarray(length, dtype=np.uint64)
+        sr = np.ascontiguousarray(start_pos_res, dtype=np.uint64)
+        assert ref.dtype == np.uint32 and alt.dtype == np.uint32 and res.dtype == np.uint32
+        assert res.flags.c_contiguous and res.flags.writeable
+        ref = np.ascontiguousarray(ref)
+        alt = np.ascontiguousarray(alt)
+        row = ctypes.c_int64(-1)
+        rc = self._lib.v2p_execute_gir_shared(self._h, _p(code), _p(sp), _p(ln), _p(sr), code.size,
+                                              _p(ref), ref.size, _p(alt), alt.size, _p(res), res.size, ctypes.byref(row))
+        if rc != N.V2P_OK:
+            raise V2PError(rc, (self._lib.v2p_last_error(self._h) or b"").decode(), int(row.value))
+        return res
+
+    def coalesce_stats(self) -> Tuple[int, int]:
+        """(batches launched, calls served) by execute_gir_shared on this context."""
+        nb, nc = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self._lib.v2p_coalesce_stats(self._h, ctypes.byref(nb), ctypes.byref(nc)))
+        return int(nb.value), int(nc.value)
+
     def validate_gir(self, code, start_pos, length, start_pos_res, n_ref: int, n_alt: int, n_res: int) -> Tuple[int, int]:
         """DEBUG_GPU inspection: (first bad row or -1, reason status)."""
         code = np.ascontiguousarray(code, dtype=np.uint8)
