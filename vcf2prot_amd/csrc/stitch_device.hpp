@@ -110,4 +110,40 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("" ::: "memory");
 }
 
+
+// ---- reading a phase's image ahead of its stitch kernels (launch_stitch: phases) ----
+constexpr uint32_t TOUCH_CHUNKS_PER_WAVE = 4;      // records, then first descriptors, then payload bytes of four chunks in flight per wave
+// One wave: chunks [c0, c0 + 4) of `chunks` -- their records, every descriptor (one per lane and round; its line comes in) and a
+// payload descriptor's first and last source byte (frameshift tails, long insertions: first touched by the stitch kernel they would
+// be cold reads between its stores too -- C3: 2.36 -> 1.93 ms).  The loads are the point; nothing is kept.
+__device__ __forceinline__ void touch_chunks(const uint64_t* __restrict__ desc, const Chunk* __restrict__ chunks, uint32_t c0, uint32_t n_chunks, uint64_t n_desc,
+                                             const uint8_t* __restrict__ payload, uint64_t payload_len, uint32_t lane)
+{
+    if (c0 >= n_chunks) return;
+    Chunk ch[TOUCH_CHUNKS_PER_WAVE];
+#pragma unroll
+    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) ch[k] = chunks[c0 + k < n_chunks ? c0 + k : c0];
+    uint64_t d[TOUCH_CHUNKS_PER_WAVE];
+#pragma unroll
+    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) {
+        const uint64_t n = (ch[k].dst_n >> 48) & uint64_t(CHUNK_N_MASK), i = ch[k].task_begin + lane;
+        d[k] = (i < ch[k].task_begin + n && i < n_desc) ? desc[i] : (uint64_t(SPACE_FILL) << 62);
+    }
+    auto payload_lines = [&](uint64_t dd) {
+        const uint64_t src = dd & SRC_MASK, len = (dd >> 40) & LEN_MASK;
+        if ((dd >> 62) == SPACE_PAYLOAD && len != 0u && src < payload_len && len <= payload_len - src) {
+            const uint32_t b0 = payload[src], b1 = payload[src + len - 1u];
+            asm volatile("" :: "v"(b0), "v"(b1));
+        }
+    };
+#pragma unroll
+    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) payload_lines(d[k]);
+    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) {           // chunks of more than 64 descriptors (per-block, dense images)
+        const uint64_t n = (ch[k].dst_n >> 48) & uint64_t(CHUNK_N_MASK);
+        for (uint64_t i = ch[k].task_begin + 64u + lane; i < ch[k].task_begin + n && i < n_desc; i += 64u) payload_lines(desc[i]);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) asm volatile("" :: "v"(d[k]));
+}
+
 }  // namespace v2p

@@ -30,6 +30,8 @@ struct StitchArgs {
     uint64_t        out_len;
     unsigned long long* status;
     const uint8_t*  dots;      // set by launch_stitch(): DOTS_BYTES of '.'
+    const Chunk*    next_chunks = nullptr;   // set by launch_stitch(): the chunk records of the NEXT phase, whose image the trailing
+    uint32_t        n_next = 0;              // workgroups of a wave launch read ahead (stitch_wave.hip); 0: none
 };
 
 struct OrderedArgs {

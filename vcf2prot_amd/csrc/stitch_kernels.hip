@@ -1184,48 +1184,10 @@ static const uint8_t* device_dots(hipError_t* err)
 constexpr uint64_t PHASE_BYTES_DEFAULT = 64ull << 20;
 constexpr uint32_t PHASE_MIN_CHUNKS = 16384;            // below this a launch is one phase and is not preceded by a touch
 
-constexpr uint32_t TOUCH_CHUNKS_PER_WAVE = 4;      // records, then first descriptors, then payload bytes of four chunks in flight per wave
 __global__ __launch_bounds__(256) void touch_image_kernel(const uint64_t* __restrict__ desc, const Chunk* __restrict__ chunks, uint32_t n_chunks, uint64_t n_desc,
-                                                          const uint8_t* __restrict__ payload, uint64_t payload_len, int lines_only)
+                                                          const uint8_t* __restrict__ payload, uint64_t payload_len)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t c0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * TOUCH_CHUNKS_PER_WAVE;
-    if (c0 >= n_chunks) return;
-    Chunk ch[TOUCH_CHUNKS_PER_WAVE];
-#pragma unroll
-    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) ch[k] = chunks[c0 + k < n_chunks ? c0 + k : c0];
-    if (lines_only) {                                                // (A/B: one load per 128-byte descriptor line, payload untouched)
-#pragma unroll
-        for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) {
-            const uint64_t n = (ch[k].dst_n >> 48) & uint64_t(CHUNK_N_MASK), idx = (ch[k].task_begin & ~15ull) + lane * 16ull;
-            if (idx < ch[k].task_begin + n && idx < n_desc) { const uint64_t v = desc[idx]; asm volatile("" :: "v"(v)); }
-        }
-        return;
-    }
-    // every descriptor of the chunks (one per lane and round): its line comes in, and a payload descriptor's source lines with it
-    // (frameshift tails, long insertions: first touched by the stitch kernel they would be cold reads between its stores too --
-    // C3: 2.36 -> 1.93 ms)
-    uint64_t d[TOUCH_CHUNKS_PER_WAVE];
-#pragma unroll
-    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) {
-        const uint64_t n = (ch[k].dst_n >> 48) & uint64_t(CHUNK_N_MASK), i = ch[k].task_begin + lane;
-        d[k] = (i < ch[k].task_begin + n && i < n_desc) ? desc[i] : (uint64_t(SPACE_FILL) << 62);
-    }
-    auto payload_lines = [&](uint64_t dd) {
-        const uint64_t src = dd & SRC_MASK, len = (dd >> 40) & LEN_MASK;
-        if ((dd >> 62) == SPACE_PAYLOAD && len != 0u && src < payload_len && len <= payload_len - src) {
-            const uint32_t b0 = payload[src], b1 = payload[src + len - 1u];
-            asm volatile("" :: "v"(b0), "v"(b1));
-        }
-    };
-#pragma unroll
-    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) payload_lines(d[k]);
-    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) {           // chunks of more than 64 descriptors (per-block, dense images)
-        const uint64_t n = (ch[k].dst_n >> 48) & uint64_t(CHUNK_N_MASK);
-        for (uint64_t i = ch[k].task_begin + 64u + lane; i < ch[k].task_begin + n && i < n_desc; i += 64u) payload_lines(desc[i]);
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) asm volatile("" :: "v"(d[k]));      // (the loads are the point; nothing is kept)
+    touch_chunks(desc, chunks, (blockIdx.x * 4u + (threadIdx.x >> 6)) * TOUCH_CHUNKS_PER_WAVE, n_chunks, n_desc, payload, payload_len, threadIdx.x & 63u);
 }
 
 static hipError_t launch_stitch_range(const StitchArgs& args, hipStream_t stream, int nontemporal, uint32_t max_blocks);
@@ -1247,12 +1209,20 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     uint64_t per = uint64_t(double(phase_bytes) / per_chunk);
     per = per < 4096 ? 4096 : (per & ~7ull);                         // (a multiple of 8 keeps workgroup b on the XCD the chunk order dealt chunk b to)
     static const bool no_touch = getenv("V2P_PHASE_NO_TOUCH") != nullptr;
-    const int lines_only = getenv("V2P_TOUCH_LINES") != nullptr;
+    // a pure wave image: the read-ahead of phase k + 1 rides on the trailing workgroups of phase k's launch (they are dispatched while
+    // its last chunks drain) instead of a kernel of its own between the two; only phase 0 has a touch kernel (V2P_PHASE_OWN_TOUCH: A/B)
+    static const bool own_touch = getenv("V2P_PHASE_OWN_TOUCH") != nullptr;
+    const bool ride = !own_touch && !no_touch && (nontemporal & 4) != 0 && (nontemporal & 48) == 48 && !(nontemporal & 2);
     for (uint64_t c0 = 0; c0 < args.n_chunks; c0 += per) {
         const uint32_t nc = uint32_t(args.n_chunks - c0 < per ? args.n_chunks - c0 : per);
         a.chunks = args.chunks + c0;
         a.n_chunks = nc;
-        if (!no_touch) hipLaunchKernelGGL(touch_image_kernel, dim3((nc + 4u * TOUCH_CHUNKS_PER_WAVE - 1u) / (4u * TOUCH_CHUNKS_PER_WAVE)), dim3(256), 0, stream, a.desc, a.chunks, nc, a.n_desc, a.src1, a.src1_len, lines_only);
+        a.next_chunks = nullptr; a.n_next = 0;
+        if (ride && c0 + per < args.n_chunks) {
+            a.next_chunks = args.chunks + c0 + per;
+            a.n_next = uint32_t(args.n_chunks - (c0 + per) < per ? args.n_chunks - (c0 + per) : per);
+        }
+        if (!no_touch && (!ride || c0 == 0)) hipLaunchKernelGGL(touch_image_kernel, dim3((nc + 4u * TOUCH_CHUNKS_PER_WAVE - 1u) / (4u * TOUCH_CHUNKS_PER_WAVE)), dim3(256), 0, stream, a.desc, a.chunks, nc, a.n_desc, a.src1, a.src1_len);
         err = launch_stitch_range(a, stream, nontemporal, 0);
         if (err != hipSuccess) return err;
     }

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
                                                             const uint8_t* __restrict__ p_src0, const uint8_t* __restrict__ p_src1,
                                                             uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
                                                             const uint8_t* __restrict__ p_dots,
-                                                            uint32_t n_chunks, uint64_t n_desc, uint64_t src0_len, uint64_t src1_len, uint64_t out_len)
+                                                            uint32_t n_chunks, uint64_t n_desc, uint64_t src0_len, uint64_t src1_len, uint64_t out_len,
+                                                            const Chunk* __restrict__ p_next, uint32_t n_next)
 {
     constexpr uint32_t ROWS = CHUNK_BYTES_WAVE / 1024u;              // 1 KiB rows of a chunk: all gathered before the first store
     static_assert(ROWS <= 16u, "a lane's map bytes and record indices are packed four rows to a register");
@@ -130,7 +131,13 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = WPG == 1 ? 0u : uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
     const uint32_t c = blockIdx.x * uint32_t(WPG) + wid;
-    if (c >= n_chunks) return;
+    if (c >= n_chunks) {
+        // the launch's trailing workgroups: they are dispatched while its last chunks drain, and read the NEXT phase's chunk
+        // records, descriptors and payload lines into the caches (launch_stitch: phases) -- the read-ahead costs no launch of its own
+        const uint32_t first = (n_chunks + uint32_t(WPG) - 1u) / uint32_t(WPG) * uint32_t(WPG);
+        if (c >= first) touch_chunks(p_desc, p_next, (c - first) * TOUCH_CHUNKS_PER_WAVE, n_next, n_desc, p_src1, src1_len, lane);
+        return;
+    }
     WaveLds& L = s_all[wid];
     const uint64_t tb = p_chunks[c].task_begin, dn = p_chunks[c].dst_n;
     if (!(dn & CHUNK_WAVE)) return;                                  // the chunks of another kernel
@@ -356,8 +363,11 @@ hipError_t launch_stitch_wave(const StitchArgs& a, hipStream_t stream, bool nt, 
     for (uint32_t c0 = 0; c0 < a.n_chunks; c0 += sub) {
         const uint32_t nc = a.n_chunks - c0 < sub ? a.n_chunks - c0 : sub;
         const Chunk* ch = a.chunks + c0;
-#define V2P_LW(WW, NTT) hipLaunchKernelGGL((stitchw_kernel<WW, NTT>), dim3((nc + (WW) - 1u) / (WW)), dim3(64 * (WW)), 0, stream, \
-        a.desc, ch, a.src0, a.src1, a.out, a.status, a.dots, nc, a.n_desc, a.src0_len, a.src1_len, a.out_len)
+        const bool last = c0 + sub >= a.n_chunks;                    // (the read-ahead rides on the launch's last sub-launch)
+        const uint32_t n_next = last && a.next_chunks ? a.n_next : 0u;
+        const uint32_t tw = (n_next + TOUCH_CHUNKS_PER_WAVE - 1u) / TOUCH_CHUNKS_PER_WAVE;       // read-ahead waves
+#define V2P_LW(WW, NTT) hipLaunchKernelGGL((stitchw_kernel<WW, NTT>), dim3((nc + (WW) - 1u) / (WW) + (tw + (WW) - 1u) / (WW)), dim3(64 * (WW)), 0, stream, \
+        a.desc, ch, a.src0, a.src1, a.out, a.status, a.dots, nc, a.n_desc, a.src0_len, a.src1_len, a.out_len, a.next_chunks, n_next)
         if (waves_per_group == 4) { if (nt) V2P_LW(4, true); else V2P_LW(4, false); }
         else if (waves_per_group == 2) { if (nt) V2P_LW(2, true); else V2P_LW(2, false); }
         else { if (nt) V2P_LW(1, true); else V2P_LW(1, false); }
