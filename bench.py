@@ -548,7 +548,7 @@ def main():
                                   "outside descriptors + the proteome once (reference reads are served by L2 and not counted)",
                          "hbm_bytes_min_per_launch": hbm_min,
                          "algorithmic_bytes_per_launch": b_alg, "algorithmic_GBps": b_alg / (avg_ms * 1e-3) / 1e9,
-                         "kernel": "stitchw_kernel (wave image: one wave per chunk)" if (img.launch_bits & 4) else "stitch4_kernel (long-run image)" if not (img.launch_bits & 16) else ("stitch_dense_kernel (short tasks)" if ((img.launch_bits & 2) or ((img.launch_bits >> 8) & 15) > 2) and args.var in (0, 8, 9) else "stitch_kernel (per-block)"), "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms)},
+                         "kernel": "stitchw_kernel (wave image: one wave per chunk; a step = its phases of 64 MB of image, each read ahead into the memory-side cache -- kernel_ms is the whole step)" if (img.launch_bits & 4) else "stitch4_kernel (long-run image)" if not (img.launch_bits & 16) else ("stitch_dense_kernel (short tasks)" if ((img.launch_bits & 2) or ((img.launch_bits >> 8) & 15) > 2) and args.var in (0, 8, 9) else "stitch_kernel (per-block)"), "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms)},
             "kernel_only_aa_per_s_rank0": A / (avg_ms * 1e-3),
             "verified": verified, "image_build_s": t_gen,
         }

@@ -10,8 +10,13 @@ src, tag, out = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(out, exist_ok=True)
 
 
+def is_step_kernel(name):
+    """kernels of one execute() of the image: the stitch kernels and the read-ahead kernel of phase 0 (launch_stitch: phases)"""
+    return ("stitch" in name and "_kernel" in name) or "touch_image_kernel" in name
+
+
 def stitch_rows(path):
-    return [r for r in csv.DictReader(open(path)) if "stitch" in r["Kernel_Name"] and "_kernel" in r["Kernel_Name"]]
+    return [r for r in csv.DictReader(open(path)) if is_step_kernel(r["Kernel_Name"])]
 
 
 summary = {"tag": tag, "command": "python3 bench.py --no-cpu-baseline --no-pcie " + " ".join(sys.argv[4:])}
@@ -25,21 +30,34 @@ if os.path.exists(stats):
             r["Name"] = r["Name"][:110]
             w.writerow(r)
     for r in rows:
-        if "stitch" in r["Name"] and "_kernel" in r["Name"]:
-            summary.setdefault("stitch_kernels", []).append({"name": r["Name"][:60], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+        if is_step_kernel(r["Name"]):
+            summary.setdefault("stitch_kernels", []).append({"name": r["Name"][:60], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "total_ns": float(r["TotalDurationNs"]) if "TotalDurationNs" in r else float(r["AverageNs"]) * int(r["Calls"]),
                                                               "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "pct_of_gpu_time": float(r["Percentage"])})
-counters = {}
+    # one execute() = one STEP = the launches of all its phases (launch_stitch cuts a wave / long-run image into phases of 64 MB of
+    # image; a pure wave image has ONE touch_image_kernel launch per step, the later read-aheads ride on the stitch launches)
+    ks = summary.get("stitch_kernels", [])
+    touch = [k for k in ks if "touch_image" in k["name"]]
+    if touch and touch[0]["calls"]:
+        steps = touch[0]["calls"]
+        summary["steps_profiled"] = steps
+        summary["launches_per_step"] = {k["name"][:40]: k["calls"] / steps for k in ks}
+        summary["kernel_ms_per_step"] = sum(k["total_ns"] for k in ks) / steps / 1e6
+counters, n_steps = {}, {}
 for f in glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv")):
-    for r in stitch_rows(f):
-        counters.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-summary["counters_per_launch"] = {k: sum(v) / len(v) for k, v in sorted(counters.items())}
-c = summary["counters_per_launch"]
+    rows = stitch_rows(f)
+    steps = len({r["Dispatch_Id"] for r in rows if "touch_image" in r["Kernel_Name"]}) or len({r["Dispatch_Id"] for r in rows})
+    for r in rows:
+        counters[r["Counter_Name"]] = counters.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        n_steps[r["Counter_Name"]] = steps
+# per STEP (= per execute() of the image: all phases' launches summed)
+summary["counters_per_step"] = {k: v / max(n_steps[k], 1) for k, v in sorted(counters.items())}
+c = summary["counters_per_step"]
 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB-ish units of 1024 B; on gfx950 FETCH_SIZE
     # reports 1/2 of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is exact for 16-B/lane stores.
     fetch = 2.0 * c["FETCH_SIZE"] * 1024.0
     write = c["WRITE_SIZE"] * 1024.0
-    summary["hbm"] = {"fetch_bytes_corrected_x2": fetch, "write_bytes": write, "traffic_bytes_per_launch": fetch + write,
+    summary["hbm"] = {"fetch_bytes_corrected_x2": fetch, "write_bytes": write, "traffic_bytes_per_step": fetch + write,
                       "note": "separate --pmc passes; FETCH_SIZE doubled per the gfx950 correction (calibration: descriptor "
                               "stream + proteome first touch + payload ~ 1.14e9 B expected, 2*FETCH_SIZE reads the same)"}
 if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
@@ -59,6 +77,6 @@ if "hbm" in summary:
     tpath = os.path.join(out, "traffic_latest.json")
     allw = json.load(open(tpath)) if os.path.exists(tpath) else {}
     allw[wl] = {"workload": wl, "haplotypes": bl.get("config", {}).get("haplotypes_rank0"),
-                "hbm_bytes_per_launch": summary["hbm"]["traffic_bytes_per_launch"], "source": f"profiles/{tag}_summary.json"}
+                "hbm_bytes_per_launch": summary["hbm"]["traffic_bytes_per_step"], "source": f"profiles/{tag}_summary.json"}
     json.dump(allw, open(tpath, "w"), indent=1)
 print(json.dumps({k: summary[k] for k in summary if k not in ("bench_line_under_profiler",)}, indent=1)[:3000])

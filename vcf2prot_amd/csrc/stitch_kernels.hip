@@ -1192,6 +1192,13 @@ __global__ __launch_bounds__(256) void touch_image_kernel(const uint64_t* __rest
 
 static hipError_t launch_stitch_range(const StitchArgs& args, hipStream_t stream, int nontemporal, uint32_t max_blocks);
 
+// (experiments: V2P_PHASE_GAP_US -- one wave idling that long between two phases; V2P_PHASE_SYNC -- the host waits for every phase)
+__global__ void idle_kernel(uint32_t us)
+{
+    const uint64_t t0 = __builtin_readcyclecounter();       // (s_memtime: 100 MHz)
+    while (__builtin_readcyclecounter() - t0 < uint64_t(us) * 100u) __builtin_amdgcn_s_sleep(64);
+}
+
 hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemporal, uint32_t max_blocks)
 {
     if (args.n_chunks == 0) return hipSuccess;
@@ -1225,6 +1232,8 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
         if (!no_touch && (!ride || c0 == 0)) hipLaunchKernelGGL(touch_image_kernel, dim3((nc + 4u * TOUCH_CHUNKS_PER_WAVE - 1u) / (4u * TOUCH_CHUNKS_PER_WAVE)), dim3(256), 0, stream, a.desc, a.chunks, nc, a.n_desc, a.src1, a.src1_len);
         err = launch_stitch_range(a, stream, nontemporal, 0);
         if (err != hipSuccess) return err;
+        if (const char* e = getenv("V2P_PHASE_GAP_US")) hipLaunchKernelGGL(idle_kernel, dim3(1), dim3(64), 0, stream, uint32_t(atoi(e)));
+        if (getenv("V2P_PHASE_SYNC")) (void)hipStreamSynchronize(stream);
     }
     return hipGetLastError();
 }
