@@ -501,6 +501,7 @@ struct GirQueue {
     uint32_t window_us = 100;                        // how long a leader waits for company: V2P_COALESCE_US
     uint64_t n_batches = 0, n_joined = 0;            // statistics (v2p_coalesce_stats)
     std::atomic<uint64_t> ns_pack{0}, ns_join{0}, ns_stage{0}, ns_wait{0}, ns_widen{0}, ns_gpu{0};   // V2P_COALESCE_PROFILE: where the callers' time goes
+    std::atomic<uint64_t> ns_b_setup{0}, ns_b_h2d{0}, ns_b_launch{0}, ns_b_d2h{0}, ns_b_sync{0}, ns_b_window{0}, ns_b_strag{0};   // ... and the leader's
     uint64_t desc_cap() const { return cap_bytes / 16; }        // descriptors (8 B each: half the tape bytes at 16 result bytes per task)
     uint64_t chunk_cap() const { return cap_bytes / 256; }      // chunk records
 };
@@ -515,6 +516,11 @@ static void queue_destroy(v2p_ctx* c)
                 q->ns_join / 1e6 / double(q->n_joined ? q->n_joined : 1), q->ns_stage / 1e6 / double(q->n_joined ? q->n_joined : 1),
                 q->ns_wait / 1e6 / double(q->n_joined ? q->n_joined : 1), q->ns_widen / 1e6 / double(q->n_joined ? q->n_joined : 1),
                 q->ns_gpu / 1e6 / double(q->n_batches ? q->n_batches : 1));
+    if (getenv("V2P_COALESCE_PROFILE")) {
+        const double nb = double(q->n_batches ? q->n_batches : 1) * 1e6;
+        fprintf(stderr, "coalesce leader per batch ms: window %.3f stragglers %.3f | setup %.3f h2d-enqueue %.3f launch %.3f d2h-enqueue %.3f sync %.3f\n",
+                q->ns_b_window / nb, q->ns_b_strag / nb, q->ns_b_setup / nb, q->ns_b_h2d / nb, q->ns_b_launch / nb, q->ns_b_d2h / nb, q->ns_b_sync / nb);
+    }
     for (auto& b : q->batch) {
         if (b.stream) { (void)hipStreamSynchronize(b.stream); (void)hipStreamDestroy(b.stream); }
         b.h_in.release(); b.h_desc.release(); b.h_chunks.release(); b.h_out.release();
@@ -531,6 +537,10 @@ static void batch_run(v2p_ctx* c, GirBatch& b)
         if (e != hipSuccess && b.rc == V2P_OK) { b.rc = V2P_ERR_HIP; b.err = std::string(what) + ": " + hipGetErrorString(e); }
         return e == hipSuccess;
     };
+    using clk = std::chrono::steady_clock;
+    GirQueue& qq = *c->queue;
+    clk::time_point tp = clk::now();
+    auto lap = [&](std::atomic<uint64_t>& acc) { const clk::time_point n = clk::now(); acc += uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(n - tp).count()); tp = n; };
     if (!hip(hipSetDevice(c->device), "hipSetDevice")) return;
     if (!b.stream && !hip(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking), "hipStreamCreate")) return;
     // (device buffers at the batch's full capacity, once: growing them batch by batch is a hipFree + hipMalloc -- a device-wide stall -- each time)
@@ -538,10 +548,12 @@ static void batch_run(v2p_ctx* c, GirBatch& b)
     if (!hip(b.d_in.ensure(q.cap_bytes), "hipMalloc(in)") || !hip(b.d_desc.ensure(q.desc_cap() * 8 + 64), "hipMalloc(desc)") ||
         !hip(b.d_chunks.ensure(q.chunk_cap() * sizeof(Chunk)), "hipMalloc(chunks)") || !hip(b.d_out.ensure(q.cap_bytes), "hipMalloc(out)") ||
         !hip(b.d_status.ensure(sizeof(unsigned long long)), "hipMalloc(status)")) return;
+    lap(qq.ns_b_setup);
     if (!hip(hipMemsetAsync(b.d_status.ptr(), 0xFF, sizeof(unsigned long long), b.stream), "hipMemset(status)")) return;
     if (b.in_bytes && !hip(hipMemcpyAsync(b.d_in.ptr(), b.h_in.p, b.in_bytes, hipMemcpyHostToDevice, b.stream), "H2D(tapes)")) return;
     if (b.n_desc && !hip(hipMemcpyAsync(b.d_desc.ptr(), b.h_desc.p, b.n_desc * 8, hipMemcpyHostToDevice, b.stream), "H2D(desc)")) return;
     if (b.n_chunks && !hip(hipMemcpyAsync(b.d_chunks.ptr(), b.h_chunks.p, b.n_chunks * sizeof(Chunk), hipMemcpyHostToDevice, b.stream), "H2D(chunks)")) return;
+    lap(qq.ns_b_h2d);
     if (b.n_chunks) {
         const Chunk* hc = reinterpret_cast<const Chunk*>(b.h_chunks.p);
         StitchArgs a{reinterpret_cast<const uint64_t*>(b.d_desc.ptr()), b.n_desc, reinterpret_cast<const Chunk*>(b.d_chunks.ptr()), uint32_t(b.n_chunks),
@@ -549,10 +561,15 @@ static void batch_run(v2p_ctx* c, GirBatch& b)
                      b.d_out.ptr(), b.res_bytes, reinterpret_cast<unsigned long long*>(b.d_status.ptr())};
         if (!hip(launch_stitch(a, b.stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | stitch_launch_bits(hc, b.n_chunks), 0), "launch(stitch)")) return;
     }
+    lap(qq.ns_b_launch);
     if (b.res_bytes && !hip(hipMemcpyAsync(b.h_out.p, b.d_out.ptr(), b.res_bytes, hipMemcpyDeviceToHost, b.stream), "D2H(results)")) return;
-    unsigned long long st = STATUS_CLEAN;
-    if (!hip(hipMemcpyAsync(&st, b.d_status.ptr(), sizeof st, hipMemcpyDeviceToHost, b.stream), "D2H(status)")) return;
+    // (the status word comes back into the batch's pinned result staging, behind the results: a copy to pageable memory is a blocking one)
+    unsigned long long* const h_st = reinterpret_cast<unsigned long long*>(b.h_out.p + ((b.res_bytes + 15) & ~15ull));
+    if (!hip(hipMemcpyAsync(h_st, b.d_status.ptr(), sizeof *h_st, hipMemcpyDeviceToHost, b.stream), "D2H(status)")) return;
+    lap(qq.ns_b_d2h);
     if (!hip(hipStreamSynchronize(b.stream), "hipStreamSynchronize")) return;
+    lap(qq.ns_b_sync);
+    const unsigned long long st = *h_st;
     if (st != STATUS_CLEAN) {                            // (every task was bounds-checked by its caller: this is an engine fault, not an input error)
         b.rc = reason_to_err(uint32_t(st & 0xFFu));
         b.err = std::string("device: ") + err_name(b.rc) + " at descriptor " + std::to_string(st >> 8) + " of a coalesced batch";
@@ -659,7 +676,7 @@ extern "C" int v2p_execute_gir_shared(v2p_ctx* c,
             // pinned staging of a batch is allocated once, at full capacity, by its first leader (callers write into it concurrently)
             hipError_t e = hipSetDevice(c->device);
             if (e == hipSuccess) e = b->h_in.ensure(q->cap_bytes);
-            if (e == hipSuccess) e = b->h_out.ensure(q->cap_bytes);
+            if (e == hipSuccess) e = b->h_out.ensure(q->cap_bytes + 64);
             if (e == hipSuccess) e = b->h_desc.ensure(q->desc_cap() * 8);
             if (e == hipSuccess) e = b->h_chunks.ensure(q->chunk_cap() * sizeof(Chunk));
             if (e != hipSuccess) { b->rc = V2P_ERR_HIP; b->err = std::string("hipHostMalloc(batch staging): ") + hipGetErrorString(e); }
@@ -687,10 +704,14 @@ extern "C" int v2p_execute_gir_shared(v2p_ctx* c,
         ++b->n_ready;
         if (leader) {
             const auto deadline = b->opened + std::chrono::microseconds(q->window_us);
+            const clk::time_point tw = clk::now();
             while (q->open == b && std::chrono::steady_clock::now() < deadline) q->cv.wait_until(lk, deadline);
             if (q->open == b) q->open = nullptr;
             b->state = GirBatch::CLOSED;
+            q->ns_b_window += ns_since(tw);
+            const clk::time_point ts = clk::now();
             while (b->n_ready < b->n_reqs) q->cv.wait(lk);
+            q->ns_b_strag += ns_since(ts);
             lk.unlock();
             const clk::time_point tg = clk::now();
             if (b->rc == V2P_OK) batch_run(c, *b);
