@@ -112,17 +112,23 @@ __device__ __forceinline__ void lds_barrier()
 
 
 // ---- reading a phase's image ahead of its stitch kernels (launch_stitch: phases) ----
+// first chunk of read-ahead wave q of the workgroups that run on XCD r (workgroup index % 8): residue r, 4 chunks 8 apart per wave
+__device__ __forceinline__ uint32_t touch_wave_first(uint32_t r, uint32_t q) { return r + 8u * 4u * q; }
+__host__ __device__ __forceinline__ uint32_t touch_waves_per_xcd(uint32_t n_chunks) { return ((n_chunks + 7u) / 8u + 3u) / 4u; }
 constexpr uint32_t TOUCH_CHUNKS_PER_WAVE = 4;      // records, then first descriptors, then payload bytes of four chunks in flight per wave
 // One wave: chunks [c0, c0 + 4) of `chunks` -- their records, every descriptor (one per lane and round; its line comes in) and a
 // payload descriptor's first and last source byte (frameshift tails, long insertions: first touched by the stitch kernel they would
 // be cold reads between its stores too -- C3: 2.36 -> 1.93 ms).  The loads are the point; nothing is kept.
+// The chunks are c0, c0 + 8, c0 + 16, c0 + 24: chunk c is stitched by a workgroup of XCD c % 8 (launch order), and the wave reading
+// ahead runs on that XCD too (touch_wave_first), so what it reads lands in the L2 the stitch wave will look in, not only in the
+// memory-side cache behind it.
 __device__ __forceinline__ void touch_chunks(const uint64_t* __restrict__ desc, const Chunk* __restrict__ chunks, uint32_t c0, uint32_t n_chunks, uint64_t n_desc,
                                              const uint8_t* __restrict__ payload, uint64_t payload_len, uint32_t lane)
 {
     if (c0 >= n_chunks) return;
     Chunk ch[TOUCH_CHUNKS_PER_WAVE];
 #pragma unroll
-    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) ch[k] = chunks[c0 + k < n_chunks ? c0 + k : c0];
+    for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) ch[k] = chunks[c0 + 8u * k < n_chunks ? c0 + 8u * k : c0];
     uint64_t d[TOUCH_CHUNKS_PER_WAVE];
 #pragma unroll
     for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) {

@@ -1187,7 +1187,8 @@ constexpr uint32_t PHASE_MIN_CHUNKS = 16384;            // below this a launch i
 __global__ __launch_bounds__(256) void touch_image_kernel(const uint64_t* __restrict__ desc, const Chunk* __restrict__ chunks, uint32_t n_chunks, uint64_t n_desc,
                                                           const uint8_t* __restrict__ payload, uint64_t payload_len)
 {
-    touch_chunks(desc, chunks, (blockIdx.x * 4u + (threadIdx.x >> 6)) * TOUCH_CHUNKS_PER_WAVE, n_chunks, n_desc, payload, payload_len, threadIdx.x & 63u);
+    // workgroup b runs on XCD b % 8: its four waves read chunks of residue b % 8
+    touch_chunks(desc, chunks, touch_wave_first(blockIdx.x & 7u, (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6)), n_chunks, n_desc, payload, payload_len, threadIdx.x & 63u);
 }
 
 static hipError_t launch_stitch_range(const StitchArgs& args, hipStream_t stream, int nontemporal, uint32_t max_blocks);
@@ -1206,7 +1207,9 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     hipError_t err = hipSuccess;
     a.dots = device_dots(&err);
     if (!a.dots) return err;
-    uint64_t phase_bytes = PHASE_BYTES_DEFAULT;
+    // 64 MB of image per phase; 32 MB where the image is more than 1/25 of the result it describes (C3: 1/10 -- 1.91 against 2.01 ms;
+    // C2, 1/45: 3.27 against 3.21 the other way; C4 indifferent)
+    uint64_t phase_bytes = 8.0 * double(a.n_desc) > 0.04 * double(a.out_len) ? PHASE_BYTES_DEFAULT / 2 : PHASE_BYTES_DEFAULT;
     if (const char* e = getenv("V2P_PHASE_BYTES")) phase_bytes = strtoull(e, nullptr, 10);      // 0: one phase, no touch (A/B runs)
     // (the kernels of per-block and dense images are bound by their instruction stream, not by memory: phases only cost them --
     // C3 per-block 2.00 -> 2.19 ms, C5 dense 0.53 -> 0.71; wave and long-run images gain: C2 3.26 -> 2.65 ms)
@@ -1229,7 +1232,7 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
             a.next_chunks = args.chunks + c0 + per;
             a.n_next = uint32_t(args.n_chunks - (c0 + per) < per ? args.n_chunks - (c0 + per) : per);
         }
-        if (!no_touch && (!ride || c0 == 0)) hipLaunchKernelGGL(touch_image_kernel, dim3((nc + 4u * TOUCH_CHUNKS_PER_WAVE - 1u) / (4u * TOUCH_CHUNKS_PER_WAVE)), dim3(256), 0, stream, a.desc, a.chunks, nc, a.n_desc, a.src1, a.src1_len);
+        if (!no_touch && (!ride || c0 == 0)) hipLaunchKernelGGL(touch_image_kernel, dim3(8u * ((touch_waves_per_xcd(nc) + 3u) / 4u)), dim3(256), 0, stream, a.desc, a.chunks, nc, a.n_desc, a.src1, a.src1_len);
         err = launch_stitch_range(a, stream, nontemporal, 0);
         if (err != hipSuccess) return err;
         if (const char* e = getenv("V2P_PHASE_GAP_US")) hipLaunchKernelGGL(idle_kernel, dim3(1), dim3(64), 0, stream, uint32_t(atoi(e)));

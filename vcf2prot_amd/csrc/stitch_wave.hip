@@ -134,8 +134,10 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
     if (c >= n_chunks) {
         // the launch's trailing workgroups: they are dispatched while its last chunks drain, and read the NEXT phase's chunk
         // records, descriptors and payload lines into the caches (launch_stitch: phases) -- the read-ahead costs no launch of its own
-        const uint32_t first = (n_chunks + uint32_t(WPG) - 1u) / uint32_t(WPG) * uint32_t(WPG);
-        if (c >= first) touch_chunks(p_desc, p_next, (c - first) * TOUCH_CHUNKS_PER_WAVE, n_next, n_desc, p_src1, src1_len, lane);
+        // (they start at a workgroup index that is a multiple of 8: workgroup b is on XCD b % 8 and reads chunks of that residue)
+        const uint32_t first_wg = (((n_chunks + uint32_t(WPG) - 1u) / uint32_t(WPG)) + 7u) & ~7u;
+        if (blockIdx.x >= first_wg)
+            touch_chunks(p_desc, p_next, touch_wave_first(blockIdx.x & 7u, ((blockIdx.x - first_wg) >> 3) * uint32_t(WPG) + wid), n_next, n_desc, p_src1, src1_len, lane);
         return;
     }
     WaveLds& L = s_all[wid];
@@ -365,8 +367,8 @@ hipError_t launch_stitch_wave(const StitchArgs& a, hipStream_t stream, bool nt, 
         const Chunk* ch = a.chunks + c0;
         const bool last = c0 + sub >= a.n_chunks;                    // (the read-ahead rides on the launch's last sub-launch)
         const uint32_t n_next = last && a.next_chunks ? a.n_next : 0u;
-        const uint32_t tw = (n_next + TOUCH_CHUNKS_PER_WAVE - 1u) / TOUCH_CHUNKS_PER_WAVE;       // read-ahead waves
-#define V2P_LW(WW, NTT) hipLaunchKernelGGL((stitchw_kernel<WW, NTT>), dim3((nc + (WW) - 1u) / (WW) + (tw + (WW) - 1u) / (WW)), dim3(64 * (WW)), 0, stream, \
+        const uint32_t tw = n_next ? touch_waves_per_xcd(n_next) : 0u;                         // read-ahead waves per XCD
+#define V2P_LW(WW, NTT) hipLaunchKernelGGL((stitchw_kernel<WW, NTT>), dim3(tw ? ((((nc + (WW) - 1u) / (WW)) + 7u) & ~7u) + 8u * ((tw + (WW) - 1u) / (WW)) : (nc + (WW) - 1u) / (WW)), dim3(64 * (WW)), 0, stream, \
         a.desc, ch, a.src0, a.src1, a.out, a.status, a.dots, nc, a.n_desc, a.src0_len, a.src1_len, a.out_len, a.next_chunks, n_next)
         if (waves_per_group == 4) { if (nt) V2P_LW(4, true); else V2P_LW(4, false); }
         else if (waves_per_group == 2) { if (nt) V2P_LW(2, true); else V2P_LW(2, false); }
