@@ -1214,10 +1214,13 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     // (the kernels of per-block and dense images are bound by their instruction stream, not by memory: phases only cost them --
     // C3 per-block 2.00 -> 2.19 ms, C5 dense 0.53 -> 0.71; wave and long-run images gain: C2 3.26 -> 2.65 ms)
     const bool streams = (nontemporal & 4) != 0 || (nontemporal & 16) == 0;       // the image holds wave or long-run chunks
-    if (max_blocks != 0 || phase_bytes == 0 || !streams || a.n_chunks < PHASE_MIN_CHUNKS) return launch_stitch_range(a, stream, nontemporal, max_blocks);
+    uint32_t min_chunks = PHASE_MIN_CHUNKS;
+    if (const char* e = getenv("V2P_PHASE_MIN_CHUNKS")) min_chunks = uint32_t(strtoul(e, nullptr, 10));   // (tests: phases on small images)
+    if (max_blocks != 0 || phase_bytes == 0 || !streams || a.n_chunks < min_chunks) return launch_stitch_range(a, stream, nontemporal, max_blocks);
     const double per_chunk = 16.0 + 8.0 * double(a.n_desc) / double(a.n_chunks);
     uint64_t per = uint64_t(double(phase_bytes) / per_chunk);
-    per = per < 4096 ? 4096 : (per & ~7ull);                         // (a multiple of 8 keeps workgroup b on the XCD the chunk order dealt chunk b to)
+    const uint64_t per_min = getenv("V2P_PHASE_MIN_CHUNKS") ? 8u : 4096u;
+    per = per < per_min ? per_min : (per & ~7ull);                   // (a multiple of 8 keeps workgroup b on the XCD the chunk order dealt chunk b to)
     static const bool no_touch = getenv("V2P_PHASE_NO_TOUCH") != nullptr;
     // a pure wave image: the read-ahead of phase k + 1 rides on the trailing workgroups of phase k's launch (they are dispatched while
     // its last chunks drain) instead of a kernel of its own between the two; only phase 0 has a touch kernel (V2P_PHASE_OWN_TOUCH: A/B)
