@@ -187,7 +187,7 @@ def pcie_inclusive(cohort, h0, h1, n_threads, slots=3, target_image_bytes=2 << 3
             "d2h_GBps": out_total / best / 1e9, "what": "packed images -> pinned H2D -> stitch kernel -> D2H into pinned host memory"}
 
 
-def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests, dense=False, wave=False):
+def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests, dense=False, wave=False, result_bytes=0):
     """the same shard's image built ON the device from the per-transcript GIRs of step 4b (v2p_batch_build_on_device:
     step 5's running sums as prefix scans, descriptors, chunk table, XCD order).  Returns the build kernels' time and whether the
     image executes to the same per-haplotype digests."""
@@ -197,12 +197,18 @@ def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests, dense=
     stream = cohort.txstream(h0, h1, n_threads=n_threads)
     t_stream = time.perf_counter() - t0
     from vcf2prot_amd._native import V2PError
-    # a dense image: one window = the kernel's 12 KiB LDS image when its descriptors fit (<= 1024 per window), else smaller windows
-    windows = (12288, 8192, 4096) if dense else ((10240, 8192, 4096) if wave else ((28672,) if long_run else (32768,)))
-    kernel = 3 if dense else (4 if wave else (1 if long_run else 2))
+    from vcf2prot_amd.txstream import build_plan
+    # the routing of vcf2prot_amd/txstream.py::build_plan (what pipeline.vcf_to_fasta and v2p_harness vcf use): wave windows that may
+    # split once, sized by the image's result bytes per task; dense: one window = the kernel's 12 KiB LDS image when its descriptors fit
+    if dense:
+        plan = [(3, 12288), (3, 8192), (3, 4096)]
+    elif wave:
+        plan = build_plan(result_bytes / max(stream.n_tasks, 1) if result_bytes else 134.0)
+    else:
+        plan = [(1, 28672)] if long_run else [(2, 32768)]
     with Context(0) as ctx:
         ctx.upload_proteome(cohort.proteome())
-        for window in windows:
+        for kernel, window in plan:
             b = ctx.batch()
             try:
                 t0 = time.perf_counter()
@@ -211,7 +217,7 @@ def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests, dense=
                 break
             except V2PError:
                 b.close()
-                if window == windows[-1]:
+                if (kernel, window) == plan[-1]:
                     raise
         cn = b.counts()
         same = None
@@ -233,14 +239,14 @@ def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests, dense=
             ctx.set_stream(0)
         b.close()
     res = {"build_kernels_ms": ms, "call_s_incl_h2d_of_the_stream": t_call, "stream_bytes": stream.nbytes, "stream_generation_s": t_stream,
-           "window_bytes": window, "descriptors": cn["n_desc"], "chunks": cn["n_chunks"], "digests_equal_host_built_image": same,
+           "window_bytes": window, "kernel_choice": kernel, "descriptors": cn["n_desc"], "chunks": cn["n_chunks"], "digests_equal_host_built_image": same,
            "execute_ms_device_built_image": exec_ms,
            "what": "per-transcript GIRs (un-rebased Task SoA, transcript offsets, alt bytes) -> descriptors + chunk table + hap_out_begin in HBM"}
     stream.close()
     return res
 
 
-def whole_cohort_leg(workload, samples, steps, n_threads, verify_every=True, temporal=False):
+def whole_cohort_leg(workload, samples, steps, n_threads, verify_every=True, temporal=False, device_build=False):
     """One GPU, one launch per step over a WHOLE cohort (no sharding, no collective): pack, upload, verify every haplotype's digest
     against the oracle, then time `steps` launches with HIP events on the launch stream.  Used for the north star's 10 000-sample
     cohort next to the N = 1 line and for `speedup_vs_1` of a strong-scaling run."""
@@ -319,6 +325,12 @@ def whole_cohort_leg(workload, samples, steps, n_threads, verify_every=True, tem
            "every_haplotype": bool(len(check) == n_haps), "haplotypes_checked": len(check), "oracle_seconds": t_v, "image_build_s": t_pack}
     del d_out, d_desc, d_chunks, d_payload, d_prot
     torch.cuda.empty_cache()
+    if device_build:                                          # the same cohort's image built on the device from the transcript stream
+        try:
+            res["device_image_build"] = device_image_build(cohort, 0, n_haps, min(n_threads, 64), not (bits & 16), dig, dense=bool(bits & 2), wave=bool(bits & 4),
+                                                           result_bytes=int(out_bytes))
+        except Exception as e:                                # noqa: BLE001  (the leg's own numbers stand)
+            res["device_image_build"] = {"error": repr(e)}
     return res
 
 
@@ -574,7 +586,7 @@ def main():
                 line["incl_transfers"] = {"error": repr(e)}
         if world == 1 and not args.no_device_build and not args.fasta and not args.dbg and not args.dry_run:
             try:
-                line["device_image_build"] = device_image_build(cohort, h0, h1, min(n_threads, 64), not (img.launch_bits & 16), dig_all, dense=bool(img.launch_bits & 2), wave=bool(img.launch_bits & 4))
+                line["device_image_build"] = device_image_build(cohort, h0, h1, min(n_threads, 64), not (img.launch_bits & 16), dig_all, dense=bool(img.launch_bits & 2), wave=bool(img.launch_bits & 4), result_bytes=int(out_bytes))
             except Exception as e:
                 line["device_image_build"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
@@ -584,7 +596,7 @@ def main():
             try:
                 del d_desc, d_chunks, d_payload
                 torch.cuda.empty_cache()
-                line["north_star_cohort"] = whole_cohort_leg("C3", DEFAULT_SAMPLES["strong"]["C3"], 5, n_threads, verify_every=True)
+                line["north_star_cohort"] = whole_cohort_leg("C3", DEFAULT_SAMPLES["strong"]["C3"], 5, n_threads, verify_every=True, device_build=not args.no_device_build)
             except Exception as e:
                 line["north_star_cohort"] = {"error": repr(e)}
         print(json.dumps(line))

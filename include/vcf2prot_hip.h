@@ -214,7 +214,10 @@ typedef struct {
 /* kernel: 1 = route every chunk to the long-run kernel (<= 512 descriptors per window), 2 = per-block kernel, 3 = dense image
  * (stitch_dense_kernel: short tasks, fused substitutions, <= 1024 descriptors per window: windows of 4, 8 or 12 KiB, larger ones are
  * V2P_ERR_INVALID_ARG), 4 = wave image (stitchw_kernel, one wave per window: windows of 1 .. 10 KiB in steps of 1 KiB with <= 64
- * descriptors each, fused substitutions; the choice for long reference runs).
+ * descriptors each, fused substitutions; the choice for long reference runs), 5 = wave image whose windows may SPLIT ONCE (2 .. 10 KiB:
+ * a window of 65 .. 127 descriptors becomes two chunks, cut on the 1 KiB row nearest its middle that leaves both with <= 64, the
+ * descriptor under the cut split in two -- every window carries one spare descriptor slot for that; the grid can then be as coarse
+ * as the AVERAGE window allows: C3 at 8 KiB executes within 2 % of the host packer's greedy cuts, at the 4 KiB kernel 4 needs 30 % slower).
  * The offset tables of the stream are checked on the host before anything is uploaded (ascending from 0, inside their arrays):
  * V2P_ERR_INVALID_ARG with the offending index.  A window that holds more descriptors than its kernel takes is
  * V2P_ERR_UNSUPPORTED and leaves the batch empty: call again with a smaller window.

@@ -114,3 +114,58 @@ def test_device_build_can_be_retried_with_a_smaller_window(built, gpu_ctx):
     b.sync()
     b.close()
     st.close()
+
+
+@pytest.mark.parametrize("preset,h0,n,window,fasta", [
+    ("C3", 100, 40, 8192, False), ("C3", 100, 40, 10240, False), ("C3", 7, 25, 6144, False), ("C3", 100, 12, 4096, True), ("C4", 7, 3, 10240, False),
+    ("C4", 7, 3, 6144, True), ("C2", 5, 3, 10240, False), ("C2", 5, 2, 10240, True), ("C1", 0, 8, 2048, False)])
+def test_wave_windows_that_split(built, gpu_ctx, coracle, preset, h0, n, window, fasta):
+    """kernel = 5: wave windows of up to ten 1 KiB rows where a window of 65 .. 127 descriptors becomes TWO chunks, cut on a row, the
+    descriptor under the cut split in two (copy / fill / immediate / fused substitution on either side of its literal) -- so the grid
+    can be as coarse as the AVERAGE window allows, not the worst one.  Every chunk respects what one wave takes, every haplotype is
+    the oracle's (with FASTA emit: the host packer's file text)."""
+    import ctypes
+    from vcf2prot_amd.cohort import Cohort
+    c = Cohort.preset(preset)
+    gpu_ctx.upload_reference(c.proteome(), c.fasta_headers())
+    stream = c.txstream(h0, h0 + n, n_threads=3)
+    keep = []
+    if fasta:
+        off, ln = [], []
+        for h in range(h0, h0 + n):
+            for tx in c.haplotype(h).tx_id:
+                off.append(1 + (2 * int(tx) + (h & 1)) * Cohort.HEADER_BYTES)
+                ln.append(Cohort.HEADER_BYTES)
+        keep = [np.array(off, dtype=np.uint64), np.array(ln, dtype=np.uint32)]
+        stream.struct.tx_header_off = keep[0].ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+        stream.struct.tx_header_len = keep[1].ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+    b = gpu_ctx.batch()
+    b.build_on_device(stream, window, 5)
+    desc, chunks, hb = b.download_image()
+    nd = ((chunks[:, 1] >> np.uint64(48)) & np.uint64(0x7FF)).astype(np.int64)
+    dst = (chunks[:, 1] & np.uint64((1 << 48) - 1)).astype(np.int64)
+    n_windows = (int(hb[-1]) + window - 1) // window
+    assert nd.max() <= 64 and (dst % 1024 == 0).all() and chunks.shape[0] >= n_windows
+    assert (((chunks[:, 1] >> np.uint64(60)) & np.uint64(0xF)) == 1).all()                       # CHUNK_WAVE only
+    order = np.argsort(dst)
+    ends = np.concatenate([dst[order][1:], [int(hb[-1])]])
+    assert ((ends - dst[order]) <= window).all() and ((ends - dst[order]) > 0).all()
+    if preset in ("C3", "C4") and (window >= 8192 or fasta):
+        assert chunks.shape[0] > n_windows                                                        # some windows did split
+    b.execute()
+    b.sync()
+    if fasta:
+        host = c.pack(h0, h0 + n, n_threads=2, fasta=True)
+        hbatch = gpu_ctx.batch()
+        hbatch.set_packed(host.desc, host.chunks, host.payload, host.hap_out_begin)
+        hbatch.finalize()
+        hbatch.execute()
+        hbatch.sync()
+        for i in range(n):
+            assert np.array_equal(b.download_hap(i), hbatch.download_hap(i)), (preset, window, i)
+        hbatch.close()
+    else:
+        for i in range(n):
+            assert np.array_equal(b.download_hap(i), oracle_hap(c, coracle, h0 + i)), (preset, window, h0 + i)
+    b.close()
+    stream.close()

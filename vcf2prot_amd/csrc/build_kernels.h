@@ -29,7 +29,10 @@ struct BuildArgs {
     uint32_t window;              // result bytes per chunk (grid)
     int      long_run;            // route every chunk to stitch4_kernel
     int      dense;               // ... to stitch_dense_kernel (fusion on as for long_run)
-    int      wave;                // with long_run: ... to stitchw_kernel instead (windows of <= 8 KiB and <= 64 descriptors)
+    int      wave;                // with long_run: ... to stitchw_kernel instead (windows of <= 10 KiB and <= 64 descriptors)
+    int      split;               // with wave: a window of 65 .. 127 descriptors becomes TWO chunks, cut on a 1 KiB row (the descriptor under the
+                                  // cut is split in two; every window carries a spare descriptor slot for that).  chunks_tmp / bucket / sub then hold
+                                  // 2 * n_windows entries: window k's (first) chunk at k, second chunks from n_windows on (meta[4] counts them)
     // scans and outputs
     const uint64_t* tx_res_base;  // [n_tx + 1] exclusive prefix of the transcripts' arena lengths (tx_res_len, + header + line feed with FASTA emit)
     uint32_t* tx_desc_count;      // [n_tx]
@@ -40,7 +43,7 @@ struct BuildArgs {
     uint8_t*  bucket;             // [n_windows] proteome slice of each chunk
     uint8_t*  sub;                // [n_windows] window of that slice (xcd_sub_window)
     uint64_t* hap_out_begin;      // [n_haps + 1]
-    uint32_t* meta;               // [4]: any long-run chunk, any with > 256 descriptors, any per-block chunk, most descriptors of a per-block chunk
+    uint32_t* meta;               // [8]: any long-run chunk, any with > 256 descriptors, any per-block chunk, most descriptors of a per-block chunk, second chunks of split windows
     unsigned long long* status;
 };
 

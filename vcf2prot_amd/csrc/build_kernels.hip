@@ -136,9 +136,13 @@ __device__ __forceinline__ uint32_t put(const BuildArgs& a, PairSink& sink, uint
     while (len) {
         const uint32_t room = W - at.off;
         const uint32_t piece = uint32_t(len < room ? len : room);
+        if (a.split && at.off == 0u) {                                       // the window's spare slot (chunk_kernel may need it to split a descriptor)
+            if (EMIT) { sink.store(a.desc, k, uint64_t(SPACE_FILL) << 62); a.chunk_first[at.win] = k; }
+            ++k; ++n;
+        }
         if (EMIT) {
             sink.store(a.desc, k, (src & SRC_MASK) | (uint64_t(piece & LEN_MASK) << 40) | (uint64_t(space) << 62));
-            if (at.off == 0u) a.chunk_first[at.win] = k;
+            if (at.off == 0u && !a.split) a.chunk_first[at.win] = k;
         }
         ++k; ++n;
         if (space == SPACE_IMM) src = piece >= 8 ? 0 : src >> (8 * piece);
@@ -187,9 +191,13 @@ struct Walker {
         const uint64_t total = uint64_t(len1) + 1u + len2;
         const WinPos at = win_pos(base, rel, a.window);
         if (uint64_t(at.off) + total <= a.window) {                              // the three inside one window
+            if (a.split && at.off == 0u) {
+                if (EMIT) { sink.store(a.desc, k, uint64_t(SPACE_FILL) << 62); a.chunk_first[at.win] = k; }
+                ++k; ++cnt;
+            }
             if (EMIT) {
                 sink.store(a.desc, k, SNV3_MARK | (uint64_t(byte & 0xFFu) << 53) | (uint64_t(len2 & 0xFFFu) << 41) | (uint64_t(len1 & 0xFFFu) << 29) | (src & SNV3_MAX_SRC));
-                if (at.off == 0u) a.chunk_first[at.win] = k;
+                if (at.off == 0u && !a.split) a.chunk_first[at.win] = k;
             }
             ++k; ++cnt;
         } else {
@@ -350,6 +358,122 @@ __global__ __launch_bounds__(256) void hap_begin_kernel(BuildArgs a, uint64_t ou
     if (k <= a.n_haps) a.hap_out_begin[k] = k < a.n_haps ? a.tx_res_base[a.hap_tx_begin[k]] : out_bytes;   // res_counter at the haplotype's first transcript
 }
 
+
+// ---- a wave window that may split once (BuildArgs::split) ------------------------------------------------------------------
+// The window's slots are [spare][d0 .. d(m-1)].  m <= 64: one chunk.  65 .. 127: two chunks, cut on the 1 KiB row nearest the middle
+// that leaves both with <= 64 descriptors; the descriptor lying across the cut becomes two (its first part moves, with everything
+// before it, one slot down into the spare; its second part takes its old slot) -- each kind splits into valid descriptors:
+// copies and fills at any byte, an immediate by shifting its literal, a fused substitution into a copy and a fused substitution
+// (or the reverse) on either side of its literal.
+__device__ __forceinline__ uint32_t wave_desc_len(uint64_t d)
+{
+    return (d & SNV3_MARK) == SNV3_MARK ? uint32_t((d >> 29) & 0xFFFu) + 1u + uint32_t((d >> 41) & 0xFFFu) : uint32_t(d >> 40) & LEN_MASK;
+}
+__device__ __forceinline__ void split_desc(uint64_t d, uint32_t x, uint64_t& lo, uint64_t& hi)      // 0 < x < length
+{
+    if ((d & SNV3_MARK) == SNV3_MARK) {
+        const uint64_t src = d & SNV3_MAX_SRC;
+        const uint32_t len1 = uint32_t((d >> 29) & 0xFFFu), len2 = uint32_t((d >> 41) & 0xFFFu);
+        const uint64_t byte = (d >> 53) & 0xFFull;
+        if (x <= len1) {                                             // inside (or right behind) the first copy
+            lo = (src & SRC_MASK) | (uint64_t(x) << 40);
+            hi = SNV3_MARK | (byte << 53) | (uint64_t(len2) << 41) | (uint64_t(len1 - x) << 29) | ((src + x) & SNV3_MAX_SRC);
+        } else {                                                     // behind the literal
+            const uint32_t k2 = x - len1 - 1u;
+            lo = SNV3_MARK | (byte << 53) | (uint64_t(k2) << 41) | (uint64_t(len1) << 29) | src;
+            hi = ((src + x) & SRC_MASK) | (uint64_t(len2 - k2) << 40);
+        }
+        return;
+    }
+    const uint64_t space = d >> 62, src = d & SRC_MASK;
+    const uint32_t len = uint32_t(d >> 40) & LEN_MASK;
+    if (space == SPACE_IMM) { lo = (src & ((1ull << (8u * x)) - 1ull)) | (uint64_t(x) << 40) | (space << 62); hi = (src >> (8u * x)) | (uint64_t(len - x) << 40) | (space << 62); }
+    else if (space == SPACE_FILL) { lo = (uint64_t(x) << 40) | (space << 62); hi = (uint64_t(len - x) << 40) | (space << 62); }
+    else { lo = src | (uint64_t(x) << 40) | (space << 62); hi = ((src + x) & SRC_MASK) | (uint64_t(len - x) << 40) | (space << 62); }
+}
+// proteome slice key of a chunk: the first reference read among its first six descriptors (order_chunks_for_xcds)
+__device__ __forceinline__ uint64_t first_ref_key(const BuildArgs& a, uint64_t d, bool mine, uint32_t rel)
+{
+    const bool snv = (d & SNV3_MARK) == SNV3_MARK;
+    const uint64_t src = snv ? (d & SNV3_MAX_SRC) : (d & SRC_MASK);
+    const bool cand = mine && rel < 6u && (snv || (d >> 62) == SPACE_PROTEOME) && src < a.proteome_len && wave_desc_len(d) != 0u;
+    const unsigned long long m = __ballot(cand);
+    if (!m) return 0;
+    const int first = __ffsll(static_cast<long long>(m)) - 1;
+    return (uint64_t(uint32_t(__shfl(int(uint32_t(src >> 32)), first, 64))) << 32) | uint32_t(__shfl(int(uint32_t(src)), first, 64));
+}
+__device__ __forceinline__ void put_chunk(const BuildArgs& a, uint64_t slot, uint64_t tb, uint64_t dst, uint32_t n, uint64_t key)
+{
+    a.chunks_tmp[slot] = Chunk{tb, dst | (uint64_t(n) << 48) | CHUNK_WAVE};
+    const uint64_t per = (a.proteome_len + 7) / 8;
+    const uint64_t bk = per ? key / per : 0;
+    a.bucket[slot] = uint8_t(bk < 8 ? bk : 7);
+    a.sub[slot] = xcd_sub_window(key, a.bucket[slot], per);
+}
+__device__ __forceinline__ void chunk_split_window(const BuildArgs& a, uint64_t k, uint64_t n_windows, uint64_t tb, uint32_t n_slots, uint32_t lane)
+{
+    const uint32_t m = n_slots ? n_slots - 1u : 0u;                  // real descriptors (slot 0 is the spare)
+    if (m > 2u * CHUNK_TASKS_WAVE - 1u) { if (lane == 0) breport(a.status, tb, STATUS_TOO_MANY); return; }
+    volatile uint32_t* meta = a.meta;
+    if (lane == 0 && !(meta[0] & 4u)) atomicOr(&a.meta[0], 4u);
+    const uint64_t d0 = lane < m ? a.desc[tb + 1u + lane] : (uint64_t(SPACE_FILL) << 62);
+    const uint64_t d1 = lane + 64u < m ? a.desc[tb + 65u + lane] : (uint64_t(SPACE_FILL) << 62);
+    if (m <= CHUNK_TASKS_WAVE) {
+        const uint64_t key = first_ref_key(a, d0, lane < m, lane);
+        if (lane == 0) put_chunk(a, k, tb + 1u, k * a.window, m, key);
+        return;
+    }
+    // positions inside the window: descriptor i covers [start_i, end_i)
+    const uint32_t l0 = wave_desc_len(d0), l1 = wave_desc_len(d1);
+    uint32_t e0 = l0, e1 = l1;
+#pragma unroll
+    for (uint32_t s = 1; s < 64u; s <<= 1) { const uint32_t y0 = __shfl_up(e0, s, 64), y1 = __shfl_up(e1, s, 64); if (lane >= s) { e0 += y0; e1 += y1; } }
+    e1 += uint32_t(__shfl(int(e0), 63, 64));
+    const uint32_t s0 = e0 - l0, s1 = e1 - l1;
+    const bool v0 = lane < m, v1 = lane + 64u < m;
+    // the cut: a 1 KiB row R, both sides <= 64 descriptors (the one lying across R counts on both), nearest the window's middle
+    uint32_t best = 0, best_dist = 0xFFFFFFFFu;
+    for (uint32_t R = 1024u; R < a.window; R += 1024u) {
+        const uint32_t nA = uint32_t(__popcll(__ballot(v0 && s0 < R))) + uint32_t(__popcll(__ballot(v1 && s1 < R)));          // start before R
+        const uint32_t done = uint32_t(__popcll(__ballot(v0 && e0 <= R))) + uint32_t(__popcll(__ballot(v1 && e1 <= R)));      // end at or before R
+        const uint32_t nB = m - done;
+        const uint32_t dist = R > a.window / 2u ? R - a.window / 2u : a.window / 2u - R;
+        if (nA >= 1u && nB >= 1u && nA <= CHUNK_TASKS_WAVE && nB <= CHUNK_TASKS_WAVE && dist < best_dist) { best = R; best_dist = dist; }
+    }
+    if (best == 0u) { if (lane == 0) breport(a.status, tb, STATUS_TOO_MANY); return; }
+    const uint32_t R = best;
+    const uint32_t nA = uint32_t(__popcll(__ballot(v0 && s0 < R))) + uint32_t(__popcll(__ballot(v1 && s1 < R)));
+    const bool x0 = v0 && s0 < R && e0 > R, x1 = v1 && s1 < R && e1 > R;         // the descriptor lying across R (at most one), index nA - 1
+    const bool across = (__ballot(x0) | __ballot(x1)) != 0ull;
+    uint64_t tbA, tbB;
+    uint32_t cntB;
+    if (across) {
+        // [d0 .. d(j-1), lo(dj)] move one slot down (slots tb .. tb + j), hi(dj) takes dj's slot, the rest stays
+        uint64_t lo0 = d0, hi0 = 0, lo1 = d1, hi1 = 0;
+        if (x0) split_desc(d0, R - s0, lo0, hi0);
+        if (x1) split_desc(d1, R - s1, lo1, hi1);
+        if (v0 && s0 < R) a.desc[tb + lane] = lo0;
+        if (v1 && s1 < R) a.desc[tb + 64u + lane] = lo1;
+        if (x0) a.desc[tb + 1u + lane] = hi0;                        // (after the moves of the same lane; other lanes write other slots)
+        if (x1) a.desc[tb + 65u + lane] = hi1;
+        tbA = tb; tbB = tb + nA; cntB = m - nA + 1u;
+    } else {
+        tbA = tb + 1u; tbB = tb + 1u + nA; cntB = m - nA;
+    }
+    // keys: chunk A from its first descriptors (unchanged by the split unless the very first one lies across: then its first part,
+    // same source), chunk B from the descriptors from index nA - (across ? 1 : 0) on
+    const uint64_t keyA = first_ref_key(a, d0, v0, lane);
+    const uint32_t jB = across ? nA - 1u : nA;                       // index of B's first descriptor (its source: dj's, advanced -- same slice but for a pathological few)
+    const uint32_t r0 = lane >= jB ? lane - jB : 0xFFFFu, r1 = lane + 64u >= jB ? lane + 64u - jB : 0xFFFFu;
+    const uint64_t kb0 = first_ref_key(a, d0, v0 && lane >= jB, r0), kb1 = first_ref_key(a, d1, v1 && lane + 64u >= jB, r1);
+    const uint64_t keyB = (jB < 64u && kb0) ? kb0 : (kb1 ? kb1 : kb0);
+    if (lane == 0) {
+        put_chunk(a, k, tbA, k * a.window, nA, keyA);
+        const uint32_t o = atomicAdd(&a.meta[4], 1u);
+        put_chunk(a, n_windows + o, tbB, k * a.window + R, cntB, keyB);
+    }
+}
+
 // one WAVE per window: its descriptors read 64 at a time (a lane per window walked them one by one: 0.62 ms for C2's 559 k windows)
 __global__ __launch_bounds__(256) void chunk_kernel(BuildArgs a, uint64_t n_windows, uint64_t n_desc, uint64_t out_bytes)
 {
@@ -359,6 +483,7 @@ __global__ __launch_bounds__(256) void chunk_kernel(BuildArgs a, uint64_t n_wind
     const uint64_t tb = a.chunk_first[k];
     const uint64_t tb_next = k + 1 < n_windows ? a.chunk_first[k + 1] : n_desc;
     const uint64_t n = tb_next - tb;
+    if (a.split) { chunk_split_window(a, k, n_windows, tb, uint32_t(n < 4096u ? n : 4096u), lane); return; }
     if (n > CHUNK_TASKS_DEEP) { if (lane == 0) breport(a.status, tb, STATUS_TOO_MANY); return; }   // too many descriptors in one window: pick a smaller grid
     // tasks of the window (a fused substitution is up to three) and the proteome slice of its first reference read
     // (order_chunks_for_xcds looks at the first six descriptors)

@@ -376,11 +376,18 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
         st.tx_header_off = txs.hdr_off.data(); st.tx_header_len = txs.hdr_len.data();
         // routing as the host packer would choose it (result bytes per task); a window with too many descriptors is retried smaller
         const double bpt = double(txs.result_bytes) / double(st.n_tasks ? st.n_tasks : 1);
-        const std::pair<int, uint32_t> long_plan[] = {{4, 10240}, {4, 4096}, {2, 32768}, {2, 16384}, {2, 4096}, {3, 12288}, {3, 8192}, {3, 4096}};
-        const std::pair<int, uint32_t> mid_plan[] = {{4, 4096}, {4, 2048}, {2, 32768}, {2, 16384}, {2, 4096}, {3, 12288}, {3, 8192}, {3, 4096}};
-        const std::pair<int, uint32_t> dense_plan[] = {{3, 12288}, {3, 8192}, {3, 4096}, {2, 4096}};
-        const std::pair<int, uint32_t>* plan = bpt >= 120 ? long_plan : (bpt >= 40 ? mid_plan : dense_plan);
-        const size_t n_plan = bpt >= 120 ? 8 : (bpt >= 40 ? 8 : 4);
+        // (vcf2prot_amd/txstream.py::build_plan: wave windows that may split once, sized for ~56 descriptors on average)
+        std::vector<std::pair<int, uint32_t>> plan_v;
+        if (bpt < 40) plan_v = {{3, 12288}, {3, 8192}, {3, 4096}, {2, 4096}};
+        else {
+            uint32_t w = uint32_t(double(bpt) * 1.85 * 56.0) / 1024u * 1024u;
+            w = w < 2048u ? 2048u : (w > 10240u ? 10240u : w);
+            if (bpt >= 120) plan_v = {{4, 10240}, {5, 10240}, {5, 8192}};
+            else { plan_v = {{5, w}}; if (w >= 4096u) plan_v.push_back({5, w - 2048u}); }
+            for (auto p : {std::pair<int, uint32_t>{4, 4096}, {4, 2048}, {2, 32768}, {2, 16384}, {2, 4096}, {3, 12288}, {3, 8192}, {3, 4096}}) plan_v.push_back(p);
+        }
+        const std::pair<int, uint32_t>* plan = plan_v.data();
+        const size_t n_plan = plan_v.size();
         int rc = V2P_ERR_UNSUPPORTED;
         for (size_t k = 0; k < n_plan && rc == V2P_ERR_UNSUPPORTED; ++k) rc = v2p_batch_build_on_device(b, &st, plan[k].second, plan[k].first, nullptr);
         chk(rc);

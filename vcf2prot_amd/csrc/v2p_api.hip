@@ -1016,10 +1016,13 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     std::lock_guard<std::mutex> lk(c->mu);
     if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
     if (b->hap_open || b->img.n_haplotypes()) return c->fail(V2P_ERR_STATE, "the batch already holds host-built haplotypes");
+    const bool split = kernel == 5;                       // wave windows that may split once (65 .. 127 descriptors -> two chunks)
+    if (split) kernel = 4;
     if (window_bytes == 0 || window_bytes % (kernel == 4 ? 1024u : 4096u) || window_bytes > CHUNK_BYTES - 4080u)
         return c->fail(V2P_ERR_INVALID_ARG, "window_bytes must be a multiple of 4096 (wave images: of 1024), at most 61440");
     if (kernel == 1 && window_bytes > CHUNK_BYTES_LONG) return c->fail(V2P_ERR_INVALID_ARG, "the long-run kernel takes windows of at most 32768 bytes");
     if (kernel == 4 && window_bytes > CHUNK_BYTES_WAVE) return c->fail(V2P_ERR_INVALID_ARG, "a wave image takes windows of at most 10240 bytes (one chunk = ten 1 KiB rows of one wave)");
+    if (split && window_bytes < 2048u) return c->fail(V2P_ERR_INVALID_ARG, "a window that may split holds at least two 1 KiB rows");
     // (a grid chunk starts on a multiple of 4096: no 16-byte phase, so 12288 bytes fill the kernel's LDS image exactly)
     if (kernel == 3 && window_bytes > 12288u) return c->fail(V2P_ERR_INVALID_ARG, "a dense image takes windows of 4096, 8192 or 12288 bytes (one chunk = one 12 KiB LDS image)");
     if (!s->hap_tx_begin || (s->n_tx && (!s->tx_proteome_off || !s->tx_ref_len || !s->tx_res_len || !s->tx_task_begin || !s->tx_alt_begin)) ||
@@ -1069,7 +1072,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     const uint64_t o_hap = carve((n_h + 1) * 8), o_poff = carve(n_tx * 8), o_rlen = carve(n_tx * 4), o_res = carve(n_tx * 4),
                    o_tb = carve((n_tx + 1) * 8), o_ab = carve((n_tx + 1) * 8), o_code = carve(n_tk), o_sp = carve(n_tk * 4), o_ln = carve(n_tk * 4),
                    o_sr = carve(n_tk * 4), o_base = carve((n_tx + 1) * 8), o_cnt = carve(n_tx * 4), o_dbase = carve((n_tx + 1) * 8),
-                   o_tiles = carve(n_tiles * 8), o_meta = carve(16),
+                   o_tiles = carve(n_tiles * 8), o_meta = carve(32),
                    o_hoff = carve(fasta ? n_tx * 8 : 0), o_hlen = carve(fasta ? n_tx * 4 : 0), o_alen = carve(fasta ? n_tx * 4 : 0);
     HIP_TRY(c, b->d_build.ensure(off), "hipMalloc(build)");
     uint8_t* const d = b->d_build.ptr();
@@ -1083,7 +1086,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     if (fasta) { UP(o_hoff, s->tx_header_off, n_tx * 8, "H2D(tx_header_off)"); UP(o_hlen, s->tx_header_len, n_tx * 4, "H2D(tx_header_len)"); UP(o_alen, arena_len.data(), n_tx * 4, "H2D(arena_len)"); }
 #undef UP
     if (s->n_alt) HIP_TRY(c, hipMemcpyAsync(b->d_payload.ptr(), s->alt, s->n_alt, hipMemcpyHostToDevice, c->stream), "H2D(alt)");
-    HIP_TRY(c, hipMemsetAsync(d + o_meta, 0, 16, c->stream), "hipMemset(meta)");
+    HIP_TRY(c, hipMemsetAsync(d + o_meta, 0, 32, c->stream), "hipMemset(meta)");
     int rc = init_status(c, b->d_status);
     if (rc) return rc;
     // two brackets: the counting kernels, then -- after the host has read the two totals and allocated the image -- the emitting ones
@@ -1113,7 +1116,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     a.start_pos_res = reinterpret_cast<const uint32_t*>(d + o_sr); a.alt = b->d_payload.ptr();
     a.tx_header_off = fasta ? reinterpret_cast<const uint64_t*>(d + o_hoff) : nullptr;
     a.tx_header_len = fasta ? reinterpret_cast<const uint32_t*>(d + o_hlen) : nullptr;
-    a.proteome_len = c->proteome_len; a.window = window_bytes; a.long_run = kernel == 1 || kernel == 4; a.dense = kernel == 3; a.wave = kernel == 4;
+    a.proteome_len = c->proteome_len; a.window = window_bytes; a.long_run = kernel == 1 || kernel == 4; a.dense = kernel == 3; a.wave = kernel == 4; a.split = split;
     a.tx_res_base = reinterpret_cast<const uint64_t*>(d + o_base); a.tx_desc_count = reinterpret_cast<uint32_t*>(d + o_cnt);
     a.desc_base = reinterpret_cast<const uint64_t*>(d + o_dbase); a.meta = reinterpret_cast<uint32_t*>(d + o_meta);
     a.status = reinterpret_cast<unsigned long long*>(b->d_status.ptr());
@@ -1132,15 +1135,17 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     const uint64_t n_windows = (out_bytes + window_bytes - 1) / window_bytes;
     if (n_windows > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch");
     DevBuf& scratch = guard.scratch;                      // chunk_first, chunks in result order, slices, per-block histograms
-    const uint64_t n_blocks = (n_windows + 255) / 256;
-    const uint64_t n_sub = uint64_t(XCD_SUB) * n_blocks;      // counters of the window sort
-    const uint64_t s_first = 0, s_tmp = up8(n_windows * 8), s_bucket = s_tmp + up8(n_windows * 16), s_hist = s_bucket + up8(n_windows),
-                   s_sub = s_hist + up8((n_blocks + 1) * 8 * 4), s_tmp2 = s_sub + up8(n_windows), s_bucket2 = s_tmp2 + up8(n_windows * 16),
-                   s_subhist = s_bucket2 + up8(n_windows), s_substart = s_subhist + up8(n_sub * 4), s_subtiles = s_substart + up8((n_sub + 1) * 8),
-                   s_end = s_subtiles + up8(scan_tiles_for(n_sub) * 8);
+    const uint64_t cap = split ? 2 * n_windows : n_windows;   // chunk slots: a window that splits adds one behind the n_windows first ones
+    if (cap > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch");
+    const uint64_t n_blocks_cap = (cap + 255) / 256;
+    const uint64_t n_sub_cap = uint64_t(XCD_SUB) * n_blocks_cap;      // counters of the window sort
+    const uint64_t s_first = 0, s_tmp = up8(n_windows * 8), s_bucket = s_tmp + up8(cap * 16), s_hist = s_bucket + up8(cap),
+                   s_sub = s_hist + up8((n_blocks_cap + 1) * 8 * 4), s_tmp2 = s_sub + up8(cap), s_bucket2 = s_tmp2 + up8(cap * 16),
+                   s_subhist = s_bucket2 + up8(cap), s_substart = s_subhist + up8(n_sub_cap * 4), s_subtiles = s_substart + up8((n_sub_cap + 1) * 8),
+                   s_end = s_subtiles + up8(scan_tiles_for(n_sub_cap) * 8);
     HIP_TRY(c, scratch.ensure(s_end), "hipMalloc(build scratch)");
     HIP_TRY(c, b->d_desc.ensure(n_desc * 8), "hipMalloc(desc)");
-    HIP_TRY(c, b->d_chunks.ensure(n_windows * sizeof(Chunk)), "hipMalloc(chunks)");
+    HIP_TRY(c, b->d_chunks.ensure(cap * sizeof(Chunk)), "hipMalloc(chunks)");
     HIP_TRY(c, b->d_out.ensure((out_bytes + 15) & ~15ull), "hipMalloc(out)");
     HIP_TRY(c, b->d_hap.ensure((n_h + 1) * 8), "hipMalloc(hap_begin)");
     HIP_TRY(c, b->d_digest.ensure((n_h ? n_h : 1) * 8), "hipMalloc(digest)");
@@ -1152,16 +1157,23 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     a.hap_out_begin = reinterpret_cast<uint64_t*>(b->d_hap.ptr());
     HIP_TRY(c, hipEventRecord(e2, c->stream), "hipEventRecord");
     HIP_TRY(c, launch_build(a, n_windows, n_desc, out_bytes, 1, c->stream), "launch(emit)");
-    const bool reorder = !(c->flags & V2P_FLAG_RESULT_ORDER) && n_windows >= 16 && c->proteome_len != 0 && n_desc != 0;
+    uint64_t n_chunks = n_windows;
+    if (split) {                                          // how many windows split: the sorts below run over every chunk
+        uint32_t extra = 0;
+        HIP_TRY(c, hipMemcpyAsync(&extra, d + o_meta + 16, 4, hipMemcpyDeviceToHost, c->stream), "D2H(split windows)");
+        HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+        n_chunks = n_windows + extra;
+    }
+    const bool reorder = !(c->flags & V2P_FLAG_RESULT_ORDER) && n_chunks >= 16 && c->proteome_len != 0 && n_desc != 0;
     if (reorder) {
         Chunk* by_window = reinterpret_cast<Chunk*>(scratch.ptr() + s_tmp2);
-        HIP_TRY(c, launch_sub_order(a.chunks_tmp, a.bucket, a.sub, n_windows, reinterpret_cast<uint32_t*>(scratch.ptr() + s_subhist),
+        HIP_TRY(c, launch_sub_order(a.chunks_tmp, a.bucket, a.sub, n_chunks, reinterpret_cast<uint32_t*>(scratch.ptr() + s_subhist),
                                     reinterpret_cast<uint64_t*>(scratch.ptr() + s_substart), reinterpret_cast<uint64_t*>(scratch.ptr() + s_subtiles),
                                     by_window, scratch.ptr() + s_bucket2, c->stream), "launch(window order)");
-        HIP_TRY(c, launch_xcd_order(by_window, scratch.ptr() + s_bucket2, n_windows, reinterpret_cast<uint32_t*>(scratch.ptr() + s_hist),
+        HIP_TRY(c, launch_xcd_order(by_window, scratch.ptr() + s_bucket2, n_chunks, reinterpret_cast<uint32_t*>(scratch.ptr() + s_hist),
                                     reinterpret_cast<Chunk*>(b->d_chunks.ptr()), c->stream), "launch(xcd order)");
     }
-    else if (n_windows) HIP_TRY(c, hipMemcpyAsync(b->d_chunks.ptr(), a.chunks_tmp, n_windows * sizeof(Chunk), hipMemcpyDeviceToDevice, c->stream), "D2D(chunks)");
+    else if (n_chunks) HIP_TRY(c, hipMemcpyAsync(b->d_chunks.ptr(), a.chunks_tmp, n_chunks * sizeof(Chunk), hipMemcpyDeviceToDevice, c->stream), "D2D(chunks)");
     HIP_TRY(c, hipEventRecord(e3, c->stream), "hipEventRecord");
     uint32_t meta[4] = {0, 0, 0, 0};
     HIP_TRY(c, hipMemcpyAsync(meta, d + o_meta, 16, hipMemcpyDeviceToHost, c->stream), "D2H(meta)");
@@ -1175,7 +1187,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     if (rc) { (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return rc; }
     guard.ok = true;
     if (build_ms) *build_ms = ms;
-    b->n_desc = n_desc; b->n_chunks = n_windows; b->n_payload = s->n_alt; b->out_bytes = out_bytes; b->n_haps = n_h;
+    b->n_desc = n_desc; b->n_chunks = n_chunks; b->n_payload = s->n_alt; b->out_bytes = out_bytes; b->n_haps = n_h;
     const int tpt = meta[3] <= 256u ? 1 : (meta[3] <= 512u ? 2 : 4);
     b->launch_hint = ((meta[0] & 2u) ? 2 : 0) | ((meta[0] & 4u) ? 4 : 0) | ((meta[0] & 1u) ? 0 : 16) | (meta[2] ? 0 : 32) | ((meta[1] ? 2 : 1) << 6) | (tpt << 8);
     b->uses_proteome = true;

@@ -111,22 +111,28 @@ class HostTxStream:
         self.keep = []
 
 
+def build_plan(bytes_per_task: float) -> list:
+    """(kernel, window_bytes) pairs to try in order for v2p_batch_build_on_device, by result bytes per task -- the routing the host
+    packer would choose.  Wave images (>= 40 bytes per task): windows that may split once (kernel 5) sized for about 56 descriptors
+    on average (a fused image has ~1.85x the task's bytes per descriptor), so that most windows are one chunk and the few above 64
+    descriptors become two; long runs (>= 120) start with plain ten-row windows (no spare slots).  Dense images below 40."""
+    bpt = float(bytes_per_task)
+    if bpt < 40:
+        return [(3, 12288), (3, 8192), (3, 4096), (2, 4096)]
+    w = int(bpt * 1.85 * 56) // 1024 * 1024
+    w = max(2048, min(10240, w))
+    plan = [(4, 10240), (5, 10240), (5, 8192)] if bpt >= 120 else [(5, w)] + ([(5, w - 2048)] if w >= 4096 else [])
+    return plan + [(4, 4096), (4, 2048), (2, 32768), (2, 16384), (2, 4096), (3, 12288), (3, 8192), (3, 4096)]
+
+
 def build_on_device_auto(batch, stream, result_bytes: Optional[int] = None) -> dict:
-    """v2p_batch_build_on_device with the routing the host packer would choose: by result bytes per task a wave image (long
-    reference runs), a per-block image or a dense one; a window that holds more descriptors than its kernel takes
+    """v2p_batch_build_on_device with build_plan(): a window that holds more descriptors than its kernel takes
     (V2P_ERR_UNSUPPORTED) is retried smaller, then with the next kernel."""
     from ._native import V2PError
     n_tasks = max(int(stream.struct.n_tasks), 1)
     rb = result_bytes if result_bytes is not None else getattr(stream, "result_bytes", 0)
-    bpt = rb / n_tasks
-    if bpt >= 120:
-        plan = [(4, 10240), (4, 4096), (2, 32768), (2, 16384), (2, 4096), (3, 12288), (3, 8192), (3, 4096)]
-    elif bpt >= 40:
-        plan = [(4, 4096), (4, 2048), (2, 32768), (2, 16384), (2, 4096), (3, 12288), (3, 8192), (3, 4096)]
-    else:
-        plan = [(3, 12288), (3, 8192), (3, 4096), (2, 4096)]
     last = None
-    for kernel, window in plan:
+    for kernel, window in build_plan(rb / n_tasks):
         try:
             ms = batch.build_on_device(stream, window, kernel)
             return {"kernel": kernel, "window": window, "build_ms": ms}
