@@ -95,7 +95,7 @@ int v2p_execute_gir(v2p_ctx* ctx,
 
 /* The same arm for MANY workers sharing ONE context (the reference enters GIR::execute from every Rayon worker: parts/exec.rs:36-39,
  * personalized_genome.rs:64-65).  Thread-safe: concurrent calls are gathered for V2P_COALESCE_US microseconds (default 100) into one
- * batch of at most V2P_COALESCE_MB megabytes of tapes (default 32) -- every caller narrows its own tapes and packs its own
+ * batch of at most V2P_COALESCE_MB megabytes of tapes (default 16) -- every caller narrows its own tapes and packs its own
  * descriptors into the batch's pinned staging on its own thread -- then ONE upload, ONE launch and ONE download serve them all, and
  * up to V2P_COALESCE_BATCHES batches (default 8) are alive on their own streams.  `code` holds the exec codes as the SoA marshaller has them
  * (gir.rs:283-299, usize -> uint64_t: no narrowing copy on the Rust side); any value other than 0 / 1 is V2P_ERR_BAD_CODE

@@ -496,8 +496,8 @@ struct GirQueue {
     std::condition_variable cv;
     GirBatch batch[N_BATCH];
     GirBatch* open = nullptr;
-    uint64_t cap_bytes = 32ull << 20;                // tape bytes (and result bytes) one batch takes: V2P_COALESCE_MB (small batches, many in flight: 16 workers on C2
-                                                     // reach 1.0e10 aa/s with 128 MB x 4, 1.5e10 with 32 MB x 8, 1.9e10 with 16 MB x 8)
+    uint64_t cap_bytes = 16ull << 20;                // tape bytes (and result bytes) one batch takes: V2P_COALESCE_MB (small batches, many in flight: 16 workers on C2
+                                                     // reach 1.0e10 aa/s with 128 MB x 4, 1.75e10 with 32 MB x 8, 2.1e10 with 16 MB x 8)
     uint32_t window_us = 100;                        // how long a leader waits for company: V2P_COALESCE_US
     uint64_t n_batches = 0, n_joined = 0;            // statistics (v2p_coalesce_stats)
     std::atomic<uint64_t> ns_pack{0}, ns_join{0}, ns_stage{0}, ns_wait{0}, ns_widen{0}, ns_gpu{0};   // V2P_COALESCE_PROFILE: where the callers' time goes
@@ -541,7 +541,9 @@ static void batch_run(v2p_ctx* c, GirBatch& b)
     GirQueue& qq = *c->queue;
     clk::time_point tp = clk::now();
     auto lap = [&](std::atomic<uint64_t>& acc) { const clk::time_point n = clk::now(); acc += uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(n - tp).count()); tp = n; };
-    if (!hip(hipSetDevice(c->device), "hipSetDevice")) return;
+    // (hipSetDevice once per host thread and device: with sixteen leaders in the runtime at once the call cost 0.3 ms of every batch)
+    thread_local int device_set = -1;
+    if (device_set != c->device) { if (!hip(hipSetDevice(c->device), "hipSetDevice")) return; device_set = c->device; }
     if (!b.stream && !hip(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking), "hipStreamCreate")) return;
     // (device buffers at the batch's full capacity, once: growing them batch by batch is a hipFree + hipMalloc -- a device-wide stall -- each time)
     const GirQueue& q = *c->queue;
@@ -621,6 +623,24 @@ extern "C" int v2p_execute_gir_shared(v2p_ctx* c,
                 if (const char* e = getenv("V2P_COALESCE_MB")) { const uint64_t mb = strtoull(e, nullptr, 10); if (mb >= 1 && mb <= 16384) c->queue->cap_bytes = mb << 20; }
                 if (const char* e = getenv("V2P_COALESCE_US")) c->queue->window_us = uint32_t(strtoul(e, nullptr, 10));
                 if (const char* e = getenv("V2P_COALESCE_BATCHES")) { const int k = atoi(e); if (k >= 1 && k <= GirQueue::N_BATCH) c->queue->n_batch = k; }
+                // every batch's staging, device buffers and stream now, by the first caller: a batch that allocates at its first use
+                // does so inside somebody's call (pinned staging alone is tens of milliseconds per batch)
+                GirQueue& q0 = *c->queue;
+                hipError_t e = hipSetDevice(c->device);
+                for (int k = 0; k < q0.n_batch && e == hipSuccess; ++k) {
+                    GirBatch& bb = q0.batch[k];
+                    if (e == hipSuccess) e = bb.h_in.ensure(q0.cap_bytes);
+                    if (e == hipSuccess) e = bb.h_out.ensure(q0.cap_bytes + 64);
+                    if (e == hipSuccess) e = bb.h_desc.ensure(q0.desc_cap() * 8);
+                    if (e == hipSuccess) e = bb.h_chunks.ensure(q0.chunk_cap() * sizeof(Chunk));
+                    if (e == hipSuccess) e = bb.d_in.ensure(q0.cap_bytes);
+                    if (e == hipSuccess) e = bb.d_out.ensure(q0.cap_bytes);
+                    if (e == hipSuccess) e = bb.d_desc.ensure(q0.desc_cap() * 8 + 64);
+                    if (e == hipSuccess) e = bb.d_chunks.ensure(q0.chunk_cap() * sizeof(Chunk));
+                    if (e == hipSuccess) e = bb.d_status.ensure(sizeof(unsigned long long));
+                    if (e == hipSuccess) e = hipStreamCreateWithFlags(&bb.stream, hipStreamNonBlocking);
+                }
+                if (e != hipSuccess) { queue_destroy(c); return c->fail(V2P_ERR_HIP, std::string("coalescing queue: ") + hipGetErrorString(e)); }
             }
         }
         q = c->queue;
