@@ -127,6 +127,7 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
     };
     __shared__ __attribute__((aligned(16))) WaveLds s_all[WPG];
     __shared__ u32x4 s_mask[17];                                     // s_mask[j]: bytes >= j of a block
+    __shared__ u32x4 s_one[17];                                      // s_one[j]: byte j of a block alone (16: none) -- where a replaced residue goes
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = WPG == 1 ? 0u : uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
@@ -159,6 +160,10 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) m[k] = jm <= 4u * k ? 0xFFFFFFFFu : (jm >= 4u * k + 4u ? 0u : 0xFFFFFFFFu << (8u * (jm - 4u * k)));
         s_mask[jm] = m;
+        u32x4 o1;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) o1[k] = (jm >> 2) == k && jm < 16u ? 0xFFu << (8u * (jm & 3u)) : 0u;
+        s_one[jm] = o1;
     }
 #pragma unroll
     for (uint32_t k = 0; k < ND; ++k) L.map32[ND * lane + k] = 0u;
@@ -313,13 +318,20 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
     for (uint32_t j = 0; j < ROWS; ++j) {
         const uint32_t b16 = (j << 10) + l16;
         const uint32_t r = (pk[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
-        const u32x4 t = reinterpret_cast<const u32x4*>(L.rec)[r];
-        const uint32_t e = t[2] >> 16;
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 t23 = reinterpret_cast<const u32x2*>(L.rec)[2u * r + 1u];       // (start|end, literal: the record's second half)
+        const uint32_t e = t23[0] >> 16;
         const bool cut = e < b16 + 16u;
         const u32x4 p = L.patch[cut ? r + 1u : CHUNK_TASKS_WAVE];
         const uint32_t ja = e - b16;                               // (1 .. 15 for a cut block inside the chunk)
         const u32x4 m = s_mask[cut && ja < 16u ? ja : 16u];
-        u32x4 o = wrec_lit(v[j], t[3], b16);
+        // (the replaced residue of a fused substitution through a one-byte mask from LDS and four v_bfi, like the tail merge:
+        // placing it arithmetically -- shift, compare and select per dword -- was 17 VALU a row; this is 8 and one ds_read_b128)
+        const uint32_t lq = (t23[1] & 0xFFFFu) - b16;
+        const u32x4 lm = s_one[lq < 16u ? lq : 16u];
+        const uint32_t lb = ((t23[1] >> 16) & 0xFFu) * 0x01010101u;
+        u32x4 o = v[j];
+        o[0] = (lb & lm[0]) | (o[0] & ~lm[0]); o[1] = (lb & lm[1]) | (o[1] & ~lm[1]); o[2] = (lb & lm[2]) | (o[2] & ~lm[2]); o[3] = (lb & lm[3]) | (o[3] & ~lm[3]);
         o = wmerge(o, p, m);
         const bool whole = int32_t(l16) <= last16 - int32_t(j << 10) && (j != 0u || l16 >= head);
         const uint32_t off = (whole && !(V2P_WAVE_ABLATE & 4)) ? l16 : 0x80000000u;
