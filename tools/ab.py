@@ -93,6 +93,10 @@ def main():
     for spec in a.variants:
         kv = dict(x.split("=") for x in spec.split(",") if x)
         pack = {k: int(kv[k]) for k in ("chunk_tasks", "chunk_bytes", "cut_align", "soft_window") if k in kv}
+        if int(kv.get("linecut", 1)):
+            os.environ.pop("V2P_NO_LINE_CUT", None)
+        else:
+            os.environ["V2P_NO_LINE_CUT"] = "1"
         if int(kv.get("grid", 0)):            # chunks cut on a fixed result grid (the device builder's rule)
             img = cohort.pack_grid(0, cohort.n_haplotypes, int(kv["grid"]), 2 if int(kv.get("var", 0)) in (1, 2) else int(kv.get("kernel", 1)))
         else:

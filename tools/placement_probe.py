@@ -22,7 +22,8 @@ def main():
     cohort = Cohort.preset(wl, n_samples=samples)
     prot = cohort.proteome()
     resident = np.concatenate([prot, cohort.fasta_headers()])
-    img = cohort.pack(0, cohort.n_haplotypes, n_threads=min(64, os.cpu_count() or 1))
+    pack_kw = dict(x.split("=") for x in sys.argv[4:])
+    img = cohort.pack(0, cohort.n_haplotypes, n_threads=min(64, os.cpu_count() or 1), **{k: int(v) for k, v in pack_kw.items()})
     chunks = np.ascontiguousarray(img.chunks)
     lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, prot.size)
     bits = int(lib.v2p_stitch_launch_bits(chunks.ctypes.data, chunks.shape[0])) | 1
@@ -58,6 +59,10 @@ def main():
         return statistics.median(ms)
 
     offs = [0, 256, 4096, 65536, 1 << 20, 2 << 20, (2 << 20) + 4096, 16 << 20, 100 << 20, 128 << 20, 256 << 20, 512 << 20, 777 << 20, (1 << 30) - 4096]
+    if len(sys.argv) > 3 and sys.argv[3] == "sub":        # sub-line / sub-row shifts of the arena: are 1 KiB-aligned rows better or worse?
+        for o in [0, 16, 32, 48, 64, 128, 144, 512, 528, 1024, 0, 16, 64]:
+            print(f"out    offset {o:>11d}: {run(o, 0, 0):.3f} ms", flush=True)
+        return
     for name, idx in (("out", 0), ("desc", 1), ("chunks", 2)):
         for o in offs:
             args = [0, 0, 0]

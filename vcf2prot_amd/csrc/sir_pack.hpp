@@ -49,6 +49,7 @@
 #else
 #define V2P_HOST_DEVICE
 #endif
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <string>
@@ -501,7 +502,14 @@ private:
             // preferred cut: a multiple of cut_align (4 KiB = one full 256-lane pass of 16-byte blocks, so no
             // partially filled pass); when that cannot be reached any more, a multiple of 16
             uint32_t align = cut_pref();
-            if (open_units() + 6 >= chunk_tasks || open_bytes_ + (align - uint32_t(arena_cursor_ & uint64_t(align - 1))) > chunk_bytes) align = 16;
+            if (open_units() + 6 >= chunk_tasks || open_bytes_ + (align - uint32_t(arena_cursor_ & uint64_t(align - 1))) > chunk_bytes) {
+                // a wave chunk that cannot reach a row boundary any more still ends on a 128-byte line while two slots are left: its rows
+                // then cover whole lines, and no line of the arena is written in two halves by two waves
+                const bool cut_line = getenv("V2P_NO_LINE_CUT") == nullptr;      // (A/B switch, read while packing)
+                const bool line = cut_line && kernel_choice == 4 && cut_pref() >= 128u && open_units() + 2 < chunk_tasks &&
+                                  open_bytes_ + (128u - uint32_t(arena_cursor_ & 127ull)) <= chunk_bytes;
+                align = line ? 128u : 16u;
+            }
             const uint32_t misal = uint32_t(arena_cursor_ & uint64_t(align - 1));
             if (misal == 0 && open_n_ > 0) { close_chunk(); continue; }       // aligned cut
             const uint32_t r = align - misal;
