@@ -1228,6 +1228,17 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     // its last chunks drain) instead of a kernel of its own between the two; only phase 0 has a touch kernel (V2P_PHASE_OWN_TOUCH: A/B)
     static const bool own_touch = getenv("V2P_PHASE_OWN_TOUCH") != nullptr;
     const bool ride = !own_touch && !no_touch && (nontemporal & 4) != 0 && (nontemporal & 48) == 48 && !(nontemporal & 2);
+    // (V2P_PHASE_ONE_LAUNCH, A/B: ONE launch for all phases, the read-ahead workgroups of phase g + 1 placed in the grid before the
+    // stitch workgroups of phase g (stitch_wave.hip) -- no kernel boundary, no tail, no launch gap between two phases.  Measured:
+    // C2 3.16 against 3.21 ms, but C3 1.98 against 1.85 and C3 whole 11.1 against 9.35: the boundary is what keeps two phases'
+    // images from sharing the L2 and the read-ahead from running into the stores.  Not the default.)
+    const int wsel = (nontemporal >> 28) & 3;
+    if (ride && wsel == 0 && getenv("V2P_PHASE_ONE_LAUNCH") != nullptr && per <= 0x7FFFFFFFull) {
+        const uint32_t n0 = uint32_t(args.n_chunks < per ? args.n_chunks : per);
+        hipLaunchKernelGGL(touch_image_kernel, dim3(8u * ((touch_waves_per_xcd(n0) + 3u) / 4u)), dim3(256), 0, stream, a.desc, a.chunks, n0, a.n_desc, a.src1, a.src1_len);
+        a.phase_chunks = uint32_t(per);
+        return launch_stitch_range(a, stream, nontemporal, 0);
+    }
     for (uint64_t c0 = 0; c0 < args.n_chunks; c0 += per) {
         const uint32_t nc = uint32_t(args.n_chunks - c0 < per ? args.n_chunks - c0 : per);
         a.chunks = args.chunks + c0;

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
                                                             uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
                                                             const uint8_t* __restrict__ p_dots,
                                                             uint32_t n_chunks, uint64_t n_desc, uint64_t src0_len, uint64_t src1_len, uint64_t out_len,
-                                                            const Chunk* __restrict__ p_next, uint32_t n_next)
+                                                            const Chunk* __restrict__ p_next, uint32_t n_next, uint32_t phase_chunks)
 {
     constexpr uint32_t ROWS = CHUNK_BYTES_WAVE / 1024u;              // 1 KiB rows of a chunk: all gathered before the first store
     static_assert(ROWS <= 16u, "a lane's map bytes and record indices are packed four rows to a register");
@@ -131,8 +131,24 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = WPG == 1 ? 0u : uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
-    const uint32_t c = blockIdx.x * uint32_t(WPG) + wid;
-    if (c >= n_chunks) {
+    uint32_t c = blockIdx.x * uint32_t(WPG) + wid;
+    if (WPG == 1 && phase_chunks != 0u) {
+        // ONE launch for all phases (launch_stitch): the grid is, phase after phase, [read-ahead workgroups of phase g + 1][stitch
+        // workgroups of phase g] -- workgroups are dispatched in index order, so a phase's image is read while the phase before it
+        // is being stitched, without a kernel boundary (its tail, its launch gap) between two phases.  Both group sizes are
+        // multiples of 8: workgroup b stays on XCD b % 8 = the XCD of the chunks it stitches or reads ahead.
+        const uint32_t tw = 8u * touch_waves_per_xcd(phase_chunks), per = tw + phase_chunks;
+        const uint32_t g = blockIdx.x / per, r = blockIdx.x - g * per;
+        if (r < tw) {
+            const uint64_t base = uint64_t(g + 1u) * phase_chunks;
+            if (base < n_chunks)
+                touch_chunks(p_desc, p_chunks + base, touch_wave_first(r & 7u, r >> 3), uint32_t(n_chunks - base < phase_chunks ? n_chunks - base : phase_chunks),
+                             n_desc, p_src1, src1_len, lane);
+            return;
+        }
+        c = g * phase_chunks + (r - tw);
+        if (c >= n_chunks) return;
+    } else if (c >= n_chunks) {
         // the launch's trailing workgroups: they are dispatched while its last chunks drain, and read the NEXT phase's chunk
         // records, descriptors and payload lines into the caches (launch_stitch: phases) -- the read-ahead costs no launch of its own
         // (they start at a workgroup index that is a multiple of 8: workgroup b is on XCD b % 8 and reads chunks of that residue)
@@ -368,6 +384,16 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
 hipError_t launch_stitch_wave(const StitchArgs& a, hipStream_t stream, bool nt, int waves_per_group)
 {
     if (a.n_chunks == 0) return hipSuccess;
+    if (a.phase_chunks != 0u && waves_per_group == 1) {              // every phase in one launch, read-ahead workgroups interleaved (see the kernel)
+        const uint32_t P = a.phase_chunks, tw = 8u * touch_waves_per_xcd(P);
+        const uint64_t groups = (uint64_t(a.n_chunks) + P - 1u) / P, grid = groups * (uint64_t(tw) + P);
+        if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        if (nt) hipLaunchKernelGGL((stitchw_kernel<1, true>), dim3(uint32_t(grid)), dim3(64), 0, stream, a.desc, a.chunks, a.src0, a.src1, a.out, a.status, a.dots,
+                                   a.n_chunks, a.n_desc, a.src0_len, a.src1_len, a.out_len, nullptr, 0u, P);
+        else hipLaunchKernelGGL((stitchw_kernel<1, false>), dim3(uint32_t(grid)), dim3(64), 0, stream, a.desc, a.chunks, a.src0, a.src1, a.out, a.status, a.dots,
+                                a.n_chunks, a.n_desc, a.src0_len, a.src1_len, a.out_len, nullptr, 0u, P);
+        return hipGetLastError();
+    }
     // (one launch.  Sub-launches of 8 Ki ... 128 Ki chunks -- the waves of a fresh launch read their descriptors together and store
     // together, which a bare copy kernel rewards: tools/wave_copy_bench.py -- cost this kernel 1 ... 17 %: V2P_WAVE_SUB, experiments only)
     uint32_t sub = 0;
@@ -381,7 +407,7 @@ hipError_t launch_stitch_wave(const StitchArgs& a, hipStream_t stream, bool nt, 
         const uint32_t n_next = last && a.next_chunks ? a.n_next : 0u;
         const uint32_t tw = n_next ? touch_waves_per_xcd(n_next) : 0u;                         // read-ahead waves per XCD
 #define V2P_LW(WW, NTT) hipLaunchKernelGGL((stitchw_kernel<WW, NTT>), dim3(tw ? ((((nc + (WW) - 1u) / (WW)) + 7u) & ~7u) + 8u * ((tw + (WW) - 1u) / (WW)) : (nc + (WW) - 1u) / (WW)), dim3(64 * (WW)), 0, stream, \
-        a.desc, ch, a.src0, a.src1, a.out, a.status, a.dots, nc, a.n_desc, a.src0_len, a.src1_len, a.out_len, a.next_chunks, n_next)
+        a.desc, ch, a.src0, a.src1, a.out, a.status, a.dots, nc, a.n_desc, a.src0_len, a.src1_len, a.out_len, a.next_chunks, n_next, 0u)
         if (waves_per_group == 4) { if (nt) V2P_LW(4, true); else V2P_LW(4, false); }
         else if (waves_per_group == 2) { if (nt) V2P_LW(2, true); else V2P_LW(2, false); }
         else { if (nt) V2P_LW(1, true); else V2P_LW(1, false); }
