@@ -111,7 +111,9 @@ def random_stream(rng, n_haps, n_ref_tx, shape, window):
     (1, "snv", 4096, 3), (2, "snv", 8192, 3), (3, "snv", 4096, 2), (4, "snv", 4096, 1),
     (5, "mix", 4096, 2), (6, "mix", 16384, 2), (7, "mix", 8192, 1), (8, "mix", 4096, 3), (9, "mix", 28672, 1),
     (10, "long", 4096, 1), (11, "long", 4096, 2), (12, "long", 8192, 3), (13, "long", 32768, 2),
-    (14, "long", 4096, 4), (15, "long", 8192, 4)])       # (wave images: <= 64 descriptors per window)
+    (14, "long", 4096, 4), (15, "long", 8192, 4),        # (wave images: <= 64 descriptors per window)
+    (16, "long", 4096, 5), (17, "long", 8192, 5), (18, "long", 10240, 5), (19, "mix", 2048, 5), (20, "mix", 4096, 5),
+    (22, "long", 6144, 5), (23, "mix", 3072, 5)])        # (wave windows that may split once: <= 127 descriptors per window)
 def test_random_streams_equal_the_oracle(built, gpu_ctx, coracle, seed, shape, window, kernel):
     rng = np.random.default_rng(seed)
     proteome, stream, want = random_stream(rng, n_haps=40, n_ref_tx=25, shape=shape, window=window)
