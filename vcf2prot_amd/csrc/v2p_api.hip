@@ -152,6 +152,10 @@ void ctx_unlock(v2p_ctx* c) { c->mu.unlock(); }
 
 struct GirQueue;
 static void queue_destroy(v2p_ctx* c);
+namespace {
+uint32_t narrow_chars(const uint32_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n);   // (AVX2 when the CPU has it: defined with the coalescing queue)
+void widen_chars(const uint8_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n);
+}
 
 extern "C" {
 
@@ -335,9 +339,7 @@ int v2p_execute_gir(v2p_ctx* c,
         HIP_TRY(c, c->h_in.ensure(((n_ref + 15) & ~uint64_t(15)) + n_alt + 64), "hipHostMalloc(in)");
         uint8_t* const h8 = c->h_in.p;
         uint8_t* const a8 = h8 + ((n_ref + 15) & ~uint64_t(15));
-        uint32_t seen = 0;
-        for (uint64_t i = 0; i < n_ref; ++i) { seen |= ref[i]; h8[i] = uint8_t(ref[i]); }
-        for (uint64_t i = 0; i < n_alt; ++i) { seen |= alt[i]; a8[i] = uint8_t(alt[i]); }
+        const uint32_t seen = narrow_chars(ref, h8, n_ref) | narrow_chars(alt, a8, n_alt);
         if (seen > 0xFFu) E = sizeof(uint32_t);
     }
     HIP_TRY(c, c->d_ref.ensure(n_ref * E), "hipMalloc(ref)");
@@ -400,7 +402,7 @@ int v2p_execute_gir(v2p_ctx* c,
             const uint64_t b = start_pos_res[i];
             uint64_t e = b + length[i];
             for (++i; i < n_tasks && start_pos_res[i] == e; ++i) e += length[i];
-            for (uint64_t k = b; k < e; ++k) res[k] = st[k];
+            widen_chars(st + b, res + b, e - b);
         }
     } else {
         const uint32_t* st = reinterpret_cast<const uint32_t*>(c->h_stage.p);
