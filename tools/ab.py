@@ -150,7 +150,7 @@ def main():
         d_desc = torch.zeros(desc_arr.size + 16, dtype=torch.int64, device=dev)       # (64 readable bytes either side of the descriptors)
         d_desc[8:8 + desc_arr.size] = torch.from_numpy(desc_arr.view(np.int64)).to(dev)
         v = dict(spec=spec, d_desc=d_desc, n_desc=int(desc_arr.size), d_chunks=torch.from_numpy(chunks.view(np.int64)).to(dev),
-                 d_pay=d_pay, n_pay=img.payload.size, phase=kv.get("phase"), gap=int(kv.get("gap", 0)), sync=int(kv.get("sync", 0)), onelaunch=int(kv.get("onelaunch", 0)), n_chunks=chunks.shape[0], out=img.out_bytes,
+                 d_pay=d_pay, n_pay=img.payload.size, phase=kv.get("phase"), gap=int(kv.get("gap", 0)), sync=int(kv.get("sync", 0)), onelaunch=int(kv.get("onelaunch", 0)), sc1=int(kv.get("sc1", 0)), n_chunks=chunks.shape[0], out=img.out_bytes,
                  flags=int(kv.get("nt", 1)) | v_bits | (int(kv.get("var", 0)) << 12) | (int(kv.get("dbg", 0)) << 16) | (int(kv.get("wgs", 0)) << 24) | (int(kv.get("wpg", 0)) << 28), ms=[])
         vs.append(v)
         max_out = max(max_out, img.out_bytes)
@@ -161,7 +161,7 @@ def main():
             os.environ.pop("V2P_PHASE_BYTES", None)
         else:
             os.environ["V2P_PHASE_BYTES"] = str(int(float(v["phase"]) * (1 << 20)))      # phase=<MB of image per phase>, 0 = one launch, no touch
-        for key, env in (("gap", "V2P_PHASE_GAP_US"), ("sync", "V2P_PHASE_SYNC"), ("onelaunch", "V2P_PHASE_ONE_LAUNCH")):
+        for key, env in (("gap", "V2P_PHASE_GAP_US"), ("sync", "V2P_PHASE_SYNC"), ("onelaunch", "V2P_PHASE_ONE_LAUNCH"), ("sc1", "V2P_WAVE_SC1")):
             if v[key]:
                 os.environ[env] = str(v[key])
             else:

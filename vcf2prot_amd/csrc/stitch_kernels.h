@@ -32,6 +32,7 @@ struct StitchArgs {
     const uint8_t*  dots;      // set by launch_stitch(): DOTS_BYTES of '.'
     const Chunk*    next_chunks = nullptr;   // set by launch_stitch(): the chunk records of the NEXT phase, whose image the trailing
     uint32_t        n_next = 0;              // workgroups of a wave launch read ahead (stitch_wave.hip); 0: none
+    uint32_t        store_sc1 = 0;           // set by launch_stitch(): the wave kernel's row stores "sc1 nt" instead of "nt" (thin descriptor streams)
     uint32_t        phase_chunks = 0;        // set by launch_stitch(): != 0 -- ONE wave launch for all phases of that many chunks, the read-ahead
                                              // workgroups of phase g + 1 placed in the grid before the stitch workgroups of phase g
 };

@@ -1213,6 +1213,9 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     // 12.0 with 64; a 2 000-sample slice 1.82 / 1.73 / 1.74 with 16 / 24 / 32; C4 whole 6.9 / 6.9 / 8.1 with 16 / 32 / 64; C2, 1/45: 3.31 / 3.24 / 3.21 the other way)
     uint64_t phase_bytes = 8.0 * double(a.n_desc) > 0.04 * double(a.out_len) ? PHASE_BYTES_RICH : PHASE_BYTES_DEFAULT;
     if (const char* e = getenv("V2P_PHASE_BYTES")) phase_bytes = strtoull(e, nullptr, 10);      // 0: one phase, no touch (A/B runs)
+    // (V2P_WAVE_SC1=1 / 0 forces / forbids "sc1 nt" row stores, A/B; by default images with a thin descriptor stream get them)
+    if (const char* e = getenv("V2P_WAVE_SC1")) a.store_sc1 = atoi(e) != 0;
+    else a.store_sc1 = !(8.0 * double(a.n_desc) > 0.04 * double(a.out_len));       // C2 3.14 -> 3.06 ms (-2.6 %), C4 +0.9 %, C3 +6 %
     // (the kernels of per-block and dense images are bound by their instruction stream, not by memory: phases only cost them --
     // C3 per-block 2.00 -> 2.19 ms, C5 dense 0.53 -> 0.71; wave and long-run images gain: C2 3.26 -> 2.65 ms)
     const bool streams = (nontemporal & 4) != 0 || (nontemporal & 16) == 0;       // the image holds wave or long-run chunks
