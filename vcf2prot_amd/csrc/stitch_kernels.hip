@@ -1208,14 +1208,15 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     hipError_t err = hipSuccess;
     a.dots = device_dots(&err);
     if (!a.dots) return err;
-    // 64 MB of image per phase; 20 MB where the image is more than 1/25 of the result it describes: 2.5 MB per XCD, which its L2
+    // 64 MB of image per phase; 20 MB where the image is more than 1/33 of the result it describes: 2.5 MB per XCD, which its L2
     // holds next to the proteome slice it works on (C3 whole, 1/10: 8.85 ms with 20 MB, 8.87 with 16, 9.2 with 12, 9.3 with 24, 10.3 with 32,
     // 12.0 with 64; a 2 000-sample slice 1.82 / 1.73 / 1.74 with 16 / 24 / 32; C4 whole 6.9 / 6.9 / 8.1 with 16 / 32 / 64; C2, 1/45: 3.31 / 3.24 / 3.21 the other way)
-    uint64_t phase_bytes = 8.0 * double(a.n_desc) > 0.04 * double(a.out_len) ? PHASE_BYTES_RICH : PHASE_BYTES_DEFAULT;
+    const bool rich = 8.0 * double(a.n_desc) > 0.03 * double(a.out_len);        // C2: 2.2 %, C4: 3.7 %, C3: 5 %
+    uint64_t phase_bytes = rich ? PHASE_BYTES_RICH : PHASE_BYTES_DEFAULT;
     if (const char* e = getenv("V2P_PHASE_BYTES")) phase_bytes = strtoull(e, nullptr, 10);      // 0: one phase, no touch (A/B runs)
     // (V2P_WAVE_SC1=1 / 0 forces / forbids "sc1 nt" row stores, A/B; by default images with a thin descriptor stream get them)
     if (const char* e = getenv("V2P_WAVE_SC1")) a.store_sc1 = atoi(e) != 0;
-    else a.store_sc1 = !(8.0 * double(a.n_desc) > 0.04 * double(a.out_len));       // C2 3.14 -> 3.06 ms (-2.6 %), C4 +0.9 %, C3 +6 %
+    else a.store_sc1 = !rich;       // C2 3.14 -> 3.06 ms (-2.6 %), C4 +0.9 %, C3 +6 %
     // (the kernels of per-block and dense images are bound by their instruction stream, not by memory: phases only cost them --
     // C3 per-block 2.00 -> 2.19 ms, C5 dense 0.53 -> 0.71; wave and long-run images gain: C2 3.26 -> 2.65 ms)
     const bool streams = (nontemporal & 4) != 0 || (nontemporal & 16) == 0;       // the image holds wave or long-run chunks
