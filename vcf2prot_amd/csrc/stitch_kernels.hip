@@ -1194,12 +1194,15 @@ __global__ __launch_bounds__(256) void touch_image_kernel(const uint64_t* __rest
 
 static hipError_t launch_stitch_range(const StitchArgs& args, hipStream_t stream, int nontemporal, uint32_t max_blocks);
 
-// (experiments: V2P_PHASE_GAP_US -- one wave idling that long between two phases; V2P_PHASE_SYNC -- the host waits for every phase)
+// (experiments, libv2p_bench.so only: V2P_PHASE_GAP_US -- one wave idling that long between two phases; V2P_PHASE_SYNC -- the host waits
+// for every phase.  Neither changed the step time.)
+#ifdef V2P_BENCH_VARIANTS
 __global__ void idle_kernel(uint32_t us)
 {
     const uint64_t t0 = __builtin_readcyclecounter();       // (s_memtime: 100 MHz)
     while (__builtin_readcyclecounter() - t0 < uint64_t(us) * 100u) __builtin_amdgcn_s_sleep(64);
 }
+#endif
 
 hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemporal, uint32_t max_blocks)
 {
@@ -1255,8 +1258,10 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
         if (!no_touch && (!ride || c0 == 0)) hipLaunchKernelGGL(touch_image_kernel, dim3(8u * ((touch_waves_per_xcd(nc) + 3u) / 4u)), dim3(256), 0, stream, a.desc, a.chunks, nc, a.n_desc, a.src1, a.src1_len);
         err = launch_stitch_range(a, stream, nontemporal, 0);
         if (err != hipSuccess) return err;
+#ifdef V2P_BENCH_VARIANTS
         if (const char* e = getenv("V2P_PHASE_GAP_US")) hipLaunchKernelGGL(idle_kernel, dim3(1), dim3(64), 0, stream, uint32_t(atoi(e)));
         if (getenv("V2P_PHASE_SYNC")) (void)hipStreamSynchronize(stream);
+#endif
     }
     return hipGetLastError();
 }

@@ -398,7 +398,9 @@ hipError_t launch_stitch_wave(const StitchArgs& a, hipStream_t stream, bool nt, 
     // (one launch.  Sub-launches of 8 Ki ... 128 Ki chunks -- the waves of a fresh launch read their descriptors together and store
     // together, which a bare copy kernel rewards: tools/wave_copy_bench.py -- cost this kernel 1 ... 17 %: V2P_WAVE_SUB, experiments only)
     uint32_t sub = 0;
+#ifdef V2P_BENCH_VARIANTS
     if (const char* e = getenv("V2P_WAVE_SUB")) sub = uint32_t(strtoul(e, nullptr, 10));
+#endif
     if (sub == 0 || sub > a.n_chunks) sub = a.n_chunks;
     sub = (sub + 7u) & ~7u;                                          // (keeps workgroup b on the XCD the chunk order dealt chunk b to)
     for (uint32_t c0 = 0; c0 < a.n_chunks; c0 += sub) {
