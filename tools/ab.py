@@ -133,8 +133,26 @@ def main():
             chunks = np.ascontiguousarray(chunks[np.argsort(key // w, kind="stable")])
         elif int(kv.get("l1", 0)):
             chunks = l1_order(chunks, img.desc, n_prot, int(kv["l1"]))
+        elif int(kv.get("blocks", 0)) > 1:        # experiment: the XCD / window order inside blocks of haplotypes (equal result bytes), block after block
+            nb = int(kv["blocks"])
+            dstv = (chunks[:, 1] & np.uint64((1 << 48) - 1)).astype(np.int64)
+            blk = np.minimum(dstv * nb // max(int(img.out_bytes), 1), nb - 1)
+            parts = []
+            for k in range(nb):
+                sub_c = np.ascontiguousarray(chunks[blk == k])
+                if sub_c.shape[0]:
+                    lib.v2p_order_chunks_for_xcds(sub_c.ctypes.data, sub_c.shape[0], img.desc.ctypes.data, img.desc.size, n_prot)
+                    pad = (-sub_c.shape[0]) % 8              # (keep every block's first entry on XCD 0: empty chunks)
+                    if pad:
+                        sub_c = np.concatenate([sub_c, np.zeros((pad, 2), dtype=np.uint64) + np.array([0, 1 << 60], dtype=np.uint64)])
+                    parts.append(sub_c)
+            chunks = np.ascontiguousarray(np.concatenate(parts))
         elif int(kv.get("xcd", 1)):
             os.environ["V2P_ORDER_WINDOWS"] = str(int(kv.get("sub", 1)))
+            if "maxblocks" in kv:
+                os.environ["V2P_ORDER_MAX_BLOCKS"] = str(int(kv["maxblocks"]))
+            else:
+                os.environ.pop("V2P_ORDER_MAX_BLOCKS", None)
             lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, n_prot)
         desc_arr = img.desc
         if int(kv.get("relayout", 0)):            # experiment: the descriptors physically in launch order (chunk after chunk)

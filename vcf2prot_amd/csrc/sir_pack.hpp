@@ -49,6 +49,7 @@
 #else
 #define V2P_HOST_DEVICE
 #endif
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -560,8 +561,8 @@ V2P_HOST_DEVICE inline uint8_t xcd_sub_window(uint64_t key, uint32_t slice, uint
 // chunk whose reference reads fall into proteome slice x keeps 1/8 of the proteome hot in
 // each L2 (measured on C2: HBM fetch 7.2 GB -> 0.6 GB per pass).  Placement only changes
 // speed, never results: chunks are independent.
-inline void order_chunks_for_xcds(Chunk* chunks, uint64_t n_chunks, const uint64_t* desc, uint64_t n_desc,
-                                  uint64_t proteome_len, unsigned n_xcd = 8, bool window_major = true)
+inline void order_chunks_for_xcds_range(Chunk* chunks, uint64_t n_chunks, const uint64_t* desc, uint64_t n_desc,
+                                        uint64_t proteome_len, unsigned n_xcd = 8, bool window_major = true)
 {
     if (n_chunks < 2 * n_xcd || proteome_len == 0 || n_desc == 0) return;
     std::vector<uint32_t> bucket(n_chunks);
@@ -604,6 +605,48 @@ inline void order_chunks_for_xcds(Chunk* chunks, uint64_t n_chunks, const uint64
             if (r < count[x]) out[pos++] = chunks[idx[x][r]];
     for (uint64_t c = 0; c < n_chunks; ++c) chunks[c] = out[c];
     (void)start; (void)seen;
+}
+
+// The order above, applied inside BLOCKS of the arena: block after block (haplotypes [h0, h1) whose results fill about
+// `block_bytes`), and inside a block slice by slice, window by window.  One order over a whole cohort keeps the reference reads of
+// the workgroups in flight together but scatters their STORES over the whole arena (C3 whole, 36 GB: every chunk of a phase in
+// another 2 MB page); inside blocks of about eight times the proteome the reads still share their windows and the stores stay
+// within a few hundred MB: C3 whole 8.86 -> 7.6-7.8 ms, a 2 000-sample slice 1.74 -> 1.56, C4 whole 7.0 -> 6.3, C2 unchanged
+// (profiles/r03_ab_block_order.txt).  Blocks smaller than that lose the reuse of the reference (C4, 56 MB proteome: 8.5 ms with
+// 40 MB blocks).  Blocks are equal shares of the table's ENTRIES, on multiples of 8 (entry 8j + x of a block = the j-th chunk of
+// slice x, on XCD x).  max_blocks <= 1: one order for the whole table.
+inline uint64_t xcd_order_block_bytes(uint64_t proteome_len) { const uint64_t b = 8u * proteome_len; return b < (32ull << 20) ? (32ull << 20) : b; }
+constexpr uint32_t XCD_ORDER_MAX_BLOCKS_DEVICE = 64;        // the device builder orders block by block with a few launches each: at most this many
+// number of blocks for a table whose results span `span_bytes`, and the table entries [first, last) of block k: equal shares of
+// the ENTRIES (in arena order), on multiples of 8 -- the one rule both builders use
+inline uint32_t xcd_order_blocks(uint64_t span_bytes, uint64_t proteome_len, uint64_t n_entries, uint32_t max_blocks, uint64_t n_desc)
+{
+    // (an image whose descriptors are a thin stream -- C2: 2.2 % of its result -- gains nothing from blocks and loses 5-7 % with
+    // a few dozen of them: one order for the whole table, as in round 2)
+    if (8.0 * double(n_desc) <= 0.03 * double(span_bytes)) return 1;
+    const uint64_t bb = xcd_order_block_bytes(proteome_len);
+    uint64_t nb = (span_bytes + bb - 1) / bb;
+    if (nb > max_blocks) nb = max_blocks;
+    if (nb * 16u > n_entries) nb = n_entries / 16u;          // (a block is at least 16 entries)
+    return uint32_t(nb < 1 ? 1 : nb);
+}
+inline uint64_t xcd_order_block_first(uint64_t n_entries, uint32_t n_blocks, uint32_t k)
+{
+    return k >= n_blocks ? n_entries : ((n_entries * k / n_blocks) & ~uint64_t(7));
+}
+inline void order_chunks_for_xcds(Chunk* chunks, uint64_t n_chunks, const uint64_t* desc, uint64_t n_desc,
+                                  uint64_t proteome_len, unsigned n_xcd = 8, bool window_major = true, uint32_t max_blocks = 4096)
+{
+    if (max_blocks <= 1 || n_chunks < 2 * n_xcd || proteome_len == 0) { order_chunks_for_xcds_range(chunks, n_chunks, desc, n_desc, proteome_len, n_xcd, window_major); return; }
+    // the table in arena order first (the packers emit it so; a caller's table may not be)
+    bool sorted = true;
+    for (uint64_t c = 1; c < n_chunks && sorted; ++c) sorted = (chunks[c - 1].dst_n & DST_MASK) <= (chunks[c].dst_n & DST_MASK);
+    if (!sorted) std::stable_sort(chunks, chunks + n_chunks, [](const Chunk& a, const Chunk& b) { return (a.dst_n & DST_MASK) < (b.dst_n & DST_MASK); });
+    const uint32_t nb = xcd_order_blocks(chunks[n_chunks - 1].dst_n & DST_MASK, proteome_len, n_chunks, max_blocks, n_desc);
+    for (uint32_t k = 0; k < nb; ++k) {
+        const uint64_t c0 = xcd_order_block_first(n_chunks, nb, k), c1 = xcd_order_block_first(n_chunks, nb, k + 1);
+        order_chunks_for_xcds_range(chunks + c0, c1 - c0, desc, n_desc, proteome_len, n_xcd, window_major);
+    }
 }
 
 // Interleaves one haplotype's tasks with FASTA record literals.  Records tile the result tape

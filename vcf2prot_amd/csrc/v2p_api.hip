@@ -1188,12 +1188,25 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     }
     const bool reorder = !(c->flags & V2P_FLAG_RESULT_ORDER) && n_chunks >= 16 && c->proteome_len != 0 && n_desc != 0;
     if (reorder) {
+        // the XCD / window order inside blocks of the arena (sir_pack.hpp: order_chunks_for_xcds): the first n_windows entries are in
+        // arena order and are dealt block by block -- the same sort kernels on each block's range, at most 64 blocks; the second
+        // chunks of split windows (behind them, in no particular order) are one more range
         Chunk* by_window = reinterpret_cast<Chunk*>(scratch.ptr() + s_tmp2);
-        HIP_TRY(c, launch_sub_order(a.chunks_tmp, a.bucket, a.sub, n_chunks, reinterpret_cast<uint32_t*>(scratch.ptr() + s_subhist),
-                                    reinterpret_cast<uint64_t*>(scratch.ptr() + s_substart), reinterpret_cast<uint64_t*>(scratch.ptr() + s_subtiles),
-                                    by_window, scratch.ptr() + s_bucket2, c->stream), "launch(window order)");
-        HIP_TRY(c, launch_xcd_order(by_window, scratch.ptr() + s_bucket2, n_chunks, reinterpret_cast<uint32_t*>(scratch.ptr() + s_hist),
-                                    reinterpret_cast<Chunk*>(b->d_chunks.ptr()), c->stream), "launch(xcd order)");
+        const uint32_t nb = xcd_order_blocks(n_windows ? (n_windows - 1) * uint64_t(window_bytes) : 0, c->proteome_len, n_windows, XCD_ORDER_MAX_BLOCKS_DEVICE, n_desc);   // (span = the last window's offset: what the host rule sees)
+        for (uint32_t k = 0; k <= nb; ++k) {
+            const uint64_t k0 = k < nb ? xcd_order_block_first(n_windows, nb, k) : n_windows;
+            const uint64_t k1 = k < nb ? xcd_order_block_first(n_windows, nb, k + 1) : n_chunks;
+            if (k1 <= k0) continue;
+            if (k1 - k0 < 16) {                               // (too few to deal: as they are)
+                HIP_TRY(c, hipMemcpyAsync(b->d_chunks.ptr() + k0 * sizeof(Chunk), a.chunks_tmp + k0, (k1 - k0) * sizeof(Chunk), hipMemcpyDeviceToDevice, c->stream), "D2D(chunks)");
+                continue;
+            }
+            HIP_TRY(c, launch_sub_order(a.chunks_tmp + k0, a.bucket + k0, a.sub + k0, k1 - k0, reinterpret_cast<uint32_t*>(scratch.ptr() + s_subhist),
+                                        reinterpret_cast<uint64_t*>(scratch.ptr() + s_substart), reinterpret_cast<uint64_t*>(scratch.ptr() + s_subtiles),
+                                        by_window, scratch.ptr() + s_bucket2, c->stream), "launch(window order)");
+            HIP_TRY(c, launch_xcd_order(by_window, scratch.ptr() + s_bucket2, k1 - k0, reinterpret_cast<uint32_t*>(scratch.ptr() + s_hist),
+                                        reinterpret_cast<Chunk*>(b->d_chunks.ptr()) + k0, c->stream), "launch(xcd order)");
+        }
     }
     else if (n_chunks) HIP_TRY(c, hipMemcpyAsync(b->d_chunks.ptr(), a.chunks_tmp, n_chunks * sizeof(Chunk), hipMemcpyDeviceToDevice, c->stream), "D2D(chunks)");
     HIP_TRY(c, hipEventRecord(e3, c->stream), "hipEventRecord");
@@ -1551,7 +1564,9 @@ int v2p_order_chunks_for_xcds(v2p_chunk* chunks, uint64_t n_chunks, const uint64
 {
     if ((n_chunks && !chunks) || (n_desc && !desc)) return V2P_ERR_INVALID_ARG;
     const char* e = getenv("V2P_ORDER_WINDOWS");                   // (experiments: 0 = haplotype-major inside a slice)
-    order_chunks_for_xcds(reinterpret_cast<Chunk*>(chunks), n_chunks, desc, n_desc, proteome_len, 8, !(e && e[0] == '0'));
+    const char* eb = getenv("V2P_ORDER_MAX_BLOCKS");               // (tests, experiments: 1 = one order for the whole table, 64 = what the device builder does)
+    order_chunks_for_xcds(reinterpret_cast<Chunk*>(chunks), n_chunks, desc, n_desc, proteome_len, 8, !(e && e[0] == '0'),
+                          eb ? uint32_t(strtoul(eb, nullptr, 10)) : 4096u);
     return V2P_OK;
 }
 
