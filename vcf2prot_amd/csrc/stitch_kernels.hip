@@ -1182,7 +1182,7 @@ static const uint8_t* device_dots(hipError_t* err)
 // non-temporal and do not displace them) -- and the stitch kernels then find them there.  The copy benchmark: 3.47 -> 6.04 TB/s with
 // 64 MB phases, the touch kernels' time included.
 constexpr uint64_t PHASE_BYTES_DEFAULT = 64ull << 20;
-constexpr uint64_t PHASE_BYTES_RICH = 20ull << 20;       // descriptor-rich images (below)
+constexpr uint64_t PHASE_BYTES_RICH = 28ull << 20;       // descriptor-rich images (below)
 constexpr uint32_t PHASE_MIN_CHUNKS = 16384;            // below this a launch is one phase and is not preceded by a touch
 
 __global__ __launch_bounds__(256) void touch_image_kernel(const uint64_t* __restrict__ desc, const Chunk* __restrict__ chunks, uint32_t n_chunks, uint64_t n_desc,
@@ -1211,7 +1211,9 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     hipError_t err = hipSuccess;
     a.dots = device_dots(&err);
     if (!a.dots) return err;
-    // 64 MB of image per phase; 20 MB where the image is more than 1/33 of the result it describes: 2.5 MB per XCD, which its L2
+    // 64 MB of image per phase; 28 MB where the image is more than 1/33 of the result it describes (with the chunk table dealt inside blocks
+    // of the arena -- sir_pack.hpp -- C3 whole: 7.44 / 7.42 / 7.57 / 7.63 ms with 24 / 28 / 32 / 36 MB, 8.2 with 12, 8.1 with 48; before the
+    // blocks the best was 20 MB:) 2.5 MB per XCD, which its L2
     // holds next to the proteome slice it works on (C3 whole, 1/10: 8.85 ms with 20 MB, 8.87 with 16, 9.2 with 12, 9.3 with 24, 10.3 with 32,
     // 12.0 with 64; a 2 000-sample slice 1.82 / 1.73 / 1.74 with 16 / 24 / 32; C4 whole 6.9 / 6.9 / 8.1 with 16 / 32 / 64; C2, 1/45: 3.31 / 3.24 / 3.21 the other way)
     const bool rich = 8.0 * double(a.n_desc) > 0.03 * double(a.out_len);        // C2: 2.2 %, C4: 3.7 %, C3: 5 %
