@@ -18,9 +18,8 @@ def oracle_hap(c, coracle, h):
     ("C3", 100, 40, 16384, 2), ("C3", 100, 40, 16384, 1), ("C4", 7, 3, 32768, 2), ("C5", 50, 300, 4096, 2),
     ("C5", 50, 300, 4096, 3), ("C5", 11, 100, 8192, 3), ("C5", 200, 150, 12288, 3), ("C1", 0, 8, 4096, 3),     # 3: dense image (fused descriptors, stitch_dense_kernel)
     ("C2", 5, 3, 10240, 4), ("C2", 9, 2, 4096, 4), ("C3", 100, 40, 4096, 4), ("C4", 7, 3, 4096, 4)])     # 4: wave image (stitchw_kernel)
-def test_device_built_image_equals_host_grid_image(built, gpu_ctx, coracle, monkeypatch, preset, h0, n, window, kernel):
+def test_device_built_image_equals_host_grid_image(built, gpu_ctx, coracle, preset, h0, n, window, kernel):
     from vcf2prot_amd.cohort import Cohort
-    monkeypatch.setenv("V2P_ORDER_MAX_BLOCKS", "64")       # (the device builder deals at most 64 blocks; the host rule is otherwise the same)
     c = Cohort.preset(preset)
     gpu_ctx.upload_proteome(c.proteome())
     want = c.pack_grid(h0, h0 + n, window, kernel)

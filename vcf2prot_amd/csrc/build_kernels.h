@@ -56,5 +56,11 @@ hipError_t launch_xcd_order(const Chunk* in, const uint8_t* bucket, uint64_t n, 
 hipError_t launch_sub_order(const Chunk* in, const uint8_t* bucket, const uint8_t* sub, uint64_t n, uint32_t* hist, uint64_t* start, uint64_t* tiles,
                             Chunk* out, uint8_t* out_bucket, hipStream_t stream);
 uint64_t scan_tiles_for(uint64_t n);
+// both sorts over the first n entries of a table in arena order, inside nb blocks of it (sir_pack.hpp: xcd_order_blocks /
+// xcd_order_block_first), one launch each for all blocks; subhist / substart / tiles sized for XCD_SUB * order_blocks_thread_blocks(n, nb)
+// counters, hist8 for 8 * that many, tot for 8 * nb
+hipError_t launch_order_blocks(const Chunk* in, const uint8_t* bucket, const uint8_t* sub, uint64_t n, uint32_t nb, uint32_t* subhist, uint64_t* substart,
+                               uint64_t* tiles, Chunk* by_window, uint8_t* bucket2, uint32_t* hist8, uint32_t* tot, Chunk* out, hipStream_t stream);
+uint64_t order_blocks_thread_blocks(uint64_t n, uint32_t nb);
 
 }  // namespace v2p

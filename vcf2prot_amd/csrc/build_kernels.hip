@@ -616,6 +616,126 @@ __global__ __launch_bounds__(256) void xcd_scatter_kernel(const Chunk* __restric
     out[pos] = in[k];
 }
 
+// ---- the same two sorts for ALL blocks of the table in one launch each (sir_pack.hpp: the order is applied inside blocks of the
+// arena): grid = (thread blocks of the largest block, blocks); block y holds the entries [first(y), first(y + 1)) -- pure arithmetic,
+// xcd_order_block_first -- and, since the blocks follow each other in the table, ONE scan over [block][window][thread block]
+// counters gives every entry its final place in the window order, and the slice deal only adds the block's first entry.
+__global__ __launch_bounds__(256) void sub_hist_seg_kernel(const uint8_t* __restrict__ sub, uint64_t n, uint32_t nb, uint32_t tbmax, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t s[XCD_SUB];
+    s[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t y = blockIdx.y, x = blockIdx.x;
+    const uint64_t k0 = xcd_order_block_first(n, nb, y), k1 = xcd_order_block_first(n, nb, y + 1u);
+    const uint64_t k = k0 + uint64_t(x) * 256u + threadIdx.x;
+    if (k < k1) atomicAdd(&s[sub[k]], 1u);
+    __syncthreads();
+    hist[(uint64_t(y) * XCD_SUB + threadIdx.x) * tbmax + x] = s[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void sub_scatter_seg_kernel(const Chunk* __restrict__ in, const uint8_t* __restrict__ bucket, const uint8_t* __restrict__ sub,
+                                                              uint64_t n, uint32_t nb, uint32_t tbmax, const uint64_t* __restrict__ start,
+                                                              Chunk* __restrict__ out, uint8_t* __restrict__ out_bucket)
+{
+    __shared__ uint8_t s_sub[256];
+    const uint32_t y = blockIdx.y, x = blockIdx.x;
+    const uint64_t k0 = xcd_order_block_first(n, nb, y), k1 = xcd_order_block_first(n, nb, y + 1u);
+    const uint64_t k = k0 + uint64_t(x) * 256u + threadIdx.x;
+    const bool live = k < k1;
+    const uint8_t mine = live ? sub[k] : 0;
+    s_sub[threadIdx.x] = mine;
+    __syncthreads();
+    if (!live) return;
+    uint32_t rank = 0;
+    for (uint32_t t = 0; t < threadIdx.x; ++t) rank += s_sub[t] == mine ? 1u : 0u;
+    const uint64_t pos = start[(uint64_t(y) * XCD_SUB + mine) * tbmax + x] + rank;
+    out[pos] = in[k];
+    out_bucket[pos] = bucket[k];
+}
+
+__global__ __launch_bounds__(256) void xcd_hist_seg_kernel(const uint8_t* __restrict__ bucket, uint64_t n, uint32_t nb, uint32_t tbmax, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t s[8];
+    if (threadIdx.x < 8) s[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t y = blockIdx.y, x = blockIdx.x;
+    const uint64_t k0 = xcd_order_block_first(n, nb, y), k1 = xcd_order_block_first(n, nb, y + 1u);
+    const uint64_t k = k0 + uint64_t(x) * 256u + threadIdx.x;
+    if (k < k1) atomicAdd(&s[bucket[k]], 1u);
+    __syncthreads();
+    if (threadIdx.x < 8) hist[(uint64_t(y) * tbmax + x) * 8u + threadIdx.x] = s[threadIdx.x];
+}
+
+// per block: exclusive prefix of each slice's counts over the block's thread blocks, totals in tot[y * 8 + slice]
+__global__ __launch_bounds__(512) void xcd_scan_seg_kernel(uint32_t* __restrict__ hist, uint32_t tbmax, uint32_t* __restrict__ tot)
+{
+    const uint32_t y = blockIdx.x, x = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t* h = hist + uint64_t(y) * tbmax * 8u;
+    uint32_t run = 0;
+    for (uint32_t b0 = 0; b0 < tbmax; b0 += 64u) {
+        const uint32_t b = b0 + lane;
+        const uint32_t c = b < tbmax ? h[b * 8u + x] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+        if (b < tbmax) h[b * 8u + x] = run + incl - c;
+        run += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) tot[y * 8u + x] = run;
+}
+
+__global__ __launch_bounds__(256) void xcd_scatter_seg_kernel(const Chunk* __restrict__ in, const uint8_t* __restrict__ bucket, uint64_t n, uint32_t nb, uint32_t tbmax,
+                                                              const uint32_t* __restrict__ hist, const uint32_t* __restrict__ tot, Chunk* __restrict__ out)
+{
+    __shared__ uint32_t s_wave[4][8];
+    const uint32_t y = blockIdx.y, xb = blockIdx.x;
+    const uint64_t k0 = xcd_order_block_first(n, nb, y), k1 = xcd_order_block_first(n, nb, y + 1u);
+    const uint64_t k = k0 + uint64_t(xb) * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const bool live = k < k1;
+    const uint32_t x = live ? bucket[k] : 8u;
+    uint32_t in_wave = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 8; ++q) {
+        const unsigned long long m = __ballot(x == q);
+        if (x == q) in_wave = uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+        if (lane == 0) s_wave[wid][q] = uint32_t(__popcll(m));
+    }
+    __syncthreads();
+    if (!live) return;
+    uint32_t r = hist[(uint64_t(y) * tbmax + xb) * 8u + x] + in_wave;
+    for (uint32_t w = 0; w < wid; ++w) r += s_wave[w][x];
+    uint64_t pos = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 8; ++q) {
+        const uint32_t c = tot[y * 8u + q];
+        pos += c < r ? c : r;
+        if (q < x && c > r) ++pos;
+    }
+    out[k0 + pos] = in[k];
+}
+
+// both sorts over the first n entries of the table, block by block (nb blocks): scratch as launch_sub_order / launch_xcd_order,
+// sized for (n / 256 + nb) thread blocks; tot = 8 * nb u32
+hipError_t launch_order_blocks(const Chunk* in, const uint8_t* bucket, const uint8_t* sub, uint64_t n, uint32_t nb, uint32_t* subhist, uint64_t* substart,
+                               uint64_t* tiles, Chunk* by_window, uint8_t* bucket2, uint32_t* hist8, uint32_t* tot, Chunk* out, hipStream_t stream)
+{
+    if (n == 0 || nb == 0) return hipSuccess;
+    uint64_t biggest = 0;
+    for (uint32_t y = 0; y < nb; ++y) { const uint64_t e = xcd_order_block_first(n, nb, y + 1u) - xcd_order_block_first(n, nb, y); if (e > biggest) biggest = e; }
+    const uint32_t tbmax = uint32_t((biggest + 255) / 256);
+    const dim3 grid(tbmax, nb);
+    hipLaunchKernelGGL(sub_hist_seg_kernel, grid, dim3(256), 0, stream, sub, n, nb, tbmax, subhist);
+    hipError_t e = launch_scan_u32(subhist, uint64_t(nb) * XCD_SUB * tbmax, substart, tiles, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sub_scatter_seg_kernel, grid, dim3(256), 0, stream, in, bucket, sub, n, nb, tbmax, substart, by_window, bucket2);
+    hipLaunchKernelGGL(xcd_hist_seg_kernel, grid, dim3(256), 0, stream, bucket2, n, nb, tbmax, hist8);
+    hipLaunchKernelGGL(xcd_scan_seg_kernel, dim3(nb), dim3(512), 0, stream, hist8, tbmax, tot);
+    hipLaunchKernelGGL(xcd_scatter_seg_kernel, grid, dim3(256), 0, stream, by_window, bucket2, n, nb, tbmax, hist8, tot, out);
+    return hipGetLastError();
+}
+uint64_t order_blocks_thread_blocks(uint64_t n, uint32_t nb) { return (n + 255) / 256 + 2ull * nb + 2; }   // >= nb * tbmax for any equal-share split
+
 hipError_t launch_build(const BuildArgs& a, uint64_t n_windows, uint64_t n_desc, uint64_t out_bytes, int phase, hipStream_t stream)
 {
     const uint32_t tx_blocks = uint32_t((a.n_tx + 255) / 256);

@@ -616,7 +616,7 @@ inline void order_chunks_for_xcds_range(Chunk* chunks, uint64_t n_chunks, const 
 // 40 MB blocks).  Blocks are equal shares of the table's ENTRIES, on multiples of 8 (entry 8j + x of a block = the j-th chunk of
 // slice x, on XCD x).  max_blocks <= 1: one order for the whole table.
 inline uint64_t xcd_order_block_bytes(uint64_t proteome_len) { const uint64_t b = 8u * proteome_len; return b < (32ull << 20) ? (32ull << 20) : b; }
-constexpr uint32_t XCD_ORDER_MAX_BLOCKS_DEVICE = 64;        // the device builder orders block by block with a few launches each: at most this many
+constexpr uint32_t XCD_ORDER_MAX_BLOCKS = 4096;             // blocks of one table (both builders)
 // number of blocks for a table whose results span `span_bytes`, and the table entries [first, last) of block k: equal shares of
 // the ENTRIES (in arena order), on multiples of 8 -- the one rule both builders use
 inline uint32_t xcd_order_blocks(uint64_t span_bytes, uint64_t proteome_len, uint64_t n_entries, uint32_t max_blocks, uint64_t n_desc)
@@ -627,15 +627,15 @@ inline uint32_t xcd_order_blocks(uint64_t span_bytes, uint64_t proteome_len, uin
     const uint64_t bb = xcd_order_block_bytes(proteome_len);
     uint64_t nb = (span_bytes + bb - 1) / bb;
     if (nb > max_blocks) nb = max_blocks;
-    if (nb * 16u > n_entries) nb = n_entries / 16u;          // (a block is at least 16 entries)
+    if (nb * 64u > n_entries) nb = n_entries / 64u;          // (a block is at least 56 entries: 8 per XCD to deal)
     return uint32_t(nb < 1 ? 1 : nb);
 }
-inline uint64_t xcd_order_block_first(uint64_t n_entries, uint32_t n_blocks, uint32_t k)
+V2P_HOST_DEVICE inline uint64_t xcd_order_block_first(uint64_t n_entries, uint32_t n_blocks, uint32_t k)
 {
     return k >= n_blocks ? n_entries : ((n_entries * k / n_blocks) & ~uint64_t(7));
 }
 inline void order_chunks_for_xcds(Chunk* chunks, uint64_t n_chunks, const uint64_t* desc, uint64_t n_desc,
-                                  uint64_t proteome_len, unsigned n_xcd = 8, bool window_major = true, uint32_t max_blocks = 4096)
+                                  uint64_t proteome_len, unsigned n_xcd = 8, bool window_major = true, uint32_t max_blocks = XCD_ORDER_MAX_BLOCKS)
 {
     if (max_blocks <= 1 || n_chunks < 2 * n_xcd || proteome_len == 0) { order_chunks_for_xcds_range(chunks, n_chunks, desc, n_desc, proteome_len, n_xcd, window_major); return; }
     // the table in arena order first (the packers emit it so; a caller's table may not be)

@@ -1159,12 +1159,12 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     DevBuf& scratch = guard.scratch;                      // chunk_first, chunks in result order, slices, per-block histograms
     const uint64_t cap = split ? 2 * n_windows : n_windows;   // chunk slots: a window that splits adds one behind the n_windows first ones
     if (cap > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch");
-    const uint64_t n_blocks_cap = (cap + 255) / 256;
+    const uint64_t n_blocks_cap = order_blocks_thread_blocks(cap, XCD_ORDER_MAX_BLOCKS);   // thread blocks of the two sorts, all blocks of the table together
     const uint64_t n_sub_cap = uint64_t(XCD_SUB) * n_blocks_cap;      // counters of the window sort
     const uint64_t s_first = 0, s_tmp = up8(n_windows * 8), s_bucket = s_tmp + up8(cap * 16), s_hist = s_bucket + up8(cap),
                    s_sub = s_hist + up8((n_blocks_cap + 1) * 8 * 4), s_tmp2 = s_sub + up8(cap), s_bucket2 = s_tmp2 + up8(cap * 16),
                    s_subhist = s_bucket2 + up8(cap), s_substart = s_subhist + up8(n_sub_cap * 4), s_subtiles = s_substart + up8((n_sub_cap + 1) * 8),
-                   s_end = s_subtiles + up8(scan_tiles_for(n_sub_cap) * 8);
+                   s_tot = s_subtiles + up8(scan_tiles_for(n_sub_cap) * 8), s_end = s_tot + up8(uint64_t(XCD_ORDER_MAX_BLOCKS) * 8 * 4);
     HIP_TRY(c, scratch.ensure(s_end), "hipMalloc(build scratch)");
     HIP_TRY(c, b->d_desc.ensure(n_desc * 8), "hipMalloc(desc)");
     HIP_TRY(c, b->d_chunks.ensure(cap * sizeof(Chunk)), "hipMalloc(chunks)");
@@ -1189,23 +1189,24 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     const bool reorder = !(c->flags & V2P_FLAG_RESULT_ORDER) && n_chunks >= 16 && c->proteome_len != 0 && n_desc != 0;
     if (reorder) {
         // the XCD / window order inside blocks of the arena (sir_pack.hpp: order_chunks_for_xcds): the first n_windows entries are in
-        // arena order and are dealt block by block -- the same sort kernels on each block's range, at most 64 blocks; the second
+        // arena order and are dealt inside their blocks, all blocks in one launch per sort step (launch_order_blocks); the second
         // chunks of split windows (behind them, in no particular order) are one more range
         Chunk* by_window = reinterpret_cast<Chunk*>(scratch.ptr() + s_tmp2);
-        const uint32_t nb = xcd_order_blocks(n_windows ? (n_windows - 1) * uint64_t(window_bytes) : 0, c->proteome_len, n_windows, XCD_ORDER_MAX_BLOCKS_DEVICE, n_desc);   // (span = the last window's offset: what the host rule sees)
-        for (uint32_t k = 0; k <= nb; ++k) {
-            const uint64_t k0 = k < nb ? xcd_order_block_first(n_windows, nb, k) : n_windows;
-            const uint64_t k1 = k < nb ? xcd_order_block_first(n_windows, nb, k + 1) : n_chunks;
-            if (k1 <= k0) continue;
-            if (k1 - k0 < 16) {                               // (too few to deal: as they are)
-                HIP_TRY(c, hipMemcpyAsync(b->d_chunks.ptr() + k0 * sizeof(Chunk), a.chunks_tmp + k0, (k1 - k0) * sizeof(Chunk), hipMemcpyDeviceToDevice, c->stream), "D2D(chunks)");
-                continue;
+        const uint32_t nb = xcd_order_blocks(n_windows ? (n_windows - 1) * uint64_t(window_bytes) : 0, c->proteome_len, n_windows, XCD_ORDER_MAX_BLOCKS, n_desc);   // (span = the last window's offset: what the host rule sees)
+        HIP_TRY(c, launch_order_blocks(a.chunks_tmp, a.bucket, a.sub, n_windows, nb, reinterpret_cast<uint32_t*>(scratch.ptr() + s_subhist),
+                                       reinterpret_cast<uint64_t*>(scratch.ptr() + s_substart), reinterpret_cast<uint64_t*>(scratch.ptr() + s_subtiles),
+                                       by_window, scratch.ptr() + s_bucket2, reinterpret_cast<uint32_t*>(scratch.ptr() + s_hist),
+                                       reinterpret_cast<uint32_t*>(scratch.ptr() + s_tot), reinterpret_cast<Chunk*>(b->d_chunks.ptr()), c->stream), "launch(order)");
+        if (n_chunks > n_windows) {                           // the second chunks of split windows: one more range, dealt by itself
+            const uint64_t k0 = n_windows, nt = n_chunks - n_windows;
+            if (nt < 16) HIP_TRY(c, hipMemcpyAsync(b->d_chunks.ptr() + k0 * sizeof(Chunk), a.chunks_tmp + k0, nt * sizeof(Chunk), hipMemcpyDeviceToDevice, c->stream), "D2D(chunks)");
+            else {
+                HIP_TRY(c, launch_sub_order(a.chunks_tmp + k0, a.bucket + k0, a.sub + k0, nt, reinterpret_cast<uint32_t*>(scratch.ptr() + s_subhist),
+                                            reinterpret_cast<uint64_t*>(scratch.ptr() + s_substart), reinterpret_cast<uint64_t*>(scratch.ptr() + s_subtiles),
+                                            by_window, scratch.ptr() + s_bucket2, c->stream), "launch(window order)");
+                HIP_TRY(c, launch_xcd_order(by_window, scratch.ptr() + s_bucket2, nt, reinterpret_cast<uint32_t*>(scratch.ptr() + s_hist),
+                                            reinterpret_cast<Chunk*>(b->d_chunks.ptr()) + k0, c->stream), "launch(xcd order)");
             }
-            HIP_TRY(c, launch_sub_order(a.chunks_tmp + k0, a.bucket + k0, a.sub + k0, k1 - k0, reinterpret_cast<uint32_t*>(scratch.ptr() + s_subhist),
-                                        reinterpret_cast<uint64_t*>(scratch.ptr() + s_substart), reinterpret_cast<uint64_t*>(scratch.ptr() + s_subtiles),
-                                        by_window, scratch.ptr() + s_bucket2, c->stream), "launch(window order)");
-            HIP_TRY(c, launch_xcd_order(by_window, scratch.ptr() + s_bucket2, k1 - k0, reinterpret_cast<uint32_t*>(scratch.ptr() + s_hist),
-                                        reinterpret_cast<Chunk*>(b->d_chunks.ptr()) + k0, c->stream), "launch(xcd order)");
         }
     }
     else if (n_chunks) HIP_TRY(c, hipMemcpyAsync(b->d_chunks.ptr(), a.chunks_tmp, n_chunks * sizeof(Chunk), hipMemcpyDeviceToDevice, c->stream), "D2D(chunks)");
