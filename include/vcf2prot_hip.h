@@ -305,8 +305,7 @@ int v2p_stitch_launch_bits(const v2p_chunk* chunks, uint64_t n_chunks);
  * of it after the other -- for an image whose descriptors are more than 3 % of its result, block after block of the arena (equal
  * shares of the table's entries in result order, about eight times the proteome each): the reference reads of the workgroups in
  * flight share their windows AND their stores stay within one block (C3 whole: 9.2 -> 7.9 ms).  The table is brought into result
- * order first if it is not.  v2p_batch_finalize() does this itself (v2p_batch_build_on_device the same on the device, at most 64
- * blocks); callers of v2p_stitch_launch() may want it too.  Speed only: chunks are independent. */
+ * order first if it is not.  v2p_batch_finalize() does this itself (v2p_batch_build_on_device the same on the device); callers of v2p_stitch_launch() may want it too.  Speed only: chunks are independent. */
 int v2p_order_chunks_for_xcds(v2p_chunk* chunks, uint64_t n_chunks, const uint64_t* desc, uint64_t n_desc,
                               uint64_t proteome_len);
 int v2p_digest_launch(void* hip_stream, const uint8_t* d_out, const uint64_t* d_hap_begin, uint64_t n_haps,
