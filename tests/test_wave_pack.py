@@ -79,3 +79,59 @@ def test_wave_grid_image_equals_oracle_and_refuses_overfull_windows(built, corac
         Cohort.preset("C5").pack_grid(0, 4, 8192, 4)               # ~1 000 descriptors per 8 KiB window
     with pytest.raises(RuntimeError):
         c.pack_grid(0, 2, 12288, 4)                                 # a wave chunk is at most ten rows
+
+
+def test_chunk_order_inside_blocks_of_the_arena(built):
+    """v2p_order_chunks_for_xcds (host logic, no GPU): for a descriptor-rich image the XCD / window order is applied inside blocks of
+    the arena -- equal shares of the table's entries in result order, about eight times the proteome each -- so the table stays a
+    permutation, every block holds exactly its own stretch of the arena, and inside a block entry 8j + x reads proteome slice x;
+    a thin image (C2) keeps one order for the whole table."""
+    from vcf2prot_amd import _native as N
+    from vcf2prot_amd.cohort import Cohort
+    lib = N.hip_lib()
+    c = Cohort.preset("C3")
+    n_prot = c.proteome().size
+    img = c.pack(0, 160, n_threads=4)                                   # ~290 MB of result: several 64 MB blocks
+    before = np.ascontiguousarray(img.chunks).copy()
+    after = before.copy()
+    assert lib.v2p_order_chunks_for_xcds(after.ctypes.data, after.shape[0], img.desc.ctypes.data, img.desc.size, n_prot) == 0
+    key = lambda t: t[:, 0].astype(np.uint64) * np.uint64(1 << 20) + (t[:, 1] & np.uint64((1 << 20) - 1))
+    assert np.array_equal(np.sort(key(before)), np.sort(key(after)))  # a permutation
+    dst_b = (before[:, 1] & np.uint64((1 << 48) - 1)).astype(np.int64)
+    dst_a = (after[:, 1] & np.uint64((1 << 48) - 1)).astype(np.int64)
+    assert (np.diff(dst_b) >= 0).all()                                  # the packer emits arena order
+    n = before.shape[0]
+    span = int(dst_b[-1])
+    nb = min((span + 8 * n_prot - 1) // (8 * n_prot), n // 64)
+    assert nb >= 3
+    first = [((n * k // nb) & ~7) if k < nb else n for k in range(nb + 1)]
+    for k in range(nb):
+        a, b = first[k], first[k + 1]
+        assert np.array_equal(np.sort(dst_a[a:b]), dst_b[a:b]), k       # block k = its own stretch of the arena, reordered inside
+        # entry 8j + x of the block: a chunk whose first reference read lies in proteome slice x (while all slices still have chunks)
+        tb = after[a:a + 64, 0].astype(np.int64)
+        d = img.desc[tb]
+        snv = (d >> np.uint64(61)) == np.uint64(7)
+        src = np.where(snv, d & np.uint64((1 << 29) - 1), d & np.uint64((1 << 40) - 1)).astype(np.int64)
+        is_ref = snv | ((d >> np.uint64(62)) == 0)
+        per = (n_prot + 7) // 8
+        ok = ~is_ref | (np.minimum(src // per, 7) == (np.arange(64) % 8))
+        assert ok.mean() > 0.9, (k, ok.mean())
+    one = before.copy()
+    os_env = __import__("os").environ
+    os_env["V2P_ORDER_MAX_BLOCKS"] = "1"
+    try:
+        assert lib.v2p_order_chunks_for_xcds(one.ctypes.data, one.shape[0], img.desc.ctypes.data, img.desc.size, n_prot) == 0
+    finally:
+        os_env.pop("V2P_ORDER_MAX_BLOCKS", None)
+    assert not np.array_equal(one, after)                               # one order over the whole table is a different table
+    c2 = Cohort.preset("C2")
+    img2 = c2.pack(0, 40, n_threads=4)                                  # 320 MB, descriptors 2 % of it: thin
+    t1 = np.ascontiguousarray(img2.chunks).copy(); t2 = t1.copy()
+    assert lib.v2p_order_chunks_for_xcds(t1.ctypes.data, t1.shape[0], img2.desc.ctypes.data, img2.desc.size, c2.proteome().size) == 0
+    os_env["V2P_ORDER_MAX_BLOCKS"] = "1"
+    try:
+        assert lib.v2p_order_chunks_for_xcds(t2.ctypes.data, t2.shape[0], img2.desc.ctypes.data, img2.desc.size, c2.proteome().size) == 0
+    finally:
+        os_env.pop("V2P_ORDER_MAX_BLOCKS", None)
+    assert np.array_equal(t1, t2)
