@@ -1211,11 +1211,11 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     hipError_t err = hipSuccess;
     a.dots = device_dots(&err);
     if (!a.dots) return err;
-    // 64 MB of image per phase; 28 MB where the image is more than 1/33 of the result it describes (with the chunk table dealt inside blocks
-    // of the arena -- sir_pack.hpp -- C3 whole: 7.44 / 7.42 / 7.57 / 7.63 ms with 24 / 28 / 32 / 36 MB, 8.2 with 12, 8.1 with 48; before the
-    // blocks the best was 20 MB:) 2.5 MB per XCD, which its L2
-    // holds next to the proteome slice it works on (C3 whole, 1/10: 8.85 ms with 20 MB, 8.87 with 16, 9.2 with 12, 9.3 with 24, 10.3 with 32,
-    // 12.0 with 64; a 2 000-sample slice 1.82 / 1.73 / 1.74 with 16 / 24 / 32; C4 whole 6.9 / 6.9 / 8.1 with 16 / 32 / 64; C2, 1/45: 3.31 / 3.24 / 3.21 the other way)
+    // 64 MB of image per phase; 28 MB where the image is more than 1/33 of the result it describes: about 3.5 MB per XCD, most of which
+    // its 4 MB L2 holds next to the proteome windows it works on.  With the chunk table dealt inside blocks of the arena (sir_pack.hpp)
+    // C3 whole runs 7.44 / 7.42 / 7.57 / 7.63 ms with 24 / 28 / 32 / 36 MB phases, 8.2 with 12, 8.1 with 48 (with ONE order for the whole
+    // table the best was 20 MB: 8.85 ms; 10.3 with 32, 12.0 with 64); C4 whole 6.26 / 6.16 / 7.09 with 20 / 32 / 48; C2, whose image is
+    // 1/45 of its result: 3.31 / 3.24 / 3.21 with 16 / 32 / 64 the other way.
     const bool rich = 8.0 * double(a.n_desc) > 0.03 * double(a.out_len);        // C2: 2.2 %, C4: 3.7 %, C3: 5 %
     uint64_t phase_bytes = rich ? PHASE_BYTES_RICH : PHASE_BYTES_DEFAULT;
     if (const char* e = getenv("V2P_PHASE_BYTES")) phase_bytes = strtoull(e, nullptr, 10);      // 0: one phase, no touch (A/B runs)
