@@ -125,6 +125,13 @@ void v2p_txstream_free(v2p_txstream_buf* s);
 /* Host image of haplotypes [h0, h1) cut on a fixed result grid (what the device builder produces): v2p_cohort_pack with
  * ImageBuilder::grid_bytes = window_bytes; kernel 1 = long-run routing, 2 = per block */
 int  v2p_cohort_pack_grid(const v2p_cohort* c, uint64_t h0, uint64_t h1, uint32_t window_bytes, int kernel, v2p_packed_image* out);
+/* Host ROWS image of a transcript stream (vcf2prot_amd/csrc/rows_image.hpp) -- what v2p_batch_build_on_device(kernel 6: wave, 7: dense)
+ * must reproduce byte for byte: whole descriptors in result order (nothing cut), chunks cut afterwards on 1 KiB rows of the arena
+ * (head skip / row clip in the chunk records, include/vcf2prot_hip.h), chunk table in arena order.  mode 1 = wave image, 2 = dense.
+ * emulate_k = 0: the sequential restatement of the packer's state machine; a power of two <= 64: the device kernel's tiles of that
+ * many transcripts, its 64-item windows and ballot masks emulated lane by lane (the two must agree).  *status (optional): the
+ * device-style status word (task << 8 | reason; ~0 = clean). */
+int  v2p_txstream_pack_rows(const v2p_txstream_buf* s, uint64_t proteome_len, int mode, uint32_t emulate_k, v2p_packed_image* out, uint64_t* status);
 /* FASTA record headers of every transcript and haplotype parity: one leading '\n', then 19 bytes each;
  * header of (transcript t, parity p) at 1 + (2*t + p) * 19.  Returns the bytes needed; fills `out` when cap suffices. */
 uint64_t v2p_cohort_fasta_headers(const v2p_cohort* c, uint8_t* out, uint64_t cap);

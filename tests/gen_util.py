@@ -39,6 +39,14 @@ def oracle_run(coracle, g, ref, alt, fill=ord(".")):
     return coracle.gir_execute_u8(t, ref, alt, res)
 
 
+def _desc_len(d):
+    if (d >> 62) == 3 and (d >> 61) & 1:
+        return ((d >> 29) & 0xFFF) + 1 + ((d >> 41) & 0xFFF)
+    if (d >> 60) == 0xD:
+        return ((d >> 29) & 31) + ((d >> 34) & 31) + ((d >> 39) & 31) + 2
+    return (d >> 40) & ((1 << 22) - 1)
+
+
 def interpret_image(desc, chunks, resident, payload, out_bytes):
     """Pure-Python reading of the device image format (vcf2prot_amd/csrc/sir_pack.hpp): what the stitch kernels must write.
     desc: uint64 descriptors; chunks: (n, 2) uint64 {first descriptor, result offset:48 | descriptors:16}."""
@@ -46,6 +54,14 @@ def interpret_image(desc, chunks, resident, payload, out_bytes):
     out = np.zeros(out_bytes, dtype=np.uint8)
     for tb, dn in chunks:
         nd, dst = (int(dn) >> 48) & 0x7FF, int(dn) & ((1 << 48) - 1)       # the top bits route the chunk to a kernel
+        if (int(dn) >> 59) & 1:                   # ROWS image (sir_pack.hpp: CHUNK_CLIP): the chunk starts on a 1 KiB row, skips the bytes of its first descriptor
+            rows, dst = dst & 1023, dst & ~1023   # that belong to the chunk before (top 22 bits of task_begin) and stops after `rows` KiB (0: wherever its descriptors end)
+            skip, tb = int(tb) >> 42, int(tb) & ((1 << 42) - 1)
+            part = interpret_image(desc[tb:tb + nd], np.array([[0, nd << 48]], dtype=np.uint64), resident, payload, sum(_desc_len(int(d)) for d in desc[tb:tb + nd]))
+            part = part[skip:] if not rows else part[skip:skip + rows * 1024]
+            assert not rows or part.size == rows * 1024, "a clipped chunk must produce every byte of its rows"
+            out[dst:dst + part.size] = part
+            continue
         for d in desc[int(tb):int(tb) + nd]:
             d = int(d)
             space = d >> 62

@@ -1,0 +1,101 @@
+"""Random transcript streams (v2p_txstream) with their expected results in plain numpy -- shared by the device-build fuzz tests and
+the host tests of ROWS images.  The preset cohorts have regular Task shapes; these streams do not: empty haplotypes, transcripts
+without tasks, zero-length tasks, cells no task covers, alt payloads from 1 byte to longer than a chunk, reference runs from 0 to
+several windows, substitution triples at every distance from a window boundary, tasks ending exactly on one."""
+import ctypes
+
+import numpy as np
+
+
+class Stream:
+    """A v2p_txstream over numpy arrays (kept alive here)."""
+
+    def __init__(self, hap_tx_begin, tx_off, tx_ref_len, tx_res_len, tx_task_begin, tx_alt_begin, code, sp, ln, sr, alt):
+        from vcf2prot_amd._cohort_api import TxStreamBuf
+        pad = 64                                     # the builder reads a few entries past the last task / alt byte of a transcript
+        self.keep = [np.ascontiguousarray(hap_tx_begin, dtype=np.uint64), np.ascontiguousarray(tx_off, dtype=np.uint64),
+                     np.ascontiguousarray(tx_ref_len, dtype=np.uint32), np.ascontiguousarray(tx_res_len, dtype=np.uint32),
+                     np.ascontiguousarray(tx_task_begin, dtype=np.uint64), np.ascontiguousarray(tx_alt_begin, dtype=np.uint64),
+                     np.concatenate([np.asarray(code, dtype=np.uint8), np.zeros(pad, np.uint8)]),
+                     np.concatenate([np.asarray(sp, dtype=np.uint32), np.zeros(pad, np.uint32)]),
+                     np.concatenate([np.asarray(ln, dtype=np.uint32), np.zeros(pad, np.uint32)]),
+                     np.concatenate([np.asarray(sr, dtype=np.uint32), np.zeros(pad, np.uint32)]),
+                     np.concatenate([np.asarray(alt, dtype=np.uint8), np.zeros(pad, np.uint8)])]
+        k = self.keep
+        s = TxStreamBuf()
+        s.n_haps, s.n_tx, s.n_tasks, s.n_alt = len(hap_tx_begin) - 1, len(tx_off), len(code), len(alt)
+        P64, P32, P8 = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint8)
+        s.hap_tx_begin, s.tx_proteome_off = k[0].ctypes.data_as(P64), k[1].ctypes.data_as(P64)
+        s.tx_ref_len, s.tx_res_len = k[2].ctypes.data_as(P32), k[3].ctypes.data_as(P32)
+        s.tx_task_begin, s.tx_alt_begin = k[4].ctypes.data_as(P64), k[5].ctypes.data_as(P64)
+        s.code, s.start_pos, s.length, s.start_pos_res = k[6].ctypes.data_as(P8), k[7].ctypes.data_as(P32), k[8].ctypes.data_as(P32), k[9].ctypes.data_as(P32)
+        s.alt = k[10].ctypes.data_as(P8)
+        self.struct = s
+
+
+def random_stream(rng, n_haps, n_ref_tx, shape, window):
+    """Returns (proteome, Stream, [expected result of every haplotype])."""
+    AA = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    ref_len = rng.integers(1, 3 * window if shape == "long" else 900, size=n_ref_tx)
+    ref_off = np.concatenate([[0], np.cumsum(ref_len)])
+    proteome = AA[rng.integers(0, AA.size, size=int(ref_off[-1]))]
+    hap_tx_begin, tx_off, tx_ref_len, tx_res_len, tx_task_begin, tx_alt_begin = [0], [], [], [], [0], [0]
+    code, sp, ln, sr, alt, want = [], [], [], [], [], []
+    for h in range(n_haps):
+        n_tx = 0 if rng.random() < 0.1 else int(rng.integers(1, 12))
+        res_h = []
+        for _ in range(n_tx):
+            t = int(rng.integers(0, n_ref_tx))
+            L = int(ref_len[t])
+            ref = proteome[ref_off[t]:ref_off[t] + L]
+            tasks, talt, cur_ref, cur_res = [], [], 0, 0
+            if rng.random() < 0.05:
+                pass                                                      # a transcript without tasks
+            else:
+                while cur_ref < L:
+                    r = rng.random()
+                    if shape == "snv":
+                        run = int(rng.integers(0, 14))
+                    elif shape == "long":
+                        run = int(rng.integers(0, 2 * window))
+                    else:
+                        run = int(rng.integers(0, 200))
+                    if r < 0.08:
+                        run = max(0, (window - cur_res % window) - int(rng.integers(0, 3)))      # end on / next to a window boundary
+                    run = min(run, L - cur_ref)
+                    if rng.random() < 0.05:
+                        cur_res += int(rng.integers(1, 40))              # cells nothing writes
+                    if run or rng.random() < 0.1:
+                        tasks.append((0, cur_ref, run, cur_res))          # (a zero-length task now and then)
+                    cur_ref += run
+                    cur_res += run
+                    if cur_ref >= L:
+                        break
+                    r = rng.random()
+                    if r < (0.85 if shape == "snv" else 0.5):             # substitution: one alt byte, the reference goes on one residue later
+                        n_alt_b, skip = 1, 1
+                    elif r < 0.8:                                         # insertion / delins
+                        n_alt_b, skip = int(rng.integers(1, 9 if shape != "long" else window + 100)), int(rng.integers(0, 4))
+                    elif r < 0.9:                                         # deletion
+                        n_alt_b, skip = 0, int(rng.integers(1, 30))
+                    else:                                                 # frameshift-like: a long alt tail, the rest of the reference dropped
+                        n_alt_b, skip = int(rng.integers(6, 70)), L
+                    if n_alt_b:
+                        tasks.append((1, len(talt), n_alt_b, cur_res))
+                        talt.extend(AA[rng.integers(0, AA.size, size=n_alt_b)].tolist())
+                        cur_res += n_alt_b
+                    cur_ref += skip
+            res_len = cur_res + (int(rng.integers(1, 20)) if rng.random() < 0.1 else 0)          # trailing uncovered cells
+            out = np.full(res_len, ord("."), dtype=np.uint8)
+            ta = np.asarray(talt, dtype=np.uint8)
+            for c, s_, l_, r_ in tasks:
+                out[r_:r_ + l_] = (ref if c == 0 else ta)[s_:s_ + l_]
+            res_h.append(out)
+            tx_off.append(int(ref_off[t])); tx_ref_len.append(L); tx_res_len.append(res_len)
+            for c, s_, l_, r_ in tasks:
+                code.append(c); sp.append(s_); ln.append(l_); sr.append(r_)
+            alt.extend(talt)
+            tx_task_begin.append(len(code)); tx_alt_begin.append(len(alt))
+        hap_tx_begin.append(len(tx_off))
+        want.append(np.concatenate(res_h) if res_h else np.zeros(0, np.uint8))
+    return proteome, Stream(hap_tx_begin, tx_off, tx_ref_len, tx_res_len, tx_task_begin, tx_alt_begin, code, sp, ln, sr, alt), want

@@ -71,5 +71,6 @@ COHORT_API = {
     "v2p_cohort_launch_bits": (c_int, [c_void_p, c_uint64]),
     "v2p_cohort_txstream": (c_int, [c_void_p, c_uint64, c_uint64, c_int, POINTER(TxStreamBuf)]),
     "v2p_txstream_free": (None, [POINTER(TxStreamBuf)]),
+    "v2p_txstream_pack_rows": (c_int, [POINTER(TxStreamBuf), c_uint64, c_int, c_uint32, POINTER(PackedImage), POINTER(c_uint64)]),
     "v2p_cohort_pack_grid": (c_int, [c_void_p, c_uint64, c_uint64, c_uint32, c_int, POINTER(PackedImage)]),
 }

@@ -24,6 +24,7 @@
 
 #include "../../include/v2p_cohort.h"
 #include "sir_pack.hpp"
+#include "rows_image.hpp"
 
 namespace {
 
@@ -713,6 +714,35 @@ int v2p_cohort_pack_grid(const v2p_cohort* c, uint64_t h0, uint64_t h1, uint32_t
     memcpy(out->hap_out_begin, im.hap_out_begin.data(), (out->n_haps + 1) * 8);
     out->n_tasks = im.n_ref_tasks; out->n_copy_bytes = im.n_copy_bytes;
     out->max_chunk_tasks = im.max_chunk_tasks > im.max_long_tasks ? im.max_chunk_tasks : im.max_long_tasks;
+    return 0;
+}
+
+// ROWS image of a transcript stream on the host (rows_image.hpp): what v2p_batch_build_on_device(kernel 6 / 7) must reproduce.
+int v2p_txstream_pack_rows(const v2p_txstream_buf* s, uint64_t proteome_len, int mode, uint32_t emulate_k, v2p_packed_image* out, uint64_t* status)
+{
+    if (!s || !out || (mode != v2p::ROWS_WAVE && mode != v2p::ROWS_DENSE) || emulate_k > 64 || (emulate_k & (emulate_k - 1))) return -1;
+    memset(out, 0, sizeof *out);
+    v2p::TxStreamView v{s->n_haps, s->n_tx, s->n_tasks, s->n_alt, s->hap_tx_begin, s->tx_proteome_off, s->tx_ref_len, s->tx_res_len, s->tx_task_begin, s->tx_alt_begin,
+                        s->code, s->start_pos, s->length, s->start_pos_res, s->alt, s->tx_header_off, s->tx_header_len};
+    v2p::RowsImage im;
+    std::vector<uint64_t> cover;
+    if (emulate_k) v2p::rows_emulate(v, proteome_len, mode, emulate_k, im, &cover);
+    else v2p::rows_reference(v, proteome_len, mode, im);
+    if (status) *status = im.status;
+    if (im.status != ~0ull) return v2p::PACK_RES_OOB;
+    if (!v2p::rows_cut(im, mode, emulate_k ? &cover : nullptr)) { if (status) *status = im.status; return v2p::PACK_TOO_LARGE; }
+    out->n_desc = im.desc.size(); out->n_chunks = im.chunks.size(); out->n_payload = s->n_alt; out->n_haps = s->n_haps;
+    out->desc = static_cast<uint64_t*>(malloc((out->n_desc ? out->n_desc : 1) * 8));
+    out->chunks = static_cast<v2p_chunk*>(malloc((out->n_chunks ? out->n_chunks : 1) * sizeof(v2p_chunk)));
+    out->payload = static_cast<uint8_t*>(malloc(out->n_payload ? out->n_payload : 1));
+    out->hap_out_begin = static_cast<uint64_t*>(malloc((out->n_haps + 1) * 8));
+    if (!out->desc || !out->chunks || !out->payload || !out->hap_out_begin) { v2p_packed_free(out); return -2; }
+    if (out->n_desc) memcpy(out->desc, im.desc.data(), out->n_desc * 8);
+    if (out->n_chunks) memcpy(out->chunks, im.chunks.data(), out->n_chunks * sizeof(v2p_chunk));
+    if (out->n_payload) memcpy(out->payload, s->alt, out->n_payload);
+    memcpy(out->hap_out_begin, im.hap_out_begin.data(), (out->n_haps + 1) * 8);
+    out->n_tasks = s->n_tasks;
+    for (uint64_t i = 0; i < s->n_tasks; ++i) out->n_copy_bytes += s->length[i];
     return 0;
 }
 

@@ -95,10 +95,25 @@ constexpr uint32_t PAD_BYTES  = 32;            // readable slack before AND afte
                                                // around a task's bytes (up to 30 bytes before its first byte in a chunk's ragged head block, 31 after its last)
 
 struct Chunk {
-    uint64_t task_begin;   // index of the first descriptor
+    uint64_t task_begin;   // index of the first descriptor (low 42 bits) | head skip (22 bits, rows images)
     uint64_t dst_n;        // result offset (48 bits) | descriptor count (16 bits)
 };
 static_assert(sizeof(Chunk) == 16, "Chunk is 16 bytes");
+
+// ---- ROWS images (round 4; rows_image.hpp, build_rows.hip): the descriptors are written FIRST, whole -- nothing is cut at a chunk
+// boundary -- and the chunks are cut afterwards on 1 KiB rows of the arena.  A descriptor that lies across a cut belongs to both
+// chunks: the later one skips the bytes of its first descriptor that lie before the cut (HEAD SKIP, the top 22 bits of
+// task_begin), the earlier one stops after `rows` KiB (CHUNK_CLIP: the chunk starts on a multiple of 1024 and the low ten bits of
+// its result offset hold the rows it covers; 0 = whatever its descriptors produce).  Images of the host packer never set either.
+constexpr uint32_t TB_IDX_BITS = 42;
+constexpr uint64_t TB_IDX_MASK = (1ull << TB_IDX_BITS) - 1;
+constexpr uint64_t CHUNK_CLIP  = 1ull << 59;
+constexpr uint32_t ROW_BYTES   = 1024;
+constexpr uint32_t PIECE_MAX   = (1u << 22) - 1024u;   // longest descriptor of a rows image (the head skip has 22 bits)
+V2P_HOST_DEVICE inline uint64_t chunk_first(uint64_t task_begin) { return task_begin & TB_IDX_MASK; }
+V2P_HOST_DEVICE inline uint32_t chunk_head_skip(uint64_t task_begin) { return uint32_t(task_begin >> TB_IDX_BITS); }
+V2P_HOST_DEVICE inline uint64_t chunk_dst(uint64_t dst_n) { return (dst_n & CHUNK_CLIP) ? (dst_n & ((1ull << 48) - 1) & ~1023ull) : (dst_n & ((1ull << 48) - 1)); }
+V2P_HOST_DEVICE inline uint32_t chunk_rows(uint64_t dst_n) { return (dst_n & CHUNK_CLIP) ? uint32_t(dst_n & 1023u) : 0u; }
 
 inline uint64_t pack_desc(uint64_t src, uint32_t len, unsigned space) {
     return (src & SRC_MASK) | (uint64_t(len & LEN_MASK) << 40) | (uint64_t(space & 3u) << 62);
@@ -569,7 +584,7 @@ inline void order_chunks_for_xcds_range(Chunk* chunks, uint64_t n_chunks, const 
     std::vector<uint8_t> sub(n_chunks);
     std::vector<uint64_t> count(n_xcd, 0);
     for (uint64_t c = 0; c < n_chunks; ++c) {
-        const uint64_t tb = chunks[c].task_begin;
+        const uint64_t tb = chunk_first(chunks[c].task_begin);
         const uint32_t n = chunk_n(chunks[c].dst_n);
         uint64_t key = 0;
         for (uint32_t k = 0; k < n && k < 6 && tb + k < n_desc; ++k)       // skip FASTA literals stored behind the proteome
@@ -640,9 +655,9 @@ inline void order_chunks_for_xcds(Chunk* chunks, uint64_t n_chunks, const uint64
     if (max_blocks <= 1 || n_chunks < 2 * n_xcd || proteome_len == 0) { order_chunks_for_xcds_range(chunks, n_chunks, desc, n_desc, proteome_len, n_xcd, window_major); return; }
     // the table in arena order first (the packers emit it so; a caller's table may not be)
     bool sorted = true;
-    for (uint64_t c = 1; c < n_chunks && sorted; ++c) sorted = (chunks[c - 1].dst_n & DST_MASK) <= (chunks[c].dst_n & DST_MASK);
-    if (!sorted) std::stable_sort(chunks, chunks + n_chunks, [](const Chunk& a, const Chunk& b) { return (a.dst_n & DST_MASK) < (b.dst_n & DST_MASK); });
-    const uint32_t nb = xcd_order_blocks(chunks[n_chunks - 1].dst_n & DST_MASK, proteome_len, n_chunks, max_blocks, n_desc);
+    for (uint64_t c = 1; c < n_chunks && sorted; ++c) sorted = chunk_dst(chunks[c - 1].dst_n) <= chunk_dst(chunks[c].dst_n);
+    if (!sorted) std::stable_sort(chunks, chunks + n_chunks, [](const Chunk& a, const Chunk& b) { return chunk_dst(a.dst_n) < chunk_dst(b.dst_n); });
+    const uint32_t nb = xcd_order_blocks(chunk_dst(chunks[n_chunks - 1].dst_n), proteome_len, n_chunks, max_blocks, n_desc);
     for (uint32_t k = 0; k < nb; ++k) {
         const uint64_t c0 = xcd_order_block_first(n_chunks, nb, k), c1 = xcd_order_block_first(n_chunks, nb, k + 1);
         order_chunks_for_xcds_range(chunks + c0, c1 - c0, desc, n_desc, proteome_len, n_xcd, window_major);

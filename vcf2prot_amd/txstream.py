@@ -111,6 +111,36 @@ class HostTxStream:
         self.keep = []
 
 
+def pack_rows(stream, proteome_len: int, mode: int = 1, emulate_k: int = 0):
+    """The ROWS image of a transcript stream built on the HOST (csrc/rows_image.hpp; include/v2p_cohort.h: v2p_txstream_pack_rows) --
+    what v2p_batch_build_on_device(kernel 6 / 7) must reproduce: mode 1 = wave image, 2 = dense; emulate_k = 0: the sequential
+    restatement of the packer's state machine, a power of two <= 64: the device kernel's tiles / windows / ballot masks emulated
+    lane by lane.  Returns a cohort.Packed (chunk table in arena order); raises RowsError(status word) for what the device reports."""
+    from . import _native as N
+    from ._cohort_api import PackedImage
+    from .cohort import Packed, _arr
+    lib = N.cohort_lib()
+    img = PackedImage()
+    status = ctypes.c_uint64(0)
+    rc = lib.v2p_txstream_pack_rows(ctypes.byref(stream.struct), proteome_len, mode, emulate_k, ctypes.byref(img), ctypes.byref(status))
+    if rc != 0:
+        raise RowsError(rc, int(status.value))
+    try:
+        chunks = (np.ctypeslib.as_array(ctypes.cast(img.chunks, ctypes.POINTER(ctypes.c_uint64)), shape=(int(img.n_chunks) * 2,)).astype(np.uint64, copy=True).reshape(-1, 2)
+                  if img.n_chunks else np.zeros((0, 2), dtype=np.uint64))
+        return Packed(_arr(img.desc, img.n_desc, np.uint64), chunks, _arr(img.payload, img.n_payload, np.uint8), _arr(img.hap_out_begin, img.n_haps + 1, np.uint64),
+                      int(img.n_tasks), int(img.n_copy_bytes), 0)
+    finally:
+        lib.v2p_packed_free(ctypes.byref(img))
+
+
+class RowsError(RuntimeError):
+    def __init__(self, rc: int, status: int):
+        self.rc, self.status = rc, status
+        self.index, self.reason = (status >> 8, status & 0xFF) if status != 0xFFFFFFFFFFFFFFFF else (-1, 0)
+        super().__init__(f"rows image refused: rc={rc} task/descriptor {self.index} reason {self.reason}")
+
+
 def build_plan(bytes_per_task: float) -> list:
     """(kernel, window_bytes) pairs to try in order for v2p_batch_build_on_device, by result bytes per task -- the routing the host
     packer would choose.  Wave images (>= 40 bytes per task): windows that may split once (kernel 5) sized for about 56 descriptors
