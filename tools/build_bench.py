@@ -46,7 +46,7 @@ def main():
     t_stream = time.perf_counter() - t0
     sizes = cohort.result_sizes(0, n_haps, n_threads=nt)
     result_bytes = int(sizes.sum())
-    plan = [(a.kernel, a.window)] if a.kernel and a.window else build_plan(result_bytes / max(stream.n_tasks, 1))
+    plan = [(a.kernel, a.window)] if a.kernel else build_plan(result_bytes / max(stream.n_tasks, 1))
     out = {"workload": a.workload, "samples": samples, "haplotypes": n_haps, "transcripts": stream.n_tx, "tasks": stream.n_tasks,
            "stream_bytes": stream.nbytes, "result_bytes": result_bytes, "stream_generation_s": t_stream}
     with Context(0) as ctx:

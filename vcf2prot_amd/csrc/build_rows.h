@@ -1,0 +1,67 @@
+// build_rows.h -- argument block and host launchers of the ONE-PASS device image builder (build_rows.hip; image format: rows_image.hpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sir_pack.hpp"
+#include "rows_image.hpp"
+#include "stitch_kernels.h"
+
+namespace v2p {
+
+constexpr uint32_t STATUS_ROWS_TOO_MANY = 5;       // a 1 KiB row holds more descriptors than a chunk may (= build_kernels.h: STATUS_TOO_MANY)
+constexpr uint32_t STATUS_ROWS_STAGE = 6;          // a tile's descriptors / rows do not fit the wave's LDS stage: rebuild with the two-phase kernel
+constexpr uint32_t STATUS_ROWS_CAP = 7;            // the descriptor array is too small (tasks behind gaps): rebuild with the full bound
+
+struct RowsArgs {
+    // the transcript stream (v2p_txstream), on the device
+    uint64_t n_tx, n_tasks, n_alt;
+    const uint64_t* tx_proteome_off;
+    const uint32_t* tx_ref_len;
+    const uint32_t* tx_res_len;
+    const uint64_t* tx_task_begin;
+    const uint64_t* tx_alt_begin;
+    const uint8_t*  code;
+    const uint32_t* start_pos;
+    const uint32_t* length;
+    const uint32_t* start_pos_res;
+    const uint8_t*  alt;
+    const uint64_t* tx_header_off;      // FASTA emit (nullptr: plain tapes)
+    const uint32_t* tx_header_len;
+    const uint64_t* hap_tx_begin;
+    uint64_t n_haps;
+    uint64_t proteome_len;
+    // tiles: K transcripts (HEAD items) each, a power of two <= 64
+    uint32_t K, log2K;
+    uint64_t n_tiles;
+    uint64_t* tile_bytes;               // [n_tiles] arena bytes of each tile -> (scan) tile_res_base
+    uint64_t* tile_res_base;            // [n_tiles + 1]
+    uint64_t* tile_state;               // [n_tiles] decoupled look-back over the tiles' descriptor counts: flag << 62 | value
+    uint64_t* totals;                   // [4]: descriptors, chunks, result offset of the last chunk, -
+    uint64_t* desc;
+    uint64_t  desc_cap;
+    uint64_t* cover;                    // [n_rows] per 1 KiB row of the arena: descriptor covering its first byte << 22 | offset inside it
+    uint64_t  n_rows, out_bytes;
+    // the cutter
+    uint32_t* seg_count;                // [n_segs] chunks of each segment of ROWS_SEG rows
+    const uint64_t* seg_base;           // [n_segs + 1] exclusive prefix
+    uint64_t  n_segs;
+    Chunk*    chunks_tmp;               // arena order
+    uint8_t*  bucket;
+    uint8_t*  sub;
+    uint64_t* hap_out_begin;
+    unsigned long long* status;
+};
+
+// arena bytes per tile (+ u64 exclusive scan into tile_res_base, total behind the last tile)
+hipError_t launch_rows_tile_bytes(const RowsArgs& a, uint64_t* scan_scratch, hipStream_t stream);
+uint64_t rows_scan_scratch_entries(uint64_t n);
+// the parse: mode ROWS_WAVE / ROWS_DENSE; two_phase: every tile counted first and written straight to the arrays afterwards
+// (no LDS stage: any tile size); grid = persistent waves (all co-resident), computed here
+hipError_t launch_rows_parse(const RowsArgs& a, int mode, bool two_phase, hipStream_t stream);
+hipError_t launch_rows_hap_begin(const RowsArgs& a, hipStream_t stream);
+// the cutter: count pass (seg_count, totals[2] = last chunk's result offset), then -- after the scan of seg_count -- the emit pass
+// (chunks_tmp in arena order) and the proteome slice / window of every chunk (bucket, sub)
+hipError_t launch_rows_cut(const RowsArgs& a, int mode, bool emit, hipStream_t stream);
+hipError_t launch_rows_keys(const RowsArgs& a, uint64_t n_chunks, uint64_t n_desc, hipStream_t stream);
+
+}  // namespace v2p

@@ -544,21 +544,22 @@ private:
 };
 
 // Launch bits of v2p_stitch_launch / launch_stitch for a chunk table: which kernels have work and how many tasks per lane they
-// need (bit 1: chunks flagged for stitch_dense_kernel, bit 2: chunks flagged for stitchw_kernel, bit 4: no long-run chunk, bit 5: no per-block chunk, bits 6..7: tasks per
+// need (bit 1: chunks flagged for stitch_dense_kernel, bit 2: chunks flagged for stitchw_kernel, bit 3: a rows image (CHUNK_CLIP), bit 4: no long-run chunk, bit 5: no per-block chunk, bits 6..7: tasks per
 // lane of stitch4_kernel, bits 8..11: of stitch_kernel).
 inline int stitch_launch_bits(const Chunk* chunks, uint64_t n_chunks)
 {
     uint32_t max_pb = 0;
-    bool any_long = false, any_long2 = false, any_pb = false, any_dense = false, any_wave = false;
+    bool any_long = false, any_long2 = false, any_pb = false, any_dense = false, any_wave = false, any_clip = false;
     for (uint64_t i = 0; i < n_chunks; ++i) {
         const uint64_t dn = chunks[i].dst_n;
+        any_clip = any_clip || (dn & CHUNK_CLIP) != 0;
         if (dn & CHUNK_LONG) { any_long = true; any_long2 = any_long2 || (dn & CHUNK_LONG2) != 0; }
         else if (dn & CHUNK_DENSE) any_dense = true;
         else if (dn & CHUNK_WAVE) any_wave = true;
         else { any_pb = true; const uint32_t n = chunk_n(dn); if (n > max_pb) max_pb = n; }
     }
     const int tpt = max_pb <= 256u ? 1 : (max_pb <= 512u ? 2 : 4);
-    return (any_dense ? 2 : 0) | (any_wave ? 4 : 0) | (any_long ? 0 : 16) | (any_pb ? 0 : 32) | ((any_long2 ? 2 : 1) << 6) | (tpt << 8);
+    return (any_dense ? 2 : 0) | (any_wave ? 4 : 0) | (any_clip ? 8 : 0) | (any_long ? 0 : 16) | (any_pb ? 0 : 32) | ((any_long2 ? 2 : 1) << 6) | (tpt << 8);
 }
 
 constexpr uint32_t XCD_SUB = 256;                  // windows per proteome slice in the launch order

@@ -132,8 +132,8 @@ __device__ __forceinline__ void touch_chunks(const uint64_t* __restrict__ desc, 
     uint64_t d[TOUCH_CHUNKS_PER_WAVE];
 #pragma unroll
     for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) {
-        const uint64_t n = (ch[k].dst_n >> 48) & uint64_t(CHUNK_N_MASK), i = ch[k].task_begin + lane;
-        d[k] = (i < ch[k].task_begin + n && i < n_desc) ? desc[i] : (uint64_t(SPACE_FILL) << 62);
+        const uint64_t n = (ch[k].dst_n >> 48) & uint64_t(CHUNK_N_MASK), tb = ch[k].task_begin & TB_IDX_MASK, i = tb + lane;
+        d[k] = (i < tb + n && i < n_desc) ? desc[i] : (uint64_t(SPACE_FILL) << 62);
     }
     auto payload_lines = [&](uint64_t dd) {
         const uint64_t src = dd & SRC_MASK, len = (dd >> 40) & LEN_MASK;
@@ -146,7 +146,8 @@ __device__ __forceinline__ void touch_chunks(const uint64_t* __restrict__ desc, 
     for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) payload_lines(d[k]);
     for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) {           // chunks of more than 64 descriptors (per-block, dense images)
         const uint64_t n = (ch[k].dst_n >> 48) & uint64_t(CHUNK_N_MASK);
-        for (uint64_t i = ch[k].task_begin + 64u + lane; i < ch[k].task_begin + n && i < n_desc; i += 64u) payload_lines(desc[i]);
+        const uint64_t tb = ch[k].task_begin & TB_IDX_MASK;
+        for (uint64_t i = tb + 64u + lane; i < tb + n && i < n_desc; i += 64u) payload_lines(desc[i]);
     }
 #pragma unroll
     for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) asm volatile("" :: "v"(d[k]));

@@ -33,6 +33,7 @@ struct StitchArgs {
     const Chunk*    next_chunks = nullptr;   // set by launch_stitch(): the chunk records of the NEXT phase, whose image the trailing
     uint32_t        n_next = 0;              // workgroups of a wave launch read ahead (stitch_wave.hip); 0: none
     uint32_t        store_sc1 = 0;           // set by launch_stitch(): the wave kernel's row stores "sc1 nt" instead of "nt" (thin descriptor streams)
+    uint32_t        rows = 0;                // set by launch_stitch(): a rows image (sir_pack.hpp: every chunk carries CHUNK_CLIP) -- stitchw_kernel's ROWS instance
     uint32_t        phase_chunks = 0;        // set by launch_stitch(): != 0 -- ONE wave launch for all phases of that many chunks, the read-ahead
                                              // workgroups of phase g + 1 placed in the grid before the stitch workgroups of phase g
 };

@@ -408,7 +408,9 @@ __device__ __forceinline__ void dense_put(uint32_t* img, const u32x4* lowmask, u
 // DBG != 0: timing-only ablations (results are wrong): 1 = no gathers, 2 = no stores, 3 = no LDS puts
 // ONE: every chunk is a single window (the chunks a dense image flags; a larger one is refused) -- its own instance, because with
 // the multi-window path in the same kernel the compiler keeps 95 VGPRs live instead of 58
-template <bool NT, bool DW, int DBG = 0, bool ONE = false>
+// RIMG: the image is a rows image (sir_pack.hpp: CHUNK_CLIP on every chunk) -- the chunk starts on a 1 KiB row, skips the head of
+// its first descriptor and clips its last one after its rows; an instance of its own (the host packer's images run the code they ran)
+template <bool NT, bool DW, int DBG = 0, bool ONE = false, bool RIMG = false>
 __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __restrict__ p_desc, const Chunk* __restrict__ p_chunks,
                                                               const uint8_t* __restrict__ p_src0, const uint8_t* __restrict__ p_src1,
                                                               uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
@@ -436,14 +438,18 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
         for (uint32_t k = 0; k < 4u; ++k) m[k] = tid >= 4u * k + 4u ? 0xFFFFFFFFu : (tid <= 4u * k ? 0u : (1u << (8u * (tid - 4u * k))) - 1u);
         s_low[tid] = m;
     }
-    const uint64_t tb = a.chunks[c].task_begin;
+    const uint64_t tb_raw = a.chunks[c].task_begin;
     const uint64_t dn = a.chunks[c].dst_n;
     if (dn & (CHUNK_LONG | CHUNK_WAVE)) return;            // long-run chunks belong to stitch4_kernel, wave chunks to stitchw_kernel
     if (filter == 3u && !(dn & CHUNK_DENSE)) return;       // (the other chunks of this image go to the per-block kernel)
+    const uint64_t tb = RIMG ? tb_raw & TB_IDX_MASK : tb_raw;
+    if (RIMG != ((dn & CHUNK_CLIP) != 0ull)) { if (tid == 0) report(a.status, tb, STATUS_RES_OOB); return; }      // (the launcher picked the wrong instance)
+    const uint32_t hskip = RIMG ? uint32_t(tb_raw >> TB_IDX_BITS) : 0u;
+    const uint32_t clip_bytes = RIMG ? (uint32_t(dn) & 1023u) << 10 : 0u;
     const bool fused = (dn & CHUNK_DENSE) != 0ull;         // the chunk may hold fused substitution descriptors
     const uint32_t n_hdr = uint32_t(dn >> 48) & CHUNK_N_MASK;
-    const uint64_t dst = dn & ((1ull << 48) - 1);
-    const uint32_t head = uint32_t(dst & 15ull);
+    const uint64_t dst = RIMG ? (dn & ((1ull << 48) - 1) & ~1023ull) : (dn & ((1ull << 48) - 1));
+    const uint32_t head = RIMG ? 0u : uint32_t(dst & 15ull);
     const bool hdr_ok = n_hdr <= K && tb <= a.n_desc && n_hdr <= a.n_desc - tb;
     const uint32_t n = hdr_ok ? n_hdr : 0u;
 
@@ -489,11 +495,25 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
             const uint64_t so = (uint64_t(so_hi) << 32) | so_lo;
             const uint64_t limit = space == SPACE_PROTEOME ? a.src0_len : (space == SPACE_PAYLOAD ? a.src1_len : ~0ull);
             // never read out of bounds (task.rs would panic); a fused descriptor outside a dense image's chunk is refused too
-            const bool bd = so + used > limit || (space == SPACE_IMM && ln > IMM_MAX_BYTES) || (fz && !fused);
+            bool bd = so + used > limit || (space == SPACE_IMM && ln > IMM_MAX_BYTES) || (fz && !fused);
+            // a rows image: the chunk's first descriptor begins in the chunk before -- its stream starts `hskip` bytes in
+            const uint32_t hs = (RIMG && k == 0 && tid == 0u) ? hskip : 0u;
+            uint64_t so_h = so;
+            uint32_t p1 = l1, p2 = l1 + 1u + l2;            // where the literals of a fused run sit
+            bool lit1 = fz, lit2 = is5;
+            if (RIMG && k == 0) {
+                if (hs != 0u && hs >= ln) bd = true;
+                else {
+                    ln -= hs;
+                    so_h = space == SPACE_IMM ? so >> (8u * hs) : (space == SPACE_FILL ? so : so + hs);
+                    lit1 = lit1 && hs <= p1; lit2 = lit2 && hs <= p2;
+                    p1 -= hs; p2 -= hs;
+                }
+            }
             if (bd) { bad |= 1u << k; ln = 0u; }
-            patch[k] = (fz && !bd) ? (l1 | b1 << 12 | 1u << 20 | (is5 ? (l1 + 1u + l2) << 21 | 1u << 28 : 0u)) : 0u;
+            patch[k] = (fz && !bd) ? ((lit1 ? (p1 & 0xFFFu) | b1 << 12 | 1u << 20 : 0u) | (lit2 ? (p2 & 0x7Fu) << 21 | 1u << 28 : 0u)) : 0u;
             len[k] = ln;
-            sw[k] = (uint64_t((is5 ? b2 << 16 : 0u) | space << 8 | so_hi) << 32) | so_lo;   // (the second literal rides in bits 48..55)
+            sw[k] = (uint64_t((is5 ? b2 << 16 : 0u) | space << 8 | uint32_t(so_h >> 32)) << 32) | uint32_t(so_h);   // (the second literal rides in bits 48..55)
             lsum += len[k];
         }
 #pragma unroll
@@ -512,8 +532,24 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
     if (lane == 63u) s_w[0][wid] = incl;
     lds_barrier();
     const uint32_t l0 = s_w[0][0], l1 = s_w[0][1], l2 = s_w[0][2], l3 = s_w[0][3];
-    const uint32_t total = l0 + l1 + l2 + l3;
+    uint32_t total = l0 + l1 + l2 + l3;
     const uint32_t excl = incl - lsum + (wid > 0 ? l0 : 0u) + (wid > 1 ? l1 : 0u) + (wid > 2 ? l2 : 0u);
+    if (RIMG && clip_bytes != 0u) {
+        // the row clip: the chunk's last descriptor gives up what lies behind the chunk's rows (a literal there is nobody's)
+        if (total < clip_bytes) { if (tid == 0) report(a.status, tb, STATUS_RES_OOB); return; }
+        const uint32_t excess = total - clip_bytes;
+#pragma unroll
+        for (int k = 0; k < TPT; ++k)
+            if (tid * TPT + k + 1u == n && excess != 0u) {
+                if (excess >= len[k]) { report(a.status, tb, STATUS_RES_OOB); len[k] = 0u; patch[k] = 0u; }
+                else {
+                    len[k] -= excess;
+                    if ((patch[k] & 0xFFFu) >= len[k]) patch[k] &= ~(1u << 20);
+                    if (((patch[k] >> 21) & 0x7Fu) >= len[k]) patch[k] &= ~(1u << 28);
+                }
+            }
+        total = clip_bytes;
+    }
     if (!(hdr_ok && dst + total <= a.out_len)) {            // never write out of bounds
         if (tid == 0) report(a.status, tb, STATUS_RES_OOB);
         return;
@@ -1216,6 +1252,7 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     // C3 whole runs 7.44 / 7.42 / 7.57 / 7.63 ms with 24 / 28 / 32 / 36 MB phases, 8.2 with 12, 8.1 with 48 (with ONE order for the whole
     // table the best was 20 MB: 8.85 ms; 10.3 with 32, 12.0 with 64); C4 whole 6.26 / 6.16 / 7.09 with 20 / 32 / 48; C2, whose image is
     // 1/45 of its result: 3.31 / 3.24 / 3.21 with 16 / 32 / 64 the other way.
+    a.rows = (nontemporal & 8) != 0;                                             // (bit 3: a rows image, sir_pack.hpp: CHUNK_CLIP on every chunk)
     const bool rich = 8.0 * double(a.n_desc) > 0.03 * double(a.out_len);        // C2: 2.2 %, C4: 3.7 %, C3: 5 %
     uint64_t phase_bytes = rich ? PHASE_BYTES_RICH : PHASE_BYTES_DEFAULT;
     if (const char* e = getenv("V2P_PHASE_BYTES")) phase_bytes = strtoull(e, nullptr, 10);      // 0: one phase, no touch (A/B runs)
@@ -1335,7 +1372,8 @@ static hipError_t launch_stitch_range(const StitchArgs& a, hipStream_t stream, i
     const int tpt_long = (nontemporal >> 6) & 3;        // bits 6..7: tasks per lane of the largest long-run chunk (0 = 2)
     // dense images (chunks of more than 512 short tasks) go to stitch_dense_kernel; variant 3 keeps them on the per-block kernel and
     // variant 8 sends every per-block chunk of any image there (A/B runs)
-#define V2P_LDD(NTT, DWW, DD, FF) do { if ((FF) == 3) hipLaunchKernelGGL((stitch_dense_kernel<NTT, DWW, DD, true>), dim3(a.n_chunks), dim3(256), 0, stream, V2P_KARGS, uint32_t(FF)); \
+#define V2P_LDD(NTT, DWW, DD, FF) do { if ((FF) == 3 && a.rows) hipLaunchKernelGGL((stitch_dense_kernel<NTT, false, 0, true, true>), dim3(a.n_chunks), dim3(256), 0, stream, V2P_KARGS, uint32_t(FF)); \
+        else if ((FF) == 3) hipLaunchKernelGGL((stitch_dense_kernel<NTT, DWW, DD, true>), dim3(a.n_chunks), dim3(256), 0, stream, V2P_KARGS, uint32_t(FF)); \
         else hipLaunchKernelGGL((stitch_dense_kernel<NTT, DWW, DD, false>), dim3(a.n_chunks), dim3(256), 0, stream, V2P_KARGS, uint32_t(FF)); } while (0)
 #ifdef V2P_BENCH_VARIANTS
 #define V2P_LD(NTT, FF) do { if (var == 9) V2P_LDD(NTT, true, 0, FF); else if (dbg == 1) V2P_LDD(NTT, false, 1, FF); else if (dbg == 2) V2P_LDD(NTT, false, 2, FF); \

@@ -109,7 +109,10 @@ __device__ __forceinline__ u32x4 wmerge(u32x4 v, u32x4 ld, u32x4 m)      // byte
 #ifndef V2P_WAVE_OCC
 #define V2P_WAVE_OCC 8
 #endif
-template <int WPG, bool NT, bool SC1 = false>
+// RIMG: the image is a rows image (sir_pack.hpp: CHUNK_CLIP) -- every chunk starts on a 1 KiB row (no ragged head), may skip the
+// head of its first descriptor and clip its last one; an instance of its own, so that the host packer's images run the code they
+// always ran (the kernel sits at 62-64 VGPRs: a handful of extra live values made hipcc spill a gathered row).
+template <int WPG, bool NT, bool SC1 = false, bool RIMG = false>
 __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const uint64_t* __restrict__ p_desc, const Chunk* __restrict__ p_chunks,
                                                             const uint8_t* __restrict__ p_src0, const uint8_t* __restrict__ p_src1,
                                                             uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
@@ -158,11 +161,17 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
         return;
     }
     WaveLds& L = s_all[wid];
-    const uint64_t tb = p_chunks[c].task_begin, dn = p_chunks[c].dst_n;
+    const uint64_t tb_raw = p_chunks[c].task_begin, dn = p_chunks[c].dst_n;
     if (!(dn & CHUNK_WAVE)) return;                                  // the chunks of another kernel
+    // ROWS images (sir_pack.hpp): the chunk's first descriptor may begin in the chunk before -- skip its first `hskip` bytes --
+    // and its last one may go on into the next -- stop after `clip_bytes` (whole 1 KiB rows; 0: wherever the descriptors end)
+    const uint64_t tb = RIMG ? tb_raw & TB_IDX_MASK : tb_raw;
+    const uint32_t hskip = RIMG ? uint32_t(tb_raw >> TB_IDX_BITS) : 0u;
     const uint32_t n_hdr = uint32_t(dn >> 48) & CHUNK_N_MASK;
-    const uint64_t dst = dn & DST_MASK;
-    const uint32_t head = uint32_t(dst) & 15u;
+    if (RIMG != ((dn & CHUNK_CLIP) != 0ull)) { if (lane == 0u) report(p_status, tb, STATUS_RES_OOB); return; }      // (the launcher picked the wrong instance: refused, not guessed)
+    const uint64_t dst = RIMG ? (dn & DST_MASK & ~1023ull) : (dn & DST_MASK);
+    const uint32_t clip_bytes = RIMG ? (uint32_t(dn) & 1023u) << 10 : 0u;
+    const uint32_t head = RIMG ? 0u : uint32_t(dst) & 15u;
     // a chunk table that points outside the descriptor array is refused, not followed
     const bool hdr_ok = n_hdr <= CHUNK_TASKS_WAVE && tb <= n_desc && n_hdr <= n_desc - tb;
     const uint32_t n = hdr_ok ? n_hdr : 0u;
@@ -192,19 +201,27 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
     const bool snv = (dhi >> 29) == 7u;                              // fused substitution: src 0..28, len1 29..40, len2 41..52, byte 53..60
     const bool imm = !snv && space == SPACE_IMM;                     // (a two-substitution descriptor of a dense image lands here with a huge length: refused)
     const uint32_t len1 = snv ? (dlo >> 29) | ((dhi & 0x1FFu) << 3) : (dhi >> 8) & 0x3FFFFFu;
-    const uint32_t bytes = snv ? len1 + 1u + ((dhi >> 9) & 0xFFFu) : len1;
+    const uint32_t bytes0 = snv ? len1 + 1u + ((dhi >> 9) & 0xFFFu) : len1;          // the whole descriptor
+    const uint32_t hs = lane == 0u ? hskip : 0u;                                     // (a record is a stream: skipping its head is an address and a length)
     const uint64_t src = snv ? uint64_t(dlo & 0x1FFFFFFFu) : ((uint64_t(dhi & 0xFFu) << 32) | dlo);
-    const bool gathers = !imm && bytes != 0u && (snv || space != SPACE_FILL);       // ('.' fill, idle lanes, empty records and immediates read the dots)
+    const bool gathers = !imm && bytes0 != 0u && (snv || space != SPACE_FILL);      // ('.' fill, idle lanes, empty records and immediates read the dots)
     const bool ref = snv || space == SPACE_PROTEOME;
-    const bool bad = imm ? len1 > IMM_MAX_BYTES : (gathers && src + bytes > (ref ? src0_len : src1_len));   // never read out of bounds: task.rs would panic
+    const bool bad = (hs != 0u && hs >= bytes0) || (imm ? len1 > IMM_MAX_BYTES : (gathers && src + bytes0 > (ref ? src0_len : src1_len)));   // never read out of bounds: task.rs would panic
     // (an immediate record's bytes ARE in memory: the low bytes of its own descriptor, just loaded -- it is a stream like any other)
-    const uint64_t a = imm ? reinterpret_cast<uint64_t>(p_desc + tb + lane) : (gathers ? reinterpret_cast<uint64_t>(ref ? p_src0 : p_src1) + src : dots16);
-    const uint32_t incl = wave_incl_scan(bad ? 0u : bytes);
-    const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+    const uint64_t a = (imm ? reinterpret_cast<uint64_t>(p_desc + tb + lane) : (gathers ? reinterpret_cast<uint64_t>(ref ? p_src0 : p_src1) + src : dots16)) + (gathers || imm ? hs : 0u);
+    const uint32_t bytes_h = bytes0 - hs;
+    const uint32_t incl0 = wave_incl_scan(bad ? 0u : bytes_h);
+    const uint32_t total0 = uint32_t(__builtin_amdgcn_readlane(int(incl0), 63));
+    // the row clip: the chunk's last descriptor gives up what lies behind the chunk's rows
+    const uint32_t excess = clip_bytes != 0u && total0 > clip_bytes ? total0 - clip_bytes : 0u;
+    const bool clip_bad = clip_bytes != 0u && (total0 < clip_bytes || (lane + 1u == n && excess >= bytes_h));
+    const uint32_t bytes = bytes_h - (lane + 1u == n ? excess : 0u);
+    const uint32_t incl = incl0 - (lane + 1u >= n ? excess : 0u);
+    const uint32_t total = total0 - excess;
     const uint32_t ptotal = head + total;                            // end of the chunk in block space
     const uint32_t nblk = total ? (ptotal + 15u) >> 4 : 0u;
     const bool any_bad = __ballot(bad) != 0ull;
-    if (!(hdr_ok && dst + total <= out_len && nblk <= CHUNK_BYTES_WAVE / 16u) || any_bad) {     // never write out of bounds
+    if (!(hdr_ok && dst + total <= out_len && nblk <= CHUNK_BYTES_WAVE / 16u) || any_bad || __ballot(clip_bad) != 0ull) {     // never write out of bounds
         if (bad) report(p_status, tb + lane, STATUS_SRC_OOB);        // reported, and the chunk is not executed
         if (!any_bad && lane == 0u) report(p_status, tb, STATUS_RES_OOB);
         return;
@@ -220,10 +237,11 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
 #endif
     const uint32_t start = ptotal - (total - (incl - bytes));        // = head + exclusive prefix; lanes >= n sit at ptotal
     const uint32_t end = start + bytes;
-    const uint32_t lit_pos = start + len1;                           // (fused substitutions only)
+    const uint32_t lit_rel = len1 - hs;                              // (fused substitutions only; a skipped or clipped residue is nobody's)
+    const uint32_t lit_pos = start + lit_rel;
     const uint32_t lit_byte = (dhi >> 21) & 0xFFu;
     const uint64_t adj = a - start;
-    const uint32_t my_lit = snv ? lit_pos | (lit_byte << 16) : WREC_NOLIT;
+    const uint32_t my_lit = snv && hs <= len1 && lit_rel < bytes ? lit_pos | (lit_byte << 16) : WREC_NOLIT;
     {
         WRec t;
         t.a_lo = uint32_t(adj); t.a_hi = uint32_t(adj >> 32);
@@ -389,6 +407,7 @@ hipError_t launch_stitch_wave(const StitchArgs& a, hipStream_t stream, bool nt, 
         const uint32_t P = a.phase_chunks, tw = 8u * touch_waves_per_xcd(P);
         const uint64_t groups = (uint64_t(a.n_chunks) + P - 1u) / P, grid = groups * (uint64_t(tw) + P);
         if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        if (a.rows) return hipErrorInvalidValue;                     // (one launch for all phases is an A/B switch of host-packed images)
         if (nt) hipLaunchKernelGGL((stitchw_kernel<1, true>), dim3(uint32_t(grid)), dim3(64), 0, stream, a.desc, a.chunks, a.src0, a.src1, a.out, a.status, a.dots,
                                    a.n_chunks, a.n_desc, a.src0_len, a.src1_len, a.out_len, nullptr, 0u, P);
         else hipLaunchKernelGGL((stitchw_kernel<1, false>), dim3(uint32_t(grid)), dim3(64), 0, stream, a.desc, a.chunks, a.src0, a.src1, a.out, a.status, a.dots,
@@ -411,12 +430,16 @@ hipError_t launch_stitch_wave(const StitchArgs& a, hipStream_t stream, bool nt, 
         const uint32_t tw = n_next ? touch_waves_per_xcd(n_next) : 0u;                         // read-ahead waves per XCD
 #define V2P_LW(WW, NTT) hipLaunchKernelGGL((stitchw_kernel<WW, NTT>), dim3(tw ? ((((nc + (WW) - 1u) / (WW)) + 7u) & ~7u) + 8u * ((tw + (WW) - 1u) / (WW)) : (nc + (WW) - 1u) / (WW)), dim3(64 * (WW)), 0, stream, \
         a.desc, ch, a.src0, a.src1, a.out, a.status, a.dots, nc, a.n_desc, a.src0_len, a.src1_len, a.out_len, a.next_chunks, n_next, 0u)
-        if (waves_per_group == 4) { if (nt) V2P_LW(4, true); else V2P_LW(4, false); }
+#define V2P_LWR(NTT, SCC) hipLaunchKernelGGL((stitchw_kernel<1, NTT, SCC, true>), dim3(tw ? (((nc + 7u) & ~7u) + 8u * tw) : nc), dim3(64), 0, stream, \
+        a.desc, ch, a.src0, a.src1, a.out, a.status, a.dots, nc, a.n_desc, a.src0_len, a.src1_len, a.out_len, a.next_chunks, n_next, 0u)
+        if (a.rows) { if (nt && a.store_sc1) V2P_LWR(true, true); else if (nt) V2P_LWR(true, false); else V2P_LWR(false, false); }
+        else if (waves_per_group == 4) { if (nt) V2P_LW(4, true); else V2P_LW(4, false); }
         else if (waves_per_group == 2) { if (nt) V2P_LW(2, true); else V2P_LW(2, false); }
         else if (nt && a.store_sc1) hipLaunchKernelGGL((stitchw_kernel<1, true, true>), dim3(tw ? (((nc + 7u) & ~7u) + 8u * tw) : nc), dim3(64), 0, stream,
                                                       a.desc, ch, a.src0, a.src1, a.out, a.status, a.dots, nc, a.n_desc, a.src0_len, a.src1_len, a.out_len, a.next_chunks, n_next, 0u);
         else { if (nt) V2P_LW(1, true); else V2P_LW(1, false); }
 #undef V2P_LW
+#undef V2P_LWR
     }
     return hipGetLastError();
 }

@@ -20,6 +20,7 @@
 #include "sir_pack.hpp"
 #include "stitch_kernels.h"
 #include "build_kernels.h"
+#include "build_rows.h"
 #include "v2p_ctx_internal.h"
 
 using namespace v2p;
@@ -1030,6 +1031,177 @@ int v2p_batch_end_haplotype(v2p_batch* b)
     return V2P_OK;
 }
 
+// ---- ROWS images: the image built in ONE pass (build_rows.hip; format: rows_image.hpp) -----------------------------------------
+// Called by v2p_batch_build_on_device (kernel 6: wave image, 7: dense) with the stream's tables already checked and c->mu held.
+static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool fasta, float* build_ms)
+{
+    v2p_ctx* c = b->ctx;
+    const uint64_t n_tx = s->n_tx, n_tk = s->n_tasks, n_h = s->n_haps;
+    // tiles of K transcripts, one wave each: about 450 items (tasks + transcripts) per tile, so that a tile's descriptors fit the
+    // wave's LDS stage; deep Task vectors get small K
+    const double items_per_tx = double(n_tk + n_tx + 1) / double(n_tx + 1);
+    uint32_t K = 64, log2K = 6;
+    while (K > 1 && double(K) * items_per_tx > 448.0) { K >>= 1; --log2K; }
+    const uint64_t n_tiles = (n_tx + 1 + K - 1) / K;
+    auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
+    uint64_t off = 0;
+    auto carve = [&](uint64_t bytes) { const uint64_t o = off; off += up8(bytes); return o; };
+    const uint64_t o_hap = carve((n_h + 1) * 8), o_poff = carve(n_tx * 8), o_rlen = carve(n_tx * 4), o_res = carve(n_tx * 4),
+                   o_tb = carve((n_tx + 1) * 8), o_ab = carve((n_tx + 1) * 8), o_code = carve(n_tk + 64), o_sp = carve((n_tk + 16) * 4), o_ln = carve((n_tk + 16) * 4),
+                   o_sr = carve((n_tk + 16) * 4), o_hoff = carve(fasta ? n_tx * 8 : 0), o_hlen = carve(fasta ? n_tx * 4 : 0),
+                   o_tbytes = carve(n_tiles * 8), o_tbase = carve((n_tiles + 1) * 8), o_tstate = carve(n_tiles * 8), o_totals = carve(64),
+                   o_scan = carve(rows_scan_scratch_entries(n_tiles) * 8);
+    HIP_TRY(c, b->d_build.ensure(off), "hipMalloc(build)");
+    uint8_t* const d = b->d_build.ptr();
+    HIP_TRY(c, b->d_payload.ensure(s->n_alt), "hipMalloc(alt)");
+#define UP(dst_off, src, bytes, what) do { if (bytes) HIP_TRY(c, hipMemcpyAsync(d + (dst_off), (src), (bytes), hipMemcpyHostToDevice, c->stream), what); } while (0)
+    UP(o_hap, s->hap_tx_begin, (n_h + 1) * 8, "H2D(hap_tx_begin)"); UP(o_poff, s->tx_proteome_off, n_tx * 8, "H2D(tx_proteome_off)");
+    UP(o_rlen, s->tx_ref_len, n_tx * 4, "H2D(tx_ref_len)"); UP(o_res, s->tx_res_len, n_tx * 4, "H2D(tx_res_len)");
+    UP(o_tb, s->tx_task_begin, (n_tx + 1) * 8, "H2D(tx_task_begin)"); UP(o_ab, s->tx_alt_begin, (n_tx + 1) * 8, "H2D(tx_alt_begin)");
+    UP(o_code, s->code, n_tk, "H2D(code)"); UP(o_sp, s->start_pos, n_tk * 4, "H2D(start_pos)"); UP(o_ln, s->length, n_tk * 4, "H2D(length)");
+    UP(o_sr, s->start_pos_res, n_tk * 4, "H2D(start_pos_res)");
+    if (fasta) { UP(o_hoff, s->tx_header_off, n_tx * 8, "H2D(tx_header_off)"); UP(o_hlen, s->tx_header_len, n_tx * 4, "H2D(tx_header_len)"); }
+#undef UP
+    if (s->n_alt) HIP_TRY(c, hipMemcpyAsync(b->d_payload.ptr(), s->alt, s->n_alt, hipMemcpyHostToDevice, c->stream), "H2D(alt)");
+    int rc = init_status(c, b->d_status);
+    if (rc) return rc;
+    struct Cleanup {
+        hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        DevBuf scratch, cover;
+        v2p_batch* b;
+        bool ok = false;
+        explicit Cleanup(v2p_batch* b_) : b(b_) {}
+        ~Cleanup() {
+            for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+            scratch.release(); cover.release();
+            b->d_build.release();
+            if (!ok) { b->img.hap_out_begin.assign(1, 0); b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0; }
+        }
+    } guard(b);
+    for (hipEvent_t& e : guard.ev) HIP_TRY(c, hipEventCreate(&e), "hipEventCreate");
+    RowsArgs a{};
+    a.n_tx = n_tx; a.n_tasks = n_tk; a.n_alt = s->n_alt; a.n_haps = n_h;
+    a.hap_tx_begin = reinterpret_cast<const uint64_t*>(d + o_hap); a.tx_proteome_off = reinterpret_cast<const uint64_t*>(d + o_poff);
+    a.tx_ref_len = reinterpret_cast<const uint32_t*>(d + o_rlen); a.tx_res_len = reinterpret_cast<const uint32_t*>(d + o_res);
+    a.tx_task_begin = reinterpret_cast<const uint64_t*>(d + o_tb); a.tx_alt_begin = reinterpret_cast<const uint64_t*>(d + o_ab);
+    a.code = d + o_code; a.start_pos = reinterpret_cast<const uint32_t*>(d + o_sp); a.length = reinterpret_cast<const uint32_t*>(d + o_ln);
+    a.start_pos_res = reinterpret_cast<const uint32_t*>(d + o_sr); a.alt = b->d_payload.ptr();
+    a.tx_header_off = fasta ? reinterpret_cast<const uint64_t*>(d + o_hoff) : nullptr;
+    a.tx_header_len = fasta ? reinterpret_cast<const uint32_t*>(d + o_hlen) : nullptr;
+    a.proteome_len = c->proteome_len; a.K = K; a.log2K = log2K; a.n_tiles = n_tiles;
+    a.tile_bytes = reinterpret_cast<uint64_t*>(d + o_tbytes); a.tile_res_base = reinterpret_cast<uint64_t*>(d + o_tbase);
+    a.tile_state = reinterpret_cast<uint64_t*>(d + o_tstate); a.totals = reinterpret_cast<uint64_t*>(d + o_totals);
+    a.status = reinterpret_cast<unsigned long long*>(b->d_status.ptr());
+    // 1. res_counter per tile (haplotype_instruction.rs:90,132 as a scan); the host needs the arena's size for the row map
+    HIP_TRY(c, hipEventRecord(guard.ev[0], c->stream), "hipEventRecord");
+    HIP_TRY(c, launch_rows_tile_bytes(a, reinterpret_cast<uint64_t*>(d + o_scan), c->stream), "launch(tile bytes)");
+    HIP_TRY(c, hipEventRecord(guard.ev[1], c->stream), "hipEventRecord");
+    uint64_t out_bytes = 0;
+    HIP_TRY(c, hipMemcpyAsync(&out_bytes, d + o_tbase + n_tiles * 8, 8, hipMemcpyDeviceToHost, c->stream), "D2H(out_bytes)");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    const uint64_t n_rows = (out_bytes + ROW_BYTES - 1) / ROW_BYTES, n_segs = (n_rows + ROWS_SEG - 1) / ROWS_SEG;
+    if (n_rows > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 rows in one batch");
+    a.out_bytes = out_bytes; a.n_rows = n_rows; a.n_segs = n_segs;
+    // scratch of the parse and the count pass of the cutter: row map, chunks per segment + their scan
+    const uint64_t c_cover = 0, c_segc = up8((n_rows + 1) * 8), c_segb = c_segc + up8((n_segs + 1) * 4), c_tiles = c_segb + up8((n_segs + 2) * 8),
+                   c_end = c_tiles + up8(scan_tiles_for(n_segs + 1) * 8);
+    HIP_TRY(c, guard.cover.ensure(c_end), "hipMalloc(row map)");
+    a.cover = reinterpret_cast<uint64_t*>(guard.cover.ptr() + c_cover);
+    a.seg_count = reinterpret_cast<uint32_t*>(guard.cover.ptr() + c_segc);
+    a.seg_base = reinterpret_cast<const uint64_t*>(guard.cover.ptr() + c_segb);
+    HIP_TRY(c, b->d_hap.ensure((n_h + 1) * 8), "hipMalloc(hap_begin)");
+    a.hap_out_begin = reinterpret_cast<uint64_t*>(b->d_hap.ptr());
+    // the descriptor array: every task at most one descriptor (+ one '.' fill if there is a gap in front of it: second attempt),
+    // every transcript at most three more (fill, line feed, header), runs of more than 4 MiB one per piece
+    const uint64_t per_head = fasta ? 3 : 1;
+    uint64_t desc_cap = n_tk + per_head * (n_tx + 1) + out_bytes / PIECE_MAX + 64;
+    bool two_phase = false;
+    uint64_t totals[4] = {0, 0, 0, 0}, n_chunks = 0;
+    float ms_parse = 0.f;
+    for (int attempt = 0; ; ++attempt) {
+        HIP_TRY(c, b->d_desc.ensure(desc_cap * 8), "hipMalloc(desc)");
+        a.desc = reinterpret_cast<uint64_t*>(b->d_desc.ptr()); a.desc_cap = desc_cap;
+        HIP_TRY(c, hipMemsetAsync(d + o_tstate, 0, n_tiles * 8, c->stream), "hipMemset(tile state)");
+        HIP_TRY(c, hipMemsetAsync(d + o_totals, 0, 64, c->stream), "hipMemset(totals)");
+        HIP_TRY(c, hipEventRecord(guard.ev[2], c->stream), "hipEventRecord");
+        HIP_TRY(c, launch_rows_parse(a, mode, two_phase, c->stream), "launch(parse)");
+        HIP_TRY(c, launch_rows_hap_begin(a, c->stream), "launch(hap_begin)");
+        HIP_TRY(c, launch_rows_cut(a, mode, false, c->stream), "launch(cut: count)");
+        HIP_TRY(c, launch_scan_u32(a.seg_count, n_segs, const_cast<uint64_t*>(a.seg_base), reinterpret_cast<uint64_t*>(guard.cover.ptr() + c_tiles), c->stream), "launch(scan)");
+        HIP_TRY(c, hipEventRecord(guard.ev[3], c->stream), "hipEventRecord");
+        HIP_TRY(c, hipMemcpyAsync(totals, d + o_totals, 32, hipMemcpyDeviceToHost, c->stream), "D2H(totals)");
+        HIP_TRY(c, hipMemcpyAsync(&n_chunks, guard.cover.ptr() + c_segb + n_segs * 8, 8, hipMemcpyDeviceToHost, c->stream), "D2H(n_chunks)");
+        unsigned long long st = STATUS_CLEAN;
+        HIP_TRY(c, hipMemcpyAsync(&st, b->d_status.ptr(), 8, hipMemcpyDeviceToHost, c->stream), "D2H(status)");
+        HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, guard.ev[2], guard.ev[3]);
+        ms_parse += ms;
+        const uint32_t reason = st == STATUS_CLEAN ? 0u : uint32_t(st & 0xFFu);
+        if ((reason == STATUS_ROWS_STAGE || reason == STATUS_ROWS_CAP) && attempt < 3) {
+            // a tile that does not fit the wave's stage: every tile counted first, then written straight to the arrays; tasks behind
+            // gaps: the full bound (a '.' fill in front of every task)
+            if (reason == STATUS_ROWS_STAGE) two_phase = true;
+            else desc_cap = 2 * n_tk + 3 * (n_tx + 1) + out_bytes / PIECE_MAX + 64;
+            rc = init_status(c, b->d_status);
+            if (rc) return rc;
+            continue;
+        }
+        if (reason == STATUS_ROWS_TOO_MANY) {
+            (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream);
+            return c->fail(V2P_ERR_UNSUPPORTED, mode == ROWS_DENSE ? "a 1 KiB row of the result holds more than 1024 descriptors"
+                                                                   : "a 1 KiB row of the result holds more than 64 descriptors: not a wave image (kernel 7 builds a dense one)", int64_t(st >> 8));
+        }
+        rc = collect_status(c, b->d_status);              // what the reference would panic on
+        if (rc) { (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return rc; }
+        break;
+    }
+    const uint64_t n_desc = totals[0], last_dst = totals[2];
+    if (n_chunks > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch");
+    // 2. the chunk table: emit, keys, XCD / window order inside blocks of the arena (as the host packer's)
+    const uint64_t cap = n_chunks ? n_chunks : 1;
+    const uint64_t n_blocks_cap = order_blocks_thread_blocks(cap, XCD_ORDER_MAX_BLOCKS);
+    const uint64_t n_sub_cap = uint64_t(XCD_SUB) * n_blocks_cap;
+    const uint64_t s_tmp = 0, s_bucket = s_tmp + up8(cap * 16), s_hist = s_bucket + up8(cap),
+                   s_sub = s_hist + up8((n_blocks_cap + 1) * 8 * 4), s_tmp2 = s_sub + up8(cap), s_bucket2 = s_tmp2 + up8(cap * 16),
+                   s_subhist = s_bucket2 + up8(cap), s_substart = s_subhist + up8(n_sub_cap * 4), s_subtiles = s_substart + up8((n_sub_cap + 1) * 8),
+                   s_tot = s_subtiles + up8(scan_tiles_for(n_sub_cap) * 8), s_end = s_tot + up8(uint64_t(XCD_ORDER_MAX_BLOCKS) * 8 * 4);
+    DevBuf& scratch = guard.scratch;
+    HIP_TRY(c, scratch.ensure(s_end), "hipMalloc(build scratch)");
+    HIP_TRY(c, b->d_chunks.ensure(cap * sizeof(Chunk)), "hipMalloc(chunks)");
+    HIP_TRY(c, b->d_out.ensure((out_bytes + 15) & ~15ull), "hipMalloc(out)");
+    HIP_TRY(c, b->d_digest.ensure((n_h ? n_h : 1) * 8), "hipMalloc(digest)");
+    a.chunks_tmp = reinterpret_cast<Chunk*>(scratch.ptr() + s_tmp);
+    a.bucket = scratch.ptr() + s_bucket;
+    a.sub = scratch.ptr() + s_sub;
+    HIP_TRY(c, hipEventRecord(guard.ev[4], c->stream), "hipEventRecord");
+    HIP_TRY(c, launch_rows_cut(a, mode, true, c->stream), "launch(cut: emit)");
+    const bool reorder = !(c->flags & V2P_FLAG_RESULT_ORDER) && n_chunks >= 16 && c->proteome_len != 0 && n_desc != 0;
+    if (reorder) {
+        HIP_TRY(c, launch_rows_keys(a, n_chunks, n_desc, c->stream), "launch(keys)");
+        const uint32_t nb = xcd_order_blocks(last_dst, c->proteome_len, n_chunks, XCD_ORDER_MAX_BLOCKS, n_desc);
+        HIP_TRY(c, launch_order_blocks(a.chunks_tmp, a.bucket, a.sub, n_chunks, nb, reinterpret_cast<uint32_t*>(scratch.ptr() + s_subhist),
+                                       reinterpret_cast<uint64_t*>(scratch.ptr() + s_substart), reinterpret_cast<uint64_t*>(scratch.ptr() + s_subtiles),
+                                       reinterpret_cast<Chunk*>(scratch.ptr() + s_tmp2), scratch.ptr() + s_bucket2, reinterpret_cast<uint32_t*>(scratch.ptr() + s_hist),
+                                       reinterpret_cast<uint32_t*>(scratch.ptr() + s_tot), reinterpret_cast<Chunk*>(b->d_chunks.ptr()), c->stream), "launch(order)");
+    } else if (n_chunks) HIP_TRY(c, hipMemcpyAsync(b->d_chunks.ptr(), a.chunks_tmp, n_chunks * sizeof(Chunk), hipMemcpyDeviceToDevice, c->stream), "D2D(chunks)");
+    HIP_TRY(c, hipEventRecord(guard.ev[5], c->stream), "hipEventRecord");
+    b->img.hap_out_begin.assign(n_h + 1, 0);
+    HIP_TRY(c, hipMemcpyAsync(b->img.hap_out_begin.data(), b->d_hap.ptr(), (n_h + 1) * 8, hipMemcpyDeviceToHost, c->stream), "D2H(hap_begin)");
+    rc = collect_status(c, b->d_status);
+    if (rc) { (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return rc; }
+    float ms0 = 0.f, ms2 = 0.f;
+    (void)hipEventElapsedTime(&ms0, guard.ev[0], guard.ev[1]);
+    (void)hipEventElapsedTime(&ms2, guard.ev[4], guard.ev[5]);
+    if (build_ms) *build_ms = ms0 + ms_parse + ms2;
+    guard.ok = true;
+    b->n_desc = n_desc; b->n_chunks = n_chunks; b->n_payload = s->n_alt; b->out_bytes = out_bytes; b->n_haps = n_h;
+    b->launch_hint = (mode == ROWS_DENSE ? 2 : 4) | 8 | 16 | 32 | (1 << 6) | (1 << 8);
+    b->uses_proteome = true;
+    b->finalized = true;
+    return V2P_OK;
+}
+
 // ---- image build on the device ---------------------------------------------------------------------------------------------
 int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t window_bytes, int kernel, float* build_ms)
 {
@@ -1040,7 +1212,8 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     if (b->hap_open || b->img.n_haplotypes()) return c->fail(V2P_ERR_STATE, "the batch already holds host-built haplotypes");
     const bool split = kernel == 5;                       // wave windows that may split once (65 .. 127 descriptors -> two chunks)
     if (split) kernel = 4;
-    if (window_bytes == 0 || window_bytes % (kernel == 4 ? 1024u : 4096u) || window_bytes > CHUNK_BYTES - 4080u)
+    const bool rows = kernel == 6 || kernel == 7;         // ROWS images (round 4): one pass, whole descriptors, chunks cut on 1 KiB rows afterwards; no window
+    if (!rows && (window_bytes == 0 || window_bytes % (kernel == 4 ? 1024u : 4096u) || window_bytes > CHUNK_BYTES - 4080u))
         return c->fail(V2P_ERR_INVALID_ARG, "window_bytes must be a multiple of 4096 (wave images: of 1024), at most 61440");
     if (kernel == 1 && window_bytes > CHUNK_BYTES_LONG) return c->fail(V2P_ERR_INVALID_ARG, "the long-run kernel takes windows of at most 32768 bytes");
     if (kernel == 4 && window_bytes > CHUNK_BYTES_WAVE) return c->fail(V2P_ERR_INVALID_ARG, "a wave image takes windows of at most 10240 bytes (one chunk = ten 1 KiB rows of one wave)");
@@ -1085,6 +1258,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
         }
     }
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    if (rows) return build_rows_image(b, s, kernel == 7 ? ROWS_DENSE : ROWS_WAVE, fasta, build_ms);
     const uint64_t n_tx = s->n_tx, n_tk = s->n_tasks, n_h = s->n_haps;
     const uint64_t n_tiles = (n_tx + 1023) / 1024 + 2;
     // one device allocation, carved: stream arrays, then scratch
