@@ -11,6 +11,7 @@ namespace v2p {
 constexpr uint32_t STATUS_ROWS_TOO_MANY = 5;       // a 1 KiB row holds more descriptors than a chunk may (= build_kernels.h: STATUS_TOO_MANY)
 constexpr uint32_t STATUS_ROWS_STAGE = 6;          // a tile's descriptors / rows do not fit the wave's LDS stage: rebuild with the two-phase kernel
 constexpr uint32_t STATUS_ROWS_CAP = 7;            // the descriptor array is too small (tasks behind gaps): rebuild with the full bound
+constexpr uint32_t STATUS_ROWS_SPAN = 8;           // a tile of transcripts spans more than 2 GiB of result
 
 struct RowsArgs {
     // the transcript stream (v2p_txstream), on the device
@@ -35,11 +36,14 @@ struct RowsArgs {
     uint64_t n_tiles;
     uint64_t* tile_bytes;               // [n_tiles] arena bytes of each tile -> (scan) tile_res_base
     uint64_t* tile_res_base;            // [n_tiles + 1]
-    uint64_t* tile_state;               // [n_tiles] decoupled look-back over the tiles' descriptor counts: flag << 62 | value
-    uint64_t* totals;                   // [4]: descriptors, chunks, result offset of the last chunk, -
+    uint32_t* tile_count;               // [n_tiles] descriptors of each tile -> (scan) tile_desc_base
+    uint64_t* tile_desc_base;           // [n_tiles + 1]
+    uint64_t* desc_pad;                 // [n_tiles * ROWS_PAD] the tiles' descriptors before compaction
+    uint64_t* totals;                   // [4]: -, -, result offset of the last chunk, -
     uint64_t* desc;
     uint64_t  desc_cap;
-    uint64_t* cover;                    // [n_rows] per 1 KiB row of the arena: descriptor covering its first byte << 22 | offset inside it
+    uint64_t* cover;                    // [n_rows] per 1 KiB row of the arena, the descriptor covering its first byte: tile : 26 | index inside the tile : 16 |
+                                        // offset inside the descriptor : 22 -- or, from the two-pass form, 1 << 63 | index << 22 | offset
     uint64_t  n_rows, out_bytes;
     // the cutter
     uint32_t* seg_count;                // [n_segs] chunks of each segment of ROWS_SEG rows
@@ -50,14 +54,18 @@ struct RowsArgs {
     uint8_t*  sub;
     uint64_t* hap_out_begin;
     unsigned long long* status;
+    uint32_t dbg;                       // development only (V2P_ROWS_DBG, results are wrong): 1 no look-back, 2 no write-out, 4 one window per tile
 };
 
 // arena bytes per tile (+ u64 exclusive scan into tile_res_base, total behind the last tile)
 hipError_t launch_rows_tile_bytes(const RowsArgs& a, uint64_t* scan_scratch, hipStream_t stream);
 uint64_t rows_scan_scratch_entries(uint64_t n);
-// the parse: mode ROWS_WAVE / ROWS_DENSE; two_phase: every tile counted first and written straight to the arrays afterwards
-// (no LDS stage: any tile size); grid = persistent waves (all co-resident), computed here
-hipError_t launch_rows_parse(const RowsArgs& a, int mode, bool two_phase, hipStream_t stream);
+constexpr uint32_t ROWS_PAD_SLOTS = 256;           // descriptor slots per tile in the padded array (= build_rows.hip: ROWS_PAD)
+// the parse: mode ROWS_WAVE / ROWS_DENSE; phase 0: descriptors into the padded array + tile_count (a tile that does not fit its slots
+// is reported: STATUS_ROWS_STAGE), 1: tile_count only, 2: descriptors straight to desc + tile_desc_base[tile] (the two-pass form: any tile)
+hipError_t launch_rows_parse(const RowsArgs& a, int mode, bool fasta, int phase, hipStream_t stream);
+// padded -> dense (tile_desc_base = the scan of tile_count)
+hipError_t launch_rows_compact(const RowsArgs& a, hipStream_t stream);
 hipError_t launch_rows_hap_begin(const RowsArgs& a, hipStream_t stream);
 // the cutter: count pass (seg_count, totals[2] = last chunk's result offset), then -- after the scan of seg_count -- the emit pass
 // (chunks_tmp in arena order) and the proteome slice / window of every chunk (bucket, sub)

@@ -106,80 +106,146 @@ __global__ __launch_bounds__(256) void rows_scan_apply(const uint64_t* __restric
 }
 
 // ---- the parse ------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t ROWS_CAP = 384;             // descriptors a wave stages in LDS per tile
-constexpr uint32_t ROWS_CAPR = 128;            // rows of the arena a tile may touch (their cover entries are staged too)
-enum : int { PH_STAGE = 0, PH_COUNT = 1, PH_DIRECT = 2 };
-constexpr uint64_t LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_VALUE = (1ull << 62) - 1;
+// What bounds it (measured, profiles/r04_build_*): vector-instruction issue.  A window of 64 items costs a few hundred VALU
+// instructions however its loads are arranged (a burst of the tile's Task arrays into LDS with global_load_lds changed nothing; a
+// decoupled look-back for the descriptors' final place cost a third of the kernel: persistent waves run in lockstep, so every
+// generation of tiles waits for the prefix to ripple through it).  So: one tile per 64-lane workgroup, plain grid; descriptors go
+// to a PADDED array -- ROWS_PAD slots per tile -- and a copy kernel compacts them once a scan of the tiles' counts has told every
+// tile where it starts; positions are 32-bit offsets from the tile's first emitted byte; per-transcript values sit in LDS as
+// arrays of words; everything rare (runs of more than 1 KiB, which may cross two rows, or of more than a descriptor's length
+// field) is behind one wave-uniform branch.
+constexpr uint32_t ROWS_PAD = 256;             // descriptor slots per tile in the padded array (a tile with more: the two-pass form)
+enum : int { PH_PAD = 0, PH_COUNT = 1, PH_DIRECT = 2 };
 
-struct __attribute__((aligned(16))) TxRec { uint64_t poff, alt0, res_base, hsrc; uint32_t ref_len, res_len, n_alt, hl; };
-static_assert(sizeof(TxRec) == 48, "three 16-byte LDS reads");
-
-struct WaveLds {
-    TxRec tx[65];                              // slot j = transcript t0 - 1 + j
-    uint64_t stage[ROWS_CAP];
-    uint64_t cover[ROWS_CAPR];
+struct __attribute__((aligned(16))) WaveLds {
+    uint64_t base[2][66];                      // [0]: proteome offset of the slot's transcript, [1]: its alt tape's offset (slot j = transcript t0 - 1 + j)
+    uint32_t bound[2][66];                     // [0]: its reference length, [1]: its alt tape's length
+    uint32_t res_len[66];
+    uint32_t pos[66];                          // arena offset of its first result byte (behind its FASTA header) minus the tile's first emitted byte
+    uint32_t hl[66];                           // FASTA: length of its record header (0: none)
+    uint64_t hsrc[66];                         // ... and where the header sits in the resident reference
     uint32_t flag[16];                         // one byte per lane: the item is a HEAD
 };
 
-// One tile's windows.  PHASE: PH_STAGE descriptors and cover entries into LDS (the caller writes them out once it knows where the
-// tile's descriptors start), PH_COUNT nothing (count only), PH_DIRECT straight to the arrays from descriptor `base` on.
-// Returns the number of descriptors of the tile; *over: something did not fit the stage.
-template <int MODE, int PHASE>
-__device__ __forceinline__ uint32_t rows_tile(const RowsArgs& a, WaveLds& L, uint32_t lane, uint64_t t0, uint32_t nh, uint64_t I0, uint64_t I1, uint64_t hp,
-                                              uint32_t carry_e0, uint64_t row_first, uint64_t base, bool& over)
+// PHASE: PH_PAD descriptors to the tile's slots of the padded array and its count to tile_count (a tile that does not fit is
+// reported); PH_COUNT only the count; PH_DIRECT descriptors to their final place (tile_desc_base: the scan of the counts).
+template <int MODE, bool FASTA, int PHASE>
+__global__ __launch_bounds__(64) void rows_parse_kernel(RowsArgs a)
 {
     constexpr uint32_t CTX = MODE == ROWS_DENSE ? 4u : 2u, ADV = 62u - CTX;
+    __shared__ WaveLds L;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t tile = blockIdx.x;
+    const uint64_t n_heads = a.n_tx + 1u;
+    const uint64_t t0 = tile << a.log2K;
+    const uint32_t nh = uint32_t(n_heads - t0 < a.K ? n_heads - t0 : a.K);
+    const uint64_t t1 = t0 + nh;
+    const uint64_t task_lo = a.tx_task_begin[t0], task_end = t1 <= a.n_tx ? a.tx_task_begin[t1] : a.n_tasks;
+    const uint64_t tile_base = a.tile_res_base[tile];
+    // end of the last task before the tile: HEAD(t0) fills the rest of the transcript before it with '.'
+    uint32_t carry_e = 0, prev_res_len = 0, prev_hl = 0;
+    uint64_t prev_hsrc = 0;
+    if (t0 > 0) {
+        prev_res_len = a.tx_res_len[t0 - 1u];
+        if (FASTA) { prev_hl = a.tx_header_len[t0 - 1u]; prev_hsrc = prev_hl ? a.proteome_len + a.tx_header_off[t0 - 1u] : 0ull; }
+        if (task_lo > a.tx_task_begin[t0 - 1u]) { const uint64_t i = task_lo - 1u; carry_e = a.start_pos_res[i] + a.length[i]; }
+    }
+    // the tile's descriptors start where the transcript BEFORE it left off (HEAD(t0) writes that one's '.' fill and line feed): positions
+    // are 32-bit offsets from there (a tile of more than 2 GiB of result takes the two-pass form with K = 1 ... refused below)
+    const uint32_t prev_tail = (prev_res_len > carry_e ? prev_res_len - carry_e : 0u) + (prev_hl ? 1u : 0u);
+    const uint64_t ebase = tile_base - prev_tail;
+    const uint64_t tile_end = a.tile_res_base[tile + 1u];
+    if (tile_end - ebase > 0x7FFFFFFFull) { if (lane == 0) rreport(a.status, task_lo, STATUS_ROWS_SPAN); if (PHASE != PH_DIRECT && lane == 0) a.tile_count[tile] = 0u; return; }
+    const uint32_t eoff = uint32_t(ebase) & (ROW_BYTES - 1u);        // the tile's first emitted byte inside its row
+    const uint64_t erow = ebase / ROW_BYTES;
+    // ---- the tile's transcripts: slot lane + 1 = transcript t0 + lane, slot 0 = the one before the tile ----
+    uint32_t hp = 0xFFFFFFFFu;                                       // item (relative to the tile's first) of the lane's HEAD
+    {
+        const uint64_t u = t0 + lane;
+        const bool valid = lane < nh && u < a.n_tx;
+        uint64_t poff = 0, alt0 = 0, hsrc = 0;
+        uint32_t ref_len = 0, res_len = 0, n_alt = 0, hl = 0, alen = 0;
+        if (lane < nh) hp = uint32_t(a.tx_task_begin[u] - task_lo) + lane;
+        if (valid) {
+            poff = a.tx_proteome_off[u]; alt0 = a.tx_alt_begin[u]; n_alt = uint32_t(a.tx_alt_begin[u + 1] - alt0);
+            ref_len = a.tx_ref_len[u]; res_len = a.tx_res_len[u];
+            if (FASTA) { hl = a.tx_header_len[u]; hsrc = hl ? a.proteome_len + a.tx_header_off[u] : 0ull; }
+            alen = res_len + (hl ? hl + 1u : 0u);                    // (< 2^31 in total: checked above)
+            if (PHASE != PH_DIRECT && poff + ref_len > a.proteome_len) rreport(a.status, a.tx_task_begin[u], STATUS_SRC_OOB);   // transcript outside the resident proteome
+        }
+        const uint32_t rb = prev_tail + wave_incl_scan(alen) - alen;  // the transcript's first arena byte, from ebase
+        if (lane < nh) {
+            L.base[0][lane + 1u] = poff; L.base[1][lane + 1u] = alt0; L.bound[0][lane + 1u] = ref_len; L.bound[1][lane + 1u] = n_alt;
+            L.res_len[lane + 1u] = res_len; L.pos[lane + 1u] = rb + hl;
+            if (FASTA) { L.hl[lane + 1u] = hl; L.hsrc[lane + 1u] = hsrc; }
+        }
+        if (lane == 0) {
+            L.res_len[0] = prev_res_len; L.pos[0] = 0u - carry_e;    // (slot 0's tasks ended at carry_e: its '.' fill starts at offset 0)
+            if (FASTA) { L.hl[0] = prev_hl; L.hsrc[0] = prev_hsrc; }
+        }
+    }
+    asm volatile("" ::: "memory");
+    const uint32_t n_items = uint32_t(task_end - task_lo) + nh;
+    const uint8_t* const g_code = a.code + task_lo;
+    const uint32_t* const g_sp = a.start_pos + task_lo;
+    const uint32_t* const g_ln = a.length + task_lo;
+    const uint32_t* const g_sr = a.start_pos_res + task_lo;
+    uint64_t* const out = PHASE == PH_PAD ? a.desc_pad + tile * ROWS_PAD : (PHASE == PH_DIRECT ? a.desc + a.tile_desc_base[tile] : nullptr);
+    (void)out;
+    const uint32_t out_cap = PHASE == PH_PAD ? ROWS_PAD : 0xFFFFFFFFu;
+    // cover entry: tile : 25 | descriptor inside the tile : 16 | offset inside it : 22 -- the two-pass form: 1 << 63 | descriptor << 22 | offset
+    const uint64_t dbase = PHASE == PH_DIRECT ? a.tile_desc_base[tile] : 0ull;
+    auto cover_word = [&](uint32_t dk, uint32_t off) -> uint64_t { return PHASE == PH_DIRECT ? (1ull << 63) | ((dbase + dk) << 22) | off : (tile << 38) | (uint64_t(dk) << 22) | off; };
+
     uint32_t tile_cnt = 0;                     // descriptors of the tile so far (wave-uniform)
-    uint32_t carry_e = carry_e0;
     uint64_t carry_h = 0, carry_second = 0;
     bool first = true;
-    for (uint64_t R0 = I0; ; R0 += ADV) {
-        const uint32_t nvalid = uint32_t(I1 - R0 < 64u ? I1 - R0 : 64u);
-        const bool last = R0 + 64u >= I1;
+    for (uint32_t R0 = 0; ; R0 += ADV) {
+        const uint32_t nvalid = n_items - R0 < 64u ? n_items - R0 : 64u;
+        const bool last = R0 + 64u >= n_items;
         const uint32_t e_lo = first ? 0u : CTX, e_hi = last ? nvalid : 62u;
         // ---- which items are HEADs, and every item's transcript ----
         if (lane < 16u) L.flag[lane] = 0u;
         asm volatile("" ::: "memory");
-        const bool my_head_in = lane < nh && hp >= R0 && hp < R0 + 64u;
-        if (my_head_in) reinterpret_cast<uint8_t*>(L.flag)[uint32_t(hp - R0)] = 1u;
+        if (hp - R0 < 64u) reinterpret_cast<uint8_t*>(L.flag)[hp - R0] = 1u;
         asm volatile("" ::: "memory");
         const bool active = lane < nvalid;
         const bool isHead = reinterpret_cast<const uint8_t*>(L.flag)[lane] != 0u;      // (lanes >= nvalid: no HEAD of this tile lies there)
         const uint64_t headmask = __ballot(isHead);
-        const uint32_t heads_before = uint32_t(__popcll(__ballot(lane < nh && hp < R0)));
+        const uint32_t heads_before = uint32_t(__popcll(__ballot(hp < R0)));
         const uint32_t slot = heads_before + mbcnt(headmask) + (isHead ? 1u : 0u);       // slot of the item's transcript (a HEAD: the one it opens)
         const bool isTask = active && !isHead;
-        const uint64_t item = R0 + lane;
-        const uint64_t ti = item - (t0 + slot - 1u) - 1u;                                // task index
-        // ---- the stream: one coalesced load per array ----
+        const uint32_t ti = R0 + lane - slot;                                            // task, relative to the tile's first
         uint32_t code = 0, sp = 0, ln = 0, sr = 0;
-        if (isTask) { code = a.code[ti]; sp = a.start_pos[ti]; ln = a.length[ti]; sr = a.start_pos_res[ti]; }
-        const TxRec x = L.tx[slot < 65u ? slot : 0u];
+        if (isTask) { code = g_code[ti]; sp = g_sp[ti]; ln = g_ln[ti]; sr = g_sr[ti]; }
+        const uint32_t res_len = L.res_len[slot], pos0 = L.pos[slot];
         // ---- update_task / Task::execute checks; result positions ----
-        const bool res_oob = isTask && uint64_t(sr) + ln > x.res_len;
+        const bool res_oob = isTask && (ln > res_len || sr > res_len - ln);
         const uint32_t e = isTask && !res_oob ? sr + ln : 0u;                             // end of the task inside its transcript's result
         const uint32_t pe = up1(e, carry_e);                                              // ... of the item before
+        const uint32_t csel = code == 1u ? 1u : 0u;
+        const uint32_t bound = L.bound[csel][slot];
         uint32_t why = 0;
         if (isTask) {
             if (code > 1u) why = STATUS_BAD_CODE;
             else if (res_oob) why = STATUS_RES_OOB;
-            else if (uint64_t(sp) + ln > (code == 0u ? x.ref_len : x.n_alt)) why = STATUS_SRC_OOB;
+            else if (ln > bound || sp > bound - ln) why = STATUS_SRC_OOB;
             else if (sr < pe) why = STATUS_NOT_CONTIGUOUS;
         }
         const bool in_emit = lane >= e_lo && lane < e_hi;
-        if (why != 0u && in_emit && PHASE != PH_DIRECT) rreport(a.status, ti, why);
+        if (PHASE != PH_DIRECT && __ballot(why != 0u && in_emit)) { if (why != 0u && in_emit) rreport(a.status, task_lo + ti, why); }
         const bool good = isTask && why == 0u;
         // ---- classes of the fusion state machine ----
         const bool isRef = good && code == 0u;
         const bool imm = good && code == 1u && ln - 1u < IMM_MAX_BYTES;
-        const uint64_t src = (isRef ? x.poff : x.alt0) + sp;
+        const uint64_t src = L.base[csel][slot] + sp;
         uint64_t lit = 0;
         if (imm) {                                                                        // short alt payloads travel inside their descriptor
             struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
             lit = reinterpret_cast<const U64*>(a.alt + src)->v & (~0ull >> (64u - 8u * ln));
         }
         const bool ps = isRef && ln <= SNV3_MAX_LEN;
-        const bool cA = ps && src + ln + 1u + SNV3_MAX_LEN <= SNV3_MAX_SRC;
+        const bool cA = ps && src + ln <= SNV3_MAX_SRC - 1u - SNV3_MAX_LEN;
         const bool cB = imm && ln == 1u;
         const bool c0 = ps && ln > 0u && src >= 1u && src + ln <= SNV3_MAX_SRC;
         const uint32_t src32 = uint32_t(src);
@@ -204,184 +270,127 @@ __device__ __forceinline__ uint32_t rows_tile(const RowsArgs& a, WaveLds& L, uin
         }
         const uint64_t absorbed = (p.F >> 1) | ((p.F & p.real) >> 2) | (MODE == ROWS_DENSE ? (second >> 2) & p.F : 0ull);
         const bool isAbs = (absorbed >> lane) & 1ull, isSecond = (second >> lane) & 1ull;
-        // ---- what the lane emits: up to three runs of result bytes, in order ----
-        //   HEAD: '.' fill of the transcript it closes, that transcript's line feed, its own header;  task: '.' fill of a gap, itself
-        const TxRec pv = L.tx[isHead ? slot - 1u : 0u];
-        uint64_t w0 = 0, w1 = 0, w2 = 0;                               // descriptor words (w0, w1: plain words whose length may exceed a piece)
-        uint64_t l0 = 0, l1 = 0, l2 = 0, q0 = 0, q1 = 0, q2 = 0;      // lengths, arena positions
-        if (isHead && active) {
-            if (pv.res_len > pe) { l0 = pv.res_len - pe; q0 = pv.res_base + pv.hl + pe; w0 = uint64_t(SPACE_FILL) << 62; }
-            if (pv.hl) { l1 = 1; q1 = pv.res_base + pv.hl + pv.res_len; w1 = ((pv.hsrc + pv.hl - 1u) & SRC_MASK) | (uint64_t(SPACE_PROTEOME) << 62); }
-            if (x.hl) { l2 = x.hl; q2 = x.res_base; w2 = (x.hsrc & SRC_MASK) | (uint64_t(SPACE_PROTEOME) << 62); }
+        // ---- what the lane emits: up to three runs of result bytes, in order, back to back from offset q0 ----
+        //   HEAD: '.' fill of the transcript it closes, [FASTA: that transcript's line feed, its own header];  task: '.' fill of a gap, itself
+        uint32_t w0l = 0, w0h = 0, w1l = 0, w1h = 0, w2l = 0, w2h = 0;      // descriptor words (the length field of a plain one is filled in below)
+        uint32_t l0 = 0, l1 = 0, l2 = 0, q0 = 0;
+        bool fusedw = false;                                                 // w1 is a complete fused word
+        if (isHead) {
+            const uint32_t prl = L.res_len[slot - 1u];
+            q0 = L.pos[slot - 1u] + pe;
+            l0 = prl > pe ? prl - pe : 0u; w0h = SPACE_FILL << 30;
+            if (FASTA) {
+                const uint32_t phl = L.hl[slot - 1u], xhl = L.hl[slot];
+                if (phl) { const uint64_t lf = L.hsrc[slot - 1u] + phl - 1u; l1 = 1u; w1l = uint32_t(lf); w1h = uint32_t(lf >> 32) & 0xFFu; }
+                if (xhl) { const uint64_t hs = L.hsrc[slot]; l2 = xhl; w2l = uint32_t(hs); w2h = uint32_t(hs >> 32) & 0xFFu; }
+            }
         } else if (good) {
-            const uint64_t posbase = x.res_base + x.hl;
-            if (gap) { l0 = sr - pe; q0 = posbase + pe; w0 = uint64_t(SPACE_FILL) << 62; }
+            q0 = pos0 + pe;
+            if (gap) { l0 = sr - pe; w0h = SPACE_FILL << 30; }
             if (isF) {
                 if (!isAbs) {
+                    fusedw = true;
                     if (MODE == ROWS_DENSE && isSecond) {
-                        l1 = uint64_t(p_len1) + 1u + p_len2 + 1u + ln; q1 = posbase + sr - 1u - p_len2 - 1u - p_len1;
-                        w1 = SNV5_MARK | (uint64_t(f_byte) << 52) | (uint64_t(p_byte) << 44) | (uint64_t(ln & 31u) << 39) | (uint64_t(p_len2 & 31u) << 34) | (uint64_t(p_len1 & 31u) << 29) | (uint64_t(p_run) & SNV3_MAX_SRC);
+                        l1 = p_len1 + 1u + p_len2 + 1u + ln; q0 -= p_len1 + p_len2 + 2u;
+                        const uint64_t w = SNV5_MARK | (uint64_t(f_byte) << 52) | (uint64_t(p_byte) << 44) | (uint64_t(ln & 31u) << 39) | (uint64_t(p_len2 & 31u) << 34) | (uint64_t(p_len1 & 31u) << 29) | (uint64_t(p_run) & SNV3_MAX_SRC);
+                        w1l = uint32_t(w); w1h = uint32_t(w >> 32);
                     } else {
-                        l1 = uint64_t(f_len1) + 1u + ln; q1 = posbase + sr - 1u - f_len1;
-                        w1 = SNV3_MARK | (uint64_t(f_byte) << 53) | (uint64_t(ln & 0xFFFu) << 41) | (uint64_t(f_len1 & 0xFFFu) << 29) | (uint64_t(f_run) & SNV3_MAX_SRC);
+                        l1 = f_len1 + 1u + ln; q0 -= f_len1 + 1u;
+                        w1l = (f_run & 0x1FFFFFFFu) | (f_len1 << 29);
+                        w1h = ((f_len1 & 0xFFFu) >> 3) | ((ln & 0xFFFu) << 9) | (f_byte << 21) | (7u << 29);
                     }
                 }
             } else if (!isAbs && ln != 0u) {
-                l1 = ln; q1 = posbase + sr;
-                w1 = imm ? (lit | (uint64_t(SPACE_IMM) << 62)) : ((src & SRC_MASK) | (uint64_t(isRef ? SPACE_PROTEOME : SPACE_PAYLOAD) << 62));
+                l1 = ln;
+                if (imm) { w1l = uint32_t(lit); w1h = uint32_t(lit >> 32) | (SPACE_IMM << 30); }
+                else { w1l = src32; w1h = (uint32_t(src >> 32) & 0xFFu) | ((isRef ? SPACE_PROTEOME : SPACE_PAYLOAD) << 30); }
             }
         }
         if (!in_emit) { l0 = 0; l1 = 0; l2 = 0; }
-        // pieces: a run longer than a descriptor's length field (a '.' fill or copy of more than 4 MiB) is several descriptors
-        const bool fusedw = good && isF;                                                   // (its word is complete: the length is not a field of it)
-        const uint32_t n0 = l0 ? uint32_t((l0 + PIECE_MAX - 1u) / PIECE_MAX) : 0u;
-        const uint32_t n1 = l1 ? (fusedw ? 1u : uint32_t((l1 + PIECE_MAX - 1u) / PIECE_MAX)) : 0u;
-        const uint32_t n2 = l2 ? uint32_t((l2 + PIECE_MAX - 1u) / PIECE_MAX) : 0u;
-        const uint32_t cnt = n0 + n1 + n2;
-        const uint32_t incl = wave_incl_scan(cnt);
-        const uint32_t round_total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
-        if (PHASE != PH_COUNT && round_total != 0u) {
-            uint32_t k = tile_cnt + incl - cnt;                                           // the lane's first slot, tile-relative
-            auto put = [&](uint64_t word, uint64_t len, uint64_t pos, bool whole) {
-                // one run: pieces of at most PIECE_MAX bytes (whole: a ready fused word)
-                const unsigned space = unsigned(word >> 62);
-                uint64_t sfield = word & SRC_MASK;
-                while (len) {
-                    const uint32_t piece = whole ? uint32_t(len) : uint32_t(len < PIECE_MAX ? len : PIECE_MAX);
-                    const uint64_t dword = whole ? word : ((word & ~SRC_MASK) | (sfield & SRC_MASK) | (uint64_t(piece) << 40));
-                    if (PHASE == PH_STAGE) { if (k < ROWS_CAP) L.stage[k] = dword; }
-                    else if (base + k < a.desc_cap) a.desc[base + k] = dword;
-                    // rows whose first byte lies inside the piece
-                    for (uint64_t r = (pos + ROW_BYTES - 1u) / ROW_BYTES; r * ROW_BYTES < pos + piece; ++r) {
-                        if (r == 0u) continue;
-                        const uint64_t off = r * ROW_BYTES - pos;
-                        if (PHASE == PH_STAGE) { const uint64_t rr = r - row_first; if (rr < ROWS_CAPR) L.cover[rr] = (uint64_t(k) << 22) | off; }
-                        else if (r < a.n_rows) a.cover[r] = ((base + k) << 22) | off;
+        // Everything rare behind ONE uniform branch: a run of more than 1 KiB (it may cross two rows of the arena, or exceed a
+        // descriptor's length field and become several descriptors)
+        const bool slow = __ballot(l0 > ROW_BYTES || l1 > ROW_BYTES || (FASTA && l2 > ROW_BYTES)) != 0ull;
+        if (!slow) {
+            const uint32_t c0n = l0 ? 1u : 0u, c1n = l1 ? 1u : 0u, c2n = FASTA && l2 ? 1u : 0u;
+            const uint32_t cnt = c0n + c1n + c2n;
+            const uint32_t incl = wave_incl_scan(cnt);
+            const uint32_t round_total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+            if (PHASE != PH_COUNT && round_total != 0u) {
+                const uint32_t k = tile_cnt + incl - cnt;                                 // the lane's first slot inside the tile
+                if (!fusedw) w1h |= l1 << 8;
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                if (l0 && k < out_cap) *reinterpret_cast<u32x2*>(out + k) = u32x2{w0l, w0h | (l0 << 8)};
+                if (l1 && k + c0n < out_cap) *reinterpret_cast<u32x2*>(out + k + c0n) = u32x2{w1l, w1h};
+                if (FASTA && l2 && k + c0n + c1n < out_cap) *reinterpret_cast<u32x2*>(out + k + c0n + c1n) = u32x2{w2l, w2h | (l2 << 8)};
+                // the rows whose first byte the lane's runs cover: its span is at most 2 (FASTA: 3) KiB + ...; one boundary per run at most
+                const uint32_t s = eoff + q0, t1e = s + l0, t2e = t1e + l1, t3e = t2e + (FASTA ? l2 : 0u);
+                const uint32_t rfirst = (s + ROW_BYTES - 1u) >> 10;                       // first boundary at or behind the span's start
+                if ((rfirst << 10) < t3e && cnt != 0u) {
+                    for (uint32_t r = rfirst; (r << 10) < t3e; ++r) {                      // (one round, rarely two)
+                        const uint32_t rb = r << 10;
+                        const uint32_t which = rb < t1e ? 0u : (rb < t2e ? 1u : 2u);
+                        const uint32_t dk = which == 0u ? k : (which == 1u ? k + c0n : k + c0n + c1n);
+                        const uint32_t off = rb - (which == 0u ? s : (which == 1u ? t1e : t2e));
+                        const uint64_t row = erow + r;
+                        if (row >= 1u && row < a.n_rows) a.cover[row] = cover_word(dk, off);
                     }
-                    if (space == SPACE_PROTEOME || space == SPACE_PAYLOAD) sfield += piece;      // (an immediate is never cut: <= 5 bytes)
-                    len -= piece; pos += piece; ++k;
-                    if (whole) break;
                 }
-            };
-            if (l0) put(w0, l0, q0, false);
-            if (l1) put(w1, l1, q1, fusedw);
-            if (l2) put(w2, l2, q2, false);
+            }
+            tile_cnt += round_total;
+        } else {
+            // the general form: any length, any number of pieces and rows
+            const uint64_t W0 = (uint64_t(w0h) << 32) | w0l, W1 = (uint64_t(w1h) << 32) | w1l, W2 = (uint64_t(w2h) << 32) | w2l;
+            auto pieces = [](uint32_t l) -> uint32_t { return l == 0u ? 0u : (l + PIECE_MAX - 1u) / PIECE_MAX; };
+            const uint32_t n0 = pieces(l0), n1 = fusedw ? (l1 ? 1u : 0u) : pieces(l1), n2 = pieces(l2);
+            const uint32_t cnt = n0 + n1 + n2;
+            const uint32_t incl = wave_incl_scan(cnt);
+            const uint32_t round_total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+            if (PHASE != PH_COUNT && round_total != 0u) {
+                uint32_t k = tile_cnt + incl - cnt;
+                uint32_t pos = eoff + q0;
+                auto put = [&](uint64_t word, uint32_t len, bool whole) {
+                    const unsigned space = unsigned(word >> 62);
+                    uint64_t sfield = word & SRC_MASK;
+                    while (len) {
+                        const uint32_t piece = whole ? len : (len < PIECE_MAX ? len : PIECE_MAX);
+                        const uint64_t dword = whole ? word : ((word & ~SRC_MASK) | (sfield & SRC_MASK) | (uint64_t(piece) << 40));
+                        if (k < out_cap) out[k] = dword;
+                        for (uint32_t r = (pos + ROW_BYTES - 1u) >> 10; (uint64_t(r) << 10) < uint64_t(pos) + piece; ++r) {
+                            const uint64_t row = erow + r;
+                            if (row >= 1u && row < a.n_rows) a.cover[row] = cover_word(k, (r << 10) - pos);
+                        }
+                        if (space == SPACE_PROTEOME || space == SPACE_PAYLOAD) sfield += piece;      // (an immediate is never cut: <= 5 bytes)
+                        len -= piece; pos += piece; ++k;
+                        if (whole) break;
+                    }
+                };
+                if (l0) put(W0, l0, false);
+                if (l1) put(W1, l1, fusedw);
+                if (l2) put(W2, l2, false);
+            }
+            tile_cnt += round_total;
         }
-        tile_cnt += round_total;
         if (last) break;
         carry_h = p.h >> ADV; carry_second = second >> ADV;
         carry_e = uint32_t(__builtin_amdgcn_readlane(int(e), int(ADV - 1u)));
         first = false;
     }
-    if (PHASE == PH_STAGE && tile_cnt > ROWS_CAP) over = true;
-    return tile_cnt;
+    if (PHASE != PH_DIRECT && lane == 0) {
+        a.tile_count[tile] = tile_cnt;
+        if (PHASE == PH_PAD && (tile_cnt > ROWS_PAD || tile_cnt > 0xFFFFu)) rreport(a.status, tile, STATUS_ROWS_STAGE);
+    }
 }
 
-// decoupled look-back over the tiles' descriptor counts: returns the number of descriptors before `tile`
-__device__ __forceinline__ uint64_t rows_lookback(uint64_t* state, uint64_t tile, uint64_t count, uint32_t lane)
+// descriptors out of the padded array into their final, dense place (tile_desc_base: the scan of the tiles' counts): one wave per tile
+__global__ __launch_bounds__(256) void rows_compact_kernel(RowsArgs a)
 {
-    if (tile == 0) {
-        if (lane == 0) __hip_atomic_store(&state[0], LB_PREFIX | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0;
-    }
-    if (lane == 0) __hip_atomic_store(&state[tile], LB_AGG | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint64_t sum = 0;
-    int64_t j = int64_t(tile) - 1;
-    for (;;) {
-        const int64_t idx = j - int64_t(lane);
-        const uint64_t v = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_PREFIX;
-        const uint64_t pm = __ballot((v >> 62) == 2ull), em = __ballot((v >> 62) == 0ull);
-        const uint32_t firstP = pm ? uint32_t(__builtin_ctzll(pm)) : 64u;
-        const uint64_t need = firstP >= 63u ? ~0ull : ((2ull << firstP) - 1ull);          // lanes 0 .. firstP must have published
-        if (em & need) { __builtin_amdgcn_s_sleep(2); continue; }
-        sum += wave_sum64(lane <= firstP ? (v & LB_VALUE) : 0ull);
-        if (firstP < 64u) break;
-        j -= 64;
-    }
-    if (lane == 0) __hip_atomic_store(&state[tile], LB_PREFIX | (sum + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return sum;
-}
-
-template <int MODE, bool TWO_PHASE>
-__global__ __launch_bounds__(64) void rows_parse_kernel(RowsArgs a)
-{
-    __shared__ WaveLds L;
-    const uint32_t lane = threadIdx.x;
-    const uint64_t n_heads = a.n_tx + 1u;
-    for (uint64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const uint64_t t0 = tile << a.log2K;
-        const uint32_t nh = uint32_t(n_heads - t0 < a.K ? n_heads - t0 : a.K);
-        // ---- the tile's transcripts: slot lane + 1 = transcript t0 + lane, slot 0 = the one before the tile ----
-        const uint64_t tile_base = a.tile_res_base[tile];
-        uint64_t hp = ~0ull;
-        {
-            const uint64_t u = t0 + lane;
-            const bool valid = lane < nh && u < a.n_tx;
-            TxRec r{0, 0, 0, 0, 0, 0, 0, 0};
-            uint64_t alen = 0;
-            if (lane < nh) hp = (u <= a.n_tx ? a.tx_task_begin[u] : a.n_tasks) + u;
-            if (valid) {
-                r.poff = a.tx_proteome_off[u]; r.alt0 = a.tx_alt_begin[u]; r.n_alt = uint32_t(a.tx_alt_begin[u + 1] - r.alt0);
-                r.ref_len = a.tx_ref_len[u]; r.res_len = a.tx_res_len[u];
-                r.hl = a.tx_header_len ? a.tx_header_len[u] : 0u;
-                r.hsrc = r.hl ? a.proteome_len + a.tx_header_off[u] : 0ull;
-                alen = uint64_t(r.res_len) + (r.hl ? r.hl + 1u : 0u);
-                if (r.poff + r.ref_len > a.proteome_len) rreport(a.status, a.tx_task_begin[u], STATUS_SRC_OOB);   // transcript outside the resident proteome
-            }
-            r.res_base = tile_base + wave_incl_scan64(alen, lane) - alen;
-            if (lane < nh) L.tx[lane + 1u] = r;
-            if (lane == 0) {
-                TxRec q{0, 0, 0, 0, 0, 0, 0, 0};
-                if (t0 > 0) {
-                    const uint64_t v = t0 - 1u;
-                    q.res_len = a.tx_res_len[v]; q.hl = a.tx_header_len ? a.tx_header_len[v] : 0u;
-                    q.hsrc = q.hl ? a.proteome_len + a.tx_header_off[v] : 0ull;
-                    q.res_base = tile_base - (uint64_t(q.res_len) + (q.hl ? q.hl + 1u : 0u));
-                }
-                L.tx[0] = q;
-            }
-        }
-        asm volatile("" ::: "memory");
-        const uint64_t I0 = t0 <= a.n_tx ? a.tx_task_begin[t0] + t0 : a.n_tasks + n_heads;
-        const uint64_t t1 = t0 + nh;
-        const uint64_t I1 = t1 <= a.n_tx ? a.tx_task_begin[t1] + t1 : a.n_tasks + n_heads;
-        // end of the last task before the tile: HEAD(t0) fills the rest of the transcript before it with '.'
-        uint32_t carry_e = 0;
-        if (t0 > 0 && a.tx_task_begin[t0] > a.tx_task_begin[t0 - 1u]) { const uint64_t i = a.tx_task_begin[t0] - 1u; carry_e = a.start_pos_res[i] + a.length[i]; }
-        // The tile's descriptors start where the transcript BEFORE it left off (HEAD(t0) writes that one's '.' fill and line feed) and
-        // end where its own last transcript's tasks do (the HEAD of the next tile closes it): the rows they may cover
-        const TxRec q0 = L.tx[0];
-        const uint64_t emit_start = tile_base - ((q0.res_len > carry_e ? q0.res_len - carry_e : 0u) + (q0.hl ? 1u : 0u));
-        const uint64_t row_first = (emit_start + ROW_BYTES - 1u) / ROW_BYTES;
-        const uint64_t tile_end = a.tile_res_base[tile + 1u];
-        bool over = false;
-        if (!TWO_PHASE) {
-            const uint64_t n_rows_tile = tile_end > row_first * ROW_BYTES ? (tile_end - row_first * ROW_BYTES + ROW_BYTES - 1u) / ROW_BYTES : 0u;
-            for (uint32_t k = lane; k < ROWS_CAPR; k += 64u) L.cover[k] = ~0ull;
-            asm volatile("" ::: "memory");
-            const uint32_t n = rows_tile<MODE, PH_STAGE>(a, L, lane, t0, nh, I0, I1, hp, carry_e, row_first, 0, over);
-            if (n_rows_tile > ROWS_CAPR) over = true;
-            const uint64_t base = rows_lookback(a.tile_state, tile, n, lane);
-            if (over) { if (lane == 0) rreport(a.status, tile, STATUS_ROWS_STAGE); }
-            else if (base + n > a.desc_cap) { if (lane == 0) rreport(a.status, tile, STATUS_ROWS_CAP); }
-            else {
-                asm volatile("" ::: "memory");
-                for (uint32_t k = lane; k < n; k += 64u) a.desc[base + k] = L.stage[k];
-                for (uint32_t k = lane; k < n_rows_tile; k += 64u) {                  // (rows behind the tile's last task belong to the next tile)
-                    const uint64_t r = row_first + k, c = L.cover[k];
-                    if (c != ~0ull && r >= 1u && r < a.n_rows) a.cover[r] = c + (base << 22);
-                }
-            }
-            if (tile + 1u == a.n_tiles && lane == 0) a.totals[0] = base + n;
-        } else {
-            const uint32_t n = rows_tile<MODE, PH_COUNT>(a, L, lane, t0, nh, I0, I1, hp, carry_e, row_first, 0, over);
-            const uint64_t base = rows_lookback(a.tile_state, tile, n, lane);
-            if (base + n > a.desc_cap) { if (lane == 0) rreport(a.status, tile, STATUS_ROWS_CAP); }
-            else (void)rows_tile<MODE, PH_DIRECT>(a, L, lane, t0, nh, I0, I1, hp, carry_e, row_first, base, over);
-            if (tile + 1u == a.n_tiles && lane == 0) a.totals[0] = base + n;
-        }
-        asm volatile("" ::: "memory");
-    }
+    const uint64_t tile = uint64_t(blockIdx.x) * 4u + (threadIdx.x >> 6);
+    if (tile >= a.n_tiles) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t b0 = a.tile_desc_base[tile], n = a.tile_desc_base[tile + 1u] - b0;
+    if (n > ROWS_PAD || b0 + n > a.desc_cap) return;                  // (reported by the parse / by the host)
+    const uint64_t* src = a.desc_pad + tile * ROWS_PAD;
+    for (uint32_t k = lane; k < n; k += 64u) a.desc[b0 + k] = src[k];
 }
 
 __global__ __launch_bounds__(256) void rows_hap_begin_kernel(RowsArgs a)
@@ -401,7 +410,7 @@ template <bool EMIT>
 __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_rows, uint32_t max_desc, uint64_t flag)
 {
     const uint32_t lane = threadIdx.x;
-    const uint64_t n_desc = a.totals[0];                                                  // (written by the parse's last tile)
+    const uint64_t n_desc = a.tile_desc_base[a.n_tiles];
     if (*a.status != STATUS_CLEAN) {                                                      // the parse failed (or asks for its two-phase form): the row map is not to be walked
         if (!EMIT && lane == 0) a.seg_count[blockIdx.x] = 0u;
         return;
@@ -415,9 +424,8 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
     while (r0 < s1) {
         // rows r0 .. r0 + 63 in registers: the descriptor covering each row's first byte
         const uint64_t b = r0, r = b + lane;
-        uint64_t c = 0;
-        if (r >= 1u && r < a.n_rows) c = a.cover[r];
-        const uint64_t idx = c >> 22;
+        uint64_t c = 0, idx = 0;
+        if (r >= 1u && r < a.n_rows) { c = a.cover[r]; idx = (c >> 63) ? (c >> 22) & ((1ull << 41) - 1ull) : a.tile_desc_base[c >> 38] + ((c >> 22) & 0xFFFFu); }
         const uint32_t off = uint32_t(c) & 0x3FFFFFu;
         const uint64_t lastd = r >= a.n_rows ? n_desc - 1u : (off ? idx : idx - 1u);      // last descriptor of a chunk that ends at row r
         uint32_t cur = 0;
@@ -484,29 +492,31 @@ hipError_t launch_rows_tile_bytes(const RowsArgs& a, uint64_t* scan_scratch, hip
     return hipGetLastError();
 }
 
-template <int MODE, bool TP>
-static hipError_t launch_parse_t(const RowsArgs& a, hipStream_t stream)
+static_assert(ROWS_PAD == ROWS_PAD_SLOTS, "build_rows.h");
+
+template <int MODE, bool FASTA>
+static hipError_t launch_parse_t(const RowsArgs& a, int phase, hipStream_t stream)
 {
-    int dev = 0, cus = 0, per_cu = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rows_parse_kernel<MODE, TP>, 64, 0);
-    if (e != hipSuccess) return e;
-    if (per_cu < 1) per_cu = 1;
-    // persistent waves, ALL co-resident: the look-back of a tile only ever waits for tiles of waves that are running
-    uint64_t grid = uint64_t(cus) * uint64_t(per_cu);
-    if (grid > a.n_tiles) grid = a.n_tiles;
-    hipLaunchKernelGGL((rows_parse_kernel<MODE, TP>), dim3(uint32_t(grid)), dim3(64), 0, stream, a);
+    const dim3 grid{uint32_t(a.n_tiles)};
+    if (phase == PH_PAD) hipLaunchKernelGGL((rows_parse_kernel<MODE, FASTA, PH_PAD>), grid, dim3(64), 0, stream, a);
+    else if (phase == PH_COUNT) hipLaunchKernelGGL((rows_parse_kernel<MODE, FASTA, PH_COUNT>), grid, dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((rows_parse_kernel<MODE, FASTA, PH_DIRECT>), grid, dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_rows_parse(const RowsArgs& a, int mode, bool two_phase, hipStream_t stream)
+hipError_t launch_rows_parse(const RowsArgs& a, int mode, bool fasta, int phase, hipStream_t stream)
 {
     if (a.n_tiles == 0) return hipSuccess;
-    if (mode == ROWS_DENSE) return two_phase ? launch_parse_t<ROWS_DENSE, true>(a, stream) : launch_parse_t<ROWS_DENSE, false>(a, stream);
-    return two_phase ? launch_parse_t<ROWS_WAVE, true>(a, stream) : launch_parse_t<ROWS_WAVE, false>(a, stream);
+    if (a.n_tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (mode == ROWS_DENSE) return fasta ? launch_parse_t<ROWS_DENSE, true>(a, phase, stream) : launch_parse_t<ROWS_DENSE, false>(a, phase, stream);
+    return fasta ? launch_parse_t<ROWS_WAVE, true>(a, phase, stream) : launch_parse_t<ROWS_WAVE, false>(a, phase, stream);
+}
+
+hipError_t launch_rows_compact(const RowsArgs& a, hipStream_t stream)
+{
+    if (a.n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(rows_compact_kernel, dim3(uint32_t((a.n_tiles + 3) / 4)), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_rows_hap_begin(const RowsArgs& a, hipStream_t stream)

@@ -1037,20 +1037,20 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
 {
     v2p_ctx* c = b->ctx;
     const uint64_t n_tx = s->n_tx, n_tk = s->n_tasks, n_h = s->n_haps;
-    // tiles of K transcripts, one wave each: about 450 items (tasks + transcripts) per tile, so that a tile's descriptors fit the
-    // wave's LDS stage; deep Task vectors get small K
+    // tiles of K transcripts, one wave each: about 200 items (tasks + transcripts) per tile, so that a tile's descriptors fit its
+    // slots of the padded array; deep Task vectors get small K
     const double items_per_tx = double(n_tk + n_tx + 1) / double(n_tx + 1);
     uint32_t K = 64, log2K = 6;
-    while (K > 1 && double(K) * items_per_tx > 448.0) { K >>= 1; --log2K; }
+    while (K > 1 && double(K) * items_per_tx > (fasta ? 200.0 : 360.0)) { K >>= 1; --log2K; }
     const uint64_t n_tiles = (n_tx + 1 + K - 1) / K;
     auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
     uint64_t off = 0;
     auto carve = [&](uint64_t bytes) { const uint64_t o = off; off += up8(bytes); return o; };
     const uint64_t o_hap = carve((n_h + 1) * 8), o_poff = carve(n_tx * 8), o_rlen = carve(n_tx * 4), o_res = carve(n_tx * 4),
-                   o_tb = carve((n_tx + 1) * 8), o_ab = carve((n_tx + 1) * 8), o_code = carve(n_tk + 64), o_sp = carve((n_tk + 16) * 4), o_ln = carve((n_tk + 16) * 4),
+                   o_tb = carve((n_tx + 2) * 8), o_ab = carve((n_tx + 2) * 8), o_code = carve(n_tk + 64), o_sp = carve((n_tk + 16) * 4), o_ln = carve((n_tk + 16) * 4),
                    o_sr = carve((n_tk + 16) * 4), o_hoff = carve(fasta ? n_tx * 8 : 0), o_hlen = carve(fasta ? n_tx * 4 : 0),
-                   o_tbytes = carve(n_tiles * 8), o_tbase = carve((n_tiles + 1) * 8), o_tstate = carve(n_tiles * 8), o_totals = carve(64),
-                   o_scan = carve(rows_scan_scratch_entries(n_tiles) * 8);
+                   o_tbytes = carve(n_tiles * 8), o_tbase = carve((n_tiles + 1) * 8), o_tcount = carve((n_tiles + 1) * 4), o_tdbase = carve((n_tiles + 2) * 8),
+                   o_totals = carve(64), o_scan = carve((rows_scan_scratch_entries(n_tiles) + scan_tiles_for(n_tiles + 1)) * 8);
     HIP_TRY(c, b->d_build.ensure(off), "hipMalloc(build)");
     uint8_t* const d = b->d_build.ptr();
     HIP_TRY(c, b->d_payload.ensure(s->n_alt), "hipMalloc(alt)");
@@ -1066,14 +1066,14 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
     int rc = init_status(c, b->d_status);
     if (rc) return rc;
     struct Cleanup {
-        hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        DevBuf scratch, cover;
+        hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        DevBuf scratch, cover, pad;
         v2p_batch* b;
         bool ok = false;
         explicit Cleanup(v2p_batch* b_) : b(b_) {}
         ~Cleanup() {
             for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
-            scratch.release(); cover.release();
+            scratch.release(); cover.release(); pad.release();
             b->d_build.release();
             if (!ok) { b->img.hap_out_begin.assign(1, 0); b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0; }
         }
@@ -1090,11 +1090,13 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
     a.tx_header_len = fasta ? reinterpret_cast<const uint32_t*>(d + o_hlen) : nullptr;
     a.proteome_len = c->proteome_len; a.K = K; a.log2K = log2K; a.n_tiles = n_tiles;
     a.tile_bytes = reinterpret_cast<uint64_t*>(d + o_tbytes); a.tile_res_base = reinterpret_cast<uint64_t*>(d + o_tbase);
-    a.tile_state = reinterpret_cast<uint64_t*>(d + o_tstate); a.totals = reinterpret_cast<uint64_t*>(d + o_totals);
+    a.tile_count = reinterpret_cast<uint32_t*>(d + o_tcount); a.tile_desc_base = reinterpret_cast<uint64_t*>(d + o_tdbase);
+    a.totals = reinterpret_cast<uint64_t*>(d + o_totals);
     a.status = reinterpret_cast<unsigned long long*>(b->d_status.ptr());
+    uint64_t* const scan_scratch = reinterpret_cast<uint64_t*>(d + o_scan);
     // 1. res_counter per tile (haplotype_instruction.rs:90,132 as a scan); the host needs the arena's size for the row map
     HIP_TRY(c, hipEventRecord(guard.ev[0], c->stream), "hipEventRecord");
-    HIP_TRY(c, launch_rows_tile_bytes(a, reinterpret_cast<uint64_t*>(d + o_scan), c->stream), "launch(tile bytes)");
+    HIP_TRY(c, launch_rows_tile_bytes(a, scan_scratch, c->stream), "launch(tile bytes)");
     HIP_TRY(c, hipEventRecord(guard.ev[1], c->stream), "hipEventRecord");
     uint64_t out_bytes = 0;
     HIP_TRY(c, hipMemcpyAsync(&out_bytes, d + o_tbase + n_tiles * 8, 8, hipMemcpyDeviceToHost, c->stream), "D2H(out_bytes)");
@@ -1111,26 +1113,22 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
     a.seg_base = reinterpret_cast<const uint64_t*>(guard.cover.ptr() + c_segb);
     HIP_TRY(c, b->d_hap.ensure((n_h + 1) * 8), "hipMalloc(hap_begin)");
     a.hap_out_begin = reinterpret_cast<uint64_t*>(b->d_hap.ptr());
-    // the descriptor array: every task at most one descriptor (+ one '.' fill if there is a gap in front of it: second attempt),
-    // every transcript at most three more (fill, line feed, header), runs of more than 4 MiB one per piece
-    const uint64_t per_head = fasta ? 3 : 1;
-    uint64_t desc_cap = n_tk + per_head * (n_tx + 1) + out_bytes / PIECE_MAX + 64;
-    bool two_phase = false;
-    uint64_t totals[4] = {0, 0, 0, 0}, n_chunks = 0;
+    HIP_TRY(c, hipMemsetAsync(d + o_totals, 0, 64, c->stream), "hipMemset(totals)");
+    // 2. the parse.  One pass: every tile's descriptors into its slots of a padded array, the tiles' counts scanned, a copy kernel
+    // compacts.  A tile that does not fit its slots (a transcript with hundreds of tasks ...): the two-pass form -- count, scan, write.
+    bool two_pass = n_tiles >= (1ull << 25);
+    uint64_t n_desc = 0;
     float ms_parse = 0.f;
     for (int attempt = 0; ; ++attempt) {
-        HIP_TRY(c, b->d_desc.ensure(desc_cap * 8), "hipMalloc(desc)");
-        a.desc = reinterpret_cast<uint64_t*>(b->d_desc.ptr()); a.desc_cap = desc_cap;
-        HIP_TRY(c, hipMemsetAsync(d + o_tstate, 0, n_tiles * 8, c->stream), "hipMemset(tile state)");
-        HIP_TRY(c, hipMemsetAsync(d + o_totals, 0, 64, c->stream), "hipMemset(totals)");
         HIP_TRY(c, hipEventRecord(guard.ev[2], c->stream), "hipEventRecord");
-        HIP_TRY(c, launch_rows_parse(a, mode, two_phase, c->stream), "launch(parse)");
-        HIP_TRY(c, launch_rows_hap_begin(a, c->stream), "launch(hap_begin)");
-        HIP_TRY(c, launch_rows_cut(a, mode, false, c->stream), "launch(cut: count)");
-        HIP_TRY(c, launch_scan_u32(a.seg_count, n_segs, const_cast<uint64_t*>(a.seg_base), reinterpret_cast<uint64_t*>(guard.cover.ptr() + c_tiles), c->stream), "launch(scan)");
+        if (!two_pass) {
+            HIP_TRY(c, guard.pad.ensure(n_tiles * ROWS_PAD_SLOTS * 8), "hipMalloc(padded descriptors)");
+            a.desc_pad = reinterpret_cast<uint64_t*>(guard.pad.ptr());
+        }
+        HIP_TRY(c, launch_rows_parse(a, mode, fasta, two_pass ? 1 : 0, c->stream), "launch(parse)");
+        HIP_TRY(c, launch_scan_u32(a.tile_count, n_tiles, a.tile_desc_base, scan_scratch + rows_scan_scratch_entries(n_tiles), c->stream), "launch(scan)");
         HIP_TRY(c, hipEventRecord(guard.ev[3], c->stream), "hipEventRecord");
-        HIP_TRY(c, hipMemcpyAsync(totals, d + o_totals, 32, hipMemcpyDeviceToHost, c->stream), "D2H(totals)");
-        HIP_TRY(c, hipMemcpyAsync(&n_chunks, guard.cover.ptr() + c_segb + n_segs * 8, 8, hipMemcpyDeviceToHost, c->stream), "D2H(n_chunks)");
+        HIP_TRY(c, hipMemcpyAsync(&n_desc, d + o_tdbase + n_tiles * 8, 8, hipMemcpyDeviceToHost, c->stream), "D2H(n_desc)");
         unsigned long long st = STATUS_CLEAN;
         HIP_TRY(c, hipMemcpyAsync(&st, b->d_status.ptr(), 8, hipMemcpyDeviceToHost, c->stream), "D2H(status)");
         HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
@@ -1138,27 +1136,46 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
         (void)hipEventElapsedTime(&ms, guard.ev[2], guard.ev[3]);
         ms_parse += ms;
         const uint32_t reason = st == STATUS_CLEAN ? 0u : uint32_t(st & 0xFFu);
-        if ((reason == STATUS_ROWS_STAGE || reason == STATUS_ROWS_CAP) && attempt < 3) {
-            // a tile that does not fit the wave's stage: every tile counted first, then written straight to the arrays; tasks behind
-            // gaps: the full bound (a '.' fill in front of every task)
-            if (reason == STATUS_ROWS_STAGE) two_phase = true;
-            else desc_cap = 2 * n_tk + 3 * (n_tx + 1) + out_bytes / PIECE_MAX + 64;
+        if (reason == STATUS_ROWS_STAGE && !two_pass && attempt == 0) {
+            two_pass = true;
+            guard.pad.release();
             rc = init_status(c, b->d_status);
             if (rc) return rc;
             continue;
         }
-        if (reason == STATUS_ROWS_TOO_MANY) {
-            (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream);
-            return c->fail(V2P_ERR_UNSUPPORTED, mode == ROWS_DENSE ? "a 1 KiB row of the result holds more than 1024 descriptors"
-                                                                   : "a 1 KiB row of the result holds more than 64 descriptors: not a wave image (kernel 7 builds a dense one)", int64_t(st >> 8));
-        }
+        if (reason == STATUS_ROWS_SPAN) { (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return c->fail(V2P_ERR_UNSUPPORTED, "64 consecutive transcripts with more than 2 GiB of result", int64_t(st >> 8)); }
         rc = collect_status(c, b->d_status);              // what the reference would panic on
         if (rc) { (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return rc; }
         break;
     }
-    const uint64_t n_desc = totals[0], last_dst = totals[2];
+    HIP_TRY(c, b->d_desc.ensure((n_desc ? n_desc : 1) * 8), "hipMalloc(desc)");
+    a.desc = reinterpret_cast<uint64_t*>(b->d_desc.ptr()); a.desc_cap = n_desc;
+    HIP_TRY(c, hipEventRecord(guard.ev[4], c->stream), "hipEventRecord");
+    if (two_pass) HIP_TRY(c, launch_rows_parse(a, mode, fasta, 2, c->stream), "launch(parse: write)");
+    else HIP_TRY(c, launch_rows_compact(a, c->stream), "launch(compact)");
+    HIP_TRY(c, launch_rows_hap_begin(a, c->stream), "launch(hap_begin)");
+    HIP_TRY(c, launch_rows_cut(a, mode, false, c->stream), "launch(cut: count)");
+    HIP_TRY(c, launch_scan_u32(a.seg_count, n_segs, const_cast<uint64_t*>(a.seg_base), reinterpret_cast<uint64_t*>(guard.cover.ptr() + c_tiles), c->stream), "launch(scan)");
+    HIP_TRY(c, hipEventRecord(guard.ev[5], c->stream), "hipEventRecord");
+    uint64_t totals[4] = {0, 0, 0, 0}, n_chunks = 0;
+    HIP_TRY(c, hipMemcpyAsync(totals, d + o_totals, 32, hipMemcpyDeviceToHost, c->stream), "D2H(totals)");
+    HIP_TRY(c, hipMemcpyAsync(&n_chunks, guard.cover.ptr() + c_segb + n_segs * 8, 8, hipMemcpyDeviceToHost, c->stream), "D2H(n_chunks)");
+    {
+        unsigned long long st = STATUS_CLEAN;
+        HIP_TRY(c, hipMemcpyAsync(&st, b->d_status.ptr(), 8, hipMemcpyDeviceToHost, c->stream), "D2H(status)");
+        HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+        if (st != STATUS_CLEAN && uint32_t(st & 0xFFu) == STATUS_ROWS_TOO_MANY) {
+            (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream);
+            return c->fail(V2P_ERR_UNSUPPORTED, mode == ROWS_DENSE ? "a 1 KiB row of the result holds more than 1024 descriptors"
+                                                                   : "a 1 KiB row of the result holds more than 64 descriptors: not a wave image (kernel 7 builds a dense one)", int64_t(st >> 8));
+        }
+        rc = collect_status(c, b->d_status);
+        if (rc) { (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return rc; }
+    }
+    guard.pad.release();
+    const uint64_t last_dst = totals[2];
     if (n_chunks > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch");
-    // 2. the chunk table: emit, keys, XCD / window order inside blocks of the arena (as the host packer's)
+    // 3. the chunk table: emit, keys, XCD / window order inside blocks of the arena (as the host packer's)
     const uint64_t cap = n_chunks ? n_chunks : 1;
     const uint64_t n_blocks_cap = order_blocks_thread_blocks(cap, XCD_ORDER_MAX_BLOCKS);
     const uint64_t n_sub_cap = uint64_t(XCD_SUB) * n_blocks_cap;
@@ -1174,7 +1191,7 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
     a.chunks_tmp = reinterpret_cast<Chunk*>(scratch.ptr() + s_tmp);
     a.bucket = scratch.ptr() + s_bucket;
     a.sub = scratch.ptr() + s_sub;
-    HIP_TRY(c, hipEventRecord(guard.ev[4], c->stream), "hipEventRecord");
+    HIP_TRY(c, hipEventRecord(guard.ev[6], c->stream), "hipEventRecord");
     HIP_TRY(c, launch_rows_cut(a, mode, true, c->stream), "launch(cut: emit)");
     const bool reorder = !(c->flags & V2P_FLAG_RESULT_ORDER) && n_chunks >= 16 && c->proteome_len != 0 && n_desc != 0;
     if (reorder) {
@@ -1185,15 +1202,16 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
                                        reinterpret_cast<Chunk*>(scratch.ptr() + s_tmp2), scratch.ptr() + s_bucket2, reinterpret_cast<uint32_t*>(scratch.ptr() + s_hist),
                                        reinterpret_cast<uint32_t*>(scratch.ptr() + s_tot), reinterpret_cast<Chunk*>(b->d_chunks.ptr()), c->stream), "launch(order)");
     } else if (n_chunks) HIP_TRY(c, hipMemcpyAsync(b->d_chunks.ptr(), a.chunks_tmp, n_chunks * sizeof(Chunk), hipMemcpyDeviceToDevice, c->stream), "D2D(chunks)");
-    HIP_TRY(c, hipEventRecord(guard.ev[5], c->stream), "hipEventRecord");
+    HIP_TRY(c, hipEventRecord(guard.ev[7], c->stream), "hipEventRecord");
     b->img.hap_out_begin.assign(n_h + 1, 0);
     HIP_TRY(c, hipMemcpyAsync(b->img.hap_out_begin.data(), b->d_hap.ptr(), (n_h + 1) * 8, hipMemcpyDeviceToHost, c->stream), "D2H(hap_begin)");
     rc = collect_status(c, b->d_status);
     if (rc) { (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return rc; }
-    float ms0 = 0.f, ms2 = 0.f;
+    float ms0 = 0.f, ms1 = 0.f, ms2 = 0.f;
     (void)hipEventElapsedTime(&ms0, guard.ev[0], guard.ev[1]);
-    (void)hipEventElapsedTime(&ms2, guard.ev[4], guard.ev[5]);
-    if (build_ms) *build_ms = ms0 + ms_parse + ms2;
+    (void)hipEventElapsedTime(&ms1, guard.ev[4], guard.ev[5]);
+    (void)hipEventElapsedTime(&ms2, guard.ev[6], guard.ev[7]);
+    if (build_ms) *build_ms = ms0 + ms_parse + ms1 + ms2;
     guard.ok = true;
     b->n_desc = n_desc; b->n_chunks = n_chunks; b->n_payload = s->n_alt; b->out_bytes = out_bytes; b->n_haps = n_h;
     b->launch_hint = (mode == ROWS_DENSE ? 2 : 4) | 8 | 16 | 32 | (1 << 6) | (1 << 8);
