@@ -55,11 +55,11 @@ def interpret_image(desc, chunks, resident, payload, out_bytes):
     for tb, dn in chunks:
         nd, dst = (int(dn) >> 48) & 0x7FF, int(dn) & ((1 << 48) - 1)       # the top bits route the chunk to a kernel
         if (int(dn) >> 59) & 1:                   # ROWS image (sir_pack.hpp: CHUNK_CLIP): the chunk starts on a 1 KiB row, skips the bytes of its first descriptor
-            rows, dst = dst & 1023, dst & ~1023   # that belong to the chunk before (top 22 bits of task_begin) and stops after `rows` KiB (0: wherever its descriptors end)
-            skip, tb = int(tb) >> 42, int(tb) & ((1 << 42) - 1)
+            tb = int(tb)                          # that belong to the chunk before and drops the bytes of its last one that belong to the next (11 bits each, top of task_begin)
+            skip, clip, tb = (tb >> 42) & 0x7FF, tb >> 53, tb & ((1 << 42) - 1)
+            assert dst % 1024 == 0
             part = interpret_image(desc[tb:tb + nd], np.array([[0, nd << 48]], dtype=np.uint64), resident, payload, sum(_desc_len(int(d)) for d in desc[tb:tb + nd]))
-            part = part[skip:] if not rows else part[skip:skip + rows * 1024]
-            assert not rows or part.size == rows * 1024, "a clipped chunk must produce every byte of its rows"
+            part = part[skip:part.size - clip]
             out[dst:dst + part.size] = part
             continue
         for d in desc[int(tb):int(tb) + nd]:

@@ -9,7 +9,7 @@
 import numpy as np
 import pytest
 
-from gen_util import interpret_image
+from gen_util import interpret_image, _desc_len
 from stream_util import random_stream
 
 
@@ -20,14 +20,20 @@ def _check_geometry(img, mode, out_bytes):
         return
     dn = ch[:, 1]
     assert ((dn >> np.uint64(59)) & np.uint64(1)).all()
-    dst = (dn & np.uint64((1 << 48) - 1) & ~np.uint64(1023)).astype(np.int64)
-    rows = (dn & np.uint64(1023)).astype(np.int64)
+    dst = (dn & np.uint64((1 << 48) - 1)).astype(np.int64)
     nd = ((dn >> np.uint64(48)) & np.uint64(0x7FF)).astype(np.int64)
     flag = (dn >> np.uint64(60)).astype(np.int64)
     assert (flag == (1 if mode == 1 else 2)).all()
-    assert dst[0] == 0 and (np.diff(dst) > 0).all()
+    assert dst[0] == 0 and (np.diff(dst) > 0).all() and (dst % 1024 == 0).all()
     ends = np.concatenate([dst[1:], [out_bytes]])
-    assert (rows[:-1] * 1024 == (ends - dst)[:-1]).all() and rows[-1] == 0
+    # head skip / tail clip: what the chunk's descriptors produce minus both is exactly its rows
+    lens = np.array([_desc_len(int(d)) for d in img.desc], dtype=np.int64)
+    cum = np.concatenate([[0], np.cumsum(lens)])
+    tb = (ch[:, 0] & np.uint64((1 << 42) - 1)).astype(np.int64)
+    skip = ((ch[:, 0] >> np.uint64(42)) & np.uint64(0x7FF)).astype(np.int64)
+    clip = (ch[:, 0] >> np.uint64(53)).astype(np.int64)
+    assert ((cum[tb + nd] - cum[tb]) - skip - clip == ends - dst).all()
+    assert lens.max() <= 2047
     assert nd.max() <= (64 if mode == 1 else 1024) and (ends - dst).max() <= (10240 if mode == 1 else 12288)
     assert ((dst // (640 * 1024)) == ((ends - 1) // (640 * 1024))).all()          # no chunk crosses a segment of the cutter
 

@@ -244,8 +244,8 @@ __global__ __launch_bounds__(64) void rows_parse_kernel(RowsArgs a)
             struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
             lit = reinterpret_cast<const U64*>(a.alt + src)->v & (~0ull >> (64u - 8u * ln));
         }
-        const bool ps = isRef && ln <= SNV3_MAX_LEN;
-        const bool cA = ps && src + ln <= SNV3_MAX_SRC - 1u - SNV3_MAX_LEN;
+        const bool ps = isRef && ln <= ROWS_FUSE_LEN;
+        const bool cA = ps && src + ln <= SNV3_MAX_SRC - 1u - ROWS_FUSE_LEN;
         const bool cB = imm && ln == 1u;
         const bool c0 = ps && ln > 0u && src >= 1u && src + ln <= SNV3_MAX_SRC;
         const uint32_t src32 = uint32_t(src);
@@ -437,9 +437,15 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
             if (!m) { if (lane == 0) rreport(a.status, f, STATUS_ROWS_TOO_MANY); return; }
             const uint32_t hb = 63u - uint32_t(__builtin_clzll(m));
             if (EMIT && lane == hb) {
-                const uint64_t n = lastd - f + 1u, r1 = b + hb;
-                const uint64_t rows = r1 >= a.n_rows ? 0u : uint64_t(hb - cur);
-                a.chunks_tmp[out_k] = Chunk{f | (uint64_t(hs) << TB_IDX_BITS), ((b + cur) * ROW_BYTES) | rows | (n << 48) | CHUNK_CLIP | flag};
+                const uint64_t n = lastd - f + 1u;
+                uint32_t tc = 0;                                                          // what the chunk's last descriptor has behind the cut
+                if (r < a.n_rows && off != 0u) {
+                    const uint64_t d = a.desc[lastd];
+                    const uint32_t dl = (d >> 60) == 0xDull ? uint32_t((d >> 29) & 31u) + uint32_t((d >> 34) & 31u) + uint32_t((d >> 39) & 31u) + 2u
+                                      : ((d & SNV3_MARK) == SNV3_MARK ? uint32_t((d >> 29) & 0xFFFu) + 1u + uint32_t((d >> 41) & 0xFFFu) : uint32_t(d >> 40) & LEN_MASK);
+                    tc = dl - off;
+                }
+                a.chunks_tmp[out_k] = Chunk{f | (uint64_t(hs) << TB_IDX_BITS) | (uint64_t(tc) << (TB_IDX_BITS + TB_SKIP_BITS)), ((b + cur) * ROW_BYTES) | (n << 48) | CHUNK_CLIP | flag};
             }
             last_dst = (b + cur) * ROW_BYTES;
             ++count; ++out_k;

@@ -168,7 +168,7 @@ inline void rows_reference(const TxStreamView& s, uint64_t proteome_len, int mod
             // ImageBuilder::stage (kernel_choice 4)
             if (st == 2) {
                 const bool fits = s0_len == 0 ? (ln > 0 && src >= 1 && src - 1 + 1 + ln <= SNV3_MAX_SRC) : (ln == 0 || src == s0_src + s0_len + 1);
-                if (space == SPACE_PROTEOME && ln <= SNV3_MAX_LEN && fits) {
+                if (space == SPACE_PROTEOME && ln <= ROWS_FUSE_LEN && fits) {
                     const uint64_t run = s0_len == 0 ? src - 1 : s0_src;
                     st = 0;
                     const Fused f{true, i, run, uint32_t(s0_len), uint32_t(s1_byte & 0xFF), uint32_t(ln)};
@@ -188,7 +188,7 @@ inline void rows_reference(const TxStreamView& s, uint64_t proteome_len, int mod
                 if (space == SPACE_IMM && ln == 1) { s1_byte = src; st = 2; continue; }
                 flush();
             }
-            if (space == SPACE_PROTEOME && ln <= SNV3_MAX_LEN && src + ln + 1 + SNV3_MAX_LEN <= SNV3_MAX_SRC) { s0_src = src; s0_len = ln; st = 1; continue; }
+            if (space == SPACE_PROTEOME && ln <= ROWS_FUSE_LEN && src + ln + 1 + ROWS_FUSE_LEN <= SNV3_MAX_SRC) { s0_src = src; s0_len = ln; st = 1; continue; }
             if (space == SPACE_IMM && ln == 1) { s0_src = 0; s0_len = 0; s1_byte = src; st = 2; continue; }
             out(space, src, ln);
         }
@@ -306,8 +306,8 @@ inline void rows_emulate(const TxStreamView& s, uint64_t proteome_len, int mode,
                 imm[l] = code[l] == 1 && ln[l] >= 1 && ln[l] <= IMM_MAX_BYTES;
                 src[l] = isRef[l] ? x.poff + sp[l] : x.alt0 + sp[l];
                 if (imm[l] && !bad[l]) { uint64_t v = 0; for (uint64_t k = 0; k < ln[l]; ++k) v |= uint64_t(s.alt[x.alt0 + sp[l] + k]) << (8 * k); lit[l] = v; }
-                const bool ps = isRef[l] && ln[l] <= SNV3_MAX_LEN;
-                if (isRef[l] && ln[l] <= SNV3_MAX_LEN && src[l] + ln[l] + 1 + SNV3_MAX_LEN <= SNV3_MAX_SRC) mA |= 1ull << l;
+                const bool ps = isRef[l] && ln[l] <= ROWS_FUSE_LEN;
+                if (isRef[l] && ln[l] <= ROWS_FUSE_LEN && src[l] + ln[l] + 1 + ROWS_FUSE_LEN <= SNV3_MAX_SRC) mA |= 1ull << l;
                 if (imm[l] && ln[l] == 1) mB |= 1ull << l;
                 if (ps) mPS |= 1ull << l;
                 const bool c0 = ps && ln[l] > 0 && src[l] >= 1 && src[l] + ln[l] <= SNV3_MAX_SRC;
@@ -422,10 +422,12 @@ inline bool rows_cut(RowsImage& im, int mode, const std::vector<uint64_t>* cover
             const uint64_t f = first_of(r0, hs);
             uint64_t r1 = r0 + max_rows < seg_end ? r0 + max_rows : seg_end;
             while (r1 > r0 + 1 && last_of(r1) - f + 1 > max_desc) --r1;
-            const uint64_t n = last_of(r1) - f + 1;
+            const uint64_t lastd = last_of(r1), n = lastd - f + 1;
             if (n > max_desc) { rows_report(im, f, ROWS_TOO_MANY); return false; }
-            const uint64_t rows = r1 >= n_rows ? 0 : r1 - r0;
-            im.chunks.push_back(Chunk{f | (uint64_t(hs) << TB_IDX_BITS), (r0 * ROW_BYTES) | rows | (n << 48) | CHUNK_CLIP | flag});
+            // what the chunk's last descriptor has behind the cut
+            uint32_t tc = 0;
+            if (r1 < n_rows && (cover[r1] & 0x3FFFFFu)) tc = desc_len(im.desc[lastd]) - uint32_t(cover[r1] & 0x3FFFFFu);
+            im.chunks.push_back(Chunk{f | (uint64_t(hs) << TB_IDX_BITS) | (uint64_t(tc) << (TB_IDX_BITS + TB_SKIP_BITS)), (r0 * ROW_BYTES) | (n << 48) | CHUNK_CLIP | flag});
             r0 = r1;
         }
     }

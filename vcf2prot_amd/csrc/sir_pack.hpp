@@ -102,18 +102,21 @@ static_assert(sizeof(Chunk) == 16, "Chunk is 16 bytes");
 
 // ---- ROWS images (round 4; rows_image.hpp, build_rows.hip): the descriptors are written FIRST, whole -- nothing is cut at a chunk
 // boundary -- and the chunks are cut afterwards on 1 KiB rows of the arena.  A descriptor that lies across a cut belongs to both
-// chunks: the later one skips the bytes of its first descriptor that lie before the cut (HEAD SKIP, the top 22 bits of
-// task_begin), the earlier one stops after `rows` KiB (CHUNK_CLIP: the chunk starts on a multiple of 1024 and the low ten bits of
-// its result offset hold the rows it covers; 0 = whatever its descriptors produce).  Images of the host packer never set either.
+// chunks: the later one skips the bytes of its first descriptor that lie before the cut (HEAD SKIP), the earlier one drops the
+// bytes of its last descriptor that lie behind it (TAIL CLIP): 11 bits each in the top of task_begin, so a descriptor of a rows
+// image produces at most 2047 bytes (longer runs are several descriptors; a fused substitution takes copies of <= 1023 residues).
+// CHUNK_CLIP marks the chunks of a rows image (they start on a multiple of 1024).  Images of the host packer never set any of it.
 constexpr uint32_t TB_IDX_BITS = 42;
 constexpr uint64_t TB_IDX_MASK = (1ull << TB_IDX_BITS) - 1;
+constexpr uint32_t TB_SKIP_BITS = 11;
 constexpr uint64_t CHUNK_CLIP  = 1ull << 59;
 constexpr uint32_t ROW_BYTES   = 1024;
-constexpr uint32_t PIECE_MAX   = (1u << 22) - 1024u;   // longest descriptor of a rows image (the head skip has 22 bits)
+constexpr uint32_t PIECE_MAX   = (1u << TB_SKIP_BITS) - 1u;   // longest descriptor of a rows image: 2047 bytes
+constexpr uint32_t ROWS_FUSE_LEN = 1023;                      // longest copy inside a fused substitution of a rows image (1023 + 1 + 1023 = 2047)
 V2P_HOST_DEVICE inline uint64_t chunk_first(uint64_t task_begin) { return task_begin & TB_IDX_MASK; }
-V2P_HOST_DEVICE inline uint32_t chunk_head_skip(uint64_t task_begin) { return uint32_t(task_begin >> TB_IDX_BITS); }
-V2P_HOST_DEVICE inline uint64_t chunk_dst(uint64_t dst_n) { return (dst_n & CHUNK_CLIP) ? (dst_n & ((1ull << 48) - 1) & ~1023ull) : (dst_n & ((1ull << 48) - 1)); }
-V2P_HOST_DEVICE inline uint32_t chunk_rows(uint64_t dst_n) { return (dst_n & CHUNK_CLIP) ? uint32_t(dst_n & 1023u) : 0u; }
+V2P_HOST_DEVICE inline uint32_t chunk_head_skip(uint64_t task_begin) { return uint32_t(task_begin >> TB_IDX_BITS) & PIECE_MAX; }
+V2P_HOST_DEVICE inline uint32_t chunk_tail_clip(uint64_t task_begin) { return uint32_t(task_begin >> (TB_IDX_BITS + TB_SKIP_BITS)) & PIECE_MAX; }
+V2P_HOST_DEVICE inline uint64_t chunk_dst(uint64_t dst_n) { return dst_n & ((1ull << 48) - 1); }
 
 inline uint64_t pack_desc(uint64_t src, uint32_t len, unsigned space) {
     return (src & SRC_MASK) | (uint64_t(len & LEN_MASK) << 40) | (uint64_t(space & 3u) << 62);

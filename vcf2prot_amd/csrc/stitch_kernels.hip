@@ -444,11 +444,11 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
     if (filter == 3u && !(dn & CHUNK_DENSE)) return;       // (the other chunks of this image go to the per-block kernel)
     const uint64_t tb = RIMG ? tb_raw & TB_IDX_MASK : tb_raw;
     if (RIMG != ((dn & CHUNK_CLIP) != 0ull)) { if (tid == 0) report(a.status, tb, STATUS_RES_OOB); return; }      // (the launcher picked the wrong instance)
-    const uint32_t hskip = RIMG ? uint32_t(tb_raw >> TB_IDX_BITS) : 0u;
-    const uint32_t clip_bytes = RIMG ? (uint32_t(dn) & 1023u) << 10 : 0u;
+    const uint32_t hskip = RIMG ? uint32_t(tb_raw >> TB_IDX_BITS) & PIECE_MAX : 0u;
+    const uint32_t tclip = RIMG ? uint32_t(tb_raw >> (TB_IDX_BITS + TB_SKIP_BITS)) : 0u;
     const bool fused = (dn & CHUNK_DENSE) != 0ull;         // the chunk may hold fused substitution descriptors
     const uint32_t n_hdr = uint32_t(dn >> 48) & CHUNK_N_MASK;
-    const uint64_t dst = RIMG ? (dn & ((1ull << 48) - 1) & ~1023ull) : (dn & ((1ull << 48) - 1));
+    const uint64_t dst = dn & ((1ull << 48) - 1);
     const uint32_t head = RIMG ? 0u : uint32_t(dst & 15ull);
     const bool hdr_ok = n_hdr <= K && tb <= a.n_desc && n_hdr <= a.n_desc - tb;
     const uint32_t n = hdr_ok ? n_hdr : 0u;
@@ -496,18 +496,21 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
             const uint64_t limit = space == SPACE_PROTEOME ? a.src0_len : (space == SPACE_PAYLOAD ? a.src1_len : ~0ull);
             // never read out of bounds (task.rs would panic); a fused descriptor outside a dense image's chunk is refused too
             bool bd = so + used > limit || (space == SPACE_IMM && ln > IMM_MAX_BYTES) || (fz && !fused);
-            // a rows image: the chunk's first descriptor begins in the chunk before -- its stream starts `hskip` bytes in
+            // a rows image: the chunk's first descriptor begins in the chunk before -- its stream starts `hskip` bytes in -- and its last
+            // one goes on into the next: `tclip` bytes less (a literal there is nobody's)
             const uint32_t hs = (RIMG && k == 0 && tid == 0u) ? hskip : 0u;
+            const uint32_t tcl = (RIMG && tid * TPT + k + 1u == n) ? tclip : 0u;
             uint64_t so_h = so;
             uint32_t p1 = l1, p2 = l1 + 1u + l2;            // where the literals of a fused run sit
             bool lit1 = fz, lit2 = is5;
-            if (RIMG && k == 0) {
-                if (hs != 0u && hs >= ln) bd = true;
+            if (RIMG) {
+                if (hs + tcl != 0u && hs + tcl >= ln) bd = true;
                 else {
-                    ln -= hs;
-                    so_h = space == SPACE_IMM ? so >> (8u * hs) : (space == SPACE_FILL ? so : so + hs);
+                    ln -= hs + tcl;
+                    if (k == 0) so_h = space == SPACE_IMM ? so >> (8u * hs) : (space == SPACE_FILL ? so : so + hs);
                     lit1 = lit1 && hs <= p1; lit2 = lit2 && hs <= p2;
                     p1 -= hs; p2 -= hs;
+                    lit1 = lit1 && p1 < ln; lit2 = lit2 && p2 < ln;
                 }
             }
             if (bd) { bad |= 1u << k; ln = 0u; }
@@ -532,24 +535,8 @@ __global__ __launch_bounds__(256) void stitch_dense_kernel(const uint64_t* __res
     if (lane == 63u) s_w[0][wid] = incl;
     lds_barrier();
     const uint32_t l0 = s_w[0][0], l1 = s_w[0][1], l2 = s_w[0][2], l3 = s_w[0][3];
-    uint32_t total = l0 + l1 + l2 + l3;
+    const uint32_t total = l0 + l1 + l2 + l3;
     const uint32_t excl = incl - lsum + (wid > 0 ? l0 : 0u) + (wid > 1 ? l1 : 0u) + (wid > 2 ? l2 : 0u);
-    if (RIMG && clip_bytes != 0u) {
-        // the row clip: the chunk's last descriptor gives up what lies behind the chunk's rows (a literal there is nobody's)
-        if (total < clip_bytes) { if (tid == 0) report(a.status, tb, STATUS_RES_OOB); return; }
-        const uint32_t excess = total - clip_bytes;
-#pragma unroll
-        for (int k = 0; k < TPT; ++k)
-            if (tid * TPT + k + 1u == n && excess != 0u) {
-                if (excess >= len[k]) { report(a.status, tb, STATUS_RES_OOB); len[k] = 0u; patch[k] = 0u; }
-                else {
-                    len[k] -= excess;
-                    if ((patch[k] & 0xFFFu) >= len[k]) patch[k] &= ~(1u << 20);
-                    if (((patch[k] >> 21) & 0x7Fu) >= len[k]) patch[k] &= ~(1u << 28);
-                }
-            }
-        total = clip_bytes;
-    }
     if (!(hdr_ok && dst + total <= a.out_len)) {            // never write out of bounds
         if (tid == 0) report(a.status, tb, STATUS_RES_OOB);
         return;

@@ -166,11 +166,11 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
     // ROWS images (sir_pack.hpp): the chunk's first descriptor may begin in the chunk before -- skip its first `hskip` bytes --
     // and its last one may go on into the next -- stop after `clip_bytes` (whole 1 KiB rows; 0: wherever the descriptors end)
     const uint64_t tb = RIMG ? tb_raw & TB_IDX_MASK : tb_raw;
-    const uint32_t hskip = RIMG ? uint32_t(tb_raw >> TB_IDX_BITS) : 0u;
+    const uint32_t hskip = RIMG ? uint32_t(tb_raw >> TB_IDX_BITS) & PIECE_MAX : 0u;
+    const uint32_t tclip = RIMG ? uint32_t(tb_raw >> (TB_IDX_BITS + TB_SKIP_BITS)) : 0u;
     const uint32_t n_hdr = uint32_t(dn >> 48) & CHUNK_N_MASK;
     if (RIMG != ((dn & CHUNK_CLIP) != 0ull)) { if (lane == 0u) report(p_status, tb, STATUS_RES_OOB); return; }      // (the launcher picked the wrong instance: refused, not guessed)
-    const uint64_t dst = RIMG ? (dn & DST_MASK & ~1023ull) : (dn & DST_MASK);
-    const uint32_t clip_bytes = RIMG ? (uint32_t(dn) & 1023u) << 10 : 0u;
+    const uint64_t dst = dn & DST_MASK;
     const uint32_t head = RIMG ? 0u : uint32_t(dst) & 15u;
     // a chunk table that points outside the descriptor array is refused, not followed
     const bool hdr_ok = n_hdr <= CHUNK_TASKS_WAVE && tb <= n_desc && n_hdr <= n_desc - tb;
@@ -202,26 +202,21 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
     const bool imm = !snv && space == SPACE_IMM;                     // (a two-substitution descriptor of a dense image lands here with a huge length: refused)
     const uint32_t len1 = snv ? (dlo >> 29) | ((dhi & 0x1FFu) << 3) : (dhi >> 8) & 0x3FFFFFu;
     const uint32_t bytes0 = snv ? len1 + 1u + ((dhi >> 9) & 0xFFFu) : len1;          // the whole descriptor
-    const uint32_t hs = lane == 0u ? hskip : 0u;                                     // (a record is a stream: skipping its head is an address and a length)
+    // (a record is a stream: skipping its head or dropping its tail is an address and a length)
+    const uint32_t hs = RIMG && lane == 0u ? hskip : 0u, tcl = RIMG && lane + 1u == n ? tclip : 0u;
     const uint64_t src = snv ? uint64_t(dlo & 0x1FFFFFFFu) : ((uint64_t(dhi & 0xFFu) << 32) | dlo);
     const bool gathers = !imm && bytes0 != 0u && (snv || space != SPACE_FILL);      // ('.' fill, idle lanes, empty records and immediates read the dots)
     const bool ref = snv || space == SPACE_PROTEOME;
-    const bool bad = (hs != 0u && hs >= bytes0) || (imm ? len1 > IMM_MAX_BYTES : (gathers && src + bytes0 > (ref ? src0_len : src1_len)));   // never read out of bounds: task.rs would panic
+    const bool bad = (RIMG && hs + tcl != 0u && hs + tcl >= bytes0) || (imm ? len1 > IMM_MAX_BYTES : (gathers && src + bytes0 > (ref ? src0_len : src1_len)));   // never read out of bounds: task.rs would panic
     // (an immediate record's bytes ARE in memory: the low bytes of its own descriptor, just loaded -- it is a stream like any other)
     const uint64_t a = (imm ? reinterpret_cast<uint64_t>(p_desc + tb + lane) : (gathers ? reinterpret_cast<uint64_t>(ref ? p_src0 : p_src1) + src : dots16)) + (gathers || imm ? hs : 0u);
-    const uint32_t bytes_h = bytes0 - hs;
-    const uint32_t incl0 = wave_incl_scan(bad ? 0u : bytes_h);
-    const uint32_t total0 = uint32_t(__builtin_amdgcn_readlane(int(incl0), 63));
-    // the row clip: the chunk's last descriptor gives up what lies behind the chunk's rows
-    const uint32_t excess = clip_bytes != 0u && total0 > clip_bytes ? total0 - clip_bytes : 0u;
-    const bool clip_bad = clip_bytes != 0u && (total0 < clip_bytes || (lane + 1u == n && excess >= bytes_h));
-    const uint32_t bytes = bytes_h - (lane + 1u == n ? excess : 0u);
-    const uint32_t incl = incl0 - (lane + 1u >= n ? excess : 0u);
-    const uint32_t total = total0 - excess;
+    const uint32_t bytes = bytes0 - hs - tcl;
+    const uint32_t incl = wave_incl_scan(bad ? 0u : bytes);
+    const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
     const uint32_t ptotal = head + total;                            // end of the chunk in block space
     const uint32_t nblk = total ? (ptotal + 15u) >> 4 : 0u;
     const bool any_bad = __ballot(bad) != 0ull;
-    if (!(hdr_ok && dst + total <= out_len && nblk <= CHUNK_BYTES_WAVE / 16u) || any_bad || __ballot(clip_bad) != 0ull) {     // never write out of bounds
+    if (!(hdr_ok && dst + total <= out_len && nblk <= CHUNK_BYTES_WAVE / 16u && (!RIMG || (uint32_t(dst) & 1023u) == 0u)) || any_bad) {     // never write out of bounds
         if (bad) report(p_status, tb + lane, STATUS_SRC_OOB);        // reported, and the chunk is not executed
         if (!any_bad && lane == 0u) report(p_status, tb, STATUS_RES_OOB);
         return;
