@@ -376,16 +376,10 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
         st.tx_header_off = txs.hdr_off.data(); st.tx_header_len = txs.hdr_len.data();
         // routing as the host packer would choose it (result bytes per task); a window with too many descriptors is retried smaller
         const double bpt = double(txs.result_bytes) / double(st.n_tasks ? st.n_tasks : 1);
-        // (vcf2prot_amd/txstream.py::build_plan: wave windows that may split once, sized for ~56 descriptors on average)
+        // (vcf2prot_amd/txstream.py::build_plan: rows images -- wave from 40 result bytes per task, dense below or when a row is too full)
         std::vector<std::pair<int, uint32_t>> plan_v;
-        if (bpt < 40) plan_v = {{3, 12288}, {3, 8192}, {3, 4096}, {2, 4096}};
-        else {
-            uint32_t w = uint32_t(double(bpt) * 1.85 * 56.0) / 1024u * 1024u;
-            w = w < 2048u ? 2048u : (w > 10240u ? 10240u : w);
-            if (bpt >= 120) plan_v = {{4, 10240}, {5, 10240}, {5, 8192}};
-            else { plan_v = {{5, w}}; if (w >= 4096u) plan_v.push_back({5, w - 2048u}); }
-            for (auto p : {std::pair<int, uint32_t>{4, 4096}, {4, 2048}, {2, 32768}, {2, 16384}, {2, 4096}, {3, 12288}, {3, 8192}, {3, 4096}}) plan_v.push_back(p);
-        }
+        if (bpt < 40) plan_v = {{7, 0}, {3, 12288}, {3, 8192}, {3, 4096}, {2, 4096}};
+        else plan_v = {{6, 0}, {7, 0}, {2, 32768}, {2, 16384}, {2, 4096}};
         const std::pair<int, uint32_t>* plan = plan_v.data();
         const size_t n_plan = plan_v.size();
         int rc = V2P_ERR_UNSUPPORTED;

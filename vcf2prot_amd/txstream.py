@@ -143,16 +143,13 @@ class RowsError(RuntimeError):
 
 def build_plan(bytes_per_task: float) -> list:
     """(kernel, window_bytes) pairs to try in order for v2p_batch_build_on_device, by result bytes per task -- the routing the host
-    packer would choose.  Wave images (>= 40 bytes per task): windows that may split once (kernel 5) sized for about 56 descriptors
-    on average (a fused image has ~1.85x the task's bytes per descriptor), so that most windows are one chunk and the few above 64
-    descriptors become two; long runs (>= 120) start with plain ten-row windows (no spare slots).  Dense images below 40."""
+    packer would choose.  Round 4: ROWS images (one pass over the stream, chunks cut afterwards on 1 KiB rows; no window to choose):
+    a wave image (kernel 6) from 40 result bytes per task, a dense one (7) below -- and whenever a 1 KiB row of the result holds
+    more descriptors than a wave has lanes.  The grid builders of round 3 stay behind them as the last resort."""
     bpt = float(bytes_per_task)
     if bpt < 40:
-        return [(3, 12288), (3, 8192), (3, 4096), (2, 4096)]
-    w = int(bpt * 1.85 * 56) // 1024 * 1024
-    w = max(2048, min(10240, w))
-    plan = [(4, 10240), (5, 10240), (5, 8192)] if bpt >= 120 else [(5, w)] + ([(5, w - 2048)] if w >= 4096 else [])
-    return plan + [(4, 4096), (4, 2048), (2, 32768), (2, 16384), (2, 4096), (3, 12288), (3, 8192), (3, 4096)]
+        return [(7, 0), (3, 12288), (3, 8192), (3, 4096), (2, 4096)]
+    return [(6, 0), (7, 0), (2, 32768), (2, 16384), (2, 4096)]
 
 
 def build_on_device_auto(batch, stream, result_bytes: Optional[int] = None) -> dict:
