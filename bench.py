@@ -1,26 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X SIR executor (vcf2prot step 6) -- driver contract in the task brief.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C4|C5] [--samples S]
-                    [--scaling weak|strong]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C4|C5] [--samples S] [--scaling weak|strong]
 
-One "step" = one pass of the hot path (stitch kernel: K0 fill + K1 in-chunk scan + K2
-gather/scatter) over this rank's whole shard, inputs already resident in HBM.  At N=1 the
-workload is BASELINE.json configs[1] ("C2": 1 000 samples x 20 k transcripts x ~400 aa, one
-missense per transcript => 2 000 haplotypes, A = 1.6e10 residues, N = 1.2e8 tasks); the same
-line carries `north_star_cohort`: configs[2] ("C3", the north star's 10 000-sample cohort,
-20 000 haplotypes, 36 GB of result) whole, in one launch, every haplotype verified.
+One "step" = one pass of the hot path -- v2p_batch_execute through the C ABI: the stitch kernel's phases (K0 fill + K1 in-chunk
+scan + K2 gather / scatter) over this rank's whole shard, inputs resident in HBM.  The workload at every N is the north star's
+cohort, BASELINE.json configs[2] ("C3": 10 000 samples = 20 000 haplotypes, full alteration mix, 3.6e10 residues), strong scaling:
+at N = 1 the whole cohort is ONE image and one execute per step; at N > 1 it is cut into contiguous haplotype ranges of equal
+result bytes (shard.shard_by_bytes), one rank per GPU, no data-path collective.  The image every step executes is the one the
+product builds: ON the device, from the per-transcript Task vectors of step 4b (v2p_batch_build_on_device, rows images).
 
---gpus N > 1 launches itself: the parent spawns `python -m torch.distributed.run` with N ranks
-(one per GPU, RCCL) before it touches any GPU, and exits with the children's code; under an
-external launcher (RANK/WORLD_SIZE set) it just runs as a rank.  Its default is the north
-star's run: --workload C3 --scaling strong.
-  --scaling weak   every rank executes its own `--samples`-sample shard of a samples*N cohort (default at N = 1)
-  --scaling strong one cohort of `--samples` samples (C3: the 10 000-sample cohort of the north star),
-                   cut into contiguous haplotype ranges of equal result bytes (shard.shard_by_bytes);
-                   rank 0 first times the whole cohort alone for `speedup_vs_1` (default at N > 1)
-Haplotypes are independent: no data-path collective; the step's only exchange is the all-gather of
-{haplotypes, result bytes} per rank.  Rank 0 prints ONE JSON line.
+The N = 1 line also carries
+  one_shot        Task vectors -> result bytes ONCE, as the reference does it (build kernels + the first execute on a fresh arena)
+  host_packed     the same cohort's host-packed image executed alternately with the device-built one
+  c2_cohort       BASELINE.json configs[1] ("C2": 1 000 samples x 20 k transcripts, one missense each) the same way
+  cpu_baseline    the oracle's reference-faithful flavour on this box's host cores (bounded sample)
+  incl_transfers  PCIe-inclusive rate through v2p_pipeline_* (not `value`)
+
+--gpus N > 1 launches itself: the parent spawns `python -m torch.distributed.run` with N ranks (one per GPU, RCCL) before it touches
+any GPU, and exits with the children's code; under an external launcher (RANK/WORLD_SIZE set) it just runs as a rank.
+  --scaling strong one cohort of `--samples` samples cut by result bytes (default)
+  --scaling weak   every rank executes its own `--samples`-sample shard of a samples*N cohort
+Haplotypes are independent: the path's only exchange is ONE all-gather of {haplotypes, result bytes} per image (the sizes do not
+change between steps); it is timed by itself (`allgather_us`).  Every rank verifies its own shard against the oracle; rank 0 prints
+ONE JSON line.
 """
 from __future__ import annotations
 
@@ -45,34 +48,23 @@ DEFAULT_SAMPLES = {"weak": {"C2": 1000, "C3": 2000, "C4": 313, "C5": 10000},
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=None, choices=["C2", "C3", "C4", "C5"], help="default: C2 at one GPU, C3 (the north star's cohort) at several")
-    ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="default: weak at one GPU, strong at several")
-    ap.add_argument("--no-north-star", action="store_true", help="N = 1: skip the north_star_cohort leg (C3 whole, 36 GB, one launch)")
-    ap.add_argument("--no-speedup-ref", action="store_true", help="N > 1, strong scaling: do not time the whole cohort on rank 0 alone first")
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"], help="default: C3, the north star's cohort")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--samples", type=int, default=0, help="weak: samples per GPU; strong: samples of the whole cohort (0 = the config's own size)")
+    ap.add_argument("--no-c2", action="store_true", help="N = 1: skip the c2_cohort leg (BASELINE configs[1])")
+    ap.add_argument("--no-host-packed", action="store_true", help="skip the host-packed image of the same cohort (A/B of the two builders)")
+    ap.add_argument("--no-speedup-ref", action="store_true", help="N > 1, strong scaling: do not time the whole cohort on rank 0 alone first")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the transfers-inclusive leg (v2p_pipeline_*)")
-    ap.add_argument("--no-device-build", action="store_true", help="skip the device-side image build leg (v2p_batch_build_on_device)")
-    ap.add_argument("--verify", default="all", choices=["all", "sample", "none"],
-                    help="haplotypes whose digest is compared with the oracle before timing")
+    ap.add_argument("--verify", default="all", choices=["all", "sample", "none"], help="haplotypes whose digest is compared with the oracle before timing")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--temporal", action="store_true", help="plain result stores instead of non-temporal")
-    ap.add_argument("--max-blocks", type=int, default=0)
-    ap.add_argument("--fasta", action="store_true", help="FASTA-emitting image: headers and line feeds fused into the scatter (SURVEY 8f rank 1)")
-    ap.add_argument("--var", type=int, default=0, help="K2 variant (0 = default, 1 = legacy byte-granular gathers)")
-    ap.add_argument("--kernel", type=int, default=0, help="image routing: 0 = the packer's choice, 1 = long-run (stitch4_kernel), 2 = per block, 3 = dense, 4 = wave (stitchw_kernel)")
-    ap.add_argument("--wpg", type=int, default=0, help="stitchw_kernel: waves per workgroup selector (0 = 1, 1 = 2, 2 = 4)")
-    ap.add_argument("--no-fuse", action="store_true", help="one descriptor per task (no fused substitutions)")
-    ap.add_argument("--cut-align", type=int, default=0)
-    ap.add_argument("--chunk-tasks", type=int, default=0)
-    ap.add_argument("--chunk-bytes", type=int, default=0)
-    ap.add_argument("--dbg", type=int, default=0, help="timing-only kernel ablation (results are wrong; implies --verify none)")
+    ap.add_argument("--host-image", action="store_true", help="time the host-packed image instead of the device-built one")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise launch, sharding and the size all-gather over gloo (CPU test of the N-rank path)")
-    ap.add_argument("--xcd-order", type=int, default=-1, help="0: launch chunks in result order instead of dealing them to XCDs by proteome slice")
     a = ap.parse_args()
-    if a.no_verify or a.dbg or a.dry_run:
+    if a.no_verify or a.dry_run:
         a.verify = "none"
     return a
 
@@ -91,8 +83,7 @@ def self_launch(n: int) -> int:
 
 
 def oracle_digests(workload, n_samples, haps, workers):
-    """Digest of the oracle's result tape for every haplotype index in `haps` (thread pool; the C oracle
-    and the generator release the GIL)."""
+    """Digest of the oracle's result tape for every haplotype index in `haps` (thread pool; the C oracle and the generator release the GIL)."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     from sir_oracle import COracle
@@ -117,8 +108,8 @@ def oracle_digests(workload, n_samples, haps, workers):
 
 
 def cpu_baseline(cohort, h0, n_haps, n_threads, budget_s=12.0):
-    """Oracle (C restatement of task.rs:38-50 / gir.rs:230-234 / exec.rs:34-40), reference-faithful
-    flavour: u32 chars, 32-byte AoS tasks, '.' fill, haplotypes over a persistent thread pool."""
+    """Oracle (C restatement of task.rs:38-50 / gir.rs:230-234 / exec.rs:34-40), reference-faithful flavour: u32 chars, 32-byte AoS
+    tasks, '.' fill, haplotypes over a persistent thread pool."""
     import numpy as np
     import psutil
     from sir_oracle import COracle
@@ -152,8 +143,8 @@ def cpu_baseline(cohort, h0, n_haps, n_threads, budget_s=12.0):
 
 
 def pcie_inclusive(cohort, h0, h1, n_threads, slots=3, target_image_bytes=2 << 30):
-    """Transfers-inclusive rate through the C ABI's streamed pipeline (v2p_pipeline_*): H2D of descriptors + alt bytes,
-    stitch kernel, D2H of the result into pinned host memory, `slots` images in flight.  Not `value`."""
+    """Transfers-inclusive rate through the C ABI's streamed pipeline (v2p_pipeline_*): H2D of descriptors + alt bytes, stitch
+    kernel, D2H of the result into pinned host memory, `slots` images in flight.  Not `value`."""
     from vcf2prot_amd.engine import Context, Pipeline
     sizes = cohort.result_sizes(h0, h1)
     total = int(sizes.sum())
@@ -187,153 +178,171 @@ def pcie_inclusive(cohort, h0, h1, n_threads, slots=3, target_image_bytes=2 << 3
             "d2h_GBps": out_total / best / 1e9, "what": "packed images -> pinned H2D -> stitch kernel -> D2H into pinned host memory"}
 
 
-def device_image_build(cohort, h0, h1, n_threads, long_run, want_digests, dense=False, wave=False, result_bytes=0):
-    """the same shard's image built ON the device from the per-transcript GIRs of step 4b (v2p_batch_build_on_device:
-    step 5's running sums as prefix scans, descriptors, chunk table, XCD order).  Returns the build kernels' time and whether the
-    image executes to the same per-haplotype digests."""
+def image_stats(desc, chunks, proteome_bytes, out_bytes):
+    """Bytes that must cross the HBM interface per execute: every result byte written once, every descriptor and chunk record read
+    once, the alt bytes that are not inside a descriptor, the proteome once."""
     import numpy as np
+    spaces = (desc >> np.uint64(62)).astype(np.uint8)
+    fused = ((desc >> np.uint64(61)) == 7) | ((desc >> np.uint64(60)) == 0xD)
+    lens = ((desc >> np.uint64(40)) & np.uint64((1 << 22) - 1)).astype(np.int64)
+    payload_touched = int(lens[(spaces == 1)].sum())
+    n_fused = int(fused.sum())
+    n_imm = int(((spaces == 3) & ~fused).sum())
+    hbm_min = int(out_bytes) + 8 * int(desc.size) + 16 * int(chunks.shape[0]) + payload_touched + int(proteome_bytes)
+    return hbm_min, n_fused, n_imm
+
+
+class Timed:
+    """A finalized batch on a context whose launches go to a torch stream: execute() timed with HIP events on that stream."""
+
+    def __init__(self, ctx, batch):
+        import torch
+        self.torch, self.ctx, self.b = torch, ctx, batch
+        self.ts = torch.cuda.Stream()
+
+    def run(self, steps, warmup, barrier=lambda: None):
+        """W untimed steps, then EXACTLY K steps bracketed by a barrier + torch.cuda.synchronize() on both sides (the driver's contract)."""
+        torch, ts = self.torch, self.ts
+        self.ctx.set_stream(ts.cuda_stream)
+        for _ in range(warmup):
+            self.b.execute()
+        self.b.sync()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for e0, e1 in ev:
+            e0.record(ts)
+            self.b.execute()
+            e1.record(ts)
+        self.b.sync()                                           # waits for the stream, collects the device status word
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        self.ctx.set_stream(0)
+        return elapsed, [a.elapsed_time(b) for a, b in ev]
+
+    def once(self):
+        torch, ts = self.torch, self.ts
+        self.ctx.set_stream(ts.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(ts)
+        self.b.execute()
+        e1.record(ts)
+        self.b.sync()
+        self.ctx.set_stream(0)
+        return e0.elapsed_time(e1)
+
+
+def device_build(ctx, stream, result_bytes):
+    """v2p_batch_build_on_device with the product's plan (txstream.build_plan).  Returns (batch, info)."""
+    from vcf2prot_amd.txstream import build_on_device_auto
+    b = ctx.batch()
+    t0 = time.perf_counter()
+    info = build_on_device_auto(b, stream, result_bytes)
+    info["call_s_incl_h2d_of_the_stream"] = time.perf_counter() - t0
+    return b, info
+
+
+def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verify, temporal=False, host_packed=True, time_host_image=False, label="", barrier=lambda: None):
+    """One GPU (this rank's), haplotypes [h0, h1) of the cohort: the image built on the device from the transcript stream, every
+    haplotype's digest checked against the oracle, `steps` executes timed; the one-shot numbers; optionally the host-packed image of
+    the same haplotypes executed alternately.  Returns the numbers as a dict."""
+    import numpy as np
+    import torch
+    from vcf2prot_amd.cohort import Cohort
     from vcf2prot_amd.engine import Context
+    cohort = Cohort.preset(workload, n_samples=cohort_samples)
+    proteome = cohort.proteome()
+    n_haps = h1 - h0
     t0 = time.perf_counter()
     stream = cohort.txstream(h0, h1, n_threads=n_threads)
     t_stream = time.perf_counter() - t0
-    from vcf2prot_amd._native import V2PError
-    from vcf2prot_amd.txstream import build_plan
-    # the routing of vcf2prot_amd/txstream.py::build_plan (what pipeline.vcf_to_fasta and v2p_harness vcf use): wave windows that may
-    # split once, sized by the image's result bytes per task; dense: one window = the kernel's 12 KiB LDS image when its descriptors fit
-    if dense:
-        plan = [(3, 12288), (3, 8192), (3, 4096)]
-    elif wave:
-        plan = build_plan(result_bytes / max(stream.n_tasks, 1) if result_bytes else 134.0)
-    else:
-        plan = [(1, 28672)] if long_run else [(2, 32768)]
-    with Context(0) as ctx:
-        ctx.upload_proteome(cohort.proteome())
-        for kernel, window in plan:
-            b = ctx.batch()
-            try:
-                t0 = time.perf_counter()
-                ms = b.build_on_device(stream, window, kernel)
-                t_call = time.perf_counter() - t0
-                break
-            except V2PError:
-                b.close()
-                if (kernel, window) == plan[-1]:
-                    raise
-        cn = b.counts()
-        same = None
-        exec_ms = None
-        if want_digests is not None:
-            import torch
-            b.execute()
-            b.sync()
-            same = bool(np.array_equal(b.digests(), want_digests))
-            ts = torch.cuda.Stream()                             # (a stream of its own: the null stream would mean "the ctx's own" to the ABI)
-            ctx.set_stream(ts.cuda_stream)                       # HIP events on the stream the kernel is launched on
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-            for e0, e1 in evs:
-                e0.record(ts)
-                b.execute()
-                e1.record(ts)
-            b.sync()
-            exec_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
-            ctx.set_stream(0)
+    A = int(np.ctypeslib.as_array(stream.struct.length, shape=(max(stream.n_tasks, 1),))[:stream.n_tasks].sum(dtype=np.int64)) if stream.n_tasks else 0
+    NT = stream.n_tasks
+    sizes = cohort.result_sizes(h0, h1, n_threads=n_threads)
+    out_bytes = int(sizes.sum())
+    res = {"workload": f"{workload}: {cohort_samples} samples, haplotypes [{h0}, {h1}) x {cohort.n_transcripts} transcripts" + (f" ({label})" if label else ""),
+           "haplotypes": n_haps, "aa": A, "tasks": NT, "result_bytes": out_bytes, "stream_bytes": stream.nbytes, "stream_generation_s": t_stream}
+    ctx = Context(torch.cuda.current_device(), temporal_stores=temporal)
+    try:
+        ctx.upload_proteome(proteome)
+        # ---- one shot: Task vectors -> result bytes once.  Twice: the arena of the first build is fresh memory (its first touch is the
+        # driver's page mapping, not the kernel), the second build gets recycled memory -- what a service that keeps its arenas sees
+        one = {}
+        b, info = device_build(ctx, stream, out_bytes)
+        t = Timed(ctx, b)
+        one["build_kernels_ms_first_call"] = info["build_ms"]
+        one["first_execute_ms_fresh_arena"] = t.once()
         b.close()
-    res = {"build_kernels_ms": ms, "call_s_incl_h2d_of_the_stream": t_call, "stream_bytes": stream.nbytes, "stream_generation_s": t_stream,
-           "window_bytes": window, "kernel_choice": kernel, "descriptors": cn["n_desc"], "chunks": cn["n_chunks"], "digests_equal_host_built_image": same,
-           "execute_ms_device_built_image": exec_ms,
-           "what": "per-transcript GIRs (un-rebased Task SoA, transcript offsets, alt bytes) -> descriptors + chunk table + hap_out_begin in HBM"}
-    stream.close()
-    return res
-
-
-def whole_cohort_leg(workload, samples, steps, n_threads, verify_every=True, temporal=False, device_build=False):
-    """One GPU, one launch per step over a WHOLE cohort (no sharding, no collective): pack, upload, verify every haplotype's digest
-    against the oracle, then time `steps` launches with HIP events on the launch stream.  Used for the north star's 10 000-sample
-    cohort next to the N = 1 line and for `speedup_vs_1` of a strong-scaling run."""
-    import numpy as np
-    import torch
-    from vcf2prot_amd import _native as N
-    from vcf2prot_amd.cohort import Cohort
-    lib = N.hip_lib()
-    dev = torch.device("cuda", torch.cuda.current_device())
-    cohort = Cohort.preset(workload, n_samples=samples)
-    n_haps = cohort.n_haplotypes
-    t0 = time.perf_counter()
-    img = cohort.pack(0, n_haps, n_threads=min(n_threads, 64))
-    t_pack = time.perf_counter() - t0
-    proteome = cohort.proteome()
-    PAD = 64
-
-    def padded(arr):
-        t = torch.zeros(arr.size + 2 * PAD, dtype=torch.uint8, device=dev)
-        if arr.size:
-            t[PAD:PAD + arr.size] = torch.from_numpy(arr).to(dev)
-        return t
-    d_prot, d_payload = padded(proteome), padded(img.payload)
-    chunks = np.ascontiguousarray(img.chunks)
-    assert lib.v2p_order_chunks_for_xcds(chunks.ctypes.data, chunks.shape[0], img.desc.ctypes.data, img.desc.size, proteome.size) == 0
-    d_desc = padded(img.desc.view(np.uint8))                   # (64 readable bytes either side: the ABI asks for 16 before and 32 behind)
-    d_chunks = torch.from_numpy(chunks.view(np.int64)).to(dev)
-    d_hap = torch.from_numpy(img.hap_out_begin.view(np.int64)).to(dev)
-    out_bytes = img.out_bytes
-    d_out = torch.empty(out_bytes + 32, dtype=torch.uint8, device=dev)
-    d_status = torch.full((1,), -1, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream()
-    flags = (0 if temporal else 1) | img.launch_bits
-
-    def launch():
-        rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), d_desc.data_ptr() + PAD, img.desc.size, d_chunks.data_ptr(), chunks.shape[0],
-                                   d_prot.data_ptr() + PAD, proteome.size, d_payload.data_ptr() + PAD, img.payload.size,
-                                   d_out.data_ptr(), out_bytes, d_status.data_ptr(), flags, 0)
-        if rc != 0:
-            raise RuntimeError(f"v2p_stitch_launch failed: {rc}")
-    launch()
-    launch()
-    torch.cuda.synchronize()
-    if int(d_status.item()) != -1:
-        raise RuntimeError(f"device reported a task error: status={int(d_status.item()):#x}")
-    d_dig = torch.zeros(n_haps, dtype=torch.int64, device=dev)
-    lib.v2p_digest_launch(ctypes.c_void_p(stream.cuda_stream), d_out.data_ptr(), d_hap.data_ptr(), n_haps, out_bytes, d_dig.data_ptr())
-    torch.cuda.synchronize()
-    dig = d_dig.cpu().numpy().view(np.uint64)
-    check = list(range(n_haps)) if verify_every else sorted(set(np.linspace(0, n_haps - 1, min(n_haps, 512)).astype(int).tolist()))
-    t_v = time.perf_counter()
-    want = oracle_digests(workload, samples, check, min(n_threads, 64))
-    bad = [h for h in check if int(dig[h]) != want[h]]
-    if bad:
-        raise RuntimeError(f"PARITY FAILURE: haplotypes {bad[:8]} of {workload} differ from the oracle ({len(bad)} of {len(check)})")
-    t_v = time.perf_counter() - t_v
-    for _ in range(3):                                        # (the GPU sat idle while the host checked the digests: untimed warm-up, as the main leg has)
-        launch()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    for e0, e1 in ev:
-        e0.record(stream)
-        launch()
-        e1.record(stream)
-    torch.cuda.synchronize()
-    ms = [a.elapsed_time(b) for a, b in ev]
-    spaces = (img.desc >> np.uint64(62)).astype(np.uint8)
-    lens = ((img.desc >> np.uint64(40)) & np.uint64((1 << 22) - 1)).astype(np.int64)
-    n_fused = int(((img.desc >> np.uint64(61)) == 7).sum())
-    hbm_min = out_bytes + 8 * int(img.desc.size) + 16 * int(chunks.shape[0]) + int(lens[spaces == 1].sum()) + int(proteome.size)
-    avg = sum(ms) / len(ms)
-    bits = img.launch_bits
-    res = {"workload": f"{workload}: {samples} samples = {n_haps} haplotypes x {cohort.n_transcripts} transcripts, whole cohort in ONE launch on one GPU",
-           "aa": int(img.n_copy_bytes), "tasks": int(img.n_tasks), "result_bytes": int(out_bytes), "descriptors": int(img.desc.size),
-           "fused_substitution_descriptors": n_fused, "chunks": int(chunks.shape[0]),
-           "kernel": "stitchw_kernel" if bits & 4 else ("stitch4_kernel" if not (bits & 16) else ("stitch_dense_kernel" if bits & 2 else "stitch_kernel (per block)")),
-           "steps": steps, "warmup": 3, "ms": avg, "ms_min": min(ms), "aa_per_s": img.n_copy_bytes / (avg * 1e-3),
-           "hbm_bytes_min_per_launch": hbm_min, "achieved_GBps": hbm_min / (avg * 1e-3) / 1e9, "frac": hbm_min / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "every_haplotype": bool(len(check) == n_haps), "haplotypes_checked": len(check), "oracle_seconds": t_v, "image_build_s": t_pack}
-    del d_out, d_desc, d_chunks, d_payload, d_prot
-    torch.cuda.empty_cache()
-    if device_build:                                          # the same cohort's image built on the device from the transcript stream
-        try:
-            res["device_image_build"] = device_image_build(cohort, 0, n_haps, min(n_threads, 64), not (bits & 16), dig, dense=bool(bits & 2), wave=bool(bits & 4),
-                                                           result_bytes=int(out_bytes))
-        except Exception as e:                                # noqa: BLE001  (the leg's own numbers stand)
-            res["device_image_build"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        b, info = device_build(ctx, stream, out_bytes)
+        t = Timed(ctx, b)
+        cn = b.counts()
+        first_ms = t.once()
+        one.update({"build_kernels_ms": info["build_ms"], "first_execute_ms": first_ms, "total_ms": info["build_ms"] + first_ms,
+                    "aa_per_s": A / ((info["build_ms"] + first_ms) * 1e-3) if A else 0.0,
+                    "build_call_s_incl_h2d_of_the_stream": info["call_s_incl_h2d_of_the_stream"], "kernel_choice": info["kernel"],
+                    "what": "per-transcript Task vectors (un-rebased SoA, transcript offsets, alt bytes) resident in HBM -> descriptors + chunk table "
+                            "(v2p_batch_build_on_device: step 5 as scans, one-pass parse, row cutter, XCD order) -> the first v2p_batch_execute on the batch's "
+                            "arena (recycled device memory; *_fresh_arena: memory the process never touched)"})
+        desc, chunks, hb = b.download_image()
+        hbm_min, n_fused, n_imm = image_stats(desc, chunks, proteome.size, out_bytes)
+        # bytes one shot must move: the stream read once, the image written and read once, the result written once
+        one_bytes = stream.nbytes + 2 * (8 * int(desc.size) + 16 * int(chunks.shape[0])) + out_bytes + int(proteome.size)
+        one["hbm_bytes_min"] = one_bytes
+        one["frac_physical"] = one_bytes / (one["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        res.update({"descriptors": int(desc.size), "chunks": int(chunks.shape[0]), "fused_substitution_descriptors": n_fused, "immediate_descriptors": n_imm,
+                    "kernel": "stitchw_kernel (rows image)" if info["kernel"] == 6 else ("stitch_dense_kernel (rows image)" if info["kernel"] == 7 else f"kernel choice {info['kernel']}"),
+                    "hbm_bytes_min_per_launch": hbm_min, "algorithmic_bytes_per_launch": 2 * A + 16 * NT, "one_shot": one})
+        del desc, chunks
+        # ---- parity before timing: per-haplotype digests vs the oracle ----
+        dig = b.digests()
+        verified = None
+        if verify != "none":
+            every = verify == "all"
+            check = list(range(n_haps)) if every else sorted(set(np.linspace(0, n_haps - 1, min(n_haps, 512)).astype(int).tolist()))
+            t_v = time.perf_counter()
+            want = oracle_digests(workload, cohort_samples, [h0 + i for i in check], n_threads)
+            bad = [h0 + i for i in check if int(dig[i]) != want[h0 + i]]
+            if bad:
+                raise RuntimeError(f"PARITY FAILURE: haplotypes {bad[:8]} of {workload} differ from the oracle ({len(bad)} of {len(check)})")
+            verified = {"haplotypes_checked": len(check), "of": n_haps, "every_haplotype": bool(len(check) == n_haps),
+                        "digest_of_digests": f"{int(np.bitwise_xor.reduce(dig)) if dig.size else 0:016x}", "oracle_seconds": time.perf_counter() - t_v}
+        res["verified"] = verified
+        # ---- the host-packed image of the same haplotypes (the packer of rounds 1-3): A/B in one process ----
+        hbatch = None
+        if host_packed or time_host_image:
+            t0 = time.perf_counter()
+            img = cohort.pack(h0, h1, n_threads=n_threads)
+            t_pack = time.perf_counter() - t0
+            hbatch = ctx.batch()
+            hbatch.set_packed(img.desc, img.chunks, img.payload, img.hap_out_begin)
+            hbatch.finalize()
+            hbatch.execute()
+            hbatch.sync()
+            same = bool(np.array_equal(hbatch.digests(), dig))
+            th = Timed(ctx, hbatch)
+            ab_h, ab_d = [], []
+            for _ in range(3):
+                th.once(); t.once()
+            for _ in range(9):
+                ab_h.append(th.once()); ab_d.append(t.once())
+            res["host_packed"] = {"image_build_s": t_pack, "descriptors": int(img.desc.size), "chunks": int(img.chunks.shape[0]), "digests_equal_device_built_image": same,
+                                  "ab_execute_ms_host_packed": sorted(ab_h)[4], "ab_execute_ms_device_built": sorted(ab_d)[4],
+                                  "what": "the same haplotypes packed on the host (sir_pack.hpp, greedy chunks), executed alternately with the device-built image in this process"}
+            del img
+        # ---- timed region ----
+        timed = Timed(ctx, hbatch) if time_host_image else t
+        elapsed, kern_ms = timed.run(steps, warmup, barrier)
+        res.update({"elapsed_s": elapsed, "kernel_ms": kern_ms, "image_timed": "host-packed" if time_host_image else "device-built"})
+        if hbatch is not None:
+            hbatch.close()
+        b.close()
+    finally:
+        stream.close()
+        ctx.close()
+        torch.cuda.empty_cache()
     return res
 
 
@@ -345,10 +354,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
-    if args.workload is None:
-        args.workload = "C2" if world == 1 else "C3"
-    if args.scaling is None:
-        args.scaling = "weak" if world == 1 else "strong"
 
     import numpy as np
     import torch
@@ -381,15 +386,12 @@ def main():
             sir_oracle.build_c_oracle()
     if dist_on:
         dist.barrier()
-    from vcf2prot_amd import _native as N
     from vcf2prot_amd.cohort import Cohort
-    from vcf2prot_amd.shard import shard_by_bytes
-    # (--dbg: timing-only ablations live in libv2p_bench.so, the V2P_BENCH_VARIANTS build of the engine)
-    lib = None if args.dry_run else (N.bench_lib() if args.dbg else N.hip_lib())
+    from vcf2prot_amd.shard import layout_from_sizes, shard_by_bytes
 
     # ---- synthetic cohort at the Task boundary; this rank's shard --------------------
     samples = args.samples or DEFAULT_SAMPLES[args.scaling][args.workload]
-    n_threads = max(1, (os.cpu_count() or 1) // world)
+    n_threads = max(1, min(64, (os.cpu_count() or 1) // world))
     if args.scaling == "weak":
         cohort_samples = samples * world
         cohort = Cohort.preset(args.workload, n_samples=cohort_samples)
@@ -397,148 +399,81 @@ def main():
     else:
         cohort_samples = samples
         cohort = Cohort.preset(args.workload, n_samples=cohort_samples)
-        sizes = cohort.result_sizes(0, cohort.n_haplotypes, n_threads=min(n_threads, 64))
+        sizes = cohort.result_sizes(0, cohort.n_haplotypes, n_threads=n_threads)
         h0, h1 = shard_by_bytes(sizes.tolist(), world)[rank]              # equal result bytes per rank
     speedup_ref = None
     if world > 1 and args.scaling == "strong" and rank == 0 and not args.no_speedup_ref and not args.dry_run:
-        try:                                                   # the same cohort alone on this GPU, one launch (the 1-GPU point of the curve)
-            speedup_ref = whole_cohort_leg(args.workload, cohort_samples, max(3, min(args.steps, 10)), n_threads, verify_every=args.verify == "all")
+        try:                                                   # the same cohort alone on this GPU, one image (the 1-GPU point of the curve)
+            r1 = cohort_leg(args.workload, cohort_samples, 0, cohort.n_haplotypes, max(3, min(args.steps, 10)), 3, n_threads, "sample", temporal=args.temporal, host_packed=False)
+            speedup_ref = {"ms_per_step_wall": 1e3 * r1["elapsed_s"] / len(r1["kernel_ms"]), "kernel_ms_avg": sum(r1["kernel_ms"]) / len(r1["kernel_ms"]),
+                           "haplotypes": r1["haplotypes"], "result_bytes": r1["result_bytes"], "verified": r1["verified"],
+                           "method": "the whole cohort as one device-built image on rank 0 alone: host wall-clock around the same execute loop the N-rank run times"}
         except Exception as e:
             speedup_ref = {"error": repr(e)}
     if dist_on:
         dist.barrier()
-    t_gen = time.perf_counter()
-    img = cohort.pack(h0, h1, n_threads=min(n_threads, 64), chunk_tasks=args.chunk_tasks, chunk_bytes=args.chunk_bytes, fasta=args.fasta, cut_align=args.cut_align,
-                      fuse=not args.no_fuse and args.var not in (1, 2, 3) and not args.max_blocks, kernel=2 if (args.var in (1, 2, 3) or args.max_blocks) else args.kernel)
-    t_gen = time.perf_counter() - t_gen
-    A, NT = img.n_copy_bytes, img.n_tasks
-    b_alg = 2 * A + 16 * NT
-    proteome = cohort.proteome()
-    n_proteome = proteome.size
-    if args.fasta:                                             # resident reference = proteome + record headers
-        proteome = np.concatenate([proteome, cohort.fasta_headers()])
-        args.verify = "none"                                   # digests are defined on the plain result tape
 
-    PAD = 64                                                   # the ABI asks for 32 readable bytes either side
+    if args.dry_run:
+        # no kernel: the shard's sizes from the generator, the exchange over gloo
+        st = cohort.txstream(h0, h1, n_threads=n_threads)
+        A = int(np.ctypeslib.as_array(st.struct.length, shape=(max(st.n_tasks, 1),))[:st.n_tasks].sum(dtype=np.int64)) if st.n_tasks else 0
+        leg = {"haplotypes": h1 - h0, "aa": A, "tasks": st.n_tasks, "result_bytes": int(cohort.result_sizes(h0, h1, n_threads=n_threads).sum()),
+               "elapsed_s": 1e-3, "kernel_ms": [1.0] * max(args.steps, 1), "verified": None, "descriptors": 0, "chunks": 0, "hbm_bytes_min_per_launch": 0,
+               "algorithmic_bytes_per_launch": 2 * A + 16 * st.n_tasks, "workload": f"{args.workload} (dry run)", "kernel": "none (dry run)"}
+        st.close()
+    else:
+        leg = cohort_leg(args.workload, cohort_samples, h0, h1, args.steps, args.warmup, n_threads, args.verify, temporal=args.temporal,
+                         host_packed=not args.no_host_packed and world == 1, time_host_image=args.host_image,
+                         barrier=(dist.barrier if dist_on else (lambda: None)))
+    n_haps, out_bytes, A, NT = leg["haplotypes"], leg["result_bytes"], leg["aa"], leg["tasks"]
 
-    def padded(arr):
-        t = torch.zeros(arr.size + 2 * PAD, dtype=torch.uint8, device=dev)
-        if arr.size:
-            t[PAD:PAD + arr.size] = torch.from_numpy(arr).to(dev)
-        return t
-
-    d_prot, d_payload = padded(proteome), padded(img.payload)
-    d_desc = padded(img.desc.view(np.uint8))                   # (readable slack either side, like the source tapes: include/vcf2prot_hip.h)
-    n_desc = int(img.desc.size)
-    img.chunks = np.ascontiguousarray(img.chunks)
-    if args.xcd_order != 0 and not args.dry_run:           # XCD-aware launch order (speed only; chunks are independent)
-        rc = lib.v2p_order_chunks_for_xcds(img.chunks.ctypes.data, img.chunks.shape[0], img.desc.ctypes.data, img.desc.size, n_proteome)
-        assert rc == 0
-    d_chunks = torch.from_numpy(np.ascontiguousarray(img.chunks).view(np.int64)).to(dev)
-    d_hap = torch.from_numpy(img.hap_out_begin.view(np.int64)).to(dev)
-    out_bytes = img.out_bytes
-    d_out = torch.empty(out_bytes + 32, dtype=torch.uint8, device=dev)
-    d_status = torch.full((1,), -1, dtype=torch.int64, device=dev)
-    n_chunks = int(img.chunks.shape[0])
-    n_haps = int(img.hap_out_begin.size - 1)
-    # immediate descriptors carry their bytes; what the kernel can touch of the payload arena is the rest
-    spaces = (img.desc >> np.uint64(62)).astype(np.uint8)
-    lens = ((img.desc >> np.uint64(40)) & np.uint64((1 << 22) - 1)).astype(np.int64)
-    payload_touched = int(lens[spaces == 1].sum())
-    n_fused = int(((img.desc >> np.uint64(61)) == 7).sum())
-    n_imm = int((spaces == 3).sum()) - n_fused
-    # bytes that must cross the HBM interface per launch: every result byte written once, every descriptor and chunk
-    # header read once, the alt bytes that are not inside a descriptor, the proteome once
-    hbm_min = out_bytes + 8 * n_desc + 16 * n_chunks + payload_touched + int(proteome.size)
-    del spaces, lens
-    assert d_out.data_ptr() % 16 == 0
-    stream = None if args.dry_run else torch.cuda.current_stream()
+    # ---- the path's only exchange: {haplotypes, result bytes} of every rank, ONCE per image (sizes do not change between steps) ----
+    layout, allgather_us = None, None
     sizes_t = torch.tensor([n_haps, out_bytes], dtype=torch.int64, device=dev)
     all_sizes = torch.zeros(2 * world, dtype=torch.int64, device=dev)
-    flags = (0 if args.temporal else 1) | img.launch_bits | (args.var << 12) | (args.dbg << 16) | (args.wpg << 28)
-
-    def launch():
-        if args.dry_run:
-            if dist_on:
-                dist.all_gather_into_tensor(all_sizes, sizes_t)
-            return
-        rc = lib.v2p_stitch_launch(ctypes.c_void_p(stream.cuda_stream), d_desc.data_ptr() + PAD, n_desc, d_chunks.data_ptr(), n_chunks,
-                                   d_prot.data_ptr() + PAD, proteome.size, d_payload.data_ptr() + PAD, img.payload.size,
-                                   d_out.data_ptr(), out_bytes, d_status.data_ptr(), flags, args.max_blocks)
-        if rc != 0:
-            raise RuntimeError(f"v2p_stitch_launch failed: {rc}")
-        if dist_on:                                            # the path's only exchange: result sizes for the global offsets
+    if dist_on:
+        dist.all_gather_into_tensor(all_sizes, sizes_t)        # (the first one sets the communicator up)
+        if not args.dry_run:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
             dist.all_gather_into_tensor(all_sizes, sizes_t)
+        if not args.dry_run:
+            torch.cuda.synchronize()
+        allgather_us = (time.perf_counter() - t0) / 10 * 1e6
+        flat = all_sizes.cpu().tolist()
+        layout = layout_from_sizes(rank, flat[0::2], flat[1::2])
 
-    sync = (lambda: None) if args.dry_run else torch.cuda.synchronize
-    for _ in range(max(args.warmup, 1) if args.verify != "none" else args.warmup):
-        launch()
-    sync()
-    if int(d_status.item()) != -1 and not args.dbg:
-        sys.exit(f"device reported a task error: status={int(d_status.item()):#x}")
-
-    # ---- parity before timing: per-haplotype digests vs the oracle --------------------
-    verified = None
-    dig_all = None
-    if args.verify != "none":
-        d_dig = torch.zeros(n_haps, dtype=torch.int64, device=dev)
-        lib.v2p_digest_launch(ctypes.c_void_p(stream.cuda_stream), d_out.data_ptr(), d_hap.data_ptr(), n_haps, out_bytes, d_dig.data_ptr())
-        torch.cuda.synchronize()
-        dig = d_dig.cpu().numpy().view(np.uint64)
-        dig_all = dig.copy()
-        every = args.verify == "all" and out_bytes <= 24 * 10 ** 9
-        check = list(range(n_haps)) if every else sorted(set(np.linspace(0, n_haps - 1, min(n_haps, 512)).astype(int).tolist()))
-        t_v = time.perf_counter()
-        want = oracle_digests(args.workload, cohort_samples, [h0 + i for i in check], min(n_threads, 64))
-        bad = [h0 + i for i in check if int(dig[i]) != want[h0 + i]]
-        if bad:
-            sys.exit(f"PARITY FAILURE: haplotypes {bad[:8]} differ from the oracle ({len(bad)} of {len(check)})")
-        verified = {"haplotypes_checked": len(check), "of": n_haps, "every_haplotype": bool(len(check) == n_haps),
-                    "digest_of_digests": f"{int(np.bitwise_xor.reduce(dig)):016x}", "oracle_seconds": time.perf_counter() - t_v}
-
-    # ---- timed region -------------------------------------------------------------
-    ev = [] if args.dry_run else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if dist_on:
-        dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        if ev:
-            ev[k][0].record(stream)
-        launch()
-        if ev:
-            ev[k][1].record(stream)
-    sync()
-    if dist_on:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms = [a.elapsed_time(b) for a, b in ev] or [1e3 * elapsed / max(args.steps, 1)]
-    if int(d_status.item()) != -1 and not args.dbg:
-        sys.exit(f"device reported a task error: status={int(d_status.item()):#x}")
-
-    tot = torch.tensor([elapsed, float(A), float(NT), float(n_haps), float(out_bytes)], dtype=torch.float64, device=dev)
+    # ---- the timed region of the contract: barrier + synchronize on both sides of K steps, MAX over ranks ----
+    elapsed = leg["elapsed_s"]
+    kern_ms = leg["kernel_ms"]
+    ok_flag = 1.0 if (args.verify == "none" or leg["verified"] is not None) else 0.0
+    tot = torch.tensor([elapsed, float(A), float(NT), float(n_haps), float(out_bytes), ok_flag, sum(kern_ms) / len(kern_ms)], dtype=torch.float64, device=dev)
     per_rank = None
     if dist_on:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        gathered = torch.zeros(5 * world, dtype=torch.float64, device=dev)
+        gathered = torch.zeros(7 * world, dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(gathered, tot)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         elapsed = float(mx[0].item())
         A_all, NT_all = float(tot[1].item()), float(tot[2].item())
-        g = gathered.cpu().view(world, 5).tolist()
-        per_rank = [{"rank": r, "seconds": g[r][0], "aa": int(g[r][1]), "haplotypes": int(g[r][3]), "result_bytes": int(g[r][4])} for r in range(world)]
-        seen = all_sizes.cpu().view(world, 2).tolist()          # what the in-step all-gather delivered: every rank's sizes
-        assert [int(x[0]) for x in seen] == [p["haplotypes"] for p in per_rank], "all-gather of result sizes disagrees"
+        g = gathered.cpu().view(world, 7).tolist()
+        per_rank = [{"rank": r, "seconds": g[r][0], "aa": int(g[r][1]), "haplotypes": int(g[r][3]), "result_bytes": int(g[r][4]), "verified": bool(g[r][5]),
+                     "kernel_ms_avg": g[r][6], "first_haplotype": sum(int(g[q][3]) for q in range(r)), "byte_offset": sum(int(g[q][4]) for q in range(r))} for r in range(world)]
+        assert [int(x) for x in layout.n_haps] == [p["haplotypes"] for p in per_rank], "all-gather of result sizes disagrees"
     else:
         A_all, NT_all = float(A), float(NT)
 
     if rank == 0:
+        steps = len(kern_ms)
         avg_ms = sum(kern_ms) / len(kern_ms)
-        achieved = hbm_min / (avg_ms * 1e-3) / 1e9
+        hbm_min = leg["hbm_bytes_min_per_launch"]
+        b_alg = leg["algorithmic_bytes_per_launch"]
+        achieved = hbm_min / (avg_ms * 1e-3) / 1e9 if not args.dry_run else 0.0
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not args.dry_run:
             try:
                 tj = json.load(open(tpath))
                 tj = tj.get(args.workload, tj)
@@ -548,60 +483,73 @@ def main():
                                       " (profiles/traffic_latest.json)")
             except Exception:
                 traffic = None
+        whole = world == 1 and args.scaling == "strong"
         line = {
-            "metric": "amino-acids written/sec", "value": A_all * args.steps / elapsed, "unit": "aa/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "metric": "amino-acids written/sec", "value": A_all * steps / elapsed, "unit": "aa/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: " + (f"{samples} samples/GPU x {world} GPU(s)" if args.scaling == "weak" else f"one {samples}-sample cohort over {world} GPU(s), equal result bytes per rank")
+            "config": {"workload": f"{args.workload}: " + (f"{samples} samples/GPU x {world} GPU(s)" if args.scaling == "weak" else
+                                                          (f"the whole {samples}-sample cohort as ONE image, one v2p_batch_execute per step" if whole else
+                                                           f"one {samples}-sample cohort over {world} GPU(s), equal result bytes per rank"))
                                    + f" ({int(A_all):.3e} aa) x {cohort.n_transcripts} transcripts, SIR Task vectors at the step-6 boundary",
-                       "haplotypes_rank0": n_haps, "tasks_rank0": NT, "aa_rank0": A, "chunks_rank0": n_chunks,
-                       "descriptor_bytes": 8, "long_run_chunks_rank0": int((img.chunks[:, 1] >> np.uint64(63)).sum()), "immediate_descriptors_rank0": n_imm, "fused_substitution_descriptors_rank0": n_fused, "descriptors_rank0": n_desc, 
-                       "parallelism": f"haplotype-sharded x{world}, no data-path collective; per step one all-gather of 16 B per rank (RCCL)" if world > 1 else "1 GPU"},
+                       "haplotypes_rank0": n_haps, "tasks_rank0": NT, "aa_rank0": A, "chunks_rank0": leg["chunks"], "descriptors_rank0": leg["descriptors"],
+                       "descriptor_bytes": 8, "image": leg.get("image_timed", "none") + " (v2p_batch_build_on_device from the transcript stream)" if not args.host_image else "host-packed",
+                       "fused_substitution_descriptors_rank0": leg.get("fused_substitution_descriptors"), "immediate_descriptors_rank0": leg.get("immediate_descriptors"),
+                       "step": "v2p_batch_execute through the C ABI (ctypes), HIP events on the launch stream",
+                       "parallelism": f"haplotype-sharded x{world}, no data-path collective; one all-gather of 16 B per rank per image (RCCL), outside the step loop" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": achieved / HBM_PEAK_GBS, "frac_definition": "physical",
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "bytes": "achieved = hbm_bytes_min / kernel time: result bytes written once + 8 B per descriptor + 16 B per chunk + alt bytes "
                                   "outside descriptors + the proteome once (reference reads are served by L2 and not counted)",
                          "hbm_bytes_min_per_launch": hbm_min,
                          "algorithmic_bytes_per_launch": b_alg, "algorithmic_GBps": b_alg / (avg_ms * 1e-3) / 1e9,
-                         "kernel": "stitchw_kernel (wave image: one wave per chunk; a step = its phases of 64 MB of image, each read ahead into the memory-side cache -- kernel_ms is the whole step)" if (img.launch_bits & 4) else "stitch4_kernel (long-run image)" if not (img.launch_bits & 16) else ("stitch_dense_kernel (short tasks)" if ((img.launch_bits & 2) or ((img.launch_bits >> 8) & 15) > 2) and args.var in (0, 8, 9) else "stitch_kernel (per-block)"), "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms)},
+                         "frac_b_alg": b_alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_b_alg_note": "SURVEY 8d's B_alg = 2A + 16N prices one HBM read per residue and 16 B per Task; the design serves reference reads from L2 and fuses "
+                                            "Task triples into 8-byte descriptors, so this ratio exceeds 1 without skipping work -- `frac` (physical bytes) is the roofline figure",
+                         "kernel": leg["kernel"] + ": a step = the image's phases, each read ahead into the memory-side cache (touch_image_kernel + stitch launches) -- kernel_ms is the whole step",
+                         "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms)},
             "kernel_only_aa_per_s_rank0": A / (avg_ms * 1e-3),
-            "verified": verified, "image_build_s": t_gen,
+            "verified": leg["verified"], "stream_generation_s": leg.get("stream_generation_s"),
         }
+        for k in ("one_shot", "host_packed"):
+            if k in leg:
+                line[k] = leg[k]
         if per_rank:
             line["per_rank"] = per_rank
             line["world_size_seen_by_rccl"] = int(dist.get_world_size()) if dist_on else 1
+            line["verified_ranks"] = sum(1 for p in per_rank if p["verified"]) if args.verify != "none" else 0
+            line["allgather_us"] = allgather_us
         if speedup_ref is not None:
             line["one_gpu_reference"] = speedup_ref
-            if "ms" in speedup_ref:                              # same cohort, same step: time on one GPU / time on `world` GPUs
-                line["speedup_vs_1"] = speedup_ref["ms"] / (1e3 * elapsed / args.steps)
+            if "ms_per_step_wall" in speedup_ref:              # same cohort, same loop, same clock: host wall-clock per step on one GPU / on `world` GPUs
+                line["speedup_vs_1"] = speedup_ref["ms_per_step_wall"] / (1e3 * elapsed / steps)
+                line["speedup_method"] = "host wall-clock per step of the execute loop (barrier + synchronize on both sides), 1 GPU whole cohort / max over ranks"
         if args.dry_run:
             line["data"] = "synthetic (dry run: no kernel was launched, value is meaningless)"
-        # free the big device buffers before the host-side legs
-        del d_out
-        if not args.dry_run:
-            torch.cuda.empty_cache()
-        if world == 1 and not args.no_pcie and not args.fasta and not args.dbg and not args.dry_run:
-            try:
-                pc = pcie_inclusive(cohort, h0, h1, min(n_threads, 64))
-                line["incl_transfers_aa_per_s"] = pc.pop("aa_per_s")
-                line["incl_transfers"] = pc
-            except Exception as e:           # never lose the bench line to the secondary leg
-                line["incl_transfers"] = {"error": repr(e)}
-        if world == 1 and not args.no_device_build and not args.fasta and not args.dbg and not args.dry_run:
-            try:
-                line["device_image_build"] = device_image_build(cohort, h0, h1, min(n_threads, 64), not (img.launch_bits & 16), dig_all, dense=bool(img.launch_bits & 2), wave=bool(img.launch_bits & 4), result_bytes=int(out_bytes))
-            except Exception as e:
-                line["device_image_build"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline and not args.dry_run:
-            line["cpu_baseline"] = cpu_baseline(cohort, h0, n_haps, os.cpu_count() or 1)
-        if world == 1 and not args.no_north_star and not args.dry_run and not args.dbg and not args.fasta and args.workload == "C2" and args.kernel == 0 and not args.var:
-            # the north star's own cohort (BASELINE.json configs[2]): 10 000 samples, whole, one launch, every haplotype verified
-            try:
-                del d_desc, d_chunks, d_payload
-                torch.cuda.empty_cache()
-                line["north_star_cohort"] = whole_cohort_leg("C3", DEFAULT_SAMPLES["strong"]["C3"], 10, n_threads, verify_every=True, device_build=not args.no_device_build)
-            except Exception as e:
-                line["north_star_cohort"] = {"error": repr(e)}
+        if world == 1 and not args.dry_run:
+            if not args.no_c2 and args.workload == "C3" and not args.samples:
+                try:                                           # BASELINE.json configs[1]: the SNV-only cohort of 1 000 samples, the same way
+                    c2 = cohort_leg("C2", DEFAULT_SAMPLES["strong"]["C2"], 0, 2 * DEFAULT_SAMPLES["strong"]["C2"], min(args.steps, 50), 5, n_threads, args.verify,
+                                    temporal=args.temporal, host_packed=not args.no_host_packed)
+                    ms2 = sum(c2["kernel_ms"]) / len(c2["kernel_ms"])
+                    c2.update({"ms": ms2, "ms_min": min(c2["kernel_ms"]), "aa_per_s": c2["aa"] / (ms2 * 1e-3), "achieved_GBps": c2["hbm_bytes_min_per_launch"] / (ms2 * 1e-3) / 1e9,
+                               "frac": c2["hbm_bytes_min_per_launch"] / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "steps": len(c2["kernel_ms"])})
+                    del c2["kernel_ms"]
+                    line["c2_cohort"] = c2
+                except Exception as e:                         # never lose the bench line to a secondary leg
+                    line["c2_cohort"] = {"error": repr(e)}
+            if not args.no_pcie:
+                try:
+                    c2c = Cohort.preset("C2", n_samples=1000)
+                    pc = pcie_inclusive(c2c, 0, c2c.n_haplotypes, n_threads)
+                    line["incl_transfers_aa_per_s"] = pc.pop("aa_per_s")
+                    pc["workload"] = "C2, 1 000 samples"
+                    line["incl_transfers"] = pc
+                except Exception as e:
+                    line["incl_transfers"] = {"error": repr(e)}
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(cohort, h0, n_haps, os.cpu_count() or 1)
         print(json.dumps(line))
     if dist_on:
         dist.barrier()

@@ -1,6 +1,6 @@
 """bench.py --gpus N must launch itself (one rank per GPU) from a plain shell, propagate the ranks' exit code and print
 ONE JSON line on rank 0.  Here on CPU: --dry-run runs the whole N-rank path (spawn, rendezvous on 127.0.0.1, sharding,
-the per-step all-gather of {haplotypes, result bytes}) over gloo without launching a kernel."""
+the all-gather of {haplotypes, result bytes} -- once per image, outside the step loop) over gloo without launching a kernel."""
 import json
 import os
 import subprocess
@@ -49,7 +49,25 @@ def test_several_gpus_default_to_the_north_star_run(built):
     assert two["world_size_seen_by_rccl"] == 2 and len(two["per_rank"]) == 2
     assert sum(r["haplotypes"] for r in two["per_rank"]) == 60
     one = run_bench("--samples", "2")
-    assert one["n_gpus"] == 1 and one["scaling"] == "weak" and one["config"]["workload"].startswith("C2")
+    assert one["n_gpus"] == 1 and one["scaling"] == "strong" and one["config"]["workload"].startswith("C3")    # the same cohort at every N: the whole of it on one GPU
+
+
+def test_eight_ranks_cut_the_north_star_cohort_evenly(built):
+    """World size 8 over gloo (no GPU): the C3 cohort cut by result bytes -- shares within 1 % of each other for a cohort of this size,
+    the ranges contiguous and complete, every rank's offsets those of the single arena (what the size all-gather tells it)."""
+    one = run_bench("--gpus", "1", "--samples", "800")
+    eight = run_bench("--gpus", "8", "--samples", "800")
+    ranks = eight["per_rank"]
+    assert eight["world_size_seen_by_rccl"] == 8 and [r["rank"] for r in ranks] == list(range(8))
+    assert sum(r["haplotypes"] for r in ranks) == 1600 == one["config"]["haplotypes_rank0"]
+    assert sum(r["aa"] for r in ranks) == one["config"]["aa_rank0"]
+    share = [r["result_bytes"] for r in ranks]
+    assert max(share) - min(share) < 0.01 * (sum(share) / 8)
+    first, off = 0, 0
+    for r in ranks:                                                                  # exclusive prefix sums = offsets inside ONE arena
+        assert r["first_haplotype"] == first and r["byte_offset"] == off
+        first += r["haplotypes"]; off += r["result_bytes"]
+    assert off == sum(share) and "allgather_us" in eight
 
 
 def test_child_failure_is_propagated(built):
