@@ -104,6 +104,7 @@ int64_t v2p_cohort_describe(const v2p_cohort* c, uint64_t hap, char* buf, uint64
 #define V2P_PACK_LONG_RUN 32u  /* route every chunk of <= 512 tasks to the long-run kernel, whatever its shape */
 #define V2P_PACK_DENSE 64u       /* the image goes to stitch_dense_kernel: chunks of <= 1024 short tasks, fused substitutions allowed */
 #define V2P_PACK_WAVE 128u       /* the image goes to stitchw_kernel: one wave per chunk of <= 64 descriptors and <= 10 KiB, fused substitutions allowed */
+#define V2P_PACK_NO_LINE_CUT 0x800000u /* wave images: no 128-byte fallback cut (A/B runs) */
 #define V2P_PACK_NO_DOUBLE 8u /* dense images: one substitution per fused descriptor only (A/B runs) */
 #define V2P_PACK_NO_FUSE 4u /* one descriptor per task: no fused substitutions (A/B runs, per-block kernel) */
 #define V2P_PACK_NO_IMM 2u  /* keep short alt payloads in the payload arena instead of inside their descriptors (A/B runs) */

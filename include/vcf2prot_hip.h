@@ -291,21 +291,35 @@ int  v2p_pipeline_wait(v2p_pipeline* p, uint32_t ticket, const uint8_t** result,
 int  v2p_pipeline_release(v2p_pipeline* p, uint32_t ticket);
 
 /* ---- raw launchers on caller-owned device memory (torch tensors, other runtimes) ----- */
+/* How a launch is done.  Zero-initialise, set what is needed: every 0 (store_sc1: -1) means "the library's choice". */
+typedef struct {
+    uint32_t nontemporal;        /* 1: non-temporal result stores (the default of every batch), 0: plain stores                       */
+    uint32_t routing;            /* v2p_stitch_launch_bits() of the (host copy of the) chunk table: which kernels have work; a chunk
+                                  * whose kernel is not named by it is not executed                                                  */
+    uint64_t phase_bytes;        /* wave / long-run images are launched in phases of this many bytes of image (chunk records +
+                                  * descriptors), each read ahead into the memory-side cache: 0 = 64 MB (28 MB where the image is more
+                                  * than 3 % of its result), ~0 = one launch and no read-ahead                                      */
+    uint32_t phase_min_chunks;   /* images with fewer chunks are launched at once (0 = 16384; tests lower it)                        */
+    int32_t  store_sc1;          /* wave images: 1 / 0 force / forbid "sc1 nt" row stores, -1 = by the image's descriptor share      */
+    uint32_t max_blocks;         /* != 0: cap the grid of the per-block kernel (persistent workgroups); refused for images with
+                                  * long-run, dense or wave chunks                                                                  */
+    uint32_t variant;            /* 0; 3 = per-block kernel also where the dense one would be picked, 8 = the dense kernel for every
+                                  * per-block chunk (routing-only A/B switches; kernel variants live in libv2p_bench.so)            */
+} v2p_launch_opts;
 /* src0/src1 must have 32 readable bytes before and after (the kernel loads whole aligned 16-byte
  * blocks around a task's bytes), and so must d_desc (16 before, 32 after: stitchw_kernel reads an immediate descriptor's literal
  * bytes as a stream out of the descriptor array itself); out must be 16-byte aligned; status is one device uint64 initialised
- * to ~0; chunks that point outside d_desc[0, n_desc) are reported in it, never followed.
- * `nontemporal`: bit 0 non-temporal result stores | v2p_stitch_launch_bits() of the (host copy of the) chunk table -- the bits say
- * which kernels have work; a chunk whose kernel is not named by them is not executed.  max_blocks != 0 caps the grid of the
- * per-block kernel (persistent workgroups) and is refused for images with long-run, dense or wave chunks. */
-int v2p_stitch_launch(void* hip_stream,
-                      const uint64_t* d_desc, uint64_t n_desc, const v2p_chunk* d_chunks, uint32_t n_chunks,
-                      const uint8_t* d_src0, uint64_t src0_len,
-                      const uint8_t* d_src1, uint64_t src1_len,
-                      uint8_t* d_out, uint64_t out_len,
-                      uint64_t* d_status, int nontemporal, uint32_t max_blocks);
-/* Host-side: which stitch kernels a chunk table needs and their tasks per lane (bits 1..11 of `nontemporal`: bit 1 dense chunks,
- * bit 2 wave chunks, bit 4 no long-run chunk, bit 5 no per-block chunk, 6..7 / 8..11 tasks per lane): wave chunks go to
+ * to ~0; chunks that point outside d_desc[0, n_desc) are reported in it, never followed. */
+int v2p_stitch_launch_opts(void* hip_stream,
+                           const uint64_t* d_desc, uint64_t n_desc, const v2p_chunk* d_chunks, uint32_t n_chunks,
+                           const uint8_t* d_src0, uint64_t src0_len,
+                           const uint8_t* d_src1, uint64_t src1_len,
+                           uint8_t* d_out, uint64_t out_len,
+                           uint64_t* d_status, const v2p_launch_opts* opts);
+/* phase size, phase threshold and store policy of every batch this context executes from now on (A/B runs, tests); NULL: the defaults */
+int v2p_set_launch_opts(v2p_ctx* ctx, const v2p_launch_opts* opts);
+/* Host-side: which stitch kernels a chunk table needs and their tasks per lane (v2p_launch_opts.routing: bit 1 dense chunks,
+ * bit 2 wave chunks, bit 3 a rows image, bit 4 no long-run chunk, bit 5 no per-block chunk, 6..7 / 8..11 tasks per lane): wave chunks go to
  * stitchw_kernel, long-run chunks to stitch4_kernel, the others to stitch_kernel (per block) or, when chunks hold more than 512
  * descriptors (short tasks), to stitch_dense_kernel.  A chunk flagged dense (bit 61 of dst_n) must hold at most 12288 bytes of result incl. its 16-byte phase --
  * the kernel's LDS image; the builders never make a larger one, and the kernel refuses one (status: result out of bounds) rather
@@ -315,7 +329,7 @@ int v2p_stitch_launch_bits(const v2p_chunk* chunks, uint64_t n_chunks);
  * of it after the other -- for an image whose descriptors are more than 3 % of its result, block after block of the arena (equal
  * shares of the table's entries in result order, about eight times the proteome each): the reference reads of the workgroups in
  * flight share their windows AND their stores stay within one block (C3 whole: 9.2 -> 7.9 ms).  The table is brought into result
- * order first if it is not.  v2p_batch_finalize() does this itself (v2p_batch_build_on_device the same on the device); callers of v2p_stitch_launch() may want it too.  Speed only: chunks are independent. */
+ * order first if it is not.  v2p_batch_finalize() does this itself (v2p_batch_build_on_device the same on the device); callers of v2p_stitch_launch_opts() may want it too.  Speed only: chunks are independent. */
 int v2p_order_chunks_for_xcds(v2p_chunk* chunks, uint64_t n_chunks, const uint64_t* desc, uint64_t n_desc,
                               uint64_t proteome_len);
 int v2p_digest_launch(void* hip_stream, const uint8_t* d_out, const uint64_t* d_hap_begin, uint64_t n_haps,

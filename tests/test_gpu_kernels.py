@@ -108,7 +108,7 @@ def test_dense_kernel_on_any_per_block_image(built, coracle, preset, h0, n):
     from hip_util import DevBuf
     from vcf2prot_amd import _native as N
     from vcf2prot_amd.cohort import Cohort
-    lib = N.hip_lib()
+    lib, blib = N.hip_lib(), N.bench_lib()             # (variant 9 is a kernel variant: libv2p_bench.so; 8 only routes: the engine's own launcher)
     c = Cohort.preset(preset)
     prot = c.proteome()
     want = np.concatenate(oracle_haps(c, coracle, h0, n))
@@ -121,8 +121,12 @@ def test_dense_kernel_on_any_per_block_image(built, coracle, preset, h0, n):
         for var in (8, 9):
             d_out = DevBuf(img.out_bytes + 32, fill=0x2E)
             d_status = DevBuf.of(np.full(1, -1, dtype=np.int64))
-            rc = lib.v2p_stitch_launch(None, d_desc.ptr, img.desc.size, d_chunks.ptr, chunks.shape[0], d_prot.ptr, prot.size, d_pay.ptr, img.payload.size,
-                                       d_out.ptr, img.out_bytes, d_status.ptr, 1 | bits | (var << 12), 0)
+            if var == 8:
+                rc = N.stitch_launch(lib, None, d_desc.ptr, img.desc.size, d_chunks.ptr, chunks.shape[0], d_prot.ptr, prot.size, d_pay.ptr, img.payload.size,
+                                     d_out.ptr, img.out_bytes, d_status.ptr, N.LaunchOpts(routing=bits, variant=8))
+            else:
+                rc = blib.v2p_stitch_launch(None, d_desc.ptr, img.desc.size, d_chunks.ptr, chunks.shape[0], d_prot.ptr, prot.size, d_pay.ptr, img.payload.size,
+                                            d_out.ptr, img.out_bytes, d_status.ptr, 1 | bits | (var << 12), 0)
             assert rc == 0
             assert d_status.download().view(np.int64)[0] == -1
             got = d_out.download()
@@ -137,7 +141,7 @@ def test_dense_kernel_on_any_per_block_image(built, coracle, preset, h0, n):
 
 def test_oversized_dense_chunk_is_refused_not_executed(built):
     """A chunk flagged dense must fit the kernel's 12 KiB LDS image; the builders never make a larger one, and one that arrives
-    through v2p_stitch_launch is reported in the status word and nothing of it is written."""
+    through v2p_stitch_launch_opts is reported in the status word and nothing of it is written."""
     from hip_util import DevBuf
     from vcf2prot_amd import _native as N
     from vcf2prot_amd.cohort import Cohort
@@ -153,8 +157,8 @@ def test_oversized_dense_chunk_is_refused_not_executed(built):
     d_status = DevBuf.of(np.full(1, -1, dtype=np.int64))
     bits = int(lib.v2p_stitch_launch_bits(chunks.ctypes.data, chunks.shape[0]))
     assert bits & 2
-    rc = lib.v2p_stitch_launch(None, d_desc.ptr, img.desc.size, d_chunks.ptr, chunks.shape[0], d_prot.ptr, prot.size, d_pay.ptr, img.payload.size,
-                               d_out.ptr, img.out_bytes, d_status.ptr, 1 | bits, 0)
+    rc = N.stitch_launch(lib, None, d_desc.ptr, img.desc.size, d_chunks.ptr, chunks.shape[0], d_prot.ptr, prot.size, d_pay.ptr, img.payload.size,
+                         d_out.ptr, img.out_bytes, d_status.ptr, N.LaunchOpts(routing=bits))
     assert rc == 0
     assert d_status.download().view(np.int64)[0] != -1                   # reported
     got = d_out.download()[:img.out_bytes]
@@ -172,7 +176,7 @@ def test_lds_staged_reference_variant_is_exact(built, coracle, preset, h0, n):
     from hip_util import DevBuf
     from vcf2prot_amd import _native as N
     from vcf2prot_amd.cohort import Cohort
-    lib = N.hip_lib()
+    lib = N.bench_lib()                                  # (kernel variants 7 / 11 exist only in the bench build of the engine)
     c = Cohort.preset(preset)
     prot = c.proteome()
     want = np.concatenate(oracle_haps(c, coracle, h0, n))

@@ -100,7 +100,7 @@ def test_wave_kernel_refuses_bad_images(built, gpu_ctx):
 
 @pytest.mark.parametrize("preset,h0,n,kernel,phase_bytes", [("C3", 20, 12, 4, 40_000), ("C3", 20, 12, 4, 7_000), ("C2", 1, 3, 4, 20_000), ("C4", 3, 3, 4, 100_000),
                                                             ("C2", 1, 3, 1, 30_000), ("C1", 0, 8, 4, 600)])
-def test_phased_launches_on_small_images(built, gpu_ctx, coracle, monkeypatch, preset, h0, n, kernel, phase_bytes):
+def test_phased_launches_on_small_images(built, gpu_ctx, coracle, preset, h0, n, kernel, phase_bytes):
     """launch_stitch cuts wave and long-run images into phases (a read-ahead of the phase's chunk records, descriptors and payload
     lines, riding on the previous phase's trailing workgroups for a pure wave image); only images of >= 16 384 chunks are phased, so
     here the threshold is lowered and the phases made tiny: dozens of phases, a ragged last one, read-ahead sets smaller than a wave
@@ -111,14 +111,16 @@ def test_phased_launches_on_small_images(built, gpu_ctx, coracle, monkeypatch, p
     gpu_ctx.upload_proteome(c.proteome())
     want = oracle_haps(c, coracle, h0, n)
     img = c.pack(h0, h0 + n, n_threads=2, kernel=kernel)
-    monkeypatch.setenv("V2P_PHASE_MIN_CHUNKS", "1")
-    monkeypatch.setenv("V2P_PHASE_BYTES", str(phase_bytes))
-    per_chunk = 16 + 8 * img.desc.size / max(img.chunks.shape[0], 1)
-    assert img.chunks.shape[0] > 2 * max(8, phase_bytes / per_chunk) or preset == "C1"      # really several phases
-    got = run_image(gpu_ctx, img)
-    for i in range(n):
-        assert np.array_equal(got[i], want[i]), (preset, kernel, phase_bytes, i)
-    monkeypatch.delenv("V2P_PHASE_BYTES")
-    got = run_image(gpu_ctx, img)                                     # default phase size, threshold still lowered
-    for i in range(n):
-        assert np.array_equal(got[i], want[i]), (preset, kernel, "default", i)
+    gpu_ctx.set_launch_opts(phase_bytes=phase_bytes, phase_min_chunks=1)
+    try:
+        per_chunk = 16 + 8 * img.desc.size / max(img.chunks.shape[0], 1)
+        assert img.chunks.shape[0] > 2 * max(8, phase_bytes / per_chunk) or preset == "C1"      # really several phases
+        got = run_image(gpu_ctx, img)
+        for i in range(n):
+            assert np.array_equal(got[i], want[i]), (preset, kernel, phase_bytes, i)
+        gpu_ctx.set_launch_opts(phase_min_chunks=1)
+        got = run_image(gpu_ctx, img)                                     # default phase size, threshold still lowered
+        for i in range(n):
+            assert np.array_equal(got[i], want[i]), (preset, kernel, "default", i)
+    finally:
+        gpu_ctx.set_launch_opts()

@@ -119,9 +119,10 @@ def test_chunk_order_inside_blocks_of_the_arena(built):
         assert ok.mean() > 0.9, (k, ok.mean())
     one = before.copy()
     os_env = __import__("os").environ
+    blib = N.bench_lib()                                                # (the experiment switch is read by the bench build of the library only)
     os_env["V2P_ORDER_MAX_BLOCKS"] = "1"
     try:
-        assert lib.v2p_order_chunks_for_xcds(one.ctypes.data, one.shape[0], img.desc.ctypes.data, img.desc.size, n_prot) == 0
+        assert blib.v2p_order_chunks_for_xcds(one.ctypes.data, one.shape[0], img.desc.ctypes.data, img.desc.size, n_prot) == 0
     finally:
         os_env.pop("V2P_ORDER_MAX_BLOCKS", None)
     assert not np.array_equal(one, after)                               # one order over the whole table is a different table
@@ -131,7 +132,7 @@ def test_chunk_order_inside_blocks_of_the_arena(built):
     assert lib.v2p_order_chunks_for_xcds(t1.ctypes.data, t1.shape[0], img2.desc.ctypes.data, img2.desc.size, c2.proteome().size) == 0
     os_env["V2P_ORDER_MAX_BLOCKS"] = "1"
     try:
-        assert lib.v2p_order_chunks_for_xcds(t2.ctypes.data, t2.shape[0], img2.desc.ctypes.data, img2.desc.size, c2.proteome().size) == 0
+        assert blib.v2p_order_chunks_for_xcds(t2.ctypes.data, t2.shape[0], img2.desc.ctypes.data, img2.desc.size, c2.proteome().size) == 0
     finally:
         os_env.pop("V2P_ORDER_MAX_BLOCKS", None)
     assert np.array_equal(t1, t2)

@@ -74,7 +74,7 @@ def main():
     if a.lib:
         N.HIP_LIB_PATH = os.path.abspath(a.lib)
     # timing-only ablations (dbg=N: results are wrong) exist only in libv2p_bench.so, the V2P_BENCH_VARIANTS build of the engine
-    lib = N.bench_lib() if (not a.lib and any("dbg=" in v for v in a.variants)) else N.hip_lib()
+    lib = N.bench_lib()        # (the launcher with the packed flag word -- variants, ablations, env switches -- lives in libv2p_bench.so)
     dev = torch.device("cuda", 0)
     over = {}
     if a.mean_len:
@@ -93,10 +93,7 @@ def main():
     for spec in a.variants:
         kv = dict(x.split("=") for x in spec.split(",") if x)
         pack = {k: int(kv[k]) for k in ("chunk_tasks", "chunk_bytes", "cut_align", "soft_window") if k in kv}
-        if int(kv.get("linecut", 1)):
-            os.environ.pop("V2P_NO_LINE_CUT", None)
-        else:
-            os.environ["V2P_NO_LINE_CUT"] = "1"
+        pack["line_cut"] = bool(int(kv.get("linecut", 1)))
         if int(kv.get("grid", 0)):            # chunks cut on a fixed result grid (the device builder's rule)
             img = cohort.pack_grid(0, cohort.n_haplotypes, int(kv["grid"]), 2 if int(kv.get("var", 0)) in (1, 2) else int(kv.get("kernel", 1)))
         else:

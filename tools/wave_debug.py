@@ -26,7 +26,7 @@ def main():
     a = ap.parse_args()
     if a.lib:
         N.HIP_LIB_PATH = os.path.abspath(a.lib)
-    lib = N.hip_lib()
+    lib = N.bench_lib()        # (v2p_stitch_launch with the packed flag word: libv2p_bench.so)
     dev = torch.device("cuda", 0)
     c = Cohort.preset(a.preset)
     prot = c.proteome()

@@ -79,8 +79,9 @@ HIP_API = {
                                     POINTER(c_uint32)]),
     "v2p_pipeline_wait": (c_int, [c_void_p, c_uint32, POINTER(c_void_p), POINTER(c_uint64)]),
     "v2p_pipeline_release": (c_int, [c_void_p, c_uint32]),
-    "v2p_stitch_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, c_uint64,
-                                  c_void_p, c_uint64, c_void_p, c_int, c_uint32]),
+    "v2p_stitch_launch_opts": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, c_uint64,
+                                       c_void_p, c_uint64, c_void_p, c_void_p]),
+    "v2p_set_launch_opts": (c_int, [c_void_p, c_void_p]),
     "v2p_stitch_launch_bits": (c_int, [c_void_p, c_uint64]),
     "v2p_order_chunks_for_xcds": (c_int, [c_void_p, c_uint64, c_void_p, c_uint64, c_uint64]),
     "v2p_digest_launch": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
@@ -88,6 +89,21 @@ HIP_API = {
 
 _hip = None
 _cohort = None
+
+
+class LaunchOpts(ctypes.Structure):
+    """v2p_launch_opts (include/vcf2prot_hip.h): zero = the library's choice (store_sc1: -1)."""
+    _fields_ = [("nontemporal", c_uint32), ("routing", c_uint32), ("phase_bytes", c_uint64), ("phase_min_chunks", c_uint32),
+                ("store_sc1", ctypes.c_int32), ("max_blocks", c_uint32), ("variant", c_uint32)]
+
+    def __init__(self, nontemporal=1, routing=0, phase_bytes=0, phase_min_chunks=0, store_sc1=-1, max_blocks=0, variant=0):
+        super().__init__(nontemporal, routing, phase_bytes, phase_min_chunks, store_sc1, max_blocks, variant)
+
+
+def stitch_launch(lib, stream, d_desc, n_desc, d_chunks, n_chunks, d_src0, src0_len, d_src1, src1_len, d_out, out_len, d_status, opts: "LaunchOpts") -> int:
+    """v2p_stitch_launch_opts on raw device pointers (ints)."""
+    return int(lib.v2p_stitch_launch_opts(ctypes.c_void_p(stream) if stream else None, d_desc, n_desc, d_chunks, n_chunks, d_src0, src0_len, d_src1, src1_len,
+                                          d_out, out_len, d_status, ctypes.byref(opts)))
 
 
 def _bind(lib, api):
@@ -117,6 +133,9 @@ BENCH_API = {
     "v2p_copy_bench_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int, c_void_p]),
     "v2p_gather_bench_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_uint32, c_uint32, c_void_p]),
     "v2p_fill_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_int]),
+    # the launcher with the packed flag word (kernel variants, timing-only ablations): csrc/bench/v2p_bench.h
+    "v2p_stitch_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, c_uint64,
+                                  c_void_p, c_uint64, c_void_p, c_int, c_uint32]),
 }
 _bench = None
 

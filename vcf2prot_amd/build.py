@@ -113,11 +113,13 @@ def build_harness(force: bool = False, verbose: bool = False) -> str:
 
 
 def build_all(force: bool = False, verbose: bool = False):
+    """The product: engine library, host library, C++ harness.  (libv2p_bench.so -- development tools, kernel variants -- is built by
+    build_bench(), lazily by _native.bench_lib(), and by __graft_entry__.build() so that it travels to the GPU box.)"""
     libs = build_hip(force, verbose), build_cohort(force, verbose)
     build_harness(force, verbose)
-    build_bench(force, verbose)
     return libs
 
 
 if __name__ == "__main__":
     print(build_all(force="--force" in sys.argv, verbose=True))
+    print(build_bench(force="--force" in sys.argv, verbose=True))

@@ -207,11 +207,11 @@ class Cohort:
 
     def pack(self, h0: int, h1: int, n_threads: int = 0, chunk_tasks: int = 0, chunk_bytes: int = 0,
              fasta: bool = False, cut_align: int = 0, soft_window: int = 0, inline_payload: bool = True, fuse: bool = True, double: bool = True,
-             kernel: int = 0) -> Packed:
+             kernel: int = 0, line_cut: bool = True) -> Packed:
         import os
         img = PackedImage()
         nt = n_threads or min(32, os.cpu_count() or 1)
-        rc = self._lib.v2p_cohort_pack(self._h, h0, h1, nt, chunk_tasks, chunk_bytes, (1 if fasta else 0) | (0 if inline_payload else 2) | (0 if fuse else 4) | (0 if double else 8) | {2: 16, 1: 32, 3: 64, 4: 128}.get(kernel, 0) | (cut_align << 8) | (soft_window << 24), ctypes.byref(img))
+        rc = self._lib.v2p_cohort_pack(self._h, h0, h1, nt, chunk_tasks, chunk_bytes, (1 if fasta else 0) | (0 if inline_payload else 2) | (0 if fuse else 4) | (0 if double else 8) | {2: 16, 1: 32, 3: 64, 4: 128}.get(kernel, 0) | (cut_align << 8) | (soft_window << 24) | (0 if line_cut else 0x800000), ctypes.byref(img))
         if rc != 0:
             raise RuntimeError(f"v2p_cohort_pack failed ({rc})")
         try:

@@ -19,6 +19,13 @@ hipError_t launch_fill(uint8_t* out, uint64_t bytes, uint32_t word, int nontempo
 }
 extern "C" {
 #endif
+/* the engine's launcher with the packed flag word (V2P_BENCH_VARIANTS build only): bit 0 non-temporal stores | v2p_stitch_launch_bits() |
+ * kernel variant << 12 (1 / 2 per-block gathers, 4..6 stitch4 rows per round, 7 / 11 LDS-staged reference, 9 dword-aligned dense gathers) |
+ * timing-only ablation << 16 (results are wrong) | KiB of idle LDS << 24 | waves per workgroup selector << 28; V2P_PHASE_BYTES,
+ * V2P_WAVE_SC1, V2P_PHASE_MIN_CHUNKS, V2P_PHASE_NO_TOUCH / _OWN_TOUCH / _ONE_LAUNCH are read from the environment at every call */
+int v2p_stitch_launch(void* hip_stream, const uint64_t* d_desc, uint64_t n_desc, const void* d_chunks, uint32_t n_chunks,
+                      const uint8_t* d_src0, uint64_t src0_len, const uint8_t* d_src1, uint64_t src1_len,
+                      uint8_t* d_out, uint64_t out_len, uint64_t* d_status, int nontemporal, uint32_t max_blocks);
 int v2p_fill_launch(void* hip_stream, uint8_t* d_out, uint64_t bytes, uint32_t word, int nontemporal);
 /* microbenchmark: `blocks` workgroups x 4 waves each issue `iters` 16-byte-per-lane gathers (1 KiB per wave
  * instruction) from a window of `window` bytes at byte misalignment `misalign` (0 = aligned); d_sink: one u32 per wave */

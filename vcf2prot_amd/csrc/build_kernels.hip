@@ -413,7 +413,7 @@ __device__ __forceinline__ void put_chunk(const BuildArgs& a, uint64_t slot, uin
 __device__ __forceinline__ void chunk_split_window(const BuildArgs& a, uint64_t k, uint64_t n_windows, uint64_t tb, uint32_t n_slots, uint32_t lane)
 {
     const uint32_t m = n_slots ? n_slots - 1u : 0u;                  // real descriptors (slot 0 is the spare)
-    if (m > 2u * CHUNK_TASKS_WAVE - 1u) { if (lane == 0) breport(a.status, tb, STATUS_TOO_MANY); return; }
+    if (m > 2u * CHUNK_TASKS_WAVE - 1u) { if (lane == 0) { breport(a.status, tb, STATUS_TOO_MANY); a.chunks_tmp[k] = Chunk{tb, (k * a.window) | CHUNK_WAVE}; a.bucket[k] = 0; a.sub[k] = 0; } return; }   // (the sorts behind this kernel read every entry)
     volatile uint32_t* meta = a.meta;
     if (lane == 0 && !(meta[0] & 4u)) atomicOr(&a.meta[0], 4u);
     const uint64_t d0 = lane < m ? a.desc[tb + 1u + lane] : (uint64_t(SPACE_FILL) << 62);
@@ -440,7 +440,7 @@ __device__ __forceinline__ void chunk_split_window(const BuildArgs& a, uint64_t 
         const uint32_t dist = R > a.window / 2u ? R - a.window / 2u : a.window / 2u - R;
         if (nA >= 1u && nB >= 1u && nA <= CHUNK_TASKS_WAVE && nB <= CHUNK_TASKS_WAVE && dist < best_dist) { best = R; best_dist = dist; }
     }
-    if (best == 0u) { if (lane == 0) breport(a.status, tb, STATUS_TOO_MANY); return; }
+    if (best == 0u) { if (lane == 0) { breport(a.status, tb, STATUS_TOO_MANY); a.chunks_tmp[k] = Chunk{tb, (k * a.window) | CHUNK_WAVE}; a.bucket[k] = 0; a.sub[k] = 0; } return; }
     const uint32_t R = best;
     const uint32_t nA = uint32_t(__popcll(__ballot(v0 && s0 < R))) + uint32_t(__popcll(__ballot(v1 && s1 < R)));
     const bool x0 = v0 && s0 < R && e0 > R, x1 = v1 && s1 < R && e1 > R;         // the descriptor lying across R (at most one), index nA - 1
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void chunk_kernel(BuildArgs a, uint64_t n_wind
     const uint64_t tb_next = k + 1 < n_windows ? a.chunk_first[k + 1] : n_desc;
     const uint64_t n = tb_next - tb;
     if (a.split) { chunk_split_window(a, k, n_windows, tb, uint32_t(n < 4096u ? n : 4096u), lane); return; }
-    if (n > CHUNK_TASKS_DEEP) { if (lane == 0) breport(a.status, tb, STATUS_TOO_MANY); return; }   // too many descriptors in one window: pick a smaller grid
+    if (n > CHUNK_TASKS_DEEP) { if (lane == 0) { breport(a.status, tb, STATUS_TOO_MANY); a.chunks_tmp[k] = Chunk{tb, k * a.window}; a.bucket[k] = 0; a.sub[k] = 0; } return; }   // too many descriptors in one window: pick a smaller grid
     // tasks of the window (a fused substitution is up to three) and the proteome slice of its first reference read
     // (order_chunks_for_xcds looks at the first six descriptors)
     uint32_t tasks = 0;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void chunk_kernel(BuildArgs a, uint64_t n_wind
 #pragma unroll
     for (uint32_t dlt = 32u; dlt; dlt >>= 1) tasks += uint32_t(__shfl_xor(int(tasks), int(dlt), 64));
     if (lane != 0) return;
-    if (a.wave ? n > CHUNK_TASKS_WAVE : (a.long_run && tasks > 2u * CHUNK_TASKS)) { breport(a.status, tb, STATUS_TOO_MANY); return; }
+    if (a.wave ? n > CHUNK_TASKS_WAVE : (a.long_run && tasks > 2u * CHUNK_TASKS)) { breport(a.status, tb, STATUS_TOO_MANY); a.chunks_tmp[k] = Chunk{tb, k * a.window}; a.bucket[k] = 0; a.sub[k] = 0; return; }
     uint64_t flags = 0;
     if (a.wave) flags = CHUNK_WAVE;
     else if (a.long_run) flags = CHUNK_LONG | (tasks > CHUNK_TASKS ? CHUNK_LONG2 : 0ull);

@@ -177,13 +177,14 @@ public:
     bool fuse_double = true;          // dense images: two substitutions in a row -> one descriptor
     uint64_t n_fused = 0;             // fused substitutions in the image
     bool grid_overflow = false;       // grid cutting: some window holds more descriptors than its kernel takes (PACK_TOO_LARGE)
+    bool line_cut = true;             // a wave chunk that cannot reach a row boundary any more still ends on a 128-byte line (false: A/B runs)
 
     // Empty the image for another build; the vectors keep their capacity, the settings return to their defaults.
     void reset() {
         desc.clear(); chunks.clear(); payload.clear(); hap_out_begin.assign(1, 0);
         n_copy_bytes = n_ref_tasks = n_fused = n_long_chunks = n_dense_chunks = n_wave_chunks = 0;
         chunk_tasks = CHUNK_TASKS; adaptive_tasks = true; chunk_bytes = CHUNK_BYTES_LONG; adaptive_bytes = true; cut_align = CUT_ALIGN;
-        grid_overflow = false; max_chunk_tasks = max_long_tasks = 0; soft_window = 8; inline_payload = true; fuse_snv = true; fuse_double = true; kernel_choice = 0; grid_bytes = 0;
+        grid_overflow = false; max_chunk_tasks = max_long_tasks = 0; soft_window = 8; inline_payload = true; fuse_snv = true; fuse_double = true; kernel_choice = 0; grid_bytes = 0; line_cut = true;
         cursor_ = extra_ = arena_cursor_ = open_begin_ = open_dst_ = 0;
         open_n_ = open_bytes_ = open_desc_ = 0; open_fused_ = false; st_n_ = 0; st0_virtual_ = false;
     }
@@ -524,8 +525,7 @@ private:
             if (open_units() + 6 >= chunk_tasks || open_bytes_ + (align - uint32_t(arena_cursor_ & uint64_t(align - 1))) > chunk_bytes) {
                 // a wave chunk that cannot reach a row boundary any more still ends on a 128-byte line while two slots are left: its rows
                 // then cover whole lines, and no line of the arena is written in two halves by two waves
-                const bool cut_line = getenv("V2P_NO_LINE_CUT") == nullptr;      // (A/B switch, read while packing)
-                const bool line = cut_line && kernel_choice == 4 && cut_pref() >= 128u && open_units() + 2 < chunk_tasks &&
+                const bool line = line_cut && kernel_choice == 4 && cut_pref() >= 128u && open_units() + 2 < chunk_tasks &&
                                   open_bytes_ + (128u - uint32_t(arena_cursor_ & 127ull)) <= chunk_bytes;
                 align = line ? 128u : 16u;
             }

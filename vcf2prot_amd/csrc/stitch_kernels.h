@@ -33,6 +33,11 @@ struct StitchArgs {
     const Chunk*    next_chunks = nullptr;   // set by launch_stitch(): the chunk records of the NEXT phase, whose image the trailing
     uint32_t        n_next = 0;              // workgroups of a wave launch read ahead (stitch_wave.hip); 0: none
     uint32_t        store_sc1 = 0;           // set by launch_stitch(): the wave kernel's row stores "sc1 nt" instead of "nt" (thin descriptor streams)
+    // launch options (include/vcf2prot_hip.h: v2p_launch_opts; 0 / -1 = the library's choice)
+    uint64_t        opt_phase_bytes = 0;     // image bytes per phase of a wave / long-run image (~0ull: one launch, no read-ahead)
+    uint32_t        opt_phase_min_chunks = 0;// images with fewer chunks are launched at once
+    int32_t         opt_store_sc1 = -1;      // wave images: force (1) / forbid (0) "sc1 nt" row stores
+    uint32_t        opt_touch = 0;           // bench builds: 1 = no read-ahead, 2 = the read-ahead as kernels of its own, 4 = one launch for all phases
     uint32_t        rows = 0;                // set by launch_stitch(): a rows image (sir_pack.hpp: every chunk carries CHUNK_CLIP) -- stitchw_kernel's ROWS instance
     uint32_t        phase_chunks = 0;        // set by launch_stitch(): != 0 -- ONE wave launch for all phases of that many chunks, the read-ahead
                                              // workgroups of phase g + 1 placed in the grid before the stitch workgroups of phase g

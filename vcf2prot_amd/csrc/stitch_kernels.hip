@@ -1241,32 +1241,33 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     // 1/45 of its result: 3.31 / 3.24 / 3.21 with 16 / 32 / 64 the other way.
     a.rows = (nontemporal & 8) != 0;                                             // (bit 3: a rows image, sir_pack.hpp: CHUNK_CLIP on every chunk)
     const bool rich = 8.0 * double(a.n_desc) > 0.03 * double(a.out_len);        // C2: 2.2 %, C4: 3.7 %, C3: 5 %
+    // (phase size, store policy and threshold are launch options -- v2p_launch_opts, v2p_set_launch_opts -- for A/B runs and tests:
+    // nothing here reads the environment)
     uint64_t phase_bytes = rich ? PHASE_BYTES_RICH : PHASE_BYTES_DEFAULT;
-    if (const char* e = getenv("V2P_PHASE_BYTES")) phase_bytes = strtoull(e, nullptr, 10);      // 0: one phase, no touch (A/B runs)
-    // (V2P_WAVE_SC1=1 / 0 forces / forbids "sc1 nt" row stores, A/B; by default images with a thin descriptor stream get them)
-    if (const char* e = getenv("V2P_WAVE_SC1")) a.store_sc1 = atoi(e) != 0;
-    else a.store_sc1 = !rich;       // C2 3.14 -> 3.06 ms (-2.6 %), C4 +0.9 %, C3 +6 %
+    if (a.opt_phase_bytes == ~0ull) phase_bytes = 0;                             // one phase, no touch
+    else if (a.opt_phase_bytes != 0) phase_bytes = a.opt_phase_bytes;
+    // ("sc1 nt" row stores: by default images with a thin descriptor stream get them -- C2 3.14 -> 3.06 ms (-2.6 %), C4 +0.9 %, C3 +6 %)
+    a.store_sc1 = a.opt_store_sc1 >= 0 ? uint32_t(a.opt_store_sc1 != 0) : uint32_t(!rich);
     // (the kernels of per-block and dense images are bound by their instruction stream, not by memory: phases only cost them --
     // C3 per-block 2.00 -> 2.19 ms, C5 dense 0.53 -> 0.71; wave and long-run images gain: C2 3.26 -> 2.65 ms)
     const bool streams = (nontemporal & 4) != 0 || (nontemporal & 16) == 0;       // the image holds wave or long-run chunks
-    uint32_t min_chunks = PHASE_MIN_CHUNKS;
-    if (const char* e = getenv("V2P_PHASE_MIN_CHUNKS")) min_chunks = uint32_t(strtoul(e, nullptr, 10));   // (tests: phases on small images)
+    const uint32_t min_chunks = a.opt_phase_min_chunks ? a.opt_phase_min_chunks : PHASE_MIN_CHUNKS;
     if (max_blocks != 0 || phase_bytes == 0 || !streams || a.n_chunks < min_chunks) return launch_stitch_range(a, stream, nontemporal, max_blocks);
     const double per_chunk = 16.0 + 8.0 * double(a.n_desc) / double(a.n_chunks);
     uint64_t per = uint64_t(double(phase_bytes) / per_chunk);
-    const uint64_t per_min = getenv("V2P_PHASE_MIN_CHUNKS") ? 8u : 4096u;
+    const uint64_t per_min = a.opt_phase_min_chunks ? 8u : 4096u;    // (a lowered threshold -- tests -- also allows tiny phases)
     per = per < per_min ? per_min : (per & ~7ull);                   // (a multiple of 8 keeps workgroup b on the XCD the chunk order dealt chunk b to)
-    static const bool no_touch = getenv("V2P_PHASE_NO_TOUCH") != nullptr;
+    const bool no_touch = (a.opt_touch & 1u) != 0;
     // a pure wave image: the read-ahead of phase k + 1 rides on the trailing workgroups of phase k's launch (they are dispatched while
-    // its last chunks drain) instead of a kernel of its own between the two; only phase 0 has a touch kernel (V2P_PHASE_OWN_TOUCH: A/B)
-    static const bool own_touch = getenv("V2P_PHASE_OWN_TOUCH") != nullptr;
+    // its last chunks drain) instead of a kernel of its own between the two; only phase 0 has a touch kernel (opt_touch 2: A/B)
+    const bool own_touch = (a.opt_touch & 2u) != 0;
     const bool ride = !own_touch && !no_touch && (nontemporal & 4) != 0 && (nontemporal & 48) == 48 && !(nontemporal & 2);
     // (V2P_PHASE_ONE_LAUNCH, A/B: ONE launch for all phases, the read-ahead workgroups of phase g + 1 placed in the grid before the
     // stitch workgroups of phase g (stitch_wave.hip) -- no kernel boundary, no tail, no launch gap between two phases.  Measured:
     // C2 3.16 against 3.21 ms, but C3 1.98 against 1.85 and C3 whole 11.1 against 9.35: the boundary is what keeps two phases'
     // images from sharing the L2 and the read-ahead from running into the stores.  Not the default.)
     const int wsel = (nontemporal >> 28) & 3;
-    if (ride && wsel == 0 && getenv("V2P_PHASE_ONE_LAUNCH") != nullptr && per <= 0x7FFFFFFFull) {
+    if (ride && wsel == 0 && (a.opt_touch & 4u) != 0 && per <= 0x7FFFFFFFull) {
         const uint32_t n0 = uint32_t(args.n_chunks < per ? args.n_chunks : per);
         hipLaunchKernelGGL(touch_image_kernel, dim3(8u * ((touch_waves_per_xcd(n0) + 3u) / 4u)), dim3(256), 0, stream, a.desc, a.chunks, n0, a.n_desc, a.src1, a.src1_len);
         a.phase_chunks = uint32_t(per);
@@ -1305,7 +1306,9 @@ static hipError_t launch_stitch_range(const StitchArgs& a, hipStream_t stream, i
     const int var = (nontemporal >> 12) & 0xF;
     const int dbg = (nontemporal >> 16) & 0xFF;
 #ifndef V2P_BENCH_VARIANTS
-    if (dbg) return hipErrorInvalidValue;               // timing-only ablations (wrong results) are not in this library
+    // timing-only ablations (wrong results), the kernels' A/B variants, idle LDS and waves-per-group selectors are not in this
+    // library (libv2p_bench.so has them): only the routing-only variants 3 and 8 are
+    if (dbg || (var != 0 && var != 3 && var != 8) || (nontemporal >> 24) != 0) return hipErrorInvalidValue;
 #endif
     const uint32_t grid = grid_for(a.n_chunks, max_blocks ? max_blocks : 0x7FFFFFFFu);
     int tpt = (nontemporal >> 8) & 0xF;                 // chunks hold <= 256*tpt tasks
@@ -1326,11 +1329,12 @@ static hipError_t launch_stitch_range(const StitchArgs& a, hipStream_t stream, i
 #else
 #define V2P_LAUNCH_V(TT, VV, FF) V2P_L(TT, true, VV, 0, FF)
 #endif
+#define V2P_L4(TT, NTT, DD, RR, FF) hipLaunchKernelGGL((stitch4_kernel<TT, NTT, DD, RR>), dim3(grid), dim3(256), lds_pad, stream, V2P_KARGS, uint32_t(FF))
+#ifdef V2P_BENCH_VARIANTS
 #define V2P_LAUNCH(TT, FF) do { \
         if (!nt) V2P_L(TT, false, 0, 0, FF); \
         else if (var == 1) V2P_LAUNCH_V(TT, 1, FF); \
         else V2P_LAUNCH_V(TT, 0, FF); } while (0)
-#define V2P_L4(TT, NTT, DD, RR, FF) hipLaunchKernelGGL((stitch4_kernel<TT, NTT, DD, RR>), dim3(grid), dim3(256), lds_pad, stream, V2P_KARGS, uint32_t(FF))
 #define V2P_L3(TT, NTT, DD, FF) do { \
         if (var == 4) V2P_L4(TT, NTT, DD, 1, FF); \
         else if (var == 7) hipLaunchKernelGGL((stitch4_kernel<TT, NTT, DD, 8, 36864u>), dim3(grid), dim3(256), lds_pad, stream, V2P_KARGS, uint32_t(FF)); \
@@ -1338,6 +1342,10 @@ static hipError_t launch_stitch_range(const StitchArgs& a, hipStream_t stream, i
         else if (var == 5) V2P_L4(TT, NTT, DD, 2, FF); \
         else if (var == 6) V2P_L4(TT, NTT, DD, 4, FF); \
         else V2P_L4(TT, NTT, DD, 8, FF); } while (0)
+#else
+#define V2P_LAUNCH(TT, FF) do { if (!nt) V2P_L(TT, false, 0, 0, FF); else V2P_LAUNCH_V(TT, 0, FF); } while (0)
+#define V2P_L3(TT, NTT, DD, FF) V2P_L4(TT, NTT, DD, 8, FF)
+#endif
 #ifdef V2P_BENCH_VARIANTS
 #define V2P_LAUNCH3(TT, FF) do { \
         if (!nt) V2P_L3(TT, false, 0, FF); \
@@ -1366,7 +1374,7 @@ static hipError_t launch_stitch_range(const StitchArgs& a, hipStream_t stream, i
 #define V2P_LD(NTT, FF) do { if (var == 9) V2P_LDD(NTT, true, 0, FF); else if (dbg == 1) V2P_LDD(NTT, false, 1, FF); else if (dbg == 2) V2P_LDD(NTT, false, 2, FF); \
         else if (dbg == 3) V2P_LDD(NTT, false, 3, FF); else V2P_LDD(NTT, false, 0, FF); } while (0)
 #else
-#define V2P_LD(NTT, FF) do { if (var == 9) V2P_LDD(NTT, true, 0, FF); else V2P_LDD(NTT, false, 0, FF); } while (0)
+#define V2P_LD(NTT, FF) V2P_LDD(NTT, false, 0, FF)
 #endif
     // chunks flagged for stitchw_kernel (bit 2): one wave per chunk; bits 28..29: waves per workgroup (0 = 1, 1 = 2, 2 = 4; A/B runs)
     if ((nontemporal & 4) && !max_blocks) {

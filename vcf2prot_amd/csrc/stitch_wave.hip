@@ -66,8 +66,9 @@ struct WChk {
 };
 // (V2P_WAVE_ABLATE, development builds only, results are wrong: bit 0 the copy phase gathers the dots, bit 1 the patch phase does,
 // bit 2 no result store)
-#ifndef V2P_WAVE_ABLATE
-#define V2P_WAVE_ABLATE 0
+#if !defined(V2P_WAVE_ABLATE) || !defined(V2P_BENCH_VARIANTS)
+#undef V2P_WAVE_ABLATE
+#define V2P_WAVE_ABLATE 0                    /* (the engine library never ablates) */
 #endif
 __device__ __forceinline__ u32x4 wgather(uint64_t addr, const WChk& k, uint32_t site)
 {
@@ -428,8 +429,10 @@ hipError_t launch_stitch_wave(const StitchArgs& a, hipStream_t stream, bool nt, 
 #define V2P_LWR(NTT, SCC) hipLaunchKernelGGL((stitchw_kernel<1, NTT, SCC, true>), dim3(tw ? (((nc + 7u) & ~7u) + 8u * tw) : nc), dim3(64), 0, stream, \
         a.desc, ch, a.src0, a.src1, a.out, a.status, a.dots, nc, a.n_desc, a.src0_len, a.src1_len, a.out_len, a.next_chunks, n_next, 0u)
         if (a.rows) { if (nt && a.store_sc1) V2P_LWR(true, true); else if (nt) V2P_LWR(true, false); else V2P_LWR(false, false); }
+#ifdef V2P_BENCH_VARIANTS
         else if (waves_per_group == 4) { if (nt) V2P_LW(4, true); else V2P_LW(4, false); }
         else if (waves_per_group == 2) { if (nt) V2P_LW(2, true); else V2P_LW(2, false); }
+#endif
         else if (nt && a.store_sc1) hipLaunchKernelGGL((stitchw_kernel<1, true, true>), dim3(tw ? (((nc + 7u) & ~7u) + 8u * tw) : nc), dim3(64), 0, stream,
                                                       a.desc, ch, a.src0, a.src1, a.out, a.status, a.dots, nc, a.n_desc, a.src0_len, a.src1_len, a.out_len, a.next_chunks, n_next, 0u);
         else { if (nt) V2P_LW(1, true); else V2P_LW(1, false); }

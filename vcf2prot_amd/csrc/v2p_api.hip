@@ -117,6 +117,7 @@ struct v2p_ctx {
     PinnedBuf h_stage, h_in;                         // pinned staging: results coming back / narrowed tapes going out
     ImageBuilder gir_img;                            // reused across v2p_execute_gir calls (its vectors keep their capacity)
     struct GirQueue* queue = nullptr;                // v2p_execute_gir_shared: batches of concurrent callers (created at the first call)
+    v2p_launch_opts launch_opts{1u, 0u, 0ull, 0u, -1, 0u, 0u};   // v2p_set_launch_opts: phase size / threshold / store policy of this context's batches (A/B runs, tests)
 
     int fail(int code, const std::string& msg, int64_t index = -1) { err = msg; err_index = index; return code; }
     int hip_fail(hipError_t e, const char* what) {
@@ -1509,6 +1510,7 @@ int v2p_batch_execute(v2p_batch* b)
     StitchArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), b->n_desc, reinterpret_cast<const Chunk*>(b->d_chunks.ptr()),
                  uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->d_payload.ptr(), b->n_payload,
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
+    a.opt_phase_bytes = c->launch_opts.phase_bytes; a.opt_phase_min_chunks = c->launch_opts.phase_min_chunks; a.opt_store_sc1 = c->launch_opts.store_sc1;
     HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint, 0), "launch(stitch)");
     return V2P_OK;
 }
@@ -1727,6 +1729,34 @@ int v2p_pipeline_release(v2p_pipeline* p, uint32_t ticket)
 
 // ---- raw launchers -------------------------------------------------------------
 
+int v2p_stitch_launch_opts(void* hip_stream,
+                           const uint64_t* d_desc, uint64_t n_desc, const v2p_chunk* d_chunks, uint32_t n_chunks,
+                           const uint8_t* d_src0, uint64_t src0_len,
+                           const uint8_t* d_src1, uint64_t src1_len,
+                           uint8_t* d_out, uint64_t out_len,
+                           uint64_t* d_status, const v2p_launch_opts* opts)
+{
+    if ((reinterpret_cast<uintptr_t>(d_out) & 15u) || !d_status || !opts) return V2P_ERR_INVALID_ARG;
+    if (opts->routing & ~0xFFFu) return V2P_ERR_INVALID_ARG;      // (v2p_stitch_launch_bits() fills bits 1 .. 11)
+    StitchArgs a{d_desc, n_desc, reinterpret_cast<const Chunk*>(d_chunks), n_chunks, d_src0, src0_len, d_src1, src1_len,
+                 d_out, out_len, reinterpret_cast<unsigned long long*>(d_status)};
+    a.opt_phase_bytes = opts->phase_bytes; a.opt_phase_min_chunks = opts->phase_min_chunks; a.opt_store_sc1 = opts->store_sc1;
+    const int flags = int(opts->nontemporal ? 1u : 0u) | int(opts->routing & 0xFFEu) | int((opts->variant == 3u || opts->variant == 8u ? opts->variant : 0u) << 12);
+    if (opts->variant != 0u && opts->variant != 3u && opts->variant != 8u) return V2P_ERR_INVALID_ARG;
+    return launch_stitch(a, reinterpret_cast<hipStream_t>(hip_stream), flags, opts->max_blocks) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
+}
+
+int v2p_set_launch_opts(v2p_ctx* c, const v2p_launch_opts* opts)
+{
+    if (!c) return V2P_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (opts) c->launch_opts = *opts; else c->launch_opts = v2p_launch_opts{1u, 0u, 0ull, 0u, -1, 0u, 0u};
+    return V2P_OK;
+}
+
+#ifdef V2P_BENCH_VARIANTS
+// libv2p_bench.so only (csrc/bench/v2p_bench.h): the launcher with the packed flag word -- kernel variants, timing-only ablations,
+// idle LDS, waves per workgroup -- and the A/B switches read from the environment at every call
 int v2p_stitch_launch(void* hip_stream,
                       const uint64_t* d_desc, uint64_t n_desc, const v2p_chunk* d_chunks, uint32_t n_chunks,
                       const uint8_t* d_src0, uint64_t src0_len,
@@ -1737,8 +1767,13 @@ int v2p_stitch_launch(void* hip_stream,
     if ((reinterpret_cast<uintptr_t>(d_out) & 15u) || !d_status) return V2P_ERR_INVALID_ARG;
     StitchArgs a{d_desc, n_desc, reinterpret_cast<const Chunk*>(d_chunks), n_chunks, d_src0, src0_len, d_src1, src1_len,
                  d_out, out_len, reinterpret_cast<unsigned long long*>(d_status)};
+    if (const char* e = getenv("V2P_PHASE_BYTES")) { const uint64_t v = strtoull(e, nullptr, 10); a.opt_phase_bytes = v ? v : ~0ull; }   // 0: one phase, no touch
+    if (const char* e = getenv("V2P_WAVE_SC1")) a.opt_store_sc1 = atoi(e) != 0;
+    if (const char* e = getenv("V2P_PHASE_MIN_CHUNKS")) a.opt_phase_min_chunks = uint32_t(strtoul(e, nullptr, 10));
+    a.opt_touch = (getenv("V2P_PHASE_NO_TOUCH") ? 1u : 0u) | (getenv("V2P_PHASE_OWN_TOUCH") ? 2u : 0u) | (getenv("V2P_PHASE_ONE_LAUNCH") ? 4u : 0u);
     return launch_stitch(a, reinterpret_cast<hipStream_t>(hip_stream), nontemporal, max_blocks) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
 }
+#endif
 
 int v2p_digest_launch(void* hip_stream, const uint8_t* d_out, const uint64_t* d_hap_begin, uint64_t n_haps,
                       uint64_t out_bytes, uint64_t* d_digests)
@@ -1756,10 +1791,14 @@ int v2p_stitch_launch_bits(const v2p_chunk* chunks, uint64_t n_chunks)
 int v2p_order_chunks_for_xcds(v2p_chunk* chunks, uint64_t n_chunks, const uint64_t* desc, uint64_t n_desc, uint64_t proteome_len)
 {
     if ((n_chunks && !chunks) || (n_desc && !desc)) return V2P_ERR_INVALID_ARG;
+#ifdef V2P_BENCH_VARIANTS
     const char* e = getenv("V2P_ORDER_WINDOWS");                   // (experiments: 0 = haplotype-major inside a slice)
-    const char* eb = getenv("V2P_ORDER_MAX_BLOCKS");               // (tests, experiments: 1 = one order for the whole table, 64 = what the device builder does)
+    const char* eb = getenv("V2P_ORDER_MAX_BLOCKS");               // (experiments: 1 = one order for the whole table)
     order_chunks_for_xcds(reinterpret_cast<Chunk*>(chunks), n_chunks, desc, n_desc, proteome_len, 8, !(e && e[0] == '0'),
-                          eb ? uint32_t(strtoul(eb, nullptr, 10)) : 4096u);
+                          eb ? uint32_t(strtoul(eb, nullptr, 10)) : XCD_ORDER_MAX_BLOCKS);
+#else
+    order_chunks_for_xcds(reinterpret_cast<Chunk*>(chunks), n_chunks, desc, n_desc, proteome_len);
+#endif
     return V2P_OK;
 }
 
