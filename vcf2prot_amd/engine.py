@@ -66,11 +66,11 @@ def _p(a: Optional[np.ndarray]):
 class Context:
     """One ``v2p_ctx`` (one HIP stream on one GPU).  Not thread-safe by design: one per worker."""
 
-    def __init__(self, device: int = 0, debug_gpu: Optional[bool] = None, temporal_stores: bool = False):
+    def __init__(self, device: int = 0, debug_gpu: Optional[bool] = None, temporal_stores: bool = False, result_order: bool = False):
         self._lib = N.hip_lib()
         if debug_gpu is None:  # README.md:156-157: DEBUG_GPU is an environment flag
             debug_gpu = "DEBUG_GPU" in os.environ
-        flags = (N.V2P_FLAG_DEBUG_GPU if debug_gpu else 0) | (N.V2P_FLAG_TEMPORAL if temporal_stores else 0)
+        flags = (N.V2P_FLAG_DEBUG_GPU if debug_gpu else 0) | (N.V2P_FLAG_TEMPORAL if temporal_stores else 0) | (4 if result_order else 0)   # 4: V2P_FLAG_RESULT_ORDER (chunk tables are launched as given)
         h = ctypes.c_void_p()
         rc = self._lib.v2p_init(device, flags, ctypes.byref(h))
         if rc != N.V2P_OK:
