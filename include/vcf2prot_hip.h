@@ -109,6 +109,21 @@ int v2p_execute_gir_shared(v2p_ctx* ctx,
                            const uint32_t* ref, uint64_t n_ref,
                            const uint32_t* alt, uint64_t n_alt,
                            uint32_t* res, uint64_t n_res, int64_t* err_row);
+/* The same arm in two halves, for a worker that has something else to do while its batch is on the GPU -- packing the next haplotype's
+ * GIR (personalized_genome.rs:64-65 calls GIR::execute for haplotype 1, then for haplotype 2): v2p_gir_submit checks the tasks,
+ * narrows the tapes and stages this call's share of a batch on the calling thread, then returns; the batch's own runner thread
+ * closes it when the gathering window ends, uploads, launches, downloads; v2p_gir_collect waits for that and widens the result into
+ * `res`.  Every array given to submit (and `res`) must stay valid and untouched until collect, which must be called exactly once per
+ * ticket -- also after an error, which it reports (a task the reference would panic on is reported by collect, not by submit).
+ * v2p_execute_gir_shared is submit + collect. */
+typedef struct v2p_gir_ticket v2p_gir_ticket;
+int v2p_gir_submit(v2p_ctx* ctx,
+                   const uint64_t* code, const uint64_t* start_pos, const uint64_t* length,
+                   const uint64_t* start_pos_res, uint64_t n_tasks,
+                   const uint32_t* ref, uint64_t n_ref,
+                   const uint32_t* alt, uint64_t n_alt,
+                   uint32_t* res, uint64_t n_res, v2p_gir_ticket** ticket);
+int v2p_gir_collect(v2p_ctx* ctx, v2p_gir_ticket* ticket, int64_t* err_row);
 /* batches launched / calls served by v2p_execute_gir_shared on this context so far */
 int v2p_coalesce_stats(v2p_ctx* ctx, uint64_t* n_batches, uint64_t* n_calls);
 

@@ -50,24 +50,49 @@ def _jobs(coracle, seed, n):
     return jobs
 
 
-@pytest.mark.parametrize("n_threads,n_jobs,seed", [(64, 640, 1), (16, 200, 2), (3, 48, 3)])
-def test_threads_on_one_context_are_coalesced_and_exact(gpu_ctx, coracle, n_threads, n_jobs, seed):
+@pytest.mark.parametrize("n_threads,n_jobs,seed,two_halves", [(64, 640, 1, False), (16, 200, 2, False), (3, 48, 3, False), (16, 320, 4, True), (64, 512, 5, True)])
+def test_threads_on_one_context_are_coalesced_and_exact(gpu_ctx, coracle, n_threads, n_jobs, seed, two_halves):
+    """two_halves: every worker keeps TWO calls in flight -- v2p_gir_submit for job k + 1 before v2p_gir_collect of job k
+    (personalized_genome.rs:64-65: a sample's two haplotypes) -- every kind of GIR, every panic, reported by collect."""
     from vcf2prot_amd._native import V2PError, ERR_NAMES
     jobs = _jobs(coracle, seed, n_jobs)
     nb0, nc0 = gpu_ctx.coalesce_stats()
     results, failures = [None] * n_jobs, []
     nxt, lock = [0], threading.Lock()
 
+    def finish(item):
+        j, tk, res = item
+        try:
+            gpu_ctx.gir_collect(tk)
+            results[j] = res
+        except V2PError as e:
+            results[j] = (ERR_NAMES.get(e.code, e.code), e.index, res)
+        except Exception as e:                           # noqa: BLE001
+            failures.append((j, repr(e)))
+
     def worker():
+        pending = []
         while True:
             with lock:
                 j = nxt[0]
                 nxt[0] += 1
             if j >= n_jobs:
+                for item in pending:
+                    finish(item)
                 return
             job = jobs[j]
             g = job["g"]
             res = np.full(g["n_res"], job["fill"], dtype=np.uint32)
+            if two_halves:
+                try:
+                    tk = gpu_ctx.gir_submit(g["code"], g["start_pos"], g["length"], g["start_pos_res"], job["ref"], job["alt"], res)
+                except Exception as e:                   # noqa: BLE001
+                    failures.append((j, repr(e)))
+                    continue
+                pending.append((j, tk, res))
+                if len(pending) == 2:
+                    finish(pending.pop(0))
+                continue
             try:
                 gpu_ctx.execute_gir_shared(g["code"], g["start_pos"], g["length"], g["start_pos_res"], job["ref"], job["alt"], res)
                 results[j] = res
@@ -102,11 +127,11 @@ def test_harness_workers_sharing_one_context(built, coracle):
     from vcf2prot_amd import build
     from vcf2prot_amd.cohort import Cohort
     harness = build.build_harness()
-    for preset, n, threads in (("C1", 8, 4), ("C3", 12, 6)):
-        p = subprocess.run([harness, "run", preset, str(n), str(threads), "--shared"], capture_output=True, text=True, timeout=300)
+    for preset, n, threads, flag in (("C1", 8, 4, "--shared"), ("C3", 12, 6, "--shared"), ("C3", 24, 6, "--async"), ("C2", 16, 16, "--async")):
+        p = subprocess.run([harness, "run", preset, str(n), str(threads), flag], capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stdout + p.stderr
         out = json.loads(p.stdout.strip().split("\n")[-1])
-        assert "shared" in out["mode"]
+        assert "shared" in out["mode"] and (flag == "--shared" or "v2p_gir_submit" in out["mode"])
         c = Cohort.preset(preset)
         for h in range(n):
             hap = c.haplotype(h)

@@ -19,7 +19,7 @@ def stitch_rows(path):
     return [r for r in csv.DictReader(open(path)) if is_step_kernel(r["Kernel_Name"])]
 
 
-summary = {"tag": tag, "command": "python3 bench.py --no-cpu-baseline --no-pcie " + " ".join(sys.argv[4:])}
+summary = {"tag": tag, "command": "python3 bench.py --no-cpu-baseline --no-pcie --no-c2 --no-host-packed --verify sample --steps 10 --warmup 3 " + " ".join(sys.argv[4:])}
 stats = os.path.join(src, "trace", "trace_kernel_stats.csv")
 if os.path.exists(stats):
     rows = list(csv.DictReader(open(stats)))
@@ -42,6 +42,28 @@ if os.path.exists(stats):
         summary["steps_profiled"] = steps
         summary["launches_per_step"] = {k["name"][:40]: k["calls"] / steps for k in ks}
         summary["kernel_ms_per_step"] = sum(k["total_ns"] for k in ks) / steps / 1e6
+# the TIMED steps alone (the run also executes the image right after its build, on a fresh arena, and warms up): every execute begins
+# with a touch_image_kernel launch; the last `steps` executes of the trace are the ones bench.py times
+trace = glob.glob(os.path.join(src, "trace", "*kernel_trace.csv"))
+if trace:
+    rows = [r for r in csv.DictReader(open(trace[0])) if is_step_kernel(r["Kernel_Name"])]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    execs, build = [], {}
+    for r in rows:
+        if "touch_image" in r["Kernel_Name"] or not execs:
+            execs.append(0.0)
+        execs[-1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    k = 10
+    if len(execs) >= k:
+        summary["timed_steps"] = {"steps": k, "kernel_ms_per_step": sum(execs[-k:]) / k, "min": min(execs[-k:]), "max": max(execs[-k:]), "all_executes_ms": [round(x, 3) for x in execs]}
+    for r in csv.DictReader(open(trace[0])):
+        n = r["Kernel_Name"]
+        if any(t in n for t in ("rows_", "scan_", "sub_", "xcd_")):
+            key = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
+            build.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    if build:
+        summary["build_kernels_ms_per_build"] = {k2: sum(v) / 2.0 for k2, v in sorted(build.items(), key=lambda kv: -sum(kv[1]))}     # (the run builds the image twice)
+        summary["build_kernels_ms_total_per_build"] = sum(sum(v) for v in build.values()) / 2.0
 counters, n_steps = {}, {}
 for f in glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv")):
     rows = stitch_rows(f)
@@ -49,6 +71,18 @@ for f in glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv")):
     for r in rows:
         counters[r["Counter_Name"]] = counters.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         n_steps[r["Counter_Name"]] = steps
+# the image-build kernels of the same run (build_rows.hip): FETCH_SIZE / WRITE_SIZE per build (the run builds the image twice)
+bc = {}
+for f in glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        if any(t in n for t in ("rows_", "scan_", "sub_", "xcd_")) and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            key = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
+            bc.setdefault(key, {}).setdefault(r["Counter_Name"], 0.0)
+            bc[key][r["Counter_Name"]] += float(r["Counter_Value"])
+if bc:
+    summary["build_traffic_bytes_per_build"] = {k: {"fetch_bytes_corrected_x2": 2.0 * v.get("FETCH_SIZE", 0.0) * 1024.0 / 2.0, "write_bytes": v.get("WRITE_SIZE", 0.0) * 1024.0 / 2.0} for k, v in sorted(bc.items())}
+    summary["build_traffic_total_bytes_per_build"] = sum(v["fetch_bytes_corrected_x2"] + v["write_bytes"] for v in summary["build_traffic_bytes_per_build"].values())
 # per STEP (= per execute() of the image: all phases' launches summed)
 summary["counters_per_step"] = {k: v / max(n_steps[k], 1) for k, v in sorted(counters.items())}
 c = summary["counters_per_step"]

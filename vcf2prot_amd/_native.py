@@ -42,6 +42,8 @@ HIP_API = {
                                 c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_uint64]),
     "v2p_execute_gir_shared": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
                                        c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_uint64, POINTER(c_int64)]),
+    "v2p_gir_submit": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_uint64, POINTER(c_void_p)]),
+    "v2p_gir_collect": (c_int, [c_void_p, c_void_p, POINTER(ctypes.c_int64)]),
     "v2p_coalesce_stats": (c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
     "v2p_validate_gir": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
                                  c_uint64, c_uint64, c_uint64, POINTER(c_int64), POINTER(c_int)]),

@@ -116,10 +116,35 @@ public:
         return {std::move(res_), std::move(annotation_)};
     }
 
+    // ... and in two halves (v2p_gir_submit / v2p_gir_collect): the worker that calls GIR::execute for haplotype 1 and then for
+    // haplotype 2 (personalized_genome.rs:64-65) submits the first, packs and submits the second while the first batch is on the
+    // GPU, then collects both.  The GIR owns the arrays the engine reads until collect() has returned.
+    void submit(Engine engine, GpuContext& ctx)
+    {
+        if (engine != Engine::GPU) throw std::logic_error("the st/mt engines are the reference's CPU code");
+        const size_t n = g_rep_.size();
+        soa_.resize(4 * n);
+        uint64_t* code = soa_.data(), *sp = code + n, *ln = sp + n, *sr = ln + n;
+        for (size_t i = 0; i < n; ++i) { code[i] = g_rep_[i].exe_code; sp[i] = g_rep_[i].start_pos; ln[i] = g_rep_[i].length; sr[i] = g_rep_[i].start_pos_res; }
+        const int rc = v2p_gir_submit(ctx.raw(), code, sp, ln, sr, n, reinterpret_cast<const uint32_t*>(ref_.data()), ref_.size(),
+                                      reinterpret_cast<const uint32_t*>(alt_.data()), alt_.size(), reinterpret_cast<uint32_t*>(&res_[0]), res_.size(), &ticket_);
+        if (rc != V2P_OK) throw Panic(rc, v2p_last_error(ctx.raw()), v2p_last_error_index(ctx.raw()));
+    }
+    std::pair<std::u32string, Annotation> collect(GpuContext& ctx) &&
+    {
+        int64_t row = -1;
+        const int rc = v2p_gir_collect(ctx.raw(), ticket_, &row);
+        ticket_ = nullptr;
+        if (rc != V2P_OK) throw Panic(rc, v2p_last_error(ctx.raw()), row);
+        return {std::move(res_), std::move(annotation_)};
+    }
+
 private:
     std::vector<Task> g_rep_;
     Annotation annotation_;
     std::u32string alt_, ref_, res_;
+    std::vector<uint64_t> soa_;                                   // the marshalled Task vector of a submitted GIR
+    v2p_gir_ticket* ticket_ = nullptr;
 };
 
 // parts/exec.rs:23-42 for Engine::GPU: jobs (haplotype GIRs) are pulled by a pool of workers,

@@ -77,7 +77,7 @@ static uint64_t mix64(uint64_t x)
     return x ^ (x >> 31);
 }
 
-static int run(const char* preset, uint64_t n_haps, int threads, bool shared)
+static int run(const char* preset, uint64_t n_haps, int threads, bool shared, bool async)
 {
     v2p_cohort_params p;
     if (v2p_cohort_preset(preset, &p)) { std::fprintf(stderr, "unknown preset %s\n", preset); return 2; }
@@ -139,6 +139,18 @@ static int run(const char* preset, uint64_t n_haps, int threads, bool shared)
                         { GIR warm = make_gir(uint64_t(t) % n_haps); (void)std::move(warm).execute_shared(Engine::GPU, *one); }
                         if (++ready == threads) t0 = std::chrono::steady_clock::now();
                         while (ready.load() < threads) std::this_thread::yield();
+                        if (async) {
+                            // two haplotypes per worker in flight, as a sample's two are (personalized_genome.rs:64-65): the second is
+                            // marshalled and staged while the first one's batch is on the GPU
+                            uint64_t prev = ~0ull;
+                            for (uint64_t h = next++; h < n_haps; h = next++) {
+                                girs[h]->submit(Engine::GPU, *one);
+                                if (prev != ~0ull) results[prev] = std::move(*girs[prev]).collect(*one).first;
+                                prev = h;
+                            }
+                            if (prev != ~0ull) results[prev] = std::move(*girs[prev]).collect(*one).first;
+                            return;
+                        }
                         for (uint64_t h = next++; h < n_haps; h = next++) {
                             auto out = std::move(*girs[h]).execute_shared(Engine::GPU, *one);
                             results[h] = std::move(out.first);
@@ -162,7 +174,7 @@ static int run(const char* preset, uint64_t n_haps, int threads, bool shared)
     for (uint64_t h = 0; h < n_haps; ++h) consume(h, std::move(results[h]), Annotation());
     std::printf("{\"mode\": \"gir-faithful: GIR::execute(Engine::GPU) on prebuilt GIRs (Rust chars in and out), %d worker threads, %s\", \"preset\": \"%s\", "
                 "\"haplotypes\": %llu, \"aa\": %llu, \"seconds\": %.6f, \"aa_per_s\": %.4e, \"digests\": [",
-                threads, shared ? "ONE shared ctx, calls coalesced (v2p_execute_gir_shared)" : "one ctx each", preset,
+                threads, shared ? (async ? "ONE shared ctx, calls coalesced, two GIRs per worker in flight (v2p_gir_submit / v2p_gir_collect)" : "ONE shared ctx, calls coalesced (v2p_execute_gir_shared)") : "one ctx each", preset,
                 (unsigned long long)n_haps, (unsigned long long)aa_timed, secs, double(aa_timed) / secs);
     for (uint64_t h = 0; h < n_haps; ++h) std::printf("%s%llu", h ? ", " : "", (unsigned long long)digest[h]);
     std::printf("]}\n");
@@ -450,7 +462,8 @@ int main(int argc, char** argv)
     }
     if (argc >= 2 && !std::strcmp(argv[1], "kat")) return kat();
     if (argc >= 5 && !std::strcmp(argv[1], "run"))
-        return run(argv[2], std::strtoull(argv[3], nullptr, 10), std::atoi(argv[4]), argc >= 6 && !std::strcmp(argv[5], "--shared"));
-    std::fprintf(stderr, "usage: v2p_harness kat | run <preset> <haplotypes> <threads> [--shared]\n");
+        return run(argv[2], std::strtoull(argv[3], nullptr, 10), std::atoi(argv[4]), argc >= 6 && (!std::strcmp(argv[5], "--shared") || !std::strcmp(argv[5], "--async")),
+                   argc >= 6 && !std::strcmp(argv[5], "--async"));
+    std::fprintf(stderr, "usage: v2p_harness kat | run <preset> <haplotypes> <threads> [--shared | --async]\n");
     return 2;
 }

@@ -14,6 +14,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/vcf2prot_hip.h"
@@ -506,6 +507,8 @@ struct GirQueue {
     uint64_t n_batches = 0, n_joined = 0;            // statistics (v2p_coalesce_stats)
     std::atomic<uint64_t> ns_pack{0}, ns_join{0}, ns_stage{0}, ns_wait{0}, ns_widen{0}, ns_gpu{0};   // V2P_COALESCE_PROFILE: where the callers' time goes
     std::atomic<uint64_t> ns_b_setup{0}, ns_b_h2d{0}, ns_b_launch{0}, ns_b_d2h{0}, ns_b_sync{0}, ns_b_window{0}, ns_b_strag{0};   // ... and the leader's
+    std::vector<std::thread> runners;                // one per batch slot: closes its batch when the gathering window ends, uploads, launches, downloads, waits
+    bool stop = false;                               // (nobody's GIR::execute call does that any more: v2p_gir_submit returns once its share is staged)
     uint64_t desc_cap() const { return cap_bytes / 16; }        // descriptors (8 B each: half the tape bytes at 16 result bytes per task)
     uint64_t chunk_cap() const { return cap_bytes / 256; }      // chunk records
 };
@@ -514,6 +517,9 @@ static void queue_destroy(v2p_ctx* c)
 {
     GirQueue* q = c->queue;
     if (!q) return;
+    { std::lock_guard<std::mutex> lk(q->mu); q->stop = true; }
+    q->cv.notify_all();
+    for (auto& t : q->runners) if (t.joinable()) t.join();
     if (getenv("V2P_COALESCE_PROFILE"))
         fprintf(stderr, "coalesce: %llu calls in %llu batches; per call ms: pack %.3f join %.3f stage %.3f wait %.3f widen %.3f; gpu per batch %.3f\n",
                 (unsigned long long)q->n_joined, (unsigned long long)q->n_batches, q->ns_pack / 1e6 / double(q->n_joined ? q->n_joined : 1),
@@ -582,42 +588,91 @@ static void batch_run(v2p_ctx* c, GirBatch& b)
     }
 }
 
-extern "C" int v2p_execute_gir_shared(v2p_ctx* c,
-                                      const uint64_t* code, const uint64_t* start_pos, const uint64_t* length,
-                                      const uint64_t* start_pos_res, uint64_t n_tasks,
-                                      const uint32_t* ref, uint64_t n_ref, const uint32_t* alt, uint64_t n_alt,
-                                      uint32_t* res, uint64_t n_res, int64_t* err_row)
+// A call in flight between v2p_gir_submit and v2p_gir_collect
+struct v2p_gir_ticket {
+    GirBatch* b = nullptr;                       // nullptr: executed inside submit (ordered / oversized GIRs) -- rc is final
+    int rc = V2P_OK;
+    int64_t row = -1;
+    std::string err;
+    bool wide = false;
+    uint64_t res_off = 0;
+    // the caller's arrays (they stay the caller's, valid until collect)
+    const uint64_t* code = nullptr; const uint64_t* start_pos = nullptr; const uint64_t* length = nullptr; const uint64_t* start_pos_res = nullptr;
+    uint64_t n_tasks = 0;
+    const uint32_t* ref = nullptr; uint64_t n_ref = 0; const uint32_t* alt = nullptr; uint64_t n_alt = 0;
+    uint32_t* res = nullptr; uint64_t n_res = 0;
+};
+
+// the runner of batch slot k: everything a batch needs after its members staged their shares
+static void queue_runner(v2p_ctx* c, GirQueue* q, int k)
 {
-    if (err_row) *err_row = -1;
-    if (!c) return V2P_ERR_INVALID_ARG;
+    using clk = std::chrono::steady_clock;
+    auto ns_since = [](clk::time_point t) { return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t).count()); };
+    GirBatch* b = &q->batch[k];
+    std::unique_lock<std::mutex> lk(q->mu);
+    for (;;) {
+        q->cv.wait(lk, [&] { return q->stop || b->state == GirBatch::OPEN; });
+        if (q->stop) return;
+        const auto deadline = b->opened + std::chrono::microseconds(q->window_us);
+        const clk::time_point tw = clk::now();
+        while (!q->stop && q->open == b && clk::now() < deadline) q->cv.wait_until(lk, deadline);
+        if (q->open == b) q->open = nullptr;
+        b->state = GirBatch::CLOSED;
+        q->ns_b_window += ns_since(tw);
+        const clk::time_point ts = clk::now();
+        while (b->n_ready < b->n_reqs) q->cv.wait(lk);
+        q->ns_b_strag += ns_since(ts);
+        lk.unlock();
+        const clk::time_point tg = clk::now();
+        if (b->rc == V2P_OK) batch_run(c, *b);
+        q->ns_gpu += ns_since(tg);
+        lk.lock();
+        b->state = GirBatch::DONE;
+        q->cv.notify_all();
+    }
+}
+
+static int gir_solo(v2p_ctx* c, v2p_gir_ticket& t)
+{
+    std::vector<uint8_t> c8(t.n_tasks);
+    for (uint64_t i = 0; i < t.n_tasks; ++i) c8[i] = uint8_t(t.code[i]);
+    const int rc = v2p_execute_gir(c, c8.data(), t.start_pos, t.length, t.start_pos_res, t.n_tasks, t.ref, t.n_ref, t.alt, t.n_alt, t.res, t.n_res);
+    if (rc != V2P_OK) t.row = v2p_last_error_index(c);
+    return rc;
+}
+
+extern "C" int v2p_gir_submit(v2p_ctx* c,
+                              const uint64_t* code, const uint64_t* start_pos, const uint64_t* length,
+                              const uint64_t* start_pos_res, uint64_t n_tasks,
+                              const uint32_t* ref, uint64_t n_ref, const uint32_t* alt, uint64_t n_alt,
+                              uint32_t* res, uint64_t n_res, v2p_gir_ticket** ticket)
+{
+    if (!c || !ticket) return V2P_ERR_INVALID_ARG;
+    *ticket = nullptr;
     auto fail = [&](int code_, const std::string& msg, int64_t row) {
-        if (err_row) *err_row = row;
         std::lock_guard<std::mutex> lk(c->mu);
         return c->fail(code_, msg, row);
     };
     if ((n_tasks && (!code || !start_pos || !length || !start_pos_res)) || (n_ref && !ref) || (n_alt && !alt) || (n_res && !res))
         return fail(V2P_ERR_INVALID_ARG, "null argument", -1);
-    if (n_tasks == 0) return V2P_OK;
+    std::unique_ptr<v2p_gir_ticket> t(new (std::nothrow) v2p_gir_ticket());
+    if (!t) return fail(V2P_ERR_HIP, "out of host memory", -1);
+    t->code = code; t->start_pos = start_pos; t->length = length; t->start_pos_res = start_pos_res; t->n_tasks = n_tasks;
+    t->ref = ref; t->n_ref = n_ref; t->alt = alt; t->n_alt = n_alt; t->res = res; t->n_res = n_res;
+    if (n_tasks == 0) { *ticket = t.release(); return V2P_OK; }
     // every task's bounds first, on the calling thread: the reference would panic (haplotype_instruction.rs:154, task.rs:42-49)
     bool canonical = true;
     uint64_t cursor = 0;
     for (uint64_t i = 0; i < n_tasks; ++i) {
-        if (code[i] > 1) return fail(V2P_ERR_BAD_CODE, std::string(err_name(V2P_ERR_BAD_CODE)) + " at row " + std::to_string(i), int64_t(i));
+        int bad = 0;
         const uint64_t n_src = code[i] == 0 ? n_ref : n_alt;
-        if (start_pos_res[i] + length[i] > n_res || start_pos_res[i] + length[i] < length[i])
-            return fail(V2P_ERR_RES_OOB, std::string(err_name(V2P_ERR_RES_OOB)) + " at row " + std::to_string(i), int64_t(i));
-        if (start_pos[i] + length[i] > n_src || start_pos[i] + length[i] < length[i])
-            return fail(V2P_ERR_SRC_OOB, std::string(err_name(V2P_ERR_SRC_OOB)) + " at row " + std::to_string(i), int64_t(i));
+        if (code[i] > 1) bad = V2P_ERR_BAD_CODE;
+        else if (start_pos_res[i] + length[i] > n_res || start_pos_res[i] + length[i] < length[i]) bad = V2P_ERR_RES_OOB;
+        else if (start_pos[i] + length[i] > n_src || start_pos[i] + length[i] < length[i]) bad = V2P_ERR_SRC_OOB;
+        if (bad) { t->rc = bad; t->row = int64_t(i); t->err = std::string(err_name(bad)) + " at row " + std::to_string(i); *ticket = t.release(); return V2P_OK; }   // (reported by collect, like a panic inside GIR::execute)
         if (start_pos_res[i] < cursor) canonical = false;
         cursor = start_pos_res[i] + length[i];
     }
-    auto solo = [&]() {                                   // ordered / wide-char / oversized GIRs: the one-haplotype path, serialised on the context
-        std::vector<uint8_t> c8(n_tasks);
-        for (uint64_t i = 0; i < n_tasks; ++i) c8[i] = uint8_t(code[i]);
-        const int rc = v2p_execute_gir(c, c8.data(), start_pos, length, start_pos_res, n_tasks, ref, n_ref, alt, n_alt, res, n_res);
-        if (rc != V2P_OK && err_row) *err_row = v2p_last_error_index(c);
-        return rc;
-    };
     GirQueue* q;
     {
         std::lock_guard<std::mutex> lk(c->mu);
@@ -627,7 +682,7 @@ extern "C" int v2p_execute_gir_shared(v2p_ctx* c,
                 if (const char* e = getenv("V2P_COALESCE_MB")) { const uint64_t mb = strtoull(e, nullptr, 10); if (mb >= 1 && mb <= 16384) c->queue->cap_bytes = mb << 20; }
                 if (const char* e = getenv("V2P_COALESCE_US")) c->queue->window_us = uint32_t(strtoul(e, nullptr, 10));
                 if (const char* e = getenv("V2P_COALESCE_BATCHES")) { const int k = atoi(e); if (k >= 1 && k <= GirQueue::N_BATCH) c->queue->n_batch = k; }
-                // every batch's staging, device buffers and stream now, by the first caller: a batch that allocates at its first use
+                // every batch's staging, device buffers, stream and runner now, by the first caller: a batch that allocates at its first use
                 // does so inside somebody's call (pinned staging alone is tens of milliseconds per batch)
                 GirQueue& q0 = *c->queue;
                 hipError_t e = hipSetDevice(c->device);
@@ -645,16 +700,18 @@ extern "C" int v2p_execute_gir_shared(v2p_ctx* c,
                     if (e == hipSuccess) e = hipStreamCreateWithFlags(&bb.stream, hipStreamNonBlocking);
                 }
                 if (e != hipSuccess) { queue_destroy(c); return c->fail(V2P_ERR_HIP, std::string("coalescing queue: ") + hipGetErrorString(e)); }
+                for (int k = 0; k < q0.n_batch; ++k) q0.runners.emplace_back(queue_runner, c, c->queue, k);
             }
         }
         q = c->queue;
     }
     if (!q) return fail(V2P_ERR_HIP, "out of host memory", -1);
     const uint64_t ref_room = (n_ref + 15) & ~15ull, in_need = ref_room + ((n_alt + 15) & ~15ull), res_need = (n_res + 4095) & ~4095ull;
-    if (!canonical || in_need > q->cap_bytes || res_need > q->cap_bytes) return solo();
+    // ordered / oversized GIRs: the one-haplotype path, serialised on the context, inside this call
+    if (!canonical || in_need > q->cap_bytes || res_need > q->cap_bytes) { t->rc = gir_solo(c, *t); if (t->rc) t->err = v2p_last_error(c); *ticket = t.release(); return V2P_OK; }
 
     using clk = std::chrono::steady_clock;
-    auto ns_since = [](clk::time_point t) { return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t).count()); };
+    auto ns_since = [](clk::time_point tt) { return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - tt).count()); };
     clk::time_point tp = clk::now();
     // the caller's own image, cut as if its result began the arena: batch offsets are multiples of 4 KiB, so the cuts keep their alignment
     thread_local ImageBuilder img;
@@ -664,31 +721,35 @@ extern "C" int v2p_execute_gir_shared(v2p_ctx* c,
     img.desc.reserve(n_tasks + n_tasks / 4 + 64);
     for (uint64_t i = 0; i < n_tasks; ++i) {
         const int ps = img.add_task(code[i] == 0 ? SPACE_PROTEOME : SPACE_PAYLOAD, start_pos[i], length[i], start_pos_res[i], n_res);
-        if (ps != PACK_OK) return fail(pack_to_err(ps), "pack failed", int64_t(i));
+        if (ps != PACK_OK) { t->rc = pack_to_err(ps); t->row = int64_t(i); t->err = "pack failed"; *ticket = t.release(); return V2P_OK; }
     }
     img.end_haplotype(n_res);
     img.finish();
     const uint64_t nd = img.desc.size(), nc = img.chunks.size();
-    if (nd > q->desc_cap() || nc > q->chunk_cap()) return solo();
+    if (nd > q->desc_cap() || nc > q->chunk_cap()) { t->rc = gir_solo(c, *t); if (t->rc) t->err = v2p_last_error(c); *ticket = t.release(); return V2P_OK; }
 
     q->ns_pack += ns_since(tp); tp = clk::now();
     // ---- join a batch ----
     GirBatch* b = nullptr;
-    bool leader = false;
     uint64_t in_off = 0, res_off = 0, desc_off = 0, chunk_off = 0;
     {
         std::unique_lock<std::mutex> lk(q->mu);
         for (;;) {
             if (q->open && (q->open->in_bytes + in_need > q->cap_bytes || q->open->res_bytes + res_need > q->cap_bytes ||
-                            q->open->n_desc + nd > q->desc_cap() || q->open->n_chunks + nc > q->chunk_cap()))
-                q->open = nullptr;                       // full: its leader closes it when the window ends; this call opens the next one
+                            q->open->n_desc + nd > q->desc_cap() || q->open->n_chunks + nc > q->chunk_cap())) {
+                q->open = nullptr;                       // full: its runner closes it; this call opens the next one
+                q->cv.notify_all();
+            }
             if (!q->open) {
+                b = nullptr;
                 for (int k = 0; k < q->n_batch; ++k) if (q->batch[k].state == GirBatch::FREE) { b = &q->batch[k]; break; }
                 if (!b) { q->cv.wait(lk); continue; }    // every batch is in flight
-                b->state = GirBatch::OPEN; b->n_reqs = b->n_ready = b->n_left = 0;
+                b->n_reqs = b->n_ready = b->n_left = 0;
                 b->in_bytes = b->res_bytes = b->n_desc = b->n_chunks = 0; b->rc = V2P_OK; b->err.clear();
                 b->opened = std::chrono::steady_clock::now();
-                q->open = b; leader = true; ++q->n_batches;
+                b->state = GirBatch::OPEN;
+                q->open = b; ++q->n_batches;
+                q->cv.notify_all();                      // (its runner starts the gathering window)
             }
             b = q->open;
             break;
@@ -696,23 +757,13 @@ extern "C" int v2p_execute_gir_shared(v2p_ctx* c,
         in_off = b->in_bytes; res_off = b->res_bytes; desc_off = b->n_desc; chunk_off = b->n_chunks;
         b->in_bytes += in_need; b->res_bytes += res_need; b->n_desc += nd; b->n_chunks += nc;
         ++b->n_reqs; ++b->n_left; ++q->n_joined;
-        if (leader) {
-            // pinned staging of a batch is allocated once, at full capacity, by its first leader (callers write into it concurrently)
-            hipError_t e = hipSetDevice(c->device);
-            if (e == hipSuccess) e = b->h_in.ensure(q->cap_bytes);
-            if (e == hipSuccess) e = b->h_out.ensure(q->cap_bytes + 64);
-            if (e == hipSuccess) e = b->h_desc.ensure(q->desc_cap() * 8);
-            if (e == hipSuccess) e = b->h_chunks.ensure(q->chunk_cap() * sizeof(Chunk));
-            if (e != hipSuccess) { b->rc = V2P_ERR_HIP; b->err = std::string("hipHostMalloc(batch staging): ") + hipGetErrorString(e); }
-        }
     }
     q->ns_join += ns_since(tp); tp = clk::now();
     // ---- this caller's share of the staging, on its own thread ----
-    bool wide = false;
-    if (b->rc == V2P_OK) {
+    {
         uint32_t seen = narrow_chars(ref, b->h_in.p + in_off, n_ref);
         seen |= narrow_chars(alt, b->h_in.p + in_off + ref_room, n_alt);
-        wide = seen > 0xFFu;                             // a char above 0xFF: this GIR takes the 4-byte path by itself (its chunks run on garbage nobody reads)
+        t->wide = seen > 0xFFu;                          // a char above 0xFF: this GIR takes the 4-byte path by itself (its chunks run on garbage nobody reads)
         uint64_t* hd = reinterpret_cast<uint64_t*>(b->h_desc.p) + desc_off;
         for (uint64_t i = 0; i < nd; ++i) {
             const uint64_t d = img.desc[i];
@@ -722,43 +773,48 @@ extern "C" int v2p_execute_gir_shared(v2p_ctx* c,
         Chunk* hc = reinterpret_cast<Chunk*>(b->h_chunks.p) + chunk_off;
         for (uint64_t i = 0; i < nc; ++i) hc[i] = Chunk{img.chunks[i].task_begin + desc_off, img.chunks[i].dst_n + res_off};
     }
-    q->ns_stage += ns_since(tp); tp = clk::now();
+    q->ns_stage += ns_since(tp);
+    {
+        std::lock_guard<std::mutex> lk(q->mu);
+        ++b->n_ready;
+    }
+    q->cv.notify_all();                                  // (the batch's runner may be waiting for this caller's share)
+    t->b = b; t->res_off = res_off;
+    *ticket = t.release();
+    return V2P_OK;
+}
+
+extern "C" int v2p_gir_collect(v2p_ctx* c, v2p_gir_ticket* tk, int64_t* err_row)
+{
+    if (err_row) *err_row = -1;
+    if (!c || !tk) return V2P_ERR_INVALID_ARG;
+    std::unique_ptr<v2p_gir_ticket> t(tk);
+    auto fail = [&](int code_, const std::string& msg, int64_t row) {
+        if (err_row) *err_row = row;
+        std::lock_guard<std::mutex> lk(c->mu);
+        return c->fail(code_, msg, row);
+    };
+    GirBatch* b = t->b;
+    if (!b) return t->rc == V2P_OK ? V2P_OK : fail(t->rc, t->err, t->row);
+    GirQueue* q = c->queue;
+    using clk = std::chrono::steady_clock;
+    auto ns_since = [](clk::time_point tt) { return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - tt).count()); };
+    clk::time_point tp = clk::now();
     {
         std::unique_lock<std::mutex> lk(q->mu);
-        ++b->n_ready;
-        if (leader) {
-            const auto deadline = b->opened + std::chrono::microseconds(q->window_us);
-            const clk::time_point tw = clk::now();
-            while (q->open == b && std::chrono::steady_clock::now() < deadline) q->cv.wait_until(lk, deadline);
-            if (q->open == b) q->open = nullptr;
-            b->state = GirBatch::CLOSED;
-            q->ns_b_window += ns_since(tw);
-            const clk::time_point ts = clk::now();
-            while (b->n_ready < b->n_reqs) q->cv.wait(lk);
-            q->ns_b_strag += ns_since(ts);
-            lk.unlock();
-            const clk::time_point tg = clk::now();
-            if (b->rc == V2P_OK) batch_run(c, *b);
-            q->ns_gpu += ns_since(tg);
-            lk.lock();
-            b->state = GirBatch::DONE;
-            q->cv.notify_all();
-        } else {
-            q->cv.notify_all();                          // (the leader may be waiting for this caller's share)
-            while (b->state != GirBatch::DONE) q->cv.wait(lk);
-        }
+        while (b->state != GirBatch::DONE) q->cv.wait(lk);
     }
     q->ns_wait += ns_since(tp); tp = clk::now();
-    int rc = b->rc;
-    std::string err = rc != V2P_OK ? b->err : std::string();
-    if (rc == V2P_OK && !wide) {
+    const int rc = b->rc;
+    const std::string err = rc != V2P_OK ? b->err : std::string();
+    if (rc == V2P_OK && !t->wide) {
         // only cells some task covers go to the caller (the others keep the caller's content: haplotype_instruction.rs:78 filled them with '.')
-        const uint8_t* st = b->h_out.p + res_off;
-        for (uint64_t i = 0; i < n_tasks;) {
-            const uint64_t lo = start_pos_res[i];
-            uint64_t hi = lo + length[i];
-            for (++i; i < n_tasks && start_pos_res[i] == hi; ++i) hi += length[i];
-            widen_chars(st + lo, res + lo, hi - lo);
+        const uint8_t* st = b->h_out.p + t->res_off;
+        for (uint64_t i = 0; i < t->n_tasks;) {
+            const uint64_t lo = t->start_pos_res[i];
+            uint64_t hi = lo + t->length[i];
+            for (++i; i < t->n_tasks && t->start_pos_res[i] == hi; ++i) hi += t->length[i];
+            widen_chars(st + lo, t->res + lo, hi - lo);
         }
     }
     q->ns_widen += ns_since(tp);
@@ -767,7 +823,22 @@ extern "C" int v2p_execute_gir_shared(v2p_ctx* c,
         if (--b->n_left == 0) { b->state = GirBatch::FREE; q->cv.notify_all(); }
     }
     if (rc != V2P_OK) return fail(rc, err, -1);
-    return wide ? solo() : V2P_OK;
+    if (t->wide) { const int r2 = gir_solo(c, *t); if (r2 != V2P_OK && err_row) *err_row = t->row; return r2; }
+    return V2P_OK;
+}
+
+// the blocking form: GIR::execute as the reference calls it
+extern "C" int v2p_execute_gir_shared(v2p_ctx* c,
+                                      const uint64_t* code, const uint64_t* start_pos, const uint64_t* length,
+                                      const uint64_t* start_pos_res, uint64_t n_tasks,
+                                      const uint32_t* ref, uint64_t n_ref, const uint32_t* alt, uint64_t n_alt,
+                                      uint32_t* res, uint64_t n_res, int64_t* err_row)
+{
+    if (err_row) *err_row = -1;
+    v2p_gir_ticket* t = nullptr;
+    const int rc = v2p_gir_submit(c, code, start_pos, length, start_pos_res, n_tasks, ref, n_ref, alt, n_alt, res, n_res, &t);
+    if (rc != V2P_OK) return rc;
+    return v2p_gir_collect(c, t, err_row);
 }
 
 extern "C" int v2p_coalesce_stats(v2p_ctx* c, uint64_t* n_batches, uint64_t* n_calls)

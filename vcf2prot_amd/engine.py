@@ -153,6 +153,33 @@ class Context:
             raise V2PError(rc, (self._lib.v2p_last_error(self._h) or b"").decode(), int(row.value))
         return res
 
+    def gir_submit(self, code, start_pos, length, start_pos_res, ref: np.ndarray, alt: np.ndarray, res: np.ndarray):
+        """v2p_gir_submit: the first half of execute_gir_shared -- checks, narrows and stages this call's share of a batch on the calling
+        thread and returns a ticket; the arrays stay referenced by the ticket until gir_collect."""
+        code = np.ascontiguousarray(code, dtype=np.uint64)
+        sp = np.ascontiguousarray(start_pos, dtype=np.uint64)
+        ln = np.ascontiguousarray(length, dtype=np.uint64)
+        sr = np.ascontiguousarray(start_pos_res, dtype=np.uint64)
+        assert ref.dtype == np.uint32 and alt.dtype == np.uint32 and res.dtype == np.uint32
+        assert res.flags.c_contiguous and res.flags.writeable
+        ref = np.ascontiguousarray(ref)
+        alt = np.ascontiguousarray(alt)
+        h = ctypes.c_void_p()
+        rc = self._lib.v2p_gir_submit(self._h, _p(code), _p(sp), _p(ln), _p(sr), code.size, _p(ref), ref.size, _p(alt), alt.size, _p(res), res.size, ctypes.byref(h))
+        if rc != N.V2P_OK:
+            raise V2PError(rc, (self._lib.v2p_last_error(self._h) or b"").decode(), int(self._lib.v2p_last_error_index(self._h)))
+        return (h, (code, sp, ln, sr, ref, alt, res))
+
+    def gir_collect(self, ticket) -> np.ndarray:
+        """v2p_gir_collect: waits for the ticket's batch, widens the result into the `res` given to gir_submit and returns it; a task
+        the reference would panic on raises here."""
+        h, keep = ticket
+        row = ctypes.c_int64(-1)
+        rc = self._lib.v2p_gir_collect(self._h, h, ctypes.byref(row))
+        if rc != N.V2P_OK:
+            raise V2PError(rc, (self._lib.v2p_last_error(self._h) or b"").decode(), int(row.value))
+        return keep[6]
+
     def coalesce_stats(self) -> Tuple[int, int]:
         """(batches launched, calls served) by execute_gir_shared on this context."""
         nb, nc = ctypes.c_uint64(0), ctypes.c_uint64(0)
