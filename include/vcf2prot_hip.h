@@ -36,6 +36,7 @@ extern "C" {
 #endif
 
 #define V2P_OK                   0
+#define V2P_BUSY                 1   /* v2p_gir_submit only: every batch of the queue is in flight -- collect a ticket, then submit again */
 #define V2P_ERR_INVALID_ARG     -1
 #define V2P_ERR_HIP             -2   /* HIP runtime error, no device, out of memory        */
 #define V2P_ERR_BAD_CODE        -3   /* exe_code not in {0,1} (haplotype_instruction.rs:154) */
@@ -115,7 +116,9 @@ int v2p_execute_gir_shared(v2p_ctx* ctx,
  * closes it when the gathering window ends, uploads, launches, downloads; v2p_gir_collect waits for that and widens the result into
  * `res`.  Every array given to submit (and `res`) must stay valid and untouched until collect, which must be called exactly once per
  * ticket -- also after an error, which it reports (a task the reference would panic on is reported by collect, not by submit).
- * v2p_execute_gir_shared is submit + collect. */
+ * A batch slot is recycled when all its members have collected, so submit never waits for one: when every batch is in flight it
+ * returns V2P_BUSY (nothing staged, *ticket = NULL) and the caller collects its oldest ticket before submitting again -- a worker
+ * with two haplotypes in flight cannot deadlock the queue.  v2p_execute_gir_shared is submit (waiting for a slot) + collect. */
 typedef struct v2p_gir_ticket v2p_gir_ticket;
 int v2p_gir_submit(v2p_ctx* ctx,
                    const uint64_t* code, const uint64_t* start_pos, const uint64_t* length,

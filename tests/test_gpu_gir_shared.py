@@ -86,6 +86,10 @@ def test_threads_on_one_context_are_coalesced_and_exact(gpu_ctx, coracle, n_thre
             if two_halves:
                 try:
                     tk = gpu_ctx.gir_submit(g["code"], g["start_pos"], g["length"], g["start_pos_res"], job["ref"], job["alt"], res)
+                    while tk is None:                    # V2P_BUSY: every batch in flight -- collect what this worker holds, then again
+                        if pending:
+                            finish(pending.pop(0))
+                        tk = gpu_ctx.gir_submit(g["code"], g["start_pos"], g["length"], g["start_pos_res"], job["ref"], job["alt"], res)
                 except Exception as e:                   # noqa: BLE001
                     failures.append((j, repr(e)))
                     continue

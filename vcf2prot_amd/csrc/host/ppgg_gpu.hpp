@@ -119,7 +119,8 @@ public:
     // ... and in two halves (v2p_gir_submit / v2p_gir_collect): the worker that calls GIR::execute for haplotype 1 and then for
     // haplotype 2 (personalized_genome.rs:64-65) submits the first, packs and submits the second while the first batch is on the
     // GPU, then collects both.  The GIR owns the arrays the engine reads until collect() has returned.
-    void submit(Engine engine, GpuContext& ctx)
+    // returns false when every batch of the queue is in flight (V2P_BUSY): collect an earlier GIR, then submit again
+    bool submit(Engine engine, GpuContext& ctx)
     {
         if (engine != Engine::GPU) throw std::logic_error("the st/mt engines are the reference's CPU code");
         const size_t n = g_rep_.size();
@@ -128,7 +129,9 @@ public:
         for (size_t i = 0; i < n; ++i) { code[i] = g_rep_[i].exe_code; sp[i] = g_rep_[i].start_pos; ln[i] = g_rep_[i].length; sr[i] = g_rep_[i].start_pos_res; }
         const int rc = v2p_gir_submit(ctx.raw(), code, sp, ln, sr, n, reinterpret_cast<const uint32_t*>(ref_.data()), ref_.size(),
                                       reinterpret_cast<const uint32_t*>(alt_.data()), alt_.size(), reinterpret_cast<uint32_t*>(&res_[0]), res_.size(), &ticket_);
+        if (rc == V2P_BUSY) return false;
         if (rc != V2P_OK) throw Panic(rc, v2p_last_error(ctx.raw()), v2p_last_error_index(ctx.raw()));
+        return true;
     }
     std::pair<std::u32string, Annotation> collect(GpuContext& ctx) &&
     {

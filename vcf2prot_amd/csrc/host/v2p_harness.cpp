@@ -144,7 +144,10 @@ static int run(const char* preset, uint64_t n_haps, int threads, bool shared, bo
                             // marshalled and staged while the first one's batch is on the GPU
                             uint64_t prev = ~0ull;
                             for (uint64_t h = next++; h < n_haps; h = next++) {
-                                girs[h]->submit(Engine::GPU, *one);
+                                if (!girs[h]->submit(Engine::GPU, *one)) {            // every batch in flight: take the first haplotype's result, then go on
+                                    if (prev != ~0ull) { results[prev] = std::move(*girs[prev]).collect(*one).first; prev = ~0ull; }
+                                    while (!girs[h]->submit(Engine::GPU, *one)) std::this_thread::yield();
+                                }
                                 if (prev != ~0ull) results[prev] = std::move(*girs[prev]).collect(*one).first;
                                 prev = h;
                             }

@@ -641,11 +641,13 @@ static int gir_solo(v2p_ctx* c, v2p_gir_ticket& t)
     return rc;
 }
 
-extern "C" int v2p_gir_submit(v2p_ctx* c,
-                              const uint64_t* code, const uint64_t* start_pos, const uint64_t* length,
-                              const uint64_t* start_pos_res, uint64_t n_tasks,
-                              const uint32_t* ref, uint64_t n_ref, const uint32_t* alt, uint64_t n_alt,
-                              uint32_t* res, uint64_t n_res, v2p_gir_ticket** ticket)
+// may_wait: block until a batch slot is free (only a caller that holds no uncollected ticket may: a slot is freed by the collects of
+// its members); else return V2P_BUSY
+static int gir_submit_impl(v2p_ctx* c,
+                           const uint64_t* code, const uint64_t* start_pos, const uint64_t* length,
+                           const uint64_t* start_pos_res, uint64_t n_tasks,
+                           const uint32_t* ref, uint64_t n_ref, const uint32_t* alt, uint64_t n_alt,
+                           uint32_t* res, uint64_t n_res, v2p_gir_ticket** ticket, bool may_wait)
 {
     if (!c || !ticket) return V2P_ERR_INVALID_ARG;
     *ticket = nullptr;
@@ -743,7 +745,11 @@ extern "C" int v2p_gir_submit(v2p_ctx* c,
             if (!q->open) {
                 b = nullptr;
                 for (int k = 0; k < q->n_batch; ++k) if (q->batch[k].state == GirBatch::FREE) { b = &q->batch[k]; break; }
-                if (!b) { q->cv.wait(lk); continue; }    // every batch is in flight
+                if (!b) {                                // every batch is in flight
+                    if (!may_wait) return V2P_BUSY;      // (nothing of this call has been staged yet)
+                    q->cv.wait(lk);
+                    continue;
+                }
                 b->n_reqs = b->n_ready = b->n_left = 0;
                 b->in_bytes = b->res_bytes = b->n_desc = b->n_chunks = 0; b->rc = V2P_OK; b->err.clear();
                 b->opened = std::chrono::steady_clock::now();
@@ -782,6 +788,15 @@ extern "C" int v2p_gir_submit(v2p_ctx* c,
     t->b = b; t->res_off = res_off;
     *ticket = t.release();
     return V2P_OK;
+}
+
+extern "C" int v2p_gir_submit(v2p_ctx* c,
+                              const uint64_t* code, const uint64_t* start_pos, const uint64_t* length,
+                              const uint64_t* start_pos_res, uint64_t n_tasks,
+                              const uint32_t* ref, uint64_t n_ref, const uint32_t* alt, uint64_t n_alt,
+                              uint32_t* res, uint64_t n_res, v2p_gir_ticket** ticket)
+{
+    return gir_submit_impl(c, code, start_pos, length, start_pos_res, n_tasks, ref, n_ref, alt, n_alt, res, n_res, ticket, false);
 }
 
 extern "C" int v2p_gir_collect(v2p_ctx* c, v2p_gir_ticket* tk, int64_t* err_row)
@@ -836,7 +851,7 @@ extern "C" int v2p_execute_gir_shared(v2p_ctx* c,
 {
     if (err_row) *err_row = -1;
     v2p_gir_ticket* t = nullptr;
-    const int rc = v2p_gir_submit(c, code, start_pos, length, start_pos_res, n_tasks, ref, n_ref, alt, n_alt, res, n_res, &t);
+    const int rc = gir_submit_impl(c, code, start_pos, length, start_pos_res, n_tasks, ref, n_ref, alt, n_alt, res, n_res, &t, true);
     if (rc != V2P_OK) return rc;
     return v2p_gir_collect(c, t, err_row);
 }

@@ -166,6 +166,8 @@ class Context:
         alt = np.ascontiguousarray(alt)
         h = ctypes.c_void_p()
         rc = self._lib.v2p_gir_submit(self._h, _p(code), _p(sp), _p(ln), _p(sr), code.size, _p(ref), ref.size, _p(alt), alt.size, _p(res), res.size, ctypes.byref(h))
+        if rc == 1:                                      # V2P_BUSY: every batch of the queue is in flight -- collect a ticket, then submit again
+            return None
         if rc != N.V2P_OK:
             raise V2PError(rc, (self._lib.v2p_last_error(self._h) or b"").decode(), int(self._lib.v2p_last_error_index(self._h)))
         return (h, (code, sp, ln, sr, ref, alt, res))
