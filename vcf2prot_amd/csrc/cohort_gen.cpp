@@ -465,7 +465,7 @@ int v2p_cohort_pack(const v2p_cohort* c, uint64_t h0, uint64_t h1, int n_threads
         if (flags & V2P_PACK_NO_LINE_CUT) im.line_cut = false;
         if (flags & V2P_PACK_PER_BLOCK) im.kernel_choice = 2;
         if (flags & V2P_PACK_LONG_RUN) im.kernel_choice = 1;
-        if (flags & V2P_PACK_DENSE) im.kernel_choice = 3;
+        if (flags & V2P_PACK_DENSE) im.set_kernel(3);
         if ((flags >> 8) & 0x7FFF) im.cut_align = (flags >> 8) & 0x7FFF;   // experiment knobs: bits 8..22 cut alignment (bit 23: V2P_PACK_NO_LINE_CUT),
         if (flags >> 24) im.soft_window = flags >> 24;                     //                   bits 24..31 closing window
     }

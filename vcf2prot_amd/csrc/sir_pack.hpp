@@ -192,6 +192,9 @@ public:
     void set_kernel(int k) {
         kernel_choice = k;
         if (k == 4 && !grid_bytes) { chunk_tasks = CHUNK_TASKS_WAVE; chunk_bytes = CHUNK_BYTES_WAVE; adaptive_tasks = false; adaptive_bytes = false; }
+        // (a dense image's FIRST chunk too: the limits used to follow the kernel only from the second chunk on, and 256 fused descriptors of
+        // 50+ bytes overran the kernel's 12 KiB window -- found by tools/routing_sweep.py)
+        if (k == 3 && !grid_bytes) { if (adaptive_tasks) chunk_tasks = CHUNK_TASKS_DEEP; if (adaptive_bytes) chunk_bytes = CHUNK_BYTES_DENSE; }
     }
     // Build a PART of a larger arena (threads packing haplotype ranges side by side): the part's first result byte sits at absolute
     // arena offset `o`, so that chunk cuts are aligned in the arena the kernels write, not in the part.  Call before the first task;
