@@ -56,7 +56,7 @@ def test_rows_image_of_the_preset_cohorts(built, coracle, preset, h0, n, mode):
     base = c.pack(h0, h0 + n, n_threads=1, kernel=2)
     assert np.array_equal(ref.hap_out_begin, base.hap_out_begin)
     assert np.array_equal(got, interpret_image(base.desc, base.chunks, prot, base.payload, base.out_bytes))
-    for k in (1, 2, 8, 64):
+    for k in (1, 2, 8, 41, 64):
         emu = pack_rows(s, prot.size, mode, k)
         assert np.array_equal(emu.desc, ref.desc), (preset, mode, k, int(np.argmax(emu.desc[:min(emu.desc.size, ref.desc.size)] != ref.desc[:min(emu.desc.size, ref.desc.size)])))
         assert np.array_equal(emu.chunks, ref.chunks) and np.array_equal(emu.hap_out_begin, ref.hap_out_begin)
@@ -82,7 +82,7 @@ def test_rows_image_of_random_streams(built, seed, shape, mode):
         got = interpret_image(ref.desc, ref.chunks, proteome, ref.payload, ref.out_bytes)
         assert np.array_equal(np.diff(ref.hap_out_begin.astype(np.int64)), [w.size for w in want])
         assert np.array_equal(got, np.concatenate(want) if want else np.zeros(0, np.uint8))
-    for k in (1, 4, 16, 64):
+    for k in (1, 3, 16, 61, 64):
         try:
             emu = pack_rows(stream, proteome.size, mode, k)
         except RowsError as e:
@@ -90,4 +90,42 @@ def test_rows_image_of_random_streams(built, seed, shape, mode):
             continue
         assert ref is not None
         assert np.array_equal(emu.desc, ref.desc), (seed, shape, mode, k)
+        assert np.array_equal(emu.chunks, ref.chunks) and np.array_equal(emu.hap_out_begin, ref.hap_out_begin)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("fasta", [False, True])
+def test_rows_image_of_the_reference_task_dumps(built, golden, mode, fasta):
+    """The 36 transcript GIRs harvested from the reference binary, several per haplotype, plain and with FASTA emit (header, line
+    feed: personalized_genome.rs:90-113): the sequential restatement, the lane-by-lane emulation of the device kernel for several
+    tile sizes, and the text the binary wrote."""
+    from test_gpu_device_build_fasta import _stream_of_cases
+    from vcf2prot_amd.txstream import pack_rows, RowsError
+    cases = golden["cases"]
+    refs, off = {}, 0
+    for c in cases:
+        if c["ref"] not in refs:
+            refs[c["ref"]] = off
+            off += len(c["ref"])
+    proteome = np.frombuffer("".join(refs).encode(), dtype=np.uint8)
+    headers = "\n" + "".join(f">{c['name']}_1\n" for c in cases)
+    hdr_off, o = [], 1
+    for c in cases:
+        hdr_off.append(o)
+        o += len(c["name"]) + 4
+    resident = np.concatenate([proteome, np.frombuffer(headers.encode(), dtype=np.uint8)])
+    per_hap = 7
+    stream = _stream_of_cases(cases, refs, hdr_off, fasta, per_hap)
+    try:
+        ref = pack_rows(stream, proteome.size, mode, 0)
+    except RowsError as e:
+        assert mode == 1 and e.reason == 5
+        return
+    _check_geometry(ref, mode, ref.out_bytes)
+    text = interpret_image(ref.desc, ref.chunks, resident, ref.payload, ref.out_bytes).tobytes().decode()
+    want = "".join(f">{c['name']}_1\n{c['expected']}\n" for c in cases) if fasta else "".join(c["expected"] for c in cases)
+    assert text == want
+    for k in (1, 2, 5, 7, 36, 64):
+        emu = pack_rows(stream, proteome.size, mode, k)
+        assert np.array_equal(emu.desc, ref.desc), (mode, fasta, k)
         assert np.array_equal(emu.chunks, ref.chunks) and np.array_equal(emu.hap_out_begin, ref.hap_out_begin)

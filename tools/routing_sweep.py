@@ -5,7 +5,7 @@ for images whose descriptors are more than 3 % of their result, else 64 MB), sto
 
     python tools/routing_sweep.py [--quick] > profiles/r04_routing_sweep.json
 
-Grid: transcript length {150, 250, 400, 800, 1600} x alterations per altered transcript {1, 2, 4, 8, 16} x proteome {8, 56} MB
+Grid: transcript length {150, 250, 400, 800, 1600} x alterations per altered transcript {1, 2, 3, 4, 6, 8, 12, 16} x proteome {8, 56} MB
 (a transcript enters a haplotype's Task vector only if it is altered, so "0.25 alterations per transcript" is not a point of this
 boundary).  Per point, in ONE process, alternating: the host packer's own choice with the launcher's defaults (`lib`), the
 device-built rows image (`rows`, what the product ships), and every forced combination; median of the alternated runs.
@@ -26,7 +26,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true", help="a 3 x 3 x 1 sub-grid")
     ap.add_argument("--target-gb", type=float, default=1.5)
-    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--L", type=int, nargs="*", help="transcript lengths instead of the grid's")
+    ap.add_argument("--K", type=int, nargs="*", help="alteration counts instead of the grid's")
+    ap.add_argument("--P", type=int, nargs="*", help="proteome sizes (MB) instead of the grid's")
     a = ap.parse_args()
     import torch
     from vcf2prot_amd import build, _native as N
@@ -36,8 +39,9 @@ def main():
     from vcf2prot_amd.txstream import build_on_device_auto
     blib = N.bench_lib()                     # (v2p_order_chunks_for_xcds with V2P_ORDER_MAX_BLOCKS: the forced one-block order)
     Ls = [150, 400, 1600] if a.quick else [150, 250, 400, 800, 1600]
-    Ks = [1, 4, 16] if a.quick else [1, 2, 4, 8, 16]
+    Ks = [1, 4, 16] if a.quick else [1, 2, 3, 4, 6, 8, 12, 16]
     Ps = [8] if a.quick else [8, 56]
+    Ls, Ks, Ps = a.L or Ls, a.K or Ks, a.P or Ps
     nt = min(64, os.cpu_count() or 1)
     points = []
     for P in Ps:
@@ -117,6 +121,7 @@ def main():
                     for _ in range(a.rounds):
                         for name, cx, bb, opts in todo:
                             cx.set_launch_opts(**opts)
+                            bb.execute()                              # untimed: the two contexts hold a proteome copy each, and the variant that follows a switch would pay for a cold one
                             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                             e0.record(ts); bb.execute(); e1.record(ts); bb.sync()
                             times[name].append(e0.elapsed_time(e1))

@@ -31,8 +31,8 @@ struct RowsArgs {
     const uint64_t* hap_tx_begin;
     uint64_t n_haps;
     uint64_t proteome_len;
-    // tiles: K transcripts (HEAD items) each, a power of two <= 64
-    uint32_t K, log2K;
+    // tiles: K consecutive transcripts each, 1 <= K <= 64
+    uint32_t K;
     uint64_t n_tiles;
     uint64_t* tile_bytes;               // [n_tiles] arena bytes of each tile -> (scan) tile_res_base
     uint64_t* tile_res_base;            // [n_tiles + 1]

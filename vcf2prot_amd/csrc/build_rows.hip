@@ -25,6 +25,8 @@ namespace {
 
 __device__ __forceinline__ void rreport(unsigned long long* status, uint64_t index, uint32_t reason) { atomicMin(status, (unsigned long long)((index << 8) | reason)); }
 __device__ __forceinline__ uint32_t mbcnt(uint64_t m) { return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u)); }
+// the lane's bit of a wave-uniform mask: one v_cndmask on the SGPR pair, no shifts
+__device__ __forceinline__ bool lane_bit(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 // lane i receives lane i - 1's value, lane 0 `first` (DPP wave_shr:1)
 __device__ __forceinline__ uint32_t up1(uint32_t x, uint32_t first) { return uint32_t(__builtin_amdgcn_update_dpp(int(first), int(x), 0x138, 0xf, 0xf, false)); }
 __device__ __forceinline__ uint32_t up2(uint32_t x) { return up1(up1(x, 0u), 0u); }
@@ -42,17 +44,48 @@ __device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v, uint32_t lane)
 }
 
 // ---- arena bytes per tile ----------------------------------------------------------------------------------------------------
+// lane = transcript (coalesced).  Tiles are K (1 .. 64, any number) consecutive transcripts, so a wave's 64 lanes are a few runs of
+// equal tile: a segmented scan over the wave, then one global add per run (tile_bytes is zeroed by the launcher; two waves meet in
+// a tile at most)
 __global__ __launch_bounds__(256) void rows_tile_bytes_kernel(RowsArgs a)
 {
     const uint64_t t = uint64_t(blockIdx.x) * 256u + threadIdx.x;
-    uint64_t len = 0;
-    if (t < a.n_tx) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool valid = t < a.n_tx;
+    uint64_t v = 0;
+    if (valid) {
         const uint32_t hl = a.tx_header_len ? a.tx_header_len[t] : 0u;
-        len = uint64_t(a.tx_res_len[t]) + (hl ? hl + 1u : 0u);
+        v = uint64_t(a.tx_res_len[t]) + (hl ? hl + 1u : 0u);
     }
-    // K consecutive lanes are one tile (K a power of two <= 64, tiles aligned with the wave)
-    for (uint32_t o = 1; o < a.K; o <<= 1) len += __shfl_xor(len, int(o));
-    if ((t & (a.K - 1u)) == 0u && (t >> a.log2K) < a.n_tiles) a.tile_bytes[t >> a.log2K] = len;
+    const uint64_t t_wave = t - lane;
+    const uint32_t seg = uint32_t((valid ? t : a.n_tx - 1u) / a.K - t_wave / a.K);     // the lane's tile, counted from the wave's first
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t y = __shfl_up(v, o);
+        const uint32_t so = uint32_t(__shfl_up(int(seg), o));
+        if (lane >= uint32_t(o) && so == seg) v += y;
+    }
+    const uint32_t next = uint32_t(__shfl_down(int(seg), 1));
+    if (valid && (lane == 63u || next != seg || t + 1u == a.n_tx)) atomicAdd(reinterpret_cast<unsigned long long*>(a.tile_bytes) + t / a.K, (unsigned long long)v);
+}
+
+// the same for tiles of at least half a wave: one wave per tile, four tiles per workgroup, the sum by two 32-bit DPP scans (64
+// lengths below 2^32: their low 26 bits sum below 2^32, their high 6 bits below 2^12) instead of 64-bit shuffles through the LDS
+__global__ __launch_bounds__(256) void rows_tile_bytes_wave_kernel(RowsArgs a)
+{
+    const uint64_t tile = uint64_t(blockIdx.x) * 4u + (threadIdx.x >> 6);
+    if (tile >= a.n_tiles) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t t = tile * a.K + lane;
+    uint32_t len = 0;
+    if (lane < a.K && t < a.n_tx) {
+        const uint32_t hl = a.tx_header_len ? a.tx_header_len[t] : 0u;
+        const uint64_t l = uint64_t(a.tx_res_len[t]) + (hl ? hl + 1u : 0u);
+        if (l >> 31) rreport(a.status, a.tx_task_begin[t], STATUS_ROWS_SPAN);   // (the parse would refuse its tile: more than 2 GiB)
+        len = uint32_t(l);
+    }
+    const uint32_t lo = wave_incl_scan(len & 0x3FFFFFFu), hi = wave_incl_scan(len >> 26);
+    if (lane == 63u) a.tile_bytes[tile] = uint64_t(lo) + (uint64_t(hi) << 26);
 }
 
 // exclusive scan of u64 values, three passes over 1024-element tiles (as build_kernels.hip's launch_scan_u32)
@@ -117,79 +150,88 @@ __global__ __launch_bounds__(256) void rows_scan_apply(const uint64_t* __restric
 constexpr uint32_t ROWS_PAD = 256;             // descriptor slots per tile in the padded array (a tile with more: the two-pass form)
 enum : int { PH_PAD = 0, PH_COUNT = 1, PH_DIRECT = 2 };
 
+constexpr uint32_t ROWS_ALT_LDS = 512;         // alt bytes of a tile kept in LDS (64 lanes x 8)
 struct __attribute__((aligned(16))) WaveLds {
-    uint64_t base[2][66];                      // [0]: proteome offset of the slot's transcript, [1]: its alt tape's offset (slot j = transcript t0 - 1 + j)
-    uint32_t bound[2][66];                     // [0]: its reference length, [1]: its alt tape's length
-    uint32_t res_len[66];
-    uint32_t pos[66];                          // arena offset of its first result byte (behind its FASTA header) minus the tile's first emitted byte
-    uint32_t hl[66];                           // FASTA: length of its record header (0: none)
-    uint64_t hsrc[66];                         // ... and where the header sits in the resident reference
-    uint32_t flag[16];                         // one byte per lane: the item is a HEAD
+    uint64_t base[2][64];                      // [0]: proteome offset of the tile's j-th transcript, [1]: its alt tape's offset
+    uint32_t bound[2][64];                     // [0]: its reference length, [1]: its alt tape's length
+    uint32_t res_len[64];
+    uint32_t pos[64];                          // arena offset of its first result byte (behind its FASTA header) minus the tile's first byte
+    uint32_t hl[64];                           // FASTA: length of its record header (0: none)
+    uint64_t hsrc[64];                         // ... and where the header sits in the resident reference
+    uint32_t flag[16];                         // one byte per lane: the item is its transcript's first
+    uint32_t alt[ROWS_ALT_LDS / 4u + 2u];      // the tile's alt bytes (when they fit): literals are read from here, not from memory
 };
 
+// Items (round 4, second form): every Task is an item, and a transcript WITHOUT tasks contributes one item of its own; there are no
+// HEAD items any more -- a transcript's first item also opens it (FASTA: its header), its last item also closes it ('.' fill of the
+// cells behind the last task, haplotype_instruction.rs:78; FASTA: the line feed).  A lane therefore emits up to three (FASTA: five)
+// runs of result bytes, back to back: [header] ['.' fill of the gap before the task] [the task] ['.' tail] [line feed].
 // PHASE: PH_PAD descriptors to the tile's slots of the padded array and its count to tile_count (a tile that does not fit is
 // reported); PH_COUNT only the count; PH_DIRECT descriptors to their final place (tile_desc_base: the scan of the counts).
 template <int MODE, bool FASTA, int PHASE>
-__global__ __launch_bounds__(64) void rows_parse_kernel(RowsArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_parse_kernel(RowsArgs a)
 {
     constexpr uint32_t CTX = MODE == ROWS_DENSE ? 4u : 2u, ADV = 62u - CTX;
+    constexpr int NR = FASTA ? 5 : 3;                                 // runs a lane may emit
+    constexpr int RG = FASTA ? 1 : 0, RS = RG + 1, RT = RG + 2;       // run numbers: [0 header] RG gap, RS the task itself, RT tail [4 line feed]
     __shared__ WaveLds L;
     const uint32_t lane = threadIdx.x;
     const uint64_t tile = blockIdx.x;
-    const uint64_t n_heads = a.n_tx + 1u;
-    const uint64_t t0 = tile << a.log2K;
-    const uint32_t nh = uint32_t(n_heads - t0 < a.K ? n_heads - t0 : a.K);
-    const uint64_t t1 = t0 + nh;
-    const uint64_t task_lo = a.tx_task_begin[t0], task_end = t1 <= a.n_tx ? a.tx_task_begin[t1] : a.n_tasks;
-    const uint64_t tile_base = a.tile_res_base[tile];
-    // end of the last task before the tile: HEAD(t0) fills the rest of the transcript before it with '.'
-    uint32_t carry_e = 0, prev_res_len = 0, prev_hl = 0;
-    uint64_t prev_hsrc = 0;
-    if (t0 > 0) {
-        prev_res_len = a.tx_res_len[t0 - 1u];
-        if (FASTA) { prev_hl = a.tx_header_len[t0 - 1u]; prev_hsrc = prev_hl ? a.proteome_len + a.tx_header_off[t0 - 1u] : 0ull; }
-        if (task_lo > a.tx_task_begin[t0 - 1u]) { const uint64_t i = task_lo - 1u; carry_e = a.start_pos_res[i] + a.length[i]; }
-    }
-    // the tile's descriptors start where the transcript BEFORE it left off (HEAD(t0) writes that one's '.' fill and line feed): positions
-    // are 32-bit offsets from there (a tile of more than 2 GiB of result takes the two-pass form with K = 1 ... refused below)
-    const uint32_t prev_tail = (prev_res_len > carry_e ? prev_res_len - carry_e : 0u) + (prev_hl ? 1u : 0u);
-    const uint64_t ebase = tile_base - prev_tail;
-    const uint64_t tile_end = a.tile_res_base[tile + 1u];
-    if (tile_end - ebase > 0x7FFFFFFFull) { if (lane == 0) rreport(a.status, task_lo, STATUS_ROWS_SPAN); if (PHASE != PH_DIRECT && lane == 0) a.tile_count[tile] = 0u; return; }
-    const uint32_t eoff = uint32_t(ebase) & (ROW_BYTES - 1u);        // the tile's first emitted byte inside its row
-    const uint64_t erow = ebase / ROW_BYTES;
-    // ---- the tile's transcripts: slot lane + 1 = transcript t0 + lane, slot 0 = the one before the tile ----
-    uint32_t hp = 0xFFFFFFFFu;                                       // item (relative to the tile's first) of the lane's HEAD
-    {
-        const uint64_t u = t0 + lane;
-        const bool valid = lane < nh && u < a.n_tx;
-        uint64_t poff = 0, alt0 = 0, hsrc = 0;
-        uint32_t ref_len = 0, res_len = 0, n_alt = 0, hl = 0, alen = 0;
-        if (lane < nh) hp = uint32_t(a.tx_task_begin[u] - task_lo) + lane;
-        if (valid) {
-            poff = a.tx_proteome_off[u]; alt0 = a.tx_alt_begin[u]; n_alt = uint32_t(a.tx_alt_begin[u + 1] - alt0);
-            ref_len = a.tx_ref_len[u]; res_len = a.tx_res_len[u];
-            if (FASTA) { hl = a.tx_header_len[u]; hsrc = hl ? a.proteome_len + a.tx_header_off[u] : 0ull; }
-            alen = res_len + (hl ? hl + 1u : 0u);                    // (< 2^31 in total: checked above)
-            if (PHASE != PH_DIRECT && poff + ref_len > a.proteome_len) rreport(a.status, a.tx_task_begin[u], STATUS_SRC_OOB);   // transcript outside the resident proteome
-        }
-        const uint32_t rb = prev_tail + wave_incl_scan(alen) - alen;  // the transcript's first arena byte, from ebase
-        if (lane < nh) {
-            L.base[0][lane + 1u] = poff; L.base[1][lane + 1u] = alt0; L.bound[0][lane + 1u] = ref_len; L.bound[1][lane + 1u] = n_alt;
-            L.res_len[lane + 1u] = res_len; L.pos[lane + 1u] = rb + hl;
-            if (FASTA) { L.hl[lane + 1u] = hl; L.hsrc[lane + 1u] = hsrc; }
-        }
-        if (lane == 0) {
-            L.res_len[0] = prev_res_len; L.pos[0] = 0u - carry_e;    // (slot 0's tasks ended at carry_e: its '.' fill starts at offset 0)
-            if (FASTA) { L.hl[0] = prev_hl; L.hsrc[0] = prev_hsrc; }
-        }
-    }
-    asm volatile("" ::: "memory");
-    const uint32_t n_items = uint32_t(task_end - task_lo) + nh;
+    const uint64_t t0 = tile * a.K;
+    const uint32_t nh = uint32_t(a.n_tx - t0 < a.K ? a.n_tx - t0 : a.K);
+    const uint64_t task_lo = a.tx_task_begin[t0], task_end = a.tx_task_begin[t0 + nh];
+    const uint64_t alt_lo = a.tx_alt_begin[t0], alt_n = a.tx_alt_begin[t0 + nh] - alt_lo;
+    const uint64_t tile_base = a.tile_res_base[tile], tile_end = a.tile_res_base[tile + 1u];
+    // positions are 32-bit offsets from the tile's first byte (a tile of more than 2 GiB of result is refused)
+    if (tile_end - tile_base > 0x7FFFFFFFull) { if (lane == 0) rreport(a.status, task_lo, STATUS_ROWS_SPAN); if (PHASE != PH_DIRECT && lane == 0) a.tile_count[tile] = 0u; return; }
+    const uint32_t eoff = uint32_t(tile_base) & (ROW_BYTES - 1u);    // the tile's first byte inside its row
+    const uint64_t erow = tile_base / ROW_BYTES;
+    // Everything a tile reads before its first window is requested at once -- the transcripts' tables, the first window's tasks
+    // (as if every transcript had tasks: item = task; a tile with an empty transcript reloads), the tile's alt bytes: what bounds
+    // this kernel on shallow Task vectors is the chain of dependent loads per tile, not its instructions
     const uint8_t* const g_code = a.code + task_lo;
     const uint32_t* const g_sp = a.start_pos + task_lo;
     const uint32_t* const g_ln = a.length + task_lo;
     const uint32_t* const g_sr = a.start_pos_res + task_lo;
+    const uint32_t n_tile_tasks = uint32_t(task_end - task_lo);
+    uint32_t pf_code = 0, pf_sp = 0, pf_ln = 0, pf_sr = 0;            // the tasks of the window about to be worked on (item = task)
+    auto prefetch = [&](uint32_t i) { pf_code = 0; pf_sp = 0; pf_ln = 0; pf_sr = 0; if (i < n_tile_tasks) { pf_code = g_code[i]; pf_sp = g_sp[i]; pf_ln = g_ln[i]; pf_sr = g_sr[i]; } };
+    prefetch(lane);
+    const bool alt_in_lds = alt_n <= ROWS_ALT_LDS;
+    {
+        struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
+        uint64_t ab = 0;
+        if (alt_in_lds && uint64_t(lane) * 8u < alt_n) ab = reinterpret_cast<const U64*>(a.alt + alt_lo + lane * 8u)->v;
+        if (alt_in_lds) { L.alt[lane * 2u] = uint32_t(ab); L.alt[lane * 2u + 1u] = uint32_t(ab >> 32); }
+        if (lane < 2u) L.alt[ROWS_ALT_LDS / 4u + lane] = 0u;
+    }
+    // ---- the tile's transcripts: lane j = transcript t0 + j ----
+    uint32_t hp = 0xFFFFFFFFu;                                       // item (relative to the tile's first) of the lane's transcript's first
+    uint64_t ne;                                                     // transcripts of the tile without tasks (they are one item each)
+    {
+        const uint64_t u = t0 + lane;
+        const bool valid = lane < nh;
+        uint64_t poff = 0, alt0 = 0, hsrc = 0, tb0 = 0, tb1 = 0;
+        uint32_t ref_len = 0, res_len = 0, n_alt = 0, hl = 0, alen = 0;
+        if (valid) {
+            tb0 = a.tx_task_begin[u]; tb1 = a.tx_task_begin[u + 1];
+            poff = a.tx_proteome_off[u]; alt0 = a.tx_alt_begin[u]; n_alt = uint32_t(a.tx_alt_begin[u + 1] - alt0);
+            ref_len = a.tx_ref_len[u]; res_len = a.tx_res_len[u];
+            if (FASTA) { hl = a.tx_header_len[u]; hsrc = hl ? a.proteome_len + a.tx_header_off[u] : 0ull; }
+            alen = res_len + (hl ? hl + 1u : 0u);                    // (< 2^31 in total: checked above)
+            if (PHASE != PH_DIRECT && poff + ref_len > a.proteome_len) rreport(a.status, tb0, STATUS_SRC_OOB);   // transcript outside the resident proteome
+        }
+        ne = __ballot(valid && tb1 == tb0);
+        if (valid) hp = uint32_t(tb0 - task_lo) + mbcnt(ne);
+        const uint32_t rb = wave_incl_scan(alen) - alen;            // the transcript's first arena byte, from the tile's
+        if (valid) {
+            L.base[0][lane] = poff; L.base[1][lane] = alt0; L.bound[0][lane] = ref_len; L.bound[1][lane] = n_alt;
+            L.res_len[lane] = res_len; L.pos[lane] = rb + hl;
+            if (FASTA) { L.hl[lane] = hl; L.hsrc[lane] = hsrc; }
+        }
+    }
+    asm volatile("" ::: "memory");
+    const uint32_t n_items = n_tile_tasks + uint32_t(__popcll(ne));                      // >= nh >= 1
     uint64_t* const out = PHASE == PH_PAD ? a.desc_pad + tile * ROWS_PAD : (PHASE == PH_DIRECT ? a.desc + a.tile_desc_base[tile] : nullptr);
     (void)out;
     const uint32_t out_cap = PHASE == PH_PAD ? ROWS_PAD : 0xFFFFFFFFu;
@@ -199,48 +241,65 @@ __global__ __launch_bounds__(64) void rows_parse_kernel(RowsArgs a)
 
     uint32_t tile_cnt = 0;                     // descriptors of the tile so far (wave-uniform)
     uint64_t carry_h = 0, carry_second = 0;
+    uint32_t carry_e = 0;
     bool first = true;
     for (uint32_t R0 = 0; ; R0 += ADV) {
         const uint32_t nvalid = n_items - R0 < 64u ? n_items - R0 : 64u;
         const bool last = R0 + 64u >= n_items;
         const uint32_t e_lo = first ? 0u : CTX, e_hi = last ? nvalid : 62u;
-        // ---- which items are HEADs, and every item's transcript ----
+        // ---- which items open a transcript, and every item's transcript ----
         if (lane < 16u) L.flag[lane] = 0u;
         asm volatile("" ::: "memory");
         if (hp - R0 < 64u) reinterpret_cast<uint8_t*>(L.flag)[hp - R0] = 1u;
         asm volatile("" ::: "memory");
         const bool active = lane < nvalid;
-        const bool isHead = reinterpret_cast<const uint8_t*>(L.flag)[lane] != 0u;      // (lanes >= nvalid: no HEAD of this tile lies there)
-        const uint64_t headmask = __ballot(isHead);
+        const bool isFirst = reinterpret_cast<const uint8_t*>(L.flag)[lane] != 0u;     // (lanes >= nvalid: no transcript of this tile starts there)
+        const uint64_t firstmask = __ballot(isFirst);
         const uint32_t heads_before = uint32_t(__popcll(__ballot(hp < R0)));
-        const uint32_t slot = heads_before + mbcnt(headmask) + (isHead ? 1u : 0u);       // slot of the item's transcript (a HEAD: the one it opens)
-        const bool isTask = active && !isHead;
-        const uint32_t ti = R0 + lane - slot;                                            // task, relative to the tile's first
-        uint32_t code = 0, sp = 0, ln = 0, sr = 0;
-        if (isTask) { code = g_code[ti]; sp = g_sp[ti]; ln = g_ln[ti]; sr = g_sr[ti]; }
-        const uint32_t res_len = L.res_len[slot], pos0 = L.pos[slot];
+        const uint32_t slot = heads_before + mbcnt(firstmask) + (isFirst ? 1u : 0u) - 1u;   // the item's transcript (item 0 opens one: never negative for an active lane)
+        // the transcript's last item: the next one opens another, or the tile ends
+        const uint64_t lastmask = (firstmask >> 1) | (last && nvalid ? 1ull << (nvalid - 1u) : 0ull);
+        const bool isLast = lane_bit(lastmask);
+        uint32_t ti = R0 + lane;                                                         // task, relative to the tile's first
+        bool isEmpty = false;
+        // this window's tasks were requested a window ago; the next window's are requested now
+        uint32_t code = pf_code, sp = pf_sp, ln = pf_ln, sr = pf_sr;
+        if (!last) prefetch(R0 + ADV + lane);
+        if (ne) {                                                                        // (uniform, rare: transcripts without tasks in this tile)
+            const uint64_t below = ne & ((1ull << (slot & 63u)) - 1ull);
+            ti -= uint32_t(__popcll(below));
+            isEmpty = isFirst && ((ne >> (slot & 63u)) & 1ull);
+            code = 0; sp = 0; ln = 0; sr = 0;
+            if (active && !isEmpty) { code = g_code[ti]; sp = g_sp[ti]; ln = g_ln[ti]; sr = g_sr[ti]; }
+        }
+        const bool isTask = active && !isEmpty;
+        const uint32_t res_len = L.res_len[slot & 63u], pos0 = L.pos[slot & 63u];
         // ---- update_task / Task::execute checks; result positions ----
         const bool res_oob = isTask && (ln > res_len || sr > res_len - ln);
         const uint32_t e = isTask && !res_oob ? sr + ln : 0u;                             // end of the task inside its transcript's result
-        const uint32_t pe = up1(e, carry_e);                                              // ... of the item before
+        const uint32_t pe_raw = up1(e, carry_e);                                          // ... of the item before
+        const uint32_t pe = isFirst ? 0u : pe_raw;
         const uint32_t csel = code == 1u ? 1u : 0u;
-        const uint32_t bound = L.bound[csel][slot];
-        uint32_t why = 0;
-        if (isTask) {
-            if (code > 1u) why = STATUS_BAD_CODE;
-            else if (res_oob) why = STATUS_RES_OOB;
-            else if (ln > bound || sp > bound - ln) why = STATUS_SRC_OOB;
-            else if (sr < pe) why = STATUS_NOT_CONTIGUOUS;
-        }
+        const uint32_t bound = L.bound[csel][slot & 63u];
+        const bool src_oob = ln > bound || sp > bound - ln;
+        const bool anybad = isTask && (code > 1u || res_oob || src_oob || sr < pe);
         const bool in_emit = lane >= e_lo && lane < e_hi;
-        if (PHASE != PH_DIRECT && __ballot(why != 0u && in_emit)) { if (why != 0u && in_emit) rreport(a.status, task_lo + ti, why); }
-        const bool good = isTask && why == 0u;
+        if (PHASE != PH_DIRECT && __ballot(anybad && in_emit)) {                           // (rare: which rule, in update_task's order)
+            const uint32_t why = code > 1u ? STATUS_BAD_CODE : (res_oob ? STATUS_RES_OOB : (src_oob ? STATUS_SRC_OOB : STATUS_NOT_CONTIGUOUS));
+            if (anybad && in_emit) rreport(a.status, task_lo + ti, why);
+        }
+        const bool good = isTask && !anybad;
         // ---- classes of the fusion state machine ----
         const bool isRef = good && code == 0u;
         const bool imm = good && code == 1u && ln - 1u < IMM_MAX_BYTES;
-        const uint64_t src = L.base[csel][slot] + sp;
+        const uint64_t src = L.base[csel][slot & 63u] + sp;
         uint64_t lit = 0;
-        if (imm) {                                                                        // short alt payloads travel inside their descriptor
+        if (alt_in_lds) {                                                                 // short alt payloads travel inside their descriptor
+            const uint32_t rel = imm ? uint32_t(src - alt_lo) : 0u;                       // (< ROWS_ALT_LDS: inside the transcript's alt tape, checked above)
+            const uint32_t d0 = L.alt[rel >> 2], d1 = L.alt[(rel >> 2) + 1u];
+            const uint64_t v = ((uint64_t(d1) << 32) | d0) >> (8u * (rel & 3u));
+            lit = imm ? v & (~0ull >> (64u - 8u * ln)) : 0ull;
+        } else if (imm) {
             struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
             lit = reinterpret_cast<const U64*>(a.alt + src)->v & (~0ull >> (64u - 8u * ln));
         }
@@ -251,11 +310,10 @@ __global__ __launch_bounds__(64) void rows_parse_kernel(RowsArgs a)
         const uint32_t src32 = uint32_t(src);
         const uint32_t src2 = up2(src32), ln2 = up2(ln);
         const bool c1 = ln2 == 0u ? c0 : (ps && (ln == 0u || src == uint64_t(src2) + ln2 + 1u));
-        const uint64_t prev_head = (headmask << 1) | (first ? 1ull : 0ull);
         const bool gap = good && sr > pe;
-        const uint64_t mRst = ~__ballot(good) | prev_head | __ballot(gap);
+        const uint64_t mRst = ~__ballot(good) | firstmask | __ballot(gap);
         const RowsParse p = rows_parse(__ballot(cA), __ballot(cB), __ballot(ps), __ballot(c0), __ballot(c1), mRst, !first, carry_h);
-        const bool isF = (p.F >> lane) & 1ull, isReal = (p.real >> lane) & 1ull;
+        const bool isF = lane_bit(p.F), isReal = lane_bit(p.real);
         // a closing lane's fused substitution: run, len1, byte, len2
         const uint32_t f_len1 = isF && isReal ? ln2 : 0u;
         const uint32_t f_byte = up1(uint32_t(lit), 0u) & 0xFFu;
@@ -264,85 +322,102 @@ __global__ __launch_bounds__(64) void rows_parse_kernel(RowsArgs a)
         uint32_t p_len1 = 0, p_len2 = 0, p_run = 0, p_byte = 0;
         if (MODE == ROWS_DENSE) {
             p_len1 = up2(f_len1); p_len2 = up2(ln); p_run = up2(f_run); p_byte = up2(f_byte);
-            const bool Lc = isF && ((p.F >> (lane >= 2u ? lane - 2u : 63u)) & 1ull) && lane >= 2u && !((mRst >> (lane - 1u)) & 1ull) && f_len1 == 0u &&
+            const bool Lc = isF && lane_bit(p.F << 2) && !lane_bit(mRst << 1) && f_len1 == 0u &&
                             p_len1 <= SNV5_MAX_LEN && p_len2 <= SNV5_MAX_LEN && ln <= SNV5_MAX_LEN && f_run == p_run + p_len1 + 1u + p_len2;
             second = rows_pair(__ballot(Lc), !first, carry_second);
         }
         const uint64_t absorbed = (p.F >> 1) | ((p.F & p.real) >> 2) | (MODE == ROWS_DENSE ? (second >> 2) & p.F : 0ull);
-        const bool isAbs = (absorbed >> lane) & 1ull, isSecond = (second >> lane) & 1ull;
-        // ---- what the lane emits: up to three runs of result bytes, in order, back to back from offset q0 ----
-        //   HEAD: '.' fill of the transcript it closes, [FASTA: that transcript's line feed, its own header];  task: '.' fill of a gap, itself
-        uint32_t w0l = 0, w0h = 0, w1l = 0, w1h = 0, w2l = 0, w2h = 0;      // descriptor words (the length field of a plain one is filled in below)
-        uint32_t l0 = 0, l1 = 0, l2 = 0, q0 = 0;
-        bool fusedw = false;                                                 // w1 is a complete fused word
-        if (isHead) {
-            const uint32_t prl = L.res_len[slot - 1u];
-            q0 = L.pos[slot - 1u] + pe;
-            l0 = prl > pe ? prl - pe : 0u; w0h = SPACE_FILL << 30;
-            if (FASTA) {
-                const uint32_t phl = L.hl[slot - 1u], xhl = L.hl[slot];
-                if (phl) { const uint64_t lf = L.hsrc[slot - 1u] + phl - 1u; l1 = 1u; w1l = uint32_t(lf); w1h = uint32_t(lf >> 32) & 0xFFu; }
-                if (xhl) { const uint64_t hs = L.hsrc[slot]; l2 = xhl; w2l = uint32_t(hs); w2h = uint32_t(hs >> 32) & 0xFFu; }
-            }
-        } else if (good) {
-            q0 = pos0 + pe;
-            if (gap) { l0 = sr - pe; w0h = SPACE_FILL << 30; }
-            if (isF) {
-                if (!isAbs) {
-                    fusedw = true;
-                    if (MODE == ROWS_DENSE && isSecond) {
-                        l1 = p_len1 + 1u + p_len2 + 1u + ln; q0 -= p_len1 + p_len2 + 2u;
-                        const uint64_t w = SNV5_MARK | (uint64_t(f_byte) << 52) | (uint64_t(p_byte) << 44) | (uint64_t(ln & 31u) << 39) | (uint64_t(p_len2 & 31u) << 34) | (uint64_t(p_len1 & 31u) << 29) | (uint64_t(p_run) & SNV3_MAX_SRC);
-                        w1l = uint32_t(w); w1h = uint32_t(w >> 32);
-                    } else {
-                        l1 = f_len1 + 1u + ln; q0 -= f_len1 + 1u;
-                        w1l = (f_run & 0x1FFFFFFFu) | (f_len1 << 29);
-                        w1h = ((f_len1 & 0xFFFu) >> 3) | ((ln & 0xFFFu) << 9) | (f_byte << 21) | (7u << 29);
-                    }
+        const bool isAbs = lane_bit(absorbed), isSecond = lane_bit(second);
+        // ---- what the lane emits: NR runs of result bytes, in order, back to back from offset q0 ----
+        uint32_t wl[NR], wh[NR], rl[NR];               // descriptor words (the length field of a plain one is filled in below), lengths
+#pragma unroll
+        for (int i = 0; i < NR; ++i) { wl[i] = 0u; wh[i] = 0u; rl[i] = 0u; }
+        bool fusedw = false;                           // run RS is a complete fused word
+        uint32_t q0 = pos0 + pe;
+        if (active) {
+            if constexpr (FASTA) {
+                const uint32_t xhl = L.hl[slot & 63u];
+                if (xhl) {
+                    const uint64_t hs = L.hsrc[slot & 63u];
+                    if (isFirst) { rl[0] = xhl; wl[0] = uint32_t(hs); wh[0] = uint32_t(hs >> 32) & 0xFFu; q0 -= xhl; }
+                    if (isLast) { const uint64_t lf = hs + xhl - 1u; rl[4] = 1u; wl[4] = uint32_t(lf); wh[4] = uint32_t(lf >> 32) & 0xFFu; }
                 }
-            } else if (!isAbs && ln != 0u) {
-                l1 = ln;
-                if (imm) { w1l = uint32_t(lit); w1h = uint32_t(lit >> 32) | (SPACE_IMM << 30); }
-                else { w1l = src32; w1h = (uint32_t(src >> 32) & 0xFFu) | ((isRef ? SPACE_PROTEOME : SPACE_PAYLOAD) << 30); }
+            }
+            if (isLast && (good || isEmpty)) { rl[RT] = res_len - e; wh[RT] = SPACE_FILL << 30; }
+            if (good) {
+                if (gap) { rl[RG] = sr - pe; wh[RG] = SPACE_FILL << 30; }
+                if (isF) {
+                    if (!isAbs) {
+                        fusedw = true;
+                        if (MODE == ROWS_DENSE && isSecond) {
+                            rl[RS] = p_len1 + 1u + p_len2 + 1u + ln; q0 -= p_len1 + p_len2 + 2u;
+                            const uint64_t w = SNV5_MARK | (uint64_t(f_byte) << 52) | (uint64_t(p_byte) << 44) | (uint64_t(ln & 31u) << 39) | (uint64_t(p_len2 & 31u) << 34) | (uint64_t(p_len1 & 31u) << 29) | (uint64_t(p_run) & SNV3_MAX_SRC);
+                            wl[RS] = uint32_t(w); wh[RS] = uint32_t(w >> 32);
+                        } else {
+                            rl[RS] = f_len1 + 1u + ln; q0 -= f_len1 + 1u;
+                            wl[RS] = (f_run & 0x1FFFFFFFu) | (f_len1 << 29);
+                            wh[RS] = ((f_len1 & 0xFFFu) >> 3) | ((ln & 0xFFFu) << 9) | (f_byte << 21) | (7u << 29);
+                        }
+                    }
+                } else if (!isAbs && ln != 0u) {
+                    rl[RS] = ln;
+                    if (imm) { wl[RS] = uint32_t(lit); wh[RS] = uint32_t(lit >> 32) | (SPACE_IMM << 30); }
+                    else { wl[RS] = src32; wh[RS] = (uint32_t(src >> 32) & 0xFFu) | ((isRef ? SPACE_PROTEOME : SPACE_PAYLOAD) << 30); }
+                }
             }
         }
-        if (!in_emit) { l0 = 0; l1 = 0; l2 = 0; }
+        if (!in_emit) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) rl[i] = 0u;
+        }
         // Everything rare behind ONE uniform branch: a run of more than 1 KiB (it may cross two rows of the arena, or exceed a
         // descriptor's length field and become several descriptors)
-        const bool slow = __ballot(l0 > ROW_BYTES || l1 > ROW_BYTES || (FASTA && l2 > ROW_BYTES)) != 0ull;
+        bool big = false;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) big = big || rl[i] > ROW_BYTES;
+        const bool slow = __ballot(big) != 0ull;
         if (!slow) {
-            const uint32_t c0n = l0 ? 1u : 0u, c1n = l1 ? 1u : 0u, c2n = FASTA && l2 ? 1u : 0u;
-            const uint32_t cnt = c0n + c1n + c2n;
+            uint32_t cn[NR], cnt = 0;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) { cn[i] = rl[i] ? 1u : 0u; cnt += cn[i]; }
             const uint32_t incl = wave_incl_scan(cnt);
             const uint32_t round_total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
             if (PHASE != PH_COUNT && round_total != 0u) {
                 const uint32_t k = tile_cnt + incl - cnt;                                 // the lane's first slot inside the tile
-                if (!fusedw) w1h |= l1 << 8;
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                if (l0 && k < out_cap) *reinterpret_cast<u32x2*>(out + k) = u32x2{w0l, w0h | (l0 << 8)};
-                if (l1 && k + c0n < out_cap) *reinterpret_cast<u32x2*>(out + k + c0n) = u32x2{w1l, w1h};
-                if (FASTA && l2 && k + c0n + c1n < out_cap) *reinterpret_cast<u32x2*>(out + k + c0n + c1n) = u32x2{w2l, w2h | (l2 << 8)};
-                // the rows whose first byte the lane's runs cover: its span is at most 2 (FASTA: 3) KiB + ...; one boundary per run at most
-                const uint32_t s = eoff + q0, t1e = s + l0, t2e = t1e + l1, t3e = t2e + (FASTA ? l2 : 0u);
-                const uint32_t rfirst = (s + ROW_BYTES - 1u) >> 10;                       // first boundary at or behind the span's start
-                if ((rfirst << 10) < t3e && cnt != 0u) {
-                    for (uint32_t r = rfirst; (r << 10) < t3e; ++r) {                      // (one round, rarely two)
+                uint32_t kk = k;
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    if (rl[i] && kk < out_cap) *reinterpret_cast<u32x2*>(out + kk) = u32x2{wl[i], (i == RS && fusedw) ? wh[i] : (wh[i] | (rl[i] << 8))};
+                    kk += cn[i];
+                }
+                // the rows whose first byte the lane's runs cover: every run is at most 1 KiB here, so a run holds at most one boundary
+                const uint32_t s0 = eoff + q0;
+                uint32_t end[NR];
+                {
+                    uint32_t t = s0;
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) { t += rl[i]; end[i] = t; }
+                }
+                const uint32_t rfirst = (s0 + ROW_BYTES - 1u) >> 10;                      // first boundary at or behind the span's start
+                if ((rfirst << 10) < end[NR - 1] && cnt != 0u) {
+                    for (uint32_t r = rfirst; (r << 10) < end[NR - 1]; ++r) {              // (one round, rarely more)
                         const uint32_t rb = r << 10;
-                        const uint32_t which = rb < t1e ? 0u : (rb < t2e ? 1u : 2u);
-                        const uint32_t dk = which == 0u ? k : (which == 1u ? k + c0n : k + c0n + c1n);
-                        const uint32_t off = rb - (which == 0u ? s : (which == 1u ? t1e : t2e));
+                        uint32_t dk = k, st = s0;
+#pragma unroll
+                        for (int i = 0; i + 1 < NR; ++i) if (rb >= end[i]) { dk += cn[i]; st = end[i]; }
                         const uint64_t row = erow + r;
-                        if (row >= 1u && row < a.n_rows) a.cover[row] = cover_word(dk, off);
+                        if (row >= 1u && row < a.n_rows) a.cover[row] = cover_word(dk, rb - st);
                     }
                 }
             }
             tile_cnt += round_total;
         } else {
             // the general form: any length, any number of pieces and rows
-            const uint64_t W0 = (uint64_t(w0h) << 32) | w0l, W1 = (uint64_t(w1h) << 32) | w1l, W2 = (uint64_t(w2h) << 32) | w2l;
             auto pieces = [](uint32_t l) -> uint32_t { return l == 0u ? 0u : (l + PIECE_MAX - 1u) / PIECE_MAX; };
-            const uint32_t n0 = pieces(l0), n1 = fusedw ? (l1 ? 1u : 0u) : pieces(l1), n2 = pieces(l2);
-            const uint32_t cnt = n0 + n1 + n2;
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) cnt += (i == RS && fusedw) ? (rl[i] ? 1u : 0u) : pieces(rl[i]);
             const uint32_t incl = wave_incl_scan(cnt);
             const uint32_t round_total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
             if (PHASE != PH_COUNT && round_total != 0u) {
@@ -364,9 +439,8 @@ __global__ __launch_bounds__(64) void rows_parse_kernel(RowsArgs a)
                         if (whole) break;
                     }
                 };
-                if (l0) put(W0, l0, false);
-                if (l1) put(W1, l1, fusedw);
-                if (l2) put(W2, l2, false);
+#pragma unroll
+                for (int i = 0; i < NR; ++i) if (rl[i]) put((uint64_t(wh[i]) << 32) | wl[i], rl[i], i == RS && fusedw);
             }
             tile_cnt += round_total;
         }
@@ -398,10 +472,10 @@ __global__ __launch_bounds__(256) void rows_hap_begin_kernel(RowsArgs a)
     const uint64_t h = uint64_t(blockIdx.x) * 256u + threadIdx.x;
     if (h > a.n_haps) return;
     const uint64_t t = h < a.n_haps ? a.hap_tx_begin[h] : a.n_tx;
-    const uint64_t tile = t >> a.log2K;
+    const uint64_t tile = t / a.K;
     uint64_t b = a.tile_res_base[tile < a.n_tiles ? tile : a.n_tiles];
     if (tile < a.n_tiles)
-        for (uint64_t u = tile << a.log2K; u < t; ++u) { const uint32_t hl = a.tx_header_len ? a.tx_header_len[u] : 0u; b += uint64_t(a.tx_res_len[u]) + (hl ? hl + 1u : 0u); }
+        for (uint64_t u = tile * a.K; u < t; ++u) { const uint32_t hl = a.tx_header_len ? a.tx_header_len[u] : 0u; b += uint64_t(a.tx_res_len[u]) + (hl ? hl + 1u : 0u); }
     a.hap_out_begin[h] = b;
 }
 
@@ -428,6 +502,15 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
         if (r >= 1u && r < a.n_rows) { c = a.cover[r]; idx = (c >> 63) ? (c >> 22) & ((1ull << 41) - 1ull) : a.tile_desc_base[c >> 38] + ((c >> 22) & 0xFFFFu); }
         const uint32_t off = uint32_t(c) & 0x3FFFFFu;
         const uint64_t lastd = r >= a.n_rows ? n_desc - 1u : (off ? idx : idx - 1u);      // last descriptor of a chunk that ends at row r
+        // what a chunk ending at row r leaves of its last descriptor behind the cut -- for all 64 rows at once, not inside the walk (a
+        // dependent load per chunk there made the emitting pass twice as slow as the counting one)
+        uint32_t tc = 0;
+        if (EMIT && r < a.n_rows && off != 0u) {
+            const uint64_t d = a.desc[lastd];
+            const uint32_t dl = (d >> 60) == 0xDull ? uint32_t((d >> 29) & 31u) + uint32_t((d >> 34) & 31u) + uint32_t((d >> 39) & 31u) + 2u
+                              : ((d & SNV3_MARK) == SNV3_MARK ? uint32_t((d >> 29) & 0xFFFu) + 1u + uint32_t((d >> 41) & 0xFFFu) : uint32_t(d >> 40) & LEN_MASK);
+            tc = dl - off;
+        }
         uint32_t cur = 0;
         for (;;) {
             const uint64_t f = uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(idx)), int(cur)))) | (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(idx >> 32)), int(cur)))) << 32);
@@ -438,13 +521,6 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
             const uint32_t hb = 63u - uint32_t(__builtin_clzll(m));
             if (EMIT && lane == hb) {
                 const uint64_t n = lastd - f + 1u;
-                uint32_t tc = 0;                                                          // what the chunk's last descriptor has behind the cut
-                if (r < a.n_rows && off != 0u) {
-                    const uint64_t d = a.desc[lastd];
-                    const uint32_t dl = (d >> 60) == 0xDull ? uint32_t((d >> 29) & 31u) + uint32_t((d >> 34) & 31u) + uint32_t((d >> 39) & 31u) + 2u
-                                      : ((d & SNV3_MARK) == SNV3_MARK ? uint32_t((d >> 29) & 0xFFFu) + 1u + uint32_t((d >> 41) & 0xFFFu) : uint32_t(d >> 40) & LEN_MASK);
-                    tc = dl - off;
-                }
                 a.chunks_tmp[out_k] = Chunk{f | (uint64_t(hs) << TB_IDX_BITS) | (uint64_t(tc) << (TB_IDX_BITS + TB_SKIP_BITS)), ((b + cur) * ROW_BYTES) | (n << 48) | CHUNK_CLIP | flag};
             }
             last_dst = (b + cur) * ROW_BYTES;
@@ -489,8 +565,12 @@ uint64_t rows_scan_scratch_entries(uint64_t n) { return (n + RS_TILE - 1) / RS_T
 
 hipError_t launch_rows_tile_bytes(const RowsArgs& a, uint64_t* scan_scratch, hipStream_t stream)
 {
-    const uint64_t n_lanes = a.n_tiles << a.log2K;
-    hipLaunchKernelGGL(rows_tile_bytes_kernel, dim3(uint32_t((n_lanes + 255) / 256)), dim3(256), 0, stream, a);
+    if (a.K >= 32u) hipLaunchKernelGGL(rows_tile_bytes_wave_kernel, dim3(uint32_t((a.n_tiles + 3) / 4)), dim3(256), 0, stream, a);
+    else {
+        hipError_t e = hipMemsetAsync(a.tile_bytes, 0, a.n_tiles * 8, stream);
+        if (e != hipSuccess) return e;
+        if (a.n_tx) hipLaunchKernelGGL(rows_tile_bytes_kernel, dim3(uint32_t((a.n_tx + 255) / 256)), dim3(256), 0, stream, a);
+    }
     const uint64_t n = a.n_tiles, n_t = (n + RS_TILE - 1) / RS_TILE;
     hipLaunchKernelGGL(rows_scan_sums, dim3(uint32_t(n_t)), dim3(256), 0, stream, a.tile_bytes, n, scan_scratch);
     hipLaunchKernelGGL(rows_scan_tiles, dim3(1), dim3(1024), 0, stream, scan_scratch, n_t);

@@ -721,7 +721,7 @@ int v2p_cohort_pack_grid(const v2p_cohort* c, uint64_t h0, uint64_t h1, uint32_t
 // ROWS image of a transcript stream on the host (rows_image.hpp): what v2p_batch_build_on_device(kernel 6 / 7) must reproduce.
 int v2p_txstream_pack_rows(const v2p_txstream_buf* s, uint64_t proteome_len, int mode, uint32_t emulate_k, v2p_packed_image* out, uint64_t* status)
 {
-    if (!s || !out || (mode != v2p::ROWS_WAVE && mode != v2p::ROWS_DENSE) || emulate_k > 64 || (emulate_k & (emulate_k - 1))) return -1;
+    if (!s || !out || (mode != v2p::ROWS_WAVE && mode != v2p::ROWS_DENSE) || emulate_k > 64) return -1;
     memset(out, 0, sizeof *out);
     v2p::TxStreamView v{s->n_haps, s->n_tx, s->n_tasks, s->n_alt, s->hap_tx_begin, s->tx_proteome_off, s->tx_ref_len, s->tx_res_len, s->tx_task_begin, s->tx_alt_begin,
                         s->code, s->start_pos, s->length, s->start_pos_res, s->alt, s->tx_header_off, s->tx_header_len};

@@ -393,7 +393,7 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
         const double bpt = double(txs.result_bytes) / double(st.n_tasks ? st.n_tasks : 1);
         // (vcf2prot_amd/txstream.py::build_plan: rows images -- wave from 40 result bytes per task, dense below or when a row is too full)
         std::vector<std::pair<int, uint32_t>> plan_v;
-        if (bpt < 40) plan_v = {{7, 0}, {3, 12288}, {3, 8192}, {3, 4096}, {2, 4096}};
+        if (bpt < 24) plan_v = {{7, 0}, {3, 12288}, {3, 8192}, {3, 4096}, {2, 4096}};
         else plan_v = {{6, 0}, {7, 0}, {2, 32768}, {2, 16384}, {2, 4096}};
         const std::pair<int, uint32_t>* plan = plan_v.data();
         const size_t n_plan = plan_v.size();

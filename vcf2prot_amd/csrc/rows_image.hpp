@@ -3,10 +3,10 @@
 // What v2p_batch_build_on_device produced until round 3 -- descriptors cut on a fixed grid of result windows, counted in one walk
 // over the Task arrays and written in a second one, one lane per transcript -- cost the north star's cohort 12.3 ms for an execute
 // of 7.6.  A rows image drops the grid:
-//   1. PARSE (build_rows.hip: parse_kernel; here: rows_reference / rows_emulate): lane = ITEM of the stream -- every Task
-//      (task.rs:2-9) and, in front of each transcript's tasks, one HEAD item that closes the transcript before it ('.' fill of the
-//      cells no task covers, haplotype_instruction.rs:78; FASTA line feed) and opens its own (FASTA header,
-//      personalized_genome.rs:90-113).  Step 5 (haplotype_instruction.rs:94-133) is what it always was here: ref_counter
+//   1. PARSE (build_rows.hip: rows_parse_kernel; here: rows_reference / rows_emulate): lane = ITEM of the stream -- every Task
+//      (task.rs:2-9); a transcript's first item also opens it (FASTA header, personalized_genome.rs:90-113), its last item also
+//      closes it ('.' fill of the cells no task covers, haplotype_instruction.rs:78; FASTA line feed); a transcript without tasks
+//      is one item of its own.  Step 5 (haplotype_instruction.rs:94-133) is what it always was here: ref_counter
 //      disappears (reference tasks read the resident proteome), alt_counter is tx_alt_begin, res_counter a prefix sum.  The
 //      descriptors are the packer's (sir_pack.hpp) -- plain, '.' fill, immediate, fused substitution -- but WHOLE: nothing is cut.
 //      The greedy fusion of the packer's stage() -- a three-state machine over the tasks of a transcript -- is solved for 64 tasks
@@ -40,6 +40,7 @@ V2P_HOST_DEVICE inline uint64_t solve_stride2(uint64_t g0, uint64_t g1)
 #pragma unroll
 #endif
     for (int s = 2; s < 64; s <<= 1) {
+        if (f0 == f1) break;                                           // every lane's function is a constant already (the usual case after a step or two)
         const uint64_t sh0 = f0 << s, sh1 = f1 << s;
         const uint64_t n0 = (sh0 & f1) | (~sh0 & f0);
         const uint64_t n1 = (sh1 & f1) | (~sh1 & f0);
@@ -202,17 +203,17 @@ inline void rows_reference(const TxStreamView& s, uint64_t proteome_len, int mod
     im.out_bytes = res_base;
 }
 
-// ---- the device kernel's structure, lane by lane (build_rows.hip: parse_kernel) ----
-// Items: HEAD(t) sits at item tx_task_begin[t] + t, task i of transcript t at item i + t + 1; HEAD(n_tx) closes the last transcript.
-// A tile is K HEADs with the tasks behind them (one wave); a window is 64 consecutive items of it; a window's first CTX lanes are
-// context (emitted by the window before, re-read so that every lane sees its true neighbours), its last two are look-ahead.
+// ---- the device kernel's structure, lane by lane (build_rows.hip: rows_parse_kernel) ----
+// Items: every task is one, and a transcript without tasks contributes one item of its own.  A transcript's first item also opens it
+// (FASTA header), its last item also closes it ('.' tail, FASTA line feed).  A tile is K consecutive transcripts (one wave); a window
+// is 64 consecutive items of it; a window's first CTX lanes are context (emitted by the window before, re-read so that every lane
+// sees its true neighbours), its last two are look-ahead.
 struct RowsEmuStats { uint64_t tiles = 0, windows = 0, max_tile_desc = 0; };
 inline void rows_emulate(const TxStreamView& s, uint64_t proteome_len, int mode, uint32_t K, RowsImage& im, std::vector<uint64_t>* cover_out = nullptr, RowsEmuStats* stats = nullptr)
 {
     im = RowsImage();
     const uint32_t CTX = mode == ROWS_DENSE ? 4u : 2u;
-    const uint64_t n_heads = s.n_tx + 1, n_tiles = (n_heads + K - 1) / K;
-    const uint64_t n_items = s.n_tasks + n_heads;
+    const uint64_t n_tiles = s.n_tx ? (s.n_tx + K - 1) / K : 1;
     // P0: arena bytes per tile -> exclusive prefix
     std::vector<uint64_t> tile_res_base(n_tiles + 1, 0);
     for (uint64_t t = 0; t < s.n_tx; ++t) tile_res_base[t / K + 1] += rows_arena_len(s, t);
@@ -225,87 +226,78 @@ inline void rows_emulate(const TxStreamView& s, uint64_t proteome_len, int mode,
         im.hap_out_begin.assign(s.n_haps + 1, 0);
         for (uint64_t h = 0; h <= s.n_haps; ++h) {
             const uint64_t t = h < s.n_haps ? s.hap_tx_begin[h] : s.n_tx;
-            uint64_t b = tile_res_base[t / K];
-            for (uint64_t u = (t / K) * K; u < t; ++u) b += rows_arena_len(s, u);
+            const uint64_t tile = t / K;
+            uint64_t b = tile_res_base[tile < n_tiles ? tile : n_tiles];
+            if (tile < n_tiles) for (uint64_t u = tile * K; u < t; ++u) b += rows_arena_len(s, u);
             im.hap_out_begin[h] = b;
         }
     }
     std::vector<uint64_t>& d = im.desc;
     for (uint64_t tile = 0; tile < n_tiles; ++tile) {
         const uint64_t t0 = tile * K;
-        const uint32_t nh = uint32_t(n_heads - t0 < K ? n_heads - t0 : K);
-        auto head_item = [&](uint64_t t) { return (t <= s.n_tx ? s.tx_task_begin[t < s.n_tx ? t : s.n_tx] : s.n_tasks) + t; };
-        const uint64_t I0 = head_item(t0), I1 = t0 + nh <= s.n_tx ? head_item(t0 + nh) : n_items;
-        // per-transcript table, slot j = transcript t0 - 1 + j (slot 0: the transcript before the tile)
-        struct Tx { bool valid = false; uint64_t poff = 0, alt0 = 0, res_base = 0, hsrc = 0; uint32_t ref_len = 0, res_len = 0, n_alt = 0, hl = 0; };
-        std::vector<Tx> tx(nh + 1);
+        const uint32_t nh = uint32_t(s.n_tx - t0 < K ? s.n_tx - t0 : K);
+        // per-transcript table and the tile's items
+        struct Tx { uint64_t poff = 0, alt0 = 0, res_base = 0, hsrc = 0; uint32_t ref_len = 0, res_len = 0, n_alt = 0, hl = 0; };
+        struct Item { uint32_t j; bool first, lastp, empty; uint64_t task; };
+        std::vector<Tx> tx(nh ? nh : 1);
+        std::vector<Item> items;
         {
             uint64_t rb = tile_res_base[tile];
-            for (uint32_t j = 0; j <= nh; ++j) {
-                const int64_t u = int64_t(t0) - 1 + j;
-                if (u < 0 || uint64_t(u) >= s.n_tx) { tx[j].res_base = j ? rb : 0; continue; }
+            for (uint32_t j = 0; j < nh; ++j) {
+                const uint64_t u = t0 + j;
                 Tx& x = tx[j];
-                x.valid = true; x.poff = s.tx_proteome_off[u]; x.alt0 = s.tx_alt_begin[u]; x.n_alt = uint32_t(s.tx_alt_begin[u + 1] - x.alt0);
+                x.poff = s.tx_proteome_off[u]; x.alt0 = s.tx_alt_begin[u]; x.n_alt = uint32_t(s.tx_alt_begin[u + 1] - x.alt0);
                 x.ref_len = s.tx_ref_len[u]; x.res_len = s.tx_res_len[u]; x.hl = s.tx_header_len ? s.tx_header_len[u] : 0u;
                 x.hsrc = x.hl ? proteome_len + s.tx_header_off[u] : 0ull;
-                if (j == 0) x.res_base = rb - rows_arena_len(s, uint64_t(u));
-                else { x.res_base = rb; rb += rows_arena_len(s, uint64_t(u)); }
-                if (j >= 1 && x.poff + x.ref_len > proteome_len) rows_report(im, s.tx_task_begin[u], ROWS_SRC_OOB);
+                x.res_base = rb; rb += rows_arena_len(s, u);
+                if (x.poff + x.ref_len > proteome_len) rows_report(im, s.tx_task_begin[u], ROWS_SRC_OOB);
+                const uint64_t i0 = s.tx_task_begin[u], i1 = s.tx_task_begin[u + 1];
+                if (i0 == i1) items.push_back(Item{j, true, true, true, 0});
+                else for (uint64_t i = i0; i < i1; ++i) items.push_back(Item{j, i == i0, i + 1 == i1, false, i});
             }
         }
-        // end of the last task before the tile (for HEAD(t0)'s '.' fill of the transcript before)
-        uint64_t carry_e = 0;
-        if (t0 > 0 && s.tx_task_begin[t0 <= s.n_tx ? t0 : s.n_tx] > s.tx_task_begin[t0 - 1]) {
-            const uint64_t i = s.tx_task_begin[t0 <= s.n_tx ? t0 : s.n_tx] - 1;
-            carry_e = uint64_t(s.start_pos_res[i]) + s.length[i];
-        }
-        uint64_t carry_h = 0, carry_second = 0;
+        const uint64_t I1 = items.size();
+        uint64_t carry_e = 0, carry_h = 0, carry_second = 0;
         const uint64_t tile_desc0 = d.size();
         bool first = true;
-        for (uint64_t R0 = I0; ; ) {
+        for (uint64_t R0 = 0; ; ) {
             const uint32_t nvalid = uint32_t(I1 - R0 < 64 ? I1 - R0 : 64);
             const bool last = R0 + 64 >= I1;
             const uint32_t e_lo = first ? 0u : CTX, e_hi = last ? nvalid : 62u;
             // ---- per lane ----
-            bool isHead[64] = {}, isTask[64] = {};
-            uint32_t jj[64] = {};                                     // slot of the lane's transcript (HEAD: the transcript it opens)
+            bool isFirst[64] = {}, isLast[64] = {}, isEmpty[64] = {}, isTask[64] = {};
+            uint32_t jj[64] = {};                                     // the lane's transcript inside the tile
             uint64_t ti[64] = {}, sp[64] = {}, ln[64] = {}, sr[64] = {}, e[64] = {}, pe[64] = {}, src[64] = {}, lit[64] = {};
             uint32_t code[64] = {};
             bool isRef[64] = {}, imm[64] = {}, bad[64] = {};
             for (uint32_t l = 0; l < nvalid; ++l) {
-                const uint64_t item = R0 + l;
-                // the transcript whose HEAD is the last one at or before the item
-                uint32_t j = 0;
-                for (uint32_t q = 0; q < nh; ++q) if (head_item(t0 + q) <= item) j = q;
-                jj[l] = j + 1;
-                isHead[l] = head_item(t0 + j) == item;
-                isTask[l] = !isHead[l];
+                const Item& it = items[R0 + l];
+                jj[l] = it.j; isFirst[l] = it.first; isLast[l] = it.lastp; isEmpty[l] = it.empty; isTask[l] = !it.empty;
                 if (isTask[l]) {
-                    const uint64_t i = item - (t0 + j) - 1;
+                    const uint64_t i = it.task;
                     ti[l] = i; code[l] = s.code[i]; sp[l] = s.start_pos[i]; ln[l] = s.length[i]; sr[l] = s.start_pos_res[i];
-                    e[l] = sr[l] + ln[l];
+                    if (sr[l] + ln[l] <= tx[it.j].res_len) e[l] = sr[l] + ln[l];
                 }
             }
-            for (uint32_t l = 0; l < nvalid; ++l) pe[l] = l ? e[l - 1] : carry_e;
+            for (uint32_t l = 0; l < nvalid; ++l) pe[l] = isFirst[l] ? 0 : (l ? e[l - 1] : carry_e);
             uint64_t mA = 0, mB = 0, mPS = 0, mC0 = 0, mC1 = 0, mRst = 0;
             uint64_t gapfill[64] = {};
             for (uint32_t l = 0; l < 64; ++l) {
-                if (l >= nvalid || isHead[l]) { mRst |= 1ull << l; continue; }
+                if (l >= nvalid || !isTask[l]) { mRst |= 1ull << l; continue; }
                 const Tx& x = tx[jj[l]];
                 uint32_t why = 0;
                 if (code[l] > 1u) why = ROWS_BAD_CODE;
                 else if (sr[l] + ln[l] > x.res_len) why = ROWS_RES_OOB;
                 else if (sp[l] + ln[l] > (code[l] == 0 ? uint64_t(x.ref_len) : uint64_t(x.n_alt))) why = ROWS_SRC_OOB;
                 else if (sr[l] < pe[l]) why = ROWS_NOT_CONTIGUOUS;
-                if (why) { if (l >= e_lo && l < e_hi) rows_report(im, ti[l], why); bad[l] = true; }
-                const bool prevHead = l == 0 ? first : isHead[l - 1];   // (a later window's lane 0 is context: its reset bit is never used)
-                const bool gap = !bad[l] && sr[l] > pe[l];
+                if (why) { if (l >= e_lo && l < e_hi) rows_report(im, ti[l], why); bad[l] = true; mRst |= 1ull << l; continue; }
+                const bool gap = sr[l] > pe[l];
                 if (gap) gapfill[l] = sr[l] - pe[l];
-                if (prevHead || gap) mRst |= 1ull << l;
+                if (isFirst[l] || gap) mRst |= 1ull << l;             // (a later window's lane 0 is context: its reset bit is never used)
                 isRef[l] = code[l] == 0;
                 imm[l] = code[l] == 1 && ln[l] >= 1 && ln[l] <= IMM_MAX_BYTES;
                 src[l] = isRef[l] ? x.poff + sp[l] : x.alt0 + sp[l];
-                if (imm[l] && !bad[l]) { uint64_t v = 0; for (uint64_t k = 0; k < ln[l]; ++k) v |= uint64_t(s.alt[x.alt0 + sp[l] + k]) << (8 * k); lit[l] = v; }
+                if (imm[l]) { uint64_t v = 0; for (uint64_t k = 0; k < ln[l]; ++k) v |= uint64_t(s.alt[x.alt0 + sp[l] + k]) << (8 * k); lit[l] = v; }
                 const bool ps = isRef[l] && ln[l] <= ROWS_FUSE_LEN;
                 if (isRef[l] && ln[l] <= ROWS_FUSE_LEN && src[l] + ln[l] + 1 + ROWS_FUSE_LEN <= SNV3_MAX_SRC) mA |= 1ull << l;
                 if (imm[l] && ln[l] == 1) mB |= 1ull << l;
@@ -336,7 +328,7 @@ inline void rows_emulate(const TxStreamView& s, uint64_t proteome_len, int mode,
                 second = rows_pair(L, !first, carry_second);
             }
             const uint64_t absorbed = (p.F >> 1) | ((p.F & p.real) >> 2) | (mode == ROWS_DENSE ? (second >> 2) & p.F : 0ull);
-            // ---- emission, lane by lane (the device: ballots of "emits 1 / 2 / 3", mbcnt for the slots) ----
+            // ---- emission, lane by lane (the device: one scan of the lanes' descriptor counts) ----
             for (uint32_t l = e_lo; l < e_hi; ++l) {
                 const Tx& x = tx[jj[l]];
                 auto put = [&](uint64_t pos, unsigned space, uint64_t sr_, uint64_t len) {       // plain descriptor(s) at arena position pos
@@ -354,30 +346,28 @@ inline void rows_emulate(const TxStreamView& s, uint64_t proteome_len, int mode,
                     d.push_back(word);
                     for (uint64_t r = (pos + ROW_BYTES - 1) / ROW_BYTES; r * ROW_BYTES < pos + len; ++r) if (r >= 1) cover[r] = (k << 22) | (r * ROW_BYTES - pos);
                 };
-                if (isHead[l]) {
-                    const Tx& pv = tx[jj[l] - 1];                       // the transcript this HEAD closes
-                    if (pv.valid) {
-                        if (pv.res_len > pe[l]) put(pv.res_base + pv.hl + pe[l], SPACE_FILL, 0, pv.res_len - pe[l]);
-                        if (pv.hl) put(pv.res_base + pv.hl + pv.res_len, SPACE_PROTEOME, pv.hsrc + pv.hl - 1u, 1);
-                    }
-                    if (x.valid && x.hl) put(x.res_base, SPACE_PROTEOME, x.hsrc, x.hl);
-                    continue;
-                }
-                if (bad[l]) continue;
                 const uint64_t posbase = x.res_base + x.hl;
+                if (isFirst[l] && x.hl) put(x.res_base, SPACE_PROTEOME, x.hsrc, x.hl);
+                auto close = [&]() {                                  // the transcript's last item: '.' tail, line feed
+                    if (!isLast[l]) return;
+                    if (x.res_len > e[l]) put(posbase + e[l], SPACE_FILL, 0, x.res_len - e[l]);
+                    if (x.hl) put(posbase + x.res_len, SPACE_PROTEOME, x.hsrc + x.hl - 1u, 1);
+                };
+                if (isEmpty[l]) { close(); continue; }
+                if (bad[l]) continue;
                 if (gapfill[l]) put(posbase + pe[l], SPACE_FILL, 0, gapfill[l]);
                 if ((p.F >> l) & 1) {
-                    if ((absorbed >> l) & 1) continue;                  // dense: the first of a pair
-                    if ((second >> l) & 1) {
-                        const uint32_t a1 = f_len1[l - 2], a2 = f_len2[l - 2];
-                        put1(posbase + sr[l] - 1 - a2 - 1 - a1, pack_snv5(f_run[l - 2], a1, uint8_t(f_byte[l - 2]), a2, uint8_t(f_byte[l]), f_len2[l]), uint64_t(a1) + 1 + a2 + 1 + f_len2[l]);
-                    } else put1(posbase + sr[l] - 1 - f_len1[l], pack_snv3(f_run[l], f_len1[l], f_len2[l], uint8_t(f_byte[l])), uint64_t(f_len1[l]) + 1 + f_len2[l]);
-                    continue;
+                    if (!((absorbed >> l) & 1)) {                       // (dense: the first of a pair is absorbed)
+                        if ((second >> l) & 1) {
+                            const uint32_t a1 = f_len1[l - 2], a2 = f_len2[l - 2];
+                            put1(posbase + sr[l] - 1 - a2 - 1 - a1, pack_snv5(f_run[l - 2], a1, uint8_t(f_byte[l - 2]), a2, uint8_t(f_byte[l]), f_len2[l]), uint64_t(a1) + 1 + a2 + 1 + f_len2[l]);
+                        } else put1(posbase + sr[l] - 1 - f_len1[l], pack_snv3(f_run[l], f_len1[l], f_len2[l], uint8_t(f_byte[l])), uint64_t(f_len1[l]) + 1 + f_len2[l]);
+                    }
+                } else if (!((absorbed >> l) & 1) && ln[l] != 0) {
+                    if (imm[l]) put(posbase + sr[l], SPACE_IMM, lit[l], ln[l]);
+                    else put(posbase + sr[l], isRef[l] ? SPACE_PROTEOME : SPACE_PAYLOAD, src[l], ln[l]);
                 }
-                if ((absorbed >> l) & 1) continue;
-                if (ln[l] == 0) continue;
-                if (imm[l]) put(posbase + sr[l], SPACE_IMM, lit[l], ln[l]);
-                else put(posbase + sr[l], isRef[l] ? SPACE_PROTEOME : SPACE_PAYLOAD, src[l], ln[l]);
+                close();
             }
             if (stats) ++stats->windows;
             if (last) break;

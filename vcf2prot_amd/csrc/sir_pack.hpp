@@ -89,7 +89,7 @@ constexpr uint64_t CHUNK_DENSE = 1ull << 61;   // chunk header flag: chunk of a 
 constexpr uint64_t CHUNK_WAVE = 1ull << 60;    // chunk header flag: chunk of a wave image (<= 64 descriptors, <= 10 KiB, fused substitutions allowed): stitchw_kernel
 constexpr uint32_t CHUNK_N_MASK = 0x7FF;       // descriptor count: bits 48..58 of dst_n
 inline uint32_t chunk_n(uint64_t dst_n) { return uint32_t(dst_n >> 48) & CHUNK_N_MASK; }
-constexpr uint32_t WAVE_BYTES_PER_TASK = 40;    // an image whose first chunk has at least this many result bytes per task is a wave image (stitchw_kernel); below: dense
+constexpr uint32_t WAVE_BYTES_PER_TASK = 24;    // an image whose first chunk has at least this many result bytes per task is a wave image (stitchw_kernel); below: dense
 constexpr uint32_t LONG_RUN_BYTES_PER_TASK = 120;   // an image whose first chunk has at least this many result bytes per task goes to stitch4_kernel
 constexpr uint32_t PAD_BYTES  = 32;            // readable slack before AND after a source arena: the kernel loads whole 16-byte aligned blocks
                                                // around a task's bytes (up to 30 bytes before its first byte in a chunk's ragged head block, 31 after its last)

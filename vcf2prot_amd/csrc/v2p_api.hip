@@ -1120,16 +1120,49 @@ int v2p_batch_end_haplotype(v2p_batch* b)
 
 // ---- ROWS images: the image built in ONE pass (build_rows.hip; format: rows_image.hpp) -----------------------------------------
 // Called by v2p_batch_build_on_device (kernel 6: wave image, 7: dense) with the stream's tables already checked and c->mu held.
+// Tiles of K consecutive transcripts, one wave each (K <= 64: the kernel's prologue gives every transcript of the tile a lane).  A
+// wave takes 64 items in its first window and ADV more in every further one, so K is picked to FILL the tile's last window: among
+// the window counts w whose capacity stays below ~360 items (a tile's descriptors must fit its 256 slots of the padded array; one
+// that does not sends the build to its two-pass form), the K <= 64 with the least work per transcript (windows + a tile's fixed
+// cost) -- mean and spread of the items per transcript from a sample of the stream.
+static uint32_t rows_pick_k(const v2p_txstream* s, int mode, bool fasta)
+{
+    const uint64_t n_tx = s->n_tx;
+    if (n_tx == 0) return 1;
+    const uint64_t step = n_tx > 65536 ? n_tx / 65536 : 1;
+    double sum = 0, sq = 0, cnt = 0;
+    for (uint64_t u = 0; u < n_tx; u += step) {
+        const uint64_t nt = s->tx_task_begin[u + 1] - s->tx_task_begin[u];
+        const double x = nt ? double(nt) : 1.0;                      // (a transcript without tasks is one item)
+        sum += x; sq += x * x; cnt += 1;
+    }
+    const double m = sum / cnt, var = sq / cnt - m * m > 0 ? sq / cnt - m * m : 0.0, sd = sqrt(var);
+    const double adv = mode == ROWS_DENSE ? 58.0 : 60.0, z = 1.3;
+    const double k_cap = fasta ? 240.0 / (m + 2.0) : 64.0;           // FASTA: a header and a line feed per transcript on top
+    uint32_t best_k = 1;
+    double best_cost = 1e30;
+    for (uint32_t w = 1; w <= 8; ++w) {
+        const double cap = 64.0 + (w - 1) * adv;
+        if (w > 1 && cap > 360.0) break;
+        // K m + z sd sqrt(K) <= cap
+        const double x = (-z * sd + sqrt(z * z * var + 4.0 * m * cap)) / (2.0 * m);
+        double k = floor(x * x);
+        if (k > 64.0) k = 64.0;
+        if (k > k_cap) k = floor(k_cap);
+        if (k < 1.0) k = 1.0;
+        const double windows = 1.0 + (k * m + z * sd * sqrt(k) > 64.0 ? ceil((k * m + z * sd * sqrt(k) - 64.0) / adv) : 0.0);
+        const double cost = (windows + 4.0) / k;                        // (a tile's fixed cost -- its dependent loads before the first window -- is worth about four windows)
+        if (cost < best_cost - 1e-12 || (cost < best_cost + 1e-12 && k > best_k)) { best_cost = cost; best_k = uint32_t(k); }
+    }
+    return best_k;
+}
+
 static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool fasta, float* build_ms)
 {
     v2p_ctx* c = b->ctx;
     const uint64_t n_tx = s->n_tx, n_tk = s->n_tasks, n_h = s->n_haps;
-    // tiles of K transcripts, one wave each: about 200 items (tasks + transcripts) per tile, so that a tile's descriptors fit its
-    // slots of the padded array; deep Task vectors get small K
-    const double items_per_tx = double(n_tk + n_tx + 1) / double(n_tx + 1);
-    uint32_t K = 64, log2K = 6;
-    while (K > 1 && double(K) * items_per_tx > (fasta ? 200.0 : 360.0)) { K >>= 1; --log2K; }
-    const uint64_t n_tiles = (n_tx + 1 + K - 1) / K;
+    const uint32_t K = rows_pick_k(s, mode, fasta);
+    const uint64_t n_tiles = n_tx ? (n_tx + K - 1) / K : 1;
     auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
     uint64_t off = 0;
     auto carve = [&](uint64_t bytes) { const uint64_t o = off; off += up8(bytes); return o; };
@@ -1175,7 +1208,7 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
     a.start_pos_res = reinterpret_cast<const uint32_t*>(d + o_sr); a.alt = b->d_payload.ptr();
     a.tx_header_off = fasta ? reinterpret_cast<const uint64_t*>(d + o_hoff) : nullptr;
     a.tx_header_len = fasta ? reinterpret_cast<const uint32_t*>(d + o_hlen) : nullptr;
-    a.proteome_len = c->proteome_len; a.K = K; a.log2K = log2K; a.n_tiles = n_tiles;
+    a.proteome_len = c->proteome_len; a.K = K; a.n_tiles = n_tiles;
     a.tile_bytes = reinterpret_cast<uint64_t*>(d + o_tbytes); a.tile_res_base = reinterpret_cast<uint64_t*>(d + o_tbase);
     a.tile_count = reinterpret_cast<uint32_t*>(d + o_tcount); a.tile_desc_base = reinterpret_cast<uint64_t*>(d + o_tdbase);
     a.totals = reinterpret_cast<uint64_t*>(d + o_totals);

@@ -114,7 +114,7 @@ class HostTxStream:
 def pack_rows(stream, proteome_len: int, mode: int = 1, emulate_k: int = 0):
     """The ROWS image of a transcript stream built on the HOST (csrc/rows_image.hpp; include/v2p_cohort.h: v2p_txstream_pack_rows) --
     what v2p_batch_build_on_device(kernel 6 / 7) must reproduce: mode 1 = wave image, 2 = dense; emulate_k = 0: the sequential
-    restatement of the packer's state machine, a power of two <= 64: the device kernel's tiles / windows / ballot masks emulated
+    restatement of the packer's state machine, 1 .. 64: the device kernel's tiles / windows / ballot masks emulated
     lane by lane.  Returns a cohort.Packed (chunk table in arena order); raises RowsError(status word) for what the device reports."""
     from . import _native as N
     from ._cohort_api import PackedImage
@@ -134,6 +134,9 @@ def pack_rows(stream, proteome_len: int, mode: int = 1, emulate_k: int = 0):
         lib.v2p_packed_free(ctypes.byref(img))
 
 
+WAVE_BYTES_PER_TASK = 24      # = sir_pack.hpp: WAVE_BYTES_PER_TASK (profiles/r04_routing_sweep.json: the wave kernel wins from ~23 result bytes per task up)
+
+
 class RowsError(RuntimeError):
     def __init__(self, rc: int, status: int):
         self.rc, self.status = rc, status
@@ -144,10 +147,10 @@ class RowsError(RuntimeError):
 def build_plan(bytes_per_task: float) -> list:
     """(kernel, window_bytes) pairs to try in order for v2p_batch_build_on_device, by result bytes per task -- the routing the host
     packer would choose.  Round 4: ROWS images (one pass over the stream, chunks cut afterwards on 1 KiB rows; no window to choose):
-    a wave image (kernel 6) from 40 result bytes per task, a dense one (7) below -- and whenever a 1 KiB row of the result holds
+    a wave image (kernel 6) from 24 result bytes per task, a dense one (7) below -- and whenever a 1 KiB row of the result holds
     more descriptors than a wave has lanes.  The grid builders of round 3 stay behind them as the last resort."""
     bpt = float(bytes_per_task)
-    if bpt < 40:
+    if bpt < WAVE_BYTES_PER_TASK:
         return [(7, 0), (3, 12288), (3, 8192), (3, 4096), (2, 4096)]
     return [(6, 0), (7, 0), (2, 32768), (2, 16384), (2, 4096)]
 
