@@ -343,6 +343,19 @@ int v2p_set_launch_opts(v2p_ctx* ctx, const v2p_launch_opts* opts);
  * the kernel's LDS image; the builders never make a larger one, and the kernel refuses one (status: result out of bounds) rather
  * than executing it. */
 int v2p_stitch_launch_bits(const v2p_chunk* chunks, uint64_t n_chunks);
+/* Host-side, no GPU work: the routing rules the library applies to an image of these sizes -- which kernel its builders pack it
+ * for, how its chunk table is ordered, how it is launched -- so that hosts and tests can see them (measured:
+ * profiles/r04_routing_sweep.json, tools/routing_sweep.py; pinned by tests/test_routing_rules.py). */
+typedef struct v2p_routing {
+    uint32_t wave_bytes_per_task;   /* an image with at least this many result bytes per Task is a wave image (stitchw_kernel: kernel 6 / 4), below a dense one (7 / 3) */
+    uint32_t rich;                  /* 1: its descriptors are more than 3 % of its result */
+    uint32_t phased;                /* 1: launched in phases with read-ahead (wave / long-run images of at least 16 384 chunks) */
+    uint32_t store_sc1;             /* 1: "sc1 nt" row stores (thin images) */
+    uint64_t phase_bytes;           /* bytes of image per phase: 28 MB rich, 64 MB thin */
+    uint32_t order_blocks;          /* blocks of the arena inside which the chunk table is dealt to the XCDs (1: one order for the whole table) */
+    uint32_t reserved;
+} v2p_routing;
+int v2p_routing_rules(uint64_t n_desc, uint64_t n_chunks, uint64_t result_bytes, uint64_t proteome_len, int wave_image, v2p_routing* out);
 /* Host-side: reorder a chunk table so that workgroup 8*j + x (XCD x) works on proteome slice x and, inside a slice, on one window
  * of it after the other -- for an image whose descriptors are more than 3 % of its result, block after block of the arena (equal
  * shares of the table's entries in result order, about eight times the proteome each): the reference reads of the workgroups in

@@ -135,4 +135,5 @@ def test_chunk_order_inside_blocks_of_the_arena(built):
         assert blib.v2p_order_chunks_for_xcds(t2.ctypes.data, t2.shape[0], img2.desc.ctypes.data, img2.desc.size, c2.proteome().size) == 0
     finally:
         os_env.pop("V2P_ORDER_MAX_BLOCKS", None)
-    assert np.array_equal(t1, t2)
+    # (a thin image keeps ONE order only from 2 GB on -- round 4's sweep -- which tests/test_routing_rules.py pins; this 320 MB one is dealt in blocks)
+    assert not np.array_equal(t1, t2) and np.array_equal(np.sort(t1[:, 1]), np.sort(t2[:, 1]))

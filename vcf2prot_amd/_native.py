@@ -85,12 +85,28 @@ HIP_API = {
                                        c_void_p, c_uint64, c_void_p, c_void_p]),
     "v2p_set_launch_opts": (c_int, [c_void_p, c_void_p]),
     "v2p_stitch_launch_bits": (c_int, [c_void_p, c_uint64]),
+    "v2p_routing_rules": (c_int, [c_uint64, c_uint64, c_uint64, c_uint64, c_int, c_void_p]),
     "v2p_order_chunks_for_xcds": (c_int, [c_void_p, c_uint64, c_void_p, c_uint64, c_uint64]),
     "v2p_digest_launch": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]),
 }
 
 _hip = None
 _cohort = None
+
+
+class Routing(ctypes.Structure):
+    """v2p_routing (include/vcf2prot_hip.h)"""
+    _fields_ = [("wave_bytes_per_task", ctypes.c_uint32), ("rich", ctypes.c_uint32), ("phased", ctypes.c_uint32), ("store_sc1", ctypes.c_uint32),
+                ("phase_bytes", ctypes.c_uint64), ("order_blocks", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+def routing_rules(n_desc: int, n_chunks: int, result_bytes: int, proteome_len: int, wave_image: bool = True) -> dict:
+    """v2p_routing_rules: the library's routing rules for an image of these sizes (host-side, no GPU work)."""
+    r = Routing()
+    rc = hip_lib().v2p_routing_rules(n_desc, n_chunks, result_bytes, proteome_len, 1 if wave_image else 0, ctypes.byref(r))
+    if rc != 0:
+        raise V2PError(rc, "v2p_routing_rules")
+    return {k: int(getattr(r, k)) for k, _ in Routing._fields_ if k != "reserved"}
 
 
 class LaunchOpts(ctypes.Structure):

@@ -637,6 +637,15 @@ inline void order_chunks_for_xcds_range(Chunk* chunks, uint64_t n_chunks, const 
 // (profiles/r03_ab_block_order.txt).  Blocks smaller than that lose the reuse of the reference (C4, 56 MB proteome: 8.5 ms with
 // 40 MB blocks).  Blocks are equal shares of the table's ENTRIES, on multiples of 8 (entry 8j + x of a block = the j-th chunk of
 // slice x, on XCD x).  max_blocks <= 1: one order for the whole table.
+// An image is "rich" when its descriptors are more than 3 % of the result they describe (C2: 2.2 %, C4: 3.7 %, C3: 5 %): the launcher
+// gives rich images smaller phases and plain stores, the chunk order gives thin ones of 2 GB and more ONE order for the whole table
+// (profiles/r04_routing_sweep.json)
+constexpr double IMAGE_RICH_SHARE = 0.03;
+inline bool image_is_rich(uint64_t n_desc, uint64_t result_bytes) { return 8.0 * double(n_desc) > IMAGE_RICH_SHARE * double(result_bytes); }
+constexpr uint64_t THIN_ONE_ORDER_FROM = 2ull << 30;
+constexpr uint64_t PHASE_BYTES_DEFAULT = 64ull << 20;    // bytes of image (chunk records + descriptors) per launch phase
+constexpr uint64_t PHASE_BYTES_RICH = 28ull << 20;       // ... of a rich image
+constexpr uint32_t PHASE_MIN_CHUNKS = 16384;            // below this a launch is one phase and is not preceded by a read-ahead
 inline uint64_t xcd_order_block_bytes(uint64_t proteome_len) { const uint64_t b = 8u * proteome_len; return b < (32ull << 20) ? (32ull << 20) : b; }
 constexpr uint32_t XCD_ORDER_MAX_BLOCKS = 4096;             // blocks of one table (both builders)
 // number of blocks for a table whose results span `span_bytes`, and the table entries [first, last) of block k: equal shares of
@@ -644,8 +653,9 @@ constexpr uint32_t XCD_ORDER_MAX_BLOCKS = 4096;             // blocks of one tab
 inline uint32_t xcd_order_blocks(uint64_t span_bytes, uint64_t proteome_len, uint64_t n_entries, uint32_t max_blocks, uint64_t n_desc)
 {
     // (an image whose descriptors are a thin stream -- C2: 2.2 % of its result -- gains nothing from blocks and loses 5-7 % with
-    // a few dozen of them: one order for the whole table, as in round 2)
-    if (8.0 * double(n_desc) <= 0.03 * double(span_bytes)) return 1;
+    // a few dozen of them: one order for the whole table, as in round 2.  Below 2 GB the sweep of round 4 says the opposite --
+    // 1.5 GB images of 800- and 1600-residue transcripts: 0.23-0.24 ms in blocks against 0.26-0.29 -- so small images keep the blocks)
+    if (!image_is_rich(n_desc, span_bytes) && span_bytes >= THIN_ONE_ORDER_FROM) return 1;
     const uint64_t bb = xcd_order_block_bytes(proteome_len);
     uint64_t nb = (span_bytes + bb - 1) / bb;
     if (nb > max_blocks) nb = max_blocks;

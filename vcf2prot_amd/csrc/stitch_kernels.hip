@@ -1204,9 +1204,7 @@ static const uint8_t* device_dots(hipError_t* err)
 // descriptor lines -- a read-only kernel at read speed, which leaves them in the memory-side cache (256 MB; the result stores are
 // non-temporal and do not displace them) -- and the stitch kernels then find them there.  The copy benchmark: 3.47 -> 6.04 TB/s with
 // 64 MB phases, the touch kernels' time included.
-constexpr uint64_t PHASE_BYTES_DEFAULT = 64ull << 20;
-constexpr uint64_t PHASE_BYTES_RICH = 28ull << 20;       // descriptor-rich images (below)
-constexpr uint32_t PHASE_MIN_CHUNKS = 16384;            // below this a launch is one phase and is not preceded by a touch
+// (PHASE_BYTES_DEFAULT / PHASE_BYTES_RICH / PHASE_MIN_CHUNKS and image_is_rich(): sir_pack.hpp, next to the chunk order's rule)
 
 __global__ __launch_bounds__(256) void touch_image_kernel(const uint64_t* __restrict__ desc, const Chunk* __restrict__ chunks, uint32_t n_chunks, uint64_t n_desc,
                                                           const uint8_t* __restrict__ payload, uint64_t payload_len)
@@ -1240,7 +1238,7 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     // table the best was 20 MB: 8.85 ms; 10.3 with 32, 12.0 with 64); C4 whole 6.26 / 6.16 / 7.09 with 20 / 32 / 48; C2, whose image is
     // 1/45 of its result: 3.31 / 3.24 / 3.21 with 16 / 32 / 64 the other way.
     a.rows = (nontemporal & 8) != 0;                                             // (bit 3: a rows image, sir_pack.hpp: CHUNK_CLIP on every chunk)
-    const bool rich = 8.0 * double(a.n_desc) > 0.03 * double(a.out_len);        // C2: 2.2 %, C4: 3.7 %, C3: 5 %
+    const bool rich = image_is_rich(a.n_desc, a.out_len);                        // C2: 2.2 %, C4: 3.7 %, C3: 5 %
     // (phase size, store policy and threshold are launch options -- v2p_launch_opts, v2p_set_launch_opts -- for A/B runs and tests:
     // nothing here reads the environment)
     uint64_t phase_bytes = rich ? PHASE_BYTES_RICH : PHASE_BYTES_DEFAULT;

@@ -1907,6 +1907,20 @@ int v2p_stitch_launch_bits(const v2p_chunk* chunks, uint64_t n_chunks)
     return stitch_launch_bits(reinterpret_cast<const Chunk*>(chunks), n_chunks);
 }
 
+int v2p_routing_rules(uint64_t n_desc, uint64_t n_chunks, uint64_t result_bytes, uint64_t proteome_len, int wave_image, v2p_routing* out)
+{
+    if (!out) return V2P_ERR_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    const bool rich = image_is_rich(n_desc, result_bytes);
+    out->wave_bytes_per_task = WAVE_BYTES_PER_TASK;
+    out->rich = rich ? 1u : 0u;
+    out->phased = (wave_image && n_chunks >= PHASE_MIN_CHUNKS) ? 1u : 0u;       // (launch_stitch: dense and per-block images are one launch)
+    out->store_sc1 = rich ? 0u : 1u;
+    out->phase_bytes = rich ? PHASE_BYTES_RICH : PHASE_BYTES_DEFAULT;
+    out->order_blocks = (n_chunks < 16 || proteome_len == 0) ? 1u : xcd_order_blocks(result_bytes, proteome_len, n_chunks, XCD_ORDER_MAX_BLOCKS, n_desc);
+    return V2P_OK;
+}
+
 int v2p_order_chunks_for_xcds(v2p_chunk* chunks, uint64_t n_chunks, const uint64_t* desc, uint64_t n_desc, uint64_t proteome_len)
 {
     if ((n_chunks && !chunks) || (n_desc && !desc)) return V2P_ERR_INVALID_ARG;
