@@ -775,4 +775,10 @@ hipError_t launch_xcd_order(const Chunk* in, const uint8_t* bucket, uint64_t n, 
     return hipGetLastError();
 }
 
+hipError_t preload_build_kernels()
+{
+    hipFuncAttributes at;
+    return hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&scan_tiles));
+}
+
 }  // namespace v2p

@@ -628,4 +628,10 @@ hipError_t launch_rows_keys(const RowsArgs& a, uint64_t n_chunks, uint64_t n_des
     return hipGetLastError();
 }
 
+hipError_t preload_build_rows()
+{
+    hipFuncAttributes at;
+    return hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&rows_compact_kernel));
+}
+
 }  // namespace v2p

@@ -202,6 +202,9 @@ int v2p_init(int device_ordinal, unsigned flags, v2p_ctx** out)
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_init_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return V2P_ERR_HIP; }
     c->stream = c->own_stream;
+    // (the kernels' code objects now, not under the first batch's clock; a failure here would only surface again at the first launch)
+    (void)preload_stitch_kernels(); (void)preload_stitch_wave(); (void)preload_build_kernels(); (void)preload_build_rows();
+    (void)hipDeviceSynchronize();
     *out = c;
     return V2P_OK;
 }
