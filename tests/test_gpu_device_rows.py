@@ -178,3 +178,28 @@ def test_rows_builder_falls_back_for_tiles_that_do_not_fit_the_stage(built, gpu_
         got = b.download_hap(0)
         assert np.array_equal(got[:L], want) and np.array_equal(got[L:], prot)
         b.close()
+
+
+def test_cutter_falls_back_when_a_segment_has_more_chunks_than_its_padded_slots(built, gpu_ctx, coracle):
+    """100-residue transcripts with one substitution each: a wave chunk's 64 descriptors are 6 KiB, so a 640-row segment holds about
+    107 chunks -- more than the 96 slots the cutter's single pass has per segment: the builder then runs the emitting pass after the
+    scan instead of the copy.  Same image as the host's, same tapes as the oracle's."""
+    from vcf2prot_amd.cohort import Cohort
+    c = Cohort.preset("C3", mean_len=100.0, len_model=0, fixed_len=100, n_transcripts=4000, alts_fixed=1, altered_per_hap=2000, n_samples=8,
+                      mix=[1.0] + [0.0] * 5)
+    prot = c.proteome()
+    gpu_ctx.upload_proteome(prot)
+    n = c.n_haplotypes
+    stream = c.txstream(0, n, n_threads=3)
+    b = gpu_ctx.batch()
+    b.build_on_device(stream, 0, 6)
+    want = _same_image(gpu_ctx, b, stream, prot.size, 1)
+    per_seg = np.bincount((want.chunks[:, 1] & np.uint64((1 << 48) - 1)) // np.uint64(640 * 1024))
+    assert per_seg.max() > 96, per_seg.max()                        # (the case this test is about)
+    b.execute()
+    b.sync()
+    for i in range(n):
+        assert np.array_equal(b.download_hap(i), oracle_hap(c, coracle, i)), i
+    b.close()
+    stream.close()
+    c.close()

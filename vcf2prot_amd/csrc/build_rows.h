@@ -50,6 +50,7 @@ struct RowsArgs {
     const uint64_t* seg_base;           // [n_segs + 1] exclusive prefix
     uint64_t  n_segs;
     Chunk*    chunks_tmp;               // arena order
+    Chunk*    chunks_pad;               // [n_segs * ROWS_CHUNK_PAD] the cutter's single pass
     uint8_t*  bucket;
     uint8_t*  sub;
     uint64_t* hap_out_begin;
@@ -60,6 +61,7 @@ struct RowsArgs {
 // arena bytes per tile (+ u64 exclusive scan into tile_res_base, total behind the last tile)
 hipError_t launch_rows_tile_bytes(const RowsArgs& a, uint64_t* scan_scratch, hipStream_t stream);
 uint64_t rows_scan_scratch_entries(uint64_t n);
+constexpr uint32_t ROWS_CHUNK_PAD = 96;            // chunk slots per segment of 640 rows in the cutter's padded table (64 ten-row chunks tile a segment)
 constexpr uint32_t ROWS_PAD_SLOTS = 256;           // descriptor slots per tile in the padded array (= build_rows.hip: ROWS_PAD)
 // the parse: mode ROWS_WAVE / ROWS_DENSE; phase 0: descriptors into the padded array + tile_count (a tile that does not fit its slots
 // is reported: STATUS_ROWS_STAGE), 1: tile_count only, 2: descriptors straight to desc + tile_desc_base[tile] (the two-pass form: any tile)
@@ -67,9 +69,11 @@ hipError_t launch_rows_parse(const RowsArgs& a, int mode, bool fasta, int phase,
 // padded -> dense (tile_desc_base = the scan of tile_count)
 hipError_t launch_rows_compact(const RowsArgs& a, hipStream_t stream);
 hipError_t launch_rows_hap_begin(const RowsArgs& a, hipStream_t stream);
-// the cutter: count pass (seg_count, totals[2] = last chunk's result offset), then -- after the scan of seg_count -- the emit pass
-// (chunks_tmp in arena order) and the proteome slice / window of every chunk (bucket, sub)
-hipError_t launch_rows_cut(const RowsArgs& a, int mode, bool emit, hipStream_t stream);
+// the cutter, pass 0: count (seg_count, totals[2] = last chunk's result offset); 1: emit at seg_base (the scan of seg_count) into
+// chunks_tmp; 2: count AND emit into chunks_pad (ROWS_CHUNK_PAD slots per segment; totals[3] != 0: a segment did not fit, run pass 1)
+hipError_t launch_rows_cut(const RowsArgs& a, int mode, int pass, hipStream_t stream);
+// pass 2's padded table -> chunks_tmp in arena order
+hipError_t launch_rows_chunk_compact(const RowsArgs& a, hipStream_t stream);
 hipError_t launch_rows_keys(const RowsArgs& a, uint64_t n_chunks, uint64_t n_desc, hipStream_t stream);
 
 }  // namespace v2p

@@ -480,19 +480,24 @@ __global__ __launch_bounds__(256) void rows_hap_begin_kernel(RowsArgs a)
 }
 
 // ---- the cutter: one wave per segment of ROWS_SEG rows ----------------------------------------------------------------------------
-template <bool EMIT>
+// PASS 0: count the chunks of every segment (seg_count);  1: emit them at seg_base[seg] (after the scan of the counts);
+//      2: both at once -- counted, and emitted to the segment's ROWS_CHUNK_PAD slots of a padded table that a copy kernel compacts
+//         after the scan (a segment with more chunks than slots raises totals[3]: the host then runs pass 1 instead of the copy)
+template <int PASS>
 __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_rows, uint32_t max_desc, uint64_t flag)
 {
+    constexpr bool EMIT = PASS != 0;
     const uint32_t lane = threadIdx.x;
     const uint64_t n_desc = a.tile_desc_base[a.n_tiles];
     if (*a.status != STATUS_CLEAN) {                                                      // the parse failed (or asks for its two-phase form): the row map is not to be walked
-        if (!EMIT && lane == 0) a.seg_count[blockIdx.x] = 0u;
+        if (PASS != 1 && lane == 0) a.seg_count[blockIdx.x] = 0u;
         return;
     }
     const uint64_t seg = blockIdx.x;
     const uint64_t s0 = seg * ROWS_SEG, s1 = s0 + ROWS_SEG < a.n_rows ? s0 + ROWS_SEG : a.n_rows;
     uint32_t count = 0;
-    uint64_t out_k = EMIT ? a.seg_base[seg] : 0;
+    uint64_t out_k = PASS == 1 ? a.seg_base[seg] : (PASS == 2 ? seg * ROWS_CHUNK_PAD : 0);
+    Chunk* const table = PASS == 2 ? a.chunks_pad : a.chunks_tmp;
     uint64_t last_dst = 0;
     uint64_t r0 = s0;
     while (r0 < s1) {
@@ -519,9 +524,9 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
             const uint64_t m = __ballot(ok);
             if (!m) { if (lane == 0) rreport(a.status, f, STATUS_ROWS_TOO_MANY); return; }
             const uint32_t hb = 63u - uint32_t(__builtin_clzll(m));
-            if (EMIT && lane == hb) {
+            if (EMIT && lane == hb && (PASS != 2 || count < ROWS_CHUNK_PAD)) {
                 const uint64_t n = lastd - f + 1u;
-                a.chunks_tmp[out_k] = Chunk{f | (uint64_t(hs) << TB_IDX_BITS) | (uint64_t(tc) << (TB_IDX_BITS + TB_SKIP_BITS)), ((b + cur) * ROW_BYTES) | (n << 48) | CHUNK_CLIP | flag};
+                table[out_k] = Chunk{f | (uint64_t(hs) << TB_IDX_BITS) | (uint64_t(tc) << (TB_IDX_BITS + TB_SKIP_BITS)), ((b + cur) * ROW_BYTES) | (n << 48) | CHUNK_CLIP | flag};
             }
             last_dst = (b + cur) * ROW_BYTES;
             ++count; ++out_k;
@@ -531,10 +536,21 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
         }
         r0 = b + cur;
     }
-    if (!EMIT && lane == 0) {
+    if (PASS != 1 && lane == 0) {
         a.seg_count[seg] = count;
         if (seg + 1u == a.n_segs) a.totals[2] = last_dst;
+        if (PASS == 2 && count > ROWS_CHUNK_PAD) atomicOr(reinterpret_cast<unsigned long long*>(a.totals) + 3, 1ull);
     }
+}
+
+// the padded chunk table of pass 2 -> arena order (seg_base: the scan of the segments' counts): one wave per segment
+__global__ __launch_bounds__(256) void rows_chunk_compact_kernel(RowsArgs a)
+{
+    const uint64_t seg = uint64_t(blockIdx.x) * 4u + (threadIdx.x >> 6);
+    if (seg >= a.n_segs) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t b0 = a.seg_base[seg], n = a.seg_base[seg + 1u] - b0;
+    for (uint32_t k = lane; k < n && k < ROWS_CHUNK_PAD; k += 64u) a.chunks_tmp[b0 + k] = a.chunks_pad[seg * ROWS_CHUNK_PAD + k];
 }
 
 // proteome slice and window of every chunk (order_chunks_for_xcds: the first reference read among its first six descriptors)
@@ -611,13 +627,21 @@ hipError_t launch_rows_hap_begin(const RowsArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_rows_cut(const RowsArgs& a, int mode, bool emit, hipStream_t stream)
+hipError_t launch_rows_cut(const RowsArgs& a, int mode, int pass, hipStream_t stream)
 {
     if (a.n_segs == 0) return hipSuccess;
     const uint32_t max_rows = mode == ROWS_DENSE ? ROWS_MAX_DENSE : ROWS_MAX_WAVE, max_desc = mode == ROWS_DENSE ? CHUNK_TASKS_DEEP : CHUNK_TASKS_WAVE;
     const uint64_t flag = mode == ROWS_DENSE ? CHUNK_DENSE : CHUNK_WAVE;
-    if (emit) hipLaunchKernelGGL(rows_cut_kernel<true>, dim3(uint32_t(a.n_segs)), dim3(64), 0, stream, a, max_rows, max_desc, flag);
-    else hipLaunchKernelGGL(rows_cut_kernel<false>, dim3(uint32_t(a.n_segs)), dim3(64), 0, stream, a, max_rows, max_desc, flag);
+    if (pass == 1) hipLaunchKernelGGL(rows_cut_kernel<1>, dim3(uint32_t(a.n_segs)), dim3(64), 0, stream, a, max_rows, max_desc, flag);
+    else if (pass == 2) hipLaunchKernelGGL(rows_cut_kernel<2>, dim3(uint32_t(a.n_segs)), dim3(64), 0, stream, a, max_rows, max_desc, flag);
+    else hipLaunchKernelGGL(rows_cut_kernel<0>, dim3(uint32_t(a.n_segs)), dim3(64), 0, stream, a, max_rows, max_desc, flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_chunk_compact(const RowsArgs& a, hipStream_t stream)
+{
+    if (a.n_segs == 0) return hipSuccess;
+    hipLaunchKernelGGL(rows_chunk_compact_kernel, dim3(uint32_t((a.n_segs + 3) / 4)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -1229,11 +1229,12 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
     a.out_bytes = out_bytes; a.n_rows = n_rows; a.n_segs = n_segs;
     // scratch of the parse and the count pass of the cutter: row map, chunks per segment + their scan
     const uint64_t c_cover = 0, c_segc = up8((n_rows + 1) * 8), c_segb = c_segc + up8((n_segs + 1) * 4), c_tiles = c_segb + up8((n_segs + 2) * 8),
-                   c_end = c_tiles + up8(scan_tiles_for(n_segs + 1) * 8);
+                   c_cpad = c_tiles + up8(scan_tiles_for(n_segs + 1) * 8), c_end = c_cpad + up8(n_segs * ROWS_CHUNK_PAD * sizeof(Chunk));
     HIP_TRY(c, guard.cover.ensure(c_end), "hipMalloc(row map)");
     a.cover = reinterpret_cast<uint64_t*>(guard.cover.ptr() + c_cover);
     a.seg_count = reinterpret_cast<uint32_t*>(guard.cover.ptr() + c_segc);
     a.seg_base = reinterpret_cast<const uint64_t*>(guard.cover.ptr() + c_segb);
+    a.chunks_pad = reinterpret_cast<Chunk*>(guard.cover.ptr() + c_cpad);
     HIP_TRY(c, b->d_hap.ensure((n_h + 1) * 8), "hipMalloc(hap_begin)");
     a.hap_out_begin = reinterpret_cast<uint64_t*>(b->d_hap.ptr());
     HIP_TRY(c, hipMemsetAsync(d + o_totals, 0, 64, c->stream), "hipMemset(totals)");
@@ -1277,7 +1278,7 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
     if (two_pass) HIP_TRY(c, launch_rows_parse(a, mode, fasta, 2, c->stream), "launch(parse: write)");
     else HIP_TRY(c, launch_rows_compact(a, c->stream), "launch(compact)");
     HIP_TRY(c, launch_rows_hap_begin(a, c->stream), "launch(hap_begin)");
-    HIP_TRY(c, launch_rows_cut(a, mode, false, c->stream), "launch(cut: count)");
+    HIP_TRY(c, launch_rows_cut(a, mode, 2, c->stream), "launch(cut)");
     HIP_TRY(c, launch_scan_u32(a.seg_count, n_segs, const_cast<uint64_t*>(a.seg_base), reinterpret_cast<uint64_t*>(guard.cover.ptr() + c_tiles), c->stream), "launch(scan)");
     HIP_TRY(c, hipEventRecord(guard.ev[5], c->stream), "hipEventRecord");
     uint64_t totals[4] = {0, 0, 0, 0}, n_chunks = 0;
@@ -1315,7 +1316,8 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
     a.bucket = scratch.ptr() + s_bucket;
     a.sub = scratch.ptr() + s_sub;
     HIP_TRY(c, hipEventRecord(guard.ev[6], c->stream), "hipEventRecord");
-    HIP_TRY(c, launch_rows_cut(a, mode, true, c->stream), "launch(cut: emit)");
+    if (totals[3]) HIP_TRY(c, launch_rows_cut(a, mode, 1, c->stream), "launch(cut: emit)");      // (a segment with more chunks than the padded table's slots)
+    else HIP_TRY(c, launch_rows_chunk_compact(a, c->stream), "launch(chunk table)");
     const bool reorder = !(c->flags & V2P_FLAG_RESULT_ORDER) && n_chunks >= 16 && c->proteome_len != 0 && n_desc != 0;
     if (reorder) {
         HIP_TRY(c, launch_rows_keys(a, n_chunks, n_desc, c->stream), "launch(keys)");
