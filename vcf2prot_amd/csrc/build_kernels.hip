@@ -775,10 +775,11 @@ hipError_t launch_xcd_order(const Chunk* in, const uint8_t* bucket, uint64_t n, 
     return hipGetLastError();
 }
 
+__global__ void code_object_loader_c() {}
 hipError_t preload_build_kernels()
 {
-    hipFuncAttributes at;
-    return hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&scan_tiles));
+    hipLaunchKernelGGL(code_object_loader_c, dim3(1), dim3(64), 0, nullptr);
+    return hipGetLastError();
 }
 
 }  // namespace v2p

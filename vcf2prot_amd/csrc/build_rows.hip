@@ -376,7 +376,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
 #pragma unroll
         for (int i = 0; i < NR; ++i) big = big || rl[i] > ROW_BYTES;
         const bool slow = __ballot(big) != 0ull;
-        if (!slow) {
+        // ... and the usual window before the general one: no lane has a gap, a tail or FASTA text to emit -- every lane at most its
+        // Task's own run -- so a descriptor's slot is a ballot and a popcount (no scan), and a run holds one row boundary at most
+        bool other = rl[RG] != 0u || rl[RT] != 0u;
+        if (FASTA) other = other || rl[0] != 0u || rl[NR - 1] != 0u;
+        const bool plain_window = !slow && __ballot(other) == 0ull;
+        if (plain_window) {
+            const bool has = rl[RS] != 0u;
+            const uint64_t hm = __ballot(has);
+            const uint32_t round_total = uint32_t(__popcll(hm));
+            if (PHASE != PH_COUNT && round_total != 0u) {
+                const uint32_t k = tile_cnt + mbcnt(hm);
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                if (has && k < out_cap) *reinterpret_cast<u32x2*>(out + k) = u32x2{wl[RS], fusedw ? wh[RS] : (wh[RS] | (rl[RS] << 8))};
+                const uint32_t s0 = eoff + q0, rb = ((s0 + ROW_BYTES - 1u) >> 10) << 10;
+                if (has && rb < s0 + rl[RS]) {
+                    const uint64_t row = erow + (rb >> 10);
+                    if (row >= 1u && row < a.n_rows) a.cover[row] = cover_word(k, rb - s0);
+                }
+            }
+            tile_cnt += round_total;
+        } else if (!slow) {
             uint32_t cn[NR], cnt = 0;
 #pragma unroll
             for (int i = 0; i < NR; ++i) { cn[i] = rl[i] ? 1u : 0u; cnt += cn[i]; }
@@ -652,10 +672,11 @@ hipError_t launch_rows_keys(const RowsArgs& a, uint64_t n_chunks, uint64_t n_des
     return hipGetLastError();
 }
 
+__global__ void code_object_loader_d() {}
 hipError_t preload_build_rows()
 {
-    hipFuncAttributes at;
-    return hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&rows_compact_kernel));
+    hipLaunchKernelGGL(code_object_loader_d, dim3(1), dim3(64), 0, nullptr);
+    return hipGetLastError();
 }
 
 }  // namespace v2p

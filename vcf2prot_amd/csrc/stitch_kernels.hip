@@ -1426,12 +1426,13 @@ hipError_t launch_digest(const DigestArgs& a, uint64_t out_bytes, hipStream_t st
 }
 
 // HIP loads a translation unit's code object when one of its kernels is first used -- 17 ms for the stitch kernels, paid by the first
-// execute of a process (C3 whole: 26 ms instead of 8.4).  v2p_init launches one kernel per unit on nothing instead.
+// execute of a process (C3 whole: 26 ms instead of 8.4).  v2p_init launches one empty kernel per unit instead.
+__global__ void code_object_loader_a() {}   // (a kernel of its own, so that profiles of the real ones hold no empty launches)
 hipError_t preload_stitch_kernels()
 {
     hipError_t err = hipSuccess;
     (void)device_dots(&err);                                       // (the '.' buffer of the device: an allocation, a fill and a wait)
-    hipLaunchKernelGGL(touch_image_kernel, dim3(8), dim3(256), 0, nullptr, nullptr, nullptr, 0u, uint64_t(0), nullptr, uint64_t(0));
+    hipLaunchKernelGGL(code_object_loader_a, dim3(1), dim3(64), 0, nullptr);
     return err != hipSuccess ? err : hipGetLastError();
 }
 
