@@ -195,7 +195,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
     const uint32_t* const g_sr = a.start_pos_res + task_lo;
     const uint32_t n_tile_tasks = uint32_t(task_end - task_lo);
     uint32_t pf_code = 0, pf_sp = 0, pf_ln = 0, pf_sr = 0;            // the tasks of the window about to be worked on (item = task)
-    auto prefetch = [&](uint32_t i) { pf_code = 0; pf_sp = 0; pf_ln = 0; pf_sr = 0; if (i < n_tile_tasks) { pf_code = g_code[i]; pf_sp = g_sp[i]; pf_ln = g_ln[i]; pf_sr = g_sr[i]; } };
+    // (32-bit byte offsets on the wave-uniform bases: one shift per lane instead of three 64-bit address computations)
+    auto at32 = [](const uint32_t* base, uint32_t i) -> uint32_t { return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + (i << 2)); };
+    auto prefetch = [&](uint32_t i) { pf_code = 0; pf_sp = 0; pf_ln = 0; pf_sr = 0; if (i < n_tile_tasks) { pf_code = g_code[i]; pf_sp = at32(g_sp, i); pf_ln = at32(g_ln, i); pf_sr = at32(g_sr, i); } };
     prefetch(lane);
     const bool alt_in_lds = alt_n <= ROWS_ALT_LDS;
     {
