@@ -55,7 +55,6 @@ struct RowsArgs {
     uint8_t*  sub;
     uint64_t* hap_out_begin;
     unsigned long long* status;
-    uint32_t dbg;                       // development only (V2P_ROWS_DBG, results are wrong): 1 no look-back, 2 no write-out, 4 one window per tile
 };
 
 // arena bytes per tile (+ u64 exclusive scan into tile_res_base, total behind the last tile)

@@ -3,16 +3,16 @@
 // Replaces, for wave and dense images, round 3's build_kernels.hip (one lane per transcript walking its tasks twice -- a counting
 // pass and an emitting pass, 12.3 ms for the north star's cohort whose execute takes 7.6).  Here
 //   tile_bytes   arena bytes per tile of K transcripts, scanned: res_counter of haplotype_instruction.rs:90,132 per tile
-//   parse        lane = ITEM of the stream (a Task, task.rs:2-9, or the HEAD of a transcript).  Every stream array is read once,
-//                coalesced; update_task's checks (haplotype_instruction.rs:140-158) and Task::execute's bounds (task.rs:43,47) are
-//                what the device reports instead of panicking; the packer's fusion state machine is solved for 64 items at once on
-//                ballot masks (rows_parse); descriptors -- whole, nothing is cut -- are staged in LDS and leave coalesced once a
-//                decoupled look-back over the tiles' descriptor counts has told the wave where they go; every 1 KiB row of the
-//                arena learns which descriptor covers its first byte
+//   parse        lane = ITEM of the stream (a Task, task.rs:2-9; a transcript's first item also opens it, its last also closes it).
+//                Every stream array is read once, coalesced, a window ahead of its use; update_task's checks
+//                (haplotype_instruction.rs:140-158) and Task::execute's bounds (task.rs:43,47) are what the device reports instead
+//                of panicking; the packer's fusion state machine is solved for 64 items at once on ballot masks (rows_parse);
+//                descriptors -- whole, nothing is cut -- go to the tile's slots of a padded array, compacted after a scan of the
+//                tiles' counts; every 1 KiB row of the arena learns which descriptor covers its first byte
 //   cut          one wave per segment of 640 rows walks the row map greedily: as many rows as one wave takes (ten) while the
-//                descriptors fit its lanes; counted, scanned, emitted
+//                descriptors fit its lanes; counted and emitted in one pass (padded chunk table, compacted after the scan)
 //   keys         proteome slice and window of every chunk for the XCD / window order (build_kernels.hip: launch_order_blocks)
-// Integer / index work only (no MFMA); the parse is bound by vector-instruction issue and by the stream's bytes, see DESIGN.md.
+// Integer / index work only (no MFMA); the parse is bound by instruction issue -- vector and scalar alike -- see DESIGN.md 8.2a.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "build_rows.h"
@@ -139,10 +139,10 @@ __global__ __launch_bounds__(256) void rows_scan_apply(const uint64_t* __restric
 }
 
 // ---- the parse ------------------------------------------------------------------------------------------------------------------
-// What bounds it (measured, profiles/r04_build_*): vector-instruction issue.  A window of 64 items costs a few hundred VALU
-// instructions however its loads are arranged (a burst of the tile's Task arrays into LDS with global_load_lds changed nothing; a
-// decoupled look-back for the descriptors' final place cost a third of the kernel: persistent waves run in lockstep, so every
-// generation of tiles waits for the prefix to ripple through it).  So: one tile per 64-lane workgroup, plain grid; descriptors go
+// What bounds it (measured, profiles/r04_build_*, r04_sq_counters_parse_kernel_C3.txt): instruction issue, ~200 vector and ~190
+// scalar instructions per window of 64 items, once a tile's dependent loads are requested together (below).  A burst of the tile's
+// Task arrays into LDS with global_load_lds changed nothing; a decoupled look-back for the descriptors' final place cost a third
+// of the kernel (a tile waits for every tile before it).  So: one tile per 64-lane workgroup, plain grid; descriptors go
 // to a PADDED array -- ROWS_PAD slots per tile -- and a copy kernel compacts them once a scan of the tiles' counts has told every
 // tile where it starts; positions are 32-bit offsets from the tile's first emitted byte; per-transcript values sit in LDS as
 // arrays of words; everything rare (runs of more than 1 KiB, which may cross two rows, or of more than a descriptor's length
