@@ -285,7 +285,9 @@ int v2p_batch_counts(const v2p_batch* b, uint64_t* n_haps, uint64_t* n_desc, uin
 int v2p_batch_hap_range(const v2p_batch* b, uint64_t h, uint64_t* begin, uint64_t* len);
 /* copy arena bytes [begin, begin+len) to the host (1 byte per residue) */
 int v2p_batch_download(v2p_batch* b, uint64_t begin, uint64_t len, uint8_t* out);
-/* per-haplotype digests computed on the device (sum (byte+1)*splitmix64(pos), pos relative to the haplotype) */
+/* per-haplotype digests computed on the device: sum_i (byte_i + 1) * 2^(8 * (i mod 8)) * splitmix64(i div 8)  (mod 2^64), i relative
+ * to the haplotype's first byte -- word by word: sum_k splitmix64(k) * (little-endian word k + 0x01..01 over the bytes that exist).
+ * (Round 5: one multiplier per 8 bytes; until round 4 it was one per byte and the kernel took 8 x an execute.) */
 int v2p_batch_digests(v2p_batch* b, uint64_t* digests, uint64_t n_haps);
 /* device pointer of the result arena (for callers that keep consuming on the GPU) */
 void* v2p_batch_device_out(v2p_batch* b);

@@ -37,14 +37,34 @@ def test_batched_driver_every_haplotype_equals_the_oracle(built, gpu_ctx, coracl
 
 def test_c3_whole_cohort_on_one_gpu_every_haplotype_by_digest(built, gpu_ctx, coracle):
     """BASELINE configs[2]: 10 000 samples = 20 000 haplotypes, about 38 GB of result, one launch on one MI355X (288 GB HBM);
-    the digest of EVERY haplotype equals the digest of the oracle's result."""
+    the digest of EVERY haplotype equals the digest of the oracle's result -- for the image the PRODUCT builds (on the device, from
+    the per-transcript Task vectors: v2p_batch_build_on_device, kernel 6 -- haplotype_instruction.rs:94-133 as kernels) and for the
+    host-packed image of the same haplotypes."""
     from concurrent.futures import ThreadPoolExecutor
     from vcf2prot_amd.cohort import Cohort
+    from vcf2prot_amd.txstream import build_on_device_auto
     c = Cohort.preset("C3")
     n = c.n_haplotypes
     assert n == 20000
+    threads = min(64, os.cpu_count() or 1)
     gpu_ctx.upload_proteome(c.proteome())
-    img = c.pack(0, n, n_threads=min(64, os.cpu_count() or 1))
+    # the shipped path: stream -> device-built rows image -> execute
+    stream = c.txstream(0, n, n_threads=threads)
+    sizes = c.result_sizes(0, n, n_threads=threads)
+    db = gpu_ctx.batch()
+    info = build_on_device_auto(db, stream, int(sizes.sum()))
+    stream.close()
+    assert info["kernel"] == 6, info
+    cn = db.counts()
+    assert cn["out_bytes"] == int(sizes.sum()) > 35 * 10 ** 9
+    _, _, hb = db.download_image()
+    assert np.array_equal(np.diff(hb.astype(np.int64)), sizes.astype(np.int64))
+    db.execute()
+    db.sync()
+    dig_dev = db.digests()
+    db.close()
+    # the host packer's image
+    img = c.pack(0, n, n_threads=threads)
     assert img.out_bytes > 35 * 10 ** 9
     b = gpu_ctx.batch()
     b.set_packed(img.desc, img.chunks, img.payload, img.hap_out_begin)
@@ -53,6 +73,7 @@ def test_c3_whole_cohort_on_one_gpu_every_haplotype_by_digest(built, gpu_ctx, co
     b.execute()
     b.sync()
     dig = b.digests()
+    b.close()
     workers = min(64, os.cpu_count() or 1)
 
     def oracle_digests(w):
@@ -68,6 +89,7 @@ def test_c3_whole_cohort_on_one_gpu_every_haplotype_by_digest(built, gpu_ctx, co
     with ThreadPoolExecutor(workers) as pool:
         for part in pool.map(oracle_digests, range(workers)):
             want.update(part)
+    bad = [h for h in range(n) if int(dig_dev[h]) != want[h]]
+    assert not bad, ("device-built image", bad[:10])
     bad = [h for h in range(n) if int(dig[h]) != want[h]]
-    assert not bad, bad[:10]
-    b.close()
+    assert not bad, ("host-packed image", bad[:10])

@@ -203,3 +203,57 @@ def test_cutter_falls_back_when_a_segment_has_more_chunks_than_its_padded_slots(
     b.close()
     stream.close()
     c.close()
+
+
+def test_a_haplotype_whose_arena_range_crosses_4_gib(built, gpu_ctx, coracle):
+    """Arena offsets above 2^32 INSIDE one haplotype: [3 small transcripts] [4 300 transcripts of 1 MiB each = 4.5 GB] [3 small ones],
+    one substitution per transcript.  The parse's positions are 32-bit offsets from a TILE's first byte, the cover map and the chunk
+    records hold 48-bit arena offsets: the big haplotype's digest and bytes either side of the 4 GiB line must be the oracle's
+    (task.rs:38-50 over the haplotype's own tapes, haplotype_instruction.rs:94-133).  A 1 MiB copy is 513 descriptors, so its tile
+    overflows the one-pass stage and the build runs in its two-pass form (descriptor indices up to 2.2e6 in the cover words).
+    (More than 2^25 TILES -- the one-pass cover word's tile field -- would take 2^25 transcripts of >= 360 tasks each, 157 GB of stream:
+    not reachable here; from that many tiles on the builder takes the two-pass form, whose cover word has no tile field.)"""
+    from stream_util import Stream
+    rng = np.random.default_rng(17)
+    AA = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    L, small, n_big = 1 << 20, 700, 4300
+    prot = AA[rng.integers(0, 20, size=L + 64)]
+    gpu_ctx.upload_proteome(prot)
+    lens = [small] * 3 + [L] * n_big + [small] * 3
+    n_tx = len(lens)
+    pos = [int(rng.integers(1, ln - 1)) for ln in lens]
+    sub = AA[rng.integers(0, 20, size=n_tx)]
+    code = np.tile(np.array([0, 1, 0], dtype=np.uint8), n_tx)
+    sp = np.array([v for t in range(n_tx) for v in (0, 1, pos[t] + 1)], dtype=np.uint32)
+    ln = np.array([v for t in range(n_tx) for v in (pos[t], 1, lens[t] - pos[t] - 1)], dtype=np.uint32)
+    sr = np.array([v for t in range(n_tx) for v in (0, pos[t], pos[t] + 1)], dtype=np.uint32)
+    alt = np.repeat(sub, 2)                                                   # a missense payload is pushed twice (transcript_instructions.rs:659-660)
+    s = Stream([0, 3, 3 + n_big, n_tx], [0] * n_tx, lens, lens, np.arange(0, 3 * n_tx + 1, 3), np.arange(0, 2 * n_tx + 1, 2), code, sp, ln, sr, alt)
+    b = gpu_ctx.batch()
+    b.build_on_device(s, 0, 6)
+    _, chunks, hb = b.download_image()
+    want_hb = np.concatenate([[0], np.cumsum([3 * small, n_big * L, 3 * small])]).astype(np.uint64)
+    assert np.array_equal(hb, want_hb) and int(hb[1]) < (1 << 32) < int(hb[2])
+    dst = chunks[:, 1] & np.uint64((1 << 48) - 1)
+    assert int(dst.max()) > (1 << 32) and np.all(dst % np.uint64(1024) == 0)
+    b.execute()
+    b.sync()
+    dig = b.digests()
+    # the oracle on the big haplotype's own tapes: step 5 rebases every transcript's tasks onto the haplotype's ref / alt / result tapes
+    t0, t1 = 3, 3 + n_big
+    k = np.arange(t1 - t0, dtype=np.uint64)
+    code_h = code[3 * t0:3 * t1]
+    sp_h = sp[3 * t0:3 * t1].astype(np.uint64) + np.where(code_h == 0, np.repeat(k * np.uint64(L), 3), np.repeat(k * np.uint64(2), 3))
+    sr_h = sr[3 * t0:3 * t1].astype(np.uint64) + np.repeat(k * np.uint64(L), 3)
+    tasks = coracle.pack_tasks(code_h, sp_h, ln[3 * t0:3 * t1].astype(np.uint64), sr_h)
+    want = coracle.gir_execute_u8(tasks, np.tile(prot[:L], n_big), alt[2 * t0:2 * t1], np.full(n_big * L, ord("."), dtype=np.uint8))
+    assert int(dig[1]) == coracle.digest_u8(want)
+    line = (1 << 32) - int(hb[1])                                             # the 4 GiB line inside the haplotype
+    for a, n in ((0, 4096), (line - 70000, 140000), (n_big * L - 4096, 4096)):
+        assert np.array_equal(b.download(int(hb[1]) + a, n), want[a:a + n]), a
+    del want
+    for h, (ta, tb) in ((0, (0, 3)), (2, (3 + n_big, n_tx))):
+        w = np.concatenate([np.concatenate([prot[:pos[t]], sub[t:t + 1], prot[pos[t] + 1:lens[t]]]) for t in range(ta, tb)])
+        assert np.array_equal(b.download_hap(h), w), h
+        assert int(dig[h]) == coracle.digest_u8(w)
+    b.close()

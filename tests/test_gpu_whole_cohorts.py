@@ -1,4 +1,5 @@
-"""The 8-GPU configurations of BASELINE.json WHOLE on one MI355X (both fit its 288 GB): C4 (2 504 samples = 5 008 haplotypes over the
+"""(round 5: every whole cohort also through the DEVICE builder -- the path the product ships.)
+The 8-GPU configurations of BASELINE.json WHOLE on one MI355X (both fit its 288 GB): C4 (2 504 samples = 5 008 haplotypes over the
 100 000-transcript proteome, ~30 GB of result) and C5 (100 000 deep haplotypes, ~8 GB, 1.3e9 Tasks) in ONE launch, the digest of
 every haplotype against the oracle; then the same cohort the way eight ranks would run it -- shard_by_bytes ranges executed one
 after the other -- must reproduce the single launch: per-haplotype digests, and the byte offsets the size all-gather derives
@@ -31,6 +32,22 @@ def _oracle_digests(preset, coracle, n, workers):
     return np.array([res[h] for h in range(n)], dtype=np.uint64)
 
 
+def _run_device_built(gpu_ctx, c, n, threads, kernel):
+    """The image the product ships: built ON the device from the transcript stream (v2p_batch_build_on_device, rows images)."""
+    stream = c.txstream(0, n, n_threads=threads)
+    b = gpu_ctx.batch()
+    ms = b.build_on_device(stream, 0, kernel)
+    stream.close()
+    assert ms > 0
+    _, _, hb = b.download_image()
+    b.execute()
+    b.sync()
+    dig = np.array(b.digests(), dtype=np.uint64)
+    cn = b.counts()
+    b.close()
+    return dig, hb.astype(np.int64), cn
+
+
 def _run(gpu_ctx, img):
     b = gpu_ctx.batch()
     b.set_packed(img.desc, img.chunks, img.payload, img.hap_out_begin)
@@ -59,6 +76,13 @@ def test_whole_cohort_one_launch_and_as_eight_shards(built, gpu_ctx, coracle, pr
     want = _oracle_digests(preset, coracle, n, min(32, os.cpu_count() or 1))
     bad = np.nonzero(whole != want)[0]
     assert bad.size == 0, (preset, bad[:10])
+    # ... and the device-built image of the whole cohort (C4: kernel 6, wave rows image over the 56 MB proteome, 30 GB of arena; C5:
+    # kernel 7, dense rows image, 1.29e9 Tasks): haplotype offsets, every digest against the oracle's and the host-packed image's
+    dev, dev_begin, cn = _run_device_built(gpu_ctx, c, n, threads, 6 if preset == "C4" else 7)
+    assert np.array_equal(dev_begin, whole_begin)
+    assert cn["out_bytes"] == int(whole_begin[-1])
+    bad = np.nonzero(dev != want)[0]
+    assert bad.size == 0, (preset, "device-built", bad[:10])
     # the same cohort as world = 8 would run it: contiguous ranges of equal result bytes, every rank its own image and arena
     sizes = c.result_sizes(0, n, n_threads=threads)
     assert np.array_equal(np.diff(whole_begin), sizes.astype(np.int64))

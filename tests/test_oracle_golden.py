@@ -163,9 +163,11 @@ def test_digest_matches_definition(coracle):
         x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
         x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
         return x ^ (x >> 31)
-    want = sum((int(v) + 1) * mix(i) for i, v in enumerate(a)) & ((1 << 64) - 1)
-    assert coracle.digest_u8(a) == want
-    assert coracle.digest_u32(a.astype(np.uint32)) == want
+    # include/vcf2prot_hip.h (v2p_batch_digests): sum_i (byte_i + 1) * 2^(8 * (i mod 8)) * splitmix64(i div 8)  mod 2^64
+    for n in (1000, 1003, 8, 7, 1, 0):
+        want = sum(((int(v) + 1) << (8 * (i & 7))) * mix(i >> 3) for i, v in enumerate(a[:n])) & ((1 << 64) - 1)
+        assert coracle.digest_u8(a[:n]) == want, n
+        assert coracle.digest_u32(a[:n].astype(np.uint32)) == want, n
 
 
 def test_mt_driver_equals_sequential(coracle):

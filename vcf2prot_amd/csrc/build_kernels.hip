@@ -776,9 +776,9 @@ hipError_t launch_xcd_order(const Chunk* in, const uint8_t* bucket, uint64_t n, 
 }
 
 __global__ void code_object_loader_c() {}
-hipError_t preload_build_kernels()
+hipError_t preload_build_kernels(hipStream_t stream)
 {
-    hipLaunchKernelGGL(code_object_loader_c, dim3(1), dim3(64), 0, nullptr);
+    hipLaunchKernelGGL(code_object_loader_c, dim3(1), dim3(64), 0, stream);
     return hipGetLastError();
 }
 

@@ -675,9 +675,9 @@ hipError_t launch_rows_keys(const RowsArgs& a, uint64_t n_chunks, uint64_t n_des
 }
 
 __global__ void code_object_loader_d() {}
-hipError_t preload_build_rows()
+hipError_t preload_build_rows(hipStream_t stream)
 {
-    hipLaunchKernelGGL(code_object_loader_d, dim3(1), dim3(64), 0, nullptr);
+    hipLaunchKernelGGL(code_object_loader_d, dim3(1), dim3(64), 0, stream);
     return hipGetLastError();
 }
 

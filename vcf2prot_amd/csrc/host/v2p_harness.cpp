@@ -108,7 +108,7 @@ static int run(const char* preset, uint64_t n_haps, int threads, bool shared, bo
     };
     auto consume = [&](uint64_t h, std::u32string res, Annotation) {
         uint64_t s = 0;
-        for (size_t i = 0; i < res.size(); ++i) s += (uint64_t(res[i] & 0xFFu) + 1ull) * mix64(i);
+        for (size_t i = 0; i < res.size(); ++i) s += ((uint64_t(res[i] & 0xFFu) + 1ull) << (8 * (i & 7))) * mix64(i >> 3);   // vcf2prot_hip.h: v2p_batch_digests
         digest[h] = s;
     };
     // the GIRs are built first (steps 4-5 are not the engine's), then every GIR::execute(Engine::GPU) is timed: wall clock of the

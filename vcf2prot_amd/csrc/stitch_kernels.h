@@ -78,10 +78,10 @@ hipError_t launch_ordered(const OrderedArgs& a, hipStream_t stream);
 hipError_t launch_validate(const ValidateArgs& a, hipStream_t stream);
 hipError_t launch_digest(const DigestArgs& a, uint64_t out_bytes, hipStream_t stream);
 // the translation units' code objects loaded now instead of at their first launch (v2p_init)
-hipError_t preload_stitch_kernels();
-hipError_t preload_stitch_wave();
-hipError_t preload_build_kernels();
-hipError_t preload_build_rows();
+hipError_t preload_stitch_kernels(hipStream_t stream);
+hipError_t preload_stitch_wave(hipStream_t stream);
+hipError_t preload_build_kernels(hipStream_t stream);
+hipError_t preload_build_rows(hipStream_t stream);
 }  // namespace v2p
 
 namespace v2p {

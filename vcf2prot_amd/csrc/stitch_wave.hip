@@ -443,9 +443,9 @@ hipError_t launch_stitch_wave(const StitchArgs& a, hipStream_t stream, bool nt, 
 }
 
 __global__ void code_object_loader_b() {}
-hipError_t preload_stitch_wave()
+hipError_t preload_stitch_wave(hipStream_t stream)
 {
-    hipLaunchKernelGGL(code_object_loader_b, dim3(1), dim3(64), 0, nullptr);
+    hipLaunchKernelGGL(code_object_loader_b, dim3(1), dim3(64), 0, stream);
     return hipGetLastError();
 }
 

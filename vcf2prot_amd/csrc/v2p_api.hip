@@ -47,6 +47,15 @@ struct DevBuf {
         if (e == hipSuccess) cap = want;
         return e;
     }
+    // scratch that lives for one call: exactly n bytes (ensure()'s 25 % slack is for buffers that grow from call to call)
+    hipError_t ensure_exact(size_t n) {
+        const size_t need = n + FRONT + PAD_BYTES;
+        if (need <= cap) return hipSuccess;
+        if (base) { (void)hipFree(base); base = nullptr; cap = 0; }
+        const hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), need);
+        if (e == hipSuccess) cap = need;
+        return e;
+    }
     uint8_t* ptr() const { return base ? base + FRONT : nullptr; }
     void release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; }
 };
@@ -202,9 +211,27 @@ int v2p_init(int device_ordinal, unsigned flags, v2p_ctx** out)
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_init_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return V2P_ERR_HIP; }
     c->stream = c->own_stream;
-    // (the kernels' code objects now, not under the first batch's clock; a failure here would only surface again at the first launch)
-    (void)preload_stitch_kernels(); (void)preload_stitch_wave(); (void)preload_build_kernels(); (void)preload_build_rows();
-    (void)hipDeviceSynchronize();
+    // The kernels' code objects now, not under the first batch's clock -- once per process and device, on the context's own stream
+    // (a device-wide wait here would stall the batches other contexts have in flight on this GPU).
+    {
+        static std::mutex mu;
+        static bool loaded[64] = {};
+        std::lock_guard<std::mutex> lk(mu);
+        if (device_ordinal < 64 && !loaded[device_ordinal]) {
+            hipError_t le = preload_stitch_kernels(c->own_stream);
+            if (le == hipSuccess) le = preload_stitch_wave(c->own_stream);
+            if (le == hipSuccess) le = preload_build_kernels(c->own_stream);
+            if (le == hipSuccess) le = preload_build_rows(c->own_stream);
+            if (le == hipSuccess) le = hipStreamSynchronize(c->own_stream);
+            if (le != hipSuccess) {
+                g_init_error = std::string("loading the kernels' code objects: ") + hipGetErrorString(le);
+                (void)hipStreamDestroy(c->own_stream);
+                delete c;
+                return V2P_ERR_HIP;
+            }
+            loaded[device_ordinal] = true;
+        }
+    }
     *out = c;
     return V2P_OK;
 }
@@ -1230,7 +1257,7 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
     // scratch of the parse and the count pass of the cutter: row map, chunks per segment + their scan
     const uint64_t c_cover = 0, c_segc = up8((n_rows + 1) * 8), c_segb = c_segc + up8((n_segs + 1) * 4), c_tiles = c_segb + up8((n_segs + 2) * 8),
                    c_cpad = c_tiles + up8(scan_tiles_for(n_segs + 1) * 8), c_end = c_cpad + up8(n_segs * ROWS_CHUNK_PAD * sizeof(Chunk));
-    HIP_TRY(c, guard.cover.ensure(c_end), "hipMalloc(row map)");
+    HIP_TRY(c, guard.cover.ensure_exact(c_end), "hipMalloc(row map)");
     a.cover = reinterpret_cast<uint64_t*>(guard.cover.ptr() + c_cover);
     a.seg_count = reinterpret_cast<uint32_t*>(guard.cover.ptr() + c_segc);
     a.seg_base = reinterpret_cast<const uint64_t*>(guard.cover.ptr() + c_segb);
@@ -1246,8 +1273,12 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
     for (int attempt = 0; ; ++attempt) {
         HIP_TRY(c, hipEventRecord(guard.ev[2], c->stream), "hipEventRecord");
         if (!two_pass) {
-            HIP_TRY(c, guard.pad.ensure(n_tiles * ROWS_PAD_SLOTS * 8), "hipMalloc(padded descriptors)");
-            a.desc_pad = reinterpret_cast<uint64_t*>(guard.pad.ptr());
+            // (2 KiB per tile -- C3 whole: 3.2 GB next to a 36 GB arena; when the device cannot spare it the two-pass form, which
+            // needs no padded array, builds the same image)
+            const hipError_t pe = guard.pad.ensure_exact(n_tiles * ROWS_PAD_SLOTS * 8);
+            if (pe == hipErrorOutOfMemory) { (void)hipGetLastError(); two_pass = true; }
+            else if (pe != hipSuccess) return c->hip_fail(pe, "hipMalloc(padded descriptors)");
+            else a.desc_pad = reinterpret_cast<uint64_t*>(guard.pad.ptr());
         }
         HIP_TRY(c, launch_rows_parse(a, mode, fasta, two_pass ? 1 : 0, c->stream), "launch(parse)");
         HIP_TRY(c, launch_scan_u32(a.tile_count, n_tiles, a.tile_desc_base, scan_scratch + rows_scan_scratch_entries(n_tiles), c->stream), "launch(scan)");
@@ -1308,7 +1339,7 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
                    s_subhist = s_bucket2 + up8(cap), s_substart = s_subhist + up8(n_sub_cap * 4), s_subtiles = s_substart + up8((n_sub_cap + 1) * 8),
                    s_tot = s_subtiles + up8(scan_tiles_for(n_sub_cap) * 8), s_end = s_tot + up8(uint64_t(XCD_ORDER_MAX_BLOCKS) * 8 * 4);
     DevBuf& scratch = guard.scratch;
-    HIP_TRY(c, scratch.ensure(s_end), "hipMalloc(build scratch)");
+    HIP_TRY(c, scratch.ensure_exact(s_end), "hipMalloc(build scratch)");
     HIP_TRY(c, b->d_chunks.ensure(cap * sizeof(Chunk)), "hipMalloc(chunks)");
     HIP_TRY(c, b->d_out.ensure((out_bytes + 15) & ~15ull), "hipMalloc(out)");
     HIP_TRY(c, b->d_digest.ensure((n_h ? n_h : 1) * 8), "hipMalloc(digest)");
