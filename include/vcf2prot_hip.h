@@ -253,6 +253,43 @@ typedef struct {
  * *build_ms (optional): time of the build kernels alone (two HIP event brackets: counting passes, emitting passes; not the
  * allocation of the image in between), the stream already on the device. */
 int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t window_bytes, int kernel, float* build_ms);
+/* ---- Task vectors -> result bytes ONCE, in one call (round 5) ------------------------------------------------------------------
+ * What a cohort pays exactly once is the reference's get_g_rep(..).execute(engine) (haplotype_instruction.rs:75-137 -> gir.rs:197-241,
+ * personalized_genome.rs:64-65): build a haplotype's executable image, execute it.  v2p_batch_build_on_device + v2p_batch_execute do
+ * that in two calls, the stream's H2D inside the first and the two strictly one after the other.  Here the stream is made RESIDENT
+ * first (its tables are checked on the host as for v2p_batch_build_on_device, its arrays uploaded once), and ONE call builds the
+ * rows image slice by slice on a second HIP stream while the slice before it is already being stitched on the context's stream:
+ * the builder's parse is bound by instruction issue, the stitch kernel by its stores. */
+typedef struct v2p_stream v2p_stream;
+/* the stream's arrays to the device (the host copy may be freed on return); V2P_ERR_INVALID_ARG / _SRC_OOB with the offending index
+ * as v2p_batch_build_on_device reports them */
+int  v2p_stream_upload(v2p_ctx* ctx, const v2p_txstream* s, v2p_stream** out);
+/* waits for the device; a batch built from the stream must not execute afterwards (its payload descriptors read the stream's alt bytes) */
+void v2p_stream_destroy(v2p_stream* s);
+int  v2p_stream_counts(const v2p_stream* s, uint64_t* n_haps, uint64_t* n_tx, uint64_t* n_tasks, uint64_t* out_bytes);
+/* the one-piece builder (kernel 6 / 7; 0: by the routing rule, a dense image when a wave image is refused) on a resident stream: no H2D */
+int  v2p_batch_build_from_stream(v2p_batch* b, const v2p_stream* s, int kernel, float* build_ms);
+/* Build AND execute.  kernel: 0 (routing rule), 6 or 7.  n_slices: 0 = about 3 GiB of result per slice (at most 12), else that many
+ * (<= 32).  Returns when the last slice's stitch kernels are enqueued on the context's stream (like v2p_batch_execute: asynchronous);
+ * v2p_batch_sync collects the status.  The batch is finalized: execute / digests / download work as after any build, and the image --
+ * descriptors, chunk records, haplotype offsets -- is the one v2p_batch_build_from_stream builds (only the blocks inside which the
+ * chunk table is dealt to the XCDs are per slice).  Streams the sliced builder does not take (a tile of transcripts with more than 256
+ * descriptors, a 1 KiB row with more descriptors than a chunk holds, more than 2^25 tiles) are built in one piece and executed, in
+ * the same call.  What the reference would panic on (update_task, Task::execute) is reported as by v2p_batch_build_on_device; slices
+ * before the offending one may already have been written to the arena. */
+int  v2p_batch_build_and_execute(v2p_batch* b, const v2p_stream* s, int kernel, uint32_t n_slices);
+typedef struct {
+    int32_t  kernel;             /* 6 / 7: the rows image that was built                                                            */
+    uint32_t n_slices;           /* 0: the call fell back to the one-piece builder + one execute                                    */
+    float    total_ms;           /* HIP events on the context's stream: before the first build kernel -> behind the last stitch kernel */
+    float    build_ms;           /* sum of the slices' build kernels (they overlap the stitch of the slices before: not additive)   */
+    double   call_wall_ms;       /* host wall-clock of the call (it returns when the last slice is enqueued)                        */
+    float    slice_build_ms[32];
+} v2p_oneshot_info;
+/* waits for the call's last kernel, then reports its times */
+int  v2p_batch_oneshot_info(v2p_batch* b, v2p_oneshot_info* info);
+/* a finalized batch back to empty, its device buffers kept: the next build recycles arena, descriptor array and scratch */
+int  v2p_batch_reset(v2p_batch* b);
 /* the image as it sits on the device (for checkers): sizes first (any pointer may be NULL), then the arrays */
 int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, uint64_t* hap_out_begin);
 

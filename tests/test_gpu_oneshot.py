@@ -1,0 +1,215 @@
+"""Task vectors -> result bytes in ONE call (round 5): a transcript stream made resident on the device (v2p_stream_upload), then
+v2p_batch_build_and_execute -- the rows image built slice by slice on a second HIP stream while the slice before it is stitched.
+What the reference does once per haplotype (get_g_rep(..).execute(engine): haplotype_instruction.rs:75-137 -> gir.rs:197-241,
+personalized_genome.rs:64-65).  The image must be the one-piece builder's -- descriptors byte for byte, the same chunk records, the same
+haplotype offsets -- and the arena the oracle's tapes, for every slicing."""
+import numpy as np
+import pytest
+
+from stream_util import random_stream
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_hap(c, coracle, h):
+    hap = c.haplotype(h)
+    t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+    return coracle.gir_execute_u8(t, c.ref_tape_u32(h).astype(np.uint8), hap.alt, np.full(hap.n_res, ord("."), dtype=np.uint8))
+
+
+def _sorted_chunks(chunks):
+    return chunks[np.lexsort((chunks[:, 0], chunks[:, 1] & np.uint64((1 << 48) - 1)))]
+
+
+def _one_piece(ctx, rs, kernel):
+    m = ctx.batch()
+    ms = m.build_from_stream(rs, kernel)
+    assert ms > 0
+    img = m.download_image()
+    m.execute()
+    m.sync()
+    dig = m.digests()
+    m.close()
+    return img, dig
+
+
+@pytest.mark.parametrize("preset,h0,n,kernel,slices", [
+    ("C1", 0, 8, 0, 0), ("C2", 3, 60, 6, 3), ("C3", 100, 400, 0, 5), ("C3", 0, 900, 6, 2), ("C4", 7, 12, 0, 4),
+    ("C5", 50, 1500, 0, 3), ("C5", 11, 900, 7, 7), ("C3", 100, 300, 7, 2), ("C2", 0, 40, 0, 1)])
+def test_sliced_build_and_execute_equals_the_one_piece_builder_and_the_oracle(built, gpu_ctx, coracle, preset, h0, n, kernel, slices):
+    from vcf2prot_amd.cohort import Cohort
+    c = Cohort.preset(preset)
+    gpu_ctx.upload_proteome(c.proteome())
+    stream = c.txstream(h0, h0 + n, n_threads=4)
+    rs = gpu_ctx.upload_stream(stream)
+    stream.close()                                          # (resident: the host copy may go)
+    sizes = c.result_sizes(h0, h0 + n)
+    assert rs.counts()["out_bytes"] == int(sizes.sum()) and rs.counts()["n_haps"] == n
+    (desc1, chunks1, hb1), dig1 = _one_piece(gpu_ctx, rs, kernel)
+    b = gpu_ctx.batch()
+    b.build_and_execute(rs, kernel, slices)
+    b.sync()
+    info = b.oneshot_info()
+    assert info["kernel"] in (6, 7) and info["total_ms"] > 0
+    if slices > 1:
+        assert 1 <= info["n_slices"] <= slices
+    desc, chunks, hb = b.download_image()
+    assert np.array_equal(hb, hb1) and np.array_equal(np.diff(hb.astype(np.int64)), sizes.astype(np.int64))
+    assert desc.size == desc1.size and np.array_equal(desc, desc1)
+    assert chunks.shape == chunks1.shape and np.array_equal(_sorted_chunks(chunks), _sorted_chunks(chunks1))
+    assert np.array_equal(b.digests(), dig1)
+    for i in range(0, n, max(1, n // 30)):
+        assert np.array_equal(b.download_hap(i), oracle_hap(c, coracle, h0 + i)), (preset, h0 + i)
+    # the batch is an ordinary finalized batch: executing it again changes nothing
+    b.execute()
+    b.sync()
+    assert np.array_equal(b.digests(), dig1)
+    # ... and a reset batch recycles its buffers for the next call, sliced differently
+    b.reset()
+    b.build_and_execute(rs, kernel, max(1, slices - 1) if slices else 2)
+    b.sync()
+    assert np.array_equal(b.digests(), dig1)
+    assert np.array_equal(b.download_image()[0], desc1)
+    b.close()
+    rs.close()
+
+
+@pytest.mark.parametrize("seed,shape,kernel", [(1, "snv", 7), (3, "snv", 0), (5, "mix", 6), (6, "mix", 7), (10, "long", 0), (12, "long", 6)])
+def test_random_streams_in_one_call(built, gpu_ctx, seed, shape, kernel):
+    """Irregular streams (empty haplotypes, transcripts without Tasks, gaps, long payloads): whatever path the call takes -- sliced,
+    or the one-piece builder's two-pass form / a dense image where the sliced builder declines -- the arena is the expected text."""
+    from vcf2prot_amd._native import V2PError
+    rng = np.random.default_rng(seed)
+    proteome, stream, want = random_stream(rng, n_haps=400, n_ref_tx=25, shape=shape, window=4096)
+    gpu_ctx.upload_proteome(proteome)
+    rs = gpu_ctx.upload_stream(stream)
+    b = gpu_ctx.batch()
+    try:
+        b.build_and_execute(rs, kernel, 3)
+    except V2PError as e:
+        assert kernel == 6 and e.code == -9                 # a row with more than 64 descriptors: kernel 6 was asked for by number
+        b.reset()
+        b.build_and_execute(rs, 7, 3)
+    b.sync()
+    for h, w in enumerate(want):
+        got = b.download_hap(h)
+        assert got.size == w.size and np.array_equal(got, w), (seed, shape, kernel, h)
+    b.close()
+    rs.close()
+
+
+def test_a_tile_that_overflows_its_slots_falls_back_inside_the_call(built, gpu_ctx):
+    """One transcript with thousands of Tasks: its tile's descriptors do not fit the one-pass stage, the sliced builder declines and the
+    call builds in one piece (two-pass form) and executes -- same bytes, n_slices reported as 0."""
+    from stream_util import Stream
+    rng = np.random.default_rng(5)
+    AA = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    L = 300000
+    prot = AA[rng.integers(0, 20, size=L)]
+    gpu_ctx.upload_proteome(prot)
+    code, sp, ln, sr, alt = [], [], [], [], []
+    pos = 0
+    for k in range(3000):
+        code += [0, 1]; sp += [pos, k]; ln += [59, 1]; sr += [pos, pos + 59]
+        alt.append(int(AA[k % 20])); pos += 60
+    code.append(0); sp.append(pos); ln.append(L - pos); sr.append(pos)
+    n0 = len(code)
+    code.append(0); sp.append(0); ln.append(L); sr.append(0)
+    s = Stream([0, 2], [0, 0], [L, L], [L, L], [0, n0, n0 + 1], [0, len(alt), len(alt)], code, sp, ln, sr, np.array(alt, dtype=np.uint8))
+    want = prot.copy()
+    for k in range(3000):
+        want[60 * k + 59] = AA[k % 20]
+    rs = gpu_ctx.upload_stream(s)
+    for kernel in (6, 7, 0):
+        b = gpu_ctx.batch()
+        b.build_and_execute(rs, kernel, 2)
+        b.sync()
+        assert b.oneshot_info()["n_slices"] == 0
+        got = b.download_hap(0)
+        assert np.array_equal(got[:L], want) and np.array_equal(got[L:], prot)
+        b.close()
+    rs.close()
+
+
+def test_one_call_reports_what_the_reference_would_panic_on(built, gpu_ctx):
+    """update_task (haplotype_instruction.rs:154) / Task::execute's slices (task.rs:43,47) in a LATER slice: the first offending task by
+    index, and the batch is reusable after a reset."""
+    from stream_util import Stream
+    from vcf2prot_amd._native import V2PError
+    prot = np.frombuffer(b"MEDLGENTMVLSTLRSLNNFISQRVEGGSGLEELERGGAKLMNPQRSTVWYACDEFGHIK", dtype=np.uint8)
+    gpu_ctx.upload_proteome(prot)
+    n_tx = 64 * 64 * 4                                      # enough tiles for several slices
+
+    def stream(bad_tx, bad):
+        code = np.tile(np.array([0, 1, 0], dtype=np.uint8), n_tx)
+        sp = np.tile(np.array([0, 0, 11], dtype=np.uint32), n_tx)
+        ln = np.tile(np.array([10, 1, 49], dtype=np.uint32), n_tx)
+        sr = np.tile(np.array([0, 10, 11], dtype=np.uint32), n_tx)
+        if bad == "code":
+            code[3 * bad_tx + 1] = 2
+        elif bad == "res":
+            ln[3 * bad_tx + 2] = 50
+        elif bad == "src":
+            sp[3 * bad_tx + 2] = 30; ln[3 * bad_tx + 2] = 40; sr[3 * bad_tx + 2] = 11
+        elif bad == "order":
+            sr[3 * bad_tx + 1] = 9
+        return Stream([0, n_tx // 2, n_tx], [0] * n_tx, [60] * n_tx, [60] * n_tx, np.arange(0, 3 * n_tx + 1, 3), np.arange(0, 2 * n_tx + 1, 2),
+                      code, sp, ln, sr, np.tile(np.frombuffer(b"AC", dtype=np.uint8), n_tx))
+    good = gpu_ctx.upload_stream(stream(0, None))
+    for bad, want_code, row in (("code", -3, 1), ("res", -4, 2), ("src", -5, 2), ("order", -6, 1)):
+        bad_tx = n_tx - 700                                 # in the last slice
+        rs = gpu_ctx.upload_stream(stream(bad_tx, bad))
+        b = gpu_ctx.batch()
+        with pytest.raises(V2PError) as ei:
+            b.build_and_execute(rs, 6, 4)
+            b.sync()
+        assert ei.value.code == want_code and ei.value.index == 3 * bad_tx + row, (bad, ei.value.code, ei.value.index)
+        b.reset()
+        b.build_and_execute(good, 6, 4)
+        b.sync()
+        one = bytes(prot[:10]) + b"A" + bytes(prot[11:])
+        assert b.download_hap(1).tobytes() == one * (n_tx // 2)
+        b.close()
+        rs.close()
+    good.close()
+
+
+@pytest.mark.parametrize("kernel", [0, 6, 7])
+@pytest.mark.parametrize("fasta", [False, True])
+def test_reference_task_dumps_in_one_call(gpu_ctx, golden, kernel, fasta):
+    """The 36 transcript GIRs harvested from the reference binary (its own Vec<Task> dumps), repeated over 600 haplotypes so that the
+    sliced builder has slices to cut; with FASTA emit the arena is the file text of personalized_genome.rs:90-113."""
+    from test_gpu_device_build_fasta import _stream_of_cases
+    from vcf2prot_amd._native import V2PError
+    cases = golden["cases"]
+    refs, off = {}, 0
+    for c in cases:
+        if c["ref"] not in refs:
+            refs[c["ref"]] = off
+            off += len(c["ref"])
+    proteome = np.frombuffer("".join(refs).encode(), dtype=np.uint8)
+    headers = "\n" + "".join(f">{c['name']}_1\n" for c in cases)
+    hdr_off, o = [], 1
+    for c in cases:
+        hdr_off.append(o)
+        o += len(c["name"]) + 4
+    gpu_ctx.upload_reference(proteome, np.frombuffer(headers.encode(), dtype=np.uint8))
+    per_hap, reps = 7, 100
+    stream = _stream_of_cases(cases * reps, refs, hdr_off * reps, fasta, per_hap)
+    rs = gpu_ctx.upload_stream(stream)
+    b = gpu_ctx.batch()
+    try:
+        b.build_and_execute(rs, kernel, 4)
+    except V2PError as e:
+        assert kernel == 6 and e.code == -9
+        b.reset()
+        b.build_and_execute(rs, 7, 4)
+    b.sync()
+    many = cases * reps
+    for h in range(0, (len(many) + per_hap - 1) // per_hap, 17):
+        mine = many[h * per_hap:(h + 1) * per_hap]
+        text = b.download_hap(h).tobytes().decode()
+        want = "".join(f">{c['name']}_1\n{c['expected']}\n" for c in mine) if fasta else "".join(c["expected"] for c in mine)
+        assert text == want, (kernel, fasta, h)
+    b.close()
+    rs.close()

@@ -64,6 +64,13 @@ HIP_API = {
                                         c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_uint64]),
     "v2p_batch_build_on_device": (c_int, [c_void_p, c_void_p, c_uint32, c_int, POINTER(ctypes.c_float)]),
     "v2p_batch_download_image": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "v2p_stream_upload": (c_int, [c_void_p, c_void_p, POINTER(c_void_p)]),
+    "v2p_stream_destroy": (None, [c_void_p]),
+    "v2p_stream_counts": (c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
+    "v2p_batch_build_from_stream": (c_int, [c_void_p, c_void_p, c_int, POINTER(ctypes.c_float)]),
+    "v2p_batch_build_and_execute": (c_int, [c_void_p, c_void_p, c_int, c_uint32]),
+    "v2p_batch_oneshot_info": (c_int, [c_void_p, c_void_p]),
+    "v2p_batch_reset": (c_int, [c_void_p]),
     "v2p_batch_set_packed": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_uint64,
                                      c_void_p, c_uint64]),
     "v2p_batch_finalize": (c_int, [c_void_p]),
@@ -92,6 +99,12 @@ HIP_API = {
 
 _hip = None
 _cohort = None
+
+
+class OneShotInfo(ctypes.Structure):
+    """v2p_oneshot_info (include/vcf2prot_hip.h)"""
+    _fields_ = [("kernel", ctypes.c_int32), ("n_slices", ctypes.c_uint32), ("total_ms", ctypes.c_float), ("build_ms", ctypes.c_float),
+                ("call_wall_ms", ctypes.c_double), ("slice_build_ms", ctypes.c_float * 32)]
 
 
 class Routing(ctypes.Structure):

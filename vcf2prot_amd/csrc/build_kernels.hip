@@ -69,7 +69,7 @@ __global__ __launch_bounds__(1024) void scan_tiles(uint64_t* __restrict__ tile_s
 }
 
 __global__ __launch_bounds__(256) void scan_apply(const uint32_t* __restrict__ in, uint64_t n, const uint64_t* __restrict__ tile_sum,
-                                                  uint64_t* __restrict__ out)
+                                                  uint64_t* __restrict__ out, uint64_t first)
 {
     __shared__ uint64_t s[4];
     const uint64_t base = uint64_t(blockIdx.x) * SCAN_TILE;
@@ -81,21 +81,28 @@ __global__ __launch_bounds__(256) void scan_apply(const uint32_t* __restrict__ i
     for (int o = 1; o < 64; o <<= 1) { const uint64_t y = __shfl_up(incl, o); if ((threadIdx.x & 63u) >= uint32_t(o)) incl += y; }
     if ((threadIdx.x & 63u) == 63u) s[threadIdx.x >> 6] = incl;
     __syncthreads();
-    uint64_t before = tile_sum[blockIdx.x];
+    uint64_t before = first + tile_sum[blockIdx.x];
     for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += s[w];
     uint64_t run = before + incl - v;
     for (uint32_t k = 0; k < 4; ++k) { const uint64_t i = base + threadIdx.x * 4u + k; if (i < n) out[i] = run; run += x[k]; }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = tile_sum[gridDim.x];      // the total, one past the end
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = first + tile_sum[gridDim.x];      // the total, one past the end
 }
 
-hipError_t launch_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* tile_scratch, hipStream_t stream)
+// out[i] = first + in[0] + .. + in[i - 1] for i = 0 .. n (`first`: the running total of the slices before this one, when a table is
+// scanned slice by slice -- v2p_batch_build_and_execute)
+hipError_t launch_scan_u32_from(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* tile_scratch, uint64_t first, hipStream_t stream)
 {
     const uint64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-    if (n == 0) return hipMemsetAsync(out, 0, 8, stream);
+    if (n == 0) return hipMemcpyAsync(out, &first, 8, hipMemcpyHostToDevice, stream);
     hipLaunchKernelGGL(scan_tile_sums, dim3(uint32_t(n_tiles)), dim3(256), 0, stream, in, n, tile_scratch);
     hipLaunchKernelGGL(scan_tiles, dim3(1), dim3(1024), 0, stream, tile_scratch, n_tiles);
-    hipLaunchKernelGGL(scan_apply, dim3(uint32_t(n_tiles)), dim3(256), 0, stream, in, n, tile_scratch, out);
+    hipLaunchKernelGGL(scan_apply, dim3(uint32_t(n_tiles)), dim3(256), 0, stream, in, n, tile_scratch, out, first);
     return hipGetLastError();
+}
+hipError_t launch_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* tile_scratch, hipStream_t stream)
+{
+    if (n == 0) return hipMemsetAsync(out, 0, 8, stream);
+    return launch_scan_u32_from(in, n, out, tile_scratch, 0, stream);
 }
 
 // ---- the walk over one transcript's tasks: EMIT = false counts descriptors, true writes them -------------------------------

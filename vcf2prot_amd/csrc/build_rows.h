@@ -34,6 +34,10 @@ struct RowsArgs {
     // tiles: K consecutive transcripts each, 1 <= K <= 64
     uint32_t K;
     uint64_t n_tiles;
+    // the range of tiles / cutter segments one launch works on (v2p_batch_build_and_execute builds an image slice by slice while the
+    // slice before it executes; the one-call builder: everything).  Tile and segment numbers stay global; desc_pad holds the RANGE's tiles.
+    uint64_t tile0 = 0, tile1 = 0;      // parse, compact: tiles [tile0, tile1)  (0, 0: all)
+    uint64_t seg0 = 0, seg1 = 0;        // cut, chunk compact: segments [seg0, seg1)  (0, 0: all)
     uint64_t* tile_bytes;               // [n_tiles] arena bytes of each tile -> (scan) tile_res_base
     uint64_t* tile_res_base;            // [n_tiles + 1]
     uint32_t* tile_count;               // [n_tiles] descriptors of each tile -> (scan) tile_desc_base
@@ -57,6 +61,11 @@ struct RowsArgs {
     unsigned long long* status;
 };
 
+inline void rows_ranges(const RowsArgs& a, uint64_t& t0, uint64_t& t1, uint64_t& s0, uint64_t& s1)
+{
+    t0 = a.tile0; t1 = a.tile1 ? a.tile1 : a.n_tiles;
+    s0 = a.seg0; s1 = a.seg1 ? a.seg1 : a.n_segs;
+}
 // arena bytes per tile (+ u64 exclusive scan into tile_res_base, total behind the last tile)
 hipError_t launch_rows_tile_bytes(const RowsArgs& a, uint64_t* scan_scratch, hipStream_t stream);
 uint64_t rows_scan_scratch_entries(uint64_t n);

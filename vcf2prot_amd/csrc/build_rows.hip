@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
     constexpr int RG = FASTA ? 1 : 0, RS = RG + 1, RT = RG + 2;       // run numbers: [0 header] RG gap, RS the task itself, RT tail [4 line feed]
     __shared__ WaveLds L;
     const uint32_t lane = threadIdx.x;
-    const uint64_t tile = blockIdx.x;
+    const uint64_t tile = a.tile0 + blockIdx.x;                       // (a launch works on tiles [tile0, tile1): the whole stream, or one slice of it)
     const uint64_t t0 = tile * a.K;
     const uint32_t nh = uint32_t(a.n_tx - t0 < a.K ? a.n_tx - t0 : a.K);
     const uint64_t task_lo = a.tx_task_begin[t0], task_end = a.tx_task_begin[t0 + nh];
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
     }
     asm volatile("" ::: "memory");
     const uint32_t n_items = n_tile_tasks + uint32_t(__popcll(ne));                      // >= nh >= 1
-    uint64_t* const out = PHASE == PH_PAD ? a.desc_pad + tile * ROWS_PAD : (PHASE == PH_DIRECT ? a.desc + a.tile_desc_base[tile] : nullptr);
+    uint64_t* const out = PHASE == PH_PAD ? a.desc_pad + uint64_t(blockIdx.x) * ROWS_PAD : (PHASE == PH_DIRECT ? a.desc + a.tile_desc_base[tile] : nullptr);
     (void)out;
     const uint32_t out_cap = PHASE == PH_PAD ? ROWS_PAD : 0xFFFFFFFFu;
     // cover entry: tile : 25 | descriptor inside the tile : 16 | offset inside it : 22 -- the two-pass form: 1 << 63 | descriptor << 22 | offset
@@ -480,12 +480,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
 // descriptors out of the padded array into their final, dense place (tile_desc_base: the scan of the tiles' counts): one wave per tile
 __global__ __launch_bounds__(256) void rows_compact_kernel(RowsArgs a)
 {
-    const uint64_t tile = uint64_t(blockIdx.x) * 4u + (threadIdx.x >> 6);
-    if (tile >= a.n_tiles) return;
+    const uint64_t rel = uint64_t(blockIdx.x) * 4u + (threadIdx.x >> 6), tile = a.tile0 + rel;
+    if (tile >= a.tile1) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t b0 = a.tile_desc_base[tile], n = a.tile_desc_base[tile + 1u] - b0;
     if (n > ROWS_PAD || b0 + n > a.desc_cap) return;                  // (reported by the parse / by the host)
-    const uint64_t* src = a.desc_pad + tile * ROWS_PAD;
+    const uint64_t* src = a.desc_pad + rel * ROWS_PAD;
     for (uint32_t k = lane; k < n; k += 64u) a.desc[b0 + k] = src[k];
 }
 
@@ -511,11 +511,11 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
     constexpr bool EMIT = PASS != 0;
     const uint32_t lane = threadIdx.x;
     const uint64_t n_desc = a.tile_desc_base[a.n_tiles];
+    const uint64_t seg = a.seg0 + blockIdx.x;
     if (*a.status != STATUS_CLEAN) {                                                      // the parse failed (or asks for its two-phase form): the row map is not to be walked
-        if (PASS != 1 && lane == 0) a.seg_count[blockIdx.x] = 0u;
+        if (PASS != 1 && lane == 0) a.seg_count[seg] = 0u;
         return;
     }
-    const uint64_t seg = blockIdx.x;
     const uint64_t s0 = seg * ROWS_SEG, s1 = s0 + ROWS_SEG < a.n_rows ? s0 + ROWS_SEG : a.n_rows;
     uint32_t count = 0;
     uint64_t out_k = PASS == 1 ? a.seg_base[seg] : (PASS == 2 ? seg * ROWS_CHUNK_PAD : 0);
@@ -568,8 +568,8 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
 // the padded chunk table of pass 2 -> arena order (seg_base: the scan of the segments' counts): one wave per segment
 __global__ __launch_bounds__(256) void rows_chunk_compact_kernel(RowsArgs a)
 {
-    const uint64_t seg = uint64_t(blockIdx.x) * 4u + (threadIdx.x >> 6);
-    if (seg >= a.n_segs) return;
+    const uint64_t seg = a.seg0 + uint64_t(blockIdx.x) * 4u + (threadIdx.x >> 6);
+    if (seg >= a.seg1) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t b0 = a.seg_base[seg], n = a.seg_base[seg + 1u] - b0;
     for (uint32_t k = lane; k < n && k < ROWS_CHUNK_PAD; k += 64u) a.chunks_tmp[b0 + k] = a.chunks_pad[seg * ROWS_CHUNK_PAD + k];
@@ -621,25 +621,35 @@ static_assert(ROWS_PAD == ROWS_PAD_SLOTS, "build_rows.h");
 template <int MODE, bool FASTA>
 static hipError_t launch_parse_t(const RowsArgs& a, int phase, hipStream_t stream)
 {
-    const dim3 grid{uint32_t(a.n_tiles)};
+    const dim3 grid{uint32_t(a.tile1 - a.tile0)};
     if (phase == PH_PAD) hipLaunchKernelGGL((rows_parse_kernel<MODE, FASTA, PH_PAD>), grid, dim3(64), 0, stream, a);
     else if (phase == PH_COUNT) hipLaunchKernelGGL((rows_parse_kernel<MODE, FASTA, PH_COUNT>), grid, dim3(64), 0, stream, a);
     else hipLaunchKernelGGL((rows_parse_kernel<MODE, FASTA, PH_DIRECT>), grid, dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_rows_parse(const RowsArgs& a, int mode, bool fasta, int phase, hipStream_t stream)
+// (the launchers resolve the range: tile1 / seg1 == 0 mean "to the end")
+static RowsArgs ranged(const RowsArgs& a0)
 {
-    if (a.n_tiles == 0) return hipSuccess;
-    if (a.n_tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    RowsArgs a = a0;
+    rows_ranges(a0, a.tile0, a.tile1, a.seg0, a.seg1);
+    return a;
+}
+
+hipError_t launch_rows_parse(const RowsArgs& a0, int mode, bool fasta, int phase, hipStream_t stream)
+{
+    const RowsArgs a = ranged(a0);
+    if (a.tile1 <= a.tile0) return hipSuccess;
+    if (a.tile1 - a.tile0 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (mode == ROWS_DENSE) return fasta ? launch_parse_t<ROWS_DENSE, true>(a, phase, stream) : launch_parse_t<ROWS_DENSE, false>(a, phase, stream);
     return fasta ? launch_parse_t<ROWS_WAVE, true>(a, phase, stream) : launch_parse_t<ROWS_WAVE, false>(a, phase, stream);
 }
 
-hipError_t launch_rows_compact(const RowsArgs& a, hipStream_t stream)
+hipError_t launch_rows_compact(const RowsArgs& a0, hipStream_t stream)
 {
-    if (a.n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(rows_compact_kernel, dim3(uint32_t((a.n_tiles + 3) / 4)), dim3(256), 0, stream, a);
+    const RowsArgs a = ranged(a0);
+    if (a.tile1 <= a.tile0) return hipSuccess;
+    hipLaunchKernelGGL(rows_compact_kernel, dim3(uint32_t((a.tile1 - a.tile0 + 3) / 4)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -649,21 +659,24 @@ hipError_t launch_rows_hap_begin(const RowsArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_rows_cut(const RowsArgs& a, int mode, int pass, hipStream_t stream)
+hipError_t launch_rows_cut(const RowsArgs& a0, int mode, int pass, hipStream_t stream)
 {
-    if (a.n_segs == 0) return hipSuccess;
+    const RowsArgs a = ranged(a0);
+    if (a.seg1 <= a.seg0) return hipSuccess;
+    const uint32_t n_launch = uint32_t(a.seg1 - a.seg0);
     const uint32_t max_rows = mode == ROWS_DENSE ? ROWS_MAX_DENSE : ROWS_MAX_WAVE, max_desc = mode == ROWS_DENSE ? CHUNK_TASKS_DEEP : CHUNK_TASKS_WAVE;
     const uint64_t flag = mode == ROWS_DENSE ? CHUNK_DENSE : CHUNK_WAVE;
-    if (pass == 1) hipLaunchKernelGGL(rows_cut_kernel<1>, dim3(uint32_t(a.n_segs)), dim3(64), 0, stream, a, max_rows, max_desc, flag);
-    else if (pass == 2) hipLaunchKernelGGL(rows_cut_kernel<2>, dim3(uint32_t(a.n_segs)), dim3(64), 0, stream, a, max_rows, max_desc, flag);
-    else hipLaunchKernelGGL(rows_cut_kernel<0>, dim3(uint32_t(a.n_segs)), dim3(64), 0, stream, a, max_rows, max_desc, flag);
+    if (pass == 1) hipLaunchKernelGGL(rows_cut_kernel<1>, dim3(n_launch), dim3(64), 0, stream, a, max_rows, max_desc, flag);
+    else if (pass == 2) hipLaunchKernelGGL(rows_cut_kernel<2>, dim3(n_launch), dim3(64), 0, stream, a, max_rows, max_desc, flag);
+    else hipLaunchKernelGGL(rows_cut_kernel<0>, dim3(n_launch), dim3(64), 0, stream, a, max_rows, max_desc, flag);
     return hipGetLastError();
 }
 
-hipError_t launch_rows_chunk_compact(const RowsArgs& a, hipStream_t stream)
+hipError_t launch_rows_chunk_compact(const RowsArgs& a0, hipStream_t stream)
 {
-    if (a.n_segs == 0) return hipSuccess;
-    hipLaunchKernelGGL(rows_chunk_compact_kernel, dim3(uint32_t((a.n_segs + 3) / 4)), dim3(256), 0, stream, a);
+    const RowsArgs a = ranged(a0);
+    if (a.seg1 <= a.seg0) return hipSuccess;
+    hipLaunchKernelGGL(rows_chunk_compact_kernel, dim3(uint32_t((a.seg1 - a.seg0 + 3) / 4)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -39,6 +39,8 @@ struct StitchArgs {
     int32_t         opt_store_sc1 = -1;      // wave images: force (1) / forbid (0) "sc1 nt" row stores
     uint32_t        opt_touch = 0;           // bench builds: 1 = no read-ahead, 2 = the read-ahead as kernels of its own, 4 = one launch for all phases
     uint32_t        rows = 0;                // set by launch_stitch(): a rows image (sir_pack.hpp: every chunk carries CHUNK_CLIP) -- stitchw_kernel's ROWS instance
+    uint64_t        img_desc = 0, img_bytes = 0; // the chunk table is a RANGE of a larger image (v2p_batch_build_and_execute: one slice): descriptors and result
+                                             // bytes of the range, for the routing (0: n_desc, out_len)
     uint32_t        phase_chunks = 0;        // set by launch_stitch(): != 0 -- ONE wave launch for all phases of that many chunks, the read-ahead
                                              // workgroups of phase g + 1 placed in the grid before the stitch workgroups of phase g
 };

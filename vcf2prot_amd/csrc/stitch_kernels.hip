@@ -1116,8 +1116,7 @@ __global__ __launch_bounds__(256) void validate_kernel(ValidateArgs a)
 // ---------------------------------------------------------------------------
 // digest_kernel: digest[h] = sum_i (byte_i + 1) * 2^(8 * (i mod 8)) * splitmix64(i div 8), i relative to the haplotype start
 // (mod 2^64) -- word by word: sum_k splitmix64(k) * (little-endian word k + 0x01..01 over the bytes that exist).  The
-// definition is part of the C ABI contract (include/vcf2prot_hip.h: v2p_batch_digests; oracle/sir_oracle.c: sir_digest_u8)
-// so any checker can recompute it.  Round 5: until then one splitmix64 per BYTE and a 15-step binary search per 16-byte
+// definition is part of the C ABI contract (include/vcf2prot_hip.h: v2p_batch_digests) so any checker can recompute it.  Round 5: until then one splitmix64 per BYTE and a 15-step binary search per 16-byte
 // block -- 60.9 ms for the north star's 36 GB, eight times an execute.  Now a wave walks 64 KiB of the arena, knows the
 // haplotype it is in (one scalar search when it leaves it), and a lane's 16 bytes are the pieces of two or three words:
 // two or three multipliers, whichever way the haplotype's first byte sits against the arena's 16-byte blocks.
@@ -1278,7 +1277,8 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     // table the best was 20 MB: 8.85 ms; 10.3 with 32, 12.0 with 64); C4 whole 6.26 / 6.16 / 7.09 with 20 / 32 / 48; C2, whose image is
     // 1/45 of its result: 3.31 / 3.24 / 3.21 with 16 / 32 / 64 the other way.
     a.rows = (nontemporal & 8) != 0;                                             // (bit 3: a rows image, sir_pack.hpp: CHUNK_CLIP on every chunk)
-    const bool rich = image_is_rich(a.n_desc, a.out_len);                        // C2: 2.2 %, C4: 3.7 %, C3: 5 %
+    const uint64_t img_desc = a.img_desc ? a.img_desc : a.n_desc, img_bytes = a.img_bytes ? a.img_bytes : a.out_len;
+    const bool rich = image_is_rich(img_desc, img_bytes);                        // C2: 2.2 %, C4: 3.7 %, C3: 5 %
     // (phase size, store policy and threshold are launch options -- v2p_launch_opts, v2p_set_launch_opts -- for A/B runs and tests:
     // nothing here reads the environment)
     uint64_t phase_bytes = rich ? PHASE_BYTES_RICH : PHASE_BYTES_DEFAULT;
@@ -1291,7 +1291,7 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     const bool streams = (nontemporal & 4) != 0 || (nontemporal & 16) == 0;       // the image holds wave or long-run chunks
     const uint32_t min_chunks = a.opt_phase_min_chunks ? a.opt_phase_min_chunks : PHASE_MIN_CHUNKS;
     if (max_blocks != 0 || phase_bytes == 0 || !streams || a.n_chunks < min_chunks) return launch_stitch_range(a, stream, nontemporal, max_blocks);
-    const double per_chunk = 16.0 + 8.0 * double(a.n_desc) / double(a.n_chunks);
+    const double per_chunk = 16.0 + 8.0 * double(img_desc) / double(a.n_chunks);
     uint64_t per = uint64_t(double(phase_bytes) / per_chunk);
     const uint64_t per_min = a.opt_phase_min_chunks ? 8u : 4096u;    // (a lowered threshold -- tests -- also allows tiny phases)
     per = per < per_min ? per_min : (per & ~7ull);                   // (a multiple of 8 keeps workgroup b on the XCD the chunk order dealt chunk b to)

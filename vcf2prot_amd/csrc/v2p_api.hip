@@ -116,6 +116,7 @@ struct v2p_ctx {
     int device = 0;
     unsigned flags = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t build_stream = nullptr;               // v2p_batch_build_and_execute: the image is built here while the context's stream stitches
     mutable std::mutex mu;
     std::string err;
     int64_t err_index = -1;
@@ -135,6 +136,7 @@ struct v2p_ctx {
     }
 };
 
+constexpr uint32_t V2P_MAX_SLICES = 32;
 struct v2p_batch {
     v2p_ctx* ctx = nullptr;
     ImageBuilder img;
@@ -147,6 +149,17 @@ struct v2p_batch {
     uint64_t last_hdr_src = 0; uint32_t last_hdr_len = 0;
     DevBuf d_desc, d_chunks, d_payload, d_out, d_hap, d_digest, d_status;
     DevBuf d_build;                // the transcript stream and the builder's scratch (v2p_batch_build_on_device)
+    const uint8_t* payload_dev = nullptr;   // the alt bytes the image's payload descriptors read: d_payload, or a resident v2p_stream's
+    // v2p_batch_build_and_execute: tables that outlive the call so that a batch that is rebuilt recycles them, the slices' chunk ranges
+    // and the events of the last call (read by v2p_batch_oneshot_info after a sync)
+    DevBuf d_tiles, d_cover, d_pad, d_order;
+    uint32_t n_slices = 0;
+    uint64_t slice_chunk0[V2P_MAX_SLICES + 1] = {};
+    uint64_t slice_desc[V2P_MAX_SLICES] = {}, slice_bytes[V2P_MAX_SLICES] = {};
+    hipEvent_t ev_os[2 + 2 * V2P_MAX_SLICES] = {};
+    float os_build_ms = 0.f;
+    double os_wall_ms = 0.0;
+    int os_kernel = 0;
     uint64_t n_desc = 0, n_chunks = 0, n_payload = 0, out_bytes = 0, n_haps = 0;
     uint32_t max_chunk_tasks = 0;
     int launch_hint = 0;           // stitch_launch_bits() of the chunk table
@@ -245,6 +258,7 @@ void v2p_destroy(v2p_ctx* c)
     c->d_desc.release(); c->d_chunks.release(); c->d_soa.release(); c->d_status.release();
     c->h_stage.release(); c->h_in.release();
     queue_destroy(c);
+    if (c->build_stream) (void)hipStreamDestroy(c->build_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -938,6 +952,9 @@ void v2p_batch_destroy(v2p_batch* b)
     (void)hipStreamSynchronize(b->ctx->stream);
     b->d_desc.release(); b->d_chunks.release(); b->d_payload.release(); b->d_out.release();
     b->d_hap.release(); b->d_digest.release(); b->d_status.release(); b->d_build.release();
+    b->d_tiles.release(); b->d_cover.release(); b->d_pad.release(); b->d_order.release();
+    if (b->ctx->build_stream) (void)hipStreamSynchronize(b->ctx->build_stream);
+    for (hipEvent_t e : b->ev_os) if (e) (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -1149,16 +1166,25 @@ int v2p_batch_end_haplotype(v2p_batch* b)
 }
 
 // ---- ROWS images: the image built in ONE pass (build_rows.hip; format: rows_image.hpp) -----------------------------------------
-// Called by v2p_batch_build_on_device (kernel 6: wave image, 7: dense) with the stream's tables already checked and c->mu held.
-// Tiles of K consecutive transcripts, one wave each (K <= 64: the kernel's prologue gives every transcript of the tile a lane).  A
-// wave takes 64 items in its first window and ADV more in every further one, so K is picked to FILL the tile's last window: among
-// the window counts w whose capacity stays below ~360 items (a tile's descriptors must fit its 256 slots of the padded array; one
-// that does not sends the build to its two-pass form), the K <= 64 with the least work per transcript (windows + a tile's fixed
-// cost) -- mean and spread of the items per transcript from a sample of the stream.
-static uint32_t rows_pick_k(const v2p_txstream* s, int mode, bool fasta)
+// A transcript stream as it sits on the device: either uploaded for one build (v2p_batch_build_on_device) or resident (v2p_stream).
+struct DevStreamView {
+    uint64_t n_haps = 0, n_tx = 0, n_tasks = 0, n_alt = 0;
+    const uint64_t* hap_tx_begin = nullptr; const uint64_t* tx_proteome_off = nullptr;
+    const uint32_t* tx_ref_len = nullptr; const uint32_t* tx_res_len = nullptr;
+    const uint64_t* tx_task_begin = nullptr; const uint64_t* tx_alt_begin = nullptr;
+    const uint8_t* code = nullptr; const uint32_t* start_pos = nullptr; const uint32_t* length = nullptr; const uint32_t* start_pos_res = nullptr;
+    const uint8_t* alt = nullptr;
+    const uint64_t* tx_header_off = nullptr; const uint32_t* tx_header_len = nullptr;      // FASTA emit (nullptr: plain tapes)
+    bool fasta = false;
+    double items_mean = 1.0, items_var = 0.0;          // items (Tasks; a transcript without Tasks is one) per transcript: rows_pick_k
+};
+
+// mean and spread of the items per transcript from a sample of the (host) stream
+static void stream_item_stats(const v2p_txstream* s, double* mean, double* var)
 {
+    *mean = 1.0; *var = 0.0;
     const uint64_t n_tx = s->n_tx;
-    if (n_tx == 0) return 1;
+    if (n_tx == 0) return;
     const uint64_t step = n_tx > 65536 ? n_tx / 65536 : 1;
     double sum = 0, sq = 0, cnt = 0;
     for (uint64_t u = 0; u < n_tx; u += step) {
@@ -1166,9 +1192,21 @@ static uint32_t rows_pick_k(const v2p_txstream* s, int mode, bool fasta)
         const double x = nt ? double(nt) : 1.0;                      // (a transcript without tasks is one item)
         sum += x; sq += x * x; cnt += 1;
     }
-    const double m = sum / cnt, var = sq / cnt - m * m > 0 ? sq / cnt - m * m : 0.0, sd = sqrt(var);
+    const double m = sum / cnt;
+    *mean = m; *var = sq / cnt - m * m > 0 ? sq / cnt - m * m : 0.0;
+}
+
+// Tiles of K consecutive transcripts, one wave each (K <= 64: the kernel's prologue gives every transcript of the tile a lane).  A
+// wave takes 64 items in its first window and ADV more in every further one, so K is picked to FILL the tile's last window: among
+// the window counts w whose capacity stays below ~360 items (a tile's descriptors must fit its 256 slots of the padded array; one
+// that does not sends the build to its two-pass form), the K <= 64 with the least work per transcript (windows + a tile's fixed
+// cost) -- mean and spread of the items per transcript from a sample of the stream.
+static uint32_t rows_pick_k(const DevStreamView& v, int mode)
+{
+    if (v.n_tx == 0) return 1;
+    const double m = v.items_mean, var = v.items_var, sd = sqrt(var);
     const double adv = mode == ROWS_DENSE ? 58.0 : 60.0, z = 1.3;
-    const double k_cap = fasta ? 240.0 / (m + 2.0) : 64.0;           // FASTA: a header and a line feed per transcript on top
+    const double k_cap = v.fasta ? 240.0 / (m + 2.0) : 64.0;         // FASTA: a header and a line feed per transcript on top
     uint32_t best_k = 1;
     double best_cost = 1e30;
     for (uint32_t w = 1; w <= 8; ++w) {
@@ -1187,24 +1225,20 @@ static uint32_t rows_pick_k(const v2p_txstream* s, int mode, bool fasta)
     return best_k;
 }
 
-static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool fasta, float* build_ms)
+// The stream's arrays into one device allocation (`buf`, carved) + its alt bytes (`altbuf`), on `stream`; v receives the device pointers.
+static int upload_stream(v2p_ctx* c, const v2p_txstream* s, bool fasta, DevBuf& buf, DevBuf& altbuf, DevStreamView& v, hipStream_t stream)
 {
-    v2p_ctx* c = b->ctx;
     const uint64_t n_tx = s->n_tx, n_tk = s->n_tasks, n_h = s->n_haps;
-    const uint32_t K = rows_pick_k(s, mode, fasta);
-    const uint64_t n_tiles = n_tx ? (n_tx + K - 1) / K : 1;
     auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
     uint64_t off = 0;
     auto carve = [&](uint64_t bytes) { const uint64_t o = off; off += up8(bytes); return o; };
     const uint64_t o_hap = carve((n_h + 1) * 8), o_poff = carve(n_tx * 8), o_rlen = carve(n_tx * 4), o_res = carve(n_tx * 4),
                    o_tb = carve((n_tx + 2) * 8), o_ab = carve((n_tx + 2) * 8), o_code = carve(n_tk + 64), o_sp = carve((n_tk + 16) * 4), o_ln = carve((n_tk + 16) * 4),
-                   o_sr = carve((n_tk + 16) * 4), o_hoff = carve(fasta ? n_tx * 8 : 0), o_hlen = carve(fasta ? n_tx * 4 : 0),
-                   o_tbytes = carve(n_tiles * 8), o_tbase = carve((n_tiles + 1) * 8), o_tcount = carve((n_tiles + 1) * 4), o_tdbase = carve((n_tiles + 2) * 8),
-                   o_totals = carve(64), o_scan = carve((rows_scan_scratch_entries(n_tiles) + scan_tiles_for(n_tiles + 1)) * 8);
-    HIP_TRY(c, b->d_build.ensure(off), "hipMalloc(build)");
-    uint8_t* const d = b->d_build.ptr();
-    HIP_TRY(c, b->d_payload.ensure(s->n_alt), "hipMalloc(alt)");
-#define UP(dst_off, src, bytes, what) do { if (bytes) HIP_TRY(c, hipMemcpyAsync(d + (dst_off), (src), (bytes), hipMemcpyHostToDevice, c->stream), what); } while (0)
+                   o_sr = carve((n_tk + 16) * 4), o_hoff = carve(fasta ? n_tx * 8 : 0), o_hlen = carve(fasta ? n_tx * 4 : 0);
+    HIP_TRY(c, buf.ensure(off), "hipMalloc(stream)");
+    uint8_t* const d = buf.ptr();
+    HIP_TRY(c, altbuf.ensure(s->n_alt), "hipMalloc(alt)");
+#define UP(dst_off, src, bytes, what) do { if (bytes) HIP_TRY(c, hipMemcpyAsync(d + (dst_off), (src), (bytes), hipMemcpyHostToDevice, stream), what); } while (0)
     UP(o_hap, s->hap_tx_begin, (n_h + 1) * 8, "H2D(hap_tx_begin)"); UP(o_poff, s->tx_proteome_off, n_tx * 8, "H2D(tx_proteome_off)");
     UP(o_rlen, s->tx_ref_len, n_tx * 4, "H2D(tx_ref_len)"); UP(o_res, s->tx_res_len, n_tx * 4, "H2D(tx_res_len)");
     UP(o_tb, s->tx_task_begin, (n_tx + 1) * 8, "H2D(tx_task_begin)"); UP(o_ab, s->tx_alt_begin, (n_tx + 1) * 8, "H2D(tx_alt_begin)");
@@ -1212,33 +1246,66 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
     UP(o_sr, s->start_pos_res, n_tk * 4, "H2D(start_pos_res)");
     if (fasta) { UP(o_hoff, s->tx_header_off, n_tx * 8, "H2D(tx_header_off)"); UP(o_hlen, s->tx_header_len, n_tx * 4, "H2D(tx_header_len)"); }
 #undef UP
-    if (s->n_alt) HIP_TRY(c, hipMemcpyAsync(b->d_payload.ptr(), s->alt, s->n_alt, hipMemcpyHostToDevice, c->stream), "H2D(alt)");
+    if (s->n_alt) HIP_TRY(c, hipMemcpyAsync(altbuf.ptr(), s->alt, s->n_alt, hipMemcpyHostToDevice, stream), "H2D(alt)");
+    v = DevStreamView();
+    v.n_haps = n_h; v.n_tx = n_tx; v.n_tasks = n_tk; v.n_alt = s->n_alt;
+    v.hap_tx_begin = reinterpret_cast<const uint64_t*>(d + o_hap); v.tx_proteome_off = reinterpret_cast<const uint64_t*>(d + o_poff);
+    v.tx_ref_len = reinterpret_cast<const uint32_t*>(d + o_rlen); v.tx_res_len = reinterpret_cast<const uint32_t*>(d + o_res);
+    v.tx_task_begin = reinterpret_cast<const uint64_t*>(d + o_tb); v.tx_alt_begin = reinterpret_cast<const uint64_t*>(d + o_ab);
+    v.code = d + o_code; v.start_pos = reinterpret_cast<const uint32_t*>(d + o_sp); v.length = reinterpret_cast<const uint32_t*>(d + o_ln);
+    v.start_pos_res = reinterpret_cast<const uint32_t*>(d + o_sr); v.alt = altbuf.ptr();
+    v.tx_header_off = fasta ? reinterpret_cast<const uint64_t*>(d + o_hoff) : nullptr;
+    v.tx_header_len = fasta ? reinterpret_cast<const uint32_t*>(d + o_hlen) : nullptr;
+    v.fasta = fasta;
+    stream_item_stats(s, &v.items_mean, &v.items_var);
+    return V2P_OK;
+}
+
+static void rows_args_of(const DevStreamView& v, v2p_ctx* c, uint32_t K, uint64_t n_tiles, RowsArgs& a)
+{
+    a = RowsArgs{};
+    a.n_tx = v.n_tx; a.n_tasks = v.n_tasks; a.n_alt = v.n_alt; a.n_haps = v.n_haps;
+    a.hap_tx_begin = v.hap_tx_begin; a.tx_proteome_off = v.tx_proteome_off; a.tx_ref_len = v.tx_ref_len; a.tx_res_len = v.tx_res_len;
+    a.tx_task_begin = v.tx_task_begin; a.tx_alt_begin = v.tx_alt_begin;
+    a.code = v.code; a.start_pos = v.start_pos; a.length = v.length; a.start_pos_res = v.start_pos_res; a.alt = v.alt;
+    a.tx_header_off = v.tx_header_off; a.tx_header_len = v.tx_header_len;
+    a.proteome_len = c->proteome_len; a.K = K; a.n_tiles = n_tiles;
+}
+
+// Called by v2p_batch_build_on_device / v2p_batch_build_from_stream (kernel 6: wave image, 7: dense) with the stream's tables already
+// checked and c->mu held.  own_stream_copy: the stream sits in b->d_build (uploaded for this build) and is released with it.
+static int build_rows_image(v2p_batch* b, const DevStreamView& v, int mode, float* build_ms, bool own_stream_copy)
+{
+    v2p_ctx* c = b->ctx;
+    const bool fasta = v.fasta;
+    const uint64_t n_tx = v.n_tx, n_h = v.n_haps;
+    const uint32_t K = rows_pick_k(v, mode);
+    const uint64_t n_tiles = n_tx ? (n_tx + K - 1) / K : 1;
+    auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
     int rc = init_status(c, b->d_status);
     if (rc) return rc;
     struct Cleanup {
         hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        DevBuf scratch, cover, pad;
+        DevBuf tiles, scratch, cover, pad;
         v2p_batch* b;
-        bool ok = false;
-        explicit Cleanup(v2p_batch* b_) : b(b_) {}
+        bool ok = false, own;
+        Cleanup(v2p_batch* b_, bool own_) : b(b_), own(own_) {}
         ~Cleanup() {
             for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
-            scratch.release(); cover.release(); pad.release();
-            b->d_build.release();
-            if (!ok) { b->img.hap_out_begin.assign(1, 0); b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0; }
+            tiles.release(); scratch.release(); cover.release(); pad.release();
+            if (own) b->d_build.release();
+            if (!ok) { b->img.hap_out_begin.assign(1, 0); b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0; b->payload_dev = nullptr; }
         }
-    } guard(b);
+    } guard(b, own_stream_copy);
     for (hipEvent_t& e : guard.ev) HIP_TRY(c, hipEventCreate(&e), "hipEventCreate");
-    RowsArgs a{};
-    a.n_tx = n_tx; a.n_tasks = n_tk; a.n_alt = s->n_alt; a.n_haps = n_h;
-    a.hap_tx_begin = reinterpret_cast<const uint64_t*>(d + o_hap); a.tx_proteome_off = reinterpret_cast<const uint64_t*>(d + o_poff);
-    a.tx_ref_len = reinterpret_cast<const uint32_t*>(d + o_rlen); a.tx_res_len = reinterpret_cast<const uint32_t*>(d + o_res);
-    a.tx_task_begin = reinterpret_cast<const uint64_t*>(d + o_tb); a.tx_alt_begin = reinterpret_cast<const uint64_t*>(d + o_ab);
-    a.code = d + o_code; a.start_pos = reinterpret_cast<const uint32_t*>(d + o_sp); a.length = reinterpret_cast<const uint32_t*>(d + o_ln);
-    a.start_pos_res = reinterpret_cast<const uint32_t*>(d + o_sr); a.alt = b->d_payload.ptr();
-    a.tx_header_off = fasta ? reinterpret_cast<const uint64_t*>(d + o_hoff) : nullptr;
-    a.tx_header_len = fasta ? reinterpret_cast<const uint32_t*>(d + o_hlen) : nullptr;
-    a.proteome_len = c->proteome_len; a.K = K; a.n_tiles = n_tiles;
+    uint64_t off = 0;
+    auto carve = [&](uint64_t bytes) { const uint64_t o = off; off += up8(bytes); return o; };
+    const uint64_t o_tbytes = carve(n_tiles * 8), o_tbase = carve((n_tiles + 1) * 8), o_tcount = carve((n_tiles + 1) * 4), o_tdbase = carve((n_tiles + 2) * 8),
+                   o_totals = carve(64), o_scan = carve((rows_scan_scratch_entries(n_tiles) + scan_tiles_for(n_tiles + 1)) * 8);
+    HIP_TRY(c, guard.tiles.ensure_exact(off), "hipMalloc(tile tables)");
+    uint8_t* const d = guard.tiles.ptr();
+    RowsArgs a;
+    rows_args_of(v, c, K, n_tiles, a);
     a.tile_bytes = reinterpret_cast<uint64_t*>(d + o_tbytes); a.tile_res_base = reinterpret_cast<uint64_t*>(d + o_tbase);
     a.tile_count = reinterpret_cast<uint32_t*>(d + o_tcount); a.tile_desc_base = reinterpret_cast<uint64_t*>(d + o_tdbase);
     a.totals = reinterpret_cast<uint64_t*>(d + o_totals);
@@ -1369,10 +1436,66 @@ static int build_rows_image(v2p_batch* b, const v2p_txstream* s, int mode, bool 
     (void)hipEventElapsedTime(&ms2, guard.ev[6], guard.ev[7]);
     if (build_ms) *build_ms = ms0 + ms_parse + ms1 + ms2;
     guard.ok = true;
-    b->n_desc = n_desc; b->n_chunks = n_chunks; b->n_payload = s->n_alt; b->out_bytes = out_bytes; b->n_haps = n_h;
+    b->n_desc = n_desc; b->n_chunks = n_chunks; b->n_payload = v.n_alt; b->payload_dev = v.alt; b->out_bytes = out_bytes; b->n_haps = n_h;
     b->launch_hint = (mode == ROWS_DENSE ? 2 : 4) | 8 | 16 | 32 | (1 << 6) | (1 << 8);
     b->uses_proteome = true;
     b->finalized = true;
+    b->n_slices = 0;
+    return V2P_OK;
+}
+
+// The kernels index device memory through EVERY entry of the stream's offset tables (16-byte slab loads of a transcript's tasks, the
+// unaligned 8-byte load of an immediate payload, tx_res_base[hap_tx_begin[h]]): a table that is not ascending from 0 or leaves
+// its array is refused here, with the offending index, before anything is uploaded.  Optionally: every transcript's arena length
+// (FASTA, the grid builders), the arena offset of every haplotype (res_counter of haplotype_instruction.rs:90,132 on the host).
+static int check_stream(v2p_ctx* c, const v2p_txstream* s, bool* fasta_out, std::vector<uint32_t>* arena_len, std::vector<uint64_t>* hap_out_begin)
+{
+    if (!s->hap_tx_begin || (s->n_tx && (!s->tx_proteome_off || !s->tx_ref_len || !s->tx_res_len || !s->tx_task_begin || !s->tx_alt_begin)) ||
+        (s->n_tasks && (!s->code || !s->start_pos || !s->length || !s->start_pos_res)) || (s->n_alt && !s->alt))
+        return c->fail(V2P_ERR_INVALID_ARG, "null argument");
+    if (s->hap_tx_begin[s->n_haps] != s->n_tx || (s->n_tx && (s->tx_task_begin[s->n_tx] != s->n_tasks || s->tx_alt_begin[s->n_tx] != s->n_alt)))
+        return c->fail(V2P_ERR_INVALID_ARG, "stream offsets do not add up");
+    if (s->hap_tx_begin[0] != 0) return c->fail(V2P_ERR_INVALID_ARG, "hap_tx_begin does not start at 0", 0);
+    for (uint64_t h = 0; h < s->n_haps; ++h)
+        if (s->hap_tx_begin[h + 1] < s->hap_tx_begin[h] || s->hap_tx_begin[h + 1] > s->n_tx)
+            return c->fail(V2P_ERR_INVALID_ARG, "hap_tx_begin is not ascending inside [0, n_tx] at haplotype " + std::to_string(h), int64_t(h));
+    if (s->n_tx && (s->tx_task_begin[0] != 0 || s->tx_alt_begin[0] != 0)) return c->fail(V2P_ERR_INVALID_ARG, "tx_task_begin / tx_alt_begin do not start at 0", 0);
+    for (uint64_t t = 0; t < s->n_tx; ++t) {
+        if (s->tx_task_begin[t + 1] < s->tx_task_begin[t] || s->tx_task_begin[t + 1] > s->n_tasks)
+            return c->fail(V2P_ERR_INVALID_ARG, "tx_task_begin is not ascending inside [0, n_tasks] at transcript " + std::to_string(t), int64_t(t));
+        if (s->tx_alt_begin[t + 1] < s->tx_alt_begin[t] || s->tx_alt_begin[t + 1] > s->n_alt)
+            return c->fail(V2P_ERR_INVALID_ARG, "tx_alt_begin is not ascending inside [0, n_alt] at transcript " + std::to_string(t), int64_t(t));
+        if (s->tx_proteome_off[t] + s->tx_ref_len[t] < s->tx_proteome_off[t])
+            return c->fail(V2P_ERR_INVALID_ARG, "tx_proteome_off + tx_ref_len wraps at transcript " + std::to_string(t), int64_t(t));
+    }
+    // FASTA emit: every record header inside the resident header table and ending in a line feed (the record's own line feed is read
+    // from there); a transcript's arena length is then header + residues + line feed
+    const bool fasta = s->tx_header_off && s->tx_header_len;
+    if ((s->tx_header_off == nullptr) != (s->tx_header_len == nullptr)) return c->fail(V2P_ERR_INVALID_ARG, "tx_header_off and tx_header_len come together");
+    if (fasta) {
+        if (arena_len) arena_len->resize(s->n_tx);
+        for (uint64_t t = 0; t < s->n_tx; ++t) {
+            const uint64_t ho = s->tx_header_off[t], hl = s->tx_header_len[t];
+            if (hl && (ho + hl > c->headers_len || ho + hl < ho)) return c->fail(V2P_ERR_SRC_OOB, "record header outside the resident header table at transcript " + std::to_string(t), int64_t(t));
+            if (hl && c->headers_host[ho + hl - 1] != '\n') return c->fail(V2P_ERR_INVALID_ARG, "a record header must end in a line feed (transcript " + std::to_string(t) + ")", int64_t(t));
+            const uint64_t al = uint64_t(s->tx_res_len[t]) + (hl ? hl + 1u : 0u);
+            if (al > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "a record of more than 4 GiB", int64_t(t));
+            if (arena_len) (*arena_len)[t] = uint32_t(al);
+        }
+    }
+    if (hap_out_begin) {
+        hap_out_begin->assign(s->n_haps + 1, 0);
+        uint64_t at = 0;
+        for (uint64_t h = 0; h < s->n_haps; ++h) {
+            (*hap_out_begin)[h] = at;
+            for (uint64_t t = s->hap_tx_begin[h]; t < s->hap_tx_begin[h + 1]; ++t) {
+                const uint32_t hl = fasta ? s->tx_header_len[t] : 0u;
+                at += uint64_t(s->tx_res_len[t]) + (hl ? hl + 1u : 0u);
+            }
+        }
+        (*hap_out_begin)[s->n_haps] = at;
+    }
+    *fasta_out = fasta;
     return V2P_OK;
 }
 
@@ -1394,45 +1517,19 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     if (split && window_bytes < 2048u) return c->fail(V2P_ERR_INVALID_ARG, "a window that may split holds at least two 1 KiB rows");
     // (a grid chunk starts on a multiple of 4096: no 16-byte phase, so 12288 bytes fill the kernel's LDS image exactly)
     if (kernel == 3 && window_bytes > 12288u) return c->fail(V2P_ERR_INVALID_ARG, "a dense image takes windows of 4096, 8192 or 12288 bytes (one chunk = one 12 KiB LDS image)");
-    if (!s->hap_tx_begin || (s->n_tx && (!s->tx_proteome_off || !s->tx_ref_len || !s->tx_res_len || !s->tx_task_begin || !s->tx_alt_begin)) ||
-        (s->n_tasks && (!s->code || !s->start_pos || !s->length || !s->start_pos_res)) || (s->n_alt && !s->alt))
-        return c->fail(V2P_ERR_INVALID_ARG, "null argument");
-    if (s->hap_tx_begin[s->n_haps] != s->n_tx || (s->n_tx && (s->tx_task_begin[s->n_tx] != s->n_tasks || s->tx_alt_begin[s->n_tx] != s->n_alt)))
-        return c->fail(V2P_ERR_INVALID_ARG, "stream offsets do not add up");
-    // The kernels index device memory through EVERY entry of the offset tables (16-byte slab loads of a transcript's tasks, the
-    // unaligned 8-byte load of an immediate payload, tx_res_base[hap_tx_begin[h]]): a table that is not ascending from 0 or leaves
-    // its array is refused here, with the offending index, before anything is uploaded.
-    if (s->hap_tx_begin[0] != 0) return c->fail(V2P_ERR_INVALID_ARG, "hap_tx_begin does not start at 0", 0);
-    for (uint64_t h = 0; h < s->n_haps; ++h)
-        if (s->hap_tx_begin[h + 1] < s->hap_tx_begin[h] || s->hap_tx_begin[h + 1] > s->n_tx)
-            return c->fail(V2P_ERR_INVALID_ARG, "hap_tx_begin is not ascending inside [0, n_tx] at haplotype " + std::to_string(h), int64_t(h));
-    if (s->n_tx && (s->tx_task_begin[0] != 0 || s->tx_alt_begin[0] != 0)) return c->fail(V2P_ERR_INVALID_ARG, "tx_task_begin / tx_alt_begin do not start at 0", 0);
-    for (uint64_t t = 0; t < s->n_tx; ++t) {
-        if (s->tx_task_begin[t + 1] < s->tx_task_begin[t] || s->tx_task_begin[t + 1] > s->n_tasks)
-            return c->fail(V2P_ERR_INVALID_ARG, "tx_task_begin is not ascending inside [0, n_tasks] at transcript " + std::to_string(t), int64_t(t));
-        if (s->tx_alt_begin[t + 1] < s->tx_alt_begin[t] || s->tx_alt_begin[t + 1] > s->n_alt)
-            return c->fail(V2P_ERR_INVALID_ARG, "tx_alt_begin is not ascending inside [0, n_alt] at transcript " + std::to_string(t), int64_t(t));
-        if (s->tx_proteome_off[t] + s->tx_ref_len[t] < s->tx_proteome_off[t])
-            return c->fail(V2P_ERR_INVALID_ARG, "tx_proteome_off + tx_ref_len wraps at transcript " + std::to_string(t), int64_t(t));
-    }
-    // FASTA emit: every record header inside the resident header table and ending in a line feed (the record's own line feed is read
-    // from there); a transcript's arena length is then header + residues + line feed
-    const bool fasta = s->tx_header_off && s->tx_header_len;
-    if ((s->tx_header_off == nullptr) != (s->tx_header_len == nullptr)) return c->fail(V2P_ERR_INVALID_ARG, "tx_header_off and tx_header_len come together");
+    bool fasta = false;
     std::vector<uint32_t> arena_len;
-    if (fasta) {
-        arena_len.resize(s->n_tx);
-        for (uint64_t t = 0; t < s->n_tx; ++t) {
-            const uint64_t ho = s->tx_header_off[t], hl = s->tx_header_len[t];
-            if (hl && (ho + hl > c->headers_len || ho + hl < ho)) return c->fail(V2P_ERR_SRC_OOB, "record header outside the resident header table at transcript " + std::to_string(t), int64_t(t));
-            if (hl && c->headers_host[ho + hl - 1] != '\n') return c->fail(V2P_ERR_INVALID_ARG, "a record header must end in a line feed (transcript " + std::to_string(t) + ")", int64_t(t));
-            const uint64_t al = uint64_t(s->tx_res_len[t]) + (hl ? hl + 1u : 0u);
-            if (al > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "a record of more than 4 GiB", int64_t(t));
-            arena_len[t] = uint32_t(al);
-        }
+    {
+        const int crc = check_stream(c, s, &fasta, rows ? nullptr : &arena_len, nullptr);
+        if (crc) return crc;
     }
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
-    if (rows) return build_rows_image(b, s, kernel == 7 ? ROWS_DENSE : ROWS_WAVE, fasta, build_ms);
+    if (rows) {
+        DevStreamView v;
+        const int urc = upload_stream(c, s, fasta, b->d_build, b->d_payload, v, c->stream);
+        if (urc) { b->d_build.release(); return urc; }
+        return build_rows_image(b, v, kernel == 7 ? ROWS_DENSE : ROWS_WAVE, build_ms, true);
+    }
     const uint64_t n_tx = s->n_tx, n_tk = s->n_tasks, n_h = s->n_haps;
     const uint64_t n_tiles = (n_tx + 1023) / 1024 + 2;
     // one device allocation, carved: stream arrays, then scratch
@@ -1571,11 +1668,342 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     if (rc) { (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream); return rc; }
     guard.ok = true;
     if (build_ms) *build_ms = ms;
-    b->n_desc = n_desc; b->n_chunks = n_chunks; b->n_payload = s->n_alt; b->out_bytes = out_bytes; b->n_haps = n_h;
+    b->n_desc = n_desc; b->n_chunks = n_chunks; b->n_payload = s->n_alt; b->payload_dev = b->d_payload.ptr(); b->out_bytes = out_bytes; b->n_haps = n_h;
+    b->n_slices = 0;
     const int tpt = meta[3] <= 256u ? 1 : (meta[3] <= 512u ? 2 : 4);
     b->launch_hint = ((meta[0] & 2u) ? 2 : 0) | ((meta[0] & 4u) ? 4 : 0) | ((meta[0] & 1u) ? 0 : 16) | (meta[2] ? 0 : 32) | ((meta[1] ? 2 : 1) << 6) | (tpt << 8);
     b->uses_proteome = true;
     b->finalized = true;
+    return V2P_OK;
+}
+
+// ---- a transcript stream RESIDENT on the device; Task vectors -> result bytes in ONE call -----------------------------------
+// v2p_batch_build_on_device takes a host stream, uploads it, builds, and the caller executes afterwards: two calls, the stream's H2D
+// inside the first, the build and the execute strictly one after the other.  What a cohort pays ONCE is exactly that sequence
+// (haplotype_instruction.rs:75-137 -> gir.rs:197-241), so here it is one call on a stream that is already in HBM:
+//   v2p_stream_upload             tables checked on the host (check_stream), arrays to the device once, arena offsets of the haplotypes
+//   v2p_batch_build_from_stream   the one-piece builder (build_rows_image) on it: no H2D
+//   v2p_batch_build_and_execute   the image built SLICE BY SLICE on a second HIP stream while the slice before it is being stitched on the
+//                                 context's stream: the parse is bound by instruction issue, the stitch by its stores
+struct v2p_stream {
+    v2p_ctx* ctx = nullptr;
+    DevBuf buf, alt;
+    DevStreamView v;
+    uint64_t out_bytes = 0;
+    std::vector<uint64_t> hap_out_begin;       // res_counter (haplotype_instruction.rs:90,132) at every haplotype's first transcript, from the host tables
+};
+
+int v2p_stream_upload(v2p_ctx* c, const v2p_txstream* s, v2p_stream** out)
+{
+    if (!c || !s || !out) return V2P_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::lock_guard<std::mutex> lk(c->mu);
+    v2p_stream* st = new (std::nothrow) v2p_stream();
+    if (!st) return c->fail(V2P_ERR_HIP, "out of host memory");
+    st->ctx = c;
+    bool fasta = false;
+    int rc = check_stream(c, s, &fasta, nullptr, &st->hap_out_begin);
+    if (rc == V2P_OK && hipSetDevice(c->device) != hipSuccess) rc = c->fail(V2P_ERR_HIP, "hipSetDevice");
+    if (rc == V2P_OK) rc = upload_stream(c, s, fasta, st->buf, st->alt, st->v, c->stream);
+    if (rc == V2P_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = c->fail(V2P_ERR_HIP, "hipStreamSynchronize");
+    if (rc != V2P_OK) { st->buf.release(); st->alt.release(); delete st; return rc; }
+    st->out_bytes = st->hap_out_begin.back();
+    *out = st;
+    return V2P_OK;
+}
+
+void v2p_stream_destroy(v2p_stream* st)
+{
+    if (!st) return;
+    std::lock_guard<std::mutex> lk(st->ctx->mu);
+    (void)hipSetDevice(st->ctx->device);
+    (void)hipDeviceSynchronize();                      // (batches built from it may still execute on either stream: their payload descriptors read its alt bytes)
+    st->buf.release(); st->alt.release();
+    delete st;
+}
+
+int v2p_stream_counts(const v2p_stream* st, uint64_t* n_haps, uint64_t* n_tx, uint64_t* n_tasks, uint64_t* out_bytes)
+{
+    if (!st) return V2P_ERR_INVALID_ARG;
+    if (n_haps) *n_haps = st->v.n_haps;
+    if (n_tx) *n_tx = st->v.n_tx;
+    if (n_tasks) *n_tasks = st->v.n_tasks;
+    if (out_bytes) *out_bytes = st->out_bytes;
+    return V2P_OK;
+}
+
+// kernel 0: the routing rule (sir_pack.hpp: WAVE_BYTES_PER_TASK result bytes per Task and more -> a wave image)
+static int rows_mode_for(const v2p_stream* st, int kernel)
+{
+    if (kernel == 6) return ROWS_WAVE;
+    if (kernel == 7) return ROWS_DENSE;
+    const double bpt = double(st->out_bytes) / double(st->v.n_tasks ? st->v.n_tasks : 1);
+    return bpt < double(WAVE_BYTES_PER_TASK) ? ROWS_DENSE : ROWS_WAVE;
+}
+
+int v2p_batch_reset(v2p_batch* b)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    b->img = ImageBuilder();
+    b->finalized = false; b->uses_proteome = false; b->hap_open = false;
+    b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0;
+    b->payload_dev = nullptr; b->n_slices = 0; b->launch_hint = 0;
+    return V2P_OK;
+}
+
+int v2p_batch_build_from_stream(v2p_batch* b, const v2p_stream* st, int kernel, float* build_ms)
+{
+    if (!b || !st) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    if (st->ctx != c) return V2P_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
+    if (b->hap_open || b->img.n_haplotypes()) return c->fail(V2P_ERR_STATE, "the batch already holds host-built haplotypes");
+    if (kernel != 0 && kernel != 6 && kernel != 7) return c->fail(V2P_ERR_INVALID_ARG, "a resident stream builds rows images: kernel 0 (by the routing rule), 6 or 7");
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    int mode = rows_mode_for(st, kernel);
+    int rc = build_rows_image(b, st->v, mode, build_ms, false);
+    if (rc == V2P_ERR_UNSUPPORTED && kernel == 0 && mode == ROWS_WAVE) rc = build_rows_image(b, st->v, ROWS_DENSE, build_ms, false);     // (a row with more than 64 descriptors)
+    return rc;
+}
+
+static hipError_t ensure_event(hipEvent_t& e) { return e ? hipSuccess : hipEventCreate(&e); }
+
+// One slice's share of launch_stitch's routing (phases, store policy) follows the slice, not the table it is a range of
+static hipError_t stitch_range(v2p_batch* b, uint64_t desc_bound, uint64_t chunk0, uint64_t n_chunks, uint64_t img_desc, uint64_t img_bytes, hipStream_t stream)
+{
+    v2p_ctx* c = b->ctx;
+    if (n_chunks == 0) return hipSuccess;
+    StitchArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), desc_bound, reinterpret_cast<const Chunk*>(b->d_chunks.ptr()) + chunk0,
+                 uint32_t(n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->payload_dev, b->n_payload,
+                 b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
+    a.opt_phase_bytes = c->launch_opts.phase_bytes; a.opt_phase_min_chunks = c->launch_opts.phase_min_chunks; a.opt_store_sc1 = c->launch_opts.store_sc1;
+    a.img_desc = img_desc; a.img_bytes = img_bytes;
+    return launch_stitch(a, stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint, 0);
+}
+
+// The sliced builder.  Global tables first (arena bytes per tile, their scan, the haplotypes' offsets: 0.2 ms), then per slice of tiles
+// [T_j, T_j+1) on the BUILD stream: parse into the slice's padded array, scan of its tiles' counts (continuing the slices' running
+// total), compaction into the one descriptor array, the cutter over the 640-row segments the slice completes, scan of their chunk
+// counts -- one host round trip (counts, status) -- chunk table, keys, XCD / window order inside the slice; then the slice's chunks
+// are stitched on the context's stream while the build stream is already parsing the next slice.  Descriptors, chunk records and
+// haplotype offsets are the one-piece builder's (the cutter is deterministic per segment); only the blocks inside which the
+// chunk table is dealt to the XCDs are the slice's own.  *fallback: a stream this path does not take (a tile that overflows its 256
+// slots, a row with more descriptors than the kernel's chunk, more than 2^25 tiles): nothing is lost, the caller builds in one piece.
+static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, uint32_t n_slices, bool* fallback)
+{
+    v2p_ctx* c = b->ctx;
+    const DevStreamView& v = st->v;
+    *fallback = false;
+    const uint64_t n_tx = v.n_tx, n_h = v.n_haps;
+    const uint32_t K = rows_pick_k(v, mode);
+    const uint64_t n_tiles = n_tx ? (n_tx + K - 1) / K : 1;
+    if (n_tiles >= (1ull << 25)) { *fallback = true; return V2P_OK; }
+    const uint64_t out_bytes = st->out_bytes;
+    const uint64_t n_rows = (out_bytes + ROW_BYTES - 1) / ROW_BYTES, n_segs = (n_rows + ROWS_SEG - 1) / ROWS_SEG;
+    if (n_rows > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 rows in one batch");
+    uint32_t S = n_slices;
+    if (S == 0) {                                     // about 3 GiB of arena per slice: the first slice's build is all that is not overlapped
+        S = uint32_t((out_bytes + (3ull << 30) - 1) / (3ull << 30));
+        if (S < 1) S = 1;
+        if (S > 12) S = 12;
+    }
+    if (S > V2P_MAX_SLICES) S = V2P_MAX_SLICES;
+    while (S > 1 && n_tiles / S < 64) --S;
+    auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
+    // ---- memory: everything before the first kernel (a batch that is rebuilt recycles all of it) ----
+    uint64_t off = 0;
+    auto carve = [&](uint64_t bytes) { const uint64_t o = off; off += up8(bytes); return o; };
+    const uint64_t o_tbytes = carve(n_tiles * 8), o_tbase = carve((n_tiles + 1) * 8), o_tcount = carve((n_tiles + 1) * 4), o_tdbase = carve((n_tiles + 2) * 8),
+                   o_totals = carve(64), o_scan = carve((rows_scan_scratch_entries(n_tiles) + scan_tiles_for(n_tiles + 1)) * 8);
+    HIP_TRY(c, b->d_tiles.ensure_exact(off), "hipMalloc(tile tables)");
+    uint8_t* const d = b->d_tiles.ptr();
+    const uint64_t c_cover = 0, c_segc = up8((n_rows + 1) * 8), c_segb = c_segc + up8((n_segs + 1) * 4), c_tiles = c_segb + up8((n_segs + 2) * 8),
+                   c_cpad = c_tiles + up8(scan_tiles_for(n_segs + 1) * 8), c_end = c_cpad + up8(n_segs * ROWS_CHUNK_PAD * sizeof(Chunk));
+    HIP_TRY(c, b->d_cover.ensure_exact(c_end), "hipMalloc(row map)");
+    uint64_t T[V2P_MAX_SLICES + 1], max_tiles = 0;
+    for (uint32_t j = 0; j <= S; ++j) T[j] = n_tiles * j / S;
+    for (uint32_t j = 0; j < S; ++j) if (T[j + 1] - T[j] > max_tiles) max_tiles = T[j + 1] - T[j];
+    HIP_TRY(c, b->d_pad.ensure_exact(max_tiles * ROWS_PAD_SLOTS * 8), "hipMalloc(padded descriptors)");
+    const uint64_t desc_cap = n_tiles * ROWS_PAD_SLOTS;              // (one-pass tiles hold at most their 256 slots)
+    HIP_TRY(c, b->d_desc.ensure_exact(desc_cap * 8), "hipMalloc(desc)");
+    const uint64_t cap = n_segs ? n_segs * ROWS_CHUNK_PAD : 1;
+    const uint64_t n_blocks_cap = order_blocks_thread_blocks(cap, XCD_ORDER_MAX_BLOCKS);
+    const uint64_t n_sub_cap = uint64_t(XCD_SUB) * n_blocks_cap;
+    const uint64_t s_tmp = 0, s_bucket = s_tmp + up8(cap * 16), s_hist = s_bucket + up8(cap),
+                   s_sub = s_hist + up8((n_blocks_cap + 1) * 8 * 4), s_tmp2 = s_sub + up8(cap), s_bucket2 = s_tmp2 + up8(cap * 16),
+                   s_subhist = s_bucket2 + up8(cap), s_substart = s_subhist + up8(n_sub_cap * 4), s_subtiles = s_substart + up8((n_sub_cap + 1) * 8),
+                   s_tot = s_subtiles + up8(scan_tiles_for(n_sub_cap) * 8), s_end = s_tot + up8(uint64_t(XCD_ORDER_MAX_BLOCKS) * 8 * 4);
+    HIP_TRY(c, b->d_order.ensure_exact(s_end), "hipMalloc(build scratch)");
+    HIP_TRY(c, b->d_chunks.ensure_exact(cap * sizeof(Chunk)), "hipMalloc(chunks)");
+    HIP_TRY(c, b->d_out.ensure((out_bytes + 15) & ~15ull), "hipMalloc(out)");
+    HIP_TRY(c, b->d_hap.ensure((n_h + 1) * 8), "hipMalloc(hap_begin)");
+    HIP_TRY(c, b->d_digest.ensure((n_h ? n_h : 1) * 8), "hipMalloc(digest)");
+    if (!c->build_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking), "hipStreamCreate(build)");
+    for (uint32_t k = 0; k < 2 + 2 * S; ++k) HIP_TRY(c, ensure_event(b->ev_os[k]), "hipEventCreate");
+    hipStream_t A = c->stream, B = c->build_stream;
+    int rc = init_status(c, b->d_status);             // (on A)
+    if (rc) return rc;
+    uint8_t* const sc = b->d_order.ptr();
+    RowsArgs a;
+    rows_args_of(v, c, K, n_tiles, a);
+    a.tile_bytes = reinterpret_cast<uint64_t*>(d + o_tbytes); a.tile_res_base = reinterpret_cast<uint64_t*>(d + o_tbase);
+    a.tile_count = reinterpret_cast<uint32_t*>(d + o_tcount); a.tile_desc_base = reinterpret_cast<uint64_t*>(d + o_tdbase);
+    a.totals = reinterpret_cast<uint64_t*>(d + o_totals);
+    a.status = reinterpret_cast<unsigned long long*>(b->d_status.ptr());
+    uint64_t* const scan_scratch = reinterpret_cast<uint64_t*>(d + o_scan);
+    a.out_bytes = out_bytes; a.n_rows = n_rows; a.n_segs = n_segs;
+    a.cover = reinterpret_cast<uint64_t*>(b->d_cover.ptr() + c_cover);
+    a.seg_count = reinterpret_cast<uint32_t*>(b->d_cover.ptr() + c_segc);
+    a.seg_base = reinterpret_cast<const uint64_t*>(b->d_cover.ptr() + c_segb);
+    a.chunks_pad = reinterpret_cast<Chunk*>(b->d_cover.ptr() + c_cpad);
+    a.hap_out_begin = reinterpret_cast<uint64_t*>(b->d_hap.ptr());
+    a.desc_pad = reinterpret_cast<uint64_t*>(b->d_pad.ptr());
+    a.desc = reinterpret_cast<uint64_t*>(b->d_desc.ptr()); a.desc_cap = desc_cap;
+    Chunk* const chunks_tmp = reinterpret_cast<Chunk*>(sc + s_tmp);
+    uint8_t* const bucket = sc + s_bucket; uint8_t* const sub = sc + s_sub;
+    // the batch describes the image from here on (a failure below resets it)
+    b->n_payload = v.n_alt; b->payload_dev = v.alt; b->out_bytes = out_bytes; b->n_haps = n_h;
+    b->launch_hint = (mode == ROWS_DENSE ? 2 : 4) | 8 | 16 | 32 | (1 << 6) | (1 << 8);
+    auto fail_reset = [&](int code) {
+        (void)hipStreamSynchronize(A); (void)hipStreamSynchronize(B);
+        (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, A);
+        b->img.hap_out_begin.assign(1, 0); b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0; b->payload_dev = nullptr; b->n_slices = 0;
+        return code;
+    };
+#define OS_TRY(expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return fail_reset(c->hip_fail(e__, what)); } while (0)
+    // ---- global tables ----
+    OS_TRY(hipEventRecord(b->ev_os[0], A), "hipEventRecord");
+    OS_TRY(hipStreamWaitEvent(B, b->ev_os[0], 0), "hipStreamWaitEvent");
+    OS_TRY(hipMemsetAsync(d + o_totals, 0, 64, B), "hipMemset(totals)");
+    OS_TRY(launch_rows_tile_bytes(a, scan_scratch, B), "launch(tile bytes)");
+    OS_TRY(launch_rows_hap_begin(a, B), "launch(hap_begin)");
+    uint64_t R[V2P_MAX_SLICES + 1];                                 // arena offset of every slice's first tile
+    for (uint32_t j = 0; j <= S; ++j) OS_TRY(hipMemcpyAsync(&R[j], d + o_tbase + T[j] * 8, 8, hipMemcpyDeviceToHost, B), "D2H(slice offsets)");
+    OS_TRY(hipStreamSynchronize(B), "hipStreamSynchronize");
+    if (R[S] != out_bytes) return fail_reset(c->fail(V2P_ERR_STATE, "the resident stream's tables changed since its upload"));
+    uint64_t SG[V2P_MAX_SLICES + 1];                                // segments [SG_j, SG_j+1) are complete -- their rows' cover entries and the entry of the
+    SG[0] = 0;                                                      // row behind them written -- once slice j is parsed
+    for (uint32_t j = 1; j < S; ++j) { SG[j] = R[j] ? (R[j] - 1) / (uint64_t(ROWS_SEG) * ROW_BYTES) : 0; if (SG[j] < SG[j - 1]) SG[j] = SG[j - 1]; }
+    SG[S] = n_segs;
+    for (uint32_t j = 1; j < S; ++j) if (SG[j] > n_segs) SG[j] = n_segs;
+    const bool reorder = !(c->flags & V2P_FLAG_RESULT_ORDER) && c->proteome_len != 0;
+    uint64_t desc0 = 0, chunk0 = 0;
+    b->os_build_ms = 0.f;
+    for (uint32_t j = 0; j < S; ++j) {
+        a.tile0 = T[j]; a.tile1 = T[j + 1]; a.seg0 = SG[j]; a.seg1 = SG[j + 1];
+        const uint64_t nt = T[j + 1] - T[j], ns = SG[j + 1] - SG[j];
+        OS_TRY(hipEventRecord(b->ev_os[2 + 2 * j], B), "hipEventRecord");
+        if (nt) {
+            OS_TRY(launch_rows_parse(a, mode, v.fasta, 0, B), "launch(parse)");
+            OS_TRY(launch_scan_u32_from(a.tile_count + T[j], nt, a.tile_desc_base + T[j], scan_scratch + rows_scan_scratch_entries(n_tiles), desc0, B), "launch(scan)");
+            OS_TRY(launch_rows_compact(a, B), "launch(compact)");
+        }
+        if (ns) OS_TRY(launch_rows_cut(a, mode, 2, B), "launch(cut)");
+        OS_TRY(launch_scan_u32_from(a.seg_count + SG[j], ns, const_cast<uint64_t*>(a.seg_base) + SG[j], reinterpret_cast<uint64_t*>(b->d_cover.ptr() + c_tiles), chunk0, B), "launch(scan)");
+        uint64_t desc_end = desc0, chunk_end = chunk0, totals[4] = {0, 0, 0, 0};
+        unsigned long long stw = STATUS_CLEAN;
+        if (nt) OS_TRY(hipMemcpyAsync(&desc_end, d + o_tdbase + T[j + 1] * 8, 8, hipMemcpyDeviceToHost, B), "D2H(n_desc)");
+        OS_TRY(hipMemcpyAsync(&chunk_end, b->d_cover.ptr() + c_segb + SG[j + 1] * 8, 8, hipMemcpyDeviceToHost, B), "D2H(n_chunks)");
+        OS_TRY(hipMemcpyAsync(totals, d + o_totals, 32, hipMemcpyDeviceToHost, B), "D2H(totals)");
+        OS_TRY(hipMemcpyAsync(&stw, b->d_status.ptr(), 8, hipMemcpyDeviceToHost, B), "D2H(status)");
+        OS_TRY(hipStreamSynchronize(B), "hipStreamSynchronize");
+        if (stw != STATUS_CLEAN || totals[3] != 0) {
+            const uint32_t reason = stw == STATUS_CLEAN ? 0u : uint32_t(stw & 0xFFu);
+            if (reason == 0u || reason == STATUS_ROWS_STAGE || reason == STATUS_ROWS_TOO_MANY) { *fallback = true; return fail_reset(V2P_OK); }
+            if (reason == STATUS_ROWS_SPAN) return fail_reset(c->fail(V2P_ERR_UNSUPPORTED, "64 consecutive transcripts with more than 2 GiB of result", int64_t(stw >> 8)));
+            const int code = reason_to_err(reason);                  // what the reference would panic on (update_task, Task::execute)
+            return fail_reset(c->fail(code, std::string("device: ") + err_name(code) + " at descriptor " + std::to_string(stw >> 8), int64_t(stw >> 8)));
+        }
+        const uint64_t nd = desc_end - desc0, nc = chunk_end - chunk0;
+        if (chunk_end > 0xFFFFFFFFull) return fail_reset(c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch"));
+        a.chunks_tmp = chunks_tmp;
+        if (ns) OS_TRY(launch_rows_chunk_compact(a, B), "launch(chunk table)");
+        Chunk* const out_chunks = reinterpret_cast<Chunk*>(b->d_chunks.ptr()) + chunk0;
+        if (reorder && nc >= 16 && desc_end != 0) {
+            RowsArgs ak = a;
+            ak.chunks_tmp = chunks_tmp + chunk0; ak.bucket = bucket + chunk0; ak.sub = sub + chunk0;
+            OS_TRY(launch_rows_keys(ak, nc, desc_end, B), "launch(keys)");
+            const uint32_t nb = xcd_order_blocks(ns * uint64_t(ROWS_SEG) * ROW_BYTES, c->proteome_len, nc, XCD_ORDER_MAX_BLOCKS, nd);
+            OS_TRY(launch_order_blocks(ak.chunks_tmp, ak.bucket, ak.sub, nc, nb, reinterpret_cast<uint32_t*>(sc + s_subhist),
+                                       reinterpret_cast<uint64_t*>(sc + s_substart), reinterpret_cast<uint64_t*>(sc + s_subtiles),
+                                       reinterpret_cast<Chunk*>(sc + s_tmp2), sc + s_bucket2, reinterpret_cast<uint32_t*>(sc + s_hist),
+                                       reinterpret_cast<uint32_t*>(sc + s_tot), out_chunks, B), "launch(order)");
+        } else if (nc) OS_TRY(hipMemcpyAsync(out_chunks, chunks_tmp + chunk0, nc * sizeof(Chunk), hipMemcpyDeviceToDevice, B), "D2D(chunks)");
+        OS_TRY(hipEventRecord(b->ev_os[3 + 2 * j], B), "hipEventRecord");
+        // ---- the slice is built: stitch it on the context's stream while the build stream goes on ----
+        OS_TRY(hipStreamWaitEvent(A, b->ev_os[3 + 2 * j], 0), "hipStreamWaitEvent");
+        b->slice_chunk0[j] = chunk0; b->slice_desc[j] = nd; b->slice_bytes[j] = ns * uint64_t(ROWS_SEG) * ROW_BYTES;
+        OS_TRY(stitch_range(b, desc_end, chunk0, nc, nd, b->slice_bytes[j], A), "launch(stitch)");
+        desc0 = desc_end; chunk0 = chunk_end;
+    }
+#undef OS_TRY
+    b->slice_chunk0[S] = chunk0;
+    HIP_TRY(c, hipEventRecord(b->ev_os[1], A), "hipEventRecord");
+    b->n_desc = desc0; b->n_chunks = chunk0; b->n_slices = S;
+    b->img.hap_out_begin = st->hap_out_begin;
+    b->uses_proteome = true;
+    b->finalized = true;
+    return V2P_OK;
+}
+
+int v2p_batch_build_and_execute(v2p_batch* b, const v2p_stream* st, int kernel, uint32_t n_slices)
+{
+    if (!b || !st) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    if (st->ctx != c) return V2P_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized (v2p_batch_reset recycles it)");
+    if (b->hap_open || b->img.n_haplotypes()) return c->fail(V2P_ERR_STATE, "the batch already holds host-built haplotypes");
+    if (kernel != 0 && kernel != 6 && kernel != 7) return c->fail(V2P_ERR_INVALID_ARG, "a resident stream builds rows images: kernel 0 (by the routing rule), 6 or 7");
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    const auto t0 = std::chrono::steady_clock::now();
+    int mode = rows_mode_for(st, kernel);
+    bool fallback = false;
+    int rc = build_and_execute_rows(b, st, mode, n_slices, &fallback);
+    if (rc == V2P_OK && fallback) {
+        // streams the sliced builder does not take: the one-piece builder (its two-pass form, or a dense image), then one execute
+        for (uint32_t k = 0; k < 2; ++k) HIP_TRY(c, ensure_event(b->ev_os[k]), "hipEventCreate");
+        HIP_TRY(c, hipEventRecord(b->ev_os[0], c->stream), "hipEventRecord");
+        float ms = 0.f;
+        rc = build_rows_image(b, st->v, mode, &ms, false);
+        if (rc == V2P_ERR_UNSUPPORTED && kernel == 0 && mode == ROWS_WAVE) { mode = ROWS_DENSE; rc = build_rows_image(b, st->v, mode, &ms, false); }
+        if (rc == V2P_OK) {
+            b->os_build_ms = ms;
+            const hipError_t e = stitch_range(b, b->n_desc, 0, b->n_chunks, 0, 0, c->stream);
+            if (e != hipSuccess) return c->hip_fail(e, "launch(stitch)");
+            HIP_TRY(c, hipEventRecord(b->ev_os[1], c->stream), "hipEventRecord");
+        }
+    }
+    if (rc == V2P_OK) {
+        b->os_kernel = mode == ROWS_DENSE ? 7 : 6;
+        b->os_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return rc;
+}
+
+int v2p_batch_oneshot_info(v2p_batch* b, v2p_oneshot_info* info)
+{
+    if (!b || !info) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!b->finalized || !b->ev_os[0] || !b->ev_os[1] || b->os_kernel == 0) return c->fail(V2P_ERR_STATE, "no v2p_batch_build_and_execute on this batch");
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    HIP_TRY(c, hipEventSynchronize(b->ev_os[1]), "hipEventSynchronize");
+    memset(info, 0, sizeof *info);
+    info->kernel = b->os_kernel; info->n_slices = b->n_slices; info->call_wall_ms = b->os_wall_ms;
+    HIP_TRY(c, hipEventElapsedTime(&info->total_ms, b->ev_os[0], b->ev_os[1]), "hipEventElapsedTime");
+    float sum = 0.f;
+    for (uint32_t j = 0; j < b->n_slices && j < V2P_MAX_SLICES; ++j) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, b->ev_os[2 + 2 * j], b->ev_os[3 + 2 * j]), "hipEventElapsedTime");
+        info->slice_build_ms[j] = ms; sum += ms;
+    }
+    info->build_ms = b->n_slices ? sum : b->os_build_ms;
     return V2P_OK;
 }
 
@@ -1644,6 +2072,7 @@ int v2p_batch_finalize(v2p_batch* b)
     if (b->n_chunks) HIP_TRY(c, hipMemcpyAsync(b->d_chunks.ptr(), b->img.chunks.data(), b->n_chunks * sizeof(Chunk), hipMemcpyHostToDevice, c->stream), "H2D(chunks)");
     if (b->n_payload) HIP_TRY(c, hipMemcpyAsync(b->d_payload.ptr(), b->img.payload.data(), b->n_payload, hipMemcpyHostToDevice, c->stream), "H2D(payload)");
     HIP_TRY(c, hipMemcpyAsync(b->d_hap.ptr(), b->img.hap_out_begin.data(), (b->n_haps + 1) * 8, hipMemcpyHostToDevice, c->stream), "H2D(hap_begin)");
+    b->payload_dev = b->d_payload.ptr();
     int rc = init_status(c, b->d_status);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
@@ -1663,7 +2092,7 @@ int v2p_batch_execute(v2p_batch* b)
     if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     StitchArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), b->n_desc, reinterpret_cast<const Chunk*>(b->d_chunks.ptr()),
-                 uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->d_payload.ptr(), b->n_payload,
+                 uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->payload_dev, b->n_payload,
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
     a.opt_phase_bytes = c->launch_opts.phase_bytes; a.opt_phase_min_chunks = c->launch_opts.phase_min_chunks; a.opt_store_sc1 = c->launch_opts.store_sc1;
     HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint, 0), "launch(stitch)");

@@ -202,6 +202,36 @@ class Context:
     def batch(self) -> "Batch":
         return Batch(self)
 
+    def upload_stream(self, stream) -> "ResidentStream":
+        """v2p_stream_upload: a transcript stream (cohort.TxStream, txstream.HostTxStream: anything with a `.struct` laid out like
+        v2p_txstream) made resident on this context's device -- the input of Batch.build_and_execute / build_from_stream."""
+        return ResidentStream(self, stream)
+
+
+class ResidentStream:
+    def __init__(self, ctx: "Context", stream):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        h = ctypes.c_void_p()
+        ctx._check(self._lib.v2p_stream_upload(ctx._h, ctypes.byref(stream.struct), ctypes.byref(h)))
+        self._h = h
+
+    def counts(self) -> Dict[str, int]:
+        v = [ctypes.c_uint64() for _ in range(4)]
+        self.ctx._check(self._lib.v2p_stream_counts(self._h, *[ctypes.byref(x) for x in v]))
+        return dict(zip(("n_haps", "n_tx", "n_tasks", "out_bytes"), (int(x.value) for x in v)))
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            self._lib.v2p_stream_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 class Batch:
     """Many haplotypes executed per launch from one concatenated device image."""
@@ -299,6 +329,29 @@ class Batch:
         ms = ctypes.c_float(0.0)
         self.ctx._check(self._lib.v2p_batch_build_on_device(self._h, ctypes.byref(stream.struct), window_bytes, kernel, ctypes.byref(ms)))
         return float(ms.value)
+
+    def build_from_stream(self, rs: "ResidentStream", kernel: int = 0) -> float:
+        """v2p_batch_build_from_stream: the one-piece device builder on a resident stream (no H2D).  Returns the build kernels' ms."""
+        ms = ctypes.c_float(0.0)
+        self.ctx._check(self._lib.v2p_batch_build_from_stream(self._h, rs._h, kernel, ctypes.byref(ms)))
+        self._stream_ref = rs                      # (the image's payload descriptors read the stream's alt bytes)
+        return float(ms.value)
+
+    def build_and_execute(self, rs: "ResidentStream", kernel: int = 0, n_slices: int = 0):
+        """v2p_batch_build_and_execute: Task vectors -> result bytes in one call, the image built slice by slice while the slice
+        before it is stitched.  Asynchronous like execute(); sync() collects the status."""
+        self.ctx._check(self._lib.v2p_batch_build_and_execute(self._h, rs._h, kernel, n_slices))
+        self._stream_ref = rs
+
+    def oneshot_info(self) -> dict:
+        info = N.OneShotInfo()
+        self.ctx._check(self._lib.v2p_batch_oneshot_info(self._h, ctypes.byref(info)))
+        return {"kernel": int(info.kernel), "n_slices": int(info.n_slices), "total_ms": float(info.total_ms), "build_ms": float(info.build_ms),
+                "call_wall_ms": float(info.call_wall_ms), "slice_build_ms": [float(info.slice_build_ms[j]) for j in range(int(info.n_slices))]}
+
+    def reset(self):
+        """v2p_batch_reset: back to empty, device buffers kept (the next build recycles them)."""
+        self.ctx._check(self._lib.v2p_batch_reset(self._h))
 
     def download_image(self):
         """(desc, chunks, hap_out_begin) as they sit on the device."""
