@@ -269,7 +269,8 @@ void v2p_stream_destroy(v2p_stream* s);
 int  v2p_stream_counts(const v2p_stream* s, uint64_t* n_haps, uint64_t* n_tx, uint64_t* n_tasks, uint64_t* out_bytes);
 /* the one-piece builder (kernel 6 / 7; 0: by the routing rule, a dense image when a wave image is refused) on a resident stream: no H2D */
 int  v2p_batch_build_from_stream(v2p_batch* b, const v2p_stream* s, int kernel, float* build_ms);
-/* Build AND execute.  kernel: 0 (routing rule), 6 or 7.  n_slices: 0 = about 3 GiB of result per slice (at most 12), else that many
+/* Build AND execute.  kernel: 0 (routing rule), 6 or 7.  n_slices: 0 = ONE slice -- the build, then the stitch (more slices were measured slower on every cohort: the
+ * build of slice j + 1 next to the stitch of slice j takes three times as long, profiles/r05_oneshot_slices.json) --, else that many
  * (<= 32).  Returns when the last slice's stitch kernels are enqueued on the context's stream (like v2p_batch_execute: asynchronous);
  * v2p_batch_sync collects the status.  The batch is finalized: execute / digests / download work as after any build, and the image --
  * descriptors, chunk records, haplotype offsets -- is the one v2p_batch_build_from_stream builds (only the blocks inside which the
@@ -361,7 +362,10 @@ typedef struct {
     uint32_t max_blocks;         /* != 0: cap the grid of the per-block kernel (persistent workgroups); refused for images with
                                   * long-run, dense or wave chunks                                                                  */
     uint32_t variant;            /* 0; 3 = per-block kernel also where the dense one would be picked, 8 = the dense kernel for every
-                                  * per-block chunk (routing-only A/B switches; kernel variants live in libv2p_bench.so)            */
+                                  * per-block chunk (routing-only A/B switches; kernel variants live in libv2p_bench.so).
+                                  * v2p_set_launch_opts only: 16 = ONE launch for all phases of a wave image (read-ahead workgroups of
+                                  * phase g + 1 in the grid before the stitch workgroups of phase g), 17 = the read-ahead as kernels of
+                                  * its own, 18 = no read-ahead -- A/B switches of the phased launcher                             */
 } v2p_launch_opts;
 /* src0/src1 must have 32 readable bytes before and after (the kernel loads whole aligned 16-byte
  * blocks around a task's bytes), and so must d_desc (16 before, 32 after: stitchw_kernel reads an immediate descriptor's literal

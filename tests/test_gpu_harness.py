@@ -148,3 +148,30 @@ def test_harness_vcf_mode_write_compressed(harness, tmp_path):
     for sample, recs in want.items():
         lines = gzip.open(os.path.join(tmp_path, sample + ".fasta.gz"), "rt").read().split("\n")[:-1]
         assert sorted([lines[i][1:], lines[i + 1]] for i in range(0, len(lines), 2)) == sorted(recs), sample
+
+
+@pytest.mark.parametrize("preset,samples,devices", [("C3", 40, 1), ("C3", 40, 3), ("C5", 300, 2), ("C2", 6, 4)])
+def test_sharded_host_mode_in_one_process(harness, gpu_ctx, coracle, preset, samples, devices):
+    """`v2p_harness sharded <preset> <samples> --devices N` (ppgg::execute_sharded: parts/exec.rs:34-40 across the devices of a node,
+    in ONE process -- N contexts, N worker threads, ranges of equal result bytes, one v2p_batch_build_and_execute each; on a
+    one-GPU box the shards share the device): the ranges are shard_by_bytes', the byte offsets the prefix sum of the cohort's result
+    sizes, and every haplotype's digest the oracle's."""
+    from vcf2prot_amd.cohort import Cohort
+    from vcf2prot_amd.shard import shard_by_bytes
+    p = subprocess.run([harness, "sharded", preset, str(samples), "--devices", str(devices), "--oversubscribe", "--threads", "8"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = json.loads(p.stdout.strip().split("\n")[-1])
+    c = Cohort.preset(preset, n_samples=samples)
+    n = c.n_haplotypes
+    sizes = c.result_sizes(0, n)
+    assert out["haplotypes"] == n and out["result_bytes"] == int(sizes.sum()) and len(out["shards"]) == devices
+    ranges = shard_by_bytes(sizes.tolist(), devices)
+    off = 0
+    for r, s in enumerate(out["shards"]):
+        assert (s["h0"], s["h1"]) == ranges[r] and s["byte_offset"] == off and s["bytes"] == int(sizes[s["h0"]:s["h1"]].sum())
+        off += s["bytes"]
+    for h in range(0, n, max(1, n // 64)):
+        hap = c.haplotype(h)
+        t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+        want = coracle.gir_execute_u8(t, c.ref_tape_u32(h).astype(np.uint8), hap.alt, np.full(hap.n_res, ord("."), dtype=np.uint8))
+        assert out["digests"][h] == coracle.digest_u8(want), (preset, h)

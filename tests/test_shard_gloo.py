@@ -83,3 +83,23 @@ def test_two_ranks_over_gloo_tile_the_cohort(built, preset, n_samples):
     glob = hb0[:-1] + [x + bo1 for x in hb1]
     assert glob == [int(x) for x in whole.hap_out_begin]
     assert nt0 + nt1 == whole.n_tasks and nc0 + nc1 == whole.n_copy_bytes
+
+
+def test_cpp_host_cuts_the_ranges_the_python_rule_cuts(built):
+    """ppgg::shard_by_bytes (csrc/host/ppgg_gpu.hpp: the single-process multi-device host mode, `v2p_harness sharded`) against
+    shard.shard_by_bytes on random result sizes incl. empty haplotypes, more ranks than haplotypes, one rank."""
+    import subprocess
+    from vcf2prot_amd import build
+    from vcf2prot_amd.shard import shard_by_bytes
+    harness = build.build_harness()
+    rng = np.random.default_rng(11)
+    for trial in range(25):
+        n = int(rng.integers(0, 300))
+        sizes = rng.integers(0, 5_000_000, size=n)
+        if n:
+            sizes[rng.integers(0, n, size=n // 7)] = 0
+        world = int(rng.choice([1, 2, 3, 5, 8, 16]))
+        p = subprocess.run([harness, "shard", str(world)] + [str(int(x)) for x in sizes], capture_output=True, text=True, timeout=60)
+        assert p.returncode == 0, p.stderr
+        got = [tuple(int(v) for v in ln.split()) for ln in p.stdout.strip().split("\n") if ln]
+        assert got == shard_by_bytes(sizes.tolist(), world), (trial, n, world)

@@ -27,13 +27,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def sclk():
+    """the amdgpu driver's current clock levels (shader, memory, fabric, SoC), where an ordinary user may read them"""
     out = {}
-    for p in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")[:1]:
-        try:
-            cur = [ln.strip() for ln in open(p).read().splitlines() if "*" in ln]
-            out["sclk"] = cur[0] if cur else None
-        except Exception as e:          # noqa: BLE001
-            out["sclk"] = f"unreadable: {e!r}"
+    for name in ("sclk", "mclk", "fclk", "socclk"):
+        for p in glob.glob(f"/sys/class/drm/card*/device/pp_dpm_{name}")[:1]:
+            try:
+                cur = [ln.strip() for ln in open(p).read().splitlines() if "*" in ln]
+                out[name] = cur[0] if cur else None
+            except Exception as e:          # noqa: BLE001
+                out[name] = f"unreadable: {e!r}"
     return out
 
 

@@ -237,9 +237,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
     uint64_t* const out = PHASE == PH_PAD ? a.desc_pad + uint64_t(blockIdx.x) * ROWS_PAD : (PHASE == PH_DIRECT ? a.desc + a.tile_desc_base[tile] : nullptr);
     (void)out;
     const uint32_t out_cap = PHASE == PH_PAD ? ROWS_PAD : 0xFFFFFFFFu;
-    // cover entry: tile : 25 | descriptor inside the tile : 16 | offset inside it : 22 -- the two-pass form: 1 << 63 | descriptor << 22 | offset
+    // cover entry: tile : 25 | descriptor inside the tile : 16 | what the descriptor has from the row's first byte on : 11 | offset of that byte
+    // inside it : 11 (a descriptor is at most 2047 bytes) -- the two-pass form: 1 << 63 | descriptor << 22 | rest << 11 | offset.  With the
+    // rest in the map the cutter never reads a descriptor (round 4 looked every row's up: 2.4 GB of scattered lines) and does not wait
+    // for the compaction.
     const uint64_t dbase = PHASE == PH_DIRECT ? a.tile_desc_base[tile] : 0ull;
-    auto cover_word = [&](uint32_t dk, uint32_t off) -> uint64_t { return PHASE == PH_DIRECT ? (1ull << 63) | ((dbase + dk) << 22) | off : (tile << 38) | (uint64_t(dk) << 22) | off; };
+    auto cover_word = [&](uint32_t dk, uint32_t off, uint32_t rest) -> uint64_t {
+        const uint32_t low = off | (rest << 11);
+        return PHASE == PH_DIRECT ? (1ull << 63) | ((dbase + dk) << 22) | low : (tile << 38) | (uint64_t(dk) << 22) | low;
+    };
 
     uint32_t tile_cnt = 0;                     // descriptors of the tile so far (wave-uniform)
     uint64_t carry_h = 0, carry_second = 0;
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
                 const uint32_t s0 = eoff + q0, rb = ((s0 + ROW_BYTES - 1u) >> 10) << 10;
                 if (has && rb < s0 + rl[RS]) {
                     const uint64_t row = erow + (rb >> 10);
-                    if (row >= 1u && row < a.n_rows) a.cover[row] = cover_word(k, rb - s0);
+                    if (row >= 1u && row < a.n_rows) a.cover[row] = cover_word(k, rb - s0, s0 + rl[RS] - rb);
                 }
             }
             tile_cnt += round_total;
@@ -425,11 +431,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
                 if ((rfirst << 10) < end[NR - 1] && cnt != 0u) {
                     for (uint32_t r = rfirst; (r << 10) < end[NR - 1]; ++r) {              // (one round, rarely more)
                         const uint32_t rb = r << 10;
-                        uint32_t dk = k, st = s0;
+                        uint32_t dk = k, st = s0, en = end[0];
 #pragma unroll
-                        for (int i = 0; i + 1 < NR; ++i) if (rb >= end[i]) { dk += cn[i]; st = end[i]; }
+                        for (int i = 0; i + 1 < NR; ++i) if (rb >= end[i]) { dk += cn[i]; st = end[i]; en = end[i + 1]; }
                         const uint64_t row = erow + r;
-                        if (row >= 1u && row < a.n_rows) a.cover[row] = cover_word(dk, rb - st);
+                        if (row >= 1u && row < a.n_rows) a.cover[row] = cover_word(dk, rb - st, en - rb);
                     }
                 }
             }
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
                         if (k < out_cap) out[k] = dword;
                         for (uint32_t r = (pos + ROW_BYTES - 1u) >> 10; (uint64_t(r) << 10) < uint64_t(pos) + piece; ++r) {
                             const uint64_t row = erow + r;
-                            if (row >= 1u && row < a.n_rows) a.cover[row] = cover_word(k, (r << 10) - pos);
+                            if (row >= 1u && row < a.n_rows) a.cover[row] = cover_word(k, (r << 10) - pos, pos + piece - (r << 10));
                         }
                         if (space == SPACE_PROTEOME || space == SPACE_PAYLOAD) sfield += piece;      // (an immediate is never cut: <= 5 bytes)
                         len -= piece; pos += piece; ++k;
@@ -527,17 +533,10 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
         const uint64_t b = r0, r = b + lane;
         uint64_t c = 0, idx = 0;
         if (r >= 1u && r < a.n_rows) { c = a.cover[r]; idx = (c >> 63) ? (c >> 22) & ((1ull << 41) - 1ull) : a.tile_desc_base[c >> 38] + ((c >> 22) & 0xFFFFu); }
-        const uint32_t off = uint32_t(c) & 0x3FFFFFu;
+        const uint32_t off = uint32_t(c) & PIECE_MAX;
         const uint64_t lastd = r >= a.n_rows ? n_desc - 1u : (off ? idx : idx - 1u);      // last descriptor of a chunk that ends at row r
-        // what a chunk ending at row r leaves of its last descriptor behind the cut -- for all 64 rows at once, not inside the walk (a
-        // dependent load per chunk there made the emitting pass twice as slow as the counting one)
-        uint32_t tc = 0;
-        if (EMIT && r < a.n_rows && off != 0u) {
-            const uint64_t d = a.desc[lastd];
-            const uint32_t dl = (d >> 60) == 0xDull ? uint32_t((d >> 29) & 31u) + uint32_t((d >> 34) & 31u) + uint32_t((d >> 39) & 31u) + 2u
-                              : ((d & SNV3_MARK) == SNV3_MARK ? uint32_t((d >> 29) & 0xFFFu) + 1u + uint32_t((d >> 41) & 0xFFFu) : uint32_t(d >> 40) & LEN_MASK);
-            tc = dl - off;
-        }
+        // what a chunk ending at row r leaves of its last descriptor behind the cut: the parse wrote it into the row map
+        const uint32_t tc = (EMIT && r < a.n_rows && off != 0u) ? (uint32_t(c) >> 11) & PIECE_MAX : 0u;
         uint32_t cur = 0;
         for (;;) {
             const uint64_t f = uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(idx)), int(cur)))) | (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(idx >> 32)), int(cur)))) << 32);

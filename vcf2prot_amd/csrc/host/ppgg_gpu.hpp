@@ -12,9 +12,11 @@
 // turns the same status codes back into panic!().
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdlib>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -170,6 +172,101 @@ void execute(uint64_t n_jobs, int n_threads, int device, MakeGir make_gir, Consu
         });
     for (auto& th : pool) th.join();
     for (const auto& e : errors) if (!e.empty()) throw Panic(V2P_ERR_HIP, e);
+}
+
+// ---- N devices in ONE process -------------------------------------------------------------------------------------------------
+// The reference's host is one process with a Rayon pool (parts/exec.rs:34-40); its natural shape on a node of GPUs is one engine
+// context per device inside that process -- no launcher, no collective: haplotypes are independent units
+// (haplotype_instruction.rs:94-133), the proteome is replicated, every device builds and executes a contiguous range of
+// haplotypes and the cohort-wide offsets are a prefix sum the host already knows.
+
+// contiguous haplotype ranges of equal result bytes -- the prefix sum cut at its k / world quantiles (the rule of
+// vcf2prot_amd/shard.py::shard_by_bytes, in exact integer arithmetic: haplotype h goes to the left of cut k while the middle of
+// its bytes lies before total * k / world)
+inline std::vector<std::pair<uint64_t, uint64_t>> shard_by_bytes(const std::vector<uint64_t>& result_bytes, int world)
+{
+    if (world < 1) throw std::invalid_argument("world < 1");
+    unsigned __int128 total = 0;
+    for (uint64_t b : result_bytes) total += b;
+    std::vector<uint64_t> cuts{0};
+    unsigned __int128 acc = 0;
+    uint64_t h = 0;
+    const uint64_t n = result_bytes.size();
+    for (int k = 1; k < world; ++k) {
+        while (h < n && (2 * acc + result_bytes[h]) * unsigned(world) < 2 * total * unsigned(k)) { acc += result_bytes[h]; ++h; }
+        cuts.push_back(h);
+    }
+    cuts.push_back(n);
+    std::vector<std::pair<uint64_t, uint64_t>> out;
+    for (int r = 0; r < world; ++r) out.emplace_back(cuts[size_t(r)], cuts[size_t(r) + 1]);
+    return out;
+}
+
+struct DeviceShard {
+    int rank = 0, device = 0;
+    uint64_t h0 = 0, h1 = 0;                   // haplotypes [h0, h1) of the cohort
+    uint64_t byte_offset = 0, bytes = 0;       // the shard's arena inside the cohort-wide result (prefix sum over the shards before it)
+    double seconds = 0;                        // v2p_batch_build_and_execute + sync on this device (the stream already resident)
+    float oneshot_ms = 0;                      // ... by HIP events
+};
+
+// One worker thread per entry of `devices` (a device may appear more than once: its shards then share it), each with its own
+// context: proteome upload, make_stream(h0, h1) -> the range's transcript stream (a shared_ptr that keeps its arrays alive),
+// v2p_stream_upload, ONE v2p_batch_build_and_execute, sync, then consume(shard, ctx, batch) on the worker thread (digests,
+// download, file writes).  Throws Panic with the first shard's error.
+template <class MakeStream, class Consume>
+std::vector<DeviceShard> execute_sharded(const std::vector<uint64_t>& hap_bytes, const std::vector<int>& devices,
+                                         const uint8_t* proteome, uint64_t proteome_len, MakeStream make_stream, Consume consume)
+{
+    const int world = int(devices.size());
+    const auto ranges = shard_by_bytes(hap_bytes, world);
+    std::vector<DeviceShard> shards;
+    shards.resize(size_t(world));
+    uint64_t off = 0;
+    for (int r = 0; r < world; ++r) {
+        DeviceShard& s = shards[size_t(r)];
+        s.rank = r; s.device = devices[size_t(r)]; s.h0 = ranges[size_t(r)].first; s.h1 = ranges[size_t(r)].second; s.byte_offset = off;
+        for (uint64_t h = s.h0; h < s.h1; ++h) s.bytes += hap_bytes[h];
+        off += s.bytes;
+    }
+    std::vector<std::string> errors;
+    errors.resize(size_t(world));
+    std::vector<int> codes;
+    codes.resize(size_t(world), 0);
+    std::vector<std::thread> pool;
+    for (int r = 0; r < world; ++r)
+        pool.emplace_back([&, r] {
+            DeviceShard& s = shards[size_t(r)];
+            try {
+                GpuContext ctx(s.device);
+                auto fail = [&](int rc) { throw Panic(rc, v2p_last_error(ctx.raw()), v2p_last_error_index(ctx.raw())); };
+                int rc = v2p_upload_proteome(ctx.raw(), proteome, proteome_len);
+                if (rc != V2P_OK) fail(rc);
+                std::shared_ptr<const v2p_txstream> host = make_stream(s.h0, s.h1);
+                v2p_stream* rs = nullptr;
+                if ((rc = v2p_stream_upload(ctx.raw(), host.get(), &rs)) != V2P_OK) fail(rc);
+                host.reset();
+                v2p_batch* b = nullptr;
+                if ((rc = v2p_batch_create(ctx.raw(), &b)) != V2P_OK) { v2p_stream_destroy(rs); fail(rc); }
+                const auto t0 = std::chrono::steady_clock::now();
+                rc = v2p_batch_build_and_execute(b, rs, 0, 0);
+                if (rc == V2P_OK) rc = v2p_batch_sync(b);
+                s.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (rc != V2P_OK) { const std::string m = v2p_last_error(ctx.raw()); const int64_t i = v2p_last_error_index(ctx.raw()); v2p_batch_destroy(b); v2p_stream_destroy(rs); throw Panic(rc, m, i); }
+                v2p_oneshot_info info;
+                if (v2p_batch_oneshot_info(b, &info) == V2P_OK) s.oneshot_ms = info.total_ms;
+                uint64_t out_bytes = 0;
+                v2p_batch_counts(b, nullptr, nullptr, nullptr, &out_bytes, nullptr);
+                if (out_bytes != s.bytes) { v2p_batch_destroy(b); v2p_stream_destroy(rs); throw Panic(V2P_ERR_STATE, "a shard's arena is not the sum of its haplotypes' result sizes"); }
+                consume(s, ctx.raw(), b);
+                v2p_batch_destroy(b);
+                v2p_stream_destroy(rs);
+            } catch (const Panic& p) { errors[size_t(r)] = p.what(); codes[size_t(r)] = p.code; }
+            catch (const std::exception& e) { errors[size_t(r)] = e.what(); codes[size_t(r)] = V2P_ERR_HIP; }
+        });
+    for (auto& th : pool) th.join();
+    for (int r = 0; r < world; ++r) if (!errors[size_t(r)].empty()) throw Panic(codes[size_t(r)], "shard " + std::to_string(r) + ": " + errors[size_t(r)]);
+    return shards;
 }
 
 }  // namespace ppgg

@@ -7,6 +7,10 @@
 //   v2p_harness kat                          reference known-answer tests through the mirror
 //   v2p_harness run <preset> <haps> <threads>   e.g. run C2 64 8
 //   v2p_harness vcf <in.vcf> <reference.fasta> <outdir> [--no-test] [-a] [-c]   VCF -> one FASTA(.gz) per proband, no Rust anywhere
+//   v2p_harness sharded <preset> <samples> --devices N [--oversubscribe] [--threads T]
+//                                            the cohort over N devices in THIS process (ppgg::execute_sharded): N contexts, N worker
+//                                            threads, ranges of equal result bytes, one v2p_batch_build_and_execute each
+//   v2p_harness shard <world> <bytes...>     the ranges ppgg::shard_by_bytes cuts (no GPU)
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -450,6 +454,66 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// sharded: parts/exec.rs:34-40 over the devices of one node, in one process (ppgg::execute_sharded)
+static int sharded(const char* preset, uint32_t samples, int n_devices, bool oversubscribe, int threads)
+{
+    v2p_cohort_params p;
+    if (v2p_cohort_preset(preset, &p)) { std::fprintf(stderr, "unknown preset %s\n", preset); return 2; }
+    if (samples) p.n_samples = samples;
+    v2p_cohort* c = nullptr;
+    if (v2p_cohort_create(&p, &c)) return 2;
+    const uint64_t n_haps = v2p_cohort_n_haplotypes(c);
+    const int have = v2p_device_count();
+    if (have <= 0) { std::fprintf(stderr, "no HIP device: the gpu engine has no CPU fallback\n"); return 1; }
+    if (n_devices > have && !oversubscribe) { std::fprintf(stderr, "%d devices asked for, %d present (--oversubscribe shares them)\n", n_devices, have); return 2; }
+    std::vector<int> devices;
+    for (int d = 0; d < n_devices; ++d) devices.push_back(d % have);
+    std::vector<uint64_t> sizes(n_haps);
+    if (v2p_cohort_result_sizes(c, 0, n_haps, threads, sizes.data())) return 2;
+    std::vector<uint64_t> digest(n_haps, 0);
+    const int per = threads / n_devices > 0 ? threads / n_devices : 1;
+    auto make_stream = [&](uint64_t h0, uint64_t h1) -> std::shared_ptr<const v2p_txstream> {
+        struct Owned { v2p_txstream_buf buf; v2p_txstream view; };
+        auto o = std::shared_ptr<Owned>(new Owned(), [](Owned* q) { v2p_txstream_free(&q->buf); delete q; });
+        if (v2p_cohort_txstream(c, h0, h1, per, &o->buf)) throw std::runtime_error("v2p_cohort_txstream failed");
+        const v2p_txstream_buf& b = o->buf;
+        o->view = v2p_txstream{b.n_haps, b.n_tx, b.n_tasks, b.n_alt, b.hap_tx_begin, b.tx_proteome_off, b.tx_ref_len, b.tx_res_len, b.tx_task_begin, b.tx_alt_begin,
+                               b.code, b.start_pos, b.length, b.start_pos_res, b.alt, b.tx_header_off, b.tx_header_len};
+        return std::shared_ptr<const v2p_txstream>(o, &o->view);
+    };
+    auto consume = [&](const DeviceShard& s, v2p_ctx* ctx, v2p_batch* b) {
+        // the shard's haplotypes sit in its arena at the offsets the cohort-wide prefix sum gives them, minus the shard's own
+        uint64_t at = 0;
+        for (uint64_t h = s.h0; h < s.h1; ++h) {
+            uint64_t begin = 0, len = 0;
+            if (v2p_batch_hap_range(b, h - s.h0, &begin, &len) != V2P_OK || begin != at || len != sizes[h]) throw Panic(V2P_ERR_STATE, "haplotype range of a shard disagrees with the cohort's result sizes");
+            at += len;
+        }
+        if (s.h1 > s.h0 && v2p_batch_digests(b, digest.data() + s.h0, s.h1 - s.h0) != V2P_OK) throw Panic(V2P_ERR_HIP, v2p_last_error(ctx));
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<DeviceShard> shards;
+    try { shards = execute_sharded(sizes, devices, v2p_cohort_proteome(c), v2p_cohort_proteome_len(c), make_stream, consume); }
+    catch (const Panic& e) { std::fprintf(stderr, "panicked: %s\n", e.what()); return 101; }
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    uint64_t total = 0;
+    for (uint64_t b : sizes) total += b;
+    std::printf("{\"mode\": \"sharded: %d device context(s) in one process, ranges of equal result bytes, one v2p_batch_build_and_execute each\", \"preset\": \"%s\", "
+                "\"samples\": %u, \"haplotypes\": %llu, \"result_bytes\": %llu, \"devices_present\": %d, \"wall_seconds_incl_generation_and_upload\": %.6f, \"shards\": [",
+                n_devices, preset, p.n_samples, (unsigned long long)n_haps, (unsigned long long)total, have, secs);
+    for (size_t r = 0; r < shards.size(); ++r) {
+        const DeviceShard& s = shards[r];
+        std::printf("%s{\"rank\": %d, \"device\": %d, \"h0\": %llu, \"h1\": %llu, \"byte_offset\": %llu, \"bytes\": %llu, \"seconds\": %.6f, \"oneshot_ms\": %.4f}", r ? ", " : "",
+                    s.rank, s.device, (unsigned long long)s.h0, (unsigned long long)s.h1, (unsigned long long)s.byte_offset, (unsigned long long)s.bytes, s.seconds, double(s.oneshot_ms));
+    }
+    std::printf("], \"digests\": [");
+    for (uint64_t h = 0; h < n_haps; ++h) std::printf("%s%llu", h ? ", " : "", (unsigned long long)digest[h]);
+    std::printf("]}\n");
+    v2p_cohort_destroy(c);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc >= 5 && !std::strcmp(argv[1], "vcf")) {
@@ -463,10 +527,28 @@ int main(int argc, char** argv)
         try { return vcf_mode(argv[2], argv[3], argv[4], no_test, write_all, compressed, host_build); }
         catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 101; }
     }
+    if (argc >= 3 && !std::strcmp(argv[1], "shard")) {              // the cut rule alone (no GPU): one "begin end" line per rank
+        std::vector<uint64_t> sizes;
+        for (int i = 3; i < argc; ++i) sizes.push_back(std::strtoull(argv[i], nullptr, 10));
+        for (const auto& r : shard_by_bytes(sizes, std::atoi(argv[2]))) std::printf("%llu %llu\n", (unsigned long long)r.first, (unsigned long long)r.second);
+        return 0;
+    }
+    if (argc >= 4 && !std::strcmp(argv[1], "sharded")) {
+        int n_devices = 1, threads = int(std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 8);
+        bool over = false;
+        for (int i = 4; i < argc; ++i) {
+            if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) n_devices = std::atoi(argv[++i]);
+            else if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = std::atoi(argv[++i]);
+            else if (!std::strcmp(argv[i], "--oversubscribe")) over = true;
+        }
+        if (n_devices < 1 || n_devices > 64) { std::fprintf(stderr, "--devices 1 .. 64\n"); return 2; }
+        if (threads > 64) threads = 64;
+        return sharded(argv[2], uint32_t(std::strtoul(argv[3], nullptr, 10)), n_devices, over, threads);
+    }
     if (argc >= 2 && !std::strcmp(argv[1], "kat")) return kat();
     if (argc >= 5 && !std::strcmp(argv[1], "run"))
         return run(argv[2], std::strtoull(argv[3], nullptr, 10), std::atoi(argv[4]), argc >= 6 && (!std::strcmp(argv[5], "--shared") || !std::strcmp(argv[5], "--async")),
                    argc >= 6 && !std::strcmp(argv[5], "--async"));
-    std::fprintf(stderr, "usage: v2p_harness kat | run <preset> <haplotypes> <threads> [--shared | --async]\n");
+    std::fprintf(stderr, "usage: v2p_harness kat | run <preset> <haplotypes> <threads> [--shared | --async] | sharded <preset> <samples> --devices N [--oversubscribe] | shard <world> <bytes...>\n");
     return 2;
 }

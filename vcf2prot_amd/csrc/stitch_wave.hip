@@ -403,7 +403,13 @@ hipError_t launch_stitch_wave(const StitchArgs& a, hipStream_t stream, bool nt, 
         const uint32_t P = a.phase_chunks, tw = 8u * touch_waves_per_xcd(P);
         const uint64_t groups = (uint64_t(a.n_chunks) + P - 1u) / P, grid = groups * (uint64_t(tw) + P);
         if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
-        if (a.rows) return hipErrorInvalidValue;                     // (one launch for all phases is an A/B switch of host-packed images)
+        if (a.rows) {                                                // (an A/B switch: v2p_set_launch_opts, variant 16)
+            if (nt) hipLaunchKernelGGL((stitchw_kernel<1, true, false, true>), dim3(uint32_t(grid)), dim3(64), 0, stream, a.desc, a.chunks, a.src0, a.src1, a.out, a.status, a.dots,
+                                       a.n_chunks, a.n_desc, a.src0_len, a.src1_len, a.out_len, nullptr, 0u, P);
+            else hipLaunchKernelGGL((stitchw_kernel<1, false, false, true>), dim3(uint32_t(grid)), dim3(64), 0, stream, a.desc, a.chunks, a.src0, a.src1, a.out, a.status, a.dots,
+                                    a.n_chunks, a.n_desc, a.src0_len, a.src1_len, a.out_len, nullptr, 0u, P);
+            return hipGetLastError();
+        }
         if (nt) hipLaunchKernelGGL((stitchw_kernel<1, true>), dim3(uint32_t(grid)), dim3(64), 0, stream, a.desc, a.chunks, a.src0, a.src1, a.out, a.status, a.dots,
                                    a.n_chunks, a.n_desc, a.src0_len, a.src1_len, a.out_len, nullptr, 0u, P);
         else hipLaunchKernelGGL((stitchw_kernel<1, false>), dim3(uint32_t(grid)), dim3(64), 0, stream, a.desc, a.chunks, a.src0, a.src1, a.out, a.status, a.dots,

@@ -116,7 +116,7 @@ struct v2p_ctx {
     int device = 0;
     unsigned flags = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipStream_t build_stream = nullptr;               // v2p_batch_build_and_execute: the image is built here while the context's stream stitches
+    hipStream_t build_stream = nullptr, aux_stream = nullptr;   // v2p_batch_build_and_execute: the image is built here (aux: its compaction, next to the cutter) while the context's stream stitches
     mutable std::mutex mu;
     std::string err;
     int64_t err_index = -1;
@@ -157,6 +157,7 @@ struct v2p_batch {
     uint64_t slice_chunk0[V2P_MAX_SLICES + 1] = {};
     uint64_t slice_desc[V2P_MAX_SLICES] = {}, slice_bytes[V2P_MAX_SLICES] = {};
     hipEvent_t ev_os[2 + 2 * V2P_MAX_SLICES] = {};
+    hipEvent_t ev_aux[2] = {};
     float os_build_ms = 0.f;
     double os_wall_ms = 0.0;
     int os_kernel = 0;
@@ -259,6 +260,7 @@ void v2p_destroy(v2p_ctx* c)
     c->h_stage.release(); c->h_in.release();
     queue_destroy(c);
     if (c->build_stream) (void)hipStreamDestroy(c->build_stream);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -954,7 +956,9 @@ void v2p_batch_destroy(v2p_batch* b)
     b->d_hap.release(); b->d_digest.release(); b->d_status.release(); b->d_build.release();
     b->d_tiles.release(); b->d_cover.release(); b->d_pad.release(); b->d_order.release();
     if (b->ctx->build_stream) (void)hipStreamSynchronize(b->ctx->build_stream);
+    if (b->ctx->aux_stream) (void)hipStreamSynchronize(b->ctx->aux_stream);
     for (hipEvent_t e : b->ev_os) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : b->ev_aux) if (e) (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -1771,6 +1775,10 @@ int v2p_batch_build_from_stream(v2p_batch* b, const v2p_stream* st, int kernel, 
     return rc;
 }
 
+// v2p_set_launch_opts: variant 16 / 17 / 18 = how a context's phased wave images are launched (A/B switches: tools/phase_ab.py):
+// ONE launch for all phases / the read-ahead as kernels of its own / no read-ahead
+static uint32_t touch_of(uint32_t variant) { return variant == 16u ? 4u : (variant == 17u ? 2u : (variant == 18u ? 1u : 0u)); }
+
 static hipError_t ensure_event(hipEvent_t& e) { return e ? hipSuccess : hipEventCreate(&e); }
 
 // One slice's share of launch_stitch's routing (phases, store policy) follows the slice, not the table it is a range of
@@ -1782,6 +1790,7 @@ static hipError_t stitch_range(v2p_batch* b, uint64_t desc_bound, uint64_t chunk
                  uint32_t(n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->payload_dev, b->n_payload,
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
     a.opt_phase_bytes = c->launch_opts.phase_bytes; a.opt_phase_min_chunks = c->launch_opts.phase_min_chunks; a.opt_store_sc1 = c->launch_opts.store_sc1;
+    a.opt_touch = touch_of(c->launch_opts.variant);
     a.img_desc = img_desc; a.img_bytes = img_bytes;
     return launch_stitch(a, stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint, 0);
 }
@@ -1806,12 +1815,10 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     const uint64_t out_bytes = st->out_bytes;
     const uint64_t n_rows = (out_bytes + ROW_BYTES - 1) / ROW_BYTES, n_segs = (n_rows + ROWS_SEG - 1) / ROWS_SEG;
     if (n_rows > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 rows in one batch");
-    uint32_t S = n_slices;
-    if (S == 0) {                                     // about 3 GiB of arena per slice: the first slice's build is all that is not overlapped
-        S = uint32_t((out_bytes + (3ull << 30) - 1) / (3ull << 30));
-        if (S < 1) S = 1;
-        if (S > 12) S = 12;
-    }
+    // (n_slices = 0: ONE slice.  Slices were built to overlap the build of slice j + 1 with the stitch of slice j; measured on C3 whole and
+    // C2 -- profiles/r05_oneshot_slices.json -- every added slice costs: a slice's build takes three times as long next to a running
+    // stitch (cold stream reads between its stores, the effect of DESIGN.md section 3) and the stitch slows down as well.)
+    uint32_t S = n_slices ? n_slices : 1u;
     if (S > V2P_MAX_SLICES) S = V2P_MAX_SLICES;
     while (S > 1 && n_tiles / S < 64) --S;
     auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
@@ -1844,8 +1851,10 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     HIP_TRY(c, b->d_hap.ensure((n_h + 1) * 8), "hipMalloc(hap_begin)");
     HIP_TRY(c, b->d_digest.ensure((n_h ? n_h : 1) * 8), "hipMalloc(digest)");
     if (!c->build_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking), "hipStreamCreate(build)");
+    if (!c->aux_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking), "hipStreamCreate(aux)");
     for (uint32_t k = 0; k < 2 + 2 * S; ++k) HIP_TRY(c, ensure_event(b->ev_os[k]), "hipEventCreate");
-    hipStream_t A = c->stream, B = c->build_stream;
+    for (hipEvent_t& e : b->ev_aux) HIP_TRY(c, ensure_event(e), "hipEventCreate");
+    hipStream_t A = c->stream, B = c->build_stream, X = c->aux_stream;
     int rc = init_status(c, b->d_status);             // (on A)
     if (rc) return rc;
     uint8_t* const sc = b->d_order.ptr();
@@ -1870,7 +1879,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     b->n_payload = v.n_alt; b->payload_dev = v.alt; b->out_bytes = out_bytes; b->n_haps = n_h;
     b->launch_hint = (mode == ROWS_DENSE ? 2 : 4) | 8 | 16 | 32 | (1 << 6) | (1 << 8);
     auto fail_reset = [&](int code) {
-        (void)hipStreamSynchronize(A); (void)hipStreamSynchronize(B);
+        (void)hipStreamSynchronize(A); (void)hipStreamSynchronize(B); (void)hipStreamSynchronize(X);
         (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, A);
         b->img.hap_out_begin.assign(1, 0); b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0; b->payload_dev = nullptr; b->n_slices = 0;
         return code;
@@ -1901,7 +1910,12 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
         if (nt) {
             OS_TRY(launch_rows_parse(a, mode, v.fasta, 0, B), "launch(parse)");
             OS_TRY(launch_scan_u32_from(a.tile_count + T[j], nt, a.tile_desc_base + T[j], scan_scratch + rows_scan_scratch_entries(n_tiles), desc0, B), "launch(scan)");
-            OS_TRY(launch_rows_compact(a, B), "launch(compact)");
+            // the compaction (a copy at the memory's rate) on a stream of its own, next to the cutter (one wave per 640 rows: latency), the
+            // scan of its counts and the host's round trip for them: the cutter reads the row map alone, only the keys need the descriptors
+            OS_TRY(hipEventRecord(b->ev_aux[0], B), "hipEventRecord");
+            OS_TRY(hipStreamWaitEvent(X, b->ev_aux[0], 0), "hipStreamWaitEvent");
+            OS_TRY(launch_rows_compact(a, X), "launch(compact)");
+            OS_TRY(hipEventRecord(b->ev_aux[1], X), "hipEventRecord");
         }
         if (ns) OS_TRY(launch_rows_cut(a, mode, 2, B), "launch(cut)");
         OS_TRY(launch_scan_u32_from(a.seg_count + SG[j], ns, const_cast<uint64_t*>(a.seg_base) + SG[j], reinterpret_cast<uint64_t*>(b->d_cover.ptr() + c_tiles), chunk0, B), "launch(scan)");
@@ -1923,6 +1937,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
         if (chunk_end > 0xFFFFFFFFull) return fail_reset(c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch"));
         a.chunks_tmp = chunks_tmp;
         if (ns) OS_TRY(launch_rows_chunk_compact(a, B), "launch(chunk table)");
+        if (nt) OS_TRY(hipStreamWaitEvent(B, b->ev_aux[1], 0), "hipStreamWaitEvent");      // (the descriptors are in place)
         Chunk* const out_chunks = reinterpret_cast<Chunk*>(b->d_chunks.ptr()) + chunk0;
         if (reorder && nc >= 16 && desc_end != 0) {
             RowsArgs ak = a;
@@ -2095,6 +2110,7 @@ int v2p_batch_execute(v2p_batch* b)
                  uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->payload_dev, b->n_payload,
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
     a.opt_phase_bytes = c->launch_opts.phase_bytes; a.opt_phase_min_chunks = c->launch_opts.phase_min_chunks; a.opt_store_sc1 = c->launch_opts.store_sc1;
+    a.opt_touch = touch_of(c->launch_opts.variant);
     HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint, 0), "launch(stitch)");
     return V2P_OK;
 }

@@ -103,10 +103,11 @@ class Context:
     def set_stream(self, hip_stream: int):
         self._check(self._lib.v2p_set_stream(self._h, ctypes.c_void_p(hip_stream)))
 
-    def set_launch_opts(self, phase_bytes: int = 0, phase_min_chunks: int = 0, store_sc1: int = -1):
+    def set_launch_opts(self, phase_bytes: int = 0, phase_min_chunks: int = 0, store_sc1: int = -1, variant: int = 0):
         """Phase size / phase threshold / store policy of every batch this context executes from now on (A/B runs, tests); no arguments:
-        the library's defaults (v2p_set_launch_opts)."""
-        o = N.LaunchOpts(1, 0, phase_bytes, phase_min_chunks, store_sc1, 0, 0)
+        the library's defaults (v2p_set_launch_opts).  variant 16 / 17 / 18: one launch for all phases / the read-ahead as kernels of
+        its own / no read-ahead."""
+        o = N.LaunchOpts(1, 0, phase_bytes, phase_min_chunks, store_sc1, 0, variant)
         self._check(self._lib.v2p_set_launch_opts(self._h, ctypes.byref(o)))
 
     def upload_proteome(self, aa: np.ndarray):
