@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--samples", type=int, default=10000)
     ap.add_argument("--phases", type=int, nargs="*", default=[20, 24, 28, 32, 40, 64])
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--all-forms", action="store_true", help="with --launch-forms: also one launch for all phases, own read-ahead kernels, no read-ahead")
     ap.add_argument("--launch-forms", action="store_true", help="A/B of the phased launcher's forms (v2p_set_launch_opts variant 16 / 17 / 18) instead of the store policy")
     a = ap.parse_args()
     import torch
@@ -41,7 +42,7 @@ def main():
         ctx.set_stream(ts.cuda_stream)
         variants = [("default", {})] + [(f"phase={p},sc1={s}", dict(phase_bytes=p << 20, store_sc1=s)) for p in a.phases for s in (0, 1)]
         if a.launch_forms:      # the launcher's forms on this (rows) image: one launch for all phases, own read-ahead kernels, no read-ahead
-            variants = [("default", {})] + [(f"{name},phase={p}", dict(phase_bytes=p << 20, variant=v)) for name, v in (("one_launch", 16), ("own_touch", 17), ("no_touch", 18), ("ride", 0))
+            variants = [("default", {})] + [(f"{name},phase={p}", dict(phase_bytes=p << 20, variant=v)) for name, v in (("dual", 19), ("ride", 0)) + ((("one_launch", 16), ("own_touch", 17), ("no_touch", 18)) if a.all_forms else ())
                                             for p in a.phases]
         for _ in range(6):
             b.execute()

@@ -41,6 +41,12 @@ struct StitchArgs {
     uint32_t        rows = 0;                // set by launch_stitch(): a rows image (sir_pack.hpp: every chunk carries CHUNK_CLIP) -- stitchw_kernel's ROWS instance
     uint64_t        img_desc = 0, img_bytes = 0; // the chunk table is a RANGE of a larger image (v2p_batch_build_and_execute: one slice): descriptors and result
                                              // bytes of the range, for the routing (0: n_desc, out_len)
+    // two launch streams (set by the batch's execute): a pure wave image's phases are cut in halves that alternate between `stream` and
+    // `aux_stream`, staggered by half a piece -- while one stream's kernel drains and the next one's waves ramp up, the other stream's
+    // kernel is in mid-flight and takes the freed wave slots (launch_stitch: "dual"); nullptr: one stream
+    hipStream_t     aux_stream = nullptr;
+    hipEvent_t      ev_fork = nullptr, ev_join = nullptr;
+    uint32_t        opt_dual = 0;            // 1: use them
     uint32_t        phase_chunks = 0;        // set by launch_stitch(): != 0 -- ONE wave launch for all phases of that many chunks, the read-ahead
                                              // workgroups of phase g + 1 placed in the grid before the stitch workgroups of phase g
 };

@@ -24,6 +24,8 @@
 //                   predicate of gir.rs:208-226 (wave ballot + one atomicMin per wave).
 //   digest_kernel   per-haplotype position-sensitive checksum of the result arena.
 #include <hip/hip_runtime.h>
+#include <utility>
+#include <vector>
 #include <stdint.h>
 #include <stdlib.h>
 #include <mutex>
@@ -1310,6 +1312,37 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
         hipLaunchKernelGGL(touch_image_kernel, dim3(8u * ((touch_waves_per_xcd(n0) + 3u) / 4u)), dim3(256), 0, stream, a.desc, a.chunks, n0, a.n_desc, a.src1, a.src1_len);
         a.phase_chunks = uint32_t(per);
         return launch_stitch_range(a, stream, nontemporal, 0);
+    }
+    if (ride && wsel == 0 && a.opt_dual && a.aux_stream && a.ev_fork && a.ev_join && args.n_chunks >= 4u * per) {
+        // DUAL: pieces of half a phase alternate between two streams.  A stream's kernel boundary (the drain of its last waves -- a wave
+        // lives about 17 us of a 126 us phase -- and the ramp of the next kernel's first ones) then falls into the other stream's
+        // mid-flight, which takes the freed wave slots; in flight at any time: two half-phases' image, as much as one phase before.  The
+        // read-ahead rides as before, on the trailing workgroups of the piece two back (the one before it on the same stream).
+        const uint64_t half = (per / 2u) & ~7ull;
+        std::vector<std::pair<uint64_t, uint32_t>> pieces;                            // (first chunk, chunks)
+        for (uint64_t c0 = 0; c0 < args.n_chunks; ) {
+            uint64_t nc = pieces.size() == 1u ? (half / 2u) & ~7ull : half;           // (the second stream's first piece is half as long: the stagger)
+            if (nc == 0u) nc = 8u;
+            if (nc > args.n_chunks - c0) nc = args.n_chunks - c0;
+            pieces.emplace_back(c0, uint32_t(nc));
+            c0 += nc;
+        }
+        err = hipEventRecord(a.ev_fork, stream);
+        if (err == hipSuccess) err = hipStreamWaitEvent(a.aux_stream, a.ev_fork, 0);
+        if (err != hipSuccess) return err;
+        for (size_t i = 0; i < pieces.size(); ++i) {
+            hipStream_t s = (i & 1u) ? a.aux_stream : stream;
+            a.chunks = args.chunks + pieces[i].first;
+            a.n_chunks = pieces[i].second;
+            a.next_chunks = nullptr; a.n_next = 0;
+            if (i + 2u < pieces.size()) { a.next_chunks = args.chunks + pieces[i + 2u].first; a.n_next = pieces[i + 2u].second; }
+            if (i < 2u) hipLaunchKernelGGL(touch_image_kernel, dim3(8u * ((touch_waves_per_xcd(a.n_chunks) + 3u) / 4u)), dim3(256), 0, s, a.desc, a.chunks, a.n_chunks, a.n_desc, a.src1, a.src1_len);
+            err = launch_stitch_range(a, s, nontemporal, 0);
+            if (err != hipSuccess) return err;
+        }
+        err = hipEventRecord(a.ev_join, a.aux_stream);
+        if (err == hipSuccess) err = hipStreamWaitEvent(stream, a.ev_join, 0);
+        return err != hipSuccess ? err : hipGetLastError();
     }
     for (uint64_t c0 = 0; c0 < args.n_chunks; c0 += per) {
         const uint32_t nc = uint32_t(args.n_chunks - c0 < per ? args.n_chunks - c0 : per);

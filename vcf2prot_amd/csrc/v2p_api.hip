@@ -116,6 +116,8 @@ struct v2p_ctx {
     int device = 0;
     unsigned flags = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t exec_aux = nullptr;                    // the second launch stream of dual-stream phases
+    hipEvent_t ev_exec[2] = {nullptr, nullptr};
     hipStream_t build_stream = nullptr, aux_stream = nullptr;   // v2p_batch_build_and_execute: the image is built here (aux: its compaction, next to the cutter) while the context's stream stitches
     mutable std::mutex mu;
     std::string err;
@@ -259,6 +261,8 @@ void v2p_destroy(v2p_ctx* c)
     c->d_desc.release(); c->d_chunks.release(); c->d_soa.release(); c->d_status.release();
     c->h_stage.release(); c->h_in.release();
     queue_destroy(c);
+    if (c->exec_aux) { (void)hipStreamSynchronize(c->exec_aux); (void)hipStreamDestroy(c->exec_aux); }
+    for (hipEvent_t e : c->ev_exec) if (e) (void)hipEventDestroy(e);
     if (c->build_stream) (void)hipStreamDestroy(c->build_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1779,6 +1783,15 @@ int v2p_batch_build_from_stream(v2p_batch* b, const v2p_stream* st, int kernel, 
 // ONE launch for all phases / the read-ahead as kernels of its own / no read-ahead
 static uint32_t touch_of(uint32_t variant) { return variant == 16u ? 4u : (variant == 17u ? 2u : (variant == 18u ? 1u : 0u)); }
 
+// v2p_set_launch_opts variant 19: the phases of a context's wave images in halves on two launch streams (launch_stitch: dual)
+static void dual_of(v2p_ctx* c, StitchArgs& a)
+{
+    if (c->launch_opts.variant != 19u) return;
+    if (!c->exec_aux && hipStreamCreateWithFlags(&c->exec_aux, hipStreamNonBlocking) != hipSuccess) { c->exec_aux = nullptr; return; }
+    for (hipEvent_t& e : c->ev_exec) if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return; }
+    a.aux_stream = c->exec_aux; a.ev_fork = c->ev_exec[0]; a.ev_join = c->ev_exec[1]; a.opt_dual = 1u;
+}
+
 static hipError_t ensure_event(hipEvent_t& e) { return e ? hipSuccess : hipEventCreate(&e); }
 
 // One slice's share of launch_stitch's routing (phases, store policy) follows the slice, not the table it is a range of
@@ -1791,6 +1804,7 @@ static hipError_t stitch_range(v2p_batch* b, uint64_t desc_bound, uint64_t chunk
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
     a.opt_phase_bytes = c->launch_opts.phase_bytes; a.opt_phase_min_chunks = c->launch_opts.phase_min_chunks; a.opt_store_sc1 = c->launch_opts.store_sc1;
     a.opt_touch = touch_of(c->launch_opts.variant);
+    dual_of(c, a);
     a.img_desc = img_desc; a.img_bytes = img_bytes;
     return launch_stitch(a, stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint, 0);
 }
@@ -2111,6 +2125,7 @@ int v2p_batch_execute(v2p_batch* b)
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
     a.opt_phase_bytes = c->launch_opts.phase_bytes; a.opt_phase_min_chunks = c->launch_opts.phase_min_chunks; a.opt_store_sc1 = c->launch_opts.store_sc1;
     a.opt_touch = touch_of(c->launch_opts.variant);
+    dual_of(c, a);
     HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint, 0), "launch(stitch)");
     return V2P_OK;
 }
