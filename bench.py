@@ -8,10 +8,11 @@ scan + K2 gather / scatter) over this rank's whole shard, inputs resident in HBM
 cohort, BASELINE.json configs[2] ("C3": 10 000 samples = 20 000 haplotypes, full alteration mix, 3.6e10 residues), strong scaling:
 at N = 1 the whole cohort is ONE image and one execute per step; at N > 1 it is cut into contiguous haplotype ranges of equal
 result bytes (shard.shard_by_bytes), one rank per GPU, no data-path collective.  The image every step executes is the one the
-product builds: ON the device, from the per-transcript Task vectors of step 4b (v2p_batch_build_on_device, rows images).
+product builds: ON the device, from the per-transcript Task vectors of step 4b, by the one call that also executes it the first time
+(v2p_stream_upload + v2p_batch_build_and_execute, rows images).
 
 The N = 1 line also carries
-  one_shot        Task vectors -> result bytes ONCE, as the reference does it (build kernels + the first execute on a fresh arena)
+  one_shot        Task vectors -> result bytes ONCE, as the reference does it: ONE C-ABI call (v2p_batch_build_and_execute) on the resident stream
   host_packed     the same cohort's host-packed image executed alternately with the device-built one
   c2_cohort       BASELINE.json configs[1] ("C2": 1 000 samples x 20 k transcripts, one missense each) the same way
   cpu_baseline    the oracle's reference-faithful flavour on this box's host cores (bounded sample)
@@ -55,7 +56,8 @@ def parse_args():
     ap.add_argument("--samples", type=int, default=0, help="weak: samples per GPU; strong: samples of the whole cohort (0 = the config's own size)")
     ap.add_argument("--no-c2", action="store_true", help="N = 1: skip the c2_cohort leg (BASELINE configs[1])")
     ap.add_argument("--no-host-packed", action="store_true", help="skip the host-packed image of the same cohort (A/B of the two builders)")
-    ap.add_argument("--no-speedup-ref", action="store_true", help="N > 1, strong scaling: do not time the whole cohort on rank 0 alone first")
+    ap.add_argument("--speedup-ref", action="store_true", help="N > 1, strong scaling: rank 0 first times the whole cohort alone (speedup_vs_1 on one clock); off by default -- "
+                                                                "the other ranks would wait in a barrier for it, and the driver computes the scaling curve from its own N = 1 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the transfers-inclusive leg (v2p_pipeline_*)")
     ap.add_argument("--verify", default="all", choices=["all", "sample", "none"], help="haplotypes whose digest is compared with the oracle before timing")
@@ -234,20 +236,29 @@ class Timed:
         return e0.elapsed_time(e1)
 
 
-def device_build(ctx, stream, result_bytes):
-    """v2p_batch_build_on_device with the product's plan (txstream.build_plan).  Returns (batch, info)."""
-    from vcf2prot_amd.txstream import build_on_device_auto
-    b = ctx.batch()
-    t0 = time.perf_counter()
-    info = build_on_device_auto(b, stream, result_bytes)
-    info["call_s_incl_h2d_of_the_stream"] = time.perf_counter() - t0
-    return b, info
+def box_fill_GBps(n_bytes=8 << 30, reps=4):
+    """What this box's memory system takes from a bare fill kernel (torch's fill_ of an 8 GiB buffer): boxes of the pool differ by +-8 %
+    on this path, so the step's rate is reported next to the box's own ceiling."""
+    import torch
+    x = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
+    x.fill_(46)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); x.fill_(46); e1.record(); e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None or ms < best else best
+    del x
+    torch.cuda.empty_cache()
+    return n_bytes / (best * 1e-3) / 1e9
 
 
 def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verify, temporal=False, host_packed=True, time_host_image=False, label="", barrier=lambda: None):
-    """One GPU (this rank's), haplotypes [h0, h1) of the cohort: the image built on the device from the transcript stream, every
-    haplotype's digest checked against the oracle, `steps` executes timed; the one-shot numbers; optionally the host-packed image of
-    the same haplotypes executed alternately.  Returns the numbers as a dict."""
+    """One GPU (this rank's), haplotypes [h0, h1) of the cohort.  The transcript stream is made RESIDENT (v2p_stream_upload), then the
+    product's one call -- v2p_batch_build_and_execute: image built on the device, executed -- gives the one-shot numbers and the batch
+    every step re-executes; every haplotype's digest is checked against the oracle before anything is timed; optionally the
+    host-packed image of the same haplotypes is executed alternately.  Returns the numbers as a dict."""
     import numpy as np
     import torch
     from vcf2prot_amd.cohort import Cohort
@@ -260,42 +271,63 @@ def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verif
     t_stream = time.perf_counter() - t0
     A = int(np.ctypeslib.as_array(stream.struct.length, shape=(max(stream.n_tasks, 1),))[:stream.n_tasks].sum(dtype=np.int64)) if stream.n_tasks else 0
     NT = stream.n_tasks
+    stream_bytes = stream.nbytes
     sizes = cohort.result_sizes(h0, h1, n_threads=n_threads)
     out_bytes = int(sizes.sum())
     res = {"workload": f"{workload}: {cohort_samples} samples, haplotypes [{h0}, {h1}) x {cohort.n_transcripts} transcripts" + (f" ({label})" if label else ""),
-           "haplotypes": n_haps, "aa": A, "tasks": NT, "result_bytes": out_bytes, "stream_bytes": stream.nbytes, "stream_generation_s": t_stream}
+           "haplotypes": n_haps, "aa": A, "tasks": NT, "result_bytes": out_bytes, "stream_bytes": stream_bytes, "stream_generation_s": t_stream}
     ctx = Context(torch.cuda.current_device(), temporal_stores=temporal)
+    rs = None
     try:
         ctx.upload_proteome(proteome)
-        # ---- one shot: Task vectors -> result bytes once.  Twice: the arena of the first build is fresh memory (its first touch is the
-        # driver's page mapping, not the kernel), the second build gets recycled memory -- what a service that keeps its arenas sees
+        t0 = time.perf_counter()
+        rs = ctx.upload_stream(stream)                          # tables checked on the host, arrays to HBM once: the timed regions below start with it resident
+        t_upload = time.perf_counter() - t0
+        stream.close()
+        assert rs.counts()["out_bytes"] == out_bytes
+        # ---- one shot: Task vectors -> result bytes ONCE, in one C-ABI call (v2p_batch_build_and_execute).  Three times: on a batch that
+        # owns nothing yet (its arena, descriptor array and scratch are allocated inside the call), on the same batch reset (everything
+        # recycled) behind the upload's idle time -- what a host that has just uploaded a cohort sees --, and reset again right behind four
+        # executes (the GPU's clocks up: cohorts back to back).  profiles/r05_first_execute.txt: the difference is the shader clock's ramp.
+        ts = torch.cuda.Stream()
+        ctx.set_stream(ts.cuda_stream)
+        b = ctx.batch()
         one = {}
-        b, info = device_build(ctx, stream, out_bytes)
-        t = Timed(ctx, b)
-        one["build_kernels_ms_first_call"] = info["build_ms"]
-        one["first_execute_ms_fresh_arena"] = t.once()
-        b.close()
-        torch.cuda.empty_cache()
-        b, info = device_build(ctx, stream, out_bytes)
-        t = Timed(ctx, b)
-        cn = b.counts()
-        first_ms = t.once()
-        one.update({"build_kernels_ms": info["build_ms"], "first_execute_ms": first_ms, "total_ms": info["build_ms"] + first_ms,
-                    "aa_per_s": A / ((info["build_ms"] + first_ms) * 1e-3) if A else 0.0,
-                    "build_call_s_incl_h2d_of_the_stream": info["call_s_incl_h2d_of_the_stream"], "kernel_choice": info["kernel"],
-                    "what": "per-transcript Task vectors (un-rebased SoA, transcript offsets, alt bytes) resident in HBM -> descriptors + chunk table "
-                            "(v2p_batch_build_on_device: step 5 as scans, one-pass parse, row cutter, XCD order) -> the first v2p_batch_execute on the batch's "
-                            "arena (recycled device memory; *_fresh_arena: memory the process never touched)"})
+        b.build_and_execute(rs, 0, 0); b.sync()
+        i0 = b.oneshot_info()
+        one["total_ms_first_call_allocating"] = i0["total_ms"]; one["call_wall_ms_first_call_allocating"] = i0["call_wall_ms"]
+        b.reset()
+        time.sleep(0.5)
+        b.build_and_execute(rs, 0, 0); b.sync()
+        i1 = b.oneshot_info()
+        for _ in range(4):
+            b.execute()
+        b.sync()
+        b.reset()
+        b.build_and_execute(rs, 0, 0); b.sync()
+        i2 = b.oneshot_info()
+        ctx.set_stream(0)
+        one.update({"total_ms": i1["total_ms"], "tables_ms": i1["tables_ms"], "build_kernels_ms": i1["build_ms"], "first_execute_ms": i1["total_ms"] - i1["build_ms"] - i1["tables_ms"],
+                    "call_wall_ms": i1["call_wall_ms"], "aa_per_s": A / (i1["total_ms"] * 1e-3) if A else 0.0,
+                    "total_ms_gpu_busy_before": i2["total_ms"], "build_kernels_ms_gpu_busy_before": i2["build_ms"],
+                    "aa_per_s_gpu_busy_before": A / (i2["total_ms"] * 1e-3) if A else 0.0,
+                    "kernel_choice": i1["kernel"], "n_slices": i1["n_slices"], "stream_upload_s_incl_host_checks": t_upload,
+                    "what": "ONE call, v2p_batch_build_and_execute, on the resident per-transcript Task vectors (un-rebased SoA, transcript offsets, alt bytes): "
+                            "step 5 as scans, one-pass parse, compaction beside the row cutter, XCD order, then every phase of the stitch kernel; total_ms = HIP events "
+                            "from before the first build kernel to behind the last stitch kernel, buffers recycled, 0.5 s of host sleep in front (clocks down); "
+                            "*_gpu_busy_before: the same call right behind four executes (clocks up)"})
         desc, chunks, hb = b.download_image()
         hbm_min, n_fused, n_imm = image_stats(desc, chunks, proteome.size, out_bytes)
         # bytes one shot must move: the stream read once, the image written and read once, the result written once
-        one_bytes = stream.nbytes + 2 * (8 * int(desc.size) + 16 * int(chunks.shape[0])) + out_bytes + int(proteome.size)
+        one_bytes = stream_bytes + 2 * (8 * int(desc.size) + 16 * int(chunks.shape[0])) + out_bytes + int(proteome.size)
         one["hbm_bytes_min"] = one_bytes
         one["frac_physical"] = one_bytes / (one["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        one["frac_physical_gpu_busy_before"] = one_bytes / (one["total_ms_gpu_busy_before"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         res.update({"descriptors": int(desc.size), "chunks": int(chunks.shape[0]), "fused_substitution_descriptors": n_fused, "immediate_descriptors": n_imm,
-                    "kernel": "stitchw_kernel (rows image)" if info["kernel"] == 6 else ("stitch_dense_kernel (rows image)" if info["kernel"] == 7 else f"kernel choice {info['kernel']}"),
+                    "kernel": "stitchw_kernel (rows image)" if i1["kernel"] == 6 else "stitch_dense_kernel (rows image)",
                     "hbm_bytes_min_per_launch": hbm_min, "algorithmic_bytes_per_launch": 2 * A + 16 * NT, "one_shot": one})
         del desc, chunks
+        t = Timed(ctx, b)
         # ---- parity before timing: per-haplotype digests vs the oracle ----
         dig = b.digests()
         verified = None
@@ -340,6 +372,8 @@ def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verif
             hbatch.close()
         b.close()
     finally:
+        if rs is not None:
+            rs.close()
         stream.close()
         ctx.close()
         torch.cuda.empty_cache()
@@ -402,7 +436,7 @@ def main():
         sizes = cohort.result_sizes(0, cohort.n_haplotypes, n_threads=n_threads)
         h0, h1 = shard_by_bytes(sizes.tolist(), world)[rank]              # equal result bytes per rank
     speedup_ref = None
-    if world > 1 and args.scaling == "strong" and rank == 0 and not args.no_speedup_ref and not args.dry_run:
+    if world > 1 and args.scaling == "strong" and rank == 0 and args.speedup_ref and not args.dry_run:
         try:                                                   # the same cohort alone on this GPU, one image (the 1-GPU point of the curve)
             r1 = cohort_leg(args.workload, cohort_samples, 0, cohort.n_haplotypes, max(3, min(args.steps, 10)), 3, n_threads, "sample", temporal=args.temporal, host_packed=False)
             speedup_ref = {"ms_per_step_wall": 1e3 * r1["elapsed_s"] / len(r1["kernel_ms"]), "kernel_ms_avg": sum(r1["kernel_ms"]) / len(r1["kernel_ms"]),
@@ -484,6 +518,12 @@ def main():
             except Exception:
                 traffic = None
         whole = world == 1 and args.scaling == "strong"
+        fill_gbps = None
+        if not args.dry_run:
+            try:
+                fill_gbps = box_fill_GBps()
+            except Exception:
+                fill_gbps = None
         line = {
             "metric": "amino-acids written/sec", "value": A_all * steps / elapsed, "unit": "aa/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
@@ -493,7 +533,7 @@ def main():
                                                            f"one {samples}-sample cohort over {world} GPU(s), equal result bytes per rank"))
                                    + f" ({int(A_all):.3e} aa) x {cohort.n_transcripts} transcripts, SIR Task vectors at the step-6 boundary",
                        "haplotypes_rank0": n_haps, "tasks_rank0": NT, "aa_rank0": A, "chunks_rank0": leg["chunks"], "descriptors_rank0": leg["descriptors"],
-                       "descriptor_bytes": 8, "image": leg.get("image_timed", "none") + " (v2p_batch_build_on_device from the transcript stream)" if not args.host_image else "host-packed",
+                       "descriptor_bytes": 8, "image": leg.get("image_timed", "none") + " (v2p_batch_build_and_execute on the resident transcript stream)" if not args.host_image else "host-packed",
                        "fused_substitution_descriptors_rank0": leg.get("fused_substitution_descriptors"), "immediate_descriptors_rank0": leg.get("immediate_descriptors"),
                        "step": "v2p_batch_execute through the C ABI (ctypes), HIP events on the launch stream",
                        "parallelism": f"haplotype-sharded x{world}, no data-path collective; one all-gather of 16 B per rank per image (RCCL), outside the step loop" if world > 1 else "1 GPU"},
@@ -508,7 +548,11 @@ def main():
                          "frac_b_alg_note": "SURVEY 8d's B_alg = 2A + 16N prices one HBM read per residue and 16 B per Task; the design serves reference reads from L2 and fuses "
                                             "Task triples into 8-byte descriptors, so this ratio exceeds 1 without skipping work -- `frac` (physical bytes) is the roofline figure",
                          "kernel": leg["kernel"] + ": a step = the image's phases, each read ahead into the memory-side cache (touch_image_kernel + stitch launches) -- kernel_ms is the whole step",
-                         "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms)},
+                         "kernel_ms_avg": avg_ms, "kernel_ms_min": min(kern_ms),
+                         "box_fill_GBps": fill_gbps, "frac_of_box_fill": (achieved / fill_gbps) if fill_gbps else None,
+                         "box_fill_note": "this box's rate for a bare fill of 8 GiB (torch fill_), measured in this process: boxes of the pool differ by several per cent"},
+            "comparable_to_previous_rounds": "since round 4 the N = 1 line is C3 whole (the north star's cohort), strong scaling, the size all-gather outside the step loop; "
+                                             "rounds 1-3 reported C2 / weak.  Round 5: same metric and config as round 4; one_shot is now ONE C-ABI call on a resident stream",
             "kernel_only_aa_per_s_rank0": A / (avg_ms * 1e-3),
             "verified": leg["verified"], "stream_generation_s": leg.get("stream_generation_s"),
         }

@@ -286,6 +286,7 @@ typedef struct {
     float    build_ms;           /* sum of the slices' build kernels (they overlap the stitch of the slices before: not additive)   */
     double   call_wall_ms;       /* host wall-clock of the call (it returns when the last slice is enqueued)                        */
     float    slice_build_ms[32];
+    float    tables_ms;          /* the global tables in front of the first slice: arena bytes per tile, their scan, haplotype offsets */
 } v2p_oneshot_info;
 /* waits for the call's last kernel, then reports its times */
 int  v2p_batch_oneshot_info(v2p_batch* b, v2p_oneshot_info* info);

@@ -104,7 +104,7 @@ _cohort = None
 class OneShotInfo(ctypes.Structure):
     """v2p_oneshot_info (include/vcf2prot_hip.h)"""
     _fields_ = [("kernel", ctypes.c_int32), ("n_slices", ctypes.c_uint32), ("total_ms", ctypes.c_float), ("build_ms", ctypes.c_float),
-                ("call_wall_ms", ctypes.c_double), ("slice_build_ms", ctypes.c_float * 32)]
+                ("call_wall_ms", ctypes.c_double), ("slice_build_ms", ctypes.c_float * 32), ("tables_ms", ctypes.c_float)]
 
 
 class Routing(ctypes.Structure):

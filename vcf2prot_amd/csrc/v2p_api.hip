@@ -2033,6 +2033,7 @@ int v2p_batch_oneshot_info(v2p_batch* b, v2p_oneshot_info* info)
         info->slice_build_ms[j] = ms; sum += ms;
     }
     info->build_ms = b->n_slices ? sum : b->os_build_ms;
+    if (b->n_slices) HIP_TRY(c, hipEventElapsedTime(&info->tables_ms, b->ev_os[0], b->ev_os[2]), "hipEventElapsedTime");
     return V2P_OK;
 }
 

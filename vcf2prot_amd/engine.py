@@ -348,7 +348,7 @@ class Batch:
         info = N.OneShotInfo()
         self.ctx._check(self._lib.v2p_batch_oneshot_info(self._h, ctypes.byref(info)))
         return {"kernel": int(info.kernel), "n_slices": int(info.n_slices), "total_ms": float(info.total_ms), "build_ms": float(info.build_ms),
-                "call_wall_ms": float(info.call_wall_ms), "slice_build_ms": [float(info.slice_build_ms[j]) for j in range(int(info.n_slices))]}
+                "call_wall_ms": float(info.call_wall_ms), "tables_ms": float(info.tables_ms), "slice_build_ms": [float(info.slice_build_ms[j]) for j in range(int(info.n_slices))]}
 
     def reset(self):
         """v2p_batch_reset: back to empty, device buffers kept (the next build recycles them)."""

@@ -111,17 +111,30 @@ def vcf_to_fasta(ctx, vcf: bytes, reference_fasta: str, flags: int = step4a.DEFA
                 sink.add_transcript(t[:, 0].astype(np.uint8), t[:, 1], t[:, 2], t[:, 3], off[tx], len(ref[tx]),
                                     np.frombuffer(alt, dtype=np.uint8), res_len, ho, hl)
             sink.end_haplotype()
+        rs = None
         if device_build:
+            # the product's one call (round 5): the stream made resident, then image build + execute in v2p_batch_build_and_execute; a
+            # stream even its dense rows image refuses (a 1 KiB row with more than 1 024 descriptors) goes to the grid builders of round 3
             stream = sink.finish()
-            build_on_device_auto(b, stream)
+            rs = ctx.upload_stream(stream)
+            try:
+                b.build_and_execute(rs, 0, 0)
+            except N.V2PError as e:
+                if e.code != -9:
+                    raise
+                b.reset()
+                build_on_device_auto(b, stream)
+                b.execute()
             stream.close()
         else:
             b.finalize()
-        b.execute()
+            b.execute()
         b.sync()
         out = {}
         for s, name in enumerate(idx.sample_names()):
             out[name] = b.download_hap(2 * s).tobytes() + b.download_hap(2 * s + 1).tobytes()
+        if rs is not None:
+            rs.close()
         return out
     finally:
         b.close()
