@@ -2,7 +2,7 @@
 # Run on the GPU box (via gpurun): kernel-trace stats + PMC traffic passes for bench.py (the headline leg only).
 # usage: tools/profile_round.sh <tag> [bench args...]
 set -u
-TAG=${1:-r04}; shift || true
+TAG=${1:-r05}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -14,4 +14,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- p
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 bench.py $B --no-verify --steps 3 --warmup 1 "$@" > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python3 bench.py $B --no-verify --steps 3 --warmup 1 "$@" > $OUT/bench_write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_l2 -o l2 -- python3 bench.py $B --no-verify --steps 3 --warmup 1 "$@" > $OUT/bench_l2.log 2>&1
-python3 tools/summarize_profile.py $OUT $TAG $ROOT/gpurun_out/${PROFILES_OUT:-profiles_r04} "$@"
+python3 tools/summarize_profile.py $OUT $TAG $ROOT/gpurun_out/${PROFILES_OUT:-profiles_r05} "$@"

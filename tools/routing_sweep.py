@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Are the library's routing rules -- which kernel takes an image (wave from 40 result bytes per task, dense below), phase size (28 MB
+"""Are the library's routing rules -- which kernel takes an image (wave from v2p_routing_rules().wave_bytes_per_task = 24 result bytes per task, dense below), phase size (28 MB
 for images whose descriptors are more than 3 % of their result, else 64 MB), store policy ("sc1 nt" for thin images), block order
 (one order for thin images) -- near the best forced choice AWAY from the four cohorts they were measured on?
 
@@ -88,11 +88,13 @@ def main():
                     st.close()
                     todo.append(("rows", ctx, rb, {}))
                     del base_img
+                    refused = {}
                     for kernel in (4, 3, 2):
                         try:
                             bb, rich = forced_batch(kernel)
-                        except Exception:
-                            continue                                  # (e.g. a wave image of 5-byte tasks: the packer refuses)
+                        except Exception as e:                        # (e.g. a wave image of 5-byte tasks: the packer refuses -- recorded with the point)
+                            refused[f"kernel{kernel}"] = repr(e)[:200]
+                            continue
                         if kernel == 4:
                             for phase in (28, 64):
                                 for sc1 in (0, 1):
@@ -101,7 +103,7 @@ def main():
                             todo.append(("wave,one-block", cro, b1, dict(phase_bytes=(28 if rich else 64) << 20, store_sc1=0 if rich else 1)))
                         else:
                             todo.append(("dense" if kernel == 3 else "per-block", cro, bb, {}))
-                    ok, errors, ref_dig = [], {}, None
+                    ok, errors, ref_dig = [], dict(refused), None
                     for name, cx, bb, opts in todo:                   # warm every image once; every variant must produce the same haplotypes
                         try:
                             cx.set_launch_opts(**opts); bb.execute(); bb.sync()

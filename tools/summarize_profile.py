@@ -20,6 +20,19 @@ def stitch_rows(path):
 
 
 summary = {"tag": tag, "command": "python3 bench.py --no-cpu-baseline --no-pcie --no-c2 --no-host-packed --verify sample --steps 10 --warmup 3 " + " ".join(sys.argv[4:])}
+# the bench line of the traced run: how many steps it timed (nothing here assumes 10)
+bench_line = {}
+_log = os.path.join(src, "bench_trace.log")
+if os.path.exists(_log):
+    for _line in open(_log):
+        if _line.startswith("{"):
+            bench_line = json.loads(_line)
+
+
+def n_builds(rows):
+    """image builds in a trace: one rows_parse_kernel launch each (a two-pass build has two: counted by the tile-bytes kernels instead)"""
+    tb = sum(1 for r in rows if "rows_tile_bytes" in r["Kernel_Name"])
+    return tb or sum(1 for r in rows if "rows_parse_kernel" in r["Kernel_Name"]) or 1
 stats = os.path.join(src, "trace", "trace_kernel_stats.csv")
 if os.path.exists(stats):
     rows = list(csv.DictReader(open(stats)))
@@ -46,14 +59,18 @@ if os.path.exists(stats):
 # with a touch_image_kernel launch; the last `steps` executes of the trace are the ones bench.py times
 trace = glob.glob(os.path.join(src, "trace", "*kernel_trace.csv"))
 if trace:
-    rows = [r for r in csv.DictReader(open(trace[0])) if is_step_kernel(r["Kernel_Name"])]
+    all_rows = list(csv.DictReader(open(trace[0])))
+    rows = [r for r in all_rows if is_step_kernel(r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     execs, build = [], {}
+    phased = any("touch_image" in r["Kernel_Name"] for r in rows)      # (dense / per-block images: one launch per execute, no read-ahead kernel)
     for r in rows:
-        if "touch_image" in r["Kernel_Name"] or not execs:
+        if "touch_image" in r["Kernel_Name"] or not execs or not phased:
             execs.append(0.0)
         execs[-1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-    k = 10
+    k = int(bench_line.get("steps", 10))
+    builds = n_builds(all_rows)
+    summary["image_builds_in_trace"] = builds
     if len(execs) >= k:
         summary["timed_steps"] = {"steps": k, "kernel_ms_per_step": sum(execs[-k:]) / k, "min": min(execs[-k:]), "max": max(execs[-k:]), "all_executes_ms": [round(x, 3) for x in execs]}
     for r in csv.DictReader(open(trace[0])):
@@ -62,26 +79,31 @@ if trace:
             key = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
             build.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     if build:
-        summary["build_kernels_ms_per_build"] = {k2: sum(v) / 2.0 for k2, v in sorted(build.items(), key=lambda kv: -sum(kv[1]))}     # (the run builds the image twice)
-        summary["build_kernels_ms_total_per_build"] = sum(sum(v) for v in build.values()) / 2.0
+        summary["build_kernels_ms_per_build"] = {k2: sum(v) / builds for k2, v in sorted(build.items(), key=lambda kv: -sum(kv[1]))}
+        summary["build_kernels_ms_total_per_build"] = sum(sum(v) for v in build.values()) / builds
 counters, n_steps = {}, {}
 for f in glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv")):
     rows = stitch_rows(f)
-    steps = len({r["Dispatch_Id"] for r in rows if "touch_image" in r["Kernel_Name"]}) or len({r["Dispatch_Id"] for r in rows})
+    steps = len({r["Dispatch_Id"] for r in rows if "touch_image" in r["Kernel_Name"]}) or len({r["Dispatch_Id"] for r in rows})   # (no read-ahead kernel: one launch per execute)
     for r in rows:
         counters[r["Counter_Name"]] = counters.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         n_steps[r["Counter_Name"]] = steps
 # the image-build kernels of the same run (build_rows.hip): FETCH_SIZE / WRITE_SIZE per build (the run builds the image twice)
-bc = {}
+bc, pmc_builds = {}, {}
 for f in glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv")):
-    for r in csv.DictReader(open(f)):
+    frows = list(csv.DictReader(open(f)))
+    for cn in {r["Counter_Name"] for r in frows}:
+        pmc_builds[cn] = n_builds([r for r in frows if r["Counter_Name"] == cn])
+    for r in frows:
         n = r["Kernel_Name"]
         if any(t in n for t in ("rows_", "scan_", "sub_", "xcd_")) and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             key = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
             bc.setdefault(key, {}).setdefault(r["Counter_Name"], 0.0)
             bc[key][r["Counter_Name"]] += float(r["Counter_Value"])
 if bc:
-    summary["build_traffic_bytes_per_build"] = {k: {"fetch_bytes_corrected_x2": 2.0 * v.get("FETCH_SIZE", 0.0) * 1024.0 / 2.0, "write_bytes": v.get("WRITE_SIZE", 0.0) * 1024.0 / 2.0} for k, v in sorted(bc.items())}
+    nbf, nbw = float(pmc_builds.get("FETCH_SIZE", 1) or 1), float(pmc_builds.get("WRITE_SIZE", 1) or 1)
+    summary["image_builds_in_pmc_passes"] = pmc_builds
+    summary["build_traffic_bytes_per_build"] = {k: {"fetch_bytes_corrected_x2": 2.0 * v.get("FETCH_SIZE", 0.0) * 1024.0 / nbf, "write_bytes": v.get("WRITE_SIZE", 0.0) * 1024.0 / nbw} for k, v in sorted(bc.items())}
     summary["build_traffic_total_bytes_per_build"] = sum(v["fetch_bytes_corrected_x2"] + v["write_bytes"] for v in summary["build_traffic_bytes_per_build"].values())
 # per STEP (= per execute() of the image: all phases' launches summed)
 summary["counters_per_step"] = {k: v / max(n_steps[k], 1) for k, v in sorted(counters.items())}

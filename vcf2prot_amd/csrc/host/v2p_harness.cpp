@@ -150,7 +150,7 @@ static int run(const char* preset, uint64_t n_haps, int threads, bool shared, bo
                             for (uint64_t h = next++; h < n_haps; h = next++) {
                                 if (!girs[h]->submit(Engine::GPU, *one)) {            // every batch in flight: take the first haplotype's result, then go on
                                     if (prev != ~0ull) { results[prev] = std::move(*girs[prev]).collect(*one).first; prev = ~0ull; }
-                                    while (!girs[h]->submit(Engine::GPU, *one)) std::this_thread::yield();
+                                    while (!girs[h]->submit(Engine::GPU, *one)) std::this_thread::sleep_for(std::chrono::microseconds(50));   // (a batch is on the GPU: nothing to gain from asking faster)
                                 }
                                 if (prev != ~0ull) results[prev] = std::move(*girs[prev]).collect(*one).first;
                                 prev = h;

@@ -95,7 +95,7 @@ constexpr uint32_t PAD_BYTES  = 32;            // readable slack before AND afte
                                                // around a task's bytes (up to 30 bytes before its first byte in a chunk's ragged head block, 31 after its last)
 
 struct Chunk {
-    uint64_t task_begin;   // index of the first descriptor (low 42 bits) | head skip (22 bits, rows images)
+    uint64_t task_begin;   // index of the first descriptor (low 42 bits) | rows images: head skip (11 bits) | tail clip (11 bits)
     uint64_t dst_n;        // result offset (48 bits) | descriptor count (16 bits)
 };
 static_assert(sizeof(Chunk) == 16, "Chunk is 16 bytes");

@@ -707,6 +707,19 @@ static int gir_submit_impl(v2p_ctx* c,
     };
     if ((n_tasks && (!code || !start_pos || !length || !start_pos_res)) || (n_ref && !ref) || (n_alt && !alt) || (n_res && !res))
         return fail(V2P_ERR_INVALID_ARG, "null argument", -1);
+    if (!may_wait) {
+        // v2p_gir_submit: when every batch of the queue is in flight the answer is V2P_BUSY -- BEFORE this call validates, marshals and
+        // packs its GIR (round 4 found out after all of that and threw the work away; a worker that resubmits in a loop redid it every
+        // time, exactly when the queue was saturated).  A hint: the join below decides.
+        GirQueue* q0 = nullptr;
+        { std::lock_guard<std::mutex> lk(c->mu); q0 = c->queue; }
+        if (q0) {
+            std::lock_guard<std::mutex> lk(q0->mu);
+            bool room = q0->open != nullptr;
+            for (int k = 0; k < q0->n_batch && !room; ++k) room = q0->batch[k].state == GirBatch::FREE;
+            if (!room) return V2P_BUSY;
+        }
+    }
     std::unique_ptr<v2p_gir_ticket> t(new (std::nothrow) v2p_gir_ticket());
     if (!t) return fail(V2P_ERR_HIP, "out of host memory", -1);
     t->code = code; t->start_pos = start_pos; t->length = length; t->start_pos_res = start_pos_res; t->n_tasks = n_tasks;

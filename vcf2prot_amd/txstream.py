@@ -134,7 +134,14 @@ def pack_rows(stream, proteome_len: int, mode: int = 1, emulate_k: int = 0):
         lib.v2p_packed_free(ctypes.byref(img))
 
 
-WAVE_BYTES_PER_TASK = 24      # = sir_pack.hpp: WAVE_BYTES_PER_TASK (profiles/r04_routing_sweep.json: the wave kernel wins from ~23 result bytes per task up)
+def _wave_bytes_per_task() -> int:
+    """The library's own wave / dense threshold (v2p_routing_rules: sir_pack.hpp WAVE_BYTES_PER_TASK = 24; profiles/r04_routing_sweep.json:
+    the wave kernel wins from ~23 result bytes per task up) -- read from the library so that the Python plan cannot drift from it."""
+    from . import _native as N
+    return N.routing_rules(0, 0, 0, 0)["wave_bytes_per_task"]
+
+
+WAVE_BYTES_PER_TASK = 24      # (documentation; build_plan asks the library)
 
 
 class RowsError(RuntimeError):
@@ -150,7 +157,7 @@ def build_plan(bytes_per_task: float) -> list:
     a wave image (kernel 6) from 24 result bytes per task, a dense one (7) below -- and whenever a 1 KiB row of the result holds
     more descriptors than a wave has lanes.  The grid builders of round 3 stay behind them as the last resort."""
     bpt = float(bytes_per_task)
-    if bpt < WAVE_BYTES_PER_TASK:
+    if bpt < _wave_bytes_per_task():
         return [(7, 0), (3, 12288), (3, 8192), (3, 4096), (2, 4096)]
     return [(6, 0), (7, 0), (2, 32768), (2, 16384), (2, 4096)]
 
