@@ -133,6 +133,18 @@ int  v2p_cohort_pack_grid(const v2p_cohort* c, uint64_t h0, uint64_t h1, uint32_
  * many transcripts, its 64-item windows and ballot masks emulated lane by lane (the two must agree).  *status (optional): the
  * device-style status word (task << 8 | reason; ~0 = clean). */
 int  v2p_txstream_pack_rows(const v2p_txstream_buf* s, uint64_t proteome_len, int mode, uint32_t emulate_k, v2p_packed_image* out, uint64_t* status);
+/* PATCH image (round 5; kernel 8 of v2p_batch_build_on_device: segments + patches on a 12 KiB grid, include/vcf2prot_hip.h) of a transcript
+ * stream built on the HOST -- the sequential restatement of the device builder's rules (vcf2prot_amd/csrc/patch_image_host.hpp) -- and an
+ * interpreter that executes such an image cell by cell.  *status: ~0 or (index << 8 | reason) as the device reports it (reason 9: the
+ * format declines the stream). */
+typedef struct {
+    uint64_t* seg; uint32_t* patch; v2p_chunk* chunks; uint64_t* hap_out_begin;
+    uint64_t n_chunks, n_haps, out_bytes, n_seg, n_patch;
+} v2p_patch_image;
+int  v2p_txstream_pack_patch(const v2p_txstream_buf* s, uint64_t proteome_len, v2p_patch_image* out, uint64_t* status);
+void v2p_patch_image_free(v2p_patch_image* im);
+int  v2p_patch_interpret(const uint64_t* seg, const uint32_t* patch, const v2p_chunk* chunks, uint64_t n_chunks, const uint8_t* src0, uint64_t src0_len,
+                         const uint8_t* src1, uint64_t src1_len, uint8_t* out, uint64_t out_len);
 /* FASTA record headers of every transcript and haplotype parity: one leading '\n', then 19 bytes each;
  * header of (transcript t, parity p) at 1 + (2*t + p) * 19.  Returns the bytes needed; fills `out` when cap suffices. */
 uint64_t v2p_cohort_fasta_headers(const v2p_cohort* c, uint8_t* out, uint64_t cap);

@@ -267,9 +267,9 @@ int  v2p_stream_upload(v2p_ctx* ctx, const v2p_txstream* s, v2p_stream** out);
 /* waits for the device; a batch built from the stream must not execute afterwards (its payload descriptors read the stream's alt bytes) */
 void v2p_stream_destroy(v2p_stream* s);
 int  v2p_stream_counts(const v2p_stream* s, uint64_t* n_haps, uint64_t* n_tx, uint64_t* n_tasks, uint64_t* out_bytes);
-/* the one-piece builder (kernel 6 / 7; 0: by the routing rule, a dense image when a wave image is refused) on a resident stream: no H2D */
+/* the one-piece builder (kernel 6 / 7 / 8; 0: by the routing rule, a dense image when a wave image is refused) on a resident stream: no H2D */
 int  v2p_batch_build_from_stream(v2p_batch* b, const v2p_stream* s, int kernel, float* build_ms);
-/* Build AND execute.  kernel: 0 (routing rule), 6 or 7.  n_slices: 0 = ONE slice -- the build, then the stitch (more slices were measured slower on every cohort: the
+/* Build AND execute.  kernel: 0 (routing rule), 6, 7 or 8 (a patch image: one build kernel, one stitch kernel).  n_slices: 0 = ONE slice -- the build, then the stitch (more slices were measured slower on every cohort: the
  * build of slice j + 1 next to the stitch of slice j takes three times as long, profiles/r05_oneshot_slices.json) --, else that many
  * (<= 32).  Returns when the last slice's stitch kernels are enqueued on the context's stream (like v2p_batch_execute: asynchronous);
  * v2p_batch_sync collects the status.  The batch is finalized: execute / digests / download work as after any build, and the image --
@@ -292,6 +292,20 @@ typedef struct {
 int  v2p_batch_oneshot_info(v2p_batch* b, v2p_oneshot_info* info);
 /* a finalized batch back to empty, its device buffers kept: the next build recycles arena, descriptor array and scratch */
 int  v2p_batch_reset(v2p_batch* b);
+/* ---- PATCH images (round 5; kernel 8 of v2p_batch_build_on_device / _build_from_stream / _build_and_execute) --------------------------------
+ * The image of a batch of DEEP Task vectors (a few result bytes per Task: 64 alterations in an 800-residue transcript) whose commonest
+ * Task triple -- reference copy, ONE substituted residue, the reference going on one residue later (a missense,
+ * transcript_instructions.rs:654-663) -- does not end a copy: SEGMENTS (8 bytes: source:34 | start inside the chunk:14 | length:14 |
+ * space:2 -- a run of one source, under any number of substituted residues) and PATCHES (4 bytes: position inside the chunk:14 | byte
+ * << 16) on a fixed grid of 8 KiB chunks of the arena; chunk k's segments sit in slots [1024 k, 1024 (k + 1)) of the segment array, its
+ * patches in slots [2048 k, ..) of the patch array, in no particular order; the chunk record holds first segment slot | patches << 42
+ * and arena offset | segments << 48 | bits 60 and 61.  Built by ONE kernel (one workgroup per chunk; no count pass, no scan of
+ * descriptor counts, no compaction, no cutter), executed by stitch_patch_kernel (vcf2prot_amd/csrc/patch_image.hip).  Semantics and
+ * panics are the reference's (task.rs:38-50, haplotype_instruction.rs:78,140-158).  V2P_ERR_UNSUPPORTED: a window of the result holds more
+ * segments or patches than its slots (or the sources exceed 16 GB) -- the batch is left empty: build a dense rows image (kernel 7).
+ * v2p_batch_counts reports the segments as descriptors.  For checkers: the raw arrays (1024 / 2048 slots per chunk, the chunk table in
+ * launch order; any pointer may be NULL) and the totals. */
+int v2p_batch_download_patch_image(v2p_batch* b, uint64_t* seg, uint32_t* patch, v2p_chunk* chunks, uint64_t* n_segments, uint64_t* n_patches);
 /* the image as it sits on the device (for checkers): sizes first (any pointer may be NULL), then the arrays */
 int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, uint64_t* hap_out_begin);
 

@@ -47,6 +47,12 @@ class Instruction(ctypes.Structure):
                 ("len", c_uint64), ("data", c_char_p), ("data_len", c_uint64)]
 
 
+class PatchImage(ctypes.Structure):
+    """v2p_patch_image (include/v2p_cohort.h)"""
+    _fields_ = [("seg", POINTER(c_uint64)), ("patch", POINTER(ctypes.c_uint32)), ("chunks", c_void_p), ("hap_out_begin", POINTER(c_uint64)),
+                ("n_chunks", c_uint64), ("n_haps", c_uint64), ("out_bytes", c_uint64), ("n_seg", c_uint64), ("n_patch", c_uint64)]
+
+
 COHORT_API = {
     "v2p_inspect_transcript_tasks": (c_int, [c_void_p, c_void_p, c_uint64, c_uint64, POINTER(ctypes.c_int64)]),
     "v2p_transcript_g_rep": (c_int, [POINTER(Instruction), c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
@@ -72,5 +78,8 @@ COHORT_API = {
     "v2p_cohort_txstream": (c_int, [c_void_p, c_uint64, c_uint64, c_int, POINTER(TxStreamBuf)]),
     "v2p_txstream_free": (None, [POINTER(TxStreamBuf)]),
     "v2p_txstream_pack_rows": (c_int, [POINTER(TxStreamBuf), c_uint64, c_int, c_uint32, POINTER(PackedImage), POINTER(c_uint64)]),
+    "v2p_txstream_pack_patch": (c_int, [POINTER(TxStreamBuf), c_uint64, POINTER(PatchImage), POINTER(c_uint64)]),
+    "v2p_patch_image_free": (None, [POINTER(PatchImage)]),
+    "v2p_patch_interpret": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_uint64]),
     "v2p_cohort_pack_grid": (c_int, [c_void_p, c_uint64, c_uint64, c_uint32, c_int, POINTER(PackedImage)]),
 }

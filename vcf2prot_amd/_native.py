@@ -64,6 +64,7 @@ HIP_API = {
                                         c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_uint64]),
     "v2p_batch_build_on_device": (c_int, [c_void_p, c_void_p, c_uint32, c_int, POINTER(ctypes.c_float)]),
     "v2p_batch_download_image": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "v2p_batch_download_patch_image": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
     "v2p_stream_upload": (c_int, [c_void_p, c_void_p, POINTER(c_void_p)]),
     "v2p_stream_destroy": (None, [c_void_p]),
     "v2p_stream_counts": (c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),

@@ -25,6 +25,7 @@
 #include "../../include/v2p_cohort.h"
 #include "sir_pack.hpp"
 #include "rows_image.hpp"
+#include "patch_image_host.hpp"
 
 namespace {
 
@@ -745,6 +746,45 @@ int v2p_txstream_pack_rows(const v2p_txstream_buf* s, uint64_t proteome_len, int
     out->n_tasks = s->n_tasks;
     for (uint64_t i = 0; i < s->n_tasks; ++i) out->n_copy_bytes += s->length[i];
     return 0;
+}
+
+// PATCH image of a transcript stream on the host (patch_image_host.hpp): the sequential restatement of patch_build_kernel's rules.
+int v2p_txstream_pack_patch(const v2p_txstream_buf* s, uint64_t proteome_len, v2p_patch_image* out, uint64_t* status)
+{
+    if (!s || !out) return -1;
+    memset(out, 0, sizeof *out);
+    v2p::TxStreamView v{s->n_haps, s->n_tx, s->n_tasks, s->n_alt, s->hap_tx_begin, s->tx_proteome_off, s->tx_ref_len, s->tx_res_len, s->tx_task_begin, s->tx_alt_begin,
+                        s->code, s->start_pos, s->length, s->start_pos_res, s->alt, s->tx_header_off, s->tx_header_len};
+    v2p::PatchImage im;
+    v2p::patch_reference(v, proteome_len, im);
+    if (status) *status = im.status;
+    if (im.status != ~0ull) return (im.status & 0xFF) == v2p::STATUS_PATCH_DECLINED ? v2p::PACK_TOO_LARGE : v2p::PACK_RES_OOB;
+    out->n_chunks = im.chunks.size(); out->n_haps = s->n_haps; out->out_bytes = im.out_bytes; out->n_seg = im.total_seg; out->n_patch = im.total_patch;
+    out->seg = static_cast<uint64_t*>(malloc((im.seg.size() ? im.seg.size() : 1) * 8));
+    out->patch = static_cast<uint32_t*>(malloc((im.patch.size() ? im.patch.size() : 1) * 4));
+    out->chunks = static_cast<v2p_chunk*>(malloc((out->n_chunks ? out->n_chunks : 1) * sizeof(v2p_chunk)));
+    out->hap_out_begin = static_cast<uint64_t*>(malloc((out->n_haps + 1) * 8));
+    if (!out->seg || !out->patch || !out->chunks || !out->hap_out_begin) { v2p_patch_image_free(out); return -2; }
+    if (!im.seg.empty()) memcpy(out->seg, im.seg.data(), im.seg.size() * 8);
+    if (!im.patch.empty()) memcpy(out->patch, im.patch.data(), im.patch.size() * 4);
+    if (out->n_chunks) memcpy(out->chunks, im.chunks.data(), out->n_chunks * sizeof(v2p_chunk));
+    memcpy(out->hap_out_begin, im.hap_out_begin.data(), (out->n_haps + 1) * 8);
+    return 0;
+}
+
+void v2p_patch_image_free(v2p_patch_image* im)
+{
+    if (!im) return;
+    free(im->seg); free(im->patch); free(im->chunks); free(im->hap_out_begin);
+    memset(im, 0, sizeof *im);
+}
+
+// a PATCH image executed on the host (what stitch_patch_kernel does, cell by cell; refuses a malformed chunk): 0 = done
+int v2p_patch_interpret(const uint64_t* seg, const uint32_t* patch, const v2p_chunk* chunks, uint64_t n_chunks, const uint8_t* src0, uint64_t src0_len,
+                        const uint8_t* src1, uint64_t src1_len, uint8_t* out, uint64_t out_len)
+{
+    static_assert(sizeof(v2p_chunk) == sizeof(v2p::Chunk), "chunk records");
+    return v2p::patch_interpret(seg, patch, reinterpret_cast<const v2p::Chunk*>(chunks), n_chunks, src0, src0_len, src1, src1_len, out, out_len) ? 0 : -1;
 }
 
 uint64_t v2p_cohort_fasta_headers(const v2p_cohort* c, uint8_t* out, uint64_t cap)

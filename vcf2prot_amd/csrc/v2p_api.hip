@@ -22,6 +22,7 @@
 #include "stitch_kernels.h"
 #include "build_kernels.h"
 #include "build_rows.h"
+#include "patch_image.h"
 #include "v2p_ctx_internal.h"
 
 using namespace v2p;
@@ -151,6 +152,9 @@ struct v2p_batch {
     uint64_t last_hdr_src = 0; uint32_t last_hdr_len = 0;
     DevBuf d_desc, d_chunks, d_payload, d_out, d_hap, d_digest, d_status;
     DevBuf d_build;                // the transcript stream and the builder's scratch (v2p_batch_build_on_device)
+    DevBuf d_patch;                // PATCH images (patch_image.h): the substituted residues, PATCH_PATCH_CAP slots per chunk (d_desc holds the segments)
+    bool is_patch = false;
+    uint64_t patch_segs = 0, patch_patches = 0;
     const uint8_t* payload_dev = nullptr;   // the alt bytes the image's payload descriptors read: d_payload, or a resident v2p_stream's
     // v2p_batch_build_and_execute: tables that outlive the call so that a batch that is rebuilt recycles them, the slices' chunk ranges
     // and the events of the last call (read by v2p_batch_oneshot_info after a sync)
@@ -238,6 +242,7 @@ int v2p_init(int device_ordinal, unsigned flags, v2p_ctx** out)
             if (le == hipSuccess) le = preload_stitch_wave(c->own_stream);
             if (le == hipSuccess) le = preload_build_kernels(c->own_stream);
             if (le == hipSuccess) le = preload_build_rows(c->own_stream);
+            if (le == hipSuccess) le = preload_patch_image(c->own_stream);
             if (le == hipSuccess) le = hipStreamSynchronize(c->own_stream);
             if (le != hipSuccess) {
                 g_init_error = std::string("loading the kernels' code objects: ") + hipGetErrorString(le);
@@ -971,7 +976,7 @@ void v2p_batch_destroy(v2p_batch* b)
     (void)hipStreamSynchronize(b->ctx->stream);
     b->d_desc.release(); b->d_chunks.release(); b->d_payload.release(); b->d_out.release();
     b->d_hap.release(); b->d_digest.release(); b->d_status.release(); b->d_build.release();
-    b->d_tiles.release(); b->d_cover.release(); b->d_pad.release(); b->d_order.release();
+    b->d_tiles.release(); b->d_cover.release(); b->d_pad.release(); b->d_order.release(); b->d_patch.release();
     if (b->ctx->build_stream) (void)hipStreamSynchronize(b->ctx->build_stream);
     if (b->ctx->aux_stream) (void)hipStreamSynchronize(b->ctx->aux_stream);
     for (hipEvent_t e : b->ev_os) if (e) (void)hipEventDestroy(e);
@@ -1199,6 +1204,8 @@ struct DevStreamView {
     bool fasta = false;
     double items_mean = 1.0, items_var = 0.0;          // items (Tasks; a transcript without Tasks is one) per transcript: rows_pick_k
 };
+
+static int build_patch_image(v2p_batch* b, const DevStreamView& v, float* build_ms, bool own_stream_copy, uint64_t known_out_bytes);
 
 // mean and spread of the items per transcript from a sample of the (host) stream
 static void stream_item_stats(const v2p_txstream* s, double* mean, double* var)
@@ -1530,7 +1537,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     if (b->hap_open || b->img.n_haplotypes()) return c->fail(V2P_ERR_STATE, "the batch already holds host-built haplotypes");
     const bool split = kernel == 5;                       // wave windows that may split once (65 .. 127 descriptors -> two chunks)
     if (split) kernel = 4;
-    const bool rows = kernel == 6 || kernel == 7;         // ROWS images (round 4): one pass, whole descriptors, chunks cut on 1 KiB rows afterwards; no window
+    const bool rows = kernel == 6 || kernel == 7 || kernel == 8;   // ROWS images (round 4): one pass, whole descriptors, chunks cut on 1 KiB rows afterwards; no window -- 8: a PATCH image (round 5)
     if (!rows && (window_bytes == 0 || window_bytes % (kernel == 4 ? 1024u : 4096u) || window_bytes > CHUNK_BYTES - 4080u))
         return c->fail(V2P_ERR_INVALID_ARG, "window_bytes must be a multiple of 4096 (wave images: of 1024), at most 61440");
     if (kernel == 1 && window_bytes > CHUNK_BYTES_LONG) return c->fail(V2P_ERR_INVALID_ARG, "the long-run kernel takes windows of at most 32768 bytes");
@@ -1549,6 +1556,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
         DevStreamView v;
         const int urc = upload_stream(c, s, fasta, b->d_build, b->d_payload, v, c->stream);
         if (urc) { b->d_build.release(); return urc; }
+        if (kernel == 8) return build_patch_image(b, v, build_ms, true, ~0ull);
         return build_rows_image(b, v, kernel == 7 ? ROWS_DENSE : ROWS_WAVE, build_ms, true);
     }
     const uint64_t n_tx = s->n_tx, n_tk = s->n_tasks, n_h = s->n_haps;
@@ -1698,6 +1706,116 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     return V2P_OK;
 }
 
+// ---- PATCH images (patch_image.h; kernel 8): deep Task vectors as segments + patches, ONE build kernel, one workgroup per 12 KiB window ----
+// V2P_ERR_UNSUPPORTED: the format declines the stream (a window with more segments / patches than its slots, sources beyond 16 GB) --
+// the batch is left empty and the caller builds a dense rows image (kernel 7) instead.
+static int build_patch_image(v2p_batch* b, const DevStreamView& v, float* build_ms, bool own_stream_copy, uint64_t known_out_bytes)
+{
+    v2p_ctx* c = b->ctx;
+    const uint64_t n_tx = v.n_tx, n_h = v.n_haps;
+    struct Cleanup {
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        DevBuf scratch;
+        v2p_batch* b;
+        bool ok = false, own;
+        Cleanup(v2p_batch* b_, bool own_) : b(b_), own(own_) {}
+        ~Cleanup() {
+            for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+            scratch.release();
+            if (own) b->d_build.release();
+            if (!ok) { b->img.hap_out_begin.assign(1, 0); b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0; b->payload_dev = nullptr; b->is_patch = false; }
+        }
+    } guard(b, own_stream_copy);
+    if (c->proteome_len + c->headers_len > PATCH_SRC_MAX || v.n_alt > PATCH_SRC_MAX) return c->fail(V2P_ERR_UNSUPPORTED, "a patch image addresses 16 GB of reference / alt bytes");
+    int rc = init_status(c, b->d_status);
+    if (rc) return rc;
+    for (hipEvent_t& e : guard.ev) HIP_TRY(c, hipEventCreate(&e), "hipEventCreate");
+    auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
+    // positions first: the arena's size decides everything else
+    uint64_t off = 0;
+    auto carve = [&](uint64_t bytes) { const uint64_t o = off; off += up8(bytes); return o; };
+    const uint64_t o_alen = carve((n_tx + 1) * 4), o_rbase = carve((n_tx + 2) * 8), o_scan = carve(scan_tiles_for(n_tx + 1) * 8), o_totals = carve(64);
+    // (the chunk-level scratch follows once out_bytes is known; sized here for the largest arena the stream's result lengths allow)
+    PatchBuildArgs a{};
+    a.n_tx = n_tx; a.n_tasks = v.n_tasks; a.n_haps = n_h;
+    a.tx_proteome_off = v.tx_proteome_off; a.tx_ref_len = v.tx_ref_len; a.tx_res_len = v.tx_res_len; a.tx_task_begin = v.tx_task_begin; a.tx_alt_begin = v.tx_alt_begin;
+    a.code = v.code; a.start_pos = v.start_pos; a.length = v.length; a.start_pos_res = v.start_pos_res; a.alt = v.alt;
+    a.tx_header_off = v.tx_header_off; a.tx_header_len = v.tx_header_len; a.hap_tx_begin = v.hap_tx_begin;
+    a.proteome_len = c->proteome_len; a.alt_len = v.n_alt;
+    a.status = reinterpret_cast<unsigned long long*>(b->d_status.ptr());
+    DevBuf& pos = b->d_tiles;                            // (recycled by a batch that is rebuilt)
+    HIP_TRY(c, pos.ensure_exact(off), "hipMalloc(positions)");
+    uint8_t* const d = pos.ptr();
+    a.tx_arena_len = reinterpret_cast<uint32_t*>(d + o_alen); a.tx_res_base = reinterpret_cast<uint64_t*>(d + o_rbase);
+    a.totals = reinterpret_cast<uint64_t*>(d + o_totals);
+    HIP_TRY(c, hipEventRecord(guard.ev[0], c->stream), "hipEventRecord");
+    HIP_TRY(c, hipMemsetAsync(d + o_totals, 0, 64, c->stream), "hipMemset(totals)");
+    HIP_TRY(c, launch_patch_positions(a, reinterpret_cast<uint64_t*>(d + o_scan), c->stream), "launch(positions)");
+    uint64_t out_bytes = known_out_bytes;
+    if (known_out_bytes == ~0ull) {
+        HIP_TRY(c, hipMemcpyAsync(&out_bytes, d + o_rbase + n_tx * 8, 8, hipMemcpyDeviceToHost, c->stream), "D2H(out_bytes)");
+        HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    }
+    const uint64_t n_chunks = (out_bytes + PATCH_G - 1) / PATCH_G;
+    if (n_chunks > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch");
+    a.out_bytes = out_bytes; a.n_chunks = n_chunks;
+    const uint64_t cap = n_chunks ? n_chunks : 1;
+    const uint64_t n_blocks_cap = order_blocks_thread_blocks(cap, XCD_ORDER_MAX_BLOCKS);
+    const uint64_t n_sub_cap = uint64_t(XCD_SUB) * n_blocks_cap;
+    const uint64_t s_tmp = 0, s_bucket = s_tmp + up8(cap * 16), s_hist = s_bucket + up8(cap),
+                   s_sub = s_hist + up8((n_blocks_cap + 1) * 8 * 4), s_tmp2 = s_sub + up8(cap), s_bucket2 = s_tmp2 + up8(cap * 16),
+                   s_subhist = s_bucket2 + up8(cap), s_substart = s_subhist + up8(n_sub_cap * 4), s_subtiles = s_substart + up8((n_sub_cap + 1) * 8),
+                   s_tot = s_subtiles + up8(scan_tiles_for(n_sub_cap) * 8), s_end = s_tot + up8(uint64_t(XCD_ORDER_MAX_BLOCKS) * 8 * 4);
+    DevBuf& scratch = b->d_order;
+    HIP_TRY(c, scratch.ensure_exact(s_end), "hipMalloc(build scratch)");
+    HIP_TRY(c, b->d_desc.ensure_exact(cap * PATCH_SEG_CAP * 8), "hipMalloc(segments)");
+    HIP_TRY(c, b->d_patch.ensure_exact(cap * PATCH_PATCH_CAP * 4), "hipMalloc(patches)");
+    HIP_TRY(c, b->d_chunks.ensure(cap * sizeof(Chunk)), "hipMalloc(chunks)");
+    HIP_TRY(c, b->d_out.ensure((out_bytes + 15) & ~15ull), "hipMalloc(out)");
+    HIP_TRY(c, b->d_hap.ensure((n_h + 1) * 8), "hipMalloc(hap_begin)");
+    HIP_TRY(c, b->d_digest.ensure((n_h ? n_h : 1) * 8), "hipMalloc(digest)");
+    uint8_t* const sc = scratch.ptr();
+    a.seg = reinterpret_cast<uint64_t*>(b->d_desc.ptr()); a.patch = reinterpret_cast<uint32_t*>(b->d_patch.ptr());
+    a.chunks = reinterpret_cast<Chunk*>(sc + s_tmp); a.bucket = sc + s_bucket; a.sub = sc + s_sub;
+    a.hap_out_begin = reinterpret_cast<uint64_t*>(b->d_hap.ptr());
+    HIP_TRY(c, launch_patch_hap_begin(a, c->stream), "launch(hap_begin)");
+    HIP_TRY(c, launch_patch_build(a, c->stream), "launch(patch build)");
+    const bool reorder = !(c->flags & V2P_FLAG_RESULT_ORDER) && n_chunks >= 16 && c->proteome_len != 0;
+    if (reorder) {
+        // (the XCD / window order of the chunk table, as for every other image; a declined or failed build is noticed below, before anything executes)
+        const uint32_t nb = xcd_order_blocks(out_bytes, c->proteome_len, n_chunks, XCD_ORDER_MAX_BLOCKS, n_chunks * 400u);
+        HIP_TRY(c, launch_order_blocks(a.chunks, a.bucket, a.sub, n_chunks, nb, reinterpret_cast<uint32_t*>(sc + s_subhist),
+                                       reinterpret_cast<uint64_t*>(sc + s_substart), reinterpret_cast<uint64_t*>(sc + s_subtiles),
+                                       reinterpret_cast<Chunk*>(sc + s_tmp2), sc + s_bucket2, reinterpret_cast<uint32_t*>(sc + s_hist),
+                                       reinterpret_cast<uint32_t*>(sc + s_tot), reinterpret_cast<Chunk*>(b->d_chunks.ptr()), c->stream), "launch(order)");
+    } else if (n_chunks) HIP_TRY(c, hipMemcpyAsync(b->d_chunks.ptr(), a.chunks, n_chunks * sizeof(Chunk), hipMemcpyDeviceToDevice, c->stream), "D2D(chunks)");
+    HIP_TRY(c, hipEventRecord(guard.ev[1], c->stream), "hipEventRecord");
+    uint64_t totals[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(totals, d + o_totals, 16, hipMemcpyDeviceToHost, c->stream), "D2H(totals)");
+    b->img.hap_out_begin.assign(n_h + 1, 0);
+    HIP_TRY(c, hipMemcpyAsync(b->img.hap_out_begin.data(), b->d_hap.ptr(), (n_h + 1) * 8, hipMemcpyDeviceToHost, c->stream), "D2H(hap_begin)");
+    unsigned long long st = STATUS_CLEAN;
+    HIP_TRY(c, hipMemcpyAsync(&st, b->d_status.ptr(), 8, hipMemcpyDeviceToHost, c->stream), "D2H(status)");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    if (st != STATUS_CLEAN) {
+        (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream);
+        if (uint32_t(st & 0xFFu) == STATUS_PATCH_DECLINED) return c->fail(V2P_ERR_UNSUPPORTED, "a 12 KiB window of the result holds more segments or patches than a patch image's chunk (kernel 7 builds a dense image)", int64_t(st >> 8));
+        const int code = reason_to_err(uint32_t(st & 0xFFu));          // what the reference would panic on
+        return c->fail(code, std::string("device: ") + err_name(code) + " at descriptor " + std::to_string(st >> 8), int64_t(st >> 8));
+    }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, guard.ev[0], guard.ev[1]);
+    if (build_ms) *build_ms = ms;
+    guard.ok = true;
+    b->n_desc = totals[0]; b->patch_segs = totals[0]; b->patch_patches = totals[1];
+    b->n_chunks = n_chunks; b->n_payload = v.n_alt; b->payload_dev = v.alt; b->out_bytes = out_bytes; b->n_haps = n_h;
+    b->launch_hint = 0; b->is_patch = true;
+    b->uses_proteome = true;
+    b->finalized = true;
+    b->n_slices = 0;
+    return V2P_OK;
+}
+
 // ---- a transcript stream RESIDENT on the device; Task vectors -> result bytes in ONE call -----------------------------------
 // v2p_batch_build_on_device takes a host stream, uploads it, builds, and the caller executes afterwards: two calls, the stream's H2D
 // inside the first, the build and the execute strictly one after the other.  What a cohort pays ONCE is exactly that sequence
@@ -1772,7 +1890,7 @@ int v2p_batch_reset(v2p_batch* b)
     b->img = ImageBuilder();
     b->finalized = false; b->uses_proteome = false; b->hap_open = false;
     b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0;
-    b->payload_dev = nullptr; b->n_slices = 0; b->launch_hint = 0;
+    b->payload_dev = nullptr; b->n_slices = 0; b->launch_hint = 0; b->is_patch = false; b->patch_segs = b->patch_patches = 0;
     return V2P_OK;
 }
 
@@ -1784,12 +1902,22 @@ int v2p_batch_build_from_stream(v2p_batch* b, const v2p_stream* st, int kernel, 
     std::lock_guard<std::mutex> lk(c->mu);
     if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
     if (b->hap_open || b->img.n_haplotypes()) return c->fail(V2P_ERR_STATE, "the batch already holds host-built haplotypes");
-    if (kernel != 0 && kernel != 6 && kernel != 7) return c->fail(V2P_ERR_INVALID_ARG, "a resident stream builds rows images: kernel 0 (by the routing rule), 6 or 7");
+    if (kernel != 0 && kernel != 6 && kernel != 7 && kernel != 8) return c->fail(V2P_ERR_INVALID_ARG, "a resident stream builds rows images (kernel 6, 7), a patch image (8) or what the routing rule picks (0)");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    if (kernel == 8) return build_patch_image(b, st->v, build_ms, false, st->out_bytes);
     int mode = rows_mode_for(st, kernel);
     int rc = build_rows_image(b, st->v, mode, build_ms, false);
     if (rc == V2P_ERR_UNSUPPORTED && kernel == 0 && mode == ROWS_WAVE) rc = build_rows_image(b, st->v, ROWS_DENSE, build_ms, false);     // (a row with more than 64 descriptors)
     return rc;
+}
+
+static hipError_t patch_execute(v2p_batch* b, hipStream_t stream)
+{
+    v2p_ctx* c = b->ctx;
+    PatchExecArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), reinterpret_cast<const uint32_t*>(b->d_patch.ptr()), reinterpret_cast<const Chunk*>(b->d_chunks.ptr()),
+                    uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->payload_dev, b->n_payload,
+                    b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
+    return launch_stitch_patch(a, stream, !(c->flags & V2P_FLAG_TEMPORAL));
 }
 
 // v2p_set_launch_opts: variant 16 / 17 / 18 = how a context's phased wave images are launched (A/B switches: tools/phase_ab.py):
@@ -2001,9 +2129,23 @@ int v2p_batch_build_and_execute(v2p_batch* b, const v2p_stream* st, int kernel, 
     std::lock_guard<std::mutex> lk(c->mu);
     if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized (v2p_batch_reset recycles it)");
     if (b->hap_open || b->img.n_haplotypes()) return c->fail(V2P_ERR_STATE, "the batch already holds host-built haplotypes");
-    if (kernel != 0 && kernel != 6 && kernel != 7) return c->fail(V2P_ERR_INVALID_ARG, "a resident stream builds rows images: kernel 0 (by the routing rule), 6 or 7");
+    if (kernel != 0 && kernel != 6 && kernel != 7 && kernel != 8) return c->fail(V2P_ERR_INVALID_ARG, "a resident stream builds rows images (kernel 6, 7), a patch image (8) or what the routing rule picks (0)");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     const auto t0 = std::chrono::steady_clock::now();
+    if (kernel == 8) {
+        // a PATCH image: one build kernel behind the positions' scan, then one stitch kernel, on the context's stream
+        for (uint32_t k = 0; k < 2; ++k) HIP_TRY(c, ensure_event(b->ev_os[k]), "hipEventCreate");
+        HIP_TRY(c, hipEventRecord(b->ev_os[0], c->stream), "hipEventRecord");
+        float ms = 0.f;
+        const int prc = build_patch_image(b, st->v, &ms, false, st->out_bytes);
+        if (prc != V2P_OK) return prc;
+        const hipError_t pe = patch_execute(b, c->stream);
+        if (pe != hipSuccess) return c->hip_fail(pe, "launch(stitch: patch image)");
+        HIP_TRY(c, hipEventRecord(b->ev_os[1], c->stream), "hipEventRecord");
+        b->os_build_ms = ms; b->os_kernel = 8; b->n_slices = 0;
+        b->os_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return V2P_OK;
+    }
     int mode = rows_mode_for(st, kernel);
     bool fallback = false;
     int rc = build_and_execute_rows(b, st, mode, n_slices, &fallback);
@@ -2050,12 +2192,29 @@ int v2p_batch_oneshot_info(v2p_batch* b, v2p_oneshot_info* info)
     return V2P_OK;
 }
 
+int v2p_batch_download_patch_image(v2p_batch* b, uint64_t* seg, uint32_t* patch, v2p_chunk* chunks, uint64_t* n_segments, uint64_t* n_patches)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!b->finalized || !b->is_patch) return c->fail(V2P_ERR_STATE, "not a finalized patch image");
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    if (n_segments) *n_segments = b->patch_segs;
+    if (n_patches) *n_patches = b->patch_patches;
+    if (seg && b->n_chunks) HIP_TRY(c, hipMemcpyAsync(seg, b->d_desc.ptr(), b->n_chunks * PATCH_SEG_CAP * 8, hipMemcpyDeviceToHost, c->stream), "D2H(segments)");
+    if (patch && b->n_chunks) HIP_TRY(c, hipMemcpyAsync(patch, b->d_patch.ptr(), b->n_chunks * PATCH_PATCH_CAP * 4, hipMemcpyDeviceToHost, c->stream), "D2H(patches)");
+    if (chunks && b->n_chunks) HIP_TRY(c, hipMemcpyAsync(chunks, b->d_chunks.ptr(), b->n_chunks * sizeof(Chunk), hipMemcpyDeviceToHost, c->stream), "D2H(chunks)");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    return V2P_OK;
+}
+
 int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, uint64_t* hap_out_begin)
 {
     if (!b) return V2P_ERR_INVALID_ARG;
     v2p_ctx* c = b->ctx;
     std::lock_guard<std::mutex> lk(c->mu);
     if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
+    if (b->is_patch && desc) return c->fail(V2P_ERR_STATE, "a patch image has segments and patches, not descriptors: v2p_batch_download_patch_image");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     if (desc && b->n_desc) HIP_TRY(c, hipMemcpyAsync(desc, b->d_desc.ptr(), b->n_desc * 8, hipMemcpyDeviceToHost, c->stream), "D2H(desc)");
     if (chunks && b->n_chunks) HIP_TRY(c, hipMemcpyAsync(chunks, b->d_chunks.ptr(), b->n_chunks * sizeof(Chunk), hipMemcpyDeviceToHost, c->stream), "D2H(chunks)");
@@ -2134,6 +2293,11 @@ int v2p_batch_execute(v2p_batch* b)
     std::lock_guard<std::mutex> lk(c->mu);
     if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    if (b->is_patch) {
+        const hipError_t pe = patch_execute(b, c->stream);
+        if (pe != hipSuccess) return c->hip_fail(pe, "launch(stitch: patch image)");
+        return V2P_OK;
+    }
     StitchArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), b->n_desc, reinterpret_cast<const Chunk*>(b->d_chunks.ptr()),
                  uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->payload_dev, b->n_payload,
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};

@@ -134,6 +134,44 @@ def pack_rows(stream, proteome_len: int, mode: int = 1, emulate_k: int = 0):
         lib.v2p_packed_free(ctypes.byref(img))
 
 
+def pack_patch(stream, proteome_len: int):
+    """The PATCH image of a transcript stream built on the HOST (csrc/patch_image_host.hpp; include/v2p_cohort.h: v2p_txstream_pack_patch):
+    (segments [n_chunks, 1024] u64, patches [n_chunks, 2048] u32, chunk table [n_chunks, 2] u64 in arena order, hap_out_begin, out_bytes,
+    total segments, total patches); raises RowsError(status word) for what the device reports (reason 9: the format declines the stream)."""
+    from . import _native as N
+    from ._cohort_api import PatchImage
+    lib = N.cohort_lib()
+    img = PatchImage()
+    status = ctypes.c_uint64(0)
+    rc = lib.v2p_txstream_pack_patch(ctypes.byref(stream.struct), proteome_len, ctypes.byref(img), ctypes.byref(status))
+    if rc != 0:
+        raise RowsError(rc, int(status.value))
+    try:
+        n = int(img.n_chunks)
+        seg = np.ctypeslib.as_array(img.seg, shape=(max(n, 1) * 1024,))[:n * 1024].astype(np.uint64, copy=True).reshape(n, 1024)
+        patch = np.ctypeslib.as_array(img.patch, shape=(max(n, 1) * 2048,))[:n * 2048].astype(np.uint32, copy=True).reshape(n, 2048)
+        chunks = (np.ctypeslib.as_array(ctypes.cast(img.chunks, ctypes.POINTER(ctypes.c_uint64)), shape=(n * 2,)).astype(np.uint64, copy=True).reshape(-1, 2)
+                  if n else np.zeros((0, 2), dtype=np.uint64))
+        hb = np.ctypeslib.as_array(img.hap_out_begin, shape=(int(img.n_haps) + 1,)).astype(np.uint64, copy=True)
+        return seg, patch, chunks, hb, int(img.out_bytes), int(img.n_seg), int(img.n_patch)
+    finally:
+        lib.v2p_patch_image_free(ctypes.byref(img))
+
+
+def interpret_patch(seg, patch, chunks, src0, src1, out_bytes: int):
+    """A PATCH image executed on the host, cell by cell (v2p_patch_interpret): the arena, or None when a chunk is malformed (a cell written
+    twice or never, a range out of bounds, a patch outside a reference segment)."""
+    from . import _native as N
+    lib = N.cohort_lib()
+    seg = np.ascontiguousarray(seg, dtype=np.uint64); patch = np.ascontiguousarray(patch, dtype=np.uint32)
+    chunks = np.ascontiguousarray(chunks, dtype=np.uint64).reshape(-1, 2)
+    src0 = np.ascontiguousarray(src0, dtype=np.uint8); src1 = np.ascontiguousarray(src1, dtype=np.uint8)
+    out = np.zeros(out_bytes, dtype=np.uint8)
+    rc = lib.v2p_patch_interpret(seg.ctypes.data, patch.ctypes.data, chunks.ctypes.data, chunks.shape[0], src0.ctypes.data, src0.size,
+                                 src1.ctypes.data, src1.size, out.ctypes.data, out_bytes)
+    return out if rc == 0 else None
+
+
 def _wave_bytes_per_task() -> int:
     """The library's own wave / dense threshold (v2p_routing_rules: sir_pack.hpp WAVE_BYTES_PER_TASK = 24; profiles/r04_routing_sweep.json:
     the wave kernel wins from ~23 result bytes per task up) -- read from the library so that the Python plan cannot drift from it."""
