@@ -2,9 +2,9 @@
 # SQ counters of every kernel of tools/kernel_probe.py (three passes), summarised per kernel name: usage pmc_kernels.sh <tag> <probe args...>
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-k}; shift || true
 OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd $ROOT
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/a -o a -- python3 tools/kernel_probe.py "$@" > $OUT/a.log 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/b -o b -- python3 tools/kernel_probe.py "$@" > $OUT/b.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE FETCH_SIZE WRITE_SIZE --kernel-trace --output-format csv -d $OUT/c -o c -- python3 tools/kernel_probe.py "$@" > $OUT/c.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/a -o a -- python3 tools/kernel_probe.py "$@" > $OUT/a.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/b -o b -- python3 tools/kernel_probe.py "$@" > $OUT/b.log 2>&1
+timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/c -o c -- python3 tools/kernel_probe.py "$@" > $OUT/c.log 2>&1
 python3 - <<PY
 import csv,glob,json
 res={}

@@ -40,6 +40,7 @@ struct PatchBuildArgs {
     uint32_t* tx_arena_len;             // [n_tx] scratch: result length (+ header + line feed)
     uint64_t* tx_res_base;
     uint64_t out_bytes, n_chunks;
+    uint64_t* chunk_tx;                 // [n_chunks + 1] first transcript whose record begins at or behind each chunk's first byte
     // the image
     uint64_t* seg;                      // [n_chunks * PATCH_SEG_CAP]
     uint32_t* patch;                    // [n_chunks * PATCH_PATCH_CAP]

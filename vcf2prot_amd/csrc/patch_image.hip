@@ -2,8 +2,8 @@
 // executor (stitch_patch_kernel, one workgroup per window) for batches of DEEP Task vectors.  gfx950, wave64; no MFMA (byte / index work).
 //
 //   positions   res_counter of haplotype_instruction.rs:90,132 as a scan over the transcripts' arena lengths (build_kernels.hip: launch_scan_u32)
-//   build       workgroup = window [c * 8 KiB, (c + 1) * 8 KiB) of the arena: the transcripts whose records overlap it (two binary searches in
-//               the scanned offsets), one WAVE per transcript, lane = Task (task.rs:2-9) in windows of 64 with two context lanes either side.
+//   build       workgroup = window [c * 8 KiB, (c + 1) * 8 KiB) of the arena: the transcripts whose records overlap it (a table: the first transcript at or
+//               behind every window's first byte), one WAVE per transcript, lane = Task (task.rs:2-9) in windows of 64 with two context lanes either side.
 //               A lane classifies its Task from its own fields and its neighbours' (DPP): a one-residue alt Task between two reference
 //               copies that go on one residue later is a PATCH; a reference copy that follows such a patch CONTINUES the segment of the copy
 //               before it; every other Task starts a segment (reference / alt payload / literal); cells no Task covers are '.' segments
@@ -44,12 +44,20 @@ __global__ __launch_bounds__(256) void patch_hap_begin_kernel(PatchBuildArgs a)
     a.hap_out_begin[h] = a.tx_res_base[h < a.n_haps ? a.hap_tx_begin[h] : a.n_tx];
 }
 
-// first t in [0, n] with base[t] >= x (base has n + 1 entries, non-decreasing)
-__device__ __forceinline__ uint64_t first_at_or_after(const uint64_t* __restrict__ base, uint64_t n, uint64_t x)
+// chunk_tx[c] = first transcript t in [0, n_tx] whose record begins at or behind the chunk's first byte (tx_res_base is non-decreasing):
+// transcript t writes the entries of the chunks that begin in (base[t - 1], base[t]] -- every chunk gets exactly one writer.  (The first
+// form of the builder had every WORKGROUP binary-search the 2 M offsets twice: 42 dependent loads, 4 ms of BASELINE config 5's 4.9.)
+__global__ __launch_bounds__(256) void patch_chunk_tx_kernel(PatchBuildArgs a)
 {
-    uint64_t lo = 0, hi = n + 1;
-    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (base[mid] >= x) hi = mid; else lo = mid + 1; }
-    return lo;
+    const uint64_t t = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    if (t > a.n_tx) return;
+    const uint64_t b1 = a.tx_res_base[t];
+    // chunks c with c * G <= b1 and (t == 0 or c * G > base[t - 1])
+    uint64_t c_lo = 0;
+    if (t > 0) { const uint64_t b0 = a.tx_res_base[t - 1]; c_lo = b0 / PATCH_G + 1u; }
+    uint64_t c_hi = b1 / PATCH_G;                                      // last chunk whose first byte is <= b1
+    if (c_hi >= a.n_chunks) c_hi = a.n_chunks ? a.n_chunks - 1u : 0u;
+    for (uint64_t c = c_lo; c <= c_hi && c < a.n_chunks; ++c) a.chunk_tx[c] = t;
 }
 
 template <bool FASTA>
@@ -65,31 +73,67 @@ __global__ __launch_bounds__(256) void patch_build_kernel(PatchBuildArgs a)
     __syncthreads();
     // transcripts of this window: the one lying across its first byte, then every one that begins inside it (an empty record belongs to
     // the window its offset falls in; those at the very end of the arena to the last window)
-    uint64_t t_a = first_at_or_after(a.tx_res_base, a.n_tx, lo);
+    uint64_t t_a = a.chunk_tx[c];                                        // (= first_at_or_after(tx_res_base, lo), from patch_chunk_tx_kernel)
     if (t_a > 0 && (t_a > a.n_tx || a.tx_res_base[t_a] > lo)) --t_a;
-    const uint64_t t_b = last_chunk ? a.n_tx : first_at_or_after(a.tx_res_base, a.n_tx, hi);
+    const uint64_t t_b = last_chunk ? a.n_tx : a.chunk_tx[c + 1];          // (= first_at_or_after(tx_res_base, hi))
     uint64_t* const seg_out = a.seg + c * PATCH_SEG_CAP;
     uint32_t* const patch_out = a.patch + c * PATCH_PATCH_CAP;
     constexpr int NS = FASTA ? 5 : 3;                     // segments a lane may emit: [header] gap fill, its own, tail fill [line feed]
 
-    for (uint64_t t = t_a + wave; t < t_b && t < a.n_tx; t += 4u) {
-        const uint64_t rb = a.tx_res_base[t];
-        const uint32_t hl = FASTA ? a.tx_header_len[t] : 0u;
-        const uint64_t hsrc = (FASTA && hl) ? a.proteome_len + a.tx_header_off[t] : 0ull;
-        const uint64_t base = rb + hl;                                   // arena offset of the transcript's first result cell
-        const uint64_t poff = a.tx_proteome_off[t], alt0 = a.tx_alt_begin[t];
-        const uint32_t ref_len = a.tx_ref_len[t], res_len = a.tx_res_len[t], n_alt = uint32_t(a.tx_alt_begin[t + 1] - alt0);
-        const uint64_t tb0 = a.tx_task_begin[t], tb1 = a.tx_task_begin[t + 1];
-        const uint32_t n = uint32_t(tb1 - tb0 < 0xFFFFFFFFull ? tb1 - tb0 : 0xFFFFFFFFull);
-        const bool owned = (rb >= lo && rb < hi) || (last_chunk && rb >= hi);      // the window that reports this transcript's panics
-        if (owned && lane == 0u && poff + ref_len > a.proteome_len) atomicMin(a.status, (unsigned long long)((tb0 << 8) | STATUS_SRC_OOB));
+    // The window's transcripts go through an LDS table, 64 at a time (ONE round trip for all their rows), and every wave requests the
+    // Tasks of its NEXT window of 64 -- of the same transcript or of its next one -- before it works on the current one: a wave's life
+    // was a chain of dependent round trips in the first form of this kernel (50 us per workgroup, 4.8 ms for BASELINE config 5 whatever
+    // its Task count).
+    __shared__ uint64_t s_rb[64], s_poff[64], s_alt0[64], s_tb0[64], s_hsrc[64];
+    __shared__ uint32_t s_n[64], s_reflen[64], s_reslen[64], s_nalt[64], s_hl[64];
+    const uint64_t t_end = t_b < a.n_tx ? t_b : a.n_tx;
+    auto uni32 = [](uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); };
+    auto uni64 = [&](uint64_t x) { return (uint64_t(uni32(uint32_t(x >> 32))) << 32) | uni32(uint32_t(x)); };
+    for (uint64_t g0 = t_a; g0 < t_end; g0 += 64u) {
+        const uint32_t ng = uint32_t(t_end - g0 < 64u ? t_end - g0 : 64u);
+        __syncthreads();
+        if (tid < ng) {
+            const uint64_t t = g0 + tid;
+            const uint32_t hl_ = FASTA ? a.tx_header_len[t] : 0u;
+            const uint64_t tb0_ = a.tx_task_begin[t], tb1_ = a.tx_task_begin[t + 1], alt0_ = a.tx_alt_begin[t];
+            s_rb[tid] = a.tx_res_base[t]; s_poff[tid] = a.tx_proteome_off[t]; s_alt0[tid] = alt0_; s_tb0[tid] = tb0_;
+            s_hsrc[tid] = (FASTA && hl_) ? a.proteome_len + a.tx_header_off[t] : 0ull;
+            s_n[tid] = uint32_t(tb1_ - tb0_ < 0xFFFFFFFFull ? tb1_ - tb0_ : 0xFFFFFFFFull);
+            s_reflen[tid] = a.tx_ref_len[t]; s_reslen[tid] = a.tx_res_len[t]; s_nalt[tid] = uint32_t(a.tx_alt_begin[t + 1] - alt0_); s_hl[tid] = hl_;
+        }
+        __syncthreads();
+        uint32_t r = wave, w = 0u;
+        uint32_t code = 0, sp = 0, ln = 0, sr = 0;                       // the Tasks of the window about to be worked on
+        auto fetch = [&](uint32_t rr, uint32_t ww, uint32_t& f_code, uint32_t& f_sp, uint32_t& f_ln, uint32_t& f_sr) {
+            f_code = 0; f_sp = 0; f_ln = 0; f_sr = 0;
+            if (rr < ng) {
+                const uint32_t jj = ww + lane - 2u;
+                if (jj < s_n[rr]) { const uint64_t i = s_tb0[rr] + jj; f_code = a.code[i]; f_sp = a.start_pos[i]; f_ln = a.length[i]; f_sr = a.start_pos_res[i]; }
+            }
+        };
+        fetch(r, w, code, sp, ln, sr);
         uint32_t carry_e = 0u;                                          // end of the Task before the window's first lane (lane 0's predecessor)
-        for (uint32_t w = 0; ; w += 60u) {
+        while (r < ng) {
+            const uint32_t n = uni32(s_n[r]);
+            // the window after this one: requested now
+            uint32_t nr = r, nw = w + 60u;
+            if (n == 0u || nw >= n) { nr = r + 4u; nw = 0u; }
+            uint32_t x_code, x_sp, x_ln, x_sr;
+            fetch(nr, nw, x_code, x_sp, x_ln, x_sr);
+            const uint64_t rb = uni64(s_rb[r]), poff = uni64(s_poff[r]), alt0 = uni64(s_alt0[r]), tb0 = uni64(s_tb0[r]);
+            const uint32_t hl = FASTA ? uni32(s_hl[r]) : 0u;
+            const uint64_t hsrc = FASTA ? uni64(s_hsrc[r]) : 0ull;
+            const uint64_t base = rb + hl;                                   // arena offset of the transcript's first result cell
+            const uint32_t ref_len = uni32(s_reflen[r]), res_len = uni32(s_reslen[r]), n_alt = uni32(s_nalt[r]);
+            const bool owned = (rb >= lo && rb < hi) || (last_chunk && rb >= hi);      // the window that reports this transcript's panics
+            if (w == 0u) {
+                carry_e = 0u;
+                if (owned && lane == 0u && poff + ref_len > a.proteome_len) atomicMin(a.status, (unsigned long long)((tb0 << 8) | STATUS_SRC_OOB));
+            }
+            // lane l <-> Task j = w - 2 + l of the transcript: lanes 0, 1 are context (emitted by the window before), 62, 63 look-ahead
             // lane l <-> Task j = w - 2 + l of the transcript: lanes 0, 1 are context (emitted by the window before), 62, 63 look-ahead
             const uint32_t j = w + lane - 2u;
             const bool valid = j < n;                                    // (j wraps below 0 for the context lanes of the first window)
-            uint32_t code = 0, sp = 0, ln = 0, sr = 0;
-            if (valid) { const uint64_t i = tb0 + j; code = a.code[i]; sp = a.start_pos[i]; ln = a.length[i]; sr = a.start_pos_res[i]; }
             const bool own = valid && lane >= 2u && lane < 62u;
             // ---- update_task / Task::execute, as rows_parse_kernel checks them ----
             const bool res_oob = valid && (ln > res_len || sr > res_len - ln);
@@ -207,25 +251,25 @@ __global__ __launch_bounds__(256) void patch_build_kernel(PatchBuildArgs a)
                 const uint32_t k = b0 + lanes_below(pm);
                 if (patch_here) { if (k < PATCH_PATCH_CAP) patch_out[k] = patch_word(uint32_t(base + sr - lo), pbyte); else s_over = 1u; }
             }
-            if (n == 0u || w + 60u >= n) break;
-            carry_e = uint32_t(__builtin_amdgcn_readlane(int(e), 59));   // Task w + 57 = the next window's lane 0's predecessor ... see below
-            // (the next window's lane 0 is Task w + 58; its predecessor w + 57 sits in this window's lane 59)
-        }
-        if (n == 0u && lane == 0u) {
-            // a transcript without Tasks: its cells are '.', its record still has its header and line feed (transcript_instructions.rs:338-343)
-            uint64_t ss[3] = {rb, base, base + res_len}, se[3] = {rb + hl, base + res_len, base + res_len + (hl ? 1u : 0u)};
-            uint64_t sx[3] = {hsrc, 0, hsrc + hl - 1u};
-            const unsigned sk[3] = {SPACE_PROTEOME, SPACE_FILL, SPACE_PROTEOME};
-            for (int i = 0; i < 3; ++i) {
-                if (!FASTA && i != 1) continue;
-                const uint64_t s0 = ss[i] > lo ? ss[i] : lo, e0 = se[i] < hi ? se[i] : hi;
-                if (se[i] > ss[i] && e0 > s0) {
-                    if (sk[i] != SPACE_FILL) sx[i] += s0 - ss[i];
-                    const uint32_t k = atomicAdd(&s_nseg, 1u);
-                    if (k < PATCH_SEG_CAP && sx[i] <= PATCH_SRC_MAX) seg_out[k] = patch_seg(sx[i], uint32_t(s0 - lo), uint32_t(e0 - s0), sk[i]);
-                    else s_over = 1u;
+            carry_e = uint32_t(__builtin_amdgcn_readlane(int(e), 59));   // (the next window's lane 0 is Task w + 58; its predecessor w + 57 sits in this window's lane 59)
+            if (n == 0u && lane == 0u) {
+                // a transcript without Tasks: its cells are '.', its record still has its header and line feed (transcript_instructions.rs:338-343)
+                uint64_t ss[3] = {rb, base, base + res_len}, se[3] = {rb + hl, base + res_len, base + res_len + (hl ? 1u : 0u)};
+                uint64_t sx[3] = {hsrc, 0, hsrc + hl - 1u};
+                const unsigned sk[3] = {SPACE_PROTEOME, SPACE_FILL, SPACE_PROTEOME};
+                for (int i = 0; i < 3; ++i) {
+                    if (!FASTA && i != 1) continue;
+                    const uint64_t s0 = ss[i] > lo ? ss[i] : lo, e0 = se[i] < hi ? se[i] : hi;
+                    if (se[i] > ss[i] && e0 > s0) {
+                        if (sk[i] != SPACE_FILL) sx[i] += s0 - ss[i];
+                        const uint32_t k = atomicAdd(&s_nseg, 1u);
+                        if (k < PATCH_SEG_CAP && sx[i] <= PATCH_SRC_MAX) seg_out[k] = patch_seg(sx[i], uint32_t(s0 - lo), uint32_t(e0 - s0), sk[i]);
+                        else s_over = 1u;
+                    }
                 }
             }
+
+            code = x_code; sp = x_sp; ln = x_ln; sr = x_sr; r = nr; w = nw;
         }
     }
     __syncthreads();
@@ -240,9 +284,24 @@ __global__ __launch_bounds__(256) void patch_build_kernel(PatchBuildArgs a)
         const uint8_t bucket = uint8_t(bk < 8 ? bk : 7);
         a.bucket[c] = bucket;
         a.sub[c] = xcd_sub_window(key, bucket, per);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.totals), (unsigned long long)ns);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.totals) + 1, (unsigned long long)np);
     }
+}
+
+// segments and patches of the whole image: summed over the chunk records, one atomic pair per 256 chunks (one pair per CHUNK from the
+// build kernel itself -- 390 000 atomics on two addresses -- was 4 of that kernel's 4.8 ms)
+__global__ __launch_bounds__(256) void patch_totals_kernel(PatchBuildArgs a)
+{
+    __shared__ unsigned long long s_t[2];
+    if (threadIdx.x < 2u) s_t[threadIdx.x] = 0ull;
+    __syncthreads();
+    const uint64_t c = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    uint64_t ns = 0, np = 0;
+    if (c < a.n_chunks) { ns = (a.chunks[c].dst_n >> 48) & CHUNK_N_MASK; np = patch_chunk_patches(a.chunks[c].task_begin); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { ns += __shfl_xor(ns, o); np += __shfl_xor(np, o); }
+    if ((threadIdx.x & 63u) == 0u) { atomicAdd(&s_t[0], (unsigned long long)ns); atomicAdd(&s_t[1], (unsigned long long)np); }
+    __syncthreads();
+    if (threadIdx.x == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(a.totals), s_t[0]); atomicAdd(reinterpret_cast<unsigned long long*>(a.totals) + 1, s_t[1]); }
 }
 
 // ---- the executor ----------------------------------------------------------------------------------------------------------
@@ -419,8 +478,10 @@ hipError_t launch_patch_build(const PatchBuildArgs& a, hipStream_t stream)
 {
     if (a.n_chunks == 0) return hipSuccess;
     if (a.n_chunks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(patch_chunk_tx_kernel, dim3(uint32_t((a.n_tx + 1 + 255) / 256)), dim3(256), 0, stream, a);
     if (a.tx_header_len) hipLaunchKernelGGL(patch_build_kernel<true>, dim3(uint32_t(a.n_chunks)), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(patch_build_kernel<false>, dim3(uint32_t(a.n_chunks)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(patch_totals_kernel, dim3(uint32_t((a.n_chunks + 255) / 256)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

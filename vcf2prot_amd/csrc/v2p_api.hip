@@ -1765,9 +1765,10 @@ static int build_patch_image(v2p_batch* b, const DevStreamView& v, float* build_
     const uint64_t s_tmp = 0, s_bucket = s_tmp + up8(cap * 16), s_hist = s_bucket + up8(cap),
                    s_sub = s_hist + up8((n_blocks_cap + 1) * 8 * 4), s_tmp2 = s_sub + up8(cap), s_bucket2 = s_tmp2 + up8(cap * 16),
                    s_subhist = s_bucket2 + up8(cap), s_substart = s_subhist + up8(n_sub_cap * 4), s_subtiles = s_substart + up8((n_sub_cap + 1) * 8),
-                   s_tot = s_subtiles + up8(scan_tiles_for(n_sub_cap) * 8), s_end = s_tot + up8(uint64_t(XCD_ORDER_MAX_BLOCKS) * 8 * 4);
+                   s_tot = s_subtiles + up8(scan_tiles_for(n_sub_cap) * 8), s_ctx = s_tot + up8(uint64_t(XCD_ORDER_MAX_BLOCKS) * 8 * 4), s_end = s_ctx + up8((cap + 2) * 8);
     DevBuf& scratch = b->d_order;
     HIP_TRY(c, scratch.ensure_exact(s_end), "hipMalloc(build scratch)");
+    a.chunk_tx = reinterpret_cast<uint64_t*>(scratch.ptr() + s_ctx);
     HIP_TRY(c, b->d_desc.ensure_exact(cap * PATCH_SEG_CAP * 8), "hipMalloc(segments)");
     HIP_TRY(c, b->d_patch.ensure_exact(cap * PATCH_PATCH_CAP * 4), "hipMalloc(patches)");
     HIP_TRY(c, b->d_chunks.ensure(cap * sizeof(Chunk)), "hipMalloc(chunks)");
