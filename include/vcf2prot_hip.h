@@ -298,12 +298,12 @@ int  v2p_batch_reset(v2p_batch* b);
  * transcript_instructions.rs:654-663) -- does not end a copy: SEGMENTS (8 bytes: source:34 | start inside the chunk:14 | length:14 |
  * space:2 -- a run of one source, under any number of substituted residues) and PATCHES (4 bytes: position inside the chunk:14 | byte
  * << 16) on a fixed grid of 8 KiB chunks of the arena; chunk k's segments sit in slots [1024 k, 1024 (k + 1)) of the segment array, its
- * patches in slots [2048 k, ..) of the patch array, in no particular order; the chunk record holds first segment slot | patches << 42
+ * patches in slots [1024 k, ..) of the patch array, in no particular order; the chunk record holds first segment slot | patches << 42
  * and arena offset | segments << 48 | bits 60 and 61.  Built by ONE kernel (one workgroup per chunk; no count pass, no scan of
  * descriptor counts, no compaction, no cutter), executed by stitch_patch_kernel (vcf2prot_amd/csrc/patch_image.hip).  Semantics and
  * panics are the reference's (task.rs:38-50, haplotype_instruction.rs:78,140-158).  V2P_ERR_UNSUPPORTED: a window of the result holds more
  * segments or patches than its slots (or the sources exceed 16 GB) -- the batch is left empty: build a dense rows image (kernel 7).
- * v2p_batch_counts reports the segments as descriptors.  For checkers: the raw arrays (1024 / 2048 slots per chunk, the chunk table in
+ * v2p_batch_counts reports the segments as descriptors.  For checkers: the raw arrays (1024 / 1024 slots per chunk, the chunk table in
  * launch order; any pointer may be NULL) and the totals. */
 int v2p_batch_download_patch_image(v2p_batch* b, uint64_t* seg, uint32_t* patch, v2p_chunk* chunks, uint64_t* n_segments, uint64_t* n_patches);
 /* the image as it sits on the device (for checkers): sizes first (any pointer may be NULL), then the arrays */

@@ -10,7 +10,7 @@ from stream_util import random_stream
 
 pytestmark = pytest.mark.gpu
 
-G, SEG_CAP, PATCH_CAP = 8192, 1024, 2048
+G, SEG_CAP, PATCH_CAP = 8192, 1024, 1024
 
 
 def oracle_hap(c, coracle, h):
@@ -169,7 +169,7 @@ def test_patch_builder_reports_what_the_reference_would_panic_on(built, gpu_ctx)
 
 
 def test_a_window_with_too_many_segments_is_declined_not_mangled(built, gpu_ctx):
-    """Every second residue substituted: 4 096 patches in an 8 KiB window, more than its 2 048 slots -- V2P_ERR_UNSUPPORTED, the batch left
+    """Every second residue substituted: 4 096 patches in an 8 KiB window, more than its 1 024 slots -- V2P_ERR_UNSUPPORTED, the batch left
     empty and reusable; the dense rows image (kernel 7) takes the stream."""
     from stream_util import Stream
     from vcf2prot_amd._native import V2PError

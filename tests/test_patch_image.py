@@ -93,7 +93,7 @@ def test_host_patch_builder_reports_the_reference_panics_and_declines_what_does_
         with pytest.raises(RowsError) as ei:
             pack_patch(stream(code, sp, ln, sr), prot.size)
         assert (ei.value.reason, ei.value.index) == (reason, row)
-    # every second residue substituted: 4 096 patches in an 8 KiB window, more than its 2 048 slots -- declined (reason 9), not mangled
+    # every second residue substituted: 4 096 patches in an 8 KiB window, more than its 1 024 slots -- declined (reason 9), not mangled
     rng = np.random.default_rng(3)
     AA = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
     L = 30000

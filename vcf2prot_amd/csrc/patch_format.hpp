@@ -9,7 +9,7 @@ namespace v2p {
 constexpr uint32_t PATCH_ROWS = 8;                         // 1 KiB rows of a chunk: the workgroup's LDS image
 constexpr uint32_t PATCH_G = PATCH_ROWS * ROW_BYTES;       // 8 192 bytes of arena per chunk
 constexpr uint32_t PATCH_SEG_CAP = 1024;                   // segment slots per chunk
-constexpr uint32_t PATCH_PATCH_CAP = 2048;                 // patch slots per chunk
+constexpr uint32_t PATCH_PATCH_CAP = 1024;                 // patch slots per chunk
 constexpr uint32_t PATCH_SRC_BITS = 34;                    // a segment's source offset: 16 GB of proteome (+ record headers) / alt bytes
 constexpr uint64_t PATCH_SRC_MAX = (1ull << PATCH_SRC_BITS) - 1;
 constexpr uint32_t PATCH_IMM_MAX = 4;                      // literal bytes a segment word carries (space 3): the low 32 bits of its source field

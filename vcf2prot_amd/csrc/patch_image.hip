@@ -323,6 +323,10 @@ __device__ __forceinline__ void patch_put(uint32_t* img, const u32x4* lowmask, u
     if (end > 16u) atomicOr(&img[wb + 4u], e4);
 }
 
+// (Round 5 also tried RESIDENT workgroups -- eight per CU, each walking chunks a grid apart with the next chunk's segment and patch words and
+// the record after that requested a chunk ahead, so that a chunk's life held one memory round trip instead of three: 1.64 ms against
+// 0.98 for BASELINE config 5.  gfx950 counts loads and stores in one in-order counter: a resident workgroup's gathers queue behind its
+// own previous chunk's stores, as round 3 found for the stitch kernels.  One workgroup per chunk it is.)
 // Everything a workgroup reads from memory is requested as early as its address is known: the chunk's segment words and patch words at
 // once (registers), the segments' ragged first pieces as soon as the words are decoded -- they fly under the block map's construction --
 // and the blocks' gathers right behind the map.  (The first form of this kernel went phase by phase and waited 81 % of its wave cycles:

@@ -355,11 +355,11 @@ class Batch:
         self.ctx._check(self._lib.v2p_batch_reset(self._h))
 
     def download_patch_image(self):
-        """A PATCH image (kernel 8) as it sits on the device: (segments [n_chunks, 1024] u64, patches [n_chunks, 2048] u32, chunk table in launch
+        """A PATCH image (kernel 8) as it sits on the device: (segments [n_chunks, 1024] u64, patches [n_chunks, 1024] u32, chunk table in launch
         order [n_chunks, 2] u64, total segments, total patches) -- chunk k = arena offset / 8192 owns row k of both arrays."""
         n = self.counts()["n_chunks"]
         seg = np.zeros((n, 1024), dtype=np.uint64)
-        patch = np.zeros((n, 2048), dtype=np.uint32)
+        patch = np.zeros((n, 1024), dtype=np.uint32)
         chunks = np.zeros((n, 2), dtype=np.uint64)
         ns, npat = ctypes.c_uint64(), ctypes.c_uint64()
         self.ctx._check(self._lib.v2p_batch_download_patch_image(self._h, seg.ctypes.data if n else None, patch.ctypes.data if n else None,

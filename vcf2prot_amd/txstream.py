@@ -136,7 +136,7 @@ def pack_rows(stream, proteome_len: int, mode: int = 1, emulate_k: int = 0):
 
 def pack_patch(stream, proteome_len: int):
     """The PATCH image of a transcript stream built on the HOST (csrc/patch_image_host.hpp; include/v2p_cohort.h: v2p_txstream_pack_patch):
-    (segments [n_chunks, 1024] u64, patches [n_chunks, 2048] u32, chunk table [n_chunks, 2] u64 in arena order, hap_out_begin, out_bytes,
+    (segments [n_chunks, 1024] u64, patches [n_chunks, 1024] u32, chunk table [n_chunks, 2] u64 in arena order, hap_out_begin, out_bytes,
     total segments, total patches); raises RowsError(status word) for what the device reports (reason 9: the format declines the stream)."""
     from . import _native as N
     from ._cohort_api import PatchImage
@@ -149,7 +149,7 @@ def pack_patch(stream, proteome_len: int):
     try:
         n = int(img.n_chunks)
         seg = np.ctypeslib.as_array(img.seg, shape=(max(n, 1) * 1024,))[:n * 1024].astype(np.uint64, copy=True).reshape(n, 1024)
-        patch = np.ctypeslib.as_array(img.patch, shape=(max(n, 1) * 2048,))[:n * 2048].astype(np.uint32, copy=True).reshape(n, 2048)
+        patch = np.ctypeslib.as_array(img.patch, shape=(max(n, 1) * 1024,))[:n * 1024].astype(np.uint32, copy=True).reshape(n, 1024)
         chunks = (np.ctypeslib.as_array(ctypes.cast(img.chunks, ctypes.POINTER(ctypes.c_uint64)), shape=(n * 2,)).astype(np.uint64, copy=True).reshape(-1, 2)
                   if n else np.zeros((0, 2), dtype=np.uint64))
         hb = np.ctypeslib.as_array(img.hap_out_begin, shape=(int(img.n_haps) + 1,)).astype(np.uint64, copy=True)
