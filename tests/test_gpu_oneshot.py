@@ -213,3 +213,32 @@ def test_reference_task_dumps_in_one_call(gpu_ctx, golden, kernel, fasta):
         assert text == want, (kernel, fasta, h)
     b.close()
     rs.close()
+
+
+@pytest.mark.parametrize("kernel", [0, 6, 7, 8])
+def test_degenerate_streams_in_one_call(built, gpu_ctx, kernel):
+    """No haplotypes; haplotypes without transcripts; transcripts without Tasks (start-lost: an empty GIR, transcript_instructions.rs:338-343)
+    and with nothing but cells no Task covers ('.', haplotype_instruction.rs:78); one Task."""
+    from stream_util import Stream
+    prot = np.frombuffer(b"MEDLGENTMVLSTLRSLNNFISQRVEGGSGLEELERGGAKLMNPQRSTVWYACDEFGHIK", dtype=np.uint8)
+    gpu_ctx.upload_proteome(prot)
+    z8, z32 = np.zeros(0, np.uint8), np.zeros(0, np.uint32)
+    cases = [
+        (Stream([0], [], [], [], [0], [0], z8, z32, z32, z32, z8), []),                                               # no haplotypes
+        (Stream([0, 0, 0], [], [], [], [0], [0], z8, z32, z32, z32, z8), [b"", b""]),                                 # two haplotypes, no transcripts
+        (Stream([0, 2, 3], [0, 0, 0], [60, 60, 60], [0, 7, 60], [0, 0, 0, 1], [0, 0, 0, 0], [0], [0], [60], [0], z8),  # empty GIR, seven '.', one copy
+         [b"" + b"." * 7, bytes(prot)]),
+    ]
+    for s, want in cases:
+        rs = gpu_ctx.upload_stream(s)
+        b = gpu_ctx.batch()
+        b.build_and_execute(rs, kernel, 0)
+        b.sync()
+        assert b.counts()["n_haps"] == len(want)
+        for h, w in enumerate(want):
+            assert b.download_hap(h).tobytes() == w, (kernel, h)
+        if want:
+            b.execute(); b.sync()
+            assert b.download_hap(len(want) - 1).tobytes() == want[-1]
+        b.close()
+        rs.close()
