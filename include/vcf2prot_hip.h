@@ -380,7 +380,10 @@ typedef struct {
                                   * per-block chunk (routing-only A/B switches; kernel variants live in libv2p_bench.so).
                                   * v2p_set_launch_opts only: 16 = ONE launch for all phases of a wave image (read-ahead workgroups of
                                   * phase g + 1 in the grid before the stitch workgroups of phase g), 17 = the read-ahead as kernels of
-                                  * its own, 18 = no read-ahead -- A/B switches of the phased launcher                             */
+                                  * its own, 18 = no read-ahead -- A/B switches of the phased launcher; 20 / 21 = A/B switches of
+                                  * v2p_batch_build_and_execute's builder (20: tiles dealt to the XCDs by workgroup index; 21: tile tables made
+                                  * inside the call; 22: a wave image stays padded -- no compaction pass, descriptors read from the tiles'
+                                  * slots; measured slower per execute than it saves per build)                                                  */
 } v2p_launch_opts;
 /* src0/src1 must have 32 readable bytes before and after (the kernel loads whole aligned 16-byte
  * blocks around a task's bytes), and so must d_desc (16 before, 32 after: stitchw_kernel reads an immediate descriptor's literal

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--oracle", action="store_true", help="also check a sample of haplotypes against the oracle")
+    ap.add_argument("--variants", default="", help="comma list of v2p_set_launch_opts variants (0 = the product; 20, 21: builder A/B switches): "
+                    "the one call with ONE slice under each, interleaved, instead of the slice sweep")
     a = ap.parse_args()
     import torch
     from vcf2prot_amd import build
@@ -81,6 +83,48 @@ def main():
 
         b = ctx.batch()
         res = {}
+        if a.variants:
+            vs = [int(x) for x in a.variants.split(",")]
+            for rep in range(a.reps):
+                for warm in (False, True):
+                    for var in vs:
+                        ctx.set_launch_opts(variant=var)
+                        b.reset()
+                        regime(warm)
+                        b.build_and_execute(rs, a.kernel, 1)
+                        b.sync()
+                        info = b.oneshot_info()
+                        assert np.array_equal(b.digests(), dig), var
+                        res.setdefault(f"variant{var}_{'warm' if warm else 'cold'}", []).append(
+                            {"total_ms": info["total_ms"], "build_ms_sum": info["build_ms"], "tables_ms": info.get("tables_ms", 0.0), "call_wall_ms": info["call_wall_ms"]})
+            # the image each variant leaves behind, re-executed (steady state), interleaved
+            steady = {}
+            bs = {}
+            for var in sorted(set(vs)):
+                ctx.set_launch_opts(variant=var)
+                bs[var] = ctx.batch()
+                bs[var].build_and_execute(rs, a.kernel, 1); bs[var].sync()
+            ctx.set_launch_opts()
+            for _ in range(3):
+                for var in bs:
+                    bs[var].execute()
+            for var in bs:
+                bs[var].sync()
+            for _ in range(7):
+                for var in bs:
+                    e0, e1 = ev()
+                    e0.record(ts); bs[var].execute(); e1.record(ts); bs[var].sync()
+                    steady.setdefault(f"variant{var}", []).append(e0.elapsed_time(e1))
+            for var in bs:
+                assert np.array_equal(bs[var].digests(), dig), var
+                bs[var].close()
+            out["steady_execute_ms"] = {k: round(sorted(v)[len(v) // 2], 3) for k, v in steady.items()}
+            out["runs"] = res
+            out["summary"] = {k: [round(sorted(r[f] for r in v)[len(v) // 2], 3) for f in ("total_ms", "build_ms_sum", "tables_ms")] for k, v in res.items()}
+            b.close(); ref.close(); rs.close()
+            ctx.set_stream(0)
+            print(json.dumps(out))
+            return
         # the two-call form: build, then execute, one after the other
         for warm in (False, True):
             rows = []

@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r05_call12
+mkdir -p $OUT
+cd $ROOT
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_oneshot.py tests/test_gpu_device_rows.py -q -x 2>&1 | tail -5
+timeout 600 python tools/oneshot_bench.py --workload C3 --samples 10000 --variants 0,20,21 --reps 3 > $OUT/ab_C3.json 2> $OUT/ab_C3.err; tail -c 600 $OUT/ab_C3.json
+timeout 300 python tools/oneshot_bench.py --workload C2 --variants 0,20,21 --reps 3 > $OUT/ab_C2.json 2> $OUT/ab_C2.err; tail -c 600 $OUT/ab_C2.json

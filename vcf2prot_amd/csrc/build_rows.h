@@ -43,6 +43,9 @@ struct RowsArgs {
     uint32_t* tile_count;               // [n_tiles] descriptors of each tile -> (scan) tile_desc_base
     uint64_t* tile_desc_base;           // [n_tiles + 1]
     uint64_t* desc_pad;                 // [n_tiles * ROWS_PAD] the tiles' descriptors before compaction
+    uint32_t  pad_chunks = 0;           // the cutter's records (and the keys) address the PADDED array (sir_pack.hpp: ROWS_TILE_SLOTS slots per tile, GLOBAL tile
+                                        // numbers: desc = the whole array, desc_pad = its first slot of tile0); totals[3] bit 1: a chunk did not fit the form
+    uint32_t  xcd_tiles = 1;            // the parse deals contiguous eighths of its tiles to the XCDs (0: tile = workgroup index; A/B switch)
     uint64_t* totals;                   // [4]: -, -, result offset of the last chunk, -
     uint64_t* desc;
     uint64_t  desc_cap;
@@ -70,7 +73,7 @@ inline void rows_ranges(const RowsArgs& a, uint64_t& t0, uint64_t& t1, uint64_t&
 hipError_t launch_rows_tile_bytes(const RowsArgs& a, uint64_t* scan_scratch, hipStream_t stream);
 uint64_t rows_scan_scratch_entries(uint64_t n);
 constexpr uint32_t ROWS_CHUNK_PAD = 96;            // chunk slots per segment of 640 rows in the cutter's padded table (64 ten-row chunks tile a segment)
-constexpr uint32_t ROWS_PAD_SLOTS = 256;           // descriptor slots per tile in the padded array (= build_rows.hip: ROWS_PAD)
+constexpr uint32_t ROWS_PAD_SLOTS = ROWS_TILE_SLOTS;           // descriptor slots per tile in the padded array (= build_rows.hip: ROWS_PAD)
 // the parse: mode ROWS_WAVE / ROWS_DENSE; phase 0: descriptors into the padded array + tile_count (a tile that does not fit its slots
 // is reported: STATUS_ROWS_STAGE), 1: tile_count only, 2: descriptors straight to desc + tile_desc_base[tile] (the two-pass form: any tile)
 hipError_t launch_rows_parse(const RowsArgs& a, int mode, bool fasta, int phase, hipStream_t stream);
@@ -82,6 +85,8 @@ hipError_t launch_rows_hap_begin(const RowsArgs& a, hipStream_t stream);
 hipError_t launch_rows_cut(const RowsArgs& a, int mode, int pass, hipStream_t stream);
 // pass 2's padded table -> chunks_tmp in arena order
 hipError_t launch_rows_chunk_compact(const RowsArgs& a, hipStream_t stream);
+// a padded image's chunk records -> the dense image's (v2p_batch_download_image)
+hipError_t launch_rows_chunks_dense(const Chunk* in, uint64_t n, const uint64_t* tile_desc_base, Chunk* out, hipStream_t stream);
 hipError_t launch_rows_keys(const RowsArgs& a, uint64_t n_chunks, uint64_t n_desc, hipStream_t stream);
 
 }  // namespace v2p

@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void rows_tile_bytes_wave_kernel(RowsArgs a)
     if (lane < a.K && t < a.n_tx) {
         const uint32_t hl = a.tx_header_len ? a.tx_header_len[t] : 0u;
         const uint64_t l = uint64_t(a.tx_res_len[t]) + (hl ? hl + 1u : 0u);
-        if (l >> 31) rreport(a.status, a.tx_task_begin[t], STATUS_ROWS_SPAN);   // (the parse would refuse its tile: more than 2 GiB)
-        len = uint32_t(l);
+        if ((l >> 31) && a.status) rreport(a.status, a.tx_task_begin[t], STATUS_ROWS_SPAN);   // (the parse refuses its tile: more than 2 GiB)
+        len = (l >> 31) ? 0x80000000u : uint32_t(l);                           // (saturated: the tile's sum stays above 2 GiB whatever l was)
     }
     const uint32_t lo = wave_incl_scan(len & 0x3FFFFFFu), hi = wave_incl_scan(len >> 26);
     if (lane == 63u) a.tile_bytes[tile] = uint64_t(lo) + (uint64_t(hi) << 26);
@@ -138,6 +138,13 @@ __global__ __launch_bounds__(256) void rows_scan_apply(const uint64_t* __restric
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = tile_sum[gridDim.x];
 }
 
+// workgroup b of a grid of G -> the j-th item of the contiguous range XCD b % 8 owns (a bijection of [0, G) for any G)
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t G)
+{
+    const uint32_t x = b & 7u, j = b >> 3, q = G >> 3, r = G & 7u;
+    return x * q + (x < r ? x : r) + j;
+}
+
 // ---- the parse ------------------------------------------------------------------------------------------------------------------
 // What bounds it (measured, profiles/r04_build_*, r04_sq_counters_parse_kernel_C3.txt): instruction issue, ~200 vector and ~190
 // scalar instructions per window of 64 items, once a tile's dependent loads are requested together (below).  A burst of the tile's
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256) void rows_scan_apply(const uint64_t* __restric
 // tile where it starts; positions are 32-bit offsets from the tile's first emitted byte; per-transcript values sit in LDS as
 // arrays of words; everything rare (runs of more than 1 KiB, which may cross two rows, or of more than a descriptor's length
 // field) is behind one wave-uniform branch.
-constexpr uint32_t ROWS_PAD = 256;             // descriptor slots per tile in the padded array (a tile with more: the two-pass form)
+constexpr uint32_t ROWS_PAD = ROWS_TILE_SLOTS;             // descriptor slots per tile in the padded array (a tile with more: the two-pass form)
 enum : int { PH_PAD = 0, PH_COUNT = 1, PH_DIRECT = 2 };
 
 constexpr uint32_t ROWS_ALT_LDS = 512;         // alt bytes of a tile kept in LDS (64 lanes x 8)
@@ -176,7 +183,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
     constexpr int RG = FASTA ? 1 : 0, RS = RG + 1, RT = RG + 2;       // run numbers: [0 header] RG gap, RS the task itself, RT tail [4 line feed]
     __shared__ WaveLds L;
     const uint32_t lane = threadIdx.x;
-    const uint64_t tile = a.tile0 + blockIdx.x;                       // (a launch works on tiles [tile0, tile1): the whole stream, or one slice of it)
+    // (a launch works on tiles [tile0, tile1): the whole stream, or one slice of it.)  Workgroup b runs on XCD b % 8 and every XCD has
+    // its own L2: XCD x takes a CONTIGUOUS eighth of the tiles, so that the lines of the Task arrays, the row map and the padded array
+    // that two neighbouring tiles share are fetched (and written back) by one L2, not by two
+    const uint32_t rel = a.xcd_tiles ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint64_t tile = a.tile0 + rel;
     const uint64_t t0 = tile * a.K;
     const uint32_t nh = uint32_t(a.n_tx - t0 < a.K ? a.n_tx - t0 : a.K);
     const uint64_t task_lo = a.tx_task_begin[t0], task_end = a.tx_task_begin[t0 + nh];
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
     }
     asm volatile("" ::: "memory");
     const uint32_t n_items = n_tile_tasks + uint32_t(__popcll(ne));                      // >= nh >= 1
-    uint64_t* const out = PHASE == PH_PAD ? a.desc_pad + uint64_t(blockIdx.x) * ROWS_PAD : (PHASE == PH_DIRECT ? a.desc + a.tile_desc_base[tile] : nullptr);
+    uint64_t* const out = PHASE == PH_PAD ? a.desc_pad + uint64_t(rel) * ROWS_PAD : (PHASE == PH_DIRECT ? a.desc + a.tile_desc_base[tile] : nullptr);
     (void)out;
     const uint32_t out_cap = PHASE == PH_PAD ? ROWS_PAD : 0xFFFFFFFFu;
     // cover entry: tile : 25 | descriptor inside the tile : 16 | what the descriptor has from the row's first byte on : 11 | offset of that byte
@@ -532,7 +543,21 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
         // rows r0 .. r0 + 63 in registers: the descriptor covering each row's first byte
         const uint64_t b = r0, r = b + lane;
         uint64_t c = 0, idx = 0;
-        if (r >= 1u && r < a.n_rows) { c = a.cover[r]; idx = (c >> 63) ? (c >> 22) & ((1ull << 41) - 1ull) : a.tile_desc_base[c >> 38] + ((c >> 22) & 0xFFFFu); }
+        uint32_t pslot = 0, pd = 0;              // PADDED records: the row's descriptor as a slot of the padded array; descriptors from it to the end of its tile | ... of the next tile << 16
+        if (r < a.n_rows) {
+            if (r >= 1u) c = a.cover[r];
+            if (c >> 63) idx = (c >> 22) & ((1ull << 41) - 1ull);
+            else {
+                const uint64_t tl = c >> 38, sl = (c >> 22) & 0xFFFFu, tb0 = a.tile_desc_base[tl];
+                idx = r >= 1u ? tb0 + sl : 0ull;
+                if (a.pad_chunks) {
+                    const uint64_t e1 = a.tile_desc_base[tl + 1u], e2 = tl + 2u <= a.n_tiles ? a.tile_desc_base[tl + 2u] : e1;
+                    pslot = uint32_t(tl * ROWS_PAD + sl);
+                    const uint64_t d1 = e1 - idx, d2 = e2 - idx;                     // (idx < e1 unless tile 0 is empty and r = 0: d1 = 0 marks it)
+                    pd = uint32_t(d1 < 0xFFFFu ? d1 : 0xFFFFu) | (uint32_t(d2 < 0xFFFFu ? d2 : 0xFFFFu) << 16);
+                }
+            }
+        }
         const uint32_t off = uint32_t(c) & PIECE_MAX;
         const uint64_t lastd = r >= a.n_rows ? n_desc - 1u : (off ? idx : idx - 1u);      // last descriptor of a chunk that ends at row r
         // what a chunk ending at row r leaves of its last descriptor behind the cut: the parse wrote it into the row map
@@ -545,9 +570,21 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
             const uint64_t m = __ballot(ok);
             if (!m) { if (lane == 0) rreport(a.status, f, STATUS_ROWS_TOO_MANY); return; }
             const uint32_t hb = 63u - uint32_t(__builtin_clzll(m));
+            uint32_t ps = 0, pdc = 0;
+            if (EMIT && a.pad_chunks) { ps = uint32_t(__builtin_amdgcn_readlane(int(pslot), int(cur))); pdc = uint32_t(__builtin_amdgcn_readlane(int(pd), int(cur))); }
             if (EMIT && lane == hb && (PASS != 2 || count < ROWS_CHUNK_PAD)) {
                 const uint64_t n = lastd - f + 1u;
-                table[out_k] = Chunk{f | (uint64_t(hs) << TB_IDX_BITS) | (uint64_t(tc) << (TB_IDX_BITS + TB_SKIP_BITS)), ((b + cur) * ROW_BYTES) | (n << 48) | CHUNK_CLIP | flag};
+                uint64_t first = f, n1 = 0;
+                if (a.pad_chunks) {
+                    // the record addresses the PADDED array (sir_pack.hpp): the first n1 descriptors in the start row's tile, the others from
+                    // the next tile's first slot.  A chunk that reaches into a third tile (tiles of a few descriptors) cannot say so: the
+                    // host is told (totals[3] bit 1) and builds the dense form instead
+                    const uint64_t d1 = pdc & 0xFFFFu, d2 = pdc >> 16;
+                    first = ps;
+                    n1 = n <= d1 ? 0u : d1;
+                    if (d1 == 0u || n > d2 || d1 > CHUNK_N1_MASK) atomicOr(reinterpret_cast<unsigned long long*>(a.totals) + 3, 2ull);
+                }
+                table[out_k] = Chunk{first | (uint64_t(hs) << TB_IDX_BITS) | (uint64_t(tc) << (TB_IDX_BITS + TB_SKIP_BITS)), ((b + cur) * ROW_BYTES) | n1 | (n << 48) | CHUNK_CLIP | flag};
             }
             last_dst = (b + cur) * ROW_BYTES;
             ++count; ++out_k;
@@ -581,10 +618,12 @@ __global__ __launch_bounds__(256) void rows_keys_kernel(RowsArgs a, uint64_t n_c
     if (k >= n_chunks) return;
     const Chunk ch = a.chunks_tmp[k];
     const uint64_t tb = ch.task_begin & TB_IDX_MASK;
-    const uint32_t n = uint32_t(ch.dst_n >> 48) & CHUNK_N_MASK;
+    const uint32_t n = uint32_t(ch.dst_n >> 48) & CHUNK_N_MASK, n1 = a.pad_chunks ? uint32_t(ch.dst_n & CHUNK_N1_MASK) : 0u;
     uint64_t key = 0;
-    for (uint32_t q = 0; q < n && q < 6u && tb + q < n_desc; ++q) {
-        const uint64_t d = a.desc[tb + q];
+    for (uint32_t q = 0; q < n && q < 6u; ++q) {
+        const uint64_t i = chunk_desc_slot(tb, n1, q);                   // (n_desc: the array's slots when the records address the padded array)
+        if (i >= n_desc) break;
+        const uint64_t d = a.desc[i];
         const bool snv = (d & SNV3_MARK) == SNV3_MARK || (d >> 60) == 0xDull;
         const uint64_t src = snv ? (d & SNV3_MAX_SRC) : (d & SRC_MASK);
         if ((snv || (d >> 62) == SPACE_PROTEOME) && src < a.proteome_len) { key = src; break; }
@@ -615,7 +654,7 @@ hipError_t launch_rows_tile_bytes(const RowsArgs& a, uint64_t* scan_scratch, hip
     return hipGetLastError();
 }
 
-static_assert(ROWS_PAD == ROWS_PAD_SLOTS, "build_rows.h");
+static_assert(ROWS_PAD == ROWS_PAD_SLOTS && ROWS_PAD == ROWS_TILE_SLOTS, "build_rows.h, sir_pack.hpp");
 
 template <int MODE, bool FASTA>
 static hipError_t launch_parse_t(const RowsArgs& a, int phase, hipStream_t stream)
@@ -683,6 +722,23 @@ hipError_t launch_rows_keys(const RowsArgs& a, uint64_t n_chunks, uint64_t n_des
 {
     if (n_chunks == 0) return hipSuccess;
     hipLaunchKernelGGL(rows_keys_kernel, dim3(uint32_t((n_chunks + 255) / 256)), dim3(256), 0, stream, a, n_chunks, n_desc);
+    return hipGetLastError();
+}
+
+// the records of a PADDED image (sir_pack.hpp) as records of the dense one: slot -> tile_desc_base[tile] + slot inside the tile
+__global__ __launch_bounds__(256) void rows_chunks_dense_kernel(const Chunk* __restrict__ in, uint64_t n, const uint64_t* __restrict__ tile_desc_base, Chunk* __restrict__ out)
+{
+    const uint64_t k = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    if (k >= n) return;
+    const Chunk ch = in[k];
+    const uint64_t slot = ch.task_begin & TB_IDX_MASK;
+    const uint64_t dense = tile_desc_base[slot / ROWS_TILE_SLOTS] + slot % ROWS_TILE_SLOTS;
+    out[k] = Chunk{(ch.task_begin & ~TB_IDX_MASK) | dense, ch.dst_n & ~CHUNK_N1_MASK};
+}
+hipError_t launch_rows_chunks_dense(const Chunk* in, uint64_t n, const uint64_t* tile_desc_base, Chunk* out, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rows_chunks_dense_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, stream, in, n, tile_desc_base, out);
     return hipGetLastError();
 }
 

@@ -117,6 +117,17 @@ V2P_HOST_DEVICE inline uint64_t chunk_first(uint64_t task_begin) { return task_b
 V2P_HOST_DEVICE inline uint32_t chunk_head_skip(uint64_t task_begin) { return uint32_t(task_begin >> TB_IDX_BITS) & PIECE_MAX; }
 V2P_HOST_DEVICE inline uint32_t chunk_tail_clip(uint64_t task_begin) { return uint32_t(task_begin >> (TB_IDX_BITS + TB_SKIP_BITS)) & PIECE_MAX; }
 V2P_HOST_DEVICE inline uint64_t chunk_dst(uint64_t dst_n) { return dst_n & ((1ull << 48) - 1); }
+// PADDED rows images (round 5: what v2p_batch_build_and_execute leaves behind for a wave image; never seen by a host -- a download
+// hands out the dense form).  The descriptors stay where the parse wrote them: tile t (K consecutive transcripts) owns slots
+// [ROWS_TILE_SLOTS t, ROWS_TILE_SLOTS (t + 1)) of the array, filled from its first slot -- no compaction pass.  task_begin's index is
+// a slot of that array, and a chunk whose descriptors go on into the NEXT tile says how many lie in its first one in the low ten bits
+// of dst_n (a rows chunk starts on a multiple of 1024, so they are free): 0 = all of them (every dense-addressed chunk), n1 = the
+// first n1 at task_begin, the others from the next tile's first slot.
+constexpr uint32_t ROWS_TILE_SLOTS = 256;
+constexpr uint64_t CHUNK_N1_MASK = 1023;
+V2P_HOST_DEVICE inline uint64_t chunk_next_tile(uint64_t first) { return (first / ROWS_TILE_SLOTS + 1u) * ROWS_TILE_SLOTS; }
+// slot of the chunk's k-th descriptor (n1 = dst_n & CHUNK_N1_MASK)
+V2P_HOST_DEVICE inline uint64_t chunk_desc_slot(uint64_t first, uint32_t n1, uint32_t k) { return (n1 == 0u || k < n1) ? first + k : chunk_next_tile(first) + (k - n1); }
 
 inline uint64_t pack_desc(uint64_t src, uint32_t len, unsigned space) {
     return (src & SRC_MASK) | (uint64_t(len & LEN_MASK) << 40) | (uint64_t(space & 3u) << 62);

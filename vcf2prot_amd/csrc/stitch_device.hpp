@@ -132,8 +132,10 @@ __device__ __forceinline__ void touch_chunks(const uint64_t* __restrict__ desc, 
     uint64_t d[TOUCH_CHUNKS_PER_WAVE];
 #pragma unroll
     for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k) {
-        const uint64_t n = (ch[k].dst_n >> 48) & uint64_t(CHUNK_N_MASK), tb = ch[k].task_begin & TB_IDX_MASK, i = tb + lane;
-        d[k] = (i < tb + n && i < n_desc) ? desc[i] : (uint64_t(SPACE_FILL) << 62);
+        const uint64_t n = (ch[k].dst_n >> 48) & uint64_t(CHUNK_N_MASK), tb = ch[k].task_begin & TB_IDX_MASK;
+        const uint32_t n1 = (ch[k].dst_n & CHUNK_CLIP) ? uint32_t(ch[k].dst_n & CHUNK_N1_MASK) : 0u;      // (a padded rows image: sir_pack.hpp)
+        const uint64_t i = chunk_desc_slot(tb, n1, lane);
+        d[k] = (lane < n && i < n_desc) ? desc[i] : (uint64_t(SPACE_FILL) << 62);
     }
     auto payload_lines = [&](uint64_t dd) {
         const uint64_t src = dd & SRC_MASK, len = (dd >> 40) & LEN_MASK;

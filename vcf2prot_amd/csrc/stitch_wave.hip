@@ -171,15 +171,20 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
     const uint32_t tclip = RIMG ? uint32_t(tb_raw >> (TB_IDX_BITS + TB_SKIP_BITS)) : 0u;
     const uint32_t n_hdr = uint32_t(dn >> 48) & CHUNK_N_MASK;
     if (RIMG != ((dn & CHUNK_CLIP) != 0ull)) { if (lane == 0u) report(p_status, tb, STATUS_RES_OOB); return; }      // (the launcher picked the wrong instance: refused, not guessed)
-    const uint64_t dst = dn & DST_MASK;
+    // a PADDED rows image (sir_pack.hpp): the chunk's first n1 descriptors at tb, the others from the next tile's first slot (n1 = 0: all at tb)
+    const uint32_t n1 = RIMG ? uint32_t(dn & CHUNK_N1_MASK) : 0u;
+    const uint64_t dst = RIMG ? dn & (DST_MASK & ~CHUNK_N1_MASK) : dn & DST_MASK;
     const uint32_t head = RIMG ? 0u : uint32_t(dst) & 15u;
+    const uint64_t hop = RIMG && n1 != 0u ? chunk_next_tile(tb) - tb - n1 : 0ull;      // what a lane behind the first n1 adds to tb + lane
     // a chunk table that points outside the descriptor array is refused, not followed
-    const bool hdr_ok = n_hdr <= CHUNK_TASKS_WAVE && tb <= n_desc && n_hdr <= n_desc - tb;
+    const bool hdr_ok = RIMG ? n_hdr <= CHUNK_TASKS_WAVE && tb <= n_desc && n_hdr + hop <= n_desc - tb && n1 <= n_hdr
+                             : n_hdr <= CHUNK_TASKS_WAVE && tb <= n_desc && n_hdr <= n_desc - tb;
     const uint32_t n = hdr_ok ? n_hdr : 0u;
+    const uint32_t lofs = RIMG ? lane + (n1 != 0u && lane >= n1 ? uint32_t(hop) : 0u) : lane;      // the lane's descriptor, from tb (hop <= 256)
     // (no branch around the load: lanes past the chunk's last descriptor read the chunk header and drop it.  A prefetch of a later
     // chunk's descriptor lines into the L2 from here -- 1 Ki, 4 Ki, 16 Ki chunks ahead, issued behind this load and waited for by
     // nobody before the patch phase -- was measured: C2 +3.5 %, C3 +1 % SLOWER; not kept.)
-    const uint64_t d_raw = *(lane < n ? p_desc + tb + lane : reinterpret_cast<const uint64_t*>(p_chunks + c));
+    const uint64_t d_raw = *(lane < n ? p_desc + tb + lofs : reinterpret_cast<const uint64_t*>(p_chunks + c));
     {   // the byte-mask table, without a branch (every lane writes an entry; lanes and waves that share one write the same value)
         const uint32_t jm = lane < 16u ? lane : 16u;
         u32x4 m;
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
     const bool ref = snv || space == SPACE_PROTEOME;
     const bool bad = (RIMG && hs + tcl != 0u && hs + tcl >= bytes0) || (imm ? len1 > IMM_MAX_BYTES : (gathers && src + bytes0 > (ref ? src0_len : src1_len)));   // never read out of bounds: task.rs would panic
     // (an immediate record's bytes ARE in memory: the low bytes of its own descriptor, just loaded -- it is a stream like any other)
-    const uint64_t a = (imm ? reinterpret_cast<uint64_t>(p_desc + tb + lane) : (gathers ? reinterpret_cast<uint64_t>(ref ? p_src0 : p_src1) + src : dots16)) + (gathers || imm ? hs : 0u);
+    const uint64_t a = (imm ? reinterpret_cast<uint64_t>(p_desc + tb + lofs) : (gathers ? reinterpret_cast<uint64_t>(ref ? p_src0 : p_src1) + src : dots16)) + (gathers || imm ? hs : 0u);
     const uint32_t bytes = bytes0 - hs - tcl;
     const uint32_t incl = wave_incl_scan(bad ? 0u : bytes);
     const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));

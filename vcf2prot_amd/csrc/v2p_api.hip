@@ -159,6 +159,13 @@ struct v2p_batch {
     // v2p_batch_build_and_execute: tables that outlive the call so that a batch that is rebuilt recycles them, the slices' chunk ranges
     // and the events of the last call (read by v2p_batch_oneshot_info after a sync)
     DevBuf d_tiles, d_cover, d_pad, d_order;
+    // a PADDED wave image (sir_pack.hpp; what the one call leaves behind): d_desc holds ROWS_TILE_SLOTS slots per tile, the chunk records
+    // address its slots; desc_slots = its size (the kernels' bound), n_desc the descriptors it holds; pad_tdbase = the scan of the tiles'
+    // counts (in d_tiles), with which a download hands out the dense form
+    bool pad_image = false;
+    uint64_t desc_slots = 0, pad_n_tiles = 0;
+    uint32_t pad_K = 0;
+    const uint64_t* pad_tdbase = nullptr;
     uint32_t n_slices = 0;
     uint64_t slice_chunk0[V2P_MAX_SLICES + 1] = {};
     uint64_t slice_desc[V2P_MAX_SLICES] = {}, slice_bytes[V2P_MAX_SLICES] = {};
@@ -1831,7 +1838,16 @@ struct v2p_stream {
     DevStreamView v;
     uint64_t out_bytes = 0;
     std::vector<uint64_t> hap_out_begin;       // res_counter (haplotype_instruction.rs:90,132) at every haplotype's first transcript, from the host tables
+    // res_counter per TILE of the rows builder (K transcripts: rows_pick_k for the image kind the routing rule picks) and per haplotype, on
+    // the device: tables of the stream, made once behind its upload -- v2p_batch_build_and_execute then starts with the parse
+    DevBuf tiles;
+    uint32_t tile_K = 0;
+    uint64_t n_tiles = 0;
+    const uint64_t* tile_res_base = nullptr;   // [n_tiles + 1]
+    const uint64_t* d_hap_out_begin = nullptr; // [n_haps + 1]
 };
+
+static int rows_mode_for(const v2p_stream* st, int kernel);
 
 int v2p_stream_upload(v2p_ctx* c, const v2p_txstream* s, v2p_stream** out)
 {
@@ -1845,9 +1861,30 @@ int v2p_stream_upload(v2p_ctx* c, const v2p_txstream* s, v2p_stream** out)
     int rc = check_stream(c, s, &fasta, nullptr, &st->hap_out_begin);
     if (rc == V2P_OK && hipSetDevice(c->device) != hipSuccess) rc = c->fail(V2P_ERR_HIP, "hipSetDevice");
     if (rc == V2P_OK) rc = upload_stream(c, s, fasta, st->buf, st->alt, st->v, c->stream);
+    if (rc == V2P_OK) {
+        // the tile tables of the image kind a call with kernel = 0 builds (a call that asks for the other kind makes its own)
+        st->out_bytes = st->hap_out_begin.back();
+        const uint32_t K = rows_pick_k(st->v, rows_mode_for(st, 0));
+        const uint64_t n_tiles = st->v.n_tx ? (st->v.n_tx + K - 1) / K : 1;
+        auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
+        const uint64_t o_tbytes = 0, o_tbase = up8(n_tiles * 8), o_hap = o_tbase + up8((n_tiles + 1) * 8), o_scan = o_hap + up8((st->v.n_haps + 1) * 8),
+                       o_end = o_scan + up8(rows_scan_scratch_entries(n_tiles) * 8);
+        if (st->tiles.ensure_exact(o_end) != hipSuccess) { (void)hipGetLastError(); }    // (no room: the calls make their own tables)
+        else {
+            RowsArgs a;
+            rows_args_of(st->v, c, K, n_tiles, a);
+            uint8_t* const d = st->tiles.ptr();
+            a.tile_bytes = reinterpret_cast<uint64_t*>(d + o_tbytes); a.tile_res_base = reinterpret_cast<uint64_t*>(d + o_tbase);
+            a.hap_out_begin = reinterpret_cast<uint64_t*>(d + o_hap);
+            a.status = nullptr;                                    // (a tile of more than 2 GiB is found again, and reported, by the parse)
+            hipError_t e = launch_rows_tile_bytes(a, reinterpret_cast<uint64_t*>(d + o_scan), c->stream);
+            if (e == hipSuccess) e = launch_rows_hap_begin(a, c->stream);
+            if (e != hipSuccess) rc = c->hip_fail(e, "launch(tile tables)");
+            else { st->tile_K = K; st->n_tiles = n_tiles; st->tile_res_base = a.tile_res_base; st->d_hap_out_begin = a.hap_out_begin; }
+        }
+    }
     if (rc == V2P_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = c->fail(V2P_ERR_HIP, "hipStreamSynchronize");
-    if (rc != V2P_OK) { st->buf.release(); st->alt.release(); delete st; return rc; }
-    st->out_bytes = st->hap_out_begin.back();
+    if (rc != V2P_OK) { st->buf.release(); st->alt.release(); st->tiles.release(); delete st; return rc; }
     *out = st;
     return V2P_OK;
 }
@@ -1858,7 +1895,7 @@ void v2p_stream_destroy(v2p_stream* st)
     std::lock_guard<std::mutex> lk(st->ctx->mu);
     (void)hipSetDevice(st->ctx->device);
     (void)hipDeviceSynchronize();                      // (batches built from it may still execute on either stream: their payload descriptors read its alt bytes)
-    st->buf.release(); st->alt.release();
+    st->buf.release(); st->alt.release(); st->tiles.release();
     delete st;
 }
 
@@ -1892,6 +1929,7 @@ int v2p_batch_reset(v2p_batch* b)
     b->finalized = false; b->uses_proteome = false; b->hap_open = false;
     b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0;
     b->payload_dev = nullptr; b->n_slices = 0; b->launch_hint = 0; b->is_patch = false; b->patch_segs = b->patch_patches = 0;
+    b->pad_image = false; b->desc_slots = 0; b->pad_tdbase = nullptr;
     return V2P_OK;
 }
 
@@ -1991,7 +2029,14 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     uint64_t T[V2P_MAX_SLICES + 1], max_tiles = 0;
     for (uint32_t j = 0; j <= S; ++j) T[j] = n_tiles * j / S;
     for (uint32_t j = 0; j < S; ++j) if (T[j + 1] - T[j] > max_tiles) max_tiles = T[j + 1] - T[j];
-    HIP_TRY(c, b->d_pad.ensure_exact(max_tiles * ROWS_PAD_SLOTS * 8), "hipMalloc(padded descriptors)");
+    // Variant 22 (A/B; measured and NOT the default): a wave image stays PADDED (sir_pack.hpp) -- the parse writes every tile's descriptors
+    // to its slots of d_desc and that is where the stitch kernel reads them, no compaction.  The build loses 0.6 ms of the north star's
+    // cohort's 4.7 (0.74 ms of copy, 3.6 GB of traffic) ... and every execute of the image gains 0.4-0.5 ms of its 7.6: a chunk's
+    // descriptors lie in two places, the array's lines are 55 % used, and the read-ahead of a phase covers twice the address range
+    // (profiles/r05_padded_image.txt).  One shot -0.17 ms, every later execute +6 %: the compaction stays.
+    const uint32_t bvar = c->launch_opts.variant;
+    const bool pad = mode == ROWS_WAVE && bvar == 22u && n_tiles < (1ull << 24);
+    if (!pad) HIP_TRY(c, b->d_pad.ensure_exact(max_tiles * ROWS_PAD_SLOTS * 8), "hipMalloc(padded descriptors)");
     const uint64_t desc_cap = n_tiles * ROWS_PAD_SLOTS;              // (one-pass tiles hold at most their 256 slots)
     HIP_TRY(c, b->d_desc.ensure_exact(desc_cap * 8), "hipMalloc(desc)");
     const uint64_t cap = n_segs ? n_segs * ROWS_CHUNK_PAD : 1;
@@ -2017,6 +2062,11 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     RowsArgs a;
     rows_args_of(v, c, K, n_tiles, a);
     a.tile_bytes = reinterpret_cast<uint64_t*>(d + o_tbytes); a.tile_res_base = reinterpret_cast<uint64_t*>(d + o_tbase);
+    // (A/B switches of the builder, v2p_set_launch_opts: variant 20 = tile = workgroup index in the parse, 21 = tile tables made inside the
+    // call: round 5's first form; 22 = the padded image)
+    a.xcd_tiles = bvar == 20u ? 0u : 1u;
+    const bool cached = bvar != 21u && S == 1 && st->tile_K == K && st->n_tiles == n_tiles && st->tile_res_base != nullptr;
+    if (cached) a.tile_res_base = const_cast<uint64_t*>(st->tile_res_base);      // (read only from here on)
     a.tile_count = reinterpret_cast<uint32_t*>(d + o_tcount); a.tile_desc_base = reinterpret_cast<uint64_t*>(d + o_tdbase);
     a.totals = reinterpret_cast<uint64_t*>(d + o_totals);
     a.status = reinterpret_cast<unsigned long long*>(b->d_status.ptr());
@@ -2029,6 +2079,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     a.hap_out_begin = reinterpret_cast<uint64_t*>(b->d_hap.ptr());
     a.desc_pad = reinterpret_cast<uint64_t*>(b->d_pad.ptr());
     a.desc = reinterpret_cast<uint64_t*>(b->d_desc.ptr()); a.desc_cap = desc_cap;
+    a.pad_chunks = pad ? 1u : 0u;
     Chunk* const chunks_tmp = reinterpret_cast<Chunk*>(sc + s_tmp);
     uint8_t* const bucket = sc + s_bucket; uint8_t* const sub = sc + s_sub;
     // the batch describes the image from here on (a failure below resets it)
@@ -2045,12 +2096,18 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     OS_TRY(hipEventRecord(b->ev_os[0], A), "hipEventRecord");
     OS_TRY(hipStreamWaitEvent(B, b->ev_os[0], 0), "hipStreamWaitEvent");
     OS_TRY(hipMemsetAsync(d + o_totals, 0, 64, B), "hipMemset(totals)");
-    OS_TRY(launch_rows_tile_bytes(a, scan_scratch, B), "launch(tile bytes)");
-    OS_TRY(launch_rows_hap_begin(a, B), "launch(hap_begin)");
     uint64_t R[V2P_MAX_SLICES + 1];                                 // arena offset of every slice's first tile
-    for (uint32_t j = 0; j <= S; ++j) OS_TRY(hipMemcpyAsync(&R[j], d + o_tbase + T[j] * 8, 8, hipMemcpyDeviceToHost, B), "D2H(slice offsets)");
-    OS_TRY(hipStreamSynchronize(B), "hipStreamSynchronize");
-    if (R[S] != out_bytes) return fail_reset(c->fail(V2P_ERR_STATE, "the resident stream's tables changed since its upload"));
+    if (cached) {
+        // res_counter per tile and per haplotype came with the stream (v2p_stream_upload): no kernel, no host round trip before the parse
+        OS_TRY(hipMemcpyAsync(b->d_hap.ptr(), st->d_hap_out_begin, (n_h + 1) * 8, hipMemcpyDeviceToDevice, B), "D2D(hap_begin)");
+        R[0] = 0; R[S] = out_bytes;
+    } else {
+        OS_TRY(launch_rows_tile_bytes(a, scan_scratch, B), "launch(tile bytes)");
+        OS_TRY(launch_rows_hap_begin(a, B), "launch(hap_begin)");
+        for (uint32_t j = 0; j <= S; ++j) OS_TRY(hipMemcpyAsync(&R[j], d + o_tbase + T[j] * 8, 8, hipMemcpyDeviceToHost, B), "D2H(slice offsets)");
+        OS_TRY(hipStreamSynchronize(B), "hipStreamSynchronize");
+        if (R[S] != out_bytes) return fail_reset(c->fail(V2P_ERR_STATE, "the resident stream's tables changed since its upload"));
+    }
     uint64_t SG[V2P_MAX_SLICES + 1];                                // segments [SG_j, SG_j+1) are complete -- their rows' cover entries and the entry of the
     SG[0] = 0;                                                      // row behind them written -- once slice j is parsed
     for (uint32_t j = 1; j < S; ++j) { SG[j] = R[j] ? (R[j] - 1) / (uint64_t(ROWS_SEG) * ROW_BYTES) : 0; if (SG[j] < SG[j - 1]) SG[j] = SG[j - 1]; }
@@ -2064,14 +2121,17 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
         const uint64_t nt = T[j + 1] - T[j], ns = SG[j + 1] - SG[j];
         OS_TRY(hipEventRecord(b->ev_os[2 + 2 * j], B), "hipEventRecord");
         if (nt) {
+            if (pad) a.desc_pad = a.desc + T[j] * ROWS_PAD_SLOTS;               // (the slice's tiles' own slots of the one array)
             OS_TRY(launch_rows_parse(a, mode, v.fasta, 0, B), "launch(parse)");
             OS_TRY(launch_scan_u32_from(a.tile_count + T[j], nt, a.tile_desc_base + T[j], scan_scratch + rows_scan_scratch_entries(n_tiles), desc0, B), "launch(scan)");
-            // the compaction (a copy at the memory's rate) on a stream of its own, next to the cutter (one wave per 640 rows: latency), the
-            // scan of its counts and the host's round trip for them: the cutter reads the row map alone, only the keys need the descriptors
-            OS_TRY(hipEventRecord(b->ev_aux[0], B), "hipEventRecord");
-            OS_TRY(hipStreamWaitEvent(X, b->ev_aux[0], 0), "hipStreamWaitEvent");
-            OS_TRY(launch_rows_compact(a, X), "launch(compact)");
-            OS_TRY(hipEventRecord(b->ev_aux[1], X), "hipEventRecord");
+            if (!pad) {
+                // the compaction (a copy at the memory's rate) on a stream of its own, next to the cutter (one wave per 640 rows: latency), the
+                // scan of its counts and the host's round trip for them: the cutter reads the row map alone, only the keys need the descriptors
+                OS_TRY(hipEventRecord(b->ev_aux[0], B), "hipEventRecord");
+                OS_TRY(hipStreamWaitEvent(X, b->ev_aux[0], 0), "hipStreamWaitEvent");
+                OS_TRY(launch_rows_compact(a, X), "launch(compact)");
+                OS_TRY(hipEventRecord(b->ev_aux[1], X), "hipEventRecord");
+            }
         }
         if (ns) OS_TRY(launch_rows_cut(a, mode, 2, B), "launch(cut)");
         OS_TRY(launch_scan_u32_from(a.seg_count + SG[j], ns, const_cast<uint64_t*>(a.seg_base) + SG[j], reinterpret_cast<uint64_t*>(b->d_cover.ptr() + c_tiles), chunk0, B), "launch(scan)");
@@ -2093,12 +2153,14 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
         if (chunk_end > 0xFFFFFFFFull) return fail_reset(c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch"));
         a.chunks_tmp = chunks_tmp;
         if (ns) OS_TRY(launch_rows_chunk_compact(a, B), "launch(chunk table)");
-        if (nt) OS_TRY(hipStreamWaitEvent(B, b->ev_aux[1], 0), "hipStreamWaitEvent");      // (the descriptors are in place)
+        // (the keys read the chunks' first descriptors.  Reading them from the padded array instead, so that the keys and the sorts run
+        // beside the compaction as well, was measured: nothing -- the copy runs at the memory's rate and what runs beside it waits for it)
+        if (nt && !pad) OS_TRY(hipStreamWaitEvent(B, b->ev_aux[1], 0), "hipStreamWaitEvent");      // (the descriptors are in place)
         Chunk* const out_chunks = reinterpret_cast<Chunk*>(b->d_chunks.ptr()) + chunk0;
         if (reorder && nc >= 16 && desc_end != 0) {
             RowsArgs ak = a;
             ak.chunks_tmp = chunks_tmp + chunk0; ak.bucket = bucket + chunk0; ak.sub = sub + chunk0;
-            OS_TRY(launch_rows_keys(ak, nc, desc_end, B), "launch(keys)");
+            OS_TRY(launch_rows_keys(ak, nc, pad ? desc_cap : desc_end, B), "launch(keys)");
             const uint32_t nb = xcd_order_blocks(ns * uint64_t(ROWS_SEG) * ROW_BYTES, c->proteome_len, nc, XCD_ORDER_MAX_BLOCKS, nd);
             OS_TRY(launch_order_blocks(ak.chunks_tmp, ak.bucket, ak.sub, nc, nb, reinterpret_cast<uint32_t*>(sc + s_subhist),
                                        reinterpret_cast<uint64_t*>(sc + s_substart), reinterpret_cast<uint64_t*>(sc + s_subtiles),
@@ -2109,13 +2171,14 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
         // ---- the slice is built: stitch it on the context's stream while the build stream goes on ----
         OS_TRY(hipStreamWaitEvent(A, b->ev_os[3 + 2 * j], 0), "hipStreamWaitEvent");
         b->slice_chunk0[j] = chunk0; b->slice_desc[j] = nd; b->slice_bytes[j] = ns * uint64_t(ROWS_SEG) * ROW_BYTES;
-        OS_TRY(stitch_range(b, desc_end, chunk0, nc, nd, b->slice_bytes[j], A), "launch(stitch)");
+        OS_TRY(stitch_range(b, pad ? desc_cap : desc_end, chunk0, nc, nd, b->slice_bytes[j], A), "launch(stitch)");
         desc0 = desc_end; chunk0 = chunk_end;
     }
 #undef OS_TRY
     b->slice_chunk0[S] = chunk0;
     HIP_TRY(c, hipEventRecord(b->ev_os[1], A), "hipEventRecord");
     b->n_desc = desc0; b->n_chunks = chunk0; b->n_slices = S;
+    b->pad_image = pad; b->desc_slots = pad ? desc_cap : 0; b->pad_n_tiles = n_tiles; b->pad_K = K; b->pad_tdbase = a.tile_desc_base;
     b->img.hap_out_begin = st->hap_out_begin;
     b->uses_proteome = true;
     b->finalized = true;
@@ -2217,6 +2280,30 @@ int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, ui
     if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
     if (b->is_patch && desc) return c->fail(V2P_ERR_STATE, "a patch image has segments and patches, not descriptors: v2p_batch_download_patch_image");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    if (b->pad_image) {
+        // a padded image leaves the device in the DENSE form (what every other builder produces and the host restatement describes): the
+        // compaction the call skipped and the chunk records translated, into scratch of this call -- the batch keeps executing what it has
+        DevBuf dd, dc;
+        struct Rel { DevBuf& a; DevBuf& b; ~Rel() { a.release(); b.release(); } } rel{dd, dc};
+        HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+        if (desc && b->n_desc) {
+            HIP_TRY(c, dd.ensure_exact(b->n_desc * 8), "hipMalloc(dense descriptors)");
+            RowsArgs a{};
+            a.n_tiles = b->pad_n_tiles; a.K = b->pad_K; a.tile0 = 0; a.tile1 = b->pad_n_tiles;
+            a.tile_desc_base = const_cast<uint64_t*>(b->pad_tdbase);
+            a.desc_pad = reinterpret_cast<uint64_t*>(b->d_desc.ptr()); a.desc = reinterpret_cast<uint64_t*>(dd.ptr()); a.desc_cap = b->n_desc;
+            HIP_TRY(c, launch_rows_compact(a, c->stream), "launch(compact)");
+            HIP_TRY(c, hipMemcpyAsync(desc, dd.ptr(), b->n_desc * 8, hipMemcpyDeviceToHost, c->stream), "D2H(desc)");
+        }
+        if (chunks && b->n_chunks) {
+            HIP_TRY(c, dc.ensure_exact(b->n_chunks * sizeof(Chunk)), "hipMalloc(dense chunk records)");
+            HIP_TRY(c, launch_rows_chunks_dense(reinterpret_cast<const Chunk*>(b->d_chunks.ptr()), b->n_chunks, b->pad_tdbase, reinterpret_cast<Chunk*>(dc.ptr()), c->stream), "launch(chunk records)");
+            HIP_TRY(c, hipMemcpyAsync(chunks, dc.ptr(), b->n_chunks * sizeof(Chunk), hipMemcpyDeviceToHost, c->stream), "D2H(chunks)");
+        }
+        if (hap_out_begin) HIP_TRY(c, hipMemcpyAsync(hap_out_begin, b->d_hap.ptr(), (b->n_haps + 1) * 8, hipMemcpyDeviceToHost, c->stream), "D2H(hap_begin)");
+        HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+        return V2P_OK;
+    }
     if (desc && b->n_desc) HIP_TRY(c, hipMemcpyAsync(desc, b->d_desc.ptr(), b->n_desc * 8, hipMemcpyDeviceToHost, c->stream), "D2H(desc)");
     if (chunks && b->n_chunks) HIP_TRY(c, hipMemcpyAsync(chunks, b->d_chunks.ptr(), b->n_chunks * sizeof(Chunk), hipMemcpyDeviceToHost, c->stream), "D2H(chunks)");
     if (hap_out_begin) HIP_TRY(c, hipMemcpyAsync(hap_out_begin, b->d_hap.ptr(), (b->n_haps + 1) * 8, hipMemcpyDeviceToHost, c->stream), "D2H(hap_begin)");
@@ -2299,11 +2386,12 @@ int v2p_batch_execute(v2p_batch* b)
         if (pe != hipSuccess) return c->hip_fail(pe, "launch(stitch: patch image)");
         return V2P_OK;
     }
-    StitchArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), b->n_desc, reinterpret_cast<const Chunk*>(b->d_chunks.ptr()),
+    StitchArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), b->pad_image ? b->desc_slots : b->n_desc, reinterpret_cast<const Chunk*>(b->d_chunks.ptr()),
                  uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->payload_dev, b->n_payload,
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
     a.opt_phase_bytes = c->launch_opts.phase_bytes; a.opt_phase_min_chunks = c->launch_opts.phase_min_chunks; a.opt_store_sc1 = c->launch_opts.store_sc1;
     a.opt_touch = touch_of(c->launch_opts.variant);
+    a.img_desc = b->pad_image ? b->n_desc : 0;          // (the routing looks at the descriptors the image holds, not at the array's slots)
     dual_of(c, a);
     HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint, 0), "launch(stitch)");
     return V2P_OK;
