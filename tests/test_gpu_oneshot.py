@@ -242,3 +242,34 @@ def test_degenerate_streams_in_one_call(built, gpu_ctx, kernel):
             assert b.download_hap(len(want) - 1).tobytes() == want[-1]
         b.close()
         rs.close()
+
+
+@pytest.mark.parametrize("preset,h0,n,slices", [("C3", 100, 400, 1), ("C2", 3, 60, 3), ("C4", 7, 12, 1), ("C1", 0, 8, 1)])
+def test_padded_wave_image_is_the_dense_one(built, gpu_ctx, preset, h0, n, slices):
+    """v2p_set_launch_opts variant 22: the one call leaves the descriptors in their tiles' slots (no compaction), the chunk records address
+    slots; the arena, the digests and the image a download hands out (dense form) are the compacted build's, chunk order included."""
+    from vcf2prot_amd.cohort import Cohort
+    c = Cohort.preset(preset)
+    gpu_ctx.upload_proteome(c.proteome())
+    stream = c.txstream(h0, h0 + n, n_threads=4)
+    rs = gpu_ctx.upload_stream(stream)
+    stream.close()
+    try:
+        imgs = {}
+        for var in (0, 22):
+            gpu_ctx.set_launch_opts(variant=var)
+            b = gpu_ctx.batch()
+            b.build_and_execute(rs, 6, slices)
+            b.sync()
+            d1 = b.digests()
+            b.execute(); b.sync()
+            assert np.array_equal(b.digests(), d1)
+            imgs[var] = (b.download_image(), d1, b.counts())
+            b.close()
+    finally:
+        gpu_ctx.set_launch_opts()
+    (desc0, ch0, hb0), dig0, cn0 = imgs[0]
+    (desc1, ch1, hb1), dig1, cn1 = imgs[22]
+    assert np.array_equal(dig0, dig1) and cn0 == cn1
+    assert np.array_equal(desc0, desc1) and np.array_equal(ch0, ch1) and np.array_equal(hb0, hb1)
+    rs.close()
