@@ -76,19 +76,18 @@ struct Num { bool valid; bool neg; uint64_t val; };
 template <uint32_t RM>
 __device__ __forceinline__ uint8_t rq(const uint8_t* ring, uint32_t q) { return ring[q & RM]; }
 
-// Rust integer from_str on ring[b, e): optional sign, at least one digit, digits only (value saturates far above u32)
-template <uint32_t RM>
-__device__ __forceinline__ Num parse_num(const uint8_t* ring, uint32_t b, uint32_t e)
+// Rust integer from_str on txt[b, e): optional sign, at least one digit, digits only (value saturates far above u32)
+__device__ __forceinline__ Num parse_num(const uint8_t* txt, uint32_t b, uint32_t e)
 {
     Num n{false, false, 0};
     if (b < e) {
-        const uint8_t c = rq<RM>(ring, b);
+        const uint8_t c = txt[b];
         if (c == '+' || c == '-') { n.neg = (c == '-'); ++b; }
     }
     if (b >= e) return n;
     uint64_t v = 0;
     for (uint32_t q = b; q < e; ++q) {
-        const uint32_t d = uint32_t(rq<RM>(ring, q)) - uint32_t('0');
+        const uint32_t d = uint32_t(txt[q]) - uint32_t('0');
         if (d > 9u) return n;
         v = v * 10u + d;
         if (v > (1ull << 40)) v = 1ull << 40;
@@ -99,10 +98,9 @@ __device__ __forceinline__ Num parse_num(const uint8_t* ring, uint32_t b, uint32
 }
 
 // text_parser::parse_fields + BitMask::from_string on one element: 0 = no consequences; aborts reported through err
-template <uint32_t RM>
-__device__ __forceinline__ uint32_t single_word(const uint8_t* ring, uint32_t b, uint32_t e, uint32_t& err)
+__device__ __forceinline__ uint32_t single_word(const uint8_t* txt, uint32_t b, uint32_t e, uint32_t& err)
 {
-    const Num n = parse_num<RM>(ring, b, e);
+    const Num n = parse_num(txt, b, e);
     if (!n.valid) return 0u;                                   // parse::<i32>() Err -> DEF_CONSEQ (text_parser.rs:216)
     if (n.neg) {
         if (n.val > (1ull << 31)) return 0u;                   // below i32::MIN: Err as well
@@ -128,14 +126,28 @@ __device__ __forceinline__ uint32_t filter_word(uint32_t w, uint32_t base, const
 }
 
 // ---------------------------------------------------------------------------------------------------------- parse
-// BS threads per record: 256 for wide cohorts, fewer when a record's sample columns are shorter than a 4 KiB tile
+// BS threads per record: 256 for wide cohorts, fewer when a record's sample columns are shorter than a 4 KiB tile.
+//
+// Round 5: the columns that need the parser (5 % of a cohort's) are no longer parsed step by step.  Until now every 4 KiB step ended
+// with ONE wave working a list of ~34 columns through the ~300-instruction parser while the step's other waves waited at the
+// barrier -- half of the kernel's time.  Now a column that is not settled by its last two bytes is only NOTED when it is found -- sample
+// and stream position, eight bytes of LDS -- in a list of the whole record, and the list is parsed ONCE, behind the record's last
+// step, with every lane of the workgroup busy (a record of 2 504 samples: ~140 entries).  Two barriers per step instead of three, no
+// parser between them, and what a step does for the rare columns is a dozen instructions (any code a wave runs for ONE lane costs it
+// as much as for 64: capturing the column's last eight bytes from the ring there -- the first form of this -- cost more than it saved).
+// The parser reads the column's last eight bytes from the text in memory (one unaligned load per entry; the record has just been
+// read) and they settle what the fast path settles (a tail of at most seven digits, '.', no ':' in reach); anything else -- long
+// numbers, comma lists, multi-word masks -- goes back through the text byte by byte, which therefore no longer depends on what the
+// ring still holds: the tail of a column is searched for its ':' over exactly 4 KiB.
 template <uint32_t BS>
 __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
 {
     constexpr uint32_t TILE = BS * 16u, RING = 2u * TILE, RM = RING - 1u, NW = BS / 64u;
+    constexpr uint32_t CAP = 8u * BS;                           // entries the record's list holds (flushed early when it fills)
+    constexpr uint32_t TAIL_MAX = 4096u;                        // V2P_ERR_FIELD_TOO_LONG: no ':' / tab within this many bytes before the column's end
     __shared__ __align__(16) uint8_t ring[RING];
-    __shared__ uint32_t list[TILE + 2];                         // the columns of this step that need parsing: end position | (one-digit mask + 1) << 13 | rank << 17
-    __shared__ uint32_t s_nlist;
+    __shared__ uint32_t e_f[CAP], e_pos[CAP];                         // sample, stream position one past the column
+    __shared__ uint32_t s_cnt[2];                                     // entries found in this step (double-buffered by step parity)
     __shared__ uint32_t wave_tot[NW];
     __shared__ uint32_t s_nnz;
 
@@ -144,6 +156,7 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
     const uint64_t rb = a.row_begin[row], re = a.row_end[row];
     const uintptr_t first = reinterpret_cast<uintptr_t>(a.text) + rb;
     const uintptr_t base = first & ~uintptr_t(15);
+    const uint8_t* const gtext = reinterpret_cast<const uint8_t*>(base);     // stream position q <-> gtext[q], q0 <= q < Lq
     const uint32_t q0 = uint32_t(first - base);                 // stream position of the first row byte
     const uint32_t Lq = uint32_t(re - rb) + q0;                 // stream position one past the last row byte
     const uint32_t n_tiles = Lq ? (Lq + TILE - 1u) / TILE : 1u;
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
     const uint64_t field0 = uint64_t(row) * a.n_samples;
     uint32_t fields_before = 0;
     DecCarrier* const carriers = a.carriers + uint64_t(row) * a.n_samples;
-    if (tid == 0) s_nnz = 0u;                                   // (two barriers before the first append)
+    if (tid == 0) { s_nnz = 0u; s_cnt[0] = 0u; s_cnt[1] = 0u; }      // (a barrier before the first append)
 
     auto load_tile = [&](uint32_t t) -> u32x4 {
         const uint32_t qs = t * TILE + tid * 16u;
@@ -161,91 +174,19 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
         return v;
     };
 
-    u32x4 cur = load_tile(0);
-    for (uint32_t t = 0; t < n_tiles; ++t) {
-        const uint32_t tile0 = t * TILE;
-        *reinterpret_cast<u32x4*>(&ring[(tile0 & (RING - 1u)) + tid * 16u]) = cur;
-        u32x4 nxt = {0u, 0u, 0u, 0u};
-        if (t + 1u < n_tiles) nxt = load_tile(t + 1u);
-
-        // tabs among this lane's 16 bytes that belong to the row
-        const uint32_t qs = tile0 + tid * 16u;
-        uint32_t tm = (tab_bits8(cur.x, cur.y) >> 7) | ((tab_bits8(cur.z, cur.w) >> 7) << 8);
-        if (tid == 0) s_nlist = 0u;                                            // (the previous step ended on a barrier)
-        {
-            const uint32_t lo = q0 > qs ? min(q0 - qs, 16u) : 0u;
-            const uint32_t hi = Lq > qs ? min(Lq - qs, 16u) : 0u;
-            tm &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-        }
-        const uint32_t cnt = uint32_t(__builtin_popcount(tm));
-        const uint32_t incl = dec_wave_incl_scan(cnt);
-        if ((tid & 63u) == 63u) wave_tot[wave] = incl;
-        dec_lds_barrier();
-        uint32_t wbase = 0, tile_tabs = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < NW; ++w) {
-            const uint32_t x = wave_tot[w];
-            if (w < wave) wbase += x;
-            tile_tabs += x;
-        }
-        const uint32_t lo = max(q0, t ? tile0 - TILE : 0u);               // oldest stream position still in the ring
-        // Almost every column of a real cohort carries nothing: its text ends in ":0" or ":.".  Those are settled here with
-        // two byte reads; only the others go on the list that the parser below works through, so the parser's cost scales with
-        // the carriers and not with the columns.
-        // (the rank of a column among the step's columns is only worked out for the few that go on the list)
-        auto consider = [&](uint32_t pos, bool inside, auto rank) {
-            const uint32_t p = tile0 + pos;
-            const uint8_t c1 = rq<RM>(ring, p - 1u), c2 = rq<RM>(ring, p - 2u);
-            const bool work = !(inside && c2 == ':' && (c1 == '0' || c1 == '.'));
-            const uint64_t wb = __builtin_amdgcn_ballot_w64(work);
-            if (wb) {
-                const uint32_t k = __builtin_amdgcn_mbcnt_hi(uint32_t(wb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(wb), 0u));
-                uint32_t at = 0u;
-                if (work && k == 0u) at = atomicAdd(&s_nlist, uint32_t(__builtin_popcountll(wb)));
-                at = uint32_t(__builtin_amdgcn_readlane(int(at), int(__builtin_ctzll(wb))));
-                // a one-digit mask (a record with one or two consequences: the commonest carrier) is read off right here; the list
-                // entry carries it and the parser pass below leaves such columns alone
-                const uint32_t digit = uint32_t(c1) - uint32_t('1');
-                const uint32_t pre = (inside && c2 == ':' && digit < 9u) ? digit + 2u : 0u;
-                if (work) list[at + k] = pos | (pre << 13) | (rank() << 17);
-            }
-        };
-        const uint32_t tm0 = tm, slot0 = wbase + incl - cnt;
-        if (t == 0u) {                                                         // only the first step can meet the start of the row
-            while (tm) {
-                const uint32_t b = uint32_t(__builtin_ctz(tm));
-                tm &= tm - 1u;
-                consider(tid * 16u + b, tile0 + tid * 16u + b >= lo + 2u, [&] { return slot0 + uint32_t(__builtin_popcount(tm0 & ((1u << b) - 1u))); });
-            }
-        } else {
-            while (tm) {
-                const uint32_t b = uint32_t(__builtin_ctz(tm));
-                tm &= tm - 1u;
-                consider(tid * 16u + b, true, [&] { return slot0 + uint32_t(__builtin_popcount(tm0 & ((1u << b) - 1u))); });
-            }
-        }
-        const bool last = (t + 1u == n_tiles);
-        if (last && tid == 0) consider(Lq - tile0, Lq >= lo + 2u, [&] { return tile_tabs; });   // the end of the line closes the last column
-        const uint32_t n_ends = tile_tabs + (last ? 1u : 0u);
-        dec_lds_barrier();
-        const uint32_t n_list = s_nlist;
-
-        for (uint32_t j = tid; j < n_list; j += BS) {
-            const uint32_t le = list[j];
-            const uint32_t p = tile0 + (le & 0x1FFFu);                         // one past the column's last byte
-            const uint32_t f = fields_before + (le >> 17);
-            const uint32_t pre = (le >> 13) & 15u;                              // one-digit mask + 1, or 0
-            uint32_t q = p, err = 0u, entry = pre ? pre - 1u : 0u;
-            bool colon = false, slow = pre == 0u;
-            if (__builtin_amdgcn_ballot_w64(slow) == 0ull) {
-                // (every column of this round came with its value)
-            } else if (slow && p >= lo + 8u) {
-                // fast path: the last eight bytes of the column in registers.  Settles every column whose text after the
-                // last ':' is at most seven digits (or '.'), and every column without a ':' that starts inside the window.
-                const uint32_t* ring32 = reinterpret_cast<const uint32_t*>(ring);
-                const uint32_t a8 = (p - 8u) & (RING - 1u), i0 = a8 >> 2, sh = a8 & 3u;
-                const uint32_t w0 = ring32[i0], w1 = ring32[(i0 + 1u) & (RING / 4u - 1u)], w2 = ring32[(i0 + 2u) & (RING / 4u - 1u)];
-                const uint32_t lo32 = __builtin_amdgcn_alignbyte(w1, w0, sh), hi32 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    // ---- the parser: entries [0, n) of the record's list, lane = entry; carriers appended to the record's row ----
+    auto flush = [&](uint32_t n) {
+        for (uint32_t j = tid; j < n; j += BS) {
+            const uint32_t f = e_f[j], p = e_pos[j];
+            uint32_t q = p, err = 0u, entry = 0u;
+            bool colon = false, slow = true;
+            if (p >= q0 + 8u) {
+                // fast path: the last eight bytes of the column, one unaligned load from the text (the record has just been read: L2).
+                // Settles every column whose text after the last ':' is at most seven digits (or '.'), and every column without a
+                // ':' that starts inside the window.
+                struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
+                const uint64_t w8 = reinterpret_cast<const U64 __attribute__((address_space(1)))*>(base + (p - 8u))->v;
+                const uint32_t lo32 = uint32_t(w8), hi32 = uint32_t(w8 >> 32);
                 // Straight-line: the parser is the heaviest part of the kernel (a third of its VALU work before this form).
                 const uint32_t c_hi = eq_bytes(hi32, 0x3A3A3A3Au), c_lo = eq_bytes(lo32, 0x3A3A3A3Au);
                 const uint32_t d_hi = c_hi | eq_bytes(hi32, 0x09090909u), d_lo = c_lo | eq_bytes(lo32, 0x09090909u);   // ':' or tab, 0x80 per byte
@@ -271,27 +212,29 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
                 slow = !(no_colon || dot || number);
             }
             if (slow) {
-            while (q > lo) {
-                const uint8_t c = rq<RM>(ring, q - 1u);
-                if (c == ':') { colon = true; break; }
-                if (c == '\t') break;
-                --q;
-            }
-            if (!colon && q == lo && lo > q0) err = DEC_FIELD_TOO_LONG;
+                // the column's text in memory: back to its last ':' (or to the tab / the row's first byte: no ':' at all)
+                const uint32_t lo = max(q0, p > TAIL_MAX ? p - TAIL_MAX : 0u);
+                while (q > lo) {
+                    const uint8_t c = gtext[q - 1u];
+                    if (c == ':') { colon = true; break; }
+                    if (c == '\t') break;
+                    --q;
+                }
+                if (!colon && q == lo && lo > q0) err = DEC_FIELD_TOO_LONG;
             }
             if (colon) {
-                const uint32_t s = q;                                          // tail = ring[s, p)
+                const uint32_t s = q;                                          // tail = gtext[s, p)
                 const uint32_t len = p - s;
-                if (len == 0u || (len == 1u && rq<RM>(ring, s) == '.')) {
+                if (len == 0u || (len == 1u && gtext[s] == '.')) {
                     entry = 0u;                                                // "" parses to Err, "." is the missing value
                 } else {
                     // elements, how many survive remove_leading_zeros (it strips trailing "0" elements), any '-'
                     uint32_t n_el = 1u, kept = 0u, es = s, first_end = p;
                     bool minus = false;
                     for (uint32_t k = s; k < p; ++k) {
-                        const uint8_t c = rq<RM>(ring, k);
+                        const uint8_t c = gtext[k];
                         if (c == ',') {
-                            if (!(k - es == 1u && rq<RM>(ring, es) == '0')) kept = n_el;
+                            if (!(k - es == 1u && gtext[es] == '0')) kept = n_el;
                             if (n_el == 1u) first_end = k;
                             ++n_el;
                             es = k + 1u;
@@ -299,15 +242,15 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
                             minus = true;
                         }
                     }
-                    if (!(p - es == 1u && rq<RM>(ring, es) == '0')) kept = n_el;
+                    if (!(p - es == 1u && gtext[es] == '0')) kept = n_el;
                     if (n_el == 1u) {
-                        entry = single_word<RM>(ring, s, p, err);                  // text_parser.rs:179-182
+                        entry = single_word(gtext, s, p, err);                     // text_parser.rs:179-182
                     } else if (kept == 0u) {
                         entry = 0u;                                            // "0,0" (text_parser.rs:240-243)
                     } else if (minus) {
                         err = DEC_MASK_NEGATIVE;                               // text_parser.rs:244
                     } else if (kept == 1u) {
-                        entry = single_word<RM>(ring, s, first_end, err);          // "x,0" falls back to parse_fields (text_parser.rs:189-192)
+                        entry = single_word(gtext, s, first_end, err);             // "x,0" falls back to parse_fields (text_parser.rs:189-192)
                     } else {
                         // MaskDecoder.rs:45-50: every kept element must be a u32; word k covers indices 15k .. 15k+15
                         uint32_t any = 0u;
@@ -324,8 +267,8 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
                             }
                             uint32_t eb = s, k = 0u;
                             for (uint32_t x = s; x <= p && k < kept; ++x) {
-                                if (x == p || rq<RM>(ring, x) == ',') {
-                                    const Num n = parse_num<RM>(ring, eb, x);
+                                if (x == p || gtext[x] == ',') {
+                                    const Num n = parse_num(gtext, eb, x);
                                     if (!n.valid || n.neg || n.val > 0xFFFFFFFFull) { err = DEC_MASK_PARSE; break; }
                                     const uint32_t w = uint32_t(n.val);
                                     const bool oob = w && 15u * k + top_pair(w) >= n_csq;
@@ -347,7 +290,7 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
             }
             if (f >= a.n_samples) err = err ? err : DEC_COLUMNS;
             if (err) dec_report(a.status, field0 + min(f, a.n_samples - 1u), err);
-            // append the carriers of this step to the record's row: one LDS atomic per wave, order inside a record is free
+            // append the carriers to the record's row: one LDS atomic per wave, order inside a record is free
             const bool keep = !err && entry != 0u;
             const uint64_t kb = __builtin_amdgcn_ballot_w64(keep);
             if (kb) {
@@ -358,12 +301,101 @@ __global__ __launch_bounds__(BS) void parse_rows_kernel(DecodeArgs a)
                 if (keep) carriers[at + rank] = DecCarrier{f, entry};
             }
         }
-        fields_before += n_ends;
+    };
+
+    uint32_t pending = 0;                                       // entries in the record's list (uniform)
+    u32x4 cur = load_tile(0);
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        const uint32_t tile0 = t * TILE;
+        *reinterpret_cast<u32x4*>(&ring[(tile0 & (RING - 1u)) + tid * 16u]) = cur;
+        u32x4 nxt = {0u, 0u, 0u, 0u};
+        if (t + 1u < n_tiles) nxt = load_tile(t + 1u);
+
+        // tabs among this lane's 16 bytes that belong to the row
+        const uint32_t qs = tile0 + tid * 16u;
+        uint32_t tm = (tab_bits8(cur.x, cur.y) >> 7) | ((tab_bits8(cur.z, cur.w) >> 7) << 8);
+        {
+            const uint32_t lo = q0 > qs ? min(q0 - qs, 16u) : 0u;
+            const uint32_t hi = Lq > qs ? min(Lq - qs, 16u) : 0u;
+            tm &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        }
+        const bool last = (t + 1u == n_tiles);
+        if (last) {
+            // the end of the line closes the last column: one more "tab", at Lq -- bit Lq - qs of the lane whose sixteen bytes hold
+            // that position (bit 16 of the last lane when the line ends with the tile)
+            const uint32_t te = min((Lq - tile0) >> 4, BS - 1u);
+            if (tid == te) tm |= 1u << (Lq - tile0 - te * 16u);
+        }
+        const uint32_t cnt = uint32_t(__builtin_popcount(tm));
+        const uint32_t incl = dec_wave_incl_scan(cnt);
+        if ((tid & 63u) == 63u) wave_tot[wave] = incl;
         dec_lds_barrier();
+        if (tid == 0) s_cnt[(t + 1u) & 1u] = 0u;                               // (the next step's counter: its last readers are a barrier behind)
+        uint32_t wbase = 0, tile_ends = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < NW; ++w) {
+            const uint32_t x = wave_tot[w];
+            if (w < wave) wbase += x;
+            tile_ends += x;
+        }
+        const uint32_t lo = max(q0, t ? tile0 - TILE : 0u);               // oldest stream position still in the ring
+        // Almost every column of a real cohort carries nothing: its text ends in ":0" or ":.".  Those are settled here with two byte
+        // reads per tab, in a loop without ballots or atomics; only the others are captured for the parser, so its cost scales with
+        // the carriers and not with the columns.
+        auto tab_pos = [&](uint32_t b) -> uint32_t { return tile0 + tid * 16u + b; };
+        const uint32_t tm0 = tm, slot0 = wbase + incl - cnt;
+        uint32_t wm = 0u;                                                       // the lane's column ends that need the parser
+        {
+            uint32_t tt = tm;
+            while (tt) {
+                const uint32_t b = uint32_t(__builtin_ctz(tt));
+                tt &= tt - 1u;
+                const uint32_t p = tab_pos(b);
+                const uint8_t c1 = rq<RM>(ring, p - 1u), c2 = rq<RM>(ring, p - 2u);
+                const bool empty = p >= lo + 2u && c2 == ':' && (c1 == '0' || c1 == '.');
+                wm |= empty ? 0u : 1u << b;
+            }
+        }
+        const uint32_t wm0 = wm;
+        const uint32_t nw = uint32_t(__builtin_popcount(wm));
+        uint32_t k0 = 0u;                                                       // the lane's first entry among the step's
+        if (__builtin_amdgcn_ballot_w64(nw != 0u)) {
+            const uint32_t wincl = dec_wave_incl_scan(nw);
+            uint32_t at = 0u;
+            if ((tid & 63u) == 63u) at = atomicAdd(&s_cnt[t & 1u], wincl);
+            at = uint32_t(__builtin_amdgcn_readlane(int(at), 63));
+            k0 = at + wincl - nw;
+        }
+        // noted: sample and position.  A step that finds more entries than the list has room for flushes and goes round again.
+        uint32_t done = 0u;                                                     // entries of this step already in the list or parsed (uniform)
+        for (;;) {
+            uint32_t w = wm0, k = k0;
+            while (w) {
+                const uint32_t b = uint32_t(__builtin_ctz(w));
+                w &= w - 1u;
+                const uint32_t idx = pending + (k - done);
+                if (k >= done && idx < CAP) {
+                    e_pos[idx] = tab_pos(b);
+                    e_f[idx] = fields_before + slot0 + uint32_t(__builtin_popcount(tm0 & ((1u << b) - 1u)));   // (>= n_samples: V2P_ERR_COLUMNS)
+                }
+                ++k;
+            }
+            dec_lds_barrier();
+            const uint32_t total = s_cnt[t & 1u];
+            const uint32_t fit = min(total - done, CAP - pending);
+            pending += fit; done += fit;
+            if (done == total) break;
+            flush(pending);                                                     // (rare: more than CAP non-empty columns between two flushes)
+            pending = 0u;
+            dec_lds_barrier();
+        }
+        fields_before += tile_ends;
         cur = nxt;
     }
+    flush(pending);
+    dec_lds_barrier();
     if (tid == 0) {
-        a.row_nnz[row] = s_nnz;                                                 // (the loop ends on a barrier)
+        a.row_nnz[row] = s_nnz;
         if (fields_before != a.n_samples) dec_report(a.status, field0 + min(fields_before, a.n_samples - 1u), DEC_COLUMNS);
     }
 }
