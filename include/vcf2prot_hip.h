@@ -382,8 +382,9 @@ typedef struct {
                                   * phase g + 1 in the grid before the stitch workgroups of phase g), 17 = the read-ahead as kernels of
                                   * its own, 18 = no read-ahead -- A/B switches of the phased launcher; 20 / 21 = A/B switches of
                                   * v2p_batch_build_and_execute's builder (20: tiles dealt to the XCDs by workgroup index; 21: tile tables made
-                                  * inside the call; 22: a wave image stays padded -- no compaction pass, descriptors read from the tiles'
-                                  * slots; measured slower per execute than it saves per build)                                                  */
+                                  * inside the call; 22 / 24: a wave image is compacted / stays padded whatever the rule says;
+                                  * 23 / 25: no staging of a padded image's descriptors / dense rows images staged as well;
+                                  * 23 / 26: a padded image stays padded when it is executed again (read in place / staged))                                                  */
 } v2p_launch_opts;
 /* src0/src1 must have 32 readable bytes before and after (the kernel loads whole aligned 16-byte
  * blocks around a task's bytes), and so must d_desc (16 before, 32 after: stitchw_kernel reads an immediate descriptor's literal

@@ -246,8 +246,9 @@ def test_degenerate_streams_in_one_call(built, gpu_ctx, kernel):
 
 @pytest.mark.parametrize("preset,h0,n,slices", [("C3", 100, 400, 1), ("C2", 3, 60, 3), ("C4", 7, 12, 1), ("C1", 0, 8, 1)])
 def test_padded_wave_image_is_the_dense_one(built, gpu_ctx, preset, h0, n, slices):
-    """v2p_set_launch_opts variant 22: the one call leaves the descriptors in their tiles' slots (no compaction), the chunk records address
-    slots; the arena, the digests and the image a download hands out (dense form) are the compacted build's, chunk order included."""
+    """A padded wave image (v2p_set_launch_opts variant 24 forces it, 22 forces the compaction; the rule: rich streams): the one call leaves
+    the descriptors in their tiles' slots, the chunk records address slots, the launcher stages them phase by phase (variant 23: read in
+    place); the arena, the digests and the image a download hands out (dense form) are the compacted build's, chunk order included."""
     from vcf2prot_amd.cohort import Cohort
     c = Cohort.preset(preset)
     gpu_ctx.upload_proteome(c.proteome())
@@ -256,20 +257,34 @@ def test_padded_wave_image_is_the_dense_one(built, gpu_ctx, preset, h0, n, slice
     stream.close()
     try:
         imgs = {}
-        for var in (0, 22):
-            gpu_ctx.set_launch_opts(variant=var)
+        small = dict(phase_min_chunks=16, phase_bytes=1 << 16)   # (phases, hence staging, also on these small images)
+        for var in (22, 24):
+            gpu_ctx.set_launch_opts(variant=var, **small)
             b = gpu_ctx.batch()
             b.build_and_execute(rs, 6, slices)
             b.sync()
             d1 = b.digests()
+            if var == 24:
+                for keep in (26, 23):                       # executed again as it is: staged, then read in place
+                    gpu_ctx.set_launch_opts(variant=keep, **small)
+                    b.execute(); b.sync()
+                    assert np.array_equal(b.digests(), d1), keep
+            gpu_ctx.set_launch_opts(variant=0, **small)     # ... and as the product does: made dense at the first re-execute
+            b.execute(); b.sync()
+            assert np.array_equal(b.digests(), d1)
             b.execute(); b.sync()
             assert np.array_equal(b.digests(), d1)
             imgs[var] = (b.download_image(), d1, b.counts())
+            b.reset()                                       # the batch recycles its buffers for a padded build again
+            gpu_ctx.set_launch_opts(variant=24, **small)
+            b.build_and_execute(rs, 6, 1); b.sync()
+            assert np.array_equal(b.digests(), d1)
+            assert np.array_equal(b.download_image()[0], imgs[var][0][0])
             b.close()
     finally:
         gpu_ctx.set_launch_opts()
-    (desc0, ch0, hb0), dig0, cn0 = imgs[0]
-    (desc1, ch1, hb1), dig1, cn1 = imgs[22]
+    (desc0, ch0, hb0), dig0, cn0 = imgs[22]
+    (desc1, ch1, hb1), dig1, cn1 = imgs[24]
     assert np.array_equal(dig0, dig1) and cn0 == cn1
     assert np.array_equal(desc0, desc1) and np.array_equal(ch0, ch1) and np.array_equal(hb0, hb1)
     rs.close()

@@ -29,7 +29,7 @@ with Context(0) as ctx:
             diff = np.nonzero((c0 != c1).any(axis=1))[0]
             out["first_diff"] = int(diff[0]); out["n_diff"] = int(diff.size)
         out["digests_equal"] = bool(np.array_equal(bs[VARS[0]].digests(), bs[VARS[1]].digests()))
-    for rep in range(3):
+    for rep in range(5):
         for var in VARS:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()

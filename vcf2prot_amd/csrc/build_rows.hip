@@ -726,7 +726,7 @@ hipError_t launch_rows_keys(const RowsArgs& a, uint64_t n_chunks, uint64_t n_des
 }
 
 // the records of a PADDED image (sir_pack.hpp) as records of the dense one: slot -> tile_desc_base[tile] + slot inside the tile
-__global__ __launch_bounds__(256) void rows_chunks_dense_kernel(const Chunk* __restrict__ in, uint64_t n, const uint64_t* __restrict__ tile_desc_base, Chunk* __restrict__ out)
+__global__ __launch_bounds__(256) void rows_chunks_dense_kernel(const Chunk* in, uint64_t n, const uint64_t* __restrict__ tile_desc_base, Chunk* out)      // (in == out: in place)
 {
     const uint64_t k = uint64_t(blockIdx.x) * 256u + threadIdx.x;
     if (k >= n) return;

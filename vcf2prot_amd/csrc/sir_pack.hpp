@@ -124,6 +124,7 @@ V2P_HOST_DEVICE inline uint64_t chunk_dst(uint64_t dst_n) { return dst_n & ((1ul
 // of dst_n (a rows chunk starts on a multiple of 1024, so they are free): 0 = all of them (every dense-addressed chunk), n1 = the
 // first n1 at task_begin, the others from the next tile's first slot.
 constexpr uint32_t ROWS_TILE_SLOTS = 256;
+constexpr uint32_t PAD_BYTES_PER_TASK_MAX = 125;   // a stream with at most this many result bytes per Task builds a padded wave image (C3: 84, C4: 117; C2: 134 keeps the compaction)
 constexpr uint64_t CHUNK_N1_MASK = 1023;
 V2P_HOST_DEVICE inline uint64_t chunk_next_tile(uint64_t first) { return (first / ROWS_TILE_SLOTS + 1u) * ROWS_TILE_SLOTS; }
 // slot of the chunk's k-th descriptor (n1 = dst_n & CHUNK_N1_MASK)

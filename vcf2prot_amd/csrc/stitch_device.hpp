@@ -115,6 +115,7 @@ __device__ __forceinline__ void lds_barrier()
 // first chunk of read-ahead wave q of the workgroups that run on XCD r (workgroup index % 8): residue r, 4 chunks 8 apart per wave
 __device__ __forceinline__ uint32_t touch_wave_first(uint32_t r, uint32_t q) { return r + 8u * 4u * q; }
 __host__ __device__ __forceinline__ uint32_t touch_waves_per_xcd(uint32_t n_chunks) { return ((n_chunks + 7u) / 8u + 3u) / 4u; }
+constexpr uint32_t STAGE_SLOTS = 64;               // descriptor slots per chunk of a staging buffer (= CHUNK_TASKS_WAVE)
 constexpr uint32_t TOUCH_CHUNKS_PER_WAVE = 4;      // records, then first descriptors, then payload bytes of four chunks in flight per wave
 // One wave: chunks [c0, c0 + 4) of `chunks` -- their records, every descriptor (one per lane and round; its line comes in) and a
 // payload descriptor's first and last source byte (frameshift tails, long insertions: first touched by the stitch kernel they would
@@ -122,8 +123,12 @@ constexpr uint32_t TOUCH_CHUNKS_PER_WAVE = 4;      // records, then first descri
 // The chunks are c0, c0 + 8, c0 + 16, c0 + 24: chunk c is stitched by a workgroup of XCD c % 8 (launch order), and the wave reading
 // ahead runs on that XCD too (touch_wave_first), so what it reads lands in the L2 the stitch wave will look in, not only in the
 // memory-side cache behind it.
+// stage != nullptr (round 5, STAGED descriptors): the wave also COPIES each chunk's descriptors into row (chunk index) of `stage`, 64
+// slots per chunk -- the stitch wave of chunk c then loads its descriptors from stage[64 c + lane], an address it knows before its
+// chunk record has arrived (one round trip less in its chain), from lines this XCD has just written; the image's own array -- dense,
+// or the tiles' slots of a padded image (sir_pack.hpp) -- is only ever read here, as a stream.
 __device__ __forceinline__ void touch_chunks(const uint64_t* __restrict__ desc, const Chunk* __restrict__ chunks, uint32_t c0, uint32_t n_chunks, uint64_t n_desc,
-                                             const uint8_t* __restrict__ payload, uint64_t payload_len, uint32_t lane)
+                                             const uint8_t* __restrict__ payload, uint64_t payload_len, uint32_t lane, uint64_t* __restrict__ stage = nullptr)
 {
     if (c0 >= n_chunks) return;
     Chunk ch[TOUCH_CHUNKS_PER_WAVE];
@@ -136,6 +141,11 @@ __device__ __forceinline__ void touch_chunks(const uint64_t* __restrict__ desc, 
         const uint32_t n1 = (ch[k].dst_n & CHUNK_CLIP) ? uint32_t(ch[k].dst_n & CHUNK_N1_MASK) : 0u;      // (a padded rows image: sir_pack.hpp)
         const uint64_t i = chunk_desc_slot(tb, n1, lane);
         d[k] = (lane < n && i < n_desc) ? desc[i] : (uint64_t(SPACE_FILL) << 62);
+    }
+    if (stage) {
+#pragma unroll
+        for (uint32_t k = 0; k < TOUCH_CHUNKS_PER_WAVE; ++k)
+            if (c0 + 8u * k < n_chunks) stage[uint64_t(c0 + 8u * k) * STAGE_SLOTS + lane] = d[k];
     }
     auto payload_lines = [&](uint64_t dd) {
         const uint64_t src = dd & SRC_MASK, len = (dd >> 40) & LEN_MASK;

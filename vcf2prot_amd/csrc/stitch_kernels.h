@@ -47,9 +47,18 @@ struct StitchArgs {
     hipStream_t     aux_stream = nullptr;
     hipEvent_t      ev_fork = nullptr, ev_join = nullptr;
     uint32_t        opt_dual = 0;            // 1: use them
+    // STAGED descriptors (round 5; pure wave rows images in the ride form): two buffers of stage_chunks x 64 descriptor slots; the read-ahead
+    // of a phase copies its chunks' descriptors into one of them, row = chunk index inside the phase, and stitchw_kernel reads them there
+    uint64_t*       stage = nullptr;         // [2 * stage_chunks * 64] (nullptr: descriptors are read where the image has them)
+    uint32_t        stage_chunks = 0;        // rows per buffer: at least stitch_stage_chunks() of the same arguments
+    const uint64_t* stage_cur = nullptr;     // set by launch_stitch(): this phase's buffer / the next phase's
+    uint64_t*       stage_next = nullptr;
     uint32_t        phase_chunks = 0;        // set by launch_stitch(): != 0 -- ONE wave launch for all phases of that many chunks, the read-ahead
                                              // workgroups of phase g + 1 placed in the grid before the stitch workgroups of phase g
 };
+
+// rows per staging buffer launch_stitch() would use for these arguments (0: this image is not launched in the form that stages)
+uint32_t stitch_stage_chunks(const StitchArgs& args, int nontemporal);
 
 struct OrderedArgs {
     const uint8_t*  code;

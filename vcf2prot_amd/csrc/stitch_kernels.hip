@@ -1248,10 +1248,10 @@ static const uint8_t* device_dots(hipError_t* err)
 // (PHASE_BYTES_DEFAULT / PHASE_BYTES_RICH / PHASE_MIN_CHUNKS and image_is_rich(): sir_pack.hpp, next to the chunk order's rule)
 
 __global__ __launch_bounds__(256) void touch_image_kernel(const uint64_t* __restrict__ desc, const Chunk* __restrict__ chunks, uint32_t n_chunks, uint64_t n_desc,
-                                                          const uint8_t* __restrict__ payload, uint64_t payload_len)
+                                                          const uint8_t* __restrict__ payload, uint64_t payload_len, uint64_t* __restrict__ stage)
 {
     // workgroup b runs on XCD b % 8: its four waves read chunks of residue b % 8
-    touch_chunks(desc, chunks, touch_wave_first(blockIdx.x & 7u, (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6)), n_chunks, n_desc, payload, payload_len, threadIdx.x & 63u);
+    touch_chunks(desc, chunks, touch_wave_first(blockIdx.x & 7u, (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6)), n_chunks, n_desc, payload, payload_len, threadIdx.x & 63u, stage);
 }
 
 static hipError_t launch_stitch_range(const StitchArgs& args, hipStream_t stream, int nontemporal, uint32_t max_blocks);
@@ -1265,6 +1265,38 @@ __global__ void idle_kernel(uint32_t us)
     while (__builtin_readcyclecounter() - t0 < uint64_t(us) * 100u) __builtin_amdgcn_s_sleep(64);
 }
 #endif
+
+// chunks per phase and whether the read-ahead rides on the stitch launches: launch_stitch()'s rule, also asked by the caller that sizes the
+// staging buffers (0: one launch, no phases)
+static uint64_t phase_plan(const StitchArgs& a, int nontemporal, uint32_t max_blocks, bool* ride_out)
+{
+    *ride_out = false;
+    if (a.n_chunks == 0) return 0;
+    const uint64_t img_desc = a.img_desc ? a.img_desc : a.n_desc, img_bytes = a.img_bytes ? a.img_bytes : a.out_len;
+    const bool rich = image_is_rich(img_desc, img_bytes);
+    uint64_t phase_bytes = rich ? PHASE_BYTES_RICH : PHASE_BYTES_DEFAULT;
+    if (a.opt_phase_bytes == ~0ull) phase_bytes = 0;
+    else if (a.opt_phase_bytes != 0) phase_bytes = a.opt_phase_bytes;
+    const bool streams = (nontemporal & 4) != 0 || (nontemporal & 16) == 0;
+    const uint32_t min_chunks = a.opt_phase_min_chunks ? a.opt_phase_min_chunks : PHASE_MIN_CHUNKS;
+    if (max_blocks != 0 || phase_bytes == 0 || !streams || a.n_chunks < min_chunks) return 0;
+    const double per_chunk = 16.0 + 8.0 * double(img_desc) / double(a.n_chunks);
+    uint64_t per = uint64_t(double(phase_bytes) / per_chunk);
+    const uint64_t per_min = a.opt_phase_min_chunks ? 8u : 4096u;
+    per = per < per_min ? per_min : (per & ~7ull);
+    const bool no_touch = (a.opt_touch & 1u) != 0, own_touch = (a.opt_touch & 2u) != 0;
+    *ride_out = !own_touch && !no_touch && (nontemporal & 4) != 0 && (nontemporal & 48) == 48 && !(nontemporal & 2);
+    return per;
+}
+
+uint32_t stitch_stage_chunks(const StitchArgs& args, int nontemporal)
+{
+    bool ride = false;
+    const uint64_t per = phase_plan(args, nontemporal, 0, &ride);
+    const int wsel = (nontemporal >> 28) & 3;
+    if (!ride || !(nontemporal & 8) || wsel != 0 || (args.opt_touch & 4u) != 0 || args.opt_dual || per == 0 || per > 0x7FFFFFFFull) return 0;
+    return uint32_t(per < args.n_chunks ? per : ((uint64_t(args.n_chunks) + 7u) & ~7ull));
+}
 
 hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemporal, uint32_t max_blocks)
 {
@@ -1309,7 +1341,7 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     const int wsel = (nontemporal >> 28) & 3;
     if (ride && wsel == 0 && (a.opt_touch & 4u) != 0 && per <= 0x7FFFFFFFull) {
         const uint32_t n0 = uint32_t(args.n_chunks < per ? args.n_chunks : per);
-        hipLaunchKernelGGL(touch_image_kernel, dim3(8u * ((touch_waves_per_xcd(n0) + 3u) / 4u)), dim3(256), 0, stream, a.desc, a.chunks, n0, a.n_desc, a.src1, a.src1_len);
+        hipLaunchKernelGGL(touch_image_kernel, dim3(8u * ((touch_waves_per_xcd(n0) + 3u) / 4u)), dim3(256), 0, stream, a.desc, a.chunks, n0, a.n_desc, a.src1, a.src1_len, nullptr);
         a.phase_chunks = uint32_t(per);
         return launch_stitch_range(a, stream, nontemporal, 0);
     }
@@ -1336,7 +1368,7 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
             a.n_chunks = pieces[i].second;
             a.next_chunks = nullptr; a.n_next = 0;
             if (i + 2u < pieces.size()) { a.next_chunks = args.chunks + pieces[i + 2u].first; a.n_next = pieces[i + 2u].second; }
-            if (i < 2u) hipLaunchKernelGGL(touch_image_kernel, dim3(8u * ((touch_waves_per_xcd(a.n_chunks) + 3u) / 4u)), dim3(256), 0, s, a.desc, a.chunks, a.n_chunks, a.n_desc, a.src1, a.src1_len);
+            if (i < 2u) hipLaunchKernelGGL(touch_image_kernel, dim3(8u * ((touch_waves_per_xcd(a.n_chunks) + 3u) / 4u)), dim3(256), 0, s, a.desc, a.chunks, a.n_chunks, a.n_desc, a.src1, a.src1_len, nullptr);
             err = launch_stitch_range(a, s, nontemporal, 0);
             if (err != hipSuccess) return err;
         }
@@ -1344,7 +1376,10 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
         if (err == hipSuccess) err = hipStreamWaitEvent(stream, a.ev_join, 0);
         return err != hipSuccess ? err : hipGetLastError();
     }
-    for (uint64_t c0 = 0; c0 < args.n_chunks; c0 += per) {
+    // STAGED descriptors: the ride form of a rows image with the caller's two buffers (stitch_kernels.h)
+    const bool staged = ride && a.rows && wsel == 0 && args.stage != nullptr && per <= args.stage_chunks;
+    uint32_t phase = 0;
+    for (uint64_t c0 = 0; c0 < args.n_chunks; c0 += per, ++phase) {
         const uint32_t nc = uint32_t(args.n_chunks - c0 < per ? args.n_chunks - c0 : per);
         a.chunks = args.chunks + c0;
         a.n_chunks = nc;
@@ -1353,7 +1388,13 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
             a.next_chunks = args.chunks + c0 + per;
             a.n_next = uint32_t(args.n_chunks - (c0 + per) < per ? args.n_chunks - (c0 + per) : per);
         }
-        if (!no_touch && (!ride || c0 == 0)) hipLaunchKernelGGL(touch_image_kernel, dim3(8u * ((touch_waves_per_xcd(nc) + 3u) / 4u)), dim3(256), 0, stream, a.desc, a.chunks, nc, a.n_desc, a.src1, a.src1_len);
+        a.stage_cur = nullptr; a.stage_next = nullptr;
+        if (staged) {
+            a.stage_cur = args.stage + uint64_t(phase & 1u) * args.stage_chunks * STAGE_SLOTS;
+            a.stage_next = args.stage + uint64_t((phase + 1u) & 1u) * args.stage_chunks * STAGE_SLOTS;
+        }
+        if (!no_touch && (!ride || c0 == 0)) hipLaunchKernelGGL(touch_image_kernel, dim3(8u * ((touch_waves_per_xcd(nc) + 3u) / 4u)), dim3(256), 0, stream, a.desc, a.chunks, nc, a.n_desc, a.src1, a.src1_len,
+                                                                 staged ? const_cast<uint64_t*>(a.stage_cur) : nullptr);
         err = launch_stitch_range(a, stream, nontemporal, 0);
         if (err != hipSuccess) return err;
 #ifdef V2P_BENCH_VARIANTS

@@ -113,14 +113,19 @@ __device__ __forceinline__ u32x4 wmerge(u32x4 v, u32x4 ld, u32x4 m)      // byte
 // RIMG: the image is a rows image (sir_pack.hpp: CHUNK_CLIP) -- every chunk starts on a 1 KiB row (no ragged head), may skip the
 // head of its first descriptor and clip its last one; an instance of its own, so that the host packer's images run the code they
 // always ran (the kernel sits at 62-64 VGPRs: a handful of extra live values made hipcc spill a gathered row).
-template <int WPG, bool NT, bool SC1 = false, bool RIMG = false>
+// STG (rows images launched in phases, the ride form): the chunk's descriptors are read from row c of a STAGING buffer that the read-ahead
+// of this phase filled (touch_chunks: 64 slots per chunk, in launch order) -- an address the wave knows before its chunk record has
+// arrived, so record and descriptors are requested together -- and the trailing workgroups fill the other buffer for the next phase.
+template <int WPG, bool NT, bool SC1 = false, bool RIMG = false, bool STG = false>
 __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const uint64_t* __restrict__ p_desc, const Chunk* __restrict__ p_chunks,
                                                             const uint8_t* __restrict__ p_src0, const uint8_t* __restrict__ p_src1,
                                                             uint8_t* __restrict__ p_out, unsigned long long* __restrict__ p_status,
                                                             const uint8_t* __restrict__ p_dots,
                                                             uint32_t n_chunks, uint64_t n_desc, uint64_t src0_len, uint64_t src1_len, uint64_t out_len,
-                                                            const Chunk* __restrict__ p_next, uint32_t n_next, uint32_t phase_chunks)
+                                                            const Chunk* __restrict__ p_next, uint32_t n_next, uint32_t phase_chunks,
+                                                            const uint64_t* __restrict__ p_stage = nullptr, uint64_t* __restrict__ p_stage_next = nullptr)
 {
+    static_assert(!STG || (RIMG && WPG == 1), "staged descriptors: rows images, one wave per workgroup");
     constexpr uint32_t ROWS = CHUNK_BYTES_WAVE / 1024u;              // 1 KiB rows of a chunk: all gathered before the first store
     static_assert(ROWS <= 16u, "a lane's map bytes and record indices are packed four rows to a register");
     constexpr uint32_t ND = (ROWS + 3u) / 4u;                        // map dwords per lane (4 * ND >= ROWS one-byte counters)
@@ -158,10 +163,14 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
         // (they start at a workgroup index that is a multiple of 8: workgroup b is on XCD b % 8 and reads chunks of that residue)
         const uint32_t first_wg = (((n_chunks + uint32_t(WPG) - 1u) / uint32_t(WPG)) + 7u) & ~7u;
         if (blockIdx.x >= first_wg)
-            touch_chunks(p_desc, p_next, touch_wave_first(blockIdx.x & 7u, ((blockIdx.x - first_wg) >> 3) * uint32_t(WPG) + wid), n_next, n_desc, p_src1, src1_len, lane);
+            touch_chunks(p_desc, p_next, touch_wave_first(blockIdx.x & 7u, ((blockIdx.x - first_wg) >> 3) * uint32_t(WPG) + wid), n_next, n_desc, p_src1, src1_len, lane,
+                         STG ? p_stage_next : nullptr);
         return;
     }
     WaveLds& L = s_all[wid];
+    // (STG: requested before the chunk record is looked at -- lanes past the chunk's last descriptor read slots the read-ahead filled with fills)
+    uint64_t d_stg = 0ull;
+    if (STG) d_stg = p_stage[uint64_t(c) * STAGE_SLOTS + lane];
     const uint64_t tb_raw = p_chunks[c].task_begin, dn = p_chunks[c].dst_n;
     if (!(dn & CHUNK_WAVE)) return;                                  // the chunks of another kernel
     // ROWS images (sir_pack.hpp): the chunk's first descriptor may begin in the chunk before -- skip its first `hskip` bytes --
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
     // (no branch around the load: lanes past the chunk's last descriptor read the chunk header and drop it.  A prefetch of a later
     // chunk's descriptor lines into the L2 from here -- 1 Ki, 4 Ki, 16 Ki chunks ahead, issued behind this load and waited for by
     // nobody before the patch phase -- was measured: C2 +3.5 %, C3 +1 % SLOWER; not kept.)
-    const uint64_t d_raw = *(lane < n ? p_desc + tb + lofs : reinterpret_cast<const uint64_t*>(p_chunks + c));
+    const uint64_t d_raw = STG ? d_stg : *(lane < n ? p_desc + tb + lofs : reinterpret_cast<const uint64_t*>(p_chunks + c));
     {   // the byte-mask table, without a branch (every lane writes an entry; lanes and waves that share one write the same value)
         const uint32_t jm = lane < 16u ? lane : 16u;
         u32x4 m;
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
     const bool ref = snv || space == SPACE_PROTEOME;
     const bool bad = (RIMG && hs + tcl != 0u && hs + tcl >= bytes0) || (imm ? len1 > IMM_MAX_BYTES : (gathers && src + bytes0 > (ref ? src0_len : src1_len)));   // never read out of bounds: task.rs would panic
     // (an immediate record's bytes ARE in memory: the low bytes of its own descriptor, just loaded -- it is a stream like any other)
-    const uint64_t a = (imm ? reinterpret_cast<uint64_t>(p_desc + tb + lofs) : (gathers ? reinterpret_cast<uint64_t>(ref ? p_src0 : p_src1) + src : dots16)) + (gathers || imm ? hs : 0u);
+    const uint64_t a = (imm ? (STG ? reinterpret_cast<uint64_t>(p_stage + uint64_t(c) * STAGE_SLOTS + lane) : reinterpret_cast<uint64_t>(p_desc + tb + lofs)) : (gathers ? reinterpret_cast<uint64_t>(ref ? p_src0 : p_src1) + src : dots16)) + (gathers || imm ? hs : 0u);
     const uint32_t bytes = bytes0 - hs - tcl;
     const uint32_t incl = wave_incl_scan(bad ? 0u : bytes);
     const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
@@ -234,6 +243,7 @@ __global__ __launch_bounds__(64 * WPG, V2P_WAVE_OCC) void stitchw_kernel(const u
     chk.lo[1] = reinterpret_cast<uint64_t>(p_src1) - PAD_BYTES; chk.hi[1] = reinterpret_cast<uint64_t>(p_src1) + src1_len + PAD_BYTES;
     chk.lo[2] = reinterpret_cast<uint64_t>(p_dots); chk.hi[2] = reinterpret_cast<uint64_t>(p_dots) + DOTS_BYTES;
     chk.lo[3] = reinterpret_cast<uint64_t>(p_desc) - 16u; chk.hi[3] = reinterpret_cast<uint64_t>(p_desc + n_desc) + PAD_BYTES;      // (immediate records read their own descriptors)
+    if (STG) { chk.lo[3] = reinterpret_cast<uint64_t>(p_stage) - 16u; chk.hi[3] = reinterpret_cast<uint64_t>(p_stage + uint64_t(n_chunks) * STAGE_SLOTS) + PAD_BYTES; }
     chk.status = p_status; chk.tb = c;
 #endif
     const uint32_t start = ptotal - (total - (incl - bytes));        // = head + exclusive prefix; lanes >= n sit at ptotal
@@ -438,8 +448,12 @@ hipError_t launch_stitch_wave(const StitchArgs& a, hipStream_t stream, bool nt, 
 #define V2P_LW(WW, NTT) hipLaunchKernelGGL((stitchw_kernel<WW, NTT>), dim3(tw ? ((((nc + (WW) - 1u) / (WW)) + 7u) & ~7u) + 8u * ((tw + (WW) - 1u) / (WW)) : (nc + (WW) - 1u) / (WW)), dim3(64 * (WW)), 0, stream, \
         a.desc, ch, a.src0, a.src1, a.out, a.status, a.dots, nc, a.n_desc, a.src0_len, a.src1_len, a.out_len, a.next_chunks, n_next, 0u)
 #define V2P_LWR(NTT, SCC) hipLaunchKernelGGL((stitchw_kernel<1, NTT, SCC, true>), dim3(tw ? (((nc + 7u) & ~7u) + 8u * tw) : nc), dim3(64), 0, stream, \
-        a.desc, ch, a.src0, a.src1, a.out, a.status, a.dots, nc, a.n_desc, a.src0_len, a.src1_len, a.out_len, a.next_chunks, n_next, 0u)
-        if (a.rows) { if (nt && a.store_sc1) V2P_LWR(true, true); else if (nt) V2P_LWR(true, false); else V2P_LWR(false, false); }
+        a.desc, ch, a.src0, a.src1, a.out, a.status, a.dots, nc, a.n_desc, a.src0_len, a.src1_len, a.out_len, a.next_chunks, n_next, 0u, nullptr, nullptr)
+#define V2P_LWS(NTT, SCC) hipLaunchKernelGGL((stitchw_kernel<1, NTT, SCC, true, true>), dim3(tw ? (((nc + 7u) & ~7u) + 8u * tw) : nc), dim3(64), 0, stream, \
+        a.desc, ch, a.src0, a.src1, a.out, a.status, a.dots, nc, a.n_desc, a.src0_len, a.src1_len, a.out_len, a.next_chunks, n_next, 0u, a.stage_cur, a.stage_next)
+        if (a.rows && a.stage_cur && c0 == 0u && nc == a.n_chunks) {      // (staged descriptors: the whole phase is one launch, row c of the buffer = chunk c)
+            if (nt && a.store_sc1) V2P_LWS(true, true); else if (nt) V2P_LWS(true, false); else V2P_LWS(false, false);
+        } else if (a.rows) { if (nt && a.store_sc1) V2P_LWR(true, true); else if (nt) V2P_LWR(true, false); else V2P_LWR(false, false); }
 #ifdef V2P_BENCH_VARIANTS
         else if (waves_per_group == 4) { if (nt) V2P_LW(4, true); else V2P_LW(4, false); }
         else if (waves_per_group == 2) { if (nt) V2P_LW(2, true); else V2P_LW(2, false); }
@@ -449,6 +463,7 @@ hipError_t launch_stitch_wave(const StitchArgs& a, hipStream_t stream, bool nt, 
         else { if (nt) V2P_LW(1, true); else V2P_LW(1, false); }
 #undef V2P_LW
 #undef V2P_LWR
+#undef V2P_LWS
     }
     return hipGetLastError();
 }

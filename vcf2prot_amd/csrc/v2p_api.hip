@@ -159,10 +159,12 @@ struct v2p_batch {
     // v2p_batch_build_and_execute: tables that outlive the call so that a batch that is rebuilt recycles them, the slices' chunk ranges
     // and the events of the last call (read by v2p_batch_oneshot_info after a sync)
     DevBuf d_tiles, d_cover, d_pad, d_order;
+    DevBuf d_stage;                // STAGED descriptors (stitch_kernels.h): two buffers of a phase's chunks x 64 slots, filled by the read-ahead
     // a PADDED wave image (sir_pack.hpp; what the one call leaves behind): d_desc holds ROWS_TILE_SLOTS slots per tile, the chunk records
     // address its slots; desc_slots = its size (the kernels' bound), n_desc the descriptors it holds; pad_tdbase = the scan of the tiles'
     // counts (in d_tiles), with which a download hands out the dense form
     bool pad_image = false;
+    bool desc_swapped = false;     // densify() left the image in d_pad's allocation (swapped into d_desc): v2p_batch_reset swaps back
     uint64_t desc_slots = 0, pad_n_tiles = 0;
     uint32_t pad_K = 0;
     const uint64_t* pad_tdbase = nullptr;
@@ -983,7 +985,7 @@ void v2p_batch_destroy(v2p_batch* b)
     (void)hipStreamSynchronize(b->ctx->stream);
     b->d_desc.release(); b->d_chunks.release(); b->d_payload.release(); b->d_out.release();
     b->d_hap.release(); b->d_digest.release(); b->d_status.release(); b->d_build.release();
-    b->d_tiles.release(); b->d_cover.release(); b->d_pad.release(); b->d_order.release(); b->d_patch.release();
+    b->d_tiles.release(); b->d_cover.release(); b->d_pad.release(); b->d_order.release(); b->d_patch.release(); b->d_stage.release();
     if (b->ctx->build_stream) (void)hipStreamSynchronize(b->ctx->build_stream);
     if (b->ctx->aux_stream) (void)hipStreamSynchronize(b->ctx->aux_stream);
     for (hipEvent_t e : b->ev_os) if (e) (void)hipEventDestroy(e);
@@ -1930,6 +1932,7 @@ int v2p_batch_reset(v2p_batch* b)
     b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0;
     b->payload_dev = nullptr; b->n_slices = 0; b->launch_hint = 0; b->is_patch = false; b->patch_segs = b->patch_patches = 0;
     b->pad_image = false; b->desc_slots = 0; b->pad_tdbase = nullptr;
+    if (b->desc_swapped) { std::swap(b->d_desc, b->d_pad); b->desc_swapped = false; }     // (the large allocation is the padded array's again)
     return V2P_OK;
 }
 
@@ -1974,6 +1977,21 @@ static void dual_of(v2p_ctx* c, StitchArgs& a)
 
 static hipError_t ensure_event(hipEvent_t& e) { return e ? hipSuccess : hipEventCreate(&e); }
 
+// Staging buffers for an image launch_stitch() will run in the form that stages (a pure wave rows image in phases): sized by the
+// launcher's own rule.  v2p_set_launch_opts variant 23 (A/B): no staging -- the stitch waves read descriptors where the image has them;
+// 25: dense rows images are staged as well.
+static hipError_t attach_stage(v2p_batch* b, StitchArgs& a, int hint)
+{
+    // (a padded image is staged; a dense one is read in place -- staging it as well was measured: nothing in the steady state)
+    if (b->ctx->launch_opts.variant == 23u || !(b->pad_image || b->ctx->launch_opts.variant == 25u)) return hipSuccess;
+    const uint32_t rows = stitch_stage_chunks(a, hint);
+    if (rows == 0) return hipSuccess;
+    const hipError_t e = b->d_stage.ensure(uint64_t(2) * rows * 64u * 8u);
+    if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }       // (no room: launched without)
+    a.stage = reinterpret_cast<uint64_t*>(b->d_stage.ptr()); a.stage_chunks = rows;
+    return hipSuccess;
+}
+
 // One slice's share of launch_stitch's routing (phases, store policy) follows the slice, not the table it is a range of
 static hipError_t stitch_range(v2p_batch* b, uint64_t desc_bound, uint64_t chunk0, uint64_t n_chunks, uint64_t img_desc, uint64_t img_bytes, hipStream_t stream)
 {
@@ -1986,7 +2004,9 @@ static hipError_t stitch_range(v2p_batch* b, uint64_t desc_bound, uint64_t chunk
     a.opt_touch = touch_of(c->launch_opts.variant);
     dual_of(c, a);
     a.img_desc = img_desc; a.img_bytes = img_bytes;
-    return launch_stitch(a, stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint, 0);
+    const int hint = int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint;
+    (void)attach_stage(b, a, hint);
+    return launch_stitch(a, stream, hint, 0);
 }
 
 // The sliced builder.  Global tables first (arena bytes per tile, their scan, the haplotypes' offsets: 0.2 ms), then per slice of tiles
@@ -2029,13 +2049,18 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     uint64_t T[V2P_MAX_SLICES + 1], max_tiles = 0;
     for (uint32_t j = 0; j <= S; ++j) T[j] = n_tiles * j / S;
     for (uint32_t j = 0; j < S; ++j) if (T[j + 1] - T[j] > max_tiles) max_tiles = T[j + 1] - T[j];
-    // Variant 22 (A/B; measured and NOT the default): a wave image stays PADDED (sir_pack.hpp) -- the parse writes every tile's descriptors
-    // to its slots of d_desc and that is where the stitch kernel reads them, no compaction.  The build loses 0.6 ms of the north star's
-    // cohort's 4.7 (0.74 ms of copy, 3.6 GB of traffic) ... and every execute of the image gains 0.4-0.5 ms of its 7.6: a chunk's
-    // descriptors lie in two places, the array's lines are 55 % used, and the read-ahead of a phase covers twice the address range
-    // (profiles/r05_padded_image.txt).  One shot -0.17 ms, every later execute +6 %: the compaction stays.
+    // A RICH wave image (many descriptors per result byte: C3, C4) stays PADDED (sir_pack.hpp): the parse writes every tile's descriptors to
+    // its slots of d_desc and there they stay -- no compaction pass (0.74 ms and 3.6 GB of traffic of the north star's cohort's build).
+    // Read in place by the stitch waves the padded array costs every execute 6 % (a chunk's descriptors in two places, lines 55 % used:
+    // profiles/r05_padded_image.txt); so the launcher STAGES them (stitch_kernels.h): the read-ahead of a phase, which reads the
+    // array as a stream anyway, copies the phase's descriptors into a buffer in launch order, 64 slots per chunk, and that is what
+    // stitchw_kernel reads -- steady state as the dense image's, build 0.6 ms shorter.  A thin image (C2: 28 descriptors per chunk,
+    // 64 MB phases) would half-fill its staging rows and double what a phase keeps in the caches: it keeps the compaction, and so do
+    // dense images (chunks of up to 1 024 descriptors).  The rule looks at the stream (result bytes per Task); variants 22 / 24 force
+    // the compacted / the padded form (A/B).
     const uint32_t bvar = c->launch_opts.variant;
-    const bool pad = mode == ROWS_WAVE && bvar == 22u && n_tiles < (1ull << 24);
+    const bool rich_stream = out_bytes <= uint64_t(PAD_BYTES_PER_TASK_MAX) * v.n_tasks;
+    const bool pad = mode == ROWS_WAVE && n_tiles < (1ull << 24) && bvar != 22u && (rich_stream || bvar == 24u);
     if (!pad) HIP_TRY(c, b->d_pad.ensure_exact(max_tiles * ROWS_PAD_SLOTS * 8), "hipMalloc(padded descriptors)");
     const uint64_t desc_cap = n_tiles * ROWS_PAD_SLOTS;              // (one-pass tiles hold at most their 256 slots)
     HIP_TRY(c, b->d_desc.ensure_exact(desc_cap * 8), "hipMalloc(desc)");
@@ -2063,7 +2088,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     rows_args_of(v, c, K, n_tiles, a);
     a.tile_bytes = reinterpret_cast<uint64_t*>(d + o_tbytes); a.tile_res_base = reinterpret_cast<uint64_t*>(d + o_tbase);
     // (A/B switches of the builder, v2p_set_launch_opts: variant 20 = tile = workgroup index in the parse, 21 = tile tables made inside the
-    // call: round 5's first form; 22 = the padded image)
+    // call: round 5's first form; 22 / 24 = the compacted / the padded form of a wave image whatever the rule says)
     a.xcd_tiles = bvar == 20u ? 0u : 1u;
     const bool cached = bvar != 21u && S == 1 && st->tile_K == K && st->n_tiles == n_tiles && st->tile_res_base != nullptr;
     if (cached) a.tile_res_base = const_cast<uint64_t*>(st->tile_res_base);      // (read only from here on)
@@ -2085,9 +2110,11 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     // the batch describes the image from here on (a failure below resets it)
     b->n_payload = v.n_alt; b->payload_dev = v.alt; b->out_bytes = out_bytes; b->n_haps = n_h;
     b->launch_hint = (mode == ROWS_DENSE ? 2 : 4) | 8 | 16 | 32 | (1 << 6) | (1 << 8);
+    b->pad_image = pad; b->desc_slots = pad ? desc_cap : 0; b->pad_n_tiles = n_tiles; b->pad_K = K; b->pad_tdbase = a.tile_desc_base;
     auto fail_reset = [&](int code) {
         (void)hipStreamSynchronize(A); (void)hipStreamSynchronize(B); (void)hipStreamSynchronize(X);
         (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, A);
+        b->pad_image = false; b->desc_slots = 0; b->pad_tdbase = nullptr;
         b->img.hap_out_begin.assign(1, 0); b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0; b->payload_dev = nullptr; b->n_slices = 0;
         return code;
     };
@@ -2178,7 +2205,6 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     b->slice_chunk0[S] = chunk0;
     HIP_TRY(c, hipEventRecord(b->ev_os[1], A), "hipEventRecord");
     b->n_desc = desc0; b->n_chunks = chunk0; b->n_slices = S;
-    b->pad_image = pad; b->desc_slots = pad ? desc_cap : 0; b->pad_n_tiles = n_tiles; b->pad_K = K; b->pad_tdbase = a.tile_desc_base;
     b->img.hap_out_begin = st->hap_out_begin;
     b->uses_proteome = true;
     b->finalized = true;
@@ -2272,6 +2298,30 @@ int v2p_batch_download_patch_image(v2p_batch* b, uint64_t* seg, uint32_t* patch,
     return V2P_OK;
 }
 
+// A padded image becomes the dense one (on the context's stream, for good): the compaction the one call skipped, into the batch's spare
+// descriptor buffer, and the chunk records translated in place.  Called by whoever needs the dense form -- a download, and the first
+// RE-execute of the batch: read in place the padded array costs a steady-state execute 6 %, staged 1-2 % (the read-ahead also writes),
+// so a batch that is executed again pays the 0.74 ms once and runs the dense image from then on; a cohort that is executed once -- the
+// one call -- never pays it.
+static int densify(v2p_batch* b)
+{
+    v2p_ctx* c = b->ctx;
+    if (!b->pad_image) return V2P_OK;
+    HIP_TRY(c, b->d_pad.ensure((b->n_desc ? b->n_desc : 1) * 8), "hipMalloc(dense descriptors)");
+    if (b->n_desc) {
+        RowsArgs a{};
+        a.n_tiles = b->pad_n_tiles; a.K = b->pad_K; a.tile0 = 0; a.tile1 = b->pad_n_tiles;
+        a.tile_desc_base = const_cast<uint64_t*>(b->pad_tdbase);
+        a.desc_pad = reinterpret_cast<uint64_t*>(b->d_desc.ptr()); a.desc = reinterpret_cast<uint64_t*>(b->d_pad.ptr()); a.desc_cap = b->n_desc;
+        HIP_TRY(c, launch_rows_compact(a, c->stream), "launch(compact)");
+    }
+    if (b->n_chunks) HIP_TRY(c, launch_rows_chunks_dense(reinterpret_cast<const Chunk*>(b->d_chunks.ptr()), b->n_chunks, b->pad_tdbase, reinterpret_cast<Chunk*>(b->d_chunks.ptr()), c->stream), "launch(chunk records)");
+    std::swap(b->d_desc, b->d_pad);
+    b->desc_swapped = !b->desc_swapped;
+    b->pad_image = false; b->desc_slots = 0;
+    return V2P_OK;
+}
+
 int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, uint64_t* hap_out_begin)
 {
     if (!b) return V2P_ERR_INVALID_ARG;
@@ -2280,30 +2330,7 @@ int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, ui
     if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
     if (b->is_patch && desc) return c->fail(V2P_ERR_STATE, "a patch image has segments and patches, not descriptors: v2p_batch_download_patch_image");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
-    if (b->pad_image) {
-        // a padded image leaves the device in the DENSE form (what every other builder produces and the host restatement describes): the
-        // compaction the call skipped and the chunk records translated, into scratch of this call -- the batch keeps executing what it has
-        DevBuf dd, dc;
-        struct Rel { DevBuf& a; DevBuf& b; ~Rel() { a.release(); b.release(); } } rel{dd, dc};
-        HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
-        if (desc && b->n_desc) {
-            HIP_TRY(c, dd.ensure_exact(b->n_desc * 8), "hipMalloc(dense descriptors)");
-            RowsArgs a{};
-            a.n_tiles = b->pad_n_tiles; a.K = b->pad_K; a.tile0 = 0; a.tile1 = b->pad_n_tiles;
-            a.tile_desc_base = const_cast<uint64_t*>(b->pad_tdbase);
-            a.desc_pad = reinterpret_cast<uint64_t*>(b->d_desc.ptr()); a.desc = reinterpret_cast<uint64_t*>(dd.ptr()); a.desc_cap = b->n_desc;
-            HIP_TRY(c, launch_rows_compact(a, c->stream), "launch(compact)");
-            HIP_TRY(c, hipMemcpyAsync(desc, dd.ptr(), b->n_desc * 8, hipMemcpyDeviceToHost, c->stream), "D2H(desc)");
-        }
-        if (chunks && b->n_chunks) {
-            HIP_TRY(c, dc.ensure_exact(b->n_chunks * sizeof(Chunk)), "hipMalloc(dense chunk records)");
-            HIP_TRY(c, launch_rows_chunks_dense(reinterpret_cast<const Chunk*>(b->d_chunks.ptr()), b->n_chunks, b->pad_tdbase, reinterpret_cast<Chunk*>(dc.ptr()), c->stream), "launch(chunk records)");
-            HIP_TRY(c, hipMemcpyAsync(chunks, dc.ptr(), b->n_chunks * sizeof(Chunk), hipMemcpyDeviceToHost, c->stream), "D2H(chunks)");
-        }
-        if (hap_out_begin) HIP_TRY(c, hipMemcpyAsync(hap_out_begin, b->d_hap.ptr(), (b->n_haps + 1) * 8, hipMemcpyDeviceToHost, c->stream), "D2H(hap_begin)");
-        HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
-        return V2P_OK;
-    }
+    if (b->pad_image) { const int rc = densify(b); if (rc) return rc; }       // (a padded image leaves the device in the dense form)
     if (desc && b->n_desc) HIP_TRY(c, hipMemcpyAsync(desc, b->d_desc.ptr(), b->n_desc * 8, hipMemcpyDeviceToHost, c->stream), "D2H(desc)");
     if (chunks && b->n_chunks) HIP_TRY(c, hipMemcpyAsync(chunks, b->d_chunks.ptr(), b->n_chunks * sizeof(Chunk), hipMemcpyDeviceToHost, c->stream), "D2H(chunks)");
     if (hap_out_begin) HIP_TRY(c, hipMemcpyAsync(hap_out_begin, b->d_hap.ptr(), (b->n_haps + 1) * 8, hipMemcpyDeviceToHost, c->stream), "D2H(hap_begin)");
@@ -2386,6 +2413,8 @@ int v2p_batch_execute(v2p_batch* b)
         if (pe != hipSuccess) return c->hip_fail(pe, "launch(stitch: patch image)");
         return V2P_OK;
     }
+    // (variants 23 / 26, A/B: a padded image stays padded -- read in place / staged)
+    if (b->pad_image && c->launch_opts.variant != 23u && c->launch_opts.variant != 26u) { const int rc = densify(b); if (rc) return rc; }
     StitchArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), b->pad_image ? b->desc_slots : b->n_desc, reinterpret_cast<const Chunk*>(b->d_chunks.ptr()),
                  uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->payload_dev, b->n_payload,
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
@@ -2393,7 +2422,9 @@ int v2p_batch_execute(v2p_batch* b)
     a.opt_touch = touch_of(c->launch_opts.variant);
     a.img_desc = b->pad_image ? b->n_desc : 0;          // (the routing looks at the descriptors the image holds, not at the array's slots)
     dual_of(c, a);
-    HIP_TRY(c, launch_stitch(a, c->stream, int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint, 0), "launch(stitch)");
+    const int hint = int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint;
+    (void)attach_stage(b, a, hint);
+    HIP_TRY(c, launch_stitch(a, c->stream, hint, 0), "launch(stitch)");
     return V2P_OK;
 }
 
