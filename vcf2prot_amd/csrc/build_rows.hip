@@ -271,46 +271,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
         asm volatile("" ::: "memory");
         if (hp - R0 < 64u) reinterpret_cast<uint8_t*>(L.flag)[hp - R0] = 1u;
         asm volatile("" ::: "memory");
-        const bool active = lane < nvalid;
-        const bool isFirst = reinterpret_cast<const uint8_t*>(L.flag)[lane] != 0u;     // (lanes >= nvalid: no transcript of this tile starts there)
-        const uint64_t firstmask = __ballot(isFirst);
+        // (Booleans live as 64-bit lane MASKS from here on, built from ballots of single comparisons and combined by scalar
+        // instructions; a lane reads its bit with lane_bit() where a select or a branch needs it.  Written as per-lane bools combined
+        // with && / || the compiler re-ballots every combination -- v_cndmask + v_cmp, thirteen times per window: a seventh of the
+        // kernel's vector instructions, and the vector unit is what bounds it.)
+        const uint64_t m_active = nvalid >= 64u ? ~0ull : (1ull << nvalid) - 1ull;
+        const bool active = lane_bit(m_active);
+        const uint64_t firstmask = __ballot(reinterpret_cast<const uint8_t*>(L.flag)[lane] != 0u);     // (lanes >= nvalid: no transcript of this tile starts there)
+        const bool isFirst = lane_bit(firstmask);
         const uint32_t heads_before = uint32_t(__popcll(__ballot(hp < R0)));
         const uint32_t slot = heads_before + mbcnt(firstmask) + (isFirst ? 1u : 0u) - 1u;   // the item's transcript (item 0 opens one: never negative for an active lane)
         // the transcript's last item: the next one opens another, or the tile ends
         const uint64_t lastmask = (firstmask >> 1) | (last && nvalid ? 1ull << (nvalid - 1u) : 0ull);
         const bool isLast = lane_bit(lastmask);
         uint32_t ti = R0 + lane;                                                         // task, relative to the tile's first
-        bool isEmpty = false;
+        uint64_t m_empty = 0ull;
         // this window's tasks were requested a window ago; the next window's are requested now
         uint32_t code = pf_code, sp = pf_sp, ln = pf_ln, sr = pf_sr;
         if (!last) prefetch(R0 + ADV + lane);
         if (ne) {                                                                        // (uniform, rare: transcripts without tasks in this tile)
             const uint64_t below = ne & ((1ull << (slot & 63u)) - 1ull);
             ti -= uint32_t(__popcll(below));
-            isEmpty = isFirst && ((ne >> (slot & 63u)) & 1ull);
+            const bool isEmpty0 = isFirst && ((ne >> (slot & 63u)) & 1ull);
+            m_empty = __ballot(isEmpty0) & m_active;
             code = 0; sp = 0; ln = 0; sr = 0;
-            if (active && !isEmpty) { code = g_code[ti]; sp = g_sp[ti]; ln = g_ln[ti]; sr = g_sr[ti]; }
+            if (active && !isEmpty0) { code = g_code[ti]; sp = g_sp[ti]; ln = g_ln[ti]; sr = g_sr[ti]; }
         }
-        const bool isTask = active && !isEmpty;
+        const bool isEmpty = lane_bit(m_empty);
+        const uint64_t m_task = m_active & ~m_empty;
         const uint32_t res_len = L.res_len[slot & 63u], pos0 = L.pos[slot & 63u];
         // ---- update_task / Task::execute checks; result positions ----
-        const bool res_oob = isTask && (ln > res_len || sr > res_len - ln);
-        const uint32_t e = isTask && !res_oob ? sr + ln : 0u;                             // end of the task inside its transcript's result
+        const uint64_t m_res_oob = (__ballot(ln > res_len) | __ballot(sr > res_len - ln)) & m_task;
+        const uint32_t e = lane_bit(m_task & ~m_res_oob) ? sr + ln : 0u;                  // end of the task inside its transcript's result
         const uint32_t pe_raw = up1(e, carry_e);                                          // ... of the item before
         const uint32_t pe = isFirst ? 0u : pe_raw;
-        const uint32_t csel = code == 1u ? 1u : 0u;
+        const uint64_t m_code1 = __ballot(code == 1u);
+        const uint32_t csel = lane_bit(m_code1) ? 1u : 0u;
         const uint32_t bound = L.bound[csel][slot & 63u];
-        const bool src_oob = ln > bound || sp > bound - ln;
-        const bool anybad = isTask && (code > 1u || res_oob || src_oob || sr < pe);
-        const bool in_emit = lane >= e_lo && lane < e_hi;
-        if (PHASE != PH_DIRECT && __ballot(anybad && in_emit)) {                           // (rare: which rule, in update_task's order)
+        const uint64_t m_src_oob = __ballot(ln > bound) | __ballot(sp > bound - ln);
+        const uint64_t m_bad = m_task & (__ballot(code > 1u) | m_res_oob | m_src_oob | __ballot(sr < pe));
+        const uint64_t m_in_emit = (e_hi >= 64u ? ~0ull : (1ull << e_hi) - 1ull) & ~((1ull << e_lo) - 1ull);
+        const bool in_emit = lane_bit(m_in_emit);
+        if (PHASE != PH_DIRECT && (m_bad & m_in_emit)) {                                  // (rare: which rule, in update_task's order)
+            const bool res_oob = lane_bit(m_res_oob), src_oob = lane_bit(m_src_oob);
             const uint32_t why = code > 1u ? STATUS_BAD_CODE : (res_oob ? STATUS_RES_OOB : (src_oob ? STATUS_SRC_OOB : STATUS_NOT_CONTIGUOUS));
-            if (anybad && in_emit) rreport(a.status, task_lo + ti, why);
+            if (lane_bit(m_bad & m_in_emit)) rreport(a.status, task_lo + ti, why);
         }
-        const bool good = isTask && !anybad;
+        const uint64_t m_good = m_task & ~m_bad;
+        const bool good = lane_bit(m_good);
         // ---- classes of the fusion state machine ----
-        const bool isRef = good && code == 0u;
-        const bool imm = good && code == 1u && ln - 1u < IMM_MAX_BYTES;
+        const uint64_t m_isRef = m_good & __ballot(code == 0u);
+        const uint64_t m_imm = m_good & m_code1 & __ballot(ln - 1u < IMM_MAX_BYTES);
+        const bool isRef = lane_bit(m_isRef), imm = lane_bit(m_imm);
         const uint64_t src = L.base[csel][slot & 63u] + sp;
         uint64_t lit = 0;
         if (alt_in_lds) {                                                                 // short alt payloads travel inside their descriptor
@@ -322,28 +334,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
             struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
             lit = reinterpret_cast<const U64*>(a.alt + src)->v & (~0ull >> (64u - 8u * ln));
         }
-        const bool ps = isRef && ln <= ROWS_FUSE_LEN;
-        const bool cA = ps && src + ln <= SNV3_MAX_SRC - 1u - ROWS_FUSE_LEN;
-        const bool cB = imm && ln == 1u;
-        const bool c0 = ps && ln > 0u && src >= 1u && src + ln <= SNV3_MAX_SRC;
+        const uint64_t m_ps = m_isRef & __ballot(ln <= ROWS_FUSE_LEN);
+        const uint64_t m_cA = m_ps & __ballot(src + ln <= SNV3_MAX_SRC - 1u - ROWS_FUSE_LEN);
+        const uint64_t m_cB = m_imm & __ballot(ln == 1u);
+        const uint64_t m_ln0 = __ballot(ln == 0u);
+        const uint64_t m_c0 = m_ps & ~m_ln0 & __ballot(src >= 1u) & __ballot(src + ln <= SNV3_MAX_SRC);
         const uint32_t src32 = uint32_t(src);
         const uint32_t src2 = up2(src32), ln2 = up2(ln);
-        const bool c1 = ln2 == 0u ? c0 : (ps && (ln == 0u || src == uint64_t(src2) + ln2 + 1u));
-        const bool gap = good && sr > pe;
-        const uint64_t mRst = ~__ballot(good) | firstmask | __ballot(gap);
-        const RowsParse p = rows_parse(__ballot(cA), __ballot(cB), __ballot(ps), __ballot(c0), __ballot(c1), mRst, !first, carry_h);
-        const bool isF = lane_bit(p.F), isReal = lane_bit(p.real);
+        const uint64_t m_ln20 = __ballot(ln2 == 0u);
+        const uint64_t m_c1 = (m_ln20 & m_c0) | (~m_ln20 & m_ps & (m_ln0 | __ballot(src == uint64_t(src2) + ln2 + 1u)));
+        const uint64_t m_gap = m_good & __ballot(sr > pe);
+        const bool gap = lane_bit(m_gap);
+        const uint64_t mRst = ~m_good | firstmask | m_gap;
+        const RowsParse p = rows_parse(m_cA, m_cB, m_ps, m_c0, m_c1, mRst, !first, carry_h);
+        const bool isF = lane_bit(p.F);
         // a closing lane's fused substitution: run, len1, byte, len2
-        const uint32_t f_len1 = isF && isReal ? ln2 : 0u;
+        const uint32_t f_len1 = lane_bit(p.F & p.real) ? ln2 : 0u;
         const uint32_t f_byte = up1(uint32_t(lit), 0u) & 0xFFu;
         const uint32_t f_run = f_len1 == 0u ? src32 - 1u : src2;
         uint64_t second = 0;
         uint32_t p_len1 = 0, p_len2 = 0, p_run = 0, p_byte = 0;
         if (MODE == ROWS_DENSE) {
             p_len1 = up2(f_len1); p_len2 = up2(ln); p_run = up2(f_run); p_byte = up2(f_byte);
-            const bool Lc = isF && lane_bit(p.F << 2) && !lane_bit(mRst << 1) && f_len1 == 0u &&
-                            p_len1 <= SNV5_MAX_LEN && p_len2 <= SNV5_MAX_LEN && ln <= SNV5_MAX_LEN && f_run == p_run + p_len1 + 1u + p_len2;
-            second = rows_pair(__ballot(Lc), !first, carry_second);
+            const uint64_t m_Lc = p.F & (p.F << 2) & ~(mRst << 1) & __ballot(f_len1 == 0u) & __ballot(p_len1 <= SNV5_MAX_LEN) & __ballot(p_len2 <= SNV5_MAX_LEN) &
+                                  __ballot(ln <= SNV5_MAX_LEN) & __ballot(f_run == p_run + p_len1 + 1u + p_len2);
+            second = rows_pair(m_Lc, !first, carry_second);
         }
         const uint64_t absorbed = (p.F >> 1) | ((p.F & p.real) >> 2) | (MODE == ROWS_DENSE ? (second >> 2) & p.F : 0ull);
         const bool isAbs = lane_bit(absorbed), isSecond = lane_bit(second);
@@ -391,15 +406,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
         }
         // Everything rare behind ONE uniform branch: a run of more than 1 KiB (it may cross two rows of the arena, or exceed a
         // descriptor's length field and become several descriptors)
-        bool big = false;
+        uint64_t m_big = 0ull;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) big = big || rl[i] > ROW_BYTES;
-        const bool slow = __ballot(big) != 0ull;
+        for (int i = 0; i < NR; ++i) m_big |= __ballot(rl[i] > ROW_BYTES);
+        const bool slow = m_big != 0ull;
         // ... and the usual window before the general one: no lane has a gap, a tail or FASTA text to emit -- every lane at most its
         // Task's own run -- so a descriptor's slot is a ballot and a popcount (no scan), and a run holds one row boundary at most
-        bool other = rl[RG] != 0u || rl[RT] != 0u;
-        if (FASTA) other = other || rl[0] != 0u || rl[NR - 1] != 0u;
-        const bool plain_window = !slow && __ballot(other) == 0ull;
+        uint64_t m_other = __ballot(rl[RG] != 0u) | __ballot(rl[RT] != 0u);
+        if (FASTA) m_other |= __ballot(rl[0] != 0u) | __ballot(rl[NR - 1] != 0u);
+        const bool plain_window = !slow && m_other == 0ull;
         if (plain_window) {
             const bool has = rl[RS] != 0u;
             const uint64_t hm = __ballot(has);
