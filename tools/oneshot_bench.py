@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--oracle", action="store_true", help="also check a sample of haplotypes against the oracle")
     ap.add_argument("--variants", default="", help="comma list of v2p_set_launch_opts variants (0 = the product; 20, 21: builder A/B switches): "
                     "the one call with ONE slice under each, interleaved, instead of the slice sweep")
+    ap.add_argument("--phase-mb", default="", help="with --variants: comma list of phase sizes (MB of image per phase; 0 = the library's choice) crossed with the variants")
     a = ap.parse_args()
     import torch
     from vcf2prot_amd import build
@@ -85,17 +86,19 @@ def main():
         res = {}
         if a.variants:
             vs = [int(x) for x in a.variants.split(",")]
+            phs = [int(x) for x in a.phase_mb.split(",")] if a.phase_mb else [0]
             for rep in range(a.reps):
                 for warm in (False, True):
+                  for ph in phs:
                     for var in vs:
-                        ctx.set_launch_opts(variant=var)
+                        ctx.set_launch_opts(variant=var, phase_bytes=ph << 20)
                         b.reset()
                         regime(warm)
                         b.build_and_execute(rs, a.kernel, 1)
                         b.sync()
                         info = b.oneshot_info()
                         assert np.array_equal(b.digests(), dig), var
-                        res.setdefault(f"variant{var}_{'warm' if warm else 'cold'}", []).append(
+                        res.setdefault(f"variant{var}{'_ph%d' % ph if ph else ''}_{'warm' if warm else 'cold'}", []).append(
                             {"total_ms": info["total_ms"], "build_ms_sum": info["build_ms"], "tables_ms": info.get("tables_ms", 0.0), "call_wall_ms": info["call_wall_ms"]})
             # the image each variant leaves behind, re-executed (steady state), interleaved
             steady = {}

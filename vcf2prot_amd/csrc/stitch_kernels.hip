@@ -1268,13 +1268,18 @@ __global__ void idle_kernel(uint32_t us)
 
 // chunks per phase and whether the read-ahead rides on the stitch launches: launch_stitch()'s rule, also asked by the caller that sizes the
 // staging buffers (0: one launch, no phases)
-static uint64_t phase_plan(const StitchArgs& a, int nontemporal, uint32_t max_blocks, bool* ride_out)
+static uint64_t phase_plan(const StitchArgs& a, int nontemporal, uint32_t max_blocks, bool staged, bool* ride_out)
 {
     *ride_out = false;
     if (a.n_chunks == 0) return 0;
     const uint64_t img_desc = a.img_desc ? a.img_desc : a.n_desc, img_bytes = a.img_bytes ? a.img_bytes : a.out_len;
     const bool rich = image_is_rich(img_desc, img_bytes);
     uint64_t phase_bytes = rich ? PHASE_BYTES_RICH : PHASE_BYTES_DEFAULT;
+    // STAGED descriptors are read from a buffer the read-ahead has just written, not from the image's lines it pulled in: a rich image
+    // takes larger phases then -- while the reference is small (its slice next to the phase in every XCD's L2).  One shot of C3 whole (1.8 MB
+    // of proteome): 11.95 / 11.89 / 11.82 / 11.67 / 11.80 / 11.82 ms with 28 / 36 / 40 / 44 / 48 / 56 MB, 14.7 with 64; C4 whole (56 MB):
+    // 9.36 / 9.62 / 10.29 / 11.54 with 28 / 36 / 40 / 44 (profiles/r05_staged_phase_sweep.json)
+    if (staged && rich && a.src0_len <= PHASE_STAGED_SMALL_REF) phase_bytes = PHASE_BYTES_STAGED;
     if (a.opt_phase_bytes == ~0ull) phase_bytes = 0;
     else if (a.opt_phase_bytes != 0) phase_bytes = a.opt_phase_bytes;
     const bool streams = (nontemporal & 4) != 0 || (nontemporal & 16) == 0;
@@ -1292,7 +1297,7 @@ static uint64_t phase_plan(const StitchArgs& a, int nontemporal, uint32_t max_bl
 uint32_t stitch_stage_chunks(const StitchArgs& args, int nontemporal)
 {
     bool ride = false;
-    const uint64_t per = phase_plan(args, nontemporal, 0, &ride);
+    const uint64_t per = phase_plan(args, nontemporal, 0, true, &ride);
     const int wsel = (nontemporal >> 28) & 3;
     if (!ride || !(nontemporal & 8) || wsel != 0 || (args.opt_touch & 4u) != 0 || args.opt_dual || per == 0 || per > 0x7FFFFFFFull) return 0;
     return uint32_t(per < args.n_chunks ? per : ((uint64_t(args.n_chunks) + 7u) & ~7ull));
@@ -1315,25 +1320,16 @@ hipError_t launch_stitch(const StitchArgs& args, hipStream_t stream, int nontemp
     const bool rich = image_is_rich(img_desc, img_bytes);                        // C2: 2.2 %, C4: 3.7 %, C3: 5 %
     // (phase size, store policy and threshold are launch options -- v2p_launch_opts, v2p_set_launch_opts -- for A/B runs and tests:
     // nothing here reads the environment)
-    uint64_t phase_bytes = rich ? PHASE_BYTES_RICH : PHASE_BYTES_DEFAULT;
-    if (a.opt_phase_bytes == ~0ull) phase_bytes = 0;                             // one phase, no touch
-    else if (a.opt_phase_bytes != 0) phase_bytes = a.opt_phase_bytes;
     // ("sc1 nt" row stores: by default images with a thin descriptor stream get them -- C2 3.14 -> 3.06 ms (-2.6 %), C4 +0.9 %, C3 +6 %)
     a.store_sc1 = a.opt_store_sc1 >= 0 ? uint32_t(a.opt_store_sc1 != 0) : uint32_t(!rich);
     // (the kernels of per-block and dense images are bound by their instruction stream, not by memory: phases only cost them --
     // C3 per-block 2.00 -> 2.19 ms, C5 dense 0.53 -> 0.71; wave and long-run images gain: C2 3.26 -> 2.65 ms)
-    const bool streams = (nontemporal & 4) != 0 || (nontemporal & 16) == 0;       // the image holds wave or long-run chunks
-    const uint32_t min_chunks = a.opt_phase_min_chunks ? a.opt_phase_min_chunks : PHASE_MIN_CHUNKS;
-    if (max_blocks != 0 || phase_bytes == 0 || !streams || a.n_chunks < min_chunks) return launch_stitch_range(a, stream, nontemporal, max_blocks);
-    const double per_chunk = 16.0 + 8.0 * double(img_desc) / double(a.n_chunks);
-    uint64_t per = uint64_t(double(phase_bytes) / per_chunk);
-    const uint64_t per_min = a.opt_phase_min_chunks ? 8u : 4096u;    // (a lowered threshold -- tests -- also allows tiny phases)
-    per = per < per_min ? per_min : (per & ~7ull);                   // (a multiple of 8 keeps workgroup b on the XCD the chunk order dealt chunk b to)
-    const bool no_touch = (a.opt_touch & 1u) != 0;
     // a pure wave image: the read-ahead of phase k + 1 rides on the trailing workgroups of phase k's launch (they are dispatched while
     // its last chunks drain) instead of a kernel of its own between the two; only phase 0 has a touch kernel (opt_touch 2: A/B)
-    const bool own_touch = (a.opt_touch & 2u) != 0;
-    const bool ride = !own_touch && !no_touch && (nontemporal & 4) != 0 && (nontemporal & 48) == 48 && !(nontemporal & 2);
+    bool ride = false;
+    const uint64_t per = phase_plan(a, nontemporal, max_blocks, args.stage != nullptr && a.rows, &ride);
+    if (per == 0) return launch_stitch_range(a, stream, nontemporal, max_blocks);
+    const bool no_touch = (a.opt_touch & 1u) != 0;
     // (V2P_PHASE_ONE_LAUNCH, A/B: ONE launch for all phases, the read-ahead workgroups of phase g + 1 placed in the grid before the
     // stitch workgroups of phase g (stitch_wave.hip) -- no kernel boundary, no tail, no launch gap between two phases.  Measured:
     // C2 3.16 against 3.21 ms, but C3 1.98 against 1.85 and C3 whole 11.1 against 9.35: the boundary is what keeps two phases'
