@@ -313,7 +313,9 @@ def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verif
                     "aa_per_s_gpu_busy_before": A / (i2["total_ms"] * 1e-3) if A else 0.0,
                     "kernel_choice": i1["kernel"], "n_slices": i1["n_slices"], "stream_upload_s_incl_host_checks": t_upload,
                     "what": "ONE call, v2p_batch_build_and_execute, on the resident per-transcript Task vectors (un-rebased SoA, transcript offsets, alt bytes): "
-                            "step 5 as scans, one-pass parse, compaction beside the row cutter, XCD order, then every phase of the stitch kernel; total_ms = HIP events "
+                            "res_counter per tile / haplotype are tables of the resident stream (made at its upload); one-pass parse; a rich wave image (C3, C4) stays padded -- no compaction pass -- and "
+                            "the read-ahead of every phase stages its descriptors in launch order for the stitch kernel (a thin or dense image: compaction beside the row cutter); row cutter, "
+                            "XCD order, then every phase of the stitch kernel; the timed steps behind it re-execute the same batch (made dense at its first re-execute); total_ms = HIP events "
                             "from before the first build kernel to behind the last stitch kernel, buffers recycled, 0.5 s of host sleep in front (clocks down); "
                             "*_gpu_busy_before: the same call right behind four executes (clocks up)"})
         desc, chunks, hb = b.download_image()

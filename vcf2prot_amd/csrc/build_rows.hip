@@ -558,7 +558,7 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
         // rows r0 .. r0 + 63 in registers: the descriptor covering each row's first byte
         const uint64_t b = r0, r = b + lane;
         uint64_t c = 0, idx = 0;
-        uint32_t pslot = 0, pd = 0;              // PADDED records: the row's descriptor as a slot of the padded array; descriptors from it to the end of its tile | ... of the next tile << 16
+        uint32_t pslot = 0, pd1 = 0;             // PADDED records: the row's descriptor as a slot of the padded array; descriptors from it to the end of its tile
         if (r < a.n_rows) {
             if (r >= 1u) c = a.cover[r];
             if (c >> 63) idx = (c >> 22) & ((1ull << 41) - 1ull);
@@ -566,40 +566,34 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
                 const uint64_t tl = c >> 38, sl = (c >> 22) & 0xFFFFu, tb0 = a.tile_desc_base[tl];
                 idx = r >= 1u ? tb0 + sl : 0ull;
                 if (a.pad_chunks) {
-                    const uint64_t e1 = a.tile_desc_base[tl + 1u], e2 = tl + 2u <= a.n_tiles ? a.tile_desc_base[tl + 2u] : e1;
+                    const uint64_t d1 = a.tile_desc_base[tl + 1u] - idx;             // (idx < that unless tile 0 is empty and r = 0: d1 = 0 marks it)
                     pslot = uint32_t(tl * ROWS_PAD + sl);
-                    const uint64_t d1 = e1 - idx, d2 = e2 - idx;                     // (idx < e1 unless tile 0 is empty and r = 0: d1 = 0 marks it)
-                    pd = uint32_t(d1 < 0xFFFFu ? d1 : 0xFFFFu) | (uint32_t(d2 < 0xFFFFu ? d2 : 0xFFFFu) << 16);
+                    pd1 = uint32_t(d1 < CHUNK_N1_MASK ? d1 : CHUNK_N1_MASK);
                 }
             }
         }
         const uint32_t off = uint32_t(c) & PIECE_MAX;
+        const uint32_t offd = off | (pd1 << 11);                                          // (one register, one v_readlane per chunk for both)
         const uint64_t lastd = r >= a.n_rows ? n_desc - 1u : (off ? idx : idx - 1u);      // last descriptor of a chunk that ends at row r
         // what a chunk ending at row r leaves of its last descriptor behind the cut: the parse wrote it into the row map
         const uint32_t tc = (EMIT && r < a.n_rows && off != 0u) ? (uint32_t(c) >> 11) & PIECE_MAX : 0u;
         uint32_t cur = 0;
         for (;;) {
             const uint64_t f = uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(idx)), int(cur)))) | (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(idx >> 32)), int(cur)))) << 32);
-            const uint32_t hs = uint32_t(__builtin_amdgcn_readlane(int(off), int(cur)));
+            const uint32_t hsd = uint32_t(__builtin_amdgcn_readlane(int(offd), int(cur))), hs = hsd & PIECE_MAX;
             const bool ok = lane > cur && lane <= cur + max_rows && r <= s1 && lastd - f + 1u <= max_desc;
             const uint64_t m = __ballot(ok);
             if (!m) { if (lane == 0) rreport(a.status, f, STATUS_ROWS_TOO_MANY); return; }
             const uint32_t hb = 63u - uint32_t(__builtin_clzll(m));
-            uint32_t ps = 0, pdc = 0;
-            if (EMIT && a.pad_chunks) { ps = uint32_t(__builtin_amdgcn_readlane(int(pslot), int(cur))); pdc = uint32_t(__builtin_amdgcn_readlane(int(pd), int(cur))); }
+            uint32_t ps = 0;
+            if (EMIT && a.pad_chunks) ps = uint32_t(__builtin_amdgcn_readlane(int(pslot), int(cur)));
             if (EMIT && lane == hb && (PASS != 2 || count < ROWS_CHUNK_PAD)) {
                 const uint64_t n = lastd - f + 1u;
-                uint64_t first = f, n1 = 0;
-                if (a.pad_chunks) {
-                    // the record addresses the PADDED array (sir_pack.hpp): the first n1 descriptors in the start row's tile, the others from
-                    // the next tile's first slot.  A chunk that reaches into a third tile (tiles of a few descriptors) cannot say so: the
-                    // host is told (totals[3] bit 1) and builds the dense form instead
-                    const uint64_t d1 = pdc & 0xFFFFu, d2 = pdc >> 16;
-                    first = ps;
-                    n1 = n <= d1 ? 0u : d1;
-                    if (d1 == 0u || n > d2 || d1 > CHUNK_N1_MASK) atomicOr(reinterpret_cast<unsigned long long*>(a.totals) + 3, 2ull);
-                }
-                table[out_k] = Chunk{first | (uint64_t(hs) << TB_IDX_BITS) | (uint64_t(tc) << (TB_IDX_BITS + TB_SKIP_BITS)), ((b + cur) * ROW_BYTES) | n1 | (n << 48) | CHUNK_CLIP | flag};
+                // (a.pad_chunks: the record addresses the PADDED array, sir_pack.hpp -- its first descriptor as a slot, and for now how many
+                // descriptors its tile holds from there on in the bits that will say n1: rows_chunk_compact_kernel, lane = chunk, turns that
+                // into n1 and checks that the chunk ends inside the next tile.  None of it costs this loop more than one v_readlane.)
+                const uint64_t first = a.pad_chunks ? uint64_t(ps) : f, low = a.pad_chunks ? uint64_t(hsd >> 11) : 0ull;
+                table[out_k] = Chunk{first | (uint64_t(hs) << TB_IDX_BITS) | (uint64_t(tc) << (TB_IDX_BITS + TB_SKIP_BITS)), ((b + cur) * ROW_BYTES) | low | (n << 48) | CHUNK_CLIP | flag};
             }
             last_dst = (b + cur) * ROW_BYTES;
             ++count; ++out_k;
@@ -623,7 +617,20 @@ __global__ __launch_bounds__(256) void rows_chunk_compact_kernel(RowsArgs a)
     if (seg >= a.seg1) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t b0 = a.seg_base[seg], n = a.seg_base[seg + 1u] - b0;
-    for (uint32_t k = lane; k < n && k < ROWS_CHUNK_PAD; k += 64u) a.chunks_tmp[b0 + k] = a.chunks_pad[seg * ROWS_CHUNK_PAD + k];
+    for (uint32_t k = lane; k < n && k < ROWS_CHUNK_PAD; k += 64u) {
+        Chunk ch = a.chunks_pad[seg * ROWS_CHUNK_PAD + k];
+        if (a.pad_chunks) {
+            // slot-addressed records (sir_pack.hpp): d1 -- the descriptors the first tile holds from the chunk's first one on -- becomes n1
+            // (0: the chunk ends inside that tile); a chunk that would go on into a THIRD tile (tiles of a few descriptors) cannot be
+            // written down: the host is told (totals[3] bit 1) and builds the dense form instead
+            const uint64_t d1 = ch.dst_n & CHUNK_N1_MASK, nd = (ch.dst_n >> 48) & CHUNK_N_MASK;
+            const uint64_t tl = (ch.task_begin & TB_IDX_MASK) / ROWS_PAD;
+            const uint64_t next = tl + 2u <= a.n_tiles ? a.tile_desc_base[tl + 2u] - a.tile_desc_base[tl + 1u] : 0ull;      // descriptors of the next tile
+            if (d1 == 0u || nd > d1 + next) atomicOr(reinterpret_cast<unsigned long long*>(a.totals) + 3, 2ull);
+            ch.dst_n = (ch.dst_n & ~CHUNK_N1_MASK) | (nd <= d1 ? 0ull : d1);
+        }
+        a.chunks_tmp[b0 + k] = ch;
+    }
 }
 
 // proteome slice and window of every chunk (order_chunks_for_xcds: the first reference read among its first six descriptors)

@@ -2162,6 +2162,10 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
         }
         if (ns) OS_TRY(launch_rows_cut(a, mode, 2, B), "launch(cut)");
         OS_TRY(launch_scan_u32_from(a.seg_count + SG[j], ns, const_cast<uint64_t*>(a.seg_base) + SG[j], reinterpret_cast<uint64_t*>(b->d_cover.ptr() + c_tiles), chunk0, B), "launch(scan)");
+        // (the chunk table in arena order before the host's one look at the counts: its grid is the segments', and for a padded image it
+        // is also where a chunk that does not fit the slot-addressed form is found -- totals[3])
+        a.chunks_tmp = chunks_tmp;
+        if (ns) OS_TRY(launch_rows_chunk_compact(a, B), "launch(chunk table)");
         uint64_t desc_end = desc0, chunk_end = chunk0, totals[4] = {0, 0, 0, 0};
         unsigned long long stw = STATUS_CLEAN;
         if (nt) OS_TRY(hipMemcpyAsync(&desc_end, d + o_tdbase + T[j + 1] * 8, 8, hipMemcpyDeviceToHost, B), "D2H(n_desc)");
@@ -2178,8 +2182,6 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
         }
         const uint64_t nd = desc_end - desc0, nc = chunk_end - chunk0;
         if (chunk_end > 0xFFFFFFFFull) return fail_reset(c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one batch"));
-        a.chunks_tmp = chunks_tmp;
-        if (ns) OS_TRY(launch_rows_chunk_compact(a, B), "launch(chunk table)");
         // (the keys read the chunks' first descriptors.  Reading them from the padded array instead, so that the keys and the sorts run
         // beside the compaction as well, was measured: nothing -- the copy runs at the memory's rate and what runs beside it waits for it)
         if (nt && !pad) OS_TRY(hipStreamWaitEvent(B, b->ev_aux[1], 0), "hipStreamWaitEvent");      // (the descriptors are in place)
