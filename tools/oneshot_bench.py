@@ -94,7 +94,7 @@ def main():
                         ctx.set_launch_opts(variant=var, phase_bytes=ph << 20)
                         b.reset()
                         regime(warm)
-                        b.build_and_execute(rs, a.kernel, 1)
+                        b.build_and_execute(rs, a.kernel, 0)        # (0: the library's own choice of slices)
                         b.sync()
                         info = b.oneshot_info()
                         assert np.array_equal(b.digests(), dig), var
@@ -106,7 +106,7 @@ def main():
             for var in sorted(set(vs)):
                 ctx.set_launch_opts(variant=var)
                 bs[var] = ctx.batch()
-                bs[var].build_and_execute(rs, a.kernel, 1); bs[var].sync()
+                bs[var].build_and_execute(rs, a.kernel, 0); bs[var].sync()
             ctx.set_launch_opts()
             for _ in range(3):
                 for var in bs:

@@ -48,7 +48,8 @@ struct BuildArgs {
 };
 
 hipError_t launch_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* tile_scratch, hipStream_t stream);
-hipError_t launch_scan_u32_from(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* tile_scratch, uint64_t first, hipStream_t stream);   // ... + first
+hipError_t launch_scan_u32_from(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* tile_scratch, uint64_t first, hipStream_t stream);
+hipError_t launch_scan_u32_chained(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* tile_scratch, hipStream_t stream);   // first = out[0] as the slice before left it   // ... + first
 // phase 0: count descriptors per transcript (and validate); phase 1: emit descriptors + chunk table + hap_out_begin
 hipError_t launch_build(const BuildArgs& a, uint64_t n_windows, uint64_t n_desc, uint64_t out_bytes, int phase, hipStream_t stream);
 hipError_t launch_xcd_order(const Chunk* in, const uint8_t* bucket, uint64_t n, uint32_t* hist, Chunk* out, hipStream_t stream);

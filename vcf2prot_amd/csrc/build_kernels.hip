@@ -69,9 +69,10 @@ __global__ __launch_bounds__(1024) void scan_tiles(uint64_t* __restrict__ tile_s
 }
 
 __global__ __launch_bounds__(256) void scan_apply(const uint32_t* __restrict__ in, uint64_t n, const uint64_t* __restrict__ tile_sum,
-                                                  uint64_t* __restrict__ out, uint64_t first)
+                                                  uint64_t* out, uint64_t first, const uint64_t* first_dev)
 {
     __shared__ uint64_t s[4];
+    if (first_dev) first += *first_dev;            // (a table scanned slice by slice without the host in between: the slice before left its total there)
     const uint64_t base = uint64_t(blockIdx.x) * SCAN_TILE;
     uint32_t x[4];
     uint64_t v = 0;
@@ -96,7 +97,17 @@ hipError_t launch_scan_u32_from(const uint32_t* in, uint64_t n, uint64_t* out, u
     if (n == 0) return hipMemcpyAsync(out, &first, 8, hipMemcpyHostToDevice, stream);
     hipLaunchKernelGGL(scan_tile_sums, dim3(uint32_t(n_tiles)), dim3(256), 0, stream, in, n, tile_scratch);
     hipLaunchKernelGGL(scan_tiles, dim3(1), dim3(1024), 0, stream, tile_scratch, n_tiles);
-    hipLaunchKernelGGL(scan_apply, dim3(uint32_t(n_tiles)), dim3(256), 0, stream, in, n, tile_scratch, out, first);
+    hipLaunchKernelGGL(scan_apply, dim3(uint32_t(n_tiles)), dim3(256), 0, stream, in, n, tile_scratch, out, first, static_cast<const uint64_t*>(nullptr));
+    return hipGetLastError();
+}
+// ... continuing from the total the slice before left in out[0] (on the device: nobody reads it back); n >= 1
+hipError_t launch_scan_u32_chained(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* tile_scratch, hipStream_t stream)
+{
+    const uint64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (n == 0) return hipSuccess;                                   // (out[0] already holds the total)
+    hipLaunchKernelGGL(scan_tile_sums, dim3(uint32_t(n_tiles)), dim3(256), 0, stream, in, n, tile_scratch);
+    hipLaunchKernelGGL(scan_tiles, dim3(1), dim3(1024), 0, stream, tile_scratch, n_tiles);
+    hipLaunchKernelGGL(scan_apply, dim3(uint32_t(n_tiles)), dim3(256), 0, stream, in, n, tile_scratch, out, 0ull, static_cast<const uint64_t*>(out));
     return hipGetLastError();
 }
 hipError_t launch_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* tile_scratch, hipStream_t stream)

@@ -173,6 +173,8 @@ struct v2p_batch {
     uint64_t slice_desc[V2P_MAX_SLICES] = {}, slice_bytes[V2P_MAX_SLICES] = {};
     hipEvent_t ev_os[2 + 2 * V2P_MAX_SLICES] = {};
     hipEvent_t ev_aux[2] = {};
+    hipEvent_t ev_par[V2P_MAX_SLICES] = {};   // a slice's parse and the scan of its tiles' counts are done (the slices' parses run ahead on a stream of their own)
+    bool os_ahead = false;         // the last one call built its slices that way: build time = first parse .. last slice's chunk table
     float os_build_ms = 0.f;
     double os_wall_ms = 0.0;
     int os_kernel = 0;
@@ -990,6 +992,7 @@ void v2p_batch_destroy(v2p_batch* b)
     if (b->ctx->aux_stream) (void)hipStreamSynchronize(b->ctx->aux_stream);
     for (hipEvent_t e : b->ev_os) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : b->ev_aux) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : b->ev_par) if (e) (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -1846,6 +1849,7 @@ struct v2p_stream {
     uint32_t tile_K = 0;
     uint64_t n_tiles = 0;
     const uint64_t* tile_res_base = nullptr;   // [n_tiles + 1]
+    std::vector<uint64_t> h_tile_res_base;     // ... and on the host (a call that builds in slices cuts at these offsets without asking the device)
     const uint64_t* d_hap_out_begin = nullptr; // [n_haps + 1]
 };
 
@@ -1882,7 +1886,11 @@ int v2p_stream_upload(v2p_ctx* c, const v2p_txstream* s, v2p_stream** out)
             hipError_t e = launch_rows_tile_bytes(a, reinterpret_cast<uint64_t*>(d + o_scan), c->stream);
             if (e == hipSuccess) e = launch_rows_hap_begin(a, c->stream);
             if (e != hipSuccess) rc = c->hip_fail(e, "launch(tile tables)");
-            else { st->tile_K = K; st->n_tiles = n_tiles; st->tile_res_base = a.tile_res_base; st->d_hap_out_begin = a.hap_out_begin; }
+            else {
+                st->tile_K = K; st->n_tiles = n_tiles; st->tile_res_base = a.tile_res_base; st->d_hap_out_begin = a.hap_out_begin;
+                st->h_tile_res_base.assign(n_tiles + 1, 0);
+                if (hipMemcpyAsync(st->h_tile_res_base.data(), a.tile_res_base, (n_tiles + 1) * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { (void)hipGetLastError(); st->h_tile_res_base.clear(); }
+            }
         }
     }
     if (rc == V2P_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = c->fail(V2P_ERR_HIP, "hipStreamSynchronize");
@@ -2032,7 +2040,11 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     // (n_slices = 0: ONE slice.  Slices were built to overlap the build of slice j + 1 with the stitch of slice j; measured on C3 whole and
     // C2 -- profiles/r05_oneshot_slices.json -- every added slice costs: a slice's build takes three times as long next to a running
     // stitch (cold stream reads between its stores, the effect of DESIGN.md section 3) and the stitch slows down as well.)
-    uint32_t S = n_slices ? n_slices : 1u;
+    // (a padded image -- the rule is below, where its buffers are -- is built in slices of its own kind: see `ahead`)
+    const uint32_t bvar = c->launch_opts.variant;
+    const bool rich_stream = out_bytes <= uint64_t(PAD_BYTES_PER_TASK_MAX) * v.n_tasks;
+    const bool pad = mode == ROWS_WAVE && n_tiles < (1ull << 24) && bvar != 22u && (rich_stream || bvar == 24u);
+    uint32_t S = n_slices ? n_slices : (pad && bvar == 27u ? 3u : 1u);
     if (S > V2P_MAX_SLICES) S = V2P_MAX_SLICES;
     while (S > 1 && n_tiles / S < 64) --S;
     auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
@@ -2058,9 +2070,6 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     // 64 MB phases) would half-fill its staging rows and double what a phase keeps in the caches: it keeps the compaction, and so do
     // dense images (chunks of up to 1 024 descriptors).  The rule looks at the stream (result bytes per Task); variants 22 / 24 force
     // the compacted / the padded form (A/B).
-    const uint32_t bvar = c->launch_opts.variant;
-    const bool rich_stream = out_bytes <= uint64_t(PAD_BYTES_PER_TASK_MAX) * v.n_tasks;
-    const bool pad = mode == ROWS_WAVE && n_tiles < (1ull << 24) && bvar != 22u && (rich_stream || bvar == 24u);
     if (!pad) HIP_TRY(c, b->d_pad.ensure_exact(max_tiles * ROWS_PAD_SLOTS * 8), "hipMalloc(padded descriptors)");
     const uint64_t desc_cap = n_tiles * ROWS_PAD_SLOTS;              // (one-pass tiles hold at most their 256 slots)
     HIP_TRY(c, b->d_desc.ensure_exact(desc_cap * 8), "hipMalloc(desc)");
@@ -2080,6 +2089,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     if (!c->aux_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking), "hipStreamCreate(aux)");
     for (uint32_t k = 0; k < 2 + 2 * S; ++k) HIP_TRY(c, ensure_event(b->ev_os[k]), "hipEventCreate");
     for (hipEvent_t& e : b->ev_aux) HIP_TRY(c, ensure_event(e), "hipEventCreate");
+    for (uint32_t k = 0; k < S; ++k) HIP_TRY(c, ensure_event(b->ev_par[k]), "hipEventCreate");
     hipStream_t A = c->stream, B = c->build_stream, X = c->aux_stream;
     int rc = init_status(c, b->d_status);             // (on A)
     if (rc) return rc;
@@ -2090,7 +2100,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     // (A/B switches of the builder, v2p_set_launch_opts: variant 20 = tile = workgroup index in the parse, 21 = tile tables made inside the
     // call: round 5's first form; 22 / 24 = the compacted / the padded form of a wave image whatever the rule says)
     a.xcd_tiles = bvar == 20u ? 0u : 1u;
-    const bool cached = bvar != 21u && S == 1 && st->tile_K == K && st->n_tiles == n_tiles && st->tile_res_base != nullptr;
+    const bool cached = bvar != 21u && st->tile_K == K && st->n_tiles == n_tiles && st->tile_res_base != nullptr && (S == 1 || st->h_tile_res_base.size() == n_tiles + 1);
     if (cached) a.tile_res_base = const_cast<uint64_t*>(st->tile_res_base);      // (read only from here on)
     a.tile_count = reinterpret_cast<uint32_t*>(d + o_tcount); a.tile_desc_base = reinterpret_cast<uint64_t*>(d + o_tdbase);
     a.totals = reinterpret_cast<uint64_t*>(d + o_totals);
@@ -2128,6 +2138,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
         // res_counter per tile and per haplotype came with the stream (v2p_stream_upload): no kernel, no host round trip before the parse
         OS_TRY(hipMemcpyAsync(b->d_hap.ptr(), st->d_hap_out_begin, (n_h + 1) * 8, hipMemcpyDeviceToDevice, B), "D2D(hap_begin)");
         R[0] = 0; R[S] = out_bytes;
+        for (uint32_t j = 1; j < S; ++j) R[j] = st->h_tile_res_base[T[j]];
     } else {
         OS_TRY(launch_rows_tile_bytes(a, scan_scratch, B), "launch(tile bytes)");
         OS_TRY(launch_rows_hap_begin(a, B), "launch(hap_begin)");
@@ -2143,11 +2154,34 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     const bool reorder = !(c->flags & V2P_FLAG_RESULT_ORDER) && c->proteome_len != 0;
     uint64_t desc0 = 0, chunk0 = 0;
     b->os_build_ms = 0.f;
+    // AHEAD (a padded image in more than one slice: n_slices, or three with A/B variant 27): every slice's parse -- the build's one heavy
+    // kernel -- is launched at once on a stream of its own, the count scans chained on the device, and what follows a parse (cutter,
+    // chunk table, the host's look at the counts, keys, XCD order: 0.75 ms of serial walks and small sorts) runs for slice j on the
+    // build stream WHILE slice j + 1 is parsed.  The descriptors need no second pass (padded), so nothing of a slice waits for the
+    // slices behind it; the stitch starts when the last slice's chunk table stands.  MEASURED AND NOT THE DEFAULT: C3 whole's build
+    // 3.96 -> 4.34 ms, C4 whole's 2.75 -> 3.07 with three slices -- the small kernels take wave slots and issue cycles from the parse,
+    // which is balanced on all of its units, and give back less than they take.  Overlap does not pay on this chip, again (section 4).
+    const bool ahead = pad && S > 1;
+    b->os_ahead = ahead;
+    if (ahead) {
+        OS_TRY(hipStreamWaitEvent(X, b->ev_os[0], 0), "hipStreamWaitEvent");
+        OS_TRY(hipEventRecord(b->ev_os[2], X), "hipEventRecord");
+        for (uint32_t j = 0; j < S; ++j) {
+            a.tile0 = T[j]; a.tile1 = T[j + 1];
+            const uint64_t nt = T[j + 1] - T[j];
+            a.desc_pad = a.desc + T[j] * ROWS_PAD_SLOTS;
+            if (nt) OS_TRY(launch_rows_parse(a, mode, v.fasta, 0, X), "launch(parse)");
+            if (j == 0) OS_TRY(launch_scan_u32_from(a.tile_count, nt, a.tile_desc_base, scan_scratch + rows_scan_scratch_entries(n_tiles), 0, X), "launch(scan)");
+            else OS_TRY(launch_scan_u32_chained(a.tile_count + T[j], nt, a.tile_desc_base + T[j], scan_scratch + rows_scan_scratch_entries(n_tiles), X), "launch(scan)");
+            OS_TRY(hipEventRecord(b->ev_par[j], X), "hipEventRecord");
+        }
+    }
     for (uint32_t j = 0; j < S; ++j) {
         a.tile0 = T[j]; a.tile1 = T[j + 1]; a.seg0 = SG[j]; a.seg1 = SG[j + 1];
         const uint64_t nt = T[j + 1] - T[j], ns = SG[j + 1] - SG[j];
-        OS_TRY(hipEventRecord(b->ev_os[2 + 2 * j], B), "hipEventRecord");
-        if (nt) {
+        if (ahead) OS_TRY(hipStreamWaitEvent(B, b->ev_par[j], 0), "hipStreamWaitEvent");
+        if (!ahead || j > 0) OS_TRY(hipEventRecord(b->ev_os[2 + 2 * j], B), "hipEventRecord");     // (ahead: slice 0's interval starts with its parse, on X)
+        if (nt && !ahead) {
             if (pad) a.desc_pad = a.desc + T[j] * ROWS_PAD_SLOTS;               // (the slice's tiles' own slots of the one array)
             OS_TRY(launch_rows_parse(a, mode, v.fasta, 0, B), "launch(parse)");
             OS_TRY(launch_scan_u32_from(a.tile_count + T[j], nt, a.tile_desc_base + T[j], scan_scratch + rows_scan_scratch_entries(n_tiles), desc0, B), "launch(scan)");
@@ -2197,11 +2231,20 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
                                        reinterpret_cast<uint32_t*>(sc + s_tot), out_chunks, B), "launch(order)");
         } else if (nc) OS_TRY(hipMemcpyAsync(out_chunks, chunks_tmp + chunk0, nc * sizeof(Chunk), hipMemcpyDeviceToDevice, B), "D2D(chunks)");
         OS_TRY(hipEventRecord(b->ev_os[3 + 2 * j], B), "hipEventRecord");
-        // ---- the slice is built: stitch it on the context's stream while the build stream goes on ----
-        OS_TRY(hipStreamWaitEvent(A, b->ev_os[3 + 2 * j], 0), "hipStreamWaitEvent");
         b->slice_chunk0[j] = chunk0; b->slice_desc[j] = nd; b->slice_bytes[j] = ns * uint64_t(ROWS_SEG) * ROW_BYTES;
-        OS_TRY(stitch_range(b, pad ? desc_cap : desc_end, chunk0, nc, nd, b->slice_bytes[j], A), "launch(stitch)");
+        if (!ahead) {
+            // ---- the slice is built: stitch it on the context's stream while the build stream goes on ----
+            OS_TRY(hipStreamWaitEvent(A, b->ev_os[3 + 2 * j], 0), "hipStreamWaitEvent");
+            OS_TRY(stitch_range(b, pad ? desc_cap : desc_end, chunk0, nc, nd, b->slice_bytes[j], A), "launch(stitch)");
+        }
         desc0 = desc_end; chunk0 = chunk_end;
+    }
+    if (ahead) {
+        // ---- every slice is built: the stitch, slice after slice (each table is dealt to the XCDs inside its own slice) ----
+        OS_TRY(hipStreamWaitEvent(A, b->ev_os[3 + 2 * (S - 1)], 0), "hipStreamWaitEvent");
+        b->slice_chunk0[S] = chunk0;
+        for (uint32_t j = 0; j < S; ++j)
+            OS_TRY(stitch_range(b, desc_cap, b->slice_chunk0[j], b->slice_chunk0[j + 1] - b->slice_chunk0[j], b->slice_desc[j], b->slice_bytes[j], A), "launch(stitch)");
     }
 #undef OS_TRY
     b->slice_chunk0[S] = chunk0;
@@ -2280,6 +2323,7 @@ int v2p_batch_oneshot_info(v2p_batch* b, v2p_oneshot_info* info)
         info->slice_build_ms[j] = ms; sum += ms;
     }
     info->build_ms = b->n_slices ? sum : b->os_build_ms;
+    if (b->n_slices && b->os_ahead) HIP_TRY(c, hipEventElapsedTime(&info->build_ms, b->ev_os[2], b->ev_os[3 + 2 * (b->n_slices - 1)]), "hipEventElapsedTime");   // (the slices overlap: first parse .. last chunk table)
     if (b->n_slices) HIP_TRY(c, hipEventElapsedTime(&info->tables_ms, b->ev_os[0], b->ev_os[2]), "hipEventElapsedTime");
     return V2P_OK;
 }
