@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Steady-state execute of a DENSE rows image with its descriptors staged by the read-ahead (v2p_set_launch_opts variant 25) against read in
-place (0), over phase sizes:   python tools/stage_probe.py C3 10000 [28,36,40,44,48]"""
+"""Steady-state execute of a DENSE rows image as the library launches it (variant 0: descriptors staged by the read-ahead where its rule says so)
+against read in place (variant 23), over phase sizes (0 = the library's choice):   python tools/stage_probe.py C3 10000 [0,28,36,40,44,48]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -25,14 +25,14 @@ with Context(0) as ctx:
     res = {}
     for rep in range(5):
         for ph in phases:
-            for var in (0, 25):
+            for var in (23, 0):
                 ctx.set_launch_opts(variant=var, phase_bytes=ph << 20)
                 b.execute(); b.sync()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3): b.execute()
                 b.sync(); e1.record(); e1.synchronize()
-                res.setdefault(f"{'staged' if var else 'in_place'}_ph{ph}", []).append(e0.elapsed_time(e1) / 3)
+                res.setdefault(f"{'library' if var == 0 else 'in_place'}_ph{ph}", []).append(e0.elapsed_time(e1) / 3)
     ctx.set_launch_opts()
     assert np.array_equal(b.digests(), dig)
     out["ms"] = {k: round(sorted(v)[len(v) // 2], 3) for k, v in res.items()}

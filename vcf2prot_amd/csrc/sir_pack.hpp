@@ -657,7 +657,7 @@ inline bool image_is_rich(uint64_t n_desc, uint64_t result_bytes) { return 8.0 *
 constexpr uint64_t THIN_ONE_ORDER_FROM = 2ull << 30;
 constexpr uint64_t PHASE_BYTES_DEFAULT = 64ull << 20;    // bytes of image (chunk records + descriptors) per launch phase
 constexpr uint64_t PHASE_BYTES_RICH = 28ull << 20;       // ... of a rich image
-constexpr uint64_t PHASE_BYTES_STAGED = 40ull << 20;  // ... of a rich image whose descriptors are STAGED (stitch_kernels.h) while the reference is at most
+constexpr uint64_t PHASE_BYTES_STAGED = 44ull << 20;  // ... of a rich image whose descriptors are STAGED (stitch_kernels.h) while the reference is at most
 constexpr uint64_t PHASE_STAGED_SMALL_REF = 8ull << 20;   // this long (1 MB per XCD)
 constexpr uint32_t PHASE_MIN_CHUNKS = 16384;            // below this a launch is one phase and is not preceded by a read-ahead
 inline uint64_t xcd_order_block_bytes(uint64_t proteome_len) { const uint64_t b = 8u * proteome_len; return b < (32ull << 20) ? (32ull << 20) : b; }

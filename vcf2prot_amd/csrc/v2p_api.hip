@@ -1990,8 +1990,14 @@ static hipError_t ensure_event(hipEvent_t& e) { return e ? hipSuccess : hipEvent
 // 25: dense rows images are staged as well.
 static hipError_t attach_stage(v2p_batch* b, StitchArgs& a, int hint)
 {
-    // (a padded image is staged; a dense one is read in place -- staging it as well was measured: nothing in the steady state)
-    if (b->ctx->launch_opts.variant == 23u || !(b->pad_image || b->ctx->launch_opts.variant == 25u)) return hipSuccess;
+    // A padded image is staged; so is a dense one that is rich and reads a small reference (the north star's cohort): at the 28 MB phases
+    // its lines need to be found in the caches, staging buys it nothing (7.38 against 7.42 ms), but staged descriptors allow 44 MB
+    // phases -- a third fewer launches, tails and read-ahead hand-overs: C3 whole 7.42 -> 7.23 ms per execute; read in place the image
+    // falls off a cliff there (7.3 ... 7.8 ms at 40-48 MB by run).  C4 whole (56 MB of reference) and C2 (thin: half-filled staging rows)
+    // gain nothing from either and are read in place (tools/stage_probe.py, profiles/r05_staged_steady_state.json).
+    const uint64_t idesc = a.img_desc ? a.img_desc : a.n_desc, ibytes = a.img_bytes ? a.img_bytes : a.out_len;
+    const bool small_rich = image_is_rich(idesc, ibytes) && a.src0_len <= PHASE_STAGED_SMALL_REF;
+    if (b->ctx->launch_opts.variant == 23u || !(b->pad_image || b->ctx->launch_opts.variant == 25u || small_rich)) return hipSuccess;
     const uint32_t rows = stitch_stage_chunks(a, hint);
     if (rows == 0) return hipSuccess;
     const hipError_t e = b->d_stage.ensure(uint64_t(2) * rows * 64u * 8u);
