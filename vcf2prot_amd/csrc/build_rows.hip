@@ -610,6 +610,8 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
     }
 }
 
+__device__ __forceinline__ void rows_chunk_key(const RowsArgs& a, const Chunk& ch, uint64_t k, uint64_t n_desc);
+
 // the padded chunk table of pass 2 -> arena order (seg_base: the scan of the segments' counts): one wave per segment
 __global__ __launch_bounds__(256) void rows_chunk_compact_kernel(RowsArgs a)
 {
@@ -628,17 +630,17 @@ __global__ __launch_bounds__(256) void rows_chunk_compact_kernel(RowsArgs a)
             const uint64_t next = tl + 2u <= a.n_tiles ? a.tile_desc_base[tl + 2u] - a.tile_desc_base[tl + 1u] : 0ull;      // descriptors of the next tile
             if (d1 == 0u || nd > d1 + next) atomicOr(reinterpret_cast<unsigned long long*>(a.totals) + 3, 2ull);
             ch.dst_n = (ch.dst_n & ~CHUNK_N1_MASK) | (nd <= d1 ? 0ull : d1);
+            // ... and, the descriptors of a padded image being where they stay, the chunk's keys for the XCD / window order right here
+            // (a.bucket: set by the caller that wants them; the dense form computes them in rows_keys_kernel, behind the compaction)
+            if (a.bucket) rows_chunk_key(a, ch, b0 + k, a.desc_cap);
         }
         a.chunks_tmp[b0 + k] = ch;
     }
 }
 
-// proteome slice and window of every chunk (order_chunks_for_xcds: the first reference read among its first six descriptors)
-__global__ __launch_bounds__(256) void rows_keys_kernel(RowsArgs a, uint64_t n_chunks, uint64_t n_desc)
+// proteome slice and window of a chunk (order_chunks_for_xcds: the first reference read among its first six descriptors)
+__device__ __forceinline__ void rows_chunk_key(const RowsArgs& a, const Chunk& ch, uint64_t k, uint64_t n_desc)
 {
-    const uint64_t k = uint64_t(blockIdx.x) * 256u + threadIdx.x;
-    if (k >= n_chunks) return;
-    const Chunk ch = a.chunks_tmp[k];
     const uint64_t tb = ch.task_begin & TB_IDX_MASK;
     const uint32_t n = uint32_t(ch.dst_n >> 48) & CHUNK_N_MASK, n1 = a.pad_chunks ? uint32_t(ch.dst_n & CHUNK_N1_MASK) : 0u;
     uint64_t key = 0;
@@ -655,6 +657,12 @@ __global__ __launch_bounds__(256) void rows_keys_kernel(RowsArgs a, uint64_t n_c
     const uint8_t bucket = uint8_t(bk < 8 ? bk : 7);
     a.bucket[k] = bucket;
     a.sub[k] = xcd_sub_window(key, bucket, per);
+}
+__global__ __launch_bounds__(256) void rows_keys_kernel(RowsArgs a, uint64_t n_chunks, uint64_t n_desc)
+{
+    const uint64_t k = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    if (k >= n_chunks) return;
+    rows_chunk_key(a, a.chunks_tmp[k], k, n_desc);
 }
 
 }  // namespace

@@ -2205,6 +2205,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
         // (the chunk table in arena order before the host's one look at the counts: its grid is the segments', and for a padded image it
         // is also where a chunk that does not fit the slot-addressed form is found -- totals[3])
         a.chunks_tmp = chunks_tmp;
+        a.bucket = pad && reorder ? bucket : nullptr; a.sub = pad && reorder ? sub : nullptr;      // (a padded image: the chunks' keys in the same pass)
         if (ns) OS_TRY(launch_rows_chunk_compact(a, B), "launch(chunk table)");
         uint64_t desc_end = desc0, chunk_end = chunk0, totals[4] = {0, 0, 0, 0};
         unsigned long long stw = STATUS_CLEAN;
@@ -2229,7 +2230,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
         if (reorder && nc >= 16 && desc_end != 0) {
             RowsArgs ak = a;
             ak.chunks_tmp = chunks_tmp + chunk0; ak.bucket = bucket + chunk0; ak.sub = sub + chunk0;
-            OS_TRY(launch_rows_keys(ak, nc, pad ? desc_cap : desc_end, B), "launch(keys)");
+            if (!pad) OS_TRY(launch_rows_keys(ak, nc, desc_end, B), "launch(keys)");
             const uint32_t nb = xcd_order_blocks(ns * uint64_t(ROWS_SEG) * ROW_BYTES, c->proteome_len, nc, XCD_ORDER_MAX_BLOCKS, nd);
             OS_TRY(launch_order_blocks(ak.chunks_tmp, ak.bucket, ak.sub, nc, nb, reinterpret_cast<uint32_t*>(sc + s_subhist),
                                        reinterpret_cast<uint64_t*>(sc + s_substart), reinterpret_cast<uint64_t*>(sc + s_subtiles),
