@@ -257,9 +257,14 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
  * What a cohort pays exactly once is the reference's get_g_rep(..).execute(engine) (haplotype_instruction.rs:75-137 -> gir.rs:197-241,
  * personalized_genome.rs:64-65): build a haplotype's executable image, execute it.  v2p_batch_build_on_device + v2p_batch_execute do
  * that in two calls, the stream's H2D inside the first and the two strictly one after the other.  Here the stream is made RESIDENT
- * first (its tables are checked on the host as for v2p_batch_build_on_device, its arrays uploaded once), and ONE call builds the
- * rows image slice by slice on a second HIP stream while the slice before it is already being stitched on the context's stream:
- * the builder's parse is bound by instruction issue, the stitch kernel by its stores. */
+ * first (its tables are checked on the host as for v2p_batch_build_on_device, its arrays uploaded once, res_counter per tile of
+ * transcripts and per haplotype -- haplotype_instruction.rs:90,132 as scans -- made on the device behind the upload), and ONE call
+ * builds the rows image and executes it with no host round trip but one look at the counts in between.  A RICH stream (at most 125
+ * result bytes per Task) builds a PADDED wave image: the descriptors stay in their tiles' slots (no compaction pass), the chunk records
+ * address slots, and the launcher STAGES every phase's descriptors in launch order for the stitch kernel (vcf2prot_amd/csrc/
+ * stitch_kernels.h).  The first v2p_batch_execute / v2p_batch_download_image behind the call makes such an image dense (the skipped
+ * compaction, once): what a host ever sees, and what is executed again, is the image v2p_batch_build_from_stream builds.
+ * (The image can also be built slice by slice while the slice before it is stitched -- n_slices -- which was measured slower.) */
 typedef struct v2p_stream v2p_stream;
 /* the stream's arrays to the device (the host copy may be freed on return); V2P_ERR_INVALID_ARG / _SRC_OOB with the offending index
  * as v2p_batch_build_on_device reports them */
@@ -286,7 +291,8 @@ typedef struct {
     float    build_ms;           /* sum of the slices' build kernels (they overlap the stitch of the slices before: not additive)   */
     double   call_wall_ms;       /* host wall-clock of the call (it returns when the last slice is enqueued)                        */
     float    slice_build_ms[32];
-    float    tables_ms;          /* the global tables in front of the first slice: arena bytes per tile, their scan, haplotype offsets */
+    float    tables_ms;          /* what runs in front of the first slice: the haplotype offsets' copy (the tables are the stream's) -- or, for
+                                  * a stream whose tables do not fit the image kind asked for, arena bytes per tile, their scan, the offsets   */
 } v2p_oneshot_info;
 /* waits for the call's last kernel, then reports its times */
 int  v2p_batch_oneshot_info(v2p_batch* b, v2p_oneshot_info* info);
@@ -306,7 +312,8 @@ int  v2p_batch_reset(v2p_batch* b);
  * v2p_batch_counts reports the segments as descriptors.  For checkers: the raw arrays (1024 / 1024 slots per chunk, the chunk table in
  * launch order; any pointer may be NULL) and the totals. */
 int v2p_batch_download_patch_image(v2p_batch* b, uint64_t* seg, uint32_t* patch, v2p_chunk* chunks, uint64_t* n_segments, uint64_t* n_patches);
-/* the image as it sits on the device (for checkers): sizes first (any pointer may be NULL), then the arrays */
+/* the image as it sits on the device (for checkers): sizes first (any pointer may be NULL), then the arrays.  (A padded image -- see
+ * v2p_batch_build_and_execute -- is made dense first, for good.) */
 int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, uint64_t* hap_out_begin);
 
 /* Adopt an already packed image (descriptors, chunks, payload, haplotype result ranges),
