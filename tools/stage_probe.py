@@ -11,6 +11,7 @@ from vcf2prot_amd.cohort import Cohort
 from vcf2prot_amd.engine import Context
 wl, samples = sys.argv[1], int(sys.argv[2])
 phases = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "28,36,40,44,48").split(",")]
+VARS = [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "23,0").split(",")]     # 23: read in place, 0: the library's rule, 25: staged whatever the rule says
 cohort = Cohort.preset(wl, n_samples=samples)
 n = cohort.n_haplotypes
 stream = cohort.txstream(0, n, n_threads=min(64, os.cpu_count() or 1))
@@ -25,14 +26,14 @@ with Context(0) as ctx:
     res = {}
     for rep in range(5):
         for ph in phases:
-            for var in (23, 0):
+            for var in VARS:
                 ctx.set_launch_opts(variant=var, phase_bytes=ph << 20)
                 b.execute(); b.sync()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3): b.execute()
                 b.sync(); e1.record(); e1.synchronize()
-                res.setdefault(f"{'library' if var == 0 else 'in_place'}_ph{ph}", []).append(e0.elapsed_time(e1) / 3)
+                res.setdefault(f"{ {0: 'library', 23: 'in_place', 25: 'staged'}.get(var, 'v%d' % var) }_ph{ph}", []).append(e0.elapsed_time(e1) / 3)
     ctx.set_launch_opts()
     assert np.array_equal(b.digests(), dig)
     out["ms"] = {k: round(sorted(v)[len(v) // 2], 3) for k, v in res.items()}

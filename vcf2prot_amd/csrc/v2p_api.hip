@@ -1996,7 +1996,9 @@ static hipError_t attach_stage(v2p_batch* b, StitchArgs& a, int hint)
     // falls off a cliff there (7.3 ... 7.8 ms at 40-48 MB by run).  C4 whole (56 MB of reference) and C2 (thin: half-filled staging rows)
     // gain nothing from either and are read in place (tools/stage_probe.py, profiles/r05_staged_steady_state.json).
     const uint64_t idesc = a.img_desc ? a.img_desc : a.n_desc, ibytes = a.img_bytes ? a.img_bytes : a.out_len;
-    const bool small_rich = image_is_rich(idesc, ibytes) && a.src0_len <= PHASE_STAGED_SMALL_REF;
+    // (... and large: what staging buys is FEWER phases; an image of three phases gains nothing from being one of two and pays the copy --
+    // the routing sweep's 1.5 GB images ran 1-3 % slower staged, profiles/r05_routing_sweep.json)
+    const bool small_rich = image_is_rich(idesc, ibytes) && a.src0_len <= PHASE_STAGED_SMALL_REF && 8u * idesc + 16u * uint64_t(a.n_chunks) >= 8u * PHASE_BYTES_RICH;
     if (b->ctx->launch_opts.variant == 23u || !(b->pad_image || b->ctx->launch_opts.variant == 25u || small_rich)) return hipSuccess;
     const uint32_t rows = stitch_stage_chunks(a, hint);
     if (rows == 0) return hipSuccess;
