@@ -341,6 +341,10 @@ int v2p_batch_sync(v2p_batch* b);
 
 int v2p_batch_counts(const v2p_batch* b, uint64_t* n_haps, uint64_t* n_desc, uint64_t* n_chunks,
                      uint64_t* out_bytes, uint64_t* payload_bytes);
+/* in what form the batch's image sits on the device right now (diagnostics, tests): bit 0 = padded wave image (v2p_batch_build_and_execute;
+ * made dense by the next v2p_batch_execute / download), bit 1 = a piece image was built (a dense rows image that is executed again:
+ * vcf2prot_amd/csrc/dense_pieces.h), bit 2 = staging buffers for the phases' descriptors exist */
+int v2p_batch_image_form(const v2p_batch* b);
 /* result range of haplotype h inside the arena */
 int v2p_batch_hap_range(const v2p_batch* b, uint64_t h, uint64_t* begin, uint64_t* len);
 /* copy arena bytes [begin, begin+len) to the host (1 byte per residue) */

@@ -77,6 +77,7 @@ HIP_API = {
     "v2p_batch_finalize": (c_int, [c_void_p]),
     "v2p_batch_execute": (c_int, [c_void_p]),
     "v2p_batch_sync": (c_int, [c_void_p]),
+    "v2p_batch_image_form": (c_int, [c_void_p]),
     "v2p_batch_counts": (c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64),
                                  POINTER(c_uint64), POINTER(c_uint64)]),
     "v2p_batch_hap_range": (c_int, [c_void_p, c_uint64, POINTER(c_uint64), POINTER(c_uint64)]),

@@ -22,8 +22,8 @@ ARCH = "gfx950"
 HIP_LIB = os.path.join(LIBDIR, "libvcf2prot_hip.so")
 COHORT_LIB = os.path.join(LIBDIR, "libv2p_cohort.so")
 
-HIP_SOURCES = ["stitch_kernels.hip", "stitch_wave.hip", "build_kernels.hip", "build_rows.hip", "patch_image.hip", "v2p_api.hip", "decode_kernels.hip", "v2p_decode_api.hip"]
-HIP_DEPS = HIP_SOURCES + ["rows_image.hpp", "build_rows.h", "patch_image.h", "patch_format.hpp", "stitch_kernels.h", "stitch_device.hpp", "build_kernels.h", "decode_kernels.h", "v2p_ctx_internal.h", "sir_pack.hpp",
+HIP_SOURCES = ["stitch_kernels.hip", "stitch_wave.hip", "build_kernels.hip", "build_rows.hip", "patch_image.hip", "dense_pieces.hip", "v2p_api.hip", "decode_kernels.hip", "v2p_decode_api.hip"]
+HIP_DEPS = HIP_SOURCES + ["rows_image.hpp", "build_rows.h", "patch_image.h", "dense_pieces.h", "patch_format.hpp", "stitch_kernels.h", "stitch_device.hpp", "build_kernels.h", "decode_kernels.h", "v2p_ctx_internal.h", "sir_pack.hpp",
                           os.path.join(ROOT, "include", "vcf2prot_hip.h"), os.path.join(ROOT, "include", "v2p_frontend.h")]
 COHORT_SOURCES = ["cohort_gen.cpp", os.path.join("host", "transcript_tasks.cpp"), os.path.join("host", "vcf_index.cpp"),
                   os.path.join("host", "group_muts.cpp"), os.path.join("host", "instructions.cpp")]

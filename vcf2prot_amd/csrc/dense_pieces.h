@@ -1,0 +1,51 @@
+// dense_pieces.h -- PIECE images: a dense rows image (sir_pack.hpp: chunks of up to 1 024 descriptors and twelve 1 KiB rows, C5's deep Task
+// vectors) re-written for RE-execution as a list of PIECES -- at most sixteen result bytes from one source each, position inside the
+// chunk and at most one substituted residue included -- so that the executor (stitch_pieces_kernel) has nothing to decode, nothing to
+// scan and no list of continuation pieces to build: lane = piece, one record load, one gather, one put into the chunk's LDS image.
+// Built on the device from the image a batch already holds, the first time the batch is executed AGAIN (v2p_api.hip: to_pieces);
+// a cohort that is executed once never pays for it.  Semantics: task.rs:38-50 for every descriptor of the image, unchanged.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sir_pack.hpp"
+
+namespace v2p {
+
+// a piece (8 bytes): src:29 | space:2 | offset inside the chunk's result:14 | bytes - 1:5 | position of the substituted residue:5 | has one:1 | its byte:8
+// -- up to 16 result bytes of one source (one gather, one put), at most one substituted residue.  (The fields take 32: pieces of up to 32
+// bytes -- a second gather and put for the lanes that have them -- were measured: 0.94 ms against 0.73 for C5, the wave runs both puts.)
+// (space 3, an immediate: bits 0..28 and 50..63 ARE the bytes -- up to five, first byte lowest)
+constexpr uint32_t PIECE_SRC_BITS = 29;
+constexpr uint32_t PIECE_BYTES = 16;
+constexpr uint64_t PIECE_SRC_MAX = (1ull << PIECE_SRC_BITS) - 1;   // sources beyond it: the image is not converted (the dense kernel keeps executing it)
+constexpr uint32_t PIECE_CHUNK_MAX = 2047;                       // pieces per chunk (count field of the chunk record: 11 bits)
+// chunk record: task_begin = first piece : 40 | bytes of the chunk : 14 << 40;  dst_n = result offset : 48 | pieces : 11 << 48 | CHUNK_DENSE | CHUNK_CLIP
+
+struct PieceBuildArgs {
+    const uint64_t* desc;            // the dense rows image
+    uint64_t        n_desc;
+    const Chunk*    chunks;          // in launch order (kept)
+    uint32_t        n_chunks;
+    uint64_t        src0_len, src1_len, out_len;
+    uint32_t*       count;           // [n_chunks] pieces of every chunk (pass 0) -> scan -> base
+    const uint64_t* base;            // [n_chunks + 1]
+    uint64_t*       pieces;          // pass 1
+    Chunk*          chunks2;         // pass 1
+    unsigned long long* status;      // ~0: clean; else index << 8 | reason (a descriptor the dense kernel would refuse, a chunk too large)
+};
+// pass 0: count (and validate); pass 1: write pieces and chunk records
+hipError_t launch_pieces_build(const PieceBuildArgs& a, int pass, hipStream_t stream);
+
+struct PieceExecArgs {
+    const uint64_t* pieces;
+    const Chunk*    chunks2;
+    uint32_t        n_chunks;
+    const uint8_t*  src0;            // 32 readable bytes before and after (as for every stitch kernel)
+    const uint8_t*  src1;
+    uint8_t*        out;
+    uint64_t        out_len;
+};
+hipError_t launch_stitch_pieces(const PieceExecArgs& a, hipStream_t stream, bool nontemporal);
+hipError_t preload_dense_pieces(hipStream_t stream);
+
+}  // namespace v2p

@@ -22,6 +22,7 @@
 #include "stitch_kernels.h"
 #include "build_kernels.h"
 #include "build_rows.h"
+#include "dense_pieces.h"
 #include "patch_image.h"
 #include "v2p_ctx_internal.h"
 
@@ -159,6 +160,10 @@ struct v2p_batch {
     // v2p_batch_build_and_execute: tables that outlive the call so that a batch that is rebuilt recycles them, the slices' chunk ranges
     // and the events of the last call (read by v2p_batch_oneshot_info after a sync)
     DevBuf d_tiles, d_cover, d_pad, d_order;
+    DevBuf d_pieces, d_chunks2;    // PIECE image (dense_pieces.h): what a dense rows image is executed from when it is executed AGAIN
+    bool executed = false;         // the image has been executed at least once (the one call, or a v2p_batch_execute): the NEXT execute is a re-execute
+    uint64_t n_pieces = 0;
+    int pieces_state = 0;          // 0: not tried; 1: built (d_pieces / d_chunks2 describe the batch's image); -1: the image is not converted (kept on the dense kernel)
     DevBuf d_stage;                // STAGED descriptors (stitch_kernels.h): two buffers of a phase's chunks x 64 slots, filled by the read-ahead
     // a PADDED wave image (sir_pack.hpp; what the one call leaves behind): d_desc holds ROWS_TILE_SLOTS slots per tile, the chunk records
     // address its slots; desc_slots = its size (the kernels' bound), n_desc the descriptors it holds; pad_tdbase = the scan of the tiles'
@@ -254,6 +259,7 @@ int v2p_init(int device_ordinal, unsigned flags, v2p_ctx** out)
             if (le == hipSuccess) le = preload_build_kernels(c->own_stream);
             if (le == hipSuccess) le = preload_build_rows(c->own_stream);
             if (le == hipSuccess) le = preload_patch_image(c->own_stream);
+            if (le == hipSuccess) le = preload_dense_pieces(c->own_stream);
             if (le == hipSuccess) le = hipStreamSynchronize(c->own_stream);
             if (le != hipSuccess) {
                 g_init_error = std::string("loading the kernels' code objects: ") + hipGetErrorString(le);
@@ -987,7 +993,7 @@ void v2p_batch_destroy(v2p_batch* b)
     (void)hipStreamSynchronize(b->ctx->stream);
     b->d_desc.release(); b->d_chunks.release(); b->d_payload.release(); b->d_out.release();
     b->d_hap.release(); b->d_digest.release(); b->d_status.release(); b->d_build.release();
-    b->d_tiles.release(); b->d_cover.release(); b->d_pad.release(); b->d_order.release(); b->d_patch.release(); b->d_stage.release();
+    b->d_tiles.release(); b->d_cover.release(); b->d_pad.release(); b->d_order.release(); b->d_patch.release(); b->d_stage.release(); b->d_pieces.release(); b->d_chunks2.release();
     if (b->ctx->build_stream) (void)hipStreamSynchronize(b->ctx->build_stream);
     if (b->ctx->aux_stream) (void)hipStreamSynchronize(b->ctx->aux_stream);
     for (hipEvent_t e : b->ev_os) if (e) (void)hipEventDestroy(e);
@@ -1939,7 +1945,7 @@ int v2p_batch_reset(v2p_batch* b)
     b->finalized = false; b->uses_proteome = false; b->hap_open = false;
     b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0;
     b->payload_dev = nullptr; b->n_slices = 0; b->launch_hint = 0; b->is_patch = false; b->patch_segs = b->patch_patches = 0;
-    b->pad_image = false; b->desc_slots = 0; b->pad_tdbase = nullptr;
+    b->pad_image = false; b->desc_slots = 0; b->pad_tdbase = nullptr; b->pieces_state = 0; b->executed = false;
     if (b->desc_swapped) { std::swap(b->d_desc, b->d_pad); b->desc_swapped = false; }     // (the large allocation is the padded array's again)
     return V2P_OK;
 }
@@ -2308,6 +2314,7 @@ int v2p_batch_build_and_execute(v2p_batch* b, const v2p_stream* st, int kernel, 
         }
     }
     if (rc == V2P_OK) {
+        b->executed = true;
         b->os_kernel = mode == ROWS_DENSE ? 7 : 6;
         b->os_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
@@ -2456,6 +2463,51 @@ int v2p_batch_finalize(v2p_batch* b)
     return V2P_OK;
 }
 
+// A dense rows image (every chunk a dense chunk on a 1 KiB row: launch_hint bits 1, 3, 4, 5 and not 2) that is executed AGAIN is
+// re-written as pieces first (dense_pieces.h), once; an image the form does not take (sources beyond 2 GiB, a descriptor the dense
+// kernel would refuse and report) stays on the dense kernel.  v2p_set_launch_opts variant 28 (A/B): never.
+static bool pieces_eligible(const v2p_batch* b)
+{
+    const int h = b->launch_hint;
+    return b->finalized && !b->is_patch && (h & 2) && (h & 8) && !(h & 4) && (h & 16) && (h & 32) && b->n_chunks != 0 && b->ctx->launch_opts.variant != 28u &&
+           b->ctx->launch_opts.variant != 3u && b->ctx->launch_opts.variant != 8u;
+}
+static int to_pieces(v2p_batch* b)
+{
+    v2p_ctx* c = b->ctx;
+    if (b->pieces_state != 0) return V2P_OK;
+    b->pieces_state = -1;
+    DevBuf cnt, basebuf, scratch, st;
+    struct Rel { DevBuf& a; DevBuf& b; DevBuf& c; DevBuf& d; ~Rel() { a.release(); b.release(); c.release(); d.release(); } } rel{cnt, basebuf, scratch, st};
+    const uint64_t nc = b->n_chunks;
+    HIP_TRY(c, cnt.ensure_exact((nc + 1) * 4), "hipMalloc(piece counts)");
+    HIP_TRY(c, basebuf.ensure_exact((nc + 2) * 8), "hipMalloc(piece bases)");
+    HIP_TRY(c, scratch.ensure_exact(scan_tiles_for(nc + 1) * 8 + 64), "hipMalloc(scan scratch)");
+    HIP_TRY(c, st.ensure_exact(8), "hipMalloc(status)");
+    HIP_TRY(c, hipMemsetAsync(st.ptr(), 0xFF, 8, c->stream), "hipMemset(status)");
+    PieceBuildArgs a{};
+    a.desc = reinterpret_cast<const uint64_t*>(b->d_desc.ptr()); a.n_desc = b->n_desc;
+    a.chunks = reinterpret_cast<const Chunk*>(b->d_chunks.ptr()); a.n_chunks = uint32_t(nc);
+    a.src0_len = c->proteome_len + c->headers_len; a.src1_len = b->n_payload; a.out_len = b->out_bytes;
+    a.count = reinterpret_cast<uint32_t*>(cnt.ptr()); a.base = reinterpret_cast<const uint64_t*>(basebuf.ptr());
+    a.status = reinterpret_cast<unsigned long long*>(st.ptr());
+    HIP_TRY(c, launch_pieces_build(a, 0, c->stream), "launch(pieces: count)");
+    HIP_TRY(c, launch_scan_u32(a.count, nc, const_cast<uint64_t*>(a.base), reinterpret_cast<uint64_t*>(scratch.ptr()), c->stream), "launch(scan)");
+    uint64_t total = 0;
+    unsigned long long stw = ~0ull;
+    HIP_TRY(c, hipMemcpyAsync(&total, basebuf.ptr() + nc * 8, 8, hipMemcpyDeviceToHost, c->stream), "D2H(pieces)");
+    HIP_TRY(c, hipMemcpyAsync(&stw, st.ptr(), 8, hipMemcpyDeviceToHost, c->stream), "D2H(status)");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    if (stw != ~0ull || total == 0 || total >= (1ull << 40)) return V2P_OK;            // (not converted: the dense kernel executes the image, and reports what it refuses)
+    if (b->d_pieces.ensure(total * 8) != hipSuccess || b->d_chunks2.ensure(nc * sizeof(Chunk)) != hipSuccess) { (void)hipGetLastError(); return V2P_OK; }
+    b->n_pieces = total;
+    a.pieces = reinterpret_cast<uint64_t*>(b->d_pieces.ptr()); a.chunks2 = reinterpret_cast<Chunk*>(b->d_chunks2.ptr());
+    HIP_TRY(c, launch_pieces_build(a, 1, c->stream), "launch(pieces: write)");
+    HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");                 // (the scratch above is released on return)
+    b->pieces_state = 1;
+    return V2P_OK;
+}
+
 int v2p_batch_execute(v2p_batch* b)
 {
     if (!b) return V2P_ERR_INVALID_ARG;
@@ -2470,6 +2522,15 @@ int v2p_batch_execute(v2p_batch* b)
     }
     // (variants 23 / 26, A/B: a padded image stays padded -- read in place / staged)
     if (b->pad_image && c->launch_opts.variant != 23u && c->launch_opts.variant != 26u) { const int rc = densify(b); if (rc) return rc; }
+    if (pieces_eligible(b) && b->executed) {
+        if (b->pieces_state == 0) { const int rc = to_pieces(b); if (rc) return rc; }
+        if (b->pieces_state == 1) {
+            PieceExecArgs pa{reinterpret_cast<const uint64_t*>(b->d_pieces.ptr()), reinterpret_cast<const Chunk*>(b->d_chunks2.ptr()), uint32_t(b->n_chunks),
+                             c->proteome.ptr(), b->payload_dev, b->d_out.ptr(), b->out_bytes};
+            HIP_TRY(c, launch_stitch_pieces(pa, c->stream, !(c->flags & V2P_FLAG_TEMPORAL)), "launch(stitch: pieces)");
+            return V2P_OK;
+        }
+    }
     StitchArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), b->pad_image ? b->desc_slots : b->n_desc, reinterpret_cast<const Chunk*>(b->d_chunks.ptr()),
                  uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->payload_dev, b->n_payload,
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
@@ -2480,6 +2541,7 @@ int v2p_batch_execute(v2p_batch* b)
     const int hint = int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint;
     (void)attach_stage(b, a, hint);
     HIP_TRY(c, launch_stitch(a, c->stream, hint, 0), "launch(stitch)");
+    b->executed = true;
     return V2P_OK;
 }
 
@@ -2507,6 +2569,13 @@ int v2p_batch_counts(const v2p_batch* b, uint64_t* n_haps, uint64_t* n_desc, uin
     if (out_bytes) *out_bytes = f ? b->out_bytes : b->img.out_size();
     if (payload_bytes) *payload_bytes = f ? b->n_payload : b->img.payload.size();
     return V2P_OK;
+}
+
+int v2p_batch_image_form(const v2p_batch* b)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(b->ctx->mu);
+    return (b->pad_image ? 1 : 0) | (b->pieces_state == 1 ? 2 : 0) | (b->d_stage.ptr() ? 4 : 0);
 }
 
 int v2p_batch_hap_range(const v2p_batch* b, uint64_t h, uint64_t* begin, uint64_t* len)

@@ -344,6 +344,13 @@ class Batch:
         self.ctx._check(self._lib.v2p_batch_build_and_execute(self._h, rs._h, kernel, n_slices))
         self._stream_ref = rs
 
+    def image_form(self) -> dict:
+        """v2p_batch_image_form: how the image sits on the device right now."""
+        f = self._lib.v2p_batch_image_form(self._h)
+        if f < 0:
+            self.ctx._check(f)
+        return {"padded": bool(f & 1), "pieces": bool(f & 2), "staging_buffers": bool(f & 4)}
+
     def oneshot_info(self) -> dict:
         info = N.OneShotInfo()
         self.ctx._check(self._lib.v2p_batch_oneshot_info(self._h, ctypes.byref(info)))
