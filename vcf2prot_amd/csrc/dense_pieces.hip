@@ -16,6 +16,8 @@
 // Measured (C5, 20 000 haplotypes; tools/pieces_probe.py, profiles/r05_pieces.txt): 0.73 ms against the dense kernel's 0.83-0.85, half its
 // vector instructions (255 M against 465 M) -- the piece kernel is no longer bound by them (58 % busy) but by the memory system: its
 // record stream (1.1 GB, cold reads) runs into its own 1.6 GB of result stores, DESIGN.md section 3's effect, at 3.8 TB/s together.
+// (Phases with the next phase's records read ahead on trailing workgroups, what wave images gain a third from, cost this one: 1.03 ms
+// with 256 MB phases, 1.24 with 16 MB, against 0.77 in one launch -- a read-ahead workgroup per chunk is as many workgroups again.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
