@@ -326,7 +326,7 @@ def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verif
         one["frac_physical"] = one_bytes / (one["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         one["frac_physical_gpu_busy_before"] = one_bytes / (one["total_ms_gpu_busy_before"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         res.update({"descriptors": int(desc.size), "chunks": int(chunks.shape[0]), "fused_substitution_descriptors": n_fused, "immediate_descriptors": n_imm,
-                    "kernel": "stitchw_kernel (rows image)" if i1["kernel"] == 6 else "stitch_dense_kernel (rows image)",
+                    "kernel": "stitchw_kernel (rows image)" if i1["kernel"] == 6 else "stitch_pieces_kernel (a dense rows image, re-written as <= 16-byte pieces at its first re-execute; its first execute: stitch_dense_kernel)",
                     "hbm_bytes_min_per_launch": hbm_min, "algorithmic_bytes_per_launch": 2 * A + 16 * NT, "one_shot": one})
         del desc, chunks
         t = Timed(ctx, b)
