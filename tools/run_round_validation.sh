@@ -1,7 +1,17 @@
-# Run on the GPU box (gpurun): the round's validation -- rocprofv3 stats + PMC traffic of the headline bench command (C3 whole), the
-# build profile per workload, the default bench line.  Outputs under gpurun_out/profiles_r04/; the summaries are copied to profiles/ by hand.
-mkdir -p gpurun_out/profiles_r04
-cp profiles/traffic_latest.json gpurun_out/profiles_r04/ 2>/dev/null
-timeout 1800 bash tools/profile_round.sh r04_C3whole > gpurun_out/profiles_r04/prof_C3whole.txt 2>&1
-SKIP_CEILING=1 timeout 900 bash tools/profile_round.sh r04_C2 --workload C2 > gpurun_out/profiles_r04/prof_C2.txt 2>&1
-timeout 1500 python bench.py > gpurun_out/profiles_r04/r04_bench_default_line.json 2> gpurun_out/profiles_r04/bench_default.err; echo "bench rc=$?"
+# Run on the GPU box (gpurun): the round's validation -- the GPU test suite and smoke(), rocprofv3 stats + PMC traffic of the headline bench
+# command (C3 whole) and of C4 whole / C5 / C2, the decode profile, the default bench line.  Outputs under gpurun_out/profiles_r05/ (and
+# gpurun_out/prof_*); the summaries are copied to profiles/ by hand.
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out/profiles_r05
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/profiles_r05/pytest_gpu.log 2>&1; tail -3 gpurun_out/profiles_r05/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+cp profiles/traffic_latest.json gpurun_out/profiles_r05/ 2>/dev/null
+bash tools/profile_round.sh r05_C3whole > gpurun_out/profile_C3whole.log 2>&1; tail -3 gpurun_out/profile_C3whole.log
+SKIP_CEILING=1 bash tools/profile_round.sh r05_C4whole --workload C4 --samples 2504 > gpurun_out/profile_C4whole.log 2>&1
+SKIP_CEILING=1 bash tools/profile_round.sh r05_C5 --workload C5 --samples 10000 > gpurun_out/profile_C5.log 2>&1
+SKIP_CEILING=1 bash tools/profile_round.sh r05_C2 --workload C2 --samples 1000 > gpurun_out/profile_C2.log 2>&1
+bash tools/profile_decode.sh > gpurun_out/profile_decode.log 2>&1
+timeout 1500 python bench.py > gpurun_out/profiles_r05/r05_bench_default_line.json 2> gpurun_out/profiles_r05/bench_default.err; echo "bench rc=$?"
