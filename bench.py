@@ -370,6 +370,14 @@ def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verif
         timed = Timed(ctx, hbatch) if time_host_image else t
         elapsed, kern_ms = timed.run(steps, warmup, barrier)
         res.update({"elapsed_s": elapsed, "kernel_ms": kern_ms, "image_timed": "host-packed" if time_host_image else "device-built"})
+        # ---- parity AFTER timing: the timed steps re-execute the image in its re-execution form (a padded image made dense, its descriptors
+        # staged; a dense image from its pieces) -- the arena they leave must be the one that was verified above
+        if not time_host_image:
+            after = b.digests()
+            if not np.array_equal(after, dig):
+                raise RuntimeError(f"PARITY FAILURE: the arena after the timed steps differs from the verified one ({int((after != dig).sum())} haplotypes of {workload})")
+            res["digests_equal_after_timed_steps"] = True
+            res["image_form_timed"] = b.image_form()
         if hbatch is not None:
             hbatch.close()
         b.close()
@@ -558,7 +566,7 @@ def main():
             "kernel_only_aa_per_s_rank0": A / (avg_ms * 1e-3),
             "verified": leg["verified"], "stream_generation_s": leg.get("stream_generation_s"),
         }
-        for k in ("one_shot", "host_packed"):
+        for k in ("one_shot", "host_packed", "digests_equal_after_timed_steps", "image_form_timed"):
             if k in leg:
                 line[k] = leg[k]
         if per_rank:
