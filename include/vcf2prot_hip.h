@@ -334,7 +334,12 @@ int v2p_batch_set_packed(v2p_batch* b,
 
 /* Cut the image into chunks (if built by add_*) and move it to the device. */
 int v2p_batch_finalize(v2p_batch* b);
-/* Enqueue one pass of the SIR executor over the whole batch on the ctx stream (asynchronous). */
+/* Enqueue one pass of the SIR executor over the whole batch on the ctx stream (asynchronous).
+ * The first call that executes an image AGAIN may first bring it into its re-execution form, once: a padded wave image (what
+ * v2p_batch_build_and_execute leaves behind for a rich stream) is made dense -- one copy kernel, enqueued, and an allocation of 8 bytes
+ * per descriptor -- and a dense rows image (deep Task vectors) is re-written as pieces (vcf2prot_amd/csrc/dense_pieces.h): two kernels,
+ * an allocation of about 11 bytes per descriptor and ONE wait for the stream in between (that call is not asynchronous: 1.5-2.5 ms for
+ * 10^8 descriptors).  Results are the same bytes in every form. */
 int v2p_batch_execute(v2p_batch* b);
 /* Wait for the stream and collect the device status word; task errors surface here. */
 int v2p_batch_sync(v2p_batch* b);
