@@ -11,13 +11,13 @@
 
 namespace v2p {
 
-// a piece (8 bytes): src:29 | space:2 | offset inside the chunk's result:14 | bytes - 1:5 | position of the substituted residue:5 | has one:1 | its byte:8
-// -- up to 16 result bytes of one source (one gather, one put), at most one substituted residue.  (The fields take 32: pieces of up to 32
-// bytes -- a second gather and put for the lanes that have them -- were measured: 0.94 ms against 0.73 for C5, the wave runs both puts.)
-// (space 3, an immediate: bits 0..28 and 50..63 ARE the bytes -- up to five, first byte lowest)
-constexpr uint32_t PIECE_SRC_BITS = 29;
+// a piece (8 bytes): src:31 | space:2 | offset inside the chunk's result:14 | bytes - 1:4 | position of the substituted residue:4 | has one:1 | its byte:8
+// -- up to 16 result bytes of one source (one gather, one put), at most one substituted residue.  (Pieces of up to 32 bytes -- a second
+// gather and put for the lanes that have them -- were measured: 0.94 ms against 0.73 for C5, the wave runs both puts.)
+// (space 3, an immediate: bits 0..30 and 51..63 ARE the bytes -- up to five, first byte lowest)
+constexpr uint32_t PIECE_SRC_BITS = 31;
 constexpr uint32_t PIECE_BYTES = 16;
-constexpr uint64_t PIECE_SRC_MAX = (1ull << PIECE_SRC_BITS) - 1;   // sources beyond it: the image is not converted (the dense kernel keeps executing it)
+constexpr uint64_t PIECE_SRC_MAX = (1ull << PIECE_SRC_BITS) - 1;   // sources beyond 2 GiB: the image is not converted (the dense kernel keeps executing it)
 constexpr uint32_t PIECE_CHUNK_MAX = 2047;                       // pieces per chunk (count field of the chunk record: 11 bits)
 // chunk record: task_begin = first piece : 40 | bytes of the chunk : 14 << 40;  dst_n = result offset : 48 | pieces : 11 << 48 | CHUNK_DENSE | CHUNK_CLIP
 

@@ -73,10 +73,10 @@ __device__ __forceinline__ Dec decode_desc(uint64_t d, uint32_t hs, uint32_t tcl
 
 __device__ __forceinline__ uint64_t pack_piece(uint32_t space, uint64_t src, uint32_t dst, uint32_t len, bool lit, uint32_t litpos, uint32_t byte)
 {
-    // bits: 0..28 src | 29..30 space | 31..44 dst | 45..49 len - 1 | 50..54 litpos | 55 has | 56..63 byte
-    if (space == SPACE_IMM)          // up to five bytes: bits 0..28 and 50..63 hold them
-        return (src & PIECE_SRC_MAX) | (uint64_t(SPACE_IMM) << 29) | (uint64_t(dst) << 31) | (uint64_t(len - 1u) << 45) | ((src >> 29) << 50);
-    return (src & PIECE_SRC_MAX) | (uint64_t(space) << 29) | (uint64_t(dst) << 31) | (uint64_t(len - 1u) << 45) | (uint64_t(litpos & 31u) << 50) |
+    // bits: 0..30 src | 31..32 space | 33..46 dst | 47..50 len - 1 | 51..54 litpos | 55 has | 56..63 byte
+    if (space == SPACE_IMM)          // up to five bytes: bits 0..30 and 51..63 hold them
+        return (src & PIECE_SRC_MAX) | (uint64_t(SPACE_IMM) << 31) | (uint64_t(dst) << 33) | (uint64_t(len - 1u) << 47) | ((src >> 31) << 51);
+    return (src & PIECE_SRC_MAX) | (uint64_t(space) << 31) | (uint64_t(dst) << 33) | (uint64_t(len - 1u) << 47) | (uint64_t(litpos & 15u) << 51) |
            (uint64_t(lit ? 1u : 0u) << 55) | (uint64_t(byte & 0xFFu) << 56);
 }
 
@@ -223,9 +223,9 @@ __global__ __launch_bounds__(256) void stitch_pieces_kernel(PieceExecArgs a)
     // round j's put runs behind round j + 1's gather
     auto fetch = [&](uint64_t r) -> u32x4 {
         const uint32_t lo = uint32_t(r);
-        const uint32_t space = (lo >> 29) & 3u;
+        const uint32_t space = uint32_t(r >> 31) & 3u;
         const bool mem = space == SPACE_PROTEOME || space == SPACE_PAYLOAD;
-        return gather16(reinterpret_cast<uint64_t>(space == SPACE_PAYLOAD ? a.src1 : a.src0) + (mem ? (lo & 0x1FFFFFFFu) : 0u));   // (fills, immediates, idle lanes: the proteome's first bytes, dropped)
+        return gather16(reinterpret_cast<uint64_t>(space == SPACE_PAYLOAD ? a.src1 : a.src0) + (mem ? (lo & 0x7FFFFFFFu) : 0u));   // (fills, immediates, idle lanes: the proteome's first bytes, dropped)
     };
     u32x4 g = fetch(rec[0]);
 #pragma unroll
@@ -236,14 +236,14 @@ __global__ __launch_bounds__(256) void stitch_pieces_kernel(PieceExecArgs a)
         const uint32_t k = tid + 256u * j;
         const uint64_t cur = rec[j];
         const uint32_t lo = uint32_t(cur), hi = uint32_t(cur >> 32);
-        const uint32_t space = (lo >> 29) & 3u;
-        const uint32_t o = uint32_t(cur >> 31) & 0x3FFFu, len = ((hi >> 13) & 31u) + 1u;
+        const uint32_t space = uint32_t(cur >> 31) & 3u;
+        const uint32_t o = (hi >> 1) & 0x3FFFu, len = ((hi >> 15) & 15u) + 1u;
         if (space == SPACE_FILL) g0 = u32x4{0x2E2E2E2Eu, 0x2E2E2E2Eu, 0x2E2E2E2Eu, 0x2E2E2E2Eu};
         if (space == SPACE_IMM) {
-            const uint64_t v = uint64_t(lo & 0x1FFFFFFFu) | ((cur >> 50) << 29);
+            const uint64_t v = uint64_t(lo & 0x7FFFFFFFu) | ((cur >> 51) << 31);
             g0 = u32x4{uint32_t(v), uint32_t(v >> 32), 0u, 0u};
         } else if ((hi >> 23) & 1u) {                                            // the substituted residue of a fused descriptor
-            const uint32_t q = (hi >> 18) & 31u, byte = hi >> 24;
+            const uint32_t q = (hi >> 19) & 15u, byte = hi >> 24;
             const uint32_t sh = 8u * (q & 3u), m = 0xFFu << sh, bv = byte << sh, w = q >> 2;
             g0[0] = w == 0u ? (g0[0] & ~m) | bv : g0[0];
             g0[1] = w == 1u ? (g0[1] & ~m) | bv : g0[1];
