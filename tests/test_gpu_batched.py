@@ -62,7 +62,28 @@ def test_c3_whole_cohort_on_one_gpu_every_haplotype_by_digest(built, gpu_ctx, co
     db.execute()
     db.sync()
     dig_dev = db.digests()
+    db.execute()                                             # executed again: descriptors staged by the read-ahead, 44 MB phases (round 5)
+    db.sync()
+    assert np.array_equal(db.digests(), dig_dev) and db.image_form()["staging_buffers"]
     db.close()
+    # ... and the ONE call of round 5 (v2p_stream_upload + v2p_batch_build_and_execute): the image stays PADDED, its first execute reads
+    # staged descriptors; the first re-execute makes it dense -- every form must leave the arena the two-call builder's image leaves
+    stream = c.txstream(0, n, n_threads=threads)
+    rs = gpu_ctx.upload_stream(stream)
+    stream.close()
+    ob = gpu_ctx.batch()
+    ob.build_and_execute(rs, 0, 0)
+    ob.sync()
+    form = ob.image_form()
+    assert form["padded"] and form["staging_buffers"], form
+    assert np.array_equal(ob.digests(), dig_dev), "the one call's padded, staged image"
+    ob.execute()
+    ob.sync()
+    assert not ob.image_form()["padded"] and np.array_equal(ob.digests(), dig_dev), "the one call's image, made dense and executed again"
+    _, _, hb1 = ob.download_image()
+    assert np.array_equal(hb1, hb) and ob.counts() == cn
+    ob.close()
+    rs.close()
     # the host packer's image
     img = c.pack(0, n, n_threads=threads)
     assert img.out_bytes > 35 * 10 ** 9
