@@ -2369,7 +2369,11 @@ static int densify(v2p_batch* b)
 {
     v2p_ctx* c = b->ctx;
     if (!b->pad_image) return V2P_OK;
-    HIP_TRY(c, b->d_pad.ensure((b->n_desc ? b->n_desc : 1) * 8), "hipMalloc(dense descriptors)");
+    {   // (no room for the dense copy: the image stays padded -- it executes in that form too, its descriptors staged)
+        const hipError_t me = b->d_pad.ensure((b->n_desc ? b->n_desc : 1) * 8);
+        if (me == hipErrorOutOfMemory) { (void)hipGetLastError(); return V2P_OK; }
+        HIP_TRY(c, me, "hipMalloc(dense descriptors)");
+    }
     if (b->n_desc) {
         RowsArgs a{};
         a.n_tiles = b->pad_n_tiles; a.K = b->pad_K; a.tile0 = 0; a.tile1 = b->pad_n_tiles;
@@ -2393,6 +2397,7 @@ int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, ui
     if (b->is_patch && desc) return c->fail(V2P_ERR_STATE, "a patch image has segments and patches, not descriptors: v2p_batch_download_patch_image");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     if (b->pad_image) { const int rc = densify(b); if (rc) return rc; }       // (a padded image leaves the device in the dense form)
+    if (b->pad_image) return c->fail(V2P_ERR_HIP, "no device memory for the dense copy of a padded image");
     if (desc && b->n_desc) HIP_TRY(c, hipMemcpyAsync(desc, b->d_desc.ptr(), b->n_desc * 8, hipMemcpyDeviceToHost, c->stream), "D2H(desc)");
     if (chunks && b->n_chunks) HIP_TRY(c, hipMemcpyAsync(chunks, b->d_chunks.ptr(), b->n_chunks * sizeof(Chunk), hipMemcpyDeviceToHost, c->stream), "D2H(chunks)");
     if (hap_out_begin) HIP_TRY(c, hipMemcpyAsync(hap_out_begin, b->d_hap.ptr(), (b->n_haps + 1) * 8, hipMemcpyDeviceToHost, c->stream), "D2H(hap_begin)");
@@ -2480,10 +2485,9 @@ static int to_pieces(v2p_batch* b)
     DevBuf cnt, basebuf, scratch, st;
     struct Rel { DevBuf& a; DevBuf& b; DevBuf& c; DevBuf& d; ~Rel() { a.release(); b.release(); c.release(); d.release(); } } rel{cnt, basebuf, scratch, st};
     const uint64_t nc = b->n_chunks;
-    HIP_TRY(c, cnt.ensure_exact((nc + 1) * 4), "hipMalloc(piece counts)");
-    HIP_TRY(c, basebuf.ensure_exact((nc + 2) * 8), "hipMalloc(piece bases)");
-    HIP_TRY(c, scratch.ensure_exact(scan_tiles_for(nc + 1) * 8 + 64), "hipMalloc(scan scratch)");
-    HIP_TRY(c, st.ensure_exact(8), "hipMalloc(status)");
+    // (no room for the conversion's scratch: not converted -- the dense kernel goes on executing the image)
+    if (cnt.ensure_exact((nc + 1) * 4) != hipSuccess || basebuf.ensure_exact((nc + 2) * 8) != hipSuccess ||
+        scratch.ensure_exact(scan_tiles_for(nc + 1) * 8 + 64) != hipSuccess || st.ensure_exact(8) != hipSuccess) { (void)hipGetLastError(); return V2P_OK; }
     HIP_TRY(c, hipMemsetAsync(st.ptr(), 0xFF, 8, c->stream), "hipMemset(status)");
     PieceBuildArgs a{};
     a.desc = reinterpret_cast<const uint64_t*>(b->d_desc.ptr()); a.n_desc = b->n_desc;
