@@ -88,5 +88,7 @@ hipError_t launch_rows_chunk_compact(const RowsArgs& a, hipStream_t stream);
 // a padded image's chunk records -> the dense image's (v2p_batch_download_image)
 hipError_t launch_rows_chunks_dense(const Chunk* in, uint64_t n, const uint64_t* tile_desc_base, Chunk* out, hipStream_t stream);
 hipError_t launch_rows_keys(const RowsArgs& a, uint64_t n_chunks, uint64_t n_desc, hipStream_t stream);
+// totals[4..6] = *desc_end (null: 0), *chunk_end (null: 0), *status: what the host reads once per slice, in one block
+hipError_t launch_rows_summary(const uint64_t* desc_end, const uint64_t* chunk_end, const unsigned long long* status, uint64_t* totals, hipStream_t stream);
 
 }  // namespace v2p

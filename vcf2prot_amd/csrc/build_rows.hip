@@ -748,6 +748,20 @@ hipError_t launch_rows_chunk_compact(const RowsArgs& a0, hipStream_t stream)
     return hipGetLastError();
 }
 
+// what the host looks at once per slice, gathered into the totals block: [4] descriptors up to the slice's last tile, [5] chunks up to
+// its last segment, [6] the status word -- one 64-byte copy instead of four round trips (the GPU waits for the host there)
+__global__ void rows_summary_kernel(const uint64_t* desc_end, const uint64_t* chunk_end, const unsigned long long* status, uint64_t* totals)
+{
+    totals[4] = desc_end ? *desc_end : 0ull;
+    totals[5] = chunk_end ? *chunk_end : 0ull;
+    totals[6] = *status;
+}
+hipError_t launch_rows_summary(const uint64_t* desc_end, const uint64_t* chunk_end, const unsigned long long* status, uint64_t* totals, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rows_summary_kernel, dim3(1), dim3(1), 0, stream, desc_end, chunk_end, status, totals);
+    return hipGetLastError();
+}
+
 hipError_t launch_rows_keys(const RowsArgs& a, uint64_t n_chunks, uint64_t n_desc, hipStream_t stream)
 {
     if (n_chunks == 0) return hipSuccess;
