@@ -655,17 +655,32 @@ __global__ __launch_bounds__(256) void sub_scatter_seg_kernel(const Chunk* __res
                                                               uint64_t n, uint32_t nb, uint32_t tbmax, const uint64_t* __restrict__ start,
                                                               Chunk* __restrict__ out, uint8_t* __restrict__ out_bucket)
 {
-    __shared__ uint8_t s_sub[256];
+    // (rank among the thread block's earlier entries of the same window -- stable: the lanes of a wave that hold the same window find
+    // each other with eight ballots, a wave's count per window goes through LDS.  The loop over every earlier thread this replaces
+    // was 0.105 ms of C3 whole's build.)
+    __shared__ uint32_t s_cnt[4][XCD_SUB];
     const uint32_t y = blockIdx.y, x = blockIdx.x;
     const uint64_t k0 = xcd_order_block_first(n, nb, y), k1 = xcd_order_block_first(n, nb, y + 1u);
     const uint64_t k = k0 + uint64_t(x) * 256u + threadIdx.x;
     const bool live = k < k1;
-    const uint8_t mine = live ? sub[k] : 0;
-    s_sub[threadIdx.x] = mine;
+    const uint32_t mine = live ? sub[k] : 0u;
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; ++q) s_cnt[q][threadIdx.x] = 0u;
+    __syncthreads();
+    unsigned long long peers = __ballot(live);
+#pragma unroll
+    for (uint32_t bit = 0; bit < 8u; ++bit) {
+        const bool set = ((mine >> bit) & 1u) != 0u;
+        const unsigned long long m = __ballot(set);
+        peers &= set ? m : ~m;
+    }
+    const uint32_t in_wave = uint32_t(__popcll(peers & ((1ull << lane) - 1ull)));
+    if (live && in_wave == 0u) s_cnt[wid][mine] = uint32_t(__popcll(peers));
     __syncthreads();
     if (!live) return;
-    uint32_t rank = 0;
-    for (uint32_t t = 0; t < threadIdx.x; ++t) rank += s_sub[t] == mine ? 1u : 0u;
+    uint32_t rank = in_wave;
+    for (uint32_t w = 0; w < wid; ++w) rank += s_cnt[w][mine];
     const uint64_t pos = start[(uint64_t(y) * XCD_SUB + mine) * tbmax + x] + rank;
     out[pos] = in[k];
     out_bucket[pos] = bucket[k];
