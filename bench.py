@@ -58,6 +58,8 @@ def parse_args():
     ap.add_argument("--no-host-packed", action="store_true", help="skip the host-packed image of the same cohort (A/B of the two builders)")
     ap.add_argument("--speedup-ref", action="store_true", help="N > 1, strong scaling: rank 0 first times the whole cohort alone (speedup_vs_1 on one clock); off by default -- "
                                                                 "the other ranks would wait in a barrier for it, and the driver computes the scaling curve from its own N = 1 run")
+    ap.add_argument("--clock-settle-ms", type=float, default=50.0, help="GPU kept busy with the checker's digest kernel for this long right before the W warm-up steps (0: off): the "
+                    "clocks are down after the host's oracle checks and W short steps of a small shard do not bring them back")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the transfers-inclusive leg (v2p_pipeline_*)")
     ap.add_argument("--verify", default="all", choices=["all", "sample", "none"], help="haplotypes whose digest is compared with the oracle before timing")
@@ -202,14 +204,33 @@ class Timed:
         self.torch, self.ctx, self.b = torch, ctx, batch
         self.ts = torch.cuda.Stream()
 
-    def run(self, steps, warmup, barrier=lambda: None):
-        """W untimed steps, then EXACTLY K steps bracketed by a barrier + torch.cuda.synchronize() on both sides (the driver's contract)."""
+    def settle_clocks(self, ms):
+        """Keeps the GPU busy for `ms` with the checker's own kernel -- v2p_batch_digests over the batch's arena, not a step of the path -- right
+        before the warm-up steps.  After the host's seconds of oracle checking the GPU's clocks are down and come back over ~40 ms of work
+        of this kind (profiles/r05_first_execute.txt; a bare fill or copy brings them back only part of the way: profiles/
+        r05_clock_settle.txt).  A whole-cohort step's W = 5 warm-up steps are 36 ms and cover most of that; an eighth of the cohort's are
+        4.6 ms and do not, so without this the N-rank points of the scaling curve would be timed on a lower clock than the 1-rank point."""
+        if ms <= 0:
+            return 0.0
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < ms:
+            self.b.digests()
+        return (time.perf_counter() - t0) * 1e3
+
+    def run(self, steps, warmup, barrier=lambda: None, settle_ms=0.0):
+        """[settle_ms of the digest kernel: clocks up] W untimed steps, then EXACTLY K steps bracketed by a barrier + torch.cuda.synchronize() on both
+        sides (the driver's contract)."""
         torch, ts = self.torch, self.ts
         self.ctx.set_stream(ts.cuda_stream)
+        barrier()                                               # (ranks meet BEFORE warming up: a rank that finished its checks early must not idle -- clocks down again -- between its warm-up and the timed region)
+        self.settled_ms = self.settle_clocks(settle_ms)
         for _ in range(warmup):
             self.b.execute()
         self.b.sync()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        import gc
+        gc_was = gc.isenabled()
+        gc.disable()                                            # (a collection inside a 20 ms timed region of 1 ms steps is 5 % of it)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -221,6 +242,8 @@ class Timed:
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
+        if gc_was:
+            gc.enable()
         self.ctx.set_stream(0)
         return elapsed, [a.elapsed_time(b) for a, b in ev]
 
@@ -254,7 +277,8 @@ def box_fill_GBps(n_bytes=8 << 30, reps=4):
     return n_bytes / (best * 1e-3) / 1e9
 
 
-def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verify, temporal=False, host_packed=True, time_host_image=False, label="", barrier=lambda: None):
+def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verify, temporal=False, host_packed=True, time_host_image=False, label="", barrier=lambda: None,
+               settle_ms=0.0):
     """One GPU (this rank's), haplotypes [h0, h1) of the cohort.  The transcript stream is made RESIDENT (v2p_stream_upload), then the
     product's one call -- v2p_batch_build_and_execute: image built on the device, executed -- gives the one-shot numbers and the batch
     every step re-executes; every haplotype's digest is checked against the oracle before anything is timed; optionally the
@@ -368,8 +392,8 @@ def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verif
             del img
         # ---- timed region ----
         timed = Timed(ctx, hbatch) if time_host_image else t
-        elapsed, kern_ms = timed.run(steps, warmup, barrier)
-        res.update({"elapsed_s": elapsed, "kernel_ms": kern_ms, "image_timed": "host-packed" if time_host_image else "device-built"})
+        elapsed, kern_ms = timed.run(steps, warmup, barrier, settle_ms)
+        res.update({"elapsed_s": elapsed, "kernel_ms": kern_ms, "image_timed": "host-packed" if time_host_image else "device-built", "clock_settle_ms": timed.settled_ms})
         # ---- parity AFTER timing: the timed steps re-execute the image in its re-execution form (a padded image made dense, its descriptors
         # staged; a dense image from its pieces) -- the arena they leave must be the one that was verified above
         if not time_host_image:
@@ -468,7 +492,7 @@ def main():
     else:
         leg = cohort_leg(args.workload, cohort_samples, h0, h1, args.steps, args.warmup, n_threads, args.verify, temporal=args.temporal,
                          host_packed=not args.no_host_packed and world == 1, time_host_image=args.host_image,
-                         barrier=(dist.barrier if dist_on else (lambda: None)))
+                         barrier=(dist.barrier if dist_on else (lambda: None)), settle_ms=args.clock_settle_ms)
     n_haps, out_bytes, A, NT = leg["haplotypes"], leg["result_bytes"], leg["aa"], leg["tasks"]
 
     # ---- the path's only exchange: {haplotypes, result bytes} of every rank, ONCE per image (sizes do not change between steps) ----
@@ -537,6 +561,9 @@ def main():
         line = {
             "metric": "amino-acids written/sec", "value": A_all * steps / elapsed, "unit": "aa/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
+            "clock_settle": {"ms_rank0": leg.get("clock_settle_ms"), "what": "the checker's digest kernel (v2p_batch_digests over the arena, not a step of the path) keeps the GPU busy this long right before the W warm-up steps: "
+                             "the clocks are down after the host's oracle checks and need ~40 ms of such work to come back (profiles/r05_first_execute.txt, r05_clock_settle.txt); the W warm-up "
+                             "steps of a whole cohort cover most of that, those of an eighth of it do not -- every point of the scaling curve is timed on the same clock (--clock-settle-ms 0: off)"},
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload}: " + (f"{samples} samples/GPU x {world} GPU(s)" if args.scaling == "weak" else
                                                           (f"the whole {samples}-sample cohort as ONE image, one v2p_batch_execute per step" if whole else
@@ -585,7 +612,7 @@ def main():
             if not args.no_c2 and args.workload == "C3" and not args.samples:
                 try:                                           # BASELINE.json configs[1]: the SNV-only cohort of 1 000 samples, the same way
                     c2 = cohort_leg("C2", DEFAULT_SAMPLES["strong"]["C2"], 0, 2 * DEFAULT_SAMPLES["strong"]["C2"], min(args.steps, 50), 5, n_threads, args.verify,
-                                    temporal=args.temporal, host_packed=not args.no_host_packed)
+                                    temporal=args.temporal, host_packed=not args.no_host_packed, settle_ms=args.clock_settle_ms)
                     ms2 = sum(c2["kernel_ms"]) / len(c2["kernel_ms"])
                     c2.update({"ms": ms2, "ms_min": min(c2["kernel_ms"]), "aa_per_s": c2["aa"] / (ms2 * 1e-3), "achieved_GBps": c2["hbm_bytes_min_per_launch"] / (ms2 * 1e-3) / 1e9,
                                "frac": c2["hbm_bytes_min_per_launch"] / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "steps": len(c2["kernel_ms"])})

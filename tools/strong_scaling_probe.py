@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ns", default="1,2,4,8")
+    ap.add_argument("--settle-ms", type=float, default=50.0, help="bench.py --clock-settle-ms")
     a = ap.parse_args()
     import torch
     if not torch.cuda.is_available():
@@ -36,13 +37,13 @@ def main():
     n_threads = max(1, min(64, os.cpu_count() or 1))
     cohort = Cohort.preset(a.workload, n_samples=samples)
     sizes = cohort.result_sizes(0, cohort.n_haplotypes, n_threads=n_threads)
-    out = {"workload": a.workload, "samples": samples, "haplotypes": cohort.n_haplotypes, "steps": a.steps, "points": []}
+    out = {"workload": a.workload, "samples": samples, "haplotypes": cohort.n_haplotypes, "steps": a.steps, "clock_settle_ms": a.settle_ms, "points": []}
     t1 = None
     for n in [int(x) for x in a.ns.split(",")]:
         ranges = shard_by_bytes(sizes.tolist(), n)
         ranks = []
         for r, (h0, h1) in enumerate(ranges):
-            leg = bench.cohort_leg(a.workload, samples, h0, h1, a.steps, a.warmup, n_threads, "none", host_packed=False, label=f"rank {r} of {n}")
+            leg = bench.cohort_leg(a.workload, samples, h0, h1, a.steps, a.warmup, n_threads, "none", host_packed=False, label=f"rank {r} of {n}", settle_ms=a.settle_ms)
             k = leg["kernel_ms"]
             ranks.append({"rank": r, "haplotypes": h1 - h0, "result_bytes": leg["result_bytes"], "ms_per_step_wall": 1e3 * leg["elapsed_s"] / len(k),
                           "kernel_ms_avg": sum(k) / len(k), "one_shot_total_ms": leg["one_shot"]["total_ms"],
