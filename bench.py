@@ -66,6 +66,8 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--temporal", action="store_true", help="plain result stores instead of non-temporal")
     ap.add_argument("--host-image", action="store_true", help="time the host-packed image instead of the device-built one")
+    ap.add_argument("--collectives", default="nccl", choices=["nccl", "gloo"], help="nccl (= RCCL; the product) or gloo: a TEST mode in which ranks may share a GPU "
+                    "(device = local rank mod devices present) and the size exchange runs on CPU tensors")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise launch, sharding and the size all-gather over gloo (CPU test of the N-rank path)")
     a = ap.parse_args()
     if a.no_verify or a.dry_run:
@@ -432,12 +434,18 @@ def main():
     else:
         if not torch.cuda.is_available():
             sys.exit("bench.py needs an MI355X: the gpu engine has no CPU fallback")
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+        if args.collectives == "gloo":
+            # (test mode, tests/test_gpu_bench_ranks.py: the whole N-rank path -- launch, per-rank GPU legs, barriers, the size exchange, the line --
+            # on a box with fewer GPUs than ranks; ranks share devices and the 16-byte exchange goes over gloo on CPU tensors)
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            dev = torch.device("cpu")
+        else:
+            torch.cuda.set_device(local_rank)
+            dev = torch.device("cuda", local_rank)
     dist_on = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dry_run:
+        if args.dry_run or args.collectives == "gloo":
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -599,6 +607,7 @@ def main():
         if per_rank:
             line["per_rank"] = per_rank
             line["world_size_seen_by_rccl"] = int(dist.get_world_size()) if dist_on else 1
+            line["collectives"] = "gloo (test mode: ranks may share a GPU)" if args.collectives == "gloo" or args.dry_run else "nccl (RCCL)"
             line["verified_ranks"] = sum(1 for p in per_rank if p["verified"]) if args.verify != "none" else 0
             line["allgather_us"] = allgather_us
         if speedup_ref is not None:

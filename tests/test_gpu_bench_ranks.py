@@ -1,0 +1,48 @@
+"""The N-rank path of bench.py ON THE GPU with more ranks than the box has devices (`--collectives gloo`: ranks share devices, the
+16-byte size exchange runs on CPU tensors): self-launch through torch.distributed.run, every rank's own shard made resident, built and
+executed by the one call, verified against the oracle, the ranks' barriers around the clock settle / warm-up / timed region, the
+exchange, the one JSON line of rank 0.  What is NOT covered here is RCCL itself (one GPU): the collectives are the same calls on
+another backend."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--collectives", "gloo", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pcie",
+                        "--no-c2", "--no-host-packed", "--clock-settle-ms", "5", *extra], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_strong_scaling_on_the_gpu(built, gpu_ctx):
+    one = run_bench("--gpus", "1", "--samples", "150", "--verify", "all")
+    two = run_bench("--gpus", "2", "--samples", "150", "--verify", "all")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["workload"].startswith("C3")
+    ranks = two["per_rank"]
+    assert [r["rank"] for r in ranks] == [0, 1] and two["world_size_seen_by_rccl"] == 2 and two["verified_ranks"] == 2
+    assert sum(r["haplotypes"] for r in ranks) == 300 == one["config"]["haplotypes_rank0"]
+    assert sum(r["aa"] for r in ranks) == one["config"]["aa_rank0"]                 # the same cohort, the same residues
+    assert ranks[0]["first_haplotype"] == 0 and ranks[1]["first_haplotype"] == ranks[0]["haplotypes"]
+    assert ranks[0]["byte_offset"] == 0 and ranks[1]["byte_offset"] == ranks[0]["result_bytes"]
+    a, b = (r["result_bytes"] for r in ranks)
+    assert abs(a - b) < 0.05 * (a + b)                                              # balanced by bytes
+    assert two["value"] > 0 and two["steps"] == 3 and two["warmup"] == 1 and two["clock_settle"]["ms_rank0"] >= 5
+    assert two["one_shot"]["total_ms"] > 0 and two["digests_equal_after_timed_steps"] is True
+    assert two["verified"]["every_haplotype"] is True                              # rank 0's shard; the others' verdicts are in verified_ranks
+
+
+def test_three_ranks_weak_scaling_on_the_gpu(built, gpu_ctx):
+    three = run_bench("--gpus", "3", "--workload", "C2", "--scaling", "weak", "--samples", "4", "--verify", "all")
+    assert three["n_gpus"] == 3 and three["scaling"] == "weak" and three["verified_ranks"] == 3
+    assert [r["haplotypes"] for r in three["per_rank"]] == [8, 8, 8]
+    assert [r["first_haplotype"] for r in three["per_rank"]] == [0, 8, 16]
