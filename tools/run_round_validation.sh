@@ -15,3 +15,4 @@ SKIP_CEILING=1 bash tools/profile_round.sh r05_C5 --workload C5 --samples 10000 
 SKIP_CEILING=1 bash tools/profile_round.sh r05_C2 --workload C2 --samples 1000 > gpurun_out/profile_C2.log 2>&1
 bash tools/profile_decode.sh > gpurun_out/profile_decode.log 2>&1
 timeout 1500 python bench.py > gpurun_out/profiles_r05/r05_bench_default_line.json 2> gpurun_out/profiles_r05/bench_default.err; echo "bench rc=$?"
+timeout 900 python tools/strong_scaling_probe.py > gpurun_out/profiles_r05/r05_strong_scaling_probe.json 2> gpurun_out/profiles_r05/strong_probe.err; grep '^{' gpurun_out/profiles_r05/strong_probe.err
