@@ -98,6 +98,30 @@ def test_random_streams_in_one_call(built, gpu_ctx, seed, shape, kernel):
     rs.close()
 
 
+def test_a_refused_cut_in_recycled_memory_falls_back(built, gpu_ctx):
+    """Found by tools/fuzz_one_call.py (seeds 152 -> 153): the one call launches the chunk-table pass before the host has looked at the
+    status word; a cutter that refuses a row (more than 64 descriptors: the call then builds a dense image) used to leave its segment's
+    count unwritten -- zero in fresh memory, anything in memory another batch had used: a table pass that followed it wrote out of bounds."""
+    for seed in (152, 153):
+        rng = np.random.default_rng(seed)
+        shape = ("snv", "mix", "long")[seed % 3]
+        n_haps = int(rng.integers(1, 700)); n_ref = int(rng.integers(1, 40)); window = int(rng.choice([1024, 4096, 8192]))
+        proteome, stream, want = random_stream(rng, n_haps=n_haps, n_ref_tx=n_ref, shape=shape, window=window)
+        gpu_ctx.upload_proteome(proteome)
+        rs = gpu_ctx.upload_stream(stream)
+        for kernel in (0, 8, 0):
+            b = gpu_ctx.batch()
+            b.build_and_execute(rs, kernel, 0)
+            b.sync()
+            for rep in range(2):
+                for h, w in enumerate(want):
+                    assert np.array_equal(b.download_hap(h), w), (seed, kernel, rep, h)
+                b.execute()
+                b.sync()
+            b.close()
+        rs.close()
+
+
 def test_a_tile_that_overflows_its_slots_falls_back_inside_the_call(built, gpu_ctx):
     """One transcript with thousands of Tasks: its tile's descriptors do not fit the one-pass stage, the sliced builder declines and the
     call builds in one piece (two-pass form) and executes -- same bytes, n_slices reported as 0."""

@@ -583,7 +583,7 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
             const uint32_t hsd = uint32_t(__builtin_amdgcn_readlane(int(offd), int(cur))), hs = hsd & PIECE_MAX;
             const bool ok = lane > cur && lane <= cur + max_rows && r <= s1 && lastd - f + 1u <= max_desc;
             const uint64_t m = __ballot(ok);
-            if (!m) { if (lane == 0) rreport(a.status, f, STATUS_ROWS_TOO_MANY); return; }
+            if (!m) { if (lane == 0) { rreport(a.status, f, STATUS_ROWS_TOO_MANY); if (PASS != 1) a.seg_count[seg] = 0u; } return; }      // (the count is WRITTEN: the scan and the table pass behind this kernel run before the host has looked at the status)
             const uint32_t hb = 63u - uint32_t(__builtin_clzll(m));
             uint32_t ps = 0;
             if (EMIT && a.pad_chunks) ps = uint32_t(__builtin_amdgcn_readlane(int(pslot), int(cur)));
@@ -617,6 +617,9 @@ __global__ __launch_bounds__(256) void rows_chunk_compact_kernel(RowsArgs a)
 {
     const uint64_t seg = a.seg0 + uint64_t(blockIdx.x) * 4u + (threadIdx.x >> 6);
     if (seg >= a.seg1) return;
+    // (the one call launches this pass before the host has looked at the status word: behind a parse or a cut that was refused the padded
+    // table holds whatever the memory held before -- nothing of it is followed)
+    if (*a.status != STATUS_CLEAN) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t b0 = a.seg_base[seg], n = a.seg_base[seg + 1u] - b0;
     for (uint32_t k = lane; k < n && k < ROWS_CHUNK_PAD; k += 64u) {
