@@ -10,7 +10,7 @@ import numpy as np
 class Stream:
     """A v2p_txstream over numpy arrays (kept alive here)."""
 
-    def __init__(self, hap_tx_begin, tx_off, tx_ref_len, tx_res_len, tx_task_begin, tx_alt_begin, code, sp, ln, sr, alt):
+    def __init__(self, hap_tx_begin, tx_off, tx_ref_len, tx_res_len, tx_task_begin, tx_alt_begin, code, sp, ln, sr, alt, header_off=None, header_len=None):
         from vcf2prot_amd._cohort_api import TxStreamBuf
         pad = 64                                     # the builder reads a few entries past the last task / alt byte of a transcript
         self.keep = [np.ascontiguousarray(hap_tx_begin, dtype=np.uint64), np.ascontiguousarray(tx_off, dtype=np.uint64),
@@ -30,17 +30,22 @@ class Stream:
         s.tx_task_begin, s.tx_alt_begin = k[4].ctypes.data_as(P64), k[5].ctypes.data_as(P64)
         s.code, s.start_pos, s.length, s.start_pos_res = k[6].ctypes.data_as(P8), k[7].ctypes.data_as(P32), k[8].ctypes.data_as(P32), k[9].ctypes.data_as(P32)
         s.alt = k[10].ctypes.data_as(P8)
+        if header_off is not None:                   # FASTA emit: every transcript's record header in the resident header table (length 0: none)
+            k += [np.ascontiguousarray(header_off, dtype=np.uint64), np.ascontiguousarray(header_len, dtype=np.uint32)]
+            s.tx_header_off, s.tx_header_len = k[11].ctypes.data_as(P64), k[12].ctypes.data_as(P32)
         self.struct = s
 
 
-def random_stream(rng, n_haps, n_ref_tx, shape, window):
-    """Returns (proteome, Stream, [expected result of every haplotype])."""
+def random_stream(rng, n_haps, n_ref_tx, shape, window, fasta=False):
+    """Returns (proteome, Stream, [expected result of every haplotype]); fasta: (proteome, header table, Stream, [expected FASTA text]) --
+    every transcript a record `>name_1\n` + residues + `\n` (personalized_genome.rs:90-113), a few without a header (bare residues)."""
     AA = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
     ref_len = rng.integers(1, 3 * window if shape == "long" else 900, size=n_ref_tx)
     ref_off = np.concatenate([[0], np.cumsum(ref_len)])
     proteome = AA[rng.integers(0, AA.size, size=int(ref_off[-1]))]
     hap_tx_begin, tx_off, tx_ref_len, tx_res_len, tx_task_begin, tx_alt_begin = [0], [], [], [], [0], [0]
     code, sp, ln, sr, alt, want = [], [], [], [], [], []
+    headers, hoff, hlen = bytearray(b"\n"), [], []
     for h in range(n_haps):
         n_tx = 0 if rng.random() < 0.1 else int(rng.integers(1, 12))
         res_h = []
@@ -90,6 +95,13 @@ def random_stream(rng, n_haps, n_ref_tx, shape, window):
             ta = np.asarray(talt, dtype=np.uint8)
             for c, s_, l_, r_ in tasks:
                 out[r_:r_ + l_] = (ref if c == 0 else ta)[s_:s_ + l_]
+            if fasta:
+                if rng.random() < 0.05:
+                    hoff.append(0); hlen.append(0)
+                else:
+                    name = (">T%d_%s_1\n" % (t, "x" * int(rng.integers(0, 40)))).encode()
+                    hoff.append(len(headers)); hlen.append(len(name)); headers += name
+                    out = np.concatenate([np.frombuffer(name, dtype=np.uint8), out, np.frombuffer(b"\n", dtype=np.uint8)])
             res_h.append(out)
             tx_off.append(int(ref_off[t])); tx_ref_len.append(L); tx_res_len.append(res_len)
             for c, s_, l_, r_ in tasks:
@@ -98,4 +110,7 @@ def random_stream(rng, n_haps, n_ref_tx, shape, window):
             tx_task_begin.append(len(code)); tx_alt_begin.append(len(alt))
         hap_tx_begin.append(len(tx_off))
         want.append(np.concatenate(res_h) if res_h else np.zeros(0, np.uint8))
+    if fasta:
+        return (proteome, np.frombuffer(bytes(headers), dtype=np.uint8),
+                Stream(hap_tx_begin, tx_off, tx_ref_len, tx_res_len, tx_task_begin, tx_alt_begin, code, sp, ln, sr, alt, hoff, hlen), want)
     return proteome, Stream(hap_tx_begin, tx_off, tx_ref_len, tx_res_len, tx_task_begin, tx_alt_begin, code, sp, ln, sr, alt), want

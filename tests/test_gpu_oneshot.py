@@ -98,6 +98,34 @@ def test_random_streams_in_one_call(built, gpu_ctx, seed, shape, kernel):
     rs.close()
 
 
+@pytest.mark.parametrize("seed,shape,kernel", [(2, "snv", 0), (7, "mix", 6), (11, "long", 7), (13, "mix", 0)])
+def test_random_fasta_streams_in_one_call(built, gpu_ctx, seed, shape, kernel):
+    """The same irregular streams with FASTA emit (personalized_genome.rs:90-113): every transcript's `>name_1` header and line feed around
+    its residues, a few transcripts without a header; first execute and the image's re-execution form (tools/fuzz_one_call.py runs thousands)."""
+    from vcf2prot_amd._native import V2PError
+    rng = np.random.default_rng(seed)
+    proteome, headers, stream, want = random_stream(rng, n_haps=300, n_ref_tx=20, shape=shape, window=4096, fasta=True)
+    gpu_ctx.upload_reference(proteome, headers)
+    rs = gpu_ctx.upload_stream(stream)
+    b = gpu_ctx.batch()
+    try:
+        b.build_and_execute(rs, kernel, 0)
+    except V2PError as e:
+        assert kernel == 6 and e.code == -9
+        b.reset()
+        b.build_and_execute(rs, 7, 0)
+    b.sync()
+    for rep in range(2):
+        for h, w in enumerate(want):
+            got = b.download_hap(h)
+            assert got.size == w.size and np.array_equal(got, w), (seed, shape, kernel, rep, h)
+        b.execute()
+        b.sync()
+    b.close()
+    rs.close()
+    gpu_ctx.upload_proteome(proteome)                       # (leave the shared context without a header table)
+
+
 def test_a_refused_cut_in_recycled_memory_falls_back(built, gpu_ctx):
     """Found by tools/fuzz_one_call.py (seeds 152 -> 153): the one call launches the chunk-table pass before the host has looked at the
     status word; a cutter that refuses a row (more than 64 descriptors: the call then builds a dense image) used to leave its segment's

@@ -19,14 +19,19 @@ with Context(0) as ctx:
         rng = np.random.default_rng(seed)
         shape = ("snv", "mix", "long")[seed % 3]
         n_haps = int(rng.integers(1, 700)); n_ref = int(rng.integers(1, 40)); window = int(rng.choice([1024, 4096, 8192]))
-        proteome, stream, want = random_stream(rng, n_haps=n_haps, n_ref_tx=n_ref, shape=shape, window=window)
-        ctx.upload_proteome(proteome)
+        fasta = os.environ.get("FUZZ_FASTA") == "1" or (os.environ.get("FUZZ_FASTA") is None and seed % 2 == 1)
+        if fasta:
+            proteome, headers, stream, want = random_stream(rng, n_haps=n_haps, n_ref_tx=n_ref, shape=shape, window=window, fasta=True)
+            ctx.upload_reference(proteome, headers)
+        else:
+            proteome, stream, want = random_stream(rng, n_haps=n_haps, n_ref_tx=n_ref, shape=shape, window=window)
+            ctx.upload_proteome(proteome)
         rs = ctx.upload_stream(stream)
-        for kernel in (0, 6, 7, 8):
+        for kernel in ((0, 6, 7) if fasta else (0, 6, 7, 8)):
             for slices in (0, 3):
                 for variant in ((0, 24) if kernel in (0, 6) else (0,)):            # 24: the padded form whatever the rule says
                     ctx.set_launch_opts(variant=variant)
-                    print('cfg', seed, shape, n_haps, n_ref, window, kernel, slices, variant, file=sys.stderr, flush=True)
+                    print('cfg', seed, shape, n_haps, n_ref, window, fasta, kernel, slices, variant, file=sys.stderr, flush=True)
                     b = ctx.batch()
                     try:
                         try:
@@ -41,13 +46,13 @@ with Context(0) as ctx:
                             for h, w in enumerate(want):
                                 got = b.download_hap(h)
                                 if got.size != w.size or not np.array_equal(got, w):
-                                    bad.append({"seed": seed, "shape": shape, "kernel": kernel, "slices": slices, "variant": variant, "rep": rep, "hap": h}); break
+                                    bad.append({"seed": seed, "fasta": fasta, "shape": shape, "kernel": kernel, "slices": slices, "variant": variant, "rep": rep, "hap": h}); break
                             if os.environ.get('FUZZ_TRACE'): print(' checked', rep, file=sys.stderr, flush=True)
                             b.execute(); b.sync()
                             if os.environ.get('FUZZ_TRACE'): print(' executed', rep, b.image_form(), file=sys.stderr, flush=True)
                         runs += 1
                     except Exception as e:                                           # noqa: BLE001
-                        bad.append({"seed": seed, "shape": shape, "kernel": kernel, "slices": slices, "variant": variant, "error": repr(e)[:300]})
+                        bad.append({"seed": seed, "fasta": fasta, "shape": shape, "kernel": kernel, "slices": slices, "variant": variant, "error": repr(e)[:300]})
                     finally:
                         b.close()
         ctx.set_launch_opts()
