@@ -32,5 +32,28 @@ with Context(0) as ctx:
         except Exception as e:                      # noqa: BLE001
             bad.append({**cfg, "error": repr(e)[:300]})
         runs += 1
-print(json.dumps({"seeds": [first, first + count], "runs": runs, "failures": bad[:20], "n_failures": len(bad)}))
+    # ---- aborts: one to three malformed columns at random places; the error must be the FIRST offending column's, located ----
+    from vcf2prot_amd import _native as N
+    BAD = [("0|1:-7", -20), ("0|1:3,-1", -20), ("0|1:-0", -21), ("0|1:1,,1", -21), ("0|1:1,a", -21), ("0|1:5,4294967296", -21), ("0|1:64", -22), ("0|1:1,16", -22)]
+    n_abort = 0
+    for seed in range(first, first + (count if os.environ.get("FUZZ_ABORTS", "1") == "1" else 0)):
+        r = random.Random(seed * 104729)
+        n_rec, n_smp = r.randrange(1, 400), r.randrange(1, 300)
+        text = random_vcf(seed, n_rec, n_smp, max_csq=3, p_zero=r.choice([0.0, 0.5, 0.95]), fmt_extra=r.random() < 0.5, unique_positions=False)
+        lines = text.split("\n")
+        f0 = next(i for i, ln in enumerate(lines) if ln and not ln.startswith("#"))
+        places = sorted({(r.randrange(n_rec), r.randrange(n_smp)) for _ in range(r.randrange(1, 4))})
+        kinds = [r.choice(BAD) for _ in places]
+        for (rec, smp), (txt, _) in zip(places, kinds):
+            ln = lines[f0 + rec].split("\t"); ln[9 + smp] = txt; lines[f0 + rec] = "\t".join(ln)
+        cfg = {"seed": seed, "records": n_rec, "samples": n_smp, "places": places, "kinds": kinds}
+        print("abort cfg", cfg, file=sys.stderr, flush=True)
+        try:
+            decode_bitmasks(ctx, VcfIndex("\n".join(lines).encode()))
+            bad.append({**cfg, "error": "no abort"})
+        except N.V2PError as e:
+            if e.code != kinds[0][1] or e.index != places[0][0] * n_smp + places[0][1]:
+                bad.append({**cfg, "got": [e.code, e.index]})
+        n_abort += 1
+print(json.dumps({"seeds": [first, first + count], "runs": runs, "abort_runs": n_abort, "failures": bad[:20], "n_failures": len(bad)}))
 sys.exit(1 if bad else 0)
