@@ -57,5 +57,74 @@ with Context(0) as ctx:
                         b.close()
         ctx.set_launch_opts()
         rs.close()
-print(json.dumps({"seeds": [first, first + count], "runs": runs, "failures": bad[:20], "n_failures": len(bad)}))
+    # ---- what the reference would panic on (update_task, haplotype_instruction.rs:154; Task::execute's slices, task.rs:43,47): one or two
+    # violations injected into a clean stream -- the call must report the FIRST offending Task, with update_task's precedence, and the batch
+    # must take a clean stream afterwards ----
+    n_err = 0
+    for seed in range(first, first + (count if os.environ.get("FUZZ_ERRORS", "1") == "1" else 0)):
+        rng = np.random.default_rng(seed + 77777)
+        shape = ("snv", "mix", "long")[seed % 3]
+        proteome, stream, want = random_stream(rng, n_haps=int(rng.integers(1, 500)), n_ref_tx=int(rng.integers(1, 30)), shape=shape, window=4096)
+        k = stream.keep
+        n_tasks = stream.struct.n_tasks
+        if n_tasks < 8:
+            continue
+        ctx.upload_proteome(proteome)
+        good = ctx.upload_stream(stream)
+        tb, rl, res, ab = k[4], k[2], k[3], k[5]
+        code, sp, ln, sr = (a.copy() for a in k[6:10])
+        picks = sorted(set(int(x) for x in rng.integers(0, n_tasks, size=int(rng.integers(1, 3)))))
+        picks = [p_ for j, p_ in enumerate(picks) if j == 0 or p_ - picks[j - 1] > 2]
+        expect = None
+        for i in picks:
+            t = int(np.searchsorted(tb, i, side="right") - 1)
+            kind = str(rng.choice(["code", "res", "src", "order"]))
+            if kind == "order" and (i == int(tb[t]) or int(sr[i - 1]) + int(ln[i - 1]) < 1 or int(code[i - 1]) > 1):
+                kind = "code"
+            if kind == "code":
+                code[i] = int(rng.integers(2, 256)); err = -3
+            elif kind == "res":
+                sr[i] = int(res[t]) + 1; err = -4
+            elif kind == "src":
+                bound = int(rl[t]) if code[i] == 0 else int(ab[t + 1] - ab[t])
+                sp[i] = bound + 1; err = -5
+            else:
+                sr[i] = int(sr[i - 1]) + int(ln[i - 1]) - 1; err = -6
+            if expect is None:
+                expect = (err, i, kind)
+        from stream_util import Stream
+        n_tx = stream.struct.n_tx
+        badst = Stream(k[0], k[1], k[2], k[3], k[4], k[5], code[:n_tasks], sp[:n_tasks], ln[:n_tasks], sr[:n_tasks], k[10][:stream.struct.n_alt])
+        rs = ctx.upload_stream(badst)
+        for kernel in (0, 6, 7):
+            for slices in (0, 3):
+                cfg = {"seed": seed, "shape": shape, "kernel": kernel, "slices": slices, "expect": list(expect), "picks": picks}
+                print("err cfg", cfg, file=sys.stderr, flush=True)
+                b = ctx.batch()
+                try:
+                    try:
+                        b.build_and_execute(rs, kernel, slices); b.sync()
+                        bad.append({**cfg, "error": "no error reported"})
+                    except V2PError as e:
+                        if kernel == 6 and e.code == -9:
+                            pass                                                       # (a row with more than 64 descriptors: refused before the Tasks are judged)
+                        elif e.code != expect[0] or e.index != expect[1]:
+                            bad.append({**cfg, "got": [e.code, e.index]})
+                    b.reset()
+                    try:
+                        b.build_and_execute(good, kernel, slices)
+                    except V2PError as e:
+                        if not (kernel == 6 and e.code == -9):
+                            raise
+                        b.reset(); b.build_and_execute(good, 7, slices)
+                    b.sync()
+                    if not all(np.array_equal(b.download_hap(h), w) for h, w in enumerate(want)):
+                        bad.append({**cfg, "error": "the clean stream behind the refused one gave other bytes"})
+                    n_err += 1
+                except Exception as e:                                               # noqa: BLE001
+                    bad.append({**cfg, "error": repr(e)[:300]})
+                finally:
+                    b.close()
+        rs.close(); good.close()
+print(json.dumps({"seeds": [first, first + count], "runs": runs, "error_runs": n_err, "failures": bad[:20], "n_failures": len(bad)}))
 sys.exit(1 if bad else 0)
