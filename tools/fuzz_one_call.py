@@ -57,6 +57,40 @@ with Context(0) as ctx:
                         b.close()
         ctx.set_launch_opts()
         rs.close()
+    # ---- the two-call builders on a HOST stream (v2p_batch_build_on_device): the grid builders of round 3 (kernels 1..5, a window size) and
+    # the rows builder (6, 7, 0); a refusal must be the documented one (-9: the stream does not fit the image kind that was asked for) ----
+    n_two = 0
+    for seed in range(first, first + (count if os.environ.get("FUZZ_TWO_CALL", "1") == "1" else 0)):
+        rng = np.random.default_rng(seed + 31337)
+        shape = ("snv", "mix", "long")[seed % 3]
+        window = int(rng.choice([4096, 8192]))
+        proteome, stream, want = random_stream(rng, n_haps=int(rng.integers(1, 120)), n_ref_tx=int(rng.integers(1, 30)), shape=shape, window=window)
+        # (a kind's own window sizes: per-block kernels multiples of 4 KiB up to 60 KiB, the dense kernel 4 / 8 / 12 KiB, wave kernels multiples of 1 KiB up to 10)
+        windows = {1: [4096, 8192, 16384, 28672], 2: [4096, 8192, 16384, 32768], 3: [4096, 8192, 12288], 4: [1024, 2048, 4096, 10240], 5: [2048, 3072, 4096, 6144, 10240]}
+        ctx.upload_proteome(proteome)
+        for kernel in (1, 2, 3, 4, 5, 6, 7, 0):
+            window = int(rng.choice(windows[kernel])) if kernel in windows else (4096 if kernel == 0 else 0)      # (0 with a window: round 3's routing among the grid kinds)
+            cfg = {"seed": seed, "shape": shape, "window": window, "kernel": kernel, "two_call": True}
+            print("two cfg", cfg, file=sys.stderr, flush=True)
+            b = ctx.batch()
+            try:
+                try:
+                    b.build_on_device(stream, window, kernel)
+                except V2PError as e:
+                    if e.code != -9 or kernel in (0, 7):
+                        raise
+                    continue                                                          # (an image kind asked for by number may not take the stream: too many descriptors in a window / a row)
+                for rep in range(2):
+                    b.execute(); b.sync()
+                    for h, w in enumerate(want):
+                        got = b.download_hap(h)
+                        if got.size != w.size or not np.array_equal(got, w):
+                            bad.append({**cfg, "rep": rep, "hap": h}); break
+                n_two += 1
+            except Exception as e:                                                   # noqa: BLE001
+                bad.append({**cfg, "error": repr(e)[:300]})
+            finally:
+                b.close()
     # ---- what the reference would panic on (update_task, haplotype_instruction.rs:154; Task::execute's slices, task.rs:43,47): one or two
     # violations injected into a clean stream -- the call must report the FIRST offending Task, with update_task's precedence, and the batch
     # must take a clean stream afterwards ----
@@ -126,5 +160,5 @@ with Context(0) as ctx:
                 finally:
                     b.close()
         rs.close(); good.close()
-print(json.dumps({"seeds": [first, first + count], "runs": runs, "error_runs": n_err, "failures": bad[:20], "n_failures": len(bad)}))
+print(json.dumps({"seeds": [first, first + count], "runs": runs, "two_call_runs": n_two, "error_runs": n_err, "failures": bad[:20], "n_failures": len(bad)}))
 sys.exit(1 if bad else 0)
