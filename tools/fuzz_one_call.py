@@ -29,8 +29,12 @@ with Context(0) as ctx:
         rs = ctx.upload_stream(stream)
         for kernel in ((0, 6, 7) if fasta else (0, 6, 7, 8)):
             for slices in (0, 3):
-                for variant in ((0, 24) if kernel in (0, 6) else (0,)):            # 24: the padded form whatever the rule says
-                    ctx.set_launch_opts(variant=variant)
+                for variant in ((0, 24, 25, 23) if kernel in (0, 6) else (0,)):    # 24: the padded form whatever the rule says; 25: dense images staged too; 23: no staging
+                    # (small phases -- 8+ chunks -- on some runs: the phased launches, the read-ahead riding on them and the two staging buffers also on these small images)
+                    if (seed + kernel + slices + variant) % 2:
+                        ctx.set_launch_opts(variant=variant, phase_bytes=int([2048, 16384, 1 << 18][(seed + variant) % 3]), phase_min_chunks=8)
+                    else:
+                        ctx.set_launch_opts(variant=variant)
                     print('cfg', seed, shape, n_haps, n_ref, window, fasta, kernel, slices, variant, file=sys.stderr, flush=True)
                     b = ctx.batch()
                     try:
