@@ -46,3 +46,18 @@ def test_three_ranks_weak_scaling_on_the_gpu(built, gpu_ctx):
     assert three["n_gpus"] == 3 and three["scaling"] == "weak" and three["verified_ranks"] == 3
     assert [r["haplotypes"] for r in three["per_rank"]] == [8, 8, 8]
     assert [r["first_haplotype"] for r in three["per_rank"]] == [0, 8, 16]
+
+
+def test_eight_ranks_strong_scaling_on_the_gpu(built, gpu_ctx):
+    """The driver's 8-rank command with the ranks sharing this box's device(s): eight real legs, the barriers around settle / warm-up / timed
+    region with eight participants, the 16-byte exchange, offsets that tile the cohort's single arena."""
+    eight = run_bench("--gpus", "8", "--samples", "400", "--verify", "sample")
+    ranks = eight["per_rank"]
+    assert eight["n_gpus"] == 8 and [r["rank"] for r in ranks] == list(range(8)) and eight["verified_ranks"] == 8
+    assert sum(r["haplotypes"] for r in ranks) == 800
+    off = 0
+    for r in ranks:
+        assert r["byte_offset"] == off
+        off += r["result_bytes"]
+    share = [r["result_bytes"] / off for r in ranks]
+    assert max(share) - min(share) < 0.02
