@@ -24,6 +24,10 @@
  * A ctx (and its batches) may be used from one thread at a time; create one ctx
  * per worker thread (Rayon worker) -- contexts are independent and each owns a
  * HIP stream.
+ * Environment (debugging only, read once per process): V2P_DEBUG_POISON=1 fills every device buffer with 0xA5 whenever
+ * a call sizes it -- reused allocations included -- so that no result can depend on what fresh or recycled device memory held;
+ * V2P_DECODE_CURSOR64 (v2p_frontend.h) forces the decode's 64-bit cursor kernels; the coalescing queue of v2p_execute_gir_shared
+ * takes V2P_COALESCE_MB / _US / _BATCHES / _PROFILE (below).  Launch options are set through v2p_set_launch_opts, not the environment.
  */
 #ifndef VCF2PROT_HIP_H
 #define VCF2PROT_HIP_H

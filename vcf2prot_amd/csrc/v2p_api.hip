@@ -32,30 +32,40 @@ namespace {
 
 thread_local std::string g_init_error;
 
+// V2P_DEBUG_POISON=1 (a debugging aid like the reference's DEBUG_* switches; read once): every device buffer is filled with 0xA5 whenever a
+// call (re)sizes it -- also when the allocation is reused -- so that nothing can lean on what fresh or recycled memory happens to hold
+// (tools/fuzz_*.py and the GPU suite run clean under it; one bug of that kind was found without it)
+static bool debug_poison()
+{
+    static const bool on = [] { const char* e = getenv("V2P_DEBUG_POISON"); return e && e[0] == '1'; }();
+    return on;
+}
+
 struct DevBuf {
     uint8_t* base = nullptr;
     size_t cap = 0;
+    void poison() const { if (debug_poison() && base) { (void)hipDeviceSynchronize(); (void)hipMemset(base, 0xA5, cap); (void)hipDeviceSynchronize(); } }
     // n usable bytes at ptr(), with at least PAD_BYTES readable before and after.  The front pad is a
     // whole 256 bytes so ptr() keeps hipMalloc's alignment: result arenas must start on a cache line
     // (a 1 KiB wave store that straddles lines turns into partial-line writes).
     static constexpr size_t FRONT = 256;
     hipError_t ensure(size_t n) {
         const size_t need = n + FRONT + PAD_BYTES;
-        if (need <= cap) return hipSuccess;
+        if (need <= cap) { poison(); return hipSuccess; }
         if (base) { (void)hipFree(base); base = nullptr; cap = 0; }
         size_t want = need + need / 4;
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), want);
         if (e != hipSuccess) { want = need; e = hipMalloc(reinterpret_cast<void**>(&base), want); }
-        if (e == hipSuccess) cap = want;
+        if (e == hipSuccess) { cap = want; poison(); }
         return e;
     }
     // scratch that lives for one call: exactly n bytes (ensure()'s 25 % slack is for buffers that grow from call to call)
     hipError_t ensure_exact(size_t n) {
         const size_t need = n + FRONT + PAD_BYTES;
-        if (need <= cap) return hipSuccess;
+        if (need <= cap) { poison(); return hipSuccess; }
         if (base) { (void)hipFree(base); base = nullptr; cap = 0; }
         const hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), need);
-        if (e == hipSuccess) cap = need;
+        if (e == hipSuccess) { cap = need; poison(); }
         return e;
     }
     uint8_t* ptr() const { return base ? base + FRONT : nullptr; }
