@@ -2,6 +2,7 @@
 // decode_kernels.hip.  Replaces the Engine::GPU arm of VCFRecords::get_csq_per_patient (vcf_ds.rs:192-211).
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -99,6 +100,16 @@ bool sizes_ok(uint64_t n_records, uint64_t n_samples, uint64_t ovf_words)
 #define DTRY(expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { d->release(); delete d; \
     return ctx_fail(ctx, V2P_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e__), -1); } } while (0)
 
+// hipMalloc, and under V2P_DEBUG_POISON=1 (vcf2prot_hip.h: a debugging switch) the allocation filled with 0xA5: no result may depend on
+// what fresh or recycled device memory held
+static hipError_t dmalloc(void** p, size_t n)
+{
+    static const bool poison = [] { const char* e = getenv("V2P_DEBUG_POISON"); return e && e[0] == '1'; }();
+    const hipError_t e = hipMalloc(p, n);
+    if (e == hipSuccess && poison && n) { (void)hipDeviceSynchronize(); (void)hipMemset(*p, 0xA5, n); (void)hipDeviceSynchronize(); }
+    return e;
+}
+
 extern "C" {
 
 uint64_t v2p_decode_workspace_bytes(uint64_t n_records, uint64_t n_samples, uint64_t ovf_words)
@@ -156,11 +167,11 @@ int v2p_decode_run(v2p_ctx* ctx, const uint8_t* text, uint64_t n_text,
     if (!d) return ctx_fail(ctx, V2P_ERR_HIP, "out of host memory", -1);
     d->ctx = ctx; d->n_samples = n_samples; d->n_records = n_records;
     const uint64_t n_haps = 2 * n_samples;
-    DTRY(hipMalloc(reinterpret_cast<void**>(&d->d_text), n_text + 512), "hipMalloc(text)");
-    DTRY(hipMalloc(reinterpret_cast<void**>(&d->d_rows), 2 * n_records * sizeof(uint64_t)), "hipMalloc(rows)");
-    DTRY(hipMalloc(reinterpret_cast<void**>(&d->d_csq), csq.size() * sizeof(uint32_t)), "hipMalloc(csq)");
-    DTRY(hipMalloc(reinterpret_cast<void**>(&d->d_hap_begin), (n_haps + 1) * sizeof(uint64_t)), "hipMalloc(hap_begin)");
-    DTRY(hipMalloc(reinterpret_cast<void**>(&d->d_status), 2 * sizeof(uint64_t)), "hipMalloc(status)");
+    DTRY(dmalloc(reinterpret_cast<void**>(&d->d_text), n_text + 512), "hipMalloc(text)");
+    DTRY(dmalloc(reinterpret_cast<void**>(&d->d_rows), 2 * n_records * sizeof(uint64_t)), "hipMalloc(rows)");
+    DTRY(dmalloc(reinterpret_cast<void**>(&d->d_csq), csq.size() * sizeof(uint32_t)), "hipMalloc(csq)");
+    DTRY(dmalloc(reinterpret_cast<void**>(&d->d_hap_begin), (n_haps + 1) * sizeof(uint64_t)), "hipMalloc(hap_begin)");
+    DTRY(dmalloc(reinterpret_cast<void**>(&d->d_status), 2 * sizeof(uint64_t)), "hipMalloc(status)");
     uint8_t* d_text = d->d_text + 256;
     DTRY(hipMemcpyAsync(d_text, text, n_text, hipMemcpyHostToDevice, st), "H2D(text)");
     DTRY(hipMemcpyAsync(d->d_rows, row_begin, n_records * sizeof(uint64_t), hipMemcpyHostToDevice, st), "H2D(row_begin)");
@@ -186,7 +197,7 @@ int v2p_decode_run(v2p_ctx* ctx, const uint8_t* text, uint64_t n_text,
     for (int attempt = 0; attempt < 4 && !done; ++attempt) {
         if (d->d_work) { (void)hipFree(d->d_work); d->d_work = nullptr; }
         const DecodeLayout L = decode_layout(n_records, n_samples, ovf_words);
-        DTRY(hipMalloc(reinterpret_cast<void**>(&d->d_work), L.total), "hipMalloc(decode workspace)");
+        DTRY(dmalloc(reinterpret_cast<void**>(&d->d_work), L.total), "hipMalloc(decode workspace)");
         DTRY(hipMemsetAsync(d->d_status, 0xFF, sizeof(uint64_t), st), "hipMemset(status)");
         DecodeArgs a{};
         fill_args(a, d_text, n_text, d->d_rows, d->d_rows + n_records, n_records, n_samples, d->d_csq, d->d_csq + n_records + 1,
@@ -215,7 +226,7 @@ int v2p_decode_run(v2p_ctx* ctx, const uint8_t* text, uint64_t n_text,
             break;
         }
         d->n_ids = d->hap_begin[n_haps];
-        DTRY(hipMalloc(reinterpret_cast<void**>(&d->d_ids), (d->n_ids + 64) * sizeof(uint32_t)), "hipMalloc(ids)");
+        DTRY(dmalloc(reinterpret_cast<void**>(&d->d_ids), (d->n_ids + 64) * sizeof(uint32_t)), "hipMalloc(ids)");
         a.ids = d->d_ids; a.ids_capacity = d->n_ids;
         DTRY(launch_decode(a, st, 8u), "emit_kernel");
         DTRY(hipEventRecord(ev[4], st), "hipEventRecord");
