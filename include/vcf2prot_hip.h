@@ -406,7 +406,8 @@ typedef struct {
                                   * 23 / 25: no staging of a padded image's descriptors / dense rows images staged as well;
                                   * 23 / 26: a padded image stays padded when it is executed again (read in place / staged);
                                   * 27: a padded image is built in three slices whose parses are launched ahead of the cutters (measured slower);
-                                  * 28: a dense rows image that is executed again stays on stitch_dense_kernel (never re-written as pieces))      */
+                                  * 28: a dense rows image that is executed again stays on stitch_dense_kernel (never re-written as pieces);
+                                  * 29: v2p_batch_build_and_execute behaves as if the device had no room for its one-pass scratch (tests of the fallback))   */
 } v2p_launch_opts;
 /* src0/src1 must have 32 readable bytes before and after (the kernel loads whole aligned 16-byte
  * blocks around a task's bytes), and so must d_desc (16 before, 32 after: stitchw_kernel reads an immediate descriptor's literal

@@ -150,6 +150,35 @@ def test_a_refused_cut_in_recycled_memory_falls_back(built, gpu_ctx):
         rs.close()
 
 
+def test_no_room_for_the_one_pass_scratch_falls_back_inside_the_call(built, gpu_ctx, coracle):
+    """hipErrorOutOfMemory for the one call's scratch (its padded descriptor array is up to 2 KiB per tile): nothing has been launched yet,
+    the scratch is released and the call builds in one piece -- whose builder has a two-pass form without that array -- and executes.
+    v2p_set_launch_opts variant 29 plays the full device."""
+    from vcf2prot_amd.cohort import Cohort
+    c = Cohort.preset("C3")
+    gpu_ctx.upload_proteome(c.proteome())
+    stream = c.txstream(40, 100, n_threads=8)
+    rs = gpu_ctx.upload_stream(stream)
+    stream.close()
+    b = gpu_ctx.batch()
+    b.build_and_execute(rs, 0, 0); b.sync()
+    assert b.oneshot_info()["n_slices"] == 1
+    dig = b.digests()
+    b.reset()
+    gpu_ctx.set_launch_opts(variant=29)
+    try:
+        b.build_and_execute(rs, 0, 0); b.sync()
+    finally:
+        gpu_ctx.set_launch_opts()
+    assert b.oneshot_info()["n_slices"] == 0                # the one-piece builder ran
+    assert np.array_equal(b.digests(), dig)
+    assert np.array_equal(b.download_hap(7), oracle_hap(c, coracle, 47))
+    b.execute(); b.sync()
+    assert np.array_equal(b.digests(), dig)
+    b.close()
+    rs.close()
+
+
 def test_a_tile_that_overflows_its_slots_falls_back_inside_the_call(built, gpu_ctx):
     """One transcript with thousands of Tasks: its tile's descriptors do not fit the one-pass stage, the sliced builder declines and the
     call builds in one piece (two-pass form) and executes -- same bytes, n_slices reported as 0."""

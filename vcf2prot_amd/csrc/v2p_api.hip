@@ -2073,16 +2073,20 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     if (S > V2P_MAX_SLICES) S = V2P_MAX_SLICES;
     while (S > 1 && n_tiles / S < 64) --S;
     auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
+    // (the call's scratch and its image: when the device has no room for the one-pass form -- its padded descriptor array is up to 2 KiB per
+    // tile -- nothing has been launched yet and the call builds in one piece instead, whose builder has a two-pass form without it)
+#define OS_ALLOC(expr, what) do { hipError_t e__ = (expr); if (e__ == hipErrorOutOfMemory) { (void)hipGetLastError(); b->d_tiles.release(); b->d_cover.release(); b->d_pad.release(); b->d_order.release(); *fallback = true; return V2P_OK; } \
+                                  if (e__ != hipSuccess) return c->hip_fail(e__, what); } while (0)
     // ---- memory: everything before the first kernel (a batch that is rebuilt recycles all of it) ----
     uint64_t off = 0;
     auto carve = [&](uint64_t bytes) { const uint64_t o = off; off += up8(bytes); return o; };
     const uint64_t o_tbytes = carve(n_tiles * 8), o_tbase = carve((n_tiles + 1) * 8), o_tcount = carve((n_tiles + 1) * 4), o_tdbase = carve((n_tiles + 2) * 8),
                    o_totals = carve(64), o_scan = carve((rows_scan_scratch_entries(n_tiles) + scan_tiles_for(n_tiles + 1)) * 8);
-    HIP_TRY(c, b->d_tiles.ensure_exact(off), "hipMalloc(tile tables)");
+    OS_ALLOC(bvar == 29u ? hipErrorOutOfMemory : b->d_tiles.ensure_exact(off), "hipMalloc(tile tables)");      // (variant 29, tests: as if the device had no room)
     uint8_t* const d = b->d_tiles.ptr();
     const uint64_t c_cover = 0, c_segc = up8((n_rows + 1) * 8), c_segb = c_segc + up8((n_segs + 1) * 4), c_tiles = c_segb + up8((n_segs + 2) * 8),
                    c_cpad = c_tiles + up8(scan_tiles_for(n_segs + 1) * 8), c_end = c_cpad + up8(n_segs * ROWS_CHUNK_PAD * sizeof(Chunk));
-    HIP_TRY(c, b->d_cover.ensure_exact(c_end), "hipMalloc(row map)");
+    OS_ALLOC(b->d_cover.ensure_exact(c_end), "hipMalloc(row map)");
     uint64_t T[V2P_MAX_SLICES + 1], max_tiles = 0;
     for (uint32_t j = 0; j <= S; ++j) T[j] = n_tiles * j / S;
     for (uint32_t j = 0; j < S; ++j) if (T[j + 1] - T[j] > max_tiles) max_tiles = T[j + 1] - T[j];
@@ -2095,9 +2099,9 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     // 64 MB phases) would half-fill its staging rows and double what a phase keeps in the caches: it keeps the compaction, and so do
     // dense images (chunks of up to 1 024 descriptors).  The rule looks at the stream (result bytes per Task); variants 22 / 24 force
     // the compacted / the padded form (A/B).
-    if (!pad) HIP_TRY(c, b->d_pad.ensure_exact(max_tiles * ROWS_PAD_SLOTS * 8), "hipMalloc(padded descriptors)");
+    if (!pad) OS_ALLOC(b->d_pad.ensure_exact(max_tiles * ROWS_PAD_SLOTS * 8), "hipMalloc(padded descriptors)");
     const uint64_t desc_cap = n_tiles * ROWS_PAD_SLOTS;              // (one-pass tiles hold at most their 256 slots)
-    HIP_TRY(c, b->d_desc.ensure_exact(desc_cap * 8), "hipMalloc(desc)");
+    OS_ALLOC(b->d_desc.ensure_exact(desc_cap * 8), "hipMalloc(desc)");
     const uint64_t cap = n_segs ? n_segs * ROWS_CHUNK_PAD : 1;
     const uint64_t n_blocks_cap = order_blocks_thread_blocks(cap, XCD_ORDER_MAX_BLOCKS);
     const uint64_t n_sub_cap = uint64_t(XCD_SUB) * n_blocks_cap;
@@ -2105,8 +2109,8 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
                    s_sub = s_hist + up8((n_blocks_cap + 1) * 8 * 4), s_tmp2 = s_sub + up8(cap), s_bucket2 = s_tmp2 + up8(cap * 16),
                    s_subhist = s_bucket2 + up8(cap), s_substart = s_subhist + up8(n_sub_cap * 4), s_subtiles = s_substart + up8((n_sub_cap + 1) * 8),
                    s_tot = s_subtiles + up8(scan_tiles_for(n_sub_cap) * 8), s_end = s_tot + up8(uint64_t(XCD_ORDER_MAX_BLOCKS) * 8 * 4);
-    HIP_TRY(c, b->d_order.ensure_exact(s_end), "hipMalloc(build scratch)");
-    HIP_TRY(c, b->d_chunks.ensure_exact(cap * sizeof(Chunk)), "hipMalloc(chunks)");
+    OS_ALLOC(b->d_order.ensure_exact(s_end), "hipMalloc(build scratch)");
+    OS_ALLOC(b->d_chunks.ensure_exact(cap * sizeof(Chunk)), "hipMalloc(chunks)");
     HIP_TRY(c, b->d_out.ensure((out_bytes + 15) & ~15ull), "hipMalloc(out)");
     HIP_TRY(c, b->d_hap.ensure((n_h + 1) * 8), "hipMalloc(hap_begin)");
     HIP_TRY(c, b->d_digest.ensure((n_h ? n_h : 1) * 8), "hipMalloc(digest)");
@@ -2277,6 +2281,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
             OS_TRY(stitch_range(b, desc_cap, b->slice_chunk0[j], b->slice_chunk0[j + 1] - b->slice_chunk0[j], b->slice_desc[j], b->slice_bytes[j], A), "launch(stitch)");
     }
 #undef OS_TRY
+#undef OS_ALLOC
     b->slice_chunk0[S] = chunk0;
     HIP_TRY(c, hipEventRecord(b->ev_os[1], A), "hipEventRecord");
     b->n_desc = desc0; b->n_chunks = chunk0; b->n_slices = S;
