@@ -17,6 +17,9 @@ The N = 1 line also carries
   c2_cohort       BASELINE.json configs[1] ("C2": 1 000 samples x 20 k transcripts, one missense each) the same way
   cpu_baseline    the oracle's reference-faithful flavour on this box's host cores (bounded sample)
   incl_transfers  PCIe-inclusive rate through v2p_pipeline_* (not `value`)
+and roofline.traffic measured in the run itself: last of all, two child runs of this file under `rocprofv3 --pmc FETCH_SIZE` / `--pmc
+WRITE_SIZE` (separate passes, --kernel-trace only beside them) execute the same image between two marker launches; any failure there
+leaves the figure replayed from profiles/traffic_latest.json, labelled so (--no-live-traffic: skip).
 
 --gpus N > 1 launches itself: the parent spawns `python -m torch.distributed.run` with N ranks (one per GPU, RCCL) before it touches
 any GPU, and exits with the children's code; under an external launcher (RANK/WORLD_SIZE set) it just runs as a rank.
@@ -60,6 +63,9 @@ def parse_args():
                                                                 "the other ranks would wait in a barrier for it, and the driver computes the scaling curve from its own N = 1 run")
     ap.add_argument("--clock-settle-ms", type=float, default=50.0, help="GPU kept busy with the checker's digest kernel for this long right before the W warm-up steps (0: off): the "
                     "clocks are down after the host's oracle checks and W short steps of a small shard do not bring them back")
+    ap.add_argument("--no-live-traffic", action="store_true", help="N = 1: do not measure roofline.traffic in this run (two child runs of this file under rocprofv3 --pmc, "
+                    "about a minute); the figure is then replayed from profiles/traffic_latest.json and labelled so")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)      # (the child of live_traffic(): the image, a few executes between two digest launches, nothing else)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the transfers-inclusive leg (v2p_pipeline_*)")
     ap.add_argument("--verify", default="all", choices=["all", "sample", "none"], help="haplotypes whose digest is compared with the oracle before timing")
@@ -416,8 +422,95 @@ def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verif
     return res
 
 
+def traffic_child(args):
+    """What live_traffic() runs under rocprofv3: this workload's image through the one call, warm-up executes, then K executes BETWEEN TWO
+    digest launches (the markers the parent finds the K steps by).  No oracle, no second leg; prints one JSON line."""
+    from vcf2prot_amd import build
+    build.build_hip(); build.build_cohort()
+    from vcf2prot_amd.cohort import Cohort
+    from vcf2prot_amd.engine import Context
+    samples = args.samples or DEFAULT_SAMPLES[args.scaling][args.workload]
+    cohort = Cohort.preset(args.workload, n_samples=samples)
+    nt = max(1, min(64, os.cpu_count() or 1))
+    stream = cohort.txstream(0, cohort.n_haplotypes, n_threads=nt)
+    with Context(0, temporal_stores=args.temporal) as ctx:
+        ctx.upload_proteome(cohort.proteome())
+        rs = ctx.upload_stream(stream)
+        stream.close()
+        b = ctx.batch()
+        b.build_and_execute(rs, 0, 0); b.sync()
+        for _ in range(3):
+            b.execute()
+        b.sync()
+        b.digests()
+        for _ in range(args.steps):
+            b.execute()
+        b.sync()
+        b.digests()
+        print(json.dumps({"traffic_child": True, "steps": args.steps, "haplotypes": cohort.n_haplotypes}))
+        b.close(); rs.close()
+
+
+def live_traffic(args, steps=3, timeout_s=240):
+    """roofline.traffic measured in THIS run: two child runs of this file under `rocprofv3 --pmc` -- FETCH_SIZE, then WRITE_SIZE: separate
+    passes, as MI355X_MICROARCH.md's HBM section prescribes; --kernel-trace only beside them -- each building the same image and executing it
+    `steps` times between two digest launches.  Bytes per step = (2 x FETCH_SIZE + WRITE_SIZE) x 1 024 summed over the dispatches between the
+    markers / steps (FETCH_SIZE doubled: the guide's gfx950 correction for wide coalesced reads).  Returns (bytes per step or None, how)."""
+    import csv, glob, shutil, signal, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="v2p_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable, os.path.abspath(__file__), "--traffic-child",
+               "--workload", args.workload, "--scaling", args.scaling, "--samples", str(args.samples), "--steps", str(steps)] + (["--temporal"] if args.temporal else [])
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+        env["TMPDIR"] = "/tmp"
+        try:
+            p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd="/tmp", start_new_session=True)
+            try:
+                out, err = p.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)            # (the exact process group this call started)
+                except OSError:
+                    pass
+                p.communicate()
+                return None, f"the {counter} pass did not finish in {timeout_s} s"
+            if p.returncode != 0:
+                return None, f"the {counter} pass failed: " + (err or b"").decode(errors="replace")[-300:]
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"the {counter} pass wrote no counter file"
+            per = {}                                            # dispatch -> (kernel, value): a dispatch's counter comes in one row per XCD / dimension
+            for r in csv.DictReader(open(files[0])):
+                if r.get("Counter_Name") != counter:
+                    continue
+                k = int(r["Dispatch_Id"])
+                name, v = per.get(k, (r["Kernel_Name"], 0.0))
+                per[k] = (name, v + float(r["Counter_Value"]))
+            order = sorted(per)
+            marks = [k for k in order if "digest" in per[k][0]]
+            if len(marks) < 2:
+                return None, f"the {counter} pass: the marker launches are not in the trace"
+            # (between the markers: the K executes' stitch launches and read-ahead kernels -- and the first marker's own copy-back, which is not a step's)
+            between = [per[k] for k in order if marks[-2] < k < marks[-1] and (("stitch" in per[k][0] and "_kernel" in per[k][0]) or "touch_image" in per[k][0])]
+            if not between:
+                return None, f"the {counter} pass: no stitch launch between the markers"
+            got[counter] = sum(v for _, v in between) * 1024.0 / steps
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], (
+        f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over {steps} executes of the same image in child runs of this "
+        f"file; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per execute -- FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction "
+        f"(fetch {2.0 * got['FETCH_SIZE'] / 1e9:.2f} GB, write {got['WRITE_SIZE'] / 1e9:.2f} GB)")
+
+
 def main():
     args = parse_args()
+    if args.traffic_child:
+        return traffic_child(args)
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -640,6 +733,22 @@ def main():
                     line["incl_transfers"] = {"error": repr(e)}
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(cohort, h0, n_haps, os.cpu_count() or 1)
+            if not args.no_live_traffic and not args.host_image:
+                # LAST (every number above stands whatever happens here): the PMC passes in child processes; on any failure the replayed figure stays
+                try:
+                    torch.cuda.empty_cache()
+                    t_live = time.perf_counter()
+                    tb, how = live_traffic(args)
+                    if tb is not None:
+                        line["roofline"]["traffic_replayed"] = {"bytes": line["roofline"]["traffic"], "source": line["roofline"]["traffic_source"]}
+                        line["roofline"]["traffic"] = tb
+                        line["roofline"]["traffic_source"] = how
+                        line["roofline"]["traffic_over_hbm_bytes_min"] = tb / leg["hbm_bytes_min_per_launch"]
+                    else:
+                        line["roofline"]["traffic_live_failed"] = how
+                    line["roofline"]["traffic_live_seconds"] = time.perf_counter() - t_live
+                except Exception as e:                         # noqa: BLE001
+                    line["roofline"]["traffic_live_failed"] = repr(e)[:300]
         print(json.dumps(line))
     if dist_on:
         dist.barrier()
