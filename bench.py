@@ -460,6 +460,8 @@ def live_traffic(args, steps=3, timeout_s=240):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
         return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself being profiled: no profiler inside a profiler"
     got = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="v2p_pmc_", dir="/tmp")
