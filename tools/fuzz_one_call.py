@@ -68,10 +68,14 @@ with Context(0) as ctx:
         rng = np.random.default_rng(seed + 31337)
         shape = ("snv", "mix", "long")[seed % 3]
         window = int(rng.choice([4096, 8192]))
-        proteome, stream, want = random_stream(rng, n_haps=int(rng.integers(1, 120)), n_ref_tx=int(rng.integers(1, 30)), shape=shape, window=window)
+        if seed % 2:                                                                   # (odd seeds: FASTA emit through the two-call builders too)
+            proteome, headers, stream, want = random_stream(rng, n_haps=int(rng.integers(1, 120)), n_ref_tx=int(rng.integers(1, 30)), shape=shape, window=window, fasta=True)
+            ctx.upload_reference(proteome, headers)
+        else:
+            proteome, stream, want = random_stream(rng, n_haps=int(rng.integers(1, 120)), n_ref_tx=int(rng.integers(1, 30)), shape=shape, window=window)
+            ctx.upload_proteome(proteome)
         # (a kind's own window sizes: per-block kernels multiples of 4 KiB up to 60 KiB, the dense kernel 4 / 8 / 12 KiB, wave kernels multiples of 1 KiB up to 10)
         windows = {1: [4096, 8192, 16384, 28672], 2: [4096, 8192, 16384, 32768], 3: [4096, 8192, 12288], 4: [1024, 2048, 4096, 10240], 5: [2048, 3072, 4096, 6144, 10240]}
-        ctx.upload_proteome(proteome)
         for kernel in (1, 2, 3, 4, 5, 6, 7, 0):
             window = int(rng.choice(windows[kernel])) if kernel in windows else (4096 if kernel == 0 else 0)      # (0 with a window: round 3's routing among the grid kinds)
             cfg = {"seed": seed, "shape": shape, "window": window, "kernel": kernel, "two_call": True}
