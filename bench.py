@@ -232,6 +232,7 @@ class Timed:
         self.ctx.set_stream(ts.cuda_stream)
         barrier()                                               # (ranks meet BEFORE warming up: a rank that finished its checks early must not idle -- clocks down again -- between its warm-up and the timed region)
         self.settled_ms = self.settle_clocks(settle_ms)
+        self.b.scribble()                                       # (the arena verified before is overwritten: what is digested after the timed steps is what THEY wrote, in the image's re-execution form)
         for _ in range(warmup):
             self.b.execute()
         self.b.sync()
@@ -403,7 +404,7 @@ def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verif
         elapsed, kern_ms = timed.run(steps, warmup, barrier, settle_ms)
         res.update({"elapsed_s": elapsed, "kernel_ms": kern_ms, "image_timed": "host-packed" if time_host_image else "device-built", "clock_settle_ms": timed.settled_ms})
         # ---- parity AFTER timing: the timed steps re-execute the image in its re-execution form (a padded image made dense, its descriptors
-        # staged; a dense image from its pieces) -- the arena they leave must be the one that was verified above
+        # staged; a dense image from its pieces) -- the arena they leave must be the one that was verified above (Timed.run scribbled it in between)
         if not time_host_image:
             after = b.digests()
             if not np.array_equal(after, dig):

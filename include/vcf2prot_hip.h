@@ -273,7 +273,11 @@ typedef struct v2p_stream v2p_stream;
 /* the stream's arrays to the device (the host copy may be freed on return); V2P_ERR_INVALID_ARG / _SRC_OOB with the offending index
  * as v2p_batch_build_on_device reports them */
 int  v2p_stream_upload(v2p_ctx* ctx, const v2p_txstream* s, v2p_stream** out);
-/* waits for the device; a batch built from the stream must not execute afterwards (its payload descriptors read the stream's alt bytes) */
+/* Waits for the context's own streams (not for the device: other contexts keep running).  A batch built from the stream registers with
+ * it, and its payload descriptors read the stream's alt bytes: destroying the stream ORPHANS those batches -- v2p_batch_execute on an
+ * orphan is V2P_ERR_STATE, never a read of freed memory; its arena is the batch's own and stays readable (v2p_batch_download,
+ * v2p_batch_digests, v2p_batch_sync); v2p_batch_reset makes the batch buildable again.  (The reference cannot dangle here: GIR::execute(self)
+ * consumes its tapes, gir.rs:197,230-234.) */
 void v2p_stream_destroy(v2p_stream* s);
 int  v2p_stream_counts(const v2p_stream* s, uint64_t* n_haps, uint64_t* n_tx, uint64_t* n_tasks, uint64_t* out_bytes);
 /* the one-piece builder (kernel 6 / 7 / 8; 0: by the routing rule, a dense image when a wave image is refused) on a resident stream: no H2D */
@@ -364,6 +368,10 @@ int v2p_batch_download(v2p_batch* b, uint64_t begin, uint64_t len, uint8_t* out)
 int v2p_batch_digests(v2p_batch* b, uint64_t* digests, uint64_t n_haps);
 /* device pointer of the result arena (for callers that keep consuming on the GPU) */
 void* v2p_batch_device_out(v2p_batch* b);
+/* For checkers: overwrite the whole arena with `byte` (enqueued on the context's stream).  An image that is executed AGAIN writes the
+ * bytes the first execute already left there, so a re-execution form that skipped chunks or wrote nothing would still pass a comparison:
+ * every test, fuzzer and bench leg that verifies a re-execute scribbles first. */
+int v2p_batch_scribble(v2p_batch* b, int byte);
 
 /* ---- streamed pipeline: results that must return to the host ------------------------------ */
 /* n_slots images are in flight at once, each on its own HIP stream: while image k's results

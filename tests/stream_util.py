@@ -114,3 +114,49 @@ def random_stream(rng, n_haps, n_ref_tx, shape, window, fasta=False):
         return (proteome, np.frombuffer(bytes(headers), dtype=np.uint8),
                 Stream(hap_tx_begin, tx_off, tx_ref_len, tx_res_len, tx_task_begin, tx_alt_begin, code, sp, ln, sr, alt, hoff, hlen), want)
     return proteome, Stream(hap_tx_begin, tx_off, tx_ref_len, tx_res_len, tx_task_begin, tx_alt_begin, code, sp, ln, sr, alt), want
+
+
+def regular_stream(n_haps, tx_per_hap, dense_every=1, seed=0, ref_len=1000, run=40, sub=8):
+    """A large regular stream built with numpy alone (millions of Tasks in a second): every haplotype carries `tx_per_hap` transcripts of
+    `ref_len` residues.  A DENSE transcript alternates a reference run of `run` residues with `sub` substituted residues from its alt tape
+    (a delins per run + sub residues: about 1024 / (run + sub) * 2 descriptors per KiB of result, none of them fusable or immediate for
+    sub > 5); the others are ONE reference copy.  Haplotype h is dense when h % dense_every == 0.  Returns (proteome, Stream, want(h) ->
+    expected bytes of haplotype h)."""
+    rng = np.random.default_rng(seed)
+    AA = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    n_ref_tx = 64
+    proteome2d = AA[rng.integers(0, AA.size, size=(n_ref_tx, ref_len))]
+    pairs = ref_len // (run + sub) - 1                       # (run, sub) pairs, then the rest of the reference
+    tail0 = pairs * (run + sub)
+    # one dense transcript's Tasks, relative to the transcript
+    k = np.arange(pairs)
+    d_code = np.concatenate([np.stack([np.zeros(pairs, np.uint8), np.ones(pairs, np.uint8)], 1).ravel(), [0]]).astype(np.uint8)
+    d_sp = np.concatenate([np.stack([k * (run + sub), k * sub], 1).ravel(), [tail0]]).astype(np.uint32)
+    d_ln = np.concatenate([np.stack([np.full(pairs, run), np.full(pairs, sub)], 1).ravel(), [ref_len - tail0]]).astype(np.uint32)
+    d_sr = np.concatenate([np.stack([k * (run + sub), k * (run + sub) + run], 1).ravel(), [tail0]]).astype(np.uint32)
+    nd = d_code.size
+    dense_h = (np.arange(n_haps) % dense_every) == 0
+    tx_dense = np.repeat(dense_h, tx_per_hap)
+    n_tx = n_haps * tx_per_hap
+    tx_id = rng.integers(0, n_ref_tx, size=n_tx)
+    n_tasks_tx = np.where(tx_dense, nd, 1)
+    tx_task_begin = np.concatenate([[0], np.cumsum(n_tasks_tx)]).astype(np.uint64)
+    tx_alt_begin = np.concatenate([[0], np.cumsum(np.where(tx_dense, pairs * sub, 0))]).astype(np.uint64)
+    n_tasks = int(tx_task_begin[-1])
+    code = np.zeros(n_tasks, np.uint8); sp = np.zeros(n_tasks, np.uint32); ln = np.full(n_tasks, ref_len, np.uint32); sr = np.zeros(n_tasks, np.uint32)
+    first = tx_task_begin[:-1][tx_dense].astype(np.int64)
+    idx = (first[:, None] + np.arange(nd)[None, :]).ravel()
+    code[idx] = np.tile(d_code, first.size); sp[idx] = np.tile(d_sp, first.size); ln[idx] = np.tile(d_ln, first.size); sr[idx] = np.tile(d_sr, first.size)
+    alt = AA[rng.integers(0, AA.size, size=int(tx_alt_begin[-1]))]
+    hap_tx_begin = (np.arange(n_haps + 1) * tx_per_hap).astype(np.uint64)
+    stream = Stream(hap_tx_begin, tx_id.astype(np.uint64) * ref_len, np.full(n_tx, ref_len, np.uint32), np.full(n_tx, ref_len, np.uint32),
+                    tx_task_begin, tx_alt_begin, code, sp, ln, sr, alt)
+    cols = (k[:, None] * (run + sub) + run + np.arange(sub)[None, :]).ravel()
+
+    def want(h):
+        t0, t1 = h * tx_per_hap, (h + 1) * tx_per_hap
+        out = proteome2d[tx_id[t0:t1]].copy()
+        if dense_h[h]:
+            out[:, cols] = alt[int(tx_alt_begin[t0]):int(tx_alt_begin[t1])].reshape(tx_per_hap, pairs * sub)
+        return out.ravel()
+    return proteome2d.ravel().copy(), stream, want

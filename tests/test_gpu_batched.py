@@ -62,6 +62,7 @@ def test_c3_whole_cohort_on_one_gpu_every_haplotype_by_digest(built, gpu_ctx, co
     db.execute()
     db.sync()
     dig_dev = db.digests()
+    db.scribble()
     db.execute()                                             # executed again: descriptors staged by the read-ahead, 44 MB phases (round 5)
     db.sync()
     assert np.array_equal(db.digests(), dig_dev) and db.image_form()["staging_buffers"]
@@ -77,6 +78,7 @@ def test_c3_whole_cohort_on_one_gpu_every_haplotype_by_digest(built, gpu_ctx, co
     form = ob.image_form()
     assert form["padded"] and form["staging_buffers"], form
     assert np.array_equal(ob.digests(), dig_dev), "the one call's padded, staged image"
+    ob.scribble()
     ob.execute()
     ob.sync()
     assert not ob.image_form()["padded"] and np.array_equal(ob.digests(), dig_dev), "the one call's image, made dense and executed again"

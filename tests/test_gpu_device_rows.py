@@ -143,7 +143,7 @@ def test_rows_builder_reports_what_the_reference_would_panic_on(built, gpu_ctx):
                 b.build_on_device(stream(code, sp, ln, sr), 0, kernel)
             assert ei.value.code == want_code and ei.value.index == row, (kernel, ei.value.code, ei.value.index)
             b.build_on_device(stream([0, 1, 0], [0, 0, 11], [10, 1, 49], [0, 10, 11]), 0, kernel)     # the batch is reusable
-            b.execute(); b.sync()
+            b.scribble(); b.execute(); b.sync()
             assert b.download_hap(0).tobytes() == bytes(prot[:10]) + b"A" + bytes(prot[11:])
             b.close()
 
@@ -174,7 +174,7 @@ def test_rows_builder_falls_back_for_tiles_that_do_not_fit_the_stage(built, gpu_
         b = gpu_ctx.batch()
         b.build_on_device(s, 0, kernel)
         _same_image(gpu_ctx, b, s, prot.size, 1 if kernel == 6 else 2)
-        b.execute(); b.sync()
+        b.scribble(); b.execute(); b.sync()
         got = b.download_hap(0)
         assert np.array_equal(got[:L], want) and np.array_equal(got[L:], prot)
         b.close()

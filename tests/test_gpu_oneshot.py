@@ -60,7 +60,8 @@ def test_sliced_build_and_execute_equals_the_one_piece_builder_and_the_oracle(bu
     assert np.array_equal(b.digests(), dig1)
     for i in range(0, n, max(1, n // 30)):
         assert np.array_equal(b.download_hap(i), oracle_hap(c, coracle, h0 + i)), (preset, h0 + i)
-    # the batch is an ordinary finalized batch: executing it again changes nothing
+    # the batch is an ordinary finalized batch: executing it again leaves the same arena (scribbled first: the re-execute must WRITE it)
+    b.scribble()
     b.execute()
     b.sync()
     assert np.array_equal(b.digests(), dig1)
@@ -119,6 +120,7 @@ def test_random_fasta_streams_in_one_call(built, gpu_ctx, seed, shape, kernel):
         for h, w in enumerate(want):
             got = b.download_hap(h)
             assert got.size == w.size and np.array_equal(got, w), (seed, shape, kernel, rep, h)
+        b.scribble()
         b.execute()
         b.sync()
     b.close()
@@ -144,6 +146,7 @@ def test_a_refused_cut_in_recycled_memory_falls_back(built, gpu_ctx):
             for rep in range(2):
                 for h, w in enumerate(want):
                     assert np.array_equal(b.download_hap(h), w), (seed, kernel, rep, h)
+                b.scribble()
                 b.execute()
                 b.sync()
             b.close()
@@ -173,7 +176,7 @@ def test_no_room_for_the_one_pass_scratch_falls_back_inside_the_call(built, gpu_
     assert b.oneshot_info()["n_slices"] == 0                # the one-piece builder ran
     assert np.array_equal(b.digests(), dig)
     assert np.array_equal(b.download_hap(7), oracle_hap(c, coracle, 47))
-    b.execute(); b.sync()
+    b.scribble(); b.execute(); b.sync()
     assert np.array_equal(b.digests(), dig)
     b.close()
     rs.close()
@@ -319,7 +322,7 @@ def test_degenerate_streams_in_one_call(built, gpu_ctx, kernel):
         for h, w in enumerate(want):
             assert b.download_hap(h).tobytes() == w, (kernel, h)
         if want:
-            b.execute(); b.sync()
+            b.scribble(); b.execute(); b.sync()
             assert b.download_hap(len(want) - 1).tobytes() == want[-1]
         b.close()
         rs.close()
@@ -348,12 +351,12 @@ def test_padded_wave_image_is_the_dense_one(built, gpu_ctx, preset, h0, n, slice
             if var == 24:
                 for keep in (26, 23):                       # executed again as it is: staged, then read in place
                     gpu_ctx.set_launch_opts(variant=keep, **small)
-                    b.execute(); b.sync()
+                    b.scribble(); b.execute(); b.sync()
                     assert np.array_equal(b.digests(), d1), keep
             gpu_ctx.set_launch_opts(variant=0, **small)     # ... and as the product does: made dense at the first re-execute
-            b.execute(); b.sync()
+            b.scribble(); b.execute(); b.sync()
             assert np.array_equal(b.digests(), d1)
-            b.execute(); b.sync()
+            b.scribble(); b.execute(); b.sync()
             assert np.array_equal(b.digests(), d1)
             imgs[var] = (b.download_image(), d1, b.counts())
             b.reset()                                       # the batch recycles its buffers for a padded build again

@@ -162,7 +162,7 @@ def test_patch_builder_reports_what_the_reference_would_panic_on(built, gpu_ctx)
                 b.build_on_device(stream(bad_tx, bad), 0, 8)
             assert ei.value.code == want_code and ei.value.index == 3 * bad_tx + row, (bad, bad_tx, ei.value.code, ei.value.index)
             b.build_on_device(stream(0, None), 0, 8)                       # the batch is reusable
-            b.execute(); b.sync()
+            b.scribble(); b.execute(); b.sync()
             one = bytes(prot[:10]) + b"A" + bytes(prot[11:])
             assert b.download_hap(1).tobytes() == one * (n_tx - n_tx // 2)
             b.close()
@@ -191,6 +191,6 @@ def test_a_window_with_too_many_segments_is_declined_not_mangled(built, gpu_ctx)
         b.build_on_device(s, 0, 8)
     assert ei.value.code == -9
     b.build_on_device(s, 0, 7)
-    b.execute(); b.sync()
+    b.scribble(); b.execute(); b.sync()
     assert np.array_equal(b.download_hap(0), want)
     b.close()

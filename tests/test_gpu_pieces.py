@@ -25,25 +25,25 @@ def test_a_dense_image_executed_again_runs_from_pieces(built, gpu_ctx, coracle, 
     d1 = b.digests()
     for i in range(0, n, max(1, n // 20)):
         assert np.array_equal(b.download_hap(i), oracle_hap(c, coracle, h0 + i)), (preset, h0 + i)
-    b.execute(); b.sync()                                   # executed again: pieces
+    b.scribble(); b.execute(); b.sync()                                   # executed again: pieces
     assert b.image_form()["pieces"]
     assert np.array_equal(b.digests(), d1)
     for i in range(0, n, max(1, n // 20)):
         assert np.array_equal(b.download_hap(i), oracle_hap(c, coracle, h0 + i)), (preset, h0 + i)
-    b.execute(); b.sync()
+    b.scribble(); b.execute(); b.sync()
     assert np.array_equal(b.digests(), d1)
     try:
         gpu_ctx.set_launch_opts(variant=28)                 # A/B switch: the dense kernel again
-        b.execute(); b.sync()
+        b.scribble(); b.execute(); b.sync()
         assert np.array_equal(b.digests(), d1)
     finally:
         gpu_ctx.set_launch_opts()
     # the two-call form: the first v2p_batch_execute is the image's first execute (dense kernel), the second runs from pieces
     b2 = gpu_ctx.batch()
     b2.build_from_stream(rs, 7)
-    b2.execute(); b2.sync()
+    b2.scribble(); b2.execute(); b2.sync()
     assert not b2.image_form()["pieces"] and np.array_equal(b2.digests(), d1)
-    b2.execute(); b2.sync()
+    b2.scribble(); b2.execute(); b2.sync()
     assert b2.image_form()["pieces"] and np.array_equal(b2.digests(), d1)
     b2.close(); b.close(); rs.close()
 
@@ -58,7 +58,7 @@ def test_random_streams_from_pieces(built, gpu_ctx, seed, shape):
     b = gpu_ctx.batch()
     b.build_and_execute(rs, 7, 0)
     b.sync()
-    b.execute(); b.sync()
+    b.scribble(); b.execute(); b.sync()
     assert b.image_form()["pieces"]
     for h, w in enumerate(want):
         got = b.download_hap(h)

@@ -45,7 +45,8 @@ def _run_device_built(gpu_ctx, c, n, threads, kernel):
     dig = np.array(b.digests(), dtype=np.uint64)
     cn = b.counts()
     # ... and executed AGAIN, in the image's re-execution form (round 5): a dense rows image from its pieces (csrc/dense_pieces.h), a rich
-    # wave image with its descriptors staged by the read-ahead -- the same arena
+    # wave image with its descriptors staged by the read-ahead -- the same arena, written again (scribbled in between)
+    b.scribble()
     b.execute()
     b.sync()
     assert np.array_equal(np.array(b.digests(), dtype=np.uint64), dig), "the re-executed image left another arena"

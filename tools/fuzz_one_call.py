@@ -52,7 +52,7 @@ with Context(0) as ctx:
                                 if got.size != w.size or not np.array_equal(got, w):
                                     bad.append({"seed": seed, "fasta": fasta, "shape": shape, "kernel": kernel, "slices": slices, "variant": variant, "rep": rep, "hap": h}); break
                             if os.environ.get('FUZZ_TRACE'): print(' checked', rep, file=sys.stderr, flush=True)
-                            b.execute(); b.sync()
+                            b.scribble(); b.execute(); b.sync()
                             if os.environ.get('FUZZ_TRACE'): print(' executed', rep, b.image_form(), file=sys.stderr, flush=True)
                         runs += 1
                     except Exception as e:                                           # noqa: BLE001
@@ -89,7 +89,7 @@ with Context(0) as ctx:
                         raise
                     continue                                                          # (an image kind asked for by number may not take the stream: too many descriptors in a window / a row)
                 for rep in range(2):
-                    b.execute(); b.sync()
+                    b.scribble(); b.execute(); b.sync()
                     for h, w in enumerate(want):
                         got = b.download_hap(h)
                         if got.size != w.size or not np.array_equal(got, w):

@@ -84,6 +84,7 @@ HIP_API = {
     "v2p_batch_download": (c_int, [c_void_p, c_uint64, c_uint64, c_void_p]),
     "v2p_batch_digests": (c_int, [c_void_p, c_void_p, c_uint64]),
     "v2p_batch_device_out": (c_void_p, [c_void_p]),
+    "v2p_batch_scribble": (c_int, [c_void_p, c_int]),
     "v2p_pipeline_create": (c_int, [c_void_p, c_uint32, POINTER(c_void_p)]),
     "v2p_pipeline_destroy": (None, [c_void_p]),
     "v2p_pipeline_submit": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_uint64, c_uint64,

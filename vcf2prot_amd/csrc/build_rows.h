@@ -57,7 +57,9 @@ struct RowsArgs {
     const uint64_t* seg_base;           // [n_segs + 1] exclusive prefix
     uint64_t  n_segs;
     Chunk*    chunks_tmp;               // arena order
-    Chunk*    chunks_pad;               // [n_segs * ROWS_CHUNK_PAD] the cutter's single pass
+    uint64_t  chunk_cap = ~0ull;        // records chunks_tmp (and bucket / sub) have room for: rows_chunk_compact_kernel never writes past it
+    Chunk*    chunks_pad;               // [n_segs * chunk_pad] the cutter's single pass
+    uint32_t  chunk_pad = 96;           // chunk slots per segment in chunks_pad (rows_chunk_pad_for)
     uint8_t*  bucket;
     uint8_t*  sub;
     uint64_t* hap_out_begin;
@@ -72,7 +74,22 @@ inline void rows_ranges(const RowsArgs& a, uint64_t& t0, uint64_t& t1, uint64_t&
 // arena bytes per tile (+ u64 exclusive scan into tile_res_base, total behind the last tile)
 hipError_t launch_rows_tile_bytes(const RowsArgs& a, uint64_t* scan_scratch, hipStream_t stream);
 uint64_t rows_scan_scratch_entries(uint64_t n);
-constexpr uint32_t ROWS_CHUNK_PAD = 96;            // chunk slots per segment of 640 rows in the cutter's padded table (64 ten-row chunks tile a segment)
+constexpr uint32_t ROWS_CHUNK_PAD = 96;            // chunk slots per segment of 640 rows in the cutter's padded table, at least (64 ten-row chunks tile a segment)
+// ... and for a stream of these sizes: a chunk takes rows while its descriptors fit its kernel (64 / 1024), so a stream of b result bytes
+// per Task fills a chunk after about max_desc * b / 1024 rows -- 1.5 x the segment's chunks at that rate, between 96 and 640 (one row per
+// chunk: the most a segment can hold).  Until round 5 the table had 96 slots whatever the stream: every wave image between 24 and ~100 bytes
+// per Task overflowed it, and the one call then built a second time in one piece.  16 bytes per slot, touched only where chunks are written.
+inline uint32_t rows_chunk_pad_for(uint64_t out_bytes, uint64_t n_items, int mode)
+{
+    const uint64_t max_rows = mode == ROWS_DENSE ? ROWS_MAX_DENSE : ROWS_MAX_WAVE, max_desc = mode == ROWS_DENSE ? CHUNK_TASKS_DEEP : CHUNK_TASKS_WAVE;
+    uint64_t rows = n_items ? max_desc * (out_bytes / n_items) / ROW_BYTES : max_rows;
+    if (rows < 1) rows = 1;
+    if (rows > max_rows) rows = max_rows;
+    uint64_t pad = (3u * ((ROWS_SEG + rows - 1) / rows) / 2u + 31u) & ~uint64_t(31);
+    if (pad < ROWS_CHUNK_PAD) pad = ROWS_CHUNK_PAD;
+    if (pad > ROWS_SEG) pad = ROWS_SEG;
+    return uint32_t(pad);
+}
 constexpr uint32_t ROWS_PAD_SLOTS = ROWS_TILE_SLOTS;           // descriptor slots per tile in the padded array (= build_rows.hip: ROWS_PAD)
 // the parse: mode ROWS_WAVE / ROWS_DENSE; phase 0: descriptors into the padded array + tile_count (a tile that does not fit its slots
 // is reported: STATUS_ROWS_STAGE), 1: tile_count only, 2: descriptors straight to desc + tile_desc_base[tile] (the two-pass form: any tile)
@@ -81,7 +98,7 @@ hipError_t launch_rows_parse(const RowsArgs& a, int mode, bool fasta, int phase,
 hipError_t launch_rows_compact(const RowsArgs& a, hipStream_t stream);
 hipError_t launch_rows_hap_begin(const RowsArgs& a, hipStream_t stream);
 // the cutter, pass 0: count (seg_count, totals[2] = last chunk's result offset); 1: emit at seg_base (the scan of seg_count) into
-// chunks_tmp; 2: count AND emit into chunks_pad (ROWS_CHUNK_PAD slots per segment; totals[3] != 0: a segment did not fit, run pass 1)
+// chunks_tmp; 2: count AND emit into chunks_pad (chunk_pad slots per segment; totals[3] != 0: a segment did not fit, run pass 1)
 hipError_t launch_rows_cut(const RowsArgs& a, int mode, int pass, hipStream_t stream);
 // pass 2's padded table -> chunks_tmp in arena order
 hipError_t launch_rows_chunk_compact(const RowsArgs& a, hipStream_t stream);

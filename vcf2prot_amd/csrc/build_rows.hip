@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void rows_hap_begin_kernel(RowsArgs a)
 
 // ---- the cutter: one wave per segment of ROWS_SEG rows ----------------------------------------------------------------------------
 // PASS 0: count the chunks of every segment (seg_count);  1: emit them at seg_base[seg] (after the scan of the counts);
-//      2: both at once -- counted, and emitted to the segment's ROWS_CHUNK_PAD slots of a padded table that a copy kernel compacts
+//      2: both at once -- counted, and emitted to the segment's chunk_pad slots (rows_chunk_pad_for) of a padded table that a copy kernel compacts
 //         after the scan (a segment with more chunks than slots raises totals[3]: the host then runs pass 1 instead of the copy)
 template <int PASS>
 __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_rows, uint32_t max_desc, uint64_t flag)
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
     }
     const uint64_t s0 = seg * ROWS_SEG, s1 = s0 + ROWS_SEG < a.n_rows ? s0 + ROWS_SEG : a.n_rows;
     uint32_t count = 0;
-    uint64_t out_k = PASS == 1 ? a.seg_base[seg] : (PASS == 2 ? seg * ROWS_CHUNK_PAD : 0);
+    uint64_t out_k = PASS == 1 ? a.seg_base[seg] : (PASS == 2 ? seg * a.chunk_pad : 0);
     Chunk* const table = PASS == 2 ? a.chunks_pad : a.chunks_tmp;
     uint64_t last_dst = 0;
     uint64_t r0 = s0;
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
             const uint32_t hb = 63u - uint32_t(__builtin_clzll(m));
             uint32_t ps = 0;
             if (EMIT && a.pad_chunks) ps = uint32_t(__builtin_amdgcn_readlane(int(pslot), int(cur)));
-            if (EMIT && lane == hb && (PASS != 2 || count < ROWS_CHUNK_PAD)) {
+            if (EMIT && lane == hb && (PASS != 2 || count < a.chunk_pad)) {
                 const uint64_t n = lastd - f + 1u;
                 // (a.pad_chunks: the record addresses the PADDED array, sir_pack.hpp -- its first descriptor as a slot, and for now how many
                 // descriptors its tile holds from there on in the bits that will say n1: rows_chunk_compact_kernel, lane = chunk, turns that
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64) void rows_cut_kernel(RowsArgs a, uint32_t max_r
     if (PASS != 1 && lane == 0) {
         a.seg_count[seg] = count;
         if (seg + 1u == a.n_segs) a.totals[2] = last_dst;
-        if (PASS == 2 && count > ROWS_CHUNK_PAD) atomicOr(reinterpret_cast<unsigned long long*>(a.totals) + 3, 1ull);
+        if (PASS == 2 && count > a.chunk_pad) atomicOr(reinterpret_cast<unsigned long long*>(a.totals) + 3, 1ull);
     }
 }
 
@@ -620,10 +620,15 @@ __global__ __launch_bounds__(256) void rows_chunk_compact_kernel(RowsArgs a)
     // (the one call launches this pass before the host has looked at the status word: behind a parse or a cut that was refused the padded
     // table holds whatever the memory held before -- nothing of it is followed)
     if (*a.status != STATUS_CLEAN) return;
+    // (... and behind a cut that found a segment with more chunks than its chunk_pad slots -- totals[3] bit 0, raised by the cutter
+    // that ran before this kernel on the same stream -- seg_base is the scan of the UNCLAMPED counts: the segments behind the full one
+    // would start past the table the caller sized for chunk_pad records per segment.  Nothing is written; the host sees the
+    // bit and runs the cutter's emitting pass (or, in the one call, builds in one piece).  chunk_cap bounds every store besides.)
+    if (a.totals[3] & 1ull) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t b0 = a.seg_base[seg], n = a.seg_base[seg + 1u] - b0;
-    for (uint32_t k = lane; k < n && k < ROWS_CHUNK_PAD; k += 64u) {
-        Chunk ch = a.chunks_pad[seg * ROWS_CHUNK_PAD + k];
+    for (uint32_t k = lane; k < n && k < a.chunk_pad && b0 + k < a.chunk_cap; k += 64u) {
+        Chunk ch = a.chunks_pad[seg * a.chunk_pad + k];
         if (a.pad_chunks) {
             // slot-addressed records (sir_pack.hpp): d1 -- the descriptors the first tile holds from the chunk's first one on -- becomes n1
             // (0: the chunk ends inside that tile); a chunk that would go on into a THIRD tile (tiles of a few descriptors) cannot be

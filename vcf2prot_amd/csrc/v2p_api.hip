@@ -167,6 +167,12 @@ struct v2p_batch {
     bool is_patch = false;
     uint64_t patch_segs = 0, patch_patches = 0;
     const uint8_t* payload_dev = nullptr;   // the alt bytes the image's payload descriptors read: d_payload, or a resident v2p_stream's
+    // ... in which case the batch is REGISTERED with that stream (gir.rs:197: GIR::execute(self) owns its tapes by move -- a dangling tape
+    // cannot exist there; here the tape is the stream's): v2p_stream_destroy orphans the batches built from it, and an orphan's image is
+    // never executed again (V2P_ERR_STATE) -- its arena, the batch's own memory, stays readable (download, digests)
+    struct v2p_stream* from_stream = nullptr;
+    bool orphaned = false;
+    uint64_t pieces_src0_len = 0, pieces_src1_len = 0;   // the source lengths to_pieces validated the piece image against
     // v2p_batch_build_and_execute: tables that outlive the call so that a batch that is rebuilt recycles them, the slices' chunk ranges
     // and the events of the last call (read by v2p_batch_oneshot_info after a sync)
     DevBuf d_tiles, d_cover, d_pad, d_order;
@@ -211,6 +217,9 @@ void ctx_unlock(v2p_ctx* c) { c->mu.unlock(); }
 
 struct GirQueue;
 static void queue_destroy(v2p_ctx* c);
+static void stream_attach(v2p_batch* b, const struct v2p_stream* st);
+static void stream_detach(v2p_batch* b);
+static void sync_ctx_streams(v2p_ctx* c);
 namespace {
 uint32_t narrow_chars(const uint32_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n);   // (AVX2 when the CPU has it: defined with the coalescing queue)
 void widen_chars(const uint8_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n);
@@ -1001,12 +1010,14 @@ void v2p_batch_destroy(v2p_batch* b)
 {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);
+    {
+        std::lock_guard<std::mutex> lk(b->ctx->mu);
+        stream_detach(b);
+        sync_ctx_streams(b->ctx);
+    }
     b->d_desc.release(); b->d_chunks.release(); b->d_payload.release(); b->d_out.release();
     b->d_hap.release(); b->d_digest.release(); b->d_status.release(); b->d_build.release();
     b->d_tiles.release(); b->d_cover.release(); b->d_pad.release(); b->d_order.release(); b->d_patch.release(); b->d_stage.release(); b->d_pieces.release(); b->d_chunks2.release(); b->h_sum.release();
-    if (b->ctx->build_stream) (void)hipStreamSynchronize(b->ctx->build_stream);
-    if (b->ctx->aux_stream) (void)hipStreamSynchronize(b->ctx->aux_stream);
     for (hipEvent_t e : b->ev_os) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : b->ev_aux) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : b->ev_par) if (e) (void)hipEventDestroy(e);
@@ -1232,25 +1243,32 @@ struct DevStreamView {
     const uint64_t* tx_header_off = nullptr; const uint32_t* tx_header_len = nullptr;      // FASTA emit (nullptr: plain tapes)
     bool fasta = false;
     double items_mean = 1.0, items_var = 0.0;          // items (Tasks; a transcript without Tasks is one) per transcript: rows_pick_k
+    double desc_mean = 1.0, desc_var = 0.0;            // ... and an upper estimate of the descriptors per transcript
 };
 
 static int build_patch_image(v2p_batch* b, const DevStreamView& v, float* build_ms, bool own_stream_copy, uint64_t known_out_bytes);
 
-// mean and spread of the items per transcript from a sample of the (host) stream
-static void stream_item_stats(const v2p_txstream* s, double* mean, double* var)
+// mean and spread of the items per transcript from a sample of the (host) stream -- and of an upper estimate of its DESCRIPTORS: a
+// one-residue alt Task between two reference copies fuses with both (one descriptor for three Tasks; transcript_instructions.rs:654-663
+// is where a missense becomes that triple), everything else is a descriptor of its own, plus a '.' tail
+static void stream_item_stats(const v2p_txstream* s, double* mean, double* var, double* dmean, double* dvar)
 {
-    *mean = 1.0; *var = 0.0;
+    *mean = 1.0; *var = 0.0; *dmean = 1.0; *dvar = 0.0;
     const uint64_t n_tx = s->n_tx;
     if (n_tx == 0) return;
     const uint64_t step = n_tx > 65536 ? n_tx / 65536 : 1;
-    double sum = 0, sq = 0, cnt = 0;
+    double sum = 0, sq = 0, dsum = 0, dsq = 0, cnt = 0;
     for (uint64_t u = 0; u < n_tx; u += step) {
-        const uint64_t nt = s->tx_task_begin[u + 1] - s->tx_task_begin[u];
+        const uint64_t t0 = s->tx_task_begin[u], t1 = s->tx_task_begin[u + 1], nt = t1 - t0;
         const double x = nt ? double(nt) : 1.0;                      // (a transcript without tasks is one item)
-        sum += x; sq += x * x; cnt += 1;
+        uint64_t nf = 0;
+        for (uint64_t i = t0 + 1; i + 1 < t1; ++i) nf += (s->code[i] == 1 && s->length[i] == 1 && s->code[i - 1] == 0 && s->code[i + 1] == 0) ? 1u : 0u;
+        const double d = (nt > 2 * nf ? double(nt - 2 * nf) : 1.0) + 1.0;
+        sum += x; sq += x * x; dsum += d; dsq += d * d; cnt += 1;
     }
-    const double m = sum / cnt;
+    const double m = sum / cnt, dm = dsum / cnt;
     *mean = m; *var = sq / cnt - m * m > 0 ? sq / cnt - m * m : 0.0;
+    *dmean = dm; *dvar = dsq / cnt - dm * dm > 0 ? dsq / cnt - dm * dm : 0.0;
 }
 
 // Tiles of K consecutive transcripts, one wave each (K <= 64: the kernel's prologue gives every transcript of the tile a lane).  A
@@ -1264,6 +1282,15 @@ static uint32_t rows_pick_k(const DevStreamView& v, int mode)
     const double m = v.items_mean, var = v.items_var, sd = sqrt(var);
     const double adv = mode == ROWS_DENSE ? 58.0 : 60.0, z = 1.3;
     const double k_cap = v.fasta ? 240.0 / (m + 2.0) : 64.0;         // FASTA: a header and a line feed per transcript on top
+    // ... and the tile's DESCRIPTORS must fit its 256 slots: where few Tasks fuse (runs of insertions, deletions, long payloads) the items
+    // are the descriptors, and a tile sized by its windows alone overflows -- the build then ran a second time in its two-pass form
+    double k_desc = 64.0;
+    {
+        const double dm = v.desc_mean + (v.fasta ? 2.0 : 0.0), dsd = sqrt(v.desc_var);
+        const double x = (-z * dsd + sqrt(z * z * v.desc_var + 4.0 * dm * 244.0)) / (2.0 * dm);
+        k_desc = floor(x * x);
+        if (k_desc < 1.0) k_desc = 1.0;
+    }
     uint32_t best_k = 1;
     double best_cost = 1e30;
     for (uint32_t w = 1; w <= 8; ++w) {
@@ -1274,6 +1301,7 @@ static uint32_t rows_pick_k(const DevStreamView& v, int mode)
         double k = floor(x * x);
         if (k > 64.0) k = 64.0;
         if (k > k_cap) k = floor(k_cap);
+        if (k > k_desc) k = k_desc;
         if (k < 1.0) k = 1.0;
         const double windows = 1.0 + (k * m + z * sd * sqrt(k) > 64.0 ? ceil((k * m + z * sd * sqrt(k) - 64.0) / adv) : 0.0);
         const double cost = (windows + 4.0) / k;                        // (a tile's fixed cost -- its dependent loads before the first window -- is worth about four windows)
@@ -1314,7 +1342,7 @@ static int upload_stream(v2p_ctx* c, const v2p_txstream* s, bool fasta, DevBuf& 
     v.tx_header_off = fasta ? reinterpret_cast<const uint64_t*>(d + o_hoff) : nullptr;
     v.tx_header_len = fasta ? reinterpret_cast<const uint32_t*>(d + o_hlen) : nullptr;
     v.fasta = fasta;
-    stream_item_stats(s, &v.items_mean, &v.items_var);
+    stream_item_stats(s, &v.items_mean, &v.items_var, &v.desc_mean, &v.desc_var);
     return V2P_OK;
 }
 
@@ -1378,9 +1406,11 @@ static int build_rows_image(v2p_batch* b, const DevStreamView& v, int mode, floa
     const uint64_t n_rows = (out_bytes + ROW_BYTES - 1) / ROW_BYTES, n_segs = (n_rows + ROWS_SEG - 1) / ROWS_SEG;
     if (n_rows > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 rows in one batch");
     a.out_bytes = out_bytes; a.n_rows = n_rows; a.n_segs = n_segs;
+    const uint32_t chunk_pad = rows_chunk_pad_for(out_bytes, v.n_tasks + (fasta ? 2 * n_tx : 0), mode);
+    a.chunk_pad = chunk_pad;
     // scratch of the parse and the count pass of the cutter: row map, chunks per segment + their scan
     const uint64_t c_cover = 0, c_segc = up8((n_rows + 1) * 8), c_segb = c_segc + up8((n_segs + 1) * 4), c_tiles = c_segb + up8((n_segs + 2) * 8),
-                   c_cpad = c_tiles + up8(scan_tiles_for(n_segs + 1) * 8), c_end = c_cpad + up8(n_segs * ROWS_CHUNK_PAD * sizeof(Chunk));
+                   c_cpad = c_tiles + up8(scan_tiles_for(n_segs + 1) * 8), c_end = c_cpad + up8(n_segs * chunk_pad * sizeof(Chunk));
     HIP_TRY(c, guard.cover.ensure_exact(c_end), "hipMalloc(row map)");
     a.cover = reinterpret_cast<uint64_t*>(guard.cover.ptr() + c_cover);
     a.seg_count = reinterpret_cast<uint32_t*>(guard.cover.ptr() + c_segc);
@@ -1467,7 +1497,7 @@ static int build_rows_image(v2p_batch* b, const DevStreamView& v, int mode, floa
     HIP_TRY(c, b->d_chunks.ensure(cap * sizeof(Chunk)), "hipMalloc(chunks)");
     HIP_TRY(c, b->d_out.ensure((out_bytes + 15) & ~15ull), "hipMalloc(out)");
     HIP_TRY(c, b->d_digest.ensure((n_h ? n_h : 1) * 8), "hipMalloc(digest)");
-    a.chunks_tmp = reinterpret_cast<Chunk*>(scratch.ptr() + s_tmp);
+    a.chunks_tmp = reinterpret_cast<Chunk*>(scratch.ptr() + s_tmp); a.chunk_cap = cap;
     a.bucket = scratch.ptr() + s_bucket;
     a.sub = scratch.ptr() + s_sub;
     HIP_TRY(c, hipEventRecord(guard.ev[6], c->stream), "hipEventRecord");
@@ -1868,7 +1898,33 @@ struct v2p_stream {
     const uint64_t* tile_res_base = nullptr;   // [n_tiles + 1]
     std::vector<uint64_t> h_tile_res_base;     // ... and on the host (a call that builds in slices cuts at these offsets without asking the device)
     const uint64_t* d_hap_out_begin = nullptr; // [n_haps + 1]
+    std::vector<v2p_batch*> batches;           // the batches whose images read this stream's alt bytes (under ctx->mu)
 };
+
+// every stream a context launches on: its own (or the caller's, v2p_set_stream) and the one call's build / compaction streams -- NOT the
+// device: other contexts of the process keep running (the finding of round 4 for v2p_init, of round 5 for v2p_stream_destroy)
+static void sync_ctx_streams(v2p_ctx* c)
+{
+    (void)hipStreamSynchronize(c->stream);
+    if (c->stream != c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->build_stream) (void)hipStreamSynchronize(c->build_stream);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    if (c->exec_aux) (void)hipStreamSynchronize(c->exec_aux);
+}
+static void stream_detach(v2p_batch* b)
+{
+    if (v2p_stream* st = b->from_stream) {
+        for (size_t i = 0; i < st->batches.size(); ++i) if (st->batches[i] == b) { st->batches[i] = st->batches.back(); st->batches.pop_back(); break; }
+        b->from_stream = nullptr;
+    }
+}
+static void stream_attach(v2p_batch* b, const v2p_stream* st)
+{
+    stream_detach(b);
+    v2p_stream* s = const_cast<v2p_stream*>(st);
+    s->batches.push_back(b);
+    b->from_stream = s; b->orphaned = false;
+}
 
 static int rows_mode_for(const v2p_stream* st, int kernel);
 
@@ -1921,7 +1977,11 @@ void v2p_stream_destroy(v2p_stream* st)
     if (!st) return;
     std::lock_guard<std::mutex> lk(st->ctx->mu);
     (void)hipSetDevice(st->ctx->device);
-    (void)hipDeviceSynchronize();                      // (batches built from it may still execute on either stream: their payload descriptors read its alt bytes)
+    // batches built from it may still execute on the context's streams (their payload descriptors read its alt bytes): those streams are
+    // waited for, and the batches are orphaned -- v2p_batch_execute on one is V2P_ERR_STATE from here on, never a read of freed memory
+    sync_ctx_streams(st->ctx);
+    for (v2p_batch* b : st->batches) { b->from_stream = nullptr; b->orphaned = true; b->payload_dev = nullptr; }
+    st->batches.clear();
     st->buf.release(); st->alt.release(); st->tiles.release();
     delete st;
 }
@@ -1957,6 +2017,8 @@ int v2p_batch_reset(v2p_batch* b)
     b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0;
     b->payload_dev = nullptr; b->n_slices = 0; b->launch_hint = 0; b->is_patch = false; b->patch_segs = b->patch_patches = 0;
     b->pad_image = false; b->desc_slots = 0; b->pad_tdbase = nullptr; b->pieces_state = 0; b->executed = false;
+    b->os_kernel = 0; b->os_build_ms = 0.f; b->os_wall_ms = 0.0; b->os_ahead = false;      // (v2p_batch_oneshot_info: no call to report on)
+    stream_detach(b); b->orphaned = false;
     if (b->desc_swapped) { std::swap(b->d_desc, b->d_pad); b->desc_swapped = false; }     // (the large allocation is the padded array's again)
     return V2P_OK;
 }
@@ -1971,10 +2033,12 @@ int v2p_batch_build_from_stream(v2p_batch* b, const v2p_stream* st, int kernel, 
     if (b->hap_open || b->img.n_haplotypes()) return c->fail(V2P_ERR_STATE, "the batch already holds host-built haplotypes");
     if (kernel != 0 && kernel != 6 && kernel != 7 && kernel != 8) return c->fail(V2P_ERR_INVALID_ARG, "a resident stream builds rows images (kernel 6, 7), a patch image (8) or what the routing rule picks (0)");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
-    if (kernel == 8) return build_patch_image(b, st->v, build_ms, false, st->out_bytes);
+    b->os_kernel = 0;                                   // (not a one call: v2p_batch_oneshot_info has nothing to report)
+    if (kernel == 8) { const int prc = build_patch_image(b, st->v, build_ms, false, st->out_bytes); if (prc == V2P_OK) stream_attach(b, st); return prc; }
     int mode = rows_mode_for(st, kernel);
     int rc = build_rows_image(b, st->v, mode, build_ms, false);
     if (rc == V2P_ERR_UNSUPPORTED && kernel == 0 && mode == ROWS_WAVE) rc = build_rows_image(b, st->v, ROWS_DENSE, build_ms, false);     // (a row with more than 64 descriptors)
+    if (rc == V2P_OK) stream_attach(b, st);
     return rc;
 }
 
@@ -2084,8 +2148,9 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
                    o_totals = carve(64), o_scan = carve((rows_scan_scratch_entries(n_tiles) + scan_tiles_for(n_tiles + 1)) * 8);
     OS_ALLOC(bvar == 29u ? hipErrorOutOfMemory : b->d_tiles.ensure_exact(off), "hipMalloc(tile tables)");      // (variant 29, tests: as if the device had no room)
     uint8_t* const d = b->d_tiles.ptr();
+    const uint32_t chunk_pad = rows_chunk_pad_for(out_bytes, v.n_tasks + (v.fasta ? 2 * n_tx : 0), mode);
     const uint64_t c_cover = 0, c_segc = up8((n_rows + 1) * 8), c_segb = c_segc + up8((n_segs + 1) * 4), c_tiles = c_segb + up8((n_segs + 2) * 8),
-                   c_cpad = c_tiles + up8(scan_tiles_for(n_segs + 1) * 8), c_end = c_cpad + up8(n_segs * ROWS_CHUNK_PAD * sizeof(Chunk));
+                   c_cpad = c_tiles + up8(scan_tiles_for(n_segs + 1) * 8), c_end = c_cpad + up8(n_segs * chunk_pad * sizeof(Chunk));
     OS_ALLOC(b->d_cover.ensure_exact(c_end), "hipMalloc(row map)");
     uint64_t T[V2P_MAX_SLICES + 1], max_tiles = 0;
     for (uint32_t j = 0; j <= S; ++j) T[j] = n_tiles * j / S;
@@ -2102,7 +2167,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     if (!pad) OS_ALLOC(b->d_pad.ensure_exact(max_tiles * ROWS_PAD_SLOTS * 8), "hipMalloc(padded descriptors)");
     const uint64_t desc_cap = n_tiles * ROWS_PAD_SLOTS;              // (one-pass tiles hold at most their 256 slots)
     OS_ALLOC(b->d_desc.ensure_exact(desc_cap * 8), "hipMalloc(desc)");
-    const uint64_t cap = n_segs ? n_segs * ROWS_CHUNK_PAD : 1;
+    const uint64_t cap = n_segs ? n_segs * chunk_pad : 1;
     const uint64_t n_blocks_cap = order_blocks_thread_blocks(cap, XCD_ORDER_MAX_BLOCKS);
     const uint64_t n_sub_cap = uint64_t(XCD_SUB) * n_blocks_cap;
     const uint64_t s_tmp = 0, s_bucket = s_tmp + up8(cap * 16), s_hist = s_bucket + up8(cap),
@@ -2140,7 +2205,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     a.cover = reinterpret_cast<uint64_t*>(b->d_cover.ptr() + c_cover);
     a.seg_count = reinterpret_cast<uint32_t*>(b->d_cover.ptr() + c_segc);
     a.seg_base = reinterpret_cast<const uint64_t*>(b->d_cover.ptr() + c_segb);
-    a.chunks_pad = reinterpret_cast<Chunk*>(b->d_cover.ptr() + c_cpad);
+    a.chunks_pad = reinterpret_cast<Chunk*>(b->d_cover.ptr() + c_cpad); a.chunk_pad = chunk_pad;
     a.hap_out_begin = reinterpret_cast<uint64_t*>(b->d_hap.ptr());
     a.desc_pad = reinterpret_cast<uint64_t*>(b->d_pad.ptr());
     a.desc = reinterpret_cast<uint64_t*>(b->d_desc.ptr()); a.desc_cap = desc_cap;
@@ -2228,7 +2293,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
         OS_TRY(launch_scan_u32_from(a.seg_count + SG[j], ns, const_cast<uint64_t*>(a.seg_base) + SG[j], reinterpret_cast<uint64_t*>(b->d_cover.ptr() + c_tiles), chunk0, B), "launch(scan)");
         // (the chunk table in arena order before the host's one look at the counts: its grid is the segments', and for a padded image it
         // is also where a chunk that does not fit the slot-addressed form is found -- totals[3])
-        a.chunks_tmp = chunks_tmp;
+        a.chunks_tmp = chunks_tmp; a.chunk_cap = cap;
         a.bucket = pad && reorder ? bucket : nullptr; a.sub = pad && reorder ? sub : nullptr;      // (a padded image: the chunks' keys in the same pass)
         if (ns) OS_TRY(launch_rows_chunk_compact(a, B), "launch(chunk table)");
         // (the host's one look per slice: the GPU idles while it waits, so what it reads is gathered on the device and comes back as ONE
@@ -2314,6 +2379,7 @@ int v2p_batch_build_and_execute(v2p_batch* b, const v2p_stream* st, int kernel, 
         HIP_TRY(c, hipEventRecord(b->ev_os[1], c->stream), "hipEventRecord");
         b->os_build_ms = ms; b->os_kernel = 8; b->n_slices = 0;
         b->os_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        stream_attach(b, st);
         return V2P_OK;
     }
     int mode = rows_mode_for(st, kernel);
@@ -2334,6 +2400,7 @@ int v2p_batch_build_and_execute(v2p_batch* b, const v2p_stream* st, int kernel, 
         }
     }
     if (rc == V2P_OK) {
+        stream_attach(b, st);
         b->executed = true;
         b->os_kernel = mode == ROWS_DENSE ? 7 : 6;
         b->os_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -2524,7 +2591,7 @@ static int to_pieces(v2p_batch* b)
     HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     if (stw != ~0ull || total == 0 || total >= (1ull << 40)) return V2P_OK;            // (not converted: the dense kernel executes the image, and reports what it refuses)
     if (b->d_pieces.ensure(total * 8) != hipSuccess || b->d_chunks2.ensure(nc * sizeof(Chunk)) != hipSuccess) { (void)hipGetLastError(); return V2P_OK; }
-    b->n_pieces = total;
+    b->n_pieces = total; b->pieces_src0_len = a.src0_len; b->pieces_src1_len = a.src1_len;
     a.pieces = reinterpret_cast<uint64_t*>(b->d_pieces.ptr()); a.chunks2 = reinterpret_cast<Chunk*>(b->d_chunks2.ptr());
     HIP_TRY(c, launch_pieces_build(a, 1, c->stream), "launch(pieces: write)");
     HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");                 // (the scratch above is released on return)
@@ -2538,6 +2605,7 @@ int v2p_batch_execute(v2p_batch* b)
     v2p_ctx* c = b->ctx;
     std::lock_guard<std::mutex> lk(c->mu);
     if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
+    if (b->orphaned) return c->fail(V2P_ERR_STATE, "the v2p_stream this batch was built from has been destroyed: its image cannot be executed again (the arena stays readable)");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     if (b->is_patch) {
         const hipError_t pe = patch_execute(b, c->stream);
@@ -2548,6 +2616,9 @@ int v2p_batch_execute(v2p_batch* b)
     if (b->pad_image && c->launch_opts.variant != 23u && c->launch_opts.variant != 26u) { const int rc = densify(b); if (rc) return rc; }
     if (pieces_eligible(b) && b->executed) {
         if (b->pieces_state == 0) { const int rc = to_pieces(b); if (rc) return rc; }
+        // (the piece kernel checks no source bound: to_pieces did, against the reference of that moment -- behind a v2p_upload_reference
+        // of a SHORTER reference the image goes back to the dense kernel, which checks every execute and reports V2P_ERR_SRC_OOB)
+        if (b->pieces_state == 1 && (c->proteome_len + c->headers_len < b->pieces_src0_len || b->n_payload < b->pieces_src1_len)) b->pieces_state = -1;
         if (b->pieces_state == 1) {
             PieceExecArgs pa{reinterpret_cast<const uint64_t*>(b->d_pieces.ptr()), reinterpret_cast<const Chunk*>(b->d_chunks2.ptr()), uint32_t(b->n_chunks),
                              c->proteome.ptr(), b->payload_dev, b->d_out.ptr(), b->out_bytes};
@@ -2643,6 +2714,17 @@ int v2p_batch_digests(v2p_batch* b, uint64_t* digests, uint64_t n_haps)
 }
 
 void* v2p_batch_device_out(v2p_batch* b) { return (b && b->finalized) ? b->d_out.ptr() : nullptr; }
+
+int v2p_batch_scribble(v2p_batch* b, int byte)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    if (b->out_bytes) HIP_TRY(c, hipMemsetAsync(b->d_out.ptr(), byte & 0xFF, b->out_bytes, c->stream), "hipMemset(arena)");
+    return V2P_OK;
+}
 
 // ---- streamed pipeline: H2D / kernel / D2H of successive images overlap ---------------
 

@@ -417,6 +417,10 @@ class Batch:
     def device_out(self) -> int:
         return int(self._lib.v2p_batch_device_out(self._h) or 0)
 
+    def scribble(self, byte: int = 0xEE):
+        """v2p_batch_scribble: the whole arena overwritten (checkers call it before every re-execute they verify)."""
+        self.ctx._check(self._lib.v2p_batch_scribble(self._h, byte))
+
 
 _default_ctx: Optional[Context] = None
 
