@@ -40,7 +40,7 @@ extern "C" {
 #endif
 
 #define V2P_OK                   0
-#define V2P_BUSY                 1   /* v2p_gir_submit only: every batch of the queue is in flight -- collect a ticket, then submit again */
+#define V2P_BUSY                 1   /* v2p_gir_submit: every batch of the queue is in flight -- collect a ticket, then submit again; v2p_pipeline_submit_stream: every slot is in use */
 #define V2P_ERR_INVALID_ARG     -1
 #define V2P_ERR_HIP             -2   /* HIP runtime error, no device, out of memory        */
 #define V2P_ERR_BAD_CODE        -3   /* exe_code not in {0,1} (haplotype_instruction.rs:154) */
@@ -374,21 +374,43 @@ void* v2p_batch_device_out(v2p_batch* b);
 int v2p_batch_scribble(v2p_batch* b, int byte);
 
 /* ---- streamed pipeline: results that must return to the host ------------------------------ */
-/* n_slots images are in flight at once, each on its own HIP stream: while image k's results
- * travel D2H, image k+1 executes and image k+2's descriptors travel H2D (pinned staging on both
- * sides).  Images are packed device images (v2p_cohort_pack(), or a batch builder's output)
- * against the resident reference.  Tickets are slot numbers and are reused round-robin; a slot
- * must be released before it is submitted to again. */
+/* n_slots submissions are in flight at once: while slice k's results travel D2H, slice k+1 executes and slice k+2 travels H2D (pinned
+ * staging on both sides).  Tickets are slot numbers and are reused round-robin; a slot must be released before it is submitted to again.
+ *
+ * v2p_pipeline_submit_stream (round 6) -- Task vectors in, host bytes out, nothing packed on the host: what the reference's driver does
+ * per sample (parts/exec.rs:23-42: get_g_rep(..).execute(engine), personalized_genome.rs:61-69, then the bytes to the writer, :90-113)
+ * for a SLICE of the cohort at a time.  `slice` is the transcript stream of a contiguous range of haplotypes, exactly as for
+ * v2p_stream_upload (FASTA emit: tx_header_off / tx_header_len set -- the result is file-ready text).  The CALLING thread checks the
+ * slice's tables (errors as v2p_stream_upload reports them) and copies its arrays into the slot's pinned staging with a small team of
+ * copy threads (v2p_pipeline_reserve: how many), enqueues the H2D on the slot's stream and returns: the slice's arrays may be freed.
+ * The pipeline's runner thread takes the slices in submission order through v2p_batch_build_and_execute's one call (kernel: 0, 6 or 7)
+ * on the context's streams and enqueues the arena's D2H into the slot's pinned result buffer on a stream of its own.  Submissions may
+ * come from several threads (each stages its own slice; a submission takes the first free slot, and with every slot in use returns
+ * V2P_BUSY -- nothing staged: wait for a ticket, release it, submit again).  v2p_pipeline_wait blocks until the result is in host memory -- without holding
+ * the context: other threads submit meanwhile -- and reports what the reference would have panicked on; *result stays valid until
+ * release.  V2P_SUBMIT_DIGESTS: the per-haplotype digests of v2p_batch_digests travel with the result (checkers).
+ *
+ * v2p_pipeline_submit (round 2) takes a host-PACKED device image (v2p_cohort_pack(), or a batch builder's output) against the
+ * resident reference instead. */
 typedef struct v2p_pipeline v2p_pipeline;
+#define V2P_SUBMIT_DIGESTS 1u
+typedef struct { double stage_ms; double runner_ms; } v2p_slice_times;   /* the submitter's check + staging copy; the runner's one call (enqueue + its looks at the counts) */
 int  v2p_pipeline_create(v2p_ctx* ctx, uint32_t n_slots, v2p_pipeline** out);
 void v2p_pipeline_destroy(v2p_pipeline* p);
+/* optional: pin the slots' staging (stream_bytes: a slice's arrays, about 13 bytes per Task + 32 per transcript + its alt bytes) and result
+ * buffers now rather than under the first submissions (pinning a GB takes a good fraction of a second); copy_threads (0: keep; default 8) */
+int  v2p_pipeline_reserve(v2p_pipeline* p, uint64_t stream_bytes, uint64_t out_bytes, uint32_t copy_threads);
+int  v2p_pipeline_submit_stream(v2p_pipeline* p, const v2p_txstream* slice, int kernel, unsigned flags, uint32_t* ticket);
 int  v2p_pipeline_submit(v2p_pipeline* p,
                          const uint64_t* desc, uint64_t n_desc,
                          const v2p_chunk* chunks, uint64_t n_chunks,
                          const uint8_t* payload, uint64_t n_payload,
                          uint64_t out_bytes, uint32_t* ticket);
-/* blocks until the image's results are in host memory; *result stays valid until release */
+/* blocks until the submission's results are in host memory; *result stays valid until release */
 int  v2p_pipeline_wait(v2p_pipeline* p, uint32_t ticket, const uint8_t** result, uint64_t* n);
+/* a stream slice that has been waited for: where its haplotypes start inside *result ([n_haps + 1], res_counter of
+ * haplotype_instruction.rs:90,132), its digests (NULL without V2P_SUBMIT_DIGESTS), its host-side times; any pointer may be NULL */
+int  v2p_pipeline_result_info(v2p_pipeline* p, uint32_t ticket, const uint64_t** hap_out_begin, uint64_t* n_haps, const uint64_t** digests, v2p_slice_times* times);
 int  v2p_pipeline_release(v2p_pipeline* p, uint32_t ticket);
 
 /* ---- raw launchers on caller-owned device memory (torch tensors, other runtimes) ----- */

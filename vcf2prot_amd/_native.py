@@ -90,6 +90,9 @@ HIP_API = {
     "v2p_pipeline_submit": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_void_p, c_uint64, c_uint64,
                                     POINTER(c_uint32)]),
     "v2p_pipeline_wait": (c_int, [c_void_p, c_uint32, POINTER(c_void_p), POINTER(c_uint64)]),
+    "v2p_pipeline_reserve": (c_int, [c_void_p, c_uint64, c_uint64, c_uint32]),
+    "v2p_pipeline_submit_stream": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_uint, POINTER(c_uint32)]),
+    "v2p_pipeline_result_info": (c_int, [c_void_p, c_uint32, POINTER(c_void_p), POINTER(c_uint64), POINTER(c_void_p), c_void_p]),
     "v2p_pipeline_release": (c_int, [c_void_p, c_uint32]),
     "v2p_stitch_launch_opts": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, c_uint64,
                                        c_void_p, c_uint64, c_void_p, c_void_p]),

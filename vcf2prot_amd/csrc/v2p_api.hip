@@ -68,6 +68,7 @@ struct DevBuf {
         if (e == hipSuccess) { cap = need; poison(); }
         return e;
     }
+    hipError_t ensure_os(bool grow, size_t n) { return grow ? ensure(n) : ensure_exact(n); }
     uint8_t* ptr() const { return base ? base + FRONT : nullptr; }
     void release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; }
 };
@@ -203,6 +204,8 @@ struct v2p_batch {
     uint64_t n_desc = 0, n_chunks = 0, n_payload = 0, out_bytes = 0, n_haps = 0;
     uint32_t max_chunk_tasks = 0;
     int launch_hint = 0;           // stitch_launch_bits() of the chunk table
+    bool grow = false;             // the one call sizes its buffers with slack and never shrinks them (a pipeline slot's batch: slice after slice of
+                                   // about one size -- an exact-size buffer would be freed and allocated again, and hipFree waits for the device)
 };
 
 namespace v2p {
@@ -1310,38 +1313,65 @@ static uint32_t rows_pick_k(const DevStreamView& v, int mode)
     return best_k;
 }
 
-// The stream's arrays into one device allocation (`buf`, carved) + its alt bytes (`altbuf`), on `stream`; v receives the device pointers.
-static int upload_stream(v2p_ctx* c, const v2p_txstream* s, bool fasta, DevBuf& buf, DevBuf& altbuf, DevStreamView& v, hipStream_t stream)
+// Where the stream's arrays sit in ONE allocation (device, and -- the streamed pipeline -- its pinned mirror on the host): offsets of
+// 16-byte aligned arrays, the Task arrays with the slack the parse reads past a transcript's last task.  The alt bytes are an allocation
+// of their own (the image's payload descriptors address it).
+struct StreamLayout {
+    uint64_t o_hap, o_poff, o_rlen, o_res, o_tb, o_ab, o_code, o_sp, o_ln, o_sr, o_hoff, o_hlen, total;
+};
+static StreamLayout stream_layout(uint64_t n_h, uint64_t n_tx, uint64_t n_tk, bool fasta)
 {
-    const uint64_t n_tx = s->n_tx, n_tk = s->n_tasks, n_h = s->n_haps;
     auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
     uint64_t off = 0;
     auto carve = [&](uint64_t bytes) { const uint64_t o = off; off += up8(bytes); return o; };
-    const uint64_t o_hap = carve((n_h + 1) * 8), o_poff = carve(n_tx * 8), o_rlen = carve(n_tx * 4), o_res = carve(n_tx * 4),
-                   o_tb = carve((n_tx + 2) * 8), o_ab = carve((n_tx + 2) * 8), o_code = carve(n_tk + 64), o_sp = carve((n_tk + 16) * 4), o_ln = carve((n_tk + 16) * 4),
-                   o_sr = carve((n_tk + 16) * 4), o_hoff = carve(fasta ? n_tx * 8 : 0), o_hlen = carve(fasta ? n_tx * 4 : 0);
-    HIP_TRY(c, buf.ensure(off), "hipMalloc(stream)");
+    StreamLayout L;
+    L.o_hap = carve((n_h + 1) * 8); L.o_poff = carve(n_tx * 8); L.o_rlen = carve(n_tx * 4); L.o_res = carve(n_tx * 4);
+    L.o_tb = carve((n_tx + 2) * 8); L.o_ab = carve((n_tx + 2) * 8); L.o_code = carve(n_tk + 64); L.o_sp = carve((n_tk + 16) * 4); L.o_ln = carve((n_tk + 16) * 4);
+    L.o_sr = carve((n_tk + 16) * 4); L.o_hoff = carve(fasta ? n_tx * 8 : 0); L.o_hlen = carve(fasta ? n_tx * 4 : 0);
+    L.total = off;
+    return L;
+}
+// the (dst offset, source, bytes) of every array of a host stream in that layout
+struct StreamPiece { uint64_t off; const void* src; uint64_t bytes; const char* what; };
+static uint32_t stream_pieces(const v2p_txstream* s, const StreamLayout& L, bool fasta, StreamPiece* out)
+{
+    const uint64_t n_tx = s->n_tx, n_tk = s->n_tasks, n_h = s->n_haps;
+    uint32_t n = 0;
+    auto add = [&](uint64_t off, const void* src, uint64_t bytes, const char* what) { if (bytes) out[n++] = StreamPiece{off, src, bytes, what}; };
+    add(L.o_hap, s->hap_tx_begin, (n_h + 1) * 8, "H2D(hap_tx_begin)"); add(L.o_poff, s->tx_proteome_off, n_tx * 8, "H2D(tx_proteome_off)");
+    add(L.o_rlen, s->tx_ref_len, n_tx * 4, "H2D(tx_ref_len)"); add(L.o_res, s->tx_res_len, n_tx * 4, "H2D(tx_res_len)");
+    add(L.o_tb, s->tx_task_begin, s->tx_task_begin ? (n_tx + 1) * 8 : 0, "H2D(tx_task_begin)"); add(L.o_ab, s->tx_alt_begin, s->tx_alt_begin ? (n_tx + 1) * 8 : 0, "H2D(tx_alt_begin)");
+    add(L.o_code, s->code, n_tk, "H2D(code)"); add(L.o_sp, s->start_pos, n_tk * 4, "H2D(start_pos)"); add(L.o_ln, s->length, n_tk * 4, "H2D(length)");
+    add(L.o_sr, s->start_pos_res, n_tk * 4, "H2D(start_pos_res)");
+    if (fasta) { add(L.o_hoff, s->tx_header_off, n_tx * 8, "H2D(tx_header_off)"); add(L.o_hlen, s->tx_header_len, n_tx * 4, "H2D(tx_header_len)"); }
+    return n;
+}
+static void stream_view(const v2p_txstream* s, const StreamLayout& L, bool fasta, uint8_t* d, const uint8_t* d_alt, DevStreamView& v)
+{
+    v = DevStreamView();
+    v.n_haps = s->n_haps; v.n_tx = s->n_tx; v.n_tasks = s->n_tasks; v.n_alt = s->n_alt;
+    v.hap_tx_begin = reinterpret_cast<const uint64_t*>(d + L.o_hap); v.tx_proteome_off = reinterpret_cast<const uint64_t*>(d + L.o_poff);
+    v.tx_ref_len = reinterpret_cast<const uint32_t*>(d + L.o_rlen); v.tx_res_len = reinterpret_cast<const uint32_t*>(d + L.o_res);
+    v.tx_task_begin = reinterpret_cast<const uint64_t*>(d + L.o_tb); v.tx_alt_begin = reinterpret_cast<const uint64_t*>(d + L.o_ab);
+    v.code = d + L.o_code; v.start_pos = reinterpret_cast<const uint32_t*>(d + L.o_sp); v.length = reinterpret_cast<const uint32_t*>(d + L.o_ln);
+    v.start_pos_res = reinterpret_cast<const uint32_t*>(d + L.o_sr); v.alt = d_alt;
+    v.tx_header_off = fasta ? reinterpret_cast<const uint64_t*>(d + L.o_hoff) : nullptr;
+    v.tx_header_len = fasta ? reinterpret_cast<const uint32_t*>(d + L.o_hlen) : nullptr;
+    v.fasta = fasta;
+}
+
+// The stream's arrays into one device allocation (`buf`, carved) + its alt bytes (`altbuf`), on `stream`; v receives the device pointers.
+static int upload_stream(v2p_ctx* c, const v2p_txstream* s, bool fasta, DevBuf& buf, DevBuf& altbuf, DevStreamView& v, hipStream_t stream)
+{
+    const StreamLayout L = stream_layout(s->n_haps, s->n_tx, s->n_tasks, fasta);
+    HIP_TRY(c, buf.ensure(L.total), "hipMalloc(stream)");
     uint8_t* const d = buf.ptr();
     HIP_TRY(c, altbuf.ensure(s->n_alt), "hipMalloc(alt)");
-#define UP(dst_off, src, bytes, what) do { if (bytes) HIP_TRY(c, hipMemcpyAsync(d + (dst_off), (src), (bytes), hipMemcpyHostToDevice, stream), what); } while (0)
-    UP(o_hap, s->hap_tx_begin, (n_h + 1) * 8, "H2D(hap_tx_begin)"); UP(o_poff, s->tx_proteome_off, n_tx * 8, "H2D(tx_proteome_off)");
-    UP(o_rlen, s->tx_ref_len, n_tx * 4, "H2D(tx_ref_len)"); UP(o_res, s->tx_res_len, n_tx * 4, "H2D(tx_res_len)");
-    UP(o_tb, s->tx_task_begin, (n_tx + 1) * 8, "H2D(tx_task_begin)"); UP(o_ab, s->tx_alt_begin, (n_tx + 1) * 8, "H2D(tx_alt_begin)");
-    UP(o_code, s->code, n_tk, "H2D(code)"); UP(o_sp, s->start_pos, n_tk * 4, "H2D(start_pos)"); UP(o_ln, s->length, n_tk * 4, "H2D(length)");
-    UP(o_sr, s->start_pos_res, n_tk * 4, "H2D(start_pos_res)");
-    if (fasta) { UP(o_hoff, s->tx_header_off, n_tx * 8, "H2D(tx_header_off)"); UP(o_hlen, s->tx_header_len, n_tx * 4, "H2D(tx_header_len)"); }
-#undef UP
+    StreamPiece pc[12];
+    const uint32_t np = stream_pieces(s, L, fasta, pc);
+    for (uint32_t k = 0; k < np; ++k) HIP_TRY(c, hipMemcpyAsync(d + pc[k].off, pc[k].src, pc[k].bytes, hipMemcpyHostToDevice, stream), pc[k].what);
     if (s->n_alt) HIP_TRY(c, hipMemcpyAsync(altbuf.ptr(), s->alt, s->n_alt, hipMemcpyHostToDevice, stream), "H2D(alt)");
-    v = DevStreamView();
-    v.n_haps = n_h; v.n_tx = n_tx; v.n_tasks = n_tk; v.n_alt = s->n_alt;
-    v.hap_tx_begin = reinterpret_cast<const uint64_t*>(d + o_hap); v.tx_proteome_off = reinterpret_cast<const uint64_t*>(d + o_poff);
-    v.tx_ref_len = reinterpret_cast<const uint32_t*>(d + o_rlen); v.tx_res_len = reinterpret_cast<const uint32_t*>(d + o_res);
-    v.tx_task_begin = reinterpret_cast<const uint64_t*>(d + o_tb); v.tx_alt_begin = reinterpret_cast<const uint64_t*>(d + o_ab);
-    v.code = d + o_code; v.start_pos = reinterpret_cast<const uint32_t*>(d + o_sp); v.length = reinterpret_cast<const uint32_t*>(d + o_ln);
-    v.start_pos_res = reinterpret_cast<const uint32_t*>(d + o_sr); v.alt = altbuf.ptr();
-    v.tx_header_off = fasta ? reinterpret_cast<const uint64_t*>(d + o_hoff) : nullptr;
-    v.tx_header_len = fasta ? reinterpret_cast<const uint32_t*>(d + o_hlen) : nullptr;
-    v.fasta = fasta;
+    stream_view(s, L, fasta, d, altbuf.ptr(), v);
     stream_item_stats(s, &v.items_mean, &v.items_var, &v.desc_mean, &v.desc_var);
     return V2P_OK;
 }
@@ -2005,13 +2035,13 @@ static int rows_mode_for(const v2p_stream* st, int kernel)
     return bpt < double(WAVE_BYTES_PER_TASK) ? ROWS_DENSE : ROWS_WAVE;
 }
 
-int v2p_batch_reset(v2p_batch* b)
+// (c->mu held.  wait: the context's stream is waited for -- the streamed pipeline's runner recycles a slot's batch whose last
+// kernels and copies are known to be done, and must not wait for the slice another slot has on the GPU)
+static int batch_reset_locked(v2p_batch* b, bool wait)
 {
-    if (!b) return V2P_ERR_INVALID_ARG;
     v2p_ctx* c = b->ctx;
-    std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
-    HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    if (wait) HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     b->img = ImageBuilder();
     b->finalized = false; b->uses_proteome = false; b->hap_open = false;
     b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0;
@@ -2021,6 +2051,13 @@ int v2p_batch_reset(v2p_batch* b)
     stream_detach(b); b->orphaned = false;
     if (b->desc_swapped) { std::swap(b->d_desc, b->d_pad); b->desc_swapped = false; }     // (the large allocation is the padded array's again)
     return V2P_OK;
+}
+
+int v2p_batch_reset(v2p_batch* b)
+{
+    if (!b) return V2P_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(b->ctx->mu);
+    return batch_reset_locked(b, true);
 }
 
 int v2p_batch_build_from_stream(v2p_batch* b, const v2p_stream* st, int kernel, float* build_ms)
@@ -2139,6 +2176,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
     // (the call's scratch and its image: when the device has no room for the one-pass form -- its padded descriptor array is up to 2 KiB per
     // tile -- nothing has been launched yet and the call builds in one piece instead, whose builder has a two-pass form without it)
+#define ensure_exact(n) ensure_os(b->grow, (n))
 #define OS_ALLOC(expr, what) do { hipError_t e__ = (expr); if (e__ == hipErrorOutOfMemory) { (void)hipGetLastError(); b->d_tiles.release(); b->d_cover.release(); b->d_pad.release(); b->d_order.release(); *fallback = true; return V2P_OK; } \
                                   if (e__ != hipSuccess) return c->hip_fail(e__, what); } while (0)
     // ---- memory: everything before the first kernel (a batch that is rebuilt recycles all of it) ----
@@ -2347,6 +2385,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     }
 #undef OS_TRY
 #undef OS_ALLOC
+#undef ensure_exact
     b->slice_chunk0[S] = chunk0;
     HIP_TRY(c, hipEventRecord(b->ev_os[1], A), "hipEventRecord");
     b->n_desc = desc0; b->n_chunks = chunk0; b->n_slices = S;
@@ -2356,12 +2395,10 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     return V2P_OK;
 }
 
-int v2p_batch_build_and_execute(v2p_batch* b, const v2p_stream* st, int kernel, uint32_t n_slices)
+// (c->mu held by the caller: v2p_batch_build_and_execute, and the streamed pipeline's runner)
+static int build_and_execute_locked(v2p_batch* b, const v2p_stream* st, int kernel, uint32_t n_slices)
 {
-    if (!b || !st) return V2P_ERR_INVALID_ARG;
     v2p_ctx* c = b->ctx;
-    if (st->ctx != c) return V2P_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(c->mu);
     if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized (v2p_batch_reset recycles it)");
     if (b->hap_open || b->img.n_haplotypes()) return c->fail(V2P_ERR_STATE, "the batch already holds host-built haplotypes");
     if (kernel != 0 && kernel != 6 && kernel != 7 && kernel != 8) return c->fail(V2P_ERR_INVALID_ARG, "a resident stream builds rows images (kernel 6, 7), a patch image (8) or what the routing rule picks (0)");
@@ -2406,6 +2443,15 @@ int v2p_batch_build_and_execute(v2p_batch* b, const v2p_stream* st, int kernel, 
         b->os_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return rc;
+}
+
+int v2p_batch_build_and_execute(v2p_batch* b, const v2p_stream* st, int kernel, uint32_t n_slices)
+{
+    if (!b || !st) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = b->ctx;
+    if (st->ctx != c) return V2P_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return build_and_execute_locked(b, st, kernel, n_slices);
 }
 
 int v2p_batch_oneshot_info(v2p_batch* b, v2p_oneshot_info* info)
@@ -2727,23 +2773,62 @@ int v2p_batch_scribble(v2p_batch* b, int byte)
 }
 
 // ---- streamed pipeline: H2D / kernel / D2H of successive images overlap ---------------
+// Two kinds of submission share the slots.
+//   v2p_pipeline_submit          a host-PACKED image (round 2): staged, uploaded, stitched, downloaded on the slot's stream.
+//   v2p_pipeline_submit_stream   a slice of the TRANSCRIPT STREAM -- Task vectors exactly as step 4b returns them (round 6): the caller's
+//                                thread checks the slice's tables and copies its arrays into the slot's pinned staging (a small team of
+//                                copy threads), the H2D runs on the slot's stream, the pipeline's RUNNER thread takes the slices in
+//                                submission order through the one call (image build + execute on the context's streams -- its looks at
+//                                the counts block the runner, nobody else), and the arena travels into the slot's pinned result buffer on
+//                                the slot's second stream.  What the reference does per sample (get_g_rep(..).execute(engine), then the
+//                                bytes to the host: personalized_genome.rs:61-69, parts/exec.rs:23-42) with nothing packed on the host.
+
+enum : int { SLOT_FREE = 0, SLOT_QUEUED = 1, SLOT_LAUNCHED = 2, SLOT_FAILED = 3 };
 
 struct PipeSlot {
     hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;
+    hipStream_t d2h = nullptr;    // stream submissions: the result's way home (the slot's `stream` carries the slice's H2D)
+    hipEvent_t done = nullptr, ev_h2d = nullptr, ev_exec = nullptr;
     DevBuf d_desc, d_chunks, d_payload, d_out, d_status;
     PinnedBuf h_in, h_out;
     uint64_t out_bytes = 0;
     unsigned long long status = STATUS_CLEAN;
     bool busy = false;        // holds a result the caller has not released
     bool in_flight = false;   // work was enqueued on `stream` and `done` has not been waited for
+    // ---- stream submissions ----
+    bool is_stream = false;
+    int state = SLOT_FREE;                 // (under v2p_pipeline::pmu)
+    v2p_stream* rs = nullptr;              // the slice on the device: buffers kept from submission to submission
+    v2p_batch* batch = nullptr;            // ... and its image / arena
+    StreamLayout lay{};
+    v2p_txstream shape{};                  // the slice's counts (pointers cleared) for stream_view
+    double items[4] = {1.0, 0.0, 1.0, 0.0};
+    bool fasta = false;
+    int kernel = 0;
+    unsigned sflags = 0;
+    uint64_t n_haps = 0;
+    std::vector<uint64_t> hap_out_begin;   // offsets of the slice's haplotypes inside the result
+    int rc = V2P_OK;
+    std::string err;
+    int64_t err_index = -1;
+    uint64_t o_status = 0, o_digests = 0;  // where the status word and the digests sit in h_out
+    double t_stage_ms = 0, t_queue_ms = 0, t_gpu_ms = 0;
 };
 
 struct v2p_pipeline {
     v2p_ctx* ctx = nullptr;
     std::vector<PipeSlot> slots;
     uint32_t next = 0;
+    // stream submissions
+    std::mutex pmu;
+    std::condition_variable cv;
+    std::vector<uint32_t> jobs;            // slots queued for the runner, in submission order
+    bool stop = false;
+    std::thread runner;
+    uint32_t copy_threads = 8;
 };
+
+static void pipeline_runner(v2p_pipeline* p);
 
 int v2p_pipeline_create(v2p_ctx* c, uint32_t n_slots, v2p_pipeline** out)
 {
@@ -2766,12 +2851,21 @@ int v2p_pipeline_create(v2p_ctx* c, uint32_t n_slots, v2p_pipeline** out)
 void v2p_pipeline_destroy(v2p_pipeline* p)
 {
     if (!p) return;
+    if (p->runner.joinable()) {
+        { std::lock_guard<std::mutex> lk(p->pmu); p->stop = true; }
+        p->cv.notify_all();
+        p->runner.join();
+    }
     (void)hipSetDevice(p->ctx->device);
     for (PipeSlot& s : p->slots) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
+        if (s.d2h) (void)hipStreamSynchronize(s.d2h);
+        if (s.batch) v2p_batch_destroy(s.batch);
+        if (s.rs) v2p_stream_destroy(s.rs);
         s.d_desc.release(); s.d_chunks.release(); s.d_payload.release(); s.d_out.release(); s.d_status.release();
         s.h_in.release(); s.h_out.release();
-        if (s.done) (void)hipEventDestroy(s.done);
+        for (hipEvent_t e : {s.done, s.ev_h2d, s.ev_exec}) if (e) (void)hipEventDestroy(e);
+        if (s.d2h) (void)hipStreamDestroy(s.d2h);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     delete p;
@@ -2788,16 +2882,20 @@ int v2p_pipeline_submit(v2p_pipeline* p,
     std::lock_guard<std::mutex> lk(c->mu);
     if (n_chunks > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "more than 2^32 chunks in one image");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
-    const uint32_t t = p->next;
+    uint32_t t;
+    {
+        std::lock_guard<std::mutex> pl(p->pmu);
+        t = p->next;
+        if (p->slots[t].busy) return c->fail(V2P_ERR_STATE, "pipeline slot still holds an unreleased result");
+    }
     PipeSlot& s = p->slots[t];
-    if (s.busy) return c->fail(V2P_ERR_STATE, "pipeline slot still holds an unreleased result");
     {
         const int rc = check_packed(c, n_desc, reinterpret_cast<const Chunk*>(chunks), n_chunks, nullptr, 0, out_bytes);
         if (rc) return rc;
     }
     // the slot's staging and device buffers are about to be rewritten (and possibly reallocated): whatever was
     // enqueued on it before -- a submit that failed half way, a result released without a wait -- must be done
-    if (s.in_flight) { HIP_TRY(c, hipStreamSynchronize(s.stream), "hipStreamSynchronize(slot)"); s.in_flight = false; }
+    if (s.in_flight) { HIP_TRY(c, hipStreamSynchronize(s.stream), "hipStreamSynchronize(slot)"); if (s.d2h) HIP_TRY(c, hipStreamSynchronize(s.d2h), "hipStreamSynchronize(slot)"); s.in_flight = false; }
     const size_t b_desc = size_t(n_desc) * 8, b_chunks = size_t(n_chunks) * sizeof(Chunk);
     const size_t o_chunks = (b_desc + 15) & ~size_t(15), o_payload = (o_chunks + b_chunks + 15) & ~size_t(15);
     HIP_TRY(c, s.h_in.ensure(o_payload + n_payload), "hipHostMalloc(in)");
@@ -2816,6 +2914,7 @@ int v2p_pipeline_submit(v2p_pipeline* p,
     }
     if (n_payload) memcpy(s.h_in.p + o_payload, payload, n_payload);
     s.in_flight = true;       // from here on the stream may hold work that reads h_in / writes h_out
+    s.is_stream = false;
     if (b_desc) HIP_TRY(c, hipMemcpyAsync(s.d_desc.ptr(), s.h_in.p, b_desc, hipMemcpyHostToDevice, s.stream), "H2D(desc)");
     if (b_chunks) HIP_TRY(c, hipMemcpyAsync(s.d_chunks.ptr(), s.h_in.p + o_chunks, b_chunks, hipMemcpyHostToDevice, s.stream), "H2D(chunks)");
     if (n_payload) HIP_TRY(c, hipMemcpyAsync(s.d_payload.ptr(), s.h_in.p + o_payload, n_payload, hipMemcpyHostToDevice, s.stream), "H2D(payload)");
@@ -2827,31 +2926,265 @@ int v2p_pipeline_submit(v2p_pipeline* p,
     if (out_bytes) HIP_TRY(c, hipMemcpyAsync(s.h_out.p, s.d_out.ptr(), out_bytes, hipMemcpyDeviceToHost, s.stream), "D2H(out)");
     HIP_TRY(c, hipMemcpyAsync(s.h_out.p + ((out_bytes + 7) & ~7ull), s.d_status.ptr(), sizeof(unsigned long long), hipMemcpyDeviceToHost, s.stream), "D2H(status)");
     HIP_TRY(c, hipEventRecord(s.done, s.stream), "hipEventRecord");
-    s.out_bytes = out_bytes;
-    s.busy = true;
+    s.out_bytes = out_bytes; s.o_status = (out_bytes + 7) & ~7ull;
+    {
+        std::lock_guard<std::mutex> pl(p->pmu);
+        s.busy = true; s.state = SLOT_LAUNCHED; s.rc = V2P_OK;
+        p->next = (t + 1) % uint32_t(p->slots.size());
+    }
     *ticket = t;
-    p->next = (t + 1) % uint32_t(p->slots.size());
     return V2P_OK;
+}
+
+// pageable -> pinned, a team of threads over 8 MiB pieces (one thread's memcpy moves 6-10 GB/s; the link takes 50)
+static void team_copy(uint8_t* dst_base, const StreamPiece* pc, uint32_t np, uint32_t n_threads)
+{
+    struct Job { uint8_t* d; const uint8_t* s; uint64_t n; };
+    std::vector<Job> jobs;
+    constexpr uint64_t PIECE = 8ull << 20;
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < np; ++k) {
+        total += pc[k].bytes;
+        for (uint64_t o = 0; o < pc[k].bytes; o += PIECE)
+            jobs.push_back(Job{dst_base + pc[k].off + o, static_cast<const uint8_t*>(pc[k].src) + o, pc[k].bytes - o < PIECE ? pc[k].bytes - o : PIECE});
+    }
+    uint32_t T = n_threads ? n_threads : 1;
+    if (T > jobs.size()) T = uint32_t(jobs.size());
+    if (total < (32ull << 20) || T <= 1) { for (const Job& j : jobs) memcpy(j.d, j.s, j.n); return; }
+    std::atomic<size_t> next{0};
+    auto work = [&] { for (size_t i = next++; i < jobs.size(); i = next++) memcpy(jobs[i].d, jobs[i].s, jobs[i].n); };
+    std::vector<std::thread> team;
+    for (uint32_t t = 1; t < T; ++t) team.emplace_back(work);
+    work();
+    for (std::thread& th : team) th.join();
+}
+
+int v2p_pipeline_reserve(v2p_pipeline* p, uint64_t stream_bytes, uint64_t out_bytes, uint32_t copy_threads)
+{
+    if (!p) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = p->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+    if (copy_threads) p->copy_threads = copy_threads > 64 ? 64 : copy_threads;
+    for (PipeSlot& s : p->slots) {
+        if (s.busy || s.in_flight) return c->fail(V2P_ERR_STATE, "v2p_pipeline_reserve: a slot is in use");
+        if (stream_bytes) HIP_TRY(c, s.h_in.ensure(stream_bytes), "hipHostMalloc(in)");
+        if (out_bytes) HIP_TRY(c, s.h_out.ensure(out_bytes + 64), "hipHostMalloc(out)");
+    }
+    return V2P_OK;
+}
+
+int v2p_pipeline_submit_stream(v2p_pipeline* p, const v2p_txstream* slice, int kernel, unsigned flags, uint32_t* ticket)
+{
+    if (!p || !slice || !ticket) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = p->ctx;
+    if (kernel != 0 && kernel != 6 && kernel != 7) { std::lock_guard<std::mutex> lk(c->mu); return c->fail(V2P_ERR_INVALID_ARG, "a stream slice builds rows images (kernel 6, 7) or what the routing rule picks (0)"); }
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t t;
+    {
+        std::lock_guard<std::mutex> pl(p->pmu);
+        // the first free slot from `next` on (one submitter that releases in order sees them round-robin; workers that release as they
+        // finish take whichever is free); every slot in use: V2P_BUSY, nothing staged -- wait for a ticket, release it, submit again
+        const uint32_t ns = uint32_t(p->slots.size());
+        uint32_t k = 0;
+        while (k < ns && p->slots[(p->next + k) % ns].busy) ++k;
+        if (k == ns) return V2P_BUSY;
+        t = (p->next + k) % ns;
+        p->slots[t].busy = true;                       // claimed: concurrent submitters take the slots behind it
+        p->slots[t].state = SLOT_FREE;
+        p->next = (t + 1) % ns;
+    }
+    PipeSlot& s = p->slots[t];
+    auto unclaim = [&](int rc) { std::lock_guard<std::mutex> pl(p->pmu); s.busy = false; return rc; };
+    bool fasta = false;
+    std::vector<uint64_t> hob;
+    {
+        // the slice's tables: what the kernels index device memory through is checked before anything is staged (as v2p_stream_upload)
+        std::lock_guard<std::mutex> lk(c->mu);
+        const int rc = check_stream(c, slice, &fasta, nullptr, &hob);
+        if (rc) return unclaim(rc);
+        if (hipSetDevice(c->device) != hipSuccess) return unclaim(c->fail(V2P_ERR_HIP, "hipSetDevice"));
+        hipError_t e = hipSuccess;
+        if (!s.d2h) e = hipStreamCreateWithFlags(&s.d2h, hipStreamNonBlocking);
+        if (e == hipSuccess && !s.ev_h2d) e = hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming);
+        if (e == hipSuccess && !s.ev_exec) e = hipEventCreateWithFlags(&s.ev_exec, hipEventDisableTiming);
+        if (e != hipSuccess) return unclaim(c->hip_fail(e, "pipeline stream/event"));
+        if (!s.rs) { s.rs = new (std::nothrow) v2p_stream(); if (s.rs) s.rs->ctx = c; }
+        if (!s.batch) { s.batch = new (std::nothrow) v2p_batch(); if (s.batch) { s.batch->ctx = c; s.batch->grow = true; } }
+        if (!s.rs || !s.batch) return unclaim(c->fail(V2P_ERR_HIP, "out of host memory"));
+    }
+    (void)hipSetDevice(c->device);
+    // a result released without a wait, a submission that failed half way: the slot's streams must be idle before its buffers are rewritten
+    if (s.in_flight) { (void)hipStreamSynchronize(s.stream); (void)hipStreamSynchronize(s.d2h); s.in_flight = false; }
+    const StreamLayout L = stream_layout(slice->n_haps, slice->n_tx, slice->n_tasks, fasta);
+    const uint64_t o_alt = (L.total + 255) & ~255ull;
+    const uint64_t out_bytes = hob.back();
+    const uint64_t o_status = (out_bytes + 63) & ~63ull, o_dig = o_status + 64;
+    auto hip_unclaim = [&](hipError_t e, const char* what) { std::lock_guard<std::mutex> lk(c->mu); return unclaim(c->hip_fail(e, what)); };
+    {
+        hipError_t e = s.h_in.ensure(o_alt + slice->n_alt + 64);
+        if (e == hipSuccess) e = s.h_out.ensure(o_dig + ((flags & V2P_SUBMIT_DIGESTS) ? slice->n_haps * 8 : 0) + 64);
+        if (e == hipSuccess) e = s.rs->buf.ensure(L.total);
+        if (e == hipSuccess) e = s.rs->alt.ensure(slice->n_alt);
+        if (e != hipSuccess) return hip_unclaim(e, "pipeline buffers");
+    }
+    // ---- the caller's thread (and its copy team): the slice's arrays into pinned staging, in the device layout ----
+    StreamPiece pc[13];
+    uint32_t np = stream_pieces(slice, L, fasta, pc);
+    if (slice->n_alt) pc[np++] = StreamPiece{o_alt, slice->alt, slice->n_alt, "H2D(alt)"};
+    team_copy(s.h_in.p, pc, np, p->copy_threads);
+    s.lay = L; s.fasta = fasta; s.kernel = kernel; s.sflags = flags; s.n_haps = slice->n_haps;
+    s.shape = *slice;
+    stream_item_stats(slice, &s.items[0], &s.items[1], &s.items[2], &s.items[3]);
+    s.shape.hap_tx_begin = nullptr; s.shape.tx_proteome_off = nullptr; s.shape.tx_ref_len = nullptr; s.shape.tx_res_len = nullptr; s.shape.tx_task_begin = nullptr;
+    s.shape.tx_alt_begin = nullptr; s.shape.code = nullptr; s.shape.start_pos = nullptr; s.shape.length = nullptr; s.shape.start_pos_res = nullptr; s.shape.alt = nullptr;
+    s.shape.tx_header_off = nullptr; s.shape.tx_header_len = nullptr;
+    s.hap_out_begin.swap(hob);
+    s.out_bytes = out_bytes; s.o_status = o_status; s.o_digests = o_dig;
+    s.rc = V2P_OK; s.err.clear(); s.err_index = -1; s.is_stream = true;
+    s.t_stage_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    // ---- H2D on the slot's stream: two copies from pinned memory, truly asynchronous ----
+    s.in_flight = true;
+    hipError_t e = hipSuccess;
+    if (L.total) e = hipMemcpyAsync(s.rs->buf.ptr(), s.h_in.p, L.total, hipMemcpyHostToDevice, s.stream);
+    if (e == hipSuccess && slice->n_alt) e = hipMemcpyAsync(s.rs->alt.ptr(), s.h_in.p + o_alt, slice->n_alt, hipMemcpyHostToDevice, s.stream);
+    if (e == hipSuccess) e = hipEventRecord(s.ev_h2d, s.stream);
+    if (e != hipSuccess) return hip_unclaim(e, "H2D(stream slice)");
+    {
+        std::lock_guard<std::mutex> pl(p->pmu);
+        s.state = SLOT_QUEUED;
+        p->jobs.push_back(t);
+        if (!p->runner.joinable()) p->runner = std::thread(pipeline_runner, p);
+    }
+    p->cv.notify_all();
+    *ticket = t;
+    return V2P_OK;
+}
+
+// The runner: slice after slice, in submission order, through the one call.  Holds the context while it enqueues (and while the one
+// call looks at its counts); submitters stage and upload meanwhile, waiters sleep on the slots' events.
+static void pipeline_runner(v2p_pipeline* p)
+{
+    v2p_ctx* c = p->ctx;
+    for (;;) {
+        uint32_t t;
+        {
+            std::unique_lock<std::mutex> pl(p->pmu);
+            p->cv.wait(pl, [&] { return p->stop || !p->jobs.empty(); });
+            if (p->jobs.empty()) return;               // (stop: what is queued is still run -- its waiters are owed an answer)
+            t = p->jobs.front();
+            p->jobs.erase(p->jobs.begin());
+        }
+        PipeSlot& s = p->slots[t];
+        const auto t0 = std::chrono::steady_clock::now();
+        int rc = V2P_OK;
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            auto hip = [&](hipError_t e, const char* what) { if (e != hipSuccess && rc == V2P_OK) rc = c->hip_fail(e, what); return e == hipSuccess; };
+            v2p_stream* st = s.rs;
+            v2p_batch* b = s.batch;
+            hip(hipSetDevice(c->device), "hipSetDevice");
+            if (rc == V2P_OK) rc = batch_reset_locked(b, false);
+            if (rc == V2P_OK) hip(hipStreamWaitEvent(c->stream, s.ev_h2d, 0), "hipStreamWaitEvent");
+            if (rc == V2P_OK) {
+                // the slice as a resident stream (v2p_stream_upload's second half): the view, res_counter per tile and per haplotype
+                stream_view(&s.shape, s.lay, s.fasta, st->buf.ptr(), st->alt.ptr(), st->v);
+                st->v.items_mean = s.items[0]; st->v.items_var = s.items[1]; st->v.desc_mean = s.items[2]; st->v.desc_var = s.items[3];
+                st->hap_out_begin = s.hap_out_begin;
+                st->out_bytes = s.out_bytes;
+                st->tile_K = 0; st->n_tiles = 0; st->tile_res_base = nullptr; st->d_hap_out_begin = nullptr; st->h_tile_res_base.clear();
+                const uint32_t K = rows_pick_k(st->v, rows_mode_for(st, s.kernel));
+                const uint64_t n_tiles = st->v.n_tx ? (st->v.n_tx + K - 1) / K : 1;
+                auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
+                const uint64_t o_tbytes = 0, o_tbase = up8(n_tiles * 8), o_hap = o_tbase + up8((n_tiles + 1) * 8), o_scan = o_hap + up8((st->v.n_haps + 1) * 8),
+                               o_end = o_scan + up8(rows_scan_scratch_entries(n_tiles) * 8);
+                if (st->tiles.ensure(o_end) != hipSuccess) (void)hipGetLastError();            // (no room: the call makes its own tables)
+                else {
+                    RowsArgs a;
+                    rows_args_of(st->v, c, K, n_tiles, a);
+                    uint8_t* const d = st->tiles.ptr();
+                    a.tile_bytes = reinterpret_cast<uint64_t*>(d + o_tbytes); a.tile_res_base = reinterpret_cast<uint64_t*>(d + o_tbase);
+                    a.hap_out_begin = reinterpret_cast<uint64_t*>(d + o_hap);
+                    a.status = nullptr;
+                    if (hip(launch_rows_tile_bytes(a, reinterpret_cast<uint64_t*>(d + o_scan), c->stream), "launch(tile tables)") &&
+                        hip(launch_rows_hap_begin(a, c->stream), "launch(tile tables)")) {
+                        st->tile_K = K; st->n_tiles = n_tiles; st->tile_res_base = a.tile_res_base; st->d_hap_out_begin = a.hap_out_begin;
+                    }
+                }
+            }
+            if (rc == V2P_OK) rc = build_and_execute_locked(b, st, s.kernel, 0);
+            if (rc == V2P_OK) {
+                if ((s.sflags & V2P_SUBMIT_DIGESTS) && b->n_haps) {
+                    hip(hipMemsetAsync(b->d_digest.ptr(), 0, b->n_haps * 8, c->stream), "hipMemset(digest)");
+                    DigestArgs da{b->d_out.ptr(), reinterpret_cast<const uint64_t*>(b->d_hap.ptr()), b->n_haps, reinterpret_cast<uint64_t*>(b->d_digest.ptr())};
+                    hip(launch_digest(da, b->out_bytes, c->stream), "launch(digest)");
+                }
+                hip(hipEventRecord(s.ev_exec, c->stream), "hipEventRecord");
+                hip(hipStreamWaitEvent(s.d2h, s.ev_exec, 0), "hipStreamWaitEvent");
+                // the way home: arena, status word, digests -- into pinned memory, on a stream of the slot's own (the next slice's H2D and its
+                // one call run beside it)
+                if (rc == V2P_OK && b->out_bytes) hip(hipMemcpyAsync(s.h_out.p, b->d_out.ptr(), b->out_bytes, hipMemcpyDeviceToHost, s.d2h), "D2H(out)");
+                if (rc == V2P_OK) hip(hipMemcpyAsync(s.h_out.p + s.o_status, b->d_status.ptr(), 8, hipMemcpyDeviceToHost, s.d2h), "D2H(status)");
+                if (rc == V2P_OK && (s.sflags & V2P_SUBMIT_DIGESTS) && b->n_haps) hip(hipMemcpyAsync(s.h_out.p + s.o_digests, b->d_digest.ptr(), b->n_haps * 8, hipMemcpyDeviceToHost, s.d2h), "D2H(digests)");
+                hip(hipEventRecord(s.done, s.d2h), "hipEventRecord");
+                if (rc == V2P_OK && b->out_bytes != s.out_bytes) rc = c->fail(V2P_ERR_STATE, "a slice's arena is not the sum of its transcripts' result sizes");
+            }
+            if (rc != V2P_OK) { s.err = c->err; s.err_index = c->err_index; }
+        }
+        {
+            std::lock_guard<std::mutex> pl(p->pmu);
+            s.rc = rc;
+            s.t_gpu_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            s.state = rc == V2P_OK ? SLOT_LAUNCHED : SLOT_FAILED;
+        }
+        p->cv.notify_all();
+    }
 }
 
 int v2p_pipeline_wait(v2p_pipeline* p, uint32_t ticket, const uint8_t** result, uint64_t* n)
 {
     if (!p || ticket >= p->slots.size() || !result || !n) return V2P_ERR_INVALID_ARG;
     v2p_ctx* c = p->ctx;
-    std::lock_guard<std::mutex> lk(c->mu);
     PipeSlot& s = p->slots[ticket];
-    if (!s.busy) return c->fail(V2P_ERR_STATE, "nothing submitted on this ticket");
-    HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
-    HIP_TRY(c, hipEventSynchronize(s.done), "hipEventSynchronize");
+    {
+        std::unique_lock<std::mutex> pl(p->pmu);
+        if (!s.busy) { pl.unlock(); std::lock_guard<std::mutex> lk(c->mu); return c->fail(V2P_ERR_STATE, "nothing submitted on this ticket"); }
+        p->cv.wait(pl, [&] { return s.state == SLOT_LAUNCHED || s.state == SLOT_FAILED; });       // (a stream slice: the runner has taken it through the one call)
+        if (s.state == SLOT_FAILED) {
+            const int rc = s.rc;
+            pl.unlock();
+            std::lock_guard<std::mutex> lk(c->mu);
+            return c->fail(rc, s.err, s.err_index);
+        }
+    }
+    // (the context is NOT held while the copies finish: submitters and the runner go on)
+    (void)hipSetDevice(c->device);
+    const hipError_t e = hipEventSynchronize(s.done);
+    if (e != hipSuccess) { std::lock_guard<std::mutex> lk(c->mu); return c->hip_fail(e, "hipEventSynchronize"); }
     s.in_flight = false;
     unsigned long long st;
-    memcpy(&st, s.h_out.p + ((s.out_bytes + 7) & ~7ull), sizeof st);
+    memcpy(&st, s.h_out.p + s.o_status, sizeof st);
     *result = s.h_out.p;
     *n = s.out_bytes;
     if (st != STATUS_CLEAN) {
         const int code = reason_to_err(uint32_t(st & 0xFFu));
+        std::lock_guard<std::mutex> lk(c->mu);
         return c->fail(code, std::string("device: ") + err_name(code) + " at descriptor " + std::to_string(st >> 8), int64_t(st >> 8));
     }
+    return V2P_OK;
+}
+
+int v2p_pipeline_result_info(v2p_pipeline* p, uint32_t ticket, const uint64_t** hap_out_begin, uint64_t* n_haps, const uint64_t** digests, v2p_slice_times* times)
+{
+    if (!p || ticket >= p->slots.size()) return V2P_ERR_INVALID_ARG;
+    v2p_ctx* c = p->ctx;
+    PipeSlot& s = p->slots[ticket];
+    std::lock_guard<std::mutex> pl(p->pmu);
+    if (!s.busy || !s.is_stream || s.state != SLOT_LAUNCHED || s.in_flight) { std::lock_guard<std::mutex> lk(c->mu); return c->fail(V2P_ERR_STATE, "v2p_pipeline_result_info: a stream slice that has been waited for"); }
+    if (hap_out_begin) *hap_out_begin = s.hap_out_begin.data();
+    if (n_haps) *n_haps = s.n_haps;
+    if (digests) *digests = (s.sflags & V2P_SUBMIT_DIGESTS) ? reinterpret_cast<const uint64_t*>(s.h_out.p + s.o_digests) : nullptr;
+    if (times) { times->stage_ms = s.t_stage_ms; times->runner_ms = s.t_gpu_ms; }
     return V2P_OK;
 }
 
@@ -2859,14 +3192,22 @@ int v2p_pipeline_release(v2p_pipeline* p, uint32_t ticket)
 {
     if (!p || ticket >= p->slots.size()) return V2P_ERR_INVALID_ARG;
     v2p_ctx* c = p->ctx;
-    std::lock_guard<std::mutex> lk(c->mu);
     PipeSlot& s = p->slots[ticket];
-    if (s.in_flight) {          // released without a wait: the copies into / out of the pinned buffers must end first
-        HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
-        HIP_TRY(c, hipEventSynchronize(s.done), "hipEventSynchronize");
+    {
+        // released without a wait: a queued slice is taken through the one call first, then the copies into / out of the pinned buffers must end
+        std::unique_lock<std::mutex> pl(p->pmu);
+        if (s.busy && s.is_stream) p->cv.wait(pl, [&] { return s.state == SLOT_LAUNCHED || s.state == SLOT_FAILED; });
+    }
+    if (s.in_flight) {
+        (void)hipSetDevice(c->device);
+        hipError_t e = hipSuccess;
+        if (s.state == SLOT_LAUNCHED) e = hipEventSynchronize(s.done);
+        else { e = hipStreamSynchronize(s.stream); if (e == hipSuccess && s.d2h) e = hipStreamSynchronize(s.d2h); }
+        if (e != hipSuccess) { std::lock_guard<std::mutex> lk(c->mu); return c->hip_fail(e, "hipEventSynchronize"); }
         s.in_flight = false;
     }
-    s.busy = false;
+    std::lock_guard<std::mutex> pl(p->pmu);
+    s.busy = false; s.state = SLOT_FREE;
     return V2P_OK;
 }
 

@@ -1,8 +1,11 @@
 """Cohorts larger than one device image: the role of the reference's sample-level driver (parts/exec.rs:23-42) for the gpu engine.
 
 The reference hands samples to a Rayon pool one by one; here haplotypes are cut into contiguous ranges whose result bytes fit a
-budget (shard.shard_by_bytes's prefix-sum logic), each range becomes one device image, and the images stream through
-v2p_pipeline_* -- H2D of image k+1 and D2H of image k-1 overlap the kernel of image k.  Results arrive in haplotype order.
+budget (shard.shard_by_bytes's prefix-sum logic) and the ranges stream through v2p_pipeline_* -- H2D of slice k+1 and D2H of slice
+k-1 overlap the build + execute of slice k.  Results arrive in haplotype order.
+
+run_streamed (round 6) feeds SLICES OF THE TRANSCRIPT STREAM -- the per-transcript GIRs of step 4b, nothing packed on the host
+(v2p_pipeline_submit_stream); run_batched feeds host-packed images (v2p_pipeline_submit).
 """
 from __future__ import annotations
 
@@ -35,6 +38,7 @@ class BatchResult:
     h_end: int
     out: np.ndarray              # pinned host view of the image's result arena (valid until the next batch is yielded)
     hap_out_begin: np.ndarray    # [h_end - h_begin + 1] offsets into `out`
+    digests: object = None       # run_streamed(digests=True): the device digests of the slice's haplotypes
 
     def haplotype(self, h: int) -> np.ndarray:
         i = h - self.h_begin
@@ -61,6 +65,40 @@ def run_batched(ctx: Context, pack: Callable[[int, int], object], result_bytes: 
             t, a, b, hb = inflight.pop(0)
             out = pipe.wait(t)
             yield BatchResult(a, b, out, hb)
+            pipe.release(t)
+    finally:
+        pipe.close()
+
+
+def run_streamed(ctx: Context, make_stream: Callable[[int, int], object], result_bytes: Sequence[int], budget_bytes: int,
+                 h0: int = 0, slots: int = 3, kernel: int = 0, digests: bool = False, copy_threads: int = 0,
+                 reserve: Tuple[int, int] = (0, 0)) -> Iterator[BatchResult]:
+    """Execute haplotypes h0 .. h0 + len(result_bytes) slice by slice from their TRANSCRIPT STREAM.  `make_stream(begin, end)` returns the
+    v2p_txstream of that range (cohort.Cohort.txstream, txstream.TxStreamBuilder.finish: an object with `.struct`, optionally `.close()`);
+    the resident reference must already be uploaded to `ctx`.  Yields one BatchResult per slice, in order; `out` is the slot's pinned
+    result buffer (FASTA text when the stream carries record headers) and `digests` the device digests when asked for."""
+    ranges = [(h0 + a, h0 + b) for a, b in cut_by_bytes(result_bytes, budget_bytes)]
+    pipe = Pipeline(ctx, slots)
+    try:
+        if any(reserve) or copy_threads:
+            pipe.reserve(reserve[0], reserve[1], copy_threads)
+        inflight: List[Tuple[int, int, int]] = []
+        nxt = 0
+        while nxt < len(ranges) or inflight:
+            while nxt < len(ranges) and len(inflight) < slots:
+                a, b = ranges[nxt]
+                st = make_stream(a, b)
+                t = pipe.submit_stream(st, kernel, digests)
+                if hasattr(st, "close"):
+                    st.close()                               # staged: the host copy may go
+                inflight.append((t, a, b))
+                nxt += 1
+            t, a, b = inflight.pop(0)
+            out = pipe.wait(t)
+            info = pipe.result_info(t)
+            r = BatchResult(a, b, out, info["hap_out_begin"])
+            r.digests = info["digests"]
+            yield r
             pipe.release(t)
     finally:
         pipe.close()

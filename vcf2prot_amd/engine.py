@@ -466,8 +466,8 @@ class GIR:
 
 
 class Pipeline:
-    """Streamed execution of successive packed images with H2D / kernel / D2H overlap
-    (v2p_pipeline_*): the way results reach the host when a cohort is larger than one image."""
+    """Streamed execution with H2D / kernel / D2H overlap (v2p_pipeline_*): the way results reach the host.  submit_stream: slices of the
+    transcript stream (Task vectors in, host bytes out, nothing packed on the host); submit: host-packed images."""
 
     def __init__(self, ctx: Context, n_slots: int = 3):
         self.ctx = ctx
@@ -496,6 +496,31 @@ class Pipeline:
         self.ctx._check(self._lib.v2p_pipeline_submit(self._h, _p(desc), desc.size, _p(chunks), chunks.shape[0],
                                                       _p(payload), payload.size, out_bytes, ctypes.byref(t)))
         return int(t.value)
+
+    def reserve(self, stream_bytes: int, out_bytes: int, copy_threads: int = 0):
+        """v2p_pipeline_reserve: pin the slots' staging / result buffers now; how many threads copy a slice into its staging."""
+        self.ctx._check(self._lib.v2p_pipeline_reserve(self._h, stream_bytes, out_bytes, copy_threads))
+
+    def submit_stream(self, stream, kernel: int = 0, digests: bool = False) -> int:
+        """v2p_pipeline_submit_stream: a slice of the transcript stream (anything with a `.struct` laid out like v2p_txstream) -- checked and
+        staged on this thread, uploaded, built + executed by the pipeline's runner, its arena copied back.  The slice may be freed on return.
+        Returns the ticket, or -1 when every slot is in use (V2P_BUSY: wait for a ticket, release it, submit again)."""
+        t = ctypes.c_uint32()
+        rc = self._lib.v2p_pipeline_submit_stream(self._h, ctypes.byref(stream.struct), kernel, 1 if digests else 0, ctypes.byref(t))
+        if rc == 1:                                          # V2P_BUSY: every slot is in use
+            return -1
+        self.ctx._check(rc)
+        return int(t.value)
+
+    def result_info(self, ticket: int) -> dict:
+        """v2p_pipeline_result_info of a stream slice that has been waited for: hap_out_begin (copy), digests (copy or None), times."""
+        hb, dg, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
+        times = (ctypes.c_double * 2)()
+        self.ctx._check(self._lib.v2p_pipeline_result_info(self._h, ticket, ctypes.byref(hb), ctypes.byref(n), ctypes.byref(dg), ctypes.byref(times)))
+        nh = int(n.value)
+        hob = np.ctypeslib.as_array(ctypes.cast(hb, ctypes.POINTER(ctypes.c_uint64)), shape=(nh + 1,)).copy()
+        dig = np.ctypeslib.as_array(ctypes.cast(dg, ctypes.POINTER(ctypes.c_uint64)), shape=(nh,)).copy() if dg.value and nh else (np.zeros(0, np.uint64) if dg.value else None)
+        return {"hap_out_begin": hob, "digests": dig, "stage_ms": float(times[0]), "runner_ms": float(times[1])}
 
     def wait(self, ticket: int) -> np.ndarray:
         """View of the slot's pinned result buffer (valid until release(ticket))."""
