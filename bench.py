@@ -190,6 +190,93 @@ def pcie_inclusive(cohort, h0, h1, n_threads, slots=3, target_image_bytes=2 << 3
             "d2h_GBps": out_total / best / 1e9, "what": "packed images -> pinned H2D -> stitch kernel -> D2H into pinned host memory"}
 
 
+def stream_pipeline_leg(workload, cohort_samples, n_threads, ref_digests, target_slice_bytes=1152 << 20, slots=4, reps=2, device=None):
+    """Transfers-inclusive rate FROM THE TASK STREAM (round 6): the whole cohort, slice by slice, through v2p_pipeline_submit_stream -- the
+    per-transcript Task vectors of step 4b sit in host memory (pageable, as a Rust host's Vecs would), each slice is checked and copied into
+    pinned staging by the submitting thread's copy team, uploaded, built + executed by the one call, and its arena comes back into pinned
+    host memory; `slots` slices in flight.  Nothing is packed on the host; the upload is inside the timed region.  Every haplotype's device
+    digest is compared with `ref_digests` (each of which was compared with the oracle's) in EVERY pass; the first, untimed pass (it pins the
+    buffers) also digests a sample of the HOST bytes with the oracle's digest function.  Not `value`."""
+    import numpy as np
+    from sir_oracle import COracle
+    from vcf2prot_amd.cohort import Cohort
+    from vcf2prot_amd.engine import Context, Pipeline
+    from vcf2prot_amd.shard import shard_by_bytes
+    if device is None:
+        import torch
+        device = torch.cuda.current_device()
+    cohort = Cohort.preset(workload, n_samples=cohort_samples)
+    n = cohort.n_haplotypes
+    sizes = cohort.result_sizes(0, n, n_threads=n_threads)
+    total = int(sizes.sum())
+    n_sl = int(max(slots, min(48, (total + target_slice_bytes - 1) // target_slice_bytes)))
+    ranges = [(a, b) for a, b in shard_by_bytes(sizes.tolist(), n_sl) if b > a]
+    t0 = time.perf_counter()
+    streams = [cohort.txstream(a, b, n_threads=n_threads) for a, b in ranges]
+    t_gen = time.perf_counter() - t0
+    A = 0
+    for st in streams:
+        if st.n_tasks:
+            A += int(np.ctypeslib.as_array(st.struct.length, shape=(st.n_tasks,)).sum(dtype=np.int64))
+    h2d = sum(st.nbytes for st in streams)
+    out_max = max(int(sizes[a:b].sum()) for a, b in ranges)
+    orc = COracle()
+    copy_threads = max(1, min(16, n_threads))
+    res = {"input": "task stream", "host_packing_s": 0.0, "workload": f"{workload}: the whole {cohort_samples}-sample cohort ({n} haplotypes)", "slices": len(ranges), "slots": slots,
+           "copy_threads": copy_threads, "h2d_bytes": h2d, "d2h_bytes": total, "stream_generation_s_outside": t_gen}
+    with Context(device) as ctx:
+        ctx.upload_proteome(cohort.proteome())
+        pipe = Pipeline(ctx, slots)
+        t0 = time.perf_counter()
+        pipe.reserve(int(1.05 * max(st.nbytes for st in streams)) + (1 << 20), out_max + 8 * n + (1 << 20), copy_threads)
+        res["pinning_s_outside"] = time.perf_counter() - t0
+        passes, stage_ms, runner_ms, host_checked = [], [], [], 0
+
+        def consume(job, first):
+            nonlocal host_checked
+            t, i = job
+            a, b = ranges[i]
+            out = pipe.wait(t)
+            info = pipe.result_info(t)
+            if not np.array_equal(info["digests"], ref_digests[a:b]):
+                bad = int((info["digests"] != ref_digests[a:b]).sum())
+                raise RuntimeError(f"PARITY FAILURE: {bad} haplotypes of slice {i} of {workload} came back from the stream pipeline with another digest")
+            if out.size != int(sizes[a:b].sum()):
+                raise RuntimeError(f"PARITY FAILURE: slice {i} returned {out.size} bytes")
+            if first:                                       # what crossed the link: host bytes digested by the oracle's function
+                hob = info["hap_out_begin"]
+                for j in sorted(set(np.linspace(0, b - a - 1, 3).astype(int).tolist())):
+                    if orc.digest_u8(np.ascontiguousarray(out[int(hob[j]):int(hob[j + 1])])) != int(ref_digests[a + j]):
+                        raise RuntimeError(f"PARITY FAILURE: the host bytes of haplotype {a + j} differ from the oracle")
+                    host_checked += 1
+            stage_ms.append(info["stage_ms"]); runner_ms.append(info["runner_ms"])
+            pipe.release(t)
+
+        for rep in range(1 + reps):
+            stage_ms.clear(); runner_ms.clear()
+            t0 = time.perf_counter()
+            inflight = []
+            for i, st in enumerate(streams):
+                if len(inflight) == slots:
+                    consume(inflight.pop(0), rep == 0)
+                inflight.append((pipe.submit_stream(st, 0, True), i))
+            while inflight:
+                consume(inflight.pop(0), rep == 0)
+            secs = time.perf_counter() - t0
+            if rep:
+                passes.append(secs)
+        pipe.close()
+    for st in streams:
+        st.close()
+    best = min(passes)
+    res.update({"seconds": best, "seconds_all_passes": passes, "aa_per_s": A / best, "d2h_GBps": total / best / 1e9, "h2d_GBps": h2d / best / 1e9,
+                "stage_ms_per_slice": sum(stage_ms) / len(stage_ms), "runner_ms_per_slice": sum(runner_ms) / len(runner_ms),
+                "verified": {"every_haplotype_digest_every_pass": True, "host_bytes_digested": host_checked},
+                "what": "Task vectors (pageable host memory) -> table checks + copy into pinned staging on the submitting thread's copy team -> H2D -> "
+                        "v2p_batch_build_and_execute's one call (runner thread) -> D2H of the arena into pinned host memory; upload inside the timed region, nothing packed on the host"})
+    return res
+
+
 def image_stats(desc, chunks, proteome_bytes, out_bytes):
     """Bytes that must cross the HBM interface per execute: every result byte written once, every descriptor and chunk record read
     once, the alt bytes that are not inside a descriptor, the proteome once."""
@@ -377,6 +464,8 @@ def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verif
             verified = {"haplotypes_checked": len(check), "of": n_haps, "every_haplotype": bool(len(check) == n_haps),
                         "digest_of_digests": f"{int(np.bitwise_xor.reduce(dig)) if dig.size else 0:016x}", "oracle_seconds": time.perf_counter() - t_v}
         res["verified"] = verified
+        if verified and verified["every_haplotype"]:
+            res["_oracle_checked_digests"] = np.array(dig, dtype=np.uint64)     # (every one of them compared with the oracle's above; main() pops it)
         # ---- the host-packed image of the same haplotypes (the packer of rounds 1-3): A/B in one process ----
         hbatch = None
         if host_packed or time_host_image:
@@ -722,18 +811,30 @@ def main():
                     c2.update({"ms": ms2, "ms_min": min(c2["kernel_ms"]), "aa_per_s": c2["aa"] / (ms2 * 1e-3), "achieved_GBps": c2["hbm_bytes_min_per_launch"] / (ms2 * 1e-3) / 1e9,
                                "frac": c2["hbm_bytes_min_per_launch"] / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "steps": len(c2["kernel_ms"])})
                     del c2["kernel_ms"]
+                    c2.pop("_oracle_checked_digests", None)
                     line["c2_cohort"] = c2
                 except Exception as e:                         # never lose the bench line to a secondary leg
                     line["c2_cohort"] = {"error": repr(e)}
             if not args.no_pcie:
+                ref_dig = leg.get("_oracle_checked_digests")
+                if ref_dig is not None and whole:
+                    try:                                       # Task vectors in, host bytes out: the whole cohort of the headline through the stream-fed pipeline
+                        torch.cuda.empty_cache()
+                        sp = stream_pipeline_leg(args.workload, cohort_samples, n_threads, ref_dig)
+                        line["incl_transfers_aa_per_s"] = sp.pop("aa_per_s")
+                        line["incl_transfers"] = sp
+                    except Exception as e:
+                        line["incl_transfers"] = {"error": repr(e)}
                 try:
                     c2c = Cohort.preset("C2", n_samples=1000)
                     pc = pcie_inclusive(c2c, 0, c2c.n_haplotypes, n_threads)
-                    line["incl_transfers_aa_per_s"] = pc.pop("aa_per_s")
                     pc["workload"] = "C2, 1 000 samples"
-                    line["incl_transfers"] = pc
+                    pc["input"] = "host-packed images (packing outside the timed region)"
+                    if "incl_transfers" not in line or "error" in line["incl_transfers"]:
+                        line["incl_transfers_aa_per_s"] = pc["aa_per_s"]
+                    line["incl_transfers_packed_images"] = pc
                 except Exception as e:
-                    line["incl_transfers"] = {"error": repr(e)}
+                    line["incl_transfers_packed_images"] = {"error": repr(e)}
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(cohort, h0, n_haps, os.cpu_count() or 1)
             if not args.no_live_traffic and not args.host_image:
@@ -752,6 +853,7 @@ def main():
                     line["roofline"]["traffic_live_seconds"] = time.perf_counter() - t_live
                 except Exception as e:                         # noqa: BLE001
                     line["roofline"]["traffic_live_failed"] = repr(e)[:300]
+        leg.pop("_oracle_checked_digests", None)
         print(json.dumps(line))
     if dist_on:
         dist.barrier()

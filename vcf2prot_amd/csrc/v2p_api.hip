@@ -10,6 +10,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -1565,38 +1566,41 @@ static int build_rows_image(v2p_batch* b, const DevStreamView& v, int mode, floa
 // unaligned 8-byte load of an immediate payload, tx_res_base[hap_tx_begin[h]]): a table that is not ascending from 0 or leaves
 // its array is refused here, with the offending index, before anything is uploaded.  Optionally: every transcript's arena length
 // (FASTA, the grid builders), the arena offset of every haplotype (res_counter of haplotype_instruction.rs:90,132 on the host).
-static int check_stream(v2p_ctx* c, const v2p_txstream* s, bool* fasta_out, std::vector<uint32_t>* arena_len, std::vector<uint64_t>* hap_out_begin)
+struct CheckErr { std::string msg; int64_t index = -1; int operator()(int code, const std::string& m, int64_t i = -1) { msg = m; index = i; return code; } };
+// (reads the context's header table and nothing else of it: callable without c->mu -- the streamed pipeline's submitters check their slices while the
+// runner holds the context through a one call; the error goes to `fail`, the caller hands it to c->fail under the lock)
+static int check_stream_nolock(const v2p_ctx* c, const v2p_txstream* s, bool* fasta_out, std::vector<uint32_t>* arena_len, std::vector<uint64_t>* hap_out_begin, CheckErr& fail)
 {
     if (!s->hap_tx_begin || (s->n_tx && (!s->tx_proteome_off || !s->tx_ref_len || !s->tx_res_len || !s->tx_task_begin || !s->tx_alt_begin)) ||
         (s->n_tasks && (!s->code || !s->start_pos || !s->length || !s->start_pos_res)) || (s->n_alt && !s->alt))
-        return c->fail(V2P_ERR_INVALID_ARG, "null argument");
+        return fail(V2P_ERR_INVALID_ARG, "null argument");
     if (s->hap_tx_begin[s->n_haps] != s->n_tx || (s->n_tx && (s->tx_task_begin[s->n_tx] != s->n_tasks || s->tx_alt_begin[s->n_tx] != s->n_alt)))
-        return c->fail(V2P_ERR_INVALID_ARG, "stream offsets do not add up");
-    if (s->hap_tx_begin[0] != 0) return c->fail(V2P_ERR_INVALID_ARG, "hap_tx_begin does not start at 0", 0);
+        return fail(V2P_ERR_INVALID_ARG, "stream offsets do not add up");
+    if (s->hap_tx_begin[0] != 0) return fail(V2P_ERR_INVALID_ARG, "hap_tx_begin does not start at 0", 0);
     for (uint64_t h = 0; h < s->n_haps; ++h)
         if (s->hap_tx_begin[h + 1] < s->hap_tx_begin[h] || s->hap_tx_begin[h + 1] > s->n_tx)
-            return c->fail(V2P_ERR_INVALID_ARG, "hap_tx_begin is not ascending inside [0, n_tx] at haplotype " + std::to_string(h), int64_t(h));
-    if (s->n_tx && (s->tx_task_begin[0] != 0 || s->tx_alt_begin[0] != 0)) return c->fail(V2P_ERR_INVALID_ARG, "tx_task_begin / tx_alt_begin do not start at 0", 0);
+            return fail(V2P_ERR_INVALID_ARG, "hap_tx_begin is not ascending inside [0, n_tx] at haplotype " + std::to_string(h), int64_t(h));
+    if (s->n_tx && (s->tx_task_begin[0] != 0 || s->tx_alt_begin[0] != 0)) return fail(V2P_ERR_INVALID_ARG, "tx_task_begin / tx_alt_begin do not start at 0", 0);
     for (uint64_t t = 0; t < s->n_tx; ++t) {
         if (s->tx_task_begin[t + 1] < s->tx_task_begin[t] || s->tx_task_begin[t + 1] > s->n_tasks)
-            return c->fail(V2P_ERR_INVALID_ARG, "tx_task_begin is not ascending inside [0, n_tasks] at transcript " + std::to_string(t), int64_t(t));
+            return fail(V2P_ERR_INVALID_ARG, "tx_task_begin is not ascending inside [0, n_tasks] at transcript " + std::to_string(t), int64_t(t));
         if (s->tx_alt_begin[t + 1] < s->tx_alt_begin[t] || s->tx_alt_begin[t + 1] > s->n_alt)
-            return c->fail(V2P_ERR_INVALID_ARG, "tx_alt_begin is not ascending inside [0, n_alt] at transcript " + std::to_string(t), int64_t(t));
+            return fail(V2P_ERR_INVALID_ARG, "tx_alt_begin is not ascending inside [0, n_alt] at transcript " + std::to_string(t), int64_t(t));
         if (s->tx_proteome_off[t] + s->tx_ref_len[t] < s->tx_proteome_off[t])
-            return c->fail(V2P_ERR_INVALID_ARG, "tx_proteome_off + tx_ref_len wraps at transcript " + std::to_string(t), int64_t(t));
+            return fail(V2P_ERR_INVALID_ARG, "tx_proteome_off + tx_ref_len wraps at transcript " + std::to_string(t), int64_t(t));
     }
     // FASTA emit: every record header inside the resident header table and ending in a line feed (the record's own line feed is read
     // from there); a transcript's arena length is then header + residues + line feed
     const bool fasta = s->tx_header_off && s->tx_header_len;
-    if ((s->tx_header_off == nullptr) != (s->tx_header_len == nullptr)) return c->fail(V2P_ERR_INVALID_ARG, "tx_header_off and tx_header_len come together");
+    if ((s->tx_header_off == nullptr) != (s->tx_header_len == nullptr)) return fail(V2P_ERR_INVALID_ARG, "tx_header_off and tx_header_len come together");
     if (fasta) {
         if (arena_len) arena_len->resize(s->n_tx);
         for (uint64_t t = 0; t < s->n_tx; ++t) {
             const uint64_t ho = s->tx_header_off[t], hl = s->tx_header_len[t];
-            if (hl && (ho + hl > c->headers_len || ho + hl < ho)) return c->fail(V2P_ERR_SRC_OOB, "record header outside the resident header table at transcript " + std::to_string(t), int64_t(t));
-            if (hl && c->headers_host[ho + hl - 1] != '\n') return c->fail(V2P_ERR_INVALID_ARG, "a record header must end in a line feed (transcript " + std::to_string(t) + ")", int64_t(t));
+            if (hl && (ho + hl > c->headers_len || ho + hl < ho)) return fail(V2P_ERR_SRC_OOB, "record header outside the resident header table at transcript " + std::to_string(t), int64_t(t));
+            if (hl && c->headers_host[ho + hl - 1] != '\n') return fail(V2P_ERR_INVALID_ARG, "a record header must end in a line feed (transcript " + std::to_string(t) + ")", int64_t(t));
             const uint64_t al = uint64_t(s->tx_res_len[t]) + (hl ? hl + 1u : 0u);
-            if (al > 0xFFFFFFFFull) return c->fail(V2P_ERR_UNSUPPORTED, "a record of more than 4 GiB", int64_t(t));
+            if (al > 0xFFFFFFFFull) return fail(V2P_ERR_UNSUPPORTED, "a record of more than 4 GiB", int64_t(t));
             if (arena_len) (*arena_len)[t] = uint32_t(al);
         }
     }
@@ -1614,6 +1618,13 @@ static int check_stream(v2p_ctx* c, const v2p_txstream* s, bool* fasta_out, std:
     }
     *fasta_out = fasta;
     return V2P_OK;
+}
+
+static int check_stream(v2p_ctx* c, const v2p_txstream* s, bool* fasta_out, std::vector<uint32_t>* arena_len, std::vector<uint64_t>* hap_out_begin)
+{
+    CheckErr err;
+    const int rc = check_stream_nolock(c, s, fasta_out, arena_len, hap_out_begin, err);
+    return rc == V2P_OK ? V2P_OK : c->fail(rc, err.msg, err.index);
 }
 
 // ---- image build on the device ---------------------------------------------------------------------------------------------
@@ -2937,7 +2948,7 @@ int v2p_pipeline_submit(v2p_pipeline* p,
 }
 
 // pageable -> pinned, a team of threads over 8 MiB pieces (one thread's memcpy moves 6-10 GB/s; the link takes 50)
-static void team_copy(uint8_t* dst_base, const StreamPiece* pc, uint32_t np, uint32_t n_threads)
+static void team_copy(uint8_t* dst_base, const StreamPiece* pc, uint32_t np, uint32_t n_threads, const std::function<void()>& leader_first)
 {
     struct Job { uint8_t* d; const uint8_t* s; uint64_t n; };
     std::vector<Job> jobs;
@@ -2950,11 +2961,12 @@ static void team_copy(uint8_t* dst_base, const StreamPiece* pc, uint32_t np, uin
     }
     uint32_t T = n_threads ? n_threads : 1;
     if (T > jobs.size()) T = uint32_t(jobs.size());
-    if (total < (32ull << 20) || T <= 1) { for (const Job& j : jobs) memcpy(j.d, j.s, j.n); return; }
+    if (total < (32ull << 20) || T <= 1) { leader_first(); for (const Job& j : jobs) memcpy(j.d, j.s, j.n); return; }
     std::atomic<size_t> next{0};
     auto work = [&] { for (size_t i = next++; i < jobs.size(); i = next++) memcpy(jobs[i].d, jobs[i].s, jobs[i].n); };
     std::vector<std::thread> team;
     for (uint32_t t = 1; t < T; ++t) team.emplace_back(work);
+    leader_first();                                     // (the calling thread: the table checks, then its share of the copy)
     work();
     for (std::thread& th : team) th.join();
 }
@@ -2996,46 +3008,60 @@ int v2p_pipeline_submit_stream(v2p_pipeline* p, const v2p_txstream* slice, int k
     }
     PipeSlot& s = p->slots[t];
     auto unclaim = [&](int rc) { std::lock_guard<std::mutex> pl(p->pmu); s.busy = false; return rc; };
-    bool fasta = false;
-    std::vector<uint64_t> hob;
-    {
-        // the slice's tables: what the kernels index device memory through is checked before anything is staged (as v2p_stream_upload)
-        std::lock_guard<std::mutex> lk(c->mu);
-        const int rc = check_stream(c, slice, &fasta, nullptr, &hob);
-        if (rc) return unclaim(rc);
-        if (hipSetDevice(c->device) != hipSuccess) return unclaim(c->fail(V2P_ERR_HIP, "hipSetDevice"));
+    auto hip_unclaim = [&](hipError_t e, const char* what) { std::lock_guard<std::mutex> lk(c->mu); return unclaim(c->hip_fail(e, what)); };
+    (void)hipSetDevice(c->device);
+    if (!s.d2h || !s.ev_h2d || !s.ev_exec || !s.rs || !s.batch) {               // (a slot's first stream submission)
         hipError_t e = hipSuccess;
         if (!s.d2h) e = hipStreamCreateWithFlags(&s.d2h, hipStreamNonBlocking);
         if (e == hipSuccess && !s.ev_h2d) e = hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming);
         if (e == hipSuccess && !s.ev_exec) e = hipEventCreateWithFlags(&s.ev_exec, hipEventDisableTiming);
-        if (e != hipSuccess) return unclaim(c->hip_fail(e, "pipeline stream/event"));
+        if (e != hipSuccess) return hip_unclaim(e, "pipeline stream/event");
         if (!s.rs) { s.rs = new (std::nothrow) v2p_stream(); if (s.rs) s.rs->ctx = c; }
         if (!s.batch) { s.batch = new (std::nothrow) v2p_batch(); if (s.batch) { s.batch->ctx = c; s.batch->grow = true; } }
-        if (!s.rs || !s.batch) return unclaim(c->fail(V2P_ERR_HIP, "out of host memory"));
+        if (!s.rs || !s.batch) { std::lock_guard<std::mutex> lk(c->mu); return unclaim(c->fail(V2P_ERR_HIP, "out of host memory")); }
     }
-    (void)hipSetDevice(c->device);
     // a result released without a wait, a submission that failed half way: the slot's streams must be idle before its buffers are rewritten
     if (s.in_flight) { (void)hipStreamSynchronize(s.stream); (void)hipStreamSynchronize(s.d2h); s.in_flight = false; }
-    const StreamLayout L = stream_layout(slice->n_haps, slice->n_tx, slice->n_tasks, fasta);
+    if (!slice->hap_tx_begin) { std::lock_guard<std::mutex> lk(c->mu); return unclaim(c->fail(V2P_ERR_INVALID_ARG, "null argument")); }
+    const bool fasta_shape = slice->tx_header_off && slice->tx_header_len;
+    const StreamLayout L = stream_layout(slice->n_haps, slice->n_tx, slice->n_tasks, fasta_shape);
     const uint64_t o_alt = (L.total + 255) & ~255ull;
-    const uint64_t out_bytes = hob.back();
-    const uint64_t o_status = (out_bytes + 63) & ~63ull, o_dig = o_status + 64;
-    auto hip_unclaim = [&](hipError_t e, const char* what) { std::lock_guard<std::mutex> lk(c->mu); return unclaim(c->hip_fail(e, what)); };
     {
         hipError_t e = s.h_in.ensure(o_alt + slice->n_alt + 64);
-        if (e == hipSuccess) e = s.h_out.ensure(o_dig + ((flags & V2P_SUBMIT_DIGESTS) ? slice->n_haps * 8 : 0) + 64);
         if (e == hipSuccess) e = s.rs->buf.ensure(L.total);
         if (e == hipSuccess) e = s.rs->alt.ensure(slice->n_alt);
         if (e != hipSuccess) return hip_unclaim(e, "pipeline buffers");
     }
-    // ---- the caller's thread (and its copy team): the slice's arrays into pinned staging, in the device layout ----
-    StreamPiece pc[13];
-    uint32_t np = stream_pieces(slice, L, fasta, pc);
-    if (slice->n_alt) pc[np++] = StreamPiece{o_alt, slice->alt, slice->n_alt, "H2D(alt)"};
-    team_copy(s.h_in.p, pc, np, p->copy_threads);
+    // ---- the caller's thread and its copy team.  The team copies the slice's arrays into pinned staging, in the device layout, WHILE this
+    // thread checks the slice's tables -- what the kernels index device memory through is refused before anything is uploaded (as
+    // v2p_stream_upload; without the context's lock: the runner holds it through a whole one call) -- and samples its Task shapes; a slice
+    // that fails the check has been copied for nothing (null arrays are caught first: the team never reads through one).
+    bool fasta = false;
+    std::vector<uint64_t> hob;
+    CheckErr cerr;
+    int crc = V2P_OK;
+    if ((slice->n_tx && (!slice->tx_proteome_off || !slice->tx_ref_len || !slice->tx_res_len || !slice->tx_task_begin || !slice->tx_alt_begin)) ||
+        (slice->n_tasks && (!slice->code || !slice->start_pos || !slice->length || !slice->start_pos_res)) || (slice->n_alt && !slice->alt) ||
+        ((slice->tx_header_off == nullptr) != (slice->tx_header_len == nullptr)))
+        crc = check_stream_nolock(c, slice, &fasta, nullptr, &hob, cerr);                 // (it says which)
+    if (crc == V2P_OK) {
+        StreamPiece pc[13];
+        uint32_t np = stream_pieces(slice, L, fasta_shape, pc);
+        if (slice->n_alt) pc[np++] = StreamPiece{o_alt, slice->alt, slice->n_alt, "H2D(alt)"};
+        team_copy(s.h_in.p, pc, np, p->copy_threads, [&] {
+            crc = check_stream_nolock(c, slice, &fasta, nullptr, &hob, cerr);
+            if (crc == V2P_OK) stream_item_stats(slice, &s.items[0], &s.items[1], &s.items[2], &s.items[3]);
+        });
+    }
+    if (crc != V2P_OK) { std::lock_guard<std::mutex> lk(c->mu); return unclaim(c->fail(crc == V2P_OK ? V2P_ERR_INVALID_ARG : crc, cerr.msg, cerr.index)); }
+    const uint64_t out_bytes = hob.back();
+    const uint64_t o_status = (out_bytes + 63) & ~63ull, o_dig = o_status + 64;
+    {
+        const hipError_t e = s.h_out.ensure(o_dig + ((flags & V2P_SUBMIT_DIGESTS) ? slice->n_haps * 8 : 0) + 64);
+        if (e != hipSuccess) return hip_unclaim(e, "pipeline buffers");
+    }
     s.lay = L; s.fasta = fasta; s.kernel = kernel; s.sflags = flags; s.n_haps = slice->n_haps;
     s.shape = *slice;
-    stream_item_stats(slice, &s.items[0], &s.items[1], &s.items[2], &s.items[3]);
     s.shape.hap_tx_begin = nullptr; s.shape.tx_proteome_off = nullptr; s.shape.tx_ref_len = nullptr; s.shape.tx_res_len = nullptr; s.shape.tx_task_begin = nullptr;
     s.shape.tx_alt_begin = nullptr; s.shape.code = nullptr; s.shape.start_pos = nullptr; s.shape.length = nullptr; s.shape.start_pos_res = nullptr; s.shape.alt = nullptr;
     s.shape.tx_header_off = nullptr; s.shape.tx_header_len = nullptr;
