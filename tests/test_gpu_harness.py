@@ -40,15 +40,19 @@ def test_harness_thread_pool_matches_oracle(harness, coracle, preset, n, threads
         assert out["digests"][h] == coracle.digest_u32(want), (preset, h)
 
 
+@pytest.mark.parametrize("how", [[], ["--slice-kb", "1"], ["--host-build"]], ids=["one-slice", "slice-per-proband", "host-build"])
 @pytest.mark.parametrize("stem", ["c1_example", "e2e_dense", "e2e_long"])
-def test_harness_vcf_mode_writes_the_reference_files(harness, tmp_path, stem):
+def test_harness_vcf_mode_writes_the_reference_files(harness, tmp_path, stem, how):
     """`v2p_harness vcf in.vcf ref.fasta outdir --no-test`: the reference's command line with no Rust behind it; the files it
-    writes hold the same records as the reference binary's."""
+    writes hold the same records as the reference binary's -- whether the probands travel through the stream-fed pipeline as one slice,
+    as a slice each (--slice-kb 1: every proband flushes one), or through the host builder."""
     golden = os.path.join(ROOT, "tests", "golden")
     want = json.load(open(os.path.join(golden, stem + ".json")))["fasta"]
-    p = subprocess.run([harness, "vcf", os.path.join(golden, stem + ".vcf"), os.path.join(golden, stem + "_reference.fasta"), str(tmp_path), "--no-test"],
+    p = subprocess.run([harness, "vcf", os.path.join(golden, stem + ".vcf"), os.path.join(golden, stem + "_reference.fasta"), str(tmp_path), "--no-test"] + how,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
+    if how == ["--slice-kb", "1"]:
+        assert json.loads(p.stdout.strip().split("\n")[-1])["slices"] >= min(2, len(want))
     for sample, recs in want.items():
         lines = open(os.path.join(tmp_path, sample + ".fasta")).read().split("\n")[:-1]
         got = sorted([lines[i][1:], lines[i + 1]] for i in range(0, len(lines), 2))
@@ -122,10 +126,11 @@ def test_harness_and_python_pipeline_agree_on_random_vcfs(harness, gpu_ctx, tmp_
             for no_test in (True, False):
                 out = tmp_path / f"o{trial}_{int(write_all)}_{int(no_test)}"
                 out.mkdir()
-                cmd = [harness, "vcf", str(vcf), str(fa), str(out)] + (["--no-test"] if no_test else []) + (["-a"] if write_all else [])
+                cmd = [harness, "vcf", str(vcf), str(fa), str(out)] + (["--no-test"] if no_test else []) + (["-a"] if write_all else []) + (["--slice-kb", "8"] if trial % 2 else [])
                 p = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
                 try:
-                    want = vcf_to_fasta(gpu_ctx, text.encode(), ref, flags=0 if no_test else step4a.DEFAULT_FLAGS, write_all=write_all)
+                    want = vcf_to_fasta(gpu_ctx, text.encode(), ref, flags=0 if no_test else step4a.DEFAULT_FLAGS, write_all=write_all,
+                                        slice_bytes=(256 << 20) if trial % 3 else 4096)
                 except N.V2PError:
                     assert p.returncode == 101, (trial, write_all, no_test, p.stdout, p.stderr)
                     n_abort += 1
@@ -170,6 +175,32 @@ def test_sharded_host_mode_in_one_process(harness, gpu_ctx, coracle, preset, sam
     for r, s in enumerate(out["shards"]):
         assert (s["h0"], s["h1"]) == ranges[r] and s["byte_offset"] == off and s["bytes"] == int(sizes[s["h0"]:s["h1"]].sum())
         off += s["bytes"]
+    for h in range(0, n, max(1, n // 64)):
+        hap = c.haplotype(h)
+        t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+        want = coracle.gir_execute_u8(t, c.ref_tape_u32(h).astype(np.uint8), hap.alt, np.full(hap.n_res, ord("."), dtype=np.uint8))
+        assert out["digests"][h] == coracle.digest_u8(want), (preset, h)
+
+
+@pytest.mark.parametrize("preset,samples,devices,slice_mb", [("C3", 40, 1, 8), ("C3", 40, 3, 4), ("C5", 300, 2, 1), ("C2", 6, 2, 32)])
+def test_streamed_host_mode_in_one_process(harness, gpu_ctx, coracle, preset, samples, devices, slice_mb):
+    """`v2p_harness sharded ... --streamed` (ppgg::execute_streamed): one v2p_pipeline per device context, every shard's Task vectors in
+    slices through v2p_pipeline_submit_stream, the results in HOST memory -- the digests printed are computed by the harness from the
+    host bytes (and compared there with the device's digests of the arena); here with the oracle's."""
+    from vcf2prot_amd.cohort import Cohort
+    from vcf2prot_amd.shard import shard_by_bytes
+    p = subprocess.run([harness, "sharded", preset, str(samples), "--devices", str(devices), "--oversubscribe", "--threads", "8", "--streamed", "--slice-mb", str(slice_mb)],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = json.loads(p.stdout.strip().split("\n")[-1])
+    c = Cohort.preset(preset, n_samples=samples)
+    n = c.n_haplotypes
+    sizes = c.result_sizes(0, n)
+    assert out["streamed"] and out["haplotypes"] == n and out["result_bytes"] == int(sizes.sum()) == out["host_bytes"] and len(out["shards"]) == devices
+    assert out["slices"] >= devices and out["slices"] >= int(sizes.sum()) // (slice_mb << 20)
+    ranges = shard_by_bytes(sizes.tolist(), devices)
+    for r, s in enumerate(out["shards"]):
+        assert (s["h0"], s["h1"]) == ranges[r]
     for h in range(0, n, max(1, n // 64)):
         hap = c.haplotype(h)
         t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)

@@ -269,4 +269,86 @@ std::vector<DeviceShard> execute_sharded(const std::vector<uint64_t>& hap_bytes,
     return shards;
 }
 
+// ---- ... and with the results returning to the host: one STREAM PIPELINE per device --------------------------------------------------
+// What parts/exec.rs:23-42 hands its caller is host memory (Vec<PersonalizedGenome>; the writer is next, personalized_genome.rs:90-113).
+// Each device's worker cuts its shard into slices of about `slice_bytes` of result and feeds them through v2p_pipeline_submit_stream:
+// the slice's Task vectors are checked and staged on this worker's thread, uploaded, built + executed by the one call, and the arena comes
+// back into pinned host memory while the next slices are on their way -- eight devices are eight PCIe links.  consume(shard, h0, h1,
+// bytes, n, hap_out_begin, digests) runs on the worker thread with the slice's result (valid until it returns), slices in order.
+inline std::vector<std::pair<uint64_t, uint64_t>> cut_by_bytes(const std::vector<uint64_t>& hap_bytes, uint64_t h0, uint64_t h1, uint64_t budget)
+{
+    std::vector<std::pair<uint64_t, uint64_t>> cuts;          // (vcf2prot_amd/driver.py::cut_by_bytes)
+    uint64_t begin = h0, acc = 0;
+    for (uint64_t h = h0; h < h1; ++h) {
+        if (h > begin && acc + hap_bytes[h] > budget) { cuts.emplace_back(begin, h); begin = h; acc = 0; }
+        acc += hap_bytes[h];
+    }
+    if (h1 > begin) cuts.emplace_back(begin, h1);
+    return cuts;
+}
+
+template <class MakeStream, class ConsumeSlice>
+std::vector<DeviceShard> execute_streamed(const std::vector<uint64_t>& hap_bytes, const std::vector<int>& devices,
+                                          const uint8_t* proteome, uint64_t proteome_len, const uint8_t* record_headers, uint64_t n_headers,
+                                          MakeStream make_stream, ConsumeSlice consume, uint64_t slice_bytes = 1152ull << 20, uint32_t slots = 4,
+                                          uint32_t copy_threads = 8)
+{
+    const int world = int(devices.size());
+    const auto ranges = shard_by_bytes(hap_bytes, world);
+    std::vector<DeviceShard> shards;
+    shards.resize(size_t(world));
+    uint64_t off = 0;
+    for (int r = 0; r < world; ++r) {
+        DeviceShard& s = shards[size_t(r)];
+        s.rank = r; s.device = devices[size_t(r)]; s.h0 = ranges[size_t(r)].first; s.h1 = ranges[size_t(r)].second; s.byte_offset = off;
+        for (uint64_t h = s.h0; h < s.h1; ++h) s.bytes += hap_bytes[h];
+        off += s.bytes;
+    }
+    std::vector<std::string> errors;
+    errors.resize(size_t(world));
+    std::vector<int> codes;
+    codes.resize(size_t(world), 0);
+    std::vector<std::thread> pool;
+    for (int r = 0; r < world; ++r)
+        pool.emplace_back([&, r] {
+            DeviceShard& s = shards[size_t(r)];
+            v2p_pipeline* pipe = nullptr;
+            try {
+                GpuContext ctx(s.device);
+                auto ck = [&](int rc) { if (rc != V2P_OK) throw Panic(rc, v2p_last_error(ctx.raw()), v2p_last_error_index(ctx.raw())); };
+                ck(v2p_upload_reference(ctx.raw(), proteome, proteome_len, record_headers, n_headers));
+                ck(v2p_pipeline_create(ctx.raw(), slots, &pipe));
+                ck(v2p_pipeline_reserve(pipe, 0, 0, copy_threads));
+                const auto slices = cut_by_bytes(hap_bytes, s.h0, s.h1, slice_bytes);
+                struct InFlight { uint32_t ticket; uint64_t h0, h1; };
+                std::vector<InFlight> inflight;
+                const auto t0 = std::chrono::steady_clock::now();
+                auto finish = [&](const InFlight& f) {
+                    const uint8_t* bytes = nullptr; uint64_t n = 0, nh = 0;
+                    const uint64_t* hob = nullptr; const uint64_t* dig = nullptr;
+                    ck(v2p_pipeline_wait(pipe, f.ticket, &bytes, &n));
+                    ck(v2p_pipeline_result_info(pipe, f.ticket, &hob, &nh, &dig, nullptr));
+                    if (nh != f.h1 - f.h0) throw Panic(V2P_ERR_STATE, "a slice came back with another number of haplotypes");
+                    consume(s, f.h0, f.h1, bytes, n, hob, dig);
+                    ck(v2p_pipeline_release(pipe, f.ticket));
+                };
+                for (const auto& sl : slices) {
+                    if (inflight.size() == slots) { finish(inflight.front()); inflight.erase(inflight.begin()); }
+                    std::shared_ptr<const v2p_txstream> host = make_stream(sl.first, sl.second);
+                    uint32_t t = 0;
+                    ck(v2p_pipeline_submit_stream(pipe, host.get(), 0, V2P_SUBMIT_DIGESTS, &t));       // (staged on return: the host copy goes)
+                    inflight.push_back(InFlight{t, sl.first, sl.second});
+                }
+                for (const InFlight& f : inflight) finish(f);
+                s.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                v2p_pipeline_destroy(pipe);
+                pipe = nullptr;
+            } catch (const Panic& p) { errors[size_t(r)] = p.what(); codes[size_t(r)] = p.code; if (pipe) v2p_pipeline_destroy(pipe); }
+            catch (const std::exception& e) { errors[size_t(r)] = e.what(); codes[size_t(r)] = V2P_ERR_HIP; if (pipe) v2p_pipeline_destroy(pipe); }
+        });
+    for (auto& th : pool) th.join();
+    for (int r = 0; r < world; ++r) if (!errors[size_t(r)].empty()) throw Panic(codes[size_t(r)], "shard " + std::to_string(r) + ": " + errors[size_t(r)]);
+    return shards;
+}
+
 }  // namespace ppgg

@@ -6,10 +6,14 @@
 //
 //   v2p_harness kat                          reference known-answer tests through the mirror
 //   v2p_harness run <preset> <haps> <threads>   e.g. run C2 64 8
-//   v2p_harness vcf <in.vcf> <reference.fasta> <outdir> [--no-test] [-a] [-c]   VCF -> one FASTA(.gz) per proband, no Rust anywhere
-//   v2p_harness sharded <preset> <samples> --devices N [--oversubscribe] [--threads T]
+//   v2p_harness vcf <in.vcf> <reference.fasta> <outdir> [--no-test] [-a] [-c] [--slice-kb K]   VCF -> one FASTA(.gz) per proband, no Rust anywhere;
+//                                            steps 4-5 produce slices of probands that stream through v2p_pipeline_submit_stream while the next are made
+//   v2p_harness sharded <preset> <samples> --devices N [--oversubscribe] [--threads T] [--streamed [--slice-mb M]]
 //                                            the cohort over N devices in THIS process (ppgg::execute_sharded): N contexts, N worker
-//                                            threads, ranges of equal result bytes, one v2p_batch_build_and_execute each
+//                                            threads, ranges of equal result bytes, one v2p_batch_build_and_execute each;
+//                                            --streamed (ppgg::execute_streamed): one v2p_pipeline per device, the shard's Task vectors in
+//                                            slices of M MiB of result through v2p_pipeline_submit_stream, the results IN HOST MEMORY --
+//                                            the digests printed are then digests of the host bytes
 //   v2p_harness shard <world> <bytes...>     the ranges ppgg::shard_by_bytes cuts (no GPU)
 #include <algorithm>
 #include <atomic>
@@ -232,7 +236,7 @@ static std::map<std::string, std::string> read_fasta(const std::string& text)
     return rec;
 }
 
-static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* outdir, bool no_test, bool write_all, bool compressed, bool host_build)
+static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* outdir, bool no_test, bool write_all, bool compressed, bool host_build, uint64_t slice_bytes)
 {
     using clk = std::chrono::steady_clock;
     auto since = [](clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); };
@@ -305,8 +309,11 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
                              reinterpret_cast<const uint8_t*>(headers.data()), headers.size()));
     v2p_batch* b = nullptr;
     chk(v2p_batch_create(ctx.raw(), &b));
-    // Step 5, the image packing and the record text are built ON the device (v2p_batch_build_on_device) from the per-transcript GIRs
-    // collected here as they come out of step 4b; --host-build keeps the host builder (v2p_batch_add_transcript): same bytes.
+    // Step 5, the image packing and the record text are built ON the device from the per-transcript GIRs collected here as they come out
+    // of step 4b -- in SLICES of whole probands (about slice_bytes of FASTA text each) that go through v2p_pipeline_submit_stream as soon
+    // as they are complete: while the host runs steps 4a / 4b for the next probands, the slice before is uploaded, built, executed and
+    // its text comes back into pinned memory, from where the probands' files are written (parts/exec.rs:23-42 + personalized_genome.rs:
+    // 72-117 as a pipeline).  --host-build keeps the host builder (v2p_batch_add_transcript), one image, one download: same bytes.
     struct TxStreamHost {
         std::vector<uint64_t> hap_tx_begin{0}, off, task_begin{0}, alt_begin{0}, hdr_off;
         std::vector<uint32_t> ref_len, res_len, hdr_len, sp, ln, sr;
@@ -320,11 +327,123 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
             task_begin.push_back(code.size()); alt_begin.push_back(alt.size());
             result_bytes += res + (hl ? hl + 1u : 0u);
         }
-    } txs;
+        // (the builder's slab loads read a few entries past a transcript's last task / alt byte: 64 entries of slack behind the arrays)
+        v2p_txstream view() {
+            if (!padded) { for (int k = 0; k < 64; ++k) { code.push_back(0); sp.push_back(0); ln.push_back(0); sr.push_back(0); alt.push_back(0); } padded = true; }
+            v2p_txstream st{};
+            st.n_haps = hap_tx_begin.size() - 1; st.n_tx = off.size(); st.n_tasks = code.size() - 64; st.n_alt = alt.size() - 64;
+            st.hap_tx_begin = hap_tx_begin.data(); st.tx_proteome_off = off.data(); st.tx_ref_len = ref_len.data(); st.tx_res_len = res_len.data();
+            st.tx_task_begin = task_begin.data(); st.tx_alt_begin = alt_begin.data();
+            st.code = code.data(); st.start_pos = sp.data(); st.length = ln.data(); st.start_pos_res = sr.data(); st.alt = alt.data();
+            st.tx_header_off = hdr_off.data(); st.tx_header_len = hdr_len.data();
+            return st;
+        }
+        bool padded = false;
+    };
+    std::unique_ptr<TxStreamHost> txs_p(new TxStreamHost());
+    // ---- the writer: the probands [s0, s1) of a slice, haplotype h of proband s at bytes [hob[2 (s - s0) + h], hob[.. + 1]) ----
+    uint64_t written = 0;
+    double t_write_acc = 0;
+    auto write_probands = [&](uint64_t s0, uint64_t s1, const uint8_t* bytes, const uint64_t* hob) -> bool {
+        const auto tw = clk::now();
+        for (uint64_t s = s0; s < s1; ++s) {
+            uint64_t nb, nl;
+            v2p_vcf_index_sample(idx, s, &nb, &nl);
+            const std::string path = std::string(outdir) + "/" + vcf.substr(nb, nl) + (compressed ? ".fasta.gz" : ".fasta");   // personalized_genome.rs:76-80
+            std::ofstream f;
+            gzFile gz = nullptr;
+            if (compressed) gz = gzopen(path.c_str(), "wb9");                        // GzEncoder, Compression::best() (:90)
+            else f.open(path, std::ios::binary);
+            if (compressed ? gz == nullptr : !f) { std::fprintf(stderr, "Could not create %s\n", path.c_str()); return false; }
+            for (int h = 0; h < 2; ++h) {
+                const uint64_t k = 2 * (s - s0) + uint64_t(h), begin = hob[k], len = hob[k + 1] - hob[k];
+                bool ok = true;
+                if (compressed) {
+                    for (uint64_t o = 0; o < len && ok; o += 1u << 30) {
+                        const unsigned part = unsigned(std::min<uint64_t>(len - o, 1u << 30));
+                        ok = gzwrite(gz, bytes + begin + o, part) == int(part);
+                    }
+                } else {
+                    f.write(reinterpret_cast<const char*>(bytes + begin), std::streamsize(len));
+                    ok = bool(f);
+                }
+                if (!ok) { std::fprintf(stderr, "Could not write %s\n", path.c_str()); if (gz) gzclose(gz); return false; }   // (a full disk is an error, not a short file)
+                written += len;
+            }
+            if (gz && gzclose(gz) != Z_OK) { std::fprintf(stderr, "Could not write %s\n", path.c_str()); return false; }
+            if (!compressed) { f.close(); if (!f) { std::fprintf(stderr, "Could not write %s\n", path.c_str()); return false; } }
+        }
+        t_write_acc += since(tw);
+        return true;
+    };
+    // ---- a slice the rows builders refuse (a 1 KiB row with more than 1 024 descriptors): the grid builders of round 3, smaller windows
+    // first refused (txstream.py::build_plan), on a batch of its own; its arena is downloaded whole ----
+    auto blocking_slice = [&](TxStreamHost& tx, std::vector<uint8_t>& bytes, std::vector<uint64_t>& hob) {
+        v2p_txstream st = tx.view();
+        v2p_batch* fb = nullptr;
+        chk(v2p_batch_create(ctx.raw(), &fb));
+        v2p_routing rules;
+        chk(v2p_routing_rules(0, 0, tx.result_bytes, 0, 1, &rules));
+        const double bpt = double(tx.result_bytes) / double(st.n_tasks ? st.n_tasks : 1);
+        std::vector<std::pair<int, uint32_t>> plan_v;
+        if (bpt < double(rules.wave_bytes_per_task)) plan_v = {{3, 12288}, {3, 8192}, {3, 4096}, {2, 4096}};
+        else plan_v = {{2, 32768}, {2, 16384}, {2, 4096}};
+        int rc = V2P_ERR_UNSUPPORTED;
+        for (size_t k = 0; k < plan_v.size() && rc == V2P_ERR_UNSUPPORTED; ++k) rc = v2p_batch_build_on_device(fb, &st, plan_v[k].second, plan_v[k].first, nullptr);
+        chk(rc);
+        chk(v2p_batch_execute(fb));
+        chk(v2p_batch_sync(fb));
+        hob.assign(st.n_haps + 1, 0);
+        for (uint64_t h = 0; h < st.n_haps; ++h) { uint64_t begin, len; chk(v2p_batch_hap_range(fb, h, &begin, &len)); hob[h] = begin; hob[h + 1] = begin + len; }
+        bytes.resize(hob.back());
+        if (!bytes.empty()) chk(v2p_batch_download(fb, 0, bytes.size(), bytes.data()));
+        v2p_batch_destroy(fb);
+    };
+    // ---- the pipeline ----
+    constexpr uint32_t SLOTS = 3;
+    v2p_pipeline* pipe = nullptr;
+    if (!host_build) chk(v2p_pipeline_create(ctx.raw(), SLOTS, &pipe));
+    // (every way out of this function -- a transcript the reference would panic on, a full disk -- ends the pipeline's runner before the
+    // context it works on goes)
+    struct PipeGuard { v2p_pipeline*& p; ~PipeGuard() { if (p) { v2p_pipeline_destroy(p); p = nullptr; } } } pipe_guard{pipe};
+    struct Job { uint32_t ticket; uint64_t s0, s1; std::unique_ptr<TxStreamHost> tx; };
+    std::vector<Job> inflight;
+    uint64_t n_slices = 0, n_fallback = 0;
+    auto finish = [&](Job& j) -> bool {
+        const uint8_t* bytes = nullptr; uint64_t n = 0, nh = 0;
+        const uint64_t* hob = nullptr;
+        const int rc = v2p_pipeline_wait(pipe, j.ticket, &bytes, &n);
+        if (rc == V2P_ERR_UNSUPPORTED) {
+            chk(v2p_pipeline_release(pipe, j.ticket));
+            std::vector<uint8_t> fb_bytes; std::vector<uint64_t> fb_hob;
+            blocking_slice(*j.tx, fb_bytes, fb_hob);
+            ++n_fallback;
+            return write_probands(j.s0, j.s1, fb_bytes.data(), fb_hob.data());
+        }
+        chk(rc);
+        chk(v2p_pipeline_result_info(pipe, j.ticket, &hob, &nh, nullptr, nullptr));
+        if (nh != 2 * (j.s1 - j.s0)) { std::fprintf(stderr, "panicked: a slice came back with another number of haplotypes\n"); std::exit(101); }
+        const bool ok = write_probands(j.s0, j.s1, bytes, hob);
+        chk(v2p_pipeline_release(pipe, j.ticket));
+        return ok;
+    };
+    uint64_t slice_s0 = 0;
+    auto flush = [&](uint64_t s1) -> bool {                      // probands [slice_s0, s1) are complete: off they go
+        if (s1 == slice_s0) return true;
+        if (inflight.size() == SLOTS) { if (!finish(inflight.front())) return false; inflight.erase(inflight.begin()); }
+        v2p_txstream st = txs_p->view();
+        uint32_t t = 0;
+        chk(v2p_pipeline_submit_stream(pipe, &st, 0, 0, &t));
+        inflight.push_back(Job{t, slice_s0, s1, std::move(txs_p)});
+        txs_p.reset(new TxStreamHost());
+        slice_s0 = s1; ++n_slices;
+        return true;
+    };
+    TxStreamHost* txs = nullptr;
     auto add_transcript = [&](const uint8_t* c, const uint64_t* p, const uint64_t* l, const uint64_t* r, uint64_t n, uint64_t o, uint64_t rl,
                               const uint8_t* a, uint64_t na, uint64_t res, uint64_t ho, uint32_t hl) {
         if (host_build) chk(v2p_batch_add_transcript(b, c, p, l, r, n, o, rl, a, na, res, ho, hl));
-        else txs.add(c, p, l, r, n, o, rl, a, na, res, ho, hl);
+        else txs->add(c, p, l, r, n, o, rl, a, na, res, ho, hl);
     };
     const uint64_t* hgb = v2p_groups_hap_group_begin(g);
     const uint32_t* gtx = v2p_groups_group_transcript(g);
@@ -341,6 +460,7 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
         add_transcript(&ref_code, &zero, &t.len, &zero, 1, t.off, t.len, nullptr, 0, t.len, t.hdr[hap & 1], uint32_t(name_len + 4));
     };
     for (uint64_t hap = 0; hap < 2 * S; ++hap) {
+        txs = txs_p.get();
         if (host_build) chk(v2p_batch_begin_haplotype(b));
         // the haplotype's groups, and with -a the rest of the reference around them, in sorted transcript order
         std::vector<std::pair<const std::pair<const std::string, RefTx>*, int64_t>> todo;     // (reference entry, group index or -1)
@@ -380,82 +500,38 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
                            alt.data(), n_alt, res_len, hdr_off[2 * r + (hap & 1)], uint32_t(names[r].size() + 4));
         }
         if (host_build) chk(v2p_batch_end_haplotype(b));
-        else txs.hap_tx_begin.push_back(txs.off.size());
-    }
-    t_build = since(t0); t0 = clk::now();
-    if (host_build) chk(v2p_batch_finalize(b));
-    else {
-        // (the builder's slab loads read a few entries past a transcript's last task / alt byte)
-        for (int k = 0; k < 64; ++k) { txs.code.push_back(0); txs.sp.push_back(0); txs.ln.push_back(0); txs.sr.push_back(0); txs.alt.push_back(0); }
-        v2p_txstream st{};
-        st.n_haps = 2 * S; st.n_tx = txs.off.size(); st.n_tasks = txs.code.size() - 64; st.n_alt = txs.alt.size() - 64;
-        st.hap_tx_begin = txs.hap_tx_begin.data(); st.tx_proteome_off = txs.off.data(); st.tx_ref_len = txs.ref_len.data(); st.tx_res_len = txs.res_len.data();
-        st.tx_task_begin = txs.task_begin.data(); st.tx_alt_begin = txs.alt_begin.data();
-        st.code = txs.code.data(); st.start_pos = txs.sp.data(); st.length = txs.ln.data(); st.start_pos_res = txs.sr.data(); st.alt = txs.alt.data();
-        st.tx_header_off = txs.hdr_off.data(); st.tx_header_len = txs.hdr_len.data();
-        // The product's one call (round 5): the stream resident, then image build + execute in v2p_batch_build_and_execute (kernel 0: a wave
-        // image from v2p_routing_rules().wave_bytes_per_task result bytes per Task, a dense one below or when a row is too full).  A stream
-        // even the dense rows image refuses goes to the grid builders of round 3, smaller windows first refused (txstream.py::build_plan).
-        v2p_stream* rs = nullptr;
-        chk(v2p_stream_upload(ctx.raw(), &st, &rs));
-        int rc = v2p_batch_build_and_execute(b, rs, 0, 0);
-        if (rc == V2P_ERR_UNSUPPORTED) {
-            v2p_routing rules;
-            chk(v2p_routing_rules(0, 0, txs.result_bytes, 0, 1, &rules));
-            const double bpt = double(txs.result_bytes) / double(st.n_tasks ? st.n_tasks : 1);
-            std::vector<std::pair<int, uint32_t>> plan_v;
-            if (bpt < double(rules.wave_bytes_per_task)) plan_v = {{3, 12288}, {3, 8192}, {3, 4096}, {2, 4096}};
-            else plan_v = {{2, 32768}, {2, 16384}, {2, 4096}};
-            chk(v2p_batch_reset(b));
-            for (size_t k = 0; k < plan_v.size() && rc == V2P_ERR_UNSUPPORTED; ++k) rc = v2p_batch_build_on_device(b, &st, plan_v[k].second, plan_v[k].first, nullptr);
-            chk(rc);
-            chk(v2p_batch_execute(b));
-        } else chk(rc);
-        chk(v2p_batch_sync(b));
-        v2p_stream_destroy(rs);                                    // (the arena is complete; nothing executes this batch again)
-    }
-    if (host_build) chk(v2p_batch_execute(b));
-    chk(v2p_batch_sync(b));
-    t_exec = since(t0); t0 = clk::now();
-    uint64_t written = 0;
-    std::vector<uint8_t> buf;
-    for (uint64_t s = 0; s < S; ++s) {
-        uint64_t nb, nl;
-        v2p_vcf_index_sample(idx, s, &nb, &nl);
-        const std::string path = std::string(outdir) + "/" + vcf.substr(nb, nl) + (compressed ? ".fasta.gz" : ".fasta");   // personalized_genome.rs:76-80
-        std::ofstream f;
-        gzFile gz = nullptr;
-        if (compressed) gz = gzopen(path.c_str(), "wb9");                        // GzEncoder, Compression::best() (:90)
-        else f.open(path, std::ios::binary);
-        if (compressed ? gz == nullptr : !f) { std::fprintf(stderr, "Could not create %s\n", path.c_str()); return 101; }
-        for (int h = 0; h < 2; ++h) {
-            uint64_t begin, len;
-            chk(v2p_batch_hap_range(b, 2 * s + h, &begin, &len));
-            buf.resize(len);
-            if (len) chk(v2p_batch_download(b, begin, len, buf.data()));
-            bool ok = true;
-            if (compressed) {
-                for (uint64_t o = 0; o < len && ok; o += 1u << 30) {
-                    const unsigned part = unsigned(std::min<uint64_t>(len - o, 1u << 30));
-                    ok = gzwrite(gz, buf.data() + o, part) == int(part);
-                }
-            } else {
-                f.write(reinterpret_cast<const char*>(buf.data()), std::streamsize(len));
-                ok = bool(f);
-            }
-            if (!ok) { std::fprintf(stderr, "Could not write %s\n", path.c_str()); if (gz) gzclose(gz); return 101; }   // (a full disk is an error, not a short file)
-            written += len;
+        else {
+            txs->hap_tx_begin.push_back(txs->off.size());
+            if ((hap & 1) && (txs->result_bytes >= slice_bytes || hap + 1 == 2 * S) && !flush(hap / 2 + 1)) return 101;   // a proband is complete
         }
-        if (gz && gzclose(gz) != Z_OK) { std::fprintf(stderr, "Could not write %s\n", path.c_str()); return 101; }
-        if (!compressed) { f.close(); if (!f) { std::fprintf(stderr, "Could not write %s\n", path.c_str()); return 101; } }
     }
-    t_write = since(t0);
+    t_build = since(t0) - t_write_acc; t0 = clk::now();
+    if (host_build) {
+        chk(v2p_batch_finalize(b));
+        chk(v2p_batch_execute(b));
+        chk(v2p_batch_sync(b));
+        t_exec = since(t0); t0 = clk::now();
+        std::vector<uint64_t> hob(2 * S + 1, 0);
+        for (uint64_t h = 0; h < 2 * S; ++h) { uint64_t begin, len; chk(v2p_batch_hap_range(b, h, &begin, &len)); hob[h] = begin; hob[h + 1] = begin + len; }
+        std::vector<uint8_t> bytes(hob.back());
+        if (!bytes.empty()) chk(v2p_batch_download(b, 0, bytes.size(), bytes.data()));
+        if (!write_probands(0, S, bytes.data(), hob.data())) return 101;
+    } else {
+        const double w0 = t_write_acc;
+        for (Job& j : inflight) if (!finish(j)) return 101;
+        inflight.clear();
+        v2p_pipeline_destroy(pipe);
+        pipe = nullptr;
+        t_exec = since(t0) - (t_write_acc - w0); t0 = clk::now();
+    }
+    t_write = host_build ? since(t0) : t_write_acc;
     std::printf("vcf: %llu records, %llu probands, %llu bytes of FASTA written to %s\n", (unsigned long long)R, (unsigned long long)S,
                 (unsigned long long)written, outdir);
-    std::printf("{\"records\": %llu, \"probands\": %llu, \"fasta_bytes\": %llu, \"seconds\": {\"read_files\": %.4f, \"index\": %.4f, "
+    std::printf("{\"records\": %llu, \"probands\": %llu, \"fasta_bytes\": %llu, \"slices\": %llu, \"slices_through_grid_builders\": %llu, \"seconds\": {\"read_files\": %.4f, \"index\": %.4f, "
                 "\"decode_incl_h2d\": %.4f, \"grouping\": %.4f, \"steps_4a_4b_5\": %.4f, \"h2d_step6_sync\": %.4f, \"d2h_write\": %.4f, \"total\": %.4f}, "
                 "\"decode_kernels_ms\": {\"parse\": %.3f, \"count\": %.3f, \"scan\": %.3f, \"emit\": %.3f}}\n",
-                (unsigned long long)R, (unsigned long long)S, (unsigned long long)written, t_read, t_index, t_decode, t_group, t_build, t_exec, t_write,
+                (unsigned long long)R, (unsigned long long)S, (unsigned long long)written, (unsigned long long)n_slices, (unsigned long long)n_fallback,
+                t_read, t_index, t_decode, t_group, t_build, t_exec, t_write,
                 since(t_start), kms[0], kms[1], kms[2], kms[3]);
     v2p_batch_destroy(b);
     v2p_groups_destroy(g);
@@ -465,7 +541,20 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
 
 // ------------------------------------------------------------------------------------------------------------------
 // sharded: parts/exec.rs:34-40 over the devices of one node, in one process (ppgg::execute_sharded)
-static int sharded(const char* preset, uint32_t samples, int n_devices, bool oversubscribe, int threads)
+// the checker's digest (include/vcf2prot_hip.h: v2p_batch_digests' definition) of bytes in host memory
+static uint64_t host_digest(const uint8_t* p, uint64_t n)
+{
+    auto mix = [](uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); };
+    uint64_t s = 0;
+    const uint64_t nw = n >> 3;
+    for (uint64_t k = 0; k < nw; ++k) { uint64_t w; std::memcpy(&w, p + 8 * k, 8); s += (w + 0x0101010101010101ull) * mix(k); }
+    uint64_t t = 0;
+    for (uint64_t i = 8 * nw; i < n; ++i) t += (uint64_t(p[i]) + 1ull) << (8 * (i & 7));
+    if (n & 7) s += t * mix(nw);
+    return s;
+}
+
+static int sharded(const char* preset, uint32_t samples, int n_devices, bool oversubscribe, int threads, bool streamed, uint64_t slice_mb)
 {
     v2p_cohort_params p;
     if (v2p_cohort_preset(preset, &p)) { std::fprintf(stderr, "unknown preset %s\n", preset); return 2; }
@@ -503,14 +592,32 @@ static int sharded(const char* preset, uint32_t samples, int n_devices, bool ove
     };
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<DeviceShard> shards;
-    try { shards = execute_sharded(sizes, devices, v2p_cohort_proteome(c), v2p_cohort_proteome_len(c), make_stream, consume); }
+    std::atomic<uint64_t> host_bytes{0}, n_slices{0};
+    auto consume_slice = [&](const DeviceShard&, uint64_t h0, uint64_t h1, const uint8_t* bytes, uint64_t n, const uint64_t* hob, const uint64_t* dig) {
+        // what crossed the link: every haplotype digested HERE, on the host, and compared with the device's digest of its arena
+        if (hob[h1 - h0] != n) throw Panic(V2P_ERR_STATE, "a slice's offsets do not end at its size");
+        for (uint64_t h = h0; h < h1; ++h) {
+            if (hob[h - h0 + 1] - hob[h - h0] != sizes[h]) throw Panic(V2P_ERR_STATE, "haplotype range of a slice disagrees with the cohort's result sizes");
+            digest[h] = host_digest(bytes + hob[h - h0], sizes[h]);
+            if (dig && dig[h - h0] != digest[h]) throw Panic(V2P_ERR_STATE, "the host bytes of a haplotype digest differently from its arena on the device");
+        }
+        host_bytes += n; ++n_slices;
+    };
+    try {
+        if (streamed) shards = execute_streamed(sizes, devices, v2p_cohort_proteome(c), v2p_cohort_proteome_len(c), nullptr, 0, make_stream, consume_slice,
+                                                slice_mb << 20, 4, uint32_t(per > 16 ? 16 : per));
+        else shards = execute_sharded(sizes, devices, v2p_cohort_proteome(c), v2p_cohort_proteome_len(c), make_stream, consume);
+    }
     catch (const Panic& e) { std::fprintf(stderr, "panicked: %s\n", e.what()); return 101; }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     uint64_t total = 0;
     for (uint64_t b : sizes) total += b;
-    std::printf("{\"mode\": \"sharded: %d device context(s) in one process, ranges of equal result bytes, one v2p_batch_build_and_execute each\", \"preset\": \"%s\", "
-                "\"samples\": %u, \"haplotypes\": %llu, \"result_bytes\": %llu, \"devices_present\": %d, \"wall_seconds_incl_generation_and_upload\": %.6f, \"shards\": [",
-                n_devices, preset, p.n_samples, (unsigned long long)n_haps, (unsigned long long)total, have, secs);
+    std::printf("{\"mode\": \"sharded: %d device context(s) in one process, ranges of equal result bytes, %s\", \"preset\": \"%s\", "
+                "\"samples\": %u, \"haplotypes\": %llu, \"result_bytes\": %llu, \"devices_present\": %d, \"wall_seconds_incl_generation_and_upload\": %.6f, "
+                "\"streamed\": %s, \"slices\": %llu, \"host_bytes\": %llu, \"shards\": [",
+                n_devices, streamed ? "one v2p_pipeline per device: Task-vector slices in, host bytes out (v2p_pipeline_submit_stream)" : "one v2p_batch_build_and_execute each",
+                preset, p.n_samples, (unsigned long long)n_haps, (unsigned long long)total, have, secs, streamed ? "true" : "false",
+                (unsigned long long)n_slices.load(), (unsigned long long)host_bytes.load());
     for (size_t r = 0; r < shards.size(); ++r) {
         const DeviceShard& s = shards[r];
         std::printf("%s{\"rank\": %d, \"device\": %d, \"h0\": %llu, \"h1\": %llu, \"byte_offset\": %llu, \"bytes\": %llu, \"seconds\": %.6f, \"oneshot_ms\": %.4f}", r ? ", " : "",
@@ -523,17 +630,21 @@ static int sharded(const char* preset, uint32_t samples, int n_devices, bool ove
     return 0;
 }
 
+static uint64_t vcf_slice_kb = 0;       // vcf --slice-kb K: slices of K KiB of FASTA text (tests: several slices out of a small file)
+
 int main(int argc, char** argv)
 {
     if (argc >= 5 && !std::strcmp(argv[1], "vcf")) {
         bool no_test = false, write_all = false, compressed = false, host_build = false;
+        uint64_t slice_mb = 256;
         for (int i = 5; i < argc; ++i) {
+            if (!std::strcmp(argv[i], "--slice-kb") && i + 1 < argc) { slice_mb = 0; vcf_slice_kb = std::strtoull(argv[++i], nullptr, 10); continue; }
             no_test |= !std::strcmp(argv[i], "--no-test");
             host_build |= !std::strcmp(argv[i], "--host-build");
             write_all |= !std::strcmp(argv[i], "--write-all") || !std::strcmp(argv[i], "-a");
             compressed |= !std::strcmp(argv[i], "--write-compressed") || !std::strcmp(argv[i], "-c");
         }
-        try { return vcf_mode(argv[2], argv[3], argv[4], no_test, write_all, compressed, host_build); }
+        try { return vcf_mode(argv[2], argv[3], argv[4], no_test, write_all, compressed, host_build, slice_mb ? slice_mb << 20 : (vcf_slice_kb ? vcf_slice_kb << 10 : 1)); }
         catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 101; }
     }
     if (argc >= 3 && !std::strcmp(argv[1], "shard")) {              // the cut rule alone (no GPU): one "begin end" line per rank
@@ -544,20 +655,24 @@ int main(int argc, char** argv)
     }
     if (argc >= 4 && !std::strcmp(argv[1], "sharded")) {
         int n_devices = 1, threads = int(std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 8);
-        bool over = false;
+        bool over = false, streamed = false;
+        uint64_t slice_mb = 1152;
         for (int i = 4; i < argc; ++i) {
             if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) n_devices = std::atoi(argv[++i]);
             else if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = std::atoi(argv[++i]);
+            else if (!std::strcmp(argv[i], "--slice-mb") && i + 1 < argc) slice_mb = std::strtoull(argv[++i], nullptr, 10);
             else if (!std::strcmp(argv[i], "--oversubscribe")) over = true;
+            else if (!std::strcmp(argv[i], "--streamed")) streamed = true;
         }
+        if (slice_mb < 1) slice_mb = 1;
         if (n_devices < 1 || n_devices > 64) { std::fprintf(stderr, "--devices 1 .. 64\n"); return 2; }
         if (threads > 64) threads = 64;
-        return sharded(argv[2], uint32_t(std::strtoul(argv[3], nullptr, 10)), n_devices, over, threads);
+        return sharded(argv[2], uint32_t(std::strtoul(argv[3], nullptr, 10)), n_devices, over, threads, streamed, slice_mb);
     }
     if (argc >= 2 && !std::strcmp(argv[1], "kat")) return kat();
     if (argc >= 5 && !std::strcmp(argv[1], "run"))
         return run(argv[2], std::strtoull(argv[3], nullptr, 10), std::atoi(argv[4]), argc >= 6 && (!std::strcmp(argv[5], "--shared") || !std::strcmp(argv[5], "--async")),
                    argc >= 6 && !std::strcmp(argv[5], "--async"));
-    std::fprintf(stderr, "usage: v2p_harness kat | run <preset> <haplotypes> <threads> [--shared | --async] | sharded <preset> <samples> --devices N [--oversubscribe] | shard <world> <bytes...>\n");
+    std::fprintf(stderr, "usage: v2p_harness kat | run <preset> <haplotypes> <threads> [--shared | --async] | sharded <preset> <samples> --devices N [--oversubscribe] [--streamed [--slice-mb M]] | shard <world> <bytes...>\n");
     return 2;
 }

@@ -40,11 +40,13 @@ def read_fasta(text: str) -> Dict[str, str]:
 
 
 def vcf_to_fasta(ctx, vcf: bytes, reference_fasta: str, flags: int = step4a.DEFAULT_FLAGS, write_all: bool = False,
-                 device_build: bool = True) -> Dict[str, bytes]:
+                 device_build: bool = True, slice_bytes: int = 256 << 20) -> Dict[str, bytes]:
     """{proband: text of <proband>.fasta}: the altered transcripts (personalized_genome.rs:72-117) or, with write_all
     (-a / --write_all_proteins, :118-204), every transcript of the reference per haplotype, unaltered ones as they are.
-    device_build (default): step 5, the image packing and the FASTA record text are built ON the device from the per-transcript
-    GIRs (v2p_batch_build_on_device); False: the host builder (v2p_batch_add_transcript) -- same bytes."""
+    device_build (default): the per-transcript GIRs of whole probands are gathered into SLICES of about `slice_bytes` of FASTA text and
+    every slice goes through the stream-fed pipeline as soon as it is complete (v2p_pipeline_submit_stream: step 5, the image, step 6 and
+    the record text on the device, the text back in pinned host memory) while steps 4a / 4b of the next probands run here;
+    False: the host builder (v2p_batch_add_transcript), one image -- same bytes."""
     ref = read_fasta(reference_fasta)
     idx = VcfIndex(vcf)
     lists = decode_bitmasks(ctx, idx)
@@ -67,11 +69,56 @@ def vcf_to_fasta(ctx, vcf: bytes, reference_fasta: str, flags: int = step4a.DEFA
                 hpos += len(text)
     proteome = np.frombuffer("".join(pieces).encode(), dtype=np.uint8) if pieces else np.zeros(0, np.uint8)
     ctx.upload_reference(proteome, np.frombuffer("".join(hdr).encode(), dtype=np.uint8))
-    b = ctx.batch()
+    sample_names = idx.sample_names()
+    out: Dict[str, bytes] = {}
+    b = ctx.batch() if not device_build else None
+    pipe = None
     sink = b
+    inflight = []                                                      # (ticket, first proband, one past the last, the slice's host stream)
+    slots = 3
     if device_build:
+        from .engine import Pipeline
         from .txstream import TxStreamBuilder, build_on_device_auto
+        pipe = Pipeline(ctx, slots)
         sink = TxStreamBuilder(fasta=True)
+
+    def collect(job):
+        t, s0, s1, stream = job
+        try:
+            text = pipe.wait(t)
+            hob = pipe.result_info(t)["hap_out_begin"]
+            for s in range(s0, s1):
+                k = 2 * (s - s0)
+                out[sample_names[s]] = text[int(hob[k]):int(hob[k + 2])].tobytes()
+            pipe.release(t)
+        except N.V2PError as e:
+            if e.code != -9:
+                raise
+            # a slice even the dense rows image refuses (a 1 KiB row with more than 1 024 descriptors): the grid builders of round 3
+            pipe.release(t)
+            fb = ctx.batch()
+            try:
+                build_on_device_auto(fb, stream)
+                fb.execute()
+                fb.sync()
+                for s in range(s0, s1):
+                    k = 2 * (s - s0)
+                    out[sample_names[s]] = fb.download_hap(k).tobytes() + fb.download_hap(k + 1).tobytes()
+            finally:
+                fb.close()
+        stream.close()
+
+    def flush(s1, s0_box=[0]):
+        nonlocal sink
+        if s1 == s0_box[0]:
+            return
+        if len(inflight) == slots:
+            collect(inflight.pop(0))
+        stream = sink.finish()
+        inflight.append((pipe.submit_stream(stream, 0, False), s0_box[0], s1, stream))
+        s0_box[0] = s1
+        sink = TxStreamBuilder(fasta=True)
+
     try:
         for hap in range(lists.n_haplotypes):
             if not device_build:
@@ -111,30 +158,20 @@ def vcf_to_fasta(ctx, vcf: bytes, reference_fasta: str, flags: int = step4a.DEFA
                 sink.add_transcript(t[:, 0].astype(np.uint8), t[:, 1], t[:, 2], t[:, 3], off[tx], len(ref[tx]),
                                     np.frombuffer(alt, dtype=np.uint8), res_len, ho, hl)
             sink.end_haplotype()
-        rs = None
+            if device_build and hap % 2 == 1 and (sink.result_bytes() >= slice_bytes or hap + 1 == lists.n_haplotypes):
+                flush(hap // 2 + 1)                                    # a proband is complete; the slice is full (or the last one)
         if device_build:
-            # the product's one call (round 5): the stream made resident, then image build + execute in v2p_batch_build_and_execute; a
-            # stream even its dense rows image refuses (a 1 KiB row with more than 1 024 descriptors) goes to the grid builders of round 3
-            stream = sink.finish()
-            rs = ctx.upload_stream(stream)
-            try:
-                b.build_and_execute(rs, 0, 0)
-            except N.V2PError as e:
-                if e.code != -9:
-                    raise
-                b.reset()
-                build_on_device_auto(b, stream)
-                b.execute()
-            stream.close()
+            while inflight:
+                collect(inflight.pop(0))
         else:
             b.finalize()
             b.execute()
-        b.sync()
-        out = {}
-        for s, name in enumerate(idx.sample_names()):
-            out[name] = b.download_hap(2 * s).tobytes() + b.download_hap(2 * s + 1).tobytes()
-        if rs is not None:
-            rs.close()
+            b.sync()
+            for s, name in enumerate(sample_names):
+                out[name] = b.download_hap(2 * s).tobytes() + b.download_hap(2 * s + 1).tobytes()
         return out
     finally:
-        b.close()
+        if pipe is not None:
+            pipe.close()
+        if b is not None:
+            b.close()
