@@ -438,17 +438,26 @@ def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verif
                             "XCD order, then every phase of the stitch kernel; the timed steps behind it re-execute the same batch (made dense at its first re-execute); total_ms = HIP events "
                             "from before the first build kernel to behind the last stitch kernel, buffers recycled, 0.5 s of host sleep in front (clocks down); "
                             "*_gpu_busy_before: the same call right behind four executes (clocks up)"})
-        desc, chunks, hb = b.download_image()
-        hbm_min, n_fused, n_imm = image_stats(desc, chunks, proteome.size, out_bytes)
+        tiles = b.image_form().get("tiles", False)
+        if tiles:
+            # a TILE image (deep Task vectors, round 6): 8-byte pieces in the tiles' slots; a tile's record is its count (4 B) and its res_counter (8 B)
+            cn = b.counts()
+            n_desc_img, n_chunks_img, image_bytes = cn["n_desc"], cn["n_chunks"], 8 * cn["n_desc"] + 12 * cn["n_chunks"]
+            hbm_min, n_fused, n_imm = out_bytes + image_bytes + int(proteome.size), None, None
+        else:
+            desc, chunks, hb = b.download_image()
+            hbm_min, n_fused, n_imm = image_stats(desc, chunks, proteome.size, out_bytes)
+            n_desc_img, n_chunks_img, image_bytes = int(desc.size), int(chunks.shape[0]), 8 * int(desc.size) + 16 * int(chunks.shape[0])
+            del desc, chunks
         # bytes one shot must move: the stream read once, the image written and read once, the result written once
-        one_bytes = stream_bytes + 2 * (8 * int(desc.size) + 16 * int(chunks.shape[0])) + out_bytes + int(proteome.size)
+        one_bytes = stream_bytes + 2 * image_bytes + out_bytes + int(proteome.size)
         one["hbm_bytes_min"] = one_bytes
         one["frac_physical"] = one_bytes / (one["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         one["frac_physical_gpu_busy_before"] = one_bytes / (one["total_ms_gpu_busy_before"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-        res.update({"descriptors": int(desc.size), "chunks": int(chunks.shape[0]), "fused_substitution_descriptors": n_fused, "immediate_descriptors": n_imm,
-                    "kernel": "stitchw_kernel (rows image)" if i1["kernel"] == 6 else "stitch_pieces_kernel (a dense rows image, re-written as <= 16-byte pieces at its first re-execute; its first execute: stitch_dense_kernel)",
+        res.update({"descriptors": n_desc_img, "chunks": n_chunks_img, "fused_substitution_descriptors": n_fused, "immediate_descriptors": n_imm,
+                    "kernel": "stitchw_kernel (rows image)" if i1["kernel"] == 6 else ("stitch_tiles_kernel (a tile image: <= 16-byte pieces straight from the parse, one workgroup per tile of transcripts; first execute and every later one)" if tiles else
+                                                                                         "stitch_pieces_kernel (a dense rows image, re-written as <= 16-byte pieces at its first re-execute; its first execute: stitch_dense_kernel)"),
                     "hbm_bytes_min_per_launch": hbm_min, "algorithmic_bytes_per_launch": 2 * A + 16 * NT, "one_shot": one})
-        del desc, chunks
         t = Timed(ctx, b)
         # ---- parity before timing: per-haplotype digests vs the oracle ----
         dig = b.digests()

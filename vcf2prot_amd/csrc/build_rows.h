@@ -46,6 +46,8 @@ struct RowsArgs {
     uint32_t  pad_chunks = 0;           // the cutter's records (and the keys) address the PADDED array (sir_pack.hpp: ROWS_TILE_SLOTS slots per tile, GLOBAL tile
                                         // numbers: desc = the whole array, desc_pad = its first slot of tile0); totals[3] bit 1: a chunk did not fit the form
     uint32_t  xcd_tiles = 1;            // the parse deals contiguous eighths of its tiles to the XCDs (0: tile = workgroup index; A/B switch)
+    uint32_t  tile_slots = 0;           // TILE images (ROWS_TILES; dense_pieces.h): piece slots per tile in desc_pad (<= 2048) ...
+    uint32_t  tile_span_max = 0;        // ... and the most result bytes a tile may hold (the executor's LDS image; <= 16368)
     uint64_t* totals;                   // [4]: -, -, result offset of the last chunk, -
     uint64_t* desc;
     uint64_t  desc_cap;

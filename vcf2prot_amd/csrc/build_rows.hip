@@ -178,6 +178,7 @@ struct __attribute__((aligned(16))) WaveLds {
 template <int MODE, bool FASTA, int PHASE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_parse_kernel(RowsArgs a)
 {
+    constexpr bool TILES = MODE == ROWS_TILES;                       // pieces of a TILE image (dense_pieces.h) instead of descriptors: no row map, no cutter behind this kernel
     constexpr uint32_t CTX = MODE == ROWS_DENSE ? 4u : 2u, ADV = 62u - CTX;
     constexpr int NR = FASTA ? 5 : 3;                                 // runs a lane may emit
     constexpr int RG = FASTA ? 1 : 0, RS = RG + 1, RT = RG + 2;       // run numbers: [0 header] RG gap, RS the task itself, RT tail [4 line feed]
@@ -195,6 +196,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
     const uint64_t tile_base = a.tile_res_base[tile], tile_end = a.tile_res_base[tile + 1u];
     // positions are 32-bit offsets from the tile's first byte (a tile of more than 2 GiB of result is refused)
     if (tile_end - tile_base > 0x7FFFFFFFull) { if (lane == 0) rreport(a.status, task_lo, STATUS_ROWS_SPAN); if (PHASE != PH_DIRECT && lane == 0) a.tile_count[tile] = 0u; return; }
+    // a TILE image: the tile IS the executor's work item -- its result range must fit the executor's LDS image (the caller then builds a dense rows image)
+    if (TILES && tile_end - tile_base > a.tile_span_max) { if (lane == 0) { rreport(a.status, tile, STATUS_ROWS_STAGE); a.tile_count[tile] = 0u; } return; }
     const uint32_t eoff = uint32_t(tile_base) & (ROW_BYTES - 1u);    // the tile's first byte inside its row
     const uint64_t erow = tile_base / ROW_BYTES;
     // Everything a tile reads before its first window is requested at once -- the transcripts' tables, the first window's tasks
@@ -245,9 +248,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
     }
     asm volatile("" ::: "memory");
     const uint32_t n_items = n_tile_tasks + uint32_t(__popcll(ne));                      // >= nh >= 1
-    uint64_t* const out = PHASE == PH_PAD ? a.desc_pad + uint64_t(rel) * ROWS_PAD : (PHASE == PH_DIRECT ? a.desc + a.tile_desc_base[tile] : nullptr);
+    const uint32_t pad_slots = TILES ? a.tile_slots : ROWS_PAD;
+    uint64_t* const out = PHASE == PH_PAD ? a.desc_pad + uint64_t(rel) * pad_slots : (PHASE == PH_DIRECT ? a.desc + a.tile_desc_base[tile] : nullptr);
     (void)out;
-    const uint32_t out_cap = PHASE == PH_PAD ? ROWS_PAD : 0xFFFFFFFFu;
+    const uint32_t out_cap = PHASE == PH_PAD ? pad_slots : 0xFFFFFFFFu;
     // cover entry: tile : 25 | descriptor inside the tile : 16 | what the descriptor has from the row's first byte on : 11 | offset of that byte
     // inside it : 11 (a descriptor is at most 2047 bytes) -- the two-pass form: 1 << 63 | descriptor << 22 | rest << 11 | offset.  With the
     // rest in the map the cutter never reads a descriptor (round 4 looked every row's up: 2.4 GB of scattered lines) and does not wait
@@ -387,6 +391,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
                             rl[RS] = p_len1 + 1u + p_len2 + 1u + ln; q0 -= p_len1 + p_len2 + 2u;
                             const uint64_t w = SNV5_MARK | (uint64_t(f_byte) << 52) | (uint64_t(p_byte) << 44) | (uint64_t(ln & 31u) << 39) | (uint64_t(p_len2 & 31u) << 34) | (uint64_t(p_len1 & 31u) << 29) | (uint64_t(p_run) & SNV3_MAX_SRC);
                             wl[RS] = uint32_t(w); wh[RS] = uint32_t(w >> 32);
+                        } else if (TILES) {
+                            // (a piece image: the fused run is ONE contiguous source range -- the first copy, the residue the literal replaces, the
+                            // copy that goes on one residue later -- with the literal's position and byte beside it: source | has:1 << 29 | position:12 << 8 | byte)
+                            rl[RS] = f_len1 + 1u + ln; q0 -= f_len1 + 1u;
+                            wl[RS] = f_run;
+                            wh[RS] = (1u << 29) | (f_len1 << 8) | f_byte;
                         } else {
                             rl[RS] = f_len1 + 1u + ln; q0 -= f_len1 + 1u;
                             wl[RS] = (f_run & 0x1FFFFFFFu) | (f_len1 << 29);
@@ -403,6 +413,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
         if (!in_emit) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) rl[i] = 0u;
+        }
+        if constexpr (TILES) {
+            // ---- a TILE image: every run leaves as PIECES -- <= 16 result bytes of one source, their offset inside the tile's result and at
+            // most one substituted residue (dense_pieces.h) -- into the tile's slots; the tile is the executor's work item as it stands
+            uint32_t cn[NR], cnt = 0;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) { cn[i] = (rl[i] + 15u) >> 4; cnt += cn[i]; }
+            const uint32_t incl = wave_incl_scan(cnt);
+            const uint32_t round_total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+            if (PHASE != PH_COUNT && round_total != 0u) {
+                uint32_t k = tile_cnt + incl - cnt;
+                uint32_t pos = q0;                                                       // offset from the tile's first result byte (< 16 384: checked above)
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const uint32_t L = rl[i];
+                    if (L != 0u) {
+                        const uint32_t space = wh[i] >> 30;
+                        const bool haslit = i == RS && space == SPACE_PROTEOME && ((wh[i] >> 29) & 1u) != 0u;
+                        const uint32_t lp = (wh[i] >> 8) & 0xFFFu, lb = wh[i] & 0xFFu;
+                        for (uint32_t at = 0; at < L; at += 16u) {
+                            const uint32_t len = L - at < 16u ? L - at : 16u;
+                            uint64_t w;
+                            if (space == SPACE_IMM) {                                    // (<= 5 bytes: one piece; bits 0..30 and 51..63 hold them)
+                                const uint64_t v = uint64_t(wl[i]) | (uint64_t(wh[i] & 0xFFu) << 32);
+                                w = (v & 0x7FFFFFFFull) | (uint64_t(SPACE_IMM) << 31) | (uint64_t(pos) << 33) | (uint64_t(len - 1u) << 47) | ((v >> 31) << 51);
+                            } else {
+                                const bool has = haslit && lp - at < 16u;                // (unsigned: at <= lp < at + 16)
+                                const uint32_t srcw = space == SPACE_FILL ? 0u : wl[i] + at;
+                                w = uint64_t(srcw & 0x7FFFFFFFu) | (uint64_t(space) << 31) | (uint64_t(pos + at) << 33) | (uint64_t(len - 1u) << 47) |
+                                    (has ? (uint64_t((lp - at) & 15u) << 51) | (1ull << 55) | (uint64_t(lb) << 56) : 0ull);
+                            }
+                            if (k < out_cap) out[k] = w;
+                            ++k;
+                        }
+                        pos += L;
+                    }
+                }
+            }
+            tile_cnt += round_total;
+            if (last) break;
+            carry_h = p.h >> ADV; carry_second = second >> ADV;
+            carry_e = uint32_t(__builtin_amdgcn_readlane(int(e), int(ADV - 1u)));
+            first = false;
+            continue;
         }
         // Everything rare behind ONE uniform branch: a run of more than 1 KiB (it may cross two rows of the arena, or exceed a
         // descriptor's length field and become several descriptors)
@@ -505,7 +559,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
     }
     if (PHASE != PH_DIRECT && lane == 0) {
         a.tile_count[tile] = tile_cnt;
-        if (PHASE == PH_PAD && (tile_cnt > ROWS_PAD || tile_cnt > 0xFFFFu)) rreport(a.status, tile, STATUS_ROWS_STAGE);
+        if (PHASE == PH_PAD && (tile_cnt > pad_slots || tile_cnt > 0xFFFFu)) rreport(a.status, tile, STATUS_ROWS_STAGE);
     }
 }
 
@@ -718,6 +772,13 @@ hipError_t launch_rows_parse(const RowsArgs& a0, int mode, bool fasta, int phase
     if (a.tile1 <= a.tile0) return hipSuccess;
     if (a.tile1 - a.tile0 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (mode == ROWS_DENSE) return fasta ? launch_parse_t<ROWS_DENSE, true>(a, phase, stream) : launch_parse_t<ROWS_DENSE, false>(a, phase, stream);
+    if (mode == ROWS_TILES) {
+        if (phase != PH_PAD || a.tile_slots == 0u || a.tile_slots > 2048u || a.tile_span_max > 16368u) return hipErrorInvalidValue;
+        const dim3 grid{uint32_t(a.tile1 - a.tile0)};
+        if (fasta) hipLaunchKernelGGL((rows_parse_kernel<ROWS_TILES, true, PH_PAD>), grid, dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((rows_parse_kernel<ROWS_TILES, false, PH_PAD>), grid, dim3(64), 0, stream, a);
+        return hipGetLastError();
+    }
     return fasta ? launch_parse_t<ROWS_WAVE, true>(a, phase, stream) : launch_parse_t<ROWS_WAVE, false>(a, phase, stream);
 }
 

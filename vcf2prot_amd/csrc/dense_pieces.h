@@ -48,4 +48,28 @@ struct PieceExecArgs {
 hipError_t launch_stitch_pieces(const PieceExecArgs& a, hipStream_t stream, bool nontemporal);
 hipError_t preload_dense_pieces(hipStream_t stream);
 
+// ---- TILE images (round 6): pieces STRAIGHT FROM THE PARSE ----------------------------------------------------------------------------
+// The one-pass parse of build_rows.hip (ROWS_TILES) writes pieces instead of descriptors: tile t -- K consecutive transcripts, one wave of
+// the parse -- owns slots [tile_slots t, tile_slots (t + 1)) of the piece array, filled from the first, tile_count[t] of them; a piece's
+// offset is relative to the tile's first result byte, tile_res_base[t] (res_counter of haplotype_instruction.rs:90,132 per tile).  The tile
+// IS the executor's work item: no dense image first, no compaction, no row map, no cutter, no chunk table, no XCD sort, and nothing to
+// re-write when the image is executed again -- what a deep cohort's one call runs is the parse and this kernel.  A tile's result range
+// starts anywhere (not on a 1 KiB row): its LDS image is shifted by the range's offset inside its first 16-byte block, whole blocks leave
+// as aligned stores, the ragged first and last block byte by byte (two neighbouring tiles share that block, each writes its own bytes).
+constexpr uint32_t TILE_SPAN_MAX = 16368;          // result bytes of a tile (the 14-bit offset field, minus the shift)
+constexpr uint32_t TILE_SLOTS_MAX = 2048;          // pieces of a tile (eight rounds of the executor's 256 lanes)
+struct TileExecArgs {
+    const uint64_t* pieces;          // [n_tiles * tile_slots]
+    uint32_t        tile_slots;
+    const uint32_t* tile_count;      // [n_tiles]
+    const uint64_t* tile_res_base;   // [n_tiles + 1]
+    uint64_t        n_tiles;
+    const uint8_t*  src0;            // 32 readable bytes before and after (as for every stitch kernel)
+    const uint8_t*  src1;
+    uint8_t*        out;
+    uint64_t        out_len;
+    const unsigned long long* status;    // the build's status word: a build that reported anything is not executed
+};
+hipError_t launch_stitch_tiles(const TileExecArgs& a, hipStream_t stream, bool nontemporal);
+
 }  // namespace v2p

@@ -269,6 +269,94 @@ __global__ __launch_bounds__(256) void stitch_pieces_kernel(PieceExecArgs a)
     }
 }
 
+// ---- TILE images: one workgroup per tile of the parse (dense_pieces.h) ----
+constexpr uint32_t TILES_STAGE = 16384u;                   // bytes of the LDS image: TILE_SPAN_MAX + the 15 bytes a range may start inside its first block
+
+// workgroup b of a grid of G -> the j-th tile of the contiguous range XCD b % 8 owns (build_rows.hip: xcd_contiguous): neighbouring tiles
+// -- which share the 16-byte block and the cache line their ranges meet in -- are written through one L2
+__device__ __forceinline__ uint32_t tiles_xcd_contiguous(uint32_t b, uint32_t G)
+{
+    const uint32_t x = b & 7u, j = b >> 3, q = G >> 3, r = G & 7u;
+    return x * q + (x < r ? x : r) + j;
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256) void stitch_tiles_kernel(TileExecArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_img[TILES_STAGE / 4u + 8u];
+    __shared__ u32x4 s_low[17];                             // s_low[j]: the low j bytes of a 16-byte block
+    const uint32_t tid = threadIdx.x;
+    const uint64_t c = tiles_xcd_contiguous(blockIdx.x, gridDim.x);
+    if (*a.status != ~0ull) return;                         // (the parse refused the stream, or reported what the reference would panic on)
+    const uint32_t n = a.tile_count[c];
+    const uint64_t dst = a.tile_res_base[c], end = a.tile_res_base[c + 1u];
+    const uint32_t span = uint32_t(end - dst), lead = uint32_t(dst) & 15u;
+    const uint64_t p0 = c * a.tile_slots;
+    constexpr uint32_t R = TILE_SLOTS_MAX / 256u;
+    uint64_t rec[R];
+#pragma unroll
+    for (uint32_t j = 0; j < R; ++j) { const uint32_t k = tid + 256u * j; rec[j] = k < n ? a.pieces[p0 + k] : 0ull; }
+    if (tid < 17u) {
+        u32x4 m;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) m[k] = tid >= 4u * k + 4u ? 0xFFFFFFFFu : (tid <= 4u * k ? 0u : (1u << (8u * (tid - 4u * k))) - 1u);
+        s_low[tid] = m;
+    }
+    if (end <= dst || end - dst > TILE_SPAN_MAX || n > a.tile_slots || end > a.out_len) return;       // (an empty tile; the others: never built by the parse)
+    const uint32_t nblk = (lead + span + 15u) >> 4;
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (uint32_t b = tid; b < nblk + 2u; b += 256u) *reinterpret_cast<u32x4*>(&s_img[b * 4u]) = z;
+    }
+    lds_barrier();
+    auto fetch = [&](uint64_t r) -> u32x4 {
+        const uint32_t lo = uint32_t(r);
+        const uint32_t space = uint32_t(r >> 31) & 3u;
+        const bool mem = space == SPACE_PROTEOME || space == SPACE_PAYLOAD;
+        return gather16(reinterpret_cast<uint64_t>(space == SPACE_PAYLOAD ? a.src1 : a.src0) + (mem ? (lo & 0x7FFFFFFFu) : 0u));
+    };
+    u32x4 g = fetch(rec[0]);
+#pragma unroll
+    for (uint32_t j = 0; j < R; ++j) {
+        if (256u * j >= n) break;                                               // (uniform)
+        u32x4 g0 = g;
+        if (j + 1u < R && 256u * (j + 1u) < n) g = fetch(rec[j + 1u < R ? j + 1u : j]);
+        const uint32_t k = tid + 256u * j;
+        const uint64_t cur = rec[j];
+        const uint32_t lo = uint32_t(cur), hi = uint32_t(cur >> 32);
+        const uint32_t space = uint32_t(cur >> 31) & 3u;
+        const uint32_t o = ((hi >> 1) & 0x3FFFu) + lead, len = ((hi >> 15) & 15u) + 1u;
+        if (space == SPACE_FILL) g0 = u32x4{0x2E2E2E2Eu, 0x2E2E2E2Eu, 0x2E2E2E2Eu, 0x2E2E2E2Eu};
+        if (space == SPACE_IMM) {
+            const uint64_t v = uint64_t(lo & 0x7FFFFFFFu) | ((cur >> 51) << 31);
+            g0 = u32x4{uint32_t(v), uint32_t(v >> 32), 0u, 0u};
+        } else if ((hi >> 23) & 1u) {                                            // the substituted residue of a fused run
+            const uint32_t q = (hi >> 19) & 15u, byte = hi >> 24;
+            const uint32_t sh = 8u * (q & 3u), m = 0xFFu << sh, bv = byte << sh, w = q >> 2;
+            g0[0] = w == 0u ? (g0[0] & ~m) | bv : g0[0];
+            g0[1] = w == 1u ? (g0[1] & ~m) | bv : g0[1];
+            g0[2] = w == 2u ? (g0[2] & ~m) | bv : g0[2];
+            g0[3] = w == 3u ? (g0[3] & ~m) | bv : g0[3];
+        }
+        if (k < n && o + len <= lead + span) piece_put(s_img, s_low, o, g0, len);
+    }
+    lds_barrier();
+    // the image leaves: whole 16-byte blocks as aligned stores; the first and the last block of the range, shared with the neighbouring
+    // tiles, byte by byte where they are ragged
+    uint8_t* const out0 = a.out + (dst - lead);
+    for (uint32_t b = tid; b < nblk; b += 256u) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&s_img[b * 4u]);
+        uint8_t* o = out0 + (b << 4);
+        const uint32_t lo_b = b == 0u ? lead : 0u, hi_b = (b << 4) + 16u <= lead + span ? 16u : lead + span - (b << 4);
+        if (lo_b == 0u && hi_b == 16u) {
+            if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(o));
+            else *reinterpret_cast<u32x4*>(o) = v;
+        } else {
+            for (uint32_t j = lo_b; j < hi_b; ++j) o[j] = uint8_t(v[j >> 2] >> (8u * (j & 3u)));
+        }
+    }
+}
+
 __global__ void code_object_loader_e() {}
 
 }  // namespace
@@ -286,6 +374,15 @@ hipError_t launch_stitch_pieces(const PieceExecArgs& a, hipStream_t stream, bool
     if (a.n_chunks == 0) return hipSuccess;
     if (nontemporal) hipLaunchKernelGGL(stitch_pieces_kernel<true>, dim3(a.n_chunks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(stitch_pieces_kernel<false>, dim3(a.n_chunks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_stitch_tiles(const TileExecArgs& a, hipStream_t stream, bool nontemporal)
+{
+    if (a.n_tiles == 0) return hipSuccess;
+    if (a.n_tiles > 0x7FFFFFFFull || a.tile_slots == 0u || a.tile_slots > TILE_SLOTS_MAX) return hipErrorInvalidValue;
+    if (nontemporal) hipLaunchKernelGGL(stitch_tiles_kernel<true>, dim3(uint32_t(a.n_tiles)), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(stitch_tiles_kernel<false>, dim3(uint32_t(a.n_tiles)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -28,7 +28,7 @@ constexpr uint32_t ROWS_SEG = 640;             // rows per segment of the cutter
 constexpr uint32_t ROWS_MAX_WAVE = CHUNK_BYTES_WAVE / ROW_BYTES;      // 10
 constexpr uint32_t ROWS_MAX_DENSE = 12;        // the dense kernel's LDS image is 12 KiB
 
-enum : int { ROWS_WAVE = 1, ROWS_DENSE = 2 };
+enum : int { ROWS_WAVE = 1, ROWS_DENSE = 2, ROWS_TILES = 3 };      // 3 (round 6): a TILE image -- pieces straight from the parse, a tile of transcripts = the executor's work item (dense_pieces.h)
 
 // h[i] = h[i-2] ? g1[i] : g0[i] for the 64 lanes of a wave, lanes 0 and 1 taking 0 as their input: every lane's bit is a one-bit
 // function of the bit two lanes down (even and odd lanes are two independent chains); composing f_i with f_(i-s) for s = 2, 4, ..,

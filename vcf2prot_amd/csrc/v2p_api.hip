@@ -168,6 +168,13 @@ struct v2p_batch {
     DevBuf d_patch;                // PATCH images (patch_image.h): the substituted residues, PATCH_PATCH_CAP slots per chunk (d_desc holds the segments)
     bool is_patch = false;
     uint64_t patch_segs = 0, patch_patches = 0;
+    // a TILE image (dense_pieces.h; round 6: what the one call builds for deep Task vectors): d_desc holds the tiles' piece slots, the tile
+    // tables (count per tile in d_tiles; res_counter per tile there too, or the resident stream's) are the executor's work list
+    bool is_tiles = false;
+    uint32_t tile_slots = 0;
+    uint64_t tiles_n = 0;
+    const uint32_t* tiles_count = nullptr;
+    const uint64_t* tiles_res_base = nullptr;
     const uint8_t* payload_dev = nullptr;   // the alt bytes the image's payload descriptors read: d_payload, or a resident v2p_stream's
     // ... in which case the batch is REGISTERED with that stream (gir.rs:197: GIR::execute(self) owns its tapes by move -- a dangling tape
     // cannot exist there; here the tape is the stream's): v2p_stream_destroy orphans the batches built from it, and an orphan's image is
@@ -1248,6 +1255,7 @@ struct DevStreamView {
     bool fasta = false;
     double items_mean = 1.0, items_var = 0.0;          // items (Tasks; a transcript without Tasks is one) per transcript: rows_pick_k
     double desc_mean = 1.0, desc_var = 0.0;            // ... and an upper estimate of the descriptors per transcript
+    double len_mean = 0.0, len_var = 0.0;              // ... and its arena bytes (rows_pick_k_tiles)
 };
 
 static int build_patch_image(v2p_batch* b, const DevStreamView& v, float* build_ms, bool own_stream_copy, uint64_t known_out_bytes);
@@ -1255,24 +1263,56 @@ static int build_patch_image(v2p_batch* b, const DevStreamView& v, float* build_
 // mean and spread of the items per transcript from a sample of the (host) stream -- and of an upper estimate of its DESCRIPTORS: a
 // one-residue alt Task between two reference copies fuses with both (one descriptor for three Tasks; transcript_instructions.rs:654-663
 // is where a missense becomes that triple), everything else is a descriptor of its own, plus a '.' tail
-static void stream_item_stats(const v2p_txstream* s, double* mean, double* var, double* dmean, double* dvar)
+static void stream_item_stats(const v2p_txstream* s, DevStreamView& v)
 {
-    *mean = 1.0; *var = 0.0; *dmean = 1.0; *dvar = 0.0;
+    v.items_mean = 1.0; v.items_var = 0.0; v.desc_mean = 1.0; v.desc_var = 0.0; v.len_mean = 0.0; v.len_var = 0.0;
     const uint64_t n_tx = s->n_tx;
     if (n_tx == 0) return;
     const uint64_t step = n_tx > 65536 ? n_tx / 65536 : 1;
-    double sum = 0, sq = 0, dsum = 0, dsq = 0, cnt = 0;
+    const bool fasta = s->tx_header_off && s->tx_header_len;
+    double sum = 0, sq = 0, dsum = 0, dsq = 0, lsum = 0, lsq = 0, cnt = 0;
     for (uint64_t u = 0; u < n_tx; u += step) {
         const uint64_t t0 = s->tx_task_begin[u], t1 = s->tx_task_begin[u + 1], nt = t1 - t0;
         const double x = nt ? double(nt) : 1.0;                      // (a transcript without tasks is one item)
         uint64_t nf = 0;
         for (uint64_t i = t0 + 1; i + 1 < t1; ++i) nf += (s->code[i] == 1 && s->length[i] == 1 && s->code[i - 1] == 0 && s->code[i + 1] == 0) ? 1u : 0u;
         const double d = (nt > 2 * nf ? double(nt - 2 * nf) : 1.0) + 1.0;
-        sum += x; sq += x * x; dsum += d; dsq += d * d; cnt += 1;
+        const uint32_t hl = fasta ? s->tx_header_len[u] : 0u;
+        const double l = double(s->tx_res_len[u]) + (hl ? double(hl) + 1.0 : 0.0);       // arena bytes of the transcript
+        sum += x; sq += x * x; dsum += d; dsq += d * d; lsum += l; lsq += l * l; cnt += 1;
     }
-    const double m = sum / cnt, dm = dsum / cnt;
-    *mean = m; *var = sq / cnt - m * m > 0 ? sq / cnt - m * m : 0.0;
-    *dmean = dm; *dvar = dsq / cnt - dm * dm > 0 ? dsq / cnt - dm * dm : 0.0;
+    const double m = sum / cnt, dm = dsum / cnt, lm = lsum / cnt;
+    v.items_mean = m; v.items_var = sq / cnt - m * m > 0 ? sq / cnt - m * m : 0.0;
+    v.desc_mean = dm; v.desc_var = dsq / cnt - dm * dm > 0 ? dsq / cnt - dm * dm : 0.0;
+    v.len_mean = lm; v.len_var = lsq / cnt - lm * lm > 0 ? lsq / cnt - lm * lm : 0.0;
+}
+static void copy_stats(const DevStreamView& from, DevStreamView& to)
+{
+    to.items_mean = from.items_mean; to.items_var = from.items_var; to.desc_mean = from.desc_mean; to.desc_var = from.desc_var; to.len_mean = from.len_mean; to.len_var = from.len_var;
+}
+
+// TILE images (dense_pieces.h): the tile is the executor's work item -- K consecutive transcripts whose result fits its LDS image
+// (TILE_SPAN_MAX bytes) and whose pieces fit the tile's slots (<= TILE_SLOTS_MAX), with SIX standard deviations to spare on either (a
+// tile that does not fit sends the whole build to the dense rows image: it must not happen by chance).  The largest such K; *slots: a
+// power of two from 256 up that holds the tile's pieces with the same margin.  0: no K does (transcripts of a dozen KiB) -- no tile image.
+static uint32_t rows_pick_k_tiles(const DevStreamView& v, uint32_t* slots)
+{
+    *slots = 256;
+    if (v.n_tx == 0) return 1;
+    const double z = 6.0;
+    const double lm = v.len_mean > 1.0 ? v.len_mean : 1.0, lsd = sqrt(v.len_var);
+    const double pm = v.desc_mean + (v.fasta ? 2.0 : 0.0) + lm / 16.0, psd = sqrt(v.desc_var) + lsd / 16.0;     // pieces <= descriptors + result bytes / 16
+    auto k_for = [&](double m, double sd, double cap) { const double x = (-z * sd + sqrt(z * z * sd * sd + 4.0 * m * cap)) / (2.0 * m); return floor(x * x); };
+    double k = k_for(lm, lsd, double(TILE_SPAN_MAX) - 64.0);
+    const double kp = k_for(pm, psd, double(TILE_SLOTS_MAX) - 16.0);
+    if (kp < k) k = kp;
+    if (k > 64.0) k = 64.0;
+    if (k < 1.0) return 0;
+    const double need = k * pm + z * psd * sqrt(k) + 16.0;
+    uint32_t sl = 256;
+    while (sl < TILE_SLOTS_MAX && double(sl) < need) sl <<= 1;
+    *slots = sl;
+    return uint32_t(k);
 }
 
 // Tiles of K consecutive transcripts, one wave each (K <= 64: the kernel's prologue gives every transcript of the tile a lane).  A
@@ -1282,6 +1322,7 @@ static void stream_item_stats(const v2p_txstream* s, double* mean, double* var, 
 // cost) -- mean and spread of the items per transcript from a sample of the stream.
 static uint32_t rows_pick_k(const DevStreamView& v, int mode)
 {
+    if (mode == ROWS_TILES) { uint32_t slots; const uint32_t k = rows_pick_k_tiles(v, &slots); return k ? k : 1u; }
     if (v.n_tx == 0) return 1;
     const double m = v.items_mean, var = v.items_var, sd = sqrt(var);
     const double adv = mode == ROWS_DENSE ? 58.0 : 60.0, z = 1.3;
@@ -1373,7 +1414,7 @@ static int upload_stream(v2p_ctx* c, const v2p_txstream* s, bool fasta, DevBuf& 
     for (uint32_t k = 0; k < np; ++k) HIP_TRY(c, hipMemcpyAsync(d + pc[k].off, pc[k].src, pc[k].bytes, hipMemcpyHostToDevice, stream), pc[k].what);
     if (s->n_alt) HIP_TRY(c, hipMemcpyAsync(altbuf.ptr(), s->alt, s->n_alt, hipMemcpyHostToDevice, stream), "H2D(alt)");
     stream_view(s, L, fasta, d, altbuf.ptr(), v);
-    stream_item_stats(s, &v.items_mean, &v.items_var, &v.desc_mean, &v.desc_var);
+    stream_item_stats(s, v);
     return V2P_OK;
 }
 
@@ -1968,6 +2009,7 @@ static void stream_attach(v2p_batch* b, const v2p_stream* st)
 }
 
 static int rows_mode_for(const v2p_stream* st, int kernel);
+static int build_tiles(v2p_batch* b, const v2p_stream* st, bool execute, bool* fallback, float* build_ms);
 
 int v2p_stream_upload(v2p_ctx* c, const v2p_txstream* s, v2p_stream** out)
 {
@@ -2037,13 +2079,23 @@ int v2p_stream_counts(const v2p_stream* st, uint64_t* n_haps, uint64_t* n_tx, ui
     return V2P_OK;
 }
 
-// kernel 0: the routing rule (sir_pack.hpp: WAVE_BYTES_PER_TASK result bytes per Task and more -> a wave image)
+// a TILE image takes sources below 2 GiB (a piece's 31-bit source field) and transcripts a tile can hold
+static bool tiles_possible(const v2p_stream* st)
+{
+    const v2p_ctx* c = st->ctx;
+    uint32_t slots;
+    return c->proteome_len + c->headers_len + 64u <= PIECE_SRC_MAX && st->v.n_alt + 64u <= PIECE_SRC_MAX && st->v.n_tx != 0 && rows_pick_k_tiles(st->v, &slots) != 0u;
+}
+// kernel 0: the routing rule (sir_pack.hpp: WAVE_BYTES_PER_TASK result bytes per Task and more -> a wave image; below -- deep Task
+// vectors -- a TILE image where the form takes the stream, else a dense rows image; v2p_set_launch_opts variant 28 (A/B): never a tile image)
 static int rows_mode_for(const v2p_stream* st, int kernel)
 {
     if (kernel == 6) return ROWS_WAVE;
     if (kernel == 7) return ROWS_DENSE;
+    if (kernel == 9) return ROWS_TILES;
     const double bpt = double(st->out_bytes) / double(st->v.n_tasks ? st->v.n_tasks : 1);
-    return bpt < double(WAVE_BYTES_PER_TASK) ? ROWS_DENSE : ROWS_WAVE;
+    if (bpt >= double(WAVE_BYTES_PER_TASK)) return ROWS_WAVE;
+    return st->ctx->launch_opts.variant != 28u && tiles_possible(st) ? ROWS_TILES : ROWS_DENSE;
 }
 
 // (c->mu held.  wait: the context's stream is waited for -- the streamed pipeline's runner recycles a slot's batch whose last
@@ -2057,6 +2109,7 @@ static int batch_reset_locked(v2p_batch* b, bool wait)
     b->finalized = false; b->uses_proteome = false; b->hap_open = false;
     b->n_desc = b->n_chunks = b->n_payload = b->out_bytes = b->n_haps = 0;
     b->payload_dev = nullptr; b->n_slices = 0; b->launch_hint = 0; b->is_patch = false; b->patch_segs = b->patch_patches = 0;
+    b->is_tiles = false; b->tile_slots = 0; b->tiles_n = 0; b->tiles_count = nullptr; b->tiles_res_base = nullptr;
     b->pad_image = false; b->desc_slots = 0; b->pad_tdbase = nullptr; b->pieces_state = 0; b->executed = false;
     b->os_kernel = 0; b->os_build_ms = 0.f; b->os_wall_ms = 0.0; b->os_ahead = false;      // (v2p_batch_oneshot_info: no call to report on)
     stream_detach(b); b->orphaned = false;
@@ -2079,11 +2132,19 @@ int v2p_batch_build_from_stream(v2p_batch* b, const v2p_stream* st, int kernel, 
     std::lock_guard<std::mutex> lk(c->mu);
     if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
     if (b->hap_open || b->img.n_haplotypes()) return c->fail(V2P_ERR_STATE, "the batch already holds host-built haplotypes");
-    if (kernel != 0 && kernel != 6 && kernel != 7 && kernel != 8) return c->fail(V2P_ERR_INVALID_ARG, "a resident stream builds rows images (kernel 6, 7), a patch image (8) or what the routing rule picks (0)");
+    if (kernel != 0 && kernel != 6 && kernel != 7 && kernel != 8 && kernel != 9) return c->fail(V2P_ERR_INVALID_ARG, "a resident stream builds rows images (kernel 6, 7), a patch image (8), a tile image (9) or what the routing rule picks (0)");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     b->os_kernel = 0;                                   // (not a one call: v2p_batch_oneshot_info has nothing to report)
     if (kernel == 8) { const int prc = build_patch_image(b, st->v, build_ms, false, st->out_bytes); if (prc == V2P_OK) stream_attach(b, st); return prc; }
     int mode = rows_mode_for(st, kernel);
+    if (mode == ROWS_TILES) {                           // deep Task vectors: a tile image (dense_pieces.h), not executed here
+        bool fb = false;
+        const int trc = build_tiles(b, st, false, &fb, build_ms);
+        if (trc != V2P_OK) return trc;
+        if (!fb) { stream_attach(b, st); return V2P_OK; }
+        if (kernel == 9) return c->fail(V2P_ERR_UNSUPPORTED, "the stream does not fit a tile image: kernel 0 or 7 builds a dense rows image");
+        mode = ROWS_DENSE;
+    }
     int rc = build_rows_image(b, st->v, mode, build_ms, false);
     if (rc == V2P_ERR_UNSUPPORTED && kernel == 0 && mode == ROWS_WAVE) rc = build_rows_image(b, st->v, ROWS_DENSE, build_ms, false);     // (a row with more than 64 descriptors)
     if (rc == V2P_OK) stream_attach(b, st);
@@ -2406,13 +2467,109 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     return V2P_OK;
 }
 
+static hipError_t tiles_execute(v2p_batch* b, hipStream_t stream)
+{
+    v2p_ctx* c = b->ctx;
+    TileExecArgs a{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), b->tile_slots, b->tiles_count, b->tiles_res_base, b->tiles_n,
+                   c->proteome.ptr(), b->payload_dev, b->d_out.ptr(), b->out_bytes, reinterpret_cast<const unsigned long long*>(b->d_status.ptr())};
+    return launch_stitch_tiles(a, stream, !(c->flags & V2P_FLAG_TEMPORAL));
+}
+
+// A TILE image (dense_pieces.h), built -- and, in the one call, executed -- on the context's stream: [res_counter per tile and per haplotype
+// unless the resident stream carries them] the parse (pieces into the tiles' slots), the scan of the tiles' counts (their total: the
+// batch's counts), ONE look of the host at the status word, the executor.  *fallback: a stream the form does not take after all (a tile
+// whose result or whose pieces do not fit: the sample that sized the tiles missed it; no room for the piece slots) -- nothing is
+// lost, the caller builds a dense rows image.  c->mu held.
+static int build_tiles(v2p_batch* b, const v2p_stream* st, bool execute, bool* fallback, float* build_ms)
+{
+    v2p_ctx* c = b->ctx;
+    const DevStreamView& v = st->v;
+    *fallback = false;
+    uint32_t slots = 0;
+    const uint32_t K = tiles_possible(st) ? rows_pick_k_tiles(v, &slots) : 0u;
+    if (K == 0u) { *fallback = true; return V2P_OK; }
+    const uint64_t n_tx = v.n_tx, n_h = v.n_haps, out_bytes = st->out_bytes;
+    const uint64_t n_tiles = (n_tx + K - 1) / K;
+    if (n_tiles >= (1ull << 31)) { *fallback = true; return V2P_OK; }
+    auto up8 = [](uint64_t x) { return (x + 15) & ~uint64_t(15); };
+    uint64_t off = 0;
+    auto carve = [&](uint64_t bytes) { const uint64_t o = off; off += up8(bytes); return o; };
+    const uint64_t o_tbytes = carve(n_tiles * 8), o_tbase = carve((n_tiles + 1) * 8), o_tcount = carve((n_tiles + 1) * 4), o_tdbase = carve((n_tiles + 2) * 8),
+                   o_totals = carve(64), o_scan = carve((rows_scan_scratch_entries(n_tiles) + scan_tiles_for(n_tiles + 1)) * 8);
+    auto oom = [&](hipError_t e) { if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return true; } return false; };
+    {
+        hipError_t e = b->d_tiles.ensure_os(b->grow, off);
+        if (e == hipSuccess) e = b->d_desc.ensure_os(b->grow, n_tiles * slots * 8);
+        if (oom(e)) { *fallback = true; return V2P_OK; }
+        HIP_TRY(c, e, "hipMalloc(tile image)");
+    }
+    HIP_TRY(c, b->d_out.ensure((out_bytes + 15) & ~15ull), "hipMalloc(out)");
+    HIP_TRY(c, b->d_hap.ensure((n_h + 1) * 8), "hipMalloc(hap_begin)");
+    HIP_TRY(c, b->d_digest.ensure((n_h ? n_h : 1) * 8), "hipMalloc(digest)");
+    for (uint32_t k = 0; k < 4; ++k) HIP_TRY(c, ensure_event(b->ev_os[k]), "hipEventCreate");
+    HIP_TRY(c, b->h_sum.ensure(64), "hipHostMalloc(summary)");
+    hipStream_t A = c->stream;
+    int rc = init_status(c, b->d_status);
+    if (rc) return rc;
+    uint8_t* const d = b->d_tiles.ptr();
+    RowsArgs a;
+    rows_args_of(v, c, K, n_tiles, a);
+    a.tile_slots = slots; a.tile_span_max = TILE_SPAN_MAX;
+    a.tile_bytes = reinterpret_cast<uint64_t*>(d + o_tbytes); a.tile_res_base = reinterpret_cast<uint64_t*>(d + o_tbase);
+    a.tile_count = reinterpret_cast<uint32_t*>(d + o_tcount); a.tile_desc_base = reinterpret_cast<uint64_t*>(d + o_tdbase);
+    a.totals = reinterpret_cast<uint64_t*>(d + o_totals);
+    a.status = reinterpret_cast<unsigned long long*>(b->d_status.ptr());
+    a.desc_pad = reinterpret_cast<uint64_t*>(b->d_desc.ptr());
+    a.hap_out_begin = reinterpret_cast<uint64_t*>(b->d_hap.ptr());
+    a.out_bytes = out_bytes;
+    uint64_t* const scan_scratch = reinterpret_cast<uint64_t*>(d + o_scan);
+    const bool cached = c->launch_opts.variant != 21u && st->tile_K == K && st->n_tiles == n_tiles && st->tile_res_base != nullptr && st->d_hap_out_begin != nullptr;
+    HIP_TRY(c, hipEventRecord(b->ev_os[0], A), "hipEventRecord");
+    if (cached) {
+        a.tile_res_base = const_cast<uint64_t*>(st->tile_res_base);
+        HIP_TRY(c, hipMemcpyAsync(b->d_hap.ptr(), st->d_hap_out_begin, (n_h + 1) * 8, hipMemcpyDeviceToDevice, A), "D2D(hap_begin)");
+    } else {
+        HIP_TRY(c, launch_rows_tile_bytes(a, scan_scratch, A), "launch(tile bytes)");
+        HIP_TRY(c, launch_rows_hap_begin(a, A), "launch(hap_begin)");
+    }
+    HIP_TRY(c, hipEventRecord(b->ev_os[2], A), "hipEventRecord");
+    HIP_TRY(c, launch_rows_parse(a, ROWS_TILES, v.fasta, 0, A), "launch(parse: pieces)");
+    HIP_TRY(c, launch_scan_u32(a.tile_count, n_tiles, a.tile_desc_base, scan_scratch + rows_scan_scratch_entries(n_tiles), A), "launch(scan)");
+    HIP_TRY(c, launch_rows_summary(a.tile_desc_base + n_tiles, a.tile_res_base + n_tiles, a.status, a.totals, A), "launch(summary)");
+    uint64_t* const hs = reinterpret_cast<uint64_t*>(b->h_sum.p);
+    HIP_TRY(c, hipMemcpyAsync(hs, d + o_totals, 64, hipMemcpyDeviceToHost, A), "D2H(totals)");
+    HIP_TRY(c, hipEventRecord(b->ev_os[3], A), "hipEventRecord");
+    HIP_TRY(c, hipStreamSynchronize(A), "hipStreamSynchronize");
+    const unsigned long long stw = hs[6];
+    if (stw != STATUS_CLEAN) {
+        (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, A);
+        const uint32_t reason = uint32_t(stw & 0xFFu);
+        if (reason == STATUS_ROWS_STAGE || reason == STATUS_ROWS_TOO_MANY) { *fallback = true; return V2P_OK; }
+        if (reason == STATUS_ROWS_SPAN) return c->fail(V2P_ERR_UNSUPPORTED, "64 consecutive transcripts with more than 2 GiB of result", int64_t(stw >> 8));
+        const int code = reason_to_err(reason);                  // what the reference would panic on (update_task, Task::execute)
+        return c->fail(code, std::string("device: ") + err_name(code) + " at descriptor " + std::to_string(stw >> 8), int64_t(stw >> 8));
+    }
+    if (hs[5] != out_bytes) return c->fail(V2P_ERR_STATE, "the resident stream's tables changed since its upload");
+    b->is_tiles = true; b->tile_slots = slots; b->tiles_n = n_tiles; b->tiles_count = a.tile_count; b->tiles_res_base = a.tile_res_base;
+    b->n_desc = hs[4]; b->n_chunks = n_tiles; b->n_payload = v.n_alt; b->payload_dev = v.alt; b->out_bytes = out_bytes; b->n_haps = n_h;
+    b->pieces_src0_len = c->proteome_len + c->headers_len; b->pieces_src1_len = v.n_alt;
+    b->launch_hint = 0; b->pad_image = false; b->desc_slots = 0;
+    b->img.hap_out_begin = st->hap_out_begin;
+    b->uses_proteome = true; b->finalized = true;
+    b->n_slices = 1; b->slice_chunk0[0] = 0; b->slice_chunk0[1] = n_tiles; b->os_ahead = false;
+    if (execute) HIP_TRY(c, tiles_execute(b, A), "launch(stitch: tile image)");
+    HIP_TRY(c, hipEventRecord(b->ev_os[1], A), "hipEventRecord");
+    if (build_ms) { *build_ms = 0.f; (void)hipEventElapsedTime(build_ms, b->ev_os[0], b->ev_os[3]); }
+    return V2P_OK;
+}
+
 // (c->mu held by the caller: v2p_batch_build_and_execute, and the streamed pipeline's runner)
 static int build_and_execute_locked(v2p_batch* b, const v2p_stream* st, int kernel, uint32_t n_slices)
 {
     v2p_ctx* c = b->ctx;
     if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized (v2p_batch_reset recycles it)");
     if (b->hap_open || b->img.n_haplotypes()) return c->fail(V2P_ERR_STATE, "the batch already holds host-built haplotypes");
-    if (kernel != 0 && kernel != 6 && kernel != 7 && kernel != 8) return c->fail(V2P_ERR_INVALID_ARG, "a resident stream builds rows images (kernel 6, 7), a patch image (8) or what the routing rule picks (0)");
+    if (kernel != 0 && kernel != 6 && kernel != 7 && kernel != 8 && kernel != 9) return c->fail(V2P_ERR_INVALID_ARG, "a resident stream builds rows images (kernel 6, 7), a patch image (8), a tile image (9) or what the routing rule picks (0)");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     const auto t0 = std::chrono::steady_clock::now();
     if (kernel == 8) {
@@ -2432,6 +2589,19 @@ static int build_and_execute_locked(v2p_batch* b, const v2p_stream* st, int kern
     }
     int mode = rows_mode_for(st, kernel);
     bool fallback = false;
+    if (mode == ROWS_TILES) {
+        // deep Task vectors: pieces straight from the parse, the tiles executed as they stand (dense_pieces.h)
+        const int trc = build_tiles(b, st, true, &fallback, nullptr);
+        if (trc != V2P_OK) return trc;
+        if (!fallback) {
+            stream_attach(b, st);
+            b->executed = true; b->os_kernel = 9; b->os_build_ms = 0.f;
+            b->os_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            return V2P_OK;
+        }
+        if (kernel == 9) return c->fail(V2P_ERR_UNSUPPORTED, "the stream does not fit a tile image (a tile of transcripts with more than 16 368 result bytes or 2 048 pieces, sources beyond 2 GiB): kernel 0 or 7 builds a dense rows image");
+        mode = ROWS_DENSE; fallback = false;
+    }
     int rc = build_and_execute_rows(b, st, mode, n_slices, &fallback);
     if (rc == V2P_OK && fallback) {
         // streams the sliced builder does not take: the one-piece builder (its two-pass form, or a dense image), then one execute
@@ -2539,6 +2709,7 @@ int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, ui
     std::lock_guard<std::mutex> lk(c->mu);
     if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
     if (b->is_patch && desc) return c->fail(V2P_ERR_STATE, "a patch image has segments and patches, not descriptors: v2p_batch_download_patch_image");
+    if (b->is_tiles && (desc || chunks)) return c->fail(V2P_ERR_STATE, "a tile image has pieces in its tiles' slots, not descriptors and chunks (v2p_batch_build_from_stream with kernel 7 builds the dense rows image of the same stream)");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     if (b->pad_image) { const int rc = densify(b); if (rc) return rc; }       // (a padded image leaves the device in the dense form)
     if (b->pad_image) return c->fail(V2P_ERR_HIP, "no device memory for the dense copy of a padded image");
@@ -2618,7 +2789,7 @@ int v2p_batch_finalize(v2p_batch* b)
 static bool pieces_eligible(const v2p_batch* b)
 {
     const int h = b->launch_hint;
-    return b->finalized && !b->is_patch && (h & 2) && (h & 8) && !(h & 4) && (h & 16) && (h & 32) && b->n_chunks != 0 && b->ctx->launch_opts.variant != 28u &&
+    return b->finalized && !b->is_patch && !b->is_tiles && (h & 2) && (h & 8) && !(h & 4) && (h & 16) && (h & 32) && b->n_chunks != 0 && b->ctx->launch_opts.variant != 28u &&
            b->ctx->launch_opts.variant != 3u && b->ctx->launch_opts.variant != 8u;
 }
 static int to_pieces(v2p_batch* b)
@@ -2667,6 +2838,13 @@ int v2p_batch_execute(v2p_batch* b)
     if (b->is_patch) {
         const hipError_t pe = patch_execute(b, c->stream);
         if (pe != hipSuccess) return c->hip_fail(pe, "launch(stitch: patch image)");
+        return V2P_OK;
+    }
+    if (b->is_tiles) {
+        // (the executor checks no source bound: the parse did, against the reference of that moment)
+        if (c->proteome_len + c->headers_len < b->pieces_src0_len) return c->fail(V2P_ERR_SRC_OOB, "the resident reference is shorter than the one this tile image was built against: rebuild the batch");
+        HIP_TRY(c, tiles_execute(b, c->stream), "launch(stitch: tile image)");
+        b->executed = true;
         return V2P_OK;
     }
     // (variants 23 / 26, A/B: a padded image stays padded -- read in place / staged)
@@ -2727,7 +2905,7 @@ int v2p_batch_image_form(const v2p_batch* b)
 {
     if (!b) return V2P_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(b->ctx->mu);
-    return (b->pad_image ? 1 : 0) | (b->pieces_state == 1 ? 2 : 0) | (b->d_stage.ptr() ? 4 : 0);
+    return (b->pad_image ? 1 : 0) | (b->pieces_state == 1 ? 2 : 0) | (b->d_stage.ptr() ? 4 : 0) | (b->is_tiles ? 8 : 0);
 }
 
 int v2p_batch_hap_range(const v2p_batch* b, uint64_t h, uint64_t* begin, uint64_t* len)
@@ -2813,7 +2991,7 @@ struct PipeSlot {
     v2p_batch* batch = nullptr;            // ... and its image / arena
     StreamLayout lay{};
     v2p_txstream shape{};                  // the slice's counts (pointers cleared) for stream_view
-    double items[4] = {1.0, 0.0, 1.0, 0.0};
+    DevStreamView stats;                   // the slice's Task shapes, sampled by the submitter (stream_item_stats)
     bool fasta = false;
     int kernel = 0;
     unsigned sflags = 0;
@@ -3050,7 +3228,7 @@ int v2p_pipeline_submit_stream(v2p_pipeline* p, const v2p_txstream* slice, int k
         if (slice->n_alt) pc[np++] = StreamPiece{o_alt, slice->alt, slice->n_alt, "H2D(alt)"};
         team_copy(s.h_in.p, pc, np, p->copy_threads, [&] {
             crc = check_stream_nolock(c, slice, &fasta, nullptr, &hob, cerr);
-            if (crc == V2P_OK) stream_item_stats(slice, &s.items[0], &s.items[1], &s.items[2], &s.items[3]);
+            if (crc == V2P_OK) stream_item_stats(slice, s.stats);
         });
     }
     if (crc != V2P_OK) { std::lock_guard<std::mutex> lk(c->mu); return unclaim(c->fail(crc == V2P_OK ? V2P_ERR_INVALID_ARG : crc, cerr.msg, cerr.index)); }
@@ -3115,7 +3293,7 @@ static void pipeline_runner(v2p_pipeline* p)
             if (rc == V2P_OK) {
                 // the slice as a resident stream (v2p_stream_upload's second half): the view, res_counter per tile and per haplotype
                 stream_view(&s.shape, s.lay, s.fasta, st->buf.ptr(), st->alt.ptr(), st->v);
-                st->v.items_mean = s.items[0]; st->v.items_var = s.items[1]; st->v.desc_mean = s.items[2]; st->v.desc_var = s.items[3];
+                copy_stats(s.stats, st->v);
                 st->hap_out_begin = s.hap_out_begin;
                 st->out_bytes = s.out_bytes;
                 st->tile_K = 0; st->n_tiles = 0; st->tile_res_base = nullptr; st->d_hap_out_begin = nullptr; st->h_tile_res_base.clear();

@@ -349,7 +349,7 @@ class Batch:
         f = self._lib.v2p_batch_image_form(self._h)
         if f < 0:
             self.ctx._check(f)
-        return {"padded": bool(f & 1), "pieces": bool(f & 2), "staging_buffers": bool(f & 4)}
+        return {"padded": bool(f & 1), "pieces": bool(f & 2), "staging_buffers": bool(f & 4), "tiles": bool(f & 8)}
 
     def oneshot_info(self) -> dict:
         info = N.OneShotInfo()
