@@ -813,17 +813,23 @@ def main():
             line["data"] = "synthetic (dry run: no kernel was launched, value is meaningless)"
         if world == 1 and not args.dry_run:
             if not args.no_c2 and args.workload == "C3" and not args.samples:
-                try:                                           # BASELINE.json configs[1]: the SNV-only cohort of 1 000 samples, the same way
-                    c2 = cohort_leg("C2", DEFAULT_SAMPLES["strong"]["C2"], 0, 2 * DEFAULT_SAMPLES["strong"]["C2"], min(args.steps, 50), 5, n_threads, args.verify,
-                                    temporal=args.temporal, host_packed=not args.no_host_packed, settle_ms=args.clock_settle_ms)
-                    ms2 = sum(c2["kernel_ms"]) / len(c2["kernel_ms"])
-                    c2.update({"ms": ms2, "ms_min": min(c2["kernel_ms"]), "aa_per_s": c2["aa"] / (ms2 * 1e-3), "achieved_GBps": c2["hbm_bytes_min_per_launch"] / (ms2 * 1e-3) / 1e9,
-                               "frac": c2["hbm_bytes_min_per_launch"] / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "steps": len(c2["kernel_ms"])})
-                    del c2["kernel_ms"]
-                    c2.pop("_oracle_checked_digests", None)
-                    line["c2_cohort"] = c2
-                except Exception as e:                         # never lose the bench line to a secondary leg
-                    line["c2_cohort"] = {"error": repr(e)}
+                # BASELINE.json's other single-GPU configurations, whole, the same way (one call on the resident stream, EVERY haplotype's digest
+                # against the oracle, then steady-state executes): configs[1] C2 -- the SNV-only cohort of 1 000 samples --, configs[3] C4 -- 2 504
+                # samples x the whole proteome, as ONE image on this GPU --, configs[4] C5 -- 100 000 haplotypes of deep Task vectors
+                for wl, key in (("C2", "c2_cohort"), ("C4", "c4_cohort"), ("C5", "c5_cohort")):
+                    try:
+                        torch.cuda.empty_cache()
+                        t_leg = time.perf_counter()
+                        cl = cohort_leg(wl, DEFAULT_SAMPLES["strong"][wl], 0, 2 * DEFAULT_SAMPLES["strong"][wl], min(args.steps, 50 if wl == "C2" else 20), 5, n_threads, args.verify,
+                                        temporal=args.temporal, host_packed=(not args.no_host_packed) and wl == "C2", settle_ms=args.clock_settle_ms)
+                        msl = sum(cl["kernel_ms"]) / len(cl["kernel_ms"])
+                        cl.update({"ms": msl, "ms_min": min(cl["kernel_ms"]), "aa_per_s": cl["aa"] / (msl * 1e-3), "achieved_GBps": cl["hbm_bytes_min_per_launch"] / (msl * 1e-3) / 1e9,
+                                   "frac": cl["hbm_bytes_min_per_launch"] / (msl * 1e-3) / 1e9 / HBM_PEAK_GBS, "steps": len(cl["kernel_ms"]), "leg_seconds": time.perf_counter() - t_leg})
+                        del cl["kernel_ms"]
+                        cl.pop("_oracle_checked_digests", None)
+                        line[key] = cl
+                    except Exception as e:                     # never lose the bench line to a secondary leg
+                        line[key] = {"error": repr(e)}
             if not args.no_pcie:
                 ref_dig = leg.get("_oracle_checked_digests")
                 if ref_dig is not None and whole:

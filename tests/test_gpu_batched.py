@@ -116,3 +116,56 @@ def test_c3_whole_cohort_on_one_gpu_every_haplotype_by_digest(built, gpu_ctx, co
     assert not bad, ("device-built image", bad[:10])
     bad = [h for h in range(n) if int(dig[h]) != want[h]]
     assert not bad, ("host-packed image", bad[:10])
+
+
+def test_c2_whole_cohort_through_the_one_call_and_the_stream_pipeline(built, gpu_ctx, coracle):
+    """BASELINE configs[1]: 1 000 samples x 20 000 transcripts, SNV-only Tasks -- 2 000 haplotypes, 16 GB of result -- WHOLE, through the
+    product's one call (v2p_stream_upload + v2p_batch_build_and_execute) and, slice by slice with the results returning to the host,
+    through the stream-fed pipeline (v2p_pipeline_submit_stream): the digest of EVERY haplotype is the oracle's, and what comes back over
+    the link digests the same on the host."""
+    from concurrent.futures import ThreadPoolExecutor
+    from vcf2prot_amd.cohort import Cohort
+    from vcf2prot_amd.driver import run_streamed
+    c = Cohort.preset("C2")
+    n = c.n_haplotypes
+    assert n == 2000
+    threads = min(64, os.cpu_count() or 1)
+    gpu_ctx.upload_proteome(c.proteome())
+    sizes = c.result_sizes(0, n, n_threads=threads)
+    assert int(sizes.sum()) > 15 * 10 ** 9
+    stream = c.txstream(0, n, n_threads=threads)
+    rs = gpu_ctx.upload_stream(stream)
+    stream.close()
+    b = gpu_ctx.batch()
+    b.build_and_execute(rs, 0, 0)
+    b.sync()
+    assert b.oneshot_info()["kernel"] == 6
+    dig = b.digests()
+    b.scribble(); b.execute(); b.sync()
+    assert np.array_equal(b.digests(), dig), "the re-executed image left another arena"
+    b.close(); rs.close()
+    workers = threads
+
+    def oracle_digests(w):
+        cc = Cohort.preset("C2")
+        out = {}
+        for h in range(w, n, workers):
+            hap = cc.haplotype(h)
+            t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+            want = coracle.gir_execute_u8(t, cc.ref_tape_u32(h).astype(np.uint8), hap.alt, np.full(hap.n_res, ord("."), dtype=np.uint8))
+            out[h] = coracle.digest_u8(want)
+        return out
+    want = {}
+    with ThreadPoolExecutor(workers) as pool:
+        for part in pool.map(oracle_digests, range(workers)):
+            want.update(part)
+    bad = [h for h in range(n) if int(dig[h]) != want[h]]
+    assert not bad, ("the one call", bad[:10])
+    seen = 0
+    for r in run_streamed(gpu_ctx, lambda a, e: c.txstream(a, e, n_threads=threads), sizes, 1 << 30, slots=4, digests=True, copy_threads=8):
+        for h in range(r.h_begin, r.h_end):
+            assert int(r.digests[h - r.h_begin]) == want[h], ("stream pipeline", h)
+        for h in (r.h_begin, r.h_end - 1):                  # the bytes in host memory
+            assert coracle.digest_u8(np.ascontiguousarray(r.haplotype(h))) == want[h], ("stream pipeline, host bytes", h)
+        seen += r.h_end - r.h_begin
+    assert seen == n
