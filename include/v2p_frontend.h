@@ -24,6 +24,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)      /* the libraries are built with -fvisibility=hidden: what these headers declare is what they export */
+#endif
 
 struct v2p_ctx;                                   /* include/vcf2prot_hip.h */
 
@@ -143,6 +146,9 @@ const uint32_t* v2p_groups_group_transcript(const v2p_groups* g);
 const uint64_t* v2p_groups_group_member_begin(const v2p_groups* g);
 const uint32_t* v2p_groups_member_ids(const v2p_groups* g);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

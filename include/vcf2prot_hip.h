@@ -38,6 +38,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)      /* the libraries are built with -fvisibility=hidden: what these headers declare is what they export */
+#endif
 
 #define V2P_OK                   0
 #define V2P_BUSY                 1   /* v2p_gir_submit: every batch of the queue is in flight -- collect a ticket, then submit again; v2p_pipeline_submit_stream: every slot is in use */
@@ -210,9 +213,7 @@ int v2p_batch_end_haplotype(v2p_batch* b);
  * task offsets relative to the transcript and to its own alt tape), concatenated over the transcripts of every haplotype of the
  * batch, in result order.  The device does the reference's step 5 (haplotype_instruction.rs:94-133: the three running sums become
  * prefix scans; reference tasks are rebased onto the resident proteome) and the image packing (result-order descriptors, '.'
- * fill for cells no task covers, immediate descriptors, chunk table, XCD-aware order, hap_out_begin).  Chunks are cut on a fixed
- * grid of `window_bytes` of result (a multiple of 4096 -- wave images: of 1024 --, <= 65536 - 4096); a window holding more than 1024 descriptors is refused
- * (V2P_ERR_UNSUPPORTED: pick a smaller window). */
+ * fill for cells no task covers, immediate descriptors, chunk table, XCD-aware order, hap_out_begin). */
 typedef struct {
     uint64_t n_haps, n_tx, n_tasks, n_alt;
     const uint64_t* hap_tx_begin;      /* [n_haps + 1] transcripts of each haplotype                                   */
@@ -240,19 +241,12 @@ typedef struct {
  * follow each other become one descriptor).  window_bytes is ignored.  A descriptor lying across a cut is shared by the two chunks:
  * the chunk record's task_begin holds first descriptor : 42 | bytes of it that belong to the chunk before : 11 | bytes of the chunk's
  * last descriptor that belong to the next : 11, and bit 59 of dst_n marks such chunks (they start on multiples of 1024).  A row with
- * more than 64 descriptors makes kernel 6 V2P_ERR_UNSUPPORTED (build a dense image).  The north star's cohort (10 000 samples, 9.6 GB
- * of stream): 6.8 ms of kernels against 12.3 ms for kernel 5, and the image executes like the host packer's.
- * kernel 1 .. 5 -- the grid builders of rounds 2 and 3, kept for the kernels only they feed:
- * 1 = route every chunk to the long-run kernel (<= 512 descriptors per window), 2 = per-block kernel, 3 = dense image
- * (stitch_dense_kernel: short tasks, fused substitutions, <= 1024 descriptors per window: windows of 4, 8 or 12 KiB, larger ones are
- * V2P_ERR_INVALID_ARG), 4 = wave image (stitchw_kernel, one wave per window: windows of 1 .. 10 KiB in steps of 1 KiB with <= 64
- * descriptors each, fused substitutions; the choice for long reference runs), 5 = wave image whose windows may SPLIT ONCE (2 .. 10 KiB:
- * a window of 65 .. 127 descriptors becomes two chunks, cut on the 1 KiB row nearest its middle that leaves both with <= 64, the
- * descriptor under the cut split in two -- every window carries one spare descriptor slot for that; the grid can then be as coarse
- * as the AVERAGE window allows: C3 at 8 KiB executes within 2 % of the host packer's greedy cuts, at the 4 KiB kernel 4 needs 30 % slower).
+ * more than 64 descriptors makes kernel 6 V2P_ERR_UNSUPPORTED (build a dense image), one with more than 1 024 makes kernel 7 V2P_ERR_UNSUPPORTED
+ * (the host builder -- v2p_batch_add_transcript -- takes any stream).  The north star's cohort (10 000 samples, 9.6 GB of stream): 6.8 ms of kernels.
+ * (The grid builders of rounds 2-3 -- kernel 1 .. 5, fixed windows of `window_bytes` -- and PATCH images -- kernel 8 -- were never picked by a
+ * routing rule; since round 6 they live in the development library only: vcf2prot_amd/csrc/bench/v2p_bench.h.  Here: V2P_ERR_INVALID_ARG.)
  * The offset tables of the stream are checked on the host before anything is uploaded (ascending from 0, inside their arrays):
- * V2P_ERR_INVALID_ARG with the offending index.  A window that holds more descriptors than its kernel takes is
- * V2P_ERR_UNSUPPORTED and leaves the batch empty: call again with a smaller window.
+ * V2P_ERR_INVALID_ARG with the offending index.  V2P_ERR_UNSUPPORTED leaves the batch empty.
  * On success the batch is finalized (execute / sync / download / digests work as after v2p_batch_finalize).
  * *build_ms (optional): time of the build kernels alone (two HIP event brackets: counting passes, emitting passes; not the
  * allocation of the image in between), the stream already on the device. */
@@ -280,21 +274,25 @@ int  v2p_stream_upload(v2p_ctx* ctx, const v2p_txstream* s, v2p_stream** out);
  * consumes its tapes, gir.rs:197,230-234.) */
 void v2p_stream_destroy(v2p_stream* s);
 int  v2p_stream_counts(const v2p_stream* s, uint64_t* n_haps, uint64_t* n_tx, uint64_t* n_tasks, uint64_t* out_bytes);
-/* the one-piece builder (kernel 6 / 7 / 8; 0: by the routing rule, a dense image when a wave image is refused) on a resident stream: no H2D */
+/* the one-piece builder on a resident stream, no H2D: kernel 6 / 7 (rows images), 9 (a TILE image, see v2p_batch_build_and_execute), 0: by the
+ * routing rule -- a wave image from 24 result bytes per Task, below a tile image where the form takes the stream, else a dense rows image */
 int  v2p_batch_build_from_stream(v2p_batch* b, const v2p_stream* s, int kernel, float* build_ms);
-/* Build AND execute.  kernel: 0 (routing rule), 6, 7 or 8 (a patch image: one build kernel, one stitch kernel).  n_slices: 0 = ONE slice -- the build, then the stitch (more slices were measured slower on every cohort: the
- * build of slice j + 1 next to the stitch of slice j takes three times as long, profiles/r05_oneshot_slices.json) --, else that many
- * (<= 32).  Returns when the last slice's stitch kernels are enqueued on the context's stream (like v2p_batch_execute: asynchronous);
- * v2p_batch_sync collects the status.  The batch is finalized: execute / digests / download work as after any build, and the image --
- * descriptors, chunk records, haplotype offsets -- is the one v2p_batch_build_from_stream builds (only the blocks inside which the
- * chunk table is dealt to the XCDs are per slice).  Streams the sliced builder does not take (a tile of transcripts with more than 256
- * descriptors, a 1 KiB row with more descriptors than a chunk holds, more than 2^25 tiles) are built in one piece and executed, in
- * the same call.  What the reference would panic on (update_task, Task::execute) is reported as by v2p_batch_build_on_device; slices
- * before the offending one may already have been written to the arena. */
+/* Build AND execute.  kernel: 0 (the routing rule), 6, 7, or 9 -- a TILE image (round 6; vcf2prot_amd/csrc/dense_pieces.h), what the rule picks for
+ * DEEP Task vectors (fewer than 24 result bytes per Task: runs of substitutions, transcript_instructions.rs:508-629,654-663): the one-pass
+ * parse writes PIECES -- at most 16 result bytes of one source, their offset inside the tile's result, at most one substituted residue --
+ * straight into the slots of its tile of transcripts, and the tile is the executor's work item: no dense image first, no compaction, no row
+ * map, no cutter, no chunk table, and nothing to re-write when the image is executed again.  A stream the form does not take (a tile of
+ * transcripts with more than 16 368 result bytes or 2 048 pieces, sources beyond 2 GiB) builds a dense rows image under the rule and is
+ * V2P_ERR_UNSUPPORTED by number.  n_slices: 0 or 1 (the image built slice by slice beside the stitch of the slice before was measured slower
+ * on every cohort -- profiles/r05_oneshot_slices.json -- and lives in the development library).  Returns when the stitch kernels are enqueued on
+ * the context's stream (like v2p_batch_execute: asynchronous); v2p_batch_sync collects the status.  The batch is finalized: execute /
+ * digests / download work as after any build.  Streams the one-pass builder does not take (a tile of transcripts with more than 256
+ * descriptors, a 1 KiB row with more descriptors than a chunk holds, more than 2^25 tiles) are built in its two-pass form and executed, in
+ * the same call.  What the reference would panic on (update_task, Task::execute) is reported as by v2p_batch_build_on_device. */
 int  v2p_batch_build_and_execute(v2p_batch* b, const v2p_stream* s, int kernel, uint32_t n_slices);
 typedef struct {
-    int32_t  kernel;             /* 6 / 7: the rows image that was built                                                            */
-    uint32_t n_slices;           /* 0: the call fell back to the one-piece builder + one execute                                    */
+    int32_t  kernel;             /* 6 / 7: the rows image that was built; 9: a tile image                                           */
+    uint32_t n_slices;           /* 1; 0: the call fell back to the one-piece builder + one execute                                 */
     float    total_ms;           /* HIP events on the context's stream: before the first build kernel -> behind the last stitch kernel */
     float    build_ms;           /* sum of the slices' build kernels (they overlap the stitch of the slices before: not additive)   */
     double   call_wall_ms;       /* host wall-clock of the call (it returns when the last slice is enqueued)                        */
@@ -306,20 +304,6 @@ typedef struct {
 int  v2p_batch_oneshot_info(v2p_batch* b, v2p_oneshot_info* info);
 /* a finalized batch back to empty, its device buffers kept: the next build recycles arena, descriptor array and scratch */
 int  v2p_batch_reset(v2p_batch* b);
-/* ---- PATCH images (round 5; kernel 8 of v2p_batch_build_on_device / _build_from_stream / _build_and_execute) --------------------------------
- * The image of a batch of DEEP Task vectors (a few result bytes per Task: 64 alterations in an 800-residue transcript) whose commonest
- * Task triple -- reference copy, ONE substituted residue, the reference going on one residue later (a missense,
- * transcript_instructions.rs:654-663) -- does not end a copy: SEGMENTS (8 bytes: source:34 | start inside the chunk:14 | length:14 |
- * space:2 -- a run of one source, under any number of substituted residues) and PATCHES (4 bytes: position inside the chunk:14 | byte
- * << 16) on a fixed grid of 8 KiB chunks of the arena; chunk k's segments sit in slots [1024 k, 1024 (k + 1)) of the segment array, its
- * patches in slots [1024 k, ..) of the patch array, in no particular order; the chunk record holds first segment slot | patches << 42
- * and arena offset | segments << 48 | bits 60 and 61.  Built by ONE kernel (one workgroup per chunk; no count pass, no scan of
- * descriptor counts, no compaction, no cutter), executed by stitch_patch_kernel (vcf2prot_amd/csrc/patch_image.hip).  Semantics and
- * panics are the reference's (task.rs:38-50, haplotype_instruction.rs:78,140-158).  V2P_ERR_UNSUPPORTED: a window of the result holds more
- * segments or patches than its slots (or the sources exceed 16 GB) -- the batch is left empty: build a dense rows image (kernel 7).
- * v2p_batch_counts reports the segments as descriptors.  For checkers: the raw arrays (1024 / 1024 slots per chunk, the chunk table in
- * launch order; any pointer may be NULL) and the totals. */
-int v2p_batch_download_patch_image(v2p_batch* b, uint64_t* seg, uint32_t* patch, v2p_chunk* chunks, uint64_t* n_segments, uint64_t* n_patches);
 /* the image as it sits on the device (for checkers): sizes first (any pointer may be NULL), then the arrays.  (A padded image -- see
  * v2p_batch_build_and_execute -- is made dense first, for good.) */
 int v2p_batch_download_image(v2p_batch* b, uint64_t* desc, v2p_chunk* chunks, uint64_t* hap_out_begin);
@@ -356,7 +340,8 @@ int v2p_batch_counts(const v2p_batch* b, uint64_t* n_haps, uint64_t* n_desc, uin
                      uint64_t* out_bytes, uint64_t* payload_bytes);
 /* in what form the batch's image sits on the device right now (diagnostics, tests): bit 0 = padded wave image (v2p_batch_build_and_execute;
  * made dense by the next v2p_batch_execute / download), bit 1 = a piece image was built (a dense rows image that is executed again:
- * vcf2prot_amd/csrc/dense_pieces.h), bit 2 = staging buffers for the phases' descriptors exist */
+ * vcf2prot_amd/csrc/dense_pieces.h), bit 2 = staging buffers for the phases' descriptors exist, bit 3 = a TILE image (pieces in the tiles' slots:
+ * v2p_batch_download_image has no descriptors or chunks to hand out, v2p_batch_counts reports pieces and tiles in their place) */
 int v2p_batch_image_form(const v2p_batch* b);
 /* result range of haplotype h inside the arena */
 int v2p_batch_hap_range(const v2p_batch* b, uint64_t h, uint64_t* begin, uint64_t* len);
@@ -426,18 +411,8 @@ typedef struct {
     int32_t  store_sc1;          /* wave images: 1 / 0 force / forbid "sc1 nt" row stores, -1 = by the image's descriptor share      */
     uint32_t max_blocks;         /* != 0: cap the grid of the per-block kernel (persistent workgroups); refused for images with
                                   * long-run, dense or wave chunks                                                                  */
-    uint32_t variant;            /* 0; 3 = per-block kernel also where the dense one would be picked, 8 = the dense kernel for every
-                                  * per-block chunk (routing-only A/B switches; kernel variants live in libv2p_bench.so).
-                                  * v2p_set_launch_opts only: 16 = ONE launch for all phases of a wave image (read-ahead workgroups of
-                                  * phase g + 1 in the grid before the stitch workgroups of phase g), 17 = the read-ahead as kernels of
-                                  * its own, 18 = no read-ahead -- A/B switches of the phased launcher; 20 / 21 = A/B switches of
-                                  * v2p_batch_build_and_execute's builder (20: tiles dealt to the XCDs by workgroup index; 21: tile tables made
-                                  * inside the call; 22 / 24: a wave image is compacted / stays padded whatever the rule says;
-                                  * 23 / 25: no staging of a padded image's descriptors / dense rows images staged as well;
-                                  * 23 / 26: a padded image stays padded when it is executed again (read in place / staged);
-                                  * 27: a padded image is built in three slices whose parses are launched ahead of the cutters (measured slower);
-                                  * 28: a dense rows image that is executed again stays on stitch_dense_kernel (never re-written as pieces);
-                                  * 29: v2p_batch_build_and_execute behaves as if the device had no room for its one-pass scratch (tests of the fallback))   */
+    uint32_t reserved;           /* 0 (the A/B switches of rounds 3-5 that lived here -- `variant` -- exist in the development library only:
+                                  * vcf2prot_amd/csrc/bench/v2p_bench.h) */
 } v2p_launch_opts;
 /* src0/src1 must have 32 readable bytes before and after (the kernel loads whole aligned 16-byte
  * blocks around a task's bytes), and so must d_desc (16 before, 32 after: stitchw_kernel reads an immediate descriptor's literal
@@ -480,6 +455,9 @@ int v2p_order_chunks_for_xcds(v2p_chunk* chunks, uint64_t n_chunks, const uint64
                               uint64_t proteome_len);
 int v2p_digest_launch(void* hip_stream, const uint8_t* d_out, const uint64_t* d_hap_begin, uint64_t n_haps,
                       uint64_t out_bytes, uint64_t* d_digests);
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -40,3 +40,16 @@ def gpu_ctx(built):
     ctx = Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def dev_ctx(built):
+    """A context of the DEVELOPMENT library (libv2p_bench.so: the same engine compiled with V2P_BENCH_VARIANTS -- the A/B switches of the
+    builders and launchers, slices, PATCH images, the grid builders of rounds 2-3; csrc/bench/v2p_bench.h).  The tests of those paths use it;
+    every other GPU test runs on the product library (gpu_ctx)."""
+    from vcf2prot_amd import build
+    from vcf2prot_amd.engine import Context
+    build.build_bench()
+    ctx = Context(0, development=True)
+    yield ctx
+    ctx.close()

@@ -18,13 +18,13 @@ def oracle_hap(c, coracle, h):
     ("C3", 100, 40, 16384, 2), ("C3", 100, 40, 16384, 1), ("C4", 7, 3, 32768, 2), ("C5", 50, 300, 4096, 2),
     ("C5", 50, 300, 4096, 3), ("C5", 11, 100, 8192, 3), ("C5", 200, 150, 12288, 3), ("C1", 0, 8, 4096, 3),     # 3: dense image (fused descriptors, stitch_dense_kernel)
     ("C2", 5, 3, 10240, 4), ("C2", 9, 2, 4096, 4), ("C3", 100, 40, 4096, 4), ("C4", 7, 3, 4096, 4)])     # 4: wave image (stitchw_kernel)
-def test_device_built_image_equals_host_grid_image(built, gpu_ctx, coracle, preset, h0, n, window, kernel):
+def test_device_built_image_equals_host_grid_image(built, dev_ctx, coracle, preset, h0, n, window, kernel):
     from vcf2prot_amd.cohort import Cohort
     c = Cohort.preset(preset)
-    gpu_ctx.upload_proteome(c.proteome())
+    dev_ctx.upload_proteome(c.proteome())
     want = c.pack_grid(h0, h0 + n, window, kernel)
     stream = c.txstream(h0, h0 + n, n_threads=3)
-    b = gpu_ctx.batch()
+    b = dev_ctx.batch()
     ms = b.build_on_device(stream, window, kernel)
     assert ms > 0
     desc, chunks, hb = b.download_image()
@@ -32,7 +32,7 @@ def test_device_built_image_equals_host_grid_image(built, gpu_ctx, coracle, pres
     assert desc.size == want.desc.size and np.array_equal(desc, want.desc)
     # the host table is in result order until finalize() deals it to the XCDs; order both the same way
     wc = np.ascontiguousarray(want.chunks)
-    gpu_ctx._lib.v2p_order_chunks_for_xcds(wc.ctypes.data, wc.shape[0], want.desc.ctypes.data, want.desc.size, c.proteome().size)
+    dev_ctx._lib.v2p_order_chunks_for_xcds(wc.ctypes.data, wc.shape[0], want.desc.ctypes.data, want.desc.size, c.proteome().size)
     assert chunks.shape == wc.shape and np.array_equal(chunks, wc)
     b.execute()
     b.sync()
@@ -42,12 +42,12 @@ def test_device_built_image_equals_host_grid_image(built, gpu_ctx, coracle, pres
     stream.close()
 
 
-def test_device_build_reports_what_the_reference_would_panic_on(built, gpu_ctx):
+def test_device_build_reports_what_the_reference_would_panic_on(built, dev_ctx):
     """A task that reads beyond its transcript (task.rs:43/47) is found by the count pass; nothing is emitted."""
     from vcf2prot_amd._native import V2PError
     from vcf2prot_amd.cohort import Cohort
     c = Cohort.preset("C3")
-    gpu_ctx.upload_proteome(c.proteome())
+    dev_ctx.upload_proteome(c.proteome())
     stream = c.txstream(0, 4, n_threads=1)
     s = stream.struct
     victim = 1234 % int(s.n_tasks)
@@ -55,32 +55,32 @@ def test_device_build_reports_what_the_reference_would_panic_on(built, gpu_ctx):
         victim += 1
     old = s.length[victim]
     s.length[victim] = 1 << 30
-    b = gpu_ctx.batch()
+    b = dev_ctx.batch()
     with pytest.raises(V2PError) as e:
         b.build_on_device(stream, 16384, 2)
     assert e.value.index == victim
     s.length[victim] = old
     b.close()
-    b2 = gpu_ctx.batch()                                   # a window too dense for one chunk is refused, not mis-built
+    b2 = dev_ctx.batch()                                   # a window too dense for one chunk is refused, not mis-built
     dense = Cohort.preset("C5")
-    gpu_ctx.upload_proteome(dense.proteome())
+    dev_ctx.upload_proteome(dense.proteome())
     st2 = dense.txstream(0, 20, n_threads=1)
     with pytest.raises(V2PError):
         b2.build_on_device(st2, 32768, 2)
     b2.close()
 
 
-def test_device_build_refuses_broken_offset_tables(built, gpu_ctx):
+def test_device_build_refuses_broken_offset_tables(built, dev_ctx):
     """The kernels index device memory through every entry of hap_tx_begin / tx_task_begin / tx_alt_begin: a table that is not
     ascending from 0 or leaves its array is refused on the host, with the offending index, and the batch stays usable."""
     from vcf2prot_amd._native import V2PError
     from vcf2prot_amd.cohort import Cohort
     c = Cohort.preset("C3")
-    gpu_ctx.upload_proteome(c.proteome())
+    dev_ctx.upload_proteome(c.proteome())
     stream = c.txstream(0, 3, n_threads=1)
     s = stream.struct
     n_tx = int(s.n_tx)
-    b = gpu_ctx.batch()
+    b = dev_ctx.batch()
     for name, idx, value in [("tx_task_begin", 7, int(s.n_tasks) + 5), ("tx_task_begin", 9, 0), ("tx_alt_begin", 11, int(s.n_alt) + 1),
                              ("tx_alt_begin", 12, 0), ("hap_tx_begin", 1, n_tx + 3), ("hap_tx_begin", 2, 0), ("tx_proteome_off", 5, (1 << 64) - 1)]:
         arr = getattr(s, name)
@@ -96,15 +96,15 @@ def test_device_build_refuses_broken_offset_tables(built, gpu_ctx):
     stream.close()
 
 
-def test_device_build_can_be_retried_with_a_smaller_window(built, gpu_ctx):
+def test_device_build_can_be_retried_with_a_smaller_window(built, dev_ctx):
     """A window with too many descriptors is refused (V2P_ERR_UNSUPPORTED); the header says "pick a smaller window", and the same
     batch then takes one."""
     from vcf2prot_amd._native import V2PError
     from vcf2prot_amd.cohort import Cohort
     dense = Cohort.preset("C5")
-    gpu_ctx.upload_proteome(dense.proteome())
+    dev_ctx.upload_proteome(dense.proteome())
     st = dense.txstream(0, 20, n_threads=1)
-    b = gpu_ctx.batch()
+    b = dev_ctx.batch()
     with pytest.raises(V2PError):
         b.build_on_device(st, 32768, 2)
     assert b.counts()["n_haps"] == 0
@@ -119,7 +119,7 @@ def test_device_build_can_be_retried_with_a_smaller_window(built, gpu_ctx):
 @pytest.mark.parametrize("preset,h0,n,window,fasta", [
     ("C3", 100, 40, 8192, False), ("C3", 100, 40, 10240, False), ("C3", 7, 25, 6144, False), ("C3", 100, 12, 4096, True), ("C4", 7, 3, 10240, False),
     ("C4", 7, 3, 6144, True), ("C2", 5, 3, 10240, False), ("C2", 5, 2, 10240, True), ("C1", 0, 8, 2048, False)])
-def test_wave_windows_that_split(built, gpu_ctx, coracle, preset, h0, n, window, fasta):
+def test_wave_windows_that_split(built, dev_ctx, coracle, preset, h0, n, window, fasta):
     """kernel = 5: wave windows of up to ten 1 KiB rows where a window of 65 .. 127 descriptors becomes TWO chunks, cut on a row, the
     descriptor under the cut split in two (copy / fill / immediate / fused substitution on either side of its literal) -- so the grid
     can be as coarse as the AVERAGE window allows, not the worst one.  Every chunk respects what one wave takes, every haplotype is
@@ -127,7 +127,7 @@ def test_wave_windows_that_split(built, gpu_ctx, coracle, preset, h0, n, window,
     import ctypes
     from vcf2prot_amd.cohort import Cohort
     c = Cohort.preset(preset)
-    gpu_ctx.upload_reference(c.proteome(), c.fasta_headers())
+    dev_ctx.upload_reference(c.proteome(), c.fasta_headers())
     stream = c.txstream(h0, h0 + n, n_threads=3)
     keep = []
     if fasta:
@@ -139,7 +139,7 @@ def test_wave_windows_that_split(built, gpu_ctx, coracle, preset, h0, n, window,
         keep = [np.array(off, dtype=np.uint64), np.array(ln, dtype=np.uint32)]
         stream.struct.tx_header_off = keep[0].ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
         stream.struct.tx_header_len = keep[1].ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
-    b = gpu_ctx.batch()
+    b = dev_ctx.batch()
     b.build_on_device(stream, window, 5)
     desc, chunks, hb = b.download_image()
     nd = ((chunks[:, 1] >> np.uint64(48)) & np.uint64(0x7FF)).astype(np.int64)
@@ -156,7 +156,7 @@ def test_wave_windows_that_split(built, gpu_ctx, coracle, preset, h0, n, window,
     b.sync()
     if fasta:
         host = c.pack(h0, h0 + n, n_threads=2, fasta=True)
-        hbatch = gpu_ctx.batch()
+        hbatch = dev_ctx.batch()
         hbatch.set_packed(host.desc, host.chunks, host.payload, host.hap_out_begin)
         hbatch.finalize()
         hbatch.execute()

@@ -40,7 +40,7 @@ def _build(b, stream, window, kernel):
 
 @pytest.mark.parametrize("kernel,window", [(1, 4096), (2, 4096), (3, 4096), (4, 1024), (4, 10240), (2, 32768)])
 @pytest.mark.parametrize("fasta", [False, True])
-def test_reference_task_dumps_through_the_device_builder(gpu_ctx, golden, kernel, window, fasta):
+def test_reference_task_dumps_through_the_device_builder(dev_ctx, golden, kernel, window, fasta):
     """The 36 transcript GIRs harvested from the reference binary (its own Vec<Task> dumps, transcript_instructions.rs:372-382,
     un-rebased), several per haplotype: device-built image, executed, every record the sequence the binary wrote -- incl. the empty
     start-lost record and the '.' cell of test_correct_translation_20; with FASTA emit the arena is the file text."""
@@ -56,10 +56,10 @@ def test_reference_task_dumps_through_the_device_builder(gpu_ctx, golden, kernel
     for c in cases:
         hdr_off.append(o)
         o += len(c["name"]) + 4
-    gpu_ctx.upload_reference(proteome, np.frombuffer(headers.encode(), dtype=np.uint8))
+    dev_ctx.upload_reference(proteome, np.frombuffer(headers.encode(), dtype=np.uint8))
     per_hap = 7
     stream = _stream_of_cases(cases, refs, hdr_off, fasta, per_hap)
-    b = gpu_ctx.batch()
+    b = dev_ctx.batch()
     _build(b, stream, window, kernel)
     b.execute()
     b.sync()
@@ -72,7 +72,7 @@ def test_reference_task_dumps_through_the_device_builder(gpu_ctx, golden, kernel
 
 
 @pytest.mark.parametrize("kernel,window", [(2, 4096), (3, 8192), (4, 1024), (1, 4096)])
-def test_random_reference_task_vectors_through_the_device_builder(gpu_ctx, kernel, window):
+def test_random_reference_task_vectors_through_the_device_builder(dev_ctx, kernel, window):
     """The 545 random single-transcript cases the reference binary answered with a record (tests/golden/kat_random.json: its printed
     Vec<Task> and FASTA record): all of them as one batch through the device builder, FASTA emit on -- every record as the binary
     wrote it."""
@@ -100,8 +100,8 @@ def test_random_reference_task_vectors_through_the_device_builder(gpu_ctx, kerne
             sb.end_haplotype()
     sb.end_haplotype()
     stream = sb.finish()
-    gpu_ctx.upload_reference(proteome, np.frombuffer(headers.encode(), dtype=np.uint8))
-    b = gpu_ctx.batch()
+    dev_ctx.upload_reference(proteome, np.frombuffer(headers.encode(), dtype=np.uint8))
+    b = dev_ctx.batch()
     _build(b, stream, window, kernel)
     b.execute()
     b.sync()
@@ -118,15 +118,15 @@ def test_random_reference_task_vectors_through_the_device_builder(gpu_ctx, kerne
 
 @pytest.mark.parametrize("preset,h0,n,kernel,window", [("C1", 0, 8, 2, 4096), ("C1", 0, 8, 3, 4096), ("C3", 30, 6, 2, 16384), ("C3", 30, 6, 4, 1024),
                                                        ("C2", 2, 2, 4, 4096), ("C5", 5, 12, 3, 4096)])
-def test_device_built_fasta_equals_host_built_fasta(built, gpu_ctx, preset, h0, n, kernel, window):
+def test_device_built_fasta_equals_host_built_fasta(built, dev_ctx, preset, h0, n, kernel, window):
     """File-ready arena (header, residues, line feed per record) from the device builder == the one the host packer
     (ImageBuilder::add_literal between the tasks) produces for the same haplotypes, byte for byte."""
     import ctypes
     from vcf2prot_amd.cohort import Cohort
     c = Cohort.preset(preset)
-    gpu_ctx.upload_reference(c.proteome(), c.fasta_headers())
+    dev_ctx.upload_reference(c.proteome(), c.fasta_headers())
     host = c.pack(h0, h0 + n, n_threads=2, fasta=True)
-    b = gpu_ctx.batch()
+    b = dev_ctx.batch()
     b.set_packed(host.desc, host.chunks, host.payload, host.hap_out_begin)
     b.finalize()
     b.execute()
@@ -144,7 +144,7 @@ def test_device_built_fasta_equals_host_built_fasta(built, gpu_ctx, preset, h0, 
     ho, hl = np.array(hdr_off, dtype=np.uint64), np.array(hdr_len, dtype=np.uint32)
     stream.struct.tx_header_off = ho.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
     stream.struct.tx_header_len = hl.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
-    d = gpu_ctx.batch()
+    d = dev_ctx.batch()
     d.build_on_device(stream, window, kernel)
     d.execute()
     d.sync()

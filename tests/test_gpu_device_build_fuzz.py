@@ -23,11 +23,11 @@ from stream_util import Stream, random_stream  # noqa: E402,F401
     (14, "long", 4096, 4), (15, "long", 8192, 4),        # (wave images: <= 64 descriptors per window)
     (16, "long", 4096, 5), (17, "long", 8192, 5), (18, "long", 10240, 5), (19, "mix", 2048, 5), (20, "mix", 4096, 5),
     (22, "long", 6144, 5), (23, "mix", 3072, 5)])        # (wave windows that may split once: <= 127 descriptors per window)
-def test_random_streams_equal_the_oracle(built, gpu_ctx, coracle, seed, shape, window, kernel):
+def test_random_streams_equal_the_oracle(built, dev_ctx, coracle, seed, shape, window, kernel):
     rng = np.random.default_rng(seed)
     proteome, stream, want = random_stream(rng, n_haps=40, n_ref_tx=25, shape=shape, window=window)
-    gpu_ctx.upload_proteome(proteome)
-    b = gpu_ctx.batch()
+    dev_ctx.upload_proteome(proteome)
+    b = dev_ctx.batch()
     b.build_on_device(stream, window, kernel)
     desc, chunks, hb = b.download_image()
     assert np.array_equal(np.diff(hb.astype(np.int64)), [w.size for w in want])
@@ -51,13 +51,13 @@ def test_random_streams_equal_the_oracle(built, gpu_ctx, coracle, seed, shape, w
         assert np.array_equal(res, want[h][base:base + res.size])
 
 
-def test_random_stream_host_builder_agrees(built, gpu_ctx, coracle):
+def test_random_stream_host_builder_agrees(built, dev_ctx, coracle):
     """The same random transcripts through the host image builder (v2p_batch_add_transcript) give the same tapes."""
     rng = np.random.default_rng(77)
     proteome, stream, want = random_stream(rng, n_haps=30, n_ref_tx=20, shape="mix", window=4096)
-    gpu_ctx.upload_proteome(proteome)
+    dev_ctx.upload_proteome(proteome)
     k = stream.keep
-    b = gpu_ctx.batch()
+    b = dev_ctx.batch()
     for h in range(len(want)):
         b.begin_haplotype()
         for t in range(int(k[0][h]), int(k[0][h + 1])):

@@ -108,7 +108,7 @@ def test_dense_kernel_on_any_per_block_image(built, coracle, preset, h0, n):
     from hip_util import DevBuf
     from vcf2prot_amd import _native as N
     from vcf2prot_amd.cohort import Cohort
-    lib, blib = N.hip_lib(), N.bench_lib()             # (variant 9 is a kernel variant: libv2p_bench.so; 8 only routes: the engine's own launcher)
+    lib, blib = N.hip_lib(), N.bench_lib()             # (both switches live in libv2p_bench.so: 9 is a kernel variant, 8 a routing switch of its launcher)
     c = Cohort.preset(preset)
     prot = c.proteome()
     want = np.concatenate(oracle_haps(c, coracle, h0, n))
@@ -122,8 +122,11 @@ def test_dense_kernel_on_any_per_block_image(built, coracle, preset, h0, n):
             d_out = DevBuf(img.out_bytes + 32, fill=0x2E)
             d_status = DevBuf.of(np.full(1, -1, dtype=np.int64))
             if var == 8:
-                rc = N.stitch_launch(lib, None, d_desc.ptr, img.desc.size, d_chunks.ptr, chunks.shape[0], d_prot.ptr, prot.size, d_pay.ptr, img.payload.size,
-                                     d_out.ptr, img.out_bytes, d_status.ptr, N.LaunchOpts(routing=bits, variant=8))
+                rc = N.stitch_launch(blib, None, d_desc.ptr, img.desc.size, d_chunks.ptr, chunks.shape[0], d_prot.ptr, prot.size, d_pay.ptr, img.payload.size,
+                                     d_out.ptr, img.out_bytes, d_status.ptr, N.LaunchOpts(routing=bits, reserved=8))
+                # (the product's launcher takes no routing switch: reserved must be 0)
+                assert N.stitch_launch(lib, None, d_desc.ptr, img.desc.size, d_chunks.ptr, chunks.shape[0], d_prot.ptr, prot.size, d_pay.ptr, img.payload.size,
+                                       d_out.ptr, img.out_bytes, d_status.ptr, N.LaunchOpts(routing=bits, reserved=8)) == -1
             else:
                 rc = blib.v2p_stitch_launch(None, d_desc.ptr, img.desc.size, d_chunks.ptr, chunks.shape[0], d_prot.ptr, prot.size, d_pay.ptr, img.payload.size,
                                             d_out.ptr, img.out_bytes, d_status.ptr, 1 | bits | (var << 12), 0)

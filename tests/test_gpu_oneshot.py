@@ -11,6 +11,13 @@ from stream_util import random_stream
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["product", "development"])
+def one(request, gpu_ctx, dev_ctx):
+    """(context, development?) -- every test of this module runs on the PRODUCT library (one slice, no switches) and on the development
+    library (libv2p_bench.so: the same engine with slices, the A/B switches and PATCH images compiled in; csrc/bench/v2p_bench.h)."""
+    return (gpu_ctx, False) if request.param == "product" else (dev_ctx, True)
+
+
 def oracle_hap(c, coracle, h):
     hap = c.haplotype(h)
     t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
@@ -36,7 +43,8 @@ def _one_piece(ctx, rs, kernel):
 @pytest.mark.parametrize("preset,h0,n,kernel,slices", [
     ("C1", 0, 8, 0, 0), ("C2", 3, 60, 6, 3), ("C3", 100, 400, 0, 5), ("C3", 0, 900, 6, 2), ("C4", 7, 12, 0, 4),
     ("C5", 50, 1500, 0, 3), ("C5", 11, 900, 7, 7), ("C3", 100, 300, 7, 2), ("C2", 0, 40, 0, 1)])
-def test_sliced_build_and_execute_equals_the_one_piece_builder_and_the_oracle(built, gpu_ctx, coracle, preset, h0, n, kernel, slices):
+def test_sliced_build_and_execute_equals_the_one_piece_builder_and_the_oracle(built, one, coracle, preset, h0, n, kernel, slices):
+    gpu_ctx, dev = one
     from vcf2prot_amd.cohort import Cohort
     c = Cohort.preset(preset)
     gpu_ctx.upload_proteome(c.proteome())
@@ -47,13 +55,13 @@ def test_sliced_build_and_execute_equals_the_one_piece_builder_and_the_oracle(bu
     assert rs.counts()["out_bytes"] == int(sizes.sum()) and rs.counts()["n_haps"] == n
     img1, dig1 = _one_piece(gpu_ctx, rs, kernel)
     b = gpu_ctx.batch()
-    b.build_and_execute(rs, kernel, slices)
+    b.build_and_execute(rs, kernel, slices if dev else min(slices, 1))
     b.sync()
     info = b.oneshot_info()
     assert info["kernel"] in (6, 7, 9) and info["total_ms"] > 0
     tiles = b.image_form()["tiles"]
     assert tiles == (info["kernel"] == 9) == (img1 is None) and (not tiles or (kernel == 0 and preset == "C5"))
-    if slices > 1 and not tiles:
+    if slices > 1 and not tiles and dev:
         assert 1 <= info["n_slices"] <= slices
     _, _, hb = b.download_image() if not tiles else (None, None, np.array([b.hap_range(i)[0] for i in range(n)] + [int(sizes.sum())], dtype=np.uint64))
     assert np.array_equal(np.diff(hb.astype(np.int64)), sizes.astype(np.int64))
@@ -73,7 +81,7 @@ def test_sliced_build_and_execute_equals_the_one_piece_builder_and_the_oracle(bu
     assert np.array_equal(b.digests(), dig1)
     # ... and a reset batch recycles its buffers for the next call, sliced differently
     b.reset()
-    b.build_and_execute(rs, kernel, max(1, slices - 1) if slices else 2)
+    b.build_and_execute(rs, kernel, (max(1, slices - 1) if slices else 2) if dev else 1)
     b.sync()
     assert np.array_equal(b.digests(), dig1)
     if not tiles:
@@ -83,9 +91,10 @@ def test_sliced_build_and_execute_equals_the_one_piece_builder_and_the_oracle(bu
 
 
 @pytest.mark.parametrize("seed,shape,kernel", [(1, "snv", 7), (3, "snv", 0), (5, "mix", 6), (6, "mix", 7), (10, "long", 0), (12, "long", 6)])
-def test_random_streams_in_one_call(built, gpu_ctx, seed, shape, kernel):
+def test_random_streams_in_one_call(built, one, seed, shape, kernel):
     """Irregular streams (empty haplotypes, transcripts without Tasks, gaps, long payloads): whatever path the call takes -- sliced,
     or the one-piece builder's two-pass form / a dense image where the sliced builder declines -- the arena is the expected text."""
+    gpu_ctx, dev = one
     from vcf2prot_amd._native import V2PError
     rng = np.random.default_rng(seed)
     proteome, stream, want = random_stream(rng, n_haps=400, n_ref_tx=25, shape=shape, window=4096)
@@ -93,11 +102,11 @@ def test_random_streams_in_one_call(built, gpu_ctx, seed, shape, kernel):
     rs = gpu_ctx.upload_stream(stream)
     b = gpu_ctx.batch()
     try:
-        b.build_and_execute(rs, kernel, 3)
+        b.build_and_execute(rs, kernel, 3 if dev else 0)
     except V2PError as e:
         assert kernel == 6 and e.code == -9                 # a row with more than 64 descriptors: kernel 6 was asked for by number
         b.reset()
-        b.build_and_execute(rs, 7, 3)
+        b.build_and_execute(rs, 7, 3 if dev else 0)
     b.sync()
     for h, w in enumerate(want):
         got = b.download_hap(h)
@@ -107,9 +116,10 @@ def test_random_streams_in_one_call(built, gpu_ctx, seed, shape, kernel):
 
 
 @pytest.mark.parametrize("seed,shape,kernel", [(2, "snv", 0), (7, "mix", 6), (11, "long", 7), (13, "mix", 0)])
-def test_random_fasta_streams_in_one_call(built, gpu_ctx, seed, shape, kernel):
+def test_random_fasta_streams_in_one_call(built, one, seed, shape, kernel):
     """The same irregular streams with FASTA emit (personalized_genome.rs:90-113): every transcript's `>name_1` header and line feed around
     its residues, a few transcripts without a header; first execute and the image's re-execution form (tools/fuzz_one_call.py runs thousands)."""
+    gpu_ctx, dev = one
     from vcf2prot_amd._native import V2PError
     rng = np.random.default_rng(seed)
     proteome, headers, stream, want = random_stream(rng, n_haps=300, n_ref_tx=20, shape=shape, window=4096, fasta=True)
@@ -135,10 +145,11 @@ def test_random_fasta_streams_in_one_call(built, gpu_ctx, seed, shape, kernel):
     gpu_ctx.upload_proteome(proteome)                       # (leave the shared context without a header table)
 
 
-def test_a_refused_cut_in_recycled_memory_falls_back(built, gpu_ctx):
+def test_a_refused_cut_in_recycled_memory_falls_back(built, one):
     """Found by tools/fuzz_one_call.py (seeds 152 -> 153): the one call launches the chunk-table pass before the host has looked at the
     status word; a cutter that refuses a row (more than 64 descriptors: the call then builds a dense image) used to leave its segment's
     count unwritten -- zero in fresh memory, anything in memory another batch had used: a table pass that followed it wrote out of bounds."""
+    gpu_ctx, dev = one
     for seed in (152, 153):
         rng = np.random.default_rng(seed)
         shape = ("snv", "mix", "long")[seed % 3]
@@ -146,9 +157,14 @@ def test_a_refused_cut_in_recycled_memory_falls_back(built, gpu_ctx):
         proteome, stream, want = random_stream(rng, n_haps=n_haps, n_ref_tx=n_ref, shape=shape, window=window)
         gpu_ctx.upload_proteome(proteome)
         rs = gpu_ctx.upload_stream(stream)
-        for kernel in (0, 8, 0):
+        for kernel in ((0, 8, 0) if dev else (0, 9, 0)):
             b = gpu_ctx.batch()
-            b.build_and_execute(rs, kernel, 0)
+            try:
+                b.build_and_execute(rs, kernel, 0)
+            except Exception as e:                          # (a tile image asked for by number may refuse the stream)
+                assert kernel == 9 and getattr(e, "code", 0) == -9, e
+                b.close()
+                continue
             b.sync()
             for rep in range(2):
                 for h, w in enumerate(want):
@@ -160,10 +176,13 @@ def test_a_refused_cut_in_recycled_memory_falls_back(built, gpu_ctx):
         rs.close()
 
 
-def test_no_room_for_the_one_pass_scratch_falls_back_inside_the_call(built, gpu_ctx, coracle):
+def test_no_room_for_the_one_pass_scratch_falls_back_inside_the_call(built, one, coracle):
     """hipErrorOutOfMemory for the one call's scratch (its padded descriptor array is up to 2 KiB per tile): nothing has been launched yet,
     the scratch is released and the call builds in one piece -- whose builder has a two-pass form without that array -- and executes.
-    v2p_set_launch_opts variant 29 plays the full device."""
+    The development library's variant 29 plays the full device."""
+    gpu_ctx, dev = one
+    if not dev:
+        pytest.skip("the A/B switches exist in the development library only")
     from vcf2prot_amd.cohort import Cohort
     c = Cohort.preset("C3")
     gpu_ctx.upload_proteome(c.proteome())
@@ -189,9 +208,10 @@ def test_no_room_for_the_one_pass_scratch_falls_back_inside_the_call(built, gpu_
     rs.close()
 
 
-def test_a_tile_that_overflows_its_slots_falls_back_inside_the_call(built, gpu_ctx):
+def test_a_tile_that_overflows_its_slots_falls_back_inside_the_call(built, one):
     """One transcript with thousands of Tasks: its tile's descriptors do not fit the one-pass stage, the sliced builder declines and the
     call builds in one piece (two-pass form) and executes -- same bytes, n_slices reported as 0."""
+    gpu_ctx, dev = one
     from stream_util import Stream
     rng = np.random.default_rng(5)
     AA = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
@@ -213,7 +233,7 @@ def test_a_tile_that_overflows_its_slots_falls_back_inside_the_call(built, gpu_c
     rs = gpu_ctx.upload_stream(s)
     for kernel in (6, 7, 0):
         b = gpu_ctx.batch()
-        b.build_and_execute(rs, kernel, 2)
+        b.build_and_execute(rs, kernel, 2 if dev else 0)
         b.sync()
         assert b.oneshot_info()["n_slices"] == 0
         got = b.download_hap(0)
@@ -222,9 +242,10 @@ def test_a_tile_that_overflows_its_slots_falls_back_inside_the_call(built, gpu_c
     rs.close()
 
 
-def test_one_call_reports_what_the_reference_would_panic_on(built, gpu_ctx):
+def test_one_call_reports_what_the_reference_would_panic_on(built, one):
     """update_task (haplotype_instruction.rs:154) / Task::execute's slices (task.rs:43,47) in a LATER slice: the first offending task by
     index, and the batch is reusable after a reset."""
+    gpu_ctx, dev = one
     from stream_util import Stream
     from vcf2prot_amd._native import V2PError
     prot = np.frombuffer(b"MEDLGENTMVLSTLRSLNNFISQRVEGGSGLEELERGGAKLMNPQRSTVWYACDEFGHIK", dtype=np.uint8)
@@ -252,11 +273,11 @@ def test_one_call_reports_what_the_reference_would_panic_on(built, gpu_ctx):
         rs = gpu_ctx.upload_stream(stream(bad_tx, bad))
         b = gpu_ctx.batch()
         with pytest.raises(V2PError) as ei:
-            b.build_and_execute(rs, 6, 4)
+            b.build_and_execute(rs, 6, 4 if dev else 0)
             b.sync()
         assert ei.value.code == want_code and ei.value.index == 3 * bad_tx + row, (bad, ei.value.code, ei.value.index)
         b.reset()
-        b.build_and_execute(good, 6, 4)
+        b.build_and_execute(good, 6, 4 if dev else 0)
         b.sync()
         one = bytes(prot[:10]) + b"A" + bytes(prot[11:])
         assert b.download_hap(1).tobytes() == one * (n_tx // 2)
@@ -267,9 +288,10 @@ def test_one_call_reports_what_the_reference_would_panic_on(built, gpu_ctx):
 
 @pytest.mark.parametrize("kernel", [0, 6, 7])
 @pytest.mark.parametrize("fasta", [False, True])
-def test_reference_task_dumps_in_one_call(gpu_ctx, golden, kernel, fasta):
+def test_reference_task_dumps_in_one_call(one, golden, kernel, fasta):
     """The 36 transcript GIRs harvested from the reference binary (its own Vec<Task> dumps), repeated over 600 haplotypes so that the
     sliced builder has slices to cut; with FASTA emit the arena is the file text of personalized_genome.rs:90-113."""
+    gpu_ctx, dev = one
     from test_gpu_device_build_fasta import _stream_of_cases
     from vcf2prot_amd._native import V2PError
     cases = golden["cases"]
@@ -290,11 +312,11 @@ def test_reference_task_dumps_in_one_call(gpu_ctx, golden, kernel, fasta):
     rs = gpu_ctx.upload_stream(stream)
     b = gpu_ctx.batch()
     try:
-        b.build_and_execute(rs, kernel, 4)
+        b.build_and_execute(rs, kernel, 4 if dev else 0)
     except V2PError as e:
         assert kernel == 6 and e.code == -9
         b.reset()
-        b.build_and_execute(rs, 7, 4)
+        b.build_and_execute(rs, 7, 4 if dev else 0)
     b.sync()
     many = cases * reps
     for h in range(0, (len(many) + per_hap - 1) // per_hap, 17):
@@ -306,10 +328,13 @@ def test_reference_task_dumps_in_one_call(gpu_ctx, golden, kernel, fasta):
     rs.close()
 
 
-@pytest.mark.parametrize("kernel", [0, 6, 7, 8])
-def test_degenerate_streams_in_one_call(built, gpu_ctx, kernel):
+@pytest.mark.parametrize("kernel", [0, 6, 7, 8, 9])
+def test_degenerate_streams_in_one_call(built, one, kernel):
     """No haplotypes; haplotypes without transcripts; transcripts without Tasks (start-lost: an empty GIR, transcript_instructions.rs:338-343)
     and with nothing but cells no Task covers ('.', haplotype_instruction.rs:78); one Task."""
+    gpu_ctx, dev = one
+    if kernel == 8 and not dev:
+        pytest.skip("PATCH images exist in the development library only")
     from stream_util import Stream
     prot = np.frombuffer(b"MEDLGENTMVLSTLRSLNNFISQRVEGGSGLEELERGGAKLMNPQRSTVWYACDEFGHIK", dtype=np.uint8)
     gpu_ctx.upload_proteome(prot)
@@ -336,10 +361,13 @@ def test_degenerate_streams_in_one_call(built, gpu_ctx, kernel):
 
 
 @pytest.mark.parametrize("preset,h0,n,slices", [("C3", 100, 400, 1), ("C2", 3, 60, 3), ("C4", 7, 12, 1), ("C1", 0, 8, 1)])
-def test_padded_wave_image_is_the_dense_one(built, gpu_ctx, preset, h0, n, slices):
+def test_padded_wave_image_is_the_dense_one(built, one, preset, h0, n, slices):
     """A padded wave image (v2p_set_launch_opts variant 24 forces it, 22 forces the compaction; the rule: rich streams): the one call leaves
     the descriptors in their tiles' slots, the chunk records address slots, the launcher stages them phase by phase (variant 23: read in
     place); the arena, the digests and the image a download hands out (dense form) are the compacted build's, chunk order included."""
+    gpu_ctx, dev = one
+    if not dev:
+        pytest.skip("the A/B switches exist in the development library only")
     from vcf2prot_amd.cohort import Cohort
     c = Cohort.preset(preset)
     gpu_ctx.upload_proteome(c.proteome())
@@ -352,7 +380,7 @@ def test_padded_wave_image_is_the_dense_one(built, gpu_ctx, preset, h0, n, slice
         for var in (22, 24):
             gpu_ctx.set_launch_opts(variant=var, **small)
             b = gpu_ctx.batch()
-            b.build_and_execute(rs, 6, slices)
+            b.build_and_execute(rs, 6, slices if dev else min(slices, 1))
             b.sync()
             d1 = b.digests()
             if var == 24:

@@ -49,12 +49,12 @@ def check_image(b):
 
 
 @pytest.mark.parametrize("preset,h0,n", [("C5", 50, 300), ("C5", 0, 64), ("C1", 0, 8), ("C2", 5, 12), ("C3", 100, 60), ("C4", 7, 3)])
-def test_patch_image_of_the_preset_cohorts(built, gpu_ctx, coracle, preset, h0, n):
+def test_patch_image_of_the_preset_cohorts(built, dev_ctx, coracle, preset, h0, n):
     from vcf2prot_amd.cohort import Cohort
     c = Cohort.preset(preset)
-    gpu_ctx.upload_proteome(c.proteome())
+    dev_ctx.upload_proteome(c.proteome())
     stream = c.txstream(h0, h0 + n, n_threads=3)
-    b = gpu_ctx.batch()
+    b = dev_ctx.batch()
     ms = b.build_on_device(stream, 0, 8)
     assert ms > 0
     sizes = c.result_sizes(h0, h0 + n)
@@ -70,9 +70,9 @@ def test_patch_image_of_the_preset_cohorts(built, gpu_ctx, coracle, preset, h0, 
     for i in range(0, n, max(1, n // 40)):
         assert np.array_equal(b.download_hap(i), oracle_hap(c, coracle, h0 + i)), (preset, h0 + i)
     # the same through a resident stream and the one call
-    rs = gpu_ctx.upload_stream(stream)
+    rs = dev_ctx.upload_stream(stream)
     stream.close()
-    b2 = gpu_ctx.batch()
+    b2 = dev_ctx.batch()
     b2.build_and_execute(rs, 8, 0)
     b2.sync()
     assert b2.oneshot_info()["kernel"] == 8
@@ -81,13 +81,13 @@ def test_patch_image_of_the_preset_cohorts(built, gpu_ctx, coracle, preset, h0, 
 
 
 @pytest.mark.parametrize("seed,shape", [(1, "snv"), (2, "snv"), (3, "snv"), (5, "mix"), (6, "mix"), (7, "mix"), (10, "long"), (11, "long"), (13, "mix"), (14, "long")])
-def test_random_streams_as_patch_images(built, gpu_ctx, seed, shape):
+def test_random_streams_as_patch_images(built, dev_ctx, seed, shape):
     """Irregular streams: empty haplotypes, transcripts without Tasks, zero-length Tasks, cells no Task covers, alt payloads from one byte
     to longer than a chunk, substitution triples at every distance from a chunk boundary."""
     rng = np.random.default_rng(seed)
     proteome, stream, want = random_stream(rng, n_haps=60, n_ref_tx=25, shape=shape, window=4096)
-    gpu_ctx.upload_proteome(proteome)
-    b = gpu_ctx.batch()
+    dev_ctx.upload_proteome(proteome)
+    b = dev_ctx.batch()
     b.build_on_device(stream, 0, 8)
     check_image(b)
     b.execute()
@@ -99,7 +99,7 @@ def test_random_streams_as_patch_images(built, gpu_ctx, seed, shape):
 
 
 @pytest.mark.parametrize("fasta", [False, True])
-def test_reference_task_dumps_as_a_patch_image(gpu_ctx, golden, fasta):
+def test_reference_task_dumps_as_a_patch_image(dev_ctx, golden, fasta):
     """The 36 transcript GIRs harvested from the reference binary (its own Vec<Task> dumps), several per haplotype, repeated so that the
     arena has many chunks; with FASTA emit the arena is the file text of personalized_genome.rs:90-113."""
     from test_gpu_device_build_fasta import _stream_of_cases
@@ -115,11 +115,11 @@ def test_reference_task_dumps_as_a_patch_image(gpu_ctx, golden, fasta):
     for c in cases:
         hdr_off.append(o)
         o += len(c["name"]) + 4
-    gpu_ctx.upload_reference(proteome, np.frombuffer(headers.encode(), dtype=np.uint8))
+    dev_ctx.upload_reference(proteome, np.frombuffer(headers.encode(), dtype=np.uint8))
     per_hap, reps = 7, 40
     many = cases * reps
     stream = _stream_of_cases(many, refs, hdr_off * reps, fasta, per_hap)
-    b = gpu_ctx.batch()
+    b = dev_ctx.batch()
     b.build_on_device(stream, 0, 8)
     check_image(b)
     b.execute()
@@ -132,12 +132,12 @@ def test_reference_task_dumps_as_a_patch_image(gpu_ctx, golden, fasta):
     b.close()
 
 
-def test_patch_builder_reports_what_the_reference_would_panic_on(built, gpu_ctx):
+def test_patch_builder_reports_what_the_reference_would_panic_on(built, dev_ctx):
     """update_task (haplotype_instruction.rs:154) and Task::execute's slices (task.rs:43,47): the first offending Task, by index."""
     from stream_util import Stream
     from vcf2prot_amd._native import V2PError
     prot = np.frombuffer(b"MEDLGENTMVLSTLRSLNNFISQRVEGGSGLEELERGGAKLMNPQRSTVWYACDEFGHIK", dtype=np.uint8)
-    gpu_ctx.upload_proteome(prot)
+    dev_ctx.upload_proteome(prot)
     n_tx = 900                                             # several chunks
 
     def stream(bad_tx, bad):
@@ -157,7 +157,7 @@ def test_patch_builder_reports_what_the_reference_would_panic_on(built, gpu_ctx)
                       code, sp, ln, sr, np.tile(np.frombuffer(b"AC", dtype=np.uint8), n_tx))
     for bad, want_code, row in (("code", -3, 1), ("res", -4, 2), ("src", -5, 2), ("order", -6, 1)):
         for bad_tx in (0, 455, n_tx - 1):
-            b = gpu_ctx.batch()
+            b = dev_ctx.batch()
             with pytest.raises(V2PError) as ei:
                 b.build_on_device(stream(bad_tx, bad), 0, 8)
             assert ei.value.code == want_code and ei.value.index == 3 * bad_tx + row, (bad, bad_tx, ei.value.code, ei.value.index)
@@ -168,7 +168,7 @@ def test_patch_builder_reports_what_the_reference_would_panic_on(built, gpu_ctx)
             b.close()
 
 
-def test_a_window_with_too_many_segments_is_declined_not_mangled(built, gpu_ctx):
+def test_a_window_with_too_many_segments_is_declined_not_mangled(built, dev_ctx):
     """Every second residue substituted: 4 096 patches in an 8 KiB window, more than its 1 024 slots -- V2P_ERR_UNSUPPORTED, the batch left
     empty and reusable; the dense rows image (kernel 7) takes the stream."""
     from stream_util import Stream
@@ -177,7 +177,7 @@ def test_a_window_with_too_many_segments_is_declined_not_mangled(built, gpu_ctx)
     AA = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
     L = 30000
     prot = AA[rng.integers(0, 20, size=L)]
-    gpu_ctx.upload_proteome(prot)
+    dev_ctx.upload_proteome(prot)
     n = L // 2
     code = np.tile(np.array([0, 1], dtype=np.uint8), n)
     sp = np.empty(2 * n, dtype=np.uint32); sp[0::2] = np.arange(0, L, 2); sp[1::2] = np.arange(n)
@@ -186,7 +186,7 @@ def test_a_window_with_too_many_segments_is_declined_not_mangled(built, gpu_ctx)
     alt = AA[rng.integers(0, 20, size=n)]
     s = Stream([0, 1], [0], [L], [L], [0, 2 * n], [0, n], code, sp, ln, sr, alt)
     want = np.empty(L, dtype=np.uint8); want[0::2] = prot[0::2]; want[1::2] = alt
-    b = gpu_ctx.batch()
+    b = dev_ctx.batch()
     with pytest.raises(V2PError) as ei:
         b.build_on_device(s, 0, 8)
     assert ei.value.code == -9

@@ -16,7 +16,7 @@ from vcf2prot_amd._native import V2PError  # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    ctx = engine.Context(0)
+    ctx = engine.Context(0, development=True)
     bad = refused = 0
     for seed in range(1000, 1000 + n):
         rng = np.random.default_rng(seed)

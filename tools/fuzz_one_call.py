@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
 """A wider net than the fixed seeds of tests/test_gpu_oneshot.py: random irregular transcript streams (tests/stream_util.py) through the ONE
 call under every kernel choice and slicing, the image's re-execution forms (dense from padded, pieces from dense, staged) included --
-every haplotype's bytes against the numpy expectation.    python tools/fuzz_one_call.py [first_seed] [n_seeds]"""
+every haplotype's bytes against the numpy expectation.    python tools/fuzz_one_call.py [first_seed] [n_seeds] [--development]
+Default: the PRODUCT library and what it takes (kernel 0 / 6 / 7 / 9, one slice, no switches).  --development: libv2p_bench.so -- the same
+engine compiled with the A/B switches, slices, PATCH images (kernel 8) and the grid builders of rounds 2-3 (csrc/bench/v2p_bench.h)."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from vcf2prot_amd import build
+DEV = "--development" in sys.argv
+sys.argv = [x for x in sys.argv if x != "--development"]
 build.build_hip(); build.build_cohort()
+if DEV:
+    build.build_bench()
 from vcf2prot_amd.engine import Context
 from vcf2prot_amd._native import V2PError
 from stream_util import random_stream
 
 first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 60
 bad, runs = [], 0
-with Context(0) as ctx:
+UNSUPPORTED_BY_NUMBER = (6, 8, 9)                       # an image kind asked for by number may refuse the stream (-9); 0 and 7 take every stream these generators make
+with Context(0, development=DEV) as ctx:
     for seed in range(first, first + count):
         rng = np.random.default_rng(seed)
         shape = ("snv", "mix", "long")[seed % 3]
@@ -27,9 +34,9 @@ with Context(0) as ctx:
             proteome, stream, want = random_stream(rng, n_haps=n_haps, n_ref_tx=n_ref, shape=shape, window=window)
             ctx.upload_proteome(proteome)
         rs = ctx.upload_stream(stream)
-        for kernel in ((0, 6, 7) if fasta else (0, 6, 7, 8)):
-            for slices in (0, 3):
-                for variant in ((0, 24, 25, 23) if kernel in (0, 6) else (0,)):    # 24: the padded form whatever the rule says; 25: dense images staged too; 23: no staging
+        for kernel in ((0, 6, 7, 9) + ((8,) if DEV and not fasta else ())):
+            for slices in ((0, 3) if DEV else (0, 1)):
+                for variant in ((0, 24, 25, 23, 28) if DEV and kernel in (0, 6) else (0,)):    # 24: the padded form whatever the rule says; 25: dense images staged too; 23: no staging; 28: never a tile image
                     # (small phases -- 8+ chunks -- on some runs: the phased launches, the read-ahead riding on them and the two staging buffers also on these small images)
                     if (seed + kernel + slices + variant) % 2:
                         ctx.set_launch_opts(variant=variant, phase_bytes=int([2048, 16384, 1 << 18][(seed + variant) % 3]), phase_min_chunks=8)
@@ -41,7 +48,7 @@ with Context(0) as ctx:
                         try:
                             b.build_and_execute(rs, kernel, slices)
                         except V2PError as e:
-                            if not (kernel == 6 and e.code == -9):
+                            if not (kernel in UNSUPPORTED_BY_NUMBER and e.code == -9):
                                 raise
                             b.reset(); b.build_and_execute(rs, 7, slices)
                         b.sync()
@@ -76,8 +83,8 @@ with Context(0) as ctx:
             ctx.upload_proteome(proteome)
         # (a kind's own window sizes: per-block kernels multiples of 4 KiB up to 60 KiB, the dense kernel 4 / 8 / 12 KiB, wave kernels multiples of 1 KiB up to 10)
         windows = {1: [4096, 8192, 16384, 28672], 2: [4096, 8192, 16384, 32768], 3: [4096, 8192, 12288], 4: [1024, 2048, 4096, 10240], 5: [2048, 3072, 4096, 6144, 10240]}
-        for kernel in (1, 2, 3, 4, 5, 6, 7, 0):
-            window = int(rng.choice(windows[kernel])) if kernel in windows else (4096 if kernel == 0 else 0)      # (0 with a window: round 3's routing among the grid kinds)
+        for kernel in ((1, 2, 3, 4, 5, 6, 7) if DEV else (6, 7)):
+            window = int(rng.choice(windows[kernel])) if kernel in windows else 0
             cfg = {"seed": seed, "shape": shape, "window": window, "kernel": kernel, "two_call": True}
             print("two cfg", cfg, file=sys.stderr, flush=True)
             b = ctx.batch()
@@ -85,7 +92,7 @@ with Context(0) as ctx:
                 try:
                     b.build_on_device(stream, window, kernel)
                 except V2PError as e:
-                    if e.code != -9 or kernel in (0, 7):
+                    if e.code != -9 or kernel == 7:
                         raise
                     continue                                                          # (an image kind asked for by number may not take the stream: too many descriptors in a window / a row)
                 for rep in range(2):
@@ -138,8 +145,8 @@ with Context(0) as ctx:
         n_tx = stream.struct.n_tx
         badst = Stream(k[0], k[1], k[2], k[3], k[4], k[5], code[:n_tasks], sp[:n_tasks], ln[:n_tasks], sr[:n_tasks], k[10][:stream.struct.n_alt])
         rs = ctx.upload_stream(badst)
-        for kernel in (0, 6, 7):
-            for slices in (0, 3):
+        for kernel in (0, 6, 7, 9):
+            for slices in ((0, 3) if DEV else (0,)):
                 cfg = {"seed": seed, "shape": shape, "kernel": kernel, "slices": slices, "expect": list(expect), "picks": picks}
                 print("err cfg", cfg, file=sys.stderr, flush=True)
                 b = ctx.batch()
@@ -148,15 +155,15 @@ with Context(0) as ctx:
                         b.build_and_execute(rs, kernel, slices); b.sync()
                         bad.append({**cfg, "error": "no error reported"})
                     except V2PError as e:
-                        if kernel == 6 and e.code == -9:
-                            pass                                                       # (a row with more than 64 descriptors: refused before the Tasks are judged)
+                        if kernel in (6, 9) and e.code == -9:
+                            pass                                                       # (a row with more than 64 descriptors, transcripts no tile holds: refused before the Tasks are judged)
                         elif e.code != expect[0] or e.index != expect[1]:
                             bad.append({**cfg, "got": [e.code, e.index]})
                     b.reset()
                     try:
                         b.build_and_execute(good, kernel, slices)
                     except V2PError as e:
-                        if not (kernel == 6 and e.code == -9):
+                        if not (kernel in (6, 9) and e.code == -9):
                             raise
                         b.reset(); b.build_and_execute(good, 7, slices)
                     b.sync()

@@ -48,7 +48,7 @@ def main():
     def ev():
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    with Context(0) as ctx:
+    with Context(0, development=True) as ctx:      # (the A/B switches live in libv2p_bench.so)
         ctx.upload_proteome(cohort.proteome())
         t0 = time.perf_counter()
         rs = ctx.upload_stream(stream)

@@ -33,7 +33,7 @@ def main():
     nt = min(64, os.cpu_count() or 1)
     st = c.txstream(0, n, n_threads=nt)
     rb = int(c.result_sizes(0, n, n_threads=nt).sum())
-    with Context(0) as ctx:
+    with Context(0, development=True) as ctx:      # (the A/B switches live in libv2p_bench.so)
         ctx.upload_proteome(c.proteome())
         b = ctx.batch()
         info = build_on_device_auto(b, st, rb)

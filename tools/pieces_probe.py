@@ -15,7 +15,7 @@ cohort = Cohort.preset(wl, n_samples=samples)
 n = cohort.n_haplotypes
 stream = cohort.txstream(0, n, n_threads=min(64, os.cpu_count() or 1))
 out = {"workload": wl, "samples": samples, "haplotypes": n}
-with Context(0) as ctx:
+with Context(0, development=True) as ctx:      # (the A/B switches live in libv2p_bench.so)
     ctx.upload_proteome(cohort.proteome())
     rs = ctx.upload_stream(stream); stream.close()
     b = ctx.batch(); b.build_and_execute(rs, kernel, 0); b.sync()

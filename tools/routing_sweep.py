@@ -56,7 +56,7 @@ def main():
                 res_bytes = int(c.result_sizes(0, n_h, n_threads=nt).sum())
                 variants = {}
                 # two contexts: `ctx` orders chunk tables itself (the product), `cro` launches them as given (forced orders)
-                with Context(0) as ctx, Context(0, result_order=True) as cro:
+                with Context(0, development=True) as ctx, Context(0, result_order=True, development=True) as cro:
                     ctx.upload_proteome(prot)
                     cro.upload_proteome(prot)
                     ts = torch.cuda.Stream()

@@ -64,7 +64,6 @@ HIP_API = {
                                         c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_uint64]),
     "v2p_batch_build_on_device": (c_int, [c_void_p, c_void_p, c_uint32, c_int, POINTER(ctypes.c_float)]),
     "v2p_batch_download_image": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
-    "v2p_batch_download_patch_image": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
     "v2p_stream_upload": (c_int, [c_void_p, c_void_p, POINTER(c_void_p)]),
     "v2p_stream_destroy": (None, [c_void_p]),
     "v2p_stream_counts": (c_int, [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
@@ -131,10 +130,10 @@ def routing_rules(n_desc: int, n_chunks: int, result_bytes: int, proteome_len: i
 class LaunchOpts(ctypes.Structure):
     """v2p_launch_opts (include/vcf2prot_hip.h): zero = the library's choice (store_sc1: -1)."""
     _fields_ = [("nontemporal", c_uint32), ("routing", c_uint32), ("phase_bytes", c_uint64), ("phase_min_chunks", c_uint32),
-                ("store_sc1", ctypes.c_int32), ("max_blocks", c_uint32), ("variant", c_uint32)]
+                ("store_sc1", ctypes.c_int32), ("max_blocks", c_uint32), ("reserved", c_uint32)]
 
-    def __init__(self, nontemporal=1, routing=0, phase_bytes=0, phase_min_chunks=0, store_sc1=-1, max_blocks=0, variant=0):
-        super().__init__(nontemporal, routing, phase_bytes, phase_min_chunks, store_sc1, max_blocks, variant)
+    def __init__(self, nontemporal=1, routing=0, phase_bytes=0, phase_min_chunks=0, store_sc1=-1, max_blocks=0, reserved=0):
+        super().__init__(nontemporal, routing, phase_bytes, phase_min_chunks, store_sc1, max_blocks, reserved)       # reserved: 0 (libv2p_bench.so: 3 / 8, csrc/bench/v2p_bench.h)
 
 
 def stitch_launch(lib, stream, d_desc, n_desc, d_chunks, n_chunks, d_src0, src0_len, d_src1, src1_len, d_out, out_len, d_status, opts: "LaunchOpts") -> int:
@@ -173,6 +172,9 @@ BENCH_API = {
     # the launcher with the packed flag word (kernel variants, timing-only ablations): csrc/bench/v2p_bench.h
     "v2p_stitch_launch": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p, c_uint32, c_void_p, c_uint64, c_void_p, c_uint64,
                                   c_void_p, c_uint64, c_void_p, c_int, c_uint32]),
+    # what no routing rule of the product picks (V2P_BENCH_VARIANTS build of the engine)
+    "v2p_batch_download_patch_image": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_uint64), POINTER(c_uint64)]),
+    "v2p_bench_set_variant": (c_int, [c_void_p, c_uint32]),
 }
 _bench = None
 

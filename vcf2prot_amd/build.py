@@ -22,7 +22,7 @@ ARCH = "gfx950"
 HIP_LIB = os.path.join(LIBDIR, "libvcf2prot_hip.so")
 COHORT_LIB = os.path.join(LIBDIR, "libv2p_cohort.so")
 
-HIP_SOURCES = ["stitch_kernels.hip", "stitch_wave.hip", "build_kernels.hip", "build_rows.hip", "patch_image.hip", "dense_pieces.hip", "v2p_api.hip", "decode_kernels.hip", "v2p_decode_api.hip"]
+HIP_SOURCES = ["stitch_kernels.hip", "stitch_wave.hip", "build_kernels.hip", "build_rows.hip", "dense_pieces.hip", "v2p_api.hip", "decode_kernels.hip", "v2p_decode_api.hip"]
 HIP_DEPS = HIP_SOURCES + ["rows_image.hpp", "build_rows.h", "patch_image.h", "dense_pieces.h", "patch_format.hpp", "stitch_kernels.h", "stitch_device.hpp", "build_kernels.h", "decode_kernels.h", "v2p_ctx_internal.h", "sir_pack.hpp",
                           os.path.join(ROOT, "include", "vcf2prot_hip.h"), os.path.join(ROOT, "include", "v2p_frontend.h")]
 COHORT_SOURCES = ["cohort_gen.cpp", os.path.join("host", "transcript_tasks.cpp"), os.path.join("host", "vcf_index.cpp"),
@@ -61,7 +61,7 @@ def _compile_objects(sources, deps, objdir, extra, force, verbose):
         obj = os.path.join(objdir, os.path.basename(src).rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", *extra,
+            jobs.append([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result", *extra,
                          "-c", os.path.join(CSRC, src), "-o", obj])
     if jobs:
         def run(cmd):
@@ -98,7 +98,9 @@ def build_cohort(force: bool = False, verbose: bool = False) -> str:
 
 
 BENCH_LIB = os.path.join(LIBDIR, "libv2p_bench.so")
-BENCH_SOURCES = HIP_SOURCES + [os.path.join("bench", "bench_kernels.hip"), os.path.join("bench", "wave_copy_bench.hip")]
+# (the development library also carries what no routing rule of the product picks: PATCH images, the grid builders of rounds 2-3, the
+# A/B switches of the builders and launchers -- compiled in by V2P_BENCH_VARIANTS)
+BENCH_SOURCES = HIP_SOURCES + ["patch_image.hip", os.path.join("bench", "bench_kernels.hip"), os.path.join("bench", "wave_copy_bench.hip")]
 BENCH_DEPS = HIP_DEPS + [os.path.join("bench", "bench_kernels.hip"), os.path.join("bench", "wave_copy_bench.hip"), os.path.join("bench", "v2p_bench.h")]
 
 

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64, 8) void wave_chain_persist_kernel(ChainParams p
     }
 }
 
-extern "C" int v2p_bench_wave_chain(void* stream, const uint8_t* src, uint64_t window, uint8_t* out, uint64_t bytes, const uint64_t* dsc,
+extern "C" __attribute__((visibility("default"))) int v2p_bench_wave_chain(void* stream, const uint8_t* src, uint64_t window, uint8_t* out, uint64_t bytes, const uint64_t* dsc,
                                     const uint64_t* rec, uint32_t pattern, uint32_t dsc_lanes, uint32_t remap, uint32_t persist_waves)
 {
     ChainParams p{src, window, out, bytes / 8192u, dsc, rec, pattern, 5u, 26u, dsc_lanes, remap, 0u};
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void touch_kernel(const u32x4* __restrict__ p,
 
 // the copy in `phases` sub-launches, each preceded by a kernel that reads its descriptors (dsc_lanes * 8 bytes of every 512-byte slot
 // are what the copy reads; the touch reads whole slots) -- descriptor reads then never mix with the result stores
-extern "C" int v2p_bench_wave_copy_phased(void* stream, const uint8_t* src, uint64_t window, uint8_t* out, uint64_t bytes, const uint64_t* dsc,
+extern "C" __attribute__((visibility("default"))) int v2p_bench_wave_copy_phased(void* stream, const uint8_t* src, uint64_t window, uint8_t* out, uint64_t bytes, const uint64_t* dsc,
                                           uint32_t pattern, uint32_t dsc_lanes, uint32_t aux, uint32_t phases, uint32_t* sink, int touch)
 {
     const uint64_t n_chunks = bytes / 8192u;
@@ -231,7 +231,7 @@ extern "C" int v2p_bench_wave_copy_phased(void* stream, const uint8_t* src, uint
     return e == hipSuccess ? 0 : -100 - int(e);
 }
 
-extern "C" int v2p_bench_wave_copy(void* stream, const uint8_t* src, uint64_t window, uint8_t* out, uint64_t bytes, const uint64_t* dsc,
+extern "C" __attribute__((visibility("default"))) int v2p_bench_wave_copy(void* stream, const uint8_t* src, uint64_t window, uint8_t* out, uint64_t bytes, const uint64_t* dsc,
                                    uint32_t pattern, uint32_t shift, uint32_t n_p, uint32_t run_blocks, uint32_t aligned, int wpg,
                                    uint32_t dsc_lanes, uint32_t dsc_mod, uint32_t aux, uint32_t prefetch)
 {

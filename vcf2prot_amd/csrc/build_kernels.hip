@@ -116,6 +116,7 @@ hipError_t launch_scan_u32(const uint32_t* in, uint64_t n, uint64_t* out, uint64
     return launch_scan_u32_from(in, n, out, tile_scratch, 0, stream);
 }
 
+#ifdef V2P_BENCH_VARIANTS   // the GRID builders of rounds 2-3 (v2p_batch_build_on_device kernel 1 .. 5): libv2p_bench.so only -- no routing rule picks them
 // ---- the walk over one transcript's tasks: EMIT = false counts descriptors, true writes them -------------------------------
 __device__ __forceinline__ uint32_t pieces(uint64_t dst, uint64_t len, uint32_t W) { return uint32_t((dst + len - 1) / W - dst / W) + 1u; }
 
@@ -634,6 +635,8 @@ __global__ __launch_bounds__(256) void xcd_scatter_kernel(const Chunk* __restric
     out[pos] = in[k];
 }
 
+#endif   // V2P_BENCH_VARIANTS: the grid builders and their one-block sorts
+
 // ---- the same two sorts for ALL blocks of the table in one launch each (sir_pack.hpp: the order is applied inside blocks of the
 // arena): grid = (thread blocks of the largest block, blocks); block y holds the entries [first(y), first(y + 1)) -- pure arithmetic,
 // xcd_order_block_first -- and, since the blocks follow each other in the table, ONE scan over [block][window][thread block]
@@ -769,6 +772,7 @@ hipError_t launch_order_blocks(const Chunk* in, const uint8_t* bucket, const uin
 }
 uint64_t order_blocks_thread_blocks(uint64_t n, uint32_t nb) { return (n + 255) / 256 + 2ull * nb + 2; }   // >= nb * tbmax for any equal-share split
 
+#ifdef V2P_BENCH_VARIANTS
 hipError_t launch_build(const BuildArgs& a, uint64_t n_windows, uint64_t n_desc, uint64_t out_bytes, int phase, hipStream_t stream)
 {
     const uint32_t tx_blocks = uint32_t((a.n_tx + 255) / 256);
@@ -784,7 +788,11 @@ hipError_t launch_build(const BuildArgs& a, uint64_t n_windows, uint64_t n_desc,
     return hipGetLastError();
 }
 
+#endif
+
 uint64_t scan_tiles_for(uint64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 1; }
+
+#ifdef V2P_BENCH_VARIANTS
 
 hipError_t launch_sub_order(const Chunk* in, const uint8_t* bucket, const uint8_t* sub, uint64_t n, uint32_t* hist, uint64_t* start, uint64_t* tiles,
                             Chunk* out, uint8_t* out_bucket, hipStream_t stream)
@@ -807,6 +815,8 @@ hipError_t launch_xcd_order(const Chunk* in, const uint8_t* bucket, uint64_t n, 
     hipLaunchKernelGGL(xcd_scatter_kernel, dim3(uint32_t(n_blocks)), dim3(256), 0, stream, in, bucket, n, hist, n_blocks, out);
     return hipGetLastError();
 }
+
+#endif   // V2P_BENCH_VARIANTS: launch_sub_order / launch_xcd_order (one block)
 
 __global__ void code_object_loader_c() {}
 hipError_t preload_build_kernels(hipStream_t stream)

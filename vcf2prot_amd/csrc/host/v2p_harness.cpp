@@ -376,21 +376,25 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
         t_write_acc += since(tw);
         return true;
     };
-    // ---- a slice the rows builders refuse (a 1 KiB row with more than 1 024 descriptors): the grid builders of round 3, smaller windows
-    // first refused (txstream.py::build_plan), on a batch of its own; its arena is downloaded whole ----
+    // ---- a slice the rows builders refuse (a 1 KiB row with more than 1 024 descriptors): the HOST builder takes any stream (step 5 on the
+    // host: v2p_batch_begin_haplotype / _add_transcript / _end_haplotype + v2p_batch_finalize), on a batch of its own; its arena is downloaded whole ----
     auto blocking_slice = [&](TxStreamHost& tx, std::vector<uint8_t>& bytes, std::vector<uint64_t>& hob) {
         v2p_txstream st = tx.view();
         v2p_batch* fb = nullptr;
         chk(v2p_batch_create(ctx.raw(), &fb));
-        v2p_routing rules;
-        chk(v2p_routing_rules(0, 0, tx.result_bytes, 0, 1, &rules));
-        const double bpt = double(tx.result_bytes) / double(st.n_tasks ? st.n_tasks : 1);
-        std::vector<std::pair<int, uint32_t>> plan_v;
-        if (bpt < double(rules.wave_bytes_per_task)) plan_v = {{3, 12288}, {3, 8192}, {3, 4096}, {2, 4096}};
-        else plan_v = {{2, 32768}, {2, 16384}, {2, 4096}};
-        int rc = V2P_ERR_UNSUPPORTED;
-        for (size_t k = 0; k < plan_v.size() && rc == V2P_ERR_UNSUPPORTED; ++k) rc = v2p_batch_build_on_device(fb, &st, plan_v[k].second, plan_v[k].first, nullptr);
-        chk(rc);
+        std::vector<uint64_t> sp64, ln64, sr64;
+        for (uint64_t h = 0; h < st.n_haps; ++h) {
+            chk(v2p_batch_begin_haplotype(fb));
+            for (uint64_t t = st.hap_tx_begin[h]; t < st.hap_tx_begin[h + 1]; ++t) {
+                const uint64_t k0 = st.tx_task_begin[t], k1 = st.tx_task_begin[t + 1], n = k1 - k0;
+                sp64.assign(st.start_pos + k0, st.start_pos + k1); ln64.assign(st.length + k0, st.length + k1); sr64.assign(st.start_pos_res + k0, st.start_pos_res + k1);
+                chk(v2p_batch_add_transcript(fb, st.code + k0, sp64.data(), ln64.data(), sr64.data(), n, st.tx_proteome_off[t], st.tx_ref_len[t],
+                                             st.alt + st.tx_alt_begin[t], st.tx_alt_begin[t + 1] - st.tx_alt_begin[t], st.tx_res_len[t],
+                                             st.tx_header_off[t], st.tx_header_len[t]));
+            }
+            chk(v2p_batch_end_haplotype(fb));
+        }
+        chk(v2p_batch_finalize(fb));
         chk(v2p_batch_execute(fb));
         chk(v2p_batch_sync(fb));
         hob.assign(st.n_haps + 1, 0);
@@ -527,7 +531,7 @@ static int vcf_mode(const char* vcf_path, const char* fasta_path, const char* ou
     t_write = host_build ? since(t0) : t_write_acc;
     std::printf("vcf: %llu records, %llu probands, %llu bytes of FASTA written to %s\n", (unsigned long long)R, (unsigned long long)S,
                 (unsigned long long)written, outdir);
-    std::printf("{\"records\": %llu, \"probands\": %llu, \"fasta_bytes\": %llu, \"slices\": %llu, \"slices_through_grid_builders\": %llu, \"seconds\": {\"read_files\": %.4f, \"index\": %.4f, "
+    std::printf("{\"records\": %llu, \"probands\": %llu, \"fasta_bytes\": %llu, \"slices\": %llu, \"slices_through_the_host_builder\": %llu, \"seconds\": {\"read_files\": %.4f, \"index\": %.4f, "
                 "\"decode_incl_h2d\": %.4f, \"grouping\": %.4f, \"steps_4a_4b_5\": %.4f, \"h2d_step6_sync\": %.4f, \"d2h_write\": %.4f, \"total\": %.4f}, "
                 "\"decode_kernels_ms\": {\"parse\": %.3f, \"count\": %.3f, \"scan\": %.3f, \"emit\": %.3f}}\n",
                 (unsigned long long)R, (unsigned long long)S, (unsigned long long)written, (unsigned long long)n_slices, (unsigned long long)n_fallback,

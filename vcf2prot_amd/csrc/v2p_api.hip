@@ -24,7 +24,10 @@
 #include "build_kernels.h"
 #include "build_rows.h"
 #include "dense_pieces.h"
+#ifdef V2P_BENCH_VARIANTS
 #include "patch_image.h"
+#include "bench/v2p_bench.h"
+#endif
 #include "v2p_ctx_internal.h"
 
 using namespace v2p;
@@ -145,6 +148,7 @@ struct v2p_ctx {
     ImageBuilder gir_img;                            // reused across v2p_execute_gir calls (its vectors keep their capacity)
     struct GirQueue* queue = nullptr;                // v2p_execute_gir_shared: batches of concurrent callers (created at the first call)
     v2p_launch_opts launch_opts{1u, 0u, 0ull, 0u, -1, 0u, 0u};   // v2p_set_launch_opts: phase size / threshold / store policy of this context's batches (A/B runs, tests)
+    uint32_t variant = 0;                              // libv2p_bench.so only (v2p_bench_set_variant: csrc/bench/v2p_bench.h): the A/B switches of the builders and launchers
 
     int fail(int code, const std::string& msg, int64_t index = -1) { err = msg; err_index = index; return code; }
     int hip_fail(hipError_t e, const char* what) {
@@ -224,6 +228,17 @@ void ctx_lock(v2p_ctx* c) { c->mu.lock(); }
 void ctx_unlock(v2p_ctx* c) { c->mu.unlock(); }
 }  // namespace v2p
 
+// The A/B switches (16 .. 29) of rounds 4-5 exist in the development library only; the product's rules are not switchable.
+static inline uint32_t ctx_variant(const v2p_ctx* c)
+{
+#ifdef V2P_BENCH_VARIANTS
+    return c->variant;
+#else
+    (void)c;
+    return 0u;
+#endif
+}
+
 #define HIP_TRY(ctx, expr, what) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return (ctx)->hip_fail(e__, what); } while (0)
 
 struct GirQueue;
@@ -289,7 +304,9 @@ int v2p_init(int device_ordinal, unsigned flags, v2p_ctx** out)
             if (le == hipSuccess) le = preload_stitch_wave(c->own_stream);
             if (le == hipSuccess) le = preload_build_kernels(c->own_stream);
             if (le == hipSuccess) le = preload_build_rows(c->own_stream);
+#ifdef V2P_BENCH_VARIANTS
             if (le == hipSuccess) le = preload_patch_image(c->own_stream);
+#endif
             if (le == hipSuccess) le = preload_dense_pieces(c->own_stream);
             if (le == hipSuccess) le = hipStreamSynchronize(c->own_stream);
             if (le != hipSuccess) {
@@ -1258,7 +1275,9 @@ struct DevStreamView {
     double len_mean = 0.0, len_var = 0.0;              // ... and its arena bytes (rows_pick_k_tiles)
 };
 
+#ifdef V2P_BENCH_VARIANTS
 static int build_patch_image(v2p_batch* b, const DevStreamView& v, float* build_ms, bool own_stream_copy, uint64_t known_out_bytes);
+#endif
 
 // mean and spread of the items per transcript from a sample of the (host) stream -- and of an upper estimate of its DESCRIPTORS: a
 // one-residue alt Task between two reference copies fuses with both (one descriptor for three Tasks; transcript_instructions.rs:654-663
@@ -1676,6 +1695,13 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     std::lock_guard<std::mutex> lk(c->mu);
     if (b->finalized) return c->fail(V2P_ERR_STATE, "batch already finalized");
     if (b->hap_open || b->img.n_haplotypes()) return c->fail(V2P_ERR_STATE, "the batch already holds host-built haplotypes");
+#ifndef V2P_BENCH_VARIANTS
+    // the product builds ROWS images (round 4: one pass, whole descriptors, chunks cut on 1 KiB rows afterwards; no window).  The grid builders
+    // of rounds 2-3 (kernel 1 .. 5) and PATCH images (8) were never picked by a routing rule: they live in libv2p_bench.so (csrc/bench/v2p_bench.h)
+    if (kernel != 6 && kernel != 7) return c->fail(V2P_ERR_INVALID_ARG, "v2p_batch_build_on_device builds rows images: kernel 6 (wave) or 7 (dense)");
+    (void)window_bytes;
+    const bool rows = true;
+#else
     const bool split = kernel == 5;                       // wave windows that may split once (65 .. 127 descriptors -> two chunks)
     if (split) kernel = 4;
     const bool rows = kernel == 6 || kernel == 7 || kernel == 8;   // ROWS images (round 4): one pass, whole descriptors, chunks cut on 1 KiB rows afterwards; no window -- 8: a PATCH image (round 5)
@@ -1686,6 +1712,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     if (split && window_bytes < 2048u) return c->fail(V2P_ERR_INVALID_ARG, "a window that may split holds at least two 1 KiB rows");
     // (a grid chunk starts on a multiple of 4096: no 16-byte phase, so 12288 bytes fill the kernel's LDS image exactly)
     if (kernel == 3 && window_bytes > 12288u) return c->fail(V2P_ERR_INVALID_ARG, "a dense image takes windows of 4096, 8192 or 12288 bytes (one chunk = one 12 KiB LDS image)");
+#endif
     bool fasta = false;
     std::vector<uint32_t> arena_len;
     {
@@ -1697,9 +1724,14 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
         DevStreamView v;
         const int urc = upload_stream(c, s, fasta, b->d_build, b->d_payload, v, c->stream);
         if (urc) { b->d_build.release(); return urc; }
+#ifdef V2P_BENCH_VARIANTS
         if (kernel == 8) return build_patch_image(b, v, build_ms, true, ~0ull);
+#endif
         return build_rows_image(b, v, kernel == 7 ? ROWS_DENSE : ROWS_WAVE, build_ms, true);
     }
+#ifndef V2P_BENCH_VARIANTS
+    return c->fail(V2P_ERR_INVALID_ARG, "kernel");
+#else
     const uint64_t n_tx = s->n_tx, n_tk = s->n_tasks, n_h = s->n_haps;
     const uint64_t n_tiles = (n_tx + 1023) / 1024 + 2;
     // one device allocation, carved: stream arrays, then scratch
@@ -1845,8 +1877,10 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
     b->uses_proteome = true;
     b->finalized = true;
     return V2P_OK;
+#endif   // V2P_BENCH_VARIANTS: the grid builders
 }
 
+#ifdef V2P_BENCH_VARIANTS
 // ---- PATCH images (patch_image.h; kernel 8): deep Task vectors as segments + patches, ONE build kernel, one workgroup per 12 KiB window ----
 // V2P_ERR_UNSUPPORTED: the format declines the stream (a window with more segments / patches than its slots, sources beyond 16 GB) --
 // the batch is left empty and the caller builds a dense rows image (kernel 7) instead.
@@ -1957,6 +1991,7 @@ static int build_patch_image(v2p_batch* b, const DevStreamView& v, float* build_
     b->n_slices = 0;
     return V2P_OK;
 }
+#endif   // V2P_BENCH_VARIANTS: patch images
 
 // ---- a transcript stream RESIDENT on the device; Task vectors -> result bytes in ONE call -----------------------------------
 // v2p_batch_build_on_device takes a host stream, uploads it, builds, and the caller executes afterwards: two calls, the stream's H2D
@@ -2087,7 +2122,7 @@ static bool tiles_possible(const v2p_stream* st)
     return c->proteome_len + c->headers_len + 64u <= PIECE_SRC_MAX && st->v.n_alt + 64u <= PIECE_SRC_MAX && st->v.n_tx != 0 && rows_pick_k_tiles(st->v, &slots) != 0u;
 }
 // kernel 0: the routing rule (sir_pack.hpp: WAVE_BYTES_PER_TASK result bytes per Task and more -> a wave image; below -- deep Task
-// vectors -- a TILE image where the form takes the stream, else a dense rows image; v2p_set_launch_opts variant 28 (A/B): never a tile image)
+// vectors -- a TILE image where the form takes the stream, else a dense rows image; libv2p_bench.so's variant 28 (A/B): never a tile image)
 static int rows_mode_for(const v2p_stream* st, int kernel)
 {
     if (kernel == 6) return ROWS_WAVE;
@@ -2095,7 +2130,7 @@ static int rows_mode_for(const v2p_stream* st, int kernel)
     if (kernel == 9) return ROWS_TILES;
     const double bpt = double(st->out_bytes) / double(st->v.n_tasks ? st->v.n_tasks : 1);
     if (bpt >= double(WAVE_BYTES_PER_TASK)) return ROWS_WAVE;
-    return st->ctx->launch_opts.variant != 28u && tiles_possible(st) ? ROWS_TILES : ROWS_DENSE;
+    return ctx_variant(st->ctx) != 28u && tiles_possible(st) ? ROWS_TILES : ROWS_DENSE;
 }
 
 // (c->mu held.  wait: the context's stream is waited for -- the streamed pipeline's runner recycles a slot's batch whose last
@@ -2135,7 +2170,11 @@ int v2p_batch_build_from_stream(v2p_batch* b, const v2p_stream* st, int kernel, 
     if (kernel != 0 && kernel != 6 && kernel != 7 && kernel != 8 && kernel != 9) return c->fail(V2P_ERR_INVALID_ARG, "a resident stream builds rows images (kernel 6, 7), a patch image (8), a tile image (9) or what the routing rule picks (0)");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     b->os_kernel = 0;                                   // (not a one call: v2p_batch_oneshot_info has nothing to report)
+#ifdef V2P_BENCH_VARIANTS
     if (kernel == 8) { const int prc = build_patch_image(b, st->v, build_ms, false, st->out_bytes); if (prc == V2P_OK) stream_attach(b, st); return prc; }
+#else
+    if (kernel == 8) return c->fail(V2P_ERR_INVALID_ARG, "patch images (kernel 8) live in libv2p_bench.so");
+#endif
     int mode = rows_mode_for(st, kernel);
     if (mode == ROWS_TILES) {                           // deep Task vectors: a tile image (dense_pieces.h), not executed here
         bool fb = false;
@@ -2151,6 +2190,7 @@ int v2p_batch_build_from_stream(v2p_batch* b, const v2p_stream* st, int kernel, 
     return rc;
 }
 
+#ifdef V2P_BENCH_VARIANTS
 static hipError_t patch_execute(v2p_batch* b, hipStream_t stream)
 {
     v2p_ctx* c = b->ctx;
@@ -2159,15 +2199,16 @@ static hipError_t patch_execute(v2p_batch* b, hipStream_t stream)
                     b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
     return launch_stitch_patch(a, stream, !(c->flags & V2P_FLAG_TEMPORAL));
 }
+#endif
 
 // v2p_set_launch_opts: variant 16 / 17 / 18 = how a context's phased wave images are launched (A/B switches: tools/phase_ab.py):
 // ONE launch for all phases / the read-ahead as kernels of its own / no read-ahead
 static uint32_t touch_of(uint32_t variant) { return variant == 16u ? 4u : (variant == 17u ? 2u : (variant == 18u ? 1u : 0u)); }
 
-// v2p_set_launch_opts variant 19: the phases of a context's wave images in halves on two launch streams (launch_stitch: dual)
+// libv2p_bench.so's variant 19: the phases of a context's wave images in halves on two launch streams (launch_stitch: dual)
 static void dual_of(v2p_ctx* c, StitchArgs& a)
 {
-    if (c->launch_opts.variant != 19u) return;
+    if (ctx_variant(c) != 19u) return;
     if (!c->exec_aux && hipStreamCreateWithFlags(&c->exec_aux, hipStreamNonBlocking) != hipSuccess) { c->exec_aux = nullptr; return; }
     for (hipEvent_t& e : c->ev_exec) if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return; }
     a.aux_stream = c->exec_aux; a.ev_fork = c->ev_exec[0]; a.ev_join = c->ev_exec[1]; a.opt_dual = 1u;
@@ -2176,7 +2217,7 @@ static void dual_of(v2p_ctx* c, StitchArgs& a)
 static hipError_t ensure_event(hipEvent_t& e) { return e ? hipSuccess : hipEventCreate(&e); }
 
 // Staging buffers for an image launch_stitch() will run in the form that stages (a pure wave rows image in phases): sized by the
-// launcher's own rule.  v2p_set_launch_opts variant 23 (A/B): no staging -- the stitch waves read descriptors where the image has them;
+// launcher's own rule.  libv2p_bench.so's variant 23 (A/B): no staging -- the stitch waves read descriptors where the image has them;
 // 25: dense rows images are staged as well.
 static hipError_t attach_stage(v2p_batch* b, StitchArgs& a, int hint)
 {
@@ -2189,7 +2230,7 @@ static hipError_t attach_stage(v2p_batch* b, StitchArgs& a, int hint)
     // (... and large: what staging buys is FEWER phases; an image of three phases gains nothing from being one of two and pays the copy --
     // the routing sweep's 1.5 GB images ran 1-3 % slower staged, profiles/r05_routing_sweep.json)
     const bool small_rich = image_is_rich(idesc, ibytes) && a.src0_len <= PHASE_STAGED_SMALL_REF && 8u * idesc + 16u * uint64_t(a.n_chunks) >= 8u * PHASE_BYTES_RICH;
-    if (b->ctx->launch_opts.variant == 23u || !(b->pad_image || b->ctx->launch_opts.variant == 25u || small_rich)) return hipSuccess;
+    if (ctx_variant(b->ctx) == 23u || !(b->pad_image || ctx_variant(b->ctx) == 25u || small_rich)) return hipSuccess;
     const uint32_t rows = stitch_stage_chunks(a, hint);
     if (rows == 0) return hipSuccess;
     const hipError_t e = b->d_stage.ensure(uint64_t(2) * rows * 64u * 8u);
@@ -2207,7 +2248,7 @@ static hipError_t stitch_range(v2p_batch* b, uint64_t desc_bound, uint64_t chunk
                  uint32_t(n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->payload_dev, b->n_payload,
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
     a.opt_phase_bytes = c->launch_opts.phase_bytes; a.opt_phase_min_chunks = c->launch_opts.phase_min_chunks; a.opt_store_sc1 = c->launch_opts.store_sc1;
-    a.opt_touch = touch_of(c->launch_opts.variant);
+    a.opt_touch = touch_of(ctx_variant(c));
     dual_of(c, a);
     a.img_desc = img_desc; a.img_bytes = img_bytes;
     const int hint = int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint;
@@ -2239,7 +2280,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
     // C2 -- profiles/r05_oneshot_slices.json -- every added slice costs: a slice's build takes three times as long next to a running
     // stitch (cold stream reads between its stores, the effect of DESIGN.md section 3) and the stitch slows down as well.)
     // (a padded image -- the rule is below, where its buffers are -- is built in slices of its own kind: see `ahead`)
-    const uint32_t bvar = c->launch_opts.variant;
+    const uint32_t bvar = ctx_variant(c);
     const bool rich_stream = out_bytes <= uint64_t(PAD_BYTES_PER_TASK_MAX) * v.n_tasks;
     const bool pad = mode == ROWS_WAVE && n_tiles < (1ull << 24) && bvar != 22u && (rich_stream || bvar == 24u);
     uint32_t S = n_slices ? n_slices : (pad && bvar == 27u ? 3u : 1u);
@@ -2523,7 +2564,7 @@ static int build_tiles(v2p_batch* b, const v2p_stream* st, bool execute, bool* f
     a.hap_out_begin = reinterpret_cast<uint64_t*>(b->d_hap.ptr());
     a.out_bytes = out_bytes;
     uint64_t* const scan_scratch = reinterpret_cast<uint64_t*>(d + o_scan);
-    const bool cached = c->launch_opts.variant != 21u && st->tile_K == K && st->n_tiles == n_tiles && st->tile_res_base != nullptr && st->d_hap_out_begin != nullptr;
+    const bool cached = ctx_variant(c) != 21u && st->tile_K == K && st->n_tiles == n_tiles && st->tile_res_base != nullptr && st->d_hap_out_begin != nullptr;
     HIP_TRY(c, hipEventRecord(b->ev_os[0], A), "hipEventRecord");
     if (cached) {
         a.tile_res_base = const_cast<uint64_t*>(st->tile_res_base);
@@ -2572,6 +2613,10 @@ static int build_and_execute_locked(v2p_batch* b, const v2p_stream* st, int kern
     if (kernel != 0 && kernel != 6 && kernel != 7 && kernel != 8 && kernel != 9) return c->fail(V2P_ERR_INVALID_ARG, "a resident stream builds rows images (kernel 6, 7), a patch image (8), a tile image (9) or what the routing rule picks (0)");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
     const auto t0 = std::chrono::steady_clock::now();
+#ifndef V2P_BENCH_VARIANTS
+    if (kernel == 8) return c->fail(V2P_ERR_INVALID_ARG, "patch images (kernel 8) live in libv2p_bench.so");
+    if (n_slices > 1) return c->fail(V2P_ERR_INVALID_ARG, "n_slices: 0 or 1 (building in slices was measured slower on every cohort and lives in libv2p_bench.so)");
+#else
     if (kernel == 8) {
         // a PATCH image: one build kernel behind the positions' scan, then one stitch kernel, on the context's stream
         for (uint32_t k = 0; k < 2; ++k) HIP_TRY(c, ensure_event(b->ev_os[k]), "hipEventCreate");
@@ -2587,6 +2632,7 @@ static int build_and_execute_locked(v2p_batch* b, const v2p_stream* st, int kern
         stream_attach(b, st);
         return V2P_OK;
     }
+#endif
     int mode = rows_mode_for(st, kernel);
     bool fallback = false;
     if (mode == ROWS_TILES) {
@@ -2658,6 +2704,7 @@ int v2p_batch_oneshot_info(v2p_batch* b, v2p_oneshot_info* info)
     return V2P_OK;
 }
 
+#ifdef V2P_BENCH_VARIANTS
 int v2p_batch_download_patch_image(v2p_batch* b, uint64_t* seg, uint32_t* patch, v2p_chunk* chunks, uint64_t* n_segments, uint64_t* n_patches)
 {
     if (!b) return V2P_ERR_INVALID_ARG;
@@ -2673,6 +2720,7 @@ int v2p_batch_download_patch_image(v2p_batch* b, uint64_t* seg, uint32_t* patch,
     HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     return V2P_OK;
 }
+#endif
 
 // A padded image becomes the dense one (on the context's stream, for good): the compaction the one call skipped, into the batch's spare
 // descriptor buffer, and the chunk records translated in place.  Called by whoever needs the dense form -- a download, and the first
@@ -2785,12 +2833,12 @@ int v2p_batch_finalize(v2p_batch* b)
 
 // A dense rows image (every chunk a dense chunk on a 1 KiB row: launch_hint bits 1, 3, 4, 5 and not 2) that is executed AGAIN is
 // re-written as pieces first (dense_pieces.h), once; an image the form does not take (sources beyond 2 GiB, a descriptor the dense
-// kernel would refuse and report) stays on the dense kernel.  v2p_set_launch_opts variant 28 (A/B): never.
+// kernel would refuse and report) stays on the dense kernel.  libv2p_bench.so's variant 28 (A/B): never.
 static bool pieces_eligible(const v2p_batch* b)
 {
     const int h = b->launch_hint;
-    return b->finalized && !b->is_patch && !b->is_tiles && (h & 2) && (h & 8) && !(h & 4) && (h & 16) && (h & 32) && b->n_chunks != 0 && b->ctx->launch_opts.variant != 28u &&
-           b->ctx->launch_opts.variant != 3u && b->ctx->launch_opts.variant != 8u;
+    return b->finalized && !b->is_patch && !b->is_tiles && (h & 2) && (h & 8) && !(h & 4) && (h & 16) && (h & 32) && b->n_chunks != 0 && ctx_variant(b->ctx) != 28u &&
+           ctx_variant(b->ctx) != 3u && ctx_variant(b->ctx) != 8u;
 }
 static int to_pieces(v2p_batch* b)
 {
@@ -2835,11 +2883,13 @@ int v2p_batch_execute(v2p_batch* b)
     if (!b->finalized) return c->fail(V2P_ERR_STATE, "batch not finalized");
     if (b->orphaned) return c->fail(V2P_ERR_STATE, "the v2p_stream this batch was built from has been destroyed: its image cannot be executed again (the arena stays readable)");
     HIP_TRY(c, hipSetDevice(c->device), "hipSetDevice");
+#ifdef V2P_BENCH_VARIANTS
     if (b->is_patch) {
         const hipError_t pe = patch_execute(b, c->stream);
         if (pe != hipSuccess) return c->hip_fail(pe, "launch(stitch: patch image)");
         return V2P_OK;
     }
+#endif
     if (b->is_tiles) {
         // (the executor checks no source bound: the parse did, against the reference of that moment)
         if (c->proteome_len + c->headers_len < b->pieces_src0_len) return c->fail(V2P_ERR_SRC_OOB, "the resident reference is shorter than the one this tile image was built against: rebuild the batch");
@@ -2848,7 +2898,7 @@ int v2p_batch_execute(v2p_batch* b)
         return V2P_OK;
     }
     // (variants 23 / 26, A/B: a padded image stays padded -- read in place / staged)
-    if (b->pad_image && c->launch_opts.variant != 23u && c->launch_opts.variant != 26u) { const int rc = densify(b); if (rc) return rc; }
+    if (b->pad_image && ctx_variant(c) != 23u && ctx_variant(c) != 26u) { const int rc = densify(b); if (rc) return rc; }
     if (pieces_eligible(b) && b->executed) {
         if (b->pieces_state == 0) { const int rc = to_pieces(b); if (rc) return rc; }
         // (the piece kernel checks no source bound: to_pieces did, against the reference of that moment -- behind a v2p_upload_reference
@@ -2865,7 +2915,7 @@ int v2p_batch_execute(v2p_batch* b)
                  uint32_t(b->n_chunks), c->proteome.ptr(), c->proteome_len + c->headers_len, b->payload_dev, b->n_payload,
                  b->d_out.ptr(), b->out_bytes, reinterpret_cast<unsigned long long*>(b->d_status.ptr())};
     a.opt_phase_bytes = c->launch_opts.phase_bytes; a.opt_phase_min_chunks = c->launch_opts.phase_min_chunks; a.opt_store_sc1 = c->launch_opts.store_sc1;
-    a.opt_touch = touch_of(c->launch_opts.variant);
+    a.opt_touch = touch_of(ctx_variant(c));
     a.img_desc = b->pad_image ? b->n_desc : 0;          // (the routing looks at the descriptors the image holds, not at the array's slots)
     dual_of(c, a);
     const int hint = int(!(c->flags & V2P_FLAG_TEMPORAL)) | b->launch_hint;
@@ -3429,8 +3479,14 @@ int v2p_stitch_launch_opts(void* hip_stream,
     StitchArgs a{d_desc, n_desc, reinterpret_cast<const Chunk*>(d_chunks), n_chunks, d_src0, src0_len, d_src1, src1_len,
                  d_out, out_len, reinterpret_cast<unsigned long long*>(d_status)};
     a.opt_phase_bytes = opts->phase_bytes; a.opt_phase_min_chunks = opts->phase_min_chunks; a.opt_store_sc1 = opts->store_sc1;
-    const int flags = int(opts->nontemporal ? 1u : 0u) | int(opts->routing & 0xFFEu) | int((opts->variant == 3u || opts->variant == 8u ? opts->variant : 0u) << 12);
-    if (opts->variant != 0u && opts->variant != 3u && opts->variant != 8u) return V2P_ERR_INVALID_ARG;
+#ifdef V2P_BENCH_VARIANTS
+    // (the development library: `reserved` = 3 / 8 route every per-block chunk to the per-block / the dense kernel -- routing-only A/B switches)
+    const int flags = int(opts->nontemporal ? 1u : 0u) | int(opts->routing & 0xFFEu) | int((opts->reserved == 3u || opts->reserved == 8u ? opts->reserved : 0u) << 12);
+    if (opts->reserved != 0u && opts->reserved != 3u && opts->reserved != 8u) return V2P_ERR_INVALID_ARG;
+#else
+    const int flags = int(opts->nontemporal ? 1u : 0u) | int(opts->routing & 0xFFEu);
+    if (opts->reserved != 0u) return V2P_ERR_INVALID_ARG;
+#endif
     return launch_stitch(a, reinterpret_cast<hipStream_t>(hip_stream), flags, opts->max_blocks) == hipSuccess ? V2P_OK : V2P_ERR_HIP;
 }
 
@@ -3438,9 +3494,21 @@ int v2p_set_launch_opts(v2p_ctx* c, const v2p_launch_opts* opts)
 {
     if (!c) return V2P_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (opts && opts->reserved != 0u) return c->fail(V2P_ERR_INVALID_ARG, "v2p_launch_opts.reserved must be 0");
     if (opts) c->launch_opts = *opts; else c->launch_opts = v2p_launch_opts{1u, 0u, 0ull, 0u, -1, 0u, 0u};
     return V2P_OK;
 }
+
+#ifdef V2P_BENCH_VARIANTS
+// libv2p_bench.so only (csrc/bench/v2p_bench.h): the A/B switches 16 .. 29 of the builders and launchers
+int v2p_bench_set_variant(v2p_ctx* c, uint32_t variant)
+{
+    if (!c) return V2P_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->variant = variant;
+    return V2P_OK;
+}
+#endif
 
 #ifdef V2P_BENCH_VARIANTS
 // libv2p_bench.so only (csrc/bench/v2p_bench.h): the launcher with the packed flag word -- kernel variants, timing-only ablations,

@@ -66,8 +66,11 @@ def _p(a: Optional[np.ndarray]):
 class Context:
     """One ``v2p_ctx`` (one HIP stream on one GPU).  Not thread-safe by design: one per worker."""
 
-    def __init__(self, device: int = 0, debug_gpu: Optional[bool] = None, temporal_stores: bool = False, result_order: bool = False):
-        self._lib = N.hip_lib()
+    def __init__(self, device: int = 0, debug_gpu: Optional[bool] = None, temporal_stores: bool = False, result_order: bool = False, development: bool = False):
+        # development: libv2p_bench.so -- the same engine compiled with V2P_BENCH_VARIANTS (the A/B switches of the builders and launchers,
+        # the grid builders of rounds 2-3, PATCH images: csrc/bench/v2p_bench.h).  Tools and the tests of those paths; never the product.
+        self._lib = N.bench_lib() if development else N.hip_lib()
+        self.development = development
         if debug_gpu is None:  # README.md:156-157: DEBUG_GPU is an environment flag
             debug_gpu = "DEBUG_GPU" in os.environ
         flags = (N.V2P_FLAG_DEBUG_GPU if debug_gpu else 0) | (N.V2P_FLAG_TEMPORAL if temporal_stores else 0) | (4 if result_order else 0)   # 4: V2P_FLAG_RESULT_ORDER (chunk tables are launched as given)
@@ -105,10 +108,14 @@ class Context:
 
     def set_launch_opts(self, phase_bytes: int = 0, phase_min_chunks: int = 0, store_sc1: int = -1, variant: int = 0):
         """Phase size / phase threshold / store policy of every batch this context executes from now on (A/B runs, tests); no arguments:
-        the library's defaults (v2p_set_launch_opts).  variant 16 / 17 / 18: one launch for all phases / the read-ahead as kernels of
-        its own / no read-ahead."""
-        o = N.LaunchOpts(1, 0, phase_bytes, phase_min_chunks, store_sc1, 0, variant)
+        the library's defaults (v2p_set_launch_opts).  variant (development contexts only: v2p_bench_set_variant, csrc/bench/v2p_bench.h):
+        16 / 17 / 18 one launch for all phases / the read-ahead as kernels of its own / no read-ahead, 20 .. 29 the builders' switches."""
+        o = N.LaunchOpts(1, 0, phase_bytes, phase_min_chunks, store_sc1, 0, 0)
         self._check(self._lib.v2p_set_launch_opts(self._h, ctypes.byref(o)))
+        if variant or self.development:
+            if not self.development:
+                raise ValueError("launch variants (A/B switches) exist in the development library only: Context(development=True)")
+            self._check(self._lib.v2p_bench_set_variant(self._h, variant))
 
     def upload_proteome(self, aa: np.ndarray):
         aa = np.ascontiguousarray(aa, dtype=np.uint8)

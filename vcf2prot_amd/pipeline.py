@@ -94,7 +94,7 @@ def vcf_to_fasta(ctx, vcf: bytes, reference_fasta: str, flags: int = step4a.DEFA
         except N.V2PError as e:
             if e.code != -9:
                 raise
-            # a slice even the dense rows image refuses (a 1 KiB row with more than 1 024 descriptors): the grid builders of round 3
+            # a slice even the dense rows image refuses (a 1 KiB row with more than 1 024 descriptors): the host builder takes any stream
             pipe.release(t)
             fb = ctx.batch()
             try:

@@ -190,29 +190,54 @@ class RowsError(RuntimeError):
 
 
 def build_plan(bytes_per_task: float) -> list:
-    """(kernel, window_bytes) pairs to try in order for v2p_batch_build_on_device, by result bytes per task -- the routing the host
-    packer would choose.  Round 4: ROWS images (one pass over the stream, chunks cut afterwards on 1 KiB rows; no window to choose):
-    a wave image (kernel 6) from 24 result bytes per task, a dense one (7) below -- and whenever a 1 KiB row of the result holds
-    more descriptors than a wave has lanes.  The grid builders of round 3 stay behind them as the last resort."""
+    """(kernel, window_bytes) pairs to try in order for v2p_batch_build_on_device, by result bytes per task -- the routing the library's one
+    call applies.  ROWS images (one pass over the stream, chunks cut afterwards on 1 KiB rows; no window to choose): a wave image (kernel 6)
+    from 24 result bytes per task, a dense one (7) below -- and whenever a 1 KiB row of the result holds more descriptors than a wave has
+    lanes.  A stream even the dense rows image refuses (a row with more than 1 024 descriptors) goes to the HOST builder (host_build below).
+    (Until round 5 the grid builders of rounds 2-3 stood behind them; they live in the development library now.)"""
     bpt = float(bytes_per_task)
     if bpt < _wave_bytes_per_task():
-        return [(7, 0), (3, 12288), (3, 8192), (3, 4096), (2, 4096)]
-    return [(6, 0), (7, 0), (2, 32768), (2, 16384), (2, 4096)]
+        return [(7, 0)]
+    return [(6, 0), (7, 0)]
 
 
 def build_on_device_auto(batch, stream, result_bytes: Optional[int] = None) -> dict:
-    """v2p_batch_build_on_device with build_plan(): a window that holds more descriptors than its kernel takes
-    (V2P_ERR_UNSUPPORTED) is retried smaller, then with the next kernel."""
+    """v2p_batch_build_on_device with build_plan(): an image kind that refuses the stream (V2P_ERR_UNSUPPORTED) is followed by the next;
+    the last resort is the host builder, which takes any stream."""
     from ._native import V2PError
     n_tasks = max(int(stream.struct.n_tasks), 1)
     rb = result_bytes if result_bytes is not None else getattr(stream, "result_bytes", 0)
-    last = None
     for kernel, window in build_plan(rb / n_tasks):
         try:
             ms = batch.build_on_device(stream, window, kernel)
             return {"kernel": kernel, "window": window, "build_ms": ms}
         except V2PError as e:
-            if e.code != -9:                 # V2P_ERR_UNSUPPORTED: too many descriptors in some window -- anything else is final
+            if e.code != -9:                 # V2P_ERR_UNSUPPORTED: too many descriptors in some row -- anything else is final
                 raise
-            last = e
-    raise last
+    host_build(batch, stream)
+    return {"kernel": -1, "window": 0, "build_ms": 0.0}
+
+
+def host_build(batch, stream):
+    """The last resort for a stream the device builders refuse: its transcripts through the HOST builder (v2p_batch_begin_haplotype /
+    _add_transcript / _end_haplotype + v2p_batch_finalize: step 5 on the host, haplotype_instruction.rs:94-133) -- any stream, at host speed."""
+    s = stream.struct
+    n_h, n_tx, n_tk, n_alt = int(s.n_haps), int(s.n_tx), int(s.n_tasks), int(s.n_alt)
+
+    def arr(p, n, dt):
+        return np.ctypeslib.as_array(p, shape=(max(n, 1),))[:n].astype(dt, copy=False) if n else np.zeros(0, dt)
+    hb, tb, ab = arr(s.hap_tx_begin, n_h + 1, np.uint64), arr(s.tx_task_begin, n_tx + 1, np.uint64), arr(s.tx_alt_begin, n_tx + 1, np.uint64)
+    off, rl, res = arr(s.tx_proteome_off, n_tx, np.uint64), arr(s.tx_ref_len, n_tx, np.uint32), arr(s.tx_res_len, n_tx, np.uint32)
+    code, sp, ln, sr = arr(s.code, n_tk, np.uint8), arr(s.start_pos, n_tk, np.uint32), arr(s.length, n_tk, np.uint32), arr(s.start_pos_res, n_tk, np.uint32)
+    alt = arr(s.alt, n_alt, np.uint8)
+    fasta = bool(s.tx_header_off) and bool(s.tx_header_len)
+    ho = arr(s.tx_header_off, n_tx, np.uint64) if fasta else None
+    hl = arr(s.tx_header_len, n_tx, np.uint32) if fasta else None
+    for h in range(n_h):
+        batch.begin_haplotype()
+        for t in range(int(hb[h]), int(hb[h + 1])):
+            a, b = int(tb[t]), int(tb[t + 1])
+            batch.add_transcript(code[a:b], sp[a:b].astype(np.uint64), ln[a:b].astype(np.uint64), sr[a:b].astype(np.uint64), int(off[t]), int(rl[t]),
+                                 alt[int(ab[t]):int(ab[t + 1])], int(res[t]), int(ho[t]) if fasta else 0, int(hl[t]) if fasta else 0)
+        batch.end_haplotype()
+    batch.finalize()
