@@ -60,7 +60,7 @@ def test_sliced_build_and_execute_equals_the_one_piece_builder_and_the_oracle(bu
     info = b.oneshot_info()
     assert info["kernel"] in (6, 7, 9) and info["total_ms"] > 0
     tiles = b.image_form()["tiles"]
-    assert tiles == (info["kernel"] == 9) == (img1 is None) and (not tiles or (kernel == 0 and preset == "C5"))
+    assert tiles == (info["kernel"] == 9) == (img1 is None) and (not tiles or kernel == 0)
     if slices > 1 and not tiles and dev:
         assert 1 <= info["n_slices"] <= slices
     _, _, hb = b.download_image() if not tiles else (None, None, np.array([b.hap_range(i)[0] for i in range(n)] + [int(sizes.sum())], dtype=np.uint64))
@@ -348,7 +348,12 @@ def test_degenerate_streams_in_one_call(built, one, kernel):
     for s, want in cases:
         rs = gpu_ctx.upload_stream(s)
         b = gpu_ctx.batch()
-        b.build_and_execute(rs, kernel, 0)
+        try:
+            b.build_and_execute(rs, kernel, 0)
+        except Exception as e:                              # (a tile image asked for by number refuses a stream without transcripts; the rule builds a rows image)
+            assert kernel == 9 and getattr(e, "code", 0) == -9 and s.struct.n_tx == 0, e
+            b.reset()
+            b.build_and_execute(rs, 0, 0)
         b.sync()
         assert b.counts()["n_haps"] == len(want)
         for h, w in enumerate(want):
