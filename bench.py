@@ -420,7 +420,10 @@ def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verif
         time.sleep(0.5)
         b.build_and_execute(rs, 0, 0); b.sync()
         i1 = b.oneshot_info()
-        for _ in range(4):
+        # (clocks up: at least four executes and at least ~40 ms of them -- four executes of an eighth of the cohort are 4 ms, which leaves the
+        # shader clock where the idle host left it: profiles/r05_first_execute.txt)
+        n_busy = max(4, min(400, int(40.0 / max(i1["total_ms"] - i1["build_ms"] - i1["tables_ms"], 0.05))))
+        for _ in range(n_busy):
             b.execute()
         b.sync()
         b.reset()
@@ -437,7 +440,7 @@ def cohort_leg(workload, cohort_samples, h0, h1, steps, warmup, n_threads, verif
                             "the read-ahead of every phase stages its descriptors in launch order for the stitch kernel (a thin or dense image: compaction beside the row cutter); row cutter, "
                             "XCD order, then every phase of the stitch kernel; the timed steps behind it re-execute the same batch (made dense at its first re-execute); total_ms = HIP events "
                             "from before the first build kernel to behind the last stitch kernel, buffers recycled, 0.5 s of host sleep in front (clocks down); "
-                            "*_gpu_busy_before: the same call right behind four executes (clocks up)"})
+                            "*_gpu_busy_before: the same call right behind >= 4 executes and >= 40 ms of them (clocks up)"})
         tiles = b.image_form().get("tiles", False)
         if tiles:
             # a TILE image (deep Task vectors, round 6): 8-byte pieces in the tiles' slots; a tile's record is its count (4 B) and its res_counter (8 B)
