@@ -143,3 +143,41 @@ def test_submissions_from_several_threads(built, gpu_ctx, coracle):
         t.join()
     pipe.close()
     assert not errors, errors
+
+
+def test_slots_tables_and_busy(built, gpu_ctx):
+    """Every slot in use: V2P_BUSY, nothing staged (Python: -1).  A slice with a broken offset table: refused at submit with the offending index
+    (as v2p_stream_upload refuses it), its slot free again.  Results released out of order: the next submission takes the free slot."""
+    from stream_util import Stream
+    from vcf2prot_amd.engine import Pipeline
+    from vcf2prot_amd._native import V2PError
+    rng = np.random.default_rng(17)
+    proteome, stream, want = random_stream(rng, n_haps=40, n_ref_tx=10, shape="mix", window=4096)
+    gpu_ctx.upload_proteome(proteome)
+    pipe = Pipeline(gpu_ctx, 2)
+    try:
+        t0 = pipe.submit_stream(stream, 0, False)
+        t1 = pipe.submit_stream(stream, 0, False)
+        assert {t0, t1} == {0, 1}
+        assert pipe.submit_stream(stream, 0, False) == -1              # V2P_BUSY
+        k = stream.keep
+        arrays = [x.copy() for x in k[:6]] + [x[:-64].copy() for x in k[6:11]]
+        arrays[4][3] = arrays[4][2] - 1 if arrays[4][2] else 10 ** 9    # tx_task_begin not ascending at transcript 2
+        bad = Stream(*arrays)
+        out1 = pipe.wait(t1)                                            # out of order: the second first
+        hob = pipe.result_info(t1)["hap_out_begin"]
+        assert np.array_equal(out1[int(hob[5]):int(hob[6])], want[5])
+        pipe.release(t1)
+        with pytest.raises(V2PError) as e:
+            pipe.submit_stream(bad, 0, False)
+        assert e.value.code == -1 and e.value.index == 2, (e.value.code, e.value.index)
+        t2 = pipe.submit_stream(stream, 0, True)                        # the refused submission left its slot free
+        assert t2 == t1
+        for t in (t0, t2):
+            out = pipe.wait(t)
+            hob = pipe.result_info(t)["hap_out_begin"]
+            for h in (0, 17, 39):
+                assert np.array_equal(out[int(hob[h]):int(hob[h + 1])], want[h])
+            pipe.release(t)
+    finally:
+        pipe.close()

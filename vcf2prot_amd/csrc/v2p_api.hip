@@ -1881,7 +1881,7 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
 }
 
 #ifdef V2P_BENCH_VARIANTS
-// ---- PATCH images (patch_image.h; kernel 8): deep Task vectors as segments + patches, ONE build kernel, one workgroup per 12 KiB window ----
+// ---- PATCH images (patch_image.h; kernel 8): deep Task vectors as segments + patches, ONE build kernel, one workgroup per 8 KiB window ----
 // V2P_ERR_UNSUPPORTED: the format declines the stream (a window with more segments / patches than its slots, sources beyond 16 GB) --
 // the batch is left empty and the caller builds a dense rows image (kernel 7) instead.
 static int build_patch_image(v2p_batch* b, const DevStreamView& v, float* build_ms, bool own_stream_copy, uint64_t known_out_bytes)
@@ -1975,7 +1975,7 @@ static int build_patch_image(v2p_batch* b, const DevStreamView& v, float* build_
     HIP_TRY(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     if (st != STATUS_CLEAN) {
         (void)hipMemsetAsync(b->d_status.ptr(), 0xFF, 8, c->stream);
-        if (uint32_t(st & 0xFFu) == STATUS_PATCH_DECLINED) return c->fail(V2P_ERR_UNSUPPORTED, "a 12 KiB window of the result holds more segments or patches than a patch image's chunk (kernel 7 builds a dense image)", int64_t(st >> 8));
+        if (uint32_t(st & 0xFFu) == STATUS_PATCH_DECLINED) return c->fail(V2P_ERR_UNSUPPORTED, "a 8 KiB window of the result holds more segments or patches than a patch image's chunk (kernel 7 builds a dense image)", int64_t(st >> 8));
         const int code = reason_to_err(uint32_t(st & 0xFFu));          // what the reference would panic on
         return c->fail(code, std::string("device: ") + err_name(code) + " at descriptor " + std::to_string(st >> 8), int64_t(st >> 8));
     }
