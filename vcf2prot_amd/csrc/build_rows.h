@@ -31,6 +31,7 @@ struct RowsArgs {
     const uint64_t* hap_tx_begin;
     uint64_t n_haps;
     uint64_t proteome_len;
+    uint64_t headers_len = 0;           // the FASTA header table behind the proteome (sources of header / line-feed runs: proteome_len + offset)
     // tiles: K consecutive transcripts each, 1 <= K <= 64
     uint32_t K;
     uint64_t n_tiles;

@@ -15,6 +15,7 @@
 // Integer / index work only (no MFMA); the parse is bound by instruction issue -- vector and scalar alike -- see DESIGN.md 8.2a.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "build_rows.h"
 #include "build_kernels.h"
 #include "stitch_device.hpp"
@@ -175,9 +176,13 @@ struct __attribute__((aligned(16))) WaveLds {
 // runs of result bytes, back to back: [header] ['.' fill of the gap before the task] [the task] ['.' tail] [line feed].
 // PHASE: PH_PAD descriptors to the tile's slots of the padded array and its count to tile_count (a tile that does not fit is
 // reported); PH_COUNT only the count; PH_DIRECT descriptors to their final place (tile_desc_base: the scan of the counts).
-template <int MODE, bool FASTA, int PHASE>
+// SRC32 (round 6): every source offset of the launch -- resident reference incl. the header table, the stream's alt bytes -- is below 2^32
+// (the launcher checks): a Task's source and the fusion rules' comparisons on it are 32-bit arithmetic.  64-bit adds and compares issue
+// at a fraction of the 32-bit rate, and this kernel is bound by instruction issue: eight of them per window were a tenth of its time.
+template <int MODE, bool FASTA, int PHASE, bool SRC32>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_parse_kernel(RowsArgs a)
 {
+    using src_t = typename std::conditional<SRC32, uint32_t, uint64_t>::type;
     constexpr bool TILES = MODE == ROWS_TILES;                       // pieces of a TILE image (dense_pieces.h) instead of descriptors: no row map, no cutter behind this kernel
     constexpr uint32_t CTX = MODE == ROWS_DENSE ? 4u : 2u, ADV = 62u - CTX;
     constexpr int NR = FASTA ? 5 : 3;                                 // runs a lane may emit
@@ -327,10 +332,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
         const uint64_t m_isRef = m_good & __ballot(code == 0u);
         const uint64_t m_imm = m_good & m_code1 & __ballot(ln - 1u < IMM_MAX_BYTES);
         const bool isRef = lane_bit(m_isRef), imm = lane_bit(m_imm);
-        const uint64_t src = L.base[csel][slot & 63u] + sp;
+        const src_t src = (SRC32 ? src_t(reinterpret_cast<const uint32_t*>(&L.base[0][0])[2u * (csel * 64u + (slot & 63u))]) : src_t(L.base[csel][slot & 63u])) + sp;
         uint64_t lit = 0;
         if (alt_in_lds) {                                                                 // short alt payloads travel inside their descriptor
-            const uint32_t rel = imm ? uint32_t(src - alt_lo) : 0u;                       // (< ROWS_ALT_LDS: inside the transcript's alt tape, checked above)
+            const uint32_t rel = imm ? uint32_t(src - src_t(alt_lo)) : 0u;                // (< ROWS_ALT_LDS: inside the transcript's alt tape, checked above)
             const uint32_t d0 = L.alt[rel >> 2], d1 = L.alt[(rel >> 2) + 1u];
             const uint64_t v = ((uint64_t(d1) << 32) | d0) >> (8u * (rel & 3u));
             lit = imm ? v & (~0ull >> (64u - 8u * ln)) : 0ull;
@@ -339,14 +344,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
             lit = reinterpret_cast<const U64*>(a.alt + src)->v & (~0ull >> (64u - 8u * ln));
         }
         const uint64_t m_ps = m_isRef & __ballot(ln <= ROWS_FUSE_LEN);
-        const uint64_t m_cA = m_ps & __ballot(src + ln <= SNV3_MAX_SRC - 1u - ROWS_FUSE_LEN);
+        const uint64_t m_cA = m_ps & __ballot(src + ln <= src_t(SNV3_MAX_SRC - 1u - ROWS_FUSE_LEN));
         const uint64_t m_cB = m_imm & __ballot(ln == 1u);
         const uint64_t m_ln0 = __ballot(ln == 0u);
-        const uint64_t m_c0 = m_ps & ~m_ln0 & __ballot(src >= 1u) & __ballot(src + ln <= SNV3_MAX_SRC);
+        const uint64_t m_c0 = m_ps & ~m_ln0 & __ballot(src >= 1u) & __ballot(src + ln <= src_t(SNV3_MAX_SRC));
         const uint32_t src32 = uint32_t(src);
         const uint32_t src2 = up2(src32), ln2 = up2(ln);
         const uint64_t m_ln20 = __ballot(ln2 == 0u);
-        const uint64_t m_c1 = (m_ln20 & m_c0) | (~m_ln20 & m_ps & (m_ln0 | __ballot(src == uint64_t(src2) + ln2 + 1u)));
+        const uint64_t m_c1 = (m_ln20 & m_c0) | (~m_ln20 & m_ps & (m_ln0 | __ballot(src == src_t(src2) + ln2 + 1u)));
         const uint64_t m_gap = m_good & __ballot(sr > pe);
         const bool gap = lane_bit(m_gap);
         const uint64_t mRst = ~m_good | firstmask | m_gap;
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
                 } else if (!isAbs && ln != 0u) {
                     rl[RS] = ln;
                     if (imm) { wl[RS] = uint32_t(lit); wh[RS] = uint32_t(lit >> 32) | (SPACE_IMM << 30); }
-                    else { wl[RS] = src32; wh[RS] = (uint32_t(src >> 32) & 0xFFu) | ((isRef ? SPACE_PROTEOME : SPACE_PAYLOAD) << 30); }
+                    else { wl[RS] = src32; wh[RS] = (SRC32 ? 0u : uint32_t(uint64_t(src) >> 32) & 0xFFu) | ((isRef ? SPACE_PROTEOME : SPACE_PAYLOAD) << 30); }
                 }
             }
         }
@@ -434,17 +439,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
                         const uint32_t lp = (wh[i] >> 8) & 0xFFFu, lb = wh[i] & 0xFFu;
                         for (uint32_t at = 0; at < L; at += 16u) {
                             const uint32_t len = L - at < 16u ? L - at : 16u;
-                            uint64_t w;
+                            // (the piece as two 32-bit words: low = source : 31 | space bit 0; high = space bit 1 | offset : 14 << 1 | bytes - 1 : 4 << 15 |
+                            // residue position : 4 << 19 | has one << 23 | its byte << 24 -- dense_pieces.h's layout without 64-bit shifts)
+                            uint32_t w_lo, w_hi = (space >> 1) | ((pos + at) << 1) | ((len - 1u) << 15);
                             if (space == SPACE_IMM) {                                    // (<= 5 bytes: one piece; bits 0..30 and 51..63 hold them)
-                                const uint64_t v = uint64_t(wl[i]) | (uint64_t(wh[i] & 0xFFu) << 32);
-                                w = (v & 0x7FFFFFFFull) | (uint64_t(SPACE_IMM) << 31) | (uint64_t(pos) << 33) | (uint64_t(len - 1u) << 47) | ((v >> 31) << 51);
+                                const uint32_t v_hi9 = (wl[i] >> 31) | ((wh[i] & 0xFFu) << 1);       // bits 31 .. 39 of the literal
+                                w_lo = wl[i] | 0x80000000u;
+                                w_hi |= v_hi9 << 19;
                             } else {
                                 const bool has = haslit && lp - at < 16u;                // (unsigned: at <= lp < at + 16)
                                 const uint32_t srcw = space == SPACE_FILL ? 0u : wl[i] + at;
-                                w = uint64_t(srcw & 0x7FFFFFFFu) | (uint64_t(space) << 31) | (uint64_t(pos + at) << 33) | (uint64_t(len - 1u) << 47) |
-                                    (has ? (uint64_t((lp - at) & 15u) << 51) | (1ull << 55) | (uint64_t(lb) << 56) : 0ull);
+                                w_lo = (srcw & 0x7FFFFFFFu) | (space << 31);
+                                w_hi |= has ? (((lp - at) & 15u) << 19) | (1u << 23) | (lb << 24) : 0u;
                             }
-                            if (k < out_cap) out[k] = w;
+                            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                            if (k < out_cap) *reinterpret_cast<u32x2*>(out + k) = u32x2{w_lo, w_hi};
                             ++k;
                         }
                         pos += L;
@@ -748,13 +757,18 @@ hipError_t launch_rows_tile_bytes(const RowsArgs& a, uint64_t* scan_scratch, hip
 
 static_assert(ROWS_PAD == ROWS_PAD_SLOTS && ROWS_PAD == ROWS_TILE_SLOTS, "build_rows.h, sir_pack.hpp");
 
+// every source offset a Task of this launch can name fits 32 bits, with room for the longest run behind it (the header table sits behind the proteome)
+static bool rows_src32(const RowsArgs& a) { return a.proteome_len + a.headers_len + (1ull << 16) < (1ull << 32) && a.n_alt + (1ull << 16) < (1ull << 32); }
+
 template <int MODE, bool FASTA>
 static hipError_t launch_parse_t(const RowsArgs& a, int phase, hipStream_t stream)
 {
     const dim3 grid{uint32_t(a.tile1 - a.tile0)};
-    if (phase == PH_PAD) hipLaunchKernelGGL((rows_parse_kernel<MODE, FASTA, PH_PAD>), grid, dim3(64), 0, stream, a);
-    else if (phase == PH_COUNT) hipLaunchKernelGGL((rows_parse_kernel<MODE, FASTA, PH_COUNT>), grid, dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((rows_parse_kernel<MODE, FASTA, PH_DIRECT>), grid, dim3(64), 0, stream, a);
+    // (the one-pass form -- what every cohort that fits its tiles runs -- has a 32-bit instance; the two-pass form keeps 64-bit sources)
+    if (phase == PH_PAD && rows_src32(a)) hipLaunchKernelGGL((rows_parse_kernel<MODE, FASTA, PH_PAD, true>), grid, dim3(64), 0, stream, a);
+    else if (phase == PH_PAD) hipLaunchKernelGGL((rows_parse_kernel<MODE, FASTA, PH_PAD, false>), grid, dim3(64), 0, stream, a);
+    else if (phase == PH_COUNT) hipLaunchKernelGGL((rows_parse_kernel<MODE, FASTA, PH_COUNT, false>), grid, dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((rows_parse_kernel<MODE, FASTA, PH_DIRECT, false>), grid, dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -773,10 +787,10 @@ hipError_t launch_rows_parse(const RowsArgs& a0, int mode, bool fasta, int phase
     if (a.tile1 - a.tile0 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     if (mode == ROWS_DENSE) return fasta ? launch_parse_t<ROWS_DENSE, true>(a, phase, stream) : launch_parse_t<ROWS_DENSE, false>(a, phase, stream);
     if (mode == ROWS_TILES) {
-        if (phase != PH_PAD || a.tile_slots == 0u || a.tile_slots > 2048u || a.tile_span_max > 16368u) return hipErrorInvalidValue;
+        if (phase != PH_PAD || a.tile_slots == 0u || a.tile_slots > 2048u || a.tile_span_max > 16368u || !rows_src32(a)) return hipErrorInvalidValue;   // (a piece's source field: 31 bits)
         const dim3 grid{uint32_t(a.tile1 - a.tile0)};
-        if (fasta) hipLaunchKernelGGL((rows_parse_kernel<ROWS_TILES, true, PH_PAD>), grid, dim3(64), 0, stream, a);
-        else hipLaunchKernelGGL((rows_parse_kernel<ROWS_TILES, false, PH_PAD>), grid, dim3(64), 0, stream, a);
+        if (fasta) hipLaunchKernelGGL((rows_parse_kernel<ROWS_TILES, true, PH_PAD, true>), grid, dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((rows_parse_kernel<ROWS_TILES, false, PH_PAD, true>), grid, dim3(64), 0, stream, a);
         return hipGetLastError();
     }
     return fasta ? launch_parse_t<ROWS_WAVE, true>(a, phase, stream) : launch_parse_t<ROWS_WAVE, false>(a, phase, stream);

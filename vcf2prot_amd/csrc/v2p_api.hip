@@ -1445,7 +1445,7 @@ static void rows_args_of(const DevStreamView& v, v2p_ctx* c, uint32_t K, uint64_
     a.tx_task_begin = v.tx_task_begin; a.tx_alt_begin = v.tx_alt_begin;
     a.code = v.code; a.start_pos = v.start_pos; a.length = v.length; a.start_pos_res = v.start_pos_res; a.alt = v.alt;
     a.tx_header_off = v.tx_header_off; a.tx_header_len = v.tx_header_len;
-    a.proteome_len = c->proteome_len; a.K = K; a.n_tiles = n_tiles;
+    a.proteome_len = c->proteome_len; a.headers_len = c->headers_len; a.K = K; a.n_tiles = n_tiles;
 }
 
 // Called by v2p_batch_build_on_device / v2p_batch_build_from_stream (kernel 6: wave image, 7: dense) with the stream's tables already
