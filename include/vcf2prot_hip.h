@@ -368,7 +368,7 @@ int v2p_batch_scribble(v2p_batch* b, int byte);
  * v2p_stream_upload (FASTA emit: tx_header_off / tx_header_len set -- the result is file-ready text).  The CALLING thread checks the
  * slice's tables (errors as v2p_stream_upload reports them) and copies its arrays into the slot's pinned staging with a small team of
  * copy threads (v2p_pipeline_reserve: how many), enqueues the H2D on the slot's stream and returns: the slice's arrays may be freed.
- * The pipeline's runner thread takes the slices in submission order through v2p_batch_build_and_execute's one call (kernel: 0, 6 or 7)
+ * The pipeline's runner thread takes the slices in submission order through v2p_batch_build_and_execute's one call (kernel: 0, 6, 7 or 9)
  * on the context's streams and enqueues the arena's D2H into the slot's pinned result buffer on a stream of its own.  Submissions may
  * come from several threads (each stages its own slice; a submission takes the first free slot, and with every slot in use returns
  * V2P_BUSY -- nothing staged: wait for a ticket, release it, submit again).  v2p_pipeline_wait blocks until the result is in host memory -- without holding

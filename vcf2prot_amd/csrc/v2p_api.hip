@@ -3218,7 +3218,7 @@ int v2p_pipeline_submit_stream(v2p_pipeline* p, const v2p_txstream* slice, int k
 {
     if (!p || !slice || !ticket) return V2P_ERR_INVALID_ARG;
     v2p_ctx* c = p->ctx;
-    if (kernel != 0 && kernel != 6 && kernel != 7) { std::lock_guard<std::mutex> lk(c->mu); return c->fail(V2P_ERR_INVALID_ARG, "a stream slice builds rows images (kernel 6, 7) or what the routing rule picks (0)"); }
+    if (kernel != 0 && kernel != 6 && kernel != 7 && kernel != 9) { std::lock_guard<std::mutex> lk(c->mu); return c->fail(V2P_ERR_INVALID_ARG, "a stream slice builds rows images (kernel 6, 7), a tile image (9) or what the routing rule picks (0)"); }
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t t;
     {
