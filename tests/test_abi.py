@@ -91,3 +91,20 @@ def test_product_does_not_reach_into_oracle():
                 if re.search(r"sir_oracle|oracle/|from oracle|import oracle", text):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_product_library_exports_only_what_the_headers_declare(built):
+    """Round 6: libvcf2prot_hip.so is built with -fvisibility=hidden -- its dynamic symbol table holds the C ABI of include/vcf2prot_hip.h and
+    include/v2p_frontend.h (the decode) and nothing else: no C++ internals, none of the development library's entry points (PATCH images,
+    the packed-flag launcher, the A/B switch setter), nothing of the grid builders."""
+    import subprocess
+    from vcf2prot_amd import _native as N
+    out = subprocess.run(["nm", "-D", "--defined-only", N.HIP_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    declared = set(_declared("vcf2prot_hip.h")) | {n for n in _declared("v2p_frontend.h") if n.startswith("v2p_decode_")}
+    assert exported <= declared, sorted(exported - declared)
+    assert declared <= exported, sorted(declared - exported)
+    for dev_only in ("v2p_batch_download_patch_image", "v2p_stitch_launch", "v2p_bench_set_variant"):
+        assert dev_only not in exported
+    text = open(os.path.join(ROOT, "include", "vcf2prot_hip.h")).read()
+    assert "variant" not in text.split("typedef struct {\n    uint32_t nontemporal;")[1].split("} v2p_launch_opts;")[0].replace("`variant`", "")
