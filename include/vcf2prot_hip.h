@@ -443,7 +443,7 @@ typedef struct v2p_routing {
     uint32_t store_sc1;             /* 1: "sc1 nt" row stores (thin images) */
     uint64_t phase_bytes;           /* bytes of image per phase: 28 MB rich, 64 MB thin */
     uint32_t order_blocks;          /* blocks of the arena inside which the chunk table is dealt to the XCDs (1: one order for the whole table) */
-    uint32_t reserved;
+    uint32_t order_windows;         /* inside an XCD's proteome slice the table goes 1: window by window, 0: haplotype after haplotype (thin images of 2 GB and more; round 6) */
 } v2p_routing;
 int v2p_routing_rules(uint64_t n_desc, uint64_t n_chunks, uint64_t result_bytes, uint64_t proteome_len, int wave_image, v2p_routing* out);
 /* Host-side: reorder a chunk table so that workgroup 8*j + x (XCD x) works on proteome slice x and, inside a slice, on one window

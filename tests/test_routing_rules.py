@@ -65,6 +65,11 @@ def test_chunk_order_blocks(built):
     assert routing_rules(int(0.02 * 16 * GB / 8), 1_500_000, 16 * GB, 8 * MB)["order_blocks"] == 1
     assert routing_rules(int(0.02 * 2 * GB / 8), 200_000, 2 * GB, 8 * MB)["order_blocks"] == 1
     assert routing_rules(int(0.02 * 1.5 * GB / 8), 150_000, int(1.5 * GB), 8 * MB)["order_blocks"] == 24
+    # ... and (round 6) that one order goes haplotype after haplotype inside an XCD's slice, not window by window: the same speed wherever the
+    # arena landed (profiles/r06_arena_placement.txt); rich images and small thin ones keep the windows
+    assert routing_rules(int(0.02 * 16 * GB / 8), 1_500_000, 16 * GB, 8 * MB)["order_windows"] == 0
+    assert routing_rules(int(0.02 * 1.5 * GB / 8), 150_000, int(1.5 * GB), 8 * MB)["order_windows"] == 1
+    assert routing_rules(int(0.05 * 36 * GB / 8), 3_700_000, 36 * GB, 8 * MB)["order_windows"] == 1
     # a block holds at least 64 chunks
     assert routing_rules(int(0.05 * GB / 8), 640, 1 * GB, 8 * MB)["order_blocks"] == 10
     assert routing_rules(1000, 8, 1 * GB, 8 * MB)["order_blocks"] == 1

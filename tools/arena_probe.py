@@ -52,6 +52,10 @@ def main():
                 rot = 0
                 if nb < 0:                                  # one order for the whole table, XCD x's sequence rotated by x * rot / 64 of its length
                     rot, nb = -nb, 1
+                if nb == 0:                                 # haplotype-major inside an XCD's proteome slice (the development library's V2P_ORDER_WINDOWS=0), one order
+                    os.environ["V2P_ORDER_WINDOWS"] = "0"; os.environ["V2P_ORDER_MAX_BLOCKS"] = "1"
+                    N.bench_lib().v2p_order_chunks_for_xcds(ch.ctypes.data, n, img.desc.ctypes.data, img.desc.size, c.proteome().size)
+                    del os.environ["V2P_ORDER_WINDOWS"], os.environ["V2P_ORDER_MAX_BLOCKS"]
                 for j in range(nb):
                     c0, c1 = (n * j // nb) & ~7, ((n * (j + 1) // nb) & ~7) if j + 1 < nb else n
                     sub = np.ascontiguousarray(ch[c0:c1])

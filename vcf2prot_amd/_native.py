@@ -115,7 +115,7 @@ class OneShotInfo(ctypes.Structure):
 class Routing(ctypes.Structure):
     """v2p_routing (include/vcf2prot_hip.h)"""
     _fields_ = [("wave_bytes_per_task", ctypes.c_uint32), ("rich", ctypes.c_uint32), ("phased", ctypes.c_uint32), ("store_sc1", ctypes.c_uint32),
-                ("phase_bytes", ctypes.c_uint64), ("order_blocks", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("phase_bytes", ctypes.c_uint64), ("order_blocks", ctypes.c_uint32), ("order_windows", ctypes.c_uint32)]
 
 
 def routing_rules(n_desc: int, n_chunks: int, result_bytes: int, proteome_len: int, wave_image: bool = True) -> dict:

@@ -65,6 +65,7 @@ struct RowsArgs {
     uint32_t  chunk_pad = 96;           // chunk slots per segment in chunks_pad (rows_chunk_pad_for)
     uint8_t*  bucket;
     uint8_t*  sub;
+    uint32_t  hap_major = 0;            // the chunks' window keys are all 0: haplotype-major inside an XCD's slice (sir_pack.hpp: xcd_order_window_major)
     uint64_t* hap_out_begin;
     unsigned long long* status;
 };

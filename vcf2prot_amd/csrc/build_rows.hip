@@ -727,7 +727,7 @@ __device__ __forceinline__ void rows_chunk_key(const RowsArgs& a, const Chunk& c
     const uint64_t bk = per ? key / per : 0;
     const uint8_t bucket = uint8_t(bk < 8 ? bk : 7);
     a.bucket[k] = bucket;
-    a.sub[k] = xcd_sub_window(key, bucket, per);
+    a.sub[k] = a.hap_major ? uint8_t(0) : xcd_sub_window(key, bucket, per);      // (haplotype-major inside a slice: every window key equal, the stable sort keeps the arena's order)
 }
 __global__ __launch_bounds__(256) void rows_keys_kernel(RowsArgs a, uint64_t n_chunks, uint64_t n_desc)
 {

@@ -676,6 +676,14 @@ inline uint32_t xcd_order_blocks(uint64_t span_bytes, uint64_t proteome_len, uin
     if (nb * 64u > n_entries) nb = n_entries / 64u;          // (a block is at least 56 entries: 8 per XCD to deal)
     return uint32_t(nb < 1 ? 1 : nb);
 }
+// Inside an XCD's proteome slice: window by window (every haplotype's chunk of window 0, then of window 1 ...: the workgroups in flight
+// share their reference window) -- except for a THIN image of 2 GB and more (C2: one order for the whole table), which goes HAPLOTYPE
+// after haplotype (round 6).  Window-major, an XCD sweeps the whole arena once per window, every chunk of a sweep a haplotype (8 MB) away
+// from the last; that runs at 2.45 ms on some arenas and 3.1 on others -- where the allocation landed, nothing else
+// (profiles/r06_arena_placement.txt) -- while haplotype-major, whose consecutive chunks are neighbours in the arena, runs at 2.70 on every
+// arena (slow ones were four of five in the run that compared them).  Rich images keep the windows (C3 whole 7.68 against 7.87 ms, C4 whole
+// 6.30 against 7.91): they are dealt inside 64 MB blocks, where a sweep is short anyway and the reference window is what matters.
+inline bool xcd_order_window_major(uint64_t span_bytes, uint64_t n_desc) { return image_is_rich(n_desc, span_bytes) || span_bytes < THIN_ONE_ORDER_FROM; }
 V2P_HOST_DEVICE inline uint64_t xcd_order_block_first(uint64_t n_entries, uint32_t n_blocks, uint32_t k)
 {
     return k >= n_blocks ? n_entries : ((n_entries * k / n_blocks) & ~uint64_t(7));
@@ -689,6 +697,7 @@ inline void order_chunks_for_xcds(Chunk* chunks, uint64_t n_chunks, const uint64
     for (uint64_t c = 1; c < n_chunks && sorted; ++c) sorted = chunk_dst(chunks[c - 1].dst_n) <= chunk_dst(chunks[c].dst_n);
     if (!sorted) std::stable_sort(chunks, chunks + n_chunks, [](const Chunk& a, const Chunk& b) { return chunk_dst(a.dst_n) < chunk_dst(b.dst_n); });
     const uint32_t nb = xcd_order_blocks(chunk_dst(chunks[n_chunks - 1].dst_n), proteome_len, n_chunks, max_blocks, n_desc);
+    window_major = window_major && xcd_order_window_major(chunk_dst(chunks[n_chunks - 1].dst_n), n_desc);
     for (uint32_t k = 0; k < nb; ++k) {
         const uint64_t c0 = xcd_order_block_first(n_chunks, nb, k), c1 = xcd_order_block_first(n_chunks, nb, k + 1);
         order_chunks_for_xcds_range(chunks + c0, c1 - c0, desc, n_desc, proteome_len, n_xcd, window_major);

@@ -1596,6 +1596,7 @@ static int build_rows_image(v2p_batch* b, const DevStreamView& v, int mode, floa
     else HIP_TRY(c, launch_rows_chunk_compact(a, c->stream), "launch(chunk table)");
     const bool reorder = !(c->flags & V2P_FLAG_RESULT_ORDER) && n_chunks >= 16 && c->proteome_len != 0 && n_desc != 0;
     if (reorder) {
+        a.hap_major = xcd_order_window_major(last_dst, n_desc) ? 0u : 1u;
         HIP_TRY(c, launch_rows_keys(a, n_chunks, n_desc, c->stream), "launch(keys)");
         const uint32_t nb = xcd_order_blocks(last_dst, c->proteome_len, n_chunks, XCD_ORDER_MAX_BLOCKS, n_desc);
         HIP_TRY(c, launch_order_blocks(a.chunks_tmp, a.bucket, a.sub, n_chunks, nb, reinterpret_cast<uint32_t*>(scratch.ptr() + s_subhist),
@@ -2473,6 +2474,7 @@ static int build_and_execute_rows(v2p_batch* b, const v2p_stream* st, int mode, 
         if (reorder && nc >= 16 && desc_end != 0) {
             RowsArgs ak = a;
             ak.chunks_tmp = chunks_tmp + chunk0; ak.bucket = bucket + chunk0; ak.sub = sub + chunk0;
+            ak.hap_major = xcd_order_window_major(ns * uint64_t(ROWS_SEG) * ROW_BYTES, nd) ? 0u : 1u;      // (a padded image is rich: window-major, keys made in the table pass)
             if (!pad) OS_TRY(launch_rows_keys(ak, nc, desc_end, B), "launch(keys)");
             const uint32_t nb = xcd_order_blocks(ns * uint64_t(ROWS_SEG) * ROW_BYTES, c->proteome_len, nc, XCD_ORDER_MAX_BLOCKS, nd);
             OS_TRY(launch_order_blocks(ak.chunks_tmp, ak.bucket, ak.sub, nc, nb, reinterpret_cast<uint32_t*>(sc + s_subhist),
@@ -3555,6 +3557,7 @@ int v2p_routing_rules(uint64_t n_desc, uint64_t n_chunks, uint64_t result_bytes,
     out->store_sc1 = rich ? 0u : 1u;
     out->phase_bytes = rich ? PHASE_BYTES_RICH : PHASE_BYTES_DEFAULT;
     out->order_blocks = (n_chunks < 16 || proteome_len == 0) ? 1u : xcd_order_blocks(result_bytes, proteome_len, n_chunks, XCD_ORDER_MAX_BLOCKS, n_desc);
+    out->order_windows = xcd_order_window_major(result_bytes, n_desc) ? 1u : 0u;
     return V2P_OK;
 }
 
