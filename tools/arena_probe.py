@@ -56,11 +56,17 @@ def main():
                     os.environ["V2P_ORDER_WINDOWS"] = "0"; os.environ["V2P_ORDER_MAX_BLOCKS"] = "1"
                     N.bench_lib().v2p_order_chunks_for_xcds(ch.ctypes.data, n, img.desc.ctypes.data, img.desc.size, c.proteome().size)
                     del os.environ["V2P_ORDER_WINDOWS"], os.environ["V2P_ORDER_MAX_BLOCKS"]
+                hap = nb >= 100000                          # 100000 + nb: nb blocks, haplotype-major inside each (development library's order)
+                if hap:
+                    nb -= 100000
+                    os.environ["V2P_ORDER_WINDOWS"] = "0"; os.environ["V2P_ORDER_MAX_BLOCKS"] = "1"
                 for j in range(nb):
                     c0, c1 = (n * j // nb) & ~7, ((n * (j + 1) // nb) & ~7) if j + 1 < nb else n
                     sub = np.ascontiguousarray(ch[c0:c1])
-                    N.hip_lib().v2p_order_chunks_for_xcds(sub.ctypes.data, sub.shape[0], img.desc.ctypes.data, img.desc.size, c.proteome().size)
+                    (N.bench_lib() if hap else N.hip_lib()).v2p_order_chunks_for_xcds(sub.ctypes.data, sub.shape[0], img.desc.ctypes.data, img.desc.size, c.proteome().size)
                     ch[c0:c1] = sub
+                if hap:
+                    del os.environ["V2P_ORDER_WINDOWS"], os.environ["V2P_ORDER_MAX_BLOCKS"]
                 if rot:
                     m = n // 8 * 8
                     seqs = [ch[x:m:8].copy() for x in range(8)]
