@@ -184,3 +184,29 @@ def test_a_large_deep_stream(built, gpu_ctx):
     for h in range(1, 176, 7):
         assert np.array_equal(b.download_hap(h), want(h)), h
     b.close(); rs.close()
+
+
+@pytest.mark.parametrize("seed,shape,fasta,slices", [(2, "snv", False, 3), (7, "mix", True, 5), (9, "mix", False, 32)])
+def test_tile_image_built_and_executed_in_slices(built, dev_ctx, seed, shape, fasta, slices):
+    """Development library (A/B, profiles/r06_tile_slices.txt): slice j's tiles executed on a second stream while slice j + 1 is parsed --
+    the same arena as the product's one parse + one execute; the product library refuses n_slices > 1."""
+    rng = np.random.default_rng(seed)
+    if fasta:
+        proteome, headers, stream, want = random_stream(rng, n_haps=300, n_ref_tx=20, shape=shape, window=4096, fasta=True)
+        dev_ctx.upload_reference(proteome, headers)
+    else:
+        proteome, stream, want = random_stream(rng, n_haps=300, n_ref_tx=20, shape=shape, window=4096)
+        dev_ctx.upload_proteome(proteome)
+    rs = dev_ctx.upload_stream(stream)
+    b = dev_ctx.batch()
+    b.build_and_execute(rs, 9, slices)
+    b.sync()
+    assert b.image_form()["tiles"]
+    for rep in range(2):
+        for h, w in enumerate(want):
+            got = b.download_hap(h)
+            assert got.size == w.size and np.array_equal(got, w), (seed, shape, fasta, slices, rep, h)
+        b.scribble(); b.execute(); b.sync()
+    b.close(); rs.close()
+    if fasta:
+        dev_ctx.upload_proteome(proteome)

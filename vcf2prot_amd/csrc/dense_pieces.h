@@ -63,12 +63,13 @@ struct TileExecArgs {
     uint32_t        tile_slots;
     const uint32_t* tile_count;      // [n_tiles]
     const uint64_t* tile_res_base;   // [n_tiles + 1]
-    uint64_t        n_tiles;
+    uint64_t        n_tiles;         // tiles of this launch: [tile0, tile0 + n_tiles)
     const uint8_t*  src0;            // 32 readable bytes before and after (as for every stitch kernel)
     const uint8_t*  src1;
     uint8_t*        out;
     uint64_t        out_len;
     const unsigned long long* status;    // the build's status word: a build that reported anything is not executed
+    uint64_t        tile0 = 0;       // first tile of the launch (the whole image: 0)
 };
 hipError_t launch_stitch_tiles(const TileExecArgs& a, hipStream_t stream, bool nontemporal);
 

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void stitch_tiles_kernel(TileExecArgs a)
     __shared__ __attribute__((aligned(16))) uint32_t s_img[TILES_STAGE / 4u + 8u];
     __shared__ u32x4 s_low[17];                             // s_low[j]: the low j bytes of a 16-byte block
     const uint32_t tid = threadIdx.x;
-    const uint64_t c = tiles_xcd_contiguous(blockIdx.x, gridDim.x);
+    const uint64_t c = a.tile0 + tiles_xcd_contiguous(blockIdx.x, gridDim.x);
     if (*a.status != ~0ull) return;                         // (the parse refused the stream, or reported what the reference would panic on)
     const uint32_t n = a.tile_count[c];
     const uint64_t dst = a.tile_res_base[c], end = a.tile_res_base[c + 1u];

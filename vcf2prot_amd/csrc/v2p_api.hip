@@ -2045,7 +2045,7 @@ static void stream_attach(v2p_batch* b, const v2p_stream* st)
 }
 
 static int rows_mode_for(const v2p_stream* st, int kernel);
-static int build_tiles(v2p_batch* b, const v2p_stream* st, bool execute, bool* fallback, float* build_ms);
+static int build_tiles(v2p_batch* b, const v2p_stream* st, bool execute, bool* fallback, float* build_ms, uint32_t n_slices = 1);
 
 int v2p_stream_upload(v2p_ctx* c, const v2p_txstream* s, v2p_stream** out)
 {
@@ -2523,7 +2523,7 @@ static hipError_t tiles_execute(v2p_batch* b, hipStream_t stream)
 // batch's counts), ONE look of the host at the status word, the executor.  *fallback: a stream the form does not take after all (a tile
 // whose result or whose pieces do not fit: the sample that sized the tiles missed it; no room for the piece slots) -- nothing is
 // lost, the caller builds a dense rows image.  c->mu held.
-static int build_tiles(v2p_batch* b, const v2p_stream* st, bool execute, bool* fallback, float* build_ms)
+static int build_tiles(v2p_batch* b, const v2p_stream* st, bool execute, bool* fallback, float* build_ms, uint32_t n_slices)
 {
     v2p_ctx* c = b->ctx;
     const DevStreamView& v = st->v;
@@ -2576,6 +2576,37 @@ static int build_tiles(v2p_batch* b, const v2p_stream* st, bool execute, bool* f
         HIP_TRY(c, launch_rows_hap_begin(a, A), "launch(hap_begin)");
     }
     HIP_TRY(c, hipEventRecord(b->ev_os[2], A), "hipEventRecord");
+    bool executed_in_slices = false;
+#ifdef V2P_BENCH_VARIANTS
+    // (A/B, libv2p_bench.so: the tiles in S slices -- a tile is the executor's work item as it leaves the parse, so slice j is executed on a
+    // second stream while slice j + 1 is parsed; the executor reads the status word itself and the host's look comes behind everything.
+    // Measured (profiles/r06_tile_slices.txt): C5 whole 12.1 -> 11.7 / 11.4 / 11.2 ms with 4 / 8 / 16 slices, C5 fifth 2.58 -> 2.51 with 4,
+    // 2.74 with 16; the same with the executor's stream at the highest priority.  The parse fills every wave slot; not the product's form.)
+    if (execute && n_slices > 1 && n_tiles >= n_slices) {
+        const uint32_t S = n_slices < V2P_MAX_SLICES ? n_slices : V2P_MAX_SLICES;
+        if (!c->build_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking), "hipStreamCreate(build)");
+        for (uint32_t k = 0; k < S; ++k) HIP_TRY(c, ensure_event(b->ev_par[k]), "hipEventCreate");
+        HIP_TRY(c, ensure_event(b->ev_aux[0]), "hipEventCreate");
+        hipStream_t B = c->build_stream;
+        uint64_t* const pad0 = a.desc_pad;
+        for (uint32_t j = 0; j < S; ++j) {
+            RowsArgs aj = a;
+            aj.tile0 = n_tiles * j / S; aj.tile1 = n_tiles * (j + 1) / S;
+            aj.desc_pad = pad0 + aj.tile0 * slots;
+            HIP_TRY(c, launch_rows_parse(aj, ROWS_TILES, v.fasta, 0, A), "launch(parse: pieces)");
+            HIP_TRY(c, hipEventRecord(b->ev_par[j], A), "hipEventRecord");
+            HIP_TRY(c, hipStreamWaitEvent(B, b->ev_par[j], 0), "hipStreamWaitEvent");
+            TileExecArgs x{reinterpret_cast<const uint64_t*>(b->d_desc.ptr()), slots, a.tile_count, a.tile_res_base, aj.tile1 - aj.tile0,
+                           c->proteome.ptr(), v.alt, b->d_out.ptr(), out_bytes, reinterpret_cast<const unsigned long long*>(b->d_status.ptr()), aj.tile0};
+            HIP_TRY(c, launch_stitch_tiles(x, B, !(c->flags & V2P_FLAG_TEMPORAL)), "launch(stitch: tile image)");
+        }
+        HIP_TRY(c, hipEventRecord(b->ev_aux[0], B), "hipEventRecord");
+        HIP_TRY(c, hipStreamWaitEvent(A, b->ev_aux[0], 0), "hipStreamWaitEvent");
+        executed_in_slices = true;
+    } else
+#else
+    (void)n_slices;
+#endif
     HIP_TRY(c, launch_rows_parse(a, ROWS_TILES, v.fasta, 0, A), "launch(parse: pieces)");
     HIP_TRY(c, launch_scan_u32(a.tile_count, n_tiles, a.tile_desc_base, scan_scratch + rows_scan_scratch_entries(n_tiles), A), "launch(scan)");
     HIP_TRY(c, launch_rows_summary(a.tile_desc_base + n_tiles, a.tile_res_base + n_tiles, a.status, a.totals, A), "launch(summary)");
@@ -2600,7 +2631,7 @@ static int build_tiles(v2p_batch* b, const v2p_stream* st, bool execute, bool* f
     b->img.hap_out_begin = st->hap_out_begin;
     b->uses_proteome = true; b->finalized = true;
     b->n_slices = 1; b->slice_chunk0[0] = 0; b->slice_chunk0[1] = n_tiles; b->os_ahead = false;
-    if (execute) HIP_TRY(c, tiles_execute(b, A), "launch(stitch: tile image)");
+    if (execute && !executed_in_slices) HIP_TRY(c, tiles_execute(b, A), "launch(stitch: tile image)");
     HIP_TRY(c, hipEventRecord(b->ev_os[1], A), "hipEventRecord");
     if (build_ms) { *build_ms = 0.f; (void)hipEventElapsedTime(build_ms, b->ev_os[0], b->ev_os[3]); }
     return V2P_OK;
@@ -2639,7 +2670,7 @@ static int build_and_execute_locked(v2p_batch* b, const v2p_stream* st, int kern
     bool fallback = false;
     if (mode == ROWS_TILES) {
         // deep Task vectors: pieces straight from the parse, the tiles executed as they stand (dense_pieces.h)
-        const int trc = build_tiles(b, st, true, &fallback, nullptr);
+        const int trc = build_tiles(b, st, true, &fallback, nullptr, n_slices);
         if (trc != V2P_OK) return trc;
         if (!fallback) {
             stream_attach(b, st);
