@@ -265,8 +265,8 @@ int v2p_batch_build_on_device(v2p_batch* b, const v2p_txstream* s, uint32_t wind
  * (The image can also be built slice by slice while the slice before it is stitched -- n_slices -- which was measured slower.) */
 typedef struct v2p_stream v2p_stream;
 /* the stream's arrays to the device (the host copy may be freed on return); V2P_ERR_INVALID_ARG / _SRC_OOB with the offending index
- * as v2p_batch_build_on_device reports them.  A stream of 64 MB or more goes up through a ring of pinned slots filled by a small team of
- * threads (the link's rate instead of a pageable copy's), its tables checked on a thread beside the copy: C3 whole, 9.6 GB: 0.23 s */
+ * as v2p_batch_build_on_device reports them.  The tables are checked on a thread beside the copy (C3 whole, 9.6 GB and 20 M transcripts:
+ * 0.17 - 0.24 s, the link's rate) */
 int  v2p_stream_upload(v2p_ctx* ctx, const v2p_txstream* s, v2p_stream** out);
 /* Waits for the context's own streams (not for the device: other contexts keep running).  A batch built from the stream registers with
  * it, and its payload descriptors read the stream's alt bytes: destroying the stream ORPHANS those batches -- v2p_batch_execute on an

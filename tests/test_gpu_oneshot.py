@@ -412,3 +412,38 @@ def test_padded_wave_image_is_the_dense_one(built, one, preset, h0, n, slices):
     assert np.array_equal(dig0, dig1) and cn0 == cn1
     assert np.array_equal(desc0, desc1) and np.array_equal(ch0, ch1) and np.array_equal(hb0, hb1)
     rs.close()
+
+
+def test_large_uploads_and_whole_arena_downloads(built, gpu_ctx, coracle):
+    """A stream of > 100 MB uploaded with its tables checked beside the copy, its arena (~ 470 MB) downloaded in one call and in ragged ranges
+    (sizes and offsets off every alignment): the bytes in host memory are the oracle's."""
+    import time
+    from vcf2prot_amd.cohort import Cohort
+    c = Cohort.preset("C3")
+    n = 260                                                              # ~ 125 MB of Task vectors, ~ 470 MB of result
+    gpu_ctx.upload_proteome(c.proteome())
+    stream = c.txstream(0, n, n_threads=8)
+    rs = gpu_ctx.upload_stream(stream)
+    stream.close()
+    b = gpu_ctx.batch()
+    b.build_and_execute(rs, 0, 0); b.sync()
+    total = b.counts()["out_bytes"]
+    assert total > 300 << 20
+    t0 = time.perf_counter()
+    whole = b.download(0, total)
+    dt = time.perf_counter() - t0
+    for h in (0, 1, 77, n - 1):
+        lo, ln = b.hap_range(h)
+        hap = c.haplotype(h)
+        t = coracle.pack_tasks(hap.code, hap.start_pos, hap.length, hap.start_pos_res)
+        want = coracle.gir_execute_u8(t, c.ref_tape_u32(h).astype(np.uint8), hap.alt, np.full(hap.n_res, ord("."), dtype=np.uint8))
+        assert np.array_equal(whole[lo:lo + ln], want), h
+    dig = b.digests()
+    for h in range(0, n, 13):
+        lo, ln = b.hap_range(h)
+        assert coracle.digest_u8(np.ascontiguousarray(whole[lo:lo + ln])) == int(dig[h]), h
+    for begin, length in ((1, (64 << 20) + 3), (12345, total - 12345 - 7), (total - (64 << 20) - 1, (64 << 20) + 1)):
+        part = b.download(begin, length)
+        assert np.array_equal(part, whole[begin:begin + length]), (begin, length)
+    print(f"download of {total / 1e6:.0f} MB: {total / dt / 1e9:.1f} GB/s")
+    b.close(); rs.close()

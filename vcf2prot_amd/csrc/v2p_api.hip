@@ -145,8 +145,6 @@ struct v2p_ctx {
     // GIR-mode scratch (grow-only)
     DevBuf d_ref, d_alt, d_res, d_desc, d_chunks, d_soa, d_status;
     PinnedBuf h_stage, h_in;                         // pinned staging: results coming back / narrowed tapes going out
-    PinnedBuf h_up;                                  // ... and the ring v2p_stream_upload stages a large stream through (staged_h2d)
-    hipEvent_t ev_up[16] = {};
     ImageBuilder gir_img;                            // reused across v2p_execute_gir calls (its vectors keep their capacity)
     struct GirQueue* queue = nullptr;                // v2p_execute_gir_shared: batches of concurrent callers (created at the first call)
     v2p_launch_opts launch_opts{1u, 0u, 0ull, 0u, -1, 0u, 0u};   // v2p_set_launch_opts: phase size / threshold / store policy of this context's batches (A/B runs, tests)
@@ -331,8 +329,7 @@ void v2p_destroy(v2p_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     c->proteome.release(); c->d_ref.release(); c->d_alt.release(); c->d_res.release();
     c->d_desc.release(); c->d_chunks.release(); c->d_soa.release(); c->d_status.release();
-    c->h_stage.release(); c->h_in.release(); c->h_up.release();
-    for (hipEvent_t e : c->ev_up) if (e) (void)hipEventDestroy(e);
+    c->h_stage.release(); c->h_in.release();
     queue_destroy(c);
     if (c->exec_aux) { (void)hipStreamSynchronize(c->exec_aux); (void)hipStreamDestroy(c->exec_aux); }
     for (hipEvent_t e : c->ev_exec) if (e) (void)hipEventDestroy(e);
@@ -1425,54 +1422,6 @@ static void stream_view(const v2p_txstream* s, const StreamLayout& L, bool fasta
 }
 
 // The stream's arrays into one device allocation (`buf`, carved) + its alt bytes (`altbuf`), on `stream`; v receives the device pointers.
-// A large stream's way up: hipMemcpy from pageable memory moves 20-25 GB/s (the runtime stages it through its own pinned buffers, one
-// thread); here a team of threads copies 8 MiB pieces into a ring of pinned slots and the calling thread sends every slot up as soon as it
-// is full -- the link's rate (C3 whole, 9.6 GB: 0.43 -> 0.2 s).  Piece j waits for the transfer of piece j - UP_SLOTS (its slot) only.
-struct UpJob { uint8_t* dst; const uint8_t* src; uint64_t bytes; };
-constexpr uint32_t UP_SLOTS = 16;
-constexpr uint64_t UP_PIECE = 8ull << 20, UP_STAGED_FROM = 64ull << 20;
-static int staged_h2d(v2p_ctx* c, const std::vector<UpJob>& jobs, hipStream_t stream)
-{
-    const size_t n = jobs.size();
-    if (n == 0) return V2P_OK;
-    HIP_TRY(c, c->h_up.ensure(size_t(UP_SLOTS) * UP_PIECE), "hipHostMalloc(upload ring)");
-    for (hipEvent_t& e : c->ev_up) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
-    std::atomic<size_t> next{0}, freed{UP_SLOTS};               // pieces [0, freed) may write their slot
-    std::atomic<bool> abort{false};
-    std::unique_ptr<std::atomic<uint8_t>[]> copied(new std::atomic<uint8_t>[n]);
-    for (size_t j = 0; j < n; ++j) copied[j].store(0, std::memory_order_relaxed);
-    uint8_t* const ring = c->h_up.p;
-    auto work = [&] {
-        for (size_t j = next++; j < n; j = next++) {
-            while (j >= freed.load(std::memory_order_acquire)) { if (abort.load(std::memory_order_relaxed)) return; std::this_thread::yield(); }
-            memcpy(ring + (j % UP_SLOTS) * UP_PIECE, jobs[j].src, jobs[j].bytes);
-            copied[j].store(1, std::memory_order_release);
-        }
-    };
-    std::vector<std::thread> team;
-    uint32_t T = std::thread::hardware_concurrency() / 8u;
-    T = T < 4u ? 4u : (T > 8u ? 8u : T);                                           // (4, 8 or 16 threads: the same 45-50 GB/s; 32: slower)
-    if (T > n) T = uint32_t(n);
-    for (uint32_t t = 0; t < T; ++t) team.emplace_back(work);
-    hipError_t err = hipSuccess;
-    size_t issued = 0, retired = 0;
-    while (retired < n && err == hipSuccess) {
-        if (issued < n && issued - retired < UP_SLOTS && copied[issued].load(std::memory_order_acquire)) {
-            err = hipMemcpyAsync(jobs[issued].dst, ring + (issued % UP_SLOTS) * UP_PIECE, jobs[issued].bytes, hipMemcpyHostToDevice, stream);
-            if (err == hipSuccess) err = hipEventRecord(c->ev_up[issued % UP_SLOTS], stream);
-            ++issued;
-        } else if (retired < issued) {                          // nothing to send yet (or every slot in flight): the oldest transfer frees its slot
-            err = hipEventSynchronize(c->ev_up[retired % UP_SLOTS]);
-            ++retired;
-            freed.store(retired + UP_SLOTS, std::memory_order_release);
-        } else std::this_thread::yield();
-    }
-    if (err != hipSuccess) abort.store(true);
-    for (std::thread& th : team) th.join();
-    if (err != hipSuccess) { (void)hipStreamSynchronize(stream); return c->hip_fail(err, "H2D(stream, staged)"); }
-    return V2P_OK;
-}
-
 static int upload_stream(v2p_ctx* c, const v2p_txstream* s, bool fasta, DevBuf& buf, DevBuf& altbuf, DevStreamView& v, hipStream_t stream, bool with_stats = true)
 {
     const StreamLayout L = stream_layout(s->n_haps, s->n_tx, s->n_tasks, fasta);
@@ -1481,22 +1430,10 @@ static int upload_stream(v2p_ctx* c, const v2p_txstream* s, bool fasta, DevBuf& 
     HIP_TRY(c, altbuf.ensure(s->n_alt), "hipMalloc(alt)");
     StreamPiece pc[12];
     const uint32_t np = stream_pieces(s, L, fasta, pc);
-    uint64_t total = s->n_alt;
-    for (uint32_t k = 0; k < np; ++k) total += pc[k].bytes;
-    if (total >= UP_STAGED_FROM) {
-        std::vector<UpJob> jobs;
-        jobs.reserve(size_t(total / UP_PIECE) + np + 2);
-        auto add = [&](uint8_t* dst, const void* src, uint64_t bytes) {
-            for (uint64_t o = 0; o < bytes; o += UP_PIECE) jobs.push_back(UpJob{dst + o, static_cast<const uint8_t*>(src) + o, bytes - o < UP_PIECE ? bytes - o : UP_PIECE});
-        };
-        for (uint32_t k = 0; k < np; ++k) add(d + pc[k].off, pc[k].src, pc[k].bytes);
-        if (s->n_alt) add(altbuf.ptr(), s->alt, s->n_alt);
-        const int rc = staged_h2d(c, jobs, stream);
-        if (rc != V2P_OK) return rc;
-    } else {
-        for (uint32_t k = 0; k < np; ++k) HIP_TRY(c, hipMemcpyAsync(d + pc[k].off, pc[k].src, pc[k].bytes, hipMemcpyHostToDevice, stream), pc[k].what);
-        if (s->n_alt) HIP_TRY(c, hipMemcpyAsync(altbuf.ptr(), s->alt, s->n_alt, hipMemcpyHostToDevice, stream), "H2D(alt)");
-    }
+    // (pageable memory as it comes: the runtime pins the caller's pages piece by piece and the copy runs at the link's rate -- 57 GB/s on
+    // C3 whole's 9.6 GB.  A ring of pinned slots filled by a thread team was measured: 45 GB/s on a first upload, 28 on the next ones.)
+    for (uint32_t k = 0; k < np; ++k) HIP_TRY(c, hipMemcpyAsync(d + pc[k].off, pc[k].src, pc[k].bytes, hipMemcpyHostToDevice, stream), pc[k].what);
+    if (s->n_alt) HIP_TRY(c, hipMemcpyAsync(altbuf.ptr(), s->alt, s->n_alt, hipMemcpyHostToDevice, stream), "H2D(alt)");
     stream_view(s, L, fasta, d, altbuf.ptr(), v);
     if (with_stats) stream_item_stats(s, v);            // (walks the Task arrays through the tables: only behind their check)
     return V2P_OK;
@@ -2121,7 +2058,7 @@ int v2p_stream_upload(v2p_ctx* c, const v2p_txstream* s, v2p_stream** out)
     if (!st) return c->fail(V2P_ERR_HIP, "out of host memory");
     st->ctx = c;
     bool fasta = false;
-    // The tables are checked BESIDE the upload (a thread of its own: C3 whole's 20 M transcripts take it 95 ms, the copy 210): what the
+    // The tables are checked BESIDE the upload (a thread of its own: C3 whole's 20 M transcripts take it 95 ms, the copy 170): what the
     // kernels index device memory through is refused before anything is built from it, and a stream that fails has been copied for
     // nothing.  Null arrays are caught first -- the copy never reads through one -- and the Task arrays are only sampled behind the check.
     int rc = V2P_OK;
