@@ -2071,9 +2071,14 @@ int v2p_stream_upload(v2p_ctx* c, const v2p_txstream* s, v2p_stream** out)
     if (rc == V2P_OK) {
         CheckErr cerr;
         int crc = V2P_OK;
-        std::thread checker([&] { crc = check_stream_nolock(c, s, &fasta, nullptr, &st->hap_out_begin, cerr); });
-        rc = upload_stream(c, s, s->tx_header_off && s->tx_header_len, st->buf, st->alt, st->v, c->stream, false);
-        checker.join();
+        auto check = [&] {
+            try { crc = check_stream_nolock(c, s, &fasta, nullptr, &st->hap_out_begin, cerr); }
+            catch (...) { crc = cerr(V2P_ERR_HIP, "out of host memory"); }
+        };
+        std::thread checker;
+        try { checker = std::thread(check); } catch (...) { check(); }                  // (no thread to be had: checked first, as before)
+        if (checker.joinable() || crc == V2P_OK) rc = upload_stream(c, s, s->tx_header_off && s->tx_header_len, st->buf, st->alt, st->v, c->stream, false);
+        if (checker.joinable()) checker.join();
         if (crc != V2P_OK) rc = c->fail(crc, cerr.msg, cerr.index);                    // (the check's verdict first: it is what the caller can act on)
         else if (rc == V2P_OK) stream_item_stats(s, st->v);
     }
@@ -3244,7 +3249,7 @@ static void team_copy(uint8_t* dst_base, const StreamPiece* pc, uint32_t np, uin
     std::atomic<size_t> next{0};
     auto work = [&] { for (size_t i = next++; i < jobs.size(); i = next++) memcpy(jobs[i].d, jobs[i].s, jobs[i].n); };
     std::vector<std::thread> team;
-    for (uint32_t t = 1; t < T; ++t) team.emplace_back(work);
+    for (uint32_t t = 1; t < T; ++t) { try { team.emplace_back(work); } catch (...) { break; } }      // (no thread to be had: the others take its share)
     leader_first();                                     // (the calling thread: the table checks, then its share of the copy)
     work();
     for (std::thread& th : team) th.join();
@@ -3356,10 +3361,13 @@ int v2p_pipeline_submit_stream(v2p_pipeline* p, const v2p_txstream* slice, int k
     if (e == hipSuccess) e = hipEventRecord(s.ev_h2d, s.stream);
     if (e != hipSuccess) return hip_unclaim(e, "H2D(stream slice)");
     {
-        std::lock_guard<std::mutex> pl(p->pmu);
+        std::unique_lock<std::mutex> pl(p->pmu);
+        if (!p->runner.joinable()) {
+            try { p->runner = std::thread(pipeline_runner, p); }
+            catch (...) { pl.unlock(); std::lock_guard<std::mutex> lk(c->mu); return unclaim(c->fail(V2P_ERR_HIP, "no thread for the pipeline's runner")); }
+        }
         s.state = SLOT_QUEUED;
         p->jobs.push_back(t);
-        if (!p->runner.joinable()) p->runner = std::thread(pipeline_runner, p);
     }
     p->cv.notify_all();
     *ticket = t;
