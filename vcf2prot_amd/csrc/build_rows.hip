@@ -306,7 +306,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
             code = 0; sp = 0; ln = 0; sr = 0;
             if (active && !isEmpty0) { code = g_code[ti]; sp = g_sp[ti]; ln = g_ln[ti]; sr = g_sr[ti]; }
         }
-        const bool isEmpty = lane_bit(m_empty);
         const uint64_t m_task = m_active & ~m_empty;
         const uint32_t res_len = L.res_len[slot & 63u], pos0 = L.pos[slot & 63u];
         // ---- update_task / Task::execute checks; result positions ----
@@ -327,7 +326,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
             if (lane_bit(m_bad & m_in_emit)) rreport(a.status, task_lo + ti, why);
         }
         const uint64_t m_good = m_task & ~m_bad;
-        const bool good = lane_bit(m_good);
         // ---- classes of the fusion state machine ----
         const uint64_t m_isRef = m_good & __ballot(code == 0u);
         const uint64_t m_imm = m_good & m_code1 & __ballot(ln - 1u < IMM_MAX_BYTES);
@@ -353,10 +351,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
         const uint64_t m_ln20 = __ballot(ln2 == 0u);
         const uint64_t m_c1 = (m_ln20 & m_c0) | (~m_ln20 & m_ps & (m_ln0 | __ballot(src == src_t(src2) + ln2 + 1u)));
         const uint64_t m_gap = m_good & __ballot(sr > pe);
-        const bool gap = lane_bit(m_gap);
         const uint64_t mRst = ~m_good | firstmask | m_gap;
         const RowsParse p = rows_parse(m_cA, m_cB, m_ps, m_c0, m_c1, mRst, !first, carry_h);
-        const bool isF = lane_bit(p.F);
         // a closing lane's fused substitution: run, len1, byte, len2
         const uint32_t f_len1 = lane_bit(p.F & p.real) ? ln2 : 0u;
         const uint32_t f_byte = up1(uint32_t(lit), 0u) & 0xFFu;
@@ -370,15 +366,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
             second = rows_pair(m_Lc, !first, carry_second);
         }
         const uint64_t absorbed = (p.F >> 1) | ((p.F & p.real) >> 2) | (MODE == ROWS_DENSE ? (second >> 2) & p.F : 0ull);
-        const bool isAbs = lane_bit(absorbed), isSecond = lane_bit(second);
+        const bool isSecond = lane_bit(second);
         // ---- what the lane emits: NR runs of result bytes, in order, back to back from offset q0 ----
+        // (Round 6, last session: straight-line selects on the lane masks.  Written as nested ifs this block compiled to a dozen exec-mask
+        // regions -- s_and_saveexec / s_cbranch_execz / s_or_b64 exec around two or three vector instructions each: 54 vector and 55 scalar
+        // instructions per window, the largest block of a kernel that is bound by the issue of both.  Every candidate is computed by every
+        // lane now and picked with v_cndmask on a mask that was a scalar value anyway.)
         uint32_t wl[NR], wh[NR], rl[NR];               // descriptor words (the length field of a plain one is filled in below), lengths
 #pragma unroll
         for (int i = 0; i < NR; ++i) { wl[i] = 0u; wh[i] = 0u; rl[i] = 0u; }
-        bool fusedw = false;                           // run RS is a complete fused word
         uint32_t q0 = pos0 + pe;
-        if (active) {
-            if constexpr (FASTA) {
+        if constexpr (FASTA) {
+            if (active) {
                 const uint32_t xhl = L.hl[slot & 63u];
                 if (xhl) {
                     const uint64_t hs = L.hsrc[slot & 63u];
@@ -386,39 +385,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
                     if (isLast) { const uint64_t lf = hs + xhl - 1u; rl[4] = 1u; wl[4] = uint32_t(lf); wh[4] = uint32_t(lf >> 32) & 0xFFu; }
                 }
             }
-            if (isLast && (good || isEmpty)) { rl[RT] = res_len - e; wh[RT] = SPACE_FILL << 30; }
-            if (good) {
-                if (gap) { rl[RG] = sr - pe; wh[RG] = SPACE_FILL << 30; }
-                if (isF) {
-                    if (!isAbs) {
-                        fusedw = true;
-                        if (MODE == ROWS_DENSE && isSecond) {
-                            rl[RS] = p_len1 + 1u + p_len2 + 1u + ln; q0 -= p_len1 + p_len2 + 2u;
-                            const uint64_t w = SNV5_MARK | (uint64_t(f_byte) << 52) | (uint64_t(p_byte) << 44) | (uint64_t(ln & 31u) << 39) | (uint64_t(p_len2 & 31u) << 34) | (uint64_t(p_len1 & 31u) << 29) | (uint64_t(p_run) & SNV3_MAX_SRC);
-                            wl[RS] = uint32_t(w); wh[RS] = uint32_t(w >> 32);
-                        } else if (TILES) {
-                            // (a piece image: the fused run is ONE contiguous source range -- the first copy, the residue the literal replaces, the
-                            // copy that goes on one residue later -- with the literal's position and byte beside it: source | has:1 << 29 | position:12 << 8 | byte)
-                            rl[RS] = f_len1 + 1u + ln; q0 -= f_len1 + 1u;
-                            wl[RS] = f_run;
-                            wh[RS] = (1u << 29) | (f_len1 << 8) | f_byte;
-                        } else {
-                            rl[RS] = f_len1 + 1u + ln; q0 -= f_len1 + 1u;
-                            wl[RS] = (f_run & 0x1FFFFFFFu) | (f_len1 << 29);
-                            wh[RS] = ((f_len1 & 0xFFFu) >> 3) | ((ln & 0xFFFu) << 9) | (f_byte << 21) | (7u << 29);
-                        }
-                    }
-                } else if (!isAbs && ln != 0u) {
-                    rl[RS] = ln;
-                    if (imm) { wl[RS] = uint32_t(lit); wh[RS] = uint32_t(lit >> 32) | (SPACE_IMM << 30); }
-                    else { wl[RS] = src32; wh[RS] = (SRC32 ? 0u : uint32_t(uint64_t(src) >> 32) & 0xFFu) | ((isRef ? SPACE_PROTEOME : SPACE_PAYLOAD) << 30); }
-                }
-            }
+            if (!in_emit) { rl[0] = 0u; rl[NR - 1] = 0u; }
         }
-        if (!in_emit) {
-#pragma unroll
-            for (int i = 0; i < NR; ++i) rl[i] = 0u;
+        // the '.' tail behind a transcript's last item, the '.' gap in front of a task (both: masks inside the active, emitting lanes)
+        rl[RT] = lane_bit(lastmask & (m_good | m_empty) & m_in_emit) ? res_len - e : 0u;  wh[RT] = SPACE_FILL << 30;
+        wh[RG] = SPACE_FILL << 30;
+        if ((m_gap & m_in_emit) != 0ull) rl[RG] = lane_bit(m_gap & m_in_emit) ? sr - pe : 0u;      // (wave-uniform: most windows have no gap)
+        // run RS: a complete fused word (the closing lane of a fusion that nothing absorbed), or the task's own plain run
+        const uint64_t m_fw = p.F & ~absorbed & m_good;
+        const uint64_t m_pl = m_good & ~p.F & ~absorbed & ~m_ln0;
+        const bool fusedw = lane_bit(m_fw);            // run RS is a complete fused word
+        uint32_t f_rl = f_len1 + 1u + ln, f_back = f_len1 + 1u, f_wl, f_wh;
+        if (TILES) {
+            // (a piece image: the fused run is ONE contiguous source range -- the first copy, the residue the literal replaces, the
+            // copy that goes on one residue later -- with the literal's position and byte beside it: source | has:1 << 29 | position:12 << 8 | byte)
+            f_wl = f_run;
+            f_wh = (1u << 29) | (f_len1 << 8) | f_byte;
+        } else {
+            f_wl = (f_run & 0x1FFFFFFFu) | (f_len1 << 29);
+            f_wh = ((f_len1 & 0xFFFu) >> 3) | ((ln & 0xFFFu) << 9) | (f_byte << 21) | (7u << 29);
         }
+        if (MODE == ROWS_DENSE) {
+            const uint64_t w = SNV5_MARK | (uint64_t(f_byte) << 52) | (uint64_t(p_byte) << 44) | (uint64_t(ln & 31u) << 39) | (uint64_t(p_len2 & 31u) << 34) | (uint64_t(p_len1 & 31u) << 29) | (uint64_t(p_run) & SNV3_MAX_SRC);
+            f_rl = isSecond ? p_len1 + 1u + p_len2 + 1u + ln : f_rl;
+            f_back = isSecond ? p_len1 + p_len2 + 2u : f_back;
+            f_wl = isSecond ? uint32_t(w) : f_wl;
+            f_wh = isSecond ? uint32_t(w >> 32) : f_wh;
+        }
+        rl[RS] = lane_bit(m_fw & m_in_emit) ? f_rl : 0u;
+        wl[RS] = f_wl; wh[RS] = f_wh;
+        if ((m_pl & m_in_emit) != 0ull) {                                                            // (wave-uniform: streams of pure substitutions have no plain run)
+            const uint32_t p_wl = imm ? uint32_t(lit) : src32;
+            const uint32_t p_wh = imm ? uint32_t(lit >> 32) | (SPACE_IMM << 30)
+                                      : (SRC32 ? 0u : uint32_t(uint64_t(src) >> 32) & 0xFFu) | ((isRef ? SPACE_PROTEOME : SPACE_PAYLOAD) << 30);
+            rl[RS] = lane_bit(m_pl & m_in_emit) ? ln : rl[RS];
+            wl[RS] = fusedw ? f_wl : p_wl;
+            wh[RS] = fusedw ? f_wh : p_wh;
+        }
+        q0 -= fusedw ? f_back : 0u;
         if constexpr (TILES) {
             // ---- a TILE image: every run leaves as PIECES -- <= 16 result bytes of one source, their offset inside the tile's result and at
             // most one substituted residue (dense_pieces.h) -- into the tile's slots; the tile is the executor's work item as it stands
