@@ -208,15 +208,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
     // Everything a tile reads before its first window is requested at once -- the transcripts' tables, the first window's tasks
     // (as if every transcript had tasks: item = task; a tile with an empty transcript reloads), the tile's alt bytes: what bounds
     // this kernel on shallow Task vectors is the chain of dependent loads per tile, not its instructions
-    const uint8_t* const g_code = a.code + task_lo;
-    const uint32_t* const g_sp = a.start_pos + task_lo;
-    const uint32_t* const g_ln = a.length + task_lo;
-    const uint32_t* const g_sr = a.start_pos_res + task_lo;
     const uint32_t n_tile_tasks = uint32_t(task_end - task_lo);
+    // (a tile without a single task -- transcripts that are all '.' -- points its task arrays at memory that is there whatever the stream
+    // holds: the loop's request for the next window has no condition around it, see prefetch_clamped)
+    const bool any_tasks = n_tile_tasks != 0u;
+    const uint8_t* const g_code = any_tasks ? a.code + task_lo : reinterpret_cast<const uint8_t*>(a.tx_task_begin);
+    const uint32_t* const g_sp = any_tasks ? a.start_pos + task_lo : reinterpret_cast<const uint32_t*>(a.tx_task_begin);
+    const uint32_t* const g_ln = any_tasks ? a.length + task_lo : reinterpret_cast<const uint32_t*>(a.tx_task_begin);
+    const uint32_t* const g_sr = any_tasks ? a.start_pos_res + task_lo : reinterpret_cast<const uint32_t*>(a.tx_task_begin);
+    const uint32_t last_task = any_tasks ? n_tile_tasks - 1u : 0u;
     uint32_t pf_code = 0, pf_sp = 0, pf_ln = 0, pf_sr = 0;            // the tasks of the window about to be worked on (item = task)
     // (32-bit byte offsets on the wave-uniform bases: one shift per lane instead of three 64-bit address computations)
     auto at32 = [](const uint32_t* base, uint32_t i) -> uint32_t { return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + (i << 2)); };
     auto prefetch = [&](uint32_t i) { pf_code = 0; pf_sp = 0; pf_ln = 0; pf_sr = 0; if (i < n_tile_tasks) { pf_code = g_code[i]; pf_sp = at32(g_sp, i); pf_ln = at32(g_ln, i); pf_sr = at32(g_sr, i); } };
+    // (inside the loop: EVERY window requests the next one's tasks, the index clamped to the tile's last task instead of lanes masked off --
+    // no zeroing, no exec-mask region, and no `if (!last)` around it, whose phi cost a second register set and eight moves per window; the
+    // last window's request is never waited for, lanes beyond the tile's tasks hold some task's values and are masked as inactive lanes are)
+    auto prefetch_clamped = [&](uint32_t i) {
+        const uint32_t j = i < last_task ? i : last_task;
+        pf_code = g_code[j]; pf_sp = at32(g_sp, j); pf_ln = at32(g_ln, j); pf_sr = at32(g_sr, j);
+    };
     prefetch(lane);
     const bool alt_in_lds = alt_n <= ROWS_ALT_LDS;
     {
@@ -272,9 +283,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
     uint32_t carry_e = 0;
     bool first = true;
     for (uint32_t R0 = 0; ; R0 += ADV) {
-        const uint32_t nvalid = n_items - R0 < 64u ? n_items - R0 : 64u;
         const bool last = R0 + 64u >= n_items;
-        const uint32_t e_lo = first ? 0u : CTX, e_hi = last ? nvalid : 62u;
         // ---- which items open a transcript, and every item's transcript ----
         if (lane < 16u) L.flag[lane] = 0u;
         asm volatile("" ::: "memory");
@@ -284,20 +293,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
         // instructions; a lane reads its bit with lane_bit() where a select or a branch needs it.  Written as per-lane bools combined
         // with && / || the compiler re-ballots every combination -- v_cndmask + v_cmp, thirteen times per window: a seventh of the
         // kernel's vector instructions, and the vector unit is what bounds it.)
-        const uint64_t m_active = nvalid >= 64u ? ~0ull : (1ull << nvalid) - 1ull;
+        const int inactive = 64 - int(n_items - R0);                                      // (n_items - R0 >= 1: a tile has at least one item)
+        const uint64_t m_active = ~0ull >> uint32_t(inactive < 0 ? 0 : inactive);
         const bool active = lane_bit(m_active);
-        const uint64_t firstmask = __ballot(reinterpret_cast<const uint8_t*>(L.flag)[lane] != 0u);     // (lanes >= nvalid: no transcript of this tile starts there)
+        const uint64_t firstmask = __ballot(reinterpret_cast<const uint8_t*>(L.flag)[lane] != 0u);     // (inactive lanes: no transcript of this tile starts there)
         const bool isFirst = lane_bit(firstmask);
         const uint32_t heads_before = uint32_t(__popcll(__ballot(hp < R0)));
         const uint32_t slot = heads_before + mbcnt(firstmask) + (isFirst ? 1u : 0u) - 1u;   // the item's transcript (item 0 opens one: never negative for an active lane)
         // the transcript's last item: the next one opens another, or the tile ends
-        const uint64_t lastmask = (firstmask >> 1) | (last && nvalid ? 1ull << (nvalid - 1u) : 0ull);
+        const uint64_t lastmask = (firstmask >> 1) | (last ? m_active ^ (m_active >> 1) : 0ull);
         const bool isLast = lane_bit(lastmask);
         uint32_t ti = R0 + lane;                                                         // task, relative to the tile's first
         uint64_t m_empty = 0ull;
         // this window's tasks were requested a window ago; the next window's are requested now
         uint32_t code = pf_code, sp = pf_sp, ln = pf_ln, sr = pf_sr;
-        if (!last) prefetch(R0 + ADV + lane);
+        prefetch_clamped(R0 + ADV + lane);
         if (ne) {                                                                        // (uniform, rare: transcripts without tasks in this tile)
             const uint64_t below = ne & ((1ull << (slot & 63u)) - 1ull);
             ti -= uint32_t(__popcll(below));
@@ -309,16 +319,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
         const uint64_t m_task = m_active & ~m_empty;
         const uint32_t res_len = L.res_len[slot & 63u], pos0 = L.pos[slot & 63u];
         // ---- update_task / Task::execute checks; result positions ----
-        const uint64_t m_res_oob = (__ballot(ln > res_len) | __ballot(sr > res_len - ln)) & m_task;
+        // (the comparison on a laundered copy: seeing `ln > res_len` next to `res_len - ln` the compiler folds them into one subtract-with-borrow
+        // and then needs a select and a second compare to turn the borrow back into a lane mask)
+        uint32_t ln_o = ln;
+        asm("" : "+v"(ln_o));
+        const uint64_t m_res_oob = (__ballot(ln_o > res_len) | __ballot(sr > res_len - ln)) & m_task;
         const uint32_t e = lane_bit(m_task & ~m_res_oob) ? sr + ln : 0u;                  // end of the task inside its transcript's result
         const uint32_t pe_raw = up1(e, carry_e);                                          // ... of the item before
         const uint32_t pe = isFirst ? 0u : pe_raw;
         const uint64_t m_code1 = __ballot(code == 1u);
         const uint32_t csel = lane_bit(m_code1) ? 1u : 0u;
         const uint32_t bound = L.bound[csel][slot & 63u];
-        const uint64_t m_src_oob = __ballot(ln > bound) | __ballot(sp > bound - ln);
+        const uint64_t m_src_oob = __ballot(ln_o > bound) | __ballot(sp > bound - ln);
         const uint64_t m_bad = m_task & (__ballot(code > 1u) | m_res_oob | m_src_oob | __ballot(sr < pe));
-        const uint64_t m_in_emit = (e_hi >= 64u ? ~0ull : (1ull << e_hi) - 1ull) & ~((1ull << e_lo) - 1ull);
+        const uint64_t m_in_emit = (last ? m_active : (1ull << 62) - 1ull) & (first ? ~0ull : ~((1ull << CTX) - 1ull));      // lanes [e_lo, e_hi)
         const bool in_emit = lane_bit(m_in_emit);
         if (PHASE != PH_DIRECT && (m_bad & m_in_emit)) {                                  // (rare: which rule, in update_task's order)
             const bool res_oob = lane_bit(m_res_oob), src_oob = lane_bit(m_src_oob);
