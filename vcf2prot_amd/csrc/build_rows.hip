@@ -30,7 +30,9 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t m) { return __builtin_amdgcn_
 __device__ __forceinline__ bool lane_bit(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 // lane i receives lane i - 1's value, lane 0 `first` (DPP wave_shr:1)
 __device__ __forceinline__ uint32_t up1(uint32_t x, uint32_t first) { return uint32_t(__builtin_amdgcn_update_dpp(int(first), int(x), 0x138, 0xf, 0xf, false)); }
-__device__ __forceinline__ uint32_t up2(uint32_t x) { return up1(up1(x, 0u), 0u); }
+// ... lane 0 receives 0: bound_ctrl writes the zero itself, no register to initialise in front of every shift
+__device__ __forceinline__ uint32_t up1z(uint32_t x) { return uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x138, 0xf, 0xf, true)); }
+__device__ __forceinline__ uint32_t up2(uint32_t x) { return up1z(up1z(x)); }
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v)
 {
 #pragma unroll
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
         const RowsParse p = rows_parse(m_cA, m_cB, m_ps, m_c0, m_c1, mRst, !first, carry_h);
         // a closing lane's fused substitution: run, len1, byte, len2
         const uint32_t f_len1 = lane_bit(p.F & p.real) ? ln2 : 0u;
-        const uint32_t f_byte = up1(uint32_t(lit), 0u) & 0xFFu;
+        const uint32_t f_byte = up1z(uint32_t(lit)) & 0xFFu;
         const uint32_t f_run = f_len1 == 0u ? src32 - 1u : src2;
         uint64_t second = 0;
         uint32_t p_len1 = 0, p_len2 = 0, p_run = 0, p_byte = 0;
