@@ -162,10 +162,12 @@ enum : int { PH_PAD = 0, PH_COUNT = 1, PH_DIRECT = 2 };
 
 constexpr uint32_t ROWS_ALT_LDS = 512;         // alt bytes of a tile kept in LDS (64 lanes x 8)
 struct __attribute__((aligned(16))) WaveLds {
-    uint64_t base[2][64];                      // [0]: proteome offset of the tile's j-th transcript, [1]: its alt tape's offset
-    uint32_t bound[2][64];                     // [0]: its reference length, [1]: its alt tape's length
-    uint32_t res_len[64];
-    uint32_t pos[64];                          // arena offset of its first result byte (behind its FASTA header) minus the tile's first byte
+    // One 32-byte record per transcript of the tile -- { res_len, pos, bound[0], bound[1] } { base[0], base[1] } -- read by a lane as two
+    // 16-byte loads the moment it knows its transcript: which of the two bounds / bases applies (the task's code) is a select on values that
+    // have arrived, not an address two more LDS round trips wait for.  pos: arena offset of the transcript's first result byte (behind its
+    // FASTA header) minus the tile's first byte; bound[0]: its reference length, [1]: its alt tape's length; base[0]: its proteome offset,
+    // [1]: its alt tape's offset (64 bits each).
+    uint32_t tx[64][8];
     uint32_t hl[64];                           // FASTA: length of its record header (0: none)
     uint64_t hsrc[64];                         // ... and where the header sits in the resident reference
     uint32_t flag[16];                         // one byte per lane: the item is its transcript's first
@@ -207,6 +209,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
     if (TILES && tile_end - tile_base > a.tile_span_max) { if (lane == 0) { rreport(a.status, tile, STATUS_ROWS_STAGE); a.tile_count[tile] = 0u; } return; }
     const uint32_t eoff = uint32_t(tile_base) & (ROW_BYTES - 1u);    // the tile's first byte inside its row
     const uint64_t erow = tile_base / ROW_BYTES;
+    // (the row map through the tile's own base and a 32-bit row number: rows [row_lo, row_lo + row_span) of the tile are rows 1 .. n_rows - 1
+    // of the arena -- one 32-bit compare and an SGPR-based store per entry instead of 64-bit adds and two 64-bit compares)
+    uint64_t* const cover_tile = a.cover + erow;
+    const uint32_t row_lo = erow == 0ull ? 1u : 0u;
+    const uint32_t row_span = a.n_rows > erow + row_lo ? uint32_t(a.n_rows - erow - row_lo < 0xFFFFFFFFull ? a.n_rows - erow - row_lo : 0xFFFFFFFFull) : 0u;
     // Everything a tile reads before its first window is requested at once -- the transcripts' tables, the first window's tasks
     // (as if every transcript had tasks: item = task; a tile with an empty transcript reloads), the tile's alt bytes: what bounds
     // this kernel on shallow Task vectors is the chain of dependent loads per tile, not its instructions
@@ -259,8 +266,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
         if (valid) hp = uint32_t(tb0 - task_lo) + mbcnt(ne);
         const uint32_t rb = wave_incl_scan(alen) - alen;            // the transcript's first arena byte, from the tile's
         if (valid) {
-            L.base[0][lane] = poff; L.base[1][lane] = alt0; L.bound[0][lane] = ref_len; L.bound[1][lane] = n_alt;
-            L.res_len[lane] = res_len; L.pos[lane] = rb + hl;
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<u32x4*>(&L.tx[lane][0]) = u32x4{res_len, rb + hl, ref_len, n_alt};
+            *reinterpret_cast<u32x4*>(&L.tx[lane][4]) = u32x4{uint32_t(poff), uint32_t(poff >> 32), uint32_t(alt0), uint32_t(alt0 >> 32)};
             if (FASTA) { L.hl[lane] = hl; L.hsrc[lane] = hsrc; }
         }
     }
@@ -319,7 +327,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
             if (active && !isEmpty0) { code = g_code[ti]; sp = g_sp[ti]; ln = g_ln[ti]; sr = g_sr[ti]; }
         }
         const uint64_t m_task = m_active & ~m_empty;
-        const uint32_t res_len = L.res_len[slot & 63u], pos0 = L.pos[slot & 63u];
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 txa = *reinterpret_cast<const u32x4*>(&L.tx[slot & 63u][0]), txb = *reinterpret_cast<const u32x4*>(&L.tx[slot & 63u][4]);
+        const uint32_t res_len = txa[0], pos0 = txa[1];
         // ---- update_task / Task::execute checks; result positions ----
         // (the comparison on a laundered copy: seeing `ln > res_len` next to `res_len - ln` the compiler folds them into one subtract-with-borrow
         // and then needs a select and a second compare to turn the borrow back into a lane mask)
@@ -330,8 +340,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
         const uint32_t pe_raw = up1(e, carry_e);                                          // ... of the item before
         const uint32_t pe = isFirst ? 0u : pe_raw;
         const uint64_t m_code1 = __ballot(code == 1u);
-        const uint32_t csel = lane_bit(m_code1) ? 1u : 0u;
-        const uint32_t bound = L.bound[csel][slot & 63u];
+        const bool code1 = lane_bit(m_code1);
+        const uint32_t bound = code1 ? txa[3] : txa[2];
         const uint64_t m_src_oob = __ballot(ln_o > bound) | __ballot(sp > bound - ln);
         const uint64_t m_bad = m_task & (__ballot(code > 1u) | m_res_oob | m_src_oob | __ballot(sr < pe));
         const uint64_t m_in_emit = (last ? m_active : (1ull << 62) - 1ull) & (first ? ~0ull : ~((1ull << CTX) - 1ull));      // lanes [e_lo, e_hi)
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
         const uint64_t m_isRef = m_good & __ballot(code == 0u);
         const uint64_t m_imm = m_good & m_code1 & __ballot(ln - 1u < IMM_MAX_BYTES);
         const bool isRef = lane_bit(m_isRef), imm = lane_bit(m_imm);
-        const src_t src = (SRC32 ? src_t(reinterpret_cast<const uint32_t*>(&L.base[0][0])[2u * (csel * 64u + (slot & 63u))]) : src_t(L.base[csel][slot & 63u])) + sp;
+        const src_t src = (SRC32 ? src_t(code1 ? txb[2] : txb[0]) : src_t(code1 ? (uint64_t(txb[3]) << 32) | txb[2] : (uint64_t(txb[1]) << 32) | txb[0])) + sp;
         uint64_t lit = 0;
         if (alt_in_lds) {                                                                 // short alt payloads travel inside their descriptor
             const uint32_t rel = imm ? uint32_t(src - src_t(alt_lo)) : 0u;                // (< ROWS_ALT_LDS: inside the transcript's alt tape, checked above)
@@ -505,12 +515,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
             if (PHASE != PH_COUNT && round_total != 0u) {
                 const uint32_t k = tile_cnt + mbcnt(hm);
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                if (has && k < out_cap) *reinterpret_cast<u32x2*>(out + k) = u32x2{wl[RS], fusedw ? wh[RS] : (wh[RS] | (rl[RS] << 8))};
+                if (has && k < out_cap) *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(out) + (k << 3)) = u32x2{wl[RS], fusedw ? wh[RS] : (wh[RS] | (rl[RS] << 8))};
                 const uint32_t s0 = eoff + q0, rb = ((s0 + ROW_BYTES - 1u) >> 10) << 10;
-                if (has && rb < s0 + rl[RS]) {
-                    const uint64_t row = erow + (rb >> 10);
-                    if (row >= 1u && row < a.n_rows) a.cover[row] = cover_word(k, rb - s0, s0 + rl[RS] - rb);
-                }
+                if (has && rb < s0 + rl[RS] && (rb >> 10) - row_lo < row_span)
+                    *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(cover_tile) + (rb >> 7)) = cover_word(k, rb - s0, s0 + rl[RS] - rb);       // (rb >> 10 rows of 8 bytes)
             }
             tile_cnt += round_total;
         } else if (!slow) {
@@ -543,8 +551,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
                         uint32_t dk = k, st = s0, en = end[0];
 #pragma unroll
                         for (int i = 0; i + 1 < NR; ++i) if (rb >= end[i]) { dk += cn[i]; st = end[i]; en = end[i + 1]; }
-                        const uint64_t row = erow + r;
-                        if (row >= 1u && row < a.n_rows) a.cover[row] = cover_word(dk, rb - st, en - rb);
+                        if (r - row_lo < row_span) *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(cover_tile) + (r << 3)) = cover_word(dk, rb - st, en - rb);
                     }
                 }
             }
