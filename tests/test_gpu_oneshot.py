@@ -447,3 +447,31 @@ def test_large_uploads_and_whole_arena_downloads(built, gpu_ctx, coracle):
         assert np.array_equal(part, whole[begin:begin + length]), (begin, length)
     print(f"download of {total / 1e6:.0f} MB: {total / dt / 1e9:.1f} GB/s")
     b.close(); rs.close()
+
+
+@pytest.mark.parametrize("n_haps", [0, 1, 5])
+def test_a_stream_without_a_single_transcript(built, gpu_ctx, n_haps):
+    """Haplotypes that carry no transcript at all (an empty slice of a cohort: tools/fuzz_pipeline.py cuts them) -- one tile of no items:
+    every builder takes it, the arena is empty, every haplotype's range is [0, 0)."""
+    from vcf2prot_amd._native import V2PError
+    from stream_util import Stream
+    z64, z32, z8 = np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint8)
+    gpu_ctx.upload_proteome(np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY" * 10, dtype=np.uint8))
+    st = Stream(np.zeros(n_haps + 1, dtype=np.uint64), z64, z32, z32, np.zeros(1, dtype=np.uint64), np.zeros(1, dtype=np.uint64), z8, z32, z32, z32, z8)
+    rs = gpu_ctx.upload_stream(st)
+    for kernel in (0, 6, 7, 9):
+        b = gpu_ctx.batch()
+        try:
+            b.build_and_execute(rs, kernel, 0)
+        except V2PError as e:
+            assert kernel == 9 and e.code == -9, (kernel, e)               # (no transcripts: no tile image by number)
+            b.close()
+            continue
+        b.sync()
+        cn = b.counts()
+        assert cn["n_haps"] == n_haps and cn["out_bytes"] == 0, cn
+        for h in range(n_haps):
+            assert b.hap_range(h) == (0, 0)
+        b.execute(); b.sync()
+        b.close()
+    rs.close()

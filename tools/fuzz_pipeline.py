@@ -77,6 +77,8 @@ with Context(0) as ctx:
             for a, b in zip(cuts[:-1], cuts[1:]):
                 kernel = int(rng.choice([0, 0, 7, 9]))
                 dig = bool(rng.integers(0, 2))
+                if os.environ.get("FUZZ_TRACE"):
+                    print("cfg", seed, shape, fasta, n_haps, "slice", a, b, "kernel", kernel, "slots", slots, file=sys.stderr, flush=True)
                 if len(inflight) == slots:
                     finish(inflight.pop(0))
                 t = pipe.submit_stream(cut(stream, a, b, fasta), kernel, dig)

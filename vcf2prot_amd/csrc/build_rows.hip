@@ -273,7 +273,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
         }
     }
     asm volatile("" ::: "memory");
-    const uint32_t n_items = n_tile_tasks + uint32_t(__popcll(ne));                      // >= nh >= 1
+    const uint32_t n_items = n_tile_tasks + uint32_t(__popcll(ne));                      // >= nh
+    // (a stream without a single transcript -- an empty slice of haplotypes -- is one tile of none: nothing to emit; every window below has
+    // at least one item, which its lane masks rely on)
+    if (n_items == 0u) { if (PHASE != PH_DIRECT && lane == 0) a.tile_count[tile] = 0u; return; }
     const uint32_t pad_slots = TILES ? a.tile_slots : ROWS_PAD;
     uint64_t* const out = PHASE == PH_PAD ? a.desc_pad + uint64_t(rel) * pad_slots : (PHASE == PH_DIRECT ? a.desc + a.tile_desc_base[tile] : nullptr);
     (void)out;
@@ -303,8 +306,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void rows_
         // instructions; a lane reads its bit with lane_bit() where a select or a branch needs it.  Written as per-lane bools combined
         // with && / || the compiler re-ballots every combination -- v_cndmask + v_cmp, thirteen times per window: a seventh of the
         // kernel's vector instructions, and the vector unit is what bounds it.)
-        const int inactive = 64 - int(n_items - R0);                                      // (n_items - R0 >= 1: a tile has at least one item)
-        const uint64_t m_active = ~0ull >> uint32_t(inactive < 0 ? 0 : inactive);
+        const uint32_t rem = n_items - R0;                                               // (>= 1: a tile has at least one item)
+        const uint64_t m_active = ~0ull >> (rem >= 64u ? 0u : 64u - rem);
         const bool active = lane_bit(m_active);
         const uint64_t firstmask = __ballot(reinterpret_cast<const uint8_t*>(L.flag)[lane] != 0u);     // (inactive lanes: no transcript of this tile starts there)
         const bool isFirst = lane_bit(firstmask);
