@@ -150,12 +150,15 @@ __device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t G)
 
 // ---- the parse ------------------------------------------------------------------------------------------------------------------
 // What bounds it (measured, profiles/r04_build_*, r04_sq_counters_parse_kernel_C3.txt): instruction issue, ~200 vector and ~190
-// scalar instructions per window of 64 items, once a tile's dependent loads are requested together (below).  A burst of the tile's
+// scalar instructions per window of 64 items in round 4 -- 142 and 158 at the end of round 6 (profiles/r06_parse_variants.txt,
+// r06_sq_counters_parse_*_end.txt), where a fifth fewer instructions bought 4-9 % of time: what is left is as much the latency of a
+// window's own chain (flags -> transcript -> records -> literal -> mask solver -> emit) as the issue of it -- once a tile's dependent
+// loads are requested together (below).  A burst of the tile's
 // Task arrays into LDS with global_load_lds changed nothing; a decoupled look-back for the descriptors' final place cost a third
 // of the kernel (a tile waits for every tile before it).  So: one tile per 64-lane workgroup, plain grid; descriptors go
 // to a PADDED array -- ROWS_PAD slots per tile -- and a copy kernel compacts them once a scan of the tiles' counts has told every
 // tile where it starts; positions are 32-bit offsets from the tile's first emitted byte; per-transcript values sit in LDS as
-// arrays of words; everything rare (runs of more than 1 KiB, which may cross two rows, or of more than a descriptor's length
+// one 32-byte record each; everything rare (runs of more than 1 KiB, which may cross two rows, or of more than a descriptor's length
 // field) is behind one wave-uniform branch.
 constexpr uint32_t ROWS_PAD = ROWS_TILE_SLOTS;             // descriptor slots per tile in the padded array (a tile with more: the two-pass form)
 enum : int { PH_PAD = 0, PH_COUNT = 1, PH_DIRECT = 2 };
