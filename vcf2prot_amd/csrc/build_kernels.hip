@@ -707,19 +707,14 @@ __global__ __launch_bounds__(512) void xcd_scan_seg_kernel(uint32_t* __restrict_
 {
     const uint32_t y = blockIdx.x, x = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t* h = hist + uint64_t(y) * tbmax * 8u;
-    // (four thread blocks per lane and round: one order for the whole table -- thin images -- is ONE workgroup walking 8 000 counts per
-    // slice, and a round is a load, a wave scan and a store that wait for one another: 57 -> 17 us on C2 whole)
     uint32_t run = 0;
-    for (uint32_t b0 = 0; b0 < tbmax; b0 += 256u) {
-        uint32_t c[4], sum = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) { const uint32_t b = b0 + lane * 4u + j; c[j] = b < tbmax ? h[b * 8u + x] : 0u; sum += c[j]; }
-        uint32_t incl = sum;
+    for (uint32_t b0 = 0; b0 < tbmax; b0 += 64u) {
+        const uint32_t b = b0 + lane;
+        const uint32_t c = b < tbmax ? h[b * 8u + x] : 0u;
+        uint32_t incl = c;
 #pragma unroll
         for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
-        uint32_t at = run + incl - sum;
-#pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) { const uint32_t b = b0 + lane * 4u + j; if (b < tbmax) h[b * 8u + x] = at; at += c[j]; }
+        if (b < tbmax) h[b * 8u + x] = run + incl - c;
         run += __shfl(incl, 63, 64);
     }
     if (lane == 0) tot[y * 8u + x] = run;
