@@ -815,6 +815,17 @@ def main():
         if args.dry_run:
             line["data"] = "synthetic (dry run: no kernel was launched, value is meaningless)"
         if world == 1 and not args.dry_run:
+            if not args.no_pcie:
+                # (right behind the headline leg, before the other cohorts come and go: 0.71 s here, 0.74-0.78 behind them)
+                ref_dig = leg.get("_oracle_checked_digests")
+                if ref_dig is not None and whole:
+                    try:                                       # Task vectors in, host bytes out: the whole cohort of the headline through the stream-fed pipeline
+                        torch.cuda.empty_cache()
+                        sp = stream_pipeline_leg(args.workload, cohort_samples, n_threads, ref_dig)
+                        line["incl_transfers_aa_per_s"] = sp.pop("aa_per_s")
+                        line["incl_transfers"] = sp
+                    except Exception as e:
+                        line["incl_transfers"] = {"error": repr(e)}
             if not args.no_c2 and args.workload == "C3" and not args.samples:
                 # BASELINE.json's other single-GPU configurations, whole, the same way (one call on the resident stream, EVERY haplotype's digest
                 # against the oracle, then steady-state executes): configs[1] C2 -- the SNV-only cohort of 1 000 samples --, configs[3] C4 -- 2 504
@@ -834,15 +845,6 @@ def main():
                     except Exception as e:                     # never lose the bench line to a secondary leg
                         line[key] = {"error": repr(e)}
             if not args.no_pcie:
-                ref_dig = leg.get("_oracle_checked_digests")
-                if ref_dig is not None and whole:
-                    try:                                       # Task vectors in, host bytes out: the whole cohort of the headline through the stream-fed pipeline
-                        torch.cuda.empty_cache()
-                        sp = stream_pipeline_leg(args.workload, cohort_samples, n_threads, ref_dig)
-                        line["incl_transfers_aa_per_s"] = sp.pop("aa_per_s")
-                        line["incl_transfers"] = sp
-                    except Exception as e:
-                        line["incl_transfers"] = {"error": repr(e)}
                 try:
                     c2c = Cohort.preset("C2", n_samples=1000)
                     pc = pcie_inclusive(c2c, 0, c2c.n_haplotypes, n_threads)
