@@ -3,7 +3,7 @@
 (v2p_pipeline_submit_stream) with a random number of slots, kernel choices 0 / 7 / 9 (an image kind asked for by number may refuse a
 slice: V2P_ERR_UNSUPPORTED from wait, the slice then goes again under the rule), with and without FASTA emit and digests; every
 haplotype's HOST bytes against the numpy expectation, every digest against the oracle's function over those bytes.
-    python tools/fuzz_pipeline.py [first_seed] [n_seeds]"""
+    python tools/fuzz_pipeline.py [first_seed] [n_seeds]        (FUZZ_TRACE=1: every slice on stderr before it is submitted)"""
 import json
 import os
 import sys
