@@ -475,3 +475,31 @@ def test_a_stream_without_a_single_transcript(built, gpu_ctx, n_haps):
         b.execute(); b.sync()
         b.close()
     rs.close()
+
+
+def test_a_tile_of_more_than_2_gib_is_refused(built, gpu_ctx):
+    """Positions inside a tile of transcripts are 32-bit offsets from its first byte: 64 consecutive transcripts with more than 2 GiB of result
+    between them (here: 64 x 40 MB of '.', no Task at all) are V2P_ERR_UNSUPPORTED from every builder -- reported, never wrapped -- and the
+    batch takes an ordinary stream afterwards."""
+    from vcf2prot_amd._native import V2PError
+    from stream_util import Stream, regular_stream
+    n_tx = 64
+    z32, z8 = np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint8)
+    gpu_ctx.upload_proteome(np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY" * 10, dtype=np.uint8))
+    st = Stream(np.array([0, n_tx], dtype=np.uint64), np.zeros(n_tx, dtype=np.uint64), np.full(n_tx, 10, dtype=np.uint32), np.full(n_tx, 40_000_000, dtype=np.uint32),
+                np.zeros(n_tx + 1, dtype=np.uint64), np.zeros(n_tx + 1, dtype=np.uint64), z8, z32, z32, z32, z8)
+    rs = gpu_ctx.upload_stream(st)
+    b = gpu_ctx.batch()
+    for kernel in (0, 6, 7, 9):
+        with pytest.raises(V2PError) as e:
+            b.build_and_execute(rs, kernel, 0)
+        assert e.value.code == -9, (kernel, e.value)
+        b.reset()
+    rs.close()
+    proteome, stream, want = regular_stream(n_haps=4, tx_per_hap=6, seed=3)
+    gpu_ctx.upload_proteome(proteome)
+    rs = gpu_ctx.upload_stream(stream)
+    b.build_and_execute(rs, 0, 0); b.sync()
+    for h in range(4):
+        assert np.array_equal(b.download_hap(h), want(h))
+    b.close(); rs.close()
