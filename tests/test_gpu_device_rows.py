@@ -257,3 +257,50 @@ def test_a_haplotype_whose_arena_range_crosses_4_gib(built, gpu_ctx, coracle):
         assert np.array_equal(b.download_hap(h), w), h
         assert int(dig[h]) == coracle.digest_u8(w)
     b.close()
+
+
+@pytest.mark.parametrize("kernel", [0, 6, 7])
+def test_a_reference_beyond_4_gib(built, gpu_ctx, kernel):
+    """Source offsets above 2^32: a resident proteome of 4 GiB + 2 MiB, transcripts just below, across and above the 4 GiB line, each with one
+    substituted residue (task.rs:38-50).  The one-pass parse has a 32-bit instance for every cohort whose sources fit (SRC32); this one
+    must take the 64-bit instance -- bases of 64 bits out of the per-transcript LDS record, sources of 40 bits in the descriptors -- and a
+    tile image (31-bit sources) must not be picked by the rule, nor built by number."""
+    from vcf2prot_amd._native import V2PError
+    from stream_util import Stream
+    rng = np.random.default_rng(23)
+    AA = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    G4 = 1 << 32
+    block = AA[rng.integers(0, 20, size=1 << 20)]
+    prot = np.tile(block, (G4 >> 20) + 2)                                      # 4 GiB + 2 MiB
+    # ... with distinct text where the transcripts sit, so that a wrapped or truncated source offset cannot read the same residues
+    marks = [G4 - 5000, G4 - 300, G4 + 7, G4 + (1 << 20) + 12345]
+    lens = [900, 777, 1200, 64]
+    for m, ln in zip(marks, lens):
+        prot[m:m + ln] = AA[rng.integers(0, 20, size=ln)]
+    gpu_ctx.upload_proteome(prot)
+    n_tx = len(marks)
+    pos = [int(rng.integers(1, ln - 1)) for ln in lens]
+    sub = AA[rng.integers(0, 20, size=n_tx)]
+    code = np.tile(np.array([0, 1, 0], dtype=np.uint8), n_tx)
+    sp = np.array([v for t in range(n_tx) for v in (0, 1, pos[t] + 1)], dtype=np.uint32)
+    ln = np.array([v for t in range(n_tx) for v in (pos[t], 1, lens[t] - pos[t] - 1)], dtype=np.uint32)
+    sr = np.array([v for t in range(n_tx) for v in (0, pos[t], pos[t] + 1)], dtype=np.uint32)
+    alt = np.repeat(sub, 2)
+    s = Stream([0, 2, n_tx], marks, lens, lens, np.arange(0, 3 * n_tx + 1, 3), np.arange(0, 2 * n_tx + 1, 2), code, sp, ln, sr, alt)
+    want = [np.concatenate([np.concatenate([prot[marks[t]:marks[t] + pos[t]], sub[t:t + 1], prot[marks[t] + pos[t] + 1:marks[t] + lens[t]]]) for t in ts]) for ts in ((0, 1), (2, 3))]
+    rs = gpu_ctx.upload_stream(s)
+    b = gpu_ctx.batch()
+    b.build_and_execute(rs, kernel, 0)
+    b.sync()
+    assert not b.image_form()["tiles"]
+    for rep in range(2):
+        for h in range(2):
+            assert np.array_equal(b.download_hap(h), want[h]), (kernel, rep, h)
+        b.scribble(); b.execute(); b.sync()
+    b.reset()
+    with pytest.raises(V2PError) as e:
+        b.build_and_execute(rs, 9, 0)
+    assert e.value.code == -9
+    b.close(); rs.close()
+    del prot
+    gpu_ctx.upload_proteome(block[:1000])
